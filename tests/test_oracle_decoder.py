@@ -1,0 +1,82 @@
+"""Oracle (oracle/decoder_ref.py) vs golden outputs of the real reference
+(tests/golden/decoder_golden.npz, made by tests/golden/make_golden.py)."""
+import numpy as np
+import torch
+
+from oracle import decoder_ref as R
+from zeroshape_amd import synthetic as syn
+
+TOL = 2e-6  # same torch ops on the same CPU: differences are blocking/threading only
+
+
+def test_pos_embed_matches_reference(decoder_golden):
+    pe = R.pos_embed_2d_sincos(256, 14, cls_token=True)
+    assert pe.shape == (197, 256) and pe.dtype == np.float64
+    rows = [0, 1, 2, 14, 15, 100, 195, 196]
+    np.testing.assert_array_equal(pe[rows], decoder_golden["pos_embed_f64_rows"])
+    np.testing.assert_allclose([pe.sum(), np.abs(pe).sum()], decoder_golden["pos_embed_f64_sum"], rtol=1e-12)
+    np.testing.assert_array_equal(pe.astype(np.float32), decoder_golden["pos_embed_f32"])
+    assert np.all(pe[0] == 0)  # cls row is zero (utils/pos_embed.py:35)
+
+
+def test_linspace_and_grid(decoder_golden):
+    for N in (32, 64, 128, 256):
+        g = R.dense_grid(-1.5, 1.5, N)[0]
+        np.testing.assert_array_equal(g[:, 0, 0, 0].numpy(), decoder_golden["linspace_%d" % N])
+        np.testing.assert_array_equal(g[0, :, 0, 1].numpy(), decoder_golden["linspace_%d" % N])
+        np.testing.assert_array_equal(g[0, 0, :, 2].numpy(), decoder_golden["linspace_%d" % N])
+        if N > 64:
+            break
+    g = R.dense_grid(-1.5, 1.5, 32)
+    got = g[0, [0, 0, 5, 32], [0, 7, 6, 32], [0, 3, 9, 32]].numpy()
+    np.testing.assert_array_equal(got, decoder_golden["grid32_corner_pts"])
+
+
+def test_level_grid_vox32(decoder_golden, seeded_sd):
+    latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=2))[:1]
+    grid = R.dense_grid(-1.5, 1.5, 32)
+    occ = R.level_grid(seeded_sd, latent, grid)[0].numpy()
+    assert list(occ.shape) == list(decoder_golden["occ32_shape"])
+    np.testing.assert_allclose(occ[::5, ::5, ::5], decoder_golden["occ32_stride5"], atol=TOL, rtol=0)
+    bits = np.unpackbits(decoder_golden["occ32_bits"])[: occ.size].astype(bool)
+    mism = (occ > 0.5).reshape(-1) != bits
+    # occupancy index set is bit-exact (any mismatch must sit exactly on the 0.5 level)
+    assert mism.sum() == 0 or np.all(np.abs(occ.reshape(-1)[mism] - 0.5) < 1e-6)
+    assert mism.sum() <= 1
+
+
+def test_slice_logits_and_attn(decoder_golden, seeded_sd):
+    latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=2))[:1]
+    for N, keys in ((32, ("logit32_slice%d", 1)), (64, ("logit64_slice%d_s16", 16)),
+                    (128, ("logit128_slice%d_s16", 16))):
+        grid = R.dense_grid(-1.5, 1.5, N).view(1, N + 1, (N + 1) ** 2, 3)
+        fmt, stride = keys
+        for i in (0, N // 2, N):
+            lg, at = R.implicit_forward(seeded_sd, latent, grid[:, i])
+            np.testing.assert_allclose(lg[0, ::stride].numpy(), decoder_golden[fmt % i], atol=TOL, rtol=0)
+            if N == 32 and i == 16:
+                np.testing.assert_allclose(at[0, ::97].numpy(), decoder_golden["attn32_slice16_rows"],
+                                           atol=1e-7, rtol=0)
+
+
+def test_training_shape_call(decoder_golden, seeded_sd):
+    latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=2))
+    rs = np.random.RandomState(123)
+    pts = torch.from_numpy(rs.uniform(-1, 1, size=(2, 4096, 3)).astype(np.float32))
+    lg, at = R.implicit_forward(seeded_sd, latent, pts)
+    np.testing.assert_allclose(lg.numpy(), decoder_golden["pts4096_logit"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(at[:, ::512].numpy(), decoder_golden["pts4096_attn_rows"], atol=1e-7, rtol=0)
+    # attn excludes the self column AFTER softmax over 198 -> rows sum to < 1 (implicit.py:63,79)
+    rs_ = at.sum(-1).numpy()
+    np.testing.assert_allclose(rs_, decoder_golden["pts4096_attn_rowsum"], atol=1e-6, rtol=0)
+    assert np.all(rs_ < 1.0)
+
+
+def test_points_are_independent_units(seeded_sd):
+    """slice-wise == all-at-once (SURVEY.md section 3.4 probe): basis for sharding."""
+    latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=1))
+    pts = torch.from_numpy(syn.seeded_cloud(9, 1, 300, -1.5, 1.5))
+    full, _ = R.implicit_forward(seeded_sd, latent, pts)
+    a, _ = R.implicit_forward(seeded_sd, latent, pts[:, :123])
+    b, _ = R.implicit_forward(seeded_sd, latent, pts[:, 123:])
+    np.testing.assert_allclose(torch.cat([a, b], 1).numpy(), full.numpy(), atol=2e-6, rtol=0)

@@ -1,0 +1,105 @@
+"""Build-owned deterministic synthetic inputs (no checkpoints or datasets ship with
+the reference: weights/.gitignore:1-3).  The same generator is used by the golden
+fixture script (in the build container, beside the real reference), by the tests
+and by bench.py (on the GPU box), so no weight files need to travel.
+
+Shapes/keys follow the reference's ``impl_network`` state_dict
+(model/shape/implicit.py:186-231) for the default
+options/shape.yaml:19-44 configuration.
+"""
+import numpy as np
+
+# options/shape.yaml:19-44
+N_CHANNELS = 256
+LATENT_DIM = 256
+NUM_HEADS = 8
+ATT_BLOCKS = 2
+MLP_RATIO = 4
+MLP_LAYERS = 8
+SKIP_IN = (2, 4, 6)
+NUM_PATCHES = 196  # (224 // 16) ** 2, graph_shape.py:58-64
+
+
+def impl_network_shapes(n_channels=N_CHANNELS, latent_dim=LATENT_DIM, att_blocks=ATT_BLOCKS,
+                        mlp_ratio=MLP_RATIO, mlp_layers=MLP_LAYERS, skip_in=SKIP_IN,
+                        num_patches=NUM_PATCHES):
+    """Ordered {key: shape} of the reference decoder's state_dict."""
+    C = n_channels
+    s = {}
+    s["pos_embed"] = (1, num_patches + 1, C)
+    s["point_proj.proj.weight"] = (C, 3)
+    s["point_proj.proj.bias"] = (C,)
+    s["latent_proj.weight"] = (C, latent_dim)
+    s["latent_proj.bias"] = (C,)
+    for b in range(att_blocks):
+        p = "blocks_attn.%d." % b
+        s[p + "norm1.weight"] = (C,)
+        s[p + "norm1.bias"] = (C,)
+        s[p + "attn.qkv.weight"] = (3 * C, C)
+        s[p + "attn.qkv.bias"] = (3 * C,)
+        s[p + "attn.proj.weight"] = (C, C)
+        s[p + "attn.proj.bias"] = (C,)
+        s[p + "norm2.weight"] = (C,)
+        s[p + "norm2.bias"] = (C,)
+        s[p + "mlp.fc1.weight"] = (int(C * mlp_ratio), C)
+        s[p + "mlp.fc1.bias"] = (int(C * mlp_ratio),)
+        s[p + "mlp.fc2.weight"] = (C, int(C * mlp_ratio))
+        s[p + "mlp.fc2.bias"] = (C,)
+    s["norm.weight"] = (C,)
+    s["norm.bias"] = (C,)
+    dims = [3 + C] + [C] * mlp_layers + [1]
+    for l in range(len(dims) - 1):
+        in_dim = dims[l] + (dims[0] if l in skip_in else 0)
+        s["impl_mlp.layers.%d.weight" % l] = (dims[l + 1], in_dim)
+        s["impl_mlp.layers.%d.bias" % l] = (dims[l + 1],)
+    return s
+
+
+def seeded_state_dict(seed=0, pos_embed=None, **cfg):
+    """Deterministic fp32 numpy state_dict.  Unlike the reference's init
+    (xavier weights, zero biases, unit LayerNorm - implicit.py:238-249) every
+    tensor is non-trivial so that bias / affine / skip paths are exercised:
+      weights  ~ U(-a, a), a = sqrt(6/(fan_in+fan_out))   (xavier-uniform range)
+      biases   ~ 0.1 * N(0,1)
+      LN gamma ~ 1 + 0.1 * N(0,1);  LN beta ~ 0.1 * N(0,1)
+    (logits then straddle 0: about a third of a [-1.5,1.5]^3 grid is 'inside').
+    One RandomState per key (seed, crc of key) -> independent of key order.
+    ``pos_embed`` must be supplied by the caller (fixed sin-cos table)."""
+    import zlib
+    shapes = impl_network_shapes(**cfg)
+    sd = {}
+    for k, shp in shapes.items():
+        rs = np.random.RandomState((seed * 1000003 + zlib.crc32(k.encode())) % (2 ** 31))
+        if k == "pos_embed":
+            if pos_embed is None:
+                raise ValueError("pos_embed table required")
+            sd[k] = np.asarray(pos_embed, np.float32).reshape(shp)
+        elif k.endswith("weight") and len(shp) == 2:
+            a = np.sqrt(6.0 / (shp[0] + shp[1]))
+            w = rs.uniform(-a, a, size=shp)
+            sd[k] = w.astype(np.float32)
+        elif "norm" in k and k.endswith("weight"):
+            sd[k] = (1.0 + 0.1 * rs.randn(*shp)).astype(np.float32)
+        else:
+            sd[k] = (0.1 * rs.randn(*shp)).astype(np.float32)
+    return sd
+
+
+def seeded_latent(seed=0, batch=1, n_tokens=NUM_PATCHES + 1, dim=LATENT_DIM):
+    """latent_depth stand-in: N(0,1) [B, 197, 256]."""
+    rs = np.random.RandomState(seed + 7919)
+    return rs.randn(batch, n_tokens, dim).astype(np.float32)
+
+
+def seeded_cloud(seed, batch, n, lo=-0.5, hi=0.5):
+    """uniform point clouds in [lo,hi]^3 (SURVEY.md section 8-d Chamfer inputs)."""
+    rs = np.random.RandomState(seed + 104729)
+    return rs.uniform(lo, hi, size=(batch, n, 3)).astype(np.float32)
+
+
+def ellipsoid_cloud(seed, n, radii=(0.5, 0.35, 0.25)):
+    """points on an axis-aligned ellipsoid surface (brute-force-search test shape)."""
+    rs = np.random.RandomState(seed + 15485863)
+    v = rs.randn(n, 3)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    return (v * np.asarray(radii)).astype(np.float32)
