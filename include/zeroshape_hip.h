@@ -1,0 +1,114 @@
+/* zeroshape_hip.h - C ABI of libzeroshape_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for ZeroShape's dense SDF-query / Chamfer hot path.  Plain
+ * pointers and sizes only: every pointer is a DEVICE pointer unless marked
+ * [host]; `stream` is a hipStream_t passed as void* (NULL = default stream).
+ * All entry points are asynchronous w.r.t. the host (they enqueue on `stream`
+ * and return) and return 1 on success, 0 on failure - the convention of the
+ * reference's native launchers (external/chamfer3D/chamfer3D.cu:145-151).
+ * After a 0, zs_last_error() gives a thread-local message.  Nothing here
+ * allocates device memory; callers own every buffer.
+ *
+ * Reference interfaces replaced (paths relative to the upstream ZeroShape tree):
+ *   zs_chamfer_forward   <- chamfer_cuda_forward,  external/chamfer3D/chamfer3D.cu:136-154
+ *                           (bound as chamfer_3D.forward, chamfer_cuda.cpp:19-21,31)
+ *   zs_chamfer_backward  <- chamfer_cuda_backward, external/chamfer3D/chamfer3D.cu:176-195
+ *                           (bound as chamfer_3D.backward, chamfer_cuda.cpp:24-28,32)
+ *   zs_sdf_*             <- Implicit.forward, model/shape/implicit.py:251-288, as it is
+ *                           driven by compute_level_grid, utils/eval_3D.py:22-45, and
+ *                           get_dense_3D_grid, utils/eval_3D.py:11-20
+ *   zs_bf_*              <- brute_force_search inner loop, utils/eval_3D.py:150-168
+ *                           (rotate + normalize_pc :93-102 + chamfer + compute_fscore :215-231)
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ */
+#ifndef ZEROSHAPE_HIP_H
+#define ZEROSHAPE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZS_ABI_VERSION 1
+
+/* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
+int zs_abi_version(void);
+
+/* Thread-local description of the last failure ("" if none). [host] */
+const char *zs_last_error(void);
+
+/* ------------------------------------------------------------------------- *
+ * Chamfer-3D nearest neighbour (external/chamfer3D/chamfer3D.cu)
+ * ------------------------------------------------------------------------- */
+
+/* For every point of xyz1[b][n][3] the SQUARED distance to, and index of, its
+ * nearest point in xyz2[b][m][3], and vice versa.  fp32, contiguous.
+ *   dist1[b][n], idx1[b][n]  : nearest in xyz2 for each xyz1 point
+ *   dist2[b][m], idx2[b][m]  : nearest in xyz1 for each xyz2 point
+ * d = fma(dz,dz, fma(dy,dy, dx*dx)) with (dx,dy,dz) = other - self (bit-exact with
+ * the reference kernel under nvcc's default FMA contraction); ties resolve to the
+ * LOWEST index (chamfer3D.cu:36,126).  If the other cloud is empty the outputs of
+ * that direction are left untouched (the reference kernel writes nothing either;
+ * its caller pre-zeroes them, dist_chamfer_3D.py:29-38). */
+int zs_chamfer_forward(const float *xyz1, const float *xyz2, int b, int n, int m,
+                       float *dist1, float *dist2, int *idx1, int *idx2, void *stream);
+
+/* Gradient scatter (chamfer3D.cu:155-195): gradxyz1[b][n][3] / gradxyz2[b][m][3] are
+ * ACCUMULATED into with fp32 atomics (caller zeroes them, dist_chamfer_3D.py:51-55):
+ *   g = 2*graddist1[i][j];  gradxyz1[i][j] += g*(p1 - p2[idx1]);  gradxyz2[i][idx1] -= same
+ * and symmetrically for direction 2. */
+int zs_chamfer_backward(const float *xyz1, const float *xyz2, int b, int n, int m,
+                        float *gradxyz1, float *gradxyz2,
+                        const float *graddist1, const float *graddist2,
+                        const int *idx1, const int *idx2, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Implicit occupancy decoder (model/shape/implicit.py), default architecture of
+ * options/shape.yaml:19-44: C=256, 8 heads x 32, 2 attention blocks (mlp 4x),
+ * 197 latent tokens, 8-layer softplus(beta=100) MLP with skips at 2,4,6.
+ *
+ * Data flow:
+ *   zs_sdf_program_bytes()                  size of one packed "decoder program"
+ *   [host] pack the state_dict             zeroshape_amd/program.py -> float32 words
+ *   zs_sdf_prologue(program, latent, ...)  per image: hoisted latent path
+ *                                          (latent_proj + pos_embed, block-0 latent
+ *                                          self-attention + MLP, K/V of both blocks)
+ *                                          written into the program's K/V records
+ *   zs_sdf_query_points / _grid            per query point: the fused decoder
+ * ------------------------------------------------------------------------- */
+
+/* Bytes of one per-image decoder program (weights in MFMA operand order + K/V). */
+size_t zs_sdf_program_bytes(void);
+/* Bytes of the per-image scratch the prologue needs. */
+size_t zs_sdf_prologue_scratch_bytes(void);
+
+/* Fill the per-image K/V records of `programs[i]` (i < batch; programs are
+ * program_stride_bytes apart, each initialised by copying the packed weights)
+ * from latent_depth[batch][197][256] fp32.  `lat_params` is the packed latent-path
+ * parameter block (zeroshape_amd/program.py: pack_latent_params). */
+int zs_sdf_prologue(void *programs, size_t program_stride_bytes, const float *lat_params,
+                    const float *latent_depth, int batch, void *scratch, void *stream);
+
+/* logits[batch][m] = Implicit(latent, None, points[batch][m][3]) (pre-sigmoid).
+ * attn (optional, may be NULL): [batch][m][197] = mean over heads and blocks of the
+ * point->latent attention probabilities (implicit.py:63,79,277). */
+int zs_sdf_query_points(const void *programs, size_t program_stride_bytes, int batch,
+                        const float *points, int m, float *logits, float *attn, void *stream);
+
+/* Dense-grid query without materialising the points tensor.  Evaluates x-slices
+ * [slice_begin, slice_end) of the G^3 grid (G = vox_res+1 samples per axis; coordinate
+ * i -> axis[i], `axis` being torch.linspace(range_min, range_max, G) supplied by the
+ * caller so values are bit-identical to utils/eval_3D.py:16).  Layout of out:
+ * [batch][slice_end-slice_begin][G][G], x slowest / z fastest, like occ in
+ * utils/eval_3D.py:45-46.  apply_sigmoid!=0 stores sigmoid(logit) (compute_level_grid's
+ * return), else the logit. */
+int zs_sdf_query_grid(const void *programs, size_t program_stride_bytes, int batch,
+                      const float *axis, int G, int slice_begin, int slice_end,
+                      int apply_sigmoid, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZEROSHAPE_HIP_H */

@@ -1,0 +1,56 @@
+"""Host logic: the packed decoder program (zeroshape_amd/program.py), consumed in the
+kernel's schedule by a numpy MFMA emulator (tests/mfma_emulator.py), reproduces the
+oracle.  This pins record order, the accumulator-layout permutation and every params
+offset on the CPU, before any GPU run."""
+import numpy as np
+import torch
+
+from oracle import decoder_ref as R
+from zeroshape_amd import program as P
+from zeroshape_amd import synthetic as syn
+from tests import mfma_emulator as E
+
+
+def test_layout_constants():
+    assert P.G_HEAD % P.RING == 0 and P.G_MLP_TILE % P.RING == 0 and P.G_KV_HEAD % P.RING == 0
+    assert P.G_TOTAL == 9856 and P.G_TOTAL * 4 == 39424
+    assert P.PROGRAM_BYTES == (9856 + 8) * 1024
+    assert P.PARAMS.total * 4 < 64 * 1024          # params are staged in LDS
+    assert sorted(P.ROW_TABLE.reshape(-1).tolist()) == list(range(32))
+
+
+def test_rowparam_roundtrip():
+    v = np.arange(256, dtype=np.float32)
+    rpv = P.rowparam(v).reshape(8, 2, 16)
+    for t in range(8):
+        for hi in range(2):
+            for r in range(16):
+                assert rpv[t, hi, r] == 32 * t + P.row(r, hi)
+
+
+def test_mfma_emulator_is_a_matmul():
+    rs = np.random.RandomState(0)
+    W = rs.randn(32, 32)            # one output tile, one input tile
+    X = rs.randn(32, 32)            # [feature][point]
+    recs = P._interleave(P._records_linear(W.astype(np.float32), 0, 0)).astype(np.float64)
+    xt = np.stack([X[E.ROWS[r], E.COL] for r in range(16)])      # activation tile in registers
+    acc = E.gemm_tile(E.Stream(recs), [xt], np.zeros((16, 64)))
+    Y = W.astype(np.float32).astype(np.float64) @ X              # asymmetric: catches transposes
+    np.testing.assert_allclose(acc, np.stack([Y[E.ROWS[r], E.COL] for r in range(16)]), atol=1e-12)
+
+
+def test_emulated_kernel_matches_oracle(seeded_sd):
+    sd_np = {k: v.numpy() for k, v in seeded_sd.items()}
+    latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=1))
+    lp = R.latent_path(seeded_sd, latent)
+    kv = {}
+    for blk in range(2):
+        for h in range(8):
+            kv[(blk, h)] = (lp["k%d" % blk][0, h].numpy(), lp["v%d" % blk][0, h].numpy())
+    recs = P.pack_records(sd_np, kv)
+    params = P.pack_params(sd_np)
+    assert recs.size == P.PROGRAM_FLOATS and recs.dtype == np.float32
+    pts = syn.seeded_cloud(11, 1, 32, -1.5, 1.5)
+    want, _ = R.implicit_forward(seeded_sd, latent, torch.from_numpy(pts))
+    got = E.decode_wave(recs, params, pts[0])
+    np.testing.assert_allclose(got, want[0].numpy().astype(np.float64), atol=2e-5, rtol=0)

@@ -1,0 +1,84 @@
+"""ctypes binding of libzeroshape_hip.so (C ABI in include/zeroshape_hip.h).
+
+There is NO fallback: if the library is missing or a symbol is absent this module
+raises, and every product entry point that needs the GPU path raises with it.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzeroshape_hip.so")
+
+_c_void_p = ctypes.c_void_p
+_c_int = ctypes.c_int
+_c_size_t = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/zeroshape_hip.h one to one
+SIGNATURES = {
+    "zs_abi_version": (_c_int, []),
+    "zs_last_error": (ctypes.c_char_p, []),
+    "zs_chamfer_forward": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int,
+                                    _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "zs_chamfer_backward": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int,
+                                     _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                                     _c_void_p, _c_void_p, _c_void_p]),
+    "zs_sdf_program_bytes": (_c_size_t, []),
+    "zs_sdf_prologue_scratch_bytes": (_c_size_t, []),
+    "zs_sdf_prologue": (_c_int, [_c_void_p, _c_size_t, _c_void_p, _c_void_p, _c_int,
+                                 _c_void_p, _c_void_p]),
+    "zs_sdf_query_points": (_c_int, [_c_void_p, _c_size_t, _c_int, _c_void_p, _c_int,
+                                     _c_void_p, _c_void_p, _c_void_p]),
+    "zs_sdf_query_grid": (_c_int, [_c_void_p, _c_size_t, _c_int, _c_void_p, _c_int, _c_int,
+                                   _c_int, _c_int, _c_void_p, _c_void_p]),
+}
+
+ABI_VERSION = 1
+_lib = None
+
+
+class ZeroShapeHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and type the library.  Raises ZeroShapeHipError when it is absent:
+    build it with ``python -m zeroshape_amd.build`` (or __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ZeroShapeHipError(
+            "HIP library not built: %s is missing (run `python -m zeroshape_amd.build`). "
+            "zeroshape_amd has no CPU/PyTorch fallback for this path." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 not found
+        raise ZeroShapeHipError("cannot load %s: %s" % (LIB_PATH, e)) from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ZeroShapeHipError("%s does not export %s" % (LIB_PATH, name)) from e
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.zs_abi_version()
+    if v != ABI_VERSION:
+        raise ZeroShapeHipError("ABI mismatch: library %d, binding %d" % (v, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 1:
+        msg = load().zs_last_error()
+        raise ZeroShapeHipError("%s failed: %s" % (what, (msg or b"").decode(errors="replace")))
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor / None."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream_ptr(device=None):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,71 @@
+"""Ahead-of-time build of libzeroshape_hip.so for gfx950 (hipcc cross-compiles
+without a GPU).  The .so is written in-tree (zeroshape_amd/libzeroshape_hip.so):
+git-ignored, but it travels to the GPU box with the gpurun snapshot.
+
+    python -m zeroshape_amd.build [--force] [--verbose]
+"""
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+LIB = os.path.join(HERE, "libzeroshape_hip.so")
+OBJDIR = os.path.join(HERE, "csrc", "_obj")
+
+ARCH = "gfx950"
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall",
+          "-Wno-unused-function", "-I", INCLUDE]
+# per-file extra flags
+EXTRA = {
+    # bit-exact distance arithmetic: only the fmaf calls written in the source may fuse
+    "chamfer.hip": ["-ffp-contract=off"],
+}
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _stamp(src, flags):
+    h = hashlib.sha1()
+    h.update(" ".join(flags).encode())
+    for f in [src] + [os.path.join(CSRC, x) for x in sorted(os.listdir(CSRC)) if x.endswith(".h")] + \
+            [os.path.join(INCLUDE, "zeroshape_hip.h")]:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(OBJDIR, exist_ok=True)
+    objs, rebuilt = [], False
+    for name in sources():
+        src = os.path.join(CSRC, name)
+        obj = os.path.join(OBJDIR, name[:-4] + ".o")
+        flags = COMMON + EXTRA.get(name, [])
+        stamp_file = obj + ".stamp"
+        stamp = _stamp(src, flags)
+        old = open(stamp_file).read() if os.path.exists(stamp_file) else ""
+        if force or not os.path.exists(obj) or old != stamp:
+            cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            with open(stamp_file, "w") as fh:
+                fh.write(stamp)
+            rebuilt = True
+        objs.append(obj)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))

@@ -1,0 +1,339 @@
+"""Host-side packer: reference ``impl_network`` state_dict -> "decoder program".
+
+The fused decoder kernel (csrc/sdf_decoder.hip) keeps every activation of a
+32-point tile in registers in the accumulator layout of
+``v_mfma_f32_32x32x2_f32`` and computes each layer TRANSPOSED,
+
+    Y^T[n, t] = sum_k W[n, k] * X^T[k, t]        (n = feature, t = point)
+
+so that the output registers of one layer are, unchanged, the B operands of the
+next (no LDS round trip, no transposes).  What remains to be fed is the A operand
+(weights): one fp32 per lane per MFMA.  This module lays every weight of the model
+out as the exact sequence of A operands the kernel consumes, so the kernel's
+weight access is ONE linear stream of coalesced 16-byte loads.
+
+Layout facts (cdna_hip_programming.md section 3):
+  lane l of a wave supplies  A[i = l & 31][k = l >> 5]  and  B[k = l >> 5][j = l & 31];
+  accumulator register r of lane l holds  D[row(r, l >> 5)][l & 31],
+  row(r, hi) = (r & 3) + 8 * (r >> 2) + 4 * hi.
+Hence an activation tile (32 features x 32 points) lives in 16 registers; register r
+holds feature row(r, 0) in lanes 0-31 and row(r, 1) = row(r, 0) + 4 in lanes 32-63,
+and using register r as the B operand contracts over exactly those two features.
+The matching A "record" (64 floats) for output tile nt, input tile kt, register r is
+    rec[l] = W[32 * nt + (l & 31)][32 * kt + row(r, l >> 5)].
+Four consecutive records are interleaved per lane into one "group" (1 KiB):
+    group[l][j] = rec_{4g + j}[l]         -> one global_load_dwordx4 per lane per 4 MFMAs.
+
+Two buffers are produced:
+  * ``recs``   - the record stream (per image; the attention K/V records in it are
+                 written per image by the prologue kernel, csrc/sdf_prologue.hip);
+  * ``params`` - small per-feature vectors (biases, LayerNorm affine, the 3-wide
+                 xyz columns) in "row-param" order [tile][hi][r], staged in LDS.
+and, for the prologue, ``lat_params`` (latent-path weights, transposed [K][N]).
+
+Reference semantics: model/shape/implicit.py:251-288 (see oracle/decoder_ref.py).
+"""
+import numpy as np
+
+# architecture constants of options/shape.yaml:19-44 (the kernel is specialised for them)
+C = 256          # channels
+NT = C // 32     # 8 feature tiles
+HEADS = 8
+HD = 32          # head dim == one feature tile
+L = 197          # latent tokens
+LT = 7           # latent tiles of 32 (224 >= 197; rows >= 197 are zero / masked)
+HID = 1024
+HT = HID // 32   # 32 hidden tiles
+BLOCKS = 2
+MLP_LAYERS = 9   # impl_mlp.layers.0..8
+SKIP_IN = (2, 4, 6)
+GROUP_FLOATS = 256          # 4 records x 64 lanes
+RING = 8                    # groups the kernel prefetches ahead (tail padding)
+
+LANE = np.arange(64)
+LANE_I = LANE & 31
+LANE_HI = LANE >> 5
+
+
+def row(r, hi):
+    return (r & 3) + 8 * (r >> 2) + 4 * hi
+
+
+# feature index held by (tile-local) register r in lane-half hi, for r = 0..15
+ROW_TABLE = np.array([[row(r, hi) for r in range(16)] for hi in range(2)])  # [hi][r]
+
+
+# ----------------------------------------------------------------------------- #
+# record stream
+# ----------------------------------------------------------------------------- #
+def _records_linear(W, nt, kt):
+    """16 records [16, 64] of W (out x in) for output tile nt / input tile kt."""
+    rows = 32 * nt + LANE_I                                   # [64]
+    cols = 32 * kt + ROW_TABLE[LANE_HI][:, :].T               # [16, 64]: row(r, hi(l))
+    return W[rows[None, :], cols]
+
+
+def _interleave(recs):
+    """[n_rec, 64] -> groups [n_rec / 4, 64, 4] flattened."""
+    n = recs.shape[0]
+    assert n % 4 == 0
+    return recs.reshape(n // 4, 4, 64).transpose(0, 2, 1).reshape(-1)
+
+
+def records_for_linear(W, n_out_tiles=None, k_tiles=None):
+    """Records of a whole linear layer in consumption order: for nt: for kt: for r."""
+    W = np.asarray(W, np.float32)
+    n_out_tiles = W.shape[0] // 32 if n_out_tiles is None else n_out_tiles
+    k_tiles = W.shape[1] // 32 if k_tiles is None else k_tiles
+    out = [_records_linear(W, nt, kt) for nt in range(n_out_tiles) for kt in range(k_tiles)]
+    return np.concatenate(out, axis=0)
+
+
+def kv_records(K_h, V_h):
+    """Attention records of ONE head: for lt: [16 K records][16 V records].
+    K_h, V_h: [197, 32] fp32.
+      K record (lt, r): A[i = latent row][k = head dim]  = K[32lt + (l&31)][row(r, l>>5)]
+      V record (lt, r): A[i = head dim][k = latent row]  = V[32lt + row(r, l>>5)][l&31]
+    rows >= 197 are zero (their logits are masked to -inf in the kernel)."""
+    Kp = np.zeros((LT * 32, HD), np.float32)
+    Vp = np.zeros((LT * 32, HD), np.float32)
+    Kp[:L], Vp[:L] = K_h, V_h
+    out = []
+    for lt in range(LT):
+        krec = Kp[(32 * lt + LANE_I)[None, :], ROW_TABLE[LANE_HI].T]            # [16, 64]
+        vrec = Vp[32 * lt + ROW_TABLE[LANE_HI].T, LANE_I[None, :]]              # [16, 64]
+        out += [krec, vrec]
+    return np.concatenate(out, axis=0)                                           # [224, 64]
+
+
+# groups per section (1 group = 4 records = 4 MFMAs per wave)
+G_QKV_HEAD = 3 * NT * 4          # 96: q, k, v tiles of one head (8 input tiles x 4 groups)
+G_KV_HEAD = LT * 8               # 56
+G_PROJ_HEAD = NT * 4             # 32
+G_HEAD = G_QKV_HEAD + G_KV_HEAD + G_PROJ_HEAD   # 184
+G_MLP_TILE = NT * 4 + NT * 4     # 64: fc1 tile (32) + fc2 slice (32)
+G_BLOCK = HEADS * G_HEAD + HT * G_MLP_TILE      # 3520
+G_IMPL_PLAIN = NT * NT * 4       # 256
+G_IMPL_SKIP = 2 * G_IMPL_PLAIN   # 512
+G_IMPL = G_IMPL_PLAIN * 5 + G_IMPL_SKIP * 3     # layers 0,1,3,5,7 plain; 2,4,6 skip
+G_TOTAL = BLOCKS * G_BLOCK + G_IMPL             # 9856 groups = 39424 MFMAs per 32 points
+PROGRAM_FLOATS = (G_TOTAL + RING) * GROUP_FLOATS
+PROGRAM_BYTES = PROGRAM_FLOATS * 4
+
+
+def kv_group_offset(blk, head):
+    """First group of the K/V records of (block, head) inside the record stream."""
+    return blk * G_BLOCK + head * G_HEAD + G_QKV_HEAD
+
+
+def pack_records(sd, kv=None):
+    """state_dict (numpy fp32) -> record stream [PROGRAM_FLOATS] fp32.
+    ``kv``: optional {(blk, head): (K_h [197,32], V_h [197,32])}; zeros when absent
+    (the prologue kernel fills them per image on the device)."""
+    out = []
+    for blk in range(BLOCKS):
+        p = "blocks_attn.%d." % blk
+        Wqkv = np.asarray(sd[p + "attn.qkv.weight"], np.float32)      # [768, 256]
+        Wproj = np.asarray(sd[p + "attn.proj.weight"], np.float32)    # [256, 256]
+        W1 = np.asarray(sd[p + "mlp.fc1.weight"], np.float32)         # [1024, 256]
+        W2 = np.asarray(sd[p + "mlp.fc2.weight"], np.float32)         # [256, 1024]
+        for h in range(HEADS):
+            for part in range(3):                                      # q, k, v rows of head h
+                Wt = Wqkv[part * C + h * HD: part * C + (h + 1) * HD]  # [32, 256]
+                out.append(records_for_linear(Wt))                     # 128 records
+            if kv is not None:
+                out.append(kv_records(*kv[(blk, h)]))
+            else:
+                out.append(np.zeros((G_KV_HEAD * 4, 64), np.float32))
+            out.append(records_for_linear(Wproj[:, h * HD:(h + 1) * HD]))  # for nt: 16 records
+        for ht in range(HT):
+            out.append(records_for_linear(W1[ht * 32:(ht + 1) * 32]))      # fc1 tile: 128 records
+            out.append(records_for_linear(W2[:, ht * 32:(ht + 1) * 32]))   # fc2 slice: for nt: 16
+    for l in range(MLP_LAYERS - 1):
+        W = np.asarray(sd["impl_mlp.layers.%d.weight" % l], np.float32)
+        if l == 0:
+            out.append(records_for_linear(W[:, 3:]))                       # feat part
+        elif l in SKIP_IN:
+            # cat[x (256), xyz (3), feat (256)] / sqrt(2): per output tile, x part then feat part
+            Wx, Wf = W[:, :C], W[:, C + 3:]
+            for nt in range(NT):
+                out.append(records_for_linear(Wx[32 * nt:32 * nt + 32]))
+                out.append(records_for_linear(Wf[32 * nt:32 * nt + 32]))
+        else:
+            out.append(records_for_linear(W))
+    recs = np.concatenate(out, axis=0)
+    assert recs.shape == (G_TOTAL * 4, 64), recs.shape
+    flat = _interleave(recs)
+    return np.concatenate([flat, np.zeros(RING * GROUP_FLOATS, np.float32)])
+
+
+# ----------------------------------------------------------------------------- #
+# small parameters ("row-param" order [tile][hi][r])
+# ----------------------------------------------------------------------------- #
+def rowparam(v):
+    """feature vector [32*T] -> [T][hi][r] order (flattened)."""
+    v = np.asarray(v, np.float32)
+    T = v.shape[0] // 32
+    idx = (32 * np.arange(T))[:, None, None] + ROW_TABLE[None, :, :]     # [T, 2, 16]
+    return v[idx].reshape(-1)
+
+
+def rowparam4(cols):
+    """4 feature vectors [4][32*T] -> [T][hi][r][4] (one float4 per register)."""
+    stacked = np.stack([rowparam(c).reshape(-1) for c in cols], axis=-1)
+    return stacked.reshape(-1)
+
+
+class ParamLayout(object):
+    """Offsets (in floats) of every section of the params buffer; mirrored by the
+    constants in csrc/sdf_layout.h."""
+
+    def __init__(self):
+        o = 0
+
+        def take(n):
+            nonlocal o
+            s = o
+            o += n
+            return s
+        self.PP = take(C * 4)                      # point_proj (w0, w1, w2, b)
+        self.blk = []
+        for _ in range(BLOCKS):
+            d = {}
+            d["ln1_g"] = take(C)
+            d["ln1_b"] = take(C)
+            d["bproj"] = take(C)
+            d["bqkv"] = take(HEADS * 3 * 32)       # [head][q,k,v][hi][r]
+            d["ln2_g"] = take(C)
+            d["ln2_b"] = take(C)
+            d["b2"] = take(C)
+            d["b1"] = take(HID)
+            self.blk.append(d)
+        self.lnf_g = take(C)
+        self.lnf_b = take(C)
+        self.impl = []
+        for l in range(MLP_LAYERS - 1):
+            if l == 0 or l in SKIP_IN:
+                self.impl.append(take(C * 4))      # (w_x, w_y, w_z, bias) per feature
+            else:
+                self.impl.append(take(C))          # bias
+        self.w8 = take(C)
+        self.b8 = take(16)
+        self.total = o
+
+
+PARAMS = ParamLayout()
+BLOCK_PARAM_FLOATS = 3 * C + HEADS * 96 + 3 * C + HID
+
+
+def pack_params(sd):
+    g = lambda k: np.asarray(sd[k], np.float32)
+    out = np.zeros(PARAMS.total, np.float32)
+
+    def put(off, arr):
+        out[off:off + arr.size] = arr
+    Wp = g("point_proj.proj.weight")
+    put(PARAMS.PP, rowparam4([Wp[:, 0], Wp[:, 1], Wp[:, 2], g("point_proj.proj.bias")]))
+    for blk in range(BLOCKS):
+        p, d = "blocks_attn.%d." % blk, PARAMS.blk[blk]
+        put(d["ln1_g"], rowparam(g(p + "norm1.weight")))
+        put(d["ln1_b"], rowparam(g(p + "norm1.bias")))
+        put(d["bproj"], rowparam(g(p + "attn.proj.bias")))
+        bq = g(p + "attn.qkv.bias")
+        parts = []
+        for h in range(HEADS):
+            for part in range(3):
+                parts.append(rowparam(bq[part * C + h * HD: part * C + (h + 1) * HD]))
+        put(d["bqkv"], np.concatenate(parts))
+        put(d["ln2_g"], rowparam(g(p + "norm2.weight")))
+        put(d["ln2_b"], rowparam(g(p + "norm2.bias")))
+        put(d["b2"], rowparam(g(p + "mlp.fc2.bias")))
+        put(d["b1"], rowparam(g(p + "mlp.fc1.bias")))
+    put(PARAMS.lnf_g, rowparam(g("norm.weight")))
+    put(PARAMS.lnf_b, rowparam(g("norm.bias")))
+    for l in range(MLP_LAYERS - 1):
+        W, b = g("impl_mlp.layers.%d.weight" % l), g("impl_mlp.layers.%d.bias" % l)
+        if l == 0:
+            put(PARAMS.impl[l], rowparam4([W[:, 0], W[:, 1], W[:, 2], b]))
+        elif l in SKIP_IN:
+            put(PARAMS.impl[l], rowparam4([W[:, C], W[:, C + 1], W[:, C + 2], b]))
+        else:
+            put(PARAMS.impl[l], rowparam(b))
+    put(PARAMS.w8, rowparam(g("impl_mlp.layers.8.weight")[0]))
+    out[PARAMS.b8] = g("impl_mlp.layers.8.bias")[0]
+    return out
+
+
+# ----------------------------------------------------------------------------- #
+# latent-path parameters for the prologue kernels (weights transposed to [K][N])
+# ----------------------------------------------------------------------------- #
+class LatentLayout(object):
+    def __init__(self, latent_dim=C):
+        o = 0
+
+        def take(n):
+            nonlocal o
+            s = o
+            o += n
+            return s
+        self.latent_dim = latent_dim
+        self.Wlp = take(latent_dim * C)
+        self.blp = take(C)
+        self.pos = take(L * C)
+        self.ln1g0 = take(C)
+        self.ln1b0 = take(C)
+        self.Wqkv0 = take(C * 3 * C)
+        self.bqkv0 = take(3 * C)
+        self.Wproj0 = take(C * C)
+        self.bproj0 = take(C)
+        self.ln2g0 = take(C)
+        self.ln2b0 = take(C)
+        self.W1 = take(C * HID)
+        self.b1 = take(HID)
+        self.W2 = take(HID * C)
+        self.b2 = take(C)
+        self.ln1g1 = take(C)
+        self.ln1b1 = take(C)
+        self.Wkv1 = take(C * 2 * C)
+        self.bkv1 = take(2 * C)
+        self.total = o
+
+
+LATENT = LatentLayout()
+
+
+def pack_latent_params(sd):
+    g = lambda k: np.asarray(sd[k], np.float32)
+    assert g("latent_proj.weight").shape == (C, LATENT.latent_dim)
+    out = np.zeros(LATENT.total, np.float32)
+
+    def put(off, arr):
+        arr = np.ascontiguousarray(arr, np.float32).reshape(-1)
+        out[off:off + arr.size] = arr
+    put(LATENT.Wlp, g("latent_proj.weight").T)
+    put(LATENT.blp, g("latent_proj.bias"))
+    put(LATENT.pos, g("pos_embed").reshape(L, C))
+    b0, b1 = "blocks_attn.0.", "blocks_attn.1."
+    put(LATENT.ln1g0, g(b0 + "norm1.weight"))
+    put(LATENT.ln1b0, g(b0 + "norm1.bias"))
+    put(LATENT.Wqkv0, g(b0 + "attn.qkv.weight").T)
+    put(LATENT.bqkv0, g(b0 + "attn.qkv.bias"))
+    put(LATENT.Wproj0, g(b0 + "attn.proj.weight").T)
+    put(LATENT.bproj0, g(b0 + "attn.proj.bias"))
+    put(LATENT.ln2g0, g(b0 + "norm2.weight"))
+    put(LATENT.ln2b0, g(b0 + "norm2.bias"))
+    put(LATENT.W1, g(b0 + "mlp.fc1.weight").T)
+    put(LATENT.b1, g(b0 + "mlp.fc1.bias"))
+    put(LATENT.W2, g(b0 + "mlp.fc2.weight").T)
+    put(LATENT.b2, g(b0 + "mlp.fc2.bias"))
+    put(LATENT.ln1g1, g(b1 + "norm1.weight"))
+    put(LATENT.ln1b1, g(b1 + "norm1.bias"))
+    put(LATENT.Wkv1, g(b1 + "attn.qkv.weight")[C:].T)     # k and v rows only
+    put(LATENT.bkv1, g(b1 + "attn.qkv.bias")[C:])
+    return out
+
+
+# prologue scratch per image (floats): lat, x1, x2 [197x256]; qkv0 [197x768]; attn [197x256];
+# hid [197x1024]; kv1 [197x512]
+LPAD = 200  # rows padded to a multiple of the prologue's row block (4)
+SCRATCH_FLOATS = LPAD * (3 * C + 3 * C + C + HID + 2 * C)
