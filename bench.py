@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py - SDF query-points/sec at vox_res=128 (BASELINE.json metric) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path over one batch of synthetic input with inputs
+resident in HBM: for a batch of n_gpus images (one per rank's worth of work, "weak"
+scaling) the per-image prologue + the fused decoder over every rank's x-slab of each
+image's (128+1)^3 grid, then - for N > 1 - one RCCL all_gather that rebuilds the full
+occupancy grids on every rank (zeroshape_amd/parallel.py).  N = 1: one image, one full
+129^3 grid, no collective.  value = grid points evaluated by all ranks / max-over-ranks
+time.  Weights: seeded random (no checkpoint ships with the reference); latent_depth:
+seeded N(0,1).
+
+Extra objects on the JSON line:
+  roofline     - the fused decoder kernel against the fp32-MFMA peak (157.3 TFLOP/s,
+                 MI355X_MICROARCH.md): algorithmic 5.00 MFLOP/point x
+                 points per launch / mean launch duration from HIP events on the launch stream.
+  cpu_baseline - the oracle (torch-CPU fp32 restatement of the reference, "port") timed on
+                 this host's cores on a bounded sample of x-slices of the same grid.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+VOX_RES = 128
+RANGE = (-1.5, 1.5)
+FLOP_PER_POINT = 5.00e6          # SURVEY.md section 8d (algorithmic, fp32 reference)
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact f32
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--vox-res", type=int, default=VOX_RES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from zeroshape_amd import parallel, synthetic as syn
+    from zeroshape_amd.model.shape.implicit import Implicit
+    from zeroshape_amd.utils.pos_embed import get_2d_sincos_pos_embed
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    N = args.vox_res
+    G = N + 1
+    pe = get_2d_sincos_pos_embed(256, 14, cls_token=True).astype(np.float32)
+    sd = {k: torch.from_numpy(v) for k, v in syn.seeded_state_dict(0, pos_embed=pe).items()}
+    net = Implicit(syn.NUM_PATCHES, latent_dim=256, n_channels=256, n_blocks_attn=2, n_layers_mlp=8,
+                   num_heads=8, skip_in=[2, 4, 6], pos_perlayer=False)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    batch = world                                  # weak scaling: one image of work per rank
+    latent = torch.from_numpy(syn.seeded_latent(0, batch)).to(dev)
+    axis = torch.linspace(RANGE[0], RANGE[1], G, device=dev)
+    net.packed(dev)                                # pack weights once, outside the timed region
+
+    def step():
+        st = net.prepare(latent)                   # per-image prologue (all images, every rank)
+        return parallel.sharded_level_grid(
+            lambda b, e: net.query_grid(latent, axis, apply_sigmoid=True, slice_begin=b,
+                                        slice_end=e, state=st), G)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        occ = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        occ = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert occ.shape == (batch, G, G, G)
+    points_per_step = batch * G ** 3
+    value = points_per_step * args.steps / dt
+
+    # ---- roofline of the dominant kernel: HIP events around decoder launches only -------
+    b, e, _ = parallel.slab_bounds(G, world, rank)
+    st = net.prepare(latent)
+    torch.cuda.synchronize()
+    reps = max(3, min(args.steps, 10))
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    stream = torch.cuda.current_stream(dev)       # the stream the C ABI launches on
+    ev[0].record(stream)
+    for i in range(reps):
+        net.query_grid(latent, axis, apply_sigmoid=True, slice_begin=b, slice_end=e, state=st)
+        ev[i + 1].record(stream)
+    torch.cuda.synchronize()
+    kern_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps))
+    kern_mean = sum(kern_ms) / len(kern_ms)
+    pts_launch = batch * (e - b) * G * G
+    achieved = pts_launch * FLOP_PER_POINT / (kern_mean * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": "sdf_decode_kernel<GRID>", "achieved": round(achieved, 3),
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "points_per_launch": pts_launch, "launch_ms_mean": round(kern_mean, 4),
+                "launch_ms_min": round(kern_ms[0], 4),
+                "algorithmic_flop_per_point": FLOP_PER_POINT}
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import decoder_ref
+        torch.set_num_threads(os.cpu_count() or 1)
+        cores = torch.get_num_threads()
+        grid = decoder_ref.dense_grid(RANGE[0], RANGE[1], N)
+        lat_c = latent[:1].cpu()
+        sl = list(np.linspace(0, N, 17).round().astype(int))       # evenly spaced x-slices
+        done, t1 = 0, time.perf_counter()
+        decoder_ref.level_grid(sd, lat_c, grid, slices=[sl[0]])     # warm-up slice, untimed
+        t1 = time.perf_counter()
+        for i in sl:
+            decoder_ref.level_grid(sd, lat_c, grid, slices=[int(i)])
+            done += 1
+            if time.perf_counter() - t1 > args.cpu_seconds and done >= 2:
+                break
+        cdt = time.perf_counter() - t1
+        cpu_baseline = {"value": round(done * G * G / cdt, 1), "unit": "points/s", "cores": cores,
+                        "kind": "port",
+                        "sample": "%d evenly spaced x-slices of the %d^3 grid (%d points), oracle/"
+                                  "decoder_ref.level_grid, torch-CPU fp32, %.1f s" % (done, G, done * G * G, cdt)}
+
+    if rank == 0:
+        line = {
+            "metric": "sdf_query_points_per_sec_vox%d" % N, "value": round(value, 1),
+            "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "compute_level_grid vox_res=%d: (%d+1)^3 = %d points/image, "
+                                   "range [-1.5,1.5], prologue + fused decoder + sigmoid; batch = "
+                                   "n_gpus images, x-slab sharded, RCCL all_gather for n_gpus>1"
+                                   % (N, N, G ** 3),
+                       "global_batch_images": batch, "points_per_step": points_per_step,
+                       "weights": "seeded random (zeroshape_amd/synthetic.py)"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

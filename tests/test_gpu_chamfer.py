@@ -1,0 +1,126 @@
+"""GPU parity: HIP Chamfer kernels (through the C ABI / plugin mirror) vs the oracle.
+Bar: squared distances and int32 indices BIT-EXACT (same fmaf chain, same tie rule)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import chamfer_ref as C
+from oracle import geometry_ref as G
+from zeroshape_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(a, b):
+    from zeroshape_amd.external.chamfer3D.dist_chamfer_3D import chamfer_3DDist
+    d1, d2, i1, i2 = chamfer_3DDist()(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+    return d1.cpu().numpy(), d2.cpu().numpy(), i1.cpu().numpy(), i2.cpu().numpy()
+
+
+@pytest.mark.parametrize("b,n,m", [(1, 1, 1), (2, 3, 4), (1, 5, 3), (3, 7, 511), (2, 9, 512), (2, 11, 513),
+                                   (1, 1023, 1025), (2, 300, 2049), (33, 257, 100), (4, 5000, 3000),
+                                   (24, 10000, 10000)])
+def test_forward_bit_exact(b, n, m):
+    rs = np.random.RandomState(b * 31 + n * 7 + m)
+    a = rs.uniform(-0.5, 0.5, (b, n, 3)).astype(np.float32)
+    c = rs.uniform(-0.5, 0.5, (b, m, 3)).astype(np.float32)
+    got = _run(a, c)
+    want = C.chamfer_forward(a, c)
+    for g, w, name in zip(got, want, ("dist1", "dist2", "idx1", "idx2")):
+        assert g.dtype == w.dtype and g.shape == w.shape, name
+        np.testing.assert_array_equal(g, w, err_msg=name)
+
+
+def test_ties_and_duplicates():
+    m = 2100   # spans three 1024-candidate LDS tiles
+    c = np.tile(np.array([[1, 0, 0]], np.float32), (m, 1))[None].copy()
+    a = np.zeros((1, 70, 3), np.float32)
+    d1, d2, i1, i2 = _run(a, c)
+    assert np.all(i1 == 0) and np.all(d1 == 1.0) and np.all(i2 == 0)
+    c[0, 1500] = [0.5, 0, 0]
+    c[0, 2050] = [0.5, 0, 0]
+    d1, d2, i1, i2 = _run(a, c)
+    w = C.chamfer_forward(a, c)
+    assert np.all(i1 == 1500)
+    np.testing.assert_array_equal(i1, w[2])
+    np.testing.assert_array_equal(d2, w[1])
+    # clouds made only of duplicates of a few points (collisions everywhere)
+    rs = np.random.RandomState(1)
+    base = rs.randn(5, 3).astype(np.float32)
+    a = base[rs.randint(0, 5, size=(2, 777))]
+    c = base[rs.randint(0, 5, size=(2, 1300))]
+    got, want = _run(a, c), C.chamfer_forward(a, c)
+    for g, w_ in zip(got, want):
+        np.testing.assert_array_equal(g, w_)
+
+
+def test_empty_cloud_leaves_zeros():
+    from zeroshape_amd import chamfer_3D
+    xyz1 = torch.rand(2, 5, 3).cuda()
+    xyz2 = torch.zeros(2, 0, 3).cuda()
+    d1 = torch.zeros(2, 5).cuda(); d2 = torch.zeros(2, 0).cuda()
+    i1 = torch.zeros(2, 5, dtype=torch.int32).cuda(); i2 = torch.zeros(2, 0, dtype=torch.int32).cuda()
+    assert chamfer_3D.forward(xyz1, xyz2, d1, d2, i1, i2) == 1
+    assert torch.all(d1 == 0) and torch.all(i1 == 0)
+
+
+def test_plugin_rejects_bad_tensors():
+    from zeroshape_amd import chamfer_3D
+    x = torch.rand(1, 4, 3).cuda()
+    d = torch.zeros(1, 4).cuda()
+    i = torch.zeros(1, 4, dtype=torch.int32).cuda()
+    with pytest.raises(TypeError):
+        chamfer_3D.forward(x, x, d, d, i.long(), i)
+    with pytest.raises(ValueError):
+        chamfer_3D.forward(x.cpu(), x, d, d, i, i)
+    with pytest.raises(ValueError):
+        chamfer_3D.forward(x, x, d[:, :3], d, i, i)
+
+
+def test_backward_matches_oracle():
+    rs = np.random.RandomState(3)
+    a = rs.randn(2, 400, 3).astype(np.float32)
+    c = rs.randn(2, 300, 3).astype(np.float32)
+    from zeroshape_amd.external.chamfer3D.dist_chamfer_3D import chamfer_3DDist
+    ta = torch.from_numpy(a).cuda().requires_grad_(True)
+    tc = torch.from_numpy(c).cuda().requires_grad_(True)
+    d1, d2, i1, i2 = chamfer_3DDist()(ta, tc)
+    g1 = torch.from_numpy(rs.randn(2, 400).astype(np.float32)).cuda()
+    g2 = torch.from_numpy(rs.randn(2, 300).astype(np.float32)).cuda()
+    (d1 * g1).sum().add((d2 * g2).sum()).backward()
+    wa, wc = C.chamfer_backward(a, c, g1.cpu().numpy(), g2.cpu().numpy(), i1.cpu().numpy(), i2.cpu().numpy())
+    # atomics add in a different order than the sequential oracle: tolerance, not bit-exact
+    np.testing.assert_allclose(ta.grad.cpu().numpy(), wa, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(tc.grad.cpu().numpy(), wc, rtol=1e-5, atol=1e-5)
+
+
+def test_chamfer_distance_and_fscore_helpers():
+    from zeroshape_amd.utils import eval_3D as E
+    a = torch.from_numpy(syn.seeded_cloud(1, 3, 2000))
+    c = torch.from_numpy(syn.seeded_cloud(2, 3, 1500))
+    d1, d2, i1, i2 = E.chamfer_distance(None, a.cuda(), c.cuda())
+    w1, w2, j1, j2 = G.chamfer_distance(a, c)
+    np.testing.assert_array_equal(i1.cpu().numpy(), j1.numpy())
+    np.testing.assert_allclose(d1.cpu().numpy(), w1.numpy(), rtol=2e-7, atol=0)   # sqrt rounding only
+    f = E.compute_fscore(d1, d2).cpu()
+    np.testing.assert_allclose(f.numpy(), G.compute_fscore(w1, w2).numpy(), atol=1e-6)
+    n = E.normalize_pc(a.cuda()).cpu()
+    np.testing.assert_allclose(n.numpy(), G.normalize_pc(a).numpy(), atol=1e-6)
+
+
+def test_brute_force_search_matches_oracle_scan():
+    from zeroshape_amd.utils import eval_3D as E
+    from zeroshape_amd.utils.camera import get_rotation_sphere
+    R = get_rotation_sphere(24, 24, 12, device="cpu")
+    rs = np.random.RandomState(0)
+    gt = torch.from_numpy((rs.randn(1500, 3) * np.array([0.5, 0.3, 0.2]) + rs.rand(1500, 1) * 0.3).astype(np.float32))
+    k = 1234
+    pred = (R[k].T @ gt.T).T.contiguous() + 1e-3 * torch.from_numpy(rs.randn(1500, 3).astype(np.float32))
+    sub = R[k - 36:k + 36]
+    acc, comp, f, best, gt_n, idx, cd = E.brute_force_search(pred, gt, device="cuda", rotations=sub.cuda(),
+                                                             return_index=True)
+    oacc, ocomp, of, obest, ogt, oidx = G.brute_force_search(pred, gt, rotations=sub)
+    assert idx == oidx == 36
+    np.testing.assert_allclose(float(acc), float(oacc), rtol=1e-5)
+    np.testing.assert_allclose(float(comp), float(ocomp), rtol=1e-5)
+    np.testing.assert_allclose(f.cpu().numpy(), of.numpy(), atol=1e-6)

@@ -1,0 +1,177 @@
+"""GPU parity: fused HIP decoder (prologue + per-point kernel, through the C ABI) vs the
+oracle and vs the golden outputs of the real reference.
+
+Bars (BASELINE.json north_star): logits / occupancy within 1e-4 absolute (we assert a much
+tighter 2e-5, the kernel is exact-fp32 MFMA); occupancy indices (occ > 0.5) bit-exact
+outside an ambiguity band |logit| < 1e-5 around the level set, flips inside it counted
+and bounded."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import decoder_ref as R
+from zeroshape_amd import program as P
+from zeroshape_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 2e-5     # fp32 roundoff over ~25 dependent stages; the contract is 1e-4
+BAND = 1e-5     # |logit| below which an occupancy flip is a rounding tie, not a bug
+
+
+@pytest.fixture(scope="module")
+def net(seeded_sd):
+    from zeroshape_amd.model.shape.implicit import Implicit
+    m = Implicit(syn.NUM_PATCHES, latent_dim=syn.LATENT_DIM, semantic=False, n_channels=syn.N_CHANNELS,
+                 n_blocks_attn=syn.ATT_BLOCKS, n_layers_mlp=syn.MLP_LAYERS, num_heads=syn.NUM_HEADS,
+                 posenc_3D=0, mlp_ratio=syn.MLP_RATIO, skip_in=list(syn.SKIP_IN), pos_perlayer=False)
+    m.load_state_dict(seeded_sd, strict=True)
+    return m.cuda().eval()
+
+
+def test_state_dict_contract(net, seeded_sd):
+    assert list(net.state_dict().keys()) == list(syn.impl_network_shapes().keys())
+
+
+def test_prologue_kv_records_match_oracle(net, seeded_sd):
+    latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=2))
+    st = net.prepare(latent.cuda())
+    got = st.programs.cpu().numpy()
+    lp = R.latent_path(seeded_sd, latent)
+    sd_np = {k: v.numpy() for k, v in seeded_sd.items()}
+    for b in range(2):
+        kv = {(blk, h): (lp["k%d" % blk][b, h].numpy(), lp["v%d" % blk][b, h].numpy())
+              for blk in range(2) for h in range(8)}
+        want = P.pack_program(sd_np, kv)
+        # weights / params sections are copied verbatim; K/V records are computed on the device
+        np.testing.assert_allclose(got[b], want, atol=3e-6, rtol=0)
+        same = got[b] == want
+        assert same.mean() > 0.95
+
+
+def test_training_shape_points_vs_golden(net, decoder_golden):
+    latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=2)).cuda()
+    rs = np.random.RandomState(123)
+    pts = torch.from_numpy(rs.uniform(-1, 1, size=(2, 4096, 3)).astype(np.float32)).cuda()
+    lg, attn = net(latent, None, pts)
+    assert attn is None and lg.shape == (2, 4096) and lg.dtype == torch.float32
+    np.testing.assert_allclose(lg.cpu().numpy(), decoder_golden["pts4096_logit"], atol=ATOL, rtol=0)
+
+
+@pytest.mark.parametrize("m", [1, 31, 32, 33, 127, 128, 129, 1000])
+def test_ragged_point_counts_vs_oracle(net, seeded_sd, m):
+    latent = torch.from_numpy(syn.seeded_latent(seed=3, batch=1))
+    pts = torch.from_numpy(syn.seeded_cloud(m, 1, m, -1.5, 1.5))
+    want, _ = R.implicit_forward(seeded_sd, latent, pts)
+    got, _ = net(latent.cuda(), None, pts.cuda())
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=ATOL, rtol=0)
+
+
+def test_empty_points(net):
+    latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=1)).cuda()
+    lg, _ = net(latent, None, torch.zeros(1, 0, 3).cuda())
+    assert lg.shape == (1, 0)
+
+
+def test_grid32_full_vs_golden(net, decoder_golden):
+    """vox_res = 32 through compute_level_grid's fused path: occupancy bits + values."""
+    from zeroshape_amd.utils import eval_3D as E
+    from zeroshape_amd.utils.options import EasyDict as edict
+    latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=2))[:1].cuda()
+    opt = edict(dict(device="cuda", H=224, W=224, eval=dict(vox_res=32, range=[-1.5, 1.5]),
+                     arch=dict(win_size=16)))
+    var = edict(dict(idx=[0]))
+    grid = E.get_dense_3D_grid(opt, var)
+    assert grid.shape == (1, 33, 33, 33, 3)
+    occ, vis = E.compute_level_grid(opt, net, latent, None, grid, None, vis_attn=False)
+    assert vis is None and occ.shape == (1, 33, 33, 33)
+    occ = occ[0].cpu().numpy()
+    np.testing.assert_allclose(occ[::5, ::5, ::5], decoder_golden["occ32_stride5"], atol=ATOL, rtol=0)
+    bits = np.unpackbits(decoder_golden["occ32_bits"])[: occ.size].astype(bool)
+    mism = (occ > 0.5).reshape(-1) != bits
+    # logits of the golden for three slices pin the band check
+    logit = np.log(occ / (1 - occ)).reshape(-1)
+    assert np.all(np.abs(logit[mism]) < BAND), "occupancy flip outside the rounding band"
+    assert mism.sum() <= 2
+    # raw logits for the stored slices
+    lg = net.query_grid(latent, grid._zs_grid.axis, apply_sigmoid=False)[0].cpu().numpy()
+    for i in (0, 16, 32):
+        np.testing.assert_allclose(lg[i].reshape(-1), decoder_golden["logit32_slice%d" % i], atol=ATOL, rtol=0)
+
+
+def test_generic_slice_loop_equals_fused_grid(net):
+    """compute_level_grid on a tensor NOT made by get_dense_3D_grid takes the reference's
+    slice loop through impl_network(...); must agree with the fused grid launch bit for bit
+    (same kernel arithmetic, only the coordinate source differs)."""
+    from zeroshape_amd.utils import eval_3D as E
+    from zeroshape_amd.utils.options import EasyDict as edict
+    latent = torch.from_numpy(syn.seeded_latent(seed=1, batch=2)).cuda()
+    opt = edict(dict(device="cuda", H=224, W=224, eval=dict(vox_res=8, range=[-1.5, 1.5]),
+                     arch=dict(win_size=16)))
+    var = edict(dict(idx=[0, 1]))
+    grid = E.get_dense_3D_grid(opt, var)
+    fused, _ = E.compute_level_grid(opt, net, latent, None, grid, None)
+    plain = grid.clone()            # loses the _zs_grid tag
+    loop, _ = E.compute_level_grid(opt, net, latent, None, plain, None)
+    assert torch.equal(fused, loop)
+
+
+@pytest.mark.parametrize("N", [64, 128])
+def test_grid_slices_vs_golden(net, decoder_golden, N):
+    latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=2))[:1].cuda()
+    axis = torch.linspace(-1.5, 1.5, N + 1, device="cuda")
+    np.testing.assert_array_equal(axis.cpu().numpy(), decoder_golden["linspace_%d" % N])
+    st = net.prepare(latent)
+    for i in (0, N // 2, N):
+        lg = net.query_grid(latent, axis, apply_sigmoid=False, slice_begin=i, slice_end=i + 1, state=st)
+        got = lg[0, 0].reshape(-1)[::16].cpu().numpy()
+        np.testing.assert_allclose(got, decoder_golden["logit%d_slice%d_s16" % (N, i)], atol=ATOL, rtol=0)
+
+
+def test_full_size_grid128_properties(net, seeded_sd):
+    """BASELINE config: 129^3 points.  Size-independent properties: (1) slab decomposition is
+    exact (any x-slab of the full launch equals a separate launch of that slab) - the basis
+    of the multi-GPU sharding; (2) spot-check 2048 random grid points against the oracle;
+    (3) occupancy fraction is sane and identical between sigmoid>0.5 and logit>0."""
+    N = 128
+    latent_c = torch.from_numpy(syn.seeded_latent(seed=0, batch=1))
+    latent = latent_c.cuda()
+    axis = torch.linspace(-1.5, 1.5, N + 1, device="cuda")
+    st = net.prepare(latent)
+    full = net.query_grid(latent, axis, apply_sigmoid=False, state=st)
+    assert full.shape == (1, N + 1, N + 1, N + 1)
+    slab = net.query_grid(latent, axis, apply_sigmoid=False, slice_begin=40, slice_end=57, state=st)
+    assert torch.equal(full[:, 40:57], slab)
+    occ = net.query_grid(latent, axis, apply_sigmoid=True, state=st)
+    assert torch.equal(occ > 0.5, full > 0)
+    frac = float((full > 0).float().mean())
+    assert 0.05 < frac < 0.95
+    rs = np.random.RandomState(7)
+    idx = rs.randint(0, N + 1, size=(2048, 3))
+    ax = axis.cpu()
+    pts = torch.stack([ax[idx[:, 0]], ax[idx[:, 1]], ax[idx[:, 2]]], -1)[None]
+    want, _ = R.implicit_forward(seeded_sd, latent_c, pts)
+    got = full[0, idx[:, 0], idx[:, 1], idx[:, 2]].cpu().numpy()
+    np.testing.assert_allclose(got, want[0].numpy(), atol=ATOL, rtol=0)
+    flips = (got > 0) != (want[0].numpy() > 0)
+    assert np.all(np.abs(want[0].numpy()[flips]) < BAND)
+
+
+def test_weights_update_repacks(net, seeded_sd):
+    latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=1)).cuda()
+    pts = torch.from_numpy(syn.seeded_cloud(5, 1, 64, -1, 1)).cuda()
+    a, _ = net(latent, None, pts)
+    with torch.no_grad():
+        net.impl_mlp.layers[8].bias.add_(0.25)
+    b, _ = net(latent, None, pts)
+    np.testing.assert_allclose((b - a).cpu().numpy(), 0.25, atol=1e-6)
+    with torch.no_grad():
+        net.impl_mlp.layers[8].bias.sub_(0.25)
+
+
+def test_unsupported_configs_raise():
+    from zeroshape_amd.model.shape.implicit import Implicit
+    m = Implicit(196, latent_dim=256, n_channels=256, n_blocks_attn=2, n_layers_mlp=8, num_heads=16,
+                 skip_in=[2, 4, 6], pos_perlayer=False).cuda().eval()
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 197, 256).cuda(), None, torch.zeros(1, 4, 3).cuda())

@@ -14,7 +14,8 @@ from tests import mfma_emulator as E
 def test_layout_constants():
     assert P.G_HEAD % P.RING == 0 and P.G_MLP_TILE % P.RING == 0 and P.G_KV_HEAD % P.RING == 0
     assert P.G_TOTAL == 9856 and P.G_TOTAL * 4 == 39424
-    assert P.PROGRAM_BYTES == (9856 + 8) * 1024
+    assert P.REC_FLOATS * 4 == (9856 + 8) * 1024
+    assert P.PROGRAM_BYTES == P.REC_FLOATS * 4 + P.PARAM_FLOATS * 4
     assert P.PARAMS.total * 4 < 64 * 1024          # params are staged in LDS
     assert sorted(P.ROW_TABLE.reshape(-1).tolist()) == list(range(32))
 
@@ -49,7 +50,8 @@ def test_emulated_kernel_matches_oracle(seeded_sd):
             kv[(blk, h)] = (lp["k%d" % blk][0, h].numpy(), lp["v%d" % blk][0, h].numpy())
     recs = P.pack_records(sd_np, kv)
     params = P.pack_params(sd_np)
-    assert recs.size == P.PROGRAM_FLOATS and recs.dtype == np.float32
+    assert recs.size == P.REC_FLOATS and recs.dtype == np.float32
+    assert P.pack_program(sd_np, kv).size == P.PROGRAM_FLOATS
     pts = syn.seeded_cloud(11, 1, 32, -1.5, 1.5)
     want, _ = R.implicit_forward(seeded_sd, latent, torch.from_numpy(pts))
     got = E.decode_wave(recs, params, pts[0])

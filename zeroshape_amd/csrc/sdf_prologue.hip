@@ -1,0 +1,243 @@
+// Per-image prologue of the fused decoder: the point-independent half of
+// Implicit.forward (model/shape/implicit.py:251-288) - latent_proj + pos_embed, block 0
+// on the 197 latent rows (latent self-attention implicit.py:67-71, proj, Mlp) and the
+// K/V of both blocks - computed ONCE per image instead of once per slice as the
+// reference does (utils/eval_3D.py:34-43), then written into the per-image decoder
+// program as MFMA A-operand records (zeroshape_amd/program.py: kv_records).
+//
+// 0.45 GFLOP per image against 10.7 TFLOP for a 129^3 grid: these are plain
+// fp32-FMA kernels (coalesced [K][N] weights, activations broadcast from LDS), not
+// tuned further.  Arithmetic follows oracle/decoder_ref.py::latent_path.
+#include "zs_common.h"
+#include "sdf_layout.h"
+#include "../../include/zeroshape_hip.h"
+
+#include <math.h>
+
+namespace {
+
+using namespace zs::lay;
+
+constexpr int ROWS = 4;      // latent rows per block (one wave each for the LayerNorm stats)
+constexpr int LIN_THREADS = 256;
+constexpr int KMAX = 1024;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float erf_ref(float x) { return erff(x); }
+
+// Y[r][n] = epilogue( sum_k Xn[r][k] * Wt[k][n] + bias[n] ),  Xn = LayerNorm(X[r]) if LN_IN
+// epilogue: (+ pos[r][n]) -> (GELU) -> (+ resid[r][n]).  Rows >= `rows` are clamped on
+// load and not stored.  grid = (ceil(rows / ROWS), N / 256, batch).
+template <bool LN_IN, bool GELU, bool RESID, bool POS>
+__global__ __launch_bounds__(LIN_THREADS) void lat_linear_kernel(
+    const float *__restrict__ X, int ldx, size_t x_stride, int K, const float *__restrict__ Wt,
+    const float *__restrict__ bias, int N, const float *__restrict__ ln_g,
+    const float *__restrict__ ln_b, const float *__restrict__ resid, int ldr, size_t r_stride,
+    const float *__restrict__ pos, float *__restrict__ Y, int ldy, size_t y_stride, int rows) {
+    __shared__ float xs[ROWS][KMAX];
+    const int img = blockIdx.z;
+    const int r0 = blockIdx.x * ROWS;
+    const int n = blockIdx.y * LIN_THREADS + threadIdx.x;
+    X += (size_t)img * x_stride;
+    Y += (size_t)img * y_stride;
+
+    for (int i = threadIdx.x; i < ROWS * K; i += LIN_THREADS) {
+        const int r = i / K, k = i - r * K;
+        const int rr = min(r0 + r, rows - 1);
+        xs[r][k] = X[(size_t)rr * ldx + k];
+    }
+    __syncthreads();
+    if (LN_IN) {  // K == 256: wave w normalises row w
+        const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        float v[4], s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            v[j] = xs[w][lane + 64 * j];
+            s += v[j];
+        }
+        const float mean = wave_sum(s) * (1.0f / 256.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float d = v[j] - mean;
+            q = fmaf(d, d, q);
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / 256.0f) + 1e-6f);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = lane + 64 * j;
+            xs[w][k] = fmaf((v[j] - mean) * rstd, ln_g[k], ln_b[k]);
+        }
+        __syncthreads();
+    }
+    float acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) acc[r] = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < K; k++) {
+        const float w = Wt[(size_t)k * N + n];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) acc[r] = fmaf(xs[r][k], w, acc[r]);
+    }
+    const float b = bias[n];
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        const int row = r0 + r;
+        if (row >= rows) break;
+        float v = acc[r] + b;
+        if (POS) v += pos[(size_t)row * N + n];
+        if (GELU) v = 0.5f * v * (1.0f + erf_ref(v * 0.70710678118654752440f));
+        if (RESID) v += resid[(size_t)img * r_stride + (size_t)row * ldr + n];
+        Y[(size_t)row * ldy + n] = v;
+    }
+}
+
+// latent self-attention of block 0 (implicit.py:67-71): one block per (head, image),
+// one thread per query row, K/V of the head in LDS, online softmax.
+__global__ __launch_bounds__(256) void lat_self_attn_kernel(const float *__restrict__ qkv,
+                                                            size_t stride, float *__restrict__ out,
+                                                            size_t out_stride) {
+    __shared__ float ks[L][HD];
+    __shared__ float vs[L][HD];
+    const int hd = blockIdx.x, img = blockIdx.y;
+    qkv += (size_t)img * stride;
+    out += (size_t)img * out_stride;
+    for (int i = threadIdx.x; i < L * HD; i += 256) {
+        const int r = i / HD, d = i - r * HD;
+        ks[r][d] = qkv[(size_t)r * (3 * C) + C + hd * HD + d];
+        vs[r][d] = qkv[(size_t)r * (3 * C) + 2 * C + hd * HD + d];
+    }
+    __syncthreads();
+    const int i = threadIdx.x;
+    if (i >= L) return;
+    float q[HD], o[HD];
+#pragma unroll
+    for (int d = 0; d < HD; d++) {
+        q[d] = qkv[(size_t)i * (3 * C) + hd * HD + d];
+        o[d] = 0.f;
+    }
+    const float scale = 0.17677669529663688110f;
+    float m = -INFINITY, z = 0.f;
+    for (int j = 0; j < L; j++) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; d++) s = fmaf(q[d], ks[j][d], s);
+        s *= scale;
+        const float mn = fmaxf(m, s);
+        const float a = expf(m - mn), p = expf(s - mn);
+        z = fmaf(z, a, p);
+#pragma unroll
+        for (int d = 0; d < HD; d++) o[d] = fmaf(p, vs[j][d], o[d] * a);
+        m = mn;
+    }
+    const float inv = 1.0f / z;
+#pragma unroll
+    for (int d = 0; d < HD; d++) out[(size_t)i * C + hd * HD + d] = o[d] * inv;
+}
+
+// K/V of both blocks -> A-operand records inside each image's program
+// (zeroshape_amd/program.py::kv_records; element order [blk][head][lt][K|V][r][lane]).
+__global__ __launch_bounds__(256) void pack_kv_kernel(const float *__restrict__ scratch,
+                                                      size_t scratch_stride,
+                                                      float *__restrict__ programs,
+                                                      size_t program_stride) {
+    const int img = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;  // < 2*8*7*2*16*64
+    const int lane = e & 63;
+    const int r = (e >> 6) & 15;
+    const int which = (e >> 10) & 1;
+    int t = e >> 11;
+    const int lt = t % LT;
+    t /= LT;
+    const int hd = t & 7;
+    const int blk = t >> 3;
+    if (blk >= BLOCKS) return;
+    const float *sc = scratch + (size_t)img * scratch_stride;
+    const int rw = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    // K record: A[i = latent row][k = dim];  V record: A[i = dim][k = latent row]
+    const int lrow = 32 * lt + (which == 0 ? (lane & 31) : rw);
+    const int dim = which == 0 ? rw : (lane & 31);
+    float val = 0.f;
+    if (lrow < L) {
+        if (blk == 0)
+            val = sc[S_QKV0 + (size_t)lrow * (3 * C) + (1 + which) * C + hd * HD + dim];
+        else
+            val = sc[S_KV1 + (size_t)lrow * (2 * C) + which * C + hd * HD + dim];
+    }
+    const int group = blk * G_BLOCK + hd * G_HEAD + G_QKV_HEAD + lt * 8 + which * 4 + (r >> 2);
+    programs[(size_t)img * program_stride + (size_t)group * GROUP_FLOATS + lane * 4 + (r & 3)] = val;
+}
+
+template <bool LN_IN, bool GELU, bool RESID, bool POS>
+void launch_linear(hipStream_t s, int batch, const float *X, int ldx, size_t x_stride, int K,
+                   const float *Wt, const float *bias, int N, const float *g, const float *b,
+                   const float *resid, int ldr, size_t r_stride, const float *pos, float *Y, int ldy,
+                   size_t y_stride) {
+    dim3 grid((L + ROWS - 1) / ROWS, N / LIN_THREADS, batch);
+    hipLaunchKernelGGL((lat_linear_kernel<LN_IN, GELU, RESID, POS>), grid, dim3(LIN_THREADS), 0, s, X,
+                       ldx, x_stride, K, Wt, bias, N, g, b, resid, ldr, r_stride, pos, Y, ldy,
+                       y_stride, L);
+}
+
+}  // namespace
+
+extern "C" size_t zs_sdf_prologue_scratch_bytes(void) { return (size_t)SCRATCH_FLOATS * sizeof(float); }
+
+extern "C" int zs_sdf_prologue(void *programs, size_t program_stride_bytes, const float *lat_params,
+                               const float *latent_depth, int batch, void *scratch, void *stream) {
+    if (batch < 0) {
+        zs::set_err("zs_sdf_prologue: negative batch %d", batch);
+        return 0;
+    }
+    if (batch == 0) return 1;
+    if (!programs || !lat_params || !latent_depth || !scratch) {
+        zs::set_err("zs_sdf_prologue: null pointer");
+        return 0;
+    }
+    if (program_stride_bytes % 16 != 0 || program_stride_bytes < zs_sdf_program_bytes()) {
+        zs::set_err("zs_sdf_prologue: bad program stride %zu", program_stride_bytes);
+        return 0;
+    }
+    if (batch > 65535) {
+        zs::set_err("zs_sdf_prologue: batch %d > 65535", batch);
+        return 0;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float *P = lat_params;
+    float *sc = static_cast<float *>(scratch);
+    const size_t ss = SCRATCH_FLOATS;
+    // lat = latent_proj(latent_depth) + pos_embed                     (implicit.py:257,271-272)
+    launch_linear<false, false, false, true>(s, batch, latent_depth, C, (size_t)L * C, C, P + LQ_WLP,
+                                             P + LQ_BLP, C, nullptr, nullptr, nullptr, 0, 0,
+                                             P + LQ_POS, sc + S_LAT, C, ss);
+    // qkv0 = qkv(LN1(lat))                                             (implicit.py:30-36,102)
+    launch_linear<true, false, false, false>(s, batch, sc + S_LAT, C, ss, C, P + LQ_WQKV0,
+                                             P + LQ_BQKV0, 3 * C, P + LQ_LN1G0, P + LQ_LN1B0, nullptr,
+                                             0, 0, nullptr, sc + S_QKV0, 3 * C, ss);
+    hipLaunchKernelGGL(lat_self_attn_kernel, dim3(HEADS, batch), dim3(256), 0, s, sc + S_QKV0, ss,
+                       sc + S_ATT, ss);
+    // x1 = lat + proj(attn)                                            (implicit.py:74-76,106)
+    launch_linear<false, false, true, false>(s, batch, sc + S_ATT, C, ss, C, P + LQ_WPROJ0,
+                                             P + LQ_BPROJ0, C, nullptr, nullptr, sc + S_LAT, C, ss,
+                                             nullptr, sc + S_X1, C, ss);
+    // x2 = x1 + fc2(gelu(fc1(LN2(x1))))                                (implicit.py:107; timm Mlp)
+    launch_linear<true, true, false, false>(s, batch, sc + S_X1, C, ss, C, P + LQ_W1, P + LQ_B1, HID,
+                                            P + LQ_LN2G0, P + LQ_LN2B0, nullptr, 0, 0, nullptr,
+                                            sc + S_HID, HID, ss);
+    launch_linear<false, false, true, false>(s, batch, sc + S_HID, HID, ss, HID, P + LQ_W2, P + LQ_B2,
+                                             C, nullptr, nullptr, sc + S_X1, C, ss, nullptr,
+                                             sc + S_X2, C, ss);
+    // kv1 = (k,v rows of block 1's qkv)(LN1'(x2))                      (implicit.py:30-38,100)
+    launch_linear<true, false, false, false>(s, batch, sc + S_X2, C, ss, C, P + LQ_WKV1, P + LQ_BKV1,
+                                             2 * C, P + LQ_LN1G1, P + LQ_LN1B1, nullptr, 0, 0, nullptr,
+                                             sc + S_KV1, 2 * C, ss);
+    const int elems = BLOCKS * HEADS * LT * 2 * 16 * 64;
+    hipLaunchKernelGGL(pack_kv_kernel, dim3((elems + 255) / 256, batch), dim3(256), 0, s, sc, ss,
+                       static_cast<float *>(programs), program_stride_bytes / sizeof(float));
+    return zs::check_launch("zs_sdf_prologue") ? 1 : 0;
+}

@@ -1,0 +1,233 @@
+"""Mirror of the reference's model/shape/implicit.py::Implicit (:186-288) on the
+hand-written HIP decoder.
+
+Same constructor arguments, same ``state_dict`` keys and shapes (SURVEY.md section 8-b4:
+``pos_embed``, ``point_proj.proj``, ``latent_proj``, ``blocks_attn.{i}.{norm1,attn.qkv,
+attn.proj,norm2,mlp.fc1,mlp.fc2}``, ``norm``, ``impl_mlp.layers.{l}``), same call:
+
+    logits[B, M], attn[B, M, 197] = impl_network(latent_depth[B,197,C], None, points[B,M,3])
+
+The arithmetic runs in csrc/sdf_prologue.hip (per image, the point-independent latent
+half) + csrc/sdf_decoder.hip (per point, fused) through the C ABI of
+include/zeroshape_hip.h.  There is no PyTorch fallback: without the library, or for a
+configuration the kernels are not specialised for, this module raises.
+
+Not yet on the HIP path (raises / returns None, never silently approximated):
+  * autograd through the decoder (training, graph_shape.py:185) - inference only;
+  * the attention-visualisation output: ``attn`` is None unless requested, and
+    requesting it raises NotImplementedError in this round;
+  * ``semantic=True`` / ``posenc_3D>0`` / ``pos_perlayer=True`` variants (unused by
+    options/shape.yaml).
+"""
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import _lib
+from ... import program as P
+from ...utils.pos_embed import get_2d_sincos_pos_embed
+
+
+class _Mlp(nn.Module):
+    """Parameter container with timm 0.6.12 ``Mlp`` key names (fc1 / fc2)."""
+
+    def __init__(self, in_features, hidden_features):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc2 = nn.Linear(hidden_features, in_features)
+
+
+class _Attention(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim)
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, mlp_ratio, norm_layer):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = _Attention(dim)
+        self.norm2 = norm_layer(dim)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+
+
+class _Proj3D(nn.Module):
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.proj = nn.Linear(3, embed_dim)
+
+
+class _MLPBlocks(nn.Module):
+    def __init__(self, num_hidden_layers, n_channels, latent_dim, skip_in):
+        super().__init__()
+        dims = [3 + latent_dim] + [n_channels] * num_hidden_layers + [1]
+        self.layers = nn.ModuleList([
+            nn.Linear(dims[l] + (dims[0] if l in skip_in else 0), dims[l + 1])
+            for l in range(len(dims) - 1)])
+
+
+class DecoderState(object):
+    """Per-batch device state produced by Implicit.prepare(): one decoder program per
+    image (weights + that image's K/V records)."""
+
+    def __init__(self, programs, batch):
+        self.programs, self.batch = programs, batch
+
+    @property
+    def stride_bytes(self):
+        return self.programs.stride(0) * 4
+
+
+class Implicit(nn.Module):
+    """Implicit function conditioned on depth encodings (implicit.py:186-288)."""
+
+    def __init__(self, num_patches, latent_dim=768, semantic=False, n_channels=512,
+                 n_blocks_attn=2, n_layers_mlp=6, num_heads=16, posenc_3D=0,
+                 mlp_ratio=4., norm_layer=partial(nn.LayerNorm, eps=1e-6), drop_path=0.1,
+                 skip_in=[], pos_perlayer=True):
+        super().__init__()
+        self.num_patches = num_patches
+        self.pos_perlayer = pos_perlayer
+        self.semantic = semantic
+        self.num_heads = num_heads
+        self.skip_in = tuple(skip_in)
+        self.cfg = dict(num_patches=num_patches, latent_dim=latent_dim, n_channels=n_channels,
+                        n_blocks_attn=n_blocks_attn, n_layers_mlp=n_layers_mlp, num_heads=num_heads,
+                        posenc_3D=posenc_3D, mlp_ratio=float(mlp_ratio), skip_in=tuple(skip_in),
+                        pos_perlayer=bool(pos_perlayer), semantic=bool(semantic))
+        self.point_proj = _Proj3D(n_channels)
+        self.latent_proj = nn.Linear(latent_dim, n_channels, bias=True)
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, n_channels), requires_grad=False)
+        self.blocks_attn = nn.ModuleList([_Block(n_channels, mlp_ratio, norm_layer)
+                                          for _ in range(n_blocks_attn)])
+        self.norm = norm_layer(n_channels)
+        self.impl_mlp = _MLPBlocks(n_layers_mlp, n_channels, n_channels, self.skip_in) \
+            if n_layers_mlp > 0 else None
+        if self.impl_mlp is None:
+            self.pred_head = nn.Linear(n_channels, 1, bias=True)
+        self.initialize_weights()
+        self._packed = None       # (key, template programs tensor, lat_params tensor)
+
+    # ---- init (implicit.py:232-249) -------------------------------------------------
+    def initialize_weights(self):
+        pe = get_2d_sincos_pos_embed(self.pos_embed.shape[-1], int(self.num_patches ** .5), cls_token=True)
+        self.pos_embed.data.copy_(torch.from_numpy(pe).float().unsqueeze(0))
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            torch.nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    # ---- HIP path ---------------------------------------------------------------------
+    def _check_supported(self):
+        c = self.cfg
+        want = dict(num_patches=P.L - 1, n_channels=P.C, latent_dim=P.C, n_blocks_attn=P.BLOCKS,
+                    n_layers_mlp=P.MLP_LAYERS - 1, num_heads=P.HEADS, posenc_3D=0, mlp_ratio=4.0,
+                    skip_in=P.SKIP_IN, pos_perlayer=False, semantic=False)
+        bad = {k: (c[k], v) for k, v in want.items() if c[k] != v}
+        if bad:
+            raise NotImplementedError(
+                "the HIP decoder is specialised for options/shape.yaml:19-44; unsupported "
+                "(got, need): %s" % bad)
+
+    def _weights_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def packed(self, device):
+        """(template program [PROGRAM_FLOATS], lat_params) on ``device``; repacked when any
+        parameter changed (in-place update or re-assignment)."""
+        key = (str(device),) + self._weights_key()
+        if self._packed is None or self._packed[0] != key:
+            self._check_supported()
+            sd = {k: v.detach().float().cpu().numpy() for k, v in self.state_dict().items()}
+            prog = torch.from_numpy(P.pack_program(sd)).to(device)
+            lat = torch.from_numpy(P.pack_latent_params(sd)).to(device)
+            self._packed = (key, prog, lat)
+        return self._packed[1], self._packed[2]
+
+    @torch.no_grad()
+    def prepare(self, latent_depth):
+        """Per-image prologue: latent_depth [B,197,C] (any float dtype, GPU) -> DecoderState."""
+        if not latent_depth.is_cuda:
+            raise ValueError("latent_depth must be a GPU tensor; zeroshape_amd has no CPU path")
+        lib = _lib.load()
+        lat = latent_depth.detach().to(torch.float32).contiguous()
+        B = lat.shape[0]
+        if tuple(lat.shape[1:]) != (P.L, P.C):
+            raise ValueError("latent_depth must be [B,%d,%d], got %s" % (P.L, P.C, tuple(lat.shape)))
+        template, lat_params = self.packed(lat.device)
+        assert lib.zs_sdf_program_bytes() == P.PROGRAM_BYTES, "layout mismatch between program.py and the library"
+        programs = template.unsqueeze(0).repeat(B, 1)
+        scratch = torch.empty(B * (lib.zs_sdf_prologue_scratch_bytes() // 4), dtype=torch.float32,
+                              device=lat.device)
+        with torch.cuda.device(lat.device):
+            rc = lib.zs_sdf_prologue(_lib.ptr(programs), programs.stride(0) * 4, _lib.ptr(lat_params),
+                                     _lib.ptr(lat), B, _lib.ptr(scratch),
+                                     _lib.current_stream_ptr(lat.device))
+        _lib.check(rc, "zs_sdf_prologue")
+        return DecoderState(programs, B)
+
+    @torch.no_grad()
+    def query_points(self, state, points_3D):
+        """state from prepare(); points_3D [B,M,3] -> logits [B,M] fp32."""
+        lib = _lib.load()
+        pts = points_3D.detach().to(torch.float32).contiguous()
+        if pts.dim() != 3 or pts.shape[2] != 3 or pts.shape[0] != state.batch:
+            raise ValueError("points_3D must be [%d,M,3], got %s" % (state.batch, tuple(pts.shape)))
+        if pts.device != state.programs.device:
+            raise ValueError("points_3D and latent_depth live on different devices")
+        M = pts.shape[1]
+        out = torch.empty(state.batch, M, dtype=torch.float32, device=pts.device)
+        with torch.cuda.device(pts.device):
+            rc = lib.zs_sdf_query_points(_lib.ptr(state.programs), state.stride_bytes, state.batch,
+                                         _lib.ptr(pts), M, _lib.ptr(out), None,
+                                         _lib.current_stream_ptr(pts.device))
+        _lib.check(rc, "zs_sdf_query_points")
+        return out
+
+    @torch.no_grad()
+    def query_grid(self, latent_depth, axis, apply_sigmoid=True, slice_begin=0, slice_end=None,
+                   state=None):
+        """Dense-grid query (get_dense_3D_grid + compute_level_grid, utils/eval_3D.py:11-46)
+        without a points tensor: ``axis`` = torch.linspace(range_min, range_max, G) on the GPU.
+        Returns [B, slice_end - slice_begin, G, G] (x slowest, z fastest)."""
+        lib = _lib.load()
+        if state is None:
+            state = self.prepare(latent_depth)
+        axis = axis.detach().to(torch.float32).contiguous()
+        if axis.device != state.programs.device:
+            raise ValueError("axis and latent_depth live on different devices")
+        G = axis.numel()
+        slice_end = G if slice_end is None else slice_end
+        out = torch.empty(state.batch, slice_end - slice_begin, G, G, dtype=torch.float32,
+                          device=axis.device)
+        with torch.cuda.device(axis.device):
+            rc = lib.zs_sdf_query_grid(_lib.ptr(state.programs), state.stride_bytes, state.batch,
+                                       _lib.ptr(axis), G, slice_begin, slice_end,
+                                       1 if apply_sigmoid else 0, _lib.ptr(out),
+                                       _lib.current_stream_ptr(axis.device))
+        _lib.check(rc, "zs_sdf_query_grid")
+        return out
+
+    def forward(self, latent_depth, latent_semantic, points_3D, need_attn=False):
+        """implicit.py:251-288.  Returns (logits [B,M], attn | None)."""
+        if self.semantic or latent_semantic is not None:
+            raise NotImplementedError("semantic latent codes are not used by options/shape.yaml")
+        if torch.is_grad_enabled() and (points_3D.requires_grad or latent_depth.requires_grad
+                                        or any(p.requires_grad for p in self.parameters())) \
+                and self.training:
+            raise NotImplementedError("autograd through the HIP decoder is not implemented yet "
+                                      "(inference only); call under torch.no_grad() / .eval()")
+        if need_attn:
+            raise NotImplementedError("attention visualisation output is not on the HIP path yet")
+        state = self.prepare(latent_depth)
+        return self.query_points(state, points_3D), None

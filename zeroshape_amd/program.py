@@ -117,7 +117,9 @@ G_IMPL_PLAIN = NT * NT * 4       # 256
 G_IMPL_SKIP = 2 * G_IMPL_PLAIN   # 512
 G_IMPL = G_IMPL_PLAIN * 5 + G_IMPL_SKIP * 3     # layers 0,1,3,5,7 plain; 2,4,6 skip
 G_TOTAL = BLOCKS * G_BLOCK + G_IMPL             # 9856 groups = 39424 MFMAs per 32 points
-PROGRAM_FLOATS = (G_TOTAL + RING) * GROUP_FLOATS
+REC_FLOATS = (G_TOTAL + RING) * GROUP_FLOATS     # record stream incl. prefetch tail padding
+PARAM_FLOATS = 13824                             # params section (13584 used), multiple of 256
+PROGRAM_FLOATS = REC_FLOATS + PARAM_FLOATS       # one per-image program: [records | params]
 PROGRAM_BYTES = PROGRAM_FLOATS * 4
 
 
@@ -164,7 +166,9 @@ def pack_records(sd, kv=None):
     recs = np.concatenate(out, axis=0)
     assert recs.shape == (G_TOTAL * 4, 64), recs.shape
     flat = _interleave(recs)
-    return np.concatenate([flat, np.zeros(RING * GROUP_FLOATS, np.float32)])
+    out = np.concatenate([flat, np.zeros(RING * GROUP_FLOATS, np.float32)])
+    assert out.size == REC_FLOATS
+    return out
 
 
 # ----------------------------------------------------------------------------- #
@@ -223,12 +227,13 @@ class ParamLayout(object):
 
 
 PARAMS = ParamLayout()
+assert PARAMS.total <= PARAM_FLOATS
 BLOCK_PARAM_FLOATS = 3 * C + HEADS * 96 + 3 * C + HID
 
 
 def pack_params(sd):
     g = lambda k: np.asarray(sd[k], np.float32)
-    out = np.zeros(PARAMS.total, np.float32)
+    out = np.zeros(PARAM_FLOATS, np.float32)
 
     def put(off, arr):
         out[off:off + arr.size] = arr
@@ -261,6 +266,13 @@ def pack_params(sd):
             put(PARAMS.impl[l], rowparam(b))
     put(PARAMS.w8, rowparam(g("impl_mlp.layers.8.weight")[0]))
     out[PARAMS.b8] = g("impl_mlp.layers.8.bias")[0]
+    return out
+
+
+def pack_program(sd, kv=None):
+    """One decoder program: [record stream | params] (PROGRAM_FLOATS fp32)."""
+    out = np.concatenate([pack_records(sd, kv), pack_params(sd)])
+    assert out.size == PROGRAM_FLOATS
     return out
 
 
