@@ -43,10 +43,16 @@ def test_prologue_kv_records_match_oracle(net, seeded_sd):
         kv = {(blk, h): (lp["k%d" % blk][b, h].numpy(), lp["v%d" % blk][b, h].numpy())
               for blk in range(2) for h in range(8)}
         want = P.pack_program(sd_np, kv)
-        # weights / params sections are copied verbatim; K/V records are computed on the device
+        # K/V records are computed on the device (fp32, different summation order than the
+        # oracle's GEMMs); everything else is the packed weights, copied verbatim
         np.testing.assert_allclose(got[b], want, atol=3e-6, rtol=0)
-        same = got[b] == want
-        assert same.mean() > 0.95
+        is_kv = np.zeros(want.size, bool)
+        for blk in range(2):
+            for h in range(8):
+                o = P.kv_group_offset(blk, h) * P.GROUP_FLOATS
+                is_kv[o:o + P.G_KV_HEAD * P.GROUP_FLOATS] = True
+        np.testing.assert_array_equal(got[b][~is_kv], want[~is_kv])
+        assert np.abs(want[is_kv]).max() > 0.1      # the K/V section is really populated
 
 
 def test_training_shape_points_vs_golden(net, decoder_golden):
