@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 1
+#define ZS_ABI_VERSION 2
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -76,13 +76,18 @@ int zs_chamfer_backward(const float *xyz1, const float *xyz2, int b, int n, int 
  *                                          (latent_proj + pos_embed, block-0 latent
  *                                          self-attention + MLP, K/V of both blocks)
  *                                          written into the program's K/V records
- *   zs_sdf_query_points / _grid            per query point: the fused decoder
+ *   zs_sdf_query_points / _grid            per query point: the fused decoder; `workspace`
+ *                                          (zs_sdf_workspace_bytes(), 16-byte aligned) may be
+ *                                          shared by launches on the same stream
  * ------------------------------------------------------------------------- */
 
 /* Bytes of one per-image decoder program (weights in MFMA operand order + K/V). */
 size_t zs_sdf_program_bytes(void);
 /* Bytes of the per-image scratch the prologue needs. */
 size_t zs_sdf_prologue_scratch_bytes(void);
+/* Bytes of the workspace the query kernels need (independent of batch and point count:
+ * one 96 KiB slab per resident wave, 96 MiB in all; contents are scratch). */
+size_t zs_sdf_workspace_bytes(void);
 
 /* Fill the per-image K/V records of `programs[i]` (i < batch; programs are
  * program_stride_bytes apart, each initialised by copying the packed weights)
@@ -95,7 +100,8 @@ int zs_sdf_prologue(void *programs, size_t program_stride_bytes, const float *la
  * attn (optional, may be NULL): [batch][m][197] = mean over heads and blocks of the
  * point->latent attention probabilities (implicit.py:63,79,277). */
 int zs_sdf_query_points(const void *programs, size_t program_stride_bytes, int batch,
-                        const float *points, int m, float *logits, float *attn, void *stream);
+                        const float *points, int m, float *logits, float *attn,
+                        void *workspace, void *stream);
 
 /* Dense-grid query without materialising the points tensor.  Evaluates x-slices
  * [slice_begin, slice_end) of the G^3 grid (G = vox_res+1 samples per axis; coordinate
@@ -106,7 +112,7 @@ int zs_sdf_query_points(const void *programs, size_t program_stride_bytes, int b
  * return), else the logit. */
 int zs_sdf_query_grid(const void *programs, size_t program_stride_bytes, int batch,
                       const float *axis, int G, int slice_begin, int slice_end,
-                      int apply_sigmoid, float *out, void *stream);
+                      int apply_sigmoid, float *out, void *workspace, void *stream);
 
 #ifdef __cplusplus
 }

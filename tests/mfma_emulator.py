@@ -146,26 +146,29 @@ def decode_wave(recs_flat, params, xyz):
         x = y
     feat = layer_norm(x, params, L.lnf_g, L.lnf_b)
     sq2 = math.sqrt(2.0)
-    # impl_mlp layer 0
+    # impl_mlp layer 0 (output parked in the LDS slab on the device)
     cur = []
     for nt in range(8):
         acc = xyz_affine(L.impl[0], nt, px, py, pz)
         cur.append(softplus100(gemm_tile(st, feat, acc)))
     feat_s = [t / sq2 for t in feat]
     sx, sy, sz = px / sq2, py / sq2, pz / sq2
+    # feat halves of the skip layers (workspace "Z" tiles on the device)
+    Z = {}
+    for l in P.SKIP_IN:
+        Z[l] = [gemm_tile(st, feat_s, np.zeros((16, 64))) for nt in range(8)]
     for l in range(1, P.MLP_LAYERS - 1):
         nxt = []
         if l in P.SKIP_IN:
-            xs = [t / sq2 for t in cur]
             for nt in range(8):
                 acc = xyz_affine(L.impl[l], nt, sx, sy, sz)
-                gemm_tile(st, xs, acc)
-                gemm_tile(st, feat_s, acc)
-                nxt.append(softplus100(acc))
+                gemm_tile(st, cur, acc)          # cur already holds x / sqrt(2)
+                nxt.append(softplus100(acc + Z[l][nt]))
         else:
+            post = sq2 if (l + 1) in P.SKIP_IN else 1.0
             for nt in range(8):
                 acc = rp(params, L.impl[l], nt).copy()
-                nxt.append(softplus100(gemm_tile(st, cur, acc)))
+                nxt.append(softplus100(gemm_tile(st, cur, acc)) / post)
         cur = nxt
     out = sum((cur[kt] * rp(params, L.w8, kt)).sum(axis=0) for kt in range(8))
     out = out + partner(out) + params[L.b8]

@@ -3,14 +3,20 @@
 // point-independent latent half hoisted into the prologue (csrc/sdf_prologue.hip).
 //
 // Mapping to the hardware (zeroshape_amd/program.py):
-//  * a wave owns 32 query points for the whole network; a workgroup is 4 waves
-//    (one per SIMD, 1 workgroup per CU: the kernel uses the full 512-register file);
-//  * every activation lives in registers in the v_mfma_f32_32x32x2_f32 accumulator
-//    layout and each layer is computed transposed (Y^T = W X^T), so a layer's output
-//    registers ARE the next layer's B operands: no LDS traffic, no transposes;
-//  * weights arrive as one linear stream of pre-packed A operands ("records",
-//    4 per 16-byte load), prefetched 8 loads (32 MFMAs) ahead through a register ring;
-//  * biases / LayerNorm affine / xyz columns sit in LDS (54 KiB, loaded once);
+//  * persistent workgroups (one per CU, 4 waves = one per SIMD); a wave owns 32 query
+//    points for the whole network;
+//  * every layer is computed transposed (Y^T = W X^T) with v_mfma_f32_32x32x2_f32, so the
+//    accumulator layout of one layer IS the B-operand layout of the next: no transposes;
+//  * register budget (the 512-entry file could hold everything, but hipcc spilled 3.7 GB
+//    per launch to scratch in the first version, profiles/r01_v0_*): accumulators and ONE
+//    activation array live in registers, the other activation array of a layer pair lives
+//    in the wave's private 32 KiB LDS slab (read back as B operands with conflict-free
+//    ds_read_b128), and the feat halves of the three skip layers are computed right after
+//    the final LayerNorm and parked in a per-wave global workspace (L2-resident);
+//  * weights arrive as one linear stream of pre-packed A operands ("records", 4 per
+//    16-byte load), prefetched 8 loads (32 MFMAs) ahead through a register ring of
+//    inline-asm loads with hand-counted s_waitcnt;
+//  * biases / LayerNorm affine / xyz columns sit in LDS (32 KiB, two phases);
 //  * exact-fp32 MFMA (bitwise an fmaf chain) - parity mode; 39,424 MFMAs per wave tile
 //    = 5.05 MFLOP per point including the 224-vs-197 latent padding.
 //
@@ -22,6 +28,7 @@
 #include "../../include/zeroshape_hip.h"
 
 #include <math.h>
+#include <stdint.h>
 
 namespace {
 
@@ -33,45 +40,132 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int WAVES = 4;
 constexpr int PTS_PER_WAVE = 32;
 constexpr int PTS_PER_BLOCK = WAVES * PTS_PER_WAVE;
+constexpr int MAX_WGS = 256;                       // one persistent workgroup per CU
+constexpr int SLAB_F4 = NT * 4 * 64;               // one activation array as float4 groups: 32 KiB
+constexpr int ZSLAB_F4 = 3 * SLAB_F4;              // three skip layers' feat partial products
+constexpr size_t WORKSPACE_BYTES = (size_t)MAX_WGS * WAVES * ZSLAB_F4 * sizeof(f32x4);
 
 #define DEV __device__ __forceinline__
-// Bounds the machine scheduler's window: without it hipcc interleaves neighbouring output
-// tiles / layers of the fully unrolled code and the live ranges overflow the register file.
-#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+DEV const f32x4 *uniform_ptr(const f32x4 *p) {  // make wave-uniformity provable ("s" operands)
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const f32x4 *>(((uint64_t)hi << 32) | lo);
+}
 
 // ---- weight stream: register ring, 8 x 16-byte loads in flight per lane ------------- //
-struct AStream {
-    const f32x4 *__restrict__ base;  // wave-uniform: group (consumed + RING)
-    int lane;
-    f32x4 ring[RING];
+// Left to itself hipcc sinks each global_load next to its first use (vmcnt(1) pattern, one
+// load in flight), which exposed the L2 latency on every group - 32 % of all wave cycles
+// parked in s_waitcnt in the first profile (profiles/r01_v0_*).  The ring is therefore
+// inline asm with hand-counted waits, and - because hipcc may copy, split or spill any
+// asm OUTPUT register while its load is still in flight (it did: v_mov copies of in-flight
+// ring registers at loop back-edges and exits) - the ring lives in 32 fixed registers the
+// compiler cannot see: amdgpu_num_vgpr(240) caps BOTH halves of the unified file at 240
+// (on gfx90a+ with AGPR-using asm the budget is split evenly), so v[240:255] and a[240:255]
+// are never allocated; the asm statements name them literally and list them as clobbers
+// (which also makes the kernel descriptor allocate all 512), and global loads may write
+// AGPRs directly.  Landed data is copied out with v_mov / v_accvgpr_read into ordinary
+// compiler-owned values (4 VALU per 4 MFMAs, hidden under the MFMAs).
+//
+// Protocol: ONE queue position per 16-byte load, consumed in issue order.  At position p
+// the wave waits vmcnt(RING-1) (the 7 younger loads stay in flight; loads return in
+// order, and any extra compiler VMEM op only makes the wait more conservative), copies
+// slot p % 8 out and re-issues that slot for position p + 8 in the same asm statement.
+// Most positions are weight groups; in the skip layers 4 positions per output tile fetch
+// the tile's parked feat partial product from the workspace instead.
+// tools/check_asm_ring.py audits the .s: no compiler instruction may mention v240..v255
+// or a240..a255.
+// slots 0-3 live in v[240:255], slots 4-7 in a[240:255]
+#define ZS_TAKE_ISSUE_V(A, B, C, D, SUFFIX)                                                          \
+    asm volatile("s_waitcnt vmcnt(7)\n\tv_mov_b32 %0, v" #A "\n\tv_mov_b32 %1, v" #B               \
+                 "\n\tv_mov_b32 %2, v" #C "\n\tv_mov_b32 %3, v" #D                                 \
+                 "\n\tglobal_load_dwordx4 v[" #A ":" #D "], %4, %5" SUFFIX "\n\ts_nop 1"             \
+                 : "=&v"(o.x), "=&v"(o.y), "=&v"(o.z), "=&v"(o.w)                                    \
+                 : "v"(voff), "s"(src)                                                               \
+                 : "v" #A, "v" #B, "v" #C, "v" #D)
+#define ZS_TAKE_ISSUE_A(A, B, C, D, SUFFIX)                                                          \
+    asm volatile("s_waitcnt vmcnt(7)\n\tv_accvgpr_read_b32 %0, a" #A "\n\tv_accvgpr_read_b32 %1, a" #B \
+                 "\n\tv_accvgpr_read_b32 %2, a" #C "\n\tv_accvgpr_read_b32 %3, a" #D                 \
+                 "\n\tglobal_load_dwordx4 a[" #A ":" #D "], %4, %5" SUFFIX "\n\ts_nop 1"             \
+                 : "=&v"(o.x), "=&v"(o.y), "=&v"(o.z), "=&v"(o.w)                                    \
+                 : "v"(voff), "s"(src)                                                               \
+                 : "a" #A, "a" #B, "a" #C, "a" #D)
+#define ZS_ISSUE_V(A, B, C, D)                                                                       \
+    asm volatile("global_load_dwordx4 v[" #A ":" #D "], %0, %1" : : "v"(voff), "s"(src)              \
+                 : "v" #A, "v" #B, "v" #C, "v" #D)
+#define ZS_ISSUE_A(A, B, C, D)                                                                       \
+    asm volatile("global_load_dwordx4 a[" #A ":" #D "], %0, %1" : : "v"(voff), "s"(src)              \
+                 : "a" #A, "a" #B, "a" #C, "a" #D)
 
-    DEV void init(const f32x4 *b, int ln) {
-        lane = ln;
-#pragma unroll
-        for (int i = 0; i < RING; i++) ring[i] = b[i * 64 + ln];
-        base = b + RING * 64;
+struct Stream {
+    const f32x4 *abase;  // wave-uniform (SGPR pair): next weight group to fetch
+    unsigned voff;       // lane * 16 bytes
+
+    // wait for slot, copy it out, re-issue it from `src` (plain: weights; sc1: workspace)
+    DEV f32x4 take_issue(int slot, const f32x4 *src, bool sc1) {
+        f32x4 o;
+        if (!sc1) {
+            switch (slot) {
+                case 0: ZS_TAKE_ISSUE_V(240, 241, 242, 243, ""); break;
+                case 1: ZS_TAKE_ISSUE_V(244, 245, 246, 247, ""); break;
+                case 2: ZS_TAKE_ISSUE_V(248, 249, 250, 251, ""); break;
+                case 3: ZS_TAKE_ISSUE_V(252, 253, 254, 255, ""); break;
+                case 4: ZS_TAKE_ISSUE_A(240, 241, 242, 243, ""); break;
+                case 5: ZS_TAKE_ISSUE_A(244, 245, 246, 247, ""); break;
+                case 6: ZS_TAKE_ISSUE_A(248, 249, 250, 251, ""); break;
+                default: ZS_TAKE_ISSUE_A(252, 253, 254, 255, ""); break;
+            }
+        } else {  // served by L2: this wave wrote the workspace earlier in the launch
+            switch (slot) {
+                case 0: ZS_TAKE_ISSUE_V(240, 241, 242, 243, " sc1"); break;
+                case 1: ZS_TAKE_ISSUE_V(244, 245, 246, 247, " sc1"); break;
+                case 2: ZS_TAKE_ISSUE_V(248, 249, 250, 251, " sc1"); break;
+                case 3: ZS_TAKE_ISSUE_V(252, 253, 254, 255, " sc1"); break;
+                case 4: ZS_TAKE_ISSUE_A(240, 241, 242, 243, " sc1"); break;
+                case 5: ZS_TAKE_ISSUE_A(244, 245, 246, 247, " sc1"); break;
+                case 6: ZS_TAKE_ISSUE_A(248, 249, 250, 251, " sc1"); break;
+                default: ZS_TAKE_ISSUE_A(252, 253, 254, 255, " sc1"); break;
+            }
+        }
+        return o;
     }
-    DEV f32x4 next(int slot) {  // slot is a compile-time constant after unrolling
-        f32x4 a = ring[slot];
-        ring[slot] = base[lane];
-        base += 64;
+    DEV f32x4 next(int slot) {  // weight position whose slot is re-used by a weight position
+        const f32x4 a = take_issue(slot, abase, false);
+        abase += 64;
         return a;
     }
+    DEV f32x4 next_then_z(int slot, const f32x4 *zsrc) {  // ... re-used by a workspace position
+        return take_issue(slot, zsrc, true);
+    }
+    DEV void init(const f32x4 *b, int ln) {
+        voff = ln * 16;
+        const f32x4 *src = b;
+        ZS_ISSUE_V(240, 241, 242, 243); src += 64;
+        ZS_ISSUE_V(244, 245, 246, 247); src += 64;
+        ZS_ISSUE_V(248, 249, 250, 251); src += 64;
+        ZS_ISSUE_V(252, 253, 254, 255); src += 64;
+        ZS_ISSUE_A(240, 241, 242, 243); src += 64;
+        ZS_ISSUE_A(244, 245, 246, 247); src += 64;
+        ZS_ISSUE_A(248, 249, 250, 251); src += 64;
+        ZS_ISSUE_A(252, 253, 254, 255); src += 64;
+        abase = src;
+    }
+    // retire the 8 loads still in flight past the end of the stream (padding groups)
+    DEV void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
 
 DEV f32x16 mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// acc += W_tile * X.  X = KT activation tiles as 16*KT scalars (register r of tile kt is
-// X[16*kt + r]); consumes KT*4 groups starting at ring slot `phase` (kt-major, then
-// register) - the order program.py packs them in.  `phase` (0 or 4) must be a
-// compile-time constant at every call site after unrolling.
-// Activations are deliberately plain scalars, not f32x16 tuples: only accumulators need
-// 16-register tuples, and scalars let the allocator place each B operand in either half
-// of the unified register file.
+// acc += W_tile * X.  X = KT activation tiles as 16*KT scalars in registers (register r of
+// tile kt is X[16*kt + r]); consumes KT*4 groups starting at ring slot `phase` (kt-major,
+// then register) - the order program.py packs them in.  `phase` (0 or 4) and every index
+// are compile-time constants after unrolling.  Register-resident activations are plain
+// scalars, not f32x16 tuples: only accumulators need 16-register tuples.
 template <int KT>
-DEV void gemm_tile(AStream &s, const float *X, f32x16 &acc, int phase) {
+DEV void gemm_tile(Stream &s, const float *X, f32x16 &acc, int phase) {
 #pragma unroll
     for (int kt = 0; kt < KT; kt++) {
 #pragma unroll
@@ -86,7 +180,7 @@ DEV void gemm_tile(AStream &s, const float *X, f32x16 &acc, int phase) {
 }
 
 // one-tile variant whose B operand is an accumulator tuple (q, P, o, hidden)
-DEV void gemm_tile_v(AStream &s, const f32x16 &X, f32x16 &acc, int phase) {
+DEV void gemm_tile_v(Stream &s, const f32x16 &X, f32x16 &acc, int phase) {
 #pragma unroll
     for (int g = 0; g < 4; g++) {
         const f32x4 a = s.next((phase + g) & (RING - 1));
@@ -97,9 +191,9 @@ DEV void gemm_tile_v(AStream &s, const f32x16 &X, f32x16 &acc, int phase) {
     }
 }
 
-// same as gemm_tile<NT>, with the B operands (feat / sqrt(2)) read back from the wave's
-// LDS slab ([kt][g][lane] float4: lane-contiguous -> conflict-free ds_read_b128)
-DEV void gemm_tile_lds(AStream &s, const f32x4 *fl, f32x16 &acc, int phase) {
+// 8-tile variant with the B operands read from the wave's LDS slab
+// ([kt][g][lane] float4: lane-contiguous -> conflict-free ds_read_b128)
+DEV void gemm_tile_lds(Stream &s, const f32x4 *fl, f32x16 &acc, int phase) {
 #pragma unroll
     for (int kt = 0; kt < NT; kt++) {
 #pragma unroll
@@ -110,6 +204,30 @@ DEV void gemm_tile_lds(AStream &s, const f32x4 *fl, f32x16 &acc, int phase) {
             acc = mfma(a.y, b.y, acc);
             acc = mfma(a.z, b.z, acc);
             acc = mfma(a.w, b.w, acc);
+        }
+    }
+}
+
+// one output tile of a skip layer: 32 weight positions (B = x / sqrt(2) in registers), then
+// 4 workspace positions that add the tile's parked feat partial product.  36 positions:
+// `phase` alternates 0 / 4 from tile to tile.
+DEV void skip_tile(Stream &s, const float *X, f32x16 &acc, const f32x4 *ztile, int phase) {
+#pragma unroll
+    for (int q = 0; q < 36; q++) {
+        const int slot = (phase + q) & (RING - 1);
+        // positions 24..27 re-issue their slots for positions 32..35 = the workspace tile
+        const f32x4 a = (q >= 24 && q < 28) ? s.next_then_z(slot, ztile + (q - 24) * 64) : s.next(slot);
+        if (q < 32) {
+            acc = mfma(a.x, X[4 * q + 0], acc);
+            acc = mfma(a.y, X[4 * q + 1], acc);
+            acc = mfma(a.z, X[4 * q + 2], acc);
+            acc = mfma(a.w, X[4 * q + 3], acc);
+        } else {
+            const int j = q - 32;
+            acc[4 * j + 0] += a.x;
+            acc[4 * j + 1] += a.y;
+            acc[4 * j + 2] += a.z;
+            acc[4 * j + 3] += a.w;
         }
     }
 }
@@ -167,7 +285,28 @@ DEV void ln_stats(const f32x16 *x, float &mean, float &rstd) {
     v += xhalf(v);
     rstd = 1.0f / sqrtf(v * (1.0f / 256.0f) + 1e-6f);
 }
-DEV void layer_norm(const f32x16 *x, float *h, const float *prm, int g_off, int b_off, int hi) {
+// LayerNorm -> the wave's LDS slab (B operands of the following GEMMs)
+DEV void layer_norm_lds(const f32x16 *x, f32x4 *fl, const float *prm, int g_off, int b_off, int hi) {
+    float mean, rstd;
+    ln_stats(x, mean, rstd);
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++) {
+        float g[16], b[16];
+        rp(prm, g_off, kt, hi, g);
+        rp(prm, b_off, kt, hi, b);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            f32x4 t;
+            t.x = fmaf((x[kt][4 * j + 0] - mean) * rstd, g[4 * j + 0], b[4 * j + 0]);
+            t.y = fmaf((x[kt][4 * j + 1] - mean) * rstd, g[4 * j + 1], b[4 * j + 1]);
+            t.z = fmaf((x[kt][4 * j + 2] - mean) * rstd, g[4 * j + 2], b[4 * j + 2]);
+            t.w = fmaf((x[kt][4 * j + 3] - mean) * rstd, g[4 * j + 3], b[4 * j + 3]);
+            fl[(kt * 4 + j) * 64] = t;
+        }
+    }
+}
+// LayerNorm -> registers
+DEV void layer_norm_reg(const f32x16 *x, float *h, const float *prm, int g_off, int b_off, int hi) {
     float mean, rstd;
     ln_stats(x, mean, rstd);
 #pragma unroll
@@ -221,13 +360,23 @@ DEV float softplus100(float x) {
     return z > 20.0f ? x : r;
 }
 
+DEV void store_tile_lds(f32x4 *fl, int tile, const float *v) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        f32x4 t;
+        t.x = v[4 * j + 0]; t.y = v[4 * j + 1]; t.z = v[4 * j + 2]; t.w = v[4 * j + 3];
+        fl[(tile * 4 + j) * 64] = t;
+    }
+}
+
 // One wave: 32 points (lane & 31; both lane halves carry the same point).
 // `prm`: LDS params region (phase A: program params [0, P_PHASE_B); phase B: the rest);
-// `fl`: this wave's LDS slab for feat / sqrt(2), already offset by lane.
-DEV float decode_tile(const f32x4 *__restrict__ recs, const float *__restrict__ prog_params,
-                      float *prm, f32x4 *fl, float px, float py, float pz, int lane) {
+// `fl`: this wave's LDS slab, `zs`: this wave's workspace slab - both already offset by lane
+// except `zs_u`, the same workspace slab as a wave-uniform pointer for the asm loads.
+DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, float *prm, f32x4 *fl,
+                      f32x4 *zs, const f32x4 *zs_u, float px, float py, float pz, int lane) {
     const int hi = lane >> 5;
-    AStream s;
+    Stream s;
     s.init(recs, lane);
 
     // point_proj (implicit.py:128-131); y is the residual stream, kept as accumulators
@@ -236,12 +385,11 @@ DEV float decode_tile(const f32x4 *__restrict__ recs, const float *__restrict__ 
     for (int kt = 0; kt < NT; kt++) y[kt] = xyz_affine(prm, P_PP, kt, hi, px, py, pz);
 
     const float scale = 0.17677669529663688110f;  // 32 ** -0.5
-    float h[NT * 16];
 
 #pragma unroll 1
     for (int blk = 0; blk < BLOCKS; blk++) {
         const int pb = P_BLK0 + blk * P_BLK_STRIDE;
-        layer_norm(y, h, prm, pb + PB_LN1G, pb + PB_LN1B, hi);
+        layer_norm_lds(y, fl, prm, pb + PB_LN1G, pb + PB_LN1B, hi);
         // y = x + proj_bias + sum_heads Wproj_h o_h
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) y[nt] += rp16(prm, pb + PB_BPROJ, nt, hi);
@@ -249,11 +397,11 @@ DEV float decode_tile(const f32x4 *__restrict__ recs, const float *__restrict__ 
 #pragma unroll 1
         for (int hd = 0; hd < HEADS; hd++) {
             f32x16 q = rp16(prm, pb + PB_BQKV, hd * 3 + 0, hi);
-            gemm_tile<NT>(s, h, q, 0);
+            gemm_tile_lds(s, fl, q, 0);
             f32x16 k = rp16(prm, pb + PB_BQKV, hd * 3 + 1, hi);
-            gemm_tile<NT>(s, h, k, 0);
+            gemm_tile_lds(s, fl, k, 0);
             f32x16 v = rp16(prm, pb + PB_BQKV, hd * 3 + 2, hi);
-            gemm_tile<NT>(s, h, v, 0);
+            gemm_tile_lds(s, fl, v, 0);
 
             // self logit (implicit.py:44)
             float s_self = 0.f;
@@ -312,13 +460,13 @@ DEV float decode_tile(const f32x4 *__restrict__ recs, const float *__restrict__ 
         }
 
         // MLP (timm Mlp): y += b2 + W2 gelu(W1 LN2(y) + b1), one hidden tile at a time
-        layer_norm(y, h, prm, pb + PB_LN2G, pb + PB_LN2B, hi);
+        layer_norm_lds(y, fl, prm, pb + PB_LN2G, pb + PB_LN2B, hi);
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) y[nt] += rp16(prm, pb + PB_B2, nt, hi);
 #pragma unroll 1
         for (int ht = 0; ht < HT; ht++) {
             f32x16 hid = rp16(prm, pb + PB_B1, ht, hi);
-            gemm_tile<NT>(s, h, hid, 0);
+            gemm_tile_lds(s, fl, hid, 0);
 #pragma unroll
             for (int r = 0; r < 16; r++) hid[r] = gelu_erf(hid[r]);
 #pragma unroll
@@ -326,8 +474,9 @@ DEV float decode_tile(const f32x4 *__restrict__ recs, const float *__restrict__ 
         }
     }
 
-    // final norm (implicit.py:275) -> h
-    layer_norm(y, h, prm, P_LNFG, P_LNFB, hi);
+    // final norm (implicit.py:275) -> feat, in registers
+    float h[NT * 16];
+    layer_norm_reg(y, h, prm, P_LNFG, P_LNFB, hi);
 
     // phase B params (impl_mlp) replace the phase A ones in LDS
     __syncthreads();
@@ -338,60 +487,75 @@ DEV float decode_tile(const f32x4 *__restrict__ recs, const float *__restrict__ 
     }
     __syncthreads();
 
-    // impl_mlp (implicit.py:168-184): inputs = cat[xyz, feat]; feat = h
-    float cur[NT * 16];
+    // impl_mlp (implicit.py:168-184): inputs = cat[xyz, feat].  Layer 0: feat (regs) -> LDS
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
         f32x16 acc = xyz_affine(prm, P_IMPL0 - P_PHASE_B, nt, hi, px, py, pz);
         gemm_tile<NT>(s, h, acc, 0);
+        float t[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) cur[nt * 16 + r] = softplus100(acc[r]);
+        for (int r = 0; r < 16; r++) t[r] = softplus100(acc[r]);
+        store_tile_lds(fl, nt, t);
     }
-    // the skip layers consume inputs / sqrt(2); park feat / sqrt(2) in LDS (frees 128 registers)
+    // the skip layers consume cat[x, xyz, feat] / sqrt(2): their feat halves are computed now,
+    // while feat is in registers, and parked in the workspace (Z tiles)
     const float sqrt2 = 1.41421356237309504880f;
 #pragma unroll
-    for (int kt = 0; kt < NT; kt++)
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            f32x4 t;
-            t.x = h[kt * 16 + 4 * g + 0] / sqrt2;
-            t.y = h[kt * 16 + 4 * g + 1] / sqrt2;
-            t.z = h[kt * 16 + 4 * g + 2] / sqrt2;
-            t.w = h[kt * 16 + 4 * g + 3] / sqrt2;
-            fl[(kt * 4 + g) * 64] = t;
-        }
+    for (int i = 0; i < NT * 16; i++) h[i] = h[i] / sqrt2;
     const float sx = px / sqrt2, sy = py / sqrt2, sz = pz / sqrt2;
+#pragma unroll 1
+    for (int li = 0; li < 3; li++) {
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+            gemm_tile<NT>(s, h, acc, 0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                f32x4 t;
+                t.x = acc[4 * j + 0]; t.y = acc[4 * j + 1]; t.z = acc[4 * j + 2]; t.w = acc[4 * j + 3];
+                zs[(li * SLAB_F4) + (nt * 4 + j) * 64] = t;
+            }
+        }
+    }
+    // the Z stores must have reached L2 before the sc1 read-backs (>= 256 groups later; this
+    // drain is a formality that costs one ring refill per tile)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // layer 1 (plain): cur -> h, pre-divided by sqrt(2) because layer 2 is a skip layer
+    // layer 1 (plain): LDS -> registers, pre-divided by sqrt(2) because layer 2 is a skip layer
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
         f32x16 acc = rp16(prm, P_IMPL1 - P_PHASE_B, nt, hi);
-        gemm_tile<NT>(s, cur, acc, 0);
+        gemm_tile_lds(s, fl, acc, 0);
 #pragma unroll
         for (int r = 0; r < 16; r++) h[nt * 16 + r] = softplus100(acc[r]) / sqrt2;
     }
 #pragma unroll 1
     for (int i = 0; i < 3; i++) {
         const int pp = P_IMPL_PAIR - P_PHASE_B + i * P_IMPL_PAIR_STRIDE;
-        // skip layer 2+2i: cat[x, xyz, feat] / sqrt(2) (h already holds x / sqrt(2)) -> cur
+        const f32x4 *zl = zs_u + i * SLAB_F4;
+        // skip layer 2+2i: registers (x / sqrt(2)) + parked feat half -> LDS
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
             f32x16 acc = xyz_affine(prm, pp, nt, hi, sx, sy, sz);
-            gemm_tile<NT>(s, h, acc, 0);
-            gemm_tile_lds(s, fl, acc, 0);
+            skip_tile(s, h, acc, zl + nt * 256, (nt & 1) * 4);
+            float t[16];
 #pragma unroll
-            for (int r = 0; r < 16; r++) cur[nt * 16 + r] = softplus100(acc[r]);
+            for (int r = 0; r < 16; r++) t[r] = softplus100(acc[r]);
+            store_tile_lds(fl, nt, t);
         }
-        // plain layer 3+2i: cur -> h (/ sqrt(2) when the next layer is a skip layer)
+        // plain layer 3+2i: LDS -> registers (/ sqrt(2) when the next layer is a skip layer)
         const float post = i < 2 ? sqrt2 : 1.0f;
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
             f32x16 acc = rp16(prm, pp + 1024, nt, hi);
-            gemm_tile<NT>(s, cur, acc, 0);
+            gemm_tile_lds(s, fl, acc, 0);
 #pragma unroll
             for (int r = 0; r < 16; r++) h[nt * 16 + r] = softplus100(acc[r]) / post;
         }
     }
+    s.drain();
     // layer 8: 256 -> 1
     float out = 0.f;
 #pragma unroll
@@ -406,67 +570,81 @@ DEV float decode_tile(const f32x4 *__restrict__ recs, const float *__restrict__ 
 }
 
 template <bool GRID>
-__global__ __launch_bounds__(WAVES * 64, 1) void sdf_decode_kernel(
-    const float *__restrict__ programs, size_t program_stride_floats,
+__global__ __launch_bounds__(WAVES * 64, 1) __attribute__((amdgpu_num_vgpr(240))) void sdf_decode_kernel(
+    const float *__restrict__ programs, size_t program_stride_floats, int batch,
     const float *__restrict__ points,  // !GRID: [batch][m][3]
     const float *__restrict__ axis,    //  GRID: [G]
     int G, long long first_point,      //  GRID: linear index of the first grid point
     int m,                             // points per image handled by this launch
-    float *__restrict__ out, int apply_sigmoid) {
-    // LDS: [params 32 KiB][4 x 32 KiB feat slabs] = 160 KiB, one workgroup per CU
-    __shared__ __attribute__((aligned(16))) float lds[P_PHASE_B + WAVES * NT * 16 * 64];
+    float *__restrict__ out, int apply_sigmoid, f32x4 *__restrict__ workspace) {
+    // LDS: [params 32 KiB][4 x 32 KiB activation slabs] = 160 KiB, one workgroup per CU
+    __shared__ __attribute__((aligned(16))) float lds[P_PHASE_B + WAVES * SLAB_F4 * 4];
     float *prm = lds;
-
-    const int img = blockIdx.y;
-    const float *prog = programs + (size_t)img * program_stride_floats;
-    {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(prog + REC_FLOATS);
-        f32x4 *dst = reinterpret_cast<f32x4 *>(prm);
-        for (int i = threadIdx.x; i < P_PHASE_B / 4; i += WAVES * 64) dst[i] = src[i];
-    }
-    __syncthreads();
-
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int p = blockIdx.x * PTS_PER_BLOCK + wave * PTS_PER_WAVE + (lane & 31);
-    const int pc = p < m ? p : m - 1;  // clamp: tail lanes recompute the last point
-    float px, py, pz;
-    if (GRID) {
-        const long long gp = first_point + pc;
-        const long long gg = (long long)G * G;
-        const int ix = (int)(gp / gg);
-        const int rem = (int)(gp - (long long)ix * gg);
-        const int iy = rem / G;
-        const int iz = rem - iy * G;
-        px = axis[ix];
-        py = axis[iy];
-        pz = axis[iz];
-    } else {
-        const float *q = points + ((size_t)img * m + pc) * 3;
-        px = q[0];
-        py = q[1];
-        pz = q[2];
+    f32x4 *fl = reinterpret_cast<f32x4 *>(lds + P_PHASE_B) + wave * SLAB_F4 + lane;
+    f32x4 *zslab = workspace + ((size_t)blockIdx.x * WAVES + wave) * ZSLAB_F4;
+    const f32x4 *zs_u = uniform_ptr(zslab);
+
+    const int tiles_per_img = (m + PTS_PER_BLOCK - 1) / PTS_PER_BLOCK;
+    const int total = tiles_per_img * batch;
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const int img = tile / tiles_per_img;
+        const int t = tile - img * tiles_per_img;
+        const float *prog = programs + (size_t)img * program_stride_floats;
+        __syncthreads();  // previous tile done with the phase B params
+        {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(prog + REC_FLOATS);
+            f32x4 *dst = reinterpret_cast<f32x4 *>(prm);
+            for (int i = threadIdx.x; i < P_PHASE_B / 4; i += WAVES * 64) dst[i] = src[i];
+        }
+        __syncthreads();
+
+        const int p = t * PTS_PER_BLOCK + wave * PTS_PER_WAVE + (lane & 31);
+        const int pc = p < m ? p : m - 1;  // clamp: tail lanes recompute the last point
+        float px, py, pz;
+        if (GRID) {
+            const long long gp = first_point + pc;
+            const long long gg = (long long)G * G;
+            const int ix = (int)(gp / gg);
+            const int rem = (int)(gp - (long long)ix * gg);
+            const int iy = rem / G;
+            const int iz = rem - iy * G;
+            px = axis[ix];
+            py = axis[iy];
+            pz = axis[iz];
+        } else {
+            const float *q = points + ((size_t)img * m + pc) * 3;
+            px = q[0];
+            py = q[1];
+            pz = q[2];
+        }
+        const f32x4 *recs = uniform_ptr(reinterpret_cast<const f32x4 *>(prog));
+        float logit = decode_tile(recs, prog + REC_FLOATS, prm, fl, zslab + lane, zs_u, px, py, pz, lane);
+        if (apply_sigmoid) logit = 1.0f / (1.0f + expf(-logit));
+        if (lane < 32 && p < m) out[(size_t)img * m + p] = logit;
     }
-    f32x4 *fl = reinterpret_cast<f32x4 *>(lds + P_PHASE_B + wave * (NT * 16 * 64)) + lane;
-    float logit = decode_tile(reinterpret_cast<const f32x4 *>(prog), prog + REC_FLOATS, prm, fl, px, py,
-                              pz, lane);
-    if (apply_sigmoid) logit = 1.0f / (1.0f + expf(-logit));
-    if (lane < 32 && p < m) out[(size_t)img * m + p] = logit;
+}
+
+int decode_grid_size(int batch, int m) {
+    const long long tiles = (long long)batch * ((m + PTS_PER_BLOCK - 1) / PTS_PER_BLOCK);
+    return (int)(tiles < MAX_WGS ? tiles : MAX_WGS);
 }
 
 }  // namespace
 
 extern "C" size_t zs_sdf_program_bytes(void) { return (size_t)PROGRAM_FLOATS * sizeof(float); }
+extern "C" size_t zs_sdf_workspace_bytes(void) { return WORKSPACE_BYTES; }
 
 extern "C" int zs_sdf_query_points(const void *programs, size_t program_stride_bytes, int batch,
                                    const float *points, int m, float *logits, float *attn,
-                                   void *stream) {
+                                   void *workspace, void *stream) {
     if (batch < 0 || m < 0) {
         zs::set_err("zs_sdf_query_points: negative size (batch=%d m=%d)", batch, m);
         return 0;
     }
     if (batch == 0 || m == 0) return 1;
-    if (!programs || !points || !logits) {
+    if (!programs || !points || !logits || !workspace) {
         zs::set_err("zs_sdf_query_points: null pointer");
         return 0;
     }
@@ -478,16 +656,20 @@ extern "C" int zs_sdf_query_points(const void *programs, size_t program_stride_b
         zs::set_err("zs_sdf_query_points: bad program stride %zu", program_stride_bytes);
         return 0;
     }
-    dim3 grid((m + PTS_PER_BLOCK - 1) / PTS_PER_BLOCK, batch);
-    hipLaunchKernelGGL(sdf_decode_kernel<false>, grid, dim3(WAVES * 64), 0,
+    if ((long long)batch * ((m + PTS_PER_BLOCK - 1) / PTS_PER_BLOCK) > 0x7fffffffLL) {
+        zs::set_err("zs_sdf_query_points: too many tiles");
+        return 0;
+    }
+    hipLaunchKernelGGL(sdf_decode_kernel<false>, dim3(decode_grid_size(batch, m)), dim3(WAVES * 64), 0,
                        static_cast<hipStream_t>(stream), static_cast<const float *>(programs),
-                       program_stride_bytes / sizeof(float), points, nullptr, 0, 0LL, m, logits, 0);
+                       program_stride_bytes / sizeof(float), batch, points, nullptr, 0, 0LL, m, logits,
+                       0, static_cast<f32x4 *>(workspace));
     return zs::check_launch("zs_sdf_query_points") ? 1 : 0;
 }
 
 extern "C" int zs_sdf_query_grid(const void *programs, size_t program_stride_bytes, int batch,
                                  const float *axis, int G, int slice_begin, int slice_end,
-                                 int apply_sigmoid, float *out, void *stream) {
+                                 int apply_sigmoid, float *out, void *workspace, void *stream) {
     if (batch < 0 || G <= 0 || slice_begin < 0 || slice_end > G || slice_begin > slice_end) {
         zs::set_err("zs_sdf_query_grid: bad range (batch=%d G=%d slices=[%d,%d))", batch, G,
                     slice_begin, slice_end);
@@ -495,7 +677,7 @@ extern "C" int zs_sdf_query_grid(const void *programs, size_t program_stride_byt
     }
     const long long mm = (long long)(slice_end - slice_begin) * G * G;
     if (batch == 0 || mm == 0) return 1;
-    if (!programs || !axis || !out) {
+    if (!programs || !axis || !out || !workspace) {
         zs::set_err("zs_sdf_query_grid: null pointer");
         return 0;
     }
@@ -508,10 +690,10 @@ extern "C" int zs_sdf_query_grid(const void *programs, size_t program_stride_byt
         return 0;
     }
     const int m = (int)mm;
-    dim3 grid((m + PTS_PER_BLOCK - 1) / PTS_PER_BLOCK, batch);
-    hipLaunchKernelGGL(sdf_decode_kernel<true>, grid, dim3(WAVES * 64), 0,
+    hipLaunchKernelGGL(sdf_decode_kernel<true>, dim3(decode_grid_size(batch, m)), dim3(WAVES * 64), 0,
                        static_cast<hipStream_t>(stream), static_cast<const float *>(programs),
-                       program_stride_bytes / sizeof(float), nullptr, axis, G,
-                       (long long)slice_begin * G * G, m, out, apply_sigmoid);
+                       program_stride_bytes / sizeof(float), batch, nullptr, axis, G,
+                       (long long)slice_begin * G * G, m, out, apply_sigmoid,
+                       static_cast<f32x4 *>(workspace));
     return zs::check_launch("zs_sdf_query_grid") ? 1 : 0;
 }

@@ -111,6 +111,7 @@ class Implicit(nn.Module):
             self.pred_head = nn.Linear(n_channels, 1, bias=True)
         self.initialize_weights()
         self._packed = None       # (key, template programs tensor, lat_params tensor)
+        self._workspace = {}      # device -> scratch tensor for the query kernels
 
     # ---- init (implicit.py:232-249) -------------------------------------------------
     def initialize_weights(self):
@@ -154,6 +155,15 @@ class Implicit(nn.Module):
             self._packed = (key, prog, lat)
         return self._packed[1], self._packed[2]
 
+    def workspace(self, device):
+        """Scratch for the query kernels (zs_sdf_workspace_bytes(), one per device; launches
+        on one stream serialise, so sharing it is safe)."""
+        key = str(device)
+        if key not in self._workspace:
+            n = _lib.load().zs_sdf_workspace_bytes()
+            self._workspace[key] = torch.empty(n // 4, dtype=torch.float32, device=device)
+        return self._workspace[key]
+
     @torch.no_grad()
     def prepare(self, latent_depth):
         """Per-image prologue: latent_depth [B,197,C] (any float dtype, GPU) -> DecoderState."""
@@ -190,6 +200,7 @@ class Implicit(nn.Module):
         with torch.cuda.device(pts.device):
             rc = lib.zs_sdf_query_points(_lib.ptr(state.programs), state.stride_bytes, state.batch,
                                          _lib.ptr(pts), M, _lib.ptr(out), None,
+                                         _lib.ptr(self.workspace(pts.device)),
                                          _lib.current_stream_ptr(pts.device))
         _lib.check(rc, "zs_sdf_query_points")
         return out
@@ -214,6 +225,7 @@ class Implicit(nn.Module):
             rc = lib.zs_sdf_query_grid(_lib.ptr(state.programs), state.stride_bytes, state.batch,
                                        _lib.ptr(axis), G, slice_begin, slice_end,
                                        1 if apply_sigmoid else 0, _lib.ptr(out),
+                                       _lib.ptr(self.workspace(axis.device)),
                                        _lib.current_stream_ptr(axis.device))
         _lib.check(rc, "zs_sdf_query_grid")
         return out

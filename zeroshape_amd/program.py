@@ -151,18 +151,19 @@ def pack_records(sd, kv=None):
         for ht in range(HT):
             out.append(records_for_linear(W1[ht * 32:(ht + 1) * 32]))      # fc1 tile: 128 records
             out.append(records_for_linear(W2[:, ht * 32:(ht + 1) * 32]))   # fc2 slice: for nt: 16
-    for l in range(MLP_LAYERS - 1):
-        W = np.asarray(sd["impl_mlp.layers.%d.weight" % l], np.float32)
-        if l == 0:
-            out.append(records_for_linear(W[:, 3:]))                       # feat part
-        elif l in SKIP_IN:
-            # cat[x (256), xyz (3), feat (256)] / sqrt(2): per output tile, x part then feat part
-            Wx, Wf = W[:, :C], W[:, C + 3:]
-            for nt in range(NT):
-                out.append(records_for_linear(Wx[32 * nt:32 * nt + 32]))
-                out.append(records_for_linear(Wf[32 * nt:32 * nt + 32]))
+    # impl_mlp, in the order the kernel runs it: layer 0 (feat columns), then the feat
+    # halves of the three skip layers ("Z" partial products, computed while feat is still in
+    # registers and parked in the per-wave workspace), then layers 1..7 with only the
+    # x columns left in the skip layers.
+    Wl = [np.asarray(sd["impl_mlp.layers.%d.weight" % l], np.float32) for l in range(MLP_LAYERS)]
+    out.append(records_for_linear(Wl[0][:, 3:]))                           # layer 0, feat part
+    for l in SKIP_IN:
+        out.append(records_for_linear(Wl[l][:, C + 3:]))                   # Z_l = W_l[:, feat] feat/sqrt2
+    for l in range(1, MLP_LAYERS - 1):
+        if l in SKIP_IN:
+            out.append(records_for_linear(Wl[l][:, :C]))                   # x part
         else:
-            out.append(records_for_linear(W))
+            out.append(records_for_linear(Wl[l]))
     recs = np.concatenate(out, axis=0)
     assert recs.shape == (G_TOTAL * 4, 64), recs.shape
     flat = _interleave(recs)
