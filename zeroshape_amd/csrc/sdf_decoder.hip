@@ -192,18 +192,26 @@ DEV void gemm_tile_v(Stream &s, const f32x16 &X, f32x16 &acc, int phase) {
 }
 
 // 8-tile variant with the B operands read from the wave's LDS slab
-// ([kt][g][lane] float4: lane-contiguous -> conflict-free ds_read_b128)
+// ([kt][g][lane] float4: lane-contiguous -> conflict-free ds_read_b128).  The read for
+// group g+1 is issued BEFORE the MFMAs of group g (hipcc cannot hoist it itself: LDS reads
+// do not cross the asm statements), otherwise every group paid the LDS latency with the
+// MFMA pipe idle (first v1 profile: 35 % of cycles not under an MFMA).
 DEV void gemm_tile_lds(Stream &s, const f32x4 *fl, f32x16 &acc, int phase) {
+    f32x4 b = fl[0];
 #pragma unroll
     for (int kt = 0; kt < NT; kt++) {
 #pragma unroll
         for (int g = 0; g < 4; g++) {
+            // the read sits before the asm statement (which it cannot cross), i.e. a whole
+            // group of MFMAs ahead of its use, in registers other than b's
+            f32x4 bn = b;
+            if (kt * 4 + g + 1 < NT * 4) bn = fl[(kt * 4 + g + 1) * 64];
             const f32x4 a = s.next((phase + kt * 4 + g) & (RING - 1));
-            const f32x4 b = fl[(kt * 4 + g) * 64];
             acc = mfma(a.x, b.x, acc);
             acc = mfma(a.y, b.y, acc);
             acc = mfma(a.z, b.z, acc);
             acc = mfma(a.w, b.w, acc);
+            b = bn;
         }
     }
 }
@@ -319,45 +327,40 @@ DEV void layer_norm_reg(const f32x16 *x, float *h, const float *prm, int g_off, 
     }
 }
 
-// Branch-free erff (two polynomial regimes, both evaluated, then selected); max error
-// 0.99 ulp (5.8e-8 abs) against erf() in fp64 - checked on the host in
-// tests/test_device_math.py with the same coefficients.
-DEV float erf_nb(float a) {
-    const float t = fabsf(a), s2 = a * a;
-    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
-    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
-    r = fmaf(r, s2, u);
-    r = fmaf(r, t, -1.06777877e-1f);
-    r = fmaf(r, t, -6.34846687e-1f);
-    r = fmaf(r, t, -1.28717512e-1f);
-    r = fmaf(r, t, -t);
-    const float big = copysignf(1.0f - __expf(r), a);
-    float q = -5.96761703e-4f;
-    q = fmaf(q, s2, 4.99119423e-3f);
-    q = fmaf(q, s2, -2.67681349e-2f);
-    q = fmaf(q, s2, 1.12819925e-1f);
-    q = fmaf(q, s2, -3.76125336e-1f);
-    q = fmaf(q, s2, 1.28379166e-1f);
-    q = fmaf(q, a, a);
-    return t > 0.927734375f ? big : q;
+// NOTE on VALU cost: v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate and does not
+// overlap with VALU instructions of the same SIMD (tools/ubench/mfma_chain.hip: every VALU
+// op beside a dependent MFMA chain adds its full 4 cycles), so each VALU instruction in
+// this kernel costs MFMA time.  The activation functions are therefore written for the
+// fewest instructions that still sit 2+ orders of magnitude inside the 1e-4 contract;
+// tests/test_device_math.py checks the same formulas against fp64 on the host.
+
+// exact-erf GELU (nn.GELU default; timm Mlp): 0.5 x (1 + erf(x / sqrt 2)).
+// erfc(u) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-u^2), t = 1 / (1 + p u), u >= 0
+// (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7); 1 + erf(x/sqrt2) = erfc(|u|) for x < 0
+// and 2 - erfc(|u|) otherwise.  Max abs error of GELU vs fp64: 4.2e-7 (at |x| ~ 3).
+DEV float gelu_erf(float x) {
+    const float u = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, u, 1.0f));
+    float p = 1.061405429f;
+    p = fmaf(p, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p = p * t;
+    const float w = x * 0.84932180028801904272f;  // sqrt(log2(e) / 2): exp(-u^2) = 2^-(w^2)
+    const float e = p * __builtin_amdgcn_exp2f(-(w * w));
+    const float hx = 0.5f * x;
+    return x < 0.f ? hx * e : hx * (2.0f - e);
 }
 
-// exact-erf GELU (nn.GELU default; timm Mlp)
-DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_nb(x * 0.70710678118654752440f)); }
-
-// torch.nn.Softplus(beta=100, threshold=20): z > 20 ? x : log1p(exp(z)) / 100, z = 100 x.
-// Evaluated branch-free in the overflow-safe form max(x,0) + log1p(exp(-|z|)) / 100 (same
-// function).  log1p(t) = log(w) + (t - (w - 1)) / w with w = fl(1 + t): the second term is
-// the rounding error of w, so no special case is needed when w == 1.  7e-9 max abs error
-// vs fp64 (the reference's own fp32 formula: 1.6e-8); host check in tests/test_device_math.py.
+// torch.nn.Softplus(beta=100, threshold=20): z > 20 ? x : log1p(exp(z)) / 100, z = 100 x,
+// evaluated as max(x,0) + log1p(exp(-|z|)) / 100 (same function, overflow-free; beyond the
+// threshold the second term is < 2e-11 and vanishes in fp32, so no select is needed).
+// 6 instructions, 7.8e-9 max abs error vs fp64 (the reference's own fp32 formula: 1.6e-8).
 DEV float softplus100(float x) {
-    const float z = x * 100.0f;
-    const float t = __expf(-fabsf(z));  // (0, 1]
-    const float w = 1.0f + t;
-    const float c = t - (w - 1.0f);
-    const float l = fmaf(c, __frcp_rn(w), __logf(w));
-    const float r = fmaf(l, 0.01f, fmaxf(x, 0.0f));
-    return z > 20.0f ? x : r;
+    const float t = __builtin_amdgcn_exp2f(fabsf(x) * -144.26950408889634074f);  // exp(-|z|)
+    const float l = __builtin_amdgcn_logf(1.0f + t);                             // log2(1 + t)
+    return fmaf(l, 0.0069314718055994530942f, fmaxf(x, 0.0f));                   // * ln2 / 100
 }
 
 DEV void store_tile_lds(f32x4 *fl, int tile, const float *v) {
@@ -403,11 +406,13 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
             f32x16 v = rp16(prm, pb + PB_BQKV, hd * 3 + 2, hi);
             gemm_tile_lds(s, fl, v, 0);
 
+            // logits are kept in the log2 domain: c = d^-1/2 * log2(e), softmax = 2^(c s - m)
+            const float c = scale * 1.44269504088896340736f;
             // self logit (implicit.py:44)
             float s_self = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; r++) s_self = fmaf(q[r], k[r], s_self);
-            s_self = (s_self + xhalf(s_self)) * scale;
+            s_self = (s_self + xhalf(s_self)) * c;
 
             // online softmax over 7 latent tiles (+ self), o = sum P V
             float m_run = -INFINITY, z_run = 0.f;
@@ -425,17 +430,17 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int rw = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const float sv = rw < lim ? S[r] * scale : -INFINITY;
+                    const float sv = rw < lim ? S[r] : -INFINITY;
                     S[r] = sv;
                     mt = fmaxf(mt, sv);
                 }
-                mt = fmaxf(mt, xhalf(mt));
+                mt = fmaxf(mt, xhalf(mt)) * c;
                 const float m_new = fmaxf(m_run, mt);
-                const float alpha = __expf(m_run - m_new);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
                 float zs_ = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    const float p = __expf(S[r] - m_new);
+                    const float p = __builtin_amdgcn_exp2f(fmaf(S[r], c, -m_new));
                     S[r] = p;
                     zs_ += p;
                 }
@@ -447,12 +452,13 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
             }
             {
                 const float m_new = fmaxf(m_run, s_self);
-                const float alpha = __expf(m_run - m_new);
-                const float p_self = __expf(s_self - m_new);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                const float p_self = __builtin_amdgcn_exp2f(s_self - m_new);
                 const float z = fmaf(z_run + xhalf(z_run), alpha, p_self);
                 const float inv = 1.0f / z;
+                const float a_i = alpha * inv, p_i = p_self * inv;
 #pragma unroll
-                for (int r = 0; r < 16; r++) o[r] = fmaf(p_self, v[r], o[r] * alpha) * inv;
+                for (int r = 0; r < 16; r++) o[r] = fmaf(p_i, v[r], o[r] * a_i);
             }
             // y += Wproj[:, head] o_h
 #pragma unroll
@@ -499,10 +505,11 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
     }
     // the skip layers consume cat[x, xyz, feat] / sqrt(2): their feat halves are computed now,
     // while feat is in registers, and parked in the workspace (Z tiles)
-    const float sqrt2 = 1.41421356237309504880f;
+    // (x * (1/sqrt 2) instead of the reference's x / sqrt 2: <= 1 ulp apart, 10x fewer VALU ops)
+    const float rsqrt2 = 0.70710678118654752440f;
 #pragma unroll
-    for (int i = 0; i < NT * 16; i++) h[i] = h[i] / sqrt2;
-    const float sx = px / sqrt2, sy = py / sqrt2, sz = pz / sqrt2;
+    for (int i = 0; i < NT * 16; i++) h[i] = h[i] * rsqrt2;
+    const float sx = px * rsqrt2, sy = py * rsqrt2, sz = pz * rsqrt2;
 #pragma unroll 1
     for (int li = 0; li < 3; li++) {
 #pragma unroll
@@ -529,7 +536,7 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
         f32x16 acc = rp16(prm, P_IMPL1 - P_PHASE_B, nt, hi);
         gemm_tile_lds(s, fl, acc, 0);
 #pragma unroll
-        for (int r = 0; r < 16; r++) h[nt * 16 + r] = softplus100(acc[r]) / sqrt2;
+        for (int r = 0; r < 16; r++) h[nt * 16 + r] = softplus100(acc[r]) * rsqrt2;
     }
 #pragma unroll 1
     for (int i = 0; i < 3; i++) {
@@ -546,13 +553,13 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
             store_tile_lds(fl, nt, t);
         }
         // plain layer 3+2i: LDS -> registers (/ sqrt(2) when the next layer is a skip layer)
-        const float post = i < 2 ? sqrt2 : 1.0f;
+        const float post = i < 2 ? rsqrt2 : 1.0f;
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
             f32x16 acc = rp16(prm, pp + 1024, nt, hi);
             gemm_tile_lds(s, fl, acc, 0);
 #pragma unroll
-            for (int r = 0; r < 16; r++) h[nt * 16 + r] = softplus100(acc[r]) / post;
+            for (int r = 0; r < 16; r++) h[nt * 16 + r] = softplus100(acc[r]) * post;
         }
     }
     s.drain();
