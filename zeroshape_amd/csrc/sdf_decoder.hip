@@ -98,6 +98,27 @@ DEV const f32x4 *uniform_ptr(const f32x4 *p) {  // make wave-uniformity provable
     asm volatile("global_load_dwordx4 a[" #A ":" #D "], %0, %1" : : "v"(voff), "s"(src)              \
                  : "a" #A, "a" #B, "a" #C, "a" #D)
 
+// A whole weight position in one statement: wait for the slot, run the group's 4 MFMAs with
+// the A operands read STRAIGHT from the ring registers (no copy-out: on this chip every
+// extra VALU instruction costs MFMA time, see the note at gelu_erf), then re-issue the slot.
+// The accumulator is a tied AGPR tuple ("+a"); B operands are ordinary VGPR values.
+// Hazards hipcc does not pad for asm (cdna_hip_programming.md section 5.7 item 2):
+//  * the leading s_nop 1 covers compiler VALU / v_accvgpr_write results feeding this MFMA;
+//  * 4 MFMAs accumulating into the same tuple back to back need no padding;
+//  * the reload is issued after the MFMAs, which read their operands long before a load
+//    can return;
+//  * MFMA result -> any non-accumulating reader: mfma_done() below, after the last group.
+#define ZS_MFMA4(RF, A, B, C, D, SUFFIX)                                                             \
+    asm volatile("s_waitcnt vmcnt(7)\n\ts_nop 1"                                                     \
+                 "\n\tv_mfma_f32_32x32x2_f32 %0, " RF #A ", %1, %0"                                  \
+                 "\n\tv_mfma_f32_32x32x2_f32 %0, " RF #B ", %2, %0"                                  \
+                 "\n\tv_mfma_f32_32x32x2_f32 %0, " RF #C ", %3, %0"                                  \
+                 "\n\tv_mfma_f32_32x32x2_f32 %0, " RF #D ", %4, %0"                                  \
+                 "\n\tglobal_load_dwordx4 " RF "[" #A ":" #D "], %5, %6" SUFFIX                      \
+                 : "+a"(acc)                                                                         \
+                 : "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(voff), "s"(src)                           \
+                 : RF #A, RF #B, RF #C, RF #D)
+
 struct Stream {
     const f32x4 *abase;  // wave-uniform (SGPR pair): next weight group to fetch
     unsigned voff;       // lane * 16 bytes
@@ -130,6 +151,37 @@ struct Stream {
         }
         return o;
     }
+    // weight position: 4 MFMAs + re-issue of the slot from `src`
+    DEV void mfma4_from(int slot, f32x16 &acc, float b0, float b1, float b2, float b3,
+                        const f32x4 *src, bool sc1) {
+        if (!sc1) {
+            switch (slot) {
+                case 0: ZS_MFMA4("v", 240, 241, 242, 243, ""); break;
+                case 1: ZS_MFMA4("v", 244, 245, 246, 247, ""); break;
+                case 2: ZS_MFMA4("v", 248, 249, 250, 251, ""); break;
+                case 3: ZS_MFMA4("v", 252, 253, 254, 255, ""); break;
+                case 4: ZS_MFMA4("a", 240, 241, 242, 243, ""); break;
+                case 5: ZS_MFMA4("a", 244, 245, 246, 247, ""); break;
+                case 6: ZS_MFMA4("a", 248, 249, 250, 251, ""); break;
+                default: ZS_MFMA4("a", 252, 253, 254, 255, ""); break;
+            }
+        } else {
+            switch (slot) {
+                case 0: ZS_MFMA4("v", 240, 241, 242, 243, " sc1"); break;
+                case 1: ZS_MFMA4("v", 244, 245, 246, 247, " sc1"); break;
+                case 2: ZS_MFMA4("v", 248, 249, 250, 251, " sc1"); break;
+                case 3: ZS_MFMA4("v", 252, 253, 254, 255, " sc1"); break;
+                case 4: ZS_MFMA4("a", 240, 241, 242, 243, " sc1"); break;
+                case 5: ZS_MFMA4("a", 244, 245, 246, 247, " sc1"); break;
+                case 6: ZS_MFMA4("a", 248, 249, 250, 251, " sc1"); break;
+                default: ZS_MFMA4("a", 252, 253, 254, 255, " sc1"); break;
+            }
+        }
+    }
+    DEV void mfma4(int slot, f32x16 &acc, float b0, float b1, float b2, float b3) {
+        mfma4_from(slot, acc, b0, b1, b2, b3, abase, false);
+        abase += 64;
+    }
     DEV f32x4 next(int slot) {  // weight position whose slot is re-used by a weight position
         const f32x4 a = take_issue(slot, abase, false);
         abase += 64;
@@ -155,9 +207,9 @@ struct Stream {
     DEV void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
 
-DEV f32x16 mfma(float a, float b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
+// MFMA results leave asm-land: 16-pass MFMA D -> any reader other than an accumulating MFMA
+// needs ~19 wait states that hipcc does not know about.
+DEV void mfma_done(f32x16 &acc) { asm volatile("s_nop 15\n\ts_nop 5" : "+a"(acc)); }
 
 // acc += W_tile * X.  X = KT activation tiles as 16*KT scalars in registers (register r of
 // tile kt is X[16*kt + r]); consumes KT*4 groups starting at ring slot `phase` (kt-major,
@@ -169,74 +221,65 @@ DEV void gemm_tile(Stream &s, const float *X, f32x16 &acc, int phase) {
 #pragma unroll
     for (int kt = 0; kt < KT; kt++) {
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const f32x4 a = s.next((phase + kt * 4 + g) & (RING - 1));
-            acc = mfma(a.x, X[kt * 16 + 4 * g + 0], acc);
-            acc = mfma(a.y, X[kt * 16 + 4 * g + 1], acc);
-            acc = mfma(a.z, X[kt * 16 + 4 * g + 2], acc);
-            acc = mfma(a.w, X[kt * 16 + 4 * g + 3], acc);
-        }
+        for (int g = 0; g < 4; g++)
+            s.mfma4((phase + kt * 4 + g) & (RING - 1), acc, X[kt * 16 + 4 * g + 0], X[kt * 16 + 4 * g + 1],
+                    X[kt * 16 + 4 * g + 2], X[kt * 16 + 4 * g + 3]);
     }
+    mfma_done(acc);
 }
 
-// one-tile variant whose B operand is an accumulator tuple (q, P, o, hidden)
-DEV void gemm_tile_v(Stream &s, const f32x16 &X, f32x16 &acc, int phase) {
+// one-tile variant whose B operand is a 16-register activation tile (q, P, o, hidden);
+// `last` = the caller reads acc next (several of these can chain on one accumulator)
+template <typename T>
+DEV void gemm_tile_v(Stream &s, const T &X, f32x16 &acc, int phase, bool last = true) {
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-        const f32x4 a = s.next((phase + g) & (RING - 1));
-        acc = mfma(a.x, X[4 * g + 0], acc);
-        acc = mfma(a.y, X[4 * g + 1], acc);
-        acc = mfma(a.z, X[4 * g + 2], acc);
-        acc = mfma(a.w, X[4 * g + 3], acc);
-    }
+    for (int g = 0; g < 4; g++)
+        s.mfma4((phase + g) & (RING - 1), acc, X[4 * g + 0], X[4 * g + 1], X[4 * g + 2], X[4 * g + 3]);
+    if (last) mfma_done(acc);
 }
 
 // 8-tile variant with the B operands read from the wave's LDS slab
 // ([kt][g][lane] float4: lane-contiguous -> conflict-free ds_read_b128).  The read for
-// group g+1 is issued BEFORE the MFMAs of group g (hipcc cannot hoist it itself: LDS reads
-// do not cross the asm statements), otherwise every group paid the LDS latency with the
-// MFMA pipe idle (first v1 profile: 35 % of cycles not under an MFMA).
+// group g+1 is issued BEFORE the asm statement of group g (hipcc cannot hoist it itself:
+// LDS reads do not cross the asm statements), i.e. a whole group of MFMAs ahead of its
+// use; otherwise every group paid the LDS latency with the MFMA pipe idle.
 DEV void gemm_tile_lds(Stream &s, const f32x4 *fl, f32x16 &acc, int phase) {
     f32x4 b = fl[0];
 #pragma unroll
     for (int kt = 0; kt < NT; kt++) {
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            // the read sits before the asm statement (which it cannot cross), i.e. a whole
-            // group of MFMAs ahead of its use, in registers other than b's
             f32x4 bn = b;
             if (kt * 4 + g + 1 < NT * 4) bn = fl[(kt * 4 + g + 1) * 64];
-            const f32x4 a = s.next((phase + kt * 4 + g) & (RING - 1));
-            acc = mfma(a.x, b.x, acc);
-            acc = mfma(a.y, b.y, acc);
-            acc = mfma(a.z, b.z, acc);
-            acc = mfma(a.w, b.w, acc);
+            s.mfma4((phase + kt * 4 + g) & (RING - 1), acc, b.x, b.y, b.z, b.w);
             b = bn;
         }
     }
+    mfma_done(acc);
 }
 
 // one output tile of a skip layer: 32 weight positions (B = x / sqrt(2) in registers), then
 // 4 workspace positions that add the tile's parked feat partial product.  36 positions:
-// `phase` alternates 0 / 4 from tile to tile.
+// `phase` alternates 0 / 4 from tile to tile.  Positions 24..27 re-issue their slots for
+// positions 32..35 = the workspace tile.
 DEV void skip_tile(Stream &s, const float *X, f32x16 &acc, const f32x4 *ztile, int phase) {
 #pragma unroll
-    for (int q = 0; q < 36; q++) {
+    for (int q = 0; q < 32; q++) {
         const int slot = (phase + q) & (RING - 1);
-        // positions 24..27 re-issue their slots for positions 32..35 = the workspace tile
-        const f32x4 a = (q >= 24 && q < 28) ? s.next_then_z(slot, ztile + (q - 24) * 64) : s.next(slot);
-        if (q < 32) {
-            acc = mfma(a.x, X[4 * q + 0], acc);
-            acc = mfma(a.y, X[4 * q + 1], acc);
-            acc = mfma(a.z, X[4 * q + 2], acc);
-            acc = mfma(a.w, X[4 * q + 3], acc);
-        } else {
-            const int j = q - 32;
-            acc[4 * j + 0] += a.x;
-            acc[4 * j + 1] += a.y;
-            acc[4 * j + 2] += a.z;
-            acc[4 * j + 3] += a.w;
-        }
+        if (q >= 24 && q < 28)
+            s.mfma4_from(slot, acc, X[4 * q + 0], X[4 * q + 1], X[4 * q + 2], X[4 * q + 3],
+                         ztile + (q - 24) * 64, true);
+        else
+            s.mfma4(slot, acc, X[4 * q + 0], X[4 * q + 1], X[4 * q + 2], X[4 * q + 3]);
+    }
+    mfma_done(acc);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const f32x4 a = s.next((phase + 32 + j) & (RING - 1));
+        acc[4 * j + 0] += a.x;
+        acc[4 * j + 1] += a.y;
+        acc[4 * j + 2] += a.z;
+        acc[4 * j + 3] += a.w;
     }
 }
 
@@ -406,6 +449,9 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
             f32x16 v = rp16(prm, pb + PB_BQKV, hd * 3 + 2, hi);
             gemm_tile_lds(s, fl, v, 0);
 
+            float qv[16];  // q as plain VGPR scalars: B operand of 7 x 16 MFMAs
+#pragma unroll
+            for (int r = 0; r < 16; r++) qv[r] = q[r];
             // logits are kept in the log2 domain: c = d^-1/2 * log2(e), softmax = 2^(c s - m)
             const float c = scale * 1.44269504088896340736f;
             // self logit (implicit.py:44)
@@ -424,7 +470,7 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
                 f32x16 S;
 #pragma unroll
                 for (int r = 0; r < 16; r++) S[r] = 0.f;
-                gemm_tile_v(s, q, S, 0);
+                gemm_tile_v(s, qv, S, 0);
                 const int lim = (lt == LT - 1) ? (L - 32 * (LT - 1)) : 64;  // valid rows in tile
                 float mt = -INFINITY;
 #pragma unroll
@@ -462,7 +508,7 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
             }
             // y += Wproj[:, head] o_h
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++) gemm_tile_v(s, o, y[nt], (nt & 1) * 4);
+            for (int nt = 0; nt < NT; nt++) gemm_tile_v(s, o, y[nt], (nt & 1) * 4, nt == NT - 1);
         }
 
         // MLP (timm Mlp): y += b2 + W2 gelu(W1 LN2(y) + b1), one hidden tile at a time
@@ -476,7 +522,7 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
 #pragma unroll
             for (int r = 0; r < 16; r++) hid[r] = gelu_erf(hid[r]);
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++) gemm_tile_v(s, hid, y[nt], (nt & 1) * 4);
+            for (int nt = 0; nt < NT; nt++) gemm_tile_v(s, hid, y[nt], (nt & 1) * 4, nt == NT - 1);
         }
     }
 
