@@ -123,7 +123,12 @@ def main():
     achieved = pts_launch * FLOP_PER_POINT / (kern_mean * 1e-3) / 1e12
     roofline = {"bound": "mfma", "kernel": "sdf_decode_kernel<GRID>", "achieved": round(achieved, 3),
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                # HBM-side bytes per 129^3 launch from the committed rocprofv3 PMC passes
+                # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/README.md); only
+                # meaningful for the default single-GPU vox_res=128 launch
+                "traffic": 1.88e10 if (N == 128 and world == 1) else None,
+                "traffic_unit": "bytes/launch", "traffic_source": "profiles/r01_v3_decoder_rocprofv3_summary.txt",
                 "points_per_launch": pts_launch, "launch_ms_mean": round(kern_mean, 4),
                 "launch_ms_min": round(kern_ms[0], 4),
                 "algorithmic_flop_per_point": FLOP_PER_POINT}

@@ -1,0 +1,52 @@
+"""Error bounds of the kernel's cheap activation formulas (csrc/sdf_decoder.hip: gelu_erf,
+softplus100) against fp64, evaluated on the host through an operation-for-operation C mirror
+(tests/device_math_host.c).  On this chip every VALU instruction costs MFMA time, so the
+kernel uses the shortest formulas that stay far inside the 1e-4 output contract."""
+import ctypes
+import math
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def host():
+    so = os.path.join(tempfile.mkdtemp(), "libzs_devmath.so")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", so,
+                           os.path.join(HERE, "device_math_host.c"), "-lm"])
+    lib = ctypes.CDLL(so)
+    lib.zs_host_apply.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+
+    def apply(which, x):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.empty_like(x)
+        lib.zs_host_apply(which, x.ctypes.data, y.ctypes.data, x.size)
+        return y
+    return apply
+
+
+def test_gelu_erf_error(host):
+    x = np.linspace(-9, 9, 2_000_001).astype(np.float32)
+    ref = 0.5 * x.astype(np.float64) * (1.0 + np.vectorize(math.erf)(x.astype(np.float64) / math.sqrt(2.0)))
+    err = np.abs(host(0, x) - ref)
+    assert err.max() < 6e-7                      # 4.2e-7 measured; torch's exact-erf GELU in fp32: ~1e-7
+    assert np.abs(host(0, x)[np.abs(x) < 1] - ref[np.abs(x) < 1]).max() < 2.5e-7
+    # tails: exactly x for large positive, ~0 for large negative
+    assert host(0, np.array([12.0], np.float32))[0] == 12.0
+    assert abs(host(0, np.array([-12.0], np.float32))[0]) < 1e-30
+
+
+def test_softplus100_error(host):
+    x = np.linspace(-3, 3, 2_000_001).astype(np.float32)
+    z = 100.0 * x.astype(np.float64)
+    ref = np.where(z > 20, x.astype(np.float64), np.log1p(np.exp(np.minimum(z, 20.0))) / 100.0)
+    got = host(1, x)
+    assert np.abs(got - ref).max() < 2e-8        # 7.8e-9 measured
+    # torch's threshold rule: beyond 100 x > 20 the output is x itself
+    big = x[z > 20.5]
+    np.testing.assert_array_equal(host(1, big), big)

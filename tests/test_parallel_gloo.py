@@ -1,0 +1,76 @@
+"""Multi-process (world_size 2 and 3, gloo, CPU tensors) tests of the sharding logic in
+zeroshape_amd/parallel.py: uneven x-slab partition + padded all_gather == unsharded grid;
+rotation-range sharding + lexicographic reduce == sequential first-strict-minimum scan."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from zeroshape_amd import parallel
+
+
+def _worker(rank, world, initfile, G, B):
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        full = torch.arange(B * G * G * G, dtype=torch.float32).reshape(B, G, G, G)
+
+        def query_slab(b, e):          # stand-in for the HIP grid kernel on this rank's slab
+            return full[:, b:e].clone()
+
+        got = parallel.sharded_level_grid(query_slab, G)
+        assert got.shape == (B, G, G, G)
+        assert torch.equal(got, full), "rank %d: gathered grid differs" % rank
+
+        # rotation sharding: every rank scans its range, winner = first strict minimum overall
+        n_rot = 6912
+        rs = np.random.RandomState(1)
+        cds = rs.rand(n_rot)
+        cds[[100, 5000]] = -1.0        # tie across ranks: index 100 must win
+        b, e = parallel.rotation_range(n_rot, world, rank)
+        assert (e - b) % 24 == 0 or e == n_rot
+        loc = cds[b:e]
+        if len(loc):
+            j = int(np.argmin(loc))
+            local_cd, local_idx = float(loc[j]), b + j
+        else:
+            local_cd, local_idx = float("inf"), n_rot
+        payload = torch.tensor([local_cd * 2, local_idx * 3.0], dtype=torch.float32)
+        pl, cd, idx = parallel.reduce_best_rotation(local_cd, local_idx, payload)
+        assert idx == 100 and cd == -1.0
+        assert pl[0].item() == -2.0 and pl[1].item() == 300.0
+        # the ranges tile [0, n_rot) exactly
+        cover = torch.zeros(n_rot)
+        cover[b:e] = 1
+        dist.all_reduce(cover)
+        assert torch.all(cover == 1)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,G,B", [(2, 9, 2), (2, 33, 1), (3, 5, 1), (3, 2, 2)])
+def test_sharded_grid_and_rotation_reduce(world, G, B):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, os.path.join(d, "init"), G, B), nprocs=world, join=True)
+
+
+def test_slab_bounds_cover_and_match_reference_layout():
+    for G in (1, 2, 33, 129, 257):
+        for W in (1, 2, 4, 8):
+            seen = []
+            for r in range(W):
+                b, e, per = parallel.slab_bounds(G, W, r)
+                assert 0 <= b <= e <= G and e - b <= per
+                seen += list(range(b, e))
+            assert seen == list(range(G))
+
+
+def test_single_process_passthrough():
+    x = torch.rand(1, 4, 4, 4)
+    assert parallel.gather_slabs(x, 4) is x
+    pl, cd, idx = parallel.reduce_best_rotation(0.5, 7, torch.tensor([1.0, 2.0]))
+    assert cd == 0.5 and idx == 7
