@@ -21,7 +21,9 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall",
 # per-file extra flags
 EXTRA = {
     # bit-exact distance arithmetic: only the fmaf calls written in the source may fuse
-    "chamfer.hip": ["-ffp-contract=off"],
+    # (SLP vectorisation packs the distance arithmetic into v_pk_*_f32, which is no faster
+    # on gfx950 and costs extra v_mov: off)
+    "chamfer.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
 }
 
 

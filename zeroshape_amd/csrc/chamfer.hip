@@ -23,6 +23,7 @@
 #include "../../include/zeroshape_hip.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -161,18 +162,23 @@ extern "C" int zs_chamfer_forward(const float *xyz1, const float *xyz2, int b, i
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nmax = n > m ? n : m;
-    // Q queries per lane: 2 keeps >= 2 blocks/CU at the eval shape (B=24, n=10k) while
-    // halving LDS reads per pair; tiny clouds use Q=1 for more blocks.
-    if ((long long)b * nmax >= 64 * 1024) {
-        constexpr int Q = 2;
-        dim3 grid((nmax + NN_THREADS * Q - 1) / (NN_THREADS * Q), b, 2);
-        hipLaunchKernelGGL(nn_both_kernel<Q>, grid, dim3(NN_THREADS), 0, s, xyz1, xyz2, n, m,
-                           dist1, dist2, idx1, idx2);
-    } else {
-        constexpr int Q = 1;
-        dim3 grid((nmax + NN_THREADS * Q - 1) / (NN_THREADS * Q), b, 2);
-        hipLaunchKernelGGL(nn_both_kernel<Q>, grid, dim3(NN_THREADS), 0, s, xyz1, xyz2, n, m,
-                           dist1, dist2, idx1, idx2);
+    // Q queries per lane: more queries amortise the LDS reads and add independent chains,
+    // fewer give more blocks; ZS_CHAMFER_Q overrides for experiments
+    int Q = ((long long)b * nmax >= 64 * 1024) ? 2 : 1;
+    if (const char *e = getenv("ZS_CHAMFER_Q")) Q = atoi(e);
+    dim3 grid((nmax + NN_THREADS * Q - 1) / (NN_THREADS * Q), b, 2);
+    if (Q == 4)
+        hipLaunchKernelGGL(nn_both_kernel<4>, grid, dim3(NN_THREADS), 0, s, xyz1, xyz2, n, m, dist1,
+                           dist2, idx1, idx2);
+    else if (Q == 2)
+        hipLaunchKernelGGL(nn_both_kernel<2>, grid, dim3(NN_THREADS), 0, s, xyz1, xyz2, n, m, dist1,
+                           dist2, idx1, idx2);
+    else if (Q == 1)
+        hipLaunchKernelGGL(nn_both_kernel<1>, grid, dim3(NN_THREADS), 0, s, xyz1, xyz2, n, m, dist1,
+                           dist2, idx1, idx2);
+    else {
+        zs::set_err("zs_chamfer_forward: unsupported ZS_CHAMFER_Q=%d", Q);
+        return 0;
     }
     return zs::check_launch("zs_chamfer_forward") ? 1 : 0;
 }
