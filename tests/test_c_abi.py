@@ -42,7 +42,7 @@ def test_versions_and_sizes(lib):
     assert lib.zs_abi_version() == int(re.search(r"#define ZS_ABI_VERSION (\d+)", hdr).group(1))
     assert lib.zs_sdf_program_bytes() == P.PROGRAM_BYTES
     assert lib.zs_sdf_prologue_scratch_bytes() == P.SCRATCH_FLOATS * 4
-    assert lib.zs_sdf_workspace_bytes() == 256 * 4 * 3 * 32768
+    assert lib.zs_sdf_workspace_bytes() == 256 * 4 * 3 * 32768 + 4096
     assert lib.zs_last_error() in (b"", None) or isinstance(lib.zs_last_error(), bytes)
 
 

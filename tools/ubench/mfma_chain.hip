@@ -6,7 +6,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MF(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0)
-constexpr int ITER = 2000;  // groups of 4 MFMAs per acc-variant
+constexpr int ITER = 20000;  // groups of 4 MFMAs per acc-variant
 
 template <int V>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(240))) void k(const f32x4 *w, float *out) {
@@ -69,6 +69,57 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(240))) void 
         }
         for (int j = 0; j < 12; j++) acc1[0] += x[j];
     }
+    else if (V == 6) {  // 4 independent accumulators + 12 independent VALU ops per MFMA
+        float x[12];
+        for (int j = 0; j < 12; j++) x[j] = a + j;
+        for (int i = 0; i < ITER / 4; i++) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                acc0 = MF(a, b, acc0);
+#pragma unroll
+                for (int j = 0; j < 12; j++) x[j] = fmaf(x[j], 1.0001f, 0.5f);
+                acc1 = MF(b, a, acc1);
+#pragma unroll
+                for (int j = 0; j < 12; j++) x[j] = fmaf(x[j], 1.0001f, 0.5f);
+                acc2 = MF(a, a, acc2);
+#pragma unroll
+                for (int j = 0; j < 12; j++) x[j] = fmaf(x[j], 1.0001f, 0.5f);
+                acc3 = MF(b, b, acc3);
+#pragma unroll
+                for (int j = 0; j < 12; j++) x[j] = fmaf(x[j], 1.0001f, 0.5f);
+            }
+        }
+        for (int j = 0; j < 12; j++) acc1[0] += x[j];
+    } else if (V == 7) {  // chain + 4 transcendentals (v_exp) per MFMA
+        float x[4];
+        for (int j = 0; j < 4; j++) x[j] = a + j;
+        for (int i = 0; i < ITER * 4; i++) {
+            acc0 = MF(a, b, acc0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) x[j] = __builtin_amdgcn_exp2f(x[j]);
+        }
+        for (int j = 0; j < 4; j++) acc1[0] += x[j];
+    } else if (V == 8) {  // 16x16x4 f32 chain (8 passes) + 6 VALU per MFMA (same VALU:FLOP ratio as V5)
+        typedef float f32x4v __attribute__((ext_vector_type(4)));
+        f32x4v c0 = {0, 1, 2, 3};
+        float x[6];
+        for (int j = 0; j < 6; j++) x[j] = a + j;
+        for (int i = 0; i < ITER * 8; i++) {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c0, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 6; j++) x[j] = fmaf(x[j], 1.0001f, 0.5f);
+        }
+        acc0[0] += c0[0] + c0[1] + c0[2] + c0[3];
+        for (int j = 0; j < 6; j++) acc1[0] += x[j];
+    } else if (V == 9) {  // 16x16x4 f32 chain alone
+        typedef float f32x4v __attribute__((ext_vector_type(4)));
+        f32x4v c0 = {0, 1, 2, 3}, c1 = {1, 2, 3, 4};
+        for (int i = 0; i < ITER * 4; i++) {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, c1, 0, 0, 0);
+        }
+        acc0[0] += c0[0] + c0[1] + c0[2] + c0[3] + c1[0] + c1[1] + c1[2] + c1[3];
+    }
     float s = 0;
     for (int r = 0; r < 16; r++) s += acc0[r] + acc1[r] + acc2[r] + acc3[r];
     out[blockIdx.x * 256 + threadIdx.x] = s;
@@ -89,17 +140,23 @@ void run(const char *name, const f32x4 *w, float *out) {
     double tf = mfmas * 4096 / (ms * 1e-3) / 1e12;
     double cyc = ms * 1e-3 * 2.4e9 / (ITER * 4);
     printf("%-44s %8.3f ms  %7.1f TF  ~%5.1f cyc/MFMA @2.4GHz\n", name, ms, tf, cyc);
+    fflush(stdout);
 }
 
-int main() {
+int main(int argc, char **argv) {
+    int only = argc > 1 ? atoi(argv[1]) : -1;
     f32x4 *w; float *out;
     hipMalloc(&w, 1 << 20); hipMemset(w, 0, 1 << 20);
     hipMalloc(&out, 256 * 256 * 4);
-    run<0>("V0 one dependent chain", w, out);
-    run<1>("V1 four accumulators", w, out);
-    run<2>("V2 decoder group pattern, one acc", w, out);
-    run<3>("V3 decoder group pattern, two accs", w, out);
-    run<4>("V4 chain + 3 VALU / MFMA", w, out);
-    run<5>("V5 chain + 12 VALU / MFMA", w, out);
+    if (only < 0 || only == 0) run<0>("V0 one dependent chain", w, out);
+    if (only < 0 || only == 1) run<1>("V1 four accumulators", w, out);
+    if (only < 0 || only == 2) run<2>("V2 decoder group pattern, one acc", w, out);
+    if (only < 0 || only == 3) run<3>("V3 decoder group pattern, two accs", w, out);
+    if (only < 0 || only == 4) run<4>("V4 chain + 3 VALU / MFMA", w, out);
+    if (only < 0 || only == 5) run<5>("V5 chain + 12 VALU / MFMA", w, out);
+    if (only < 0 || only == 6) run<6>("V6 four accs + 12 VALU / MFMA", w, out);
+    if (only < 0 || only == 7) run<7>("V7 chain + 4 v_exp / MFMA", w, out);
+    if (only < 0 || only == 8) run<8>("V8 16x16x4 chain + 6 VALU / MFMA (x2 MFMAs)", w, out);
+    if (only < 0 || only == 9) run<9>("V9 16x16x4 two chains (x2 MFMAs)", w, out);
     return 0;
 }

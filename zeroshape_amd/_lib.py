@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzeroshape_hip.so")
+LIB_PATH = os.environ.get("ZS_LIB_PATH") or os.path.join(_HERE, "libzeroshape_hip.so")  # override: experiments only
 
 _c_void_p = ctypes.c_void_p
 _c_int = ctypes.c_int

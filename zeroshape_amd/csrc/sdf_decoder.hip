@@ -43,7 +43,7 @@ constexpr int PTS_PER_BLOCK = WAVES * PTS_PER_WAVE;
 constexpr int MAX_WGS = 256;                       // one persistent workgroup per CU
 constexpr int SLAB_F4 = NT * 4 * 64;               // one activation array as float4 groups: 32 KiB
 constexpr int ZSLAB_F4 = 3 * SLAB_F4;              // three skip layers' feat partial products
-constexpr size_t WORKSPACE_BYTES = (size_t)MAX_WGS * WAVES * ZSLAB_F4 * sizeof(f32x4);
+constexpr size_t WORKSPACE_BYTES = (size_t)MAX_WGS * WAVES * ZSLAB_F4 * sizeof(f32x4) + 4096;  // + debug tail
 
 #define DEV __device__ __forceinline__
 
@@ -209,7 +209,11 @@ struct Stream {
 
 // MFMA results leave asm-land: 16-pass MFMA D -> any reader other than an accumulating MFMA
 // needs ~19 wait states that hipcc does not know about.
+#ifdef ZS_EXP_NO_DONE_NOPS   // timing experiment only (wrong results possible)
+DEV void mfma_done(f32x16 &acc) { asm volatile("" : "+a"(acc)); }
+#else
 DEV void mfma_done(f32x16 &acc) { asm volatile("s_nop 15\n\ts_nop 5" : "+a"(acc)); }
+#endif
 
 // acc += W_tile * X.  X = KT activation tiles as 16*KT scalars in registers (register r of
 // tile kt is X[16*kt + r]); consumes KT*4 groups starting at ring slot `phase` (kt-major,
@@ -266,9 +270,15 @@ DEV void skip_tile(Stream &s, const float *X, f32x16 &acc, const f32x4 *ztile, i
 #pragma unroll
     for (int q = 0; q < 32; q++) {
         const int slot = (phase + q) & (RING - 1);
+#ifdef ZS_EXP_Z_FROM_WEIGHTS  // timing experiment only: workspace read-backs replaced by L2-hot loads
+        if (q >= 24 && q < 28)
+            s.mfma4_from(slot, acc, X[4 * q + 0], X[4 * q + 1], X[4 * q + 2], X[4 * q + 3],
+                         s.abase - 4096, false);
+#else
         if (q >= 24 && q < 28)
             s.mfma4_from(slot, acc, X[4 * q + 0], X[4 * q + 1], X[4 * q + 2], X[4 * q + 3],
                          ztile + (q - 24) * 64, true);
+#endif
         else
             s.mfma4(slot, acc, X[4 * q + 0], X[4 * q + 1], X[4 * q + 2], X[4 * q + 3]);
     }
@@ -419,9 +429,16 @@ DEV void store_tile_lds(f32x4 *fl, int tile, const float *v) {
 // `prm`: LDS params region (phase A: program params [0, P_PHASE_B); phase B: the rest);
 // `fl`: this wave's LDS slab, `zs`: this wave's workspace slab - both already offset by lane
 // except `zs_u`, the same workspace slab as a wave-uniform pointer for the asm loads.
+#ifdef ZS_EXP_TIMING  // phase timestamps of (block 0, wave 0, first tile) -> workspace tail
+#define ZS_STAMP(i) do { if (dbg) dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ZS_STAMP(i) do { } while (0)
+#endif
 DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, float *prm, f32x4 *fl,
-                      f32x4 *zs, const f32x4 *zs_u, float px, float py, float pz, int lane) {
+                      f32x4 *zs, const f32x4 *zs_u, float px, float py, float pz, int lane,
+                      unsigned long long *dbg) {
     const int hi = lane >> 5;
+    ZS_STAMP(0);
     Stream s;
     s.init(recs, lane);
 
@@ -435,7 +452,9 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
 #pragma unroll 1
     for (int blk = 0; blk < BLOCKS; blk++) {
         const int pb = P_BLK0 + blk * P_BLK_STRIDE;
+        ZS_STAMP(1 + blk * 4);
         layer_norm_lds(y, fl, prm, pb + PB_LN1G, pb + PB_LN1B, hi);
+        ZS_STAMP(2 + blk * 4);
         // y = x + proj_bias + sum_heads Wproj_h o_h
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) y[nt] += rp16(prm, pb + PB_BPROJ, nt, hi);
@@ -511,8 +530,10 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
             for (int nt = 0; nt < NT; nt++) gemm_tile_v(s, o, y[nt], (nt & 1) * 4, nt == NT - 1);
         }
 
+        ZS_STAMP(3 + blk * 4);
         // MLP (timm Mlp): y += b2 + W2 gelu(W1 LN2(y) + b1), one hidden tile at a time
         layer_norm_lds(y, fl, prm, pb + PB_LN2G, pb + PB_LN2B, hi);
+        ZS_STAMP(4 + blk * 4);
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) y[nt] += rp16(prm, pb + PB_B2, nt, hi);
 #pragma unroll 1
@@ -526,6 +547,7 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
         }
     }
 
+    ZS_STAMP(9);
     // final norm (implicit.py:275) -> feat, in registers
     float h[NT * 16];
     layer_norm_reg(y, h, prm, P_LNFG, P_LNFB, hi);
@@ -539,6 +561,7 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
     }
     __syncthreads();
 
+    ZS_STAMP(10);
     // impl_mlp (implicit.py:168-184): inputs = cat[xyz, feat].  Layer 0: feat (regs) -> LDS
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
@@ -549,6 +572,7 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
         for (int r = 0; r < 16; r++) t[r] = softplus100(acc[r]);
         store_tile_lds(fl, nt, t);
     }
+    ZS_STAMP(11);
     // the skip layers consume cat[x, xyz, feat] / sqrt(2): their feat halves are computed now,
     // while feat is in registers, and parked in the workspace (Z tiles)
     // (x * (1/sqrt 2) instead of the reference's x / sqrt 2: <= 1 ulp apart, 10x fewer VALU ops)
@@ -574,8 +598,11 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
     }
     // the Z stores must have reached L2 before the sc1 read-backs (>= 256 groups later; this
     // drain is a formality that costs one ring refill per tile)
+#ifndef ZS_EXP_NO_ZDRAIN
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 
+    ZS_STAMP(12);
     // layer 1 (plain): LDS -> registers, pre-divided by sqrt(2) because layer 2 is a skip layer
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
@@ -584,6 +611,7 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
 #pragma unroll
         for (int r = 0; r < 16; r++) h[nt * 16 + r] = softplus100(acc[r]) * rsqrt2;
     }
+    ZS_STAMP(13);
 #pragma unroll 1
     for (int i = 0; i < 3; i++) {
         const int pp = P_IMPL_PAIR - P_PHASE_B + i * P_IMPL_PAIR_STRIDE;
@@ -608,6 +636,7 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
             for (int r = 0; r < 16; r++) h[nt * 16 + r] = softplus100(acc[r]) * post;
         }
     }
+    ZS_STAMP(14);
     s.drain();
     // layer 8: 256 -> 1
     float out = 0.f;
@@ -619,6 +648,7 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
         for (int r = 0; r < 16; r++) out = fmaf(h[kt * 16 + r], w[r], out);
     }
     out += xhalf(out);
+    ZS_STAMP(15);
     return out + prm[P_B8 - P_PHASE_B];
 }
 
@@ -673,7 +703,13 @@ __global__ __launch_bounds__(WAVES * 64, 1) __attribute__((amdgpu_num_vgpr(240))
             pz = q[2];
         }
         const f32x4 *recs = uniform_ptr(reinterpret_cast<const f32x4 *>(prog));
-        float logit = decode_tile(recs, prog + REC_FLOATS, prm, fl, zslab + lane, zs_u, px, py, pz, lane);
+#ifdef ZS_EXP_TIMING
+        unsigned long long *dbg = (blockIdx.x == 0 && threadIdx.x == 0 && tile == 0)
+            ? reinterpret_cast<unsigned long long *>(workspace + (size_t)MAX_WGS * WAVES * ZSLAB_F4) : nullptr;
+#else
+        unsigned long long *dbg = nullptr;
+#endif
+        float logit = decode_tile(recs, prog + REC_FLOATS, prm, fl, zslab + lane, zs_u, px, py, pz, lane, dbg);
         if (apply_sigmoid) logit = 1.0f / (1.0f + expf(-logit));
         if (lane < 32 && p < m) out[(size_t)img * m + p] = logit;
     }
