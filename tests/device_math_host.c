@@ -6,16 +6,14 @@
 float zs_host_gelu(float x) {
     const float u = fabsf(x) * 0.70710678118654752440f;
     const float t = 1.0f / fmaf(0.3275911f, u, 1.0f);
-    float p = 1.061405429f;
-    p = fmaf(p, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
+    float p = 0.75052702f;
+    p = fmaf(p, t, -1.02753365f);
+    p = fmaf(p, t, 1.00509130f);
+    p = fmaf(p, t, -0.20116957f);
+    p = fmaf(p, t, 0.18019173f);
     p = p * t;
-    const float w = x * 0.84932180028801904272f;
-    const float e = p * exp2f(-(w * w));
-    const float hx = 0.5f * x;
-    return x < 0.f ? hx * e : hx * (2.0f - e);
+    const float e = exp2f((u * u) * -1.44269504088896340736f);
+    return fmaf(-(u * p), e, fmaxf(x, 0.0f));
 }
 float zs_host_softplus100(float x) {
     const float t = exp2f(fabsf(x) * -144.26950408889634074f);

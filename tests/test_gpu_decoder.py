@@ -149,7 +149,9 @@ def test_full_size_grid128_properties(net, seeded_sd):
     slab = net.query_grid(latent, axis, apply_sigmoid=False, slice_begin=40, slice_end=57, state=st)
     assert torch.equal(full[:, 40:57], slab)
     occ = net.query_grid(latent, axis, apply_sigmoid=True, state=st)
-    assert torch.equal(occ > 0.5, full > 0)
+    # sigmoid(x) > 0.5 <=> x > 0 except where fp32 rounds 1 + exp(-x) to 2 (|x| < 6e-8)
+    mism = (occ > 0.5) != (full > 0)
+    assert int(mism.sum()) <= 4 and bool(torch.all(full[mism].abs() < 2e-7))
     frac = float((full > 0).float().mean())
     assert 0.05 < frac < 0.95
     rs = np.random.RandomState(7)

@@ -108,14 +108,14 @@ DEV const f32x4 *uniform_ptr(const f32x4 *p) {  // make wave-uniformity provable
 //  * the reload is issued after the MFMAs, which read their operands long before a load
 //    can return;
 //  * MFMA result -> any non-accumulating reader: mfma_done() below, after the last group.
-#define ZS_MFMA4(RF, A, B, C, D, SUFFIX)                                                             \
+#define ZS_MFMA4(ACC, RF, A, B, C, D, SUFFIX)                                                        \
     asm volatile("s_waitcnt vmcnt(7)\n\ts_nop 1"                                                     \
                  "\n\tv_mfma_f32_32x32x2_f32 %0, " RF #A ", %1, %0"                                  \
                  "\n\tv_mfma_f32_32x32x2_f32 %0, " RF #B ", %2, %0"                                  \
                  "\n\tv_mfma_f32_32x32x2_f32 %0, " RF #C ", %3, %0"                                  \
                  "\n\tv_mfma_f32_32x32x2_f32 %0, " RF #D ", %4, %0"                                  \
                  "\n\tglobal_load_dwordx4 " RF "[" #A ":" #D "], %5, %6" SUFFIX                      \
-                 : "+a"(acc)                                                                         \
+                 : ACC(acc)                                                                          \
                  : "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(voff), "s"(src)                           \
                  : RF #A, RF #B, RF #C, RF #D)
 
@@ -151,35 +151,36 @@ struct Stream {
         }
         return o;
     }
-    // weight position: 4 MFMAs + re-issue of the slot from `src`
+    // weight position: 4 MFMAs + re-issue of the slot from `src`.  AV = false: the accumulator
+    // is a long-lived AGPR tuple (the residual stream y); AV = true: a short-lived VGPR tuple
+    // whose result is post-processed by VALU code right away (q/k/v, S, o, hidden, impl
+    // layers) - saves the v_accvgpr_read/write round trips, which are full-price VALU ops.
+    template <bool VACC>
     DEV void mfma4_from(int slot, f32x16 &acc, float b0, float b1, float b2, float b3,
                         const f32x4 *src, bool sc1) {
-        if (!sc1) {
-            switch (slot) {
-                case 0: ZS_MFMA4("v", 240, 241, 242, 243, ""); break;
-                case 1: ZS_MFMA4("v", 244, 245, 246, 247, ""); break;
-                case 2: ZS_MFMA4("v", 248, 249, 250, 251, ""); break;
-                case 3: ZS_MFMA4("v", 252, 253, 254, 255, ""); break;
-                case 4: ZS_MFMA4("a", 240, 241, 242, 243, ""); break;
-                case 5: ZS_MFMA4("a", 244, 245, 246, 247, ""); break;
-                case 6: ZS_MFMA4("a", 248, 249, 250, 251, ""); break;
-                default: ZS_MFMA4("a", 252, 253, 254, 255, ""); break;
-            }
-        } else {
-            switch (slot) {
-                case 0: ZS_MFMA4("v", 240, 241, 242, 243, " sc1"); break;
-                case 1: ZS_MFMA4("v", 244, 245, 246, 247, " sc1"); break;
-                case 2: ZS_MFMA4("v", 248, 249, 250, 251, " sc1"); break;
-                case 3: ZS_MFMA4("v", 252, 253, 254, 255, " sc1"); break;
-                case 4: ZS_MFMA4("a", 240, 241, 242, 243, " sc1"); break;
-                case 5: ZS_MFMA4("a", 244, 245, 246, 247, " sc1"); break;
-                case 6: ZS_MFMA4("a", 248, 249, 250, 251, " sc1"); break;
-                default: ZS_MFMA4("a", 252, 253, 254, 255, " sc1"); break;
-            }
+#define ZS_ACC_A(x) "+a"(x)
+#define ZS_ACC_V(x) "+v"(x)
+#define ZS_SLOTS(ACC, SUFFIX)                                              \
+        switch (slot) {                                                    \
+            case 0: ZS_MFMA4(ACC, "v", 240, 241, 242, 243, SUFFIX); break; \
+            case 1: ZS_MFMA4(ACC, "v", 244, 245, 246, 247, SUFFIX); break; \
+            case 2: ZS_MFMA4(ACC, "v", 248, 249, 250, 251, SUFFIX); break; \
+            case 3: ZS_MFMA4(ACC, "v", 252, 253, 254, 255, SUFFIX); break; \
+            case 4: ZS_MFMA4(ACC, "a", 240, 241, 242, 243, SUFFIX); break; \
+            case 5: ZS_MFMA4(ACC, "a", 244, 245, 246, 247, SUFFIX); break; \
+            case 6: ZS_MFMA4(ACC, "a", 248, 249, 250, 251, SUFFIX); break; \
+            default: ZS_MFMA4(ACC, "a", 252, 253, 254, 255, SUFFIX); break; \
         }
+        if (VACC) {
+            if (!sc1) { ZS_SLOTS(ZS_ACC_V, "") } else { ZS_SLOTS(ZS_ACC_V, " sc1") }
+        } else {
+            if (!sc1) { ZS_SLOTS(ZS_ACC_A, "") } else { ZS_SLOTS(ZS_ACC_A, " sc1") }
+        }
+#undef ZS_SLOTS
     }
+    template <bool VACC>
     DEV void mfma4(int slot, f32x16 &acc, float b0, float b1, float b2, float b3) {
-        mfma4_from(slot, acc, b0, b1, b2, b3, abase, false);
+        mfma4_from<VACC>(slot, acc, b0, b1, b2, b3, abase, false);
         abase += 64;
     }
     DEV f32x4 next(int slot) {  // weight position whose slot is re-used by a weight position
@@ -209,37 +210,39 @@ struct Stream {
 
 // MFMA results leave asm-land: 16-pass MFMA D -> any reader other than an accumulating MFMA
 // needs ~19 wait states that hipcc does not know about.
-#ifdef ZS_EXP_NO_DONE_NOPS   // timing experiment only (wrong results possible)
-DEV void mfma_done(f32x16 &acc) { asm volatile("" : "+a"(acc)); }
-#else
-DEV void mfma_done(f32x16 &acc) { asm volatile("s_nop 15\n\ts_nop 5" : "+a"(acc)); }
-#endif
+template <bool VACC>
+DEV void mfma_done(f32x16 &acc) {
+    if (VACC)
+        asm volatile("s_nop 15\n\ts_nop 5" : "+v"(acc));
+    else
+        asm volatile("s_nop 15\n\ts_nop 5" : "+a"(acc));
+}
 
 // acc += W_tile * X.  X = KT activation tiles as 16*KT scalars in registers (register r of
 // tile kt is X[16*kt + r]); consumes KT*4 groups starting at ring slot `phase` (kt-major,
 // then register) - the order program.py packs them in.  `phase` (0 or 4) and every index
 // are compile-time constants after unrolling.  Register-resident activations are plain
 // scalars, not f32x16 tuples: only accumulators need 16-register tuples.
-template <int KT>
+template <int KT, bool VACC>
 DEV void gemm_tile(Stream &s, const float *X, f32x16 &acc, int phase) {
 #pragma unroll
     for (int kt = 0; kt < KT; kt++) {
 #pragma unroll
         for (int g = 0; g < 4; g++)
-            s.mfma4((phase + kt * 4 + g) & (RING - 1), acc, X[kt * 16 + 4 * g + 0], X[kt * 16 + 4 * g + 1],
-                    X[kt * 16 + 4 * g + 2], X[kt * 16 + 4 * g + 3]);
+            s.mfma4<VACC>((phase + kt * 4 + g) & (RING - 1), acc, X[kt * 16 + 4 * g + 0],
+                          X[kt * 16 + 4 * g + 1], X[kt * 16 + 4 * g + 2], X[kt * 16 + 4 * g + 3]);
     }
-    mfma_done(acc);
+    mfma_done<VACC>(acc);
 }
 
 // one-tile variant whose B operand is a 16-register activation tile (q, P, o, hidden);
 // `last` = the caller reads acc next (several of these can chain on one accumulator)
-template <typename T>
+template <bool VACC, typename T>
 DEV void gemm_tile_v(Stream &s, const T &X, f32x16 &acc, int phase, bool last = true) {
 #pragma unroll
     for (int g = 0; g < 4; g++)
-        s.mfma4((phase + g) & (RING - 1), acc, X[4 * g + 0], X[4 * g + 1], X[4 * g + 2], X[4 * g + 3]);
-    if (last) mfma_done(acc);
+        s.mfma4<VACC>((phase + g) & (RING - 1), acc, X[4 * g + 0], X[4 * g + 1], X[4 * g + 2], X[4 * g + 3]);
+    if (last) mfma_done<VACC>(acc);
 }
 
 // 8-tile variant with the B operands read from the wave's LDS slab
@@ -247,6 +250,7 @@ DEV void gemm_tile_v(Stream &s, const T &X, f32x16 &acc, int phase, bool last = 
 // group g+1 is issued BEFORE the asm statement of group g (hipcc cannot hoist it itself:
 // LDS reads do not cross the asm statements), i.e. a whole group of MFMAs ahead of its
 // use; otherwise every group paid the LDS latency with the MFMA pipe idle.
+template <bool VACC>
 DEV void gemm_tile_lds(Stream &s, const f32x4 *fl, f32x16 &acc, int phase) {
     f32x4 b = fl[0];
 #pragma unroll
@@ -255,11 +259,11 @@ DEV void gemm_tile_lds(Stream &s, const f32x4 *fl, f32x16 &acc, int phase) {
         for (int g = 0; g < 4; g++) {
             f32x4 bn = b;
             if (kt * 4 + g + 1 < NT * 4) bn = fl[(kt * 4 + g + 1) * 64];
-            s.mfma4((phase + kt * 4 + g) & (RING - 1), acc, b.x, b.y, b.z, b.w);
+            s.mfma4<VACC>((phase + kt * 4 + g) & (RING - 1), acc, b.x, b.y, b.z, b.w);
             b = bn;
         }
     }
-    mfma_done(acc);
+    mfma_done<VACC>(acc);
 }
 
 // one output tile of a skip layer: 32 weight positions (B = x / sqrt(2) in registers), then
@@ -272,17 +276,17 @@ DEV void skip_tile(Stream &s, const float *X, f32x16 &acc, const f32x4 *ztile, i
         const int slot = (phase + q) & (RING - 1);
 #ifdef ZS_EXP_Z_FROM_WEIGHTS  // timing experiment only: workspace read-backs replaced by L2-hot loads
         if (q >= 24 && q < 28)
-            s.mfma4_from(slot, acc, X[4 * q + 0], X[4 * q + 1], X[4 * q + 2], X[4 * q + 3],
-                         s.abase - 4096, false);
+            s.mfma4_from<true>(slot, acc, X[4 * q + 0], X[4 * q + 1], X[4 * q + 2], X[4 * q + 3],
+                               s.abase - 4096, false);
 #else
         if (q >= 24 && q < 28)
-            s.mfma4_from(slot, acc, X[4 * q + 0], X[4 * q + 1], X[4 * q + 2], X[4 * q + 3],
-                         ztile + (q - 24) * 64, true);
+            s.mfma4_from<true>(slot, acc, X[4 * q + 0], X[4 * q + 1], X[4 * q + 2], X[4 * q + 3],
+                               ztile + (q - 24) * 64, true);
 #endif
         else
-            s.mfma4(slot, acc, X[4 * q + 0], X[4 * q + 1], X[4 * q + 2], X[4 * q + 3]);
+            s.mfma4<true>(slot, acc, X[4 * q + 0], X[4 * q + 1], X[4 * q + 2], X[4 * q + 3]);
     }
-    mfma_done(acc);
+    mfma_done<true>(acc);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const f32x4 a = s.next((phase + 32 + j) & (RING - 1));
@@ -389,21 +393,20 @@ DEV void layer_norm_reg(const f32x16 *x, float *h, const float *prm, int g_off, 
 
 // exact-erf GELU (nn.GELU default; timm Mlp): 0.5 x (1 + erf(x / sqrt 2)).
 // erfc(u) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-u^2), t = 1 / (1 + p u), u >= 0
-// (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7); 1 + erf(x/sqrt2) = erfc(|u|) for x < 0
-// and 2 - erfc(|u|) otherwise.  Max abs error of GELU vs fp64: 4.2e-7 (at |x| ~ 3).
+// (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7).
 DEV float gelu_erf(float x) {
+    // GELU(x) = max(x,0) - g,  g = 0.5 |x| erfc(|x|/sqrt2) = u (c t) poly(t) exp(-u^2) with the
+    // 1/sqrt2 folded into the coefficients: 12 VALU + 2 transcendentals, 3.3e-7 max abs error
     const float u = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(fmaf(0.3275911f, u, 1.0f));
-    float p = 1.061405429f;
-    p = fmaf(p, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
+    float p = 0.75052702f;           // 1.061405429 / sqrt2
+    p = fmaf(p, t, -1.02753365f);    // -1.453152027 / sqrt2
+    p = fmaf(p, t, 1.00509130f);     //  1.421413741 / sqrt2
+    p = fmaf(p, t, -0.20116957f);    // -0.284496736 / sqrt2
+    p = fmaf(p, t, 0.18019173f);     //  0.254829592 / sqrt2
     p = p * t;
-    const float w = x * 0.84932180028801904272f;  // sqrt(log2(e) / 2): exp(-u^2) = 2^-(w^2)
-    const float e = p * __builtin_amdgcn_exp2f(-(w * w));
-    const float hx = 0.5f * x;
-    return x < 0.f ? hx * e : hx * (2.0f - e);
+    const float e = __builtin_amdgcn_exp2f((u * u) * -1.44269504088896340736f);
+    return fmaf(-(u * p), e, fmaxf(x, 0.0f));
 }
 
 // torch.nn.Softplus(beta=100, threshold=20): z > 20 ? x : log1p(exp(z)) / 100, z = 100 x,
@@ -429,6 +432,41 @@ DEV void store_tile_lds(f32x4 *fl, int tile, const float *v) {
 // `prm`: LDS params region (phase A: program params [0, P_PHASE_B); phase B: the rest);
 // `fl`: this wave's LDS slab, `zs`: this wave's workspace slab - both already offset by lane
 // except `zs_u`, the same workspace slab as a wave-uniform pointer for the asm loads.
+// One latent tile of the point->latent attention of one head: S = K_tile q (16 MFMAs),
+// online softmax update in the log2 domain, o += V_tile^T P (16 MFMAs).  MASK: the tile is
+// the last one and its rows >= 197 are padding.
+template <bool MASK>
+DEV void attn_tile(Stream &s, const f32x16 &q, f32x16 &o, float &m_run, float &z_run, float c, int hi) {
+    f32x16 S;
+#pragma unroll
+    for (int r = 0; r < 16; r++) S[r] = 0.f;
+    gemm_tile_v<true>(s, q, S, 0);
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        if (MASK) {
+            const int rw = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            S[r] = rw < L - 32 * (LT - 1) ? S[r] : -INFINITY;
+        }
+        mt = fmaxf(mt, S[r]);
+    }
+    mt = fmaxf(mt, xhalf(mt)) * c;
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float zs_ = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(S[r], c, -m_new));
+        S[r] = p;
+        zs_ += p;
+    }
+    z_run = fmaf(z_run, alpha, zs_);
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[r] *= alpha;
+    gemm_tile_v<true>(s, S, o, 4);
+    m_run = m_new;
+}
+
 #ifdef ZS_EXP_TIMING  // phase timestamps of (block 0, wave 0, first tile) -> workspace tail
 #define ZS_STAMP(i) do { if (dbg) dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -462,15 +500,12 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
 #pragma unroll 1
         for (int hd = 0; hd < HEADS; hd++) {
             f32x16 q = rp16(prm, pb + PB_BQKV, hd * 3 + 0, hi);
-            gemm_tile_lds(s, fl, q, 0);
+            gemm_tile_lds<true>(s, fl, q, 0);
             f32x16 k = rp16(prm, pb + PB_BQKV, hd * 3 + 1, hi);
-            gemm_tile_lds(s, fl, k, 0);
+            gemm_tile_lds<true>(s, fl, k, 0);
             f32x16 v = rp16(prm, pb + PB_BQKV, hd * 3 + 2, hi);
-            gemm_tile_lds(s, fl, v, 0);
+            gemm_tile_lds<true>(s, fl, v, 0);
 
-            float qv[16];  // q as plain VGPR scalars: B operand of 7 x 16 MFMAs
-#pragma unroll
-            for (int r = 0; r < 16; r++) qv[r] = q[r];
             // logits are kept in the log2 domain: c = d^-1/2 * log2(e), softmax = 2^(c s - m)
             const float c = scale * 1.44269504088896340736f;
             // self logit (implicit.py:44)
@@ -485,36 +520,8 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
 #pragma unroll
             for (int r = 0; r < 16; r++) o[r] = 0.f;
 #pragma unroll 1
-            for (int lt = 0; lt < LT; lt++) {
-                f32x16 S;
-#pragma unroll
-                for (int r = 0; r < 16; r++) S[r] = 0.f;
-                gemm_tile_v(s, qv, S, 0);
-                const int lim = (lt == LT - 1) ? (L - 32 * (LT - 1)) : 64;  // valid rows in tile
-                float mt = -INFINITY;
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int rw = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const float sv = rw < lim ? S[r] : -INFINITY;
-                    S[r] = sv;
-                    mt = fmaxf(mt, sv);
-                }
-                mt = fmaxf(mt, xhalf(mt)) * c;
-                const float m_new = fmaxf(m_run, mt);
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                float zs_ = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(S[r], c, -m_new));
-                    S[r] = p;
-                    zs_ += p;
-                }
-                z_run = fmaf(z_run, alpha, zs_);
-#pragma unroll
-                for (int r = 0; r < 16; r++) o[r] *= alpha;
-                gemm_tile_v(s, S, o, 4);
-                m_run = m_new;
-            }
+            for (int lt = 0; lt < LT - 1; lt++) attn_tile<false>(s, q, o, m_run, z_run, c, hi);
+            attn_tile<true>(s, q, o, m_run, z_run, c, hi);  // last tile: rows >= 197 masked
             {
                 const float m_new = fmaxf(m_run, s_self);
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -527,7 +534,7 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
             }
             // y += Wproj[:, head] o_h
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++) gemm_tile_v(s, o, y[nt], (nt & 1) * 4, nt == NT - 1);
+            for (int nt = 0; nt < NT; nt++) gemm_tile_v<false>(s, o, y[nt], (nt & 1) * 4, nt == NT - 1);
         }
 
         ZS_STAMP(3 + blk * 4);
@@ -539,11 +546,11 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
 #pragma unroll 1
         for (int ht = 0; ht < HT; ht++) {
             f32x16 hid = rp16(prm, pb + PB_B1, ht, hi);
-            gemm_tile_lds(s, fl, hid, 0);
+            gemm_tile_lds<true>(s, fl, hid, 0);
 #pragma unroll
             for (int r = 0; r < 16; r++) hid[r] = gelu_erf(hid[r]);
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++) gemm_tile_v(s, hid, y[nt], (nt & 1) * 4, nt == NT - 1);
+            for (int nt = 0; nt < NT; nt++) gemm_tile_v<false>(s, hid, y[nt], (nt & 1) * 4, nt == NT - 1);
         }
     }
 
@@ -566,7 +573,7 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
         f32x16 acc = xyz_affine(prm, P_IMPL0 - P_PHASE_B, nt, hi, px, py, pz);
-        gemm_tile<NT>(s, h, acc, 0);
+        gemm_tile<NT, true>(s, h, acc, 0);
         float t[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) t[r] = softplus100(acc[r]);
@@ -587,7 +594,7 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[r] = 0.f;
-            gemm_tile<NT>(s, h, acc, 0);
+            gemm_tile<NT, true>(s, h, acc, 0);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 f32x4 t;
@@ -607,7 +614,7 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
         f32x16 acc = rp16(prm, P_IMPL1 - P_PHASE_B, nt, hi);
-        gemm_tile_lds(s, fl, acc, 0);
+        gemm_tile_lds<true>(s, fl, acc, 0);
 #pragma unroll
         for (int r = 0; r < 16; r++) h[nt * 16 + r] = softplus100(acc[r]) * rsqrt2;
     }
@@ -631,7 +638,7 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
             f32x16 acc = rp16(prm, pp + 1024, nt, hi);
-            gemm_tile_lds(s, fl, acc, 0);
+            gemm_tile_lds<true>(s, fl, acc, 0);
 #pragma unroll
             for (int r = 0; r < 16; r++) h[nt * 16 + r] = softplus100(acc[r]) * post;
         }
