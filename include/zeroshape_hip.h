@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 2
+#define ZS_ABI_VERSION 3
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -88,6 +88,9 @@ size_t zs_sdf_prologue_scratch_bytes(void);
 /* Bytes of the workspace the query kernels need (independent of batch and point count:
  * one 96 KiB slab per resident wave, 96 MiB in all; contents are scratch). */
 size_t zs_sdf_workspace_bytes(void);
+/* Extra workspace bytes zs_sdf_query_points needs BEHIND the fixed part when `attn` is
+ * requested (raw probability tiles: ~14.5 KiB per point). */
+size_t zs_sdf_attn_scratch_bytes(int batch, int m);
 
 /* Fill the per-image K/V records of `programs[i]` (i < batch; programs are
  * program_stride_bytes apart, each initialised by copying the packed weights)
@@ -98,7 +101,9 @@ int zs_sdf_prologue(void *programs, size_t program_stride_bytes, const float *la
 
 /* logits[batch][m] = Implicit(latent, None, points[batch][m][3]) (pre-sigmoid).
  * attn (optional, may be NULL): [batch][m][197] = mean over heads and blocks of the
- * point->latent attention probabilities (implicit.py:63,79,277). */
+ * point->latent attention probabilities (implicit.py:63,79,277; the self column is
+ * excluded after the softmax over 198, so rows sum to < 1).  When given, `workspace` must
+ * hold zs_sdf_workspace_bytes() + zs_sdf_attn_scratch_bytes(batch, m) bytes. */
 int zs_sdf_query_points(const void *programs, size_t program_stride_bytes, int batch,
                         const float *points, int m, float *logits, float *attn,
                         void *workspace, void *stream);

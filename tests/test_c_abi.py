@@ -43,6 +43,8 @@ def test_versions_and_sizes(lib):
     assert lib.zs_sdf_program_bytes() == P.PROGRAM_BYTES
     assert lib.zs_sdf_prologue_scratch_bytes() == P.SCRATCH_FLOATS * 4
     assert lib.zs_sdf_workspace_bytes() == 256 * 4 * 3 * 32768 + 4096
+    assert lib.zs_sdf_attn_scratch_bytes(2, 129) == 2 * 2 * 4 * (16 * 7 * 4 * 64 * 16 + 16 * 9 * 64 * 4)
+    assert lib.zs_sdf_attn_scratch_bytes(0, 5) == 0
     assert lib.zs_last_error() in (b"", None) or isinstance(lib.zs_last_error(), bytes)
 
 

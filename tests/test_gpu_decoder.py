@@ -59,9 +59,25 @@ def test_training_shape_points_vs_golden(net, decoder_golden):
     latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=2)).cuda()
     rs = np.random.RandomState(123)
     pts = torch.from_numpy(rs.uniform(-1, 1, size=(2, 4096, 3)).astype(np.float32)).cuda()
-    lg, attn = net(latent, None, pts)
+    lg, attn = net(latent, None, pts, need_attn=False)
     assert attn is None and lg.shape == (2, 4096) and lg.dtype == torch.float32
     np.testing.assert_allclose(lg.cpu().numpy(), decoder_golden["pts4096_logit"], atol=ATOL, rtol=0)
+    # default call = the reference's contract: (logits, attn [B,M,197])
+    lg2, attn = net(latent, None, pts)
+    assert torch.equal(lg2, lg), "the attention variant must not change the logits"
+    assert attn.shape == (2, 4096, 197)
+    np.testing.assert_allclose(attn[:, ::512].cpu().numpy(), decoder_golden["pts4096_attn_rows"], atol=2e-7, rtol=0)
+    np.testing.assert_allclose(attn.sum(-1).cpu().numpy(), decoder_golden["pts4096_attn_rowsum"], atol=2e-6, rtol=0)
+
+
+def test_attention_map_vs_oracle_ragged(net, seeded_sd):
+    latent = torch.from_numpy(syn.seeded_latent(seed=5, batch=2))
+    pts = torch.from_numpy(syn.seeded_cloud(77, 2, 333, -1.5, 1.5))
+    want_l, want_a = R.implicit_forward(seeded_sd, latent, pts)
+    got_l, got_a = net(latent.cuda(), None, pts.cuda())
+    np.testing.assert_allclose(got_l.cpu().numpy(), want_l.numpy(), atol=ATOL, rtol=0)
+    np.testing.assert_allclose(got_a.cpu().numpy(), want_a.numpy(), atol=2e-7, rtol=0)
+    assert bool(torch.all(got_a.sum(-1) < 1.0))     # self column excluded after the softmax
 
 
 @pytest.mark.parametrize("m", [1, 31, 32, 33, 127, 128, 129, 1000])
@@ -69,14 +85,14 @@ def test_ragged_point_counts_vs_oracle(net, seeded_sd, m):
     latent = torch.from_numpy(syn.seeded_latent(seed=3, batch=1))
     pts = torch.from_numpy(syn.seeded_cloud(m, 1, m, -1.5, 1.5))
     want, _ = R.implicit_forward(seeded_sd, latent, pts)
-    got, _ = net(latent.cuda(), None, pts.cuda())
+    got, _ = net(latent.cuda(), None, pts.cuda(), need_attn=False)
     np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=ATOL, rtol=0)
 
 
 def test_empty_points(net):
     latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=1)).cuda()
-    lg, _ = net(latent, None, torch.zeros(1, 0, 3).cuda())
-    assert lg.shape == (1, 0)
+    lg, at = net(latent, None, torch.zeros(1, 0, 3).cuda())
+    assert lg.shape == (1, 0) and at.shape == (1, 0, 197)
 
 
 def test_grid32_full_vs_golden(net, decoder_golden):
@@ -168,10 +184,10 @@ def test_full_size_grid128_properties(net, seeded_sd):
 def test_weights_update_repacks(net, seeded_sd):
     latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=1)).cuda()
     pts = torch.from_numpy(syn.seeded_cloud(5, 1, 64, -1, 1)).cuda()
-    a, _ = net(latent, None, pts)
+    a, _ = net(latent, None, pts, need_attn=False)
     with torch.no_grad():
         net.impl_mlp.layers[8].bias.add_(0.25)
-    b, _ = net(latent, None, pts)
+    b, _ = net(latent, None, pts, need_attn=False)
     np.testing.assert_allclose((b - a).cpu().numpy(), 0.25, atol=1e-6)
     with torch.no_grad():
         net.impl_mlp.layers[8].bias.sub_(0.25)

@@ -25,6 +25,7 @@ SIGNATURES = {
     "zs_sdf_program_bytes": (_c_size_t, []),
     "zs_sdf_prologue_scratch_bytes": (_c_size_t, []),
     "zs_sdf_workspace_bytes": (_c_size_t, []),
+    "zs_sdf_attn_scratch_bytes": (_c_size_t, [_c_int, _c_int]),
     "zs_sdf_prologue": (_c_int, [_c_void_p, _c_size_t, _c_void_p, _c_void_p, _c_int,
                                  _c_void_p, _c_void_p]),
     "zs_sdf_query_points": (_c_int, [_c_void_p, _c_size_t, _c_int, _c_void_p, _c_int,
@@ -33,7 +34,7 @@ SIGNATURES = {
                                    _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 

@@ -43,6 +43,9 @@ constexpr int PTS_PER_BLOCK = WAVES * PTS_PER_WAVE;
 constexpr int MAX_WGS = 256;                       // one persistent workgroup per CU
 constexpr int SLAB_F4 = NT * 4 * 64;               // one activation array as float4 groups: 32 KiB
 constexpr int ZSLAB_F4 = 3 * SLAB_F4;              // three skip layers' feat partial products
+constexpr int ATTN_P_F4 = BLOCKS * HEADS * LT * 4 * 64;      // raw P tiles per wave tile (float4)
+constexpr int ATTN_ST_F = BLOCKS * HEADS * 9 * 64;          // 7 reference maxima + final max + 1/Z per lane
+constexpr int ATTN_WT_F4 = ATTN_P_F4 + ATTN_ST_F / 4;       // per wave tile
 constexpr size_t WORKSPACE_BYTES = (size_t)MAX_WGS * WAVES * ZSLAB_F4 * sizeof(f32x4) + 4096;  // + debug tail
 
 #define DEV __device__ __forceinline__
@@ -435,8 +438,11 @@ DEV void store_tile_lds(f32x4 *fl, int tile, const float *v) {
 // One latent tile of the point->latent attention of one head: S = K_tile q (16 MFMAs),
 // online softmax update in the log2 domain, o += V_tile^T P (16 MFMAs).  MASK: the tile is
 // the last one and its rows >= 197 are padding.
-template <bool MASK>
-DEV void attn_tile(Stream &s, const f32x16 &q, f32x16 &o, float &m_run, float &z_run, float c, int hi) {
+// ATTN: also dump the un-normalised probabilities and their reference maximum for the
+// attention-visualisation output (normalised and averaged by attn_reduce_kernel).
+template <bool MASK, bool ATTN>
+DEV void attn_tile(Stream &s, const f32x16 &q, f32x16 &o, float &m_run, float &z_run, float c, int hi,
+                   f32x4 *praw, float *pstat) {
     f32x16 S;
 #pragma unroll
     for (int r = 0; r < 16; r++) S[r] = 0.f;
@@ -461,6 +467,15 @@ DEV void attn_tile(Stream &s, const f32x16 &q, f32x16 &o, float &m_run, float &z
         zs_ += p;
     }
     z_run = fmaf(z_run, alpha, zs_);
+    if (ATTN) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            f32x4 t;
+            t.x = S[4 * j + 0]; t.y = S[4 * j + 1]; t.z = S[4 * j + 2]; t.w = S[4 * j + 3];
+            praw[j * 64] = t;
+        }
+        *pstat = m_new;
+    }
 #pragma unroll
     for (int r = 0; r < 16; r++) o[r] *= alpha;
     gemm_tile_v<true>(s, S, o, 4);
@@ -472,9 +487,10 @@ DEV void attn_tile(Stream &s, const f32x16 &q, f32x16 &o, float &m_run, float &z
 #else
 #define ZS_STAMP(i) do { } while (0)
 #endif
+template <bool ATTN>
 DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, float *prm, f32x4 *fl,
                       f32x4 *zs, const f32x4 *zs_u, float px, float py, float pz, int lane,
-                      unsigned long long *dbg) {
+                      unsigned long long *dbg, f32x4 *araw) {
     const int hi = lane >> 5;
     ZS_STAMP(0);
     Stream s;
@@ -519,15 +535,25 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
             f32x16 o;
 #pragma unroll
             for (int r = 0; r < 16; r++) o[r] = 0.f;
+            // attention-vis dump slots of this (block, head): raw P tiles + per-lane statistics
+            f32x4 *praw = ATTN ? araw + ((blk * HEADS + hd) * LT) * 256 + lane : nullptr;
+            float *pstat = ATTN ? reinterpret_cast<float *>(araw + ATTN_P_F4) + (blk * HEADS + hd) * 9 * 64 + lane
+                                : nullptr;
 #pragma unroll 1
-            for (int lt = 0; lt < LT - 1; lt++) attn_tile<false>(s, q, o, m_run, z_run, c, hi);
-            attn_tile<true>(s, q, o, m_run, z_run, c, hi);  // last tile: rows >= 197 masked
+            for (int lt = 0; lt < LT - 1; lt++)
+                attn_tile<false, ATTN>(s, q, o, m_run, z_run, c, hi, praw + lt * 256, pstat + lt * 64);
+            attn_tile<true, ATTN>(s, q, o, m_run, z_run, c, hi, praw + (LT - 1) * 256,
+                                  pstat + (LT - 1) * 64);  // last tile: rows >= 197 masked
             {
                 const float m_new = fmaxf(m_run, s_self);
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
                 const float p_self = __builtin_amdgcn_exp2f(s_self - m_new);
                 const float z = fmaf(z_run + xhalf(z_run), alpha, p_self);
                 const float inv = 1.0f / z;
+                if (ATTN) {
+                    pstat[7 * 64] = m_new;
+                    pstat[8 * 64] = inv;
+                }
                 const float a_i = alpha * inv, p_i = p_self * inv;
 #pragma unroll
                 for (int r = 0; r < 16; r++) o[r] = fmaf(p_i, v[r], o[r] * a_i);
@@ -659,14 +685,15 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
     return out + prm[P_B8 - P_PHASE_B];
 }
 
-template <bool GRID>
+template <bool GRID, bool ATTN>
 __global__ __launch_bounds__(WAVES * 64, 1) __attribute__((amdgpu_num_vgpr(240))) void sdf_decode_kernel(
     const float *__restrict__ programs, size_t program_stride_floats, int batch,
     const float *__restrict__ points,  // !GRID: [batch][m][3]
     const float *__restrict__ axis,    //  GRID: [G]
     int G, long long first_point,      //  GRID: linear index of the first grid point
     int m,                             // points per image handled by this launch
-    float *__restrict__ out, int apply_sigmoid, f32x4 *__restrict__ workspace) {
+    float *__restrict__ out, int apply_sigmoid, f32x4 *__restrict__ workspace,
+    f32x4 *__restrict__ attn_raw) {  // ATTN: [wave tile][ATTN_WT_F4]
     // LDS: [params 32 KiB][4 x 32 KiB activation slabs] = 160 KiB, one workgroup per CU
     __shared__ __attribute__((aligned(16))) float lds[P_PHASE_B + WAVES * SLAB_F4 * 4];
     float *prm = lds;
@@ -716,9 +743,41 @@ __global__ __launch_bounds__(WAVES * 64, 1) __attribute__((amdgpu_num_vgpr(240))
 #else
         unsigned long long *dbg = nullptr;
 #endif
-        float logit = decode_tile(recs, prog + REC_FLOATS, prm, fl, zslab + lane, zs_u, px, py, pz, lane, dbg);
+        f32x4 *araw = ATTN ? attn_raw + ((size_t)tile * WAVES + wave) * ATTN_WT_F4 : nullptr;
+        float logit = decode_tile<ATTN>(recs, prog + REC_FLOATS, prm, fl, zslab + lane, zs_u, px, py, pz,
+                                        lane, dbg, araw);
         if (apply_sigmoid) logit = 1.0f / (1.0f + expf(-logit));
         if (lane < 32 && p < m) out[(size_t)img * m + p] = logit;
+    }
+}
+
+// attention-visualisation epilogue (implicit.py:63,79,277): attn[img][p][l] = mean over the 16
+// (block, head) pairs of softmax probabilities of latent l, from the raw tiles dumped by the
+// ATTN kernel: P_raw * 2^(m_ref - m_final) / Z.
+__global__ __launch_bounds__(256) void attn_reduce_kernel(const f32x4 *__restrict__ raw,
+                                                          float *__restrict__ attn, int batch, int m) {
+    const int tiles_per_img = (m + PTS_PER_BLOCK - 1) / PTS_PER_BLOCK;
+    const long long total = (long long)batch * m * L;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
+         e += (long long)gridDim.x * 256) {
+        const int l = (int)(e % L);
+        const long long ip = e / L;
+        const int p = (int)(ip % m);
+        const int img = (int)(ip / m);
+        const int t = p / PTS_PER_BLOCK, wave = (p % PTS_PER_BLOCK) / PTS_PER_WAVE, tp = p % PTS_PER_WAVE;
+        const f32x4 *w = raw + (((size_t)img * tiles_per_img + t) * WAVES + wave) * ATTN_WT_F4;
+        const float *st = reinterpret_cast<const float *>(w + ATTN_P_F4);
+        const int lt = l >> 5, row = l & 31;
+        const int hi = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);
+        const int lane = tp + 32 * hi;
+        float acc = 0.f;
+        for (int bh = 0; bh < BLOCKS * HEADS; bh++) {
+            const f32x4 pv = w[((bh * LT + lt) * 4 + (r >> 2)) * 64 + lane];
+            const float pr = (r & 3) == 0 ? pv.x : (r & 3) == 1 ? pv.y : (r & 3) == 2 ? pv.z : pv.w;
+            const float *sb = st + bh * 9 * 64 + lane;
+            acc += pr * __builtin_amdgcn_exp2f(sb[lt * 64] - sb[7 * 64]) * sb[8 * 64];
+        }
+        attn[e] = acc * (1.0f / (BLOCKS * HEADS));
     }
 }
 
@@ -731,6 +790,11 @@ int decode_grid_size(int batch, int m) {
 
 extern "C" size_t zs_sdf_program_bytes(void) { return (size_t)PROGRAM_FLOATS * sizeof(float); }
 extern "C" size_t zs_sdf_workspace_bytes(void) { return WORKSPACE_BYTES; }
+extern "C" size_t zs_sdf_attn_scratch_bytes(int batch, int m) {
+    if (batch <= 0 || m <= 0) return 0;
+    const size_t wave_tiles = (size_t)batch * ((m + PTS_PER_BLOCK - 1) / PTS_PER_BLOCK) * WAVES;
+    return wave_tiles * ATTN_WT_F4 * sizeof(f32x4);
+}
 
 extern "C" int zs_sdf_query_points(const void *programs, size_t program_stride_bytes, int batch,
                                    const float *points, int m, float *logits, float *attn,
@@ -744,10 +808,6 @@ extern "C" int zs_sdf_query_points(const void *programs, size_t program_stride_b
         zs::set_err("zs_sdf_query_points: null pointer");
         return 0;
     }
-    if (attn) {
-        zs::set_err("zs_sdf_query_points: attention output not implemented in this build");
-        return 0;
-    }
     if (program_stride_bytes % 16 != 0 || program_stride_bytes < zs_sdf_program_bytes()) {
         zs::set_err("zs_sdf_query_points: bad program stride %zu", program_stride_bytes);
         return 0;
@@ -756,10 +816,23 @@ extern "C" int zs_sdf_query_points(const void *programs, size_t program_stride_b
         zs::set_err("zs_sdf_query_points: too many tiles");
         return 0;
     }
-    hipLaunchKernelGGL(sdf_decode_kernel<false>, dim3(decode_grid_size(batch, m)), dim3(WAVES * 64), 0,
-                       static_cast<hipStream_t>(stream), static_cast<const float *>(programs),
-                       program_stride_bytes / sizeof(float), batch, points, nullptr, 0, 0LL, m, logits,
-                       0, static_cast<f32x4 *>(workspace));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!attn) {
+        hipLaunchKernelGGL((sdf_decode_kernel<false, false>), dim3(decode_grid_size(batch, m)),
+                           dim3(WAVES * 64), 0, st, static_cast<const float *>(programs),
+                           program_stride_bytes / sizeof(float), batch, points, nullptr, 0, 0LL, m, logits,
+                           0, static_cast<f32x4 *>(workspace), nullptr);
+    } else {
+        // raw tiles live behind the fixed part of the workspace (zs_sdf_attn_scratch_bytes)
+        f32x4 *raw = reinterpret_cast<f32x4 *>(static_cast<char *>(workspace) + WORKSPACE_BYTES);
+        hipLaunchKernelGGL((sdf_decode_kernel<false, true>), dim3(decode_grid_size(batch, m)),
+                           dim3(WAVES * 64), 0, st, static_cast<const float *>(programs),
+                           program_stride_bytes / sizeof(float), batch, points, nullptr, 0, 0LL, m, logits,
+                           0, static_cast<f32x4 *>(workspace), raw);
+        const long long total = (long long)batch * m * L;
+        int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(attn_reduce_kernel, dim3(blocks), dim3(256), 0, st, raw, attn, batch, m);
+    }
     return zs::check_launch("zs_sdf_query_points") ? 1 : 0;
 }
 
@@ -786,10 +859,10 @@ extern "C" int zs_sdf_query_grid(const void *programs, size_t program_stride_byt
         return 0;
     }
     const int m = (int)mm;
-    hipLaunchKernelGGL(sdf_decode_kernel<true>, dim3(decode_grid_size(batch, m)), dim3(WAVES * 64), 0,
-                       static_cast<hipStream_t>(stream), static_cast<const float *>(programs),
-                       program_stride_bytes / sizeof(float), batch, nullptr, axis, G,
-                       (long long)slice_begin * G * G, m, out, apply_sigmoid,
-                       static_cast<f32x4 *>(workspace));
+    hipLaunchKernelGGL((sdf_decode_kernel<true, false>), dim3(decode_grid_size(batch, m)),
+                       dim3(WAVES * 64), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float *>(programs), program_stride_bytes / sizeof(float), batch,
+                       nullptr, axis, G, (long long)slice_begin * G * G, m, out, apply_sigmoid,
+                       static_cast<f32x4 *>(workspace), nullptr);
     return zs::check_launch("zs_sdf_query_grid") ? 1 : 0;
 }

@@ -12,10 +12,8 @@ half) + csrc/sdf_decoder.hip (per point, fused) through the C ABI of
 include/zeroshape_hip.h.  There is no PyTorch fallback: without the library, or for a
 configuration the kernels are not specialised for, this module raises.
 
-Not yet on the HIP path (raises / returns None, never silently approximated):
+Not yet on the HIP path (raises, never silently approximated):
   * autograd through the decoder (training, graph_shape.py:185) - inference only;
-  * the attention-visualisation output: ``attn`` is None unless requested, and
-    requesting it raises NotImplementedError in this round;
   * ``semantic=True`` / ``posenc_3D>0`` / ``pos_perlayer=True`` variants (unused by
     options/shape.yaml).
 """
@@ -155,13 +153,13 @@ class Implicit(nn.Module):
             self._packed = (key, prog, lat)
         return self._packed[1], self._packed[2]
 
-    def workspace(self, device):
-        """Scratch for the query kernels (zs_sdf_workspace_bytes(), one per device; launches
-        on one stream serialise, so sharing it is safe)."""
+    def workspace(self, device, extra_bytes=0):
+        """Scratch for the query kernels (zs_sdf_workspace_bytes() [+ the attention dump], one
+        per device; launches on one stream serialise, so sharing it is safe)."""
         key = str(device)
-        if key not in self._workspace:
-            n = _lib.load().zs_sdf_workspace_bytes()
-            self._workspace[key] = torch.empty(n // 4, dtype=torch.float32, device=device)
+        need = (_lib.load().zs_sdf_workspace_bytes() + extra_bytes + 3) // 4
+        if key not in self._workspace or self._workspace[key].numel() < need:
+            self._workspace[key] = torch.empty(need, dtype=torch.float32, device=device)
         return self._workspace[key]
 
     @torch.no_grad()
@@ -187,8 +185,9 @@ class Implicit(nn.Module):
         return DecoderState(programs, B)
 
     @torch.no_grad()
-    def query_points(self, state, points_3D):
-        """state from prepare(); points_3D [B,M,3] -> logits [B,M] fp32."""
+    def query_points(self, state, points_3D, need_attn=False):
+        """state from prepare(); points_3D [B,M,3] -> logits [B,M] fp32 (and, with need_attn,
+        the attention map [B,M,197] of implicit.py:277)."""
         lib = _lib.load()
         pts = points_3D.detach().to(torch.float32).contiguous()
         if pts.dim() != 3 or pts.shape[2] != 3 or pts.shape[0] != state.batch:
@@ -197,13 +196,17 @@ class Implicit(nn.Module):
             raise ValueError("points_3D and latent_depth live on different devices")
         M = pts.shape[1]
         out = torch.empty(state.batch, M, dtype=torch.float32, device=pts.device)
+        attn, extra = None, 0
+        if need_attn:
+            attn = torch.empty(state.batch, M, P.L, dtype=torch.float32, device=pts.device)
+            extra = lib.zs_sdf_attn_scratch_bytes(state.batch, M)
         with torch.cuda.device(pts.device):
             rc = lib.zs_sdf_query_points(_lib.ptr(state.programs), state.stride_bytes, state.batch,
-                                         _lib.ptr(pts), M, _lib.ptr(out), None,
-                                         _lib.ptr(self.workspace(pts.device)),
+                                         _lib.ptr(pts), M, _lib.ptr(out), _lib.ptr(attn),
+                                         _lib.ptr(self.workspace(pts.device, extra)),
                                          _lib.current_stream_ptr(pts.device))
         _lib.check(rc, "zs_sdf_query_points")
-        return out
+        return (out, attn) if need_attn else out
 
     @torch.no_grad()
     def query_grid(self, latent_depth, axis, apply_sigmoid=True, slice_begin=0, slice_end=None,
@@ -230,8 +233,10 @@ class Implicit(nn.Module):
         _lib.check(rc, "zs_sdf_query_grid")
         return out
 
-    def forward(self, latent_depth, latent_semantic, points_3D, need_attn=False):
-        """implicit.py:251-288.  Returns (logits [B,M], attn | None)."""
+    def forward(self, latent_depth, latent_semantic, points_3D, need_attn=True):
+        """implicit.py:251-288.  Returns (logits [B,M], attn [B,M,197]) like the reference;
+        callers that drop the attention map (our compute_level_grid without vis, training-shape
+        probes) pass need_attn=False and get (logits, None) from the faster kernel variant."""
         if self.semantic or latent_semantic is not None:
             raise NotImplementedError("semantic latent codes are not used by options/shape.yaml")
         if torch.is_grad_enabled() and (points_3D.requires_grad or latent_depth.requires_grad
@@ -239,7 +244,7 @@ class Implicit(nn.Module):
                 and self.training:
             raise NotImplementedError("autograd through the HIP decoder is not implemented yet "
                                       "(inference only); call under torch.no_grad() / .eval()")
-        if need_attn:
-            raise NotImplementedError("attention visualisation output is not on the HIP path yet")
         state = self.prepare(latent_depth)
+        if need_attn:
+            return self.query_points(state, points_3D, need_attn=True)
         return self.query_points(state, points_3D), None

@@ -76,8 +76,12 @@ def compute_level_grid(opt, impl_network, latent_depth, latent_semantic, points_
 
     pts = points_3D.view(batch_size, N, N * N, 3)
     occ, attn = [], []
+    hip_net = hasattr(impl_network, "query_grid")
     for i in range(N):
-        occ_slice, attn_slice = impl_network(latent_depth, latent_semantic, pts[:, i])
+        if hip_net:   # our decoder: skip the attention dump unless it is going to be drawn
+            occ_slice, attn_slice = impl_network(latent_depth, latent_semantic, pts[:, i], need_attn=vis_attn)
+        else:
+            occ_slice, attn_slice = impl_network(latent_depth, latent_semantic, pts[:, i])
         occ.append(occ_slice)
         if vis_attn:
             attn.append(attn_slice.detach())
