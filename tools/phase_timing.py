@@ -1,3 +1,14 @@
+#!/usr/bin/env python3
+"""Per-phase cycle stamps of the fused decoder (one wave, first tile).
+
+Build the instrumented library and run on the GPU box:
+
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I include -DZS_EXP_TIMING \
+          -c zeroshape_amd/csrc/sdf_decoder.hip -o /tmp/sdf_T.o
+    hipcc --offload-arch=gfx950 -shared -fPIC -o exp/lib_TIMING.so /tmp/sdf_T.o \
+          zeroshape_amd/csrc/_obj/{chamfer,common,sdf_prologue}.o
+    ZS_LIB_PATH=$PWD/exp/lib_TIMING.so python tools/phase_timing.py
+"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -277,15 +277,9 @@ DEV void skip_tile(Stream &s, const float *X, f32x16 &acc, const f32x4 *ztile, i
 #pragma unroll
     for (int q = 0; q < 32; q++) {
         const int slot = (phase + q) & (RING - 1);
-#ifdef ZS_EXP_Z_FROM_WEIGHTS  // timing experiment only: workspace read-backs replaced by L2-hot loads
-        if (q >= 24 && q < 28)
-            s.mfma4_from<true>(slot, acc, X[4 * q + 0], X[4 * q + 1], X[4 * q + 2], X[4 * q + 3],
-                               s.abase - 4096, false);
-#else
         if (q >= 24 && q < 28)
             s.mfma4_from<true>(slot, acc, X[4 * q + 0], X[4 * q + 1], X[4 * q + 2], X[4 * q + 3],
                                ztile + (q - 24) * 64, true);
-#endif
         else
             s.mfma4<true>(slot, acc, X[4 * q + 0], X[4 * q + 1], X[4 * q + 2], X[4 * q + 3]);
     }
@@ -482,7 +476,7 @@ DEV void attn_tile(Stream &s, const f32x16 &q, f32x16 &o, float &m_run, float &z
     m_run = m_new;
 }
 
-#ifdef ZS_EXP_TIMING  // phase timestamps of (block 0, wave 0, first tile) -> workspace tail
+#ifdef ZS_EXP_TIMING  // tools/phase_timing.py: cycle stamps of (block 0, wave 0, first tile) -> workspace tail
 #define ZS_STAMP(i) do { if (dbg) dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define ZS_STAMP(i) do { } while (0)
@@ -631,9 +625,7 @@ DEV float decode_tile(const f32x4 *recs, const float *__restrict__ prog_params, 
     }
     // the Z stores must have reached L2 before the sc1 read-backs (>= 256 groups later; this
     // drain is a formality that costs one ring refill per tile)
-#ifndef ZS_EXP_NO_ZDRAIN
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
 
     ZS_STAMP(12);
     // layer 1 (plain): LDS -> registers, pre-divided by sqrt(2) because layer 2 is a skip layer
