@@ -168,12 +168,13 @@ def chamfer_distance(opt, X1, X2):
 
 
 def brute_force_search(pc_pred, pc_gt, f_thresholds=[0.005, 0.01, 0.02, 0.05, 0.1, 0.2], device="cuda",
-                       rotations=None, rot_slice=None, return_index=False):
+                       rotations=None, rot_slice=None, return_index=False, batch_size=192):
     """utils/eval_3D.py:140-170: best rigid alignment over the 6912-rotation sphere by
-    Chamfer-L1.  Same batches of 24 and the same strict-first-minimum rule, but the
-    winner of each batch is picked on the device (one argmin + one sync per batch
-    instead of 24 ``if cd[j] < best_cd`` syncs, :161-168) and the rotation table is
-    cached.  ``rot_slice=(start, stop)`` restricts the scan to a contiguous range of
+    Chamfer-L1.  Same scan order and the same strict-first-minimum rule, but rotations are
+    evaluated ``batch_size`` at a time (the reference: 24, :149 - every rotation is
+    independent, so the batch size only changes the number of launches), the winner of each
+    batch is picked on the device (one argmin + one sync per batch instead of one
+    ``if cd[j] < best_cd`` sync per rotation, :161-168) and the rotation table is cached.  ``rot_slice=(start, stop)`` restricts the scan to a contiguous range of
     rotation indices (multi-GPU sharding, see zeroshape_amd/parallel.py);
     ``return_index`` appends the winning global rotation index and its cd."""
     pc_pred = pc_pred.to(device).unsqueeze(0).float()
@@ -183,7 +184,6 @@ def brute_force_search(pc_pred, pc_gt, f_thresholds=[0.005, 0.01, 0.02, 0.05, 0.
         rotations = get_rotation_sphere(azim_sample=24, elev_sample=24, roll_sample=12, scales=[1.0],
                                         device=device)
     start, stop = (0, len(rotations)) if rot_slice is None else rot_slice
-    batch_size = 24
     best_cd = np.inf
     best = None
     for i in range(start, stop, batch_size):
