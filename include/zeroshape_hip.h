@@ -17,8 +17,8 @@
  *   zs_sdf_*             <- Implicit.forward, model/shape/implicit.py:251-288, as it is
  *                           driven by compute_level_grid, utils/eval_3D.py:22-45, and
  *                           get_dense_3D_grid, utils/eval_3D.py:11-20
- *   zs_bf_*              <- brute_force_search inner loop, utils/eval_3D.py:150-168
- *                           (rotate + normalize_pc :93-102 + chamfer + compute_fscore :215-231)
+ *   zs_mc_*, zs_mesh_*   <- convert_to_explicit, utils/eval_3D.py:233-263 (PyMCubes
+ *                           marching_cubes + trimesh.sample on the host)
  * INTEGRATION.md shows the binding a maintainer of the reference would add.
  */
 #ifndef ZEROSHAPE_HIP_H
@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 3
+#define ZS_ABI_VERSION 4
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -118,6 +118,29 @@ int zs_sdf_query_points(const void *programs, size_t program_stride_bytes, int b
 int zs_sdf_query_grid(const void *programs, size_t program_stride_bytes, int batch,
                       const float *axis, int G, int slice_begin, int slice_end,
                       int apply_sigmoid, float *out, void *workspace, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Iso-surface extraction + surface sampling (replaces convert_to_explicit,
+ * utils/eval_3D.py:233-263: PyMCubes marching_cubes + trimesh sample on the host).
+ * Case tables come from the caller (zeroshape_amd/mc_tables.py): tri_table int8
+ * [256][table_stride] (edge ids, -1 padded), tri_count uint8 [256].
+ *
+ *   zs_mc_count  : per-cube triangle counts -> exclusive block offsets in `scratch`
+ *                  (zs_mc_scratch_bytes(G)) and the grand total in *total (device int)
+ *   zs_mc_emit   : tris[n_tris][3][3] fp32 triangle soup in world space
+ *                  (index * scale + offset), cube order x-slowest, deterministic
+ *   zs_mesh_sample: n_samples area-weighted points (counter-based RNG, `seed`);
+ *                  cum_area = scratch of n_tris doubles; an empty mesh yields zeros
+ * vol is [G][G][G] fp32 (x slowest), a cube corner is "inside" when value < iso.
+ * ------------------------------------------------------------------------- */
+size_t zs_mc_scratch_bytes(int G);
+int zs_mc_count(const float *vol, int G, float iso, const uint8_t *tri_count, void *scratch,
+                int *total, void *stream);
+int zs_mc_emit(const float *vol, int G, float iso, const int8_t *tri_table, int table_stride,
+               const uint8_t *tri_count, const void *scratch, float scale, float offset,
+               float *tris, int n_tris, void *stream);
+int zs_mesh_sample(const float *tris, int n_tris, int n_samples, uint64_t seed, double *cum_area,
+                   float *points, void *stream);
 
 #ifdef __cplusplus
 }

@@ -32,9 +32,14 @@ SIGNATURES = {
                                      _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "zs_sdf_query_grid": (_c_int, [_c_void_p, _c_size_t, _c_int, _c_void_p, _c_int, _c_int,
                                    _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "zs_mc_scratch_bytes": (_c_size_t, [_c_int]),
+    "zs_mc_count": (_c_int, [_c_void_p, _c_int, ctypes.c_float, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "zs_mc_emit": (_c_int, [_c_void_p, _c_int, ctypes.c_float, _c_void_p, _c_int, _c_void_p, _c_void_p,
+                            ctypes.c_float, ctypes.c_float, _c_void_p, _c_int, _c_void_p]),
+    "zs_mesh_sample": (_c_int, [_c_void_p, _c_int, _c_int, ctypes.c_uint64, _c_void_p, _c_void_p, _c_void_p]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lib = None
 
 

@@ -9,18 +9,17 @@ argument meaning and return values, running on the hand-written HIP kernels.
   compute_fscore      utils/eval_3D.py:215-231
   chamfer_distance    utils/eval_3D.py:265-269
   ICP                 utils/eval_3D.py:271-284
+  eval_metrics(_default|_BF)  utils/eval_3D.py:104-138,172-213
+  convert_to_explicit utils/eval_3D.py:233-263  (GPU marching cubes + sampling)
 
 torch is used here for device memory, streams and the tiny elementwise glue the
 reference also does in torch (means, extents, thresholds); the heavy steps - the
 decoder over the dense grid and the nearest-neighbour search - are the HIP
 kernels, and they raise if libzeroshape_hip.so is missing (no fallback).
 
-Out of scope here: convert_to_explicit / eval_metrics*
-need PyMCubes + trimesh on the host (utils/eval_3D.py:233-263), neither of which
-is in this image; ``convert_to_explicit`` imports them lazily and raises a clear
-error when absent.
+``convert_to_explicit`` (utils/eval_3D.py:233-263: PyMCubes + trimesh on the host in the
+reference) runs on the GPU here: csrc/marching_cubes.hip.
 """
-import threading
 
 import numpy as np
 import torch
@@ -208,6 +207,88 @@ def brute_force_search(pc_pred, pc_gt, f_thresholds=[0.005, 0.01, 0.02, 0.05, 0.
     return out
 
 
+def _surface_clouds(opt, level_vox, seed=0):
+    """level grids [B,G,G,G] (GPU tensor) -> (meshes, dpc_pred [B,num_points,3] fp32 on the
+    device): convert_to_explicit without the device->host->device round trip of the
+    reference (utils/eval_3D.py:115-118,181-184)."""
+    meshes, clouds = [], []
+    range_min, range_max = opt.eval.range
+    for i in range(level_vox.shape[0]):
+        tris, pts = extract_surface(level_vox[i], 0.5, range_min, range_max, opt.eval.num_points, seed + i)
+        meshes.append(SimpleMesh(tris.cpu().numpy()))
+        clouds.append(pts)
+    return meshes, torch.stack(clouds, dim=0)
+
+
+def _gt_to_view_frame(opt, var):
+    # utils/eval_3D.py:120-123 / :186-190
+    R_gt = var.pose_gt[..., :3]
+    var.dpc.points = (R_gt @ var.dpc.points.permute(0, 2, 1)).permute(0, 2, 1).contiguous()
+    if opt.data.dataset_test == 'pix3d':
+        var.dpc.points[:, :, :2] *= -1
+
+
+@torch.no_grad()
+def eval_metrics_default(opt, var, impl_network, vis_only=False):
+    """utils/eval_3D.py:104-138."""
+    points_3D = get_dense_3D_grid(opt, var)
+    batch_size = points_3D.shape[0]
+    level_vox, attn_vis = compute_level_grid(opt, impl_network, var.latent_depth, var.latent_semantic,
+                                             points_3D, var.rgb_input_map, vis_only)
+    if attn_vis:
+        var.attn_vis = attn_vis
+    var.eval_vox = points_3D.view(batch_size, -1, 3)
+    var.mesh_pred, var.dpc_pred = _surface_clouds(opt, level_vox)
+    _gt_to_view_frame(opt, var)
+    var.dpc_pred = normalize_pc(var.dpc_pred)
+    var.dpc.points = normalize_pc(var.dpc.points)
+    if vis_only:
+        return
+    if opt.eval.icp:
+        var.dpc_pred = ICP(opt, var.dpc_pred, var.dpc.points)
+    dist_acc, dist_comp, _, _ = chamfer_distance(opt, X1=var.dpc_pred, X2=var.dpc.points)
+    var.f_score = compute_fscore(dist_acc, dist_comp, opt.eval.f_thresholds)
+    assert dist_acc.shape[1] == opt.eval.num_points
+    var.cd_acc = dist_acc.mean(dim=1)
+    var.cd_comp = dist_comp.mean(dim=1)
+    return dist_acc.mean(), dist_comp.mean()
+
+
+def eval_metrics_BF(opt, var, impl_network, vis_only=False):
+    """utils/eval_3D.py:172-207."""
+    points_3D = get_dense_3D_grid(opt, var)
+    batch_size = points_3D.shape[0]
+    level_vox, attn_vis = compute_level_grid(opt, impl_network, var.latent_depth, var.latent_semantic,
+                                             points_3D, var.rgb_input_map, vis_only)
+    if attn_vis:
+        var.attn_vis = attn_vis
+    var.eval_vox = points_3D.view(batch_size, -1, 3)
+    var.mesh_pred, var.dpc_pred = _surface_clouds(opt, level_vox)
+    _gt_to_view_frame(opt, var)
+    if vis_only:
+        return
+    cd_acc, cd_comp, f_score = [], [], []
+    for i in range(batch_size):
+        best_acc, best_comp, best_fscore, best_pred, best_gt = \
+            brute_force_search(var.dpc_pred[i], var.dpc.points[i], opt.eval.f_thresholds, opt.device)
+        var.dpc_pred[i] = best_pred.clone()
+        var.dpc.points[i] = best_gt.clone()
+        cd_acc.append(best_acc)
+        cd_comp.append(best_comp)
+        f_score.append(best_fscore)
+    var.cd_acc = torch.stack(cd_acc, dim=0)
+    var.cd_comp = torch.stack(cd_comp, dim=0)
+    var.f_score = torch.stack(f_score, dim=0)
+    return var.cd_acc.mean(), var.cd_comp.mean()
+
+
+def eval_metrics(opt, var, impl_network, vis_only=False):
+    """utils/eval_3D.py:209-213."""
+    if opt.eval.brute_force:
+        return eval_metrics_BF(opt, var, impl_network, vis_only)
+    return eval_metrics_default(opt, var, impl_network, vis_only)
+
+
 def ICP(opt, X1, X2, num_iter=50):
     """utils/eval_3D.py:271-284."""
     assert len(X1) == len(X2)
@@ -225,35 +306,86 @@ def ICP(opt, X1, X2, num_iter=50):
     return X1
 
 
-def convert_to_explicit(opt, level_grids, isoval=0., to_pointcloud=False):
-    """utils/eval_3D.py:233-263 - third-party boundary (PyMCubes + trimesh on the host).
-    Kept call-compatible; raises when the packages are not installed."""
-    try:
-        import mcubes
-        import trimesh
-    except ImportError as e:
-        raise RuntimeError("convert_to_explicit needs PyMCubes and trimesh on the host "
-                           "(SURVEY.md section 8f rank 1: GPU marching cubes is a later row)") from e
-    N = len(level_grids)
-    meshes = [None] * N
-    pointclouds = [None] * N if to_pointcloud else None
+class SimpleMesh(object):
+    """Triangle-soup stand-in for the ``trimesh.Trimesh`` objects the reference stores in
+    ``var.mesh_pred`` (only used for dumps): ``vertices`` [3n,3], ``faces`` [n,3], ``triangles``
+    [n,3,3] as numpy arrays."""
 
-    def worker(i):
-        vertices, faces = mcubes.marching_cubes(level_grids[i], isovalue=isoval)
-        S = level_grids[i].shape[0]
+    def __init__(self, triangles):
+        self.triangles = np.asarray(triangles, np.float32).reshape(-1, 3, 3)
+        self.vertices = self.triangles.reshape(-1, 3)
+        self.faces = np.arange(len(self.vertices)).reshape(-1, 3)
+
+
+_MC_TABLES = {}
+
+
+def _mc_tables(device):
+    key = str(device)
+    if key not in _MC_TABLES:
+        from .. import mc_tables as T
+        stride = 16
+        tab = -np.ones((256, stride), np.int8)
+        tab[:, :T.TRI_TABLE.shape[1]] = T.TRI_TABLE
+        _MC_TABLES[key] = (torch.from_numpy(tab).to(device), torch.from_numpy(T.TRI_COUNT.astype(np.uint8)).to(device),
+                           stride)
+    return _MC_TABLES[key]
+
+
+@torch.no_grad()
+def extract_surface(level_vox, isoval, range_min, range_max, num_points=0, seed=0):
+    """GPU marching cubes (+ optional area-weighted sampling) of ONE level grid [G,G,G] that
+    already lives on the device.  Returns (triangles [n,3,3] fp32 GPU tensor,
+    points [num_points,3] fp32 GPU tensor | None).  Vertex scaling reproduces the reference's
+    ``v / S * (max - min) + min`` with S = G (utils/eval_3D.py:252-255)."""
+    from .. import _lib
+    lib = _lib.load()
+    vol = level_vox.detach().to(torch.float32).contiguous()
+    assert vol.dim() == 3 and vol.shape[0] == vol.shape[1] == vol.shape[2] and vol.is_cuda
+    G = vol.shape[0]
+    dev = vol.device
+    tab, cnt, stride = _mc_tables(dev)
+    scratch = torch.empty(lib.zs_mc_scratch_bytes(G) // 4 + 1, dtype=torch.int32, device=dev)
+    total = torch.zeros(1, dtype=torch.int32, device=dev)
+    stream = _lib.current_stream_ptr(dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.zs_mc_count(_lib.ptr(vol), G, float(isoval), _lib.ptr(cnt), _lib.ptr(scratch),
+                                   _lib.ptr(total), stream), "zs_mc_count")
+        n_tris = int(total.item())                       # 4-byte D2H: sizes the output
+        tris = torch.empty(n_tris, 3, 3, dtype=torch.float32, device=dev)
+        scale = np.float32((range_max - range_min) / G)
+        _lib.check(lib.zs_mc_emit(_lib.ptr(vol), G, float(isoval), _lib.ptr(tab), stride, _lib.ptr(cnt),
+                                  _lib.ptr(scratch), float(scale), float(range_min), _lib.ptr(tris), n_tris,
+                                  stream), "zs_mc_emit")
+        pts = None
+        if num_points:
+            pts = torch.empty(num_points, 3, dtype=torch.float32, device=dev)
+            cum = torch.empty(max(n_tris, 1), dtype=torch.float64, device=dev)
+            _lib.check(lib.zs_mesh_sample(_lib.ptr(tris), n_tris, num_points, int(seed) & ((1 << 64) - 1),
+                                          _lib.ptr(cum), _lib.ptr(pts), stream), "zs_mesh_sample")
+    return tris, pts
+
+
+def convert_to_explicit(opt, level_grids, isoval=0., to_pointcloud=False, seed=0):
+    """utils/eval_3D.py:233-263 on the GPU: marching cubes at ``isoval`` + area-weighted surface
+    sampling, one level grid at a time (no Python threads, no PyMCubes / trimesh).
+    ``level_grids``: list of [G,G,G] arrays or GPU tensors (a numpy grid is uploaded - pass
+    the tensor compute_level_grid returned to keep the grid in HBM).  Returns ``meshes``
+    (SimpleMesh list) and, with ``to_pointcloud``, ``pointclouds`` float64 [B,num_points,3]
+    like the reference (an empty mesh gives zeros, :262).  The random stream is a
+    counter-based generator seeded by ``seed`` + the grid index, not numpy's global RNG."""
+    device = getattr(opt, "device", "cuda")
+    meshes, clouds = [], []
+    for i, g in enumerate(level_grids):
+        vol = g if isinstance(g, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(g, np.float32))
+        vol = vol.to(device)
+        assert vol.shape[0] == vol.shape[1] == vol.shape[2]
         range_min, range_max = opt.eval.range
-        vertices = vertices / S * (range_max - range_min) + range_min
-        mesh = trimesh.Trimesh(vertices, faces)
-        meshes[i] = mesh
-        if pointclouds is not None:
-            pointclouds[i] = mesh.sample(opt.eval.num_points) if len(mesh.triangles) != 0 \
-                else np.zeros([opt.eval.num_points, 3])
-
-    threads = [threading.Thread(target=worker, args=(i,), daemon=False) for i in range(N)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
+        tris, pts = extract_surface(vol, isoval, range_min, range_max,
+                                    opt.eval.num_points if to_pointcloud else 0, seed + i)
+        meshes.append(SimpleMesh(tris.cpu().numpy()))
+        if to_pointcloud:
+            clouds.append(pts.cpu().numpy().astype(np.float64))
     if to_pointcloud:
-        return meshes, np.stack(pointclouds, axis=0)
+        return meshes, np.stack(clouds, axis=0)
     return meshes
