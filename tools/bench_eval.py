@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Per-sample timing of the evaluation hot path as evaluate.py drives it at the documented
+setting (README.md:108: --eval.vox_res=128 --eval.brute_force --eval.batch_size=1):
+latent -> 129^3 grid query -> marching cubes + 10k surface samples -> 6912-rotation
+brute-force Chamfer alignment.  Prints one JSON line (secondary to bench.py)."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from zeroshape_amd import synthetic as syn
+from zeroshape_amd.model.shape.implicit import Implicit
+from zeroshape_amd.utils import eval_3D as E
+from zeroshape_amd.utils.options import EasyDict as edict
+from zeroshape_amd.utils.pos_embed import get_2d_sincos_pos_embed
+
+
+def main():
+    dev = torch.device("cuda:0")
+    pe = get_2d_sincos_pos_embed(256, 14, cls_token=True).astype(np.float32)
+    sd = {k: torch.from_numpy(v) for k, v in syn.seeded_state_dict(0, pos_embed=pe).items()}
+    net = Implicit(196, latent_dim=256, n_channels=256, n_blocks_attn=2, n_layers_mlp=8, num_heads=8,
+                   skip_in=[2, 4, 6], pos_perlayer=False)
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    opt = edict(dict(device="cuda", H=224, W=224, arch=dict(win_size=16), data=dict(dataset_test="synthetic"),
+                     eval=dict(vox_res=128, range=[-1.5, 1.5], num_points=10000, icp=False, brute_force=True,
+                               f_thresholds=[0.005, 0.01, 0.02, 0.05, 0.1, 0.2])))
+    gt = torch.from_numpy(syn.ellipsoid_cloud(0, 10000))[None]
+
+    def var():
+        return edict(dict(idx=[0], latent_depth=torch.from_numpy(syn.seeded_latent(0, 1)).to(dev),
+                          latent_semantic=None, rgb_input_map=torch.zeros(1, 3, 224, 224, device=dev),
+                          pose_gt=torch.eye(3, 4)[None].to(dev), dpc=dict(points=gt.clone().to(dev))))
+
+    def sync():
+        torch.cuda.synchronize()
+        return time.perf_counter()
+
+    E.eval_metrics(opt, var(), net)                  # warm-up (rotation table, workspace, packing)
+    v = var()
+    t0 = sync()
+    grid = E.get_dense_3D_grid(opt, v)
+    lv, _ = E.compute_level_grid(opt, net, v.latent_depth, None, grid, None)
+    t1 = sync()
+    meshes, cloud = E._surface_clouds(opt, lv)
+    t2 = sync()
+    out = E.brute_force_search(cloud[0], v.dpc.points[0], opt.eval.f_thresholds, opt.device, return_index=True)
+    t3 = sync()
+    v2 = var()
+    t4 = sync()
+    E.eval_metrics(opt, v2, net)
+    t5 = sync()
+    print(json.dumps({
+        "setting": "vox_res=128, brute_force, batch 1, 10000 points",
+        "grid_query_ms": round((t1 - t0) * 1e3, 2), "marching_cubes_and_sampling_ms": round((t2 - t1) * 1e3, 2),
+        "n_triangles": int(len(meshes[0].faces)), "brute_force_ms": round((t3 - t2) * 1e3, 2),
+        "eval_metrics_total_ms": round((t5 - t4) * 1e3, 2),
+        "cd_acc": float(v2.cd_acc[0]), "cd_comp": float(v2.cd_comp[0])}))
+
+
+if __name__ == "__main__":
+    main()
