@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 4
+#define ZS_ABI_VERSION 5
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -54,6 +54,15 @@ const char *zs_last_error(void);
  * its caller pre-zeroes them, dist_chamfer_3D.py:29-38). */
 int zs_chamfer_forward(const float *xyz1, const float *xyz2, int b, int n, int m,
                        float *dist1, float *dist2, int *idx1, int *idx2, void *stream);
+
+/* Same contract and bit-identical results, but spatially accelerated: the candidate clouds
+ * are binned into uniform grids in `workspace` (zs_chamfer_workspace_bytes(b, n, m) bytes,
+ * 16-byte aligned, contents scratch) and each query only evaluates the candidates whose
+ * cells can still beat its running minimum.  Worth it from a few thousand points per cloud. */
+size_t zs_chamfer_workspace_bytes(int b, int n, int m);
+int zs_chamfer_forward_ws(const float *xyz1, const float *xyz2, int b, int n, int m,
+                          float *dist1, float *dist2, int *idx1, int *idx2,
+                          void *workspace, size_t workspace_bytes, void *stream);
 
 /* Gradient scatter (chamfer3D.cu:155-195): gradxyz1[b][n][3] / gradxyz2[b][m][3] are
  * ACCUMULATED into with fp32 atomics (caller zeroes them, dist_chamfer_3D.py:51-55):

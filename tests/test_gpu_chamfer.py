@@ -31,6 +31,46 @@ def test_forward_bit_exact(b, n, m):
         np.testing.assert_array_equal(g, w, err_msg=name)
 
 
+@pytest.mark.parametrize("kind", ["uniform", "surface", "clusters", "flat", "outliers", "line", "scaled"])
+def test_grid_accelerated_path_equals_brute_force(kind, monkeypatch):
+    """zs_chamfer_forward_ws prunes candidates with a conservative bound: results must stay
+    bit-identical to the brute-force kernel (and the oracle) on adversarial geometry."""
+    rs = np.random.RandomState(hash(kind) % 1000)
+    n, m, b = 3000, 4100, 3
+    if kind == "uniform":
+        a, c = rs.uniform(-0.5, 0.5, (b, n, 3)), rs.uniform(-0.5, 0.5, (b, m, 3))
+    elif kind == "surface":
+        a = rs.randn(b, n, 3); a /= np.linalg.norm(a, axis=-1, keepdims=True)
+        c = rs.randn(b, m, 3); c /= np.linalg.norm(c, axis=-1, keepdims=True); c *= 0.98
+    elif kind == "clusters":
+        a = rs.randn(b, n, 3) * 0.01 + rs.randint(0, 3, (b, n, 1)) * 0.4
+        c = rs.randn(b, m, 3) * 0.01 + rs.randint(0, 3, (b, m, 1)) * 0.4
+    elif kind == "flat":
+        a, c = rs.uniform(-1, 1, (b, n, 3)), rs.uniform(-1, 1, (b, m, 3))
+        c[..., 2] = 0.25                      # candidate cloud degenerate along z
+        a[0, :, 0] = -0.5                     # and a query cloud degenerate along x
+    elif kind == "outliers":
+        a, c = rs.uniform(-0.5, 0.5, (b, n, 3)), rs.uniform(-0.5, 0.5, (b, m, 3))
+        a[:, :50] += 40.0                     # queries far outside the candidates' bounding box
+        c[:, :3] -= 25.0                      # and a few far candidates stretching the grid
+    elif kind == "line":
+        t = rs.uniform(0, 1, (b, n, 1)); a = np.concatenate([t, 2 * t, -t], -1)
+        t = rs.uniform(0, 1, (b, m, 1)); c = np.concatenate([t, 2 * t, -t], -1) + 1e-3
+    else:
+        a, c = rs.uniform(-500, 500, (b, n, 3)), rs.uniform(-500, 500, (b, m, 3))
+    a, c = a.astype(np.float32), c.astype(np.float32)
+    c[:, 100] = c[:, 7]                       # exact duplicates: lowest index must win
+    a[:, 11] = c[:, 100]
+    got = _run(a, c)
+    want = C.chamfer_forward(a, c)
+    for g, w_, name in zip(got, want, ("dist1", "dist2", "idx1", "idx2")):
+        np.testing.assert_array_equal(g, w_, err_msg="%s (%s)" % (name, kind))
+    monkeypatch.setenv("ZS_CHAMFER_BRUTE", "1")
+    brute = _run(a, c)
+    for g, w_ in zip(got, brute):
+        np.testing.assert_array_equal(g, w_)
+
+
 def test_ties_and_duplicates():
     m = 2100   # spans three 1024-candidate LDS tiles
     c = np.tile(np.array([[1, 0, 0]], np.float32), (m, 1))[None].copy()

@@ -19,6 +19,10 @@ SIGNATURES = {
     "zs_last_error": (ctypes.c_char_p, []),
     "zs_chamfer_forward": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                     _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "zs_chamfer_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
+    "zs_chamfer_forward_ws": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int,
+                                       _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t,
+                                       _c_void_p]),
     "zs_chamfer_backward": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                      _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                                      _c_void_p, _c_void_p, _c_void_p]),
@@ -39,7 +43,7 @@ SIGNATURES = {
     "zs_mesh_sample": (_c_int, [_c_void_p, _c_int, _c_int, ctypes.c_uint64, _c_void_p, _c_void_p, _c_void_p]),
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 

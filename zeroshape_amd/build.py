@@ -24,6 +24,7 @@ EXTRA = {
     # (SLP vectorisation packs the distance arithmetic into v_pk_*_f32, which is no faster
     # on gfx950 and costs extra v_mov: off)
     "chamfer.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
+    "chamfer_grid.hip": ["-ffp-contract=off"],
     # vertices / sampled points reproducible op for op by oracle/mc_ref.py
     "marching_cubes.hip": ["-ffp-contract=off"],
 }
