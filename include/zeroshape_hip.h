@@ -17,6 +17,7 @@
  *   zs_sdf_*             <- Implicit.forward, model/shape/implicit.py:251-288, as it is
  *                           driven by compute_level_grid, utils/eval_3D.py:22-45, and
  *                           get_dense_3D_grid, utils/eval_3D.py:11-20
+ *   zs_bf_lower_bounds   <- pruning for brute_force_search, utils/eval_3D.py:140-170
  *   zs_mc_*, zs_mesh_*   <- convert_to_explicit, utils/eval_3D.py:233-263 (PyMCubes
  *                           marching_cubes + trimesh.sample on the host)
  * INTEGRATION.md shows the binding a maintainer of the reference would add.
@@ -31,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 5
+#define ZS_ABI_VERSION 6
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -127,6 +128,21 @@ int zs_sdf_query_points(const void *programs, size_t program_stride_bytes, int b
 int zs_sdf_query_grid(const void *programs, size_t program_stride_bytes, int batch,
                       const float *axis, int G, int slice_begin, int slice_end,
                       int apply_sigmoid, float *out, void *workspace, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Brute-force pose search support (brute_force_search, utils/eval_3D.py:140-170).
+ * lower_bounds[i] <= Chamfer-L1 of rotation i (normalize_pc(R_i pred) vs gt_normalized),
+ * up to rounding: rigorous cell-distance bounds on 32^3 occupancy grids of the two clouds.
+ * The host evaluates rotations exactly in order of increasing bound and stops when the
+ * smallest remaining bound (with a margin) exceeds the best exact distance - same winner
+ * as the exhaustive scan.  pred [n][3] raw, gt_normalized [m][3], rotations [k][3][3];
+ * grid_gt / grid_pred: zs_bf_grid_bytes() each, scratch: zs_bf_scratch_bytes().
+ * ------------------------------------------------------------------------- */
+size_t zs_bf_grid_bytes(void);
+size_t zs_bf_scratch_bytes(void);
+int zs_bf_lower_bounds(const float *pred, int n, const float *gt_normalized, int m,
+                       const float *rotations, int k, float *grid_gt, float *grid_pred,
+                       void *scratch, float *lower_bounds, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Iso-surface extraction + surface sampling (replaces convert_to_explicit,

@@ -148,6 +148,37 @@ def test_chamfer_distance_and_fscore_helpers():
     np.testing.assert_allclose(n.numpy(), G.normalize_pc(a).numpy(), atol=1e-6)
 
 
+@pytest.mark.parametrize("shape", ["asym", "ellipsoid", "sphere", "noise"])
+def test_pruned_search_equals_exhaustive_search(shape):
+    """lower-bound pruning must not change anything: same rotation index, same bits."""
+    from zeroshape_amd.utils import eval_3D as E
+    from zeroshape_amd.utils.camera import get_rotation_sphere
+    R = get_rotation_sphere(24, 24, 12, device="cuda")
+    rs = np.random.RandomState(3)
+    n = 1500
+    if shape == "asym":
+        p = rs.randn(n, 3) * np.array([0.5, 0.25, 0.1]) + rs.rand(n, 1) * np.array([0.4, 0.0, 0.2])
+    elif shape == "ellipsoid":
+        p = syn.ellipsoid_cloud(1, n)
+    elif shape == "sphere":
+        p = rs.randn(n, 3); p /= np.linalg.norm(p, axis=1, keepdims=True)   # every rotation ties
+    else:
+        p = rs.uniform(-1, 1, (n, 3))
+    pred = torch.from_numpy(p.astype(np.float32))
+    gt = (R[2345].cpu() @ pred.T).T.contiguous() + 2e-3 * torch.from_numpy(rs.randn(n, 3).astype(np.float32))
+    sl = (0, 6912) if shape != "noise" else (1000, 1700)
+    full = E.brute_force_search(pred, gt, device="cuda", rotations=R, rot_slice=sl, return_index=True, prune=False)
+    n_full = E.brute_force_search.last_evaluated
+    fast = E.brute_force_search(pred, gt, device="cuda", rotations=R, rot_slice=sl, return_index=True, prune=True)
+    n_fast = E.brute_force_search.last_evaluated
+    assert fast[5] == full[5] and fast[6] == full[6], (fast[5], full[5])
+    for a, b in zip(fast[:5], full[:5]):
+        assert torch.equal(a, b)
+    assert n_fast <= n_full
+    if shape in ("asym", "ellipsoid"):
+        assert n_fast < n_full // 4, "pruning should remove most rotations (%d of %d evaluated)" % (n_fast, n_full)
+
+
 def test_brute_force_search_matches_oracle_scan():
     from zeroshape_amd.utils import eval_3D as E
     from zeroshape_amd.utils.camera import get_rotation_sphere

@@ -51,6 +51,19 @@ def main():
     t2 = sync()
     out = E.brute_force_search(cloud[0], v.dpc.points[0], opt.eval.f_thresholds, opt.device, return_index=True)
     t3 = sync()
+    n_eval_far = E.brute_force_search.last_evaluated
+    # a ground truth the prediction can actually be aligned with (the usual case in evaluation):
+    # the predicted surface itself, re-sampled, rotated by sphere rotation #2345 and perturbed
+    _, cloud2 = E._surface_clouds(opt, lv, seed=7)
+    Rk = E.get_rotation_sphere(24, 24, 12, device=dev)[2345]
+    gt2 = (Rk @ cloud2[0].T).T.contiguous() + 0.01 * torch.randn(10000, 3, device=dev)
+    ta = sync()
+    out2 = E.brute_force_search(cloud[0], gt2, opt.eval.f_thresholds, opt.device, return_index=True)
+    tb = sync()
+    n_eval_near = E.brute_force_search.last_evaluated
+    tc = sync()
+    E.brute_force_search(cloud[0], gt2, opt.eval.f_thresholds, opt.device, return_index=True, prune=False)
+    td = sync()
     v2 = var()
     t4 = sync()
     E.eval_metrics(opt, v2, net)
@@ -59,6 +72,10 @@ def main():
         "setting": "vox_res=128, brute_force, batch 1, 10000 points",
         "grid_query_ms": round((t1 - t0) * 1e3, 2), "marching_cubes_and_sampling_ms": round((t2 - t1) * 1e3, 2),
         "n_triangles": int(len(meshes[0].faces)), "brute_force_ms": round((t3 - t2) * 1e3, 2),
+        "brute_force_rotations_evaluated": n_eval_far, "brute_force_best_cd": float(out[6]),
+        "alignable_gt": {"brute_force_ms": round((tb - ta) * 1e3, 2), "rotations_evaluated": n_eval_near,
+                         "best_index": int(out2[5]), "best_cd": float(out2[6]),
+                         "exhaustive_ms": round((td - tc) * 1e3, 2)},
         "eval_metrics_total_ms": round((t5 - t4) * 1e3, 2),
         "cd_acc": float(v2.cd_acc[0]), "cd_comp": float(v2.cd_comp[0])}))
 

@@ -36,6 +36,10 @@ SIGNATURES = {
                                      _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "zs_sdf_query_grid": (_c_int, [_c_void_p, _c_size_t, _c_int, _c_void_p, _c_int, _c_int,
                                    _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "zs_bf_grid_bytes": (_c_size_t, []),
+    "zs_bf_scratch_bytes": (_c_size_t, []),
+    "zs_bf_lower_bounds": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
+                                    _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "zs_mc_scratch_bytes": (_c_size_t, [_c_int]),
     "zs_mc_count": (_c_int, [_c_void_p, _c_int, ctypes.c_float, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "zs_mc_emit": (_c_int, [_c_void_p, _c_int, ctypes.c_float, _c_void_p, _c_int, _c_void_p, _c_void_p,
@@ -43,7 +47,7 @@ SIGNATURES = {
     "zs_mesh_sample": (_c_int, [_c_void_p, _c_int, _c_int, ctypes.c_uint64, _c_void_p, _c_void_p, _c_void_p]),
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _lib = None
 
 
