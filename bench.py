@@ -60,10 +60,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # ZS_DEVICE_OVERRIDE / ZS_DIST_BACKEND exist only to rehearse the multi-rank code path on a
+    # single-GPU box (all ranks on one device, gloo instead of RCCL); never set by the driver
+    dev_index = int(os.environ.get("ZS_DEVICE_OVERRIDE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("ZS_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     N = args.vox_res
     G = N + 1

@@ -181,6 +181,27 @@ def test_full_size_grid128_properties(net, seeded_sd):
     assert np.all(np.abs(want[0].numpy()[flips]) < BAND)
 
 
+def test_vox256_slab_and_batched_grid(net, seeded_sd):
+    """BASELINE config 5 geometry (257^3, sharded): one rank's slab of a batch of 2 images,
+    checked against the oracle on random points; slab launches of a batch equal per-image launches."""
+    N = 256
+    latent_c = torch.from_numpy(syn.seeded_latent(seed=2, batch=2))
+    latent = latent_c.cuda()
+    axis = torch.linspace(-1.5, 1.5, N + 1, device="cuda")
+    st = net.prepare(latent)
+    slab = net.query_grid(latent, axis, apply_sigmoid=False, slice_begin=224, slice_end=226, state=st)
+    assert slab.shape == (2, 2, N + 1, N + 1)
+    one = net.query_grid(latent[1:], axis, apply_sigmoid=False, slice_begin=224, slice_end=226)
+    assert torch.equal(slab[1:], one)
+    rs = np.random.RandomState(5)
+    jj, kk = rs.randint(0, N + 1, 500), rs.randint(0, N + 1, 500)
+    ax = axis.cpu()
+    pts = torch.stack([ax[225].expand(500), ax[jj], ax[kk]], -1)[None].repeat(2, 1, 1)
+    want, _ = R.implicit_forward(seeded_sd, latent_c, pts)
+    got = slab[:, 1, jj, kk].cpu().numpy()
+    np.testing.assert_allclose(got, want.numpy(), atol=ATOL, rtol=0)
+
+
 def test_weights_update_repacks(net, seeded_sd):
     latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=1)).cuda()
     pts = torch.from_numpy(syn.seeded_cloud(5, 1, 64, -1, 1)).cuda()
