@@ -20,6 +20,11 @@
  *   zs_bf_lower_bounds   <- pruning for brute_force_search, utils/eval_3D.py:140-170
  *   zs_mc_*, zs_mesh_*   <- convert_to_explicit, utils/eval_3D.py:233-263 (PyMCubes
  *                           marching_cubes + trimesh.sample on the host)
+ *   zs_seen_surface, zs_unproj_depth, zs_valid_norm_fac, zs_masked_resample,
+ *   zs_intr_param2mtx    <- the seen-surface geometry of Graph.forward,
+ *                           model/compute_graph/graph_shape.py:89-113,131-144, with
+ *                           utils/camera.py:52-108 and utils/util.py:323-345
+ *   zs_depth_metrics     <- DepthMetric.compute_metrics, utils/eval_depth.py:46-116
  * INTEGRATION.md shows the binding a maintainer of the reference would add.
  */
 #ifndef ZEROSHAPE_HIP_H
@@ -32,7 +37,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 6
+#define ZS_ABI_VERSION 7
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -166,6 +171,58 @@ int zs_mc_emit(const float *vol, int G, float iso, const int8_t *tri_table, int 
                float *tris, int n_tris, void *stream);
 int zs_mesh_sample(const float *tris, int n_tris, int n_samples, uint64_t seed, double *cum_area,
                    float *points, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Seen-surface geometry front-end (model/compute_graph/graph_shape.py:131-144).
+ * All maps are fp32, row-major, batch outermost.
+ *
+ *   zs_intr_param2mtx : params [B][3] = (scale_f, delta_cx, delta_cy) -> intr [B][3][3]
+ *                       (graph_shape.py:89-113: f = 1.3875 * W * 4^tanh(p0), ...)
+ *   zs_unproj_depth   : depth [B][H][W], intr [B][3][3] -> points [B][H*W][3] =
+ *                       K^-1 [x,y,1]^T * depth (utils/camera.py:88-108)
+ *   zs_valid_norm_fac : points [B][n][3], mask [B][n] bytes (torch.bool) -> mean [B][3] of
+ *                       the selected points and max_dist [B] = max |p - mean|
+ *                       (utils/camera.py:52-78).  An empty selection gives NaN (the
+ *                       reference raises there).
+ *   zs_masked_resample: interpolate_coordmap / interpolate_depth (utils/util.py:323-345):
+ *                       map [B][C][H][W], mask [B][1][H][W] (valid where > 0.5) ->
+ *                       out [B][C][Ho][Wo] = bilinear(map*mask)/(bilinear(mask)+1e-6) where
+ *                       bilinear(mask) > 0.5 else `bg`; mask_out [B][1][Ho][Wo] in {0,1}.
+ *                       Bilinear = torch interpolate(mode='bilinear', align_corners=False).
+ *   zs_seen_surface   : the whole chain in one launch: unproject, masked mean / max radius
+ *                       (-> mean [B][3], scale [B]), seen_points [B][H*W][3] =
+ *                       (p - mean) / scale with invalid pixels zeroed, and, when coord_dsp
+ *                       is not NULL, coord_dsp [B][3][Ho][Wo] + mask_dsp [B][1][Ho][Wo] =
+ *                       interpolate_coordmap of the channel-major seen map.
+ * ------------------------------------------------------------------------- */
+int zs_intr_param2mtx(const float *params, int batch, int H, int W, float *intr, void *stream);
+int zs_unproj_depth(const float *depth, const float *intr, int batch, int H, int W, float *points,
+                    void *stream);
+int zs_valid_norm_fac(const float *points, const uint8_t *mask, int batch, int n, float *mean,
+                      float *max_dist, void *stream);
+int zs_masked_resample(const float *map, const float *mask, int batch, int channels, int H, int W,
+                       int Ho, int Wo, float bg, float *out, float *mask_out, void *stream);
+int zs_seen_surface(const float *depth, const float *intr, const float *mask, int batch, int H, int W,
+                    int Ho, int Wo, float *seen_points, float *mean, float *scale, float *coord_dsp,
+                    float *mask_dsp, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Depth metrics with least-squares scale/shift alignment in disparity space
+ * (DepthMetric.compute_metrics, utils/eval_depth.py:46-116).  prediction, target,
+ * mask: [B][n] fp32 (valid where mask > 0.5); thresholds: [host] n_thresholds <= 8
+ * floats; depth_cap <= 0 means "no cap".  metrics [B][n_thresholds + 3] =
+ * (d>thr_0 .. d>thr_k, rmse, l1_err, abs_rel); prediction_depth [B][n] (may be NULL) =
+ * the aligned depth of every pixel; scale_shift [B][2] (may be NULL).
+ * flags: ZS_DEPTH_PRED_IS_DISPARITY = prediction_type 'disparity' (:67-68);
+ * ZS_DEPTH_SOLVE_ONLY = compute_scale_and_shift alone (:11-34): prediction and target are
+ * used as given and only scale_shift is written.
+ * ------------------------------------------------------------------------- */
+#define ZS_DEPTH_PRED_IS_DISPARITY 1
+#define ZS_DEPTH_SOLVE_ONLY 2
+int zs_depth_metrics(const float *prediction, const float *target, const float *mask, int batch, int n,
+                     int flags, float depth_cap, const float *thresholds,
+                     int n_thresholds, float *metrics, float *prediction_depth, float *scale_shift,
+                     void *stream);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,12 @@ def geometry_golden():
 
 
 @pytest.fixture(scope="session")
+def frontend_golden():
+    import numpy as np
+    return dict(np.load(os.path.join(GOLDEN, "frontend_golden.npz")))
+
+
+@pytest.fixture(scope="session")
 def seeded_sd(decoder_golden):
     """Seeded decoder weights as torch CPU tensors (pos_embed from the golden file,
     i.e. as the reference initialised it)."""

@@ -45,9 +45,19 @@ SIGNATURES = {
     "zs_mc_emit": (_c_int, [_c_void_p, _c_int, ctypes.c_float, _c_void_p, _c_int, _c_void_p, _c_void_p,
                             ctypes.c_float, ctypes.c_float, _c_void_p, _c_int, _c_void_p]),
     "zs_mesh_sample": (_c_int, [_c_void_p, _c_int, _c_int, ctypes.c_uint64, _c_void_p, _c_void_p, _c_void_p]),
+    "zs_intr_param2mtx": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "zs_unproj_depth": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "zs_valid_norm_fac": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "zs_masked_resample": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                    ctypes.c_float, _c_void_p, _c_void_p, _c_void_p]),
+    "zs_seen_surface": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                 _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "zs_depth_metrics": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, ctypes.c_float,
+                                  ctypes.POINTER(ctypes.c_float), _c_int, _c_void_p, _c_void_p, _c_void_p,
+                                  _c_void_p]),
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _lib = None
 
 

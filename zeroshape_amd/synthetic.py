@@ -103,3 +103,39 @@ def ellipsoid_cloud(seed, n, radii=(0.5, 0.35, 0.25)):
     v = rs.randn(n, 3)
     v /= np.linalg.norm(v, axis=1, keepdims=True)
     return (v * np.asarray(radii)).astype(np.float32)
+
+
+def seeded_depth_scene(seed=0, batch=2, size=224):
+    """Build-owned inputs for the seen-surface front-end (graph_shape.py:118-144): a smooth
+    bumpy depth map in [0.7, 1.7], an object mask (disk with random holes; the last sample of a
+    batch >= 3 keeps only a few pixels), and raw intrinsics parameters.  Returns float32 arrays
+    depth [B,1,S,S], mask [B,1,S,S] in {0,1}, intr_params [B,3]."""
+    rs = np.random.RandomState(1000 + seed)
+    y, x = np.meshgrid(np.arange(size), np.arange(size), indexing="ij")
+    depth, mask = [], []
+    for b in range(batch):
+        fx, fy, ph = rs.uniform(20, 60), rs.uniform(20, 60), rs.uniform(0, 6.28)
+        d = 1.2 + 0.3 * np.sin(x / fx + ph) * np.cos(y / fy) + 0.05 * rs.rand(size, size)
+        cx, cy, rad = rs.uniform(0.35, 0.65) * size, rs.uniform(0.35, 0.65) * size, rs.uniform(0.25, 0.4) * size
+        m = ((x - cx) ** 2 + (y - cy) ** 2 < rad ** 2) & (rs.rand(size, size) > 0.05)
+        if batch >= 3 and b == batch - 1:
+            m = np.zeros((size, size), bool)
+            m[rs.randint(0, size, 5), rs.randint(0, size, 5)] = True
+        depth.append(d)
+        mask.append(m)
+    depth = np.stack(depth)[:, None].astype(np.float32)
+    mask = np.stack(mask)[:, None].astype(np.float32)
+    params = rs.uniform(-0.5, 0.5, size=(batch, 3)).astype(np.float32)
+    return depth, mask, params
+
+
+def seeded_depth_pair(seed=0, batch=2, size=224):
+    """Prediction / target / mask for the depth metrics (utils/eval_depth.py): the prediction
+    is an affine-in-disparity distortion of the target plus noise.  float32 [B,1,S,S] each."""
+    rs = np.random.RandomState(2000 + seed)
+    target, mask, _ = seeded_depth_scene(seed + 7, batch, size)
+    disp = 1.0 / target
+    pred_disp = rs.uniform(0.5, 2.0, size=(batch, 1, 1, 1)) * disp + rs.uniform(0.0, 0.3, size=(batch, 1, 1, 1)) \
+        + 0.15 * rs.randn(*target.shape)
+    pred = (1.0 / np.maximum(pred_disp, 0.05)).astype(np.float32)
+    return pred, target.astype(np.float32), mask
