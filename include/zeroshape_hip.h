@@ -25,6 +25,13 @@
  *                           model/compute_graph/graph_shape.py:89-113,131-144, with
  *                           utils/camera.py:52-108 and utils/util.py:323-345
  *   zs_depth_metrics     <- DepthMetric.compute_metrics, utils/eval_depth.py:46-116
+ *   zs_conv2d_nhwc, zs_group_norm_nhwc, zs_layer_norm, zs_attention, zs_max_pool_nhwc,
+ *   zs_global_mean_nhwc, zs_upsample2x_nhwc, zs_assemble_tokens, zs_readout_concat,
+ *   zs_nchw_to_nhwc, zs_nhwc_to_nchw
+ *                        <- the layers of the image encoders: DPTDepthModel
+ *                           (model/depth/dpt_depth.py:68-122, blocks.py, vit.py), CoordEncRes
+ *                           (model/shape/seen_coord_enc.py:141-194), the intrinsics head
+ *                           (model/compute_graph/graph_shape.py:18-28,125-129)
  * INTEGRATION.md shows the binding a maintainer of the reference would add.
  */
 #ifndef ZEROSHAPE_HIP_H
@@ -37,7 +44,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 7
+#define ZS_ABI_VERSION 8
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -223,6 +230,54 @@ int zs_depth_metrics(const float *prediction, const float *target, const float *
                      int flags, float depth_cap, const float *thresholds,
                      int n_thresholds, float *metrics, float *prediction_depth, float *scale_shift,
                      void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Encoder layers (inference).  Activations are fp32 channels-last: [B][H][W][C]; a token
+ * matrix [n][C] is the B=1, H=1, W=n case.
+ *
+ * zs_conv2d_nhwc: convolution / linear layer as an implicit GEMM on the fp32 MFMA pipe.
+ *   packed_w: zs_conv2d_packed_floats(Cin,Cout,kh,kw) floats laid out [K16/4][CoutPad][4],
+ *             value W[cout][tap][cin] at k = tap*Cin + cin (tap = ky*kw + kx), K16 = K rounded
+ *             up to 16, CoutPad = Cout rounded up to 128, zero padded.  Cin % 4 == 0.
+ *   out[p][c] = act( (sum_k A[p][k] W[k][c]) * scale[c] + shift[c] + res1[p][c] + res2[p][c] )
+ *   A = input taps at (oy*stride - pad_t + ky, ox*stride - pad_l + kx); out-of-range taps are 0;
+ *   in-range taps are first ReLU'd (flags & ZS_CONV_IN_RELU) and mapped a*in_scale + in_shift.
+ *   scale / shift / res1 / res2 may be NULL (1 / 0 / none).  Explicit top/left padding with
+ *   bounds-checked bottom/right covers torch's symmetric padding and timm's 'same' padding.
+ * zs_group_norm_nhwc: y = GN_groups(x) * gamma + beta (+ residual) (ReLU if relu), per sample.
+ * zs_layer_norm: rows of length C.
+ * zs_attention: qkv [B][L][3*heads*head_dim] (q | k | v, head-major inside each) ->
+ *   out [B][L][heads*head_dim] = softmax(q k^T / sqrt(head_dim)) v.  head_dim 32 or 64.
+ * zs_max_pool_nhwc: k x k window, -inf padding.   zs_global_mean_nhwc: [B][HW][C] -> [B][C].
+ * zs_upsample2x_nhwc: bilinear, align_corners=True, [B][H][W][C] -> [B][2H][2W][C].
+ * zs_nchw_to_nhwc / zs_nhwc_to_nchw: boundary layout conversion (Cpad >= C zero-fills).
+ * zs_assemble_tokens: tokens [B][n+1][C] = [cls | feat [B][n][C]] + pos [n+1][C].
+ * zs_readout_concat: out [B][n][2C] = [tokens[b][1+i] | tokens[b][0]]  (vit.py:31-43).
+ * ------------------------------------------------------------------------- */
+#define ZS_ACT_NONE 0
+#define ZS_ACT_RELU 1
+#define ZS_ACT_GELU 2
+#define ZS_ACT_RELU_CLAMP1 3
+#define ZS_CONV_IN_RELU 1
+size_t zs_conv2d_packed_floats(int Cin, int Cout, int kh, int kw);
+int zs_conv2d_nhwc(const float *in, const float *packed_w, const float *scale, const float *shift,
+                   const float *res1, const float *res2, float *out, int batch, int Hin, int Win, int Cin,
+                   int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad_t, int pad_l, int flags,
+                   float in_scale, float in_shift, int act, void *stream);
+int zs_group_norm_nhwc(const float *x, const float *gamma, const float *beta, const float *residual, float *y,
+                       int batch, int HW, int C, int groups, float eps, int relu, void *stream);
+int zs_layer_norm(const float *x, const float *gamma, const float *beta, float *y, int rows, int C, float eps,
+                  void *stream);
+int zs_attention(const float *qkv, float *out, int batch, int L, int heads, int head_dim, void *stream);
+int zs_max_pool_nhwc(const float *x, float *y, int batch, int Hin, int Win, int C, int Hout, int Wout, int k,
+                     int stride, int pad_t, int pad_l, void *stream);
+int zs_global_mean_nhwc(const float *x, float *y, int batch, int HW, int C, void *stream);
+int zs_upsample2x_nhwc(const float *x, float *y, int batch, int Hin, int Win, int C, void *stream);
+int zs_nchw_to_nhwc(const float *x, float *y, int batch, int C, int HW, int Cpad, void *stream);
+int zs_nhwc_to_nchw(const float *x, float *y, int batch, int C, int HW, void *stream);
+int zs_assemble_tokens(const float *feat, const float *cls, const float *pos, float *tokens, int batch, int n,
+                       int C, void *stream);
+int zs_readout_concat(const float *tokens, float *out, int batch, int n, int C, void *stream);
 
 #ifdef __cplusplus
 }

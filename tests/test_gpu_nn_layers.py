@@ -1,0 +1,197 @@
+"""GPU parity of the encoder layers (csrc/nn_conv.hip, csrc/nn_ops.hip) through the C ABI vs the
+same op in PyTorch fp32 on the CPU (torch.nn.functional).  fp32 MFMA accumulates in a different
+order than the CPU kernels, so comparisons are relative to the output scale: <= 2e-5 of max|y|."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def close(got, want, tol=2e-5):
+    got, want = got.detach().cpu().double(), want.detach().double()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    scale = max(want.abs().max().item(), 1e-6)
+    err = (got - want).abs().max().item()
+    assert err <= tol * scale, "max err %.3g vs scale %.3g" % (err, scale)
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def same_pad(x, k, s, value=0.0):
+    """timm pad_same: total = max((ceil(n/s)-1)*s + k - n, 0), extra on the bottom/right."""
+    H, W = x.shape[-2:]
+    ph = max((-(-H // s) - 1) * s + k - H, 0)
+    pw = max((-(-W // s) - 1) * s + k - W, 0)
+    return F.pad(x, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2), value=value)
+
+
+CONV_CASES = [
+    # B, Cin, H, W, Cout, k, stride, padding
+    (2, 64, 14, 14, 256, 1, 1, 0),
+    (1, 256, 9, 7, 64, 3, 1, 1),
+    (2, 128, 15, 15, 128, 3, 2, 1),
+    (1, 64, 28, 28, 96, 3, 2, "same"),
+    (1, 4, 37, 41, 64, 7, 2, 3),
+    (1, 4, 32, 32, 64, 7, 2, "same"),
+    (3, 32, 12, 12, 1, 1, 1, 0),
+    (1, 768, 7, 7, 3, 1, 1, 0),
+    (1, 512, 5, 5, 200, 1, 2, 0),
+]
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,stride,padding", CONV_CASES)
+def test_conv2d_matches_torch(B, Cin, H, W, Cout, k, stride, padding):
+    from zeroshape_amd.nn import ops, pack
+    g = torch.Generator().manual_seed(Cin * 31 + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    if padding == "same":
+        want = F.conv2d(same_pad(x, k, stride), w, b, stride=stride)
+    else:
+        want = F.conv2d(x, w, b, stride=stride, padding=padding)
+    pc = pack.pack_conv(w, b, stride=stride, padding=padding).to("cuda")
+    got = ops.conv2d(nhwc(x).cuda(), pc)
+    close(got, nhwc(want))
+
+
+def test_conv2d_fused_epilogue_and_input_transforms():
+    from zeroshape_amd.nn import ops, pack
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 64, 10, 10, generator=g)
+    w = torch.randn(160, 64, 3, 3, generator=g) / 24
+    bn = dict(weight=torch.rand(160, generator=g) + 0.5, bias=torch.randn(160, generator=g),
+              running_mean=torch.randn(160, generator=g), running_var=torch.rand(160, generator=g) + 0.5, eps=1e-5)
+    r1, r2 = torch.randn(2, 160, 10, 10, generator=g), torch.randn(2, 160, 10, 10, generator=g)
+    conv = F.conv2d(F.relu(x), w, None, padding=1)
+    want = F.relu(F.batch_norm(conv, bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], False, 0.0,
+                               bn["eps"]) + r1 + r2)
+    pc = pack.pack_conv(w, None, bn=bn, padding=1).to("cuda")
+    got = ops.conv2d(nhwc(x).cuda(), pc, res1=nhwc(r1).cuda(), res2=nhwc(r2).cuda(), act=ops.ACT_RELU, in_relu=True)
+    close(got, nhwc(want))
+    # affine input transform applies to in-bounds taps only (zero padding stays zero): conv(2x-1)
+    want = F.gelu(F.conv2d(2 * x - 1, w, None, padding=1))
+    got = ops.conv2d(nhwc(x).cuda(), pack.pack_conv(w, None, padding=1).to("cuda"), act=ops.ACT_GELU,
+                     in_scale=2.0, in_shift=-1.0)
+    close(got, nhwc(want))
+    want = F.conv2d(x, w, None, padding=1).clamp(0, 1)
+    got = ops.conv2d(nhwc(x).cuda(), pack.pack_conv(w, None, padding=1).to("cuda"), act=ops.ACT_RELU_CLAMP1)
+    close(got, nhwc(want))
+
+
+def test_linear_on_tokens():
+    from zeroshape_amd.nn import ops, pack
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 197, 768, generator=g)
+    w = torch.randn(2304, 768, generator=g) / 28
+    b = torch.randn(2304, generator=g)
+    got = ops.linear(x.cuda(), pack.pack_conv(w, b).to("cuda"))
+    close(got, F.linear(x, w, b))
+    r = torch.randn(2, 197, 2304, generator=g)
+    got = ops.linear(x.cuda(), pack.pack_conv(w, b).to("cuda"), res1=r.cuda(), act=ops.ACT_GELU)
+    close(got, F.gelu(F.linear(x, w, b) + r))
+
+
+def test_cin_padding_for_rgb_input():
+    from zeroshape_amd.nn import ops, pack
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(2, 3, 40, 40, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) / 12
+    want = F.conv2d(x, w, None, stride=2, padding=3)
+    pc = pack.pack_conv(w, None, stride=2, padding=3, cin_pad=4).to("cuda")
+    got = ops.conv2d(ops.to_nhwc(x.cuda(), cpad=4), pc)
+    close(got, nhwc(want))
+    close(ops.to_nchw(got), want)
+
+
+def test_std_conv_weight_standardisation():
+    from zeroshape_amd.nn import pack
+    w = torch.randn(32, 16, 3, 3)
+    want = F.batch_norm(w.reshape(1, 32, -1), None, None, training=True, momentum=0.0, eps=1e-8).reshape_as(w)
+    close(pack.standardize_weight(w, 1e-8), want, tol=1e-6)
+
+
+@pytest.mark.parametrize("C,HW,relu,res", [(64, (12, 12), True, False), (256, (7, 9), False, True),
+                                           (1024, (4, 4), True, True)])
+def test_group_norm(C, HW, relu, res):
+    from zeroshape_amd.nn import ops
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(2, C, *HW, generator=g) * 3 + 1
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    r = torch.randn(2, C, *HW, generator=g) if res else None
+    want = F.group_norm(x, 32, gamma, beta, 1e-5)
+    if res:
+        want = want + r
+    if relu:
+        want = F.relu(want)
+    got = ops.group_norm(nhwc(x).cuda(), gamma.cuda(), beta.cuda(), 32, 1e-5, relu,
+                         nhwc(r).cuda() if res else None)
+    close(got, nhwc(want))
+
+
+def test_layer_norm():
+    from zeroshape_amd.nn import ops
+    g = torch.Generator().manual_seed(1)
+    for C in (768, 256, 100):
+        x = torch.randn(3, 50, C, generator=g) * 2 + 0.5
+        gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+        close(ops.layer_norm(x.cuda(), gamma.cuda(), beta.cuda(), 1e-6), F.layer_norm(x, (C,), gamma, beta, 1e-6))
+
+
+@pytest.mark.parametrize("L,heads,d", [(197, 12, 64), (65, 8, 32), (300, 2, 64), (5, 1, 32)])
+def test_attention(L, heads, d):
+    from zeroshape_amd.nn import ops
+    g = torch.Generator().manual_seed(L)
+    C = heads * d
+    qkv = torch.randn(2, L, 3 * C, generator=g)
+    q, k, v = qkv.reshape(2, L, 3, heads, d).permute(2, 0, 3, 1, 4)
+    attn = ((q * d ** -0.5) @ k.transpose(-2, -1)).softmax(-1)
+    want = (attn @ v).transpose(1, 2).reshape(2, L, C)
+    close(ops.attention(qkv.cuda(), heads), want)
+
+
+def test_pooling_and_resampling():
+    from zeroshape_amd.nn import ops
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 64, 17, 20, generator=g)
+    close(ops.max_pool(nhwc(x).cuda(), 3, 2, 1), nhwc(F.max_pool2d(x, 3, 2, 1)), tol=0)
+    want = F.max_pool2d(same_pad(x, 3, 2, value=float("-inf")), 3, 2)
+    close(ops.max_pool(nhwc(x).cuda(), 3, 2, "same"), nhwc(want), tol=0)
+    close(ops.global_mean(nhwc(x).cuda()), x.mean((2, 3)), tol=1e-6)
+    want = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    close(ops.upsample2x(nhwc(x).cuda()), nhwc(want), tol=2e-6)
+    one = torch.randn(1, 8, 1, 1, generator=g)
+    close(ops.upsample2x(nhwc(one).cuda()), nhwc(F.interpolate(one, scale_factor=2, mode="bilinear",
+                                                               align_corners=True)), tol=1e-6)
+
+
+def test_token_helpers():
+    from zeroshape_amd.nn import ops
+    g = torch.Generator().manual_seed(5)
+    feat, cls, pos = torch.randn(2, 196, 768, generator=g), torch.randn(768, generator=g), \
+        torch.randn(197, 768, generator=g)
+    tok = ops.assemble_tokens(feat.cuda(), cls.cuda(), pos.cuda())
+    want = torch.cat([cls.expand(2, 1, 768), feat], 1) + pos
+    close(tok, want, tol=0)
+    cat = ops.readout_concat(tok)
+    want2 = torch.cat([want[:, 1:], want[:, :1].expand(-1, 196, -1)], -1)
+    close(cat, want2, tol=0)
+
+
+def test_bad_arguments_fail_loudly():
+    from zeroshape_amd import _lib
+    from zeroshape_amd.nn import ops, pack
+    pc = pack.pack_conv(torch.randn(8, 6, 1, 1).repeat(1, 1, 1, 1)[:, :4], None).to("cuda")
+    with pytest.raises(AssertionError):
+        ops.conv2d(torch.zeros(1, 4, 4, 8, device="cuda"), pc)
+    with pytest.raises(ValueError):
+        ops.conv2d(torch.zeros(1, 4, 4, 4), pc)
+    lib = _lib.load()
+    assert lib.zs_conv2d_nhwc(None, None, None, None, None, None, None, 1, 4, 4, 6, 4, 4, 8, 1, 1, 1, 0, 0, 0, 1.0,
+                              0.0, 0, None) == 0
+    assert b"multiple of 4" in lib.zs_last_error()
+    assert lib.zs_attention(None, None, 1, 10, 2, 48, None) == 0

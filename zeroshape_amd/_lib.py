@@ -55,9 +55,23 @@ SIGNATURES = {
     "zs_depth_metrics": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, ctypes.c_float,
                                   ctypes.POINTER(ctypes.c_float), _c_int, _c_void_p, _c_void_p, _c_void_p,
                                   _c_void_p]),
+    "zs_conv2d_packed_floats": (_c_size_t, [_c_int, _c_int, _c_int, _c_int]),
+    "zs_conv2d_nhwc": (_c_int, [_c_void_p] * 7 + [_c_int] * 13 + [ctypes.c_float, ctypes.c_float, _c_int,
+                                                                  _c_void_p]),
+    "zs_group_norm_nhwc": (_c_int, [_c_void_p] * 5 + [_c_int, _c_int, _c_int, _c_int, ctypes.c_float, _c_int,
+                                                      _c_void_p]),
+    "zs_layer_norm": (_c_int, [_c_void_p] * 4 + [_c_int, _c_int, ctypes.c_float, _c_void_p]),
+    "zs_attention": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
+    "zs_max_pool_nhwc": (_c_int, [_c_void_p, _c_void_p] + [_c_int] * 10 + [_c_void_p]),
+    "zs_global_mean_nhwc": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
+    "zs_upsample2x_nhwc": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
+    "zs_nchw_to_nhwc": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
+    "zs_nhwc_to_nchw": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
+    "zs_assemble_tokens": (_c_int, [_c_void_p] * 4 + [_c_int, _c_int, _c_int, _c_void_p]),
+    "zs_readout_concat": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 _lib = None
 
 

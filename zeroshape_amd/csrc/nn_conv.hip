@@ -1,0 +1,198 @@
+// fp32 implicit-GEMM convolution / linear layer on the MFMA pipe (v_mfma_f32_32x32x2_f32), the
+// one GEMM engine of the image encoders (DPT-hybrid depth model, ResNet-50 coordinate encoder,
+// intrinsics head: SURVEY.md section 8 rows a19-a23).
+//
+// Activations are channels-last: in [B][Hin][Win][Cin], out [B][Hout][Wout][Cout]; a token
+// matrix [n][C] is the 1x1 case with Hin = Win-less geometry (B=1, H=1, W=n).  GEMM view:
+//   M = B*Hout*Wout output pixels, N = Cout, K = kh*kw*Cin (tap-major, channel-minor)
+//   D[pixel][cout] = sum_k A[pixel][k] * Wt[k][cout]
+// Weights are packed once on the host as [K16/4][CoutPad][4] floats (K16 = K rounded up to 16,
+// CoutPad = Cout rounded up to 128, zero padded; zeroshape_amd/nn/pack.py) so the B tile is a
+// straight float4 copy and a lane's four k values of one MFMA group sit in one register quad.
+//
+// Tiling: 128 pixels x 128 couts per 256-lane workgroup, wave = 64 x 64 (2 x 2 MFMA tiles, 64
+// accumulator registers), K step 16 through a double-buffered LDS ring (2 x 16 KiB) with the
+// next step's global loads in flight under the current step's 64 MFMAs per wave.
+// LDS layout [k/4][row][4]: lane (row = l%32, half = l/32) reads ONE float4 = its k values
+// {4*(2t+half)+s, s=0..3} - conflict-free ds_read_b128, any k permutation is legal because both
+// operands use the same one.
+//
+// Fused into the launch: input transform (ReLU of the input, or a*in_scale+in_shift on in-bounds
+// taps, e.g. DPT's 2x-1), per-channel scale/shift (bias or folded BatchNorm), up to two residual
+// adds, activation (ReLU / GELU(erf) / ReLU+clamp1).
+#include "zs_common.h"
+#include "../../include/zeroshape_hip.h"
+
+#include <math.h>
+#include <stdint.h>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 16, KQ = BK / 4;
+
+struct ConvArgs {
+    const float *in, *w, *scale, *shift, *res1, *res2;
+    float *out;
+    int B, Hin, Win, Cin, Hout, Wout, Cout, CoutPad, kh, kw, stride, pad_t, pad_l, K, M;
+    int in_relu, act;
+    float in_scale, in_shift;
+};
+
+__device__ __forceinline__ float activate(float v, int act) {
+    if (act == ZS_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ZS_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (act == ZS_ACT_RELU_CLAMP1) return fminf(fmaxf(v, 0.f), 1.f);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
+    __shared__ f32x4 lds_a[2][KQ][BM];
+    __shared__ f32x4 lds_b[2][KQ][BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    // this thread's two A pixels (rows tid%128 of k-quads tid/128 and tid/128 + 2)
+    const int prow = tid & (BM - 1), kq_lo = tid >> 7;
+    const int pix = m0 + prow;
+    const bool pix_ok = pix < a.M;
+    int pb = 0, py = 0, px = 0;
+    if (pix_ok) {
+        pb = pix / (a.Hout * a.Wout);
+        const int rem = pix - pb * a.Hout * a.Wout;
+        py = rem / a.Wout;
+        px = rem - py * a.Wout;
+    }
+    const int iy0 = py * a.stride - a.pad_t, ix0 = px * a.stride - a.pad_l;
+    const float *in_b = a.in + (size_t)pb * a.Hin * a.Win * a.Cin;
+    const int taps = a.kh * a.kw;
+
+    auto load_a = [&](int k) -> f32x4 {            // 4 consecutive channels of one tap
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const int tap = k / a.Cin, c = k - tap * a.Cin;
+        if (pix_ok && tap < taps) {
+            const int ky = tap / a.kw, kx = tap - ky * a.kw;
+            const int iy = iy0 + ky, ix = ix0 + kx;
+            if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
+                v = *reinterpret_cast<const f32x4 *>(in_b + ((size_t)iy * a.Win + ix) * a.Cin + c);
+                if (a.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                v = v * a.in_scale + a.in_shift;
+            }
+        }
+        return v;
+    };
+    const f32x4 *wq = reinterpret_cast<const f32x4 *>(a.w);
+    auto load_b = [&](int kq, int n) -> f32x4 { return wq[(size_t)kq * a.CoutPad + n0 + n]; };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int ksteps = (a.K + BK - 1) / BK;
+    f32x4 ra[2], rb[2];
+    ra[0] = load_a(4 * kq_lo);
+    ra[1] = load_a(4 * (kq_lo + 2));
+    rb[0] = load_b(kq_lo, prow);
+    rb[1] = load_b(kq_lo + 2, prow);
+    lds_a[0][kq_lo][prow] = ra[0];
+    lds_a[0][kq_lo + 2][prow] = ra[1];
+    lds_b[0][kq_lo][prow] = rb[0];
+    lds_b[0][kq_lo + 2][prow] = rb[1];
+    __syncthreads();
+
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64, l32 = lane & 31, half = lane >> 5;
+    for (int ks = 0; ks < ksteps; ks++) {
+        const int cur = ks & 1;
+        const bool more = ks + 1 < ksteps;
+        if (more) {
+            const int kb = (ks + 1) * BK;
+            ra[0] = load_a(kb + 4 * kq_lo);
+            ra[1] = load_a(kb + 4 * (kq_lo + 2));
+            rb[0] = load_b((ks + 1) * KQ + kq_lo, prow);
+            rb[1] = load_b((ks + 1) * KQ + kq_lo + 2, prow);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            f32x4 fa[2], fb[2];
+            fa[0] = lds_a[cur][2 * t + half][wm + l32];
+            fa[1] = lds_a[cur][2 * t + half][wm + 32 + l32];
+            fb[0] = lds_b[cur][2 * t + half][wn + l32];
+            fb[1] = lds_b[cur][2 * t + half][wn + 32 + l32];
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            lds_a[cur ^ 1][kq_lo][prow] = ra[0];
+            lds_a[cur ^ 1][kq_lo + 2][prow] = ra[1];
+            lds_b[cur ^ 1][kq_lo][prow] = rb[0];
+            lds_b[cur ^ 1][kq_lo + 2][prow] = rb[1];
+        }
+        __syncthreads();
+    }
+
+    // epilogue: D[row = 8*(r/4) + 4*half + r%4][col = l32] per 32x32 tile
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int n = n0 + wn + 32 * j + l32;
+        if (n >= a.Cout) continue;
+        const float sc = a.scale ? a.scale[n] : 1.0f, sh = a.shift ? a.shift[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wm + 32 * i + 8 * (r >> 2) + 4 * half + (r & 3);
+                if (m >= a.M) continue;
+                const size_t o = (size_t)m * a.Cout + n;
+                float v = acc[i][j][r] * sc + sh;
+                if (a.res1) v += a.res1[o];
+                if (a.res2) v += a.res2[o];
+                a.out[o] = activate(v, a.act);
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int zs_conv2d_nhwc(const float *in, const float *packed_w, const float *scale, const float *shift,
+                              const float *res1, const float *res2, float *out, int batch, int Hin, int Win,
+                              int Cin, int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad_t,
+                              int pad_l, int flags, float in_scale, float in_shift, int act, void *stream) {
+    if (batch < 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || (Cin & 3) || Hout <= 0 || Wout <= 0 || Cout <= 0 ||
+        kh <= 0 || kw <= 0 || stride <= 0 || act < 0 || act > ZS_ACT_RELU_CLAMP1) {
+        zs::set_err("zs_conv2d_nhwc: bad geometry (B=%d in %dx%dx%d out %dx%dx%d k %dx%d s %d act %d; Cin must be "
+                    "a multiple of 4)", batch, Hin, Win, Cin, Hout, Wout, Cout, kh, kw, stride, act);
+        return 0;
+    }
+    if (batch == 0) return 1;
+    if (!in || !packed_w || !out) { zs::set_err("zs_conv2d_nhwc: null pointer"); return 0; }
+    const long long M = (long long)batch * Hout * Wout;
+    if (M > (1LL << 30)) { zs::set_err("zs_conv2d_nhwc: %lld output pixels", M); return 0; }
+    ConvArgs a;
+    a.in = in; a.w = packed_w; a.scale = scale; a.shift = shift; a.res1 = res1; a.res2 = res2; a.out = out;
+    a.B = batch; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout;
+    a.CoutPad = (Cout + BN - 1) / BN * BN;
+    a.kh = kh; a.kw = kw; a.stride = stride; a.pad_t = pad_t; a.pad_l = pad_l;
+    a.K = kh * kw * Cin; a.M = (int)M;
+    a.in_relu = (flags & ZS_CONV_IN_RELU) ? 1 : 0;
+    a.act = act; a.in_scale = in_scale; a.in_shift = in_shift;
+    const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(a.CoutPad / BN));
+    hipLaunchKernelGGL(conv_gemm_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return zs::check_launch("zs_conv2d_nhwc") ? 1 : 0;
+}
+
+extern "C" size_t zs_conv2d_packed_floats(int Cin, int Cout, int kh, int kw) {
+    const size_t K16 = ((size_t)kh * kw * Cin + BK - 1) / BK * BK;
+    const size_t CoutPad = ((size_t)Cout + BN - 1) / BN * BN;
+    return K16 * CoutPad;
+}

@@ -1,0 +1,321 @@
+// The non-GEMM layers of the image encoders, channels-last
+// fp32, each an HBM-bound single pass (or a per-group / per-row reduction):
+//   GroupNorm(+residual)(+ReLU)    timm ResNetV2 GroupNormAct inside DPT-hybrid's backbone
+//   LayerNorm                      ViT blocks
+//   multi-head attention           ViT blocks (197 tokens; softmax(q k^T / sqrt(d)) v)
+//   3x3/s2 max pool, global mean   ResNet stems / heads
+//   x2 bilinear (align_corners)    DPT fusion blocks and head (model/depth/blocks.py:330-336)
+//   NCHW <-> NHWC                  boundary conversions (the reference's tensors are NCHW)
+//   token assembly / readout cat   model/depth/vit.py:127-148 / :31-43
+#include "zs_common.h"
+#include "../../include/zeroshape_hip.h"
+
+#include <math.h>
+#include <stdint.h>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float block_sum(float v, float *lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    float r = lds[0];
+    for (int w = 1; w < nw; w++) r += lds[w];
+    return r;
+}
+
+// ---- GroupNorm over (HW x C/groups) of one sample, then affine, optional residual, optional ReLU ----
+__global__ __launch_bounds__(256) void group_norm_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                         const float *__restrict__ beta,
+                                                         const float *__restrict__ res, float *__restrict__ y,
+                                                         int HW, int C, int groups, float eps, int relu) {
+    __shared__ float lds[4];
+    const int b = blockIdx.x / groups, g = blockIdx.x % groups, cg = C / groups, n = HW * cg;
+    const size_t base = (size_t)b * HW * C + (size_t)g * cg;
+    auto at = [&](int e) -> size_t { return base + (size_t)(e / cg) * C + (e % cg); };
+    float s = 0.f;
+    for (int e = threadIdx.x; e < n; e += 256) s += x[at(e)];
+    const float mean = block_sum(s, lds) / n;
+    float q = 0.f;
+    for (int e = threadIdx.x; e < n; e += 256) { const float d = x[at(e)] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(block_sum(q, lds) / n + eps);
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const size_t o = at(e);
+        const int c = g * cg + e % cg;
+        float v = (x[o] - mean) * rstd * gamma[c] + beta[c];
+        if (res) v += res[o];
+        y[o] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+
+// ---- LayerNorm over the last dimension, one wave per row ----
+__global__ __launch_bounds__(256) void layer_norm_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                         const float *__restrict__ beta, float *__restrict__ y,
+                                                         int rows, int C, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float *xr = x + (size_t)row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / C + eps);
+    for (int c = lane; c < C; c += 64) y[(size_t)row * C + c] = (xr[c] - mean) * rstd * gamma[c] + beta[c];
+}
+
+// ---- attention: one workgroup per (sample, head), one query row per lane, keys/values streamed
+//      through LDS in chunks of 64 with an online softmax ----
+template <int D>
+__global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ qkv, float *__restrict__ out, int L,
+                                                        int heads, float scale) {
+    __shared__ f32x4 lds_k[64][D / 4];
+    __shared__ f32x4 lds_v[64][D / 4];
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads, C = heads * D;
+    const float *base = qkv + (size_t)b * L * 3 * C + h * D;
+    for (int r0 = 0; r0 < L; r0 += 256) {
+        const int row = r0 + threadIdx.x;
+        const bool ok = row < L;
+        f32x4 q[D / 4], o[D / 4];
+#pragma unroll
+        for (int i = 0; i < D / 4; i++) {
+            q[i] = ok ? *reinterpret_cast<const f32x4 *>(base + (size_t)row * 3 * C + 4 * i) : f32x4{0, 0, 0, 0};
+            q[i] *= scale;
+            o[i] = f32x4{0, 0, 0, 0};
+        }
+        float mx = -INFINITY, den = 0.f;
+        for (int j0 = 0; j0 < L; j0 += 64) {
+            __syncthreads();
+            for (int e = threadIdx.x; e < 64 * (D / 4); e += 256) {
+                const int j = e / (D / 4), i = e % (D / 4);
+                const bool jok = j0 + j < L;
+                const float *kv = base + (size_t)(j0 + j) * 3 * C + 4 * i;
+                lds_k[j][i] = jok ? *reinterpret_cast<const f32x4 *>(kv + C) : f32x4{0, 0, 0, 0};
+                lds_v[j][i] = jok ? *reinterpret_cast<const f32x4 *>(kv + 2 * C) : f32x4{0, 0, 0, 0};
+            }
+            __syncthreads();
+            const int jn = min(64, L - j0);
+            for (int j = 0; j < jn; j++) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < D / 4; i++) {
+                    const f32x4 k = lds_k[j][i];
+                    s += q[i].x * k.x + q[i].y * k.y + q[i].z * k.z + q[i].w * k.w;
+                }
+                const float nm = fmaxf(mx, s), corr = __expf(mx - nm), p = __expf(s - nm);
+                den = den * corr + p;
+#pragma unroll
+                for (int i = 0; i < D / 4; i++) o[i] = o[i] * corr + p * lds_v[j][i];
+                mx = nm;
+            }
+        }
+        if (ok) {
+            const float inv = 1.0f / den;
+#pragma unroll
+            for (int i = 0; i < D / 4; i++)
+                *reinterpret_cast<f32x4 *>(out + ((size_t)b * L + row) * C + h * D + 4 * i) = o[i] * inv;
+        }
+    }
+}
+
+// ---- pooling / resampling / layout ----
+__global__ __launch_bounds__(256) void max_pool_kernel(const float *__restrict__ x, float *__restrict__ y, int B,
+                                                       int Hin, int Win, int C, int Hout, int Wout, int k, int stride,
+                                                       int pad_t, int pad_l) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)B * Hout * Wout * C;
+    if (i >= total) return;
+    const int c = i % C, ox = (i / C) % Wout, oy = (i / C / Wout) % Hout, b = i / C / Wout / Hout;
+    float m = -INFINITY;
+    for (int ky = 0; ky < k; ky++)
+        for (int kx = 0; kx < k; kx++) {
+            const int iy = oy * stride - pad_t + ky, ix = ox * stride - pad_l + kx;
+            if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win)
+                m = fmaxf(m, x[(((size_t)b * Hin + iy) * Win + ix) * C + c]);
+        }
+    y[i] = m;
+}
+
+__global__ __launch_bounds__(256) void global_mean_kernel(const float *__restrict__ x, float *__restrict__ y, int HW,
+                                                          int C) {
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int p = 0; p < HW; p++) s += x[((size_t)b * HW + p) * C + c];
+    y[(size_t)b * C + c] = s / HW;
+}
+
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float *__restrict__ x, float *__restrict__ y, int B,
+                                                         int Hin, int Win, int C) {
+    const int Hout = 2 * Hin, Wout = 2 * Win;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)B * Hout * Wout * C;
+    if (i >= total) return;
+    const int c = i % C, ox = (i / C) % Wout, oy = (i / C / Wout) % Hout, b = i / C / Wout / Hout;
+    // torch upsample_bilinear2d, align_corners=True: src = dst * (in - 1) / (out - 1)
+    const float sy = Hout > 1 ? (float)(Hin - 1) / (float)(Hout - 1) : 0.f, sx = Wout > 1 ? (float)(Win - 1) / (float)(Wout - 1) : 0.f;
+    const float fy = sy * oy, fx = sx * ox;
+    const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + (y0 < Hin - 1 ? 1 : 0), x1 = x0 + (x0 < Win - 1 ? 1 : 0);
+    const float ly = fy - y0, lx = fx - x0;
+    const float *X = x + (size_t)b * Hin * Win * C + c;
+    const float v00 = X[((size_t)y0 * Win + x0) * C], v01 = X[((size_t)y0 * Win + x1) * C],
+                v10 = X[((size_t)y1 * Win + x0) * C], v11 = X[((size_t)y1 * Win + x1) * C];
+    y[i] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+}
+
+// NCHW [B][C][H][W] -> NHWC [B][H][W][Cpad] (extra channels zero)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restrict__ x, float *__restrict__ y, int B,
+                                                           int C, int HW, int Cpad) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)B * HW * Cpad;
+    if (i >= total) return;
+    const int c = i % Cpad, p = (i / Cpad) % HW, b = i / Cpad / HW;
+    y[i] = c < C ? x[((size_t)b * C + c) * HW + p] : 0.f;
+}
+// NHWC [B][H][W][C] -> NCHW [B][C][H][W]
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float *__restrict__ x, float *__restrict__ y, int B,
+                                                           int C, int HW) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)B * HW * C;
+    if (i >= total) return;
+    const int p = i % HW, c = (i / HW) % C, b = i / HW / C;
+    y[i] = x[((size_t)b * HW + p) * C + c];
+}
+
+// tokens[b][0] = cls + pos[0]; tokens[b][1+i] = feat[b][i] + pos[1+i]   (vit.py:139-147)
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(const float *__restrict__ feat,
+                                                              const float *__restrict__ cls,
+                                                              const float *__restrict__ pos, float *__restrict__ tok,
+                                                              int B, int n, int C) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)B * (n + 1) * C;
+    if (i >= total) return;
+    const int c = i % C, t = (i / C) % (n + 1), b = i / C / (n + 1);
+    tok[i] = (t == 0 ? cls[c] : feat[((size_t)b * n + t - 1) * C + c]) + pos[(size_t)t * C + c];
+}
+
+// ProjectReadout's concatenation (vit.py:39-41): out[b][i] = [tok[b][1+i] | tok[b][0]]
+__global__ __launch_bounds__(256) void readout_concat_kernel(const float *__restrict__ tok, float *__restrict__ out,
+                                                             int B, int n, int C) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)B * n * 2 * C;
+    if (i >= total) return;
+    const int c = i % (2 * C), t = (i / (2 * C)) % n, b = i / (2 * C) / n;
+    out[i] = c < C ? tok[((size_t)b * (n + 1) + 1 + t) * C + c] : tok[(size_t)b * (n + 1) * C + (c - C)];
+}
+
+inline unsigned blocks_for(size_t total) { return (unsigned)((total + 255) / 256); }
+inline hipStream_t S(void *s) { return static_cast<hipStream_t>(s); }
+
+}  // namespace
+
+#define ZS_REQUIRE(cond, ...)            \
+    do {                                 \
+        if (!(cond)) {                   \
+            zs::set_err(__VA_ARGS__);    \
+            return 0;                    \
+        }                                \
+    } while (0)
+
+extern "C" int zs_group_norm_nhwc(const float *x, const float *gamma, const float *beta, const float *residual,
+                                  float *y, int batch, int HW, int C, int groups, float eps, int relu, void *stream) {
+    ZS_REQUIRE(batch >= 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0,
+               "zs_group_norm_nhwc: bad size (B=%d HW=%d C=%d groups=%d)", batch, HW, C, groups);
+    if (batch == 0) return 1;
+    ZS_REQUIRE(x && gamma && beta && y, "zs_group_norm_nhwc: null pointer");
+    hipLaunchKernelGGL(group_norm_kernel, dim3(batch * groups), dim3(256), 0, S(stream), x, gamma, beta, residual, y,
+                       HW, C, groups, eps, relu);
+    return zs::check_launch("zs_group_norm_nhwc") ? 1 : 0;
+}
+
+extern "C" int zs_layer_norm(const float *x, const float *gamma, const float *beta, float *y, int rows, int C,
+                             float eps, void *stream) {
+    ZS_REQUIRE(rows >= 0 && C > 0, "zs_layer_norm: bad size (rows=%d C=%d)", rows, C);
+    if (rows == 0) return 1;
+    ZS_REQUIRE(x && gamma && beta && y, "zs_layer_norm: null pointer");
+    hipLaunchKernelGGL(layer_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, S(stream), x, gamma, beta, y, rows, C,
+                       eps);
+    return zs::check_launch("zs_layer_norm") ? 1 : 0;
+}
+
+extern "C" int zs_attention(const float *qkv, float *out, int batch, int L, int heads, int head_dim, void *stream) {
+    ZS_REQUIRE(batch >= 0 && L > 0 && heads > 0 && (head_dim == 32 || head_dim == 64),
+               "zs_attention: bad size (B=%d L=%d heads=%d head_dim=%d; head_dim must be 32 or 64)", batch, L, heads,
+               head_dim);
+    if (batch == 0) return 1;
+    ZS_REQUIRE(qkv && out, "zs_attention: null pointer");
+    const float scale = 1.0f / sqrtf((float)head_dim);
+    if (head_dim == 64)
+        hipLaunchKernelGGL(attention_kernel<64>, dim3(batch * heads), dim3(256), 0, S(stream), qkv, out, L, heads, scale);
+    else
+        hipLaunchKernelGGL(attention_kernel<32>, dim3(batch * heads), dim3(256), 0, S(stream), qkv, out, L, heads, scale);
+    return zs::check_launch("zs_attention") ? 1 : 0;
+}
+
+extern "C" int zs_max_pool_nhwc(const float *x, float *y, int batch, int Hin, int Win, int C, int Hout, int Wout,
+                                int k, int stride, int pad_t, int pad_l, void *stream) {
+    ZS_REQUIRE(batch >= 0 && Hin > 0 && Win > 0 && C > 0 && Hout > 0 && Wout > 0 && k > 0 && stride > 0,
+               "zs_max_pool_nhwc: bad size");
+    if (batch == 0) return 1;
+    ZS_REQUIRE(x && y, "zs_max_pool_nhwc: null pointer");
+    hipLaunchKernelGGL(max_pool_kernel, dim3(blocks_for((size_t)batch * Hout * Wout * C)), dim3(256), 0, S(stream), x,
+                       y, batch, Hin, Win, C, Hout, Wout, k, stride, pad_t, pad_l);
+    return zs::check_launch("zs_max_pool_nhwc") ? 1 : 0;
+}
+
+extern "C" int zs_global_mean_nhwc(const float *x, float *y, int batch, int HW, int C, void *stream) {
+    ZS_REQUIRE(batch >= 0 && batch <= 65535 && HW > 0 && C > 0, "zs_global_mean_nhwc: bad size");
+    if (batch == 0) return 1;
+    ZS_REQUIRE(x && y, "zs_global_mean_nhwc: null pointer");
+    hipLaunchKernelGGL(global_mean_kernel, dim3((C + 255) / 256, batch), dim3(256), 0, S(stream), x, y, HW, C);
+    return zs::check_launch("zs_global_mean_nhwc") ? 1 : 0;
+}
+
+extern "C" int zs_upsample2x_nhwc(const float *x, float *y, int batch, int Hin, int Win, int C, void *stream) {
+    ZS_REQUIRE(batch >= 0 && Hin > 0 && Win > 0 && C > 0, "zs_upsample2x_nhwc: bad size");
+    if (batch == 0) return 1;
+    ZS_REQUIRE(x && y, "zs_upsample2x_nhwc: null pointer");
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(blocks_for((size_t)batch * 4 * Hin * Win * C)), dim3(256), 0, S(stream),
+                       x, y, batch, Hin, Win, C);
+    return zs::check_launch("zs_upsample2x_nhwc") ? 1 : 0;
+}
+
+extern "C" int zs_nchw_to_nhwc(const float *x, float *y, int batch, int C, int HW, int Cpad, void *stream) {
+    ZS_REQUIRE(batch >= 0 && C > 0 && HW > 0 && Cpad >= C, "zs_nchw_to_nhwc: bad size");
+    if (batch == 0) return 1;
+    ZS_REQUIRE(x && y, "zs_nchw_to_nhwc: null pointer");
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(blocks_for((size_t)batch * HW * Cpad)), dim3(256), 0, S(stream), x, y,
+                       batch, C, HW, Cpad);
+    return zs::check_launch("zs_nchw_to_nhwc") ? 1 : 0;
+}
+
+extern "C" int zs_nhwc_to_nchw(const float *x, float *y, int batch, int C, int HW, void *stream) {
+    ZS_REQUIRE(batch >= 0 && C > 0 && HW > 0, "zs_nhwc_to_nchw: bad size");
+    if (batch == 0) return 1;
+    ZS_REQUIRE(x && y, "zs_nhwc_to_nchw: null pointer");
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(blocks_for((size_t)batch * HW * C)), dim3(256), 0, S(stream), x, y,
+                       batch, C, HW);
+    return zs::check_launch("zs_nhwc_to_nchw") ? 1 : 0;
+}
+
+extern "C" int zs_assemble_tokens(const float *feat, const float *cls, const float *pos, float *tokens, int batch,
+                                  int n, int C, void *stream) {
+    ZS_REQUIRE(batch >= 0 && n > 0 && C > 0, "zs_assemble_tokens: bad size");
+    if (batch == 0) return 1;
+    ZS_REQUIRE(feat && cls && pos && tokens, "zs_assemble_tokens: null pointer");
+    hipLaunchKernelGGL(assemble_tokens_kernel, dim3(blocks_for((size_t)batch * (n + 1) * C)), dim3(256), 0, S(stream),
+                       feat, cls, pos, tokens, batch, n, C);
+    return zs::check_launch("zs_assemble_tokens") ? 1 : 0;
+}
+
+extern "C" int zs_readout_concat(const float *tokens, float *out, int batch, int n, int C, void *stream) {
+    ZS_REQUIRE(batch >= 0 && n > 0 && C > 0, "zs_readout_concat: bad size");
+    if (batch == 0) return 1;
+    ZS_REQUIRE(tokens && out, "zs_readout_concat: null pointer");
+    hipLaunchKernelGGL(readout_concat_kernel, dim3(blocks_for((size_t)batch * n * 2 * C)), dim3(256), 0, S(stream),
+                       tokens, out, batch, n, C);
+    return zs::check_launch("zs_readout_concat") ? 1 : 0;
+}

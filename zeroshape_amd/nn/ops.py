@@ -1,0 +1,173 @@
+"""Launch wrappers for the encoder layers (include/zeroshape_hip.h, "Encoder layers").
+Tensors are fp32 channels-last GPU tensors [B,H,W,C]; token matrices are [B,L,C]."""
+import torch
+
+from .. import _lib
+
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_CLAMP1 = 0, 1, 2, 3
+
+
+def _chk(t, what):
+    if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError("%s: contiguous fp32 GPU tensor required" % what)
+    return t
+
+
+def _stream(t):
+    return _lib.current_stream_ptr(t.device)
+
+
+def conv2d(x, pc, res1=None, res2=None, act=ACT_NONE, in_relu=False, in_scale=1.0, in_shift=0.0):
+    """x [B,H,W,Cin] -> [B,Ho,Wo,Cout] with the fused epilogue of zs_conv2d_nhwc."""
+    lib = _lib.load()
+    _chk(x, "conv2d input")
+    B, H, W, C = x.shape
+    assert C == pc.cin, "conv2d: input has %d channels, layer expects %d" % (C, pc.cin)
+    Ho, pt = pc.out_size(H, pc.kh)
+    Wo, pl = pc.out_size(W, pc.kw)
+    out = torch.empty(B, Ho, Wo, pc.cout, dtype=torch.float32, device=x.device)
+    for r in (res1, res2):
+        if r is not None:
+            _chk(r, "conv2d residual")
+            assert r.shape == out.shape
+    with torch.cuda.device(x.device):
+        _lib.check(lib.zs_conv2d_nhwc(_lib.ptr(x), _lib.ptr(pc.w), _lib.ptr(pc.scale), _lib.ptr(pc.shift),
+                                      _lib.ptr(res1), _lib.ptr(res2), _lib.ptr(out), B, H, W, C, Ho, Wo, pc.cout,
+                                      pc.kh, pc.kw, pc.stride, pt, pl, 1 if in_relu else 0, float(in_scale),
+                                      float(in_shift), act, _stream(x)), "zs_conv2d_nhwc")
+    return out
+
+
+def linear(x, pc, res1=None, act=ACT_NONE):
+    """x [..., Cin] -> [..., Cout] through the same GEMM (1x1 geometry)."""
+    lead = x.shape[:-1]
+    n = 1
+    for d in lead:
+        n *= d
+    y = conv2d(x.reshape(1, 1, n, x.shape[-1]), pc,
+               res1=None if res1 is None else res1.reshape(1, 1, n, pc.cout), act=act)
+    return y.view(*lead, pc.cout)
+
+
+def group_norm(x, gamma, beta, groups=32, eps=1e-5, relu=False, residual=None):
+    lib = _lib.load()
+    _chk(x, "group_norm input")
+    B, H, W, C = x.shape
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.zs_group_norm_nhwc(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(residual),
+                                          _lib.ptr(y), B, H * W, C, groups, float(eps), 1 if relu else 0,
+                                          _stream(x)), "zs_group_norm_nhwc")
+    return y
+
+
+def layer_norm(x, gamma, beta, eps=1e-6):
+    lib = _lib.load()
+    _chk(x, "layer_norm input")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.zs_layer_norm(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(y), rows, C, float(eps),
+                                     _stream(x)), "zs_layer_norm")
+    return y
+
+
+def attention(qkv, heads):
+    """qkv [B,L,3*C] -> [B,L,C]."""
+    lib = _lib.load()
+    _chk(qkv, "attention input")
+    B, L, C3 = qkv.shape
+    C = C3 // 3
+    out = torch.empty(B, L, C, dtype=torch.float32, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        _lib.check(lib.zs_attention(_lib.ptr(qkv), _lib.ptr(out), B, L, heads, C // heads, _stream(qkv)),
+                   "zs_attention")
+    return out
+
+
+def max_pool(x, k=3, stride=2, padding=1):
+    """padding: int (torch, -inf) or "same" (timm MaxPool2dSame)."""
+    lib = _lib.load()
+    _chk(x, "max_pool input")
+    B, H, W, C = x.shape
+
+    def size(n):
+        if padding == "same":
+            out = -(-n // stride)
+            return out, max((out - 1) * stride + k - n, 0) // 2
+        return (n + 2 * padding - k) // stride + 1, padding
+    Ho, pt = size(H)
+    Wo, pl = size(W)
+    y = torch.empty(B, Ho, Wo, C, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.zs_max_pool_nhwc(_lib.ptr(x), _lib.ptr(y), B, H, W, C, Ho, Wo, k, stride, pt, pl, _stream(x)),
+                   "zs_max_pool_nhwc")
+    return y
+
+
+def global_mean(x):
+    """[B,H,W,C] -> [B,C]."""
+    lib = _lib.load()
+    _chk(x, "global_mean input")
+    B, H, W, C = x.shape
+    y = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.zs_global_mean_nhwc(_lib.ptr(x), _lib.ptr(y), B, H * W, C, _stream(x)), "zs_global_mean_nhwc")
+    return y
+
+
+def upsample2x(x):
+    lib = _lib.load()
+    _chk(x, "upsample2x input")
+    B, H, W, C = x.shape
+    y = torch.empty(B, 2 * H, 2 * W, C, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.zs_upsample2x_nhwc(_lib.ptr(x), _lib.ptr(y), B, H, W, C, _stream(x)), "zs_upsample2x_nhwc")
+    return y
+
+
+def to_nhwc(x, cpad=None):
+    """NCHW [B,C,H,W] -> NHWC [B,H,W,cpad or C] (zero-filled extra channels)."""
+    lib = _lib.load()
+    x = _chk(x.float().contiguous(), "to_nhwc input")
+    B, C, H, W = x.shape
+    cp = cpad or C
+    y = torch.empty(B, H, W, cp, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.zs_nchw_to_nhwc(_lib.ptr(x), _lib.ptr(y), B, C, H * W, cp, _stream(x)), "zs_nchw_to_nhwc")
+    return y
+
+
+def to_nchw(x):
+    lib = _lib.load()
+    _chk(x, "to_nchw input")
+    B, H, W, C = x.shape
+    y = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.zs_nhwc_to_nchw(_lib.ptr(x), _lib.ptr(y), B, C, H * W, _stream(x)), "zs_nhwc_to_nchw")
+    return y
+
+
+def assemble_tokens(feat, cls, pos):
+    """feat [B,n,C], cls [C], pos [n+1,C] -> [B,n+1,C]."""
+    lib = _lib.load()
+    _chk(feat, "assemble_tokens input")
+    B, n, C = feat.shape
+    y = torch.empty(B, n + 1, C, dtype=torch.float32, device=feat.device)
+    with torch.cuda.device(feat.device):
+        _lib.check(lib.zs_assemble_tokens(_lib.ptr(feat), _lib.ptr(cls), _lib.ptr(pos), _lib.ptr(y), B, n, C,
+                                          _stream(feat)), "zs_assemble_tokens")
+    return y
+
+
+def readout_concat(tokens):
+    """tokens [B,n+1,C] -> [B,n,2C] = [patch token | cls token]."""
+    lib = _lib.load()
+    _chk(tokens, "readout_concat input")
+    B, n1, C = tokens.shape
+    y = torch.empty(B, n1 - 1, 2 * C, dtype=torch.float32, device=tokens.device)
+    with torch.cuda.device(tokens.device):
+        _lib.check(lib.zs_readout_concat(_lib.ptr(tokens), _lib.ptr(y), B, n1 - 1, C, _stream(tokens)),
+                   "zs_readout_concat")
+    return y
