@@ -33,6 +33,40 @@ def frontend_golden():
 
 
 @pytest.fixture(scope="session")
+def encoder_golden():
+    import numpy as np
+    return dict(np.load(os.path.join(GOLDEN, "encoder_golden.npz")))
+
+
+def _shapes(keys, shapes):
+    return {str(k): tuple(int(x) for x in str(s).split(",") if x) for k, s in zip(keys, shapes)}
+
+
+@pytest.fixture(scope="session")
+def encoder_sd(encoder_golden):
+    """Seeded encoder parameters under the reference Graph's state-dict names (torch CPU), with
+    the head calibration of tests/golden/make_encoder_golden.py applied."""
+    import torch
+    from zeroshape_amd import synthetic as syn
+    shapes = _shapes(encoder_golden["graph_keys"], encoder_golden["graph_shapes"])
+    enc = {k: v for k, v in shapes.items() if not k.startswith("impl_network.")}
+    sd = {k: torch.from_numpy(v) for k, v in syn.seeded_encoder_state_dict(enc, seed=0).items()}
+    gain, offset = encoder_golden["head_calibration"]
+    sd["dpt_depth.scratch.output_conv.4.weight"] = sd["dpt_depth.scratch.output_conv.4.weight"] * float(gain)
+    sd["dpt_depth.scratch.output_conv.4.bias"] = torch.full_like(sd["dpt_depth.scratch.output_conv.4.bias"],
+                                                                 float(offset))
+    return sd
+
+
+@pytest.fixture(scope="session")
+def att_sd(encoder_golden):
+    import torch
+    from zeroshape_amd import synthetic as syn
+    shapes = _shapes(encoder_golden["att_keys"], encoder_golden["att_shapes"])
+    return {k: torch.from_numpy(v) for k, v in syn.seeded_encoder_state_dict(shapes, seed=1).items()}
+
+
+@pytest.fixture(scope="session")
 def seeded_sd(decoder_golden):
     """Seeded decoder weights as torch CPU tensors (pos_embed from the golden file,
     i.e. as the reference initialised it)."""

@@ -139,3 +139,48 @@ def seeded_depth_pair(seed=0, batch=2, size=224):
         + 0.15 * rs.randn(*target.shape)
     pred = (1.0 / np.maximum(pred_disp, 0.05)).astype(np.float32)
     return pred, target.astype(np.float32), mask
+
+
+def seeded_encoder_state_dict(shapes, seed=0):
+    """Build-owned deterministic parameters for the image encoders.  `shapes` is an ordered
+    mapping name -> shape with the reference's state-dict names; the value of every entry is
+    drawn from a RandomState seeded by (seed, position) with a scale picked from the name, so
+    activations stay O(1) through ~100 layers:
+      conv / linear weights  N(0, 1/fan_in);  biases, BN/GN/LN beta, running_mean  0.1 N(0,1)
+      BN/GN/LN gamma  U(0.8, 1.2);  running_var  U(0.8, 1.2);  tokens / pos_embed  0.5 N(0,1)
+      num_batches_tracked  0."""
+    out = {}
+    for i, (name, shape) in enumerate(shapes.items()):
+        rs = np.random.RandomState((seed * 7919 + i * 104729 + 17) % (2 ** 31))
+        shape = tuple(int(s) for s in shape)
+        leaf = name.rsplit(".", 1)[-1]
+        if leaf == "num_batches_tracked":
+            v = np.zeros(shape, np.int64)
+        elif leaf == "running_var":
+            v = rs.uniform(0.8, 1.2, shape)
+        elif leaf == "running_mean":
+            v = 0.1 * rs.randn(*shape)
+        elif leaf in ("cls_token", "pos_embed", "two_d_pos_embed", "invalid_coord_token"):
+            v = 0.5 * rs.randn(*shape)
+        elif leaf == "bias":
+            v = 0.1 * rs.randn(*shape)
+        elif leaf == "weight" and len(shape) == 1:
+            v = rs.uniform(0.8, 1.2, shape)
+        elif leaf == "weight":
+            fan_in = int(np.prod(shape[1:]))
+            v = rs.randn(*shape) / np.sqrt(fan_in)
+        else:
+            raise KeyError("seeded_encoder_state_dict: no rule for %r" % name)
+        out[name] = v.astype(np.int64 if leaf == "num_batches_tracked" else np.float32)
+    return out
+
+
+def seeded_rgb_scene(seed=0, batch=2, size=224):
+    """RGB image in [0,1] and object mask in {0,1} ([B,3,S,S], [B,1,S,S] float32): a shaded blob
+    over a white background, like the reference's preprocessed inputs (data/synthetic.py)."""
+    depth, mask, _ = seeded_depth_scene(seed, batch, size)
+    rs = np.random.RandomState(3000 + seed)
+    tint = rs.uniform(0.2, 0.9, size=(batch, 3, 1, 1))
+    shade = (1.9 - depth) / 1.2
+    rgb = mask * (tint * shade + 0.05 * rs.rand(batch, 3, size, size)) + (1 - mask) * 1.0
+    return np.clip(rgb, 0, 1).astype(np.float32), mask
