@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 8
+#define ZS_ABI_VERSION 9
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -250,9 +250,13 @@ int zs_depth_metrics(const float *prediction, const float *target, const float *
  *   out [B][L][heads*head_dim] = softmax(q k^T / sqrt(head_dim)) v.  head_dim 32 or 64.
  * zs_max_pool_nhwc: k x k window, -inf padding.   zs_global_mean_nhwc: [B][HW][C] -> [B][C].
  * zs_upsample2x_nhwc: bilinear, align_corners=True, [B][H][W][C] -> [B][2H][2W][C].
- * zs_nchw_to_nhwc / zs_nhwc_to_nchw: boundary layout conversion (Cpad >= C zero-fills).
+ * zs_nchw_to_nhwc / zs_nhwc_to_nchw: boundary layout conversion (Cpad >= C zero-fills; mask [B][HW],
+ *   may be NULL, multiplies every channel of a pixel: CoordEncRes' coord*mask, seen_coord_enc.py:184).
  * zs_assemble_tokens: tokens [B][n+1][C] = [cls | feat [B][n][C]] + pos [n+1][C].
  * zs_readout_concat: out [B][n][2C] = [tokens[b][1+i] | tokens[b][0]]  (vit.py:31-43).
+ * zs_window_tokens: CoordEmb's token preparation (seen_coord_enc.py:50-71): emb [B][H][W][C],
+ *   mask [B][H][W] bytes (invalid pixels take invalid_token [C]), cls [C], pos [win*win+1][C] ->
+ *   out [B*(H/win)*(W/win)][win*win+1][C].
  * ------------------------------------------------------------------------- */
 #define ZS_ACT_NONE 0
 #define ZS_ACT_RELU 1
@@ -273,11 +277,14 @@ int zs_max_pool_nhwc(const float *x, float *y, int batch, int Hin, int Win, int 
                      int stride, int pad_t, int pad_l, void *stream);
 int zs_global_mean_nhwc(const float *x, float *y, int batch, int HW, int C, void *stream);
 int zs_upsample2x_nhwc(const float *x, float *y, int batch, int Hin, int Win, int C, void *stream);
-int zs_nchw_to_nhwc(const float *x, float *y, int batch, int C, int HW, int Cpad, void *stream);
+int zs_nchw_to_nhwc(const float *x, const float *mask, float *y, int batch, int C, int HW, int Cpad,
+                    void *stream);
 int zs_nhwc_to_nchw(const float *x, float *y, int batch, int C, int HW, void *stream);
 int zs_assemble_tokens(const float *feat, const float *cls, const float *pos, float *tokens, int batch, int n,
                        int C, void *stream);
 int zs_readout_concat(const float *tokens, float *out, int batch, int n, int C, void *stream);
+int zs_window_tokens(const float *emb, const uint8_t *mask, const float *invalid_token, const float *cls,
+                     const float *pos, float *out, int batch, int H, int W, int C, int win, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,132 @@
+"""GPU parity of the encoder mirrors (DPTDepthModel, intrinsics head, CoordEncRes, CoordEncAtt,
+Graph.forward) through the HIP layers vs oracle/encoder_ref.py and the golden outputs of the
+reference's own modules.  fp32 throughout; a ~100-layer stack accumulates rounding, so
+activations are compared relative to their scale: max|err| <= 1e-4 * max|want| (north_star's
+1e-4), the depth map absolutely (values in [0,1])."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoder_ref as E
+from tests.test_encoder_contract import make_opt
+from zeroshape_amd import synthetic as syn
+from zeroshape_amd.utils.options import EasyDict as edict
+
+pytestmark = pytest.mark.gpu
+
+
+def close(got, want, tol=1e-4, msg=""):
+    got = np.asarray(got.detach().cpu() if torch.is_tensor(got) else got, np.float64)
+    want = np.asarray(want.detach().cpu() if torch.is_tensor(want) else want, np.float64)
+    assert got.shape == want.shape, "%s: %s vs %s" % (msg, got.shape, want.shape)
+    err, scale = np.abs(got - want).max(), max(np.abs(want).max(), 1e-6)
+    assert err <= tol * scale, "%s: err %.3g scale %.3g (rel %.3g)" % (msg, err, scale, err / scale)
+
+
+def sample(x, step):
+    return x.detach().cpu().numpy().reshape(-1)[::step]
+
+
+@pytest.fixture(scope="module")
+def graph(encoder_sd, seeded_sd):
+    from zeroshape_amd.model.compute_graph.graph_shape import Graph
+    g = Graph(make_opt())
+    full = dict(encoder_sd)
+    full.update({"impl_network." + k: v for k, v in seeded_sd.items()})
+    g.load_state_dict(full, strict=True)
+    return g.cuda().eval()
+
+
+def test_dpt_depth_vs_oracle_and_golden(graph, encoder_sd, encoder_golden):
+    rgb, _ = [torch.from_numpy(a) for a in syn.seeded_rgb_scene(seed=0, batch=2)]
+    taps, otaps = {}, {}
+    depth, feat = graph.dpt_depth(rgb.cuda(), get_feat=True, taps=taps)
+    odepth, ofeat = E.dpt_depth(E._sub(encoder_sd, "dpt_depth."), rgb, otaps)
+    for name in ("stage0", "stage1", "stage2", "block0", "block8", "block11", "layer3_rn", "layer4_rn", "path4",
+                 "path3", "path2", "path1"):
+        t = taps[name]
+        t = t.permute(0, 3, 1, 2) if t.dim() == 4 else t           # channels-last -> NCHW
+        close(t, otaps[name], msg=name)
+        close(sample(t.contiguous(), 997), encoder_golden["dpt_%s_s997" % name], msg="golden " + name)
+    assert depth.shape == (2, 1, 224, 224) and feat.shape == (2, 768, 7, 7)
+    close(feat, ofeat, msg="layer_4")
+    np.testing.assert_allclose(depth.cpu().numpy(), odepth.numpy(), atol=1e-4, rtol=0)
+    np.testing.assert_allclose(sample(depth, 211), encoder_golden["depth_s211"], atol=1e-4, rtol=0)
+    close(sample(feat, 53), encoder_golden["intr_feat_s53"], msg="golden layer_4")
+    assert float(depth.min()) >= 0 and float(depth.max()) <= 1
+    # get_feat=False returns the depth alone (dpt_depth.py:121-122)
+    assert torch.equal(graph.dpt_depth(rgb.cuda()), depth)
+
+
+def test_graph_forward_vs_oracle_and_golden(graph, encoder_sd, encoder_golden):
+    rgb, mask = [torch.from_numpy(a) for a in syn.seeded_rgb_scene(seed=0, batch=2)]
+    opt = make_opt()
+    opt.arch.depth.dsp = 1
+    var = edict(dict(idx=torch.arange(2), rgb_input_map=rgb.cuda(), mask_input_map=mask.cuda(),
+                     pose_gt=torch.zeros(2, 3, 4).cuda()))
+    var = graph.forward(opt, var, training=False, get_loss=False)
+    want = E.graph_forward(encoder_sd, rgb, mask)
+    np.testing.assert_allclose(var.depth_pred.cpu().numpy(), want["depth_pred"].numpy(), atol=1e-4, rtol=0)
+    close(var.intr_pred, want["intr_pred"], msg="intr_pred")
+    np.testing.assert_allclose(var.intr_pred.cpu().numpy(), encoder_golden["g_intr_pred"], rtol=2e-4, atol=2e-3)
+    # seen points: the unit-ball normalisation divides by the max radius -> absolute 2e-4
+    np.testing.assert_allclose(var.seen_points.cpu().numpy(), want["seen_points"].numpy(), atol=2e-4, rtol=0)
+    np.testing.assert_allclose(sample(var.seen_points, 101), encoder_golden["g_seen_points_s101"], atol=2e-4, rtol=0)
+    assert var.latent_depth.shape == (2, 197, 256)
+    close(var.latent_depth, want["latent_depth"], tol=2e-4, msg="latent_depth")
+    close(sample(var.latent_depth, 37), encoder_golden["g_latent_depth_s37"], tol=2e-4, msg="golden latent")
+    assert torch.equal(var.validity_mask.cpu(), (mask > 0.5).float().view(2, -1))
+    assert var.latent_semantic is None
+    # the decoder takes the latent as is (graph_shape.py:185 call shape)
+    pts = torch.from_numpy(np.random.RandomState(0).uniform(-1, 1, (2, 512, 3)).astype(np.float32)).cuda()
+    logits, attn = graph.impl_network(var.latent_depth, None, pts)
+    assert logits.shape == (2, 512) and attn.shape == (2, 512, 197) and bool(torch.isfinite(logits).all())
+
+
+def test_coord_enc_res(graph, encoder_sd, encoder_golden):
+    _, mask, _ = [torch.from_numpy(a) for a in syn.seeded_depth_scene(seed=1, batch=2)]
+    coord = torch.from_numpy(np.random.RandomState(11).uniform(-1, 1, size=(2, 3, 224, 224)).astype(np.float32))
+    lat = graph.coord_encoder(coord.cuda(), mask.cuda())
+    want = E.coord_enc_res(E._sub(encoder_sd, "coord_encoder."), coord, mask)
+    assert lat.shape == (2, 197, 256)
+    close(lat, want, msg="CoordEncRes")
+    close(sample(lat, 37), encoder_golden["res_latent_s37"], msg="golden CoordEncRes")
+
+
+def test_coord_enc_att(att_sd, encoder_golden):
+    from zeroshape_amd.model.shape.seen_coord_enc import CoordEncAtt
+    enc = CoordEncAtt(embed_dim=256, n_blocks=12, num_heads=8, win_size=8)
+    enc.load_state_dict(att_sd, strict=True)
+    enc = enc.cuda().eval()
+    _, mask, _ = [torch.from_numpy(a) for a in syn.seeded_depth_scene(seed=1, batch=2)]
+    coord = torch.from_numpy(np.random.RandomState(12).uniform(-1, 1, size=(2, 112, 112, 3)).astype(np.float32))
+    m = torch.nn.functional.interpolate(mask, (112, 112)) > 0.5
+    lat = enc(coord.cuda(), m[:, 0].cuda())
+    want = E.coord_enc_att(att_sd, coord, m[:, 0])
+    assert lat.shape == (2, 197, 256)
+    close(lat, want, msg="CoordEncAtt")
+    close(sample(lat, 37), encoder_golden["att_latent_s37"], msg="golden CoordEncAtt")
+
+
+def test_repack_after_weight_update(graph):
+    """In-place parameter changes (optimizer step, load_state_dict) invalidate the packed copy."""
+    rgb, _ = [torch.from_numpy(a) for a in syn.seeded_rgb_scene(seed=0, batch=1)]
+    d0 = graph.dpt_depth(rgb.cuda()).clone()
+    b = graph.dpt_depth.scratch.output_conv[4].bias
+    with torch.no_grad():
+        b.add_(-0.25)
+    d1 = graph.dpt_depth(rgb.cuda()).clone()
+    with torch.no_grad():
+        b.add_(0.25)
+    d2 = graph.dpt_depth(rgb.cuda())
+    assert float((d0 - d1).abs().max()) > 0.1 and torch.equal(d0, d2)
+
+
+def test_batch_of_one_and_other_resolution(graph, encoder_sd):
+    """demo.py feeds B=1; DPT's flexible position embedding (vit.py:103-120) admits other sizes."""
+    rgb = torch.from_numpy(syn.seeded_rgb_scene(seed=2, batch=1, size=160)[0])
+    depth, feat = graph.dpt_depth(rgb.cuda(), get_feat=True)
+    odepth, ofeat = E.dpt_depth(E._sub(encoder_sd, "dpt_depth."), rgb)
+    assert depth.shape == (1, 1, 160, 160) and feat.shape == (1, 768, 5, 5)
+    np.testing.assert_allclose(depth.cpu().numpy(), odepth.numpy(), atol=1e-4, rtol=0)
+    close(feat, ofeat, msg="layer_4 @160")

@@ -65,13 +65,14 @@ SIGNATURES = {
     "zs_max_pool_nhwc": (_c_int, [_c_void_p, _c_void_p] + [_c_int] * 10 + [_c_void_p]),
     "zs_global_mean_nhwc": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
     "zs_upsample2x_nhwc": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
-    "zs_nchw_to_nhwc": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
+    "zs_nchw_to_nhwc": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
+    "zs_window_tokens": (_c_int, [_c_void_p] * 6 + [_c_int] * 5 + [_c_void_p]),
     "zs_nhwc_to_nchw": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
     "zs_assemble_tokens": (_c_int, [_c_void_p] * 4 + [_c_int, _c_int, _c_int, _c_void_p]),
     "zs_readout_concat": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
 }
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 _lib = None
 
 

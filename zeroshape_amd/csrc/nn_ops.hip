@@ -170,13 +170,41 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float *__restrict
     y[i] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
 }
 
-// NCHW [B][C][H][W] -> NHWC [B][H][W][Cpad] (extra channels zero)
-__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restrict__ x, float *__restrict__ y, int B,
-                                                           int C, int HW, int Cpad) {
+// NCHW [B][C][H][W] -> NHWC [B][H][W][Cpad] (extra channels zero), optionally times mask [B][HW]
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restrict__ x,
+                                                           const float *__restrict__ mask, float *__restrict__ y,
+                                                           int B, int C, int HW, int Cpad) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)B * HW * Cpad;
     if (i >= total) return;
     const int c = i % Cpad, p = (i / Cpad) % HW, b = i / Cpad / HW;
-    y[i] = c < C ? x[((size_t)b * C + c) * HW + p] : 0.f;
+    float v = c < C ? x[((size_t)b * C + c) * HW + p] : 0.f;
+    if (mask) v *= mask[(size_t)b * HW + p];
+    y[i] = v;
+}
+
+// CoordEmb's token preparation (seen_coord_enc.py:50-71): emb [B][H][W][C] with invalid pixels
+// replaced by a learned token, cut into win x win windows, + window-local position embedding,
+// cls token (+ its embedding) prepended: out [B*(H/win)*(W/win)][win*win+1][C]
+__global__ __launch_bounds__(256) void window_tokens_kernel(const float *__restrict__ emb,
+                                                            const uint8_t *__restrict__ mask,
+                                                            const float *__restrict__ invalid,
+                                                            const float *__restrict__ cls,
+                                                            const float *__restrict__ pos, float *__restrict__ out,
+                                                            int B, int H, int W, int C, int win) {
+    const int T = win * win + 1, nwx = W / win, nwy = H / win;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)B * nwy * nwx * T * C;
+    if (i >= total) return;
+    const int c = i % C, t = (i / C) % T;
+    const size_t wdx = i / C / T;
+    const int wx = wdx % nwx, wy = (wdx / nwx) % nwy, b = wdx / nwx / nwy;
+    float v;
+    if (t == 0) v = cls[c];
+    else {
+        const int py = wy * win + (t - 1) / win, px = wx * win + (t - 1) % win;
+        const size_t pix = ((size_t)b * H + py) * W + px;
+        v = mask[pix] ? emb[pix * C + c] : invalid[c];
+    }
+    out[i] = v + pos[(size_t)t * C + c];
 }
 // NHWC [B][H][W][C] -> NCHW [B][C][H][W]
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float *__restrict__ x, float *__restrict__ y, int B,
@@ -283,12 +311,13 @@ extern "C" int zs_upsample2x_nhwc(const float *x, float *y, int batch, int Hin, 
     return zs::check_launch("zs_upsample2x_nhwc") ? 1 : 0;
 }
 
-extern "C" int zs_nchw_to_nhwc(const float *x, float *y, int batch, int C, int HW, int Cpad, void *stream) {
+extern "C" int zs_nchw_to_nhwc(const float *x, const float *mask, float *y, int batch, int C, int HW, int Cpad,
+                               void *stream) {
     ZS_REQUIRE(batch >= 0 && C > 0 && HW > 0 && Cpad >= C, "zs_nchw_to_nhwc: bad size");
     if (batch == 0) return 1;
     ZS_REQUIRE(x && y, "zs_nchw_to_nhwc: null pointer");
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(blocks_for((size_t)batch * HW * Cpad)), dim3(256), 0, S(stream), x, y,
-                       batch, C, HW, Cpad);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(blocks_for((size_t)batch * HW * Cpad)), dim3(256), 0, S(stream), x,
+                       mask, y, batch, C, HW, Cpad);
     return zs::check_launch("zs_nchw_to_nhwc") ? 1 : 0;
 }
 
@@ -318,4 +347,16 @@ extern "C" int zs_readout_concat(const float *tokens, float *out, int batch, int
     hipLaunchKernelGGL(readout_concat_kernel, dim3(blocks_for((size_t)batch * n * 2 * C)), dim3(256), 0, S(stream),
                        tokens, out, batch, n, C);
     return zs::check_launch("zs_readout_concat") ? 1 : 0;
+}
+
+extern "C" int zs_window_tokens(const float *emb, const uint8_t *mask, const float *invalid_token, const float *cls,
+                                const float *pos, float *out, int batch, int H, int W, int C, int win, void *stream) {
+    ZS_REQUIRE(batch >= 0 && H > 0 && W > 0 && C > 0 && win > 0 && H % win == 0 && W % win == 0,
+               "zs_window_tokens: bad size (B=%d H=%d W=%d C=%d win=%d)", batch, H, W, C, win);
+    if (batch == 0) return 1;
+    ZS_REQUIRE(emb && mask && invalid_token && cls && pos && out, "zs_window_tokens: null pointer");
+    const size_t total = (size_t)batch * (H / win) * (W / win) * (win * win + 1) * C;
+    hipLaunchKernelGGL(window_tokens_kernel, dim3(blocks_for(total)), dim3(256), 0, S(stream), emb, mask, invalid_token,
+                       cls, pos, out, batch, H, W, C, win);
+    return zs::check_launch("zs_window_tokens") ? 1 : 0;
 }

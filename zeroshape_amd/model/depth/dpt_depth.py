@@ -1,0 +1,247 @@
+"""Mirror of the reference's model/depth/dpt_depth.py::DPTDepthModel (backbone
+"vitb_rn50_384", readout "project", the only configuration graph_shape.py:31 builds) on the HIP
+encoder layers.
+
+Same state-dict names as the reference module tree (``pretrained.model.*`` = timm's
+vit_base_resnet50_384, ``pretrained.act_postprocess{3,4}.*``, ``scratch.*``), so
+``load_state_dict(get_child_state_dict(ckpt["graph"], "dpt_depth"))`` (graph_shape.py:75) and the
+omnidata checkpoint (:87) load by name.  Forward (dpt_depth.py:68-94,115-122, vit.py:57-154):
+
+  x = 2*img - 1 -> ResNetV2 stem/stages (taps: stage0 256@H/4, stage1 512@H/8) -> 1x1 proj ->
+  [cls | tokens] + resized pos_embed -> 12 ViT blocks (taps after blocks 8 and 11) ->
+  readout-project + 1x1 (+ 3x3/s2 for tap 4) -> scratch.layerK_rn 3x3 -> refinenet4..1 ->
+  head (3x3, x2 bilinear, 3x3 + ReLU, 1x1 + ReLU) -> clamp [0,1]
+
+Inference only; there is no PyTorch fallback.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ...nn import blocks, ops, pack
+from ...nn.module import HipModule
+
+
+# ---- parameter containers (names as timm 0.6.12 / the reference register them) ----
+def _gn(c):
+    return nn.GroupNorm(32, c)
+
+
+class _ConvNorm(nn.Module):
+    def __init__(self, cin, cout, k, stride=1):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, stride=stride, bias=False)
+        self.norm = _gn(cout)
+
+
+class _BottleneckV2(nn.Module):
+    def __init__(self, cin, cout, stride, proj):
+        super().__init__()
+        mid = cout // 4
+        if proj:
+            self.downsample = _ConvNorm(cin, cout, 1, stride)
+        self.conv1 = nn.Conv2d(cin, mid, 1, bias=False)
+        self.norm1 = _gn(mid)
+        self.conv2 = nn.Conv2d(mid, mid, 3, stride=stride, bias=False)
+        self.norm2 = _gn(mid)
+        self.conv3 = nn.Conv2d(mid, cout, 1, bias=False)
+        self.norm3 = _gn(cout)
+
+
+class _Stage(nn.Module):
+    def __init__(self, cin, cout, stride, depth):
+        super().__init__()
+        self.blocks = nn.Sequential(*[_BottleneckV2(cin if i == 0 else cout, cout, stride if i == 0 else 1, i == 0)
+                                      for i in range(depth)])
+
+
+class _ResNetV2(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.stem = _ConvNorm(3, 64, 7, 2)
+        self.stages = nn.Sequential(_Stage(64, 256, 1, 3), _Stage(256, 512, 2, 4), _Stage(512, 1024, 2, 9))
+
+
+class _HybridEmbed(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.backbone = _ResNetV2()
+        self.proj = nn.Conv2d(1024, 768, 1)
+
+
+class _Attention(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.qkv = nn.Linear(dim, 3 * dim)
+        self.proj = nn.Linear(dim, dim)
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class ViTBlock(nn.Module):
+    """timm Block parameter names (norm1, attn.qkv, attn.proj, norm2, mlp.fc1, mlp.fc2)."""
+
+    def __init__(self, dim, mlp_ratio=4.0):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _Attention(dim)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+
+
+class _HybridViT(nn.Module):
+    def __init__(self, img_size=384, dim=768, depth=12, num_classes=1000):
+        super().__init__()
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
+        self.pos_embed = nn.Parameter(torch.randn(1, (img_size // 16) ** 2 + 1, dim) * 0.02)
+        self.patch_embed = _HybridEmbed()
+        self.blocks = nn.Sequential(*[ViTBlock(dim) for _ in range(depth)])
+        self.norm = nn.LayerNorm(dim, eps=1e-6)
+        self.head = nn.Linear(dim, num_classes)          # unused by DPT, present in the checkpoints
+
+
+class _ProjectReadout(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.project = nn.Sequential(nn.Linear(2 * dim, dim), nn.GELU())
+
+
+class _RCU(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv1 = nn.Conv2d(c, c, 3, padding=1)
+        self.conv2 = nn.Conv2d(c, c, 3, padding=1)
+
+
+class _Fusion(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.out_conv = nn.Conv2d(c, c, 1)
+        self.resConfUnit1 = _RCU(c)
+        self.resConfUnit2 = _RCU(c)
+
+
+class DPTDepthModel(HipModule):
+    def __init__(self, path=None, non_negative=True, num_channels=1, backbone="vitb_rn50_384", features=256,
+                 readout="project", **kwargs):
+        super().__init__()
+        if backbone != "vitb_rn50_384" or readout != "project" or not non_negative or num_channels != 1 or kwargs:
+            raise NotImplementedError("the HIP DPT is specialised for DPTDepthModel(backbone='vitb_rn50_384') "
+                                      "(model/compute_graph/graph_shape.py:31)")
+        self.features = features
+        self.pretrained = nn.Module()
+        self.pretrained.model = _HybridViT()
+        ident = lambda: nn.Sequential(nn.Identity(), nn.Identity(), nn.Identity())      # noqa: E731
+        self.pretrained.act_postprocess1, self.pretrained.act_postprocess2 = ident(), ident()
+        self.pretrained.act_postprocess3 = nn.Sequential(_ProjectReadout(768), nn.Identity(), nn.Identity(),
+                                                         nn.Conv2d(768, 768, 1))
+        self.pretrained.act_postprocess4 = nn.Sequential(_ProjectReadout(768), nn.Identity(), nn.Identity(),
+                                                         nn.Conv2d(768, 768, 1),
+                                                         nn.Conv2d(768, 768, 3, stride=2, padding=1))
+        self.scratch = nn.Module()
+        for i, c in enumerate((256, 512, 768, 768), 1):
+            setattr(self.scratch, "layer%d_rn" % i, nn.Conv2d(c, features, 3, padding=1, bias=False))
+        for i in (1, 2, 3, 4):
+            setattr(self.scratch, "refinenet%d" % i, _Fusion(features))
+        self.scratch.output_conv = nn.Sequential(
+            nn.Conv2d(features, features // 2, 3, padding=1), nn.Identity(),
+            nn.Conv2d(features // 2, 32, 3, padding=1), nn.ReLU(True),
+            nn.Conv2d(32, 1, 1), nn.ReLU(True), nn.Identity())
+        nn.init.constant_(self.scratch.output_conv[-3].bias, 0.05)        # dpt_depth.py:108
+        if path is not None:
+            self.load(path)
+        self.eval()
+
+    def load(self, path):
+        """model/depth/base_model.py:6-17."""
+        parameters = torch.load(path, map_location=torch.device("cpu"))
+        if "optimizer" in parameters:
+            parameters = parameters["model"]
+        self.load_state_dict(parameters)
+
+    # ---- packing ----
+    def _pack(self, sd, device):
+        lin = lambda p: pack.pack_conv(sd[p + ".weight"], sd[p + ".bias"]).to(device)      # noqa: E731
+        pk = dict(backbone=blocks.pack_resnetv2(sd, "pretrained.model.patch_embed.backbone.", device),
+                  proj=lin("pretrained.model.patch_embed.proj"),
+                  cls=sd["pretrained.model.cls_token"].reshape(-1).float().contiguous().to(device),
+                  pos_native=sd["pretrained.model.pos_embed"].float(), pos={},
+                  blocks=[blocks.pack_vit_block(sd, "pretrained.model.blocks.%d" % i, device) for i in range(12)],
+                  ro3=lin("pretrained.act_postprocess3.0.project.0"), pp3=lin("pretrained.act_postprocess3.3"),
+                  ro4=lin("pretrained.act_postprocess4.0.project.0"), pp4=lin("pretrained.act_postprocess4.3"),
+                  pp4s=pack.pack_conv(sd["pretrained.act_postprocess4.4.weight"], sd["pretrained.act_postprocess4.4.bias"],
+                                      stride=2, padding=1).to(device),
+                  rn=[pack.pack_conv(sd["scratch.layer%d_rn.weight" % i], None, padding=1).to(device)
+                      for i in (1, 2, 3, 4)],
+                  fusion=[blocks.pack_fusion(sd, "scratch.refinenet%d" % i, device) for i in (1, 2, 3, 4)],
+                  head0=pack.pack_conv(sd["scratch.output_conv.0.weight"], sd["scratch.output_conv.0.bias"],
+                                       padding=1).to(device),
+                  head2=pack.pack_conv(sd["scratch.output_conv.2.weight"], sd["scratch.output_conv.2.bias"],
+                                       padding=1).to(device),
+                  head4=lin("scratch.output_conv.4"), device=device)
+        return pk
+
+    @staticmethod
+    def _pos_embed(pk, gh, gw):
+        """vit.py:103-120 (_resize_pos_embed): bilinear, align_corners=False, from the native grid.
+        The reference recomputes it on every forward; here once per (checkpoint, grid) on the host."""
+        if (gh, gw) not in pk["pos"]:
+            pos = pk["pos_native"]
+            g0 = int(math.sqrt(pos.shape[1] - 1))
+            grid = pos[0, 1:].reshape(1, g0, g0, -1).permute(0, 3, 1, 2)
+            grid = F.interpolate(grid, size=(gh, gw), mode="bilinear", align_corners=False)
+            pos = torch.cat([pos[0, :1], grid.permute(0, 2, 3, 1).reshape(gh * gw, -1)], 0)
+            pk["pos"][(gh, gw)] = pos.contiguous().to(pk["device"])
+        return pk["pos"][(gh, gw)]
+
+    # ---- forward ----
+    @torch.no_grad()
+    def forward(self, image, get_feat=False, taps=None):
+        """image [B,3,H,W] in [0,1] -> depth [B,1,H,W] in [0,1] (and the tap-4 feature
+        [B,768,H/32,W/32] with get_feat), dpt_depth.py:115-122.  `taps` (a dict, tests only)
+        receives channels-last intermediates."""
+        self._need_gpu(image, "image")
+        B, C, H, W = image.shape
+        if C != 3 or H % 32 or W % 32:
+            raise ValueError("image must be [B,3,H,W] with H, W multiples of 32, got %s" % (tuple(image.shape),))
+        pk = self.packed(image.device)
+        gh, gw = H // 16, W // 16
+        x = ops.to_nhwc(image, cpad=4)
+        s0, s1, s2 = blocks.run_resnetv2(x, pk["backbone"], in_scale=2.0, in_shift=-1.0)
+        record = (lambda **kw: taps.update(kw)) if taps is not None else (lambda **kw: None)
+        record(stage0=s0, stage1=s1, stage2=s2)
+        feat = ops.conv2d(s2, pk["proj"]).view(B, gh * gw, 768)
+        tok = ops.assemble_tokens(feat, pk["cls"], self._pos_embed(pk, gh, gw))
+        hooked = {}
+        for i, blk in enumerate(pk["blocks"]):
+            tok = blocks.run_vit_block(tok, blk, 12)
+            if i in (0, 8, 11):
+                hooked[i] = tok
+        record(block0=hooked[0], block8=hooked[8], block11=hooked[11])
+
+        def reassemble(t, ro, pp):
+            r = ops.linear(ops.readout_concat(t), ro, act=ops.ACT_GELU)          # [B, gh*gw, 768]
+            return ops.conv2d(r.view(B, gh, gw, 768), pp)
+        layer_3 = reassemble(hooked[8], pk["ro3"], pk["pp3"])
+        layer_4 = ops.conv2d(reassemble(hooked[11], pk["ro4"], pk["pp4"]), pk["pp4s"])
+        rn = [ops.conv2d(l, p) for l, p in zip((s0, s1, layer_3, layer_4), pk["rn"])]
+        record(layer3_rn=rn[2], layer4_rn=rn[3])
+        path4 = blocks.run_fusion(rn[3], pk["fusion"][3])
+        path3 = blocks.run_fusion(path4, pk["fusion"][2], rn[2])
+        path2 = blocks.run_fusion(path3, pk["fusion"][1], rn[1])
+        path = blocks.run_fusion(path2, pk["fusion"][0], rn[0])
+        record(path4=path4, path3=path3, path2=path2, path1=path)
+        o = ops.upsample2x(ops.conv2d(path, pk["head0"]))
+        o = ops.conv2d(o, pk["head2"], act=ops.ACT_RELU)
+        o = ops.conv2d(o, pk["head4"], act=ops.ACT_RELU_CLAMP1)                 # [B,H,W,1]
+        depth = o.view(B, 1, H, W)                                               # C == 1: same memory order
+        if get_feat:
+            return depth, ops.to_nchw(layer_4)
+        return depth

@@ -127,16 +127,48 @@ def upsample2x(x):
     return y
 
 
-def to_nhwc(x, cpad=None):
-    """NCHW [B,C,H,W] -> NHWC [B,H,W,cpad or C] (zero-filled extra channels)."""
+def to_nhwc(x, cpad=None, mask=None):
+    """NCHW [B,C,H,W] -> NHWC [B,H,W,cpad or C] (zero-filled extra channels), optionally times a
+    per-pixel mask [B,1,H,W]."""
     lib = _lib.load()
     x = _chk(x.float().contiguous(), "to_nhwc input")
     B, C, H, W = x.shape
     cp = cpad or C
+    if mask is not None:
+        mask = _chk(mask.float().contiguous(), "to_nhwc mask")
+        assert mask.numel() == B * H * W
     y = torch.empty(B, H, W, cp, dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(lib.zs_nchw_to_nhwc(_lib.ptr(x), _lib.ptr(y), B, C, H * W, cp, _stream(x)), "zs_nchw_to_nhwc")
+        _lib.check(lib.zs_nchw_to_nhwc(_lib.ptr(x), _lib.ptr(mask), _lib.ptr(y), B, C, H * W, cp, _stream(x)),
+                   "zs_nchw_to_nhwc")
     return y
+
+
+def pad_channels(x, cpad):
+    """[..., C] -> [..., cpad] zero-filled (each row is a one-pixel image for zs_nchw_to_nhwc)."""
+    lib = _lib.load()
+    _chk(x, "pad_channels input")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty(*x.shape[:-1], cpad, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.zs_nchw_to_nhwc(_lib.ptr(x), None, _lib.ptr(y), rows, C, 1, cpad, _stream(x)),
+                   "zs_nchw_to_nhwc")
+    return y
+
+
+def window_tokens(emb, mask, invalid_token, cls, pos, win):
+    """emb [B,H,W,C], mask [B,H,W] bool -> [B*(H/win)*(W/win), win*win+1, C] (zs_window_tokens)."""
+    lib = _lib.load()
+    _chk(emb, "window_tokens input")
+    B, H, W, C = emb.shape
+    m = mask.to(torch.uint8).contiguous()
+    out = torch.empty(B * (H // win) * (W // win), win * win + 1, C, dtype=torch.float32, device=emb.device)
+    with torch.cuda.device(emb.device):
+        _lib.check(lib.zs_window_tokens(_lib.ptr(emb), _lib.ptr(m), _lib.ptr(invalid_token), _lib.ptr(cls),
+                                        _lib.ptr(pos), _lib.ptr(out), B, H, W, C, win, _stream(emb)),
+                   "zs_window_tokens")
+    return out
 
 
 def to_nchw(x):
