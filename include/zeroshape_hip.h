@@ -244,6 +244,8 @@ int zs_depth_metrics(const float *prediction, const float *target, const float *
  *   in-range taps are first ReLU'd (flags & ZS_CONV_IN_RELU) and mapped a*in_scale + in_shift.
  *   scale / shift / res1 / res2 may be NULL (1 / 0 / none).  Explicit top/left padding with
  *   bounds-checked bottom/right covers torch's symmetric padding and timm's 'same' padding.
+ *   Two tilings, chosen by problem size: 128x128 (LDS double-buffered) when that yields >= 192
+ *   workgroups, else 32x64 with K split over the four waves and a fixed-order LDS reduction.
  * zs_group_norm_nhwc: y = GN_groups(x) * gamma + beta (+ residual) (ReLU if relu), per sample.
  * zs_layer_norm: rows of length C.
  * zs_attention: qkv [B][L][3*heads*head_dim] (q | k | v, head-major inside each) ->
@@ -263,6 +265,8 @@ int zs_depth_metrics(const float *prediction, const float *target, const float *
 #define ZS_ACT_GELU 2
 #define ZS_ACT_RELU_CLAMP1 3
 #define ZS_CONV_IN_RELU 1
+#define ZS_CONV_FORCE_LARGE 2 /* tiling override (tests / tuning): 128x128 tiles */
+#define ZS_CONV_FORCE_SMALL 4 /* 32x64 tiles with the K range split over the 4 waves */
 size_t zs_conv2d_packed_floats(int Cin, int Cout, int kh, int kw);
 int zs_conv2d_nhwc(const float *in, const float *packed_w, const float *scale, const float *shift,
                    const float *res1, const float *res2, float *out, int batch, int Hin, int Win, int Cin,

@@ -130,3 +130,25 @@ def test_batch_of_one_and_other_resolution(graph, encoder_sd):
     assert depth.shape == (1, 1, 160, 160) and feat.shape == (1, 768, 5, 5)
     np.testing.assert_allclose(depth.cpu().numpy(), odepth.numpy(), atol=1e-4, rtol=0)
     close(feat, ofeat, msg="layer_4 @160")
+
+
+def test_hip_graph_replay_equals_eager(graph):
+    """The captured hipGraph replays the same launches: bit-identical outputs, also for new inputs
+    of the captured shape."""
+    opt = make_opt()
+    opt.arch.depth.dsp = 1
+    outs = {}
+    for mode in (False, True, True):
+        graph.enable_hip_graph(mode) if mode != graph._use_hip_graph else None
+        for seed in (0, 4):
+            rgb, mask = [torch.from_numpy(a).cuda() for a in syn.seeded_rgb_scene(seed=seed, batch=2)]
+            var = edict(dict(idx=[0, 1], rgb_input_map=rgb, mask_input_map=mask))
+            var = graph.forward(opt, var, training=False, get_loss=False)
+            got = [var.depth_pred, var.intr_pred, var.seen_points, var.latent_depth]
+            if seed in outs:
+                for a, b in zip(outs[seed], got):
+                    assert torch.equal(a, b)
+            else:
+                outs[seed] = [t.clone() for t in got]
+    assert len(graph._captured) == 1
+    graph.enable_hip_graph(False)

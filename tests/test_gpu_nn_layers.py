@@ -30,6 +30,9 @@ def same_pad(x, k, s, value=0.0):
 
 
 CONV_CASES = [
+    (2, 1024, 14, 14, 256, 1, 1, 0),          # long K split four ways
+    (1, 768, 7, 7, 768, 3, 1, 1),             # intrinsics head: 49 pixels, K = 6912
+    (1, 256, 56, 56, 256, 3, 1, 1),           # DPT fusion at B=1
     # B, Cin, H, W, Cout, k, stride, padding
     (2, 64, 14, 14, 256, 1, 1, 0),
     (1, 256, 9, 7, 64, 3, 1, 1),
@@ -55,8 +58,9 @@ def test_conv2d_matches_torch(B, Cin, H, W, Cout, k, stride, padding):
     else:
         want = F.conv2d(x, w, b, stride=stride, padding=padding)
     pc = pack.pack_conv(w, b, stride=stride, padding=padding).to("cuda")
-    got = ops.conv2d(nhwc(x).cuda(), pc)
-    close(got, nhwc(want))
+    for tiling in (None, "large", "small"):
+        got = ops.conv2d(nhwc(x).cuda(), pc, tiling=tiling)
+        close(got, nhwc(want))
 
 
 def test_conv2d_fused_epilogue_and_input_transforms():
@@ -71,13 +75,16 @@ def test_conv2d_fused_epilogue_and_input_transforms():
     want = F.relu(F.batch_norm(conv, bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], False, 0.0,
                                bn["eps"]) + r1 + r2)
     pc = pack.pack_conv(w, None, bn=bn, padding=1).to("cuda")
-    got = ops.conv2d(nhwc(x).cuda(), pc, res1=nhwc(r1).cuda(), res2=nhwc(r2).cuda(), act=ops.ACT_RELU, in_relu=True)
-    close(got, nhwc(want))
+    for tiling in ("large", "small"):
+        got = ops.conv2d(nhwc(x).cuda(), pc, res1=nhwc(r1).cuda(), res2=nhwc(r2).cuda(), act=ops.ACT_RELU,
+                         in_relu=True, tiling=tiling)
+        close(got, nhwc(want))
     # affine input transform applies to in-bounds taps only (zero padding stays zero): conv(2x-1)
     want = F.gelu(F.conv2d(2 * x - 1, w, None, padding=1))
-    got = ops.conv2d(nhwc(x).cuda(), pack.pack_conv(w, None, padding=1).to("cuda"), act=ops.ACT_GELU,
-                     in_scale=2.0, in_shift=-1.0)
-    close(got, nhwc(want))
+    for tiling in ("large", "small"):
+        got = ops.conv2d(nhwc(x).cuda(), pack.pack_conv(w, None, padding=1).to("cuda"), act=ops.ACT_GELU,
+                         in_scale=2.0, in_shift=-1.0, tiling=tiling)
+        close(got, nhwc(want))
     want = F.conv2d(x, w, None, padding=1).clamp(0, 1)
     got = ops.conv2d(nhwc(x).cuda(), pack.pack_conv(w, None, padding=1).to("cuda"), act=ops.ACT_RELU_CLAMP1)
     close(got, nhwc(want))

@@ -48,6 +48,37 @@ __device__ __forceinline__ float activate(float v, int act) {
     return v;
 }
 
+// position of a lane's current k (4 consecutive channels of one tap) in (ky, kx, channel) form,
+// advanced incrementally: no integer division in the K loop
+struct TapIter {
+    int c, ky, kx;
+    __device__ __forceinline__ void init(int k, int Cin, int kw) {
+        const int tap = k / Cin;
+        c = k - tap * Cin;
+        ky = tap / kw;
+        kx = tap - ky * kw;
+    }
+    // k += step, with step = adv_tap * Cin + adv_c precomputed; branch-free (selects), exact while
+    // adv_tap + 1 <= 2 * kw, and monotone in ky beyond that (positions past K only need ky >= kh)
+    __device__ __forceinline__ void advance(int adv_tap, int adv_c, int Cin, int kw) {
+        c += adv_c;
+        const int wrap = c >= Cin ? 1 : 0;
+        c -= wrap ? Cin : 0;
+        kx += adv_tap + wrap;
+        int w1 = kx >= kw ? 1 : 0;
+        kx -= w1 ? kw : 0;
+        ky += w1;
+        w1 = kx >= kw ? 1 : 0;
+        kx -= w1 ? kw : 0;
+        ky += w1;
+        ky += kx >= kw ? 1 << 20 : 0;          // still out of range: far beyond K, poison ky
+    }
+};
+
+// One A operand quad: issued unconditionally from a clamped address so the load stays in flight
+// (no branch, no wait); `ok` is applied when the value is used.
+struct AQuad { f32x4 v; bool ok; };
+
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     __shared__ f32x4 lds_a[2][KQ][BM];
     __shared__ f32x4 lds_b[2][KQ][BN];
@@ -67,22 +98,26 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     }
     const int iy0 = py * a.stride - a.pad_t, ix0 = px * a.stride - a.pad_l;
     const float *in_b = a.in + (size_t)pb * a.Hin * a.Win * a.Cin;
-    const int taps = a.kh * a.kw;
 
-    auto load_a = [&](int k) -> f32x4 {            // 4 consecutive channels of one tap
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        const int tap = k / a.Cin, c = k - tap * a.Cin;
-        if (pix_ok && tap < taps) {
-            const int ky = tap / a.kw, kx = tap - ky * a.kw;
-            const int iy = iy0 + ky, ix = ix0 + kx;
-            if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
-                v = *reinterpret_cast<const f32x4 *>(in_b + ((size_t)iy * a.Win + ix) * a.Cin + c);
-                if (a.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                v = v * a.in_scale + a.in_shift;
-            }
-        }
+    const float relu_floor = a.in_relu ? 0.f : -INFINITY;
+    auto load_a = [&](const TapIter &it) -> AQuad {            // 4 consecutive channels of one tap
+        const int iy = iy0 + it.ky, ix = ix0 + it.kx;
+        AQuad q;
+        q.ok = pix_ok && it.ky < a.kh && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        const size_t off = q.ok ? ((size_t)iy * a.Win + ix) * a.Cin + it.c : 0;
+        q.v = *reinterpret_cast<const f32x4 *>(in_b + off);
+        return q;
+    };
+    auto finish_a = [&](const AQuad &q) -> f32x4 {             // input transform, zero for padding
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = q.ok ? fmaxf(q.v[e], relu_floor) * a.in_scale + a.in_shift : 0.f;
         return v;
     };
+    const int adv_tap = BK / a.Cin, adv_c = BK % a.Cin;
+    TapIter it0, it1;
+    it0.init(4 * kq_lo, a.Cin, a.kw);
+    it1.init(4 * (kq_lo + 2), a.Cin, a.kw);
     const f32x4 *wq = reinterpret_cast<const f32x4 *>(a.w);
     auto load_b = [&](int kq, int n) -> f32x4 { return wq[(size_t)kq * a.CoutPad + n0 + n]; };
 
@@ -95,13 +130,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
     const int ksteps = (a.K + BK - 1) / BK;
-    f32x4 ra[2], rb[2];
-    ra[0] = load_a(4 * kq_lo);
-    ra[1] = load_a(4 * (kq_lo + 2));
+    AQuad ra[2];
+    f32x4 rb[2];
+    ra[0] = load_a(it0);
+    ra[1] = load_a(it1);
     rb[0] = load_b(kq_lo, prow);
     rb[1] = load_b(kq_lo + 2, prow);
-    lds_a[0][kq_lo][prow] = ra[0];
-    lds_a[0][kq_lo + 2][prow] = ra[1];
+    lds_a[0][kq_lo][prow] = finish_a(ra[0]);
+    lds_a[0][kq_lo + 2][prow] = finish_a(ra[1]);
     lds_b[0][kq_lo][prow] = rb[0];
     lds_b[0][kq_lo + 2][prow] = rb[1];
     __syncthreads();
@@ -111,9 +147,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
         const int cur = ks & 1;
         const bool more = ks + 1 < ksteps;
         if (more) {
-            const int kb = (ks + 1) * BK;
-            ra[0] = load_a(kb + 4 * kq_lo);
-            ra[1] = load_a(kb + 4 * (kq_lo + 2));
+            it0.advance(adv_tap, adv_c, a.Cin, a.kw);
+            it1.advance(adv_tap, adv_c, a.Cin, a.kw);
+            ra[0] = load_a(it0);
+            ra[1] = load_a(it1);
             rb[0] = load_b((ks + 1) * KQ + kq_lo, prow);
             rb[1] = load_b((ks + 1) * KQ + kq_lo + 2, prow);
         }
@@ -133,8 +170,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
         }
         if (more) {
-            lds_a[cur ^ 1][kq_lo][prow] = ra[0];
-            lds_a[cur ^ 1][kq_lo + 2][prow] = ra[1];
+            lds_a[cur ^ 1][kq_lo][prow] = finish_a(ra[0]);
+            lds_a[cur ^ 1][kq_lo + 2][prow] = finish_a(ra[1]);
             lds_b[cur ^ 1][kq_lo][prow] = rb[0];
             lds_b[cur ^ 1][kq_lo + 2][prow] = rb[1];
         }
@@ -162,6 +199,113 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     }
 }
 
+
+// ---- small-problem variant: many small tiles, K split across the four waves ----
+// The 128x128 tiling needs >= ~256 tiles to fill 256 CUs; a 14x14 feature map or a 197-token
+// matrix gives a handful.  Here a workgroup owns 32 pixels x 64 couts and its four waves each
+// take a contiguous quarter of K straight from global memory into MFMA operand registers (the
+// packed weight layout makes the B fragment one coalesced float4 per lane; the A fragment is one
+// float4 per lane = 4 channels of one tap), so a layer launches (M/32)*(Cout/64) workgroups and
+// a wave's dependent MFMA chain is K/4 long instead of K.  Partials are summed through LDS in a
+// fixed order (deterministic), then the same fused epilogue.
+constexpr int SM = 32, SN = 64, SU = 4;       // tile, and t-steps (8 k each) per prefetch chunk
+
+__global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
+    __shared__ float part[4][SM][SN + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, half = lane >> 5;
+    const int m0 = blockIdx.x * SM, n0 = blockIdx.y * SN;
+    const int pix = m0 + l32;
+    const bool pix_ok = pix < a.M;
+    int pb = 0, py = 0, px = 0;
+    if (pix_ok) {
+        pb = pix / (a.Hout * a.Wout);
+        const int rem = pix - pb * a.Hout * a.Wout;
+        py = rem / a.Wout;
+        px = rem - py * a.Wout;
+    }
+    const int iy0 = py * a.stride - a.pad_t, ix0 = px * a.stride - a.pad_l;
+    const float *in_b = a.in + (size_t)pb * a.Hin * a.Win * a.Cin;
+    const float relu_floor = a.in_relu ? 0.f : -INFINITY;
+    auto load_a = [&](const TapIter &it) -> AQuad {
+        const int iy = iy0 + it.ky, ix = ix0 + it.kx;
+        AQuad q;
+        q.ok = pix_ok && it.ky < a.kh && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        const size_t off = q.ok ? ((size_t)iy * a.Win + ix) * a.Cin + it.c : 0;
+        q.v = *reinterpret_cast<const f32x4 *>(in_b + off);
+        return q;
+    };
+    const f32x4 *wq = reinterpret_cast<const f32x4 *>(a.w);
+
+    const int T = (a.K + BK - 1) / BK * 2;                 // t-steps of 8 k (= 2 weight quads)
+    const int per = (T + 3) / 4, t_begin = wave * per, t_end = min(T, t_begin + per);
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+
+    AQuad fa[2][SU];
+    f32x4 fb[2][SU][2];
+    TapIter it;                                   // this lane's k = 8 t + 4 half, fetched in t order
+    it.init(8 * t_begin + 4 * half, a.Cin, a.kw);
+    const int adv_tap = 8 / a.Cin, adv_c = 8 % a.Cin;
+    // weight quads of t-steps past t_end exist (zero padding up to K16) or are clamped to the last
+    // one; their A quads are flagged invalid, so the loop needs no tail branch
+    const int kq_last = (a.K + BK - 1) / BK * KQ - 1;
+    const f32x4 *wlane = wq + n0 + l32;
+    auto fetch = [&](int buf, int t0) {
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+            const int t = t0 + u;
+            fa[buf][u] = load_a(it);
+            fa[buf][u].ok = fa[buf][u].ok && t < t_end;
+            it.advance(adv_tap, adv_c, a.Cin, a.kw);
+            const int kq = min(2 * t + half, kq_last);
+            fb[buf][u][0] = wlane[(size_t)kq * a.CoutPad];
+            fb[buf][u][1] = wlane[(size_t)kq * a.CoutPad + 32];
+        }
+    };
+    auto consume = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+            f32x4 av;
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                av[e] = fa[buf][u].ok ? fmaxf(fa[buf][u].v[e], relu_floor) * a.in_scale + a.in_shift : 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], fb[buf][u][j][s], acc[j], 0, 0, 0);
+        }
+    };
+    if (t_begin < t_end) {
+        fetch(0, t_begin);
+        for (int t0 = t_begin; t0 < t_end; t0 += 2 * SU) {
+            fetch(1, t0 + SU);
+            consume(0);
+            fetch(0, t0 + 2 * SU);
+            consume(1);
+        }
+    }
+    // D[row = 8*(r/4) + 4*half + r%4][col = l32] -> LDS, then a fixed-order 4-way sum
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) part[wave][8 * (r >> 2) + 4 * half + (r & 3)][32 * j + l32] = acc[j][r];
+    __syncthreads();
+    for (int e = tid; e < SM * SN; e += 256) {
+        const int row = e / SN, col = e % SN, m = m0 + row, n = n0 + col;
+        if (m >= a.M || n >= a.Cout) continue;
+        float v = (part[0][row][col] + part[1][row][col]) + (part[2][row][col] + part[3][row][col]);
+        v = v * (a.scale ? a.scale[n] : 1.0f) + (a.shift ? a.shift[n] : 0.0f);
+        const size_t o = (size_t)m * a.Cout + n;
+        if (a.res1) v += a.res1[o];
+        if (a.res2) v += a.res2[o];
+        a.out[o] = activate(v, a.act);
+    }
+}
+
 }  // namespace
 
 extern "C" int zs_conv2d_nhwc(const float *in, const float *packed_w, const float *scale, const float *shift,
@@ -186,8 +330,16 @@ extern "C" int zs_conv2d_nhwc(const float *in, const float *packed_w, const floa
     a.K = kh * kw * Cin; a.M = (int)M;
     a.in_relu = (flags & ZS_CONV_IN_RELU) ? 1 : 0;
     a.act = act; a.in_scale = in_scale; a.in_shift = in_shift;
-    const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(a.CoutPad / BN));
-    hipLaunchKernelGGL(conv_gemm_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    // fewer than ~3/4 of a wave of 128x128 tiles over the 256 CUs: use the small-tile split-K variant
+    const long long big_tiles = ((M + BM - 1) / BM) * (a.CoutPad / BN);
+    const bool small = (flags & ZS_CONV_FORCE_SMALL) || (!(flags & ZS_CONV_FORCE_LARGE) && big_tiles < 192);
+    if (small) {
+        const dim3 grid((unsigned)((M + SM - 1) / SM), (unsigned)((Cout + SN - 1) / SN));
+        hipLaunchKernelGGL(conv_gemm_small_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    } else {
+        const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(a.CoutPad / BN));
+        hipLaunchKernelGGL(conv_gemm_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    }
     return zs::check_launch("zs_conv2d_nhwc") ? 1 : 0;
 }
 

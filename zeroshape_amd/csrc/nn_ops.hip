@@ -34,21 +34,22 @@ __device__ __forceinline__ float block_sum(float v, float *lds) {
 }
 
 // ---- GroupNorm over (HW x C/groups) of one sample, then affine, optional residual, optional ReLU ----
-__global__ __launch_bounds__(256) void group_norm_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+constexpr int GN_BLOCK = 1024;
+__global__ __launch_bounds__(GN_BLOCK) void group_norm_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                          const float *__restrict__ beta,
                                                          const float *__restrict__ res, float *__restrict__ y,
                                                          int HW, int C, int groups, float eps, int relu) {
-    __shared__ float lds[4];
+    __shared__ float lds[GN_BLOCK / 64];
     const int b = blockIdx.x / groups, g = blockIdx.x % groups, cg = C / groups, n = HW * cg;
     const size_t base = (size_t)b * HW * C + (size_t)g * cg;
     auto at = [&](int e) -> size_t { return base + (size_t)(e / cg) * C + (e % cg); };
     float s = 0.f;
-    for (int e = threadIdx.x; e < n; e += 256) s += x[at(e)];
+    for (int e = threadIdx.x; e < n; e += GN_BLOCK) s += x[at(e)];
     const float mean = block_sum(s, lds) / n;
     float q = 0.f;
-    for (int e = threadIdx.x; e < n; e += 256) { const float d = x[at(e)] - mean; q += d * d; }
+    for (int e = threadIdx.x; e < n; e += GN_BLOCK) { const float d = x[at(e)] - mean; q += d * d; }
     const float rstd = 1.0f / sqrtf(block_sum(q, lds) / n + eps);
-    for (int e = threadIdx.x; e < n; e += 256) {
+    for (int e = threadIdx.x; e < n; e += GN_BLOCK) {
         const size_t o = at(e);
         const int c = g * cg + e % cg;
         float v = (x[o] - mean) * rstd * gamma[c] + beta[c];
@@ -73,57 +74,85 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float *__restrict
     for (int c = lane; c < C; c += 64) y[(size_t)row * C + c] = (xr[c] - mean) * rstd * gamma[c] + beta[c];
 }
 
-// ---- attention: one workgroup per (sample, head), one query row per lane, keys/values streamed
-//      through LDS in chunks of 64 with an online softmax ----
+// ---- attention on the MFMA pipe: one wave per (sample, head, 32-query tile) ----
+// Transposed formulation (the accumulator layout of one product is the operand layout of the
+// next, no shuffles):  S^T[key][query] = K Q^T  (A = K tile, B = Q^T),  softmax over keys =
+// over a lane's 16 registers + its partner half + key tiles (online),  O^T[d][query] = V^T P^T
+// (A = V^T gathered in the accumulator's key order, B = P^T = the probabilities as they sit).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
 template <int D>
-__global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ qkv, float *__restrict__ out, int L,
-                                                        int heads, float scale) {
-    __shared__ f32x4 lds_k[64][D / 4];
-    __shared__ f32x4 lds_v[64][D / 4];
-    const int b = blockIdx.x / heads, h = blockIdx.x % heads, C = heads * D;
+__global__ __launch_bounds__(64) void attention_kernel(const float *__restrict__ qkv, float *__restrict__ out, int L,
+                                                       int heads, float scale) {
+    constexpr int DQ = D / 8;                 // float4 operand quads per lane along d
+    constexpr int DT = D / 32;                // 32-row tiles of O^T
+    const int lane = threadIdx.x, l32 = lane & 31, half = lane >> 5;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads, C = heads * D, q0 = blockIdx.y * 32;
     const float *base = qkv + (size_t)b * L * 3 * C + h * D;
-    for (int r0 = 0; r0 < L; r0 += 256) {
-        const int row = r0 + threadIdx.x;
-        const bool ok = row < L;
-        f32x4 q[D / 4], o[D / 4];
+    const int qrow = min(q0 + l32, L - 1);
+    f32x4 qf[DQ];
 #pragma unroll
-        for (int i = 0; i < D / 4; i++) {
-            q[i] = ok ? *reinterpret_cast<const f32x4 *>(base + (size_t)row * 3 * C + 4 * i) : f32x4{0, 0, 0, 0};
-            q[i] *= scale;
-            o[i] = f32x4{0, 0, 0, 0};
+    for (int t = 0; t < DQ; t++)
+        qf[t] = *reinterpret_cast<const f32x4 *>(base + (size_t)qrow * 3 * C + 4 * (2 * t + half)) * scale;
+    f32x16 o[DT];
+#pragma unroll
+    for (int i = 0; i < DT; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[i][r] = 0.f;
+    float mx = -INFINITY, den = 0.f;
+    for (int k0 = 0; k0 < L; k0 += 32) {
+        // S^T tile: rows = keys, columns = queries
+        const int krow = min(k0 + l32, L - 1);
+        f32x16 sT;
+#pragma unroll
+        for (int r = 0; r < 16; r++) sT[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < DQ; t++) {
+            const f32x4 kf = *reinterpret_cast<const f32x4 *>(base + (size_t)krow * 3 * C + C + 4 * (2 * t + half));
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) sT = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s4], qf[t][s4], sT, 0, 0, 0);
         }
-        float mx = -INFINITY, den = 0.f;
-        for (int j0 = 0; j0 < L; j0 += 64) {
-            __syncthreads();
-            for (int e = threadIdx.x; e < 64 * (D / 4); e += 256) {
-                const int j = e / (D / 4), i = e % (D / 4);
-                const bool jok = j0 + j < L;
-                const float *kv = base + (size_t)(j0 + j) * 3 * C + 4 * i;
-                lds_k[j][i] = jok ? *reinterpret_cast<const f32x4 *>(kv + C) : f32x4{0, 0, 0, 0};
-                lds_v[j][i] = jok ? *reinterpret_cast<const f32x4 *>(kv + 2 * C) : f32x4{0, 0, 0, 0};
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int key = k0 + 8 * (r >> 2) + 4 * half + (r & 3);
+            sT[r] = key < L ? sT[r] : -INFINITY;
+            tmax = fmaxf(tmax, sT[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float nm = fmaxf(mx, tmax), corr = __expf(mx - nm);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            sT[r] = __expf(sT[r] - nm);
+            psum += sT[r];
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        den = den * corr + psum;
+        mx = nm;
+        // O^T += V^T P^T: step r pairs key(r, half) on both operands
+#pragma unroll
+        for (int i = 0; i < DT; i++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[i][r] *= corr;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int key = min(k0 + 8 * (r >> 2) + 4 * half + (r & 3), L - 1);
+                const float vf = base[(size_t)key * 3 * C + 2 * C + 32 * i + l32];
+                o[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, sT[r], o[i], 0, 0, 0);
             }
-            __syncthreads();
-            const int jn = min(64, L - j0);
-            for (int j = 0; j < jn; j++) {
-                float s = 0.f;
+        }
+    }
+    if (q0 + l32 < L) {
+        const float inv = 1.0f / den;
+        float *dst = out + ((size_t)b * L + q0 + l32) * C + h * D;
 #pragma unroll
-                for (int i = 0; i < D / 4; i++) {
-                    const f32x4 k = lds_k[j][i];
-                    s += q[i].x * k.x + q[i].y * k.y + q[i].z * k.z + q[i].w * k.w;
-                }
-                const float nm = fmaxf(mx, s), corr = __expf(mx - nm), p = __expf(s - nm);
-                den = den * corr + p;
+        for (int i = 0; i < DT; i++)
 #pragma unroll
-                for (int i = 0; i < D / 4; i++) o[i] = o[i] * corr + p * lds_v[j][i];
-                mx = nm;
+            for (int g = 0; g < 4; g++) {
+                const f32x4 v = {o[i][4 * g] * inv, o[i][4 * g + 1] * inv, o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv};
+                *reinterpret_cast<f32x4 *>(dst + 32 * i + 8 * g + 4 * half) = v;
             }
-        }
-        if (ok) {
-            const float inv = 1.0f / den;
-#pragma unroll
-            for (int i = 0; i < D / 4; i++)
-                *reinterpret_cast<f32x4 *>(out + ((size_t)b * L + row) * C + h * D + 4 * i) = o[i] * inv;
-        }
     }
 }
 
@@ -254,7 +283,7 @@ extern "C" int zs_group_norm_nhwc(const float *x, const float *gamma, const floa
                "zs_group_norm_nhwc: bad size (B=%d HW=%d C=%d groups=%d)", batch, HW, C, groups);
     if (batch == 0) return 1;
     ZS_REQUIRE(x && gamma && beta && y, "zs_group_norm_nhwc: null pointer");
-    hipLaunchKernelGGL(group_norm_kernel, dim3(batch * groups), dim3(256), 0, S(stream), x, gamma, beta, residual, y,
+    hipLaunchKernelGGL(group_norm_kernel, dim3(batch * groups), dim3(GN_BLOCK), 0, S(stream), x, gamma, beta, residual, y,
                        HW, C, groups, eps, relu);
     return zs::check_launch("zs_group_norm_nhwc") ? 1 : 0;
 }
@@ -276,10 +305,12 @@ extern "C" int zs_attention(const float *qkv, float *out, int batch, int L, int 
     if (batch == 0) return 1;
     ZS_REQUIRE(qkv && out, "zs_attention: null pointer");
     const float scale = 1.0f / sqrtf((float)head_dim);
+    ZS_REQUIRE(L <= 32 * 65535, "zs_attention: L = %d too long", L);
+    const dim3 grid(batch * heads, (L + 31) / 32);
     if (head_dim == 64)
-        hipLaunchKernelGGL(attention_kernel<64>, dim3(batch * heads), dim3(256), 0, S(stream), qkv, out, L, heads, scale);
+        hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(64), 0, S(stream), qkv, out, L, heads, scale);
     else
-        hipLaunchKernelGGL(attention_kernel<32>, dim3(batch * heads), dim3(256), 0, S(stream), qkv, out, L, heads, scale);
+        hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(64), 0, S(stream), qkv, out, L, heads, scale);
     return zs::check_launch("zs_attention") ? 1 : 0;
 }
 

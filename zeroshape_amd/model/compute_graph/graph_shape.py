@@ -86,10 +86,11 @@ class Graph(nn.Module):
                                      posenc_3D=opt.arch.impl.posenc_3D, mlp_ratio=opt.arch.impl.mlp_ratio,
                                      skip_in=opt.arch.impl.skip_in, pos_perlayer=opt.arch.impl.posenc_perlayer)
         self._intr = _IntrHead(self)
+        self._captured, self._use_hip_graph = {}, False
         self.eval()
 
     def __setattr__(self, name, value):
-        if name == "_intr":                       # keep the helper out of the module / state-dict tree
+        if name in ("_intr", "_captured", "_use_hip_graph"):   # helpers stay out of the module / state-dict tree
             object.__setattr__(self, name, value)
         else:
             super().__setattr__(name, value)
@@ -111,6 +112,40 @@ class Graph(nn.Module):
         """:89-113."""
         return camera.intr_param2mtx(opt, intr_params)
 
+    def enable_hip_graph(self, on=True):
+        """Replay the encoder as one captured hipGraph per input shape instead of ~350 launches
+        (weights must not change while enabled; disabling drops the captures)."""
+        self._use_hip_graph = bool(on)
+        self._captured = {}
+        return self
+
+    @torch.no_grad()
+    def encode(self, opt, rgb_input_map, mask_input_map):
+        """The encoder half of forward (:117-150) on tensors:
+        -> (depth_pred, intr_pred, seen_points, latent_depth)."""
+        dsp = opt.arch.depth.dsp
+        resnet = opt.arch.depth.encoder == 'resnet'
+
+        def run(rgb, mask):
+            depth_pred, intr_feat = self.dpt_depth(rgb, get_feat=True)
+            intr_pred = self.intr_param2mtx(opt, self._intr.run(intr_feat))
+            # :131-144 in one launch
+            seen_points, seen_3D_dsp, mask_dsp, _, _ = camera.seen_surface(opt, depth_pred, intr_pred, mask, dsp=dsp)
+            if resnet:
+                latent = self.coord_encoder(seen_3D_dsp, mask_dsp)
+            else:
+                latent = self.coord_encoder(seen_3D_dsp.permute(0, 2, 3, 1).contiguous(), mask_dsp.squeeze(1) > 0.5)
+            return depth_pred, intr_pred, seen_points, latent
+        rgb = rgb_input_map.detach().float().contiguous()
+        mask = mask_input_map.detach().float().contiguous()
+        if not self._use_hip_graph:
+            return run(rgb, mask)
+        from ...nn.capture import CapturedCall
+        key = (tuple(rgb.shape), str(rgb.device), dsp, resnet)
+        if key not in self._captured:
+            self._captured[key] = CapturedCall(run, [rgb, mask])
+        return self._captured[key](rgb, mask)
+
     @torch.no_grad()
     def forward(self, opt, var, training=False, get_loss=True):
         if training or get_loss or ('gt_sample_points' in var and 'gt_sample_sdf' in var and training):
@@ -118,17 +153,9 @@ class Graph(nn.Module):
                                       "runs on the HIP path")
         batch_size = len(var.idx)
         var.latent_semantic = None
-        var.depth_pred, intr_feat = self.dpt_depth(var.rgb_input_map, get_feat=True)
-        intr_params = self._intr.run(intr_feat)
-        var.intr_pred = self.intr_param2mtx(opt, intr_params)
+        HipModule._need_gpu(var.rgb_input_map, "var.rgb_input_map")
+        var.depth_pred, var.intr_pred, var.seen_points, var.latent_depth = self.encode(
+            opt, var.rgb_input_map, var.mask_input_map)
         var.validity_mask = (var.mask_input_map > 0.5).float().view(batch_size, -1)
-        # :131-144 in one launch
-        var.seen_points, seen_3D_dsp, mask_dsp, _, _ = camera.seen_surface(
-            opt, var.depth_pred, var.intr_pred, var.mask_input_map, dsp=opt.arch.depth.dsp)
-        if opt.arch.depth.encoder == 'resnet':
-            var.latent_depth = self.coord_encoder(seen_3D_dsp, mask_dsp)
-        else:
-            var.latent_depth = self.coord_encoder(seen_3D_dsp.permute(0, 2, 3, 1).contiguous(),
-                                                  mask_dsp.squeeze(1) > 0.5)
         var.pose = var.pose_gt if 'pose_gt' in var else None
         return var

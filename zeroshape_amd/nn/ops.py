@@ -17,8 +17,12 @@ def _stream(t):
     return _lib.current_stream_ptr(t.device)
 
 
-def conv2d(x, pc, res1=None, res2=None, act=ACT_NONE, in_relu=False, in_scale=1.0, in_shift=0.0):
-    """x [B,H,W,Cin] -> [B,Ho,Wo,Cout] with the fused epilogue of zs_conv2d_nhwc."""
+_TILING = {None: 0, "large": 2, "small": 4}
+
+
+def conv2d(x, pc, res1=None, res2=None, act=ACT_NONE, in_relu=False, in_scale=1.0, in_shift=0.0, tiling=None):
+    """x [B,H,W,Cin] -> [B,Ho,Wo,Cout] with the fused epilogue of zs_conv2d_nhwc.  `tiling`
+    ("large" / "small") overrides the size-based choice of kernel variant (tests, tuning)."""
     lib = _lib.load()
     _chk(x, "conv2d input")
     B, H, W, C = x.shape
@@ -33,7 +37,8 @@ def conv2d(x, pc, res1=None, res2=None, act=ACT_NONE, in_relu=False, in_scale=1.
     with torch.cuda.device(x.device):
         _lib.check(lib.zs_conv2d_nhwc(_lib.ptr(x), _lib.ptr(pc.w), _lib.ptr(pc.scale), _lib.ptr(pc.shift),
                                       _lib.ptr(res1), _lib.ptr(res2), _lib.ptr(out), B, H, W, C, Ho, Wo, pc.cout,
-                                      pc.kh, pc.kw, pc.stride, pt, pl, 1 if in_relu else 0, float(in_scale),
+                                      pc.kh, pc.kw, pc.stride, pt, pl, (1 if in_relu else 0) | _TILING[tiling],
+                                      float(in_scale),
                                       float(in_shift), act, _stream(x)), "zs_conv2d_nhwc")
     return out
 
