@@ -49,3 +49,61 @@ def get_child_state_dict(state_dict, key):
         if name.startswith(prefix):
             child[name.split(".", 1)[1]] = value
     return child
+
+
+def move_to_device(X, device):
+    """utils/util.py:162-175: recursive .to(device) through dicts / lists / namedtuples."""
+    if isinstance(X, dict):
+        for k, v in X.items():
+            X[k] = move_to_device(v, device)
+    elif isinstance(X, list):
+        for i, e in enumerate(X):
+            X[i] = move_to_device(e, device)
+    elif isinstance(X, tuple) and hasattr(X, "_fields"):
+        return type(X)(**move_to_device(X._asdict(), device))
+    elif isinstance(X, torch.Tensor):
+        return X.to(device=device, non_blocking=True)
+    return X
+
+
+def _bare_graph(model):
+    g = model.graph
+    return g.module if hasattr(g, "module") else g
+
+
+def load_checkpoint(opt, model, load_name):
+    """utils/util.py:228-239: load the children of ``model.graph`` that the checkpoint's "graph"
+    entry covers (strictly, per child), skip the others."""
+    checkpoint = torch.load(load_name, map_location="cpu")
+    for name, child in _bare_graph(model).named_children():
+        child_state_dict = get_child_state_dict(checkpoint["graph"], name)
+        if child_state_dict:
+            child.load_state_dict(child_state_dict, strict=True)
+    return None, None, None, None
+
+
+def restore_checkpoint(opt, model, load_name=None, resume=False, best=False, evaluate=False):
+    """utils/util.py:241-250 (loading only: resuming needs the optimiser state of training,
+    which is not built)."""
+    assert not (load_name is not None and resume)
+    if resume:
+        raise NotImplementedError("resume_checkpoint restores optimiser state; training is not built")
+    return load_checkpoint(opt, model, load_name)
+
+
+def save_checkpoint(opt, model, ep, it, best_val, best_ep, latest=False, best=False, children=None):
+    """utils/util.py:252-277: the same {epoch, iter, best_val, best_ep, graph} layout, written to
+    <output_path>/latest.ckpt (and best.ckpt / checkpoint/ep<N>.ckpt)."""
+    import os
+    import shutil
+    os.makedirs("{0}/checkpoint".format(opt.output_path), exist_ok=True)
+    sd = _bare_graph(model).state_dict()
+    if children is not None:
+        sd = {k: v for k, v in sd.items() if k.startswith(children)}
+    torch.save(dict(epoch=ep, iter=it, best_val=best_val, best_ep=best_ep, graph=sd),
+               "{0}/latest.ckpt".format(opt.output_path))
+    if best:
+        shutil.copy("{0}/latest.ckpt".format(opt.output_path), "{0}/best.ckpt".format(opt.output_path))
+    if not latest:
+        shutil.copy("{0}/latest.ckpt".format(opt.output_path),
+                    "{0}/checkpoint/ep{1}.ckpt".format(opt.output_path, ep))
