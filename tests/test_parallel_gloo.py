@@ -74,3 +74,39 @@ def test_single_process_passthrough():
     assert parallel.gather_slabs(x, 4) is x
     pl, cd, idx = parallel.reduce_best_rotation(0.5, 7, torch.tensor([1.0, 2.0]))
     assert cd == 0.5 and idx == 7
+
+
+def _rows_worker(rank, world, initfile, n_items):
+    """Dataset-sharded evaluation: DistributedSampler shards (with its padding duplicates) ->
+    gather_sample_rows == the single-process table."""
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    try:
+        table = torch.arange(n_items * 6, dtype=torch.float32).reshape(n_items, 6) * 0.5
+        sampler = torch.utils.data.distributed.DistributedSampler(list(range(n_items)), num_replicas=world,
+                                                                  rank=rank, shuffle=False, drop_last=False)
+        mine = torch.tensor(list(iter(sampler)), dtype=torch.long)
+        ids, (rows, col) = parallel.gather_sample_rows(mine, [table[mine], table[mine, 0]])
+        assert ids.tolist() == list(range(n_items)), "rank %d: ids %s" % (rank, ids.tolist())
+        assert torch.equal(rows, table) and torch.equal(col, table[:, 0])
+        # ragged shards (no sampler padding): ranks hold different counts
+        lo, hi = rank * n_items // world, (rank + 1) * n_items // world
+        if rank == world - 1:
+            hi = n_items
+        own = torch.arange(lo, hi)
+        ids, (rows,) = parallel.gather_sample_rows(own, [table[own]])
+        assert ids.tolist() == list(range(n_items)) and torch.equal(rows, table)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_items", [(2, 5), (3, 7), (2, 4)])
+def test_gather_sample_rows(world, n_items):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_rows_worker, args=(world, os.path.join(d, "init"), n_items), nprocs=world, join=True)
+
+
+def test_gather_sample_rows_single_process():
+    ids = torch.tensor([2, 0, 1, 1])
+    vals = torch.tensor([[20.], [0.], [10.], [11.]])
+    out_ids, (out,) = parallel.gather_sample_rows(ids, [vals])
+    assert out_ids.tolist() == [0, 1, 2] and out[:, 0].tolist() == [0., 10., 20.]   # first occurrence kept

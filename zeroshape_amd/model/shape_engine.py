@@ -48,7 +48,6 @@ class Runner:
         rank 0 with `opt.output_path`, writes <dataset>_full_results.txt / quantitative_<dataset>.txt /
         cd_cat.txt in the reference's formats."""
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
-        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         cd_accs, cd_comps, f_scores, cats, ids = [], [], [], [], []
         for it, batch in enumerate(self.test_loader):
             var = self.evaluate_batch(opt, edict(batch), ep, it)
@@ -60,25 +59,10 @@ class Runner:
             ids.append(torch.as_tensor(var.idx).view(-1).to(opt.device))
         cd_accs, cd_comps, f_scores = torch.cat(cd_accs), torch.cat(cd_comps), torch.cat(f_scores)
         cats, ids = torch.cat(cats).long(), torch.cat(ids).long()
-        if world > 1:                                          # :414-432 (ragged tails: pad to the max count)
-            n = torch.tensor([cd_accs.numel()], device=opt.device)
-            counts = [torch.zeros_like(n) for _ in range(world)]
-            dist.all_gather(counts, n)
-            nmax = int(max(c.item() for c in counts))
-
-            def gather(t):
-                pad = torch.zeros((nmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-                pad[:t.shape[0]] = t
-                parts = [torch.zeros_like(pad) for _ in range(world)]
-                dist.all_gather(parts, pad)
-                return torch.cat([p[:int(c.item())] for p, c in zip(parts, counts)])
-            cd_accs, cd_comps, f_scores, cats, ids = [gather(t) for t in (cd_accs, cd_comps, f_scores, cats, ids)]
-            keep = torch.unique(ids, return_inverse=False)      # DistributedSampler repeats samples to pad
-            first = torch.stack([(ids == i).nonzero()[0, 0] for i in keep])
-            cd_accs, cd_comps, f_scores, cats, ids = [t[first] for t in (cd_accs, cd_comps, f_scores, cats, ids)]
+        from .. import parallel
+        ids, (cd_accs, cd_comps, f_scores, cats) = parallel.gather_sample_rows(   # :414-432
+            ids, [cd_accs, cd_comps, f_scores, cats])
         assert cd_accs.shape[0] == len(self.test_data)
-        order = torch.argsort(ids)
-        cd_accs, cd_comps, f_scores, cats, ids = [t[order] for t in (cd_accs, cd_comps, f_scores, cats, ids)]
         out = dict(dist_acc=cd_accs.mean().item(), dist_cov=cd_comps.mean().item(),
                    f_scores=f_scores.mean(0).tolist())
         out["cd"] = (out["dist_acc"] + out["dist_cov"]) / 2

@@ -14,6 +14,11 @@ given the per-image latent and rotations are independent given the two clouds
                   winner is the FIRST strict minimum, like the sequential scan
                   (utils/eval_3D.py:161-168).
 
+  * dataset-level evaluation (the reference's own parallelism, model/shape_engine.py:414-432):
+                  per-sample metric rows of every rank are gathered, the DistributedSampler's
+                  padding duplicates dropped, and rows ordered by sample index
+                  (gather_sample_rows).
+
 The partition / merge logic is device-agnostic (tested with gloo on CPU tensors); the
 compute callbacks are the HIP kernels.
 """
@@ -93,3 +98,30 @@ def reduce_best_rotation(local_cd, local_idx, payload, group=None):
         if (cds[r] < cds[best]) or (cds[r] == cds[best] and idxs[r] < idxs[best]):
             best = r
     return out[best, 2:].to(payload.dtype).reshape(payload.shape), float(cds[best]), int(idxs[best])
+
+
+def gather_sample_rows(ids, tensors, group=None):
+    """Dataset-sharded evaluation (model/shape_engine.py:414-432): every rank holds the metric
+    rows of its samples (ids [n_r] int64, each tensor [n_r, ...]).  Returns (ids, tensors) of ALL
+    samples on every rank, sorted by id, with the duplicates a DistributedSampler appends to even
+    out the shards removed.  Ragged shards are padded to the longest one for the all_gather."""
+    rank, W = world(group)
+    if W > 1:
+        n = torch.tensor([ids.numel()], device=ids.device)
+        counts = [torch.zeros_like(n) for _ in range(W)]
+        dist.all_gather(counts, n, group=group)
+        counts = [int(c.item()) for c in counts]
+        nmax = max(counts)
+
+        def gather(t):
+            pad = t.new_zeros((nmax,) + tuple(t.shape[1:]))
+            pad[:t.shape[0]] = t
+            parts = [torch.zeros_like(pad) for _ in range(W)]
+            dist.all_gather(parts, pad, group=group)
+            return torch.cat([p[:c] for p, c in zip(parts, counts)])
+        ids, tensors = gather(ids), [gather(t) for t in tensors]
+    order = torch.argsort(ids, stable=True)
+    ids, tensors = ids[order], [t[order] for t in tensors]
+    keep = torch.ones_like(ids, dtype=torch.bool)
+    keep[1:] = ids[1:] != ids[:-1]                      # first occurrence of every sample index
+    return ids[keep], [t[keep] for t in tensors]
