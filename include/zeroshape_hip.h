@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 9
+#define ZS_ABI_VERSION 10
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -264,9 +264,12 @@ int zs_depth_metrics(const float *prediction, const float *target, const float *
 #define ZS_ACT_RELU 1
 #define ZS_ACT_GELU 2
 #define ZS_ACT_RELU_CLAMP1 3
+#define ZS_ACT_SOFTPLUS 4 /* torch Softplus(beta, threshold=20); zs_act_forward / zs_act_backward only */
 #define ZS_CONV_IN_RELU 1
 #define ZS_CONV_FORCE_LARGE 2 /* tiling override (tests / tuning): 128x128 tiles */
 #define ZS_CONV_FORCE_SMALL 4 /* 32x64 tiles with the K range split over the 4 waves */
+#define ZS_CONV_IN_DILATE2 8  /* read the input as if zero-stuffed x2 ([B][2H-1][2W-1][Cin] virtual): the
+                                 data gradient of a stride-2 convolution as a stride-1 convolution */
 size_t zs_conv2d_packed_floats(int Cin, int Cout, int kh, int kw);
 int zs_conv2d_nhwc(const float *in, const float *packed_w, const float *scale, const float *shift,
                    const float *res1, const float *res2, float *out, int batch, int Hin, int Win, int Cin,
@@ -289,6 +292,102 @@ int zs_assemble_tokens(const float *feat, const float *cls, const float *pos, fl
 int zs_readout_concat(const float *tokens, float *out, int batch, int n, int C, void *stream);
 int zs_window_tokens(const float *emb, const uint8_t *mask, const float *invalid_token, const float *cls,
                      const float *pos, float *out, int batch, int H, int W, int C, int win, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Training (fp32; autograd over these entry points lives in zeroshape_amd/nn/autograd.py).
+ * Replaces what the reference gets from torch.autograd + cuDNN/cuBLAS when train.py runs
+ * Runner.train_iteration (model/shape_engine.py:248-297): Graph.forward(training=True)
+ * (model/compute_graph/graph_shape.py:115-204), Loss.shape_loss (utils/loss.py:18-28),
+ * loss.backward(), torch.optim.AdamW.step (model/shape_engine.py:132).
+ * Every reduction runs in a fixed order (two-stage partial sums, no atomics).
+ *
+ * Convolution / linear layer gradients:
+ *   zs_pack_conv_weight : torch-layout weight w[Cout][CinTot][kh][kw] (channel sub-range
+ *       [cin0, cin0+Cin)) -> the packed operand of zs_conv2d_nhwc.  dgrad = 0: forward operand
+ *       (Cin zero-padded to a multiple of 4; zs_conv2d_packed_floats(CinP, Cout, kh, kw) floats).
+ *       dgrad = 1: operand of the DATA gradient, a convolution of dY (Cout zero-padded to a
+ *       multiple of 4 = its input channels) with flipped taps and Cin outputs
+ *       (zs_conv2d_packed_floats(CoutP, Cin, kh, kw) floats): dX = zs_conv2d_nhwc(dY, packed,
+ *       stride 1, pad = k-1-pad, ZS_CONV_IN_DILATE2 when the forward stride was 2).
+ *   zs_conv2d_wgrad : dw[cout][cin0+c][ky][kx] (=|+=) sum over output pixels of
+ *       dy[pixel][cout] * A[pixel][(ky,kx,c)], A = the forward's input taps incl. its input
+ *       transform (flags & ZS_CONV_IN_RELU, in_scale, in_shift).  in is [B][Hin][Win][CinP]
+ *       (CinP % 4 == 0, channels >= Cin are padding), dy is [B][Hout][Wout][CoutP] with
+ *       CoutP = Cout rounded up to 4.  workspace: zs_conv2d_wgrad_workspace_bytes(...).
+ *   zs_standardize_weight(_bwd) : timm StdConv2d: rows of n = Cin*kh*kw weights,
+ *       (w - mean) / sqrt(biased var + eps), and the adjoint for a gradient w.r.t. the result.
+ * Pointwise / normalisation:
+ *   zs_act_forward / zs_act_backward : GELU(erf), Softplus(beta), ReLU, ReLU+clamp1; backward
+ *       takes `ref` = the pre-activation input (GELU, softplus) or the OUTPUT (ReLU variants).
+ *   zs_add_scaled_rows : y[b][..] = x[b][..] + scale[b] * branch[b][..] (x may be NULL):
+ *       residual with per-sample stochastic depth (timm DropPath, implicit.py:8,83-109).
+ *   zs_column_sum : out[c] = scale * sum_rows x[row][c]   (bias gradients, reductions).
+ *   zs_layer_norm_bwd : dx, dgamma, dbeta of zs_layer_norm (statistics recomputed from x).
+ *   zs_attention_bwd : dqkv [B][L][3*heads*head_dim] of zs_attention; L <= 512.
+ * Decoder (model/shape/implicit.py:25-79, ImplFuncAttention):
+ *   zs_point_attention : out[b][i] = softmax over (Ll latent keys + the point itself) of
+ *       q_i k^T / sqrt(d), times the values; qkv_points [B][M][3*heads*32], qkv_latent
+ *       [B][Ll][3*heads*32] (q | k | v, head-major).  Ll <= 256, head_dim 32.
+ *   zs_point_attention_bwd : dqkv_points (all of q, k, v), dqkv_latent: k and v columns
+ *       written (accumulate_latent = 0, q columns zeroed) or added to (accumulate_latent = 1).
+ * Loss / optimiser:
+ *   zs_bce_logits(_bwd) : Loss.shape_loss: mean over n of w * BCEWithLogits(logit, sdf < 0),
+ *       w = impt_weight where |sdf| < impt_thres else 1; backward scales by *grad_loss (device).
+ *   zs_adamw_multi : torch.optim.AdamW (decoupled decay, bias correction, eps outside the
+ *       sqrt) over a DEVICE table of tensors in one launch; chunk c = elements
+ *       [chunk_start[c], +zs_multi_tensor_chunk_elems()) of tensor chunk_tensor[c].
+ *       grad_scale (device scalar, may be NULL) multiplies every gradient (clipping).
+ *   zs_copy_multi  : entry.param[i] = entry.grad[i] * scale (gradient bucketing for all-reduce).
+ *   zs_sumsq_multi : *sumsq = sum of entry.grad[i]^2 over the table (partial: n_chunks floats).
+ * ------------------------------------------------------------------------- */
+typedef struct zs_tensor_entry {
+    float *param;
+    const float *grad;
+    float *exp_avg, *exp_avg_sq;
+    unsigned long long n;
+    float lr, weight_decay;
+} zs_tensor_entry;
+
+int zs_pack_conv_weight(const float *w, float *packed, int Cout, int Cin, int cin0, int CinTot, int kh, int kw,
+                        int dgrad, void *stream);
+size_t zs_conv2d_wgrad_workspace_bytes(int batch, int Hout, int Wout, int Cin, int Cout, int kh, int kw);
+int zs_conv2d_wgrad(const float *in, const float *dy, float *dw, void *workspace, int batch, int Hin, int Win,
+                    int CinP, int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad_t, int pad_l,
+                    int flags, float in_scale, float in_shift, int Cin, int cin0, int CinTot, int accumulate,
+                    void *stream);
+int zs_standardize_weight(const float *w, float *out, int Cout, int n, float eps, void *stream);
+int zs_standardize_weight_bwd(const float *w, const float *grad_out, float *dw, int Cout, int n, float eps,
+                              void *stream);
+int zs_act_forward(const float *x, float *y, size_t n, int act, float beta, void *stream);
+int zs_act_backward(const float *dy, const float *ref, float *dx, size_t n, int act, float beta, void *stream);
+int zs_add_scaled_rows(const float *x, const float *branch, const float *scale, float *y, int batch,
+                       size_t per_sample, void *stream);
+size_t zs_column_sum_workspace_bytes(int rows, int C);
+int zs_column_sum(const float *x, float *out, int rows, int C, float scale, void *workspace, void *stream);
+size_t zs_layer_norm_bwd_workspace_bytes(int rows, int C);
+int zs_layer_norm_bwd(const float *dy, const float *x, const float *gamma, float *dx, float *dgamma, float *dbeta,
+                      int rows, int C, float eps, void *workspace, void *stream);
+size_t zs_attention_bwd_workspace_bytes(int batch, int L, int heads);
+int zs_attention_bwd(const float *qkv, const float *dout, float *dqkv, void *workspace, int batch, int L, int heads,
+                     int head_dim, void *stream);
+int zs_point_attention(const float *qkv_points, const float *qkv_latent, float *out, int batch, int M, int Ll,
+                       int heads, int head_dim, void *stream);
+size_t zs_point_attention_bwd_workspace_bytes(int batch, int M, int Ll, int heads);
+int zs_point_attention_bwd(const float *qkv_points, const float *qkv_latent, const float *dout, float *dqkv_points,
+                           float *dqkv_latent, int accumulate_latent, void *workspace, int batch, int M, int Ll,
+                           int heads, int head_dim, void *stream);
+size_t zs_bce_logits_workspace_bytes(size_t n);
+int zs_bce_logits(const float *logits, const float *sdf, size_t n, float impt_thres, float impt_weight, float *loss,
+                  void *workspace, void *stream);
+int zs_bce_logits_bwd(const float *logits, const float *sdf, size_t n, float impt_thres, float impt_weight,
+                      const float *grad_loss, float *dlogits, void *stream);
+int zs_multi_tensor_chunk_elems(void);
+int zs_adamw_multi(const zs_tensor_entry *table, const int *chunk_tensor, const unsigned long long *chunk_start,
+                   int n_chunks, float beta1, float beta2, float eps, int step, const float *grad_scale, void *stream);
+int zs_copy_multi(const zs_tensor_entry *table, const int *chunk_tensor, const unsigned long long *chunk_start,
+                  int n_chunks, float scale, void *stream);
+int zs_sumsq_multi(const zs_tensor_entry *table, const int *chunk_tensor, const unsigned long long *chunk_start,
+                   int n_chunks, float *partial, float *sumsq, void *stream);
 
 #ifdef __cplusplus
 }

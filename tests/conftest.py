@@ -74,3 +74,9 @@ def seeded_sd(decoder_golden):
     from zeroshape_amd import synthetic as syn
     sd = syn.seeded_state_dict(seed=0, pos_embed=decoder_golden["pos_embed_f32"])
     return {k: torch.from_numpy(v) for k, v in sd.items()}
+
+
+@pytest.fixture(scope="session")
+def decoder_train_golden():
+    import numpy as np
+    return dict(np.load(os.path.join(GOLDEN, "decoder_train_golden.npz")))

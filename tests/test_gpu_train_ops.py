@@ -1,0 +1,248 @@
+"""GPU parity of the training kernels (include/zeroshape_hip.h "Training") through
+zeroshape_amd/nn/autograd.py: every forward and backward against torch's CPU fp32 autograd of the
+same op (the plain-PyTorch reference of a floating-point kernel).  Tolerances are relative to the
+tensor's scale; the contract of BASELINE.json is 1e-4."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-5
+
+
+def close(got, want, rtol=RTOL, what=""):
+    got, want = got.detach().cpu().double(), want.detach().double()
+    scale = float(want.abs().max()) + 1e-30
+    err = float((got - want).abs().max())
+    assert got.shape == want.shape, what
+    assert err <= rtol * scale, "%s: max err %.3e vs scale %.3e" % (what, err, scale)
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("cfg", [
+    # B, H, W, Cin, Cout, k, stride, pad, bias, act, in_relu, in_scale
+    (2, 14, 14, 64, 96, 3, 1, 1, True, "relu", False, 1.0),
+    (1, 17, 13, 32, 40, 1, 1, 0, True, None, False, 1.0),
+    (2, 16, 16, 48, 64, 3, 2, 1, False, None, False, 1.0),
+    (2, 15, 15, 32, 64, 1, 2, 0, False, None, False, 1.0),
+    (1, 32, 32, 16, 32, 7, 2, 3, False, "relu", False, 1.0),
+    (2, 12, 12, 64, 64, 3, 1, 1, True, None, True, 1.0),
+    (1, 1, 300, 256, 256, 1, 1, 0, True, None, False, 0.70710678),
+    (3, 1, 50, 128, 1, 1, 1, 0, True, None, False, 1.0),
+    (1, 9, 9, 32, 3, 1, 1, 0, True, None, False, 1.0),
+    (2, 56, 56, 32, 128, 3, 1, 1, True, "clamp1", False, 1.0),
+    (2, 15, 14, 32, 48, 3, 2, "same", False, None, False, 1.0),
+])
+def test_conv_forward_dgrad_wgrad(cfg):
+    from zeroshape_amd.nn import autograd as A
+    B, H, W, Cin, Cout, k, stride, pad, use_bias, act, in_relu, in_scale = cfg
+    g = torch.Generator().manual_seed(B * 1000 + H * 37 + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g) if use_bias else None
+    res = torch.randn(B, Cout, 1, 1, generator=g)
+    # ---- torch CPU reference ----
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = None if b is None else b.clone().requires_grad_(True)
+    xin = (F.relu(xr) if in_relu else xr) * in_scale
+    if pad == "same":       # TF 'SAME' (timm StdConv2dSame)
+        oh, ow = -(-H // stride), -(-W // stride)
+        ph, pw = max((oh - 1) * stride + k - H, 0), max((ow - 1) * stride + k - W, 0)
+        xin = F.pad(xin, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
+        y = F.conv2d(xin, wr, br, stride=stride)
+    else:
+        y = F.conv2d(xin, wr, br, stride=stride, padding=pad)
+    resr = res.expand_as(y).contiguous().requires_grad_(True)
+    y = y + resr
+    y = F.relu(y) if act == "relu" else (y.clamp(0, 1) if act == "clamp1" else y)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    # ---- HIP ----
+    xg = nhwc(x).cuda().requires_grad_(True)
+    wg = w.cuda().requires_grad_(True)
+    bg = None if b is None else b.cuda().requires_grad_(True)
+    rg = nhwc(resr.detach()).cuda().requires_grad_(True)
+    code = {"relu": A.ACT_RELU, "clamp1": A.ACT_RELU_CLAMP1, None: A.ACT_NONE}[act]
+    yg = A.conv2d(xg, wg, bg, stride=stride, padding=pad, act=code, in_relu=in_relu, in_scale=in_scale, res1=rg)
+    close(yg.permute(0, 3, 1, 2), y, what="forward")
+    yg.backward(nhwc(gy).cuda())
+    close(xg.grad.permute(0, 3, 1, 2), xr.grad, what="dgrad")
+    close(wg.grad, wr.grad, what="wgrad")
+    close(rg.grad.permute(0, 3, 1, 2), resr.grad, what="dres")
+    if b is not None:
+        close(bg.grad, br.grad, what="dbias")
+
+
+def test_conv_weight_column_ranges_and_padded_input():
+    """The decoder's skip layers: one [256, 515] weight applied as three column-range products
+    (x | xyz | feat) / sqrt(2); xyz has 3 channels padded to 4."""
+    from zeroshape_amd.nn import autograd as A
+    g = torch.Generator().manual_seed(5)
+    n, C = 333, 256
+    xs, pts, feat = torch.randn(1, n, C, generator=g), torch.randn(1, n, 3, generator=g), torch.randn(1, n, C, generator=g)
+    w, b = torch.randn(C, 2 * C + 3, generator=g) / 16, torch.randn(C, generator=g)
+    r2 = 0.7071067811865476
+    xr, fr, wr, br = [t.clone().requires_grad_(True) for t in (xs, feat, w, b)]
+    y = F.linear(torch.cat([xr, pts, fr], -1) / np.sqrt(2), wr, br)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xg, fg, wg, bg = [t.cuda().requires_grad_(True) for t in (xs, feat, w, b)]
+    p4 = A._pad_channels(pts.cuda(), 4)
+    yg = A.linear(p4, wg, None, in_scale=r2, cin0=C, cin=3)
+    yg = A.linear(fg, wg, None, in_scale=r2, res1=yg, cin0=C + 3, cin=C)
+    yg = A.linear(xg, wg, bg, in_scale=r2, res1=yg, cin0=0, cin=C)
+    close(yg, y, what="forward")
+    yg.backward(gy.cuda())
+    close(xg.grad, xr.grad, what="dx")
+    close(fg.grad, fr.grad, what="dfeat")
+    close(wg.grad, wr.grad, what="dW")
+    close(bg.grad, br.grad, what="db")
+
+
+def test_std_conv_weight_standardisation_gradient():
+    """timm StdConv2dSame (eps 1e-8): gradient flows through the per-channel standardisation."""
+    from zeroshape_amd.nn import autograd as A
+    g = torch.Generator().manual_seed(9)
+    x, w = torch.randn(2, 32, 10, 10, generator=g), torch.randn(48, 32, 3, 3, generator=g) * 0.3 + 0.1
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    flat = wr.reshape(48, -1)
+    ws = ((flat - flat.mean(1, keepdim=True)) / torch.sqrt(flat.var(1, unbiased=False, keepdim=True) + 1e-8)).reshape(w.shape)
+    y = F.conv2d(xr, ws, None, padding=1)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xg, wg = nhwc(x).cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    yg = A.conv2d(xg, wg, None, padding="same", std_eps=1e-8)
+    close(yg.permute(0, 3, 1, 2), y, what="forward")
+    yg.backward(nhwc(gy).cuda())
+    close(xg.grad.permute(0, 3, 1, 2), xr.grad, what="dx")
+    close(wg.grad, wr.grad, rtol=1e-4, what="dW")
+
+
+@pytest.mark.parametrize("rows,C", [(37, 256), (1000, 768), (5, 64), (200, 1024)])
+def test_layer_norm_backward(rows, C):
+    from zeroshape_amd.nn import autograd as A
+    g = torch.Generator().manual_seed(rows)
+    x, ga, be = torch.randn(rows, C, generator=g) * 2 + 0.5, torch.randn(C, generator=g), torch.randn(C, generator=g)
+    xr, gr, br = [t.clone().requires_grad_(True) for t in (x, ga, be)]
+    y = F.layer_norm(xr, (C,), gr, br, 1e-6)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xg, gg, bg = [t.cuda().requires_grad_(True) for t in (x, ga, be)]
+    yg = A.layer_norm(xg, gg, bg, 1e-6)
+    close(yg, y, what="forward")
+    yg.backward(gy.cuda())
+    close(xg.grad, xr.grad, what="dx")
+    close(gg.grad, gr.grad, what="dgamma")
+    close(bg.grad, br.grad, what="dbeta")
+
+
+@pytest.mark.parametrize("name", ["gelu", "softplus", "relu"])
+def test_activations(name):
+    from zeroshape_amd.nn import autograd as A
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4000, generator=g) * (0.3 if name == "softplus" else 3)
+    x[:5] = torch.tensor([0.0, 0.19, 0.21, -0.5, 5.0])
+    xr = x.clone().requires_grad_(True)
+    y = {"gelu": F.gelu, "softplus": lambda t: F.softplus(t, beta=100), "relu": F.relu}[name](xr)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xg = x.cuda().requires_grad_(True)
+    yg = {"gelu": A.gelu, "softplus": lambda t: A.softplus(t, 100.0), "relu": A.relu}[name](xg)
+    close(yg, y, what="forward")
+    yg.backward(gy.cuda())
+    close(xg.grad, xr.grad, what="backward")
+
+
+@pytest.mark.parametrize("B,L,heads,d", [(2, 197, 12, 64), (3, 65, 8, 32), (1, 197, 8, 32), (2, 101, 12, 64)])
+def test_attention_backward(B, L, heads, d):
+    from zeroshape_amd.nn import autograd as A
+    g = torch.Generator().manual_seed(L)
+    C = heads * d
+    qkv = torch.randn(B, L, 3 * C, generator=g)
+    qr = qkv.clone().requires_grad_(True)
+    q, k, v = qr.reshape(B, L, 3, heads, d).permute(2, 0, 3, 1, 4).unbind(0)
+    o = ((q @ k.transpose(-2, -1)) * d ** -0.5).softmax(-1) @ v
+    o = o.transpose(1, 2).reshape(B, L, C)
+    go = torch.randn(o.shape, generator=g)
+    o.backward(go)
+    qg = qkv.cuda().requires_grad_(True)
+    og = A.attention(qg, heads)
+    close(og, o, what="forward")
+    og.backward(go.cuda())
+    close(qg.grad, qr.grad, what="dqkv")
+
+
+@pytest.mark.parametrize("B,M,Ll", [(2, 300, 197), (1, 1000, 197), (3, 7, 50)])
+def test_point_attention(B, M, Ll):
+    """ImplFuncAttention's point rows (implicit.py:44-66) incl. the gradient to the latent k / v."""
+    from zeroshape_amd.nn import autograd as A
+    heads, d = 8, 32
+    C = heads * d
+    g = torch.Generator().manual_seed(M)
+    qp, ql = torch.randn(B, M, 3 * C, generator=g), torch.randn(B, Ll, 3 * C, generator=g)
+    pr, lr = qp.clone().requires_grad_(True), ql.clone().requires_grad_(True)
+    sp = lambda t, n: t.reshape(B, n, 3, heads, d).permute(2, 0, 3, 1, 4).unbind(0)   # noqa: E731
+    q_p, k_p, v_p = sp(pr, M)
+    _, k_l, v_l = sp(lr, Ll)
+    cross = (q_p @ k_l.transpose(-2, -1)) * d ** -0.5
+    self_ = (q_p * k_p).sum(-1, keepdim=True) * d ** -0.5
+    joint = torch.cat([cross, self_], -1).softmax(-1)
+    o = (joint[..., :Ll] @ v_l + joint[..., Ll:] * v_p).transpose(1, 2).reshape(B, M, C)
+    go = torch.randn(o.shape, generator=g)
+    o.backward(go)
+    pg, lg = qp.cuda().requires_grad_(True), ql.cuda().requires_grad_(True)
+    og = A.point_attention(pg, lg, heads)
+    close(og, o, what="forward")
+    og.backward(go.cuda())
+    close(pg.grad, pr.grad, what="dqkv_points")
+    close(lg.grad, lr.grad, what="dqkv_latent")
+    assert float(lg.grad[..., :C].abs().max()) == 0          # latent queries are unused here
+
+
+def test_drop_path_residual_and_bce_loss():
+    from zeroshape_amd.nn import autograd as A
+    from oracle import decoder_ref as R
+    g = torch.Generator().manual_seed(1)
+    x, br = torch.randn(3, 40, 16, generator=g), torch.randn(3, 40, 16, generator=g)
+    sc = torch.tensor([0.0, 1.0 / 0.9, 1.0 / 0.9])
+    xr, brr = x.clone().requires_grad_(True), br.clone().requires_grad_(True)
+    y = xr + brr * sc.view(3, 1, 1)
+    logits = y.sum(-1) * 0.5
+    sdf = torch.randn(3, 40, generator=g) * 0.02
+    loss = R.shape_loss(logits, sdf, 0.01, 2.5) * 3.0
+    loss.backward()
+    xg, bg = x.cuda().requires_grad_(True), br.cuda().requires_grad_(True)
+    lg = A.add_scaled_rows(xg, bg, sc.cuda()).sum(-1) * 0.5
+    lossg = A.bce_logits(lg, sdf.cuda(), 0.01, 2.5) * 3.0
+    assert abs(float(lossg) - float(loss)) < 1e-6 * abs(float(loss))
+    lossg.backward()
+    close(xg.grad, xr.grad, what="dx")
+    close(bg.grad, brr.grad, what="dbranch")
+
+
+def test_adamw_multi_tensor_matches_torch():
+    from zeroshape_amd.optim import FusedAdamW
+    g = torch.Generator().manual_seed(2)
+    shapes = [(300, 70), (70,), (5, 5, 3, 3), (40000,), (1,)]
+    ref = [torch.randn(s, generator=g).requires_grad_(True) for s in shapes]
+    mine = [p.detach().clone().cuda().requires_grad_(True) for p in ref]
+    groups = lambda ps: [dict(params=ps[:2], lr=3e-3, weight_decay=0.0), dict(params=ps[2:], lr=1e-3, weight_decay=0.05)]  # noqa: E731
+    o_ref = torch.optim.AdamW(groups(ref), betas=(0.9, 0.95))
+    o_mine = FusedAdamW(groups(mine), betas=(0.9, 0.95))
+    for step in range(4):
+        for pr, pm in zip(ref, mine):
+            gr = torch.randn(pr.shape, generator=g)
+            pr.grad, pm.grad = gr.clone(), gr.cuda()
+        o_ref.step()
+        o_mine.step()
+        o_ref.zero_grad()
+        o_mine.zero_grad()
+    for pr, pm in zip(ref, mine):
+        close(pm, pr, rtol=1e-6, what="param")
+    sd = o_mine.state_dict()
+    assert sd["state"][0]["step"] == 4 and sd["state"][0]["exp_avg"].shape == (300, 70)

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("ZS_LIB_PATH") or os.path.join(_HERE, "libzeroshape_hi
 _c_void_p = ctypes.c_void_p
 _c_int = ctypes.c_int
 _c_size_t = ctypes.c_size_t
+_c_float = ctypes.c_float
 
 # name -> (restype, argtypes); mirrors include/zeroshape_hip.h one to one
 SIGNATURES = {
@@ -70,9 +71,37 @@ SIGNATURES = {
     "zs_nhwc_to_nchw": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
     "zs_assemble_tokens": (_c_int, [_c_void_p] * 4 + [_c_int, _c_int, _c_int, _c_void_p]),
     "zs_readout_concat": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
+    # ---- training ----
+    "zs_pack_conv_weight": (_c_int, [_c_void_p, _c_void_p] + [_c_int] * 7 + [_c_void_p]),
+    "zs_conv2d_wgrad_workspace_bytes": (_c_size_t, [_c_int] * 7),
+    "zs_conv2d_wgrad": (_c_int, [_c_void_p] * 4 + [_c_int] * 13 + [_c_float, _c_float] + [_c_int] * 4 + [_c_void_p]),
+    "zs_standardize_weight": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_float, _c_void_p]),
+    "zs_standardize_weight_bwd": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_float, _c_void_p]),
+    "zs_act_forward": (_c_int, [_c_void_p, _c_void_p, _c_size_t, _c_int, _c_float, _c_void_p]),
+    "zs_act_backward": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_int, _c_float, _c_void_p]),
+    "zs_add_scaled_rows": (_c_int, [_c_void_p] * 4 + [_c_int, _c_size_t, _c_void_p]),
+    "zs_column_sum_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
+    "zs_column_sum": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_float, _c_void_p, _c_void_p]),
+    "zs_layer_norm_bwd_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
+    "zs_layer_norm_bwd": (_c_int, [_c_void_p] * 6 + [_c_int, _c_int, _c_float, _c_void_p, _c_void_p]),
+    "zs_attention_bwd_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
+    "zs_attention_bwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 4 + [_c_void_p]),
+    "zs_point_attention": (_c_int, [_c_void_p] * 3 + [_c_int] * 5 + [_c_void_p]),
+    "zs_point_attention_bwd_workspace_bytes": (_c_size_t, [_c_int] * 4),
+    "zs_point_attention_bwd": (_c_int, [_c_void_p] * 5 + [_c_int, _c_void_p] + [_c_int] * 5 + [_c_void_p]),
+    "zs_bce_logits_workspace_bytes": (_c_size_t, [_c_size_t]),
+    "zs_bce_logits": (_c_int, [_c_void_p, _c_void_p, _c_size_t, _c_float, _c_float, _c_void_p, _c_void_p,
+                               _c_void_p]),
+    "zs_bce_logits_bwd": (_c_int, [_c_void_p, _c_void_p, _c_size_t, _c_float, _c_float, _c_void_p, _c_void_p,
+                                   _c_void_p]),
+    "zs_multi_tensor_chunk_elems": (_c_int, []),
+    "zs_adamw_multi": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_float, _c_float, _c_float, _c_int,
+                                _c_void_p, _c_void_p]),
+    "zs_copy_multi": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_float, _c_void_p]),
+    "zs_sumsq_multi": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p]),
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 _lib = None
 
 

@@ -39,6 +39,8 @@ struct ConvArgs {
     int B, Hin, Win, Cin, Hout, Wout, Cout, CoutPad, kh, kw, stride, pad_t, pad_l, K, M;
     int in_relu, act;
     float in_scale, in_shift;
+    int dil;   // 1, or 2: the input is read as if zero-stuffed to (H-1)*2+1 rows / columns (the
+               // data-gradient of a stride-2 convolution is a stride-1 convolution over that)
 };
 
 __device__ __forceinline__ float activate(float v, int act) {
@@ -101,9 +103,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 
     const float relu_floor = a.in_relu ? 0.f : -INFINITY;
     auto load_a = [&](const TapIter &it) -> AQuad {            // 4 consecutive channels of one tap
-        const int iy = iy0 + it.ky, ix = ix0 + it.kx;
+        const int vy = iy0 + it.ky, vx = ix0 + it.kx, sh = a.dil - 1;      // dil 1 -> 0, dil 2 -> 1
+        const int iy = vy >> sh, ix = vx >> sh;
         AQuad q;
-        q.ok = pix_ok && it.ky < a.kh && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        q.ok = pix_ok && it.ky < a.kh && vy >= 0 && iy < a.Hin && vx >= 0 && ix < a.Win && ((vy | vx) & sh) == 0;
         const size_t off = q.ok ? ((size_t)iy * a.Win + ix) * a.Cin + it.c : 0;
         q.v = *reinterpret_cast<const f32x4 *>(in_b + off);
         return q;
@@ -227,9 +230,10 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
     const float *in_b = a.in + (size_t)pb * a.Hin * a.Win * a.Cin;
     const float relu_floor = a.in_relu ? 0.f : -INFINITY;
     auto load_a = [&](const TapIter &it) -> AQuad {
-        const int iy = iy0 + it.ky, ix = ix0 + it.kx;
+        const int vy = iy0 + it.ky, vx = ix0 + it.kx, sh = a.dil - 1;      // dil 1 -> 0, dil 2 -> 1
+        const int iy = vy >> sh, ix = vx >> sh;
         AQuad q;
-        q.ok = pix_ok && it.ky < a.kh && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        q.ok = pix_ok && it.ky < a.kh && vy >= 0 && iy < a.Hin && vx >= 0 && ix < a.Win && ((vy | vx) & sh) == 0;
         const size_t off = q.ok ? ((size_t)iy * a.Win + ix) * a.Cin + it.c : 0;
         q.v = *reinterpret_cast<const f32x4 *>(in_b + off);
         return q;
@@ -330,6 +334,7 @@ extern "C" int zs_conv2d_nhwc(const float *in, const float *packed_w, const floa
     a.K = kh * kw * Cin; a.M = (int)M;
     a.in_relu = (flags & ZS_CONV_IN_RELU) ? 1 : 0;
     a.act = act; a.in_scale = in_scale; a.in_shift = in_shift;
+    a.dil = (flags & ZS_CONV_IN_DILATE2) ? 2 : 1;
     // fewer than ~3/4 of a wave of 128x128 tiles over the 256 CUs: use the small-tile split-K variant
     const long long big_tiles = ((M + BM - 1) / BM) * (a.CoutPad / BN);
     const bool small = (flags & ZS_CONV_FORCE_SMALL) || (!(flags & ZS_CONV_FORCE_LARGE) && big_tiles < 192);

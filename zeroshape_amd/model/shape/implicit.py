@@ -12,8 +12,12 @@ half) + csrc/sdf_decoder.hip (per point, fused) through the C ABI of
 include/zeroshape_hip.h.  There is no PyTorch fallback: without the library, or for a
 configuration the kernels are not specialised for, this module raises.
 
-Not yet on the HIP path (raises, never silently approximated):
-  * autograd through the decoder (training, graph_shape.py:185) - inference only;
+Training (``.train()`` mode or any call under autograd that needs gradients) runs the same
+network layer by layer through zeroshape_amd/nn/autograd.py - HIP kernels for every forward and
+backward op, torch.autograd only as the tape - including timm's per-sample DropPath
+(implicit.py:83-109, drop_path=0.1).
+
+Not on the HIP path (raises, never silently approximated):
   * ``semantic=True`` / ``posenc_3D>0`` / ``pos_perlayer=True`` variants (unused by
     options/shape.yaml).
 """
@@ -25,6 +29,7 @@ import torch.nn as nn
 
 from ... import _lib
 from ... import program as P
+from ...nn import autograd as A
 from ...utils.pos_embed import get_2d_sincos_pos_embed
 
 
@@ -107,6 +112,8 @@ class Implicit(nn.Module):
             if n_layers_mlp > 0 else None
         if self.impl_mlp is None:
             self.pred_head = nn.Linear(n_channels, 1, bias=True)
+        self.drop_path = float(drop_path)
+        self.drop_scales = None   # tests: explicit list of 2*n_blocks per-sample scale tensors [B]
         self.initialize_weights()
         self._packed = None       # (key, template programs tensor, lat_params tensor)
         self._workspace = {}      # device -> scratch tensor for the query kernels
@@ -139,7 +146,7 @@ class Implicit(nn.Module):
                 "(got, need): %s" % bad)
 
     def _weights_key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (A.GENERATION[0],) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def packed(self, device):
         """(template program [PROGRAM_FLOATS], lat_params) on ``device``; repacked when any
@@ -239,12 +246,84 @@ class Implicit(nn.Module):
         probes) pass need_attn=False and get (logits, None) from the faster kernel variant."""
         if self.semantic or latent_semantic is not None:
             raise NotImplementedError("semantic latent codes are not used by options/shape.yaml")
-        if torch.is_grad_enabled() and (points_3D.requires_grad or latent_depth.requires_grad
-                                        or any(p.requires_grad for p in self.parameters())) \
-                and self.training:
-            raise NotImplementedError("autograd through the HIP decoder is not implemented yet "
-                                      "(inference only); call under torch.no_grad() / .eval()")
+        if torch.is_grad_enabled() and (self.training or points_3D.requires_grad or latent_depth.requires_grad):
+            logits = self._forward_autograd(latent_depth, points_3D)
+            if not need_attn:
+                return logits, None
+            with torch.no_grad():      # the attention map carries no gradient in the reference's losses
+                return logits, self.query_points(self.prepare(latent_depth), points_3D, need_attn=True)[1]
         state = self.prepare(latent_depth)
         if need_attn:
             return self.query_points(state, points_3D, need_attn=True)
         return self.query_points(state, points_3D), None
+
+    # ---- training path (layer by layer, autograd over HIP kernels) -------------------------
+    def _drop_scale(self, B, device):
+        """timm drop_path (timm==0.6.12 layers/drop.py): bernoulli(keep) / keep per sample; None when
+        the branch is kept as is (eval mode or drop_path == 0)."""
+        if not self.training or self.drop_path <= 0.0:
+            return None
+        keep = 1.0 - self.drop_path
+        return torch.empty(B, dtype=torch.float32, device=device).bernoulli_(keep).div_(keep)
+
+    def _forward_autograd(self, latent_depth, points_3D):
+        """implicit.py:251-288 with the latent rows and the point rows kept as two row blocks
+        (every op but the attention is row-wise, and the attention treats the blocks differently
+        anyway, implicit.py:38-71), so no concatenated [B,197+M,C] tensor is ever built."""
+        self._check_supported()
+        if not (latent_depth.is_cuda and points_3D.is_cuda):
+            raise ValueError("latent_depth / points_3D must be GPU tensors; zeroshape_amd has no CPU path")
+        lat = latent_depth.to(torch.float32)
+        pts = points_3D.detach().to(torch.float32).contiguous()
+        B, M = pts.shape[0], pts.shape[1]
+        H = self.num_heads
+        pts4 = A._pad_channels(pts, 4)
+        xp = A.linear(pts4, self.point_proj.proj.weight, self.point_proj.proj.bias, cin=3)            # :253
+        pos = self.pos_embed.detach().expand(B, -1, -1).contiguous()
+        xl = A.linear(lat, self.latent_proj.weight, self.latent_proj.bias, res1=pos)                # :255,271-272
+        nb = len(self.blocks_attn)
+        scales = list(self.drop_scales) if self.drop_scales is not None else \
+            [self._drop_scale(B, pts.device) for _ in range(2 * nb)]
+
+        def residual(x, branch_in, w, b, scale):
+            if scale is None:
+                return A.linear(branch_in, w, b, res1=x)
+            return A.add_scaled_rows(x, A.linear(branch_in, w, b), scale)
+
+        for i, blk in enumerate(self.blocks_attn):
+            last = i == nb - 1
+            s_attn, s_mlp = scales[2 * i], scales[2 * i + 1]
+            qkv_l = A.linear(A.layer_norm(xl, blk.norm1.weight, blk.norm1.bias), blk.attn.qkv.weight,
+                             blk.attn.qkv.bias)
+            qkv_p = A.linear(A.layer_norm(xp, blk.norm1.weight, blk.norm1.bias), blk.attn.qkv.weight,
+                             blk.attn.qkv.bias)
+            op = A.point_attention(qkv_p, qkv_l, H)                                                  # :44-66
+            xp = residual(xp, op, blk.attn.proj.weight, blk.attn.proj.bias, s_attn)
+            hp = A.gelu(A.linear(A.layer_norm(xp, blk.norm2.weight, blk.norm2.bias), blk.mlp.fc1.weight,
+                                 blk.mlp.fc1.bias))
+            xp = residual(xp, hp, blk.mlp.fc2.weight, blk.mlp.fc2.bias, s_mlp)
+            if not last:                                                                             # :67-76
+                ol = A.attention(qkv_l, H)
+                xl = residual(xl, ol, blk.attn.proj.weight, blk.attn.proj.bias, s_attn)
+                hl = A.gelu(A.linear(A.layer_norm(xl, blk.norm2.weight, blk.norm2.bias), blk.mlp.fc1.weight,
+                                     blk.mlp.fc1.bias))
+                xl = residual(xl, hl, blk.mlp.fc2.weight, blk.mlp.fc2.bias, s_mlp)
+        feat = A.layer_norm(xp, self.norm.weight, self.norm.bias)                                    # :279
+        # MLPBlocks (:168-184): inputs = cat([xyz, feat]); skip layers see cat([x, inputs]) / sqrt(2).
+        # The concatenations become sums of column-range products of the same weight matrix.
+        C = feat.shape[-1]
+        layers = self.impl_mlp.layers
+        r2 = 0.7071067811865476
+        x = None
+        for l, lin in enumerate(layers):
+            if l == 0:
+                y = A.linear(pts4, lin.weight, None, cin0=0, cin=3)
+                y = A.linear(feat, lin.weight, lin.bias, res1=y, cin0=3, cin=C)
+            elif l in self.skip_in:
+                y = A.linear(pts4, lin.weight, None, in_scale=r2, cin0=C, cin=3)
+                y = A.linear(feat, lin.weight, None, in_scale=r2, res1=y, cin0=C + 3, cin=C)
+                y = A.linear(x, lin.weight, lin.bias, in_scale=r2, res1=y, cin0=0, cin=C)
+            else:
+                y = A.linear(x, lin.weight, lin.bias)
+            x = A.softplus(y, 100.0) if l < len(layers) - 1 else y
+        return x.squeeze(-1)

@@ -1,0 +1,449 @@
+"""torch.autograd bindings of the HIP training kernels (include/zeroshape_hip.h, "Training").
+
+Every op here is a torch.autograd.Function whose forward AND backward are launches of
+libzeroshape_hip.so; torch supplies the tape, the tensor memory and the stream, nothing else.
+Activations are fp32 channels-last ([B,H,W,C]; token matrices [B,L,C]), parameters stay in the
+reference's torch layout ([Cout,Cin,kh,kw] / [Cout,Cin]) and are re-packed on the GPU when they
+change (zs_pack_conv_weight), so optimiser steps need no host work.
+
+Reference behaviour reproduced: what torch.autograd gives train.py for Graph.forward(training=True)
+(model/compute_graph/graph_shape.py:115-204) and Loss.shape_loss (utils/loss.py:18-28).
+"""
+import torch
+
+from .. import _lib
+
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_CLAMP1, ACT_SOFTPLUS = 0, 1, 2, 3, 4
+_CONV_IN_RELU, _CONV_IN_DILATE2 = 1, 8
+
+# Bumped whenever parameters are updated through raw pointers (the fused optimiser): tensor
+# ._version does not see those writes, so every pack cache also keys on this counter.
+GENERATION = [0]
+
+
+def bump_generation():
+    GENERATION[0] += 1
+
+
+def _stream(t):
+    return _lib.current_stream_ptr(t.device)
+
+
+def _f32c(t, what):
+    if not (t.is_cuda and t.dtype == torch.float32):
+        raise ValueError("%s: fp32 GPU tensor required (zeroshape_amd has no CPU path)" % what)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---- scratch buffers (grow-only, one per device and purpose; launches on one stream serialise) ----
+_SCRATCH = {}
+
+
+def scratch(device, name, nbytes):
+    key = (str(device), name)
+    n = (int(nbytes) + 3) // 4
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(max(n, 1), dtype=torch.float32, device=device)
+        _SCRATCH[key] = buf
+    return buf
+
+
+def _ceil4(n):
+    return (n + 3) // 4 * 4
+
+
+# ---- per-parameter memo of derived device tensors (packed operands, standardised weights) ----
+_MEMO = {}
+
+
+def _memo(owner, subkey, make):
+    """Value of make() cached on `owner` (a Parameter) until its storage, version or the optimiser
+    generation changes."""
+    stamp = (owner.data_ptr(), owner._version, GENERATION[0], tuple(owner.shape))
+    slot = _MEMO.get(id(owner))
+    if slot is None or slot[0] != stamp or slot[2]() is not owner:
+        import weakref
+        slot = (stamp, {}, weakref.ref(owner, lambda _r, k=id(owner): _MEMO.pop(k, None)))
+        _MEMO[id(owner)] = slot
+    if subkey not in slot[1]:
+        slot[1][subkey] = make()
+    return slot[1][subkey]
+
+
+def clear_pack_cache():
+    _MEMO.clear()
+
+
+def standardize(weight, eps):
+    """timm StdConv2d weight standardisation of a Parameter (cached per weight value)."""
+    def make():
+        lib = _lib.load()
+        w = weight.detach()
+        out = torch.empty_like(w)
+        with torch.cuda.device(w.device):
+            _lib.check(lib.zs_standardize_weight(_lib.ptr(w), _lib.ptr(out), w.shape[0], w[0].numel(), float(eps),
+                                                 _stream(w)), "zs_standardize_weight")
+        return out
+    return _memo(weight, ("std", float(eps)), make)
+
+
+def _pack(weight, cin0, cin, dgrad, std_eps=None):
+    """Packed GEMM operand of `weight` (torch layout [Cout, CinTot(, kh, kw)], optionally
+    standardised first) for the forward product (dgrad=False) or the data gradient."""
+    def make():
+        lib = _lib.load()
+        w = standardize(weight, std_eps) if std_eps is not None else weight.detach()
+        cout, cintot = w.shape[0], w.shape[1]
+        kh, kw = (w.shape[2], w.shape[3]) if w.dim() == 4 else (1, 1)
+        n = lib.zs_conv2d_packed_floats(_ceil4(cout), cin, kh, kw) if dgrad else \
+            lib.zs_conv2d_packed_floats(_ceil4(cin), cout, kh, kw)
+        packed = torch.empty(n, dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            _lib.check(lib.zs_pack_conv_weight(_lib.ptr(w), _lib.ptr(packed), cout, cin, cin0, cintot, kh, kw,
+                                               1 if dgrad else 0, _stream(w)), "zs_pack_conv_weight")
+        return packed
+    return _memo(weight, ("pack", cin0, cin, bool(dgrad), std_eps), make)
+
+
+def _out_size(n, k, stride, padding):
+    if padding == "same":
+        out = -(-n // stride)
+        return out, max((out - 1) * stride + k - n, 0) // 2
+    return (n + 2 * padding - k) // stride + 1, padding
+
+
+def _conv_launch(x, packed, shift, res1, res2, out, kh, kw, stride, pt, pl, flags, in_scale, in_shift, act):
+    lib = _lib.load()
+    B, H, W, C = x.shape
+    _, Ho, Wo, Co = out.shape
+    with torch.cuda.device(x.device):
+        _lib.check(lib.zs_conv2d_nhwc(_lib.ptr(x), _lib.ptr(packed), None, _lib.ptr(shift), _lib.ptr(res1),
+                                      _lib.ptr(res2), _lib.ptr(out), B, H, W, C, Ho, Wo, Co, kh, kw, stride, pt, pl,
+                                      flags, float(in_scale), float(in_shift), act, _stream(x)), "zs_conv2d_nhwc")
+
+
+def column_sum(x2d, scale=1.0):
+    """[rows, C] -> [C]."""
+    lib = _lib.load()
+    rows, C = x2d.shape
+    out = torch.empty(C, dtype=torch.float32, device=x2d.device)
+    ws = scratch(x2d.device, "colsum", lib.zs_column_sum_workspace_bytes(rows, C))
+    with torch.cuda.device(x2d.device):
+        _lib.check(lib.zs_column_sum(_lib.ptr(x2d), _lib.ptr(out), rows, C, float(scale), _lib.ptr(ws), _stream(x2d)),
+                   "zs_column_sum")
+    return out
+
+
+def _act_backward(dy, ref, act, beta=0.0):
+    lib = _lib.load()
+    dx = torch.empty_like(dy)
+    with torch.cuda.device(dy.device):
+        _lib.check(lib.zs_act_backward(_lib.ptr(dy), _lib.ptr(ref), _lib.ptr(dx), dy.numel(), act, float(beta),
+                                       _stream(dy)), "zs_act_backward")
+    return dx
+
+
+def _pad_channels(x, cpad):
+    lib = _lib.load()
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty(*x.shape[:-1], cpad, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.zs_nchw_to_nhwc(_lib.ptr(x), None, _lib.ptr(y), rows, C, 1, cpad, _stream(x)), "zs_nchw_to_nhwc")
+    return y
+
+
+class _Conv(torch.autograd.Function):
+    """y = act(conv(T(x), W[:, cin0:cin0+cin]) + bias + res1 + res2), T = input ReLU / affine."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, res1, res2, cfg):
+        x = _f32c(x, "conv input")
+        stride, padding, act = cfg["stride"], cfg["padding"], cfg["act"]
+        assert act in (ACT_NONE, ACT_RELU, ACT_RELU_CLAMP1), "fuse only ReLU-type activations when training"
+        B, H, W, Cx = x.shape
+        cout = weight.shape[0]
+        kh, kw = (weight.shape[2], weight.shape[3]) if weight.dim() == 4 else (1, 1)
+        cin0 = cfg.get("cin0", 0)
+        cin = cfg.get("cin") or weight.shape[1]
+        assert Cx == _ceil4(cin), "input has %d channels, layer expects %d (padded to 4)" % (Cx, cin)
+        std_eps = cfg.get("std_eps")
+        Ho, pt = _out_size(H, kh, stride, padding)
+        Wo, pl = _out_size(W, kw, stride, padding)
+        out = torch.empty(B, Ho, Wo, cout, dtype=torch.float32, device=x.device)
+        flags = _CONV_IN_RELU if cfg.get("in_relu") else 0
+        _conv_launch(x, _pack(weight, cin0, cin, False, std_eps), None if bias is None else bias.detach(),
+                     None if res1 is None else _f32c(res1, "res1"), None if res2 is None else _f32c(res2, "res2"),
+                     out, kh, kw, stride, pt, pl, flags, cfg.get("in_scale", 1.0), cfg.get("in_shift", 0.0), act)
+        ctx.cfg = dict(cfg, pt=pt, pl=pl, kh=kh, kw=kw, cin0=cin0, cin=cin)
+        ctx.has = (bias is not None, res1 is not None, res2 is not None)
+        ctx.save_for_backward(x, weight, out if act != ACT_NONE else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, weight, out = ctx.saved_tensors
+        cfg = ctx.cfg
+        kh, kw, stride, pt, pl = cfg["kh"], cfg["kw"], cfg["stride"], cfg["pt"], cfg["pl"]
+        cin0, cin, act = cfg["cin0"], cfg["cin"], cfg["act"]
+        in_relu, in_scale, in_shift = bool(cfg.get("in_relu")), cfg.get("in_scale", 1.0), cfg.get("in_shift", 0.0)
+        std_eps = cfg.get("std_eps")
+        g = _f32c(dy, "conv grad")
+        if act != ACT_NONE:
+            g = _act_backward(g, out, act)
+        B, Ho, Wo, cout = g.shape
+        _, H, W, Cx = x.shape
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        db = column_sum(g.view(-1, cout)) if (ctx.has[0] and need_b) else None
+        gp = g if cout % 4 == 0 else _pad_channels(g, _ceil4(cout))
+        dw = None
+        if need_w:
+            sub = cin != weight.shape[1]
+            dw = torch.zeros_like(weight) if sub else torch.empty_like(weight)
+            ws = scratch(x.device, "wgrad", lib.zs_conv2d_wgrad_workspace_bytes(B, Ho, Wo, Cx, cout, kh, kw))
+            flags = _CONV_IN_RELU if in_relu else 0
+            with torch.cuda.device(x.device):
+                _lib.check(lib.zs_conv2d_wgrad(_lib.ptr(x), _lib.ptr(gp), _lib.ptr(dw), _lib.ptr(ws), B, H, W, Cx, Ho,
+                                               Wo, cout, kh, kw, stride, pt, pl, flags, float(in_scale),
+                                               float(in_shift), cin, cin0, weight.shape[1], 0, _stream(x)),
+                           "zs_conv2d_wgrad")
+            if std_eps is not None:
+                dws = torch.empty_like(weight)
+                with torch.cuda.device(x.device):
+                    _lib.check(lib.zs_standardize_weight_bwd(_lib.ptr(weight.detach()), _lib.ptr(dw), _lib.ptr(dws),
+                                                             weight.shape[0], weight[0].numel(), float(std_eps),
+                                                             _stream(x)), "zs_standardize_weight_bwd")
+                dw = dws
+        dx = None
+        if need_x:
+            assert cin % 4 == 0, "data gradient needs Cin % 4 == 0"
+            assert stride in (1, 2), "data gradient: stride 1 or 2"
+            dx = torch.empty(B, H, W, cin, dtype=torch.float32, device=x.device)
+            flags = _CONV_IN_DILATE2 if stride == 2 else 0
+            _conv_launch(gp, _pack(weight, cin0, cin, True, std_eps), None, None, None, dx, kh, kw, 1, kh - 1 - pt, kw - 1 - pl,
+                         flags, in_scale, 0.0, ACT_NONE)
+            if in_relu:
+                dx = _act_backward(dx, x, ACT_RELU)
+        return dx, dw, db, (g if ctx.has[1] else None), (g if ctx.has[2] else None), None
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, in_relu=False, in_scale=1.0, in_shift=0.0,
+           res1=None, res2=None, std_eps=None, cin0=0, cin=None):
+    cfg = dict(stride=stride, padding=padding, act=act, in_relu=in_relu, in_scale=in_scale, in_shift=in_shift,
+               std_eps=std_eps, cin0=cin0, cin=cin)
+    return _Conv.apply(x, weight, bias, res1, res2, cfg)
+
+
+def linear(x, weight, bias=None, act=ACT_NONE, res1=None, in_scale=1.0, cin0=0, cin=None):
+    """x [..., CinP] -> [..., Cout]."""
+    lead = x.shape[:-1]
+    n = 1
+    for d in lead:
+        n *= d
+    y = conv2d(x.reshape(1, 1, n, x.shape[-1]), weight, bias, act=act, in_scale=in_scale, cin0=cin0, cin=cin,
+               res1=None if res1 is None else res1.reshape(1, 1, n, weight.shape[0]))
+    return y.view(*lead, weight.shape[0])
+
+
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act, beta):
+        lib = _lib.load()
+        x = _f32c(x, "activation input")
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.zs_act_forward(_lib.ptr(x), _lib.ptr(y), x.numel(), act, float(beta), _stream(x)),
+                       "zs_act_forward")
+        ctx.act, ctx.beta = act, beta
+        ctx.save_for_backward(y if act in (ACT_RELU, ACT_RELU_CLAMP1) else x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ref,) = ctx.saved_tensors
+        return _act_backward(_f32c(dy, "activation grad"), ref, ctx.act, ctx.beta), None, None
+
+
+def gelu(x):
+    return _Act.apply(x, ACT_GELU, 0.0)
+
+
+def softplus(x, beta=100.0):
+    return _Act.apply(x, ACT_SOFTPLUS, beta)
+
+
+def relu(x):
+    return _Act.apply(x, ACT_RELU, 0.0)
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        lib = _lib.load()
+        x = _f32c(x, "layer_norm input")
+        C = x.shape[-1]
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.zs_layer_norm(_lib.ptr(x), _lib.ptr(gamma.detach()), _lib.ptr(beta.detach()), _lib.ptr(y),
+                                         x.numel() // C, C, float(eps), _stream(x)), "zs_layer_norm")
+        ctx.eps = eps
+        ctx.save_for_backward(x, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, gamma = ctx.saved_tensors
+        dy = _f32c(dy, "layer_norm grad")
+        C = x.shape[-1]
+        rows = x.numel() // C
+        dx = torch.empty_like(x)
+        dg = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = scratch(x.device, "ln_bwd", lib.zs_layer_norm_bwd_workspace_bytes(rows, C))
+        with torch.cuda.device(x.device):
+            _lib.check(lib.zs_layer_norm_bwd(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(gamma.detach()), _lib.ptr(dx),
+                                             _lib.ptr(dg), _lib.ptr(db), rows, C, float(ctx.eps), _lib.ptr(ws),
+                                             _stream(x)), "zs_layer_norm_bwd")
+        return dx, dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-6):
+    return _LayerNorm.apply(x, gamma, beta, eps)
+
+
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        lib = _lib.load()
+        qkv = _f32c(qkv, "attention input")
+        B, L, C3 = qkv.shape
+        C = C3 // 3
+        out = torch.empty(B, L, C, dtype=torch.float32, device=qkv.device)
+        with torch.cuda.device(qkv.device):
+            _lib.check(lib.zs_attention(_lib.ptr(qkv), _lib.ptr(out), B, L, heads, C // heads, _stream(qkv)),
+                       "zs_attention")
+        ctx.heads = heads
+        ctx.save_for_backward(qkv)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        (qkv,) = ctx.saved_tensors
+        dout = _f32c(dout, "attention grad")
+        B, L, C3 = qkv.shape
+        heads = ctx.heads
+        dqkv = torch.empty_like(qkv)
+        ws = scratch(qkv.device, "attn_bwd", lib.zs_attention_bwd_workspace_bytes(B, L, heads))
+        with torch.cuda.device(qkv.device):
+            _lib.check(lib.zs_attention_bwd(_lib.ptr(qkv), _lib.ptr(dout), _lib.ptr(dqkv), _lib.ptr(ws), B, L, heads,
+                                            C3 // 3 // heads, _stream(qkv)), "zs_attention_bwd")
+        return dqkv, None
+
+
+def attention(qkv, heads):
+    return _Attention.apply(qkv, heads)
+
+
+class _PointAttention(torch.autograd.Function):
+    """ImplFuncAttention's point rows (implicit.py:44-66): softmax over the latent keys + self."""
+
+    @staticmethod
+    def forward(ctx, qkv_p, qkv_l, heads):
+        lib = _lib.load()
+        qkv_p, qkv_l = _f32c(qkv_p, "point qkv"), _f32c(qkv_l, "latent qkv")
+        B, M, C3 = qkv_p.shape
+        Ll, C = qkv_l.shape[1], C3 // 3
+        out = torch.empty(B, M, C, dtype=torch.float32, device=qkv_p.device)
+        with torch.cuda.device(qkv_p.device):
+            _lib.check(lib.zs_point_attention(_lib.ptr(qkv_p), _lib.ptr(qkv_l), _lib.ptr(out), B, M, Ll, heads,
+                                              C // heads, _stream(qkv_p)), "zs_point_attention")
+        ctx.heads = heads
+        ctx.save_for_backward(qkv_p, qkv_l)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        qkv_p, qkv_l = ctx.saved_tensors
+        dout = _f32c(dout, "point attention grad")
+        B, M, C3 = qkv_p.shape
+        Ll, C, heads = qkv_l.shape[1], C3 // 3, ctx.heads
+        dp, dl = torch.empty_like(qkv_p), torch.empty_like(qkv_l)
+        ws = scratch(qkv_p.device, "pa_bwd", lib.zs_point_attention_bwd_workspace_bytes(B, M, Ll, heads))
+        with torch.cuda.device(qkv_p.device):
+            _lib.check(lib.zs_point_attention_bwd(_lib.ptr(qkv_p), _lib.ptr(qkv_l), _lib.ptr(dout), _lib.ptr(dp),
+                                                  _lib.ptr(dl), 0, _lib.ptr(ws), B, M, Ll, heads, C // heads,
+                                                  _stream(qkv_p)), "zs_point_attention_bwd")
+        return dp, dl, None
+
+
+def point_attention(qkv_p, qkv_l, heads):
+    return _PointAttention.apply(qkv_p, qkv_l, heads)
+
+
+def _scaled_rows(x, branch, scale):
+    lib = _lib.load()
+    B = branch.shape[0]
+    y = torch.empty_like(branch)
+    with torch.cuda.device(branch.device):
+        _lib.check(lib.zs_add_scaled_rows(_lib.ptr(x), _lib.ptr(branch), _lib.ptr(scale), _lib.ptr(y), B,
+                                          branch.numel() // B, _stream(branch)), "zs_add_scaled_rows")
+    return y
+
+
+class _AddScaledRows(torch.autograd.Function):
+    """x + scale[b] * branch: residual connection under per-sample stochastic depth (timm DropPath)."""
+
+    @staticmethod
+    def forward(ctx, x, branch, scale):
+        x, branch = _f32c(x, "residual"), _f32c(branch, "branch")
+        ctx.save_for_backward(scale)
+        return _scaled_rows(x, branch, scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (scale,) = ctx.saved_tensors
+        dy = _f32c(dy, "residual grad")
+        return dy, _scaled_rows(None, dy, scale), None
+
+
+def add_scaled_rows(x, branch, scale):
+    return _AddScaledRows.apply(x, branch, _f32c(scale, "drop-path scale"))
+
+
+class _BCELogits(torch.autograd.Function):
+    """Loss.shape_loss (utils/loss.py:18-28): mean of w * BCEWithLogits(pred, sdf < 0)."""
+
+    @staticmethod
+    def forward(ctx, logits, sdf, thres, weight):
+        lib = _lib.load()
+        logits, sdf = _f32c(logits, "logits"), _f32c(sdf, "sdf")
+        n = logits.numel()
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        ws = scratch(logits.device, "bce", lib.zs_bce_logits_workspace_bytes(n))
+        with torch.cuda.device(logits.device):
+            _lib.check(lib.zs_bce_logits(_lib.ptr(logits), _lib.ptr(sdf), n, float(thres), float(weight),
+                                         _lib.ptr(loss), _lib.ptr(ws), _stream(logits)), "zs_bce_logits")
+        ctx.thres, ctx.weight = thres, weight
+        ctx.save_for_backward(logits, sdf)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        lib = _lib.load()
+        logits, sdf = ctx.saved_tensors
+        dloss = _f32c(dloss, "loss grad")
+        dx = torch.empty_like(logits)
+        with torch.cuda.device(logits.device):
+            _lib.check(lib.zs_bce_logits_bwd(_lib.ptr(logits), _lib.ptr(sdf), logits.numel(), float(ctx.thres),
+                                             float(ctx.weight), _lib.ptr(dloss), _lib.ptr(dx), _stream(logits)),
+                       "zs_bce_logits_bwd")
+        return dx, None, None, None
+
+
+def bce_logits(logits, sdf, impt_thres=0.01, impt_weight=1.0):
+    return _BCELogits.apply(logits, sdf, impt_thres, impt_weight)
