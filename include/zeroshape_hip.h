@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 10
+#define ZS_ABI_VERSION 11
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -388,6 +388,57 @@ int zs_copy_multi(const zs_tensor_entry *table, const int *chunk_tensor, const u
                   int n_chunks, float scale, void *stream);
 int zs_sumsq_multi(const zs_tensor_entry *table, const int *chunk_tensor, const unsigned long long *chunk_start,
                    int n_chunks, float *partial, float *sumsq, void *stream);
+
+/* Encoder training (BatchNorm / GroupNorm / pooling / resampling / geometry backward).
+ *   zs_batch_norm_train : nn.BatchNorm2d in training mode over [rows][C] (rows = B*H*W): batch
+ *       mean / biased variance -> y = (x-mean)*rstd*gamma+beta (+residual) (ReLU if relu);
+ *       running_mean / running_var (may both be NULL) updated with `momentum` and the unbiased
+ *       variance like torch; save_mean / save_rstd [C] feed the backward.
+ *   zs_batch_norm_bwd   : y_relu = the forward output when ReLU was fused (masks dy), else NULL;
+ *       dresidual (may be NULL) = the masked dy.
+ *   zs_group_norm_bwd   : backward of zs_group_norm_nhwc (statistics recomputed from x).
+ *   zs_max_pool_bwd_nhwc / zs_global_mean_bwd_nhwc / zs_upsample2x_bwd_nhwc: adjoints of the
+ *       forward layers in gather form (no atomics); max-pool routes to the first maximum of a
+ *       window in row-major order, as torch does.
+ *   zs_nhwc_to_nchw_masked : y[b][c][p] = x[b][p][c] * mask[b][p], c < C <= Cpad.
+ *   zs_seen_surface_bwd : backward of zs_seen_surface for Ho = H, Wo = W (the ResNet coordinate
+ *       encoder): d_seen_points [B][HW][3] and/or d_coord_dsp [B][3][H][W] (either may be NULL)
+ *       -> d_depth [B][HW], d_intr [B][3][3], through the masked mean and the max-radius scale
+ *       (utils/camera.py:52-108 as torch.autograd differentiates them).
+ *   zs_intr_param2mtx_bwd : d_intr -> d_params [B][3] (graph_shape.py:89-113). */
+size_t zs_batch_norm_workspace_bytes(int rows, int C);
+int zs_batch_norm_train(const float *x, const float *gamma, const float *beta, const float *residual, float *y,
+                        float *running_mean, float *running_var, float *save_mean, float *save_rstd, int rows, int C,
+                        float eps, float momentum, int relu, void *workspace, void *stream);
+int zs_batch_norm_bwd(const float *x, const float *dy, const float *y_relu, const float *gamma, const float *save_mean,
+                      const float *save_rstd, float *dx, float *dresidual, float *dgamma, float *dbeta, int rows, int C,
+                      void *workspace, void *stream);
+size_t zs_group_norm_bwd_workspace_bytes(int batch, int C);
+int zs_group_norm_bwd(const float *x, const float *dy, const float *y_relu, const float *gamma, float *dx,
+                      float *dresidual, float *dgamma, float *dbeta, int batch, int HW, int C, int groups, float eps,
+                      void *workspace, void *stream);
+int zs_max_pool_bwd_nhwc(const float *x, const float *dy, float *dx, int batch, int Hin, int Win, int C, int Hout,
+                         int Wout, int k, int stride, int pad_t, int pad_l, void *stream);
+int zs_global_mean_bwd_nhwc(const float *dy, float *dx, int batch, int HW, int C, void *stream);
+int zs_upsample2x_bwd_nhwc(const float *dy, float *dx, int batch, int Hin, int Win, int C, void *stream);
+int zs_nhwc_to_nchw_masked(const float *x, const float *mask, float *y, int batch, int C, int HW, int Cpad,
+                           void *stream);
+int zs_seen_surface_bwd(const float *depth, const float *intr, const float *mask, const float *mean, const float *scale,
+                        const float *d_seen_points, const float *d_coord_dsp, int batch, int H, int W, float *d_depth,
+                        float *d_intr, void *stream);
+int zs_intr_param2mtx_bwd(const float *params, const float *d_intr, int batch, int H, int W, float *d_params,
+                          void *stream);
+/* Bilinear resize (align_corners=False) of a channels-last grid [Hi][Wi][C] -> [Ho][Wo][C]
+ * (vit.py:103-120 _resize_pos_embed); backward != 0: x is the gradient of the [Ho][Wo][C] output
+ * and y receives the gradient of the [Hi][Wi][C] input.  zs_readout_concat_bwd: adjoint of
+ * zs_readout_concat (dout [B][n][2C] -> dtokens [B][n+1][C]). */
+/* graph_shape.py:163-173: out[b][i] = ((R_b p + t_b) - mean_b) / scale_b with pose [B][3][4] = [R|t]:
+ * the ground-truth query points in the normalised frame of the (GT) seen surface. */
+int zs_transform_points(const float *points, const float *pose, const float *mean, const float *scale, float *out,
+                        int batch, int n, void *stream);
+int zs_resize_bilinear_nhwc(const float *x, float *y, int Hi, int Wi, int Ho, int Wo, int C, int backward,
+                            void *stream);
+int zs_readout_concat_bwd(const float *dout, float *dtokens, int batch, int n, int C, void *stream);
 
 #ifdef __cplusplus
 }

@@ -80,3 +80,9 @@ def seeded_sd(decoder_golden):
 def decoder_train_golden():
     import numpy as np
     return dict(np.load(os.path.join(GOLDEN, "decoder_train_golden.npz")))
+
+
+@pytest.fixture(scope="session")
+def graph_train_golden():
+    import numpy as np
+    return dict(np.load(os.path.join(GOLDEN, "graph_train_golden.npz")))

@@ -99,9 +99,24 @@ SIGNATURES = {
                                 _c_void_p, _c_void_p]),
     "zs_copy_multi": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_float, _c_void_p]),
     "zs_sumsq_multi": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "zs_batch_norm_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
+    "zs_batch_norm_train": (_c_int, [_c_void_p] * 9 + [_c_int, _c_int, _c_float, _c_float, _c_int, _c_void_p,
+                                                       _c_void_p]),
+    "zs_batch_norm_bwd": (_c_int, [_c_void_p] * 10 + [_c_int, _c_int, _c_void_p, _c_void_p]),
+    "zs_group_norm_bwd_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
+    "zs_group_norm_bwd": (_c_int, [_c_void_p] * 8 + [_c_int, _c_int, _c_int, _c_int, _c_float, _c_void_p, _c_void_p]),
+    "zs_max_pool_bwd_nhwc": (_c_int, [_c_void_p] * 3 + [_c_int] * 10 + [_c_void_p]),
+    "zs_global_mean_bwd_nhwc": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
+    "zs_upsample2x_bwd_nhwc": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
+    "zs_nhwc_to_nchw_masked": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
+    "zs_seen_surface_bwd": (_c_int, [_c_void_p] * 7 + [_c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "zs_intr_param2mtx_bwd": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "zs_transform_points": (_c_int, [_c_void_p] * 5 + [_c_int, _c_int, _c_void_p]),
+    "zs_resize_bilinear_nhwc": (_c_int, [_c_void_p, _c_void_p] + [_c_int] * 6 + [_c_void_p]),
+    "zs_readout_concat_bwd": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
 }
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 _lib = None
 
 

@@ -1,0 +1,476 @@
+// Training-side normalisation / pooling / resampling kernels (fp32, channels-last):
+//   BatchNorm2d in training mode (batch statistics, running-stat update) forward + backward
+//     - torchvision ResNet-50 and utils/layers.py:76-100 Bottleneck_Conv under graph.train()
+//   GroupNorm backward            - timm ResNetV2 (GroupNormAct) inside DPT-hybrid
+//   3x3/s2 max-pool backward, global-mean backward, x2 bilinear (align_corners=True) backward
+//   NHWC -> NCHW with a per-pixel mask (adjoint of zs_nchw_to_nhwc)
+// Reductions are two-stage with double accumulators and a fixed order: deterministic.
+#include "zs_common.h"
+#include "../../include/zeroshape_hip.h"
+
+#include <math.h>
+#include <stdint.h>
+
+namespace {
+
+inline hipStream_t S(void *s) { return static_cast<hipStream_t>(s); }
+inline unsigned blocks_for(size_t total) { return (unsigned)((total + 255) / 256); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int BLOCK>
+__device__ __forceinline__ float block_sum(float v, float *lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    float r = lds[0];
+#pragma unroll
+    for (int w = 1; w < BLOCK / 64; w++) r += lds[w];
+    return r;
+}
+
+// ---------------- BatchNorm (training) ----------------
+// column partials over row chunks: MODE 0: (sum x, sum x^2); MODE 1: (sum g, sum g*xhat) with
+// g = dy (masked by y > 0 when y is given), xhat = (x - mean) * rstd
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                         const float *__restrict__ y, const float *__restrict__ mean,
+                                                         const float *__restrict__ rstd, double *__restrict__ partial,
+                                                         int rows, int C, int rows_per_chunk) {
+    __shared__ double lds[2][4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6, c = blockIdx.x * 64 + cx;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        const float mu = MODE ? mean[c] : 0.f, rs = MODE ? rstd[c] : 0.f;
+        for (int r = r0 + ry; r < r1; r += 4) {
+            const size_t o = (size_t)r * C + c;
+            if (MODE == 0) {
+                const float v = x[o];
+                a += v;
+                b += (double)v * v;
+            } else {
+                float g = dy[o];
+                if (y && !(y[o] > 0.f)) g = 0.f;
+                a += g;
+                b += (double)g * ((x[o] - mu) * rs);
+            }
+        }
+    }
+    lds[0][ry][cx] = a;
+    lds[1][ry][cx] = b;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        partial[((size_t)blockIdx.y * 2 + 0) * C + c] = (lds[0][0][cx] + lds[0][1][cx]) + (lds[0][2][cx] + lds[0][3][cx]);
+        partial[((size_t)blockIdx.y * 2 + 1) * C + c] = (lds[1][0][cx] + lds[1][1][cx]) + (lds[1][2][cx] + lds[1][3][cx]);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const double *__restrict__ partial, int chunks, int C, int rows,
+                                                       float eps, float momentum, float *__restrict__ running_mean,
+                                                       float *__restrict__ running_var, float *__restrict__ save_mean,
+                                                       float *__restrict__ save_rstd) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < chunks; k++) {
+        s += partial[((size_t)k * 2 + 0) * C + c];
+        q += partial[((size_t)k * 2 + 1) * C + c];
+    }
+    const double mean = s / rows;
+    double var = q / rows - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    save_mean[c] = (float)mean;
+    save_rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {      // torch: running = (1 - m) * running + m * batch, unbiased variance
+        const double unbiased = rows > 1 ? var * rows / (rows - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta, const float *__restrict__ res,
+                                                       const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                       float *__restrict__ y, size_t total, int C, int relu) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = i % C;
+    float v = (x[i] - mean[c]) * rstd[c] * gamma[c] + beta[c];
+    if (res) v += res[i];
+    y[i] = relu ? fmaxf(v, 0.f) : v;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const double *__restrict__ partial, int chunks, int C,
+                                                            float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < chunks; k++) {
+        s += partial[((size_t)k * 2 + 0) * C + c];
+        q += partial[((size_t)k * 2 + 1) * C + c];
+    }
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)q;
+}
+
+// dx = gamma * rstd * (g - dbeta/N - xhat * dgamma/N); dres = g
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                           const float *__restrict__ y, const float *__restrict__ gamma,
+                                                           const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                           const float *__restrict__ dgamma,
+                                                           const float *__restrict__ dbeta, float *__restrict__ dx,
+                                                           float *__restrict__ dres, size_t total, int C, float inv_n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = i % C;
+    float g = dy[i];
+    if (y && !(y[i] > 0.f)) g = 0.f;
+    const float xh = (x[i] - mean[c]) * rstd[c];
+    dx[i] = gamma[c] * rstd[c] * (g - dbeta[c] * inv_n - xh * dgamma[c] * inv_n);
+    if (dres) dres[i] = g;
+}
+
+// ---------------- GroupNorm backward: one workgroup per (sample, group) ----------------
+constexpr int GN_BLOCK = 1024;
+__global__ __launch_bounds__(GN_BLOCK) void group_norm_bwd_kernel(
+    const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ y,
+    const float *__restrict__ gamma, float *__restrict__ dx, float *__restrict__ dres,
+    float *__restrict__ dgamma_part, float *__restrict__ dbeta_part, int HW, int C, int groups, float eps) {
+    __shared__ float lds[GN_BLOCK / 64];
+    __shared__ float col[2][64][17];                  // per-channel sums: up to 64 channels per group
+    const int b = blockIdx.x / groups, g = blockIdx.x % groups, cg = C / groups, n = HW * cg;
+    const size_t base = (size_t)b * HW * C + (size_t)g * cg;
+    auto at = [&](int e) -> size_t { return base + (size_t)(e / cg) * C + (e % cg); };
+    auto grad = [&](size_t o) -> float { return (y && !(y[o] > 0.f)) ? 0.f : dy[o]; };
+    float s = 0.f;
+    for (int e = threadIdx.x; e < n; e += GN_BLOCK) s += x[at(e)];
+    const float mean = block_sum<GN_BLOCK>(s, lds) / n;
+    float q = 0.f;
+    for (int e = threadIdx.x; e < n; e += GN_BLOCK) { const float d = x[at(e)] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(block_sum<GN_BLOCK>(q, lds) / n + eps);
+    float sg = 0.f, sgx = 0.f;
+    for (int e = threadIdx.x; e < n; e += GN_BLOCK) {
+        const size_t o = at(e);
+        const float gg = grad(o) * gamma[g * cg + e % cg], xh = (x[o] - mean) * rstd;
+        sg += gg;
+        sgx += gg * xh;
+    }
+    const float mg = block_sum<GN_BLOCK>(sg, lds) / n, mgx = block_sum<GN_BLOCK>(sgx, lds) / n;
+    for (int e = threadIdx.x; e < n; e += GN_BLOCK) {
+        const size_t o = at(e);
+        const float gr = grad(o), xh = (x[o] - mean) * rstd;
+        dx[o] = rstd * (gr * gamma[g * cg + e % cg] - mg - xh * mgx);
+        if (dres) dres[o] = gr;
+    }
+    // per-channel dgamma / dbeta of this sample: 16 row-lanes x cg channels, fixed-order sum
+    const int ch = threadIdx.x % 64, lane16 = threadIdx.x / 64;          // 16 groups of 64 threads
+    float a = 0.f, c2 = 0.f;
+    if (ch < cg)
+        for (int p = lane16; p < HW; p += 16) {
+            const size_t o = base + (size_t)p * C + ch;
+            const float gr = grad(o);
+            a += gr * (x[o] - mean) * rstd;
+            c2 += gr;
+        }
+    __syncthreads();
+    col[0][ch][lane16] = a;
+    col[1][ch][lane16] = c2;
+    __syncthreads();
+    if (threadIdx.x < cg) {
+        float ta = 0.f, tb = 0.f;
+        for (int k = 0; k < 16; k++) { ta += col[0][threadIdx.x][k]; tb += col[1][threadIdx.x][k]; }
+        dgamma_part[(size_t)b * C + g * cg + threadIdx.x] = ta;
+        dbeta_part[(size_t)b * C + g * cg + threadIdx.x] = tb;
+    }
+}
+
+__global__ __launch_bounds__(256) void sum_rows_kernel(const float *__restrict__ part, float *__restrict__ out, int rows,
+                                                       int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; r++) s += part[(size_t)r * C + c];
+    out[c] = s;
+}
+
+// ---------------- pooling / resampling backward (gather form, no atomics) ----------------
+// max pool: an input pixel receives dy of every window whose FIRST maximum (row-major scan, as
+// torch's max_pool2d picks it) it is
+__global__ __launch_bounds__(256) void max_pool_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                           float *__restrict__ dx, int B, int Hin, int Win, int C,
+                                                           int Hout, int Wout, int k, int stride, int pad_t, int pad_l) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)B * Hin * Win * C;
+    if (i >= total) return;
+    const int c = i % C, ix = (i / C) % Win, iy = (i / C / Win) % Hin, b = i / C / Win / Hin;
+    const float *X = x + (size_t)b * Hin * Win * C + c;
+    float acc = 0.f;
+    // windows (oy, ox) with oy*stride - pad_t <= iy < oy*stride - pad_t + k
+    const int oy_lo = max(0, (iy + pad_t - k + stride) / stride), oy_hi = min(Hout - 1, (iy + pad_t) / stride);
+    const int ox_lo = max(0, (ix + pad_l - k + stride) / stride), ox_hi = min(Wout - 1, (ix + pad_l) / stride);
+    for (int oy = oy_lo; oy <= oy_hi; oy++)
+        for (int ox = ox_lo; ox <= ox_hi; ox++) {
+            float m = -INFINITY;
+            int my = -1, mx = -1;
+            for (int ky = 0; ky < k; ky++)
+                for (int kx = 0; kx < k; kx++) {
+                    const int yy = oy * stride - pad_t + ky, xx = ox * stride - pad_l + kx;
+                    if (yy < 0 || yy >= Hin || xx < 0 || xx >= Win) continue;
+                    const float v = X[((size_t)yy * Win + xx) * C];
+                    if (v > m || my < 0) { m = v; my = yy; mx = xx; }
+                }
+            if (my == iy && mx == ix) acc += dy[(((size_t)b * Hout + oy) * Wout + ox) * C + c];
+        }
+    dx[i] = acc;
+}
+
+__global__ __launch_bounds__(256) void global_mean_bwd_kernel(const float *__restrict__ dy, float *__restrict__ dx,
+                                                              int HW, int C, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = i % C;
+    const size_t b = i / C / HW;
+    dx[i] = dy[b * C + c] / HW;
+}
+
+// x2 bilinear, align_corners=True: adjoint by gathering from the (few) outputs that read this input
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float *__restrict__ dy, float *__restrict__ dx, int B,
+                                                             int Hin, int Win, int C) {
+    const int Hout = 2 * Hin, Wout = 2 * Win;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)B * Hin * Win * C;
+    if (i >= total) return;
+    const int c = i % C, ix = (i / C) % Win, iy = (i / C / Win) % Hin, b = i / C / Win / Hin;
+    const float sy = Hout > 1 ? (float)(Hin - 1) / (float)(Hout - 1) : 0.f,
+                sx = Wout > 1 ? (float)(Win - 1) / (float)(Wout - 1) : 0.f;
+    // forward taps of output o: y0 = (int)(sy*o), y1 = y0 + (y0 < Hin-1), weights (1-l, l), l = sy*o - y0
+    auto weight = [](int o, int in, float s, int n) -> float {
+        const float f = s * o;
+        const int i0 = (int)f, i1 = i0 + (i0 < n - 1 ? 1 : 0);
+        const float l = f - i0;
+        float w = 0.f;
+        if (i0 == in) w += 1.f - l;
+        if (i1 == in) w += l;
+        return w;
+    };
+    const int oy_lo = max(0, 2 * iy - 3), oy_hi = min(Hout - 1, 2 * iy + 4);
+    const int ox_lo = max(0, 2 * ix - 3), ox_hi = min(Wout - 1, 2 * ix + 4);
+    const float *G = dy + (size_t)b * Hout * Wout * C + c;
+    float acc = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; oy++) {
+        const float wy = weight(oy, iy, sy, Hin);
+        if (wy == 0.f) continue;
+        for (int ox = ox_lo; ox <= ox_hi; ox++) {
+            const float wx = weight(ox, ix, sx, Win);
+            if (wx != 0.f) acc += wy * wx * G[((size_t)oy * Wout + ox) * C];
+        }
+    }
+    dx[i] = acc;
+}
+
+// NHWC [B][HW][Cpad] -> NCHW [B][C][HW] (first C channels), optionally times mask [B][HW]
+__global__ __launch_bounds__(256) void nhwc_to_nchw_masked_kernel(const float *__restrict__ x,
+                                                                  const float *__restrict__ mask, float *__restrict__ y,
+                                                                  int B, int C, int HW, int Cpad) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)B * HW * C;
+    if (i >= total) return;
+    const int p = i % HW, c = (i / HW) % C, b = i / HW / C;
+    float v = x[((size_t)b * HW + p) * Cpad + c];
+    if (mask) v *= mask[(size_t)b * HW + p];
+    y[i] = v;
+}
+
+// ---- bilinear resize, align_corners=False, channels-last [Hi][Wi][C] -> [Ho][Wo][C] ----
+// (vit.py:103-120 _resize_pos_embed: the ViT position-embedding grid is re-sampled on every forward)
+struct RTap { int i0, i1; float l0, l1; };
+__device__ __forceinline__ RTap resize_tap(int dst, float scale, int in_size) {
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    RTap t;
+    t.i0 = min((int)src, in_size - 1);
+    t.i1 = t.i0 + (t.i0 < in_size - 1 ? 1 : 0);
+    t.l1 = src - (float)t.i0;
+    t.l0 = 1.0f - t.l1;
+    return t;
+}
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float *__restrict__ x, float *__restrict__ y, int Hi,
+                                                              int Wi, int Ho, int Wo, int C) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)Ho * Wo * C;
+    if (i >= total) return;
+    const int c = i % C, ox = (i / C) % Wo, oy = i / C / Wo;
+    const RTap ty = resize_tap(oy, (float)Hi / Ho, Hi), tx = resize_tap(ox, (float)Wi / Wo, Wi);
+    const float *X = x + c;
+    y[i] = ty.l0 * (tx.l0 * X[((size_t)ty.i0 * Wi + tx.i0) * C] + tx.l1 * X[((size_t)ty.i0 * Wi + tx.i1) * C]) +
+           ty.l1 * (tx.l0 * X[((size_t)ty.i1 * Wi + tx.i0) * C] + tx.l1 * X[((size_t)ty.i1 * Wi + tx.i1) * C]);
+}
+__global__ __launch_bounds__(256) void resize_bilinear_bwd_kernel(const float *__restrict__ dy, float *__restrict__ dx,
+                                                                  int Hi, int Wi, int Ho, int Wo, int C) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)Hi * Wi * C;
+    if (i >= total) return;
+    const int c = i % C, ix = (i / C) % Wi, iy = i / C / Wi;
+    float acc = 0.f;
+    for (int oy = 0; oy < Ho; oy++) {
+        const RTap ty = resize_tap(oy, (float)Hi / Ho, Hi);
+        const float wy = (ty.i0 == iy ? ty.l0 : 0.f) + (ty.i1 == iy ? ty.l1 : 0.f);
+        if (wy == 0.f) continue;
+        for (int ox = 0; ox < Wo; ox++) {
+            const RTap tx = resize_tap(ox, (float)Wi / Wo, Wi);
+            const float wx = (tx.i0 == ix ? tx.l0 : 0.f) + (tx.i1 == ix ? tx.l1 : 0.f);
+            if (wx != 0.f) acc += wy * wx * dy[((size_t)oy * Wo + ox) * C + c];
+        }
+    }
+    dx[i] = acc;
+}
+
+// adjoint of zs_readout_concat: dtok[b][1+i][c] = dout[b][i][c]; dtok[b][0][c] = sum_i dout[b][i][C+c]
+__global__ __launch_bounds__(256) void readout_concat_bwd_kernel(const float *__restrict__ dout,
+                                                                 float *__restrict__ dtok, int B, int n, int C) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)B * (n + 1) * C;
+    if (i >= total) return;
+    const int c = i % C, t = (i / C) % (n + 1), b = i / C / (n + 1);
+    const float *G = dout + (size_t)b * n * 2 * C;
+    float v;
+    if (t > 0) v = G[(size_t)(t - 1) * 2 * C + c];
+    else {
+        v = 0.f;
+        for (int k = 0; k < n; k++) v += G[(size_t)k * 2 * C + C + c];
+    }
+    dtok[i] = v;
+}
+
+int bn_chunks(int rows) {
+    int chunks = (rows + 127) / 128;
+    if (chunks > 256) chunks = 256;
+    return chunks < 1 ? 1 : chunks;
+}
+
+}  // namespace
+
+#define ZS_REQUIRE(cond, ...)            \
+    do {                                 \
+        if (!(cond)) {                   \
+            zs::set_err(__VA_ARGS__);    \
+            return 0;                    \
+        }                                \
+    } while (0)
+
+extern "C" size_t zs_batch_norm_workspace_bytes(int rows, int C) {
+    return (size_t)bn_chunks(rows) * 2 * C * sizeof(double);
+}
+
+extern "C" int zs_batch_norm_train(const float *x, const float *gamma, const float *beta, const float *residual,
+                                   float *y, float *running_mean, float *running_var, float *save_mean,
+                                   float *save_rstd, int rows, int C, float eps, float momentum, int relu,
+                                   void *workspace, void *stream) {
+    ZS_REQUIRE(rows > 0 && C > 0, "zs_batch_norm_train: bad size (rows=%d C=%d)", rows, C);
+    ZS_REQUIRE(x && gamma && beta && y && save_mean && save_rstd && workspace, "zs_batch_norm_train: null pointer");
+    ZS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "zs_batch_norm_train: running stats come in pairs");
+    const int chunks = bn_chunks(rows), per = (rows + chunks - 1) / chunks;
+    double *partial = static_cast<double *>(workspace);
+    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3((C + 63) / 64, chunks), dim3(256), 0, S(stream), x, nullptr, nullptr,
+                       nullptr, nullptr, partial, rows, C, per);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, S(stream), partial, chunks, C, rows, eps,
+                       momentum, running_mean, running_var, save_mean, save_rstd);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for((size_t)rows * C)), dim3(256), 0, S(stream), x, gamma, beta,
+                       residual, save_mean, save_rstd, y, (size_t)rows * C, C, relu);
+    return zs::check_launch("zs_batch_norm_train") ? 1 : 0;
+}
+
+extern "C" int zs_batch_norm_bwd(const float *x, const float *dy, const float *y_relu, const float *gamma,
+                                 const float *save_mean, const float *save_rstd, float *dx, float *dresidual,
+                                 float *dgamma, float *dbeta, int rows, int C, void *workspace, void *stream) {
+    ZS_REQUIRE(rows > 0 && C > 0, "zs_batch_norm_bwd: bad size (rows=%d C=%d)", rows, C);
+    ZS_REQUIRE(x && dy && gamma && save_mean && save_rstd && dx && dgamma && dbeta && workspace,
+               "zs_batch_norm_bwd: null pointer");
+    const int chunks = bn_chunks(rows), per = (rows + chunks - 1) / chunks;
+    double *partial = static_cast<double *>(workspace);
+    hipLaunchKernelGGL(bn_partial_kernel<1>, dim3((C + 63) / 64, chunks), dim3(256), 0, S(stream), x, dy, y_relu,
+                       save_mean, save_rstd, partial, rows, C, per);
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, S(stream), partial, chunks, C, dgamma,
+                       dbeta);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for((size_t)rows * C)), dim3(256), 0, S(stream), x, dy, y_relu,
+                       gamma, save_mean, save_rstd, dgamma, dbeta, dx, dresidual, (size_t)rows * C, C, 1.0f / rows);
+    return zs::check_launch("zs_batch_norm_bwd") ? 1 : 0;
+}
+
+extern "C" int zs_group_norm_bwd(const float *x, const float *dy, const float *y_relu, const float *gamma, float *dx,
+                                 float *dresidual, float *dgamma, float *dbeta, int batch, int HW, int C, int groups,
+                                 float eps, void *workspace, void *stream) {
+    ZS_REQUIRE(batch > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0 && C / groups <= 64,
+               "zs_group_norm_bwd: bad size (B=%d HW=%d C=%d groups=%d; at most 64 channels per group)", batch, HW, C,
+               groups);
+    ZS_REQUIRE(x && dy && gamma && dx && dgamma && dbeta && workspace, "zs_group_norm_bwd: null pointer");
+    float *pg = static_cast<float *>(workspace), *pb = pg + (size_t)batch * C;
+    hipLaunchKernelGGL(group_norm_bwd_kernel, dim3(batch * groups), dim3(GN_BLOCK), 0, S(stream), x, dy, y_relu, gamma, dx,
+                       dresidual, pg, pb, HW, C, groups, eps);
+    hipLaunchKernelGGL(sum_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, S(stream), pg, dgamma, batch, C);
+    hipLaunchKernelGGL(sum_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, S(stream), pb, dbeta, batch, C);
+    return zs::check_launch("zs_group_norm_bwd") ? 1 : 0;
+}
+
+extern "C" size_t zs_group_norm_bwd_workspace_bytes(int batch, int C) { return (size_t)2 * batch * C * sizeof(float); }
+
+extern "C" int zs_max_pool_bwd_nhwc(const float *x, const float *dy, float *dx, int batch, int Hin, int Win, int C,
+                                    int Hout, int Wout, int k, int stride, int pad_t, int pad_l, void *stream) {
+    ZS_REQUIRE(batch >= 0 && Hin > 0 && Win > 0 && C > 0 && Hout > 0 && Wout > 0 && k > 0 && stride > 0,
+               "zs_max_pool_bwd_nhwc: bad size");
+    if (batch == 0) return 1;
+    ZS_REQUIRE(x && dy && dx, "zs_max_pool_bwd_nhwc: null pointer");
+    hipLaunchKernelGGL(max_pool_bwd_kernel, dim3(blocks_for((size_t)batch * Hin * Win * C)), dim3(256), 0, S(stream), x,
+                       dy, dx, batch, Hin, Win, C, Hout, Wout, k, stride, pad_t, pad_l);
+    return zs::check_launch("zs_max_pool_bwd_nhwc") ? 1 : 0;
+}
+
+extern "C" int zs_global_mean_bwd_nhwc(const float *dy, float *dx, int batch, int HW, int C, void *stream) {
+    ZS_REQUIRE(batch >= 0 && HW > 0 && C > 0, "zs_global_mean_bwd_nhwc: bad size");
+    if (batch == 0) return 1;
+    ZS_REQUIRE(dy && dx, "zs_global_mean_bwd_nhwc: null pointer");
+    const size_t total = (size_t)batch * HW * C;
+    hipLaunchKernelGGL(global_mean_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, S(stream), dy, dx, HW, C, total);
+    return zs::check_launch("zs_global_mean_bwd_nhwc") ? 1 : 0;
+}
+
+extern "C" int zs_upsample2x_bwd_nhwc(const float *dy, float *dx, int batch, int Hin, int Win, int C, void *stream) {
+    ZS_REQUIRE(batch >= 0 && Hin > 0 && Win > 0 && C > 0, "zs_upsample2x_bwd_nhwc: bad size");
+    if (batch == 0) return 1;
+    ZS_REQUIRE(dy && dx, "zs_upsample2x_bwd_nhwc: null pointer");
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(blocks_for((size_t)batch * Hin * Win * C)), dim3(256), 0, S(stream),
+                       dy, dx, batch, Hin, Win, C);
+    return zs::check_launch("zs_upsample2x_bwd_nhwc") ? 1 : 0;
+}
+
+extern "C" int zs_nhwc_to_nchw_masked(const float *x, const float *mask, float *y, int batch, int C, int HW, int Cpad,
+                                      void *stream) {
+    ZS_REQUIRE(batch >= 0 && C > 0 && HW > 0 && Cpad >= C, "zs_nhwc_to_nchw_masked: bad size");
+    if (batch == 0) return 1;
+    ZS_REQUIRE(x && y, "zs_nhwc_to_nchw_masked: null pointer");
+    hipLaunchKernelGGL(nhwc_to_nchw_masked_kernel, dim3(blocks_for((size_t)batch * HW * C)), dim3(256), 0, S(stream), x,
+                       mask, y, batch, C, HW, Cpad);
+    return zs::check_launch("zs_nhwc_to_nchw_masked") ? 1 : 0;
+}
+
+extern "C" int zs_resize_bilinear_nhwc(const float *x, float *y, int Hi, int Wi, int Ho, int Wo, int C, int backward,
+                                       void *stream) {
+    ZS_REQUIRE(Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "zs_resize_bilinear_nhwc: bad size");
+    ZS_REQUIRE(x && y, "zs_resize_bilinear_nhwc: null pointer");
+    if (!backward)
+        hipLaunchKernelGGL(resize_bilinear_kernel, dim3(blocks_for((size_t)Ho * Wo * C)), dim3(256), 0, S(stream), x, y,
+                           Hi, Wi, Ho, Wo, C);
+    else        // x = gradient w.r.t. the [Ho][Wo][C] output, y = gradient w.r.t. the [Hi][Wi][C] input
+        hipLaunchKernelGGL(resize_bilinear_bwd_kernel, dim3(blocks_for((size_t)Hi * Wi * C)), dim3(256), 0, S(stream), x,
+                           y, Hi, Wi, Ho, Wo, C);
+    return zs::check_launch("zs_resize_bilinear_nhwc") ? 1 : 0;
+}
+
+extern "C" int zs_readout_concat_bwd(const float *dout, float *dtokens, int batch, int n, int C, void *stream) {
+    ZS_REQUIRE(batch >= 0 && n > 0 && C > 0, "zs_readout_concat_bwd: bad size");
+    if (batch == 0) return 1;
+    ZS_REQUIRE(dout && dtokens, "zs_readout_concat_bwd: null pointer");
+    hipLaunchKernelGGL(readout_concat_bwd_kernel, dim3(blocks_for((size_t)batch * (n + 1) * C)), dim3(256), 0, S(stream),
+                       dout, dtokens, batch, n, C);
+    return zs::check_launch("zs_readout_concat_bwd") ? 1 : 0;
+}

@@ -7,15 +7,23 @@ implicit decoder as ``impl_network`` - every stage on the HIP library.
     # adds var.depth_pred, var.intr_pred, var.validity_mask, var.seen_points, var.latent_depth
 
 State-dict names equal the reference's (dpt_depth.*, intr_head.*, intr_proj.*,
-coord_encoder.*, impl_network.*).  Training (losses, the GT branch :152-185) is not built:
-asking for it raises.
+coord_encoder.*, impl_network.*).
+
+forward(opt, var, training=True, get_loss=True) is the training branch (:115-204): the same
+network through the autograd bindings of zeroshape_amd/nn/autograd.py (every forward and backward
+op a HIP kernel), the ground-truth branch (:152-181) and Loss.shape_loss.  Gradients reach every
+parameter the reference trains: decoder, coordinate encoder and - unless optim.fix_dpt - the depth
+model and intrinsics head, through the seen-surface geometry (zs_seen_surface_bwd).
 """
 import torch
 import torch.nn as nn
 
-from ...nn import blocks, ops, pack
+from ...nn import autograd as A
+from ...nn import blocks, ops, pack, train_blocks
 from ...nn.module import HipModule
 from ...utils import camera
+from ...utils.loss import Loss
+from ...utils.options import EasyDict as edict
 from ...utils.layers import Bottleneck_Conv
 from ...utils.util import get_child_state_dict
 from ..depth.dpt_depth import DPTDepthModel
@@ -34,7 +42,7 @@ class _IntrHead(HipModule):
     def _tensors_key(self):
         g = self._graph
         ts = list(g.intr_head.parameters()) + list(g.intr_head.buffers()) + list(g.intr_proj.parameters())
-        return tuple((t.data_ptr(), t._version) for t in ts)
+        return (A.GENERATION[0],) + tuple((t.data_ptr(), t._version) for t in ts)
 
     def state_dict(self, *a, **k):
         g = self._graph
@@ -85,6 +93,11 @@ class Graph(nn.Module):
                                      n_layers_mlp=opt.arch.impl.mlp_layers, num_heads=opt.arch.num_heads,
                                      posenc_3D=opt.arch.impl.posenc_3D, mlp_ratio=opt.arch.impl.mlp_ratio,
                                      skip_in=opt.arch.impl.skip_in, pos_perlayer=opt.arch.impl.posenc_perlayer)
+        if opt.optim.fix_dpt:                                                  # :33-36
+            for m in (self.dpt_depth, self.intr_head, self.intr_proj):
+                for p in m.parameters():
+                    p.requires_grad_(False)
+        self.loss_fns = Loss(opt)
         self._intr = _IntrHead(self)
         self._captured, self._use_hip_graph = {}, False
         self.eval()
@@ -146,16 +159,77 @@ class Graph(nn.Module):
             self._captured[key] = CapturedCall(run, [rgb, mask])
         return self._captured[key](rgb, mask)
 
-    @torch.no_grad()
     def forward(self, opt, var, training=False, get_loss=True):
-        if training or get_loss or ('gt_sample_points' in var and 'gt_sample_sdf' in var and training):
-            raise NotImplementedError("Graph.forward: only the inference branch (training=False, get_loss=False) "
-                                      "runs on the HIP path")
+        """graph_shape.py:115-192.  training / get_loss / GT samples select the autograd branch."""
         batch_size = len(var.idx)
         var.latent_semantic = None
         HipModule._need_gpu(var.rgb_input_map, "var.rgb_input_map")
-        var.depth_pred, var.intr_pred, var.seen_points, var.latent_depth = self.encode(
-            opt, var.rgb_input_map, var.mask_input_map)
-        var.validity_mask = (var.mask_input_map > 0.5).float().view(batch_size, -1)
+        with_samples = 'gt_sample_points' in var and 'gt_sample_sdf' in var
+        if not (training or get_loss or with_samples) or not torch.is_grad_enabled():
+            with torch.no_grad():
+                var.depth_pred, var.intr_pred, var.seen_points, var.latent_depth = self.encode(
+                    opt, var.rgb_input_map, var.mask_input_map)
+                var.validity_mask = (var.mask_input_map > 0.5).float().view(batch_size, -1)
+                var.pose = var.pose_gt if 'pose_gt' in var else None
+                if with_samples:
+                    self._gt_branch(opt, var)
+                    var.pred_sample_occ, _ = self.impl_network(var.latent_depth, None, var.gt_points_cam,
+                                                               need_attn=False)
+                if get_loss:
+                    return var, self.compute_loss(opt, var, training)
+            return var
+        # ---- autograd branch (:117-192 under graph.train()) ----
+        H, W = opt.H, opt.W
+        rgb = var.rgb_input_map.detach().float().contiguous()
+        mask = var.mask_input_map.detach().float().contiguous()
+        if self.dpt_depth.training:
+            var.depth_pred, layer_4 = self.dpt_depth.forward_train(rgb)
+        else:                                             # a frozen, eval-mode depth model
+            with torch.no_grad():
+                var.depth_pred, feat = self.dpt_depth(rgb, get_feat=True)
+                layer_4 = ops.to_nhwc(feat)
+        if self.intr_head.training:
+            x = train_blocks.bottleneck_conv(train_blocks.bottleneck_conv(layer_4, self.intr_head[0]), self.intr_head[1])
+            intr_params = A.linear(A.global_mean(x), self.intr_proj.weight, self.intr_proj.bias)      # :125-127
+        else:
+            with torch.no_grad():
+                intr_params = self._intr.run(ops.to_nchw(layer_4))
+        var.intr_pred = A.intr_param2mtx(intr_params, H, W)                                            # :129
+        var.validity_mask = (mask > 0.5).float().view(batch_size, -1)
+        assert opt.arch.depth.dsp == 1 and opt.arch.depth.encoder == 'resnet', \
+            "the autograd branch is built for the default ResNet coordinate encoder (options/shape.yaml:26)"
+        var.seen_points, seen_3D_dsp, mask_dsp = A.seen_surface(var.depth_pred, var.intr_pred, mask)   # :131-144
+        var.latent_depth = self.coord_encoder(seen_3D_dsp, mask_dsp)                                   # :147-150
         var.pose = var.pose_gt if 'pose_gt' in var else None
+        if with_samples:
+            with torch.no_grad():
+                self._gt_branch(opt, var)
+            var.pred_sample_occ, _ = self.impl_network(var.latent_depth, None, var.gt_points_cam,     # :185
+                                                       need_attn=False)
+        if get_loss:
+            return var, self.compute_loss(opt, var, training)
         return var
+
+    def _gt_branch(self, opt, var):
+        """:152-181 (no gradient): normalisation factors of the GT seen surface, GT query points
+        moved to that frame, near-surface points for the visualiser."""
+        batch_size = len(var.idx)
+        seen_gt, _, _, mean_gt, scale_gt = camera.seen_surface(opt, var.depth_input_map, var.intr,
+                                                               var.mask_input_map, dsp=1)
+        var.seen_points_gt = seen_gt
+        var.gt_points_cam = camera.transform_points(var.gt_sample_points, var.pose_gt, mean_gt, scale_gt)
+        close_surf_idx = torch.topk(var.gt_sample_sdf.abs(), k=min(100, var.gt_sample_sdf.shape[1]), dim=1,
+                                    largest=False)[1].unsqueeze(-1).repeat(1, 1, 3)
+        var.gt_surf_points = torch.gather(var.gt_points_cam, dim=1, index=close_surf_idx)
+        assert var.gt_points_cam.shape[0] == batch_size
+
+    def compute_loss(self, opt, var, training=False):
+        """:194-204."""
+        loss = edict()
+        if opt.loss_weight.depth is not None:
+            loss.depth = self.loss_fns.depth_loss(var.depth_pred, var.depth_input_map, var.mask_input_map)
+        if opt.loss_weight.intr is not None and training:
+            loss.intr = self.loss_fns.intr_loss(var.seen_points, var.seen_points_gt, var.validity_mask)
+        if opt.loss_weight.shape is not None and training:
+            loss.shape = self.loss_fns.shape_loss(var.pred_sample_occ, var.gt_sample_sdf)
+        return loss

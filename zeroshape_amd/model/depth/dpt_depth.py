@@ -12,7 +12,9 @@ omnidata checkpoint (:87) load by name.  Forward (dpt_depth.py:68-94,115-122, vi
   readout-project + 1x1 (+ 3x3/s2 for tap 4) -> scratch.layerK_rn 3x3 -> refinenet4..1 ->
   head (3x3, x2 bilinear, 3x3 + ReLU, 1x1 + ReLU) -> clamp [0,1]
 
-Inference only; there is no PyTorch fallback.
+In .train() mode under autograd the same network runs through nn/train_blocks.py (gradients to
+every parameter, incl. the StdConv weight standardisation and the re-sampled position embedding).
+There is no PyTorch fallback.
 """
 import math
 
@@ -20,7 +22,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ...nn import blocks, ops, pack
+from ...nn import autograd as A
+from ...nn import blocks, ops, pack, train_blocks
 from ...nn.module import HipModule
 
 
@@ -202,7 +205,6 @@ class DPTDepthModel(HipModule):
         return pk["pos"][(gh, gw)]
 
     # ---- forward ----
-    @torch.no_grad()
     def forward(self, image, get_feat=False, taps=None):
         """image [B,3,H,W] in [0,1] -> depth [B,1,H,W] in [0,1] (and the tap-4 feature
         [B,768,H/32,W/32] with get_feat), dpt_depth.py:115-122.  `taps` (a dict, tests only)
@@ -211,6 +213,57 @@ class DPTDepthModel(HipModule):
         B, C, H, W = image.shape
         if C != 3 or H % 32 or W % 32:
             raise ValueError("image must be [B,3,H,W] with H, W multiples of 32, got %s" % (tuple(image.shape),))
+        if self.training and torch.is_grad_enabled():
+            depth, layer_4 = self.forward_train(image, taps)
+            return (depth, A.to_nchw(layer_4)) if get_feat else depth
+        with torch.no_grad():
+            return self._forward_eval(image, get_feat, taps)
+
+    def forward_train(self, image, taps=None):
+        """Autograd path: -> (depth [B,1,H,W], layer_4 channels-last [B,H/32,W/32,768])."""
+        B, _, H, W = image.shape
+        gh, gw = H // 16, W // 16
+        vit, pre, sc = self.pretrained.model, self.pretrained, self.scratch
+        record = (lambda **kw: taps.update(kw)) if taps is not None else (lambda **kw: None)
+        x = A.to_nhwc(image.float(), cpad=4)
+        s0, s1, s2 = train_blocks.resnetv2(x, vit.patch_embed.backbone, in_scale=2.0, in_shift=-1.0)
+        record(stage0=s0, stage1=s1, stage2=s2)
+        feat = A.conv2d(s2, vit.patch_embed.proj.weight, vit.patch_embed.proj.bias).view(B, gh * gw, 768)
+        # vit.py:103-120: the native position grid re-sampled to (gh, gw) on every forward
+        pos = vit.pos_embed[0]
+        g0 = int(math.sqrt(pos.shape[0] - 1))
+        grid = A.resize_grid(pos[1:].reshape(g0, g0, -1), gh, gw).reshape(gh * gw, -1)
+        tok = A.assemble_tokens(feat, vit.cls_token.reshape(-1), torch.cat([pos[:1], grid], 0))
+        hooked = {}
+        for i, blk in enumerate(vit.blocks):
+            tok = train_blocks.vit_block(tok, blk, 12)
+            if i in (0, 8, 11):
+                hooked[i] = tok
+        record(block0=hooked[0], block8=hooked[8], block11=hooked[11])
+
+        def reassemble(t, post):
+            lin = post[0].project[0]
+            r = A.gelu(A.linear(A.readout_concat(t), lin.weight, lin.bias))
+            return A.conv2d(r.view(B, gh, gw, 768), post[3].weight, post[3].bias)
+        layer_3 = reassemble(hooked[8], pre.act_postprocess3)
+        p4 = pre.act_postprocess4
+        layer_4 = A.conv2d(reassemble(hooked[11], p4), p4[4].weight, p4[4].bias, stride=2, padding=1)
+        rn = [A.conv2d(l, getattr(sc, "layer%d_rn" % i).weight, None, padding=1)
+              for i, l in enumerate((s0, s1, layer_3, layer_4), 1)]
+        record(layer3_rn=rn[2], layer4_rn=rn[3])
+        path4 = train_blocks.fusion(rn[3], sc.refinenet4)
+        path3 = train_blocks.fusion(path4, sc.refinenet3, rn[2])
+        path2 = train_blocks.fusion(path3, sc.refinenet2, rn[1])
+        path = train_blocks.fusion(path2, sc.refinenet1, rn[0])
+        record(path4=path4, path3=path3, path2=path2, path1=path)
+        oc = sc.output_conv
+        o = A.upsample2x(A.conv2d(path, oc[0].weight, oc[0].bias, padding=1))
+        o = A.conv2d(o, oc[2].weight, oc[2].bias, padding=1, act=A.ACT_RELU)
+        o = A.conv2d(o, oc[4].weight, oc[4].bias, act=A.ACT_RELU_CLAMP1)        # [B,H,W,1]
+        return o.view(B, 1, H, W), layer_4
+
+    def _forward_eval(self, image, get_feat=False, taps=None):
+        B, C, H, W = image.shape
         pk = self.packed(image.device)
         gh, gw = H // 16, W // 16
         x = ops.to_nhwc(image, cpad=4)

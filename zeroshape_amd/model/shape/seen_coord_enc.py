@@ -6,7 +6,8 @@ from functools import partial
 import torch
 import torch.nn as nn
 
-from ...nn import blocks, ops, pack
+from ...nn import autograd as A
+from ...nn import blocks, ops, pack, train_blocks
 from ...nn.module import HipModule
 from ...utils.layers import Bottleneck_Conv
 from ...utils.pos_embed import get_2d_sincos_pos_embed
@@ -74,12 +75,31 @@ class CoordEncRes(HipModule):
                     p1=blocks.pack_bottleneck_conv(sd, "depth_feat_proj.1", 1, device),
                     p2=pack.pack_conv(sd["depth_feat_proj.2.weight"], sd["depth_feat_proj.2.bias"]).to(device))
 
-    @torch.no_grad()
     def forward(self, coord_obj, mask_obj):
         """coord_obj [B,3,H,W], mask_obj [B,1,H,W] -> [B, 1 + (H/ws)*(W/ws), latent_dim], global
-        token first (:180-194)."""
+        token first (:180-194).  In .train() mode under autograd: BatchNorm on batch statistics and
+        gradients to every parameter and to coord_obj (nn/train_blocks.py)."""
         self._need_gpu(coord_obj, "coord_obj")
         assert len(coord_obj.shape) == len(mask_obj.shape) == 4
+        if self.training and torch.is_grad_enabled():
+            return self._forward_train(coord_obj, mask_obj)
+        with torch.no_grad():
+            return self._forward_eval(coord_obj, mask_obj)
+
+    def _forward_train(self, coord_obj, mask_obj):
+        B = coord_obj.shape[0]
+        enc = self.encoder
+        x = A.to_nhwc(coord_obj.float(), cpad=4, mask=mask_obj)                 # coord * mask (:184)
+        feats = train_blocks.resnet50(x, enc)
+        g = A.global_mean(feats[3]).view(B, 1, 1, -1)
+        g = train_blocks.bottleneck_conv(train_blocks.bottleneck_conv(g, enc.fc[0]), enc.fc[1])
+        g = A.linear(g.view(B, 1, -1), enc.fc[2].weight, enc.fc[2].bias)
+        proj = self.depth_feat_proj
+        loc = train_blocks.bottleneck_conv(train_blocks.bottleneck_conv(feats[self.tap], proj[0]), proj[1])
+        loc = A.conv2d(loc, proj[2].weight, proj[2].bias)
+        return torch.cat([g, loc.view(B, -1, loc.shape[-1])], dim=1)
+
+    def _forward_eval(self, coord_obj, mask_obj):
         B = coord_obj.shape[0]
         pk = self.packed(coord_obj.device)
         x = ops.to_nhwc(coord_obj, cpad=4, mask=mask_obj)                       # coord * mask (:184)

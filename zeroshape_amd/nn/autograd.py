@@ -218,12 +218,13 @@ class _Conv(torch.autograd.Function):
                 dw = dws
         dx = None
         if need_x:
-            assert cin % 4 == 0, "data gradient needs Cin % 4 == 0"
             assert stride in (1, 2), "data gradient: stride 1 or 2"
             dx = torch.empty(B, H, W, cin, dtype=torch.float32, device=x.device)
             flags = _CONV_IN_DILATE2 if stride == 2 else 0
             _conv_launch(gp, _pack(weight, cin0, cin, True, std_eps), None, None, None, dx, kh, kw, 1, kh - 1 - pt, kw - 1 - pl,
                          flags, in_scale, 0.0, ACT_NONE)
+            if cin != Cx:                       # the input carried zero padding channels
+                dx = _pad_channels(dx, Cx)
             if in_relu:
                 dx = _act_backward(dx, x, ACT_RELU)
         return dx, dw, db, (g if ctx.has[1] else None), (g if ctx.has[2] else None), None
@@ -447,3 +448,414 @@ class _BCELogits(torch.autograd.Function):
 
 def bce_logits(logits, sdf, impt_thres=0.01, impt_weight=1.0):
     return _BCELogits.apply(logits, sdf, impt_thres, impt_weight)
+
+
+# =============================================================================================
+# Encoder layers: BatchNorm (training), GroupNorm, pooling, resampling, layout, geometry
+# =============================================================================================
+class _BatchNormTrain(torch.autograd.Function):
+    """nn.BatchNorm2d in training mode over channels-last x (+ residual, ReLU fused): batch
+    statistics, running-stat update (momentum, unbiased variance) as torch does."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, eps, momentum, relu):
+        lib = _lib.load()
+        x = _f32c(x, "batch_norm input")
+        C = x.shape[-1]
+        rows = x.numel() // C
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = scratch(x.device, "bn", lib.zs_batch_norm_workspace_bytes(rows, C))
+        res = None if residual is None else _f32c(residual, "batch_norm residual")
+        with torch.cuda.device(x.device):
+            _lib.check(lib.zs_batch_norm_train(_lib.ptr(x), _lib.ptr(gamma.detach()), _lib.ptr(beta.detach()),
+                                               _lib.ptr(res), _lib.ptr(y), _lib.ptr(running_mean),
+                                               _lib.ptr(running_var), _lib.ptr(mean), _lib.ptr(rstd), rows, C,
+                                               float(eps), float(momentum), 1 if relu else 0, _lib.ptr(ws),
+                                               _stream(x)), "zs_batch_norm_train")
+        ctx.relu, ctx.has_res = relu, residual is not None
+        ctx.save_for_backward(x, gamma, mean, rstd, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, gamma, mean, rstd, y = ctx.saved_tensors
+        dy = _f32c(dy, "batch_norm grad")
+        C = x.shape[-1]
+        rows = x.numel() // C
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if (ctx.has_res and ctx.relu) else None
+        dg = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = scratch(x.device, "bn", lib.zs_batch_norm_workspace_bytes(rows, C))
+        with torch.cuda.device(x.device):
+            _lib.check(lib.zs_batch_norm_bwd(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(y), _lib.ptr(gamma.detach()),
+                                             _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dg),
+                                             _lib.ptr(db), rows, C, _lib.ptr(ws), _stream(x)), "zs_batch_norm_bwd")
+        if ctx.has_res and not ctx.relu:
+            dres = dy
+        return dx, dg, db, dres, None, None, None, None, None
+
+
+def batch_norm_train(x, bn, relu=False, residual=None):
+    """bn: an nn.BatchNorm2d in training mode (its running statistics are updated in place)."""
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    y = _BatchNormTrain.apply(x, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, bn.eps, momentum, relu)
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return y
+
+
+class _GroupNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, groups, eps, relu):
+        lib = _lib.load()
+        x = _f32c(x, "group_norm input")
+        B, H, W, C = x.shape
+        y = torch.empty_like(x)
+        res = None if residual is None else _f32c(residual, "group_norm residual")
+        with torch.cuda.device(x.device):
+            _lib.check(lib.zs_group_norm_nhwc(_lib.ptr(x), _lib.ptr(gamma.detach()), _lib.ptr(beta.detach()),
+                                              _lib.ptr(res), _lib.ptr(y), B, H * W, C, groups, float(eps),
+                                              1 if relu else 0, _stream(x)), "zs_group_norm_nhwc")
+        ctx.cfg = (groups, eps, relu, residual is not None)
+        ctx.save_for_backward(x, gamma, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, gamma, y = ctx.saved_tensors
+        groups, eps, relu, has_res = ctx.cfg
+        dy = _f32c(dy, "group_norm grad")
+        B, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if (has_res and relu) else None
+        dg = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = scratch(x.device, "gn_bwd", lib.zs_group_norm_bwd_workspace_bytes(B, C))
+        with torch.cuda.device(x.device):
+            _lib.check(lib.zs_group_norm_bwd(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(y), _lib.ptr(gamma.detach()),
+                                             _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dg), _lib.ptr(db), B, H * W, C,
+                                             groups, float(eps), _lib.ptr(ws), _stream(x)), "zs_group_norm_bwd")
+        if has_res and not relu:
+            dres = dy
+        return dx, dg, db, dres, None, None, None
+
+
+def group_norm(x, gamma, beta, groups=32, eps=1e-5, relu=False, residual=None):
+    return _GroupNorm.apply(x, gamma, beta, residual, groups, eps, relu)
+
+
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, stride, padding):
+        lib = _lib.load()
+        x = _f32c(x, "max_pool input")
+        B, H, W, C = x.shape
+        Ho, pt = _out_size(H, k, stride, padding)
+        Wo, pl = _out_size(W, k, stride, padding)
+        y = torch.empty(B, Ho, Wo, C, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.zs_max_pool_nhwc(_lib.ptr(x), _lib.ptr(y), B, H, W, C, Ho, Wo, k, stride, pt, pl,
+                                            _stream(x)), "zs_max_pool_nhwc")
+        ctx.cfg = (k, stride, pt, pl, Ho, Wo)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        k, stride, pt, pl, Ho, Wo = ctx.cfg
+        dy = _f32c(dy, "max_pool grad")
+        B, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.zs_max_pool_bwd_nhwc(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dx), B, H, W, C, Ho, Wo, k, stride,
+                                                pt, pl, _stream(x)), "zs_max_pool_bwd_nhwc")
+        return dx, None, None, None
+
+
+def max_pool(x, k=3, stride=2, padding=1):
+    return _MaxPool.apply(x, k, stride, padding)
+
+
+class _GlobalMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _f32c(x, "global_mean input")
+        B, H, W, C = x.shape
+        y = torch.empty(B, C, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.zs_global_mean_nhwc(_lib.ptr(x), _lib.ptr(y), B, H * W, C, _stream(x)),
+                       "zs_global_mean_nhwc")
+        ctx.shape = (B, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        B, H, W, C = ctx.shape
+        dy = _f32c(dy, "global_mean grad")
+        dx = torch.empty(B, H, W, C, dtype=torch.float32, device=dy.device)
+        with torch.cuda.device(dy.device):
+            _lib.check(lib.zs_global_mean_bwd_nhwc(_lib.ptr(dy), _lib.ptr(dx), B, H * W, C, _stream(dy)),
+                       "zs_global_mean_bwd_nhwc")
+        return dx
+
+
+def global_mean(x):
+    return _GlobalMean.apply(x)
+
+
+class _Upsample2x(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _f32c(x, "upsample2x input")
+        B, H, W, C = x.shape
+        y = torch.empty(B, 2 * H, 2 * W, C, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.zs_upsample2x_nhwc(_lib.ptr(x), _lib.ptr(y), B, H, W, C, _stream(x)), "zs_upsample2x_nhwc")
+        ctx.shape = (B, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        B, H, W, C = ctx.shape
+        dy = _f32c(dy, "upsample2x grad")
+        dx = torch.empty(B, H, W, C, dtype=torch.float32, device=dy.device)
+        with torch.cuda.device(dy.device):
+            _lib.check(lib.zs_upsample2x_bwd_nhwc(_lib.ptr(dy), _lib.ptr(dx), B, H, W, C, _stream(dy)),
+                       "zs_upsample2x_bwd_nhwc")
+        return dx
+
+
+def upsample2x(x):
+    return _Upsample2x.apply(x)
+
+
+class _ToNHWC(torch.autograd.Function):
+    """NCHW [B,C,H,W] (times an optional per-pixel mask [B,1,H,W]) -> channels-last, zero padded to cpad."""
+
+    @staticmethod
+    def forward(ctx, x, mask, cpad):
+        lib = _lib.load()
+        x = _f32c(x, "to_nhwc input")
+        B, C, H, W = x.shape
+        m = None if mask is None else _f32c(mask.float(), "to_nhwc mask")
+        y = torch.empty(B, H, W, cpad, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.zs_nchw_to_nhwc(_lib.ptr(x), _lib.ptr(m), _lib.ptr(y), B, C, H * W, cpad, _stream(x)),
+                       "zs_nchw_to_nhwc")
+        ctx.shape = (B, C, H, W, cpad)
+        ctx.save_for_backward(m)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (m,) = ctx.saved_tensors
+        B, C, H, W, cpad = ctx.shape
+        dy = _f32c(dy, "to_nhwc grad")
+        dx = torch.empty(B, C, H, W, dtype=torch.float32, device=dy.device)
+        with torch.cuda.device(dy.device):
+            _lib.check(lib.zs_nhwc_to_nchw_masked(_lib.ptr(dy), _lib.ptr(m), _lib.ptr(dx), B, C, H * W, cpad,
+                                                  _stream(dy)), "zs_nhwc_to_nchw_masked")
+        return dx, None, None
+
+
+def to_nhwc(x, cpad=None, mask=None):
+    return _ToNHWC.apply(x, mask, cpad or x.shape[1])
+
+
+class _ToNCHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _f32c(x, "to_nchw input")
+        B, H, W, C = x.shape
+        y = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.zs_nhwc_to_nchw(_lib.ptr(x), _lib.ptr(y), B, C, H * W, _stream(x)), "zs_nhwc_to_nchw")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        dy = _f32c(dy, "to_nchw grad")
+        B, C, H, W = dy.shape
+        dx = torch.empty(B, H, W, C, dtype=torch.float32, device=dy.device)
+        with torch.cuda.device(dy.device):
+            _lib.check(lib.zs_nchw_to_nhwc(_lib.ptr(dy), None, _lib.ptr(dx), B, C, H * W, C, _stream(dy)),
+                       "zs_nchw_to_nhwc")
+        return dx
+
+
+def to_nchw(x):
+    return _ToNCHW.apply(x)
+
+
+class _SeenSurface(torch.autograd.Function):
+    """graph_shape.py:131-144 in one launch each way: (depth [B,1,H,W], intr [B,3,3], mask) ->
+    (seen_points [B,HW,3], seen_3D_dsp [B,3,H,W], mask_dsp [B,1,H,W]); same-size resample only."""
+
+    @staticmethod
+    def forward(ctx, depth, intr, mask):
+        lib = _lib.load()
+        depth, intr = _f32c(depth, "depth"), _f32c(intr, "intr")
+        m = _f32c(mask.float(), "mask")
+        B, _, H, W = depth.shape
+        dev = depth.device
+        seen = torch.empty(B, H * W, 3, dtype=torch.float32, device=dev)
+        mean = torch.empty(B, 3, dtype=torch.float32, device=dev)
+        scale = torch.empty(B, dtype=torch.float32, device=dev)
+        coord = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
+        mask_dsp = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.zs_seen_surface(_lib.ptr(depth), _lib.ptr(intr), _lib.ptr(m), B, H, W, H, W, _lib.ptr(seen),
+                                           _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(coord), _lib.ptr(mask_dsp),
+                                           _stream(depth)), "zs_seen_surface")
+        ctx.save_for_backward(depth, intr, m, mean, scale)
+        ctx.mark_non_differentiable(mask_dsp)
+        return seen, coord, mask_dsp
+
+    @staticmethod
+    def backward(ctx, d_seen, d_coord, _d_mask):
+        lib = _lib.load()
+        depth, intr, m, mean, scale = ctx.saved_tensors
+        B, _, H, W = depth.shape
+        d_seen = None if d_seen is None else _f32c(d_seen, "seen grad")
+        d_coord = None if d_coord is None else _f32c(d_coord, "coord grad")
+        dd = torch.empty_like(depth)
+        dk = torch.empty_like(intr)
+        with torch.cuda.device(depth.device):
+            _lib.check(lib.zs_seen_surface_bwd(_lib.ptr(depth), _lib.ptr(intr), _lib.ptr(m), _lib.ptr(mean),
+                                               _lib.ptr(scale), _lib.ptr(d_seen), _lib.ptr(d_coord), B, H, W,
+                                               _lib.ptr(dd), _lib.ptr(dk), _stream(depth)), "zs_seen_surface_bwd")
+        return dd, dk, None
+
+
+def seen_surface(depth, intr, mask):
+    return _SeenSurface.apply(depth, intr, mask)
+
+
+class _IntrParam2Mtx(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, params, H, W):
+        lib = _lib.load()
+        params = _f32c(params, "intr params")
+        B = params.shape[0]
+        intr = torch.empty(B, 3, 3, dtype=torch.float32, device=params.device)
+        with torch.cuda.device(params.device):
+            _lib.check(lib.zs_intr_param2mtx(_lib.ptr(params), B, H, W, _lib.ptr(intr), _stream(params)),
+                       "zs_intr_param2mtx")
+        ctx.hw = (H, W)
+        ctx.save_for_backward(params)
+        return intr
+
+    @staticmethod
+    def backward(ctx, d_intr):
+        lib = _lib.load()
+        (params,) = ctx.saved_tensors
+        d_intr = _f32c(d_intr, "intr grad")
+        dp = torch.empty_like(params)
+        with torch.cuda.device(params.device):
+            _lib.check(lib.zs_intr_param2mtx_bwd(_lib.ptr(params), _lib.ptr(d_intr), params.shape[0], ctx.hw[0],
+                                                 ctx.hw[1], _lib.ptr(dp), _stream(params)), "zs_intr_param2mtx_bwd")
+        return dp, None, None
+
+
+def intr_param2mtx(params, H, W):
+    return _IntrParam2Mtx.apply(params, H, W)
+
+
+# ---- ViT token plumbing of DPT-hybrid (model/depth/vit.py:103-148, :31-43) ----
+class _ResizeGrid(torch.autograd.Function):
+    """Bilinear (align_corners=False) resize of a channels-last grid [Hi,Wi,C] -> [Ho,Wo,C]."""
+
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        lib = _lib.load()
+        x = _f32c(x, "resize input")
+        Hi, Wi, C = x.shape
+        y = torch.empty(Ho, Wo, C, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.zs_resize_bilinear_nhwc(_lib.ptr(x), _lib.ptr(y), Hi, Wi, Ho, Wo, C, 0, _stream(x)),
+                       "zs_resize_bilinear_nhwc")
+        ctx.shape = (Hi, Wi, Ho, Wo, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        Hi, Wi, Ho, Wo, C = ctx.shape
+        dy = _f32c(dy, "resize grad")
+        dx = torch.empty(Hi, Wi, C, dtype=torch.float32, device=dy.device)
+        with torch.cuda.device(dy.device):
+            _lib.check(lib.zs_resize_bilinear_nhwc(_lib.ptr(dy), _lib.ptr(dx), Hi, Wi, Ho, Wo, C, 1, _stream(dy)),
+                       "zs_resize_bilinear_nhwc(bwd)")
+        return dx, None, None
+
+
+def resize_grid(x, Ho, Wo):
+    return _ResizeGrid.apply(x, Ho, Wo)
+
+
+class _AssembleTokens(torch.autograd.Function):
+    """tokens[b] = [cls | feat[b]] + pos   (feat [B,n,C], cls [C], pos [n+1,C])."""
+
+    @staticmethod
+    def forward(ctx, feat, cls, pos):
+        lib = _lib.load()
+        feat, cls, pos = _f32c(feat, "tokens"), _f32c(cls, "cls"), _f32c(pos, "pos")
+        B, n, C = feat.shape
+        y = torch.empty(B, n + 1, C, dtype=torch.float32, device=feat.device)
+        with torch.cuda.device(feat.device):
+            _lib.check(lib.zs_assemble_tokens(_lib.ptr(feat), _lib.ptr(cls), _lib.ptr(pos), _lib.ptr(y), B, n, C,
+                                              _stream(feat)), "zs_assemble_tokens")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _f32c(dy, "tokens grad")
+        B, n1, C = dy.shape
+        dpos = column_sum(dy.view(B, n1 * C)).view(n1, C)
+        return dy[:, 1:].contiguous(), dpos[0].contiguous(), dpos
+
+
+def assemble_tokens(feat, cls, pos):
+    return _AssembleTokens.apply(feat, cls, pos)
+
+
+class _ReadoutConcat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tokens):
+        lib = _lib.load()
+        tokens = _f32c(tokens, "readout input")
+        B, n1, C = tokens.shape
+        y = torch.empty(B, n1 - 1, 2 * C, dtype=torch.float32, device=tokens.device)
+        with torch.cuda.device(tokens.device):
+            _lib.check(lib.zs_readout_concat(_lib.ptr(tokens), _lib.ptr(y), B, n1 - 1, C, _stream(tokens)),
+                       "zs_readout_concat")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        dy = _f32c(dy, "readout grad")
+        B, n, C2 = dy.shape
+        dt = torch.empty(B, n + 1, C2 // 2, dtype=torch.float32, device=dy.device)
+        with torch.cuda.device(dy.device):
+            _lib.check(lib.zs_readout_concat_bwd(_lib.ptr(dy), _lib.ptr(dt), B, n, C2 // 2, _stream(dy)),
+                       "zs_readout_concat_bwd")
+        return dt
+
+
+def readout_concat(tokens):
+    return _ReadoutConcat.apply(tokens)

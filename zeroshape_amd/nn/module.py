@@ -13,15 +13,17 @@ class HipModule(nn.Module):
         self._packed_cache = None
 
     def _tensors_key(self):
-        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        from . import autograd
+        return (autograd.GENERATION[0],) + tuple((t.data_ptr(), t._version)
+                                                 for t in list(self.parameters()) + list(self.buffers()))
 
     def packed(self, device):
         key = (str(device),) + self._tensors_key()
         if self._packed_cache is None or self._packed_cache[0] != key:
             if self.training:
                 raise NotImplementedError(
-                    "%s: the HIP path is inference-only (BatchNorm statistics are folded, no autograd); call "
-                    ".eval() first" % type(self).__name__)
+                    "%s: the packed (folded-BatchNorm) path is the inference path; in .train() mode call the "
+                    "module under autograd (torch.enable_grad) or switch to .eval()" % type(self).__name__)
             sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
             self._packed_cache = (key, self._pack(sd, torch.device(device)))
         return self._packed_cache[1]

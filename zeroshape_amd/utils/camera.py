@@ -142,3 +142,19 @@ def seen_surface(opt, depth_map, intr, mask_input_map, dsp=None):
                                        _lib.ptr(seen), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(coord),
                                        _lib.ptr(mask_dsp), _lib.current_stream_ptr(dev)), "zs_seen_surface")
     return seen, coord, mask_dsp, mean, scale
+
+
+def transform_points(points, pose, mean, scale):
+    """graph_shape.py:163-173: points [B,N,3] in the object frame -> camera frame by pose [B,3,4]
+    -> normalised by the seen surface's (mean [B,3], scale [B]): ((R p + t) - mean) / scale."""
+    from .. import _lib
+    lib = _lib.load()
+    p, T = _dev_f32(points, "points"), _dev_f32(pose, "pose")
+    m, s = _dev_f32(mean, "mean"), _dev_f32(scale, "scale")
+    B, N, _ = p.shape
+    assert T.shape == (B, 3, 4)
+    out = torch.empty_like(p)
+    with torch.cuda.device(p.device):
+        _lib.check(lib.zs_transform_points(_lib.ptr(p), _lib.ptr(T), _lib.ptr(m), _lib.ptr(s), _lib.ptr(out), B, N,
+                                           _lib.current_stream_ptr(p.device)), "zs_transform_points")
+    return out
