@@ -1,0 +1,99 @@
+"""GPU end-to-end training through the Runner (model/shape_engine.py:85-297 mirror): option file ->
+Runner.setup_optimizer (the reference's four AdamW groups) -> train() on the analytic dataset ->
+checkpoint with optimiser state -> resume -> evaluate with the trained weights."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from zeroshape_amd.data.synthetic import Dataset
+from zeroshape_amd.utils import options
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def train_opt(tmp_path, *extra):
+    cmd = options.parse_arguments(["--yaml=%s/options/shape.yaml" % ROOT, "--output_root=%s" % tmp_path, "--batch_size=4",
+                                   "--max_epoch=1", "--pretrain.depth=", "--arch.depth.pretrained=", "--eval.vox_res=16",
+                                   "--eval.num_points=500", "--training.n_sdf_points=512", "--optim.lr=3.e-4",
+                                   "--optim.lr_ft=1.e-5"] + list(extra))
+    opt = options.set(cmd)
+    opt.world_size = 1
+    return opt
+
+
+def make_runner(opt, encoder_sd, seeded_sd, n_train=8):
+    from zeroshape_amd.model.shape_engine import Runner
+    r = Runner(opt)
+    r.load_train_dataset(opt, dataset=Dataset(opt, split="train", n_items=n_train, n_points=1000, seed=1))
+    r.load_dataset(opt, dataset=Dataset(opt, n_items=2, n_points=1000))
+    r.build_networks(opt)
+    full = dict(encoder_sd)
+    full.update({"impl_network." + k: v for k, v in seeded_sd.items()})
+    r.graph.load_state_dict(full, strict=True)
+    r.setup_optimizer(opt)
+    r.restore_checkpoint(opt)
+    return r
+
+
+def test_optimizer_groups_follow_the_reference(tmp_path, encoder_sd, seeded_sd):
+    r = make_runner(train_opt(tmp_path), encoder_sd, seeded_sd)
+    g = r.optim.param_groups
+    assert [x["lr"] for x in g] == [1e-5, 1e-5, 3e-4, 3e-4] and [x["weight_decay"] for x in g] == [0.0, 0.05, 0.0, 0.05]
+    names = {id(p): n for n, p in r.graph.named_parameters()}
+    for i, grp in enumerate(g):
+        for p in grp["params"]:
+            n = names[id(p)]
+            assert (("dpt_depth" in n or "intr_" in n) == (i < 2)) and ((p.ndim <= 1 or n.endswith(".bias")) == (i % 2 == 0)), n
+    assert sum(len(x["params"]) for x in g) == sum(1 for p in r.graph.parameters() if p.requires_grad)
+    r2 = make_runner(train_opt(tmp_path, "--optim.fix_dpt"), encoder_sd, seeded_sd)
+    assert len(r2.optim.param_groups) == 2 and all("dpt_depth" not in names_ and "intr_" not in names_ for names_ in
+                                                   [n for n, p in r2.graph.named_parameters() if p.requires_grad])
+
+
+def test_train_checkpoint_resume_evaluate(tmp_path, encoder_sd, seeded_sd):
+    opt = train_opt(tmp_path)
+    r = make_runner(opt, encoder_sd, seeded_sd)
+    before = {k: v.detach().clone() for k, v in r.graph.state_dict().items()}
+    r.graph.train()
+    losses = []
+    for ep in range(3):                                   # 3 passes over 8 items, batch 4 -> 6 iterations
+        for batch in r.train_loader:
+            from zeroshape_amd.utils import util
+            from zeroshape_amd.utils.options import EasyDict as edict
+            var = util.move_to_device(edict(batch), opt.device)
+            losses.append(float(r.train_iteration(opt, var).all))
+    assert r.it == 6 and np.isfinite(losses).all()
+    assert np.mean(losses[-2:]) < np.mean(losses[:2]), losses                # it learns something
+    after = r.graph.state_dict()
+    moved = [k for k in before if before[k].is_floating_point() and not torch.equal(before[k], after[k])]
+    assert any(k.startswith("impl_network.") for k in moved) and any(k.startswith("coord_encoder.") for k in moved)
+    assert any(k.startswith("dpt_depth.scratch") for k in moved) and any("running_mean" in k for k in moved)
+    assert torch.equal(before["impl_network.pos_embed"], after["impl_network.pos_embed"])
+    assert int(after["coord_encoder.encoder.bn1.num_batches_tracked"]) == 6
+    # checkpoint with optimiser state (utils/util.py:252-277 layout) and resume
+    r.save_checkpoint(opt, ep=2, it=r.it, best_val=0.5, best_ep=1, latest=True)
+    ck = torch.load(os.path.join(opt.output_path, "latest.ckpt"), map_location="cpu")
+    assert set(ck) == {"epoch", "iter", "best_val", "best_ep", "graph", "optim"} and ck["iter"] == 6
+    assert len(ck["optim"]["param_groups"]) == 4 and float(ck["optim"]["state"][0]["step"]) == 6
+    opt2 = train_opt(tmp_path, "--resume")
+    r2 = make_runner(opt2, encoder_sd, seeded_sd)
+    assert (r2.epoch_start, r2.iter_start, r2.best_val) == (2, 6, 0.5)
+    for k, v in r2.graph.state_dict().items():
+        assert torch.equal(v.cpu(), after[k].cpu()), k
+    st, st2 = r.optim.state_dict()["state"], r2.optim.state_dict()["state"]
+    assert all(torch.equal(st[i]["exp_avg"].cpu(), st2[i]["exp_avg"].cpu()) for i in (0, 5, 100))
+    # one more identical step on both runners gives identical weights (the optimiser state is live)
+    batch = next(iter(r.train_loader))
+    for rr, oo in ((r, opt), (r2, opt2)):
+        rr.graph.train()
+        torch.manual_seed(7)
+        rr.train_iteration(oo, util.move_to_device(edict({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}),
+                                                   oo.device))
+    for (k, a), (_, b) in zip(r.graph.state_dict().items(), r2.graph.state_dict().items()):
+        assert torch.allclose(a, b, atol=0, rtol=0), k
+    # evaluation sees the trained weights (the packed inference programs are refreshed)
+    out = r.evaluate(opt)
+    assert np.isfinite(out["cd"]) and out["cd"] > 0

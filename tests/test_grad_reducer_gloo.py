@@ -1,0 +1,88 @@
+"""World-size 2 / 3 gloo tests (CPU tensors) of parallel.GradReducer, the data-parallel gradient
+averaging of the training path: bucket layout in reverse registration order, the first (discovery)
+iteration, the overlapped iterations driven by post-accumulate hooks, parameters that never get a
+gradient, a gradient that is missing in one iteration, and p.grad re-pointed at the reduced bucket.
+The bucket packer is injected (torch copy); the product default is the HIP zs_copy_multi kernel."""
+import ctypes
+import os
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from zeroshape_amd import parallel
+
+
+def torch_pack(entries, scale, device):
+    """Test stand-in for hip_pack: same contract on host pointers."""
+    for dst, src, n in entries:
+        d = (ctypes.c_float * n).from_address(dst)
+        s = (ctypes.c_float * n).from_address(src)
+        torch.frombuffer(d, dtype=torch.float32).copy_(torch.frombuffer(s, dtype=torch.float32) * scale)
+
+
+class Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(40, 300)
+        self.b = torch.nn.Linear(300, 300)
+        self.unused = torch.nn.Linear(7, 7)          # like the ViT's norm / head: never in the graph
+        self.c = torch.nn.Linear(300, 5)
+        self.sometimes = torch.nn.Parameter(torch.ones(5))
+
+    def forward(self, x, use_sometimes=True):
+        y = self.c(torch.relu(self.b(torch.relu(self.a(x)))))
+        return y * self.sometimes if use_sometimes else y
+
+
+def _worker(rank, world, initfile):
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        net = Net()                                   # same weights on every rank
+        ref = Net()
+        ref.load_state_dict(net.state_dict())
+        red = parallel.GradReducer(net.parameters(), bucket_mb=0.3, pack_fn=torch_pack)   # several buckets
+        data = [torch.randn(world, 6, 40, generator=torch.Generator().manual_seed(100 + it)) for it in range(4)]
+        for it in range(4):
+            use = it != 2                             # iteration 2: `sometimes` gets no gradient
+            net.zero_grad(set_to_none=True)
+            net(data[it][rank], use).pow(2).mean().backward()
+            red.finish()
+            ref.zero_grad(set_to_none=True)
+            for r in range(world):                    # the average over the ranks, computed locally
+                (ref(data[it][r], use).pow(2).mean() / world).backward()
+            for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+                if n.startswith("unused"):
+                    assert p.grad is None and q.grad is None
+                elif n == "sometimes" and not use:
+                    assert float(p.grad.abs().max()) == 0 and q.grad is None
+                else:
+                    assert torch.allclose(p.grad, q.grad, atol=1e-6, rtol=1e-5), (it, n)
+            if it == 0:
+                assert len(red.buckets) >= 3
+                assert red.buckets[0][0] is net.c.bias             # reverse registration order (root parameters come first)
+                assert all(p is not net.unused.weight for b in red.buckets for p in b)
+            # gradients live in the flat buckets (no copy back)
+            bi, off = red.slot[id(net.b.weight)]
+            assert net.b.weight.grad.data_ptr() == red.flat[bi].data_ptr() + 4 * off
+        red.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_grad_reducer_matches_averaged_gradients(world):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, os.path.join(d, "init")), nprocs=world, join=True)
+
+
+def test_single_process_is_a_no_op():
+    net = Net()
+    red = parallel.GradReducer(net.parameters())
+    net(torch.randn(3, 40)).sum().backward()
+    g = net.a.weight.grad.clone()
+    red.finish()
+    assert torch.equal(net.a.weight.grad, g) and red.buckets is None

@@ -93,7 +93,7 @@ class Graph(nn.Module):
                                      n_layers_mlp=opt.arch.impl.mlp_layers, num_heads=opt.arch.num_heads,
                                      posenc_3D=opt.arch.impl.posenc_3D, mlp_ratio=opt.arch.impl.mlp_ratio,
                                      skip_in=opt.arch.impl.skip_in, pos_perlayer=opt.arch.impl.posenc_perlayer)
-        if opt.optim.fix_dpt:                                                  # :33-36
+        if opt.get("optim") and opt.optim.get("fix_dpt"):                          # :33-36
             for m in (self.dpt_depth, self.intr_head, self.intr_proj):
                 for p in m.parameters():
                     p.requires_grad_(False)

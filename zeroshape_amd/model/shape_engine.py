@@ -1,9 +1,16 @@
-"""Mirror of the evaluation half of the reference's model/shape_engine.py::Runner
-(:335-523): build the graph, restore a checkpoint, loop a test loader through
-Graph.forward + eval_metrics, gather the per-sample metrics over the ranks, write the
-reference's result files.  Training (:248-297) is not built."""
+"""Mirror of the reference's model/shape_engine.py::Runner: build the graph, restore a checkpoint,
+TRAIN it (setup_optimizer :85-136, train :186-199, train_epoch :201-246, train_iteration :248-297)
+and evaluate it (:335-523: test loader -> Graph.forward + eval_metrics -> per-sample metrics
+gathered over the ranks -> the reference's result files).
+
+Training runs one process per GPU: Graph.forward(training=True) on the HIP autograd path, gradients
+averaged over the ranks by parallel.GradReducer (bucketed RCCL all-reduce under the backward pass -
+the role torch DDP has in the reference), one fused AdamW launch (zeroshape_amd/optim.py) with the
+reference's four parameter groups.  Not rebuilt (control plane): tensorboard
+scalars, visual dumps, AMP (optim.amp is false in options/shape.yaml and the path is fp32)."""
 import os
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -16,6 +23,15 @@ class Runner:
     def __init__(self, opt):
         self.opt = opt
         self.test_data = self.test_loader = None
+        self.train_data = self.train_loader = None
+        self.reducer = None
+        self.ep = self.it = 0
+        self.best_val, self.best_ep = float("inf"), 0
+        self.epoch_start = self.iter_start = 0
+        world = getattr(opt, "world_size", 1) or 1
+        if world > 1 and "batch_size" in opt and not getattr(opt, "_batch_divided", False):
+            opt.batch_size = opt.batch_size // world                      # :33
+            opt._batch_divided = True
 
     def load_dataset(self, opt, eval_split="test", dataset=None):
         """:52-81 (test side): `dataset` defaults to the analytic stand-in, sharded over the ranks
@@ -28,13 +44,134 @@ class Runner:
         self.test_loader = torch.utils.data.DataLoader(self.test_data, batch_size=opt.eval.batch_size, shuffle=False,
                                                        sampler=sampler, num_workers=0, drop_last=False)
 
+    def load_train_dataset(self, opt, dataset=None):
+        """:52-58 (train side): shuffled, drop_last, DistributedSampler when world_size > 1."""
+        from ..data import synthetic
+        self.train_data = dataset if dataset is not None else synthetic.Dataset(opt, split="train")
+        sampler = None
+        if getattr(opt, "world_size", 1) > 1:
+            sampler = torch.utils.data.distributed.DistributedSampler(self.train_data, shuffle=True, drop_last=True)
+        self.train_loader = torch.utils.data.DataLoader(self.train_data, batch_size=opt.batch_size,
+                                                        shuffle=sampler is None, sampler=sampler, num_workers=0,
+                                                        drop_last=True)
+        self.num_batches = len(self.train_loader)
+
     def build_networks(self, opt):
         self.graph = Graph(opt).to(opt.device).eval()
 
+    # =============================================== training ===============================================
+    def setup_optimizer(self, opt):
+        """:85-136: AdamW(betas 0.9/0.95); biases and 1-d tensors without weight decay; with a
+        trainable depth model its parameters (dpt_depth.*, intr_*) train at optim.lr_ft."""
+        from .. import parallel
+        from ..optim import FusedAdamW
+        ft_nd, ft_d, sc_nd, sc_d = [], [], [], []
+        for name, param in self.graph.named_parameters():
+            if not param.requires_grad:
+                continue
+            nodecay = param.ndim <= 1 or name.endswith(".bias")
+            if 'dpt_depth' in name or 'intr_' in name:
+                if opt.optim.fix_dpt:
+                    continue
+                (ft_nd if nodecay else ft_d).append(param)
+            else:
+                (sc_nd if nodecay else sc_d).append(param)
+        wd = opt.optim.weight_decay
+        if opt.optim.fix_dpt:
+            groups = [{'params': sc_nd, 'lr': opt.optim.lr, 'weight_decay': 0.},
+                      {'params': sc_d, 'lr': opt.optim.lr, 'weight_decay': wd}]
+        else:
+            groups = [{'params': ft_nd, 'lr': opt.optim.lr_ft, 'weight_decay': 0.},
+                      {'params': ft_d, 'lr': opt.optim.lr_ft, 'weight_decay': wd},
+                      {'params': sc_nd, 'lr': opt.optim.lr, 'weight_decay': 0.},
+                      {'params': sc_d, 'lr': opt.optim.lr, 'weight_decay': wd}]
+        self.optim = FusedAdamW(groups, betas=(0.9, 0.95))
+        if opt.optim.sched:
+            self.sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.optim, opt.max_epoch)
+        if opt.optim.amp:
+            raise NotImplementedError("optim.amp: the HIP training path is fp32 (options/shape.yaml:95 amp false)")
+        if getattr(opt, "world_size", 1) > 1:
+            self.reducer = parallel.GradReducer(self.graph.parameters(),
+                                                bucket_mb=getattr(opt.optim, "bucket_mb", 64.0))
+
+    def train(self, opt):
+        """:186-199."""
+        self.ep = self.epoch_start
+        self.it = self.iter_start
+        self.graph.train()
+        for self.ep in range(self.epoch_start, opt.max_epoch):
+            self.train_epoch(opt)
+        if getattr(opt, "output_path", None) and self._rank() == 0:
+            self.save_checkpoint(opt, ep=self.ep, it=self.it, best_val=self.best_val, best_ep=self.best_ep, latest=True)
+
+    def train_epoch(self, opt):
+        """:201-246."""
+        if isinstance(self.train_loader.sampler, torch.utils.data.distributed.DistributedSampler):
+            self.train_loader.sampler.set_epoch(self.ep)
+        self.graph.train()
+        for batch in self.train_loader:
+            var = edict(batch)
+            opt.H, opt.W = opt.image_size
+            var = util.move_to_device(var, opt.device)
+            self.train_iteration(opt, var)
+        if opt.optim.sched:
+            self.sched.step()
+        if self.test_loader is not None and (self.ep + 1) % opt.freq.eval == 0:
+            current_val = self.evaluate(opt, ep=self.ep + 1, training=True)["cd"]
+            self.graph.train()
+            if current_val < self.best_val and self._rank() == 0:
+                self.best_val, self.best_ep = current_val, self.ep + 1
+                if getattr(opt, "output_path", None):
+                    self.save_checkpoint(opt, ep=self.ep, it=self.it, best_val=self.best_val, best_ep=self.best_ep,
+                                         best=True, latest=True)
+
+    def summarize_loss(self, opt, var, loss, non_act_loss_key=[]):
+        """:323-333."""
+        loss_all = 0.
+        assert "all" not in loss
+        for key in loss:
+            assert key in opt.loss_weight
+            if opt.loss_weight[key] is not None:
+                loss_all = loss_all + float(opt.loss_weight[key]) * loss[key].mean()
+        loss.update(all=loss_all)
+        return loss
+
+    def train_iteration(self, opt, var, batch_progress=None):
+        """:248-297 without its per-iteration barrier (the all-reduce already orders the ranks) and
+        without the tensorboard / visualiser calls."""
+        var, loss = self.graph.forward(opt, var, training=True, get_loss=True)
+        loss = self.summarize_loss(opt, var, loss)
+        loss_scaled = loss.all / opt.optim.accum
+        loss_scaled.backward()
+        if (self.it + 1) % opt.optim.accum == 0:
+            if self.reducer is not None:
+                self.reducer.finish()
+            if opt.optim.clip_norm:
+                self.optim.clip_grad_norm_(opt.optim.clip_norm)
+            self.optim.step()
+            self.optim.zero_grad()
+        self.it += 1
+        return loss
+
+    def save_checkpoint(self, opt, ep=0, it=0, best_val=np.inf, best_ep=1, latest=False, best=False):
+        """:525-529."""
+        util.save_checkpoint(opt, self, ep=ep, it=it, best_val=best_val, best_ep=best_ep, latest=latest, best=best)
+
+    @staticmethod
+    def _rank():
+        return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
     def restore_checkpoint(self, opt, best=False, evaluate=False):
-        """:176-190: `opt.load` names a checkpoint written by the reference or by save_checkpoint."""
-        if getattr(opt, "load", None):
+        """:138-151: `opt.resume` continues from <output_path>/latest.ckpt (graph + optimiser state);
+        `opt.load` names a checkpoint written by the reference or by save_checkpoint."""
+        epoch_start, iter_start = None, None
+        if getattr(opt, "resume", False):
+            epoch_start, iter_start, self.best_val, self.best_ep = util.restore_checkpoint(
+                opt, self, resume=opt.resume, best=best, evaluate=evaluate)
+        elif getattr(opt, "load", None):
             util.restore_checkpoint(opt, self, load_name=opt.load)
+        self.epoch_start = epoch_start or 0
+        self.iter_start = iter_start or 0
 
     @torch.no_grad()
     def evaluate_batch(self, opt, var, ep=None, it=None, single_gpu=False):
@@ -48,6 +185,7 @@ class Runner:
         rank 0 with `opt.output_path`, writes <dataset>_full_results.txt / quantitative_<dataset>.txt /
         cd_cat.txt in the reference's formats."""
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        self.graph.eval()                                                    # :337
         cd_accs, cd_comps, f_scores, cats, ids = [], [], [], [], []
         for it, batch in enumerate(self.test_loader):
             var = self.evaluate_batch(opt, edict(batch), ep, it)

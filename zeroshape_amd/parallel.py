@@ -125,3 +125,125 @@ def gather_sample_rows(ids, tensors, group=None):
     keep = torch.ones_like(ids, dtype=torch.bool)
     keep[1:] = ids[1:] != ids[:-1]                      # first occurrence of every sample index
     return ids[keep], [t[keep] for t in tensors]
+
+
+# =============================================================================================
+# Data-parallel training: bucketed gradient averaging overlapped with the backward pass
+# =============================================================================================
+def hip_pack(entries, scale, device):
+    """Default bucket packer: ONE zs_copy_multi launch copies `scale * grad` of every tensor of a
+    bucket into its slot of the flat buffer.  entries: [(dst_ptr, src_ptr, numel)]."""
+    from . import _lib
+    from .optim import build_table
+    lib = _lib.load()
+    tab, ct, cs, n = build_table([(d, s, 0, 0, k, 0.0, 0.0) for d, s, k in entries], device)
+    with torch.cuda.device(device):
+        _lib.check(lib.zs_copy_multi(_lib.ptr(tab), _lib.ptr(ct), _lib.ptr(cs), n, float(scale),
+                                     _lib.current_stream_ptr(device)), "zs_copy_multi")
+
+
+class GradReducer(object):
+    """What torch DDP does for the reference (model/shape_engine.py:83, find_unused_parameters):
+    average the gradients over the ranks, in buckets, while the backward pass is still running.
+
+    * Parameters are bucketed in REVERSE registration order (roughly the order the backward pass
+      produces them), `bucket_mb` per bucket.  RCCL's ring all-reduce over xGMI is per-link bound
+      (~153 GB/s): buckets are large (default 64 MB, ~12 for the 0.78 GB of
+      fp32 gradients) so the per-collective latency is paid a dozen times, not 600.
+    * A post-accumulate hook per parameter counts a bucket down; the last gradient of a bucket
+      packs the bucket (one kernel: grads * 1/world -> flat buffer) and issues an ASYNC all_reduce,
+      which RCCL runs on its own stream under the rest of the backward pass.
+    * finish() (after loss.backward()) flushes buckets that stayed incomplete, waits, and points
+      every p.grad at its slice of the reduced flat buffer (no copy back).
+    * Parameters that receive no gradient (the ViT's unused `norm` / `head`, vit.py:57-154) are
+      discovered in the first iteration - which therefore reduces after the backward pass, without
+      overlap - and left with grad None, as DDP leaves globally unused parameters.
+
+    pack_fn(entries, scale, device) copies gradients into the flat buffer; the default is the HIP
+    multi-tensor kernel, CPU tests inject a torch one."""
+
+    def __init__(self, params, group=None, bucket_mb=64.0, pack_fn=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group, self.bucket_bytes = group, int(bucket_mb * 2 ** 20)
+        self.pack_fn = pack_fn or hip_pack
+        self.rank, self.world = world(group)
+        self.buckets = None            # built after the first backward pass
+        self.works = []
+        self._hooks = []
+
+    # ---- bucket layout ----
+    def _build(self, used):
+        order = [p for p in reversed(self.params) if id(p) in used]
+        self.buckets, cur, size = [], [], 0
+        for p in order:
+            nbytes = p.numel() * 4
+            if cur and size + nbytes > self.bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size += nbytes
+        if cur:
+            self.buckets.append(cur)
+        self.flat, self.slot, self.pending = [], {}, []
+        for bi, plist in enumerate(self.buckets):
+            total = sum(p.numel() for p in plist)
+            flat = torch.zeros(total, dtype=torch.float32, device=plist[0].device)
+            off = 0
+            for p in plist:
+                self.slot[id(p)] = (bi, off)
+                off += p.numel()
+            self.flat.append(flat)
+            self.pending.append(len(plist))
+        for p in order:
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def _launch(self, bi):
+        plist, flat = self.buckets[bi], self.flat[bi]
+        entries = []
+        missing = False
+        for p in plist:
+            _, off = self.slot[id(p)]
+            if p.grad is None:
+                missing = True
+                continue
+            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            entries.append((flat.data_ptr() + 4 * off, g.data_ptr(), p.numel()))
+            p.grad = g
+        if missing:
+            flat.zero_()
+        self.pack_fn(entries, 1.0 / self.world, flat.device)
+        self.works.append(dist.all_reduce(flat, group=self.group, async_op=True))
+        self.pending[bi] = -1
+
+    def _on_grad(self, p):
+        bi, _ = self.slot[id(p)]
+        self.pending[bi] -= 1
+        if self.pending[bi] == 0:
+            self._launch(bi)
+
+    # ---- per-iteration API ----
+    def finish(self):
+        """Call after backward(): all gradients averaged over the ranks when it returns."""
+        if self.world == 1:
+            return
+        if self.buckets is None:
+            self._build({id(p) for p in self.params if p.grad is not None})
+            for bi in range(len(self.buckets)):
+                self._launch(bi)
+        else:
+            for bi in range(len(self.buckets)):
+                if self.pending[bi] >= 0:       # a gradient did not arrive this time: flush with zeros
+                    self._launch(bi)
+        for w in self.works:
+            w.wait()
+        self.works = []
+        for bi, plist in enumerate(self.buckets):
+            for p in plist:
+                _, off = self.slot[id(p)]
+                p.grad = self.flat[bi][off:off + p.numel()].view_as(p)
+            self.pending[bi] = len(plist)
+
+    def close(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

@@ -82,26 +82,45 @@ def load_checkpoint(opt, model, load_name):
     return None, None, None, None
 
 
+def resume_checkpoint(opt, model, best):
+    """utils/util.py:212-226: latest.ckpt / best.ckpt of opt.output_path -> graph (strict) plus every
+    training-state attribute of the runner named optim* / sched* / scaler* that the file holds."""
+    load_name = "{0}/best.ckpt".format(opt.output_path) if best else "{0}/latest.ckpt".format(opt.output_path)
+    checkpoint = torch.load(load_name, map_location="cpu")
+    _bare_graph(model).load_state_dict(checkpoint["graph"], strict=True)
+    from ..nn import autograd
+    autograd.bump_generation()
+    for key in model.__dict__:
+        if key.split("_")[0] in ["optim", "sched", "scaler"] and key in checkpoint:
+            getattr(model, key).load_state_dict(checkpoint[key])
+    ep, it = checkpoint["epoch"], checkpoint["iter"]
+    best_val, best_ep = checkpoint["best_val"], checkpoint["best_ep"] if "best_ep" in checkpoint else 0
+    return ep, it, best_val, best_ep
+
+
 def restore_checkpoint(opt, model, load_name=None, resume=False, best=False, evaluate=False):
-    """utils/util.py:241-250 (loading only: resuming needs the optimiser state of training,
-    which is not built)."""
+    """utils/util.py:241-250."""
     assert not (load_name is not None and resume)
     if resume:
-        raise NotImplementedError("resume_checkpoint restores optimiser state; training is not built")
+        return resume_checkpoint(opt, model, best)
     return load_checkpoint(opt, model, load_name)
 
 
 def save_checkpoint(opt, model, ep, it, best_val, best_ep, latest=False, best=False, children=None):
-    """utils/util.py:252-277: the same {epoch, iter, best_val, best_ep, graph} layout, written to
-    <output_path>/latest.ckpt (and best.ckpt / checkpoint/ep<N>.ckpt)."""
+    """utils/util.py:252-277: {epoch, iter, best_val, best_ep, graph} + the state of every runner
+    attribute named optim* / sched* / scaler*, written to <output_path>/latest.ckpt (and best.ckpt /
+    checkpoint/ep<N>.ckpt)."""
     import os
     import shutil
     os.makedirs("{0}/checkpoint".format(opt.output_path), exist_ok=True)
     sd = _bare_graph(model).state_dict()
     if children is not None:
         sd = {k: v for k, v in sd.items() if k.startswith(children)}
-    torch.save(dict(epoch=ep, iter=it, best_val=best_val, best_ep=best_ep, graph=sd),
-               "{0}/latest.ckpt".format(opt.output_path))
+    checkpoint = dict(epoch=ep, iter=it, best_val=best_val, best_ep=best_ep, graph=sd)
+    for key in model.__dict__:
+        if key.split("_")[0] in ["optim", "sched", "scaler"]:
+            checkpoint.update({key: getattr(model, key).state_dict()})
+    torch.save(checkpoint, "{0}/latest.ckpt".format(opt.output_path))
     if best:
         shutil.copy("{0}/latest.ckpt".format(opt.output_path), "{0}/best.ckpt".format(opt.output_path))
     if not latest:
