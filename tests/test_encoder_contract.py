@@ -75,10 +75,13 @@ def test_unsupported_configurations_raise():
         Graph(opt)
     g = Graph(make_opt())
     var = edict(dict(idx=[0], rgb_input_map=torch.zeros(1, 3, 224, 224), mask_input_map=torch.zeros(1, 1, 224, 224)))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):                       # CPU tensors: there is no CPU path, training or not
         g.forward(make_opt(), var, training=True)
-    with pytest.raises(ValueError):                       # CPU tensors: there is no CPU path
+    with pytest.raises(ValueError):
         g.forward(make_opt(), var, training=False, get_loss=False)
+    from zeroshape_amd.utils.loss import Loss
+    with pytest.raises(NotImplementedError):              # losses of options/depth.yaml: not on the HIP path yet
+        Loss(make_opt()).depth_loss(torch.zeros(1, 1, 2, 2), torch.zeros(1, 1, 2, 2), torch.zeros(1, 1, 2, 2))
     with pytest.raises(NotImplementedError):              # train mode: BN folding is eval-only
         g.dpt_depth.train().packed("cpu")
 
