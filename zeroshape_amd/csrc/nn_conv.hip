@@ -25,6 +25,7 @@
 
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -337,7 +338,8 @@ extern "C" int zs_conv2d_nhwc(const float *in, const float *packed_w, const floa
     a.dil = (flags & ZS_CONV_IN_DILATE2) ? 2 : 1;
     // fewer than ~3/4 of a wave of 128x128 tiles over the 256 CUs: use the small-tile split-K variant
     const long long big_tiles = ((M + BM - 1) / BM) * (a.CoutPad / BN);
-    const bool small = (flags & ZS_CONV_FORCE_SMALL) || (!(flags & ZS_CONV_FORCE_LARGE) && big_tiles < 192);
+    static const long long big_min = getenv("ZS_CONV_BIG_MIN") ? atoll(getenv("ZS_CONV_BIG_MIN")) : 192;
+    const bool small = (flags & ZS_CONV_FORCE_SMALL) || (!(flags & ZS_CONV_FORCE_LARGE) && big_tiles < big_min);
     if (small) {
         const dim3 grid((unsigned)((M + SM - 1) / SM), (unsigned)((Cout + SN - 1) / SN));
         hipLaunchKernelGGL(conv_gemm_small_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);

@@ -13,6 +13,7 @@
 
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -253,7 +254,8 @@ extern "C" int zs_pack_conv_weight(const float *w, float *packed, int Cout, int 
 
 static int wgrad_splits(long long M, int CoutP, int K) {
     const long long tiles = (long long)((CoutP + WM - 1) / WM) * ((K + WN - 1) / WN);
-    long long splits = (768 + tiles - 1) / tiles;                 // aim at ~3 workgroups per CU
+    static const long long target = getenv("ZS_WGRAD_TARGET") ? atoll(getenv("ZS_WGRAD_TARGET")) : 768;
+    long long splits = (target + tiles - 1) / tiles;              // aim at ~3 workgroups per CU
     const long long max_by_pixels = (M + 127) / 128;              // at least 128 pixels per split
     if (splits > max_by_pixels) splits = max_by_pixels;
     if (splits < 1) splits = 1;

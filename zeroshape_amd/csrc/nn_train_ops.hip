@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__res
 }
 
 // ---- LayerNorm backward: wave per row for dx, per-workgroup partial dgamma / dbeta ----
-constexpr int LN_ROWS = 64;      // rows per workgroup (16 per wave)
+constexpr int LN_ROWS = 16;      // rows per workgroup (4 per wave): many small workgroups, the rows are latency bound
 constexpr int LN_MAXQ = 16;      // C <= 64 * LN_MAXQ
 __global__ __launch_bounds__(256) void layer_norm_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                              const float *__restrict__ gamma, float *__restrict__ dx,

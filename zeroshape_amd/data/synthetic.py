@@ -26,8 +26,13 @@ class Dataset(torch.utils.data.Dataset):
     label2cat = ["ellipsoid"]
     cat2label = {"ellipsoid": 0}
 
-    def __init__(self, opt, split="test", n_items=8, load_3D=True, n_points=16384, seed=0):
+    def __init__(self, opt, split="test", n_items=None, load_3D=True, n_points=16384, seed=0):
         super().__init__()
+        import os
+        if n_items is None:            # launched through train.py / evaluate.py: size from the environment
+            n_items = int(os.environ.get("ZS_SYNTHETIC_ITEMS", "8"))
+        if split == "train":
+            seed += 1
         self.opt, self.split, self.load_3D, self.n_points, self.seed = opt, split, load_3D, n_points, seed
         self.list = list(range(n_items))
 

@@ -29,25 +29,44 @@ class Runner:
         self.best_val, self.best_ep = float("inf"), 0
         self.epoch_start = self.iter_start = 0
         world = getattr(opt, "world_size", 1) or 1
-        if world > 1 and "batch_size" in opt and not getattr(opt, "_batch_divided", False):
-            opt.batch_size = opt.batch_size // world                      # :33
-            opt._batch_divided = True
+        if world > 1:
+            if "port" in opt and isinstance(opt.device, int):             # launched like train.py:14-16 does
+                util.setup(opt.device, world, opt.port)                    # :32
+            if "batch_size" in opt and not getattr(opt, "_batch_divided", False):
+                opt.batch_size = opt.batch_size // world                  # :33
+                opt._batch_divided = True
 
-    def load_dataset(self, opt, eval_split="test", dataset=None):
-        """:52-81 (test side): `dataset` defaults to the analytic stand-in, sharded over the ranks
-        with a DistributedSampler when world_size > 1."""
-        from ..data import synthetic
-        self.test_data = dataset if dataset is not None else synthetic.Dataset(opt, split=eval_split)
+    def load_dataset(self, opt, eval_split="test", dataset=None, train_dataset=None):
+        """:52-81.  Datasets are the modules data.<opt.data.dataset_train|dataset_test> (importlib,
+        like the reference); this repository ships data.synthetic (an analytic stand-in, the real
+        renders live on Dropbox).  `dataset` / `train_dataset` inject Dataset objects directly.
+        The train side is loaded when the options describe a training run (batch_size present)."""
+        import importlib
+        pkg = __name__.rsplit(".", 2)[0] + ".data."
+        if dataset is None:
+            dataset = importlib.import_module(pkg + opt.data.dataset_test).Dataset(opt, split=eval_split)
+        self.test_data = dataset
         sampler = None
         if getattr(opt, "world_size", 1) > 1:
             sampler = torch.utils.data.distributed.DistributedSampler(self.test_data, shuffle=False, drop_last=False)
         self.test_loader = torch.utils.data.DataLoader(self.test_data, batch_size=opt.eval.batch_size, shuffle=False,
                                                        sampler=sampler, num_workers=0, drop_last=False)
+        if train_dataset is not None or ("batch_size" in opt and "dataset_train" in opt.data and "optim" in opt):
+            if train_dataset is None:
+                train_dataset = importlib.import_module(pkg + opt.data.dataset_train).Dataset(opt, split="train")
+            self.load_train_dataset(opt, dataset=train_dataset)
+
+    def setup_visualizer(self, opt, test=False):
+        """:153-165: tensorboard / html dumps are not rebuilt (control plane); kept so the reference's
+        train.py / evaluate.py call sequence runs."""
+        return None
 
     def load_train_dataset(self, opt, dataset=None):
         """:52-58 (train side): shuffled, drop_last, DistributedSampler when world_size > 1."""
         from ..data import synthetic
         self.train_data = dataset if dataset is not None else synthetic.Dataset(opt, split="train")
+        if opt.batch_size < 1:
+            raise ValueError("batch_size %d per process: the global batch must be >= the world size" % opt.batch_size)
         sampler = None
         if getattr(opt, "world_size", 1) > 1:
             sampler = torch.utils.data.distributed.DistributedSampler(self.train_data, shuffle=True, drop_last=True)

@@ -126,3 +126,47 @@ def save_checkpoint(opt, model, ep, it, best_val, best_ep, latest=False, best=Fa
     if not latest:
         shutil.copy("{0}/latest.ckpt".format(opt.output_path),
                     "{0}/checkpoint/ep{1}.ckpt".format(opt.output_path, ep))
+
+
+# ---- process plumbing used by train.py / evaluate.py and the engines (utils/util.py:304-356) ----
+def toggle_grad(model, requires_grad):
+    for p in model.parameters():
+        p.requires_grad_(requires_grad)
+
+
+def is_port_in_use(port):
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        return s.connect_ex(('localhost', port)) == 0
+
+
+def setup(rank, world_size, port_no):
+    """One process per GPU over RCCL ("nccl" is RCCL on ROCm).  Rendezvous on 127.0.0.1; under
+    torchrun (RANK / MASTER_* already in the environment) those settings win."""
+    import os
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(port_no))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world_size)
+
+
+def cleanup():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def print_eval(opt, loss=None, chamfer=None, depth_metrics=None):
+    """utils/util.py:140-151."""
+    message = "[eval] "
+    if loss is not None:
+        message += "loss:{:.3e}".format(float(loss.all))
+    if chamfer is not None:
+        message += " chamfer:{:.4f}|{:.4f}|{:.4f}".format(chamfer[0], chamfer[1], (chamfer[0] + chamfer[1]) / 2)
+    if depth_metrics is not None:
+        message += ", ".join("{}:{:.4f}".format(k, v) for k, v in depth_metrics.items())
+    print(message)
