@@ -212,9 +212,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 // float4 per lane = 4 channels of one tap), so a layer launches (M/32)*(Cout/64) workgroups and
 // a wave's dependent MFMA chain is K/4 long instead of K.  Partials are summed through LDS in a
 // fixed order (deterministic), then the same fused epilogue.
-constexpr int SM = 32, SN = 64, SU = 4;       // tile, and t-steps (8 k each) per prefetch chunk
+constexpr int SM = 32, SU = 4;       // tile rows, and t-steps (8 k each) per prefetch chunk
+// NJ = 32-column MFMA tiles per wave: the tile is 32 x 32*NJ (NJ = 1 when even 32x64 tiles leave CUs idle)
 
+template <int NJ>
 __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
+    constexpr int SN = 32 * NJ;
     __shared__ float part[4][SM][SN + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, half = lane >> 5;
     const int m0 = blockIdx.x * SM, n0 = blockIdx.y * SN;
@@ -243,14 +246,14 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
 
     const int T = (a.K + BK - 1) / BK * 2;                 // t-steps of 8 k (= 2 weight quads)
     const int per = (T + 3) / 4, t_begin = wave * per, t_end = min(T, t_begin + per);
-    f32x16 acc[2];
+    f32x16 acc[NJ];
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < NJ; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
 
     AQuad fa[2][SU];
-    f32x4 fb[2][SU][2];
+    f32x4 fb[2][SU][NJ];
     TapIter it;                                   // this lane's k = 8 t + 4 half, fetched in t order
     it.init(8 * t_begin + 4 * half, a.Cin, a.kw);
     const int adv_tap = 8 / a.Cin, adv_c = 8 % a.Cin;
@@ -266,8 +269,8 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
             fa[buf][u].ok = fa[buf][u].ok && t < t_end;
             it.advance(adv_tap, adv_c, a.Cin, a.kw);
             const int kq = min(2 * t + half, kq_last);
-            fb[buf][u][0] = wlane[(size_t)kq * a.CoutPad];
-            fb[buf][u][1] = wlane[(size_t)kq * a.CoutPad + 32];
+#pragma unroll
+            for (int j = 0; j < NJ; j++) fb[buf][u][j] = wlane[(size_t)kq * a.CoutPad + 32 * j];
         }
     };
     auto consume = [&](int buf) {
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
 #pragma unroll
             for (int s = 0; s < 4; s++)
 #pragma unroll
-                for (int j = 0; j < 2; j++)
+                for (int j = 0; j < NJ; j++)
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], fb[buf][u][j][s], acc[j], 0, 0, 0);
         }
     };
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
     }
     // D[row = 8*(r/4) + 4*half + r%4][col = l32] -> LDS, then a fixed-order 4-way sum
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < NJ; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) part[wave][8 * (r >> 2) + 4 * half + (r & 3)][32 * j + l32] = acc[j][r];
     __syncthreads();
@@ -341,8 +344,15 @@ extern "C" int zs_conv2d_nhwc(const float *in, const float *packed_w, const floa
     static const long long big_min = getenv("ZS_CONV_BIG_MIN") ? atoll(getenv("ZS_CONV_BIG_MIN")) : 192;
     const bool small = (flags & ZS_CONV_FORCE_SMALL) || (!(flags & ZS_CONV_FORCE_LARGE) && big_tiles < big_min);
     if (small) {
-        const dim3 grid((unsigned)((M + SM - 1) / SM), (unsigned)((Cout + SN - 1) / SN));
-        hipLaunchKernelGGL(conv_gemm_small_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+        static const long long narrow_below = getenv("ZS_CONV_NARROW_BELOW") ? atoll(getenv("ZS_CONV_NARROW_BELOW")) : 384;
+        const long long wide = ((M + SM - 1) / SM) * ((Cout + 63) / 64);
+        if (wide < narrow_below) {            // 32x32 tiles: twice the workgroups for the smallest problems
+            const dim3 grid((unsigned)((M + SM - 1) / SM), (unsigned)((Cout + 31) / 32));
+            hipLaunchKernelGGL(conv_gemm_small_kernel<1>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+        } else {
+            const dim3 grid((unsigned)((M + SM - 1) / SM), (unsigned)((Cout + 63) / 64));
+            hipLaunchKernelGGL(conv_gemm_small_kernel<2>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+        }
     } else {
         const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(a.CoutPad / BN));
         hipLaunchKernelGGL(conv_gemm_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);

@@ -86,13 +86,18 @@ __global__ __launch_bounds__(256) void column_partial_kernel(const float *__rest
     __syncthreads();
     if (ry == 0 && c < C) partial[(size_t)blockIdx.y * C + c] = (lds[0][cx] + lds[1][cx]) + (lds[2][cx] + lds[3][cx]);
 }
+// out[c] = scale * sum_k partial[k * stride + c]: 64 columns per workgroup, the chunks strided over 4
+// row-lanes and combined in a fixed order
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partial, float *__restrict__ out,
                                                               int chunks, int C, int stride, float scale) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float lds[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6, c = blockIdx.x * 64 + cx;
     float s = 0.f;
-    for (int k = 0; k < chunks; k++) s += partial[(size_t)k * stride + c];
-    out[c] = s * scale;
+    if (c < C)
+        for (int k = ry; k < chunks; k += 4) s += partial[(size_t)k * stride + c];
+    lds[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && c < C) out[c] = ((lds[0][cx] + lds[1][cx]) + (lds[2][cx] + lds[3][cx])) * scale;
 }
 
 // ---- LayerNorm backward: wave per row for dx, per-workgroup partial dgamma / dbeta ----
@@ -307,7 +312,7 @@ extern "C" int zs_column_sum(const float *x, float *out, int rows, int C, float 
     float *partial = static_cast<float *>(workspace);
     hipLaunchKernelGGL(column_partial_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, S(stream), x, partial, rows, C,
                        per);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, S(stream), partial, out, chunks, C,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 63) / 64), dim3(256), 0, S(stream), partial, out, chunks, C,
                        C, scale);
     return zs::check_launch("zs_column_sum") ? 1 : 0;
 }
@@ -326,9 +331,9 @@ extern "C" int zs_layer_norm_bwd(const float *dy, const float *x, const float *g
     hipLaunchKernelGGL(layer_norm_bwd_kernel, dim3(wgs), dim3(256), 8 * C * sizeof(float), S(stream), dy, x, gamma, dx,
                        partial, rows, C, eps);
     // partial is [wg][2][C]: rows of stride 2C, dgamma in the first half, dbeta in the second
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, S(stream), partial, dgamma, wgs, C,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 63) / 64), dim3(256), 0, S(stream), partial, dgamma, wgs, C,
                        2 * C, 1.0f);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, S(stream), partial + C, dbeta, wgs,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 63) / 64), dim3(256), 0, S(stream), partial + C, dbeta, wgs,
                        C, 2 * C, 1.0f);
     return zs::check_launch("zs_layer_norm_bwd") ? 1 : 0;
 }
