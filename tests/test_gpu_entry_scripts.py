@@ -58,3 +58,33 @@ def test_depth_engine_evaluates(tmp_path, encoder_sd):
     assert var.seen_points_pred.shape == var.seen_points_gt.shape == (2, 224 * 224, 3)
     with pytest.raises(NotImplementedError):
         r.train(opt)
+
+
+def test_demo_script_shape_and_depth(tmp_path, encoder_sd, seeded_sd):
+    """demo.py with the reference's command line on one synthetic RGBA example (configs[0] of
+    BASELINE.json, run on the GPU path: there is no CPU path to run it on)."""
+    from PIL import Image
+    opt = options.set(options.parse_arguments(["--yaml=%s/options/shape.yaml" % ROOT, "--output_root=%s" % tmp_path]),
+                      need_gpu=False)
+    item = Dataset(opt, n_items=1)[0]
+    os.makedirs(tmp_path / "data" / "images")
+    os.makedirs(tmp_path / "data" / "masks")
+    rgb = (item["rgb_input_map"].numpy().transpose(1, 2, 0) * 255).astype(np.uint8)
+    Image.fromarray(rgb).save(tmp_path / "data" / "images" / "blob.png")
+    Image.fromarray((item["mask_input_map"][0].numpy() * 255).astype(np.uint8)).save(tmp_path / "data" / "masks" / "blob.png")
+    full = dict(encoder_sd)
+    full.update({"impl_network." + k: v for k, v in seeded_sd.items()})
+    torch.save(dict(epoch=0, iter=0, best_val=1.0, best_ep=0, graph=full), tmp_path / "shape.ckpt")
+    run("demo.py", "--yaml=options/shape.yaml", "--task=shape", "--datadir=%s/data" % tmp_path, "--eval.vox_res=32",
+        "--ckpt=%s/shape.ckpt" % tmp_path, "--output_root=%s" % tmp_path)
+    preds = tmp_path / "data" / "preds"
+    assert {p.name for p in preds.iterdir()} == {"blob_image_input.png", "blob_mask_input.png", "blob_depth_est.png",
+                                                  "blob_mesh.obj"}
+    assert Image.open(preds / "blob_image_input.png").size == (224, 224)
+    obj = open(preds / "blob_mesh.obj").read().split("\n")
+    assert obj[0].startswith("# zeroshape_amd mesh")            # random weights: the surface may be empty, the file is not
+    depth_sd = {k: v for k, v in full.items() if k.startswith(("dpt_depth.", "intr_head.", "intr_proj."))}
+    torch.save(dict(epoch=0, iter=0, best_val=1.0, best_ep=0, graph=depth_sd), tmp_path / "depth.ckpt")
+    run("demo.py", "--yaml=options/depth.yaml", "--task=depth", "--datadir=%s/data" % tmp_path,
+        "--ckpt=%s/depth.ckpt" % tmp_path, "--output_root=%s" % tmp_path)
+    assert (preds / "blob_depth_est.png").exists() and not (preds / "blob_mesh.obj").exists()

@@ -97,3 +97,39 @@ def test_train_checkpoint_resume_evaluate(tmp_path, encoder_sd, seeded_sd):
     # evaluation sees the trained weights (the packed inference programs are refreshed)
     out = r.evaluate(opt)
     assert np.isfinite(out["cd"]) and out["cd"] > 0
+
+
+def test_grad_reducer_rehearsal_on_one_gpu(tmp_path, encoder_sd, seeded_sd):
+    """The multi-GPU gradient path on one GPU: an RCCL group of one rank, GradReducer(always=True) -
+    HIP bucket packing (zs_copy_multi), async all_reduce on RCCL's stream under the backward pass,
+    p.grad re-pointed at the buckets, fused AdamW reading them - gives the same weights as the
+    plain single-GPU step."""
+    import torch.distributed as dist
+    from zeroshape_amd import parallel
+    from zeroshape_amd.utils import util
+    from zeroshape_amd.utils.options import EasyDict as edict
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        results = []
+        for use_reducer in (False, True):
+            opt = train_opt(tmp_path, "--optim.fix_dpt")
+            r = make_runner(opt, encoder_sd, seeded_sd, n_train=4)
+            if use_reducer:
+                r.reducer = parallel.GradReducer(r.graph.parameters(), bucket_mb=16.0, always=True)
+            r.graph.train()
+            batch = next(iter(torch.utils.data.DataLoader(r.train_data, batch_size=4, shuffle=False)))
+            for it in range(3):                          # iteration 0 discovers the used parameters, 1-2 overlap
+                torch.manual_seed(11 + it)
+                var = util.move_to_device(edict({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}),
+                                          opt.device)
+                r.train_iteration(opt, var)
+            if use_reducer:
+                assert len(r.reducer.buckets) >= 5 and all(p.grad is None for p in r.graph.parameters())
+                r.reducer.close()
+            results.append({k: v.detach().clone() for k, v in r.graph.state_dict().items()})
+        for k in results[0]:
+            assert torch.equal(results[0][k], results[1][k]), k
+    finally:
+        dist.destroy_process_group()

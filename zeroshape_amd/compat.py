@@ -7,8 +7,8 @@ names (utils, model, data, external) to their zeroshape_amd mirrors in sys.modul
         --yaml=options/shape.yaml
 or simply `python train.py ...` with the train.py / evaluate.py of this repository, which do that.
 
-Only names that exist here are aliased; importing anything else of the reference (utils.util_vis,
-data.pix3d, ...) fails loudly with ModuleNotFoundError instead of silently falling back.
+Only names that exist here are aliased; importing anything else of the reference (data.pix3d,
+data.ocrtoc, ...) fails loudly with ModuleNotFoundError instead of silently falling back.
 """
 import importlib
 import sys
@@ -23,6 +23,7 @@ _ALIASES = {
     "utils.loss": "zeroshape_amd.utils.loss",
     "utils.layers": "zeroshape_amd.utils.layers",
     "utils.pos_embed": "zeroshape_amd.utils.pos_embed",
+    "utils.util_vis": "zeroshape_amd.utils.util_vis",
     "model": "zeroshape_amd.model",
     "model.shape_engine": "zeroshape_amd.model.shape_engine",
     "model.depth_engine": "zeroshape_amd.model.depth_engine",

@@ -162,7 +162,10 @@ class GradReducer(object):
     pack_fn(entries, scale, device) copies gradients into the flat buffer; the default is the HIP
     multi-tensor kernel, CPU tests inject a torch one."""
 
-    def __init__(self, params, group=None, bucket_mb=64.0, pack_fn=None):
+    def __init__(self, params, group=None, bucket_mb=64.0, pack_fn=None, always=False):
+        """always=True runs the bucket / all-reduce path even in a 1-rank group (single-GPU rehearsal
+        of the multi-GPU path; the all-reduce is then the identity)."""
+        self.always = always
         self.params = [p for p in params if p.requires_grad]
         self.group, self.bucket_bytes = group, int(bucket_mb * 2 ** 20)
         self.pack_fn = pack_fn or hip_pack
@@ -224,7 +227,7 @@ class GradReducer(object):
     # ---- per-iteration API ----
     def finish(self):
         """Call after backward(): all gradients averaged over the ranks when it returns."""
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             return
         if self.buckets is None:
             self._build({id(p) for p in self.params if p.grad is not None})
