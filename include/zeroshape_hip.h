@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 11
+#define ZS_ABI_VERSION 12
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -355,6 +355,13 @@ int zs_conv2d_wgrad(const float *in, const float *dy, float *dw, void *workspace
                     int CinP, int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad_t, int pad_l,
                     int flags, float in_scale, float in_shift, int Cin, int cin0, int CinTot, int accumulate,
                     void *stream);
+/* Data gradient of a convolution with Cin <= 4 input channels (the network stems: as a GEMM it would
+ * fill 3 of 128 tile columns), direct gather form: dx [B][H][W][CinP] (padding channels zeroed) =
+ * scale * sum over the output pixels that read the input pixel of dy [B][Hout][Wout][Cout] . w
+ * (torch layout, channel sub-range [cin0, cin0+Cin) of CinTot).  Cout % 4 == 0. */
+int zs_conv2d_dgrad_small_cin(const float *dy, const float *w, float *dx, int batch, int H, int W, int CinP, int Hout,
+                              int Wout, int Cout, int kh, int kw, int stride, int pad_t, int pad_l, int Cin, int cin0,
+                              int CinTot, float scale, void *stream);
 int zs_standardize_weight(const float *w, float *out, int Cout, int n, float eps, void *stream);
 int zs_standardize_weight_bwd(const float *w, const float *grad_out, float *dw, int Cout, int n, float eps,
                               void *stream);

@@ -246,3 +246,37 @@ def test_adamw_multi_tensor_matches_torch():
         close(pm, pr, rtol=1e-6, what="param")
     sd = o_mine.state_dict()
     assert sd["state"][0]["step"] == 4 and sd["state"][0]["exp_avg"].shape == (300, 70)
+
+
+@pytest.mark.parametrize("k,stride,pad,H,Cout,std", [(7, 2, 3, 32, 64, False), (7, 2, "same", 30, 64, True), (3, 1, 1, 9, 32, False)])
+def test_stem_data_gradient_small_cin(k, stride, pad, H, Cout, std):
+    """Convolutions with 3 input channels (zero-padded to 4): the data gradient takes the direct
+    gather kernel (zs_conv2d_dgrad_small_cin), incl. TF-'SAME' padding and standardised weights."""
+    from zeroshape_amd.nn import autograd as A
+    g = torch.Generator().manual_seed(k + H)
+    x = torch.randn(2, 3, H, H + 2, generator=g)
+    w = torch.randn(Cout, 3, k, k, generator=g) * 0.2 + 0.05
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ws = wr
+    if std:
+        flat = wr.reshape(Cout, -1)
+        ws = ((flat - flat.mean(1, keepdim=True)) / torch.sqrt(flat.var(1, unbiased=False, keepdim=True) + 1e-8)).reshape(w.shape)
+    xin = xr * 0.5
+    if pad == "same":
+        Hh, Ww = x.shape[2:]
+        ph = max((-(-Hh // stride) - 1) * stride + k - Hh, 0)
+        pw = max((-(-Ww // stride) - 1) * stride + k - Ww, 0)
+        y = F.conv2d(F.pad(xin, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2)), ws, None, stride=stride)
+    else:
+        y = F.conv2d(xin, ws, None, stride=stride, padding=pad)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    x4 = torch.zeros(2, H, H + 2, 4)
+    x4[..., :3] = nhwc(x)
+    xg, wg = x4.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    yg = A.conv2d(xg, wg, None, stride=stride, padding=pad, in_scale=0.5, std_eps=1e-8 if std else None)
+    close(yg.permute(0, 3, 1, 2), y, what="forward")
+    yg.backward(nhwc(gy).cuda())
+    close(xg.grad[..., :3].permute(0, 3, 1, 2), xr.grad, what="dx")
+    assert float(xg.grad[..., 3].abs().max()) == 0
+    close(wg.grad, wr.grad, rtol=1e-4, what="dW")

@@ -228,6 +228,54 @@ __global__ __launch_bounds__(256) void std_weight_bwd_kernel(const float *__rest
         dw[(size_t)blockIdx.x * n + e] = rstd * (gr[e] - mg - (r[e] - mean) * rstd * mgx);
 }
 
+// ---- data gradient of a convolution with <= 4 input channels (the network stems) ----
+// As a GEMM this has N = 3 columns in a 128-wide tile, and at stride 2 three quarters of the
+// zero-stuffed taps are padding: 2 % useful work.  Direct form instead: one thread per input pixel
+// gathers the (at most ceil(k/s)^2) output pixels that read it; weights sit in LDS as
+// [tap][cout][4 channels] (every lane of a wave that needs an entry reads the same address).
+__global__ __launch_bounds__(256) void dgrad_small_cin_kernel(const float *__restrict__ dy, const float *__restrict__ w,
+                                                              float *__restrict__ dx, int B, int H, int W, int CinP,
+                                                              int Ho, int Wo, int Cout, int kh, int kw, int stride,
+                                                              int pad_t, int pad_l, int Cin, int cin0, int ld,
+                                                              float scale) {
+    extern __shared__ f32x4 wl[];                    // [taps][Cout]
+    const int taps = kh * kw;
+    for (int e = threadIdx.x; e < taps * Cout; e += 256) {
+        const int tap = e / Cout, co = e - tap * Cout;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < Cin; c++) v[c] = w[(size_t)co * ld + (size_t)(cin0 + c) * taps + tap];
+        wl[e] = v;
+    }
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)B * H * W;
+    if (i >= total) return;
+    const int ix = i % W, iy = (i / W) % H, b = i / W / H;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ky = 0; ky < kh; ky++) {
+        const int vy = iy + pad_t - ky;
+        if (vy < 0 || vy % stride) continue;
+        const int oy = vy / stride;
+        if (oy >= Ho) continue;
+        for (int kx = 0; kx < kw; kx++) {
+            const int vx = ix + pad_l - kx;
+            if (vx < 0 || vx % stride) continue;
+            const int ox = vx / stride;
+            if (ox >= Wo) continue;
+            const f32x4 *g = reinterpret_cast<const f32x4 *>(dy + (((size_t)b * Ho + oy) * Wo + ox) * Cout);
+            const f32x4 *wt = wl + (ky * kw + kx) * Cout;
+            for (int q = 0; q < Cout / 4; q++) {
+                const f32x4 gv = g[q];
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc += wt[4 * q + e] * gv[e];
+            }
+        }
+    }
+    f32x4 out = acc * scale;
+    for (int c = Cin; c < 4; c++) out[c] = 0.f;
+    float *o = dx + i * CinP;
+    for (int c = 0; c < CinP; c++) o[c] = out[c];
+}
+
 }  // namespace
 
 #define ZS_REQUIRE(cond, ...)            \
@@ -312,4 +360,26 @@ extern "C" int zs_standardize_weight_bwd(const float *w, const float *grad_out, 
     ZS_REQUIRE(Cout > 0 && n > 0 && w && grad_out && dw, "zs_standardize_weight_bwd: bad arguments");
     hipLaunchKernelGGL(std_weight_bwd_kernel, dim3(Cout), dim3(256), 0, S(stream), w, grad_out, dw, n, eps);
     return zs::check_launch("zs_standardize_weight_bwd") ? 1 : 0;
+}
+
+extern "C" int zs_conv2d_dgrad_small_cin(const float *dy, const float *w, float *dx, int batch, int H, int W, int CinP,
+                                         int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad_t, int pad_l,
+                                         int Cin, int cin0, int CinTot, float scale, void *stream) {
+    ZS_REQUIRE(batch >= 0 && H > 0 && W > 0 && CinP > 0 && CinP <= 4 && Cin > 0 && Cin <= CinP && Hout > 0 && Wout > 0 &&
+                   Cout > 0 && (Cout & 3) == 0 && kh > 0 && kw > 0 && stride > 0 && cin0 >= 0 && cin0 + Cin <= CinTot &&
+                   (size_t)kh * kw * Cout * 16 <= 160 * 1024,
+               "zs_conv2d_dgrad_small_cin: bad geometry (B=%d in %dx%dx%d out %dx%dx%d k %dx%d s %d; Cin <= 4, "
+               "Cout %% 4 == 0, taps*Cout*16 B of LDS)", batch, H, W, CinP, Hout, Wout, Cout, kh, kw, stride);
+    if (batch == 0) return 1;
+    ZS_REQUIRE(dy && w && dx, "zs_conv2d_dgrad_small_cin: null pointer");
+    const size_t lds = (size_t)kh * kw * Cout * sizeof(f32x4);
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(dgrad_small_cin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(dgrad_small_cin_kernel, dim3(blocks_for((size_t)batch * H * W)), dim3(256), lds, S(stream), dy, w, dx,
+                       batch, H, W, CinP, Hout, Wout, Cout, kh, kw, stride, pad_t, pad_l, Cin, cin0, CinTot * kh * kw, scale);
+    return zs::check_launch("zs_conv2d_dgrad_small_cin") ? 1 : 0;
 }

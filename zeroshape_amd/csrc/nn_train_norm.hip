@@ -71,17 +71,32 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict
     }
 }
 
+// sum of the per-chunk double partials of 64 columns: the chunks strided over 4 lanes, fixed order
+__device__ __forceinline__ void bn_sum_partials(const double *__restrict__ partial, int chunks, int C, int c, int ry,
+                                                double (*lds)[4][64], double &s, double &q) {
+    const int cx = threadIdx.x & 63;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int k = ry; k < chunks; k += 4) {
+            a += partial[((size_t)k * 2 + 0) * C + c];
+            b += partial[((size_t)k * 2 + 1) * C + c];
+        }
+    lds[0][ry][cx] = a;
+    lds[1][ry][cx] = b;
+    __syncthreads();
+    s = (lds[0][0][cx] + lds[0][1][cx]) + (lds[0][2][cx] + lds[0][3][cx]);
+    q = (lds[1][0][cx] + lds[1][1][cx]) + (lds[1][2][cx] + lds[1][3][cx]);
+}
+
 __global__ __launch_bounds__(256) void bn_stats_kernel(const double *__restrict__ partial, int chunks, int C, int rows,
                                                        float eps, float momentum, float *__restrict__ running_mean,
                                                        float *__restrict__ running_var, float *__restrict__ save_mean,
                                                        float *__restrict__ save_rstd) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int k = 0; k < chunks; k++) {
-        s += partial[((size_t)k * 2 + 0) * C + c];
-        q += partial[((size_t)k * 2 + 1) * C + c];
-    }
+    __shared__ double lds[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), ry = threadIdx.x >> 6;
+    double s, q;
+    bn_sum_partials(partial, chunks, C, c, ry, lds, s, q);
+    if (ry != 0 || c >= C) return;
     const double mean = s / rows;
     double var = q / rows - mean * mean;
     var = var < 0.0 ? 0.0 : var;
@@ -108,13 +123,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__
 
 __global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const double *__restrict__ partial, int chunks, int C,
                                                             float *__restrict__ dgamma, float *__restrict__ dbeta) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int k = 0; k < chunks; k++) {
-        s += partial[((size_t)k * 2 + 0) * C + c];
-        q += partial[((size_t)k * 2 + 1) * C + c];
-    }
+    __shared__ double lds[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), ry = threadIdx.x >> 6;
+    double s, q;
+    bn_sum_partials(partial, chunks, C, c, ry, lds, s, q);
+    if (ry != 0 || c >= C) return;
     dbeta[c] = (float)s;
     dgamma[c] = (float)q;
 }
@@ -136,57 +149,68 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restri
     if (dres) dres[i] = g;
 }
 
-// ---------------- GroupNorm backward: one workgroup per (sample, group) ----------------
+// ---------------- GroupNorm backward: one workgroup per (sample, group), two passes ----------------
+// Pass A gathers every sum at once (x, x^2, g, g x with g = gamma * masked dy, and per channel
+// dy, dy x) in double; statistics and the projections follow algebraically
+// (sum g xhat = rstd (sum g x - mean sum g)).  Pass B writes dx (and the masked dy for the residual).
+// A thread keeps ONE channel (c = tid % cg, cg a power of two <= 64) and strides over the pixels.
 constexpr int GN_BLOCK = 1024;
+__device__ __forceinline__ double gn_block_sum(double v, double *lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    double r = lds[0];
+#pragma unroll
+    for (int w = 1; w < GN_BLOCK / 64; w++) r += lds[w];
+    return r;
+}
 __global__ __launch_bounds__(GN_BLOCK) void group_norm_bwd_kernel(
     const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ y,
     const float *__restrict__ gamma, float *__restrict__ dx, float *__restrict__ dres,
     float *__restrict__ dgamma_part, float *__restrict__ dbeta_part, int HW, int C, int groups, float eps) {
-    __shared__ float lds[GN_BLOCK / 64];
-    __shared__ float col[2][64][17];                  // per-channel sums: up to 64 channels per group
-    const int b = blockIdx.x / groups, g = blockIdx.x % groups, cg = C / groups, n = HW * cg;
-    const size_t base = (size_t)b * HW * C + (size_t)g * cg;
-    auto at = [&](int e) -> size_t { return base + (size_t)(e / cg) * C + (e % cg); };
-    auto grad = [&](size_t o) -> float { return (y && !(y[o] > 0.f)) ? 0.f : dy[o]; };
-    float s = 0.f;
-    for (int e = threadIdx.x; e < n; e += GN_BLOCK) s += x[at(e)];
-    const float mean = block_sum<GN_BLOCK>(s, lds) / n;
-    float q = 0.f;
-    for (int e = threadIdx.x; e < n; e += GN_BLOCK) { const float d = x[at(e)] - mean; q += d * d; }
-    const float rstd = 1.0f / sqrtf(block_sum<GN_BLOCK>(q, lds) / n + eps);
-    float sg = 0.f, sgx = 0.f;
-    for (int e = threadIdx.x; e < n; e += GN_BLOCK) {
-        const size_t o = at(e);
-        const float gg = grad(o) * gamma[g * cg + e % cg], xh = (x[o] - mean) * rstd;
-        sg += gg;
-        sgx += gg * xh;
+    __shared__ double lds[GN_BLOCK / 64];
+    __shared__ double col[2][GN_BLOCK];
+    const int b = blockIdx.x / groups, g = blockIdx.x % groups, cg = C / groups;
+    const int ch = threadIdx.x % cg, p0 = threadIdx.x / cg, pstep = GN_BLOCK / cg;
+    const size_t base = (size_t)b * HW * C + (size_t)g * cg + ch;
+    const float gam = gamma[g * cg + ch];
+    double sx = 0, sxx = 0, sr = 0, srx = 0;                   // per thread: one channel
+    for (int p = p0; p < HW; p += pstep) {
+        const size_t o = base + (size_t)p * C;
+        const float xv = x[o], gr = (y && !(y[o] > 0.f)) ? 0.f : dy[o];
+        sx += xv;
+        sxx += (double)xv * xv;
+        sr += gr;
+        srx += (double)gr * xv;
     }
-    const float mg = block_sum<GN_BLOCK>(sg, lds) / n, mgx = block_sum<GN_BLOCK>(sgx, lds) / n;
-    for (int e = threadIdx.x; e < n; e += GN_BLOCK) {
-        const size_t o = at(e);
-        const float gr = grad(o), xh = (x[o] - mean) * rstd;
-        dx[o] = rstd * (gr * gamma[g * cg + e % cg] - mg - xh * mgx);
-        if (dres) dres[o] = gr;
-    }
-    // per-channel dgamma / dbeta of this sample: 16 row-lanes x cg channels, fixed-order sum
-    const int ch = threadIdx.x % 64, lane16 = threadIdx.x / 64;          // 16 groups of 64 threads
-    float a = 0.f, c2 = 0.f;
-    if (ch < cg)
-        for (int p = lane16; p < HW; p += 16) {
-            const size_t o = base + (size_t)p * C + ch;
-            const float gr = grad(o);
-            a += gr * (x[o] - mean) * rstd;
-            c2 += gr;
-        }
+    const double n = (double)HW * cg;
+    const double Sx = gn_block_sum(sx, lds), Sxx = gn_block_sum(sxx, lds);
+    const double Sg = gn_block_sum(sr * gam, lds), Sgx = gn_block_sum(srx * gam, lds);
+    const double mean = Sx / n;
+    double var = Sxx / n - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const float mg = (float)(Sg / n), mgx = (float)((Sgx - mean * Sg) * rstd / n);
+    const float meanf = (float)mean, rstdf = (float)rstd;
+    // per-channel sums over the pixel lanes of this channel (fixed order)
     __syncthreads();
-    col[0][ch][lane16] = a;
-    col[1][ch][lane16] = c2;
+    col[0][threadIdx.x] = sr;
+    col[1][threadIdx.x] = srx;
     __syncthreads();
     if (threadIdx.x < cg) {
-        float ta = 0.f, tb = 0.f;
-        for (int k = 0; k < 16; k++) { ta += col[0][threadIdx.x][k]; tb += col[1][threadIdx.x][k]; }
-        dgamma_part[(size_t)b * C + g * cg + threadIdx.x] = ta;
-        dbeta_part[(size_t)b * C + g * cg + threadIdx.x] = tb;
+        double tr = 0, trx = 0;
+        for (int k = threadIdx.x; k < GN_BLOCK; k += cg) { tr += col[0][k]; trx += col[1][k]; }
+        dbeta_part[(size_t)b * C + g * cg + threadIdx.x] = (float)tr;
+        dgamma_part[(size_t)b * C + g * cg + threadIdx.x] = (float)((trx - mean * tr) * rstd);
+    }
+    for (int p = p0; p < HW; p += pstep) {
+        const size_t o = base + (size_t)p * C;
+        const float gr = (y && !(y[o] > 0.f)) ? 0.f : dy[o], xh = (x[o] - meanf) * rstdf;
+        dx[o] = rstdf * (gr * gam - mg - xh * mgx);
+        if (dres) dres[o] = gr;
     }
 }
 
@@ -373,7 +397,7 @@ extern "C" int zs_batch_norm_train(const float *x, const float *gamma, const flo
     double *partial = static_cast<double *>(workspace);
     hipLaunchKernelGGL(bn_partial_kernel<0>, dim3((C + 63) / 64, chunks), dim3(256), 0, S(stream), x, nullptr, nullptr,
                        nullptr, nullptr, partial, rows, C, per);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, S(stream), partial, chunks, C, rows, eps,
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((C + 63) / 64), dim3(256), 0, S(stream), partial, chunks, C, rows, eps,
                        momentum, running_mean, running_var, save_mean, save_rstd);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for((size_t)rows * C)), dim3(256), 0, S(stream), x, gamma, beta,
                        residual, save_mean, save_rstd, y, (size_t)rows * C, C, relu);
@@ -390,7 +414,7 @@ extern "C" int zs_batch_norm_bwd(const float *x, const float *dy, const float *y
     double *partial = static_cast<double *>(workspace);
     hipLaunchKernelGGL(bn_partial_kernel<1>, dim3((C + 63) / 64, chunks), dim3(256), 0, S(stream), x, dy, y_relu,
                        save_mean, save_rstd, partial, rows, C, per);
-    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, S(stream), partial, chunks, C, dgamma,
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 63) / 64), dim3(256), 0, S(stream), partial, chunks, C, dgamma,
                        dbeta);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for((size_t)rows * C)), dim3(256), 0, S(stream), x, dy, y_relu,
                        gamma, save_mean, save_rstd, dgamma, dbeta, dx, dresidual, (size_t)rows * C, C, 1.0f / rows);
@@ -400,9 +424,10 @@ extern "C" int zs_batch_norm_bwd(const float *x, const float *dy, const float *y
 extern "C" int zs_group_norm_bwd(const float *x, const float *dy, const float *y_relu, const float *gamma, float *dx,
                                  float *dresidual, float *dgamma, float *dbeta, int batch, int HW, int C, int groups,
                                  float eps, void *workspace, void *stream) {
-    ZS_REQUIRE(batch > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0 && C / groups <= 64,
-               "zs_group_norm_bwd: bad size (B=%d HW=%d C=%d groups=%d; at most 64 channels per group)", batch, HW, C,
-               groups);
+    ZS_REQUIRE(batch > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0 && C / groups <= 64 &&
+                   ((C / groups) & (C / groups - 1)) == 0,
+               "zs_group_norm_bwd: bad size (B=%d HW=%d C=%d groups=%d; channels per group: a power of two <= 64)", batch,
+               HW, C, groups);
     ZS_REQUIRE(x && dy && gamma && dx && dgamma && dbeta && workspace, "zs_group_norm_bwd: null pointer");
     float *pg = static_cast<float *>(workspace), *pb = pg + (size_t)batch * C;
     hipLaunchKernelGGL(group_norm_bwd_kernel, dim3(batch * groups), dim3(GN_BLOCK), 0, S(stream), x, dy, y_relu, gamma, dx,

@@ -219,12 +219,21 @@ class _Conv(torch.autograd.Function):
         dx = None
         if need_x:
             assert stride in (1, 2), "data gradient: stride 1 or 2"
-            dx = torch.empty(B, H, W, cin, dtype=torch.float32, device=x.device)
-            flags = _CONV_IN_DILATE2 if stride == 2 else 0
-            _conv_launch(gp, _pack(weight, cin0, cin, True, std_eps), None, None, None, dx, kh, kw, 1, kh - 1 - pt, kw - 1 - pl,
-                         flags, in_scale, 0.0, ACT_NONE)
-            if cin != Cx:                       # the input carried zero padding channels
-                dx = _pad_channels(dx, Cx)
+            if cin <= 4 and cout % 4 == 0 and kh * kw * cout * 16 <= 160 * 1024:
+                # a network stem: direct gather kernel instead of a GEMM with 3 useful columns
+                w_used = standardize(weight, std_eps) if std_eps is not None else weight.detach()
+                dx = torch.empty(B, H, W, Cx, dtype=torch.float32, device=x.device)
+                with torch.cuda.device(x.device):
+                    _lib.check(lib.zs_conv2d_dgrad_small_cin(_lib.ptr(g), _lib.ptr(w_used), _lib.ptr(dx), B, H, W, Cx, Ho, Wo,
+                                                             cout, kh, kw, stride, pt, pl, cin, cin0, weight.shape[1],
+                                                             float(in_scale), _stream(x)), "zs_conv2d_dgrad_small_cin")
+            else:
+                dx = torch.empty(B, H, W, cin, dtype=torch.float32, device=x.device)
+                flags = _CONV_IN_DILATE2 if stride == 2 else 0
+                _conv_launch(gp, _pack(weight, cin0, cin, True, std_eps), None, None, None, dx, kh, kw, 1, kh - 1 - pt,
+                             kw - 1 - pl, flags, in_scale, 0.0, ACT_NONE)
+                if cin != Cx:                       # the input carried zero padding channels
+                    dx = _pad_channels(dx, Cx)
             if in_relu:
                 dx = _act_backward(dx, x, ACT_RELU)
         return dx, dw, db, (g if ctx.has[1] else None), (g if ctx.has[2] else None), None
