@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 12
+#define ZS_ABI_VERSION 13
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -313,7 +313,9 @@ int zs_window_tokens(const float *emb, const uint8_t *mask, const float *invalid
  *       dy[pixel][cout] * A[pixel][(ky,kx,c)], A = the forward's input taps incl. its input
  *       transform (flags & ZS_CONV_IN_RELU, in_scale, in_shift).  in is [B][Hin][Win][CinP]
  *       (CinP % 4 == 0, channels >= Cin are padding), dy is [B][Hout][Wout][CoutP] with
- *       CoutP = Cout rounded up to 4.  workspace: zs_conv2d_wgrad_workspace_bytes(...).
+ *       CoutP = Cout rounded up to 4.  db (may be NULL) receives the bias gradient [Cout] = the column
+ *       sums of dy, gathered from the tiles the kernel stages anyway.
+ *       workspace: zs_conv2d_wgrad_workspace_bytes(...).
  *   zs_standardize_weight(_bwd) : timm StdConv2d: rows of n = Cin*kh*kw weights,
  *       (w - mean) / sqrt(biased var + eps), and the adjoint for a gradient w.r.t. the result.
  * Pointwise / normalisation:
@@ -351,7 +353,7 @@ typedef struct zs_tensor_entry {
 int zs_pack_conv_weight(const float *w, float *packed, int Cout, int Cin, int cin0, int CinTot, int kh, int kw,
                         int dgrad, void *stream);
 size_t zs_conv2d_wgrad_workspace_bytes(int batch, int Hout, int Wout, int Cin, int Cout, int kh, int kw);
-int zs_conv2d_wgrad(const float *in, const float *dy, float *dw, void *workspace, int batch, int Hin, int Win,
+int zs_conv2d_wgrad(const float *in, const float *dy, float *dw, float *db, void *workspace, int batch, int Hin, int Win,
                     int CinP, int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad_t, int pad_l,
                     int flags, float in_scale, float in_shift, int Cin, int cin0, int CinTot, int accumulate,
                     void *stream);

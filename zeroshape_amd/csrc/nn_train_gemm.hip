@@ -62,6 +62,7 @@ constexpr int WM = 128, WN = 128, WP = 16, WLD = 160;
 struct WgradArgs {
     const float *in, *dy;
     float *partial;                 // [splits][CoutP][K]
+    float *bias_partial;            // [splits][CoutP] column sums of dY (the bias gradient), or NULL
     int B, Hin, Win, Cin, Hout, Wout, CoutP, kh, kw, stride, pad_t, pad_l, K, M;
     int in_relu;
     float in_scale, in_shift;
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     const float relu_floor = a.in_relu ? 0.f : -INFINITY;
     const int HW = a.Hout * a.Wout;
 
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     struct Frag { f32x4 y, x; bool ok; };
     auto load = [&](int p) -> Frag {
         Frag f;
@@ -113,6 +115,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         for (int e = 0; e < 4; e++) v[e] = f.ok ? fmaxf(f.x[e], relu_floor) * a.in_scale + a.in_shift : 0.f;
         *reinterpret_cast<f32x4 *>(&lds_y[buf][row][4 * quad]) = f.y;
         *reinterpret_cast<f32x4 *>(&lds_a[buf][row][4 * quad]) = v;
+        bsum += f.y;                 // every dY row of the tile passes through exactly one thread per column quad
     };
 
     f32x16 acc[2][2];
@@ -153,6 +156,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
             __syncthreads();
         }
     }
+    if (a.bias_partial && blockIdx.y == 0) {          // bias gradient: column sums of this tile's dY rows
+        __syncthreads();
+        *reinterpret_cast<f32x4 *>(&lds_y[0][prow][4 * quad]) = bsum;
+        __syncthreads();
+        if (prow == 0 && yc_ok) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 8; r++) t += *reinterpret_cast<const f32x4 *>(&lds_y[0][r][4 * quad]);
+            *reinterpret_cast<f32x4 *>(a.bias_partial + (size_t)blockIdx.z * a.CoutP + yc) = t;
+        }
+    }
     float *dst = a.partial + (size_t)blockIdx.z * a.CoutP * a.K;
 #pragma unroll
     for (int j = 0; j < 2; j++) {
@@ -171,8 +185,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 // partial [splits][CoutP][K] (k = tap*CinP + c) -> dw[cout*ld + (cin0+c)*taps + tap], cout < Cout, c < Cin
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, float *__restrict__ dw,
                                                            int splits, int CoutP, int K, int Cout, int Cin, int CinP,
-                                                           int cin0, int ld, int taps, int accumulate) {
+                                                           int cin0, int ld, int taps, int accumulate,
+                                                           const float *__restrict__ bias_partial,
+                                                           float *__restrict__ db) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)Cout * K;
+    if (db && i < (size_t)Cout) {
+        float t = 0.f;
+        for (int z = 0; z < splits; z++) t += bias_partial[(size_t)z * CoutP + i];
+        db[i] = t;
+    }
     if (i >= total) return;
     const int k = i % K, co = i / K, tap = k / CinP, c = k - tap * CinP;
     if (c >= Cin) return;
@@ -314,10 +335,10 @@ static int wgrad_splits(long long M, int CoutP, int K) {
 extern "C" size_t zs_conv2d_wgrad_workspace_bytes(int batch, int Hout, int Wout, int Cin, int Cout, int kh, int kw) {
     const int CoutP = (Cout + 3) / 4 * 4, K = kh * kw * ((Cin + 3) / 4 * 4);
     const long long M = (long long)batch * Hout * Wout;
-    return (size_t)wgrad_splits(M, CoutP, K) * CoutP * K * sizeof(float);
+    return (size_t)wgrad_splits(M, CoutP, K) * CoutP * (K + 1) * sizeof(float);
 }
 
-extern "C" int zs_conv2d_wgrad(const float *in, const float *dy, float *dw, void *workspace, int batch, int Hin,
+extern "C" int zs_conv2d_wgrad(const float *in, const float *dy, float *dw, float *db, void *workspace, int batch, int Hin,
                                int Win, int CinP, int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad_t,
                                int pad_l, int flags, float in_scale, float in_shift, int Cin, int cin0, int CinTot,
                                int accumulate, void *stream) {
@@ -339,13 +360,15 @@ extern "C" int zs_conv2d_wgrad(const float *in, const float *dy, float *dw, void
     a.in_relu = (flags & ZS_CONV_IN_RELU) ? 1 : 0;
     a.in_scale = in_scale; a.in_shift = in_shift;
     const int splits = wgrad_splits(M, a.CoutP, a.K);
+    a.bias_partial = db ? a.partial + (size_t)splits * a.CoutP * a.K : nullptr;
     a.pix_per_split = (int)((M + splits - 1) / splits);
     a.pix_per_split = (a.pix_per_split + WP - 1) / WP * WP;
     const dim3 grid((a.CoutP + WM - 1) / WM, (a.K + WN - 1) / WN, splits);
     hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, S(stream), a);
     if (!zs::check_launch("zs_conv2d_wgrad")) return 0;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for((size_t)Cout * a.K)), dim3(256), 0, S(stream), a.partial, dw,
-                       splits, a.CoutP, a.K, Cout, Cin, CinP, cin0, CinTot * kh * kw, kh * kw, accumulate ? 1 : 0);
+                       splits, a.CoutP, a.K, Cout, Cin, CinP, cin0, CinTot * kh * kw, kh * kw, accumulate ? 1 : 0, a.bias_partial,
+                       db);
     return zs::check_launch("zs_conv2d_wgrad(reduce)") ? 1 : 0;
 }
 

@@ -196,16 +196,20 @@ class _Conv(torch.autograd.Function):
         B, Ho, Wo, cout = g.shape
         _, H, W, Cx = x.shape
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
-        db = column_sum(g.view(-1, cout)) if (ctx.has[0] and need_b) else None
+        want_b = ctx.has[0] and need_b
         gp = g if cout % 4 == 0 else _pad_channels(g, _ceil4(cout))
-        dw = None
+        dw = db = None
+        if want_b and not need_w:
+            db = column_sum(g.view(-1, cout))
         if need_w:
             sub = cin != weight.shape[1]
             dw = torch.zeros_like(weight) if sub else torch.empty_like(weight)
+            if want_b:          # the bias gradient rides on the weight-gradient kernel (it stages dY anyway)
+                db = torch.empty(cout, dtype=torch.float32, device=x.device)
             ws = scratch(x.device, "wgrad", lib.zs_conv2d_wgrad_workspace_bytes(B, Ho, Wo, Cx, cout, kh, kw))
             flags = _CONV_IN_RELU if in_relu else 0
             with torch.cuda.device(x.device):
-                _lib.check(lib.zs_conv2d_wgrad(_lib.ptr(x), _lib.ptr(gp), _lib.ptr(dw), _lib.ptr(ws), B, H, W, Cx, Ho,
+                _lib.check(lib.zs_conv2d_wgrad(_lib.ptr(x), _lib.ptr(gp), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws), B, H, W, Cx, Ho,
                                                Wo, cout, kh, kw, stride, pt, pl, flags, float(in_scale),
                                                float(in_shift), cin, cin0, weight.shape[1], 0, _stream(x)),
                            "zs_conv2d_wgrad")
