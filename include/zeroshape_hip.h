@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 13
+#define ZS_ABI_VERSION 14
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -352,6 +352,18 @@ typedef struct zs_tensor_entry {
 
 int zs_pack_conv_weight(const float *w, float *packed, int Cout, int Cin, int cin0, int CinTot, int kh, int kw,
                         int dgrad, void *stream);
+/* zs_pack_conv_weight over a DEVICE table of layers in one launch (every operand of a model after
+ * an optimiser step): ld = CinTot*kh*kw, taps = kh*kw, K16 / NPad = the padded operand dimensions
+ * (K rounded up to 16, N rounded up to 128); chunk c = elements [chunk_start[c],
+ * +zs_pack_chunk_elems()) of the operand of entry chunk_entry[c]. */
+typedef struct zs_pack_entry {
+    const float *src;
+    float *dst;
+    int Cout, Cin, cin0, ld, taps, dgrad, K16, NPad;
+} zs_pack_entry;
+int zs_pack_chunk_elems(void);
+int zs_pack_conv_weight_multi(const zs_pack_entry *table, const int *chunk_entry, const unsigned long long *chunk_start,
+                              int n_chunks, void *stream);
 size_t zs_conv2d_wgrad_workspace_bytes(int batch, int Hout, int Wout, int Cin, int Cout, int kh, int kw);
 int zs_conv2d_wgrad(const float *in, const float *dy, float *dw, float *db, void *workspace, int batch, int Hin, int Win,
                     int CinP, int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad_t, int pad_l,

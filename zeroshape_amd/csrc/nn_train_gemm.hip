@@ -49,6 +49,36 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restric
     dst[i] = v;
 }
 
+// the same over a device table of layers: one launch re-packs every operand of the model after an
+// optimiser step (chunk c = elements [chunk_start[c], +PACK_CHUNK) of entry chunk_entry[c])
+struct PackEntry {               // mirrors include/zeroshape_hip.h zs_pack_entry
+    const float *src;
+    float *dst;
+    int Cout, Cin, cin0, ld, taps, dgrad, K16, NPad;
+};
+constexpr int PACK_CHUNK = 16384;
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackEntry *__restrict__ tab,
+                                                                const int *__restrict__ chunk_entry,
+                                                                const unsigned long long *__restrict__ chunk_start) {
+    const PackEntry t = tab[chunk_entry[blockIdx.x]];
+    const size_t total = (size_t)t.K16 * t.NPad, s0 = chunk_start[blockIdx.x];
+    const size_t s1 = s0 + PACK_CHUNK < total ? s0 + PACK_CHUNK : total;
+    const int CinP = (t.Cin + 3) & ~3, CoutP = (t.Cout + 3) & ~3;
+    for (size_t i = s0 + threadIdx.x; i < s1; i += 256) {
+        const int e = i & 3, n = (i >> 2) % t.NPad, k = (int)((i >> 2) / t.NPad) * 4 + e;
+        float v = 0.f;
+        if (!t.dgrad) {
+            const int tap = k / CinP, c = k - tap * CinP;
+            if (tap < t.taps && c < t.Cin && n < t.Cout) v = t.src[(size_t)n * t.ld + (size_t)(t.cin0 + c) * t.taps + tap];
+        } else {
+            const int tap = k / CoutP, co = k - tap * CoutP;
+            if (tap < t.taps && co < t.Cout && n < t.Cin)
+                v = t.src[(size_t)co * t.ld + (size_t)(t.cin0 + n) * t.taps + (t.taps - 1 - tap)];
+        }
+        t.dst[i] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // weight gradient.  Workgroup tile: 128 couts x 128 k over a range of pixels; the pixel range is
 // split over blockIdx.z and the partial sums are reduced in a fixed order by wgrad_reduce_kernel
@@ -57,7 +87,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restric
 // A[p+half][k l32] - plain ds_read_b32, rows padded to 160 floats so the two halves hit
 // disjoint banks.
 // ---------------------------------------------------------------------------------------------
-constexpr int WM = 128, WN = 128, WP = 16, WLD = 160;
+constexpr int WP = 16;
 
 struct WgradArgs {
     const float *in, *dy;
@@ -69,20 +99,25 @@ struct WgradArgs {
     int pix_per_split;
 };
 
+// T = tile edge: 128 (a wave owns 2x2 MFMA tiles) for layers with many output pixels, 64 (one MFMA
+// tile per wave) for big weight matrices over few pixels (token matrices, 14x14 maps): four times
+// the workgroups without splitting the short pixel range into slivers whose partial tiles would
+// cost more to write and reduce than to compute.
+template <int T>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+    constexpr int WLD = T + 32;                 // row stride % 64 == 32: the two k-halves hit disjoint banks
+    constexpr int QUADS = T / 4, ROWS = 256 / QUADS, PASSES = WP / ROWS, NI = T / 64;
     __shared__ __attribute__((aligned(16))) float lds_y[2][WP][WLD];
     __shared__ __attribute__((aligned(16))) float lds_a[2][WP][WLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, half = lane >> 5;
-    const int c0 = blockIdx.x * WM, k0 = blockIdx.y * WN;
+    const int c0 = blockIdx.x * T, k0 = blockIdx.y * T;
     const int p_begin = blockIdx.z * a.pix_per_split, p_end = min(a.M, p_begin + a.pix_per_split);
 
-    // loader role: rows (pixels) tid/32 and tid/32 + 8 of the step, column quad tid%32
-    const int prow = tid >> 5, quad = tid & 31;
-    // dY column quad
+    // loader role: rows (pixels) tid/QUADS (+ROWS) of the step, column quad tid%QUADS
+    const int prow = tid / QUADS, quad = tid % QUADS;
     const int yc = c0 + 4 * quad;
     const bool yc_ok = yc < a.CoutP;
-    // A column quad: k fixed for the whole loop
-    const int kk = k0 + 4 * quad;
+    const int kk = k0 + 4 * quad;              // A column quad: k fixed for the whole loop
     const bool k_ok = kk < a.K;
     int kc = 0, ky = 0, kx = 0;
     if (k_ok) {
@@ -100,8 +135,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         Frag f;
         const bool p_ok = p < p_end;
         const int pc = p_ok ? p : p_begin;
-        f.y = yc_ok ? *reinterpret_cast<const f32x4 *>(a.dy + (size_t)pc * a.CoutP + (yc_ok ? yc : 0)) : f32x4{0, 0, 0, 0};
-        if (!p_ok) f.y = f32x4{0, 0, 0, 0};
+        f.y = (yc_ok && p_ok) ? *reinterpret_cast<const f32x4 *>(a.dy + (size_t)pc * a.CoutP + yc) : f32x4{0, 0, 0, 0};
         const int pb = pc / HW, rem = pc - pb * HW, py = rem / a.Wout, px = rem - py * a.Wout;
         const int iy = py * a.stride - a.pad_t + ky, ix = px * a.stride - a.pad_l + kx;
         f.ok = p_ok && k_ok && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
@@ -118,40 +152,47 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         bsum += f.y;                 // every dY row of the tile passes through exactly one thread per column quad
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[NI][NI];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < NI; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < NI; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+    const int wm = (wave & 1) * (T / 2), wn = (wave >> 1) * (T / 2);
     const int steps = (p_end - p_begin + WP - 1) / WP;
     if (steps > 0) {
-        Frag f0 = load(p_begin + prow), f1 = load(p_begin + prow + 8);
-        store(0, prow, f0);
-        store(0, prow + 8, f1);
+        Frag f[PASSES];
+#pragma unroll
+        for (int q = 0; q < PASSES; q++) f[q] = load(p_begin + prow + ROWS * q);
+#pragma unroll
+        for (int q = 0; q < PASSES; q++) store(0, prow + ROWS * q, f[q]);
         __syncthreads();
         for (int s = 0; s < steps; s++) {
             const int cur = s & 1;
             const bool more = s + 1 < steps;
             if (more) {
-                f0 = load(p_begin + (s + 1) * WP + prow);
-                f1 = load(p_begin + (s + 1) * WP + prow + 8);
+#pragma unroll
+                for (int q = 0; q < PASSES; q++) f[q] = load(p_begin + (s + 1) * WP + prow + ROWS * q);
             }
 #pragma unroll
             for (int t = 0; t < WP / 2; t++) {
-                const float ya0 = lds_y[cur][2 * t + half][wm + l32], ya1 = lds_y[cur][2 * t + half][wm + 32 + l32];
-                const float xb0 = lds_a[cur][2 * t + half][wn + l32], xb1 = lds_a[cur][2 * t + half][wn + 32 + l32];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya0, xb0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya0, xb1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya1, xb0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya1, xb1, acc[1][1], 0, 0, 0);
+                float ya[NI], xb[NI];
+#pragma unroll
+                for (int i = 0; i < NI; i++) {
+                    ya[i] = lds_y[cur][2 * t + half][wm + 32 * i + l32];
+                    xb[i] = lds_a[cur][2 * t + half][wn + 32 * i + l32];
+                }
+#pragma unroll
+                for (int i = 0; i < NI; i++)
+#pragma unroll
+                    for (int j = 0; j < NI; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[i], xb[j], acc[i][j], 0, 0, 0);
             }
             if (more) {
-                store(cur ^ 1, prow, f0);
-                store(cur ^ 1, prow + 8, f1);
+#pragma unroll
+                for (int q = 0; q < PASSES; q++) store(cur ^ 1, prow + ROWS * q, f[q]);
             }
             __syncthreads();
         }
@@ -163,17 +204,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         if (prow == 0 && yc_ok) {
             f32x4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 8; r++) t += *reinterpret_cast<const f32x4 *>(&lds_y[0][r][4 * quad]);
+            for (int r = 0; r < ROWS; r++) t += *reinterpret_cast<const f32x4 *>(&lds_y[0][r][4 * quad]);
             *reinterpret_cast<f32x4 *>(a.bias_partial + (size_t)blockIdx.z * a.CoutP + yc) = t;
         }
     }
     float *dst = a.partial + (size_t)blockIdx.z * a.CoutP * a.K;
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
+    for (int j = 0; j < NI; j++) {
         const int k = k0 + wn + 32 * j + l32;
         if (k >= a.K) continue;
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < NI; i++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int co = c0 + wm + 32 * i + 8 * (r >> 2) + 4 * half + (r & 3);
@@ -321,21 +362,43 @@ extern "C" int zs_pack_conv_weight(const float *w, float *packed, int Cout, int 
     return zs::check_launch("zs_pack_conv_weight") ? 1 : 0;
 }
 
-static int wgrad_splits(long long M, int CoutP, int K) {
-    const long long tiles = (long long)((CoutP + WM - 1) / WM) * ((K + WN - 1) / WN);
+static_assert(sizeof(PackEntry) == sizeof(zs_pack_entry), "PackEntry must mirror zs_pack_entry");
+
+extern "C" int zs_pack_chunk_elems(void) { return PACK_CHUNK; }
+
+extern "C" int zs_pack_conv_weight_multi(const zs_pack_entry *table, const int *chunk_entry,
+                                         const unsigned long long *chunk_start, int n_chunks, void *stream) {
+    ZS_REQUIRE(n_chunks >= 0, "zs_pack_conv_weight_multi: bad arguments");
+    if (n_chunks == 0) return 1;
+    ZS_REQUIRE(table && chunk_entry && chunk_start, "zs_pack_conv_weight_multi: null pointer");
+    hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(n_chunks), dim3(256), 0, S(stream),
+                       reinterpret_cast<const PackEntry *>(table), chunk_entry, chunk_start);
+    return zs::check_launch("zs_pack_conv_weight_multi") ? 1 : 0;
+}
+
+// tile edge and number of pixel-range splits of one weight gradient
+static void wgrad_plan(long long M, int CoutP, int K, int *tile, int *splits_out) {
     static const long long target = getenv("ZS_WGRAD_TARGET") ? atoll(getenv("ZS_WGRAD_TARGET")) : 768;
-    long long splits = (target + tiles - 1) / tiles;              // aim at ~3 workgroups per CU
-    const long long max_by_pixels = (M + 127) / 128;              // at least 128 pixels per split
+    const long long tiles128 = (long long)((CoutP + 127) / 128) * ((K + 127) / 128);
+    const long long tiles64 = (long long)((CoutP + 63) / 64) * ((K + 63) / 64);
+    // few pixels under a big weight matrix: more, smaller tiles instead of slivers of the pixel range
+    const bool small_tiles = M < 4096 && tiles128 < 192;
+    const long long tiles = small_tiles ? tiles64 : tiles128;
+    long long splits = ((small_tiles ? 512 : target) + tiles - 1) / tiles;     // aim at 2-3 workgroups per CU
+    const long long max_by_pixels = (M + 127) / 128;                           // at least 128 pixels per split
     if (splits > max_by_pixels) splits = max_by_pixels;
     if (splits < 1) splits = 1;
     if (splits > 1024) splits = 1024;
-    return (int)splits;
+    *tile = small_tiles ? 64 : 128;
+    *splits_out = (int)splits;
 }
 
 extern "C" size_t zs_conv2d_wgrad_workspace_bytes(int batch, int Hout, int Wout, int Cin, int Cout, int kh, int kw) {
     const int CoutP = (Cout + 3) / 4 * 4, K = kh * kw * ((Cin + 3) / 4 * 4);
     const long long M = (long long)batch * Hout * Wout;
-    return (size_t)wgrad_splits(M, CoutP, K) * CoutP * (K + 1) * sizeof(float);
+    int tile, splits;
+    wgrad_plan(M, CoutP, K, &tile, &splits);
+    return (size_t)splits * CoutP * (K + 1) * sizeof(float);
 }
 
 extern "C" int zs_conv2d_wgrad(const float *in, const float *dy, float *dw, float *db, void *workspace, int batch, int Hin,
@@ -359,12 +422,16 @@ extern "C" int zs_conv2d_wgrad(const float *in, const float *dy, float *dw, floa
     a.K = kh * kw * CinP; a.M = (int)M;
     a.in_relu = (flags & ZS_CONV_IN_RELU) ? 1 : 0;
     a.in_scale = in_scale; a.in_shift = in_shift;
-    const int splits = wgrad_splits(M, a.CoutP, a.K);
+    int tile, splits;
+    wgrad_plan(M, a.CoutP, a.K, &tile, &splits);
     a.bias_partial = db ? a.partial + (size_t)splits * a.CoutP * a.K : nullptr;
     a.pix_per_split = (int)((M + splits - 1) / splits);
     a.pix_per_split = (a.pix_per_split + WP - 1) / WP * WP;
-    const dim3 grid((a.CoutP + WM - 1) / WM, (a.K + WN - 1) / WN, splits);
-    hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, S(stream), a);
+    const dim3 grid((a.CoutP + tile - 1) / tile, (a.K + tile - 1) / tile, splits);
+    if (tile == 64)
+        hipLaunchKernelGGL(wgrad_kernel<64>, grid, dim3(256), 0, S(stream), a);
+    else
+        hipLaunchKernelGGL(wgrad_kernel<128>, grid, dim3(256), 0, S(stream), a);
     if (!zs::check_launch("zs_conv2d_wgrad")) return 0;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for((size_t)Cout * a.K)), dim3(256), 0, S(stream), a.partial, dw,
                        splits, a.CoutP, a.K, Cout, Cin, CinP, cin0, CinTot * kh * kw, kh * kw, accumulate ? 1 : 0, a.bias_partial,

@@ -71,39 +71,128 @@ def _memo(owner, subkey, make):
     return slot[1][subkey]
 
 
-def clear_pack_cache():
-    _MEMO.clear()
+def _stamp(w):
+    return (w.data_ptr(), w._version, GENERATION[0])
+
+
+_STD = {}       # id(weight) -> [weakref, eps, buffer, stamp]: standardised weights in persistent buffers
 
 
 def standardize(weight, eps):
-    """timm StdConv2d weight standardisation of a Parameter (cached per weight value)."""
-    def make():
+    """timm StdConv2d weight standardisation of a Parameter, refreshed when the weight changes."""
+    import weakref
+    rec = _STD.get(id(weight))
+    if rec is None or rec[0]() is not weight or rec[1] != float(eps):
+        rec = [weakref.ref(weight, lambda _r, k=id(weight): _STD.pop(k, None)), float(eps),
+               torch.empty_like(weight.detach()), None]
+        _STD[id(weight)] = rec
+    if rec[3] != _stamp(weight):
         lib = _lib.load()
         w = weight.detach()
-        out = torch.empty_like(w)
         with torch.cuda.device(w.device):
-            _lib.check(lib.zs_standardize_weight(_lib.ptr(w), _lib.ptr(out), w.shape[0], w[0].numel(), float(eps),
+            _lib.check(lib.zs_standardize_weight(_lib.ptr(w), _lib.ptr(rec[2]), w.shape[0], w[0].numel(), float(eps),
                                                  _stream(w)), "zs_standardize_weight")
-        return out
-    return _memo(weight, ("std", float(eps)), make)
+        rec[3] = _stamp(weight)
+    return rec[2]
+
+
+# ---- packed GEMM operands: persistent buffers, re-packed for ALL layers in one launch ----
+class _PackRec(object):
+    __slots__ = ("ref", "key", "packed", "stamp", "dims")
+
+
+_PACKS = {}     # (id(weight), cin0, cin, dgrad, std_eps) -> _PackRec
+_PACK_TABLE = {}    # device -> (signature, table tensors)
+
+
+def clear_pack_cache():
+    _MEMO.clear()
+    _PACKS.clear()
+    _STD.clear()
+    _PACK_TABLE.clear()
+
+
+def _pack_dims(w, cin, dgrad):
+    cout, cintot = w.shape[0], w.shape[1]
+    kh, kw = (w.shape[2], w.shape[3]) if w.dim() == 4 else (1, 1)
+    taps = kh * kw
+    kc, n = (_ceil4(cout), cin) if dgrad else (_ceil4(cin), cout)
+    return cout, cintot, kh, kw, taps, (taps * kc + 15) // 16 * 16, (n + 127) // 128 * 128
+
+
+def _refresh_all_packs(device):
+    """Re-pack every registered operand on `device` whose weight changed, in ONE launch."""
+    import numpy as np
+    lib = _lib.load()
+    recs = []
+    for key, rec in list(_PACKS.items()):
+        w = rec.ref()
+        if w is None:
+            del _PACKS[key]
+        elif w.device == device and rec.stamp != _stamp(w):
+            recs.append((rec, w))
+    if not recs:
+        return
+    entries = []
+    for rec, w in recs:
+        _, cin0, cin, dgrad, std_eps = rec.key
+        src = standardize(w, std_eps) if std_eps is not None else w.detach()
+        cout, cintot, kh, kw, taps, K16, NPad = rec.dims
+        entries.append((src.data_ptr(), rec.packed.data_ptr(), cout, cin, cin0, cintot * taps, taps, 1 if dgrad else 0,
+                        K16, NPad))
+    sig = tuple(entries)
+    cached = _PACK_TABLE.get(device)
+    if cached is None or cached[0] != sig:
+        dt = np.dtype([("src", "<u8"), ("dst", "<u8")] + [(n, "<i4") for n in ("Cout", "Cin", "cin0", "ld", "taps", "dgrad",
+                                                                             "K16", "NPad")])
+        assert dt.itemsize == 48
+        tab = np.zeros(len(entries), dt)
+        chunk = lib.zs_pack_chunk_elems()
+        ce, cs = [], []
+        for i, e in enumerate(entries):
+            tab[i] = e
+            starts = np.arange(0, e[8] * e[9], chunk, dtype=np.uint64)
+            ce.append(np.full(len(starts), i, np.int32))
+            cs.append(starts)
+        ce, cs = np.concatenate(ce), np.concatenate(cs)
+        cached = (sig, torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(device), torch.from_numpy(ce).to(device),
+                  torch.from_numpy(cs.view(np.int64)).to(device), len(ce))
+        _PACK_TABLE[device] = cached
+    _, tab_d, ce_d, cs_d, n = cached
+    with torch.cuda.device(device):
+        _lib.check(lib.zs_pack_conv_weight_multi(_lib.ptr(tab_d), _lib.ptr(ce_d), _lib.ptr(cs_d), n,
+                                                 _lib.current_stream_ptr(device)), "zs_pack_conv_weight_multi")
+    for rec, w in recs:
+        rec.stamp = _stamp(w)
 
 
 def _pack(weight, cin0, cin, dgrad, std_eps=None):
     """Packed GEMM operand of `weight` (torch layout [Cout, CinTot(, kh, kw)], optionally
-    standardised first) for the forward product (dgrad=False) or the data gradient."""
-    def make():
-        lib = _lib.load()
-        w = standardize(weight, std_eps) if std_eps is not None else weight.detach()
-        cout, cintot = w.shape[0], w.shape[1]
-        kh, kw = (w.shape[2], w.shape[3]) if w.dim() == 4 else (1, 1)
-        n = lib.zs_conv2d_packed_floats(_ceil4(cout), cin, kh, kw) if dgrad else \
-            lib.zs_conv2d_packed_floats(_ceil4(cin), cout, kh, kw)
-        packed = torch.empty(n, dtype=torch.float32, device=w.device)
-        with torch.cuda.device(w.device):
-            _lib.check(lib.zs_pack_conv_weight(_lib.ptr(w), _lib.ptr(packed), cout, cin, cin0, cintot, kh, kw,
-                                               1 if dgrad else 0, _stream(w)), "zs_pack_conv_weight")
-        return packed
-    return _memo(weight, ("pack", cin0, cin, bool(dgrad), std_eps), make)
+    standardised first) for the forward product (dgrad=False) or the data gradient.  Operands live
+    in persistent buffers; the first use of a layer packs it alone, afterwards a stale operand
+    triggers ONE launch that re-packs every registered operand whose weight changed (the state after
+    an optimiser step), instead of ~450 small launches per training step."""
+    import weakref
+    key = (id(weight), cin0, cin, bool(dgrad), std_eps)
+    rec = _PACKS.get(key)
+    if rec is not None and rec.ref() is weight:
+        if rec.stamp != _stamp(weight):
+            _refresh_all_packs(weight.device)
+        return rec.packed
+    lib = _lib.load()
+    w = standardize(weight, std_eps) if std_eps is not None else weight.detach()
+    dims = _pack_dims(w, cin, dgrad)
+    cout, cintot, kh, kw, taps, K16, NPad = dims
+    rec = _PackRec()
+    rec.ref = weakref.ref(weight, lambda _r, k=key: _PACKS.pop(k, None))
+    rec.key, rec.dims = key, dims
+    rec.packed = torch.empty(K16 * NPad, dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(lib.zs_pack_conv_weight(_lib.ptr(w), _lib.ptr(rec.packed), cout, cin, cin0, cintot, kh, kw,
+                                           1 if dgrad else 0, _stream(w)), "zs_pack_conv_weight")
+    rec.stamp = _stamp(weight)
+    _PACKS[key] = rec
+    return rec.packed
 
 
 def _out_size(n, k, stride, padding):
