@@ -381,8 +381,9 @@ static void wgrad_plan(long long M, int CoutP, int K, int *tile, int *splits_out
     static const long long target = getenv("ZS_WGRAD_TARGET") ? atoll(getenv("ZS_WGRAD_TARGET")) : 768;
     const long long tiles128 = (long long)((CoutP + 127) / 128) * ((K + 127) / 128);
     const long long tiles64 = (long long)((CoutP + 63) / 64) * ((K + 63) / 64);
-    // few pixels under a big weight matrix: more, smaller tiles instead of slivers of the pixel range
-    const bool small_tiles = M < 4096 && tiles128 < 192;
+    // big weights over few pixels, or tiny weights over many: more, smaller tiles instead of slivers of
+    // the pixel range (every split costs a partial tile to write and to reduce); measured per shape
+    const bool small_tiles = (M < 4096 && tiles128 < 192) || tiles128 <= 12;
     const long long tiles = small_tiles ? tiles64 : tiles128;
     long long splits = ((small_tiles ? 512 : target) + tiles - 1) / tiles;     // aim at 2-3 workgroups per CU
     const long long max_by_pixels = (M + 127) / 128;                           // at least 128 pixels per split
