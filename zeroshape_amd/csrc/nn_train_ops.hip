@@ -158,101 +158,120 @@ __global__ __launch_bounds__(256) void layer_norm_bwd_kernel(const float *__rest
 }
 
 // ---- attention backward (softmax(q k^T scale) v per head; qkv [B][L][3][H][D]) ----
-// pass 1, wave per (b, h, query i): recompute the probability row, dP = dO V^T,
-// dS = P * (dP - sum_j P dP); store P and dS rows; dQ_i = scale * sum_j dS_ij K_j
+// pass 1, workgroup = (b, h, tile of rows): K and V of the head staged in LDS (rows padded to D+1
+// floats: lane j reading row j is conflict-free); a wave per query row recomputes the probability
+// row, dP = dO V^T, dS = P * (dP - sum_j P dP), and stores the P and dS rows.
+// pass 2, one wave per 32x32 output tile on the MFMA pipe:
+//   dQ = scale * dS K,   dK = scale * dS^T Q,   dV = P^T dO      (contractions over L)
 constexpr int ATT_MAXJ = 8;      // L <= 512
+constexpr int ATT_ROWS = 32;     // query rows per workgroup in pass 1
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
 template <int D>
 __global__ __launch_bounds__(256) void attention_bwd_rows_kernel(const float *__restrict__ qkv,
                                                                  const float *__restrict__ dout,
-                                                                 float *__restrict__ dqkv, float *__restrict__ Pbuf,
-                                                                 float *__restrict__ dSbuf, int L, int heads,
-                                                                 float scale, int total_rows) {
-    extern __shared__ float lds[];                      // per wave: ds[L]
+                                                                 float *__restrict__ Pbuf, float *__restrict__ dSbuf,
+                                                                 int L, int heads, float scale) {
+    extern __shared__ float lds[];
+    constexpr int KS = D + 1;
+    float *Ks = lds, *Vs = lds + (size_t)L * KS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int gr_raw = blockIdx.x * 4 + wave;           // (b*heads + h) * L + i
-    const bool active = gr_raw < total_rows;
-    const int gr = active ? gr_raw : total_rows - 1;    // idle waves redo the last row, write nothing
-    const int i = gr % L, bh = gr / L, h = bh % heads, b = bh / heads, C = heads * D;
+    const int bh = blockIdx.x, h = bh % heads, b = bh / heads, C = heads * D;
     const float *base = qkv + (size_t)b * L * 3 * C + h * D;
-    const float *qi = base + (size_t)i * 3 * C, *doi = dout + ((size_t)b * L + i) * C + h * D;
-    float q[D], go[D];
-#pragma unroll
-    for (int d = 0; d < D; d++) { q[d] = qi[d]; go[d] = doi[d]; }
-    float s[ATT_MAXJ], dp[ATT_MAXJ];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < ATT_MAXJ; t++) {
-        const int j = lane + 64 * t;
-        s[t] = -INFINITY;
-        dp[t] = 0.f;
-        if (j < L) {
-            const float *kj = base + (size_t)j * 3 * C + C, *vj = kj + C;
-            float a = 0.f, c2 = 0.f;
-#pragma unroll
-            for (int d = 0; d < D; d++) { a += q[d] * kj[d]; c2 += go[d] * vj[d]; }
-            s[t] = a * scale;
-            dp[t] = c2;
-            mx = fmaxf(mx, s[t]);
-        }
-    }
-    mx = wave_max(mx);
-    float den = 0.f;
-#pragma unroll
-    for (int t = 0; t < ATT_MAXJ; t++) { s[t] = (lane + 64 * t < L) ? expf(s[t] - mx) : 0.f; den += s[t]; }
-    den = wave_sum(den);
-    float delta = 0.f;
-#pragma unroll
-    for (int t = 0; t < ATT_MAXJ; t++) { s[t] /= den; delta += s[t] * dp[t]; }
-    delta = wave_sum(delta);
-    float *dsl = lds + wave * L;
-    float *Prow = Pbuf + (size_t)gr * L, *dSrow = dSbuf + (size_t)gr * L;
-#pragma unroll
-    for (int t = 0; t < ATT_MAXJ; t++) {
-        const int j = lane + 64 * t;
-        if (j < L) {
-            const float ds = s[t] * (dp[t] - delta);
-            if (active) {
-                Prow[j] = s[t];
-                dSrow[j] = ds;
-            }
-            dsl[j] = ds;
-        }
+    for (int e = threadIdx.x; e < L * D; e += 256) {
+        const int j = e / D, d = e % D;
+        Ks[j * KS + d] = base[(size_t)j * 3 * C + C + d];
+        Vs[j * KS + d] = base[(size_t)j * 3 * C + 2 * C + d];
     }
     __syncthreads();
-    // dQ: lanes own d; two halves of the key range for D = 32
-    constexpr int PARTS = 64 / D;
-    const int d = lane % D, part = lane / D;
-    float acc = 0.f;
-    for (int j = part; j < L; j += PARTS) acc += dsl[j] * base[(size_t)j * 3 * C + C + d];
-    if (PARTS == 2) acc += __shfl_xor(acc, 32, 64);
-    if (part == 0 && active) dqkv[((size_t)b * L + i) * 3 * C + h * D + d] = acc * scale;
-}
-// pass 2, wave per (b, h, key j): dV_j = sum_i P_ij dO_i, dK_j = scale * sum_i dS_ij Q_i
-template <int D>
-__global__ __launch_bounds__(256) void attention_bwd_cols_kernel(const float *__restrict__ qkv,
-                                                                 const float *__restrict__ dout,
-                                                                 float *__restrict__ dqkv,
-                                                                 const float *__restrict__ Pbuf,
-                                                                 const float *__restrict__ dSbuf, int L, int heads,
-                                                                 float scale, int total_rows) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int gr = blockIdx.x * 4 + wave;
-    if (gr >= total_rows) return;
-    const int j = gr % L, bh = gr / L, h = bh % heads, b = bh / heads, C = heads * D;
-    constexpr int PARTS = 64 / D;
-    const int d = lane % D, part = lane / D;
-    const float *qb = qkv + (size_t)b * L * 3 * C + h * D + d, *dob = dout + (size_t)b * L * C + h * D + d;
-    const float *Pc = Pbuf + (size_t)bh * L * L + j, *dSc = dSbuf + (size_t)bh * L * L + j;
-    float dv = 0.f, dk = 0.f;
-    for (int i = part; i < L; i += PARTS) {
-        dv += Pc[(size_t)i * L] * dob[(size_t)i * C];
-        dk += dSc[(size_t)i * L] * qb[(size_t)i * 3 * C];
+    const int i_end = min(L, (int)(blockIdx.y + 1) * ATT_ROWS);
+    for (int i = blockIdx.y * ATT_ROWS + wave; i < i_end; i += 4) {
+        const float *qi = base + (size_t)i * 3 * C, *doi = dout + ((size_t)b * L + i) * C + h * D;
+        float q[D], go[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) { q[d] = qi[d]; go[d] = doi[d]; }
+        float s[ATT_MAXJ], dp[ATT_MAXJ];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < ATT_MAXJ; t++) {
+            const int j = lane + 64 * t;
+            s[t] = -INFINITY;
+            dp[t] = 0.f;
+            if (j < L) {
+                float a = 0.f, c2 = 0.f;
+#pragma unroll
+                for (int d = 0; d < D; d++) { a += q[d] * Ks[j * KS + d]; c2 += go[d] * Vs[j * KS + d]; }
+                s[t] = a * scale;
+                dp[t] = c2;
+                mx = fmaxf(mx, s[t]);
+            }
+        }
+        mx = wave_max(mx);
+        float den = 0.f;
+#pragma unroll
+        for (int t = 0; t < ATT_MAXJ; t++) { s[t] = (lane + 64 * t < L) ? expf(s[t] - mx) : 0.f; den += s[t]; }
+        den = wave_sum(den);
+        float delta = 0.f;
+#pragma unroll
+        for (int t = 0; t < ATT_MAXJ; t++) { s[t] /= den; delta += s[t] * dp[t]; }
+        delta = wave_sum(delta);
+        float *Prow = Pbuf + ((size_t)bh * L + i) * L, *dSrow = dSbuf + ((size_t)bh * L + i) * L;
+#pragma unroll
+        for (int t = 0; t < ATT_MAXJ; t++) {
+            const int j = lane + 64 * t;
+            if (j < L) {
+                Prow[j] = s[t];
+                dSrow[j] = s[t] * (dp[t] - delta);
+            }
+        }
     }
-    if (PARTS == 2) { dv += __shfl_xor(dv, 32, 64); dk += __shfl_xor(dk, 32, 64); }
-    if (part == 0) {
-        float *o = dqkv + ((size_t)b * L + j) * 3 * C + h * D + d;
-        o[C] = dk * scale;
-        o[2 * C] = dv;
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void attention_bwd_mfma_kernel(const float *__restrict__ qkv,
+                                                                const float *__restrict__ dout, float *__restrict__ dqkv,
+                                                                const float *__restrict__ Pbuf,
+                                                                const float *__restrict__ dSbuf, int L, int heads,
+                                                                float scale) {
+    constexpr int DT = D / 32;
+    const int lane = threadIdx.x, l32 = lane & 31, half = lane >> 5;
+    const int bh = blockIdx.x, h = bh % heads, b = bh / heads, C = heads * D;
+    const int LT = (L + 31) / 32;
+    const int t = blockIdx.y, which = t / (LT * DT), r0 = ((t / DT) % LT) * 32, d0 = (t % DT) * 32;
+    const float *base = qkv + (size_t)b * L * 3 * C + h * D;
+    const float *M = (which == 2 ? Pbuf : dSbuf) + (size_t)bh * L * L;
+    // A[m][k]: which 0 (dQ): dS[r0+m][k];  which 1, 2 (dK, dV): dS / P [k][r0+m]   (k = contraction index)
+    // B[k][n]: which 0: K[k][d0+n];  which 1: Q[k][d0+n];  which 2: dO[k][d0+n]
+    const int m = r0 + l32;
+    const bool m_ok = m < L;
+    const size_t a_row = which == 0 ? (size_t)min(m, L - 1) * L : (size_t)min(m, L - 1), a_step = which == 0 ? 1 : L;
+    const float *Bp = which == 0 ? base + C + d0 + l32 : (which == 1 ? base + d0 + l32 : dout + (size_t)b * L * C + h * D + d0 + l32);
+    const size_t b_step = which == 2 ? C : 3 * C;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    constexpr int U = 8;
+    for (int k0 = 0; k0 < L; k0 += 2 * U) {
+        float av[U], bv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int k = k0 + 2 * u + half;
+            const bool ok = k < L;
+            const int kc = ok ? k : L - 1;
+            av[u] = M[a_row + (size_t)kc * a_step];
+            bv[u] = Bp[(size_t)kc * b_step];
+            av[u] = (ok && m_ok) ? av[u] : 0.f;
+            bv[u] = ok ? bv[u] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+    const float mul = which == 2 ? 1.0f : scale;
+    const int col = which == 0 ? 0 : (which == 1 ? C : 2 * C);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int row = r0 + 8 * (r >> 2) + 4 * half + (r & 3);
+        if (row < L) dqkv[((size_t)b * L + row) * 3 * C + col + h * D + d0 + l32] = acc[r] * mul;
     }
 }
 
@@ -350,20 +369,27 @@ extern "C" int zs_attention_bwd(const float *qkv, const float *dout, float *dqkv
     if (batch == 0) return 1;
     ZS_REQUIRE(qkv && dout && dqkv && workspace, "zs_attention_bwd: null pointer");
     const float scale = 1.0f / sqrtf((float)head_dim);
-    const int rows = batch * heads * L;
-    float *P = static_cast<float *>(workspace), *dS = P + (size_t)rows * L;
-    const dim3 grid((rows + 3) / 4);
-    const size_t lds = 4 * (size_t)L * sizeof(float);
+    const int BH = batch * heads;
+    float *P = static_cast<float *>(workspace), *dS = P + (size_t)BH * L * L;
+    const dim3 grid1(BH, (L + ATT_ROWS - 1) / ATT_ROWS), grid2(BH, 3 * ((L + 31) / 32) * (head_dim / 32));
+    const size_t lds = (size_t)2 * L * (head_dim + 1) * sizeof(float);
+    ZS_REQUIRE(lds <= 160 * 1024, "zs_attention_bwd: L = %d needs %zu bytes of LDS", L, lds);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(attention_bwd_rows_kernel<64>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(attention_bwd_rows_kernel<32>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
     if (head_dim == 64) {
-        hipLaunchKernelGGL(attention_bwd_rows_kernel<64>, grid, dim3(256), lds, S(stream), qkv, dout, dqkv, P, dS, L,
-                           heads, scale, rows);
-        hipLaunchKernelGGL(attention_bwd_cols_kernel<64>, grid, dim3(256), 0, S(stream), qkv, dout, dqkv, P, dS, L,
-                           heads, scale, rows);
+        hipLaunchKernelGGL(attention_bwd_rows_kernel<64>, grid1, dim3(256), lds, S(stream), qkv, dout, P, dS, L, heads, scale);
+        hipLaunchKernelGGL(attention_bwd_mfma_kernel<64>, grid2, dim3(64), 0, S(stream), qkv, dout, dqkv, P, dS, L, heads,
+                           scale);
     } else {
-        hipLaunchKernelGGL(attention_bwd_rows_kernel<32>, grid, dim3(256), lds, S(stream), qkv, dout, dqkv, P, dS, L,
-                           heads, scale, rows);
-        hipLaunchKernelGGL(attention_bwd_cols_kernel<32>, grid, dim3(256), 0, S(stream), qkv, dout, dqkv, P, dS, L,
-                           heads, scale, rows);
+        hipLaunchKernelGGL(attention_bwd_rows_kernel<32>, grid1, dim3(256), lds, S(stream), qkv, dout, P, dS, L, heads, scale);
+        hipLaunchKernelGGL(attention_bwd_mfma_kernel<32>, grid2, dim3(64), 0, S(stream), qkv, dout, dqkv, P, dS, L, heads,
+                           scale);
     }
     return zs::check_launch("zs_attention_bwd") ? 1 : 0;
 }
