@@ -82,6 +82,10 @@ struct TapIter {
 // (no branch, no wait); `ok` is applied when the value is used.
 struct AQuad { f32x4 v; bool ok; };
 
+// PW: pointwise fast path (1x1, stride 1, no padding / dilation / input transform - every linear layer
+// and bottleneck 1x1): the operand address is pixel * Cin + k, no tap bookkeeping and no transform, which
+// removes most of the VALU work that the fp32 MFMA pipe cannot hide.
+template <bool PW>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     __shared__ f32x4 lds_a[2][KQ][BM];
     __shared__ f32x4 lds_b[2][KQ][BN];
@@ -122,6 +126,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     TapIter it0, it1;
     it0.init(4 * kq_lo, a.Cin, a.kw);
     it1.init(4 * (kq_lo + 2), a.Cin, a.kw);
+    const float *in_pix = a.in + (size_t)(pix_ok ? pix : 0) * a.Cin;       // PW
+    int ka0 = 4 * kq_lo, ka1 = 4 * (kq_lo + 2);
+    auto load_pw = [&](int k) -> AQuad {
+        AQuad q;
+        q.ok = pix_ok && k < a.K;
+        q.v = *reinterpret_cast<const f32x4 *>(in_pix + (q.ok ? k : 0));
+        return q;
+    };
+    auto finish_pw = [&](const AQuad &q) -> f32x4 { return q.ok ? q.v : f32x4{0.f, 0.f, 0.f, 0.f}; };
     const f32x4 *wq = reinterpret_cast<const f32x4 *>(a.w);
     auto load_b = [&](int kq, int n) -> f32x4 { return wq[(size_t)kq * a.CoutPad + n0 + n]; };
 
@@ -136,12 +149,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     const int ksteps = (a.K + BK - 1) / BK;
     AQuad ra[2];
     f32x4 rb[2];
-    ra[0] = load_a(it0);
-    ra[1] = load_a(it1);
+    ra[0] = PW ? load_pw(ka0) : load_a(it0);
+    ra[1] = PW ? load_pw(ka1) : load_a(it1);
     rb[0] = load_b(kq_lo, prow);
     rb[1] = load_b(kq_lo + 2, prow);
-    lds_a[0][kq_lo][prow] = finish_a(ra[0]);
-    lds_a[0][kq_lo + 2][prow] = finish_a(ra[1]);
+    lds_a[0][kq_lo][prow] = PW ? finish_pw(ra[0]) : finish_a(ra[0]);
+    lds_a[0][kq_lo + 2][prow] = PW ? finish_pw(ra[1]) : finish_a(ra[1]);
     lds_b[0][kq_lo][prow] = rb[0];
     lds_b[0][kq_lo + 2][prow] = rb[1];
     __syncthreads();
@@ -151,10 +164,17 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
         const int cur = ks & 1;
         const bool more = ks + 1 < ksteps;
         if (more) {
-            it0.advance(adv_tap, adv_c, a.Cin, a.kw);
-            it1.advance(adv_tap, adv_c, a.Cin, a.kw);
-            ra[0] = load_a(it0);
-            ra[1] = load_a(it1);
+            if (PW) {
+                ka0 += BK;
+                ka1 += BK;
+                ra[0] = load_pw(ka0);
+                ra[1] = load_pw(ka1);
+            } else {
+                it0.advance(adv_tap, adv_c, a.Cin, a.kw);
+                it1.advance(adv_tap, adv_c, a.Cin, a.kw);
+                ra[0] = load_a(it0);
+                ra[1] = load_a(it1);
+            }
             rb[0] = load_b((ks + 1) * KQ + kq_lo, prow);
             rb[1] = load_b((ks + 1) * KQ + kq_lo + 2, prow);
         }
@@ -174,8 +194,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
         }
         if (more) {
-            lds_a[cur ^ 1][kq_lo][prow] = finish_a(ra[0]);
-            lds_a[cur ^ 1][kq_lo + 2][prow] = finish_a(ra[1]);
+            lds_a[cur ^ 1][kq_lo][prow] = PW ? finish_pw(ra[0]) : finish_a(ra[0]);
+            lds_a[cur ^ 1][kq_lo + 2][prow] = PW ? finish_pw(ra[1]) : finish_a(ra[1]);
             lds_b[cur ^ 1][kq_lo][prow] = rb[0];
             lds_b[cur ^ 1][kq_lo + 2][prow] = rb[1];
         }
@@ -215,7 +235,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 constexpr int SM = 32, SU = 4;       // tile rows, and t-steps (8 k each) per prefetch chunk
 // NJ = 32-column MFMA tiles per wave: the tile is 32 x 32*NJ (NJ = 1 when even 32x64 tiles leave CUs idle)
 
-template <int NJ>
+template <int NJ, bool PW>
 __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
     constexpr int SN = 32 * NJ;
     __shared__ float part[4][SM][SN + 1];
@@ -256,6 +276,8 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
     f32x4 fb[2][SU][NJ];
     TapIter it;                                   // this lane's k = 8 t + 4 half, fetched in t order
     it.init(8 * t_begin + 4 * half, a.Cin, a.kw);
+    const float *in_pix = a.in + (size_t)(pix_ok ? pix : 0) * a.Cin;       // PW: address = pixel * Cin + k
+    int ka = 8 * t_begin + 4 * half;
     const int adv_tap = 8 / a.Cin, adv_c = 8 % a.Cin;
     // weight quads of t-steps past t_end exist (zero padding up to K16) or are clamped to the last
     // one; their A quads are flagged invalid, so the loop needs no tail branch
@@ -265,9 +287,15 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
 #pragma unroll
         for (int u = 0; u < SU; u++) {
             const int t = t0 + u;
-            fa[buf][u] = load_a(it);
-            fa[buf][u].ok = fa[buf][u].ok && t < t_end;
-            it.advance(adv_tap, adv_c, a.Cin, a.kw);
+            if (PW) {
+                fa[buf][u].ok = pix_ok && ka < a.K && t < t_end;
+                fa[buf][u].v = *reinterpret_cast<const f32x4 *>(in_pix + (fa[buf][u].ok ? ka : 0));
+                ka += 8;
+            } else {
+                fa[buf][u] = load_a(it);
+                fa[buf][u].ok = fa[buf][u].ok && t < t_end;
+                it.advance(adv_tap, adv_c, a.Cin, a.kw);
+            }
             const int kq = min(2 * t + half, kq_last);
 #pragma unroll
             for (int j = 0; j < NJ; j++) fb[buf][u][j] = wlane[(size_t)kq * a.CoutPad + 32 * j];
@@ -279,7 +307,8 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
             f32x4 av;
 #pragma unroll
             for (int e = 0; e < 4; e++)
-                av[e] = fa[buf][u].ok ? fmaxf(fa[buf][u].v[e], relu_floor) * a.in_scale + a.in_shift : 0.f;
+                av[e] = PW ? (fa[buf][u].ok ? fa[buf][u].v[e] : 0.f)
+                           : (fa[buf][u].ok ? fmaxf(fa[buf][u].v[e], relu_floor) * a.in_scale + a.in_shift : 0.f);
 #pragma unroll
             for (int s = 0; s < 4; s++)
 #pragma unroll
@@ -343,19 +372,25 @@ extern "C" int zs_conv2d_nhwc(const float *in, const float *packed_w, const floa
     const long long big_tiles = ((M + BM - 1) / BM) * (a.CoutPad / BN);
     static const long long big_min = getenv("ZS_CONV_BIG_MIN") ? atoll(getenv("ZS_CONV_BIG_MIN")) : 192;
     const bool small = (flags & ZS_CONV_FORCE_SMALL) || (!(flags & ZS_CONV_FORCE_LARGE) && big_tiles < big_min);
+    const bool pw = kh == 1 && kw == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && a.dil == 1 && !a.in_relu &&
+                    in_scale == 1.0f && in_shift == 0.0f && Hin == Hout && Win == Wout;
+    hipStream_t st = static_cast<hipStream_t>(stream);
     if (small) {
         static const long long narrow_below = getenv("ZS_CONV_NARROW_BELOW") ? atoll(getenv("ZS_CONV_NARROW_BELOW")) : 384;
         const long long wide = ((M + SM - 1) / SM) * ((Cout + 63) / 64);
         if (wide < narrow_below) {            // 32x32 tiles: twice the workgroups for the smallest problems
             const dim3 grid((unsigned)((M + SM - 1) / SM), (unsigned)((Cout + 31) / 32));
-            hipLaunchKernelGGL(conv_gemm_small_kernel<1>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+            if (pw) hipLaunchKernelGGL((conv_gemm_small_kernel<1, true>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((conv_gemm_small_kernel<1, false>), grid, dim3(256), 0, st, a);
         } else {
             const dim3 grid((unsigned)((M + SM - 1) / SM), (unsigned)((Cout + 63) / 64));
-            hipLaunchKernelGGL(conv_gemm_small_kernel<2>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+            if (pw) hipLaunchKernelGGL((conv_gemm_small_kernel<2, true>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((conv_gemm_small_kernel<2, false>), grid, dim3(256), 0, st, a);
         }
     } else {
         const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(a.CoutPad / BN));
-        hipLaunchKernelGGL(conv_gemm_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+        if (pw) hipLaunchKernelGGL(conv_gemm_kernel<true>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(conv_gemm_kernel<false>, grid, dim3(256), 0, st, a);
     }
     return zs::check_launch("zs_conv2d_nhwc") ? 1 : 0;
 }
