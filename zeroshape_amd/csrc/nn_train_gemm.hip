@@ -103,7 +103,9 @@ struct WgradArgs {
 // tile per wave) for big weight matrices over few pixels (token matrices, 14x14 maps): four times
 // the workgroups without splitting the short pixel range into slivers whose partial tiles would
 // cost more to write and reduce than to compute.
-template <int T>
+// PW: pointwise layers (1x1, stride 1, no padding, no input transform): A[p][k] = in[p * Cin + k], no pixel
+// decoding (two integer divisions per load) and no transform - VALU work the fp32 MFMA pipe cannot hide.
+template <int T, bool PW>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     constexpr int WLD = T + 32;                 // row stride % 64 == 32: the two k-halves hit disjoint banks
     constexpr int QUADS = T / 4, ROWS = 256 / QUADS, PASSES = WP / ROWS, NI = T / 64;
@@ -136,6 +138,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         const bool p_ok = p < p_end;
         const int pc = p_ok ? p : p_begin;
         f.y = (yc_ok && p_ok) ? *reinterpret_cast<const f32x4 *>(a.dy + (size_t)pc * a.CoutP + yc) : f32x4{0, 0, 0, 0};
+        if (PW) {
+            f.ok = p_ok && k_ok;
+            f.x = *reinterpret_cast<const f32x4 *>(a.in + (f.ok ? (size_t)pc * a.Cin + kk : 0));
+            return f;
+        }
         const int pb = pc / HW, rem = pc - pb * HW, py = rem / a.Wout, px = rem - py * a.Wout;
         const int iy = py * a.stride - a.pad_t + ky, ix = px * a.stride - a.pad_l + kx;
         f.ok = p_ok && k_ok && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
@@ -146,7 +153,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     auto store = [&](int buf, int row, const Frag &f) {
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = f.ok ? fmaxf(f.x[e], relu_floor) * a.in_scale + a.in_shift : 0.f;
+        for (int e = 0; e < 4; e++)
+            v[e] = PW ? (f.ok ? f.x[e] : 0.f) : (f.ok ? fmaxf(f.x[e], relu_floor) * a.in_scale + a.in_shift : 0.f);
         *reinterpret_cast<f32x4 *>(&lds_y[buf][row][4 * quad]) = f.y;
         *reinterpret_cast<f32x4 *>(&lds_a[buf][row][4 * quad]) = v;
         bsum += f.y;                 // every dY row of the tile passes through exactly one thread per column quad
@@ -429,10 +437,15 @@ extern "C" int zs_conv2d_wgrad(const float *in, const float *dy, float *dw, floa
     a.pix_per_split = (int)((M + splits - 1) / splits);
     a.pix_per_split = (a.pix_per_split + WP - 1) / WP * WP;
     const dim3 grid((a.CoutP + tile - 1) / tile, (a.K + tile - 1) / tile, splits);
-    if (tile == 64)
-        hipLaunchKernelGGL(wgrad_kernel<64>, grid, dim3(256), 0, S(stream), a);
-    else
-        hipLaunchKernelGGL(wgrad_kernel<128>, grid, dim3(256), 0, S(stream), a);
+    const bool pw = kh == 1 && kw == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && !a.in_relu && in_scale == 1.0f &&
+                    in_shift == 0.0f && Hin == Hout && Win == Wout;
+    if (tile == 64) {
+        if (pw) hipLaunchKernelGGL((wgrad_kernel<64, true>), grid, dim3(256), 0, S(stream), a);
+        else hipLaunchKernelGGL((wgrad_kernel<64, false>), grid, dim3(256), 0, S(stream), a);
+    } else {
+        if (pw) hipLaunchKernelGGL((wgrad_kernel<128, true>), grid, dim3(256), 0, S(stream), a);
+        else hipLaunchKernelGGL((wgrad_kernel<128, false>), grid, dim3(256), 0, S(stream), a);
+    }
     if (!zs::check_launch("zs_conv2d_wgrad")) return 0;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for((size_t)Cout * a.K)), dim3(256), 0, S(stream), a.partial, dw,
                        splits, a.CoutP, a.K, Cout, Cin, CinP, cin0, CinTot * kh * kw, kh * kw, accumulate ? 1 : 0, a.bias_partial,
