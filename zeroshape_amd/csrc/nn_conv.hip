@@ -78,6 +78,39 @@ struct TapIter {
     }
 };
 
+// Tap-major walk (Cin a multiple of the k step): a whole k step lies inside ONE tap, so validity
+// and the pixel offset are recomputed only when the tap changes (every Cin / step iterations, a
+// wave-uniform branch) and the per-step work is one add - instead of the TapIter's ~35 VALU
+// instructions per quad, which the fp32 MFMA pipe cannot hide (DESIGN.md sections 3, 11.5).
+struct TapWalk {
+    int tap, cc, ky, kx;          // uniform across the workgroup / wave
+    bool ok;                      // this lane's pixel has an in-range input at the current tap
+    size_t base;                  // offset of that input pixel (channel 0)
+    __device__ __forceinline__ void set_tap(const ConvArgs &a, bool pix_ok, int iy0, int ix0) {
+        const int vy = iy0 + ky, vx = ix0 + kx, sh = a.dil - 1;
+        const int iy = vy >> sh, ix = vx >> sh;
+        ok = pix_ok && ky < a.kh && vy >= 0 && iy < a.Hin && vx >= 0 && ix < a.Win && ((vy | vx) & sh) == 0;
+        base = ok ? ((size_t)iy * a.Win + ix) * a.Cin : 0;
+    }
+    __device__ __forceinline__ void init(const ConvArgs &a, int k, bool pix_ok, int iy0, int ix0) {
+        tap = k / a.Cin;
+        cc = k - tap * a.Cin;
+        ky = tap / a.kw;
+        kx = tap - ky * a.kw;
+        set_tap(a, pix_ok, iy0, ix0);
+    }
+    __device__ __forceinline__ void advance(const ConvArgs &a, int step, bool pix_ok, int iy0, int ix0) {
+        cc += step;
+        if (cc >= a.Cin) {        // uniform
+            cc -= a.Cin;
+            tap++;
+            kx++;
+            if (kx == a.kw) { kx = 0; ky++; }
+            set_tap(a, pix_ok, iy0, ix0);
+        }
+    }
+};
+
 // One A operand quad: issued unconditionally from a clamped address so the load stays in flight
 // (no branch, no wait); `ok` is applied when the value is used.
 struct AQuad { f32x4 v; bool ok; };
@@ -85,8 +118,10 @@ struct AQuad { f32x4 v; bool ok; };
 // PW: pointwise fast path (1x1, stride 1, no padding / dilation / input transform - every linear layer
 // and bottleneck 1x1): the operand address is pixel * Cin + k, no tap bookkeeping and no transform, which
 // removes most of the VALU work that the fp32 MFMA pipe cannot hide.
-template <bool PW>
+// MODE 0: generic taps.  MODE 2 (TM): tap-major walk, Cin % 16 == 0.  PLAIN: no input transform.
+template <bool PW, int MODE = 0, bool PLAIN = false>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
+    constexpr bool TM = MODE == 2;
     __shared__ f32x4 lds_a[2][KQ][BM];
     __shared__ f32x4 lds_b[2][KQ][BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -135,6 +170,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
         return q;
     };
     auto finish_pw = [&](const AQuad &q) -> f32x4 { return q.ok ? q.v : f32x4{0.f, 0.f, 0.f, 0.f}; };
+    TapWalk tw;                                                             // TM
+    if (TM) tw.init(a, 0, pix_ok, iy0, ix0);
+    auto load_tm = [&](int kq) -> AQuad {                                   // quad kq (0..3) of the current 16-chunk
+        AQuad q;
+        q.ok = tw.ok;
+        q.v = *reinterpret_cast<const f32x4 *>(in_b + tw.base + (tw.ok ? tw.cc + 4 * kq : 0));
+        return q;
+    };
+    auto finish_any = [&](const AQuad &q) -> f32x4 {
+        if (PW || PLAIN) return finish_pw(q);
+        return finish_a(q);
+    };
     const f32x4 *wq = reinterpret_cast<const f32x4 *>(a.w);
     auto load_b = [&](int kq, int n) -> f32x4 { return wq[(size_t)kq * a.CoutPad + n0 + n]; };
 
@@ -149,12 +196,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     const int ksteps = (a.K + BK - 1) / BK;
     AQuad ra[2];
     f32x4 rb[2];
-    ra[0] = PW ? load_pw(ka0) : load_a(it0);
-    ra[1] = PW ? load_pw(ka1) : load_a(it1);
+    ra[0] = PW ? load_pw(ka0) : (TM ? load_tm(kq_lo) : load_a(it0));
+    ra[1] = PW ? load_pw(ka1) : (TM ? load_tm(kq_lo + 2) : load_a(it1));
     rb[0] = load_b(kq_lo, prow);
     rb[1] = load_b(kq_lo + 2, prow);
-    lds_a[0][kq_lo][prow] = PW ? finish_pw(ra[0]) : finish_a(ra[0]);
-    lds_a[0][kq_lo + 2][prow] = PW ? finish_pw(ra[1]) : finish_a(ra[1]);
+    lds_a[0][kq_lo][prow] = finish_any(ra[0]);
+    lds_a[0][kq_lo + 2][prow] = finish_any(ra[1]);
     lds_b[0][kq_lo][prow] = rb[0];
     lds_b[0][kq_lo + 2][prow] = rb[1];
     __syncthreads();
@@ -169,6 +216,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
                 ka1 += BK;
                 ra[0] = load_pw(ka0);
                 ra[1] = load_pw(ka1);
+            } else if (TM) {
+                tw.advance(a, BK, pix_ok, iy0, ix0);
+                ra[0] = load_tm(kq_lo);
+                ra[1] = load_tm(kq_lo + 2);
             } else {
                 it0.advance(adv_tap, adv_c, a.Cin, a.kw);
                 it1.advance(adv_tap, adv_c, a.Cin, a.kw);
@@ -194,8 +245,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
         }
         if (more) {
-            lds_a[cur ^ 1][kq_lo][prow] = PW ? finish_pw(ra[0]) : finish_a(ra[0]);
-            lds_a[cur ^ 1][kq_lo + 2][prow] = PW ? finish_pw(ra[1]) : finish_a(ra[1]);
+            lds_a[cur ^ 1][kq_lo][prow] = finish_any(ra[0]);
+            lds_a[cur ^ 1][kq_lo + 2][prow] = finish_any(ra[1]);
             lds_b[cur ^ 1][kq_lo][prow] = rb[0];
             lds_b[cur ^ 1][kq_lo + 2][prow] = rb[1];
         }
@@ -235,8 +286,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 constexpr int SM = 32, SU = 4;       // tile rows, and t-steps (8 k each) per prefetch chunk
 // NJ = 32-column MFMA tiles per wave: the tile is 32 x 32*NJ (NJ = 1 when even 32x64 tiles leave CUs idle)
 
-template <int NJ, bool PW>
+template <int NJ, bool PW, int MODE = 0, bool PLAIN = false>
 __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
+    constexpr bool TM = MODE == 2;            // tap-major walk, Cin % 8 == 0
     constexpr int SN = 32 * NJ;
     __shared__ float part[4][SM][SN + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, half = lane >> 5;
@@ -278,6 +330,8 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
     it.init(8 * t_begin + 4 * half, a.Cin, a.kw);
     const float *in_pix = a.in + (size_t)(pix_ok ? pix : 0) * a.Cin;       // PW: address = pixel * Cin + k
     int ka = 8 * t_begin + 4 * half;
+    TapWalk tw;                                                             // TM: the wave's current 8-chunk
+    if (TM) tw.init(a, 8 * t_begin, pix_ok, iy0, ix0);
     const int adv_tap = 8 / a.Cin, adv_c = 8 % a.Cin;
     // weight quads of t-steps past t_end exist (zero padding up to K16) or are clamped to the last
     // one; their A quads are flagged invalid, so the loop needs no tail branch
@@ -291,6 +345,10 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
                 fa[buf][u].ok = pix_ok && ka < a.K && t < t_end;
                 fa[buf][u].v = *reinterpret_cast<const f32x4 *>(in_pix + (fa[buf][u].ok ? ka : 0));
                 ka += 8;
+            } else if (TM) {
+                fa[buf][u].ok = tw.ok && t < t_end;
+                fa[buf][u].v = *reinterpret_cast<const f32x4 *>(in_b + tw.base + (tw.ok ? tw.cc + 4 * half : 0));
+                tw.advance(a, 8, pix_ok, iy0, ix0);
             } else {
                 fa[buf][u] = load_a(it);
                 fa[buf][u].ok = fa[buf][u].ok && t < t_end;
@@ -307,8 +365,8 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
             f32x4 av;
 #pragma unroll
             for (int e = 0; e < 4; e++)
-                av[e] = PW ? (fa[buf][u].ok ? fa[buf][u].v[e] : 0.f)
-                           : (fa[buf][u].ok ? fmaxf(fa[buf][u].v[e], relu_floor) * a.in_scale + a.in_shift : 0.f);
+                av[e] = (PW || PLAIN) ? (fa[buf][u].ok ? fa[buf][u].v[e] : 0.f)
+                                      : (fa[buf][u].ok ? fmaxf(fa[buf][u].v[e], relu_floor) * a.in_scale + a.in_shift : 0.f);
 #pragma unroll
             for (int s = 0; s < 4; s++)
 #pragma unroll
@@ -375,23 +433,32 @@ extern "C" int zs_conv2d_nhwc(const float *in, const float *packed_w, const floa
     const bool pw = kh == 1 && kw == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && a.dil == 1 && !a.in_relu &&
                     in_scale == 1.0f && in_shift == 0.0f && Hin == Hout && Win == Wout;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool plain = !a.in_relu && in_scale == 1.0f && in_shift == 0.0f;
+    static const bool no_tm = getenv("ZS_CONV_NO_TAPMAJOR") != nullptr;       // A/B switch for measurements
+#define ZS_LAUNCH(KERNEL, ...)                                                              \
+    do {                                                                                    \
+        if (pw) hipLaunchKernelGGL((KERNEL<__VA_ARGS__ true>), grid, dim3(256), 0, st, a);     \
+        else if (tm && plain) hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, 2, true>), grid, dim3(256), 0, st, a);  \
+        else if (tm) hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, 2, false>), grid, dim3(256), 0, st, a);          \
+        else hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false>), grid, dim3(256), 0, st, a);      \
+    } while (0)
     if (small) {
         static const long long narrow_below = getenv("ZS_CONV_NARROW_BELOW") ? atoll(getenv("ZS_CONV_NARROW_BELOW")) : 384;
         const long long wide = ((M + SM - 1) / SM) * ((Cout + 63) / 64);
+        const bool tm = !pw && !no_tm && (Cin % 8) == 0;
         if (wide < narrow_below) {            // 32x32 tiles: twice the workgroups for the smallest problems
             const dim3 grid((unsigned)((M + SM - 1) / SM), (unsigned)((Cout + 31) / 32));
-            if (pw) hipLaunchKernelGGL((conv_gemm_small_kernel<1, true>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((conv_gemm_small_kernel<1, false>), grid, dim3(256), 0, st, a);
+            ZS_LAUNCH(conv_gemm_small_kernel, 1,);
         } else {
             const dim3 grid((unsigned)((M + SM - 1) / SM), (unsigned)((Cout + 63) / 64));
-            if (pw) hipLaunchKernelGGL((conv_gemm_small_kernel<2, true>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((conv_gemm_small_kernel<2, false>), grid, dim3(256), 0, st, a);
+            ZS_LAUNCH(conv_gemm_small_kernel, 2,);
         }
     } else {
         const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(a.CoutPad / BN));
-        if (pw) hipLaunchKernelGGL(conv_gemm_kernel<true>, grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(conv_gemm_kernel<false>, grid, dim3(256), 0, st, a);
+        const bool tm = !pw && !no_tm && (Cin % BK) == 0;
+        ZS_LAUNCH(conv_gemm_kernel, );
     }
+#undef ZS_LAUNCH
     return zs::check_launch("zs_conv2d_nhwc") ? 1 : 0;
 }
 
