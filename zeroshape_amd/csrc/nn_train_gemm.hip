@@ -133,7 +133,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     struct Frag { f32x4 y, x; bool ok; };
-    auto load = [&](int p) -> Frag {
+    // this thread's pixels p_begin + prow + ROWS*q + 16*step, decoded to (image, row, column) once and
+    // then advanced by 16 per step with compares and subtracts (no division in the loop); needs
+    // 16 <= 3 * Wout and 3 <= Hout... otherwise (tiny maps) the divisions stay
+    const bool incremental = !PW && a.Wout >= 6 && a.Hout >= 2;
+    int qb[PASSES], qy[PASSES], qx[PASSES];
+#pragma unroll
+    for (int q = 0; q < PASSES; q++) {
+        const int p = p_begin + prow + ROWS * q;
+        qb[q] = p / HW;
+        const int rem = p - qb[q] * HW;
+        qy[q] = rem / a.Wout;
+        qx[q] = rem - qy[q] * a.Wout;
+    }
+    auto load = [&](int p, int q) -> Frag {
         Frag f;
         const bool p_ok = p < p_end;
         const int pc = p_ok ? p : p_begin;
@@ -143,7 +156,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
             f.x = *reinterpret_cast<const f32x4 *>(a.in + (f.ok ? (size_t)pc * a.Cin + kk : 0));
             return f;
         }
-        const int pb = pc / HW, rem = pc - pb * HW, py = rem / a.Wout, px = rem - py * a.Wout;
+        int pb, py, px;
+        if (incremental) {
+            pb = qb[q]; py = qy[q]; px = qx[q];
+            qx[q] += WP;                                   // next step's pixel
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+                if (qx[q] >= a.Wout) { qx[q] -= a.Wout; qy[q]++; }
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+                if (qy[q] >= a.Hout) { qy[q] -= a.Hout; qb[q]++; }
+        } else {
+            pb = pc / HW;
+            const int rem = pc - pb * HW;
+            py = rem / a.Wout;
+            px = rem - py * a.Wout;
+        }
         const int iy = py * a.stride - a.pad_t + ky, ix = px * a.stride - a.pad_l + kx;
         f.ok = p_ok && k_ok && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
         const size_t off = f.ok ? (((size_t)pb * a.Hin + iy) * a.Win + ix) * a.Cin + kc : 0;
@@ -173,7 +201,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     if (steps > 0) {
         Frag f[PASSES];
 #pragma unroll
-        for (int q = 0; q < PASSES; q++) f[q] = load(p_begin + prow + ROWS * q);
+        for (int q = 0; q < PASSES; q++) f[q] = load(p_begin + prow + ROWS * q, q);
 #pragma unroll
         for (int q = 0; q < PASSES; q++) store(0, prow + ROWS * q, f[q]);
         __syncthreads();
@@ -182,7 +210,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
             const bool more = s + 1 < steps;
             if (more) {
 #pragma unroll
-                for (int q = 0; q < PASSES; q++) f[q] = load(p_begin + (s + 1) * WP + prow + ROWS * q);
+                for (int q = 0; q < PASSES; q++) f[q] = load(p_begin + (s + 1) * WP + prow + ROWS * q, q);
             }
 #pragma unroll
             for (int t = 0; t < WP / 2; t++) {
