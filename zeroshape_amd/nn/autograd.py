@@ -53,24 +53,6 @@ def _ceil4(n):
     return (n + 3) // 4 * 4
 
 
-# ---- per-parameter memo of derived device tensors (packed operands, standardised weights) ----
-_MEMO = {}
-
-
-def _memo(owner, subkey, make):
-    """Value of make() cached on `owner` (a Parameter) until its storage, version or the optimiser
-    generation changes."""
-    stamp = (owner.data_ptr(), owner._version, GENERATION[0], tuple(owner.shape))
-    slot = _MEMO.get(id(owner))
-    if slot is None or slot[0] != stamp or slot[2]() is not owner:
-        import weakref
-        slot = (stamp, {}, weakref.ref(owner, lambda _r, k=id(owner): _MEMO.pop(k, None)))
-        _MEMO[id(owner)] = slot
-    if subkey not in slot[1]:
-        slot[1][subkey] = make()
-    return slot[1][subkey]
-
-
 def _stamp(w):
     return (w.data_ptr(), w._version, GENERATION[0])
 
@@ -106,7 +88,6 @@ _PACK_TABLE = {}    # device -> (signature, table tensors)
 
 
 def clear_pack_cache():
-    _MEMO.clear()
     _PACKS.clear()
     _STD.clear()
     _PACK_TABLE.clear()
