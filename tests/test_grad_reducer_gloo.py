@@ -68,6 +68,18 @@ def _worker(rank, world, initfile):
             # gradients live in the flat buckets (no copy back)
             bi, off = red.slot[id(net.b.weight)]
             assert net.b.weight.grad.data_ptr() == red.flat[bi].data_ptr() + 4 * off
+        # gradient accumulation: two quiet micro-steps, the third is reduced (sum of the three, averaged)
+        net.zero_grad(set_to_none=True)
+        ref.zero_grad(set_to_none=True)
+        for k in range(3):
+            red.armed = k == 2
+            net(data[k][rank]).pow(2).mean().backward()
+            for r in range(world):
+                (ref(data[k][r]).pow(2).mean() / world).backward()
+        red.finish()
+        for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+            if not n.startswith("unused"):
+                assert torch.allclose(p.grad, q.grad, atol=1e-6, rtol=1e-5), ("accum", n)
         red.close()
     finally:
         dist.destroy_process_group()

@@ -161,6 +161,8 @@ class Runner:
         var, loss = self.graph.forward(opt, var, training=True, get_loss=True)
         loss = self.summarize_loss(opt, var, loss)
         loss_scaled = loss.all / opt.optim.accum
+        if self.reducer is not None:          # only the last micro-step of an accumulation window is reduced
+            self.reducer.armed = (self.it + 1) % opt.optim.accum == 0
         loss_scaled.backward()
         if (self.it + 1) % opt.optim.accum == 0:
             if self.reducer is not None:

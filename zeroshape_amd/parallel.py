@@ -173,6 +173,7 @@ class GradReducer(object):
         self.buckets = None            # built after the first backward pass
         self.works = []
         self._hooks = []
+        self.armed = True              # False during gradient-accumulation micro-steps: hooks stay quiet
 
     # ---- bucket layout ----
     def _build(self, used):
@@ -219,6 +220,8 @@ class GradReducer(object):
         self.pending[bi] = -1
 
     def _on_grad(self, p):
+        if not self.armed:
+            return
         bi, _ = self.slot[id(p)]
         self.pending[bi] -= 1
         if self.pending[bi] == 0:
