@@ -37,37 +37,53 @@ __device__ __forceinline__ float block_sum(float v, float *lds) {
 // ---------------- BatchNorm (training) ----------------
 // column partials over row chunks: MODE 0: (sum x, sum x^2); MODE 1: (sum g, sum g*xhat) with
 // g = dy (masked by y > 0 when y is given), xhat = (x - mean) * rstd
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// 64 channels per workgroup as 16 channel quads (float4 loads) x 16 row lanes
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict__ x, const float *__restrict__ dy,
                                                          const float *__restrict__ y, const float *__restrict__ mean,
                                                          const float *__restrict__ rstd, double *__restrict__ partial,
                                                          int rows, int C, int rows_per_chunk) {
-    __shared__ double lds[2][4][64];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6, c = blockIdx.x * 64 + cx;
+    __shared__ double lds[2][16][65];
+    const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4, c = blockIdx.x * 64 + 4 * cq;
     const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
-    double a = 0.0, b = 0.0;
-    if (c < C) {
-        const float mu = MODE ? mean[c] : 0.f, rs = MODE ? rstd[c] : 0.f;
-        for (int r = r0 + ry; r < r1; r += 4) {
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    if (c < C) {                                   // C % 4 == 0: a quad is in range as a whole
+        f32x4 mu = {0, 0, 0, 0}, rs = {0, 0, 0, 0};
+        if (MODE) {
+            mu = *reinterpret_cast<const f32x4 *>(mean + c);
+            rs = *reinterpret_cast<const f32x4 *>(rstd + c);
+        }
+        for (int r = r0 + ry; r < r1; r += 16) {
             const size_t o = (size_t)r * C + c;
+            const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + o);
             if (MODE == 0) {
-                const float v = x[o];
-                a += v;
-                b += (double)v * v;
+#pragma unroll
+                for (int e = 0; e < 4; e++) { a[e] += xv[e]; b[e] += (double)xv[e] * xv[e]; }
             } else {
-                float g = dy[o];
-                if (y && !(y[o] > 0.f)) g = 0.f;
-                a += g;
-                b += (double)g * ((x[o] - mu) * rs);
+                f32x4 g = *reinterpret_cast<const f32x4 *>(dy + o);
+                if (y) {
+                    const f32x4 yv = *reinterpret_cast<const f32x4 *>(y + o);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) g[e] = yv[e] > 0.f ? g[e] : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) { a[e] += g[e]; b[e] += (double)g[e] * ((xv[e] - mu[e]) * rs[e]); }
             }
         }
     }
-    lds[0][ry][cx] = a;
-    lds[1][ry][cx] = b;
+#pragma unroll
+    for (int e = 0; e < 4; e++) { lds[0][ry][4 * cq + e] = a[e]; lds[1][ry][4 * cq + e] = b[e]; }
     __syncthreads();
-    if (ry == 0 && c < C) {
-        partial[((size_t)blockIdx.y * 2 + 0) * C + c] = (lds[0][0][cx] + lds[0][1][cx]) + (lds[0][2][cx] + lds[0][3][cx]);
-        partial[((size_t)blockIdx.y * 2 + 1) * C + c] = (lds[1][0][cx] + lds[1][1][cx]) + (lds[1][2][cx] + lds[1][3][cx]);
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, col = threadIdx.x & 63, cc = blockIdx.x * 64 + col;
+        if (cc < C) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) t += lds[which][k][col];
+            partial[((size_t)blockIdx.y * 2 + which) * C + cc] = t;
+        }
     }
 }
 
@@ -113,12 +129,18 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__
                                                        const float *__restrict__ beta, const float *__restrict__ res,
                                                        const float *__restrict__ mean, const float *__restrict__ rstd,
                                                        float *__restrict__ y, size_t total, int C, int relu) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;          // C % 4 == 0
     if (i >= total) return;
     const int c = i % C;
-    float v = (x[i] - mean[c]) * rstd[c] * gamma[c] + beta[c];
-    if (res) v += res[i];
-    y[i] = relu ? fmaxf(v, 0.f) : v;
+    const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + i), mu = *reinterpret_cast<const f32x4 *>(mean + c),
+                rs = *reinterpret_cast<const f32x4 *>(rstd + c), ga = *reinterpret_cast<const f32x4 *>(gamma + c),
+                be = *reinterpret_cast<const f32x4 *>(beta + c);
+    f32x4 v = (xv - mu) * rs * ga + be;
+    if (res) v += *reinterpret_cast<const f32x4 *>(res + i);
+    if (relu)
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+    *reinterpret_cast<f32x4 *>(y + i) = v;
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const double *__restrict__ partial, int chunks, int C,
@@ -139,14 +161,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restri
                                                            const float *__restrict__ dgamma,
                                                            const float *__restrict__ dbeta, float *__restrict__ dx,
                                                            float *__restrict__ dres, size_t total, int C, float inv_n) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;          // C % 4 == 0
     if (i >= total) return;
     const int c = i % C;
-    float g = dy[i];
-    if (y && !(y[i] > 0.f)) g = 0.f;
-    const float xh = (x[i] - mean[c]) * rstd[c];
-    dx[i] = gamma[c] * rstd[c] * (g - dbeta[c] * inv_n - xh * dgamma[c] * inv_n);
-    if (dres) dres[i] = g;
+    f32x4 g = *reinterpret_cast<const f32x4 *>(dy + i);
+    if (y) {
+        const f32x4 yv = *reinterpret_cast<const f32x4 *>(y + i);
+#pragma unroll
+        for (int e = 0; e < 4; e++) g[e] = yv[e] > 0.f ? g[e] : 0.f;
+    }
+    const f32x4 rs = *reinterpret_cast<const f32x4 *>(rstd + c);
+    const f32x4 xh = (*reinterpret_cast<const f32x4 *>(x + i) - *reinterpret_cast<const f32x4 *>(mean + c)) * rs;
+    *reinterpret_cast<f32x4 *>(dx + i) = *reinterpret_cast<const f32x4 *>(gamma + c) * rs *
+        (g - *reinterpret_cast<const f32x4 *>(dbeta + c) * inv_n - xh * *reinterpret_cast<const f32x4 *>(dgamma + c) * inv_n);
+    if (dres) *reinterpret_cast<f32x4 *>(dres + i) = g;
 }
 
 // ---------------- GroupNorm backward: one workgroup per (sample, group), two passes ----------------
@@ -367,7 +395,7 @@ __global__ __launch_bounds__(256) void readout_concat_bwd_kernel(const float *__
 }
 
 int bn_chunks(int rows) {
-    int chunks = (rows + 127) / 128;
+    int chunks = (rows + 255) / 256;
     if (chunks > 256) chunks = 256;
     return chunks < 1 ? 1 : chunks;
 }
@@ -390,7 +418,7 @@ extern "C" int zs_batch_norm_train(const float *x, const float *gamma, const flo
                                    float *y, float *running_mean, float *running_var, float *save_mean,
                                    float *save_rstd, int rows, int C, float eps, float momentum, int relu,
                                    void *workspace, void *stream) {
-    ZS_REQUIRE(rows > 0 && C > 0, "zs_batch_norm_train: bad size (rows=%d C=%d)", rows, C);
+    ZS_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0, "zs_batch_norm_train: bad size (rows=%d C=%d; C %% 4 == 0)", rows, C);
     ZS_REQUIRE(x && gamma && beta && y && save_mean && save_rstd && workspace, "zs_batch_norm_train: null pointer");
     ZS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "zs_batch_norm_train: running stats come in pairs");
     const int chunks = bn_chunks(rows), per = (rows + chunks - 1) / chunks;
@@ -399,7 +427,7 @@ extern "C" int zs_batch_norm_train(const float *x, const float *gamma, const flo
                        nullptr, nullptr, partial, rows, C, per);
     hipLaunchKernelGGL(bn_stats_kernel, dim3((C + 63) / 64), dim3(256), 0, S(stream), partial, chunks, C, rows, eps,
                        momentum, running_mean, running_var, save_mean, save_rstd);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for((size_t)rows * C)), dim3(256), 0, S(stream), x, gamma, beta,
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for((size_t)rows * C / 4)), dim3(256), 0, S(stream), x, gamma, beta,
                        residual, save_mean, save_rstd, y, (size_t)rows * C, C, relu);
     return zs::check_launch("zs_batch_norm_train") ? 1 : 0;
 }
@@ -407,7 +435,7 @@ extern "C" int zs_batch_norm_train(const float *x, const float *gamma, const flo
 extern "C" int zs_batch_norm_bwd(const float *x, const float *dy, const float *y_relu, const float *gamma,
                                  const float *save_mean, const float *save_rstd, float *dx, float *dresidual,
                                  float *dgamma, float *dbeta, int rows, int C, void *workspace, void *stream) {
-    ZS_REQUIRE(rows > 0 && C > 0, "zs_batch_norm_bwd: bad size (rows=%d C=%d)", rows, C);
+    ZS_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0, "zs_batch_norm_bwd: bad size (rows=%d C=%d; C %% 4 == 0)", rows, C);
     ZS_REQUIRE(x && dy && gamma && save_mean && save_rstd && dx && dgamma && dbeta && workspace,
                "zs_batch_norm_bwd: null pointer");
     const int chunks = bn_chunks(rows), per = (rows + chunks - 1) / chunks;
@@ -416,7 +444,7 @@ extern "C" int zs_batch_norm_bwd(const float *x, const float *dy, const float *y
                        save_mean, save_rstd, partial, rows, C, per);
     hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 63) / 64), dim3(256), 0, S(stream), partial, chunks, C, dgamma,
                        dbeta);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for((size_t)rows * C)), dim3(256), 0, S(stream), x, dy, y_relu,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for((size_t)rows * C / 4)), dim3(256), 0, S(stream), x, dy, y_relu,
                        gamma, save_mean, save_rstd, dgamma, dbeta, dx, dresidual, (size_t)rows * C, C, 1.0f / rows);
     return zs::check_launch("zs_batch_norm_bwd") ? 1 : 0;
 }
