@@ -112,32 +112,48 @@ __global__ __launch_bounds__(256) void layer_norm_bwd_kernel(const float *__rest
 #pragma unroll
     for (int q = 0; q < LN_MAXQ; q++) dg[q] = db[q] = 0.f;
     const int r0 = blockIdx.x * LN_ROWS;
+    float gam[LN_MAXQ];
+#pragma unroll
+    for (int q = 0; q < LN_MAXQ; q++) gam[q] = lane + 64 * q < C ? gamma[lane + 64 * q] : 0.f;
     for (int rr = wave; rr < LN_ROWS; rr += 4) {
         const int row = r0 + rr;
         if (row >= rows) break;
+        // the row lives in registers (C <= 64 * LN_MAXQ): x and dy are read once
         const float *xr = x + (size_t)row * C, *gr = dy + (size_t)row * C;
+        float xv[LN_MAXQ], gv[LN_MAXQ];
         float s = 0.f;
-        for (int c = lane; c < C; c += 64) s += xr[c];
+#pragma unroll
+        for (int q = 0; q < LN_MAXQ; q++) {
+            const int c = lane + 64 * q;
+            xv[q] = c < C ? xr[c] : 0.f;
+            gv[q] = c < C ? gr[c] : 0.f;
+            s += xv[q];
+        }
         const float mean = wave_sum(s) / C;
         float q2 = 0.f;
-        for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; q2 += d * d; }
+#pragma unroll
+        for (int q = 0; q < LN_MAXQ; q++) {
+            const float d = lane + 64 * q < C ? xv[q] - mean : 0.f;
+            q2 += d * d;
+        }
         const float rstd = 1.0f / sqrtf(wave_sum(q2) / C + eps);
         float sg = 0.f, sgx = 0.f;
 #pragma unroll
         for (int q = 0; q < LN_MAXQ; q++) {
-            const int c = lane + 64 * q;
-            if (c < C) {
-                const float xh = (xr[c] - mean) * rstd, g = gr[c] * gamma[c];
+            if (lane + 64 * q < C) {
+                xv[q] = (xv[q] - mean) * rstd;                 // xhat from here on
+                const float g = gv[q] * gam[q];
                 sg += g;
-                sgx += g * xh;
-                dg[q] += gr[c] * xh;
-                db[q] += gr[c];
+                sgx += g * xv[q];
+                dg[q] += gv[q] * xv[q];
+                db[q] += gv[q];
             }
         }
         const float mg = wave_sum(sg) / C, mgx = wave_sum(sgx) / C;
-        for (int c = lane; c < C; c += 64) {
-            const float xh = (xr[c] - mean) * rstd;
-            dx[(size_t)row * C + c] = rstd * (gr[c] * gamma[c] - mg - xh * mgx);
+#pragma unroll
+        for (int q = 0; q < LN_MAXQ; q++) {
+            const int c = lane + 64 * q;
+            if (c < C) dx[(size_t)row * C + c] = rstd * (gv[q] * gam[q] - mg - xv[q] * mgx);
         }
     }
 #pragma unroll
