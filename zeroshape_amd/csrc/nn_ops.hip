@@ -33,22 +33,40 @@ __device__ __forceinline__ float block_sum(float v, float *lds) {
     return r;
 }
 
+__device__ __forceinline__ double block_sum_d(double v, double *lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    double r = lds[0];
+    for (int w = 1; w < nw; w++) r += lds[w];
+    return r;
+}
+
 // ---- GroupNorm over (HW x C/groups) of one sample, then affine, optional residual, optional ReLU ----
 constexpr int GN_BLOCK = 1024;
 __global__ __launch_bounds__(GN_BLOCK) void group_norm_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                          const float *__restrict__ beta,
                                                          const float *__restrict__ res, float *__restrict__ y,
                                                          int HW, int C, int groups, float eps, int relu) {
-    __shared__ float lds[GN_BLOCK / 64];
+    __shared__ double ldsd[GN_BLOCK / 64];
     const int b = blockIdx.x / groups, g = blockIdx.x % groups, cg = C / groups, n = HW * cg;
     const size_t base = (size_t)b * HW * C + (size_t)g * cg;
     auto at = [&](int e) -> size_t { return base + (size_t)(e / cg) * C + (e % cg); };
-    float s = 0.f;
-    for (int e = threadIdx.x; e < n; e += GN_BLOCK) s += x[at(e)];
-    const float mean = block_sum(s, lds) / n;
-    float q = 0.f;
-    for (int e = threadIdx.x; e < n; e += GN_BLOCK) { const float d = x[at(e)] - mean; q += d * d; }
-    const float rstd = 1.0f / sqrtf(block_sum(q, lds) / n + eps);
+    // one statistics pass: sum and sum of squares in double (no cancellation issue), then one output pass
+    double s = 0.0, q = 0.0;
+    for (int e = threadIdx.x; e < n; e += GN_BLOCK) {
+        const float v = x[at(e)];
+        s += v;
+        q += (double)v * v;
+    }
+    const double S = block_sum_d(s, ldsd), Q = block_sum_d(q, ldsd);
+    const double mean_d = S / n;
+    double var = Q / n - mean_d * mean_d;
+    var = var < 0.0 ? 0.0 : var;
+    const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
     for (int e = threadIdx.x; e < n; e += GN_BLOCK) {
         const size_t o = at(e);
         const int c = g * cg + e % cg;
