@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 14
+#define ZS_ABI_VERSION 15
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -402,6 +402,26 @@ int zs_bce_logits(const float *logits, const float *sdf, size_t n, float impt_th
                   void *workspace, void *stream);
 int zs_bce_logits_bwd(const float *logits, const float *sdf, size_t n, float impt_thres, float impt_weight,
                       const float *grad_loss, float *dlogits, void *stream);
+/* The depth task's losses (options/depth.yaml).
+ *   zs_midas_loss : MidasLoss.forward (model/depth/midas_loss.py:166-185, shrink_mask False) on
+ *       prediction / target / mask [B][1][H][W] (valid where mask > 0.5): scale-and-shift-invariant MAE
+ *       (median / mean-absolute-deviation alignment per image) + alpha * gradient matching over
+ *       `scales` <= 4 power-of-two strides of the least-squares aligned maps (inverse_depth != 0:
+ *       1 / (d + 1e-6) first), image-based reduction.  *loss is a device scalar; workspace
+ *       (zs_midas_loss_workspace_bytes(B)) keeps the per-image statistics for the backward.
+ *   zs_midas_loss_bwd : d loss / d prediction [B][1][H][W], scaled by *grad_loss (device), through
+ *       the median element, the deviations and the 2x2 least-squares solve, like torch.autograd.
+ *   zs_intr_loss(_bwd) : Loss.intr_loss (utils/loss.py:36-43): seen_* [n][3], mask [n] over the
+ *       whole batch; out2 = (loss, sum of the mask) on the device. */
+size_t zs_midas_loss_workspace_bytes(int batch);
+int zs_midas_loss(const float *prediction, const float *target, const float *mask, int batch, int H, int W, float alpha,
+                  int scales, int inverse_depth, float *loss, void *workspace, void *stream);
+int zs_midas_loss_bwd(const float *prediction, const float *target, const float *mask, int batch, int H, int W,
+                      float alpha, int scales, int inverse_depth, const void *workspace, const float *grad_loss,
+                      float *dprediction, void *stream);
+int zs_intr_loss(const float *seen_pred, const float *seen_gt, const float *mask, size_t n, float *out2, void *stream);
+int zs_intr_loss_bwd(const float *seen_pred, const float *seen_gt, const float *mask, size_t n, const float *out2,
+                     const float *grad_loss, float *dseen_pred, void *stream);
 int zs_multi_tensor_chunk_elems(void);
 int zs_adamw_multi(const zs_tensor_entry *table, const int *chunk_tensor, const unsigned long long *chunk_start,
                    int n_chunks, float beta1, float beta2, float eps, int step, const float *grad_scale, void *stream);

@@ -80,8 +80,10 @@ def test_unsupported_configurations_raise():
     with pytest.raises(ValueError):
         g.forward(make_opt(), var, training=False, get_loss=False)
     from zeroshape_amd.utils.loss import Loss
-    with pytest.raises(NotImplementedError):              # losses of options/depth.yaml: not on the HIP path yet
-        Loss(make_opt()).depth_loss(torch.zeros(1, 1, 2, 2), torch.zeros(1, 1, 2, 2), torch.zeros(1, 1, 2, 2))
+    lopt = edict(training=dict(shape_loss=dict(impt_weight=1, impt_thres=0.01),
+                               depth_loss=dict(grad_reg=0.1, depth_inv=True, mask_shrink=True)))
+    with pytest.raises(NotImplementedError):              # eroded masks: not on the HIP path
+        Loss(lopt).depth_loss(torch.zeros(1, 1, 2, 2), torch.zeros(1, 1, 2, 2), torch.zeros(1, 1, 2, 2))
     with pytest.raises(NotImplementedError):              # train mode: BN folding is eval-only
         g.dpt_depth.train().packed("cpu")
 

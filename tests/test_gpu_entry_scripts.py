@@ -56,8 +56,6 @@ def test_depth_engine_evaluates(tmp_path, encoder_sd):
     var = r.evaluate_batch(opt, options.EasyDict(next(iter(r.test_loader))))
     assert var.depth_pred.shape == (2, 1, 224, 224) and var.intr_pred.shape == (2, 3, 3)
     assert var.seen_points_pred.shape == var.seen_points_gt.shape == (2, 224 * 224, 3)
-    with pytest.raises(NotImplementedError):
-        r.train(opt)
 
 
 def test_demo_script_shape_and_depth(tmp_path, encoder_sd, seeded_sd):

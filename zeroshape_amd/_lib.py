@@ -97,6 +97,12 @@ SIGNATURES = {
                                _c_void_p]),
     "zs_bce_logits_bwd": (_c_int, [_c_void_p, _c_void_p, _c_size_t, _c_float, _c_float, _c_void_p, _c_void_p,
                                    _c_void_p]),
+    "zs_midas_loss_workspace_bytes": (_c_size_t, [_c_int]),
+    "zs_midas_loss": (_c_int, [_c_void_p] * 3 + [_c_int] * 3 + [_c_float, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "zs_midas_loss_bwd": (_c_int, [_c_void_p] * 3 + [_c_int] * 3 + [_c_float, _c_int, _c_int, _c_void_p, _c_void_p,
+                                                                    _c_void_p, _c_void_p]),
+    "zs_intr_loss": (_c_int, [_c_void_p] * 3 + [_c_size_t, _c_void_p, _c_void_p]),
+    "zs_intr_loss_bwd": (_c_int, [_c_void_p] * 3 + [_c_size_t] + [_c_void_p] * 4),
     "zs_multi_tensor_chunk_elems": (_c_int, []),
     "zs_adamw_multi": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_float, _c_float, _c_float, _c_int,
                                 _c_void_p, _c_void_p]),
@@ -119,7 +125,7 @@ SIGNATURES = {
     "zs_readout_concat_bwd": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
 }
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 _lib = None
 
 

@@ -6,6 +6,8 @@ loss, intrinsics loss) are not on the HIP path and raise (zeroshape_amd/utils/lo
 import torch
 import torch.nn as nn
 
+from ...nn import autograd as A
+from ...nn import ops, train_blocks
 from ...nn.module import HipModule
 from ...utils import camera
 from ...utils.layers import Bottleneck_Conv
@@ -47,22 +49,32 @@ class Graph(nn.Module):
 
     def forward(self, opt, var, training=False, get_loss=True):
         """:62-97."""
-        if training or get_loss:
-            raise NotImplementedError("graph_depth: the depth task's losses (MiDaS depth loss, intrinsics loss) are not "
-                                      "on the HIP path; inference / evaluation only (training=False, get_loss=False)")
         HipModule._need_gpu(var.rgb_input_map, "var.rgb_input_map")
         batch_size = len(var.idx)
-        with torch.no_grad():
-            rgb = var.rgb_input_map.detach().float().contiguous()
-            if not self.with_intr:
-                var.depth_pred = self.dpt_depth(rgb)
-                return var
-            var.depth_pred, intr_feat = self.dpt_depth(rgb, get_feat=True)
-            var.intr_pred = self.intr_param2mtx(opt, self._intr.run(intr_feat))
-            var.seen_points_pred = camera.seen_surface(opt, var.depth_pred, var.intr_pred, var.mask_input_map, dsp=1)[0]
-            if 'depth_input_map' in var:
-                var.seen_points_gt = camera.seen_surface(opt, var.depth_input_map, var.intr, var.mask_input_map, dsp=1)[0]
-                var.validity_mask = (var.mask_input_map > 0.5).float().view(batch_size, -1)
+        rgb = var.rgb_input_map.detach().float().contiguous()
+        mask = var.mask_input_map.detach().float().contiguous()
+        autograd = torch.is_grad_enabled() and self.dpt_depth.training
+        if not autograd:
+            with torch.no_grad():
+                if not self.with_intr:
+                    var.depth_pred = self.dpt_depth(rgb)
+                else:
+                    var.depth_pred, intr_feat = self.dpt_depth(rgb, get_feat=True)
+                    var.intr_pred = self.intr_param2mtx(opt, self._intr.run(intr_feat))
+                    var.seen_points_pred = camera.seen_surface(opt, var.depth_pred, var.intr_pred, mask, dsp=1)[0]
+        else:
+            var.depth_pred, layer_4 = self.dpt_depth.forward_train(rgb)
+            if self.with_intr:
+                x = train_blocks.bottleneck_conv(train_blocks.bottleneck_conv(layer_4, self.intr_head[0]), self.intr_head[1])
+                intr_params = A.linear(A.global_mean(x), self.intr_proj.weight, self.intr_proj.bias)
+                var.intr_pred = A.intr_param2mtx(intr_params, opt.H, opt.W)
+                var.seen_points_pred, _, _ = A.seen_surface(var.depth_pred, var.intr_pred, mask)
+        if self.with_intr and ('depth_input_map' in var or training):
+            with torch.no_grad():                                                  # :84-93
+                var.seen_points_gt = camera.seen_surface(opt, var.depth_input_map, var.intr, mask, dsp=1)[0]
+                var.validity_mask = (mask > 0.5).float().view(batch_size, -1)
+        if get_loss:
+            return var, self.compute_loss(opt, var, training)
         return var
 
     def compute_loss(self, opt, var, training=False):

@@ -1,8 +1,9 @@
-"""Mirror of the reference's model/depth_engine.py::Runner for evaluation: DPT depth + intrinsics
-through graph_depth.Graph, DepthMetric (scale/shift aligned d>thr / rmse / l1 / abs_rel, one fused
-launch per batch), per-sample metrics gathered over the ranks, best_val.txt in the reference's
-format (:270-382).  Training this task needs the MiDaS loss, which is not on the HIP path: train()
-raises."""
+"""Mirror of the reference's model/depth_engine.py::Runner: DPT depth + intrinsics through
+graph_depth.Graph.  Training (setup_optimizer :77-101: two AdamW groups; train / train_epoch /
+train_iteration :124-236) shares the loop of the shape engine - HIP autograd forward / backward, MiDaS
+depth loss + intrinsics loss, bucketed RCCL gradient averaging, fused AdamW.  Evaluation (:270-382):
+DepthMetric (scale/shift aligned d>thr / rmse / l1 / abs_rel, one fused launch per batch), per-sample
+metrics gathered over the ranks, best_val.txt in the reference's format."""
 import os
 
 import torch
@@ -11,26 +12,20 @@ import torch.distributed as dist
 from ..utils import util
 from ..utils.eval_depth import DepthMetric
 from ..utils.options import EasyDict as edict
+from . import shape_engine
 from .compute_graph import graph_depth
 
 
-class Runner:
-    def __init__(self, opt):
-        self.opt = opt
-        world = getattr(opt, "world_size", 1) or 1
-        if world > 1:
-            if "port" in opt and isinstance(opt.device, int):
-                util.setup(opt.device, world, opt.port)                      # :32
-            if "batch_size" in opt and not getattr(opt, "_batch_divided", False):
-                opt.batch_size = opt.batch_size // world
-                opt._batch_divided = True
-        self.test_data = self.test_loader = None
+class Runner(shape_engine.Runner):
+    """Inherits the process setup, the train loop (train / train_epoch / train_iteration /
+    summarize_loss / checkpoints) and restore_checkpoint of the shape engine; differs in the graph,
+    the data sets (no 3-D annotations), the optimiser groups and the evaluation."""
 
-    def load_dataset(self, opt, eval_split="test", dataset=None):
-        """:46-68 (test side; datasets without 3-D annotations: load_3D=False)."""
+    def load_dataset(self, opt, eval_split="test", dataset=None, train_dataset=None):
+        """:46-68 (datasets without 3-D annotations: load_3D=False)."""
         import importlib
+        pkg = __name__.rsplit(".", 2)[0] + ".data."
         if dataset is None:
-            pkg = __name__.rsplit(".", 2)[0] + ".data."
             dataset = importlib.import_module(pkg + opt.data.dataset_test).Dataset(opt, split=eval_split, load_3D=False)
         self.test_data = dataset
         sampler = None
@@ -38,23 +33,35 @@ class Runner:
             sampler = torch.utils.data.distributed.DistributedSampler(self.test_data, shuffle=False, drop_last=False)
         self.test_loader = torch.utils.data.DataLoader(self.test_data, batch_size=opt.eval.batch_size, shuffle=False,
                                                        sampler=sampler, num_workers=0, drop_last=False)
+        if train_dataset is not None or ("batch_size" in opt and "dataset_train" in opt.data and "optim" in opt):
+            if train_dataset is None:
+                train_dataset = importlib.import_module(pkg + opt.data.dataset_train).Dataset(opt, split="train",
+                                                                                              load_3D=False)
+            self.load_train_dataset(opt, dataset=train_dataset)
 
     def build_networks(self, opt):
         self.graph = graph_depth.Graph(opt).to(opt.device).eval()
-        self.depth_metric = DepthMetric(thresholds=opt.eval.d_thresholds, depth_cap=opt.eval.depth_cap)   # :75
+        self.depth_metric = DepthMetric(thresholds=opt.eval.d_thresholds, depth_cap=opt.eval.depth_cap)   # :73
 
     def setup_optimizer(self, opt):
-        raise NotImplementedError("depth_engine: training the depth task needs the MiDaS loss (not on the HIP path)")
-
-    def train(self, opt):
-        raise NotImplementedError("depth_engine: training the depth task needs the MiDaS loss (not on the HIP path)")
-
-    def restore_checkpoint(self, opt, best=False, evaluate=False):
-        if getattr(opt, "load", None):
-            util.restore_checkpoint(opt, self, load_name=opt.load)
-
-    def setup_visualizer(self, opt, test=False):
-        return None
+        """:77-101: biases and 1-d tensors without weight decay, everything at optim.lr."""
+        from .. import parallel
+        from ..optim import FusedAdamW
+        nodecay, decay = [], []
+        for name, param in self.graph.named_parameters():
+            if not param.requires_grad:
+                continue
+            (nodecay if (param.ndim <= 1 or name.endswith(".bias")) else decay).append(param)
+        self.optim = FusedAdamW([{'params': nodecay, 'lr': opt.optim.lr, 'weight_decay': 0.},
+                                 {'params': decay, 'lr': opt.optim.lr, 'weight_decay': opt.optim.weight_decay}],
+                                betas=(0.9, 0.95))
+        if opt.optim.sched:
+            self.sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.optim, opt.max_epoch)
+        if opt.optim.amp:
+            raise NotImplementedError("optim.amp: the HIP training path is fp32 (options/depth.yaml amp false)")
+        if getattr(opt, "world_size", 1) > 1:
+            self.reducer = parallel.GradReducer(self.graph.parameters(),
+                                                bucket_mb=getattr(opt.optim, "bucket_mb", 64.0))
 
     @torch.no_grad()
     def evaluate_batch(self, opt, var, ep=None, it=None, single_gpu=False):
@@ -88,5 +95,5 @@ class Runner:
                     for k in keys:
                         outfile.write('{}: {:.6f}\n'.format(k, metric_avg[k]))
             self.last_metrics = metric_avg
-            return metric_avg['l1_err']
-        return float('inf')
+            return dict(metric_avg, cd=metric_avg['l1_err']) if training else metric_avg['l1_err']
+        return dict(cd=float('inf')) if training else float('inf')

@@ -942,3 +942,73 @@ class _ReadoutConcat(torch.autograd.Function):
 
 def readout_concat(tokens):
     return _ReadoutConcat.apply(tokens)
+
+
+# ---- the depth task's losses (options/depth.yaml) ----
+class _MidasLoss(torch.autograd.Function):
+    """MidasLoss.forward (model/depth/midas_loss.py:166-185): ssi MAE + alpha * gradient matching."""
+
+    @staticmethod
+    def forward(ctx, prediction, target, mask, alpha, scales, inverse_depth):
+        lib = _lib.load()
+        p, t = _f32c(prediction, "depth prediction"), _f32c(target.float(), "depth target")
+        m = _f32c(mask.float(), "depth mask")
+        B, _, H, W = p.shape
+        loss = torch.empty((), dtype=torch.float32, device=p.device)
+        ws = torch.empty((lib.zs_midas_loss_workspace_bytes(B) + 3) // 4, dtype=torch.float32, device=p.device)
+        with torch.cuda.device(p.device):
+            _lib.check(lib.zs_midas_loss(_lib.ptr(p), _lib.ptr(t), _lib.ptr(m), B, H, W, float(alpha), int(scales),
+                                         1 if inverse_depth else 0, _lib.ptr(loss), _lib.ptr(ws), _stream(p)),
+                       "zs_midas_loss")
+        ctx.cfg = (alpha, scales, inverse_depth)
+        ctx.save_for_backward(p, t, m, ws)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        lib = _lib.load()
+        p, t, m, ws = ctx.saved_tensors
+        alpha, scales, inverse_depth = ctx.cfg
+        B, _, H, W = p.shape
+        dloss = _f32c(dloss, "loss grad")
+        dp = torch.empty_like(p)
+        with torch.cuda.device(p.device):
+            _lib.check(lib.zs_midas_loss_bwd(_lib.ptr(p), _lib.ptr(t), _lib.ptr(m), B, H, W, float(alpha), int(scales),
+                                             1 if inverse_depth else 0, _lib.ptr(ws), _lib.ptr(dloss), _lib.ptr(dp),
+                                             _stream(p)), "zs_midas_loss_bwd")
+        return dp, None, None, None, None, None
+
+
+def midas_loss(prediction, target, mask, alpha=0.1, scales=4, inverse_depth=True):
+    return _MidasLoss.apply(prediction, target, mask, alpha, scales, inverse_depth)
+
+
+class _IntrLoss(torch.autograd.Function):
+    """Loss.intr_loss (utils/loss.py:36-43)."""
+
+    @staticmethod
+    def forward(ctx, seen_pred, seen_gt, mask):
+        lib = _lib.load()
+        a, b, m = _f32c(seen_pred, "seen_pred"), _f32c(seen_gt.float(), "seen_gt"), _f32c(mask.float(), "mask")
+        n = m.numel()
+        assert a.numel() == 3 * n and b.numel() == 3 * n
+        out = torch.empty(2, dtype=torch.float32, device=a.device)
+        with torch.cuda.device(a.device):
+            _lib.check(lib.zs_intr_loss(_lib.ptr(a), _lib.ptr(b), _lib.ptr(m), n, _lib.ptr(out), _stream(a)), "zs_intr_loss")
+        ctx.save_for_backward(a, b, m, out)
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, dloss):
+        lib = _lib.load()
+        a, b, m, out = ctx.saved_tensors
+        dloss = _f32c(dloss, "loss grad")
+        da = torch.empty_like(a)
+        with torch.cuda.device(a.device):
+            _lib.check(lib.zs_intr_loss_bwd(_lib.ptr(a), _lib.ptr(b), _lib.ptr(m), m.numel(), _lib.ptr(out), _lib.ptr(dloss),
+                                            _lib.ptr(da), _stream(a)), "zs_intr_loss_bwd")
+        return da, None, None
+
+
+def intr_loss(seen_pred, seen_gt, mask):
+    return _IntrLoss.apply(seen_pred, seen_gt, mask)
