@@ -105,8 +105,12 @@ struct WgradArgs {
 // cost more to write and reduce than to compute.
 // PW: pointwise layers (1x1, stride 1, no padding, no input transform): A[p][k] = in[p * Cin + k], no pixel
 // decoding (two integer divisions per load) and no transform - VALU work the fp32 MFMA pipe cannot hide.
-template <int T, bool PW>
+// MODE 0: generic (pixel decode by division, 64-bit offsets, input transform).  MODE 1 = PW.
+// MODE 2 = FAST: no input transform, pixel decode advanced incrementally (Wout >= 6, Hout >= 2), 32-bit
+// offsets (the input has < 2^31 elements) - every 3x3 layer of the encoders.
+template <int T, int MODE>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+    constexpr bool PW = MODE == 1, FAST = MODE == 2;
     constexpr int WLD = T + 32;                 // row stride % 64 == 32: the two k-halves hit disjoint banks
     constexpr int QUADS = T / 4, ROWS = 256 / QUADS, PASSES = WP / ROWS, NI = T / 64;
     __shared__ __attribute__((aligned(16))) float lds_y[2][WP][WLD];
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     // this thread's pixels p_begin + prow + ROWS*q + 16*step, decoded to (image, row, column) once and
     // then advanced by 16 per step with compares and subtracts (no division in the loop); needs
     // 16 <= 3 * Wout and 3 <= Hout... otherwise (tiny maps) the divisions stay
-    const bool incremental = !PW && a.Wout >= 6 && a.Hout >= 2;
+    constexpr bool incremental = FAST;
     int qb[PASSES], qy[PASSES], qx[PASSES];
 #pragma unroll
     for (int q = 0; q < PASSES; q++) {
@@ -174,15 +178,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         }
         const int iy = py * a.stride - a.pad_t + ky, ix = px * a.stride - a.pad_l + kx;
         f.ok = p_ok && k_ok && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-        const size_t off = f.ok ? (((size_t)pb * a.Hin + iy) * a.Win + ix) * a.Cin + kc : 0;
-        f.x = *reinterpret_cast<const f32x4 *>(a.in + off);
+        if (FAST) {
+            const int off = f.ok ? ((pb * a.Hin + iy) * a.Win + ix) * a.Cin + kc : 0;
+            f.x = *reinterpret_cast<const f32x4 *>(a.in + off);
+        } else {
+            const size_t off = f.ok ? (((size_t)pb * a.Hin + iy) * a.Win + ix) * a.Cin + kc : 0;
+            f.x = *reinterpret_cast<const f32x4 *>(a.in + off);
+        }
         return f;
     };
     auto store = [&](int buf, int row, const Frag &f) {
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; e++)
-            v[e] = PW ? (f.ok ? f.x[e] : 0.f) : (f.ok ? fmaxf(f.x[e], relu_floor) * a.in_scale + a.in_shift : 0.f);
+            v[e] = (PW || FAST) ? (f.ok ? f.x[e] : 0.f) : (f.ok ? fmaxf(f.x[e], relu_floor) * a.in_scale + a.in_shift : 0.f);
         *reinterpret_cast<f32x4 *>(&lds_y[buf][row][4 * quad]) = f.y;
         *reinterpret_cast<f32x4 *>(&lds_a[buf][row][4 * quad]) = v;
         bsum += f.y;                 // every dY row of the tile passes through exactly one thread per column quad
@@ -465,15 +474,19 @@ extern "C" int zs_conv2d_wgrad(const float *in, const float *dy, float *dw, floa
     a.pix_per_split = (int)((M + splits - 1) / splits);
     a.pix_per_split = (a.pix_per_split + WP - 1) / WP * WP;
     const dim3 grid((a.CoutP + tile - 1) / tile, (a.K + tile - 1) / tile, splits);
-    const bool pw = kh == 1 && kw == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && !a.in_relu && in_scale == 1.0f &&
-                    in_shift == 0.0f && Hin == Hout && Win == Wout;
-    if (tile == 64) {
-        if (pw) hipLaunchKernelGGL((wgrad_kernel<64, true>), grid, dim3(256), 0, S(stream), a);
-        else hipLaunchKernelGGL((wgrad_kernel<64, false>), grid, dim3(256), 0, S(stream), a);
-    } else {
-        if (pw) hipLaunchKernelGGL((wgrad_kernel<128, true>), grid, dim3(256), 0, S(stream), a);
-        else hipLaunchKernelGGL((wgrad_kernel<128, false>), grid, dim3(256), 0, S(stream), a);
-    }
+    const bool plain = !a.in_relu && in_scale == 1.0f && in_shift == 0.0f;
+    const bool pw = kh == 1 && kw == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && plain && Hin == Hout && Win == Wout;
+    const bool fast = !pw && plain && Wout >= 6 && Hout >= 2 && (long long)batch * Hin * Win * CinP < (1LL << 31);
+    const int mode = pw ? 1 : (fast ? 2 : 0);
+#define ZS_WGRAD(TT)                                                                                          \
+    do {                                                                                                      \
+        if (mode == 1) hipLaunchKernelGGL((wgrad_kernel<TT, 1>), grid, dim3(256), 0, S(stream), a);            \
+        else if (mode == 2) hipLaunchKernelGGL((wgrad_kernel<TT, 2>), grid, dim3(256), 0, S(stream), a);       \
+        else hipLaunchKernelGGL((wgrad_kernel<TT, 0>), grid, dim3(256), 0, S(stream), a);                      \
+    } while (0)
+    if (tile == 64) ZS_WGRAD(64);
+    else ZS_WGRAD(128);
+#undef ZS_WGRAD
     if (!zs::check_launch("zs_conv2d_wgrad")) return 0;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for((size_t)Cout * a.K)), dim3(256), 0, S(stream), a.partial, dw,
                        splits, a.CoutP, a.K, Cout, Cin, CinP, cin0, CinTot * kh * kw, kh * kw, accumulate ? 1 : 0, a.bias_partial,
