@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 15
+#define ZS_ABI_VERSION 16
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -140,6 +140,24 @@ int zs_sdf_query_points(const void *programs, size_t program_stride_bytes, int b
 int zs_sdf_query_grid(const void *programs, size_t program_stride_bytes, int batch,
                       const float *axis, int G, int slice_begin, int slice_end,
                       int apply_sigmoid, float *out, void *workspace, void *stream);
+
+/* Split-bf16 ("bf16x3") decoder: the same network with every contraction on the bf16 matrix
+ * pipe, both operands split into two bf16 halves (A B ~= Ah Bh + Ah Bl + Al Bh, fp32
+ * accumulation): ~2^-17 relative operand error, max |logit error| ~2e-5 against the fp32
+ * reference (contract 1e-4), several times the throughput of the exact-fp32 kernels above.
+ *   zs_sdf_split_programs     fp32 programs (after zs_sdf_prologue) -> split programs of the
+ *                             same size and stride rules (split_programs must not alias programs)
+ *   zs_sdf_query_points_split / zs_sdf_query_grid_split
+ *                             as zs_sdf_query_points (without the attention map) / _grid, on
+ *                             split programs; same workspace */
+int zs_sdf_split_programs(const void *programs, size_t program_stride_bytes, void *split_programs,
+                          size_t split_stride_bytes, int batch, void *stream);
+int zs_sdf_query_points_split(const void *split_programs, size_t program_stride_bytes, int batch,
+                              const float *points, int m, float *logits, void *workspace,
+                              void *stream);
+int zs_sdf_query_grid_split(const void *split_programs, size_t program_stride_bytes, int batch,
+                            const float *axis, int G, int slice_begin, int slice_end,
+                            int apply_sigmoid, float *out, void *workspace, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Brute-force pose search support (brute_force_search, utils/eval_3D.py:140-170).

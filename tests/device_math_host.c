@@ -1,4 +1,4 @@
-/* Host mirror of the activation formulas in zeroshape_amd/csrc/sdf_decoder.hip (same
+/* Host mirror of the activation formulas in zeroshape_amd/csrc/sdf_math.h (same
  * constants, same operation order, fmaf where the kernel uses fmaf; exp2f/log2f stand in
  * for v_exp_f32 / v_log_f32, 1.0f/x for v_rcp_f32).  tests/test_device_math.py bounds
  * their error against fp64. */

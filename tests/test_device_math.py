@@ -1,4 +1,4 @@
-"""Error bounds of the kernel's cheap activation formulas (csrc/sdf_decoder.hip: gelu_erf,
+"""Error bounds of the kernel's cheap activation formulas (csrc/sdf_math.h: gelu_erf,
 softplus100) against fp64, evaluated on the host through an operation-for-operation C mirror
 (tests/device_math_host.c).  On this chip every VALU instruction costs MFMA time, so the
 kernel uses the shortest formulas that stay far inside the 1e-4 output contract."""

@@ -37,6 +37,11 @@ SIGNATURES = {
                                      _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "zs_sdf_query_grid": (_c_int, [_c_void_p, _c_size_t, _c_int, _c_void_p, _c_int, _c_int,
                                    _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "zs_sdf_split_programs": (_c_int, [_c_void_p, _c_size_t, _c_void_p, _c_size_t, _c_int, _c_void_p]),
+    "zs_sdf_query_points_split": (_c_int, [_c_void_p, _c_size_t, _c_int, _c_void_p, _c_int,
+                                           _c_void_p, _c_void_p, _c_void_p]),
+    "zs_sdf_query_grid_split": (_c_int, [_c_void_p, _c_size_t, _c_int, _c_void_p, _c_int, _c_int,
+                                         _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "zs_bf_grid_bytes": (_c_size_t, []),
     "zs_bf_scratch_bytes": (_c_size_t, []),
     "zs_bf_lower_bounds": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
@@ -125,7 +130,7 @@ SIGNATURES = {
     "zs_readout_concat_bwd": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
 }
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 _lib = None
 
 

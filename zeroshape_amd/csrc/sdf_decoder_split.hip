@@ -1,0 +1,705 @@
+// Split-bf16 ("bf16x3") variant of the fused implicit-occupancy decoder for MI355X (gfx950).
+//
+// Same algorithm, same per-point dataflow and the same decoder program as csrc/sdf_decoder.hip
+// (Implicit.forward, model/shape/implicit.py:251-288, hoisted latent half in the prologue), but
+// every contraction runs on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the rate of the
+// fp32 MFMA) with both operands split into two bf16 halves, x = hi + lo:
+//     A B  ~=  A_hi B_hi + A_hi B_lo + A_lo B_hi          (fp32 accumulation; A_lo B_lo dropped)
+// 3 MFMAs of 32 cycles per K = 16 instead of 8 fp32 MFMAs of 64 cycles: 5.3x fewer matrix
+// cycles at ~2^-17 relative operand error (measured on the oracle: max |logit error| 1.6e-5
+// against 1e-6 for fp32 - inside the 1e-4 contract; tests/test_gpu_decoder.py).
+//
+// What changes against the fp32 kernel, and why:
+//  * The transposed chain survives: accumulator registers 8j..8j+7 of a 32x32 output tile are,
+//    after a split into packed (hi, lo) bf16 pairs, exactly the B operand of K-block j of the
+//    next layer.  The matching A operand of K-block j of a 32x32 weight unit is the fp32
+//    program's records 8j..8j+7 of that unit, split the same way - so the split program has the
+//    SAME unit order and byte size as the fp32 one and is derived from it on the device
+//    (split_program_kernel), K/V records of the image included.
+//  * Weight stream.  At this rate four waves streaming private copies of the 10 MB program would
+//    pull ~50 TB/s through the vector memory path (64 B/clk/CU, L2 34 TB/s).  The four waves of a
+//    workgroup run the same program in lock step, so each 8 KiB chunk (4 K-blocks) is staged ONCE
+//    per workgroup into LDS by LDS-DMA (global_load_lds_dwordx4, one K-block per wave), two
+//    buffers, and read back as A operands with conflict-free ds_read_b128 by all four waves.
+//    One raw s_barrier per chunk: placed before the LAST K-block of a chunk is multiplied (its A
+//    operand is already in registers), so that the first A read of the next chunk is in flight
+//    under those MFMAs; the freed buffer is re-staged right behind the barrier (lead = one chunk
+//    of MFMAs, ~400+ cycles).  Ordering rules: cdna_hip_programming.md section 5 (counted vmcnt by
+//    the issuing wave, then a barrier the reader has passed; restage after an lgkmcnt-retired
+//    read + barrier).
+//  * LDS: [params window 16 KiB][A staging 2 x 8 KiB][4 x 32 KiB activation slabs] = 160 KiB.
+//    Params are paged in five windows per tile instead of two.
+//  * No asm register ring: LDS reads and MFMAs are builtins, scheduled and hazard-padded by
+//    hipcc; only the DMA + barrier are asm (they must stay out of the compiler's vmcnt
+//    bookkeeping).  The bf16 MFMA, unlike the fp32 one, overlaps with VALU work.
+#include "zs_common.h"
+#include "sdf_layout.h"
+#include "sdf_math.h"
+#include "../../include/zeroshape_hip.h"
+
+#include <math.h>
+#include <stdint.h>
+
+namespace {
+
+using namespace zs::lay;
+using zs::dm::gelu_erf;
+using zs::dm::softplus100;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int WAVES = 4;
+constexpr int PTS_PER_WAVE = 32;
+constexpr int PTS_PER_BLOCK = WAVES * PTS_PER_WAVE;
+constexpr int MAX_WGS = 256;                        // one persistent workgroup per CU
+constexpr int KB_U4 = 128;                          // one K-block: [hi: 64 lanes x 16 B][lo: 64 lanes x 16 B]
+constexpr int CK = 4;                               // K-blocks per staged chunk (= WAVES: one per wave)
+constexpr int CHUNK_BYTES = CK * KB_U4 * 16;        // 8 KiB
+constexpr int NBUF = 2;
+constexpr int KB_TOTAL = G_TOTAL / 2;               // 4,928 K-blocks = 14,784 MFMAs per wave tile
+constexpr int PRM_WINDOW = 4096;                    // floats of params resident in LDS at a time
+constexpr int STAGE_FLOATS = NBUF * CHUNK_BYTES / 4;
+constexpr int SLAB_U4 = NT * 4 * 64;                // one activation array as packed (hi, lo) K-blocks: 32 KiB
+constexpr int ZSLAB_F4 = 3 * SLAB_U4;               // fp32 feat partial products of the three skip layers
+constexpr int LDS_FLOATS = PRM_WINDOW + STAGE_FLOATS + WAVES * SLAB_U4 * 4;
+static_assert(LDS_FLOATS * 4 == 160 * 1024, "the kernel owns the whole LDS of a CU");
+static_assert(KB_TOTAL % CK == 0 && CK == WAVES, "chunking");
+static_assert(RING * GROUP_FLOATS * 4 >= CHUNK_BYTES, "the record tail must cover one chunk of prefetch");
+
+// params windows (floats, relative to the params section of the program)
+constexpr int W_PP = P_PP;                           // point_proj table
+constexpr int W_BLK0 = P_BLK0;                       // + blk * P_BLK_STRIDE: one attention block (3,328)
+constexpr int W_IMPL_A = P_LNFG;                     // final norm, impl layers 0, 1, pair 0 (3,072)
+constexpr int W_IMPL_B = P_IMPL_PAIR + P_IMPL_PAIR_STRIDE;  // pairs 1, 2, layer 8 (2,832)
+static_assert(P_BLK_STRIDE <= PRM_WINDOW && W_IMPL_B - W_IMPL_A <= PRM_WINDOW &&
+              P_USED - W_IMPL_B <= PRM_WINDOW, "params windows");
+
+#define DEV __device__ __forceinline__
+
+DEV bf16x8 as_bf(const u32x4 &v) { return __builtin_bit_cast(bf16x8, v); }
+DEV unsigned pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32 (round to nearest even)
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+// two fp32 values -> packed bf16 heads and packed bf16 remainders (x - hi is exact in fp32)
+DEV void split2(float a, float b, unsigned &h, unsigned &l) {
+    h = pk_bf16(a, b);
+    const float ha = __builtin_bit_cast(float, h << 16);
+    const float hb = __builtin_bit_cast(float, h & 0xffff0000u);
+    l = pk_bf16(a - ha, b - hb);
+}
+
+// a 32-feature x 32-point activation tile as the B operands of its two K-blocks:
+// v[2 j + 0] = hi, v[2 j + 1] = lo of K-block j (accumulator registers 8 j .. 8 j + 7)
+struct PT {
+    u32x4 v[4];
+};
+template <typename T>
+DEV PT pack_tile(const T &x) {
+    PT p;
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            unsigned h, l;
+            split2(x[8 * j + 2 * i], x[8 * j + 2 * i + 1], h, l);
+            p.v[2 * j][i] = h;
+            p.v[2 * j + 1][i] = l;
+        }
+    return p;
+}
+
+DEV void glds16(const char *gsrc, unsigned lds_dst) {  // 64 lanes x 16 B: global -> LDS[lds_dst + 16 lane]
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                 "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+// ---- weight stream: LDS-DMA staged chunks shared by the four waves ------------------ //
+struct AStream {
+    const u32x4 *buf;    // this lane's view of the chunk being consumed: [k-block][hi | lo][lane]
+    const u32x4 *nbuf;   // ... of the other buffer
+    u32x4 hi, lo;        // A operand of the next K-block (read in flight)
+    const char *gsrc;    // this lane's source of this wave's K-block of the next chunk to stage
+    unsigned dst, ndst;  // LDS byte address of this wave's K-block inside buf / nbuf (wave-uniform)
+
+    DEV void init(const char *prog, u32x4 *stage, unsigned stage_addr, int wave, int lane) {
+        const char *g = prog + wave * (KB_U4 * 16) + lane * 16;
+        dst = stage_addr + wave * (KB_U4 * 16);
+        ndst = dst + CHUNK_BYTES;
+        // the previous tile's reads and DMAs are retired in every wave before the buffers are reused
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        glds16(g, dst);
+        glds16(g + 1024, dst + 1024);
+        glds16(g + CHUNK_BYTES, ndst);
+        glds16(g + CHUNK_BYTES + 1024, ndst + 1024);
+        gsrc = g + 2 * CHUNK_BYTES;
+        asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");  // chunk 0 landed everywhere
+        buf = stage + lane;
+        nbuf = buf + CK * KB_U4;
+        hi = buf[0];
+        lo = buf[64];
+    }
+    // A operand of the K-block at position `pos` (0..3) of the current chunk; prefetches the next.
+    // At the last position: all of this chunk's reads are issued (retired by the lgkmcnt below)
+    // and this wave's share of the next chunk has landed -> barrier -> the chunk after next is
+    // staged into the buffer just freed, and the first read of the next chunk is issued.
+    DEV void step(int pos, u32x4 &ahi, u32x4 &alo) {
+        ahi = hi;
+        alo = lo;
+        if (pos == CK - 1) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            glds16(gsrc, dst);
+            glds16(gsrc + 1024, dst + 1024);
+            gsrc += CHUNK_BYTES;  // runs at most two chunks past the records: still inside the program
+            const u32x4 *t = buf;
+            buf = nbuf;
+            nbuf = t;
+            const unsigned u = dst;
+            dst = ndst;
+            ndst = u;
+            hi = buf[0];
+            lo = buf[64];
+        } else {
+            hi = buf[(pos + 1) * KB_U4];
+            lo = buf[(pos + 1) * KB_U4 + 64];
+        }
+    }
+    DEV void drain() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+};
+
+DEV void mfma3(f32x16 &acc, const u32x4 &ahi, const u32x4 &alo, const u32x4 &bhi, const u32x4 &blo) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(alo), as_bf(bhi), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(ahi), as_bf(blo), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(ahi), as_bf(bhi), acc, 0, 0, 0);
+}
+
+// acc += W_tile X, X = KT packed tiles in registers; starts at a chunk boundary
+template <int KT>
+DEV void gemm_reg(AStream &s, const PT *X, f32x16 &acc) {
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            u32x4 ahi, alo;
+            s.step((kt * 2 + j) & (CK - 1), ahi, alo);
+            mfma3(acc, ahi, alo, X[kt].v[2 * j], X[kt].v[2 * j + 1]);
+        }
+}
+// one input tile (2 K-blocks) starting at chunk position pos0 (0 or 2)
+DEV void gemm_one(AStream &s, const PT &X, f32x16 &acc, int pos0) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        u32x4 ahi, alo;
+        s.step(pos0 + j, ahi, alo);
+        mfma3(acc, ahi, alo, X.v[2 * j], X.v[2 * j + 1]);
+    }
+}
+// 8 input tiles with the B operands read from the wave's LDS slab ([k-block][hi | lo][lane]),
+// one K-block ahead of their use
+DEV void gemm_lds(AStream &s, const u32x4 *fl, f32x16 &acc) {
+    u32x4 bh = fl[0], bl = fl[64];
+#pragma unroll
+    for (int kb = 0; kb < NT * 2; kb++) {
+        u32x4 nh = bh, nl = bl;
+        if (kb + 1 < NT * 2) {
+            nh = fl[(kb + 1) * KB_U4];
+            nl = fl[(kb + 1) * KB_U4 + 64];
+        }
+        u32x4 ahi, alo;
+        s.step(kb & (CK - 1), ahi, alo);
+        mfma3(acc, ahi, alo, bh, bl);
+        bh = nh;
+        bl = nl;
+    }
+}
+
+DEV float xhalf(float v) { return __shfl_xor(v, 32, 64); }  // value of lane l ^ 32
+
+// row-param read from LDS: 16 floats for (tile, lane half)
+DEV void rp(const float *prm, int off, int tile, int hi, float *v) {
+    const f32x4 *q = reinterpret_cast<const f32x4 *>(prm + off + tile * 32 + hi * 16);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const f32x4 a = q[i];
+        v[4 * i + 0] = a.x; v[4 * i + 1] = a.y; v[4 * i + 2] = a.z; v[4 * i + 3] = a.w;
+    }
+}
+DEV f32x16 rp16(const float *prm, int off, int tile, int hi) {
+    float t[16];
+    rp(prm, off, tile, hi, t);
+    f32x16 v;
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = t[r];
+    return v;
+}
+// w.w + w.x*x + w.y*y + w.z*z for the 16 registers of (tile, hi): [tile][hi][r][4] table
+DEV f32x16 xyz_affine(const float *prm, int off, int tile, int hi, float x, float y, float z) {
+    const f32x4 *q = reinterpret_cast<const f32x4 *>(prm + off + tile * 128 + hi * 64);
+    f32x16 v;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const f32x4 w = q[r];
+        v[r] = fmaf(w.z, z, fmaf(w.y, y, fmaf(w.x, x, w.w)));
+    }
+    return v;
+}
+
+DEV void ln_stats(const f32x16 *x, float &mean, float &rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) s += x[kt][r];
+    s += xhalf(s);
+    mean = s * (1.0f / 256.0f);
+    float v = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float d = x[kt][r] - mean;
+            v = fmaf(d, d, v);
+        }
+    v += xhalf(v);
+    rstd = 1.0f / sqrtf(v * (1.0f / 256.0f) + 1e-6f);
+}
+DEV void store_tile_lds(u32x4 *fl, int tile, const PT &p) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) fl[(tile * 4 + q) * 64] = p.v[q];
+}
+// LayerNorm -> packed B operands in the wave's LDS slab
+DEV void layer_norm_lds(const f32x16 *x, u32x4 *fl, const float *prm, int g_off, int b_off, int hi) {
+    float mean, rstd;
+    ln_stats(x, mean, rstd);
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++) {
+        float g[16], b[16], t[16];
+        rp(prm, g_off, kt, hi, g);
+        rp(prm, b_off, kt, hi, b);
+#pragma unroll
+        for (int r = 0; r < 16; r++) t[r] = fmaf((x[kt][r] - mean) * rstd, g[r], b[r]);
+        store_tile_lds(fl, kt, pack_tile(t));
+    }
+}
+
+// one wave-uniform window of the params section -> LDS (all four waves)
+DEV void load_params(float *prm, const float *prog_params, int start, int count) {
+    __syncthreads();  // everyone is done with the previous window
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(prog_params + start);
+    f32x4 *dst = reinterpret_cast<f32x4 *>(prm);
+    for (int i = threadIdx.x; i < count / 4; i += WAVES * 64) dst[i] = src[i];
+    __syncthreads();
+}
+
+// One latent tile of the point->latent attention of one head: S = K_tile q (2 K-blocks), online
+// softmax update in the log2 domain, o += V_tile^T P (2 K-blocks).  MASK: last tile, rows >= 197
+// are padding.
+template <bool MASK>
+DEV void attn_tile(AStream &s, const PT &q, f32x16 &o, float &m_run, float &z_run, float c, int hi) {
+    f32x16 S;
+#pragma unroll
+    for (int r = 0; r < 16; r++) S[r] = 0.f;
+    gemm_one(s, q, S, 0);
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        if (MASK) {
+            const int rw = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            S[r] = rw < L - 32 * (LT - 1) ? S[r] : -INFINITY;
+        }
+        mt = fmaxf(mt, S[r]);
+    }
+    mt = fmaxf(mt, xhalf(mt)) * c;
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float zs_ = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(S[r], c, -m_new));
+        S[r] = p;
+        zs_ += p;
+    }
+    z_run = fmaf(z_run, alpha, zs_);
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[r] *= alpha;
+    gemm_one(s, pack_tile(S), o, 2);
+    m_run = m_new;
+}
+
+// One wave: 32 points (lane & 31; both lane halves carry the same point).
+DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage_addr, u32x4 *fl,
+                      f32x4 *zs, float px, float py, float pz, int wave, int lane) {
+    const int hi = lane >> 5;
+    const float *prog_params = reinterpret_cast<const float *>(prog) + REC_FLOATS;
+    AStream s;
+    s.init(prog, stage, stage_addr, wave, lane);
+
+    // point_proj (implicit.py:128-131); y is the residual stream, kept as accumulators
+    load_params(prm, prog_params, W_PP, 1024);
+    f32x16 y[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++) y[kt] = xyz_affine(prm, 0, kt, hi, px, py, pz);
+
+    const float scale = 0.17677669529663688110f;  // 32 ** -0.5
+
+#pragma unroll 1
+    for (int blk = 0; blk < BLOCKS; blk++) {
+        load_params(prm, prog_params, W_BLK0 + blk * P_BLK_STRIDE, P_BLK_STRIDE);
+        layer_norm_lds(y, fl, prm, PB_LN1G, PB_LN1B, hi);
+        // y = x + proj_bias + sum_heads Wproj_h o_h
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) y[nt] += rp16(prm, PB_BPROJ, nt, hi);
+
+#pragma unroll 1
+        for (int hd = 0; hd < HEADS; hd++) {
+            f32x16 q = rp16(prm, PB_BQKV, hd * 3 + 0, hi);
+            gemm_lds(s, fl, q);
+            f32x16 k = rp16(prm, PB_BQKV, hd * 3 + 1, hi);
+            gemm_lds(s, fl, k);
+            f32x16 v = rp16(prm, PB_BQKV, hd * 3 + 2, hi);
+            gemm_lds(s, fl, v);
+
+            // logits are kept in the log2 domain: c = d^-1/2 * log2(e), softmax = 2^(c s - m)
+            const float c = scale * 1.44269504088896340736f;
+            float s_self = 0.f;  // self logit (implicit.py:44), fp32
+#pragma unroll
+            for (int r = 0; r < 16; r++) s_self = fmaf(q[r], k[r], s_self);
+            s_self = (s_self + xhalf(s_self)) * c;
+            const PT qp = pack_tile(q);
+
+            float m_run = -INFINITY, z_run = 0.f;
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[r] = 0.f;
+#pragma unroll 1
+            for (int lt = 0; lt < LT - 1; lt++) attn_tile<false>(s, qp, o, m_run, z_run, c, hi);
+            attn_tile<true>(s, qp, o, m_run, z_run, c, hi);
+            {
+                const float m_new = fmaxf(m_run, s_self);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                const float p_self = __builtin_amdgcn_exp2f(s_self - m_new);
+                const float z = fmaf(z_run + xhalf(z_run), alpha, p_self);
+                const float inv = 1.0f / z;
+                const float a_i = alpha * inv, p_i = p_self * inv;
+#pragma unroll
+                for (int r = 0; r < 16; r++) o[r] = fmaf(p_i, v[r], o[r] * a_i);
+            }
+            // y += Wproj[:, head] o_h
+            const PT op = pack_tile(o);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) gemm_one(s, op, y[nt], (nt & 1) * 2);
+        }
+
+        // MLP (timm Mlp): y += b2 + W2 gelu(W1 LN2(y) + b1), one hidden tile at a time
+        layer_norm_lds(y, fl, prm, PB_LN2G, PB_LN2B, hi);
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) y[nt] += rp16(prm, PB_B2, nt, hi);
+#pragma unroll 1
+        for (int ht = 0; ht < HT; ht++) {
+            f32x16 hid = rp16(prm, PB_B1, ht, hi);
+            gemm_lds(s, fl, hid);
+#pragma unroll
+            for (int r = 0; r < 16; r++) hid[r] = gelu_erf(hid[r]);
+            const PT hp = pack_tile(hid);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) gemm_one(s, hp, y[nt], (nt & 1) * 2);
+        }
+    }
+
+    // final norm (implicit.py:275) -> feat, fp32 in registers
+    load_params(prm, prog_params, W_IMPL_A, W_IMPL_B - W_IMPL_A);
+    float h[NT * 16];
+    {
+        float mean, rstd;
+        ln_stats(y, mean, rstd);
+#pragma unroll
+        for (int kt = 0; kt < NT; kt++) {
+            float g[16], b[16];
+            rp(prm, P_LNFG - W_IMPL_A, kt, hi, g);
+            rp(prm, P_LNFB - W_IMPL_A, kt, hi, b);
+#pragma unroll
+            for (int r = 0; r < 16; r++) h[kt * 16 + r] = fmaf((y[kt][r] - mean) * rstd, g[r], b[r]);
+        }
+    }
+    PT hp[NT];
+
+    // impl_mlp (implicit.py:168-184): inputs = cat[xyz, feat].  Layer 0: feat (regs) -> LDS
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++) hp[kt] = pack_tile(h + kt * 16);
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        f32x16 acc = xyz_affine(prm, P_IMPL0 - W_IMPL_A, nt, hi, px, py, pz);
+        gemm_reg<NT>(s, hp, acc);
+        float t[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) t[r] = softplus100(acc[r]);
+        store_tile_lds(fl, nt, pack_tile(t));
+    }
+    // the skip layers consume cat[x, xyz, feat] / sqrt(2): their feat halves are computed now,
+    // while feat is in registers, and parked in the workspace (fp32 Z tiles)
+    const float rsqrt2 = 0.70710678118654752440f;
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++) {
+        float t[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) t[r] = h[kt * 16 + r] * rsqrt2;
+        hp[kt] = pack_tile(t);
+    }
+    const float sx = px * rsqrt2, sy = py * rsqrt2, sz = pz * rsqrt2;
+#pragma unroll 1
+    for (int li = 0; li < 3; li++) {
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+            gemm_reg<NT>(s, hp, acc);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                f32x4 t;
+                t.x = acc[4 * j + 0]; t.y = acc[4 * j + 1]; t.z = acc[4 * j + 2]; t.w = acc[4 * j + 3];
+                zs[(li * SLAB_U4) + (nt * 4 + j) * 64] = t;
+            }
+        }
+    }
+
+    // layer 1 (plain): LDS -> registers, pre-divided by sqrt(2) because layer 2 is a skip layer
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        f32x16 acc = rp16(prm, P_IMPL1 - W_IMPL_A, nt, hi);
+        gemm_lds(s, fl, acc);
+        float t[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) t[r] = softplus100(acc[r]) * rsqrt2;
+        hp[nt] = pack_tile(t);
+    }
+    float out = 0.f;
+#pragma unroll 1
+    for (int i = 0; i < 3; i++) {
+        if (i == 1) load_params(prm, prog_params, W_IMPL_B, P_USED - W_IMPL_B);
+        const int pp = i == 0 ? P_IMPL_PAIR - W_IMPL_A : P_IMPL_PAIR + i * P_IMPL_PAIR_STRIDE - W_IMPL_B;
+        const f32x4 *zl = zs + i * SLAB_U4;
+        // skip layer 2+2i: registers (x / sqrt(2)) + parked feat half -> LDS
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            // the parked tile is fetched first (L1-bypassing loads: this wave wrote it earlier in
+            // the launch); the stream's asm statements keep the loads from sinking behind the GEMM
+            f32x4 z[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) z[j] = __builtin_nontemporal_load(zl + (nt * 4 + j) * 64);
+            f32x16 acc = xyz_affine(prm, pp, nt, hi, sx, sy, sz);
+            gemm_reg<NT>(s, hp, acc);
+            float t[16];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                t[4 * j + 0] = softplus100(acc[4 * j + 0] + z[j].x);
+                t[4 * j + 1] = softplus100(acc[4 * j + 1] + z[j].y);
+                t[4 * j + 2] = softplus100(acc[4 * j + 2] + z[j].z);
+                t[4 * j + 3] = softplus100(acc[4 * j + 3] + z[j].w);
+            }
+            store_tile_lds(fl, nt, pack_tile(t));
+        }
+        // plain layer 3+2i: LDS -> registers (/ sqrt(2) when the next layer is a skip layer);
+        // the last one feeds layer 8 (256 -> 1), evaluated in fp32 on the spot
+        const float post = i < 2 ? rsqrt2 : 1.0f;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            f32x16 acc = rp16(prm, pp + 1024, nt, hi);
+            gemm_lds(s, fl, acc);
+            float t[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) t[r] = softplus100(acc[r]) * post;
+            if (i < 2) {
+                hp[nt] = pack_tile(t);
+            } else {
+                float w[16];
+                rp(prm, P_W8 - W_IMPL_B, nt, hi, w);
+#pragma unroll
+                for (int r = 0; r < 16; r++) out = fmaf(t[r], w[r], out);
+            }
+        }
+    }
+    s.drain();
+    out += xhalf(out);
+    return out + prm[P_B8 - W_IMPL_B];
+}
+
+template <bool GRID>
+__global__ __launch_bounds__(WAVES * 64, 1) void sdf_decode_split_kernel(
+    const char *__restrict__ programs, size_t program_stride_bytes, int batch,
+    const float *__restrict__ points,  // !GRID: [batch][m][3]
+    const float *__restrict__ axis,    //  GRID: [G]
+    int G, long long first_point,      //  GRID: linear index of the first grid point
+    int m,                             // points per image handled by this launch
+    float *__restrict__ out, int apply_sigmoid, f32x4 *__restrict__ workspace) {
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    float *prm = lds;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    u32x4 *stage = reinterpret_cast<u32x4 *>(lds + PRM_WINDOW);
+    const unsigned stage_addr = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)(lds + PRM_WINDOW));
+    u32x4 *fl = reinterpret_cast<u32x4 *>(lds + PRM_WINDOW + STAGE_FLOATS) + wave * SLAB_U4 + lane;
+    f32x4 *zslab = workspace + ((size_t)blockIdx.x * WAVES + wave) * ZSLAB_F4 + lane;
+
+    const int tiles_per_img = (m + PTS_PER_BLOCK - 1) / PTS_PER_BLOCK;
+    const int total = tiles_per_img * batch;
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const int img = tile / tiles_per_img;
+        const int t = tile - img * tiles_per_img;
+        const char *prog = programs + (size_t)img * program_stride_bytes;
+
+        const int p = t * PTS_PER_BLOCK + wave * PTS_PER_WAVE + (lane & 31);
+        const int pc = p < m ? p : m - 1;  // clamp: tail lanes recompute the last point
+        float px, py, pz;
+        if (GRID) {
+            const long long gp = first_point + pc;
+            const long long gg = (long long)G * G;
+            const int ix = (int)(gp / gg);
+            const int rem = (int)(gp - (long long)ix * gg);
+            const int iy = rem / G;
+            const int iz = rem - iy * G;
+            px = axis[ix];
+            py = axis[iy];
+            pz = axis[iz];
+        } else {
+            const float *q = points + ((size_t)img * m + pc) * 3;
+            px = q[0];
+            py = q[1];
+            pz = q[2];
+        }
+        float logit = decode_tile(prog, prm, stage, stage_addr, fl, zslab, px, py, pz, wave, lane);
+        if (apply_sigmoid) logit = 1.0f / (1.0f + expf(-logit));
+        if (lane < 32 && p < m) out[(size_t)img * m + p] = logit;
+    }
+}
+
+// fp32 decoder program -> split program: same unit order and size; K-block j of a unit holds
+// records 8 j .. 8 j + 7 of that unit as [hi: lane x 8 bf16][lo: lane x 8 bf16]; params copied.
+__global__ __launch_bounds__(256) void split_program_kernel(const float *__restrict__ src,
+                                                            size_t src_stride_floats,
+                                                            u32x4 *__restrict__ dst,
+                                                            size_t dst_stride_u4) {
+    const int img = blockIdx.y;
+    const float *s = src + (size_t)img * src_stride_floats;
+    u32x4 *d = dst + (size_t)img * dst_stride_u4;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    constexpr int REC_KB = REC_FLOATS / (KB_U4 * 4);  // K-blocks incl. the zero tail
+    if (e < REC_KB * 64) {
+        const int kb = e >> 6, lane = e & 63;
+        const f32x4 *g = reinterpret_cast<const f32x4 *>(s) + (size_t)kb * 128;  // two fp32 groups
+        const f32x4 a = g[lane], b = g[64 + lane];
+        unsigned h[4], l[4];
+        split2(a.x, a.y, h[0], l[0]);
+        split2(a.z, a.w, h[1], l[1]);
+        split2(b.x, b.y, h[2], l[2]);
+        split2(b.z, b.w, h[3], l[3]);
+        const u32x4 hi = {h[0], h[1], h[2], h[3]}, lo = {l[0], l[1], l[2], l[3]};
+        d[(size_t)kb * KB_U4 + lane] = hi;
+        d[(size_t)kb * KB_U4 + 64 + lane] = lo;
+    } else {
+        const int i = e - REC_KB * 64;
+        if (i < PARAM_FLOATS / 4)
+            d[REC_FLOATS / 4 + i] = reinterpret_cast<const u32x4 *>(s + REC_FLOATS)[i];
+    }
+}
+
+int decode_grid_size(int batch, int m) {
+    const long long tiles = (long long)batch * ((m + PTS_PER_BLOCK - 1) / PTS_PER_BLOCK);
+    return (int)(tiles < MAX_WGS ? tiles : MAX_WGS);
+}
+
+bool check_programs(const char *what, const void *programs, size_t stride) {
+    if (!programs) {
+        zs::set_err("%s: null pointer", what);
+        return false;
+    }
+    if (stride % 16 != 0 || stride < zs_sdf_program_bytes()) {
+        zs::set_err("%s: bad program stride %zu", what, stride);
+        return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" int zs_sdf_split_programs(const void *programs, size_t program_stride_bytes,
+                                     void *split_programs, size_t split_stride_bytes, int batch,
+                                     void *stream) {
+    if (batch < 0 || batch > 65535) {
+        zs::set_err("zs_sdf_split_programs: bad batch %d", batch);
+        return 0;
+    }
+    if (batch == 0) return 1;
+    if (!check_programs("zs_sdf_split_programs", programs, program_stride_bytes) ||
+        !check_programs("zs_sdf_split_programs", split_programs, split_stride_bytes))
+        return 0;
+    const int elems = (REC_FLOATS / (KB_U4 * 4)) * 64 + PARAM_FLOATS / 4;
+    hipLaunchKernelGGL(split_program_kernel, dim3((elems + 255) / 256, batch), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const float *>(programs),
+                       program_stride_bytes / sizeof(float), static_cast<u32x4 *>(split_programs),
+                       split_stride_bytes / sizeof(u32x4));
+    return zs::check_launch("zs_sdf_split_programs") ? 1 : 0;
+}
+
+extern "C" int zs_sdf_query_points_split(const void *split_programs, size_t program_stride_bytes,
+                                         int batch, const float *points, int m, float *logits,
+                                         void *workspace, void *stream) {
+    if (batch < 0 || m < 0) {
+        zs::set_err("zs_sdf_query_points_split: negative size (batch=%d m=%d)", batch, m);
+        return 0;
+    }
+    if (batch == 0 || m == 0) return 1;
+    if (!points || !logits || !workspace) {
+        zs::set_err("zs_sdf_query_points_split: null pointer");
+        return 0;
+    }
+    if (!check_programs("zs_sdf_query_points_split", split_programs, program_stride_bytes)) return 0;
+    if ((long long)batch * ((m + PTS_PER_BLOCK - 1) / PTS_PER_BLOCK) > 0x7fffffffLL) {
+        zs::set_err("zs_sdf_query_points_split: too many tiles");
+        return 0;
+    }
+    hipLaunchKernelGGL((sdf_decode_split_kernel<false>), dim3(decode_grid_size(batch, m)),
+                       dim3(WAVES * 64), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const char *>(split_programs), program_stride_bytes, batch, points,
+                       nullptr, 0, 0LL, m, logits, 0, static_cast<f32x4 *>(workspace));
+    return zs::check_launch("zs_sdf_query_points_split") ? 1 : 0;
+}
+
+extern "C" int zs_sdf_query_grid_split(const void *split_programs, size_t program_stride_bytes,
+                                       int batch, const float *axis, int G, int slice_begin,
+                                       int slice_end, int apply_sigmoid, float *out, void *workspace,
+                                       void *stream) {
+    if (batch < 0 || G <= 0 || slice_begin < 0 || slice_end > G || slice_begin > slice_end) {
+        zs::set_err("zs_sdf_query_grid_split: bad range (batch=%d G=%d slices=[%d,%d))", batch, G,
+                    slice_begin, slice_end);
+        return 0;
+    }
+    const long long mm = (long long)(slice_end - slice_begin) * G * G;
+    if (batch == 0 || mm == 0) return 1;
+    if (!axis || !out || !workspace) {
+        zs::set_err("zs_sdf_query_grid_split: null pointer");
+        return 0;
+    }
+    if (mm > 0x7fffffffLL - PTS_PER_BLOCK) {
+        zs::set_err("zs_sdf_query_grid_split: %lld points per launch exceed 2^31; split the slab", mm);
+        return 0;
+    }
+    if (!check_programs("zs_sdf_query_grid_split", split_programs, program_stride_bytes)) return 0;
+    const int m = (int)mm;
+    hipLaunchKernelGGL((sdf_decode_split_kernel<true>), dim3(decode_grid_size(batch, m)),
+                       dim3(WAVES * 64), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const char *>(split_programs), program_stride_bytes, batch, nullptr,
+                       axis, G, (long long)slice_begin * G * G, m, out, apply_sigmoid,
+                       static_cast<f32x4 *>(workspace));
+    return zs::check_launch("zs_sdf_query_grid_split") ? 1 : 0;
+}

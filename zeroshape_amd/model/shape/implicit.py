@@ -21,6 +21,7 @@ Not on the HIP path (raises, never silently approximated):
   * ``semantic=True`` / ``posenc_3D>0`` / ``pos_perlayer=True`` variants (unused by
     options/shape.yaml).
 """
+import os
 from functools import partial
 
 import numpy as np
@@ -77,8 +78,8 @@ class DecoderState(object):
     """Per-batch device state produced by Implicit.prepare(): one decoder program per
     image (weights + that image's K/V records)."""
 
-    def __init__(self, programs, batch):
-        self.programs, self.batch = programs, batch
+    def __init__(self, programs, batch, precision="f32"):
+        self.programs, self.batch, self.precision = programs, batch, precision
 
     @property
     def stride_bytes(self):
@@ -116,6 +117,11 @@ class Implicit(nn.Module):
         self.drop_scales = None   # tests: explicit list of 2*n_blocks per-sample scale tensors [B]
         self.initialize_weights()
         self._packed = None       # (key, template programs tensor, lat_params tensor)
+        # arithmetic of the fused inference kernels: "f32" = exact fp32 MFMA (bitwise an fmaf
+        # chain); "bf16x3" = split-bf16 on the bf16 matrix pipe (csrc/sdf_decoder_split.hip:
+        # |logit error| ~2e-5 against fp32, contract 1e-4, several times faster).  The attention
+        # map and the training path always use fp32.
+        self.precision = os.environ.get("ZS_DECODER_PRECISION", "f32")
         self._workspace = {}      # device -> scratch tensor for the query kernels
 
     # ---- init (implicit.py:232-249) -------------------------------------------------
@@ -170,8 +176,12 @@ class Implicit(nn.Module):
         return self._workspace[key]
 
     @torch.no_grad()
-    def prepare(self, latent_depth):
-        """Per-image prologue: latent_depth [B,197,C] (any float dtype, GPU) -> DecoderState."""
+    def prepare(self, latent_depth, precision=None):
+        """Per-image prologue: latent_depth [B,197,C] (any float dtype, GPU) -> DecoderState.
+        ``precision``: None = self.precision."""
+        precision = self.precision if precision is None else precision
+        if precision not in ("f32", "bf16x3"):
+            raise ValueError("decoder precision must be 'f32' or 'bf16x3', got %r" % (precision,))
         if not latent_depth.is_cuda:
             raise ValueError("latent_depth must be a GPU tensor; zeroshape_amd has no CPU path")
         lib = _lib.load()
@@ -189,6 +199,13 @@ class Implicit(nn.Module):
                                      _lib.ptr(lat), B, _lib.ptr(scratch),
                                      _lib.current_stream_ptr(lat.device))
         _lib.check(rc, "zs_sdf_prologue")
+        if precision == "bf16x3":
+            split = torch.empty_like(programs)
+            with torch.cuda.device(lat.device):
+                rc = lib.zs_sdf_split_programs(_lib.ptr(programs), programs.stride(0) * 4, _lib.ptr(split),
+                                               split.stride(0) * 4, B, _lib.current_stream_ptr(lat.device))
+            _lib.check(rc, "zs_sdf_split_programs")
+            return DecoderState(split, B, "bf16x3")
         return DecoderState(programs, B)
 
     @torch.no_grad()
@@ -204,6 +221,16 @@ class Implicit(nn.Module):
         M = pts.shape[1]
         out = torch.empty(state.batch, M, dtype=torch.float32, device=pts.device)
         attn, extra = None, 0
+        if state.precision == "bf16x3":
+            if need_attn:
+                raise ValueError("the attention map needs an fp32 DecoderState (prepare(..., precision='f32'))")
+            with torch.cuda.device(pts.device):
+                rc = lib.zs_sdf_query_points_split(_lib.ptr(state.programs), state.stride_bytes, state.batch,
+                                                   _lib.ptr(pts), M, _lib.ptr(out),
+                                                   _lib.ptr(self.workspace(pts.device)),
+                                                   _lib.current_stream_ptr(pts.device))
+            _lib.check(rc, "zs_sdf_query_points_split")
+            return out
         if need_attn:
             attn = torch.empty(state.batch, M, P.L, dtype=torch.float32, device=pts.device)
             extra = lib.zs_sdf_attn_scratch_bytes(state.batch, M)
@@ -231,6 +258,15 @@ class Implicit(nn.Module):
         slice_end = G if slice_end is None else slice_end
         out = torch.empty(state.batch, slice_end - slice_begin, G, G, dtype=torch.float32,
                           device=axis.device)
+        if state.precision == "bf16x3":
+            with torch.cuda.device(axis.device):
+                rc = lib.zs_sdf_query_grid_split(_lib.ptr(state.programs), state.stride_bytes, state.batch,
+                                                 _lib.ptr(axis), G, slice_begin, slice_end,
+                                                 1 if apply_sigmoid else 0, _lib.ptr(out),
+                                                 _lib.ptr(self.workspace(axis.device)),
+                                                 _lib.current_stream_ptr(axis.device))
+            _lib.check(rc, "zs_sdf_query_grid_split")
+            return out
         with torch.cuda.device(axis.device):
             rc = lib.zs_sdf_query_grid(_lib.ptr(state.programs), state.stride_bytes, state.batch,
                                        _lib.ptr(axis), G, slice_begin, slice_end,
@@ -251,11 +287,10 @@ class Implicit(nn.Module):
             if not need_attn:
                 return logits, None
             with torch.no_grad():      # the attention map carries no gradient in the reference's losses
-                return logits, self.query_points(self.prepare(latent_depth), points_3D, need_attn=True)[1]
-        state = self.prepare(latent_depth)
-        if need_attn:
-            return self.query_points(state, points_3D, need_attn=True)
-        return self.query_points(state, points_3D), None
+                return logits, self.query_points(self.prepare(latent_depth, "f32"), points_3D, need_attn=True)[1]
+        if need_attn:                  # the map comes from the fp32 kernel, and the logits with it
+            return self.query_points(self.prepare(latent_depth, "f32"), points_3D, need_attn=True)
+        return self.query_points(self.prepare(latent_depth), points_3D), None
 
     # ---- training path (layer by layer, autograd over HIP kernels) -------------------------
     def _drop_scale(self, B, device):
