@@ -19,16 +19,16 @@
 //  * Weight stream.  At this rate four waves streaming private copies of the 10 MB program would
 //    pull ~50 TB/s through the vector memory path (64 B/clk/CU, L2 34 TB/s).  The four waves of a
 //    workgroup run the same program in lock step, so each 8 KiB chunk (4 K-blocks) is staged ONCE
-//    per workgroup into LDS by LDS-DMA (global_load_lds_dwordx4, one K-block per wave), two
-//    buffers, and read back as A operands with conflict-free ds_read_b128 by all four waves.
+//    per workgroup into LDS by LDS-DMA (global_load_lds_dwordx4, one K-block per wave), three
+//    buffers (three), and read back as A operands with conflict-free ds_read_b128 by all four waves.
 //    One raw s_barrier per chunk: placed before the LAST K-block of a chunk is multiplied (its A
 //    operand is already in registers), so that the first A read of the next chunk is in flight
-//    under those MFMAs; the freed buffer is re-staged right behind the barrier (lead = one chunk
-//    of MFMAs, ~400+ cycles).  Ordering rules: cdna_hip_programming.md section 5 (counted vmcnt by
+//    under those MFMAs; the freed buffer is re-staged right behind the barrier (lead = two chunks
+//    of MFMAs; with two buffers the DMA latency was exposed at every barrier).  Ordering rules: cdna_hip_programming.md section 5 (counted vmcnt by
 //    the issuing wave, then a barrier the reader has passed; restage after an lgkmcnt-retired
 //    read + barrier).
-//  * LDS: [params window 16 KiB][A staging 2 x 8 KiB][4 x 32 KiB activation slabs] = 160 KiB.
-//    Params are paged in five windows per tile instead of two.
+//  * LDS: [params window 8 KiB][A staging 3 x 8 KiB][4 x 32 KiB activation slabs] = 160 KiB.
+//    Params are paged in nine windows per tile instead of two.
 //  * No asm register ring: LDS reads and MFMAs are builtins, scheduled and hazard-padded by
 //    hipcc; only the DMA + barrier are asm (they must stay out of the compiler's vmcnt
 //    bookkeeping).  The bf16 MFMA, unlike the fp32 one, overlaps with VALU work.
@@ -60,24 +60,30 @@ constexpr int MAX_WGS = 256;                        // one persistent workgroup 
 constexpr int KB_U4 = 128;                          // one K-block: [hi: 64 lanes x 16 B][lo: 64 lanes x 16 B]
 constexpr int CK = 4;                               // K-blocks per staged chunk (= WAVES: one per wave)
 constexpr int CHUNK_BYTES = CK * KB_U4 * 16;        // 8 KiB
-constexpr int NBUF = 2;
+constexpr int NBUF = 3;
 constexpr int KB_TOTAL = G_TOTAL / 2;               // 4,928 K-blocks = 14,784 MFMAs per wave tile
-constexpr int PRM_WINDOW = 4096;                    // floats of params resident in LDS at a time
+constexpr int PRM_WINDOW = 2048;                    // floats of params resident in LDS at a time
 constexpr int STAGE_FLOATS = NBUF * CHUNK_BYTES / 4;
 constexpr int SLAB_U4 = NT * 4 * 64;                // one activation array as packed (hi, lo) K-blocks: 32 KiB
 constexpr int ZSLAB_F4 = 3 * SLAB_U4;               // fp32 feat partial products of the three skip layers
 constexpr int LDS_FLOATS = PRM_WINDOW + STAGE_FLOATS + WAVES * SLAB_U4 * 4;
 static_assert(LDS_FLOATS * 4 == 160 * 1024, "the kernel owns the whole LDS of a CU");
 static_assert(KB_TOTAL % CK == 0 && CK == WAVES, "chunking");
-static_assert(RING * GROUP_FLOATS * 4 >= CHUNK_BYTES, "the record tail must cover one chunk of prefetch");
+// the stream prefetches NBUF chunks past its position: the last reads run into the zero tail of
+// the records and (harmlessly) the params section behind it
+static_assert((RING * GROUP_FLOATS + PARAM_FLOATS) * 4 >= NBUF * CHUNK_BYTES, "prefetch stays inside the program");
 
-// params windows (floats, relative to the params section of the program)
-constexpr int W_PP = P_PP;                           // point_proj table
-constexpr int W_BLK0 = P_BLK0;                       // + blk * P_BLK_STRIDE: one attention block (3,328)
-constexpr int W_IMPL_A = P_LNFG;                     // final norm, impl layers 0, 1, pair 0 (3,072)
-constexpr int W_IMPL_B = P_IMPL_PAIR + P_IMPL_PAIR_STRIDE;  // pairs 1, 2, layer 8 (2,832)
-static_assert(P_BLK_STRIDE <= PRM_WINDOW && W_IMPL_B - W_IMPL_A <= PRM_WINDOW &&
-              P_USED - W_IMPL_B <= PRM_WINDOW, "params windows");
+// params windows (floats, relative to the params section of the program; <= PRM_WINDOW each)
+constexpr int W_PP = P_PP;                                   // point_proj table (1,024)
+constexpr int W_ATT = P_BLK0;                                // + blk * P_BLK_STRIDE: ln1, bproj, bqkv (1,536)
+constexpr int W_MLP = P_BLK0 + PB_LN2G;                      // + blk * P_BLK_STRIDE: ln2, b2, b1 (1,792)
+constexpr int W_I0 = P_LNFG;                                 // final norm + impl layer 0 (1,536)
+constexpr int W_I1 = P_IMPL1;                                // impl layer 1 + pair 0 (1,536)
+constexpr int W_I2 = P_IMPL_PAIR + P_IMPL_PAIR_STRIDE;       // pair 1 (1,280)
+constexpr int W_I3 = P_IMPL_PAIR + 2 * P_IMPL_PAIR_STRIDE;   // pair 2 + layer 8 (1,552)
+static_assert(PB_LN2G <= PRM_WINDOW && P_BLK_STRIDE - PB_LN2G <= PRM_WINDOW && W_I1 - W_I0 <= PRM_WINDOW &&
+              W_I2 - W_I1 <= PRM_WINDOW && W_I3 - W_I2 <= PRM_WINDOW && P_USED - W_I3 <= PRM_WINDOW,
+              "params windows");
 
 #define DEV __device__ __forceinline__
 
@@ -107,7 +113,12 @@ DEV PT pack_tile(const T &x) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             unsigned h, l;
+#ifdef ZS_EXP_NOPACK
+            h = __builtin_bit_cast(unsigned, (float)x[8 * j + 2 * i]);
+            l = __builtin_bit_cast(unsigned, (float)x[8 * j + 2 * i + 1]);
+#else
             split2(x[8 * j + 2 * i], x[8 * j + 2 * i + 1], h, l);
+#endif
             p.v[2 * j][i] = h;
             p.v[2 * j + 1][i] = l;
         }
@@ -124,53 +135,60 @@ DEV void glds16(const char *gsrc, unsigned lds_dst) {  // 64 lanes x 16 B: globa
 }
 
 // ---- weight stream: LDS-DMA staged chunks shared by the four waves ------------------ //
+// Three buffers: while chunk c is consumed, chunk c+1 has (nearly) landed and chunk c+2 is in
+// flight.  One synchronisation per chunk, before its LAST K-block is multiplied (that K-block's
+// A operand is already in registers): own share of chunk c+1 landed (counted vmcnt: only the two
+// DMAs of chunk c+2 may remain) and own reads of chunk c retired -> s_barrier -> chunk c+3 is
+// staged into the buffer just freed and the first A read of chunk c+1 is issued.  Lead time of
+// a chunk: two chunk periods.
 struct AStream {
-    const u32x4 *buf;    // this lane's view of the chunk being consumed: [k-block][hi | lo][lane]
-    const u32x4 *nbuf;   // ... of the other buffer
-    u32x4 hi, lo;        // A operand of the next K-block (read in flight)
-    const char *gsrc;    // this lane's source of this wave's K-block of the next chunk to stage
-    unsigned dst, ndst;  // LDS byte address of this wave's K-block inside buf / nbuf (wave-uniform)
+    const u32x4 *buf[NBUF];   // this lane's view of the buffers, buf[0] = chunk being consumed
+    unsigned dst[NBUF];       // LDS byte address of this wave's K-block in each (wave-uniform)
+    u32x4 hi, lo;             // A operand of the next K-block (read in flight)
+    const char *gsrc;         // this lane's source of this wave's K-block of the next chunk to stage
 
     DEV void init(const char *prog, u32x4 *stage, unsigned stage_addr, int wave, int lane) {
         const char *g = prog + wave * (KB_U4 * 16) + lane * 16;
-        dst = stage_addr + wave * (KB_U4 * 16);
-        ndst = dst + CHUNK_BYTES;
         // the previous tile's reads and DMAs are retired in every wave before the buffers are reused
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        glds16(g, dst);
-        glds16(g + 1024, dst + 1024);
-        glds16(g + CHUNK_BYTES, ndst);
-        glds16(g + CHUNK_BYTES + 1024, ndst + 1024);
-        gsrc = g + 2 * CHUNK_BYTES;
-        asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");  // chunk 0 landed everywhere
-        buf = stage + lane;
-        nbuf = buf + CK * KB_U4;
-        hi = buf[0];
-        lo = buf[64];
+#pragma unroll
+        for (int i = 0; i < NBUF; i++) {
+            buf[i] = stage + i * (CK * KB_U4) + lane;
+            dst[i] = stage_addr + i * CHUNK_BYTES + wave * (KB_U4 * 16);
+            glds16(g + i * CHUNK_BYTES, dst[i]);
+            glds16(g + i * CHUNK_BYTES + 1024, dst[i] + 1024);
+        }
+        gsrc = g + NBUF * CHUNK_BYTES;
+        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");  // chunk 0 landed everywhere
+        hi = buf[0][0];
+        lo = buf[0][64];
     }
     // A operand of the K-block at position `pos` (0..3) of the current chunk; prefetches the next.
-    // At the last position: all of this chunk's reads are issued (retired by the lgkmcnt below)
-    // and this wave's share of the next chunk has landed -> barrier -> the chunk after next is
-    // staged into the buffer just freed, and the first read of the next chunk is issued.
     DEV void step(int pos, u32x4 &ahi, u32x4 &alo) {
         ahi = hi;
         alo = lo;
         if (pos == CK - 1) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            glds16(gsrc, dst);
-            glds16(gsrc + 1024, dst + 1024);
-            gsrc += CHUNK_BYTES;  // runs at most two chunks past the records: still inside the program
-            const u32x4 *t = buf;
-            buf = nbuf;
-            nbuf = t;
-            const unsigned u = dst;
-            dst = ndst;
-            ndst = u;
-            hi = buf[0];
-            lo = buf[64];
+#if defined(ZS_EXP_STAGE_MODE) && ZS_EXP_STAGE_MODE == 1
+#else
+            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            glds16(gsrc, dst[0]);
+            glds16(gsrc + 1024, dst[0] + 1024);
+#endif
+            gsrc += CHUNK_BYTES;
+            const u32x4 *t = buf[0];
+            const unsigned u = dst[0];
+#pragma unroll
+            for (int i = 0; i + 1 < NBUF; i++) {
+                buf[i] = buf[i + 1];
+                dst[i] = dst[i + 1];
+            }
+            buf[NBUF - 1] = t;
+            dst[NBUF - 1] = u;
+            hi = buf[0][0];
+            lo = buf[0][64];
         } else {
-            hi = buf[(pos + 1) * KB_U4];
-            lo = buf[(pos + 1) * KB_U4 + 64];
+            hi = buf[0][(pos + 1) * KB_U4];
+            lo = buf[0][(pos + 1) * KB_U4 + 64];
         }
     }
     DEV void drain() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
@@ -209,13 +227,13 @@ DEV void gemm_lds(AStream &s, const u32x4 *fl, f32x16 &acc) {
     u32x4 bh = fl[0], bl = fl[64];
 #pragma unroll
     for (int kb = 0; kb < NT * 2; kb++) {
+        u32x4 ahi, alo;
+        s.step(kb & (CK - 1), ahi, alo);
         u32x4 nh = bh, nl = bl;
-        if (kb + 1 < NT * 2) {
+        if (kb + 1 < NT * 2) {  // after the step: its lgkmcnt(0) must not wait for this read
             nh = fl[(kb + 1) * KB_U4];
             nl = fl[(kb + 1) * KB_U4 + 64];
         }
-        u32x4 ahi, alo;
-        s.step(kb & (CK - 1), ahi, alo);
         mfma3(acc, ahi, alo, bh, bl);
         bh = nh;
         bl = nl;
@@ -353,7 +371,7 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
 
 #pragma unroll 1
     for (int blk = 0; blk < BLOCKS; blk++) {
-        load_params(prm, prog_params, W_BLK0 + blk * P_BLK_STRIDE, P_BLK_STRIDE);
+        load_params(prm, prog_params, W_ATT + blk * P_BLK_STRIDE, PB_LN2G);
         layer_norm_lds(y, fl, prm, PB_LN1G, PB_LN1B, hi);
         // y = x + proj_bias + sum_heads Wproj_h o_h
 #pragma unroll
@@ -400,12 +418,13 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
         }
 
         // MLP (timm Mlp): y += b2 + W2 gelu(W1 LN2(y) + b1), one hidden tile at a time
-        layer_norm_lds(y, fl, prm, PB_LN2G, PB_LN2B, hi);
+        load_params(prm, prog_params, W_MLP + blk * P_BLK_STRIDE, P_BLK_STRIDE - PB_LN2G);
+        layer_norm_lds(y, fl, prm, PB_LN2G - PB_LN2G, PB_LN2B - PB_LN2G, hi);
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++) y[nt] += rp16(prm, PB_B2, nt, hi);
+        for (int nt = 0; nt < NT; nt++) y[nt] += rp16(prm, PB_B2 - PB_LN2G, nt, hi);
 #pragma unroll 1
         for (int ht = 0; ht < HT; ht++) {
-            f32x16 hid = rp16(prm, PB_B1, ht, hi);
+            f32x16 hid = rp16(prm, PB_B1 - PB_LN2G, ht, hi);
             gemm_lds(s, fl, hid);
 #pragma unroll
             for (int r = 0; r < 16; r++) hid[r] = gelu_erf(hid[r]);
@@ -416,7 +435,7 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
     }
 
     // final norm (implicit.py:275) -> feat, fp32 in registers
-    load_params(prm, prog_params, W_IMPL_A, W_IMPL_B - W_IMPL_A);
+    load_params(prm, prog_params, W_I0, W_I1 - W_I0);
     float h[NT * 16];
     {
         float mean, rstd;
@@ -424,8 +443,8 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
 #pragma unroll
         for (int kt = 0; kt < NT; kt++) {
             float g[16], b[16];
-            rp(prm, P_LNFG - W_IMPL_A, kt, hi, g);
-            rp(prm, P_LNFB - W_IMPL_A, kt, hi, b);
+            rp(prm, P_LNFG - W_I0, kt, hi, g);
+            rp(prm, P_LNFB - W_I0, kt, hi, b);
 #pragma unroll
             for (int r = 0; r < 16; r++) h[kt * 16 + r] = fmaf((y[kt][r] - mean) * rstd, g[r], b[r]);
         }
@@ -437,7 +456,7 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
     for (int kt = 0; kt < NT; kt++) hp[kt] = pack_tile(h + kt * 16);
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
-        f32x16 acc = xyz_affine(prm, P_IMPL0 - W_IMPL_A, nt, hi, px, py, pz);
+        f32x16 acc = xyz_affine(prm, P_IMPL0 - W_I0, nt, hi, px, py, pz);
         gemm_reg<NT>(s, hp, acc);
         float t[16];
 #pragma unroll
@@ -473,9 +492,10 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
     }
 
     // layer 1 (plain): LDS -> registers, pre-divided by sqrt(2) because layer 2 is a skip layer
+    load_params(prm, prog_params, W_I1, W_I2 - W_I1);
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
-        f32x16 acc = rp16(prm, P_IMPL1 - W_IMPL_A, nt, hi);
+        f32x16 acc = rp16(prm, P_IMPL1 - W_I1, nt, hi);
         gemm_lds(s, fl, acc);
         float t[16];
 #pragma unroll
@@ -485,8 +505,9 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
     float out = 0.f;
 #pragma unroll 1
     for (int i = 0; i < 3; i++) {
-        if (i == 1) load_params(prm, prog_params, W_IMPL_B, P_USED - W_IMPL_B);
-        const int pp = i == 0 ? P_IMPL_PAIR - W_IMPL_A : P_IMPL_PAIR + i * P_IMPL_PAIR_STRIDE - W_IMPL_B;
+        if (i == 1) load_params(prm, prog_params, W_I2, W_I3 - W_I2);
+        if (i == 2) load_params(prm, prog_params, W_I3, P_USED - W_I3);
+        const int pp = i == 0 ? P_IMPL_PAIR - W_I1 : 0;
         const f32x4 *zl = zs + i * SLAB_U4;
         // skip layer 2+2i: registers (x / sqrt(2)) + parked feat half -> LDS
 #pragma unroll
@@ -522,7 +543,7 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
                 hp[nt] = pack_tile(t);
             } else {
                 float w[16];
-                rp(prm, P_W8 - W_IMPL_B, nt, hi, w);
+                rp(prm, P_W8 - W_I3, nt, hi, w);
 #pragma unroll
                 for (int r = 0; r < 16; r++) out = fmaf(t[r], w[r], out);
             }
@@ -530,7 +551,7 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
     }
     s.drain();
     out += xhalf(out);
-    return out + prm[P_B8 - W_IMPL_B];
+    return out + prm[P_B8 - W_I3];
 }
 
 template <bool GRID>
