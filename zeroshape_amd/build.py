@@ -26,7 +26,9 @@ EXTRA = {
     "chamfer.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
     "chamfer_grid.hip": ["-ffp-contract=off"],
     # packed f32 VALU ops beside bf16 MFMAs cost more than the scalar forms they replace
-    "sdf_decoder_split.hip": ["-fno-slp-vectorize"],
+    # ... and MFMA accumulators in VGPRs: the activation code reads and writes them in place
+    # (with AGPR accumulators every tile paid 32 v_accvgpr moves; 484 -> 352 registers)
+    "sdf_decoder_split.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"],
     # vertices / sampled points reproducible op for op by oracle/mc_ref.py
     "marching_cubes.hip": ["-ffp-contract=off"],
 }

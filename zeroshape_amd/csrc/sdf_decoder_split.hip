@@ -125,11 +125,14 @@ DEV PT pack_tile(const T &x) {
     return p;
 }
 
-DEV void glds16(const char *gsrc, unsigned lds_dst) {  // 64 lanes x 16 B: global -> LDS[lds_dst + 16 lane]
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
-                 "\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
+// One K-block (hi and lo halves, 2 x 64 lanes x 16 B): global -> LDS[lds_dst + 16 lane (+ 1024)].
+// The instruction offset moves the global and the LDS address alike.  M0 (the LDS-DMA destination
+// base) is not saved: hipcc has no use for it in this kernel (no LDS-direct, GWS, movrel or
+// interpolation instructions; the only m0 references in the ISA are these).
+DEV void glds_kblock(const char *gsrc, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 "\n\tglobal_load_lds_dwordx4 %0, off offset:1024"
+                 :
                  : "v"(gsrc), "s"(lds_dst)
                  : "memory");
 }
@@ -140,7 +143,11 @@ DEV void glds16(const char *gsrc, unsigned lds_dst) {  // 64 lanes x 16 B: globa
 // A operand is already in registers): own share of chunk c+1 landed (counted vmcnt: only the two
 // DMAs of chunk c+2 may remain) and own reads of chunk c retired -> s_barrier -> chunk c+3 is
 // staged into the buffer just freed and the first A read of chunk c+1 is issued.  Lead time of
-// a chunk: two chunk periods.
+// a chunk: two chunk periods.  Measured alternatives (129^3 grid, this kernel 32.4 ms): two
+// buffers, lead one period: +6 ms (DMA latency exposed at every barrier); register staging
+// (global_load -> ds_write_b128 behind the barrier): +3 ms; the two DMAs moved from behind the
+// barrier into the shadows of the first MFMAs of the chunk: +0.5 ms; a DMA costs the issuing
+// wave ~56 cycles wherever it is placed, with or without saving M0.
 struct AStream {
     const u32x4 *buf[NBUF];   // this lane's view of the buffers, buf[0] = chunk being consumed
     unsigned dst[NBUF];       // LDS byte address of this wave's K-block in each (wave-uniform)
@@ -155,8 +162,7 @@ struct AStream {
         for (int i = 0; i < NBUF; i++) {
             buf[i] = stage + i * (CK * KB_U4) + lane;
             dst[i] = stage_addr + i * CHUNK_BYTES + wave * (KB_U4 * 16);
-            glds16(g + i * CHUNK_BYTES, dst[i]);
-            glds16(g + i * CHUNK_BYTES + 1024, dst[i] + 1024);
+            glds_kblock(g + i * CHUNK_BYTES, dst[i]);
         }
         gsrc = g + NBUF * CHUNK_BYTES;
         asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");  // chunk 0 landed everywhere
@@ -171,8 +177,7 @@ struct AStream {
 #if defined(ZS_EXP_STAGE_MODE) && ZS_EXP_STAGE_MODE == 1
 #else
             asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            glds16(gsrc, dst[0]);
-            glds16(gsrc + 1024, dst[0] + 1024);
+            glds_kblock(gsrc, dst[0]);
 #endif
             gsrc += CHUNK_BYTES;
             const u32x4 *t = buf[0];
