@@ -19,19 +19,20 @@
 //  * Weight stream.  At this rate four waves streaming private copies of the 10 MB program would
 //    pull ~50 TB/s through the vector memory path (64 B/clk/CU, L2 34 TB/s).  The four waves of a
 //    workgroup run the same program in lock step, so each 8 KiB chunk (4 K-blocks) is staged ONCE
-//    per workgroup into LDS by LDS-DMA (global_load_lds_dwordx4, one K-block per wave), three
-//    buffers (three), and read back as A operands with conflict-free ds_read_b128 by all four waves.
-//    One raw s_barrier per chunk: placed before the LAST K-block of a chunk is multiplied (its A
-//    operand is already in registers), so that the first A read of the next chunk is in flight
-//    under those MFMAs; the freed buffer is re-staged right behind the barrier (lead = two chunks
-//    of MFMAs; with two buffers the DMA latency was exposed at every barrier).  Ordering rules: cdna_hip_programming.md section 5 (counted vmcnt by
-//    the issuing wave, then a barrier the reader has passed; restage after an lgkmcnt-retired
-//    read + barrier).
+//    per workgroup into LDS by LDS-DMA (global_load_lds_dwordx4, one K-block per wave, three
+//    buffers) and read back as A operands with conflict-free ds_read_b128 by all four waves.
+//    One raw s_barrier per chunk (AStream below).  Ordering rules: cdna_hip_programming.md
+//    section 5 (counted vmcnt by the issuing wave, then a barrier the reader has passed; restage
+//    after an lgkmcnt-retired read + barrier).
 //  * LDS: [params window 8 KiB][A staging 3 x 8 KiB][4 x 32 KiB activation slabs] = 160 KiB.
 //    Params are paged in nine windows per tile instead of two.
 //  * No asm register ring: LDS reads and MFMAs are builtins, scheduled and hazard-padded by
-//    hipcc; only the DMA + barrier are asm (they must stay out of the compiler's vmcnt
-//    bookkeeping).  The bf16 MFMA, unlike the fp32 one, overlaps with VALU work.
+//    hipcc (VGPR-form accumulators: -mllvm -amdgpu-mfma-vgpr-form, zeroshape_amd/build.py); only
+//    the DMA, the barrier and the prefetch pin are asm.
+//  * Activations of tile t (GELU, softplus, operand split) are fed value by value between the
+//    MFMA groups of tile t+1 (software pipelines over the hidden tiles of the MLP - the split
+//    program permutes those K-blocks accordingly - and over the output tiles of impl_mlp).
+//  * The attention map (implicit.py:277) is only produced by the fp32 kernel.
 #include "zs_common.h"
 #include "sdf_layout.h"
 #include "sdf_math.h"
@@ -86,6 +87,14 @@ static_assert(PB_LN2G <= PRM_WINDOW && P_BLK_STRIDE - PB_LN2G <= PRM_WINDOW && W
               "params windows");
 
 #define DEV __device__ __forceinline__
+// pin(ahi, alo): the prefetch reads issued above stay above (memory clobber) and the MFMAs that
+// consume this K-block's A operand stay below (they read the statement's outputs).  Without it
+// hipcc hoists MFMAs over the prefetch or sinks the prefetch down to its first use as soon as
+// independent VALU work is around - either way the LDS latency is exposed at every K-block.
+typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pin(u32x4_ &a, u32x4_ &b) {
+    asm volatile("" : "+v"(a), "+v"(b) : : "memory");
+}
 
 DEV bf16x8 as_bf(const u32x4 &v) { return __builtin_bit_cast(bf16x8, v); }
 DEV unsigned pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32 (round to nearest even)
@@ -113,12 +122,7 @@ DEV PT pack_tile(const T &x) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             unsigned h, l;
-#ifdef ZS_EXP_NOPACK
-            h = __builtin_bit_cast(unsigned, (float)x[8 * j + 2 * i]);
-            l = __builtin_bit_cast(unsigned, (float)x[8 * j + 2 * i + 1]);
-#else
             split2(x[8 * j + 2 * i], x[8 * j + 2 * i + 1], h, l);
-#endif
             p.v[2 * j][i] = h;
             p.v[2 * j + 1][i] = l;
         }
@@ -142,12 +146,16 @@ DEV void glds_kblock(const char *gsrc, unsigned lds_dst) {
 // flight.  One synchronisation per chunk, before its LAST K-block is multiplied (that K-block's
 // A operand is already in registers): own share of chunk c+1 landed (counted vmcnt: only the two
 // DMAs of chunk c+2 may remain) and own reads of chunk c retired -> s_barrier -> chunk c+3 is
-// staged into the buffer just freed and the first A read of chunk c+1 is issued.  Lead time of
-// a chunk: two chunk periods.  Measured alternatives (129^3 grid, this kernel 32.4 ms): two
-// buffers, lead one period: +6 ms (DMA latency exposed at every barrier); register staging
-// (global_load -> ds_write_b128 behind the barrier): +3 ms; the two DMAs moved from behind the
-// barrier into the shadows of the first MFMAs of the chunk: +0.5 ms; a DMA costs the issuing
-// wave ~56 cycles wherever it is placed, with or without saving M0.
+// staged into the buffer just freed and the first A read of chunk c+1 is issued.
+// tools/ubench/mfma_bf16_stream.hip prices the pieces (cycles per K-block of 3 MFMAs, one wave
+// per SIMD, all CUs busy): MFMAs alone 96.1; + two ds_read_b128 105.5; + the barrier every four
+// K-blocks 124.1 (~74 cycles per barrier: the skew of four waves); + the LDS-DMA 131.6; + two
+// more ds_read_b128 for B operands from the slab 143.6.
+// Measured alternatives on the whole kernel (129^3 grid): two buffers, lead one chunk period:
+// +6 ms (DMA latency exposed at every barrier); register staging (global_load ->
+// ds_write_b128 behind the barrier): +3 ms; the DMAs moved from behind the barrier into the
+// shadows of the first MFMAs of the chunk: +0.5 ms; reads two K-blocks ahead: +0.6 ms; two
+// alternating accumulator chains: +2 ms (extra adds; a single chain already issues back to back).
 struct AStream {
     const u32x4 *buf[NBUF];   // this lane's view of the buffers, buf[0] = chunk being consumed
     unsigned dst[NBUF];       // LDS byte address of this wave's K-block in each (wave-uniform)
@@ -169,16 +177,21 @@ struct AStream {
         hi = buf[0][0];
         lo = buf[0][64];
     }
-    // A operand of the K-block at position `pos` (0..3) of the current chunk; prefetches the next.
+    // A operand of the K-block at position `pos` (0..3) of the current chunk; issues the read of
+    // the next (a distance of two K-blocks measured no better).  EXTRA_VM: vector-memory loads
+    // the caller has issued since the previous synchronisation and does not need yet (they are
+    // younger than the DMAs waited for here: the counted wait lets them stay in flight).
+    template <int EXTRA_VM = 0>
     DEV void step(int pos, u32x4 &ahi, u32x4 &alo) {
         ahi = hi;
         alo = lo;
         if (pos == CK - 1) {
-#if defined(ZS_EXP_STAGE_MODE) && ZS_EXP_STAGE_MODE == 1
-#else
-            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            static_assert(EXTRA_VM == 0 || EXTRA_VM == 4, "wait-count variants");
+            if (EXTRA_VM == 4)
+                asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             glds_kblock(gsrc, dst[0]);
-#endif
             gsrc += CHUNK_BYTES;
             const u32x4 *t = buf[0];
             const unsigned u = dst[0];
@@ -199,22 +212,59 @@ struct AStream {
     DEV void drain() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 };
 
+// One K-block: three dependent MFMAs on one accumulator.  A dependent v_mfma_f32_32x32x16_bf16
+// issues 32 cycles behind its producer (tools/ubench/mfma_bf16_stream.hip: one chain and two
+// alternating chains both run 96.1 cycles per K-block), so a second chain buys nothing.
 DEV void mfma3(f32x16 &acc, const u32x4 &ahi, const u32x4 &alo, const u32x4 &bhi, const u32x4 &blo) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(alo), as_bf(bhi), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(ahi), as_bf(blo), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(ahi), as_bf(bhi), acc, 0, 0, 0);
 }
+DEV f32x16 zero16() {
+    f32x16 v;
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = 0.f;
+    return v;
+}
 
 // acc += W_tile X, X = KT packed tiles in registers; starts at a chunk boundary
-template <int KT>
-DEV void gemm_reg(AStream &s, const PT *X, f32x16 &acc) {
+struct NoSide {
+    DEV void operator()(int) const {}
+};
+// Activation of the PREVIOUS output tile, fed one value per K-block of the current tile's GEMM
+// (16 values per lane, 16 K-blocks per 256-wide GEMM): the VALU work then sits between the MFMA
+// groups in program order, where the in-order wave issues it in their shadow (~5 issue slots per
+// 32-cycle MFMA) instead of behind the GEMM with the matrix pipe idle.  Collects the split
+// B operands of the tile.
+struct TilePacker {
+    PT p;
+    float prev;
+    DEV void feed(int kb, float v) {
+        if (kb & 1) {
+            unsigned h, l;
+            split2(prev, v, h, l);
+            p.v[2 * (kb >> 3)][(kb & 7) >> 1] = h;
+            p.v[2 * (kb >> 3) + 1][(kb & 7) >> 1] = l;
+        }
+        prev = v;
+    }
+};
+
+// SIDE: side(kb) runs behind the MFMAs of K-block kb
+template <int KT, int EXTRA_VM = 0, typename SIDE = NoSide>
+DEV void gemm_reg(AStream &s, const PT *X, f32x16 &acc, SIDE side = SIDE()) {
 #pragma unroll
     for (int kt = 0; kt < KT; kt++)
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             u32x4 ahi, alo;
-            s.step((kt * 2 + j) & (CK - 1), ahi, alo);
+            if (kt * 2 + j < CK)  // the first synchronisation leaves the caller's loads in flight
+                s.template step<EXTRA_VM>((kt * 2 + j) & (CK - 1), ahi, alo);
+            else
+                s.step((kt * 2 + j) & (CK - 1), ahi, alo);
+            pin(ahi, alo);
             mfma3(acc, ahi, alo, X[kt].v[2 * j], X[kt].v[2 * j + 1]);
+            side(kt * 2 + j);
         }
 }
 // one input tile (2 K-blocks) starting at chunk position pos0 (0 or 2)
@@ -223,12 +273,14 @@ DEV void gemm_one(AStream &s, const PT &X, f32x16 &acc, int pos0) {
     for (int j = 0; j < 2; j++) {
         u32x4 ahi, alo;
         s.step(pos0 + j, ahi, alo);
+        pin(ahi, alo);
         mfma3(acc, ahi, alo, X.v[2 * j], X.v[2 * j + 1]);
     }
 }
 // 8 input tiles with the B operands read from the wave's LDS slab ([k-block][hi | lo][lane]),
 // one K-block ahead of their use
-DEV void gemm_lds(AStream &s, const u32x4 *fl, f32x16 &acc) {
+template <typename SIDE = NoSide>
+DEV void gemm_lds(AStream &s, const u32x4 *fl, f32x16 &acc, SIDE side = SIDE()) {
     u32x4 bh = fl[0], bl = fl[64];
 #pragma unroll
     for (int kb = 0; kb < NT * 2; kb++) {
@@ -239,9 +291,43 @@ DEV void gemm_lds(AStream &s, const u32x4 *fl, f32x16 &acc) {
             nh = fl[(kb + 1) * KB_U4];
             nl = fl[(kb + 1) * KB_U4 + 64];
         }
+        pin(ahi, alo);
         mfma3(acc, ahi, alo, bh, bl);
         bh = nh;
         bl = nl;
+        side(kb);
+    }
+}
+
+// MLP software pipeline: nxt += W1[tile t+1] LN2(y) (16 K-blocks, B from the slab) with the
+// activation of the PREVIOUS hidden tile - gelu(cur) and its split into B operands - spread over
+// the K-blocks: one value per K-block, one packed pair every second K-block.  The VALU work sits
+// between the MFMA groups in program order, where the in-order wave can issue it in their shadow
+// (~5 issue slots per 32-cycle MFMA); done after the GEMM it ran with the matrix pipe idle.
+DEV void fc1_gelu(AStream &s, const u32x4 *fl, f32x16 &nxt, const f32x16 &cur, PT &hp) {
+    u32x4 bh = fl[0], bl = fl[64];
+    float g_prev = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NT * 2; kb++) {
+        u32x4 ahi, alo;
+        s.step(kb & (CK - 1), ahi, alo);
+        u32x4 nh = bh, nl = bl;
+        if (kb + 1 < NT * 2) {
+            nh = fl[(kb + 1) * KB_U4];
+            nl = fl[(kb + 1) * KB_U4 + 64];
+        }
+        pin(ahi, alo);
+        mfma3(nxt, ahi, alo, bh, bl);
+        bh = nh;
+        bl = nl;
+        const float g = gelu_erf(cur[kb]);
+        if (kb & 1) {
+            unsigned h, l;
+            split2(g_prev, g, h, l);
+            hp.v[2 * (kb >> 3)][(kb & 7) >> 1] = h;
+            hp.v[2 * (kb >> 3) + 1][(kb & 7) >> 1] = l;
+        }
+        g_prev = g;
     }
 }
 
@@ -328,9 +414,7 @@ DEV void load_params(float *prm, const float *prog_params, int start, int count)
 // are padding.
 template <bool MASK>
 DEV void attn_tile(AStream &s, const PT &q, f32x16 &o, float &m_run, float &z_run, float c, int hi) {
-    f32x16 S;
-#pragma unroll
-    for (int r = 0; r < 16; r++) S[r] = 0.f;
+    f32x16 S = zero16();
     gemm_one(s, q, S, 0);
     float mt = -INFINITY;
 #pragma unroll
@@ -358,13 +442,20 @@ DEV void attn_tile(AStream &s, const PT &q, f32x16 &o, float &m_run, float &z_ru
     m_run = m_new;
 }
 
+#ifdef ZS_EXP_TIMING  // tools/phase_timing_split.py: cycle stamps of (block 0, wave 0, first tile) -> workspace tail
+#define ZS_STAMP(i) do { if (dbg) dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ZS_STAMP(i) do { } while (0)
+#endif
 // One wave: 32 points (lane & 31; both lane halves carry the same point).
 DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage_addr, u32x4 *fl,
-                      f32x4 *zs, float px, float py, float pz, int wave, int lane) {
+                      f32x4 *zs, float px, float py, float pz, int wave, int lane,
+                      unsigned long long *dbg) {
     const int hi = lane >> 5;
     const float *prog_params = reinterpret_cast<const float *>(prog) + REC_FLOATS;
     AStream s;
     s.init(prog, stage, stage_addr, wave, lane);
+    ZS_STAMP(0);
 
     // point_proj (implicit.py:128-131); y is the residual stream, kept as accumulators
     load_params(prm, prog_params, W_PP, 1024);
@@ -372,12 +463,15 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
 #pragma unroll
     for (int kt = 0; kt < NT; kt++) y[kt] = xyz_affine(prm, 0, kt, hi, px, py, pz);
 
+    ZS_STAMP(1);
+
     const float scale = 0.17677669529663688110f;  // 32 ** -0.5
 
 #pragma unroll 1
     for (int blk = 0; blk < BLOCKS; blk++) {
         load_params(prm, prog_params, W_ATT + blk * P_BLK_STRIDE, PB_LN2G);
         layer_norm_lds(y, fl, prm, PB_LN1G, PB_LN1B, hi);
+        ZS_STAMP(2 + blk * 4);
         // y = x + proj_bias + sum_heads Wproj_h o_h
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) y[nt] += rp16(prm, PB_BPROJ, nt, hi);
@@ -400,9 +494,7 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
             const PT qp = pack_tile(q);
 
             float m_run = -INFINITY, z_run = 0.f;
-            f32x16 o;
-#pragma unroll
-            for (int r = 0; r < 16; r++) o[r] = 0.f;
+            f32x16 o = zero16();
 #pragma unroll 1
             for (int lt = 0; lt < LT - 1; lt++) attn_tile<false>(s, qp, o, m_run, z_run, c, hi);
             attn_tile<true>(s, qp, o, m_run, z_run, c, hi);
@@ -422,21 +514,33 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
             for (int nt = 0; nt < NT; nt++) gemm_one(s, op, y[nt], (nt & 1) * 2);
         }
 
+        ZS_STAMP(3 + blk * 4);
         // MLP (timm Mlp): y += b2 + W2 gelu(W1 LN2(y) + b1), one hidden tile at a time
         load_params(prm, prog_params, W_MLP + blk * P_BLK_STRIDE, P_BLK_STRIDE - PB_LN2G);
         layer_norm_lds(y, fl, prm, PB_LN2G - PB_LN2G, PB_LN2B - PB_LN2G, hi);
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) y[nt] += rp16(prm, PB_B2 - PB_LN2G, nt, hi);
+        ZS_STAMP(4 + blk * 4);
+        // software pipeline over the hidden tiles (stream order: fc1(0), [fc1(t+1), fc2(t)]..., fc2(31))
+        f32x16 hid = rp16(prm, PB_B1 - PB_LN2G, 0, hi);
+        gemm_lds(s, fl, hid);
 #pragma unroll 1
-        for (int ht = 0; ht < HT; ht++) {
-            f32x16 hid = rp16(prm, PB_B1 - PB_LN2G, ht, hi);
-            gemm_lds(s, fl, hid);
+        for (int ht = 0; ht < HT - 1; ht++) {
+            f32x16 nxt = rp16(prm, PB_B1 - PB_LN2G, ht + 1, hi);
+            PT hp;
+            fc1_gelu(s, fl, nxt, hid, hp);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) gemm_one(s, hp, y[nt], (nt & 1) * 2);
+            hid = nxt;
+        }
+        {
 #pragma unroll
             for (int r = 0; r < 16; r++) hid[r] = gelu_erf(hid[r]);
             const PT hp = pack_tile(hid);
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) gemm_one(s, hp, y[nt], (nt & 1) * 2);
         }
+        ZS_STAMP(5 + blk * 4);
     }
 
     // final norm (implicit.py:275) -> feat, fp32 in registers
@@ -454,20 +558,35 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
             for (int r = 0; r < 16; r++) h[kt * 16 + r] = fmaf((y[kt][r] - mean) * rstd, g[r], b[r]);
         }
     }
+    ZS_STAMP(10);
     PT hp[NT];
 
     // impl_mlp (implicit.py:168-184): inputs = cat[xyz, feat].  Layer 0: feat (regs) -> LDS
 #pragma unroll
     for (int kt = 0; kt < NT; kt++) hp[kt] = pack_tile(h + kt * 16);
+    // (software pipeline over the output tiles: tile nt's GEMM carries tile nt-1's activation)
+    {
+        f32x16 prev;
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-        f32x16 acc = xyz_affine(prm, P_IMPL0 - W_I0, nt, hi, px, py, pz);
-        gemm_reg<NT>(s, hp, acc);
-        float t[16];
+        for (int nt = 0; nt <= NT; nt++) {
+            TilePacker e;
+            auto side = [&](int kb) { e.feed(kb, softplus100(prev[kb])); };
+            if (nt < NT) {
+                f32x16 acc = xyz_affine(prm, P_IMPL0 - W_I0, nt, hi, px, py, pz);
+                if (nt == 0)
+                    gemm_reg<NT>(s, hp, acc);
+                else
+                    gemm_reg<NT, 0>(s, hp, acc, side);
+                if (nt > 0) store_tile_lds(fl, nt - 1, e.p);
+                prev = acc;
+            } else {
 #pragma unroll
-        for (int r = 0; r < 16; r++) t[r] = softplus100(acc[r]);
-        store_tile_lds(fl, nt, pack_tile(t));
+                for (int kb = 0; kb < 16; kb++) side(kb);
+                store_tile_lds(fl, nt - 1, e.p);
+            }
+        }
     }
+    ZS_STAMP(11);
     // the skip layers consume cat[x, xyz, feat] / sqrt(2): their feat halves are computed now,
     // while feat is in registers, and parked in the workspace (fp32 Z tiles)
     const float rsqrt2 = 0.70710678118654752440f;
@@ -496,17 +615,31 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
         }
     }
 
+    ZS_STAMP(12);
     // layer 1 (plain): LDS -> registers, pre-divided by sqrt(2) because layer 2 is a skip layer
     load_params(prm, prog_params, W_I1, W_I2 - W_I1);
+    {
+        f32x16 prev;
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-        f32x16 acc = rp16(prm, P_IMPL1 - W_I1, nt, hi);
-        gemm_lds(s, fl, acc);
-        float t[16];
+        for (int nt = 0; nt <= NT; nt++) {
+            TilePacker e;
+            auto side = [&](int kb) { e.feed(kb, softplus100(prev[kb]) * rsqrt2); };
+            if (nt < NT) {
+                f32x16 acc = rp16(prm, P_IMPL1 - W_I1, nt, hi);
+                if (nt == 0)
+                    gemm_lds(s, fl, acc);
+                else
+                    gemm_lds(s, fl, acc, side);
+                if (nt > 0) hp[nt - 1] = e.p;
+                prev = acc;
+            } else {
 #pragma unroll
-        for (int r = 0; r < 16; r++) t[r] = softplus100(acc[r]) * rsqrt2;
-        hp[nt] = pack_tile(t);
+                for (int kb = 0; kb < 16; kb++) side(kb);
+                hp[nt - 1] = e.p;
+            }
+        }
     }
+    ZS_STAMP(13);
     float out = 0.f;
 #pragma unroll 1
     for (int i = 0; i < 3; i++) {
@@ -515,47 +648,78 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
         const int pp = i == 0 ? P_IMPL_PAIR - W_I1 : 0;
         const f32x4 *zl = zs + i * SLAB_U4;
         // skip layer 2+2i: registers (x / sqrt(2)) + parked feat half -> LDS
+        {
+            f32x16 prev;
+            f32x4 zprev[4];
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++) {
-            // the parked tile is fetched first (L1-bypassing loads: this wave wrote it earlier in
-            // the launch); the stream's asm statements keep the loads from sinking behind the GEMM
-            f32x4 z[4];
+            for (int nt = 0; nt <= NT; nt++) {
+                TilePacker e;
+                auto side = [&](int kb) { e.feed(kb, softplus100(prev[kb] + zprev[kb >> 2][kb & 3])); };
+                if (nt < NT) {
+                    // the parked tile is fetched first (L1-bypassing loads: this wave wrote it earlier
+                    // in the launch); the stream's asm statements keep the loads from sinking behind
+                    // the GEMM, whose first synchronisation leaves them in flight
+                    f32x4 z[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) z[j] = __builtin_nontemporal_load(zl + (nt * 4 + j) * 64);
-            f32x16 acc = xyz_affine(prm, pp, nt, hi, sx, sy, sz);
-            gemm_reg<NT>(s, hp, acc);
-            float t[16];
+                    for (int j = 0; j < 4; j++) z[j] = __builtin_nontemporal_load(zl + (nt * 4 + j) * 64);
+                    f32x16 acc = xyz_affine(prm, pp, nt, hi, sx, sy, sz);
+                    if (nt == 0)
+                        gemm_reg<NT, 4>(s, hp, acc);
+                    else
+                        gemm_reg<NT, 4>(s, hp, acc, side);
+                    if (nt > 0) store_tile_lds(fl, nt - 1, e.p);
+                    prev = acc;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                t[4 * j + 0] = softplus100(acc[4 * j + 0] + z[j].x);
-                t[4 * j + 1] = softplus100(acc[4 * j + 1] + z[j].y);
-                t[4 * j + 2] = softplus100(acc[4 * j + 2] + z[j].z);
-                t[4 * j + 3] = softplus100(acc[4 * j + 3] + z[j].w);
+                    for (int j = 0; j < 4; j++) zprev[j] = z[j];
+                } else {
+#pragma unroll
+                    for (int kb = 0; kb < 16; kb++) side(kb);
+                    store_tile_lds(fl, nt - 1, e.p);
+                }
             }
-            store_tile_lds(fl, nt, pack_tile(t));
         }
         // plain layer 3+2i: LDS -> registers (/ sqrt(2) when the next layer is a skip layer);
         // the last one feeds layer 8 (256 -> 1), evaluated in fp32 on the spot
         const float post = i < 2 ? rsqrt2 : 1.0f;
+        {
+            f32x16 prev;
+            float w[16];  // layer 8 weights of the previous tile (last pair only)
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++) {
-            f32x16 acc = rp16(prm, pp + 1024, nt, hi);
-            gemm_lds(s, fl, acc);
-            float t[16];
+            for (int nt = 0; nt <= NT; nt++) {
+                TilePacker e;
+                auto side = [&](int kb) {
+                    const float t = softplus100(prev[kb]) * post;
+                    e.feed(kb, t);
+                    out = fmaf(t, w[kb], out);
+                };
+                if (nt > 0) {
+                    if (i == 2) {
+                        rp(prm, P_W8 - W_I3, nt - 1, hi, w);
+                    } else {
 #pragma unroll
-            for (int r = 0; r < 16; r++) t[r] = softplus100(acc[r]) * post;
-            if (i < 2) {
-                hp[nt] = pack_tile(t);
-            } else {
-                float w[16];
-                rp(prm, P_W8 - W_I3, nt, hi, w);
+                        for (int r = 0; r < 16; r++) w[r] = 0.f;
+                    }
+                }
+                if (nt < NT) {
+                    f32x16 acc = rp16(prm, pp + 1024, nt, hi);
+                    if (nt == 0)
+                        gemm_lds(s, fl, acc);
+                    else
+                        gemm_lds(s, fl, acc, side);
+                    if (nt > 0) hp[nt - 1] = e.p;
+                    prev = acc;
+                } else {
 #pragma unroll
-                for (int r = 0; r < 16; r++) out = fmaf(t[r], w[r], out);
+                    for (int kb = 0; kb < 16; kb++) side(kb);
+                    hp[nt - 1] = e.p;
+                }
             }
         }
     }
+    ZS_STAMP(14);
     s.drain();
     out += xhalf(out);
+    ZS_STAMP(15);
     return out + prm[P_B8 - W_I3];
 }
 
@@ -603,13 +767,37 @@ __global__ __launch_bounds__(WAVES * 64, 1) void sdf_decode_split_kernel(
             py = q[1];
             pz = q[2];
         }
-        float logit = decode_tile(prog, prm, stage, stage_addr, fl, zslab, px, py, pz, wave, lane);
+#ifdef ZS_EXP_TIMING
+        unsigned long long *dbg = (blockIdx.x == 0 && threadIdx.x == 0 && tile == 0)
+            ? reinterpret_cast<unsigned long long *>(workspace + (size_t)MAX_WGS * WAVES * ZSLAB_F4) : nullptr;
+#else
+        unsigned long long *dbg = nullptr;
+#endif
+        float logit = decode_tile(prog, prm, stage, stage_addr, fl, zslab, px, py, pz, wave, lane, dbg);
         if (apply_sigmoid) logit = 1.0f / (1.0f + expf(-logit));
         if (lane < 32 && p < m) out[(size_t)img * m + p] = logit;
     }
 }
 
-// fp32 decoder program -> split program: same unit order and size; K-block j of a unit holds
+// Order of the split stream: the fp32 program's, except inside the two MLP sections, where the
+// kernel runs a software pipeline over the 32 hidden tiles (fc1 of tile t+1 before fc2 of tile
+// t): fc1(0), [fc1(1), fc2(0)], ..., [fc1(31), fc2(30)], fc2(31), 16 K-blocks each.
+__host__ __device__ inline int split_source_kblock(int kb) {
+    constexpr int KB_BLOCK = G_BLOCK / 2, KB_ATT = HEADS * G_HEAD / 2, KB_MLP = HT * G_MLP_TILE / 2;
+    if (kb >= BLOCKS * KB_BLOCK) return kb;
+    const int blk = kb / KB_BLOCK, p = kb - blk * KB_BLOCK - KB_ATT;
+    if (p < 16) return kb;  // attention section, or fc1(0)
+    const int q = p - 16, it = q >> 5, r = q & 31;
+    int src;
+    if (it < HT - 1)
+        src = r < 16 ? (it + 1) * 32 + r : it * 32 + r;  // fc1(it + 1) | fc2(it)
+    else
+        src = it * 32 + 16 + r;                          // fc2(31)
+    (void)KB_MLP;
+    return blk * KB_BLOCK + KB_ATT + src;
+}
+
+// fp32 decoder program -> split program: same units and size; K-block j of a unit holds
 // records 8 j .. 8 j + 7 of that unit as [hi: lane x 8 bf16][lo: lane x 8 bf16]; params copied.
 __global__ __launch_bounds__(256) void split_program_kernel(const float *__restrict__ src,
                                                             size_t src_stride_floats,
@@ -622,7 +810,7 @@ __global__ __launch_bounds__(256) void split_program_kernel(const float *__restr
     constexpr int REC_KB = REC_FLOATS / (KB_U4 * 4);  // K-blocks incl. the zero tail
     if (e < REC_KB * 64) {
         const int kb = e >> 6, lane = e & 63;
-        const f32x4 *g = reinterpret_cast<const f32x4 *>(s) + (size_t)kb * 128;  // two fp32 groups
+        const f32x4 *g = reinterpret_cast<const f32x4 *>(s) + (size_t)split_source_kblock(kb) * 128;  // two fp32 groups
         const f32x4 a = g[lane], b = g[64 + lane];
         unsigned h[4], l[4];
         split2(a.x, a.y, h[0], l[0]);
