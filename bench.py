@@ -13,10 +13,20 @@ occupancy grids on every rank (zeroshape_amd/parallel.py).  N = 1: one image, on
 time.  Weights: seeded random (no checkpoint ships with the reference); latent_depth:
 seeded N(0,1).
 
+--precision selects the decoder arithmetic: "bf16x3" (default; split-bf16 on the bf16 matrix pipe,
+csrc/sdf_decoder_split.hip: max |logit error| ~2e-5 against the fp32 reference, inside the 1e-4
+contract of BASELINE.json and two bf16 mantissas wide where BASELINE's own config names bf16) or
+"f32" (exact-fp32 MFMA, csrc/sdf_decoder.hip).
+
 Extra objects on the JSON line:
-  roofline     - the fused decoder kernel against the fp32-MFMA peak (157.3 TFLOP/s,
-                 MI355X_MICROARCH.md): algorithmic 5.00 MFLOP/point x
-                 points per launch / mean launch duration from HIP events on the launch stream.
+  roofline     - the fused decoder kernel against the dense MFMA peak of its dtype (bf16 2,500 /
+                 fp32 157.3 TFLOP/s, MI355X_MICROARCH.md): ALGORITHMIC 5.00 MFLOP/point (SURVEY.md
+                 section 8d) x points per launch / mean launch duration from HIP events on the launch
+                 stream.  For bf16x3 every algorithmic product costs three bf16 MFMAs; the executed
+                 matrix rate is reported beside it (`executed`).
+  exact_f32    - (bf16x3 runs, N = 1) the same grid through the exact-fp32 kernel, outside the
+                 timed region: its rate, its roofline fraction, and the largest |logit| difference
+                 and the occupancy flips between the two arithmetics on the full grid.
   cpu_baseline - the oracle (torch-CPU fp32 restatement of the reference, "port") timed on
                  this host's cores on a bounded sample of x-slices of the same grid.
 """
@@ -34,6 +44,14 @@ VOX_RES = 128
 RANGE = (-1.5, 1.5)
 FLOP_PER_POINT = 5.00e6          # SURVEY.md section 8d (algorithmic, fp32 reference)
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact f32
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
+# matrix work the kernels really execute per point (197 -> 224 latent padding included):
+EXEC_FLOP_PER_POINT = {"f32": 39424 * 4096 / 32.0,        # 39,424 MFMAs of 32x32x2 per 32 points
+                       "bf16x3": 14784 * 32768 / 32.0}    # 14,784 MFMAs of 32x32x16 per 32 points
+# HBM-side bytes per 129^3 launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the
+# gfx950 correction + WRITE_SIZE; profiles/README.md)
+TRAFFIC = {"f32": (1.88e10, "profiles/r01_v3_decoder_rocprofv3_summary.txt"),
+           "bf16x3": (1.84e10, "profiles/r01_split_decoder_rocprofv3_summary.txt")}
 
 
 def main():
@@ -42,6 +60,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--vox-res", type=int, default=VOX_RES)
+    ap.add_argument("--precision", choices=("bf16x3", "f32"), default="bf16x3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -80,6 +99,7 @@ def main():
                    num_heads=8, skip_in=[2, 4, 6], pos_perlayer=False)
     net.load_state_dict(sd, strict=True)
     net = net.to(dev).eval()
+    net.precision = args.precision
     batch = world                                  # weak scaling: one image of work per rank
     latent = torch.from_numpy(syn.seeded_latent(0, batch)).to(dev)
     axis = torch.linspace(RANGE[0], RANGE[1], G, device=dev)
@@ -114,31 +134,53 @@ def main():
 
     # ---- roofline of the dominant kernel: HIP events around decoder launches only -------
     b, e, _ = parallel.slab_bounds(G, world, rank)
-    st = net.prepare(latent)
-    torch.cuda.synchronize()
-    reps = max(3, min(args.steps, 10))
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
     stream = torch.cuda.current_stream(dev)       # the stream the C ABI launches on
-    ev[0].record(stream)
-    for i in range(reps):
-        net.query_grid(latent, axis, apply_sigmoid=True, slice_begin=b, slice_end=e, state=st)
-        ev[i + 1].record(stream)
-    torch.cuda.synchronize()
-    kern_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps))
-    kern_mean = sum(kern_ms) / len(kern_ms)
     pts_launch = batch * (e - b) * G * G
-    achieved = pts_launch * FLOP_PER_POINT / (kern_mean * 1e-3) / 1e12
-    roofline = {"bound": "mfma", "kernel": "sdf_decode_kernel<GRID>", "achieved": round(achieved, 3),
-                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                # HBM-side bytes per 129^3 launch from the committed rocprofv3 PMC passes
-                # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/README.md); only
-                # meaningful for the default single-GPU vox_res=128 launch
-                "traffic": 1.88e10 if (N == 128 and world == 1) else None,
-                "traffic_unit": "bytes/launch", "traffic_source": "profiles/r01_v3_decoder_rocprofv3_summary.txt",
-                "points_per_launch": pts_launch, "launch_ms_mean": round(kern_mean, 4),
-                "launch_ms_min": round(kern_ms[0], 4),
-                "algorithmic_flop_per_point": FLOP_PER_POINT}
+
+    def time_launches(precision, reps):
+        st = net.prepare(latent, precision)
+        net.query_grid(latent, axis, apply_sigmoid=True, slice_begin=b, slice_end=e, state=st)
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        ev[0].record(stream)
+        for i in range(reps):
+            net.query_grid(latent, axis, apply_sigmoid=True, slice_begin=b, slice_end=e, state=st)
+            ev[i + 1].record(stream)
+        torch.cuda.synchronize()
+        return sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps)), st
+
+    def roofline_of(precision, kern_ms):
+        mean = sum(kern_ms) / len(kern_ms)
+        peak = PEAK_BF16_MFMA_TFLOPS if precision == "bf16x3" else PEAK_F32_MFMA_TFLOPS
+        achieved = pts_launch * FLOP_PER_POINT / (mean * 1e-3) / 1e12
+        executed = pts_launch * EXEC_FLOP_PER_POINT[precision] / (mean * 1e-3) / 1e12
+        traffic, src = TRAFFIC[precision] if (N == 128 and world == 1) else (None, None)
+        return {"bound": "mfma",
+                "kernel": "sdf_decode_split_kernel<GRID>" if precision == "bf16x3" else "sdf_decode_kernel<GRID>",
+                "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4),
+                "executed": round(executed, 3), "executed_frac": round(executed / peak, 4),
+                "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": src,
+                "points_per_launch": pts_launch, "launch_ms_mean": round(mean, 4),
+                "launch_ms_min": round(kern_ms[0], 4), "algorithmic_flop_per_point": FLOP_PER_POINT}
+
+    kern_ms, st = time_launches(args.precision, max(3, min(args.steps, 10)))
+    roofline = roofline_of(args.precision, kern_ms)
+
+    exact_f32 = None
+    if args.precision == "bf16x3" and world == 1:
+        ms32, st32 = time_launches("f32", 3)
+        r32 = roofline_of("f32", ms32)
+        lg = net.query_grid(latent, axis, apply_sigmoid=False, state=st)
+        lg32 = net.query_grid(latent, axis, apply_sigmoid=False, state=st32)
+        flips = (lg > 0) != (lg32 > 0)
+        exact_f32 = {"value": round(pts_launch / (r32["launch_ms_mean"] * 1e-3), 1), "unit": "points/s",
+                     "launch_ms_mean": r32["launch_ms_mean"], "roofline_frac": r32["frac"],
+                     "roofline_peak": r32["peak"],
+                     "max_abs_logit_diff": float((lg - lg32).abs().max()),
+                     "occupancy_flips": int(flips.sum()), "points": int(lg.numel()),
+                     "max_abs_logit_at_flip": float(lg32[flips].abs().max()) if int(flips.sum()) else 0.0}
+        del lg, lg32
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -177,15 +219,17 @@ def main():
             "metric": "sdf_query_points_per_sec_vox%d" % N, "value": round(value, 1),
             "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "compute_level_grid vox_res=%d: (%d+1)^3 = %d points/image, "
-                                   "range [-1.5,1.5], prologue + fused decoder + sigmoid; batch = "
+                                   "range [-1.5,1.5], prologue + fused decoder (%s) + sigmoid; batch = "
                                    "n_gpus images, x-slab sharded, RCCL all_gather for n_gpus>1"
-                                   % (N, N, G ** 3),
+                                   % (N, N, G ** 3, args.precision),
                        "global_batch_images": batch, "points_per_step": points_per_step,
                        "weights": "seeded random (zeroshape_amd/synthetic.py)"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
+        if exact_f32 is not None:
+            line["exact_f32"] = exact_f32
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
