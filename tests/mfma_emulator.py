@@ -44,7 +44,7 @@ class Stream(object):
         return [grp[:, j] for j in range(4)]
 
 
-def gemm_tile(stream, X, acc):
+def gemm_tile_f32(stream, X, acc):
     """acc[16,64] += W_tile @ X  with X = list of KT activation tiles [16,64];
     consumes KT*4 groups (kt-major, then register)."""
     for kt in range(len(X)):
@@ -87,9 +87,67 @@ def softplus100(x):
     return np.where(z > 20.0, x, np.log1p(np.exp(np.minimum(z, 20.0))) / 100.0)
 
 
-def decode_wave(recs_flat, params, xyz):
-    """xyz [32,3] -> logits [32] for one wave tile, following the kernel schedule."""
-    st = Stream(recs_flat)
+class SplitStream(object):
+    """The split-bf16 program (zeroshape_amd.program.split_program) consumed K-block by K-block in
+    the order csrc/sdf_decoder_split.hip consumes it."""
+    split = True
+
+    def __init__(self, words):
+        n = P.REC_FLOATS // P.KB_WORDS
+        h = np.ascontiguousarray(words[:n * P.KB_WORDS]).view(np.uint16).reshape(n, 2, 64, 8)
+        self.kb = (h.astype(np.uint32) << 16).view(np.float32).astype(np.float64)   # [kb][hi|lo][lane][e]
+        self.pos = 0
+
+    def next_kblock(self):
+        a = self.kb[self.pos]
+        self.pos += 1
+        return a[0], a[1]
+
+
+def _split_bf16(x):
+    _, hi = P.bf16_rne(x.astype(np.float32))
+    _, lo = P.bf16_rne(x.astype(np.float32) - hi)
+    return hi.astype(np.float64), lo.astype(np.float64)
+
+
+def mfma16(a, b, acc):
+    """acc[16,64] += A[32x16] @ B[16x32] in the 32x32x16 layout: lane l supplies
+    A[i = l & 31][k = (l >> 5, e)] and B[k = (l >> 5, e)][j = l & 31], e = 0..7."""
+    A = np.concatenate([a[:32], a[32:]], axis=1)        # [i][16]
+    B = np.concatenate([b[:32], b[32:]], axis=1).T      # [16][j]
+    D = A @ B
+    acc += D[ROWS, COL[None, :]]
+    return acc
+
+
+def gemm_tile_split(stream, X, acc):
+    """as gemm_tile, on the split stream: per input tile two K-blocks (registers 8j..8j+7 of the
+    tile as the B operand), three MFMAs each."""
+    for kt in range(len(X)):
+        for j in range(2):
+            ahi, alo = stream.next_kblock()
+            bhi, blo = _split_bf16(X[kt][8 * j:8 * j + 8].T)        # [lane][e]
+            mfma16(alo, bhi, acc)
+            mfma16(ahi, blo, acc)
+            mfma16(ahi, bhi, acc)
+    return acc
+
+
+def decode_wave(recs_flat, params, xyz, split=False):
+    """xyz [32,3] -> logits [32] for one wave tile, following the kernel schedule.
+    split: recs_flat is the split program (uint32 words) and the schedule that of
+    csrc/sdf_decoder_split.hip (software-pipelined MLP)."""
+    global gemm_tile
+    if split:
+        st = SplitStream(recs_flat)
+        gemm = gemm_tile_split
+    else:
+        st = Stream(recs_flat)
+        gemm = gemm_tile_f32
+    return _decode_wave(st, gemm, params, xyz, split)
+
+
+def _decode_wave(st, gemm_tile, params, xyz, split):
     L = P.PARAMS
     px = np.concatenate([xyz[:, 0], xyz[:, 0]]).astype(np.float64)
     py = np.concatenate([xyz[:, 1], xyz[:, 1]]).astype(np.float64)
@@ -138,11 +196,20 @@ def decode_wave(recs_flat, params, xyz):
                 gemm_tile(st, [o], y[nt])
         h2 = layer_norm(y, params, d["ln2_g"], d["ln2_b"])
         y = [y[nt] + rp(params, d["b2"], nt) for nt in range(8)]
-        for ht in range(P.HT):
-            hid = gemm_tile(st, h2, rp(params, d["b1"], ht).copy())
-            hid = gelu(hid)
-            for nt in range(8):
-                gemm_tile(st, [hid], y[nt])
+        if split:      # fc1(0), [fc1(t+1), fc2(t)] ..., fc2(31)
+            hid = gemm_tile(st, h2, rp(params, d["b1"], 0).copy())
+            for ht in range(P.HT):
+                nxt = gemm_tile(st, h2, rp(params, d["b1"], ht + 1).copy()) if ht + 1 < P.HT else None
+                hid = gelu(hid)
+                for nt in range(8):
+                    gemm_tile(st, [hid], y[nt])
+                hid = nxt
+        else:
+            for ht in range(P.HT):
+                hid = gemm_tile(st, h2, rp(params, d["b1"], ht).copy())
+                hid = gelu(hid)
+                for nt in range(8):
+                    gemm_tile(st, [hid], y[nt])
         x = y
     feat = layer_norm(x, params, L.lnf_g, L.lnf_b)
     sq2 = math.sqrt(2.0)
@@ -172,5 +239,8 @@ def decode_wave(recs_flat, params, xyz):
         cur = nxt
     out = sum((cur[kt] * rp(params, L.w8, kt)).sum(axis=0) for kt in range(8))
     out = out + partner(out) + params[L.b8]
-    assert st.pos == P.G_TOTAL, (st.pos, P.G_TOTAL)
+    assert st.pos == (P.KB_TOTAL if split else P.G_TOTAL), st.pos
     return out[:32]
+
+
+gemm_tile = gemm_tile_f32     # name used by tests/test_program_packing.py

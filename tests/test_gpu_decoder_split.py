@@ -30,49 +30,13 @@ def net(seeded_sd):
     return m
 
 
-def _bf16_rne(x):
-    """fp32 -> bf16 (round to nearest even) as uint16, and back to fp32."""
-    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
-    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32)
-    return r.astype(np.uint16), (r << 16).astype(np.uint32).view(np.float32)
-
-
-def split_source_kblocks(n):
-    """Stream order of the split program: the fp32 program's, except inside the two MLP
-    sections (software pipeline over the hidden tiles): fc1(0), [fc1(t+1), fc2(t)]..., fc2(31)."""
-    src = np.arange(n)
-    kb_block, kb_att = P.G_BLOCK // 2, P.HEADS * P.G_HEAD // 2
-    order = list(range(16))
-    for t in range(P.HT - 1):
-        order += [(t + 1) * 32 + r for r in range(16)] + [t * 32 + 16 + r for r in range(16)]
-    order += [(P.HT - 1) * 32 + 16 + r for r in range(16)]
-    assert sorted(order) == list(range(P.HT * 32))
-    for blk in range(P.BLOCKS):
-        base = blk * kb_block + kb_att
-        src[base:base + P.HT * 32] = base + np.array(order)
-    return src
-
-
-def split_program_host(prog):
-    """numpy mirror of split_program_kernel: K-block kb = fp32 groups 2kb, 2kb+1; per lane the
-    8 records' values -> [hi: 8 bf16][lo: 8 bf16]."""
-    rec = prog[:P.REC_FLOATS].reshape(-1, 2, 64, 4)            # [kb][group][lane][j]
-    rec = rec[split_source_kblocks(rec.shape[0])]
-    vals = rec.transpose(0, 2, 1, 3).reshape(-1, 64, 8)         # [kb][lane][e = 4 g + j]
-    hi16, hif = _bf16_rne(vals)
-    lo16, _ = _bf16_rne(vals - hif)
-    out = np.stack([hi16, lo16], axis=1)                        # [kb][hi|lo][lane][8]
-    words = np.ascontiguousarray(out).reshape(-1).view(np.uint32)
-    return np.concatenate([words, prog[P.REC_FLOATS:].view(np.uint32)])
-
-
 def test_split_program_layout(net, seeded_sd):
     latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=2)).cuda()
     f32 = net.prepare(latent, "f32")
     sp = net.prepare(latent, "bf16x3")
     assert sp.precision == "bf16x3" and sp.programs.shape == f32.programs.shape
     for b in range(2):
-        want = split_program_host(f32.programs[b].cpu().numpy())
+        want = P.split_program(f32.programs[b].cpu().numpy())
         got = sp.programs[b].cpu().numpy().view(np.uint32)
         np.testing.assert_array_equal(got, want)
 

@@ -56,3 +56,56 @@ def test_emulated_kernel_matches_oracle(seeded_sd):
     want, _ = R.implicit_forward(seeded_sd, latent, torch.from_numpy(pts))
     got = E.decode_wave(recs, params, pts[0])
     np.testing.assert_allclose(got, want[0].numpy().astype(np.float64), atol=2e-5, rtol=0)
+
+
+def test_split_stream_order_and_layout():
+    src = P.split_source_kblocks()
+    assert sorted(src) == list(range(src.size))                    # a permutation
+    kb_block, kb_att = P.G_BLOCK // 2, P.HEADS * P.G_HEAD // 2
+    assert np.array_equal(src[:kb_att], np.arange(kb_att))         # attention sections untouched
+    m = src[kb_att:kb_att + 48] - kb_att
+    assert list(m[:16]) == list(range(16))                         # fc1(0)
+    assert list(m[16:32]) == list(range(32, 48))                   # fc1(1)
+    assert list(m[32:48]) == list(range(16, 32))                   # fc2(0)
+    assert np.array_equal(src[2 * kb_block:], np.arange(2 * kb_block, src.size))   # impl_mlp + tail
+    # one 32x32 unit: K-block j holds records 8j..8j+7, hi + lo ~ the weight
+    rs = np.random.RandomState(1)
+    prog = np.zeros(P.PROGRAM_FLOATS, np.float32)
+    W = rs.randn(32, 32).astype(np.float32)
+    prog[:1024] = P._interleave(P._records_linear(W, 0, 0))
+    words = P.split_program(prog)
+    h = words[:1024].view(np.uint16).reshape(2, 2, 64, 8)
+    val = (h.astype(np.uint32) << 16).view(np.float32)
+    for j in range(2):
+        rec = np.stack([P._records_linear(W, 0, 0)[8 * j + e] for e in range(8)], axis=1)   # [lane][e]
+        np.testing.assert_allclose(val[j, 0] + val[j, 1], rec, rtol=2 ** -16, atol=0)
+        np.testing.assert_allclose(val[j, 0], rec, rtol=2 ** -8, atol=0)
+
+
+def test_split_mfma_emulator_is_a_matmul():
+    rs = np.random.RandomState(0)
+    W = rs.randn(32, 32).astype(np.float32)
+    X = rs.randn(32, 32)
+    prog = np.zeros(P.PROGRAM_FLOATS, np.float32)
+    prog[:1024] = P._interleave(P._records_linear(W, 0, 0))
+    xt = np.stack([X[E.ROWS[r], E.COL] for r in range(16)])
+    acc = E.gemm_tile_split(E.SplitStream(P.split_program(prog)), [xt], np.zeros((16, 64)))
+    Y = W.astype(np.float64) @ X
+    np.testing.assert_allclose(acc, np.stack([Y[E.ROWS[r], E.COL] for r in range(16)]), atol=5e-4)   # split arithmetic: ~2^-16 relative; a layout error would be O(1)
+
+
+def test_emulated_split_kernel_matches_oracle(seeded_sd):
+    """The split-bf16 schedule (permuted MLP stream, K-block operands, hi/lo products) on the CPU:
+    same program the device derives, within the split arithmetic's error of the oracle."""
+    sd_np = {k: v.numpy() for k, v in seeded_sd.items()}
+    latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=1))
+    lp = R.latent_path(seeded_sd, latent)
+    kv = {(blk, h): (lp["k%d" % blk][0, h].numpy(), lp["v%d" % blk][0, h].numpy())
+          for blk in range(2) for h in range(8)}
+    words = P.split_program(P.pack_program(sd_np, kv))
+    assert words.size == P.PROGRAM_FLOATS
+    pts = syn.seeded_cloud(11, 1, 32, -1.5, 1.5)
+    want, _ = R.implicit_forward(seeded_sd, latent, torch.from_numpy(pts))
+    got = E.decode_wave(words, P.pack_params(sd_np), pts[0], split=True)
+    err = np.abs(got - want[0].numpy().astype(np.float64))
+    assert err.max() < 6e-5, err.max()

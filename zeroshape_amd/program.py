@@ -350,3 +350,52 @@ def pack_latent_params(sd):
 # hid [197x1024]; kv1 [197x512]
 LPAD = 200  # rows padded to a multiple of the prologue's row block (4)
 SCRATCH_FLOATS = LPAD * (3 * C + 3 * C + C + HID + 2 * C)
+
+
+# ----------------------------------------------------------------------------- #
+# split-bf16 program (csrc/sdf_decoder_split.hip) - host mirror of zs_sdf_split_programs
+# ----------------------------------------------------------------------------- #
+# One K-block (K = 16, three bf16 MFMAs) = two fp32 groups = records 8j..8j+7 of a 32x32 weight
+# unit; per lane [hi: 8 bf16][lo: 8 bf16] with x = hi + lo.  Same units and byte size as the fp32
+# program; the product derives it on the device, this mirror exists for tests and documentation.
+KB_TOTAL = G_TOTAL // 2                 # 4,928 K-blocks per wave tile
+KB_WORDS = 512                          # 32-bit words per K-block (2 x 64 lanes x 16 B)
+
+
+def split_source_kblocks(n=None):
+    """dst K-block -> src K-block (in fp32-program order).  Identity except inside the two MLP
+    sections, where the kernel runs a software pipeline over the 32 hidden tiles (fc1 of tile
+    t+1 before fc2 of tile t): fc1(0), [fc1(1), fc2(0)], ..., [fc1(31), fc2(30)], fc2(31)."""
+    n = REC_FLOATS // GROUP_FLOATS // 2 if n is None else n
+    src = np.arange(n)
+    kb_block, kb_att = G_BLOCK // 2, HEADS * G_HEAD // 2
+    order = list(range(16))
+    for t in range(HT - 1):
+        order += [(t + 1) * 32 + r for r in range(16)] + [t * 32 + 16 + r for r in range(16)]
+    order += [(HT - 1) * 32 + 16 + r for r in range(16)]
+    assert sorted(order) == list(range(HT * 32))
+    for blk in range(BLOCKS):
+        base = blk * kb_block + kb_att
+        src[base:base + HT * 32] = base + np.array(order)
+    return src
+
+
+def bf16_rne(x):
+    """fp32 -> bf16 (round to nearest even): (uint16 bits, value as fp32)."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32)
+    return r.astype(np.uint16), (r << 16).astype(np.uint32).view(np.float32)
+
+
+def split_program(prog):
+    """fp32 program [PROGRAM_FLOATS] (float32) -> split program as uint32 words, bit for bit
+    what zs_sdf_split_programs writes."""
+    prog = np.ascontiguousarray(prog, np.float32)
+    rec = prog[:REC_FLOATS].reshape(-1, 2, 64, 4)                  # [kb][group][lane][j]
+    rec = rec[split_source_kblocks(rec.shape[0])]
+    vals = rec.transpose(0, 2, 1, 3).reshape(-1, 64, 8)             # [kb][lane][e = 4 g + j]
+    hi16, hif = bf16_rne(vals)
+    lo16, _ = bf16_rne(vals - hif)
+    out = np.stack([hi16, lo16], axis=1)                            # [kb][hi | lo][lane][8]
+    words = np.ascontiguousarray(out).reshape(-1).view(np.uint32)
+    return np.concatenate([words, prog[REC_FLOATS:].view(np.uint32)])
