@@ -27,6 +27,7 @@ def main():
                    skip_in=[2, 4, 6], pos_perlayer=False)
     net.load_state_dict(sd)
     net = net.to(dev).eval()
+    net.precision = sys.argv[sys.argv.index("--precision") + 1] if "--precision" in sys.argv else "bf16x3"
     opt = edict(dict(device="cuda", H=224, W=224, arch=dict(win_size=16), data=dict(dataset_test="synthetic"),
                      eval=dict(vox_res=128, range=[-1.5, 1.5], num_points=10000, icp=False, brute_force=True,
                                f_thresholds=[0.005, 0.01, 0.02, 0.05, 0.1, 0.2])))
@@ -69,7 +70,7 @@ def main():
     E.eval_metrics(opt, v2, net)
     t5 = sync()
     print(json.dumps({
-        "setting": "vox_res=128, brute_force, batch 1, 10000 points",
+        "setting": "vox_res=128, brute_force, batch 1, 10000 points", "decoder_precision": net.precision,
         "grid_query_ms": round((t1 - t0) * 1e3, 2), "marching_cubes_and_sampling_ms": round((t2 - t1) * 1e3, 2),
         "n_triangles": int(len(meshes[0].faces)), "brute_force_ms": round((t3 - t2) * 1e3, 2),
         "brute_force_rotations_evaluated": n_eval_far, "brute_force_best_cd": float(out[6]),
