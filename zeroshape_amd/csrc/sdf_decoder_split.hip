@@ -7,7 +7,7 @@
 //     A B  ~=  A_hi B_hi + A_hi B_lo + A_lo B_hi          (fp32 accumulation; A_lo B_lo dropped)
 // 3 MFMAs of 32 cycles per K = 16 instead of 8 fp32 MFMAs of 64 cycles: 5.3x fewer matrix
 // cycles at ~2^-17 relative operand error (measured on the oracle: max |logit error| 1.6e-5
-// against 1e-6 for fp32 - inside the 1e-4 contract; tests/test_gpu_decoder.py).
+// against 1e-6 for fp32 - inside the 1e-4 contract; tests/test_gpu_decoder_split.py).
 //
 // What changes against the fp32 kernel, and why:
 //  * The transposed chain survives: accumulator registers 8j..8j+7 of a 32x32 output tile are,
@@ -87,14 +87,12 @@ static_assert(PB_LN2G <= PRM_WINDOW && P_BLK_STRIDE - PB_LN2G <= PRM_WINDOW && W
               "params windows");
 
 #define DEV __device__ __forceinline__
+
 // pin(ahi, alo): the prefetch reads issued above stay above (memory clobber) and the MFMAs that
 // consume this K-block's A operand stay below (they read the statement's outputs).  Without it
 // hipcc hoists MFMAs over the prefetch or sinks the prefetch down to its first use as soon as
 // independent VALU work is around - either way the LDS latency is exposed at every K-block.
-typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void pin(u32x4_ &a, u32x4_ &b) {
-    asm volatile("" : "+v"(a), "+v"(b) : : "memory");
-}
+DEV void pin(u32x4 &a, u32x4 &b) { asm volatile("" : "+v"(a), "+v"(b) : : "memory"); }
 
 DEV bf16x8 as_bf(const u32x4 &v) { return __builtin_bit_cast(bf16x8, v); }
 DEV unsigned pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32 (round to nearest even)
@@ -132,7 +130,7 @@ DEV PT pack_tile(const T &x) {
 // One K-block (hi and lo halves, 2 x 64 lanes x 16 B): global -> LDS[lds_dst + 16 lane (+ 1024)].
 // The instruction offset moves the global and the LDS address alike.  M0 (the LDS-DMA destination
 // base) is not saved: hipcc has no use for it in this kernel (no LDS-direct, GWS, movrel or
-// interpolation instructions; the only m0 references in the ISA are these).
+// interpolation instructions; tools/check_split_isa.py audits the ISA for it).
 DEV void glds_kblock(const char *gsrc, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                  "\n\tglobal_load_lds_dwordx4 %0, off offset:1024"
