@@ -13,18 +13,18 @@ occupancy grids on every rank (zeroshape_amd/parallel.py).  N = 1: one image, on
 time.  Weights: seeded random (no checkpoint ships with the reference); latent_depth:
 seeded N(0,1).
 
---precision selects the decoder arithmetic: "bf16x3" (default; split-bf16 on the bf16 matrix pipe,
-csrc/sdf_decoder_split.hip: max |logit error| ~2e-5 against the fp32 reference, inside the 1e-4
-contract of BASELINE.json and two bf16 mantissas wide where BASELINE's own config names bf16) or
-"f32" (exact-fp32 MFMA, csrc/sdf_decoder.hip).
+--precision selects the decoder arithmetic: "f16x3" (default; split-fp16 on the 16-bit matrix pipe,
+csrc/sdf_decoder_split.hip: operands carried as two fp16 halves, ~2^-21 relative; max |logit
+difference| to the exact-fp32 kernel ~3e-6 with no occupancy flip on the 129^3 grid - BASELINE.json's
+contract is 1e-4 and its own config names bf16) or "f32" (exact-fp32 MFMA, csrc/sdf_decoder.hip).
 
 Extra objects on the JSON line:
-  roofline     - the fused decoder kernel against the dense MFMA peak of its dtype (bf16 2,500 /
+  roofline     - the fused decoder kernel against the dense MFMA peak of its dtype (fp16/bf16 2,500 /
                  fp32 157.3 TFLOP/s, MI355X_MICROARCH.md): ALGORITHMIC 5.00 MFLOP/point (SURVEY.md
                  section 8d) x points per launch / mean launch duration from HIP events on the launch
-                 stream.  For bf16x3 every algorithmic product costs three bf16 MFMAs; the executed
+                 stream.  For f16x3 every algorithmic product costs three fp16 MFMAs; the executed
                  matrix rate is reported beside it (`executed`).
-  exact_f32    - (bf16x3 runs, N = 1) the same grid through the exact-fp32 kernel, outside the
+  exact_f32    - (f16x3 runs, N = 1) the same grid through the exact-fp32 kernel, outside the
                  timed region: its rate, its roofline fraction, and the largest |logit| difference
                  and the occupancy flips between the two arithmetics on the full grid.
   cpu_baseline - the oracle (torch-CPU fp32 restatement of the reference, "port") timed on
@@ -44,14 +44,14 @@ VOX_RES = 128
 RANGE = (-1.5, 1.5)
 FLOP_PER_POINT = 5.00e6          # SURVEY.md section 8d (algorithmic, fp32 reference)
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact f32
-PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
+PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_{f16,bf16}, dense
 # matrix work the kernels really execute per point (197 -> 224 latent padding included):
 EXEC_FLOP_PER_POINT = {"f32": 39424 * 4096 / 32.0,        # 39,424 MFMAs of 32x32x2 per 32 points
-                       "bf16x3": 14784 * 32768 / 32.0}    # 14,784 MFMAs of 32x32x16 per 32 points
+                       "f16x3": 14784 * 32768 / 32.0}    # 14,784 MFMAs of 32x32x16 per 32 points
 # HBM-side bytes per 129^3 launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the
 # gfx950 correction + WRITE_SIZE; profiles/README.md)
 TRAFFIC = {"f32": (1.88e10, "profiles/r01_v3_decoder_rocprofv3_summary.txt"),
-           "bf16x3": (1.84e10, "profiles/r01_split_decoder_rocprofv3_summary.txt")}
+           "f16x3": (1.84e10, "profiles/r01_split_decoder_rocprofv3_summary.txt")}
 
 
 def main():
@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--vox-res", type=int, default=VOX_RES)
-    ap.add_argument("--precision", choices=("bf16x3", "f32"), default="bf16x3")
+    ap.add_argument("--precision", choices=("f16x3", "f32"), default="f16x3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -151,12 +151,12 @@ def main():
 
     def roofline_of(precision, kern_ms):
         mean = sum(kern_ms) / len(kern_ms)
-        peak = PEAK_BF16_MFMA_TFLOPS if precision == "bf16x3" else PEAK_F32_MFMA_TFLOPS
+        peak = PEAK_F16_MFMA_TFLOPS if precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
         achieved = pts_launch * FLOP_PER_POINT / (mean * 1e-3) / 1e12
         executed = pts_launch * EXEC_FLOP_PER_POINT[precision] / (mean * 1e-3) / 1e12
         traffic, src = TRAFFIC[precision] if (N == 128 and world == 1) else (None, None)
         return {"bound": "mfma",
-                "kernel": "sdf_decode_split_kernel<GRID>" if precision == "bf16x3" else "sdf_decode_kernel<GRID>",
+                "kernel": "sdf_decode_split_kernel<GRID>" if precision == "f16x3" else "sdf_decode_kernel<GRID>",
                 "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4),
                 "executed": round(executed, 3), "executed_frac": round(executed / peak, 4),
@@ -168,7 +168,7 @@ def main():
     roofline = roofline_of(args.precision, kern_ms)
 
     exact_f32 = None
-    if args.precision == "bf16x3" and world == 1:
+    if args.precision == "f16x3" and world == 1:
         ms32, st32 = time_launches("f32", 3)
         r32 = roofline_of("f32", ms32)
         lg = net.query_grid(latent, axis, apply_sigmoid=False, state=st)

@@ -141,10 +141,11 @@ int zs_sdf_query_grid(const void *programs, size_t program_stride_bytes, int bat
                       const float *axis, int G, int slice_begin, int slice_end,
                       int apply_sigmoid, float *out, void *workspace, void *stream);
 
-/* Split-bf16 ("bf16x3") decoder: the same network with every contraction on the bf16 matrix
- * pipe, both operands split into two bf16 halves (A B ~= Ah Bh + Ah Bl + Al Bh, fp32
- * accumulation): ~2^-17 relative operand error, max |logit error| ~2e-5 against the fp32
- * reference (contract 1e-4), several times the throughput of the exact-fp32 kernels above.
+/* Split-fp16 ("f16x3") decoder: the same network with every contraction on the 16-bit matrix
+ * pipe, both operands split into two fp16 halves (A B ~= Ah Bh + Ah Bl + Al Bh, fp32
+ * accumulation; halves rounded toward zero, saturating at +-65504, i.e. |x| <= 131008 and
+ * ~2^-21 relative operand error): max |logit difference| to the exact-fp32 kernels ~3e-6
+ * (contract 1e-4), 2.6x their throughput.
  *   zs_sdf_split_programs     fp32 programs (after zs_sdf_prologue) -> split programs of the
  *                             same size and stride rules (split_programs must not alias programs)
  *   zs_sdf_query_points_split / zs_sdf_query_grid_split

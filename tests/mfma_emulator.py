@@ -88,14 +88,14 @@ def softplus100(x):
 
 
 class SplitStream(object):
-    """The split-bf16 program (zeroshape_amd.program.split_program) consumed K-block by K-block in
+    """The split-fp16 program (zeroshape_amd.program.split_program) consumed K-block by K-block in
     the order csrc/sdf_decoder_split.hip consumes it."""
     split = True
 
     def __init__(self, words):
         n = P.REC_FLOATS // P.KB_WORDS
         h = np.ascontiguousarray(words[:n * P.KB_WORDS]).view(np.uint16).reshape(n, 2, 64, 8)
-        self.kb = (h.astype(np.uint32) << 16).view(np.float32).astype(np.float64)   # [kb][hi|lo][lane][e]
+        self.kb = h.view(np.float16).astype(np.float64)                            # [kb][hi|lo][lane][e]
         self.pos = 0
 
     def next_kblock(self):
@@ -104,9 +104,9 @@ class SplitStream(object):
         return a[0], a[1]
 
 
-def _split_bf16(x):
-    _, hi = P.bf16_rne(x.astype(np.float32))
-    _, lo = P.bf16_rne(x.astype(np.float32) - hi)
+def _split_f16(x):
+    _, hi = P.f16_rtz(x.astype(np.float32))
+    _, lo = P.f16_rtz(x.astype(np.float32) - hi)
     return hi.astype(np.float64), lo.astype(np.float64)
 
 
@@ -126,7 +126,7 @@ def gemm_tile_split(stream, X, acc):
     for kt in range(len(X)):
         for j in range(2):
             ahi, alo = stream.next_kblock()
-            bhi, blo = _split_bf16(X[kt][8 * j:8 * j + 8].T)        # [lane][e]
+            bhi, blo = _split_f16(X[kt][8 * j:8 * j + 8].T)        # [lane][e]
             mfma16(alo, bhi, acc)
             mfma16(ahi, blo, acc)
             mfma16(ahi, bhi, acc)

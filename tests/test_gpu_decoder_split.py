@@ -1,9 +1,10 @@
-"""GPU parity of the split-bf16 ("bf16x3") decoder (csrc/sdf_decoder_split.hip, through the C
+"""GPU parity of the split-fp16 ("f16x3") decoder (csrc/sdf_decoder_split.hip, through the C
 ABI) against the oracle, the goldens of the real reference and the exact-fp32 kernel.
 
-Bar (BASELINE.json north_star): logits / occupancy within 1e-4 absolute.  Split-bf16 carries
-~2^-17 relative operand error through ~25 dependent stages: measured max |logit error| ~2e-5;
-asserted at 6e-5.  Occupancy indices (occ > 0.5) must agree outside |logit| < BAND."""
+Bar (BASELINE.json north_star): logits / occupancy within 1e-4 absolute.  Split-fp16 carries
+~2^-21 relative operand error through ~25 dependent stages: measured max |logit difference| to
+the fp32 kernel 3.4e-6 on the 129^3 grid (no occupancy flip); asserted at 1.5e-5.  Occupancy
+indices (occ > 0.5) must agree outside |logit| < BAND."""
 import numpy as np
 import pytest
 import torch
@@ -14,8 +15,8 @@ from zeroshape_amd import synthetic as syn
 
 pytestmark = pytest.mark.gpu
 
-ATOL = 6e-5     # contract 1e-4
-BAND = 6e-5     # |logit| below which an occupancy flip is inside the arithmetic's error
+ATOL = 1.5e-5   # contract 1e-4
+BAND = 1e-5     # |logit| below which an occupancy flip is inside the arithmetic's error
 
 
 @pytest.fixture(scope="module")
@@ -26,15 +27,15 @@ def net(seeded_sd):
                  posenc_3D=0, mlp_ratio=syn.MLP_RATIO, skip_in=list(syn.SKIP_IN), pos_perlayer=False)
     m.load_state_dict(seeded_sd, strict=True)
     m = m.cuda().eval()
-    m.precision = "bf16x3"
+    m.precision = "f16x3"
     return m
 
 
 def test_split_program_layout(net, seeded_sd):
     latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=2)).cuda()
     f32 = net.prepare(latent, "f32")
-    sp = net.prepare(latent, "bf16x3")
-    assert sp.precision == "bf16x3" and sp.programs.shape == f32.programs.shape
+    sp = net.prepare(latent, "f16x3")
+    assert sp.precision == "f16x3" and sp.programs.shape == f32.programs.shape
     for b in range(2):
         want = P.split_program(f32.programs[b].cpu().numpy())
         got = sp.programs[b].cpu().numpy().view(np.uint32)
@@ -59,7 +60,7 @@ def test_training_shape_points_vs_golden_and_fp32_kernel(net, decoder_golden):
     np.testing.assert_allclose(lg.cpu().numpy(), decoder_golden["pts4096_logit"], atol=ATOL, rtol=0)
     exact = net.query_points(net.prepare(latent, "f32"), pts)
     err = (lg - exact).abs()
-    assert float(err.max()) < ATOL and float(err.mean()) < 1e-5
+    assert float(err.max()) < ATOL and float(err.mean()) < 2e-6
     # the reference's default call (with the attention map) is served by the fp32 kernel
     lg2, attn = net(latent, None, pts)
     assert torch.equal(lg2, exact) and attn.shape == (2, 4096, 197)
@@ -80,7 +81,7 @@ def test_grid32_full_vs_golden(net, decoder_golden):
     lg = net.query_grid(latent, grid._zs_grid.axis, apply_sigmoid=False)[0].cpu().numpy()
     mism = (occ > 0.5).reshape(-1) != bits
     assert np.all(np.abs(lg.reshape(-1)[mism]) < BAND), "occupancy flip outside the error band"
-    assert mism.sum() <= 4
+    assert mism.sum() <= 2
     for i in (0, 16, 32):
         np.testing.assert_allclose(lg[i].reshape(-1), decoder_golden["logit32_slice%d" % i], atol=ATOL, rtol=0)
 
@@ -126,6 +127,6 @@ def test_batched_grid_equals_per_image(net):
 def test_bad_precision_raises(net):
     with pytest.raises(ValueError):
         net.prepare(torch.zeros(1, 197, 256).cuda(), "fp8")
-    st = net.prepare(torch.zeros(1, 197, 256).cuda(), "bf16x3")
+    st = net.prepare(torch.zeros(1, 197, 256).cuda(), "f16x3")
     with pytest.raises(ValueError):
         net.query_points(st, torch.zeros(1, 4, 3).cuda(), need_attn=True)

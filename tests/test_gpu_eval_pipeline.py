@@ -88,8 +88,8 @@ def test_eval_metrics_bf_runs_and_improves_on_default(net):
     assert float(acc) <= float(acc_d) + 1e-6
 
 
-def test_eval_metrics_split_bf16_decoder_within_contract(net):
-    """The whole evaluation sample with the split-bf16 decoder (bench.py's default arithmetic)
+def test_eval_metrics_split_fp16_decoder_within_contract(net):
+    """The whole evaluation sample with the split-fp16 decoder (bench.py's default arithmetic)
     against the exact-fp32 decoder: Chamfer-L1 / F-score within the 1e-4 contract (occupancy
     differs by ~5e-6, iso-surface vertices move by ~1e-5)."""
     from zeroshape_amd.utils import eval_3D as E
@@ -99,14 +99,14 @@ def test_eval_metrics_split_bf16_decoder_within_contract(net):
     pose = torch.eye(3, 4)[None].repeat(2, 1, 1)
     out = {}
     try:
-        for prec in ("f32", "bf16x3"):
+        for prec in ("f32", "f16x3"):
             net.precision = prec
             var = _var(latent, gt.clone(), pose)
             E.eval_metrics(_opt(N, False, P), var, net)
             out[prec] = var
     finally:
         net.precision = "f32"
-    a, b = out["f32"], out["bf16x3"]
+    a, b = out["f32"], out["f16x3"]
     assert float((a.cd_acc - b.cd_acc).abs().max()) < 1e-4
     assert float((a.cd_comp - b.cd_comp).abs().max()) < 1e-4
     assert float((a.f_score - b.f_score).abs().max()) < 2e-3

@@ -74,12 +74,11 @@ def test_split_stream_order_and_layout():
     W = rs.randn(32, 32).astype(np.float32)
     prog[:1024] = P._interleave(P._records_linear(W, 0, 0))
     words = P.split_program(prog)
-    h = words[:1024].view(np.uint16).reshape(2, 2, 64, 8)
-    val = (h.astype(np.uint32) << 16).view(np.float32)
+    val = words[:1024].view(np.float16).reshape(2, 2, 64, 8).astype(np.float32)
     for j in range(2):
         rec = np.stack([P._records_linear(W, 0, 0)[8 * j + e] for e in range(8)], axis=1)   # [lane][e]
-        np.testing.assert_allclose(val[j, 0] + val[j, 1], rec, rtol=2 ** -16, atol=0)
-        np.testing.assert_allclose(val[j, 0], rec, rtol=2 ** -8, atol=0)
+        np.testing.assert_allclose(val[j, 0] + val[j, 1], rec, rtol=2 ** -20, atol=1e-7)
+        np.testing.assert_allclose(val[j, 0], rec, rtol=2 ** -10, atol=0)
 
 
 def test_split_mfma_emulator_is_a_matmul():
@@ -91,11 +90,11 @@ def test_split_mfma_emulator_is_a_matmul():
     xt = np.stack([X[E.ROWS[r], E.COL] for r in range(16)])
     acc = E.gemm_tile_split(E.SplitStream(P.split_program(prog)), [xt], np.zeros((16, 64)))
     Y = W.astype(np.float64) @ X
-    np.testing.assert_allclose(acc, np.stack([Y[E.ROWS[r], E.COL] for r in range(16)]), atol=5e-4)   # split arithmetic: ~2^-16 relative; a layout error would be O(1)
+    np.testing.assert_allclose(acc, np.stack([Y[E.ROWS[r], E.COL] for r in range(16)]), atol=5e-5)   # split arithmetic: ~2^-20 relative; a layout error would be O(1)
 
 
 def test_emulated_split_kernel_matches_oracle(seeded_sd):
-    """The split-bf16 schedule (permuted MLP stream, K-block operands, hi/lo products) on the CPU:
+    """The split-fp16 schedule (permuted MLP stream, K-block operands, hi/lo products) on the CPU:
     same program the device derives, within the split arithmetic's error of the oracle."""
     sd_np = {k: v.numpy() for k, v in seeded_sd.items()}
     latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=1))
@@ -108,4 +107,4 @@ def test_emulated_split_kernel_matches_oracle(seeded_sd):
     want, _ = R.implicit_forward(seeded_sd, latent, torch.from_numpy(pts))
     got = E.decode_wave(words, P.pack_params(sd_np), pts[0], split=True)
     err = np.abs(got - want[0].numpy().astype(np.float64))
-    assert err.max() < 6e-5, err.max()
+    assert err.max() < 1e-5, err.max()

@@ -1,4 +1,4 @@
-"""The split-bf16 decoder's inline asm relies on facts about hipcc's output (M0 untouched by the
+"""The split-fp16 decoder's inline asm relies on facts about hipcc's output (M0 untouched by the
 compiler, no scratch, VGPR-form MFMAs, raw barriers + LDS-DMA present, all of LDS allocated):
 tools/check_split_isa.py compiles the kernel for gfx950 (no GPU needed) and audits the ISA."""
 import os

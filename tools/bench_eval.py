@@ -27,7 +27,7 @@ def main():
                    skip_in=[2, 4, 6], pos_perlayer=False)
     net.load_state_dict(sd)
     net = net.to(dev).eval()
-    net.precision = sys.argv[sys.argv.index("--precision") + 1] if "--precision" in sys.argv else "bf16x3"
+    net.precision = sys.argv[sys.argv.index("--precision") + 1] if "--precision" in sys.argv else "f16x3"
     opt = edict(dict(device="cuda", H=224, W=224, arch=dict(win_size=16), data=dict(dataset_test="synthetic"),
                      eval=dict(vox_res=128, range=[-1.5, 1.5], num_points=10000, icp=False, brute_force=True,
                                f_thresholds=[0.005, 0.01, 0.02, 0.05, 0.1, 0.2])))

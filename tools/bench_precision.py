@@ -18,7 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--vox", type=int, default=128)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--modes", default="f32,bf16x3")
+    ap.add_argument("--modes", default="f32,f16x3")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     pe = get_2d_sincos_pos_embed(256, 14, cls_token=True).astype(np.float32)
@@ -45,9 +45,9 @@ def main():
         pts = out.numel()
         print(json.dumps({"mode": mode, "vox": a.vox, "points": pts, "ms_min": min(ms), "ms_mean": sum(ms) / len(ms),
                           "points_per_s": pts / (min(ms) * 1e-3), "finite": bool(torch.isfinite(out).all())}), flush=True)
-    if "f32" in outs and "bf16x3" in outs:
-        d = (outs["f32"] - outs["bf16x3"]).abs()
-        flips = (outs["f32"] > 0) != (outs["bf16x3"] > 0)
+    if "f32" in outs and "f16x3" in outs:
+        d = (outs["f32"] - outs["f16x3"]).abs()
+        flips = (outs["f32"] > 0) != (outs["f16x3"] > 0)
         print(json.dumps({"max_abs_diff": float(d.max()), "mean_abs_diff": float(d.mean()), "flips": int(flips.sum()),
                           "max_abs_logit_at_flip": float(outs["f32"][flips].abs().max()) if int(flips.sum()) else 0.0}))
 

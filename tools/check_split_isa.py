@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Audit the ISA of the split-bf16 decoder (csrc/sdf_decoder_split.hip).
+"""Audit the ISA of the split-fp16 decoder (csrc/sdf_decoder_split.hip).
 
 The kernel's LDS-DMA statements write M0 without saving it and count their own vmcnt, so:
   * M0 may only be touched inside ;;#ASMSTART/;;#ASMEND (hipcc must have no use of its own);
   * no scratch traffic / no private segment (a spill would also upset the counted waits);
-  * every MFMA is the VGPR form (-mllvm -amdgpu-mfma-vgpr-form) of v_mfma_f32_32x32x16_bf16,
+  * every MFMA is the VGPR form (-mllvm -amdgpu-mfma-vgpr-form) of v_mfma_f32_32x32x16_f16,
     14,784 / 3 K-blocks are not checked here - the instruction counters in profiles/ are;
   * each decode kernel carries LDS-DMAs and raw barriers, and allocates all 160 KiB of LDS.
 
@@ -64,7 +64,7 @@ def check(path):
             errors.append("%d: scratch traffic: %s" % (no, l))
         if l.startswith("v_mfma"):
             st["mfma"] += 1
-            if not re.match(r"v_mfma_f32_32x32x16_bf16 v\[\d+:\d+\], [va]\[\d+:\d+\], [va]\[\d+:\d+\], (v\[\d+:\d+\]|0)", l):
+            if not re.match(r"v_mfma_f32_32x32x16_f16 v\[\d+:\d+\], [va]\[\d+:\d+\], [va]\[\d+:\d+\], (v\[\d+:\d+\]|0)", l):
                 errors.append("%d: unexpected MFMA form: %s" % (no, l))
         if l.startswith("global_load_lds_dwordx4"):
             st["dma"] += 1

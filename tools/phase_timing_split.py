@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-phase cycle stamps of the split-bf16 decoder (block 0, wave 0, first tile of a full
+"""Per-phase cycle stamps of the split-fp16 decoder (block 0, wave 0, first tile of a full
 129^3 launch).  Build csrc/sdf_decoder_split.hip with -DZS_EXP_TIMING into a side library and
 run with ZS_LIB_PATH pointing at it."""
 import os, sys
@@ -15,7 +15,7 @@ net = Implicit(196, latent_dim=256, n_channels=256, n_blocks_attn=2, n_layers_ml
 net.load_state_dict(sd); net = net.to(dev).eval()
 lat = torch.from_numpy(syn.seeded_latent(0, 1)).to(dev)
 axis = torch.linspace(-1.5, 1.5, 129, device=dev)
-st = net.prepare(lat, "bf16x3")
+st = net.prepare(lat, "f16x3")
 for _ in range(2):
     net.query_grid(lat, axis, state=st)
 torch.cuda.synchronize()

@@ -1,6 +1,6 @@
-// Micro-benchmark for the split-bf16 decoder's inner loop: what does one wave per SIMD sustain with
+// Micro-benchmark for the split-fp16 decoder's inner loop: what does one wave per SIMD sustain with
 // v_mfma_f32_32x32x16_bf16 under the loop shapes of csrc/sdf_decoder_split.hip?
-//   hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form -o mfma_bf16_stream mfma_bf16_stream.hip
+//   hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form -o mfma_f16_stream mfma_f16_stream.hip
 // Reports shader cycles (s_memtime) per K-block of 3 MFMAs (ideal 96) for wave 0 of block 0, all
 // 256 CUs busy.
 #include <hip/hip_runtime.h>

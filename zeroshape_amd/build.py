@@ -25,7 +25,7 @@ EXTRA = {
     # on gfx950 and costs extra v_mov: off)
     "chamfer.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
     "chamfer_grid.hip": ["-ffp-contract=off"],
-    # packed f32 VALU ops beside bf16 MFMAs cost more than the scalar forms they replace
+    # packed f32 VALU ops beside 16-bit MFMAs cost more than the scalar forms they replace
     # ... and MFMA accumulators in VGPRs: the activation code reads and writes them in place
     # (with AGPR accumulators every tile paid 32 v_accvgpr moves; 484 -> 352 registers)
     "sdf_decoder_split.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"],

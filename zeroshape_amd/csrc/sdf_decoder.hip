@@ -389,7 +389,7 @@ DEV void layer_norm_reg(const f32x16 *x, float *h, const float *prm, int g_off, 
 // fewest instructions that still sit 2+ orders of magnitude inside the 1e-4 contract;
 // tests/test_device_math.py checks the same formulas against fp64 on the host.
 
-// gelu_erf / softplus100: csrc/sdf_math.h (shared with the split-bf16 decoder)
+// gelu_erf / softplus100: csrc/sdf_math.h (shared with the split-fp16 decoder)
 using zs::dm::gelu_erf;
 using zs::dm::softplus100;
 

@@ -1,17 +1,21 @@
-// Split-bf16 ("bf16x3") variant of the fused implicit-occupancy decoder for MI355X (gfx950).
+// Split-fp16 ("f16x3") variant of the fused implicit-occupancy decoder for MI355X (gfx950).
 //
 // Same algorithm, same per-point dataflow and the same decoder program as csrc/sdf_decoder.hip
 // (Implicit.forward, model/shape/implicit.py:251-288, hoisted latent half in the prologue), but
-// every contraction runs on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the rate of the
-// fp32 MFMA) with both operands split into two bf16 halves, x = hi + lo:
+// every contraction runs on the 16-bit matrix pipe (v_mfma_f32_32x32x16_f16, 16x the rate of the
+// fp32 MFMA) with both operands split into two fp16 halves, x ~= hi + lo:
 //     A B  ~=  A_hi B_hi + A_hi B_lo + A_lo B_hi          (fp32 accumulation; A_lo B_lo dropped)
 // 3 MFMAs of 32 cycles per K = 16 instead of 8 fp32 MFMAs of 64 cycles: 5.3x fewer matrix
-// cycles at ~2^-17 relative operand error (measured on the oracle: max |logit error| 1.6e-5
-// against 1e-6 for fp32 - inside the 1e-4 contract; tests/test_gpu_decoder_split.py).
+// cycles at ~2^-21 relative operand error: max |logit difference| to the fp32 kernel 3.4e-6 and
+// no occupancy flip on the 129^3 grid (fp32 itself is 1e-6 from fp64; the same scheme on bf16
+// halves, same cost, measured 1.9e-5 and 10 flips; plain bf16 8e-3).  Halves are rounded toward
+// zero (v_cvt_pkrtz_f16_f32), which also saturates instead of overflowing: |x| <= 131,008 is
+// representable, far beyond what LayerNorm-ed activations and these weights reach; values below
+// ~1e-4 lose relative (not absolute) precision to fp16 subnormals.  tests/test_gpu_decoder_split.py.
 //
 // What changes against the fp32 kernel, and why:
 //  * The transposed chain survives: accumulator registers 8j..8j+7 of a 32x32 output tile are,
-//    after a split into packed (hi, lo) bf16 pairs, exactly the B operand of K-block j of the
+//    after a split into packed (hi, lo) fp16 pairs, exactly the B operand of K-block j of the
 //    next layer.  The matching A operand of K-block j of a 32x32 weight unit is the fp32
 //    program's records 8j..8j+7 of that unit, split the same way - so the split program has the
 //    SAME unit order and byte size as the fp32 one and is derived from it on the device
@@ -51,8 +55,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int WAVES = 4;
 constexpr int PTS_PER_WAVE = 32;
@@ -94,17 +97,19 @@ static_assert(PB_LN2G <= PRM_WINDOW && P_BLK_STRIDE - PB_LN2G <= PRM_WINDOW && W
 // independent VALU work is around - either way the LDS latency is exposed at every K-block.
 DEV void pin(u32x4 &a, u32x4 &b) { asm volatile("" : "+v"(a), "+v"(b) : : "memory"); }
 
-DEV bf16x8 as_bf(const u32x4 &v) { return __builtin_bit_cast(bf16x8, v); }
-DEV unsigned pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32 (round to nearest even)
-    const f32x2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+DEV f16x8 as_h(const u32x4 &v) { return __builtin_bit_cast(f16x8, v); }
+DEV unsigned pk_f16(float a, float b) {  // v_cvt_pkrtz_f16_f32: toward zero, saturating at +-65504
+    return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
 }
-// two fp32 values -> packed bf16 heads and packed bf16 remainders (x - hi is exact in fp32)
+// two fp32 values -> packed fp16 heads and packed fp16 remainders: x ~= hi + lo to ~2^-21.
+// The remainder x - hi comes from one v_fma_mix_f32 per value (fp16 operand read in place from
+// the packed register, exact in fp32): 2 VALU instructions per value.
 DEV void split2(float a, float b, unsigned &h, unsigned &l) {
-    h = pk_bf16(a, b);
-    const float ha = __builtin_bit_cast(float, h << 16);
-    const float hb = __builtin_bit_cast(float, h & 0xffff0000u);
-    l = pk_bf16(a - ha, b - hb);
+    h = pk_f16(a, b);
+    float ra, rb;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(h), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(h), "v"(b));
+    l = pk_f16(ra, rb);
 }
 
 // a 32-feature x 32-point activation tile as the B operands of its two K-blocks:
@@ -145,7 +150,7 @@ DEV void glds_kblock(const char *gsrc, unsigned lds_dst) {
 // A operand is already in registers): own share of chunk c+1 landed (counted vmcnt: only the two
 // DMAs of chunk c+2 may remain) and own reads of chunk c retired -> s_barrier -> chunk c+3 is
 // staged into the buffer just freed and the first A read of chunk c+1 is issued.
-// tools/ubench/mfma_bf16_stream.hip prices the pieces (cycles per K-block of 3 MFMAs, one wave
+// tools/ubench/mfma_f16_stream.hip prices the pieces (cycles per K-block of 3 MFMAs, one wave
 // per SIMD, all CUs busy): MFMAs alone 96.1; + two ds_read_b128 105.5; + the barrier every four
 // K-blocks 124.1 (~74 cycles per barrier: the skew of four waves); + the LDS-DMA 131.6; + two
 // more ds_read_b128 for B operands from the slab 143.6.
@@ -210,13 +215,13 @@ struct AStream {
     DEV void drain() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 };
 
-// One K-block: three dependent MFMAs on one accumulator.  A dependent v_mfma_f32_32x32x16_bf16
-// issues 32 cycles behind its producer (tools/ubench/mfma_bf16_stream.hip: one chain and two
+// One K-block: three dependent MFMAs on one accumulator.  A dependent v_mfma_f32_32x32x16_f16
+// issues 32 cycles behind its producer (tools/ubench/mfma_f16_stream.hip: one chain and two
 // alternating chains both run 96.1 cycles per K-block), so a second chain buys nothing.
 DEV void mfma3(f32x16 &acc, const u32x4 &ahi, const u32x4 &alo, const u32x4 &bhi, const u32x4 &blo) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(alo), as_bf(bhi), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(ahi), as_bf(blo), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(ahi), as_bf(bhi), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(alo), as_h(bhi), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(ahi), as_h(blo), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(ahi), as_h(bhi), acc, 0, 0, 0);
 }
 DEV f32x16 zero16() {
     f32x16 v;
@@ -796,7 +801,7 @@ __host__ __device__ inline int split_source_kblock(int kb) {
 }
 
 // fp32 decoder program -> split program: same units and size; K-block j of a unit holds
-// records 8 j .. 8 j + 7 of that unit as [hi: lane x 8 bf16][lo: lane x 8 bf16]; params copied.
+// records 8 j .. 8 j + 7 of that unit as [hi: lane x 8 fp16][lo: lane x 8 fp16]; params copied.
 __global__ __launch_bounds__(256) void split_program_kernel(const float *__restrict__ src,
                                                             size_t src_stride_floats,
                                                             u32x4 *__restrict__ dst,

@@ -118,9 +118,9 @@ class Implicit(nn.Module):
         self.initialize_weights()
         self._packed = None       # (key, template programs tensor, lat_params tensor)
         # arithmetic of the fused inference kernels: "f32" = exact fp32 MFMA (bitwise an fmaf
-        # chain); "bf16x3" = split-bf16 on the bf16 matrix pipe (csrc/sdf_decoder_split.hip:
-        # |logit error| ~2e-5 against fp32, contract 1e-4, several times faster).  The attention
-        # map and the training path always use fp32.
+        # chain); "f16x3" = split-fp16 on the 16-bit matrix pipe (csrc/sdf_decoder_split.hip:
+        # |logit difference| ~3e-6 to the fp32 kernel, contract 1e-4, 2.6x faster; operands
+        # saturate at |x| = 131008).  The attention map and the training path always use fp32.
         self.precision = os.environ.get("ZS_DECODER_PRECISION", "f32")
         self._workspace = {}      # device -> scratch tensor for the query kernels
 
@@ -180,8 +180,8 @@ class Implicit(nn.Module):
         """Per-image prologue: latent_depth [B,197,C] (any float dtype, GPU) -> DecoderState.
         ``precision``: None = self.precision."""
         precision = self.precision if precision is None else precision
-        if precision not in ("f32", "bf16x3"):
-            raise ValueError("decoder precision must be 'f32' or 'bf16x3', got %r" % (precision,))
+        if precision not in ("f32", "f16x3"):
+            raise ValueError("decoder precision must be 'f32' or 'f16x3', got %r" % (precision,))
         if not latent_depth.is_cuda:
             raise ValueError("latent_depth must be a GPU tensor; zeroshape_amd has no CPU path")
         lib = _lib.load()
@@ -199,13 +199,13 @@ class Implicit(nn.Module):
                                      _lib.ptr(lat), B, _lib.ptr(scratch),
                                      _lib.current_stream_ptr(lat.device))
         _lib.check(rc, "zs_sdf_prologue")
-        if precision == "bf16x3":
+        if precision == "f16x3":
             split = torch.empty_like(programs)
             with torch.cuda.device(lat.device):
                 rc = lib.zs_sdf_split_programs(_lib.ptr(programs), programs.stride(0) * 4, _lib.ptr(split),
                                                split.stride(0) * 4, B, _lib.current_stream_ptr(lat.device))
             _lib.check(rc, "zs_sdf_split_programs")
-            return DecoderState(split, B, "bf16x3")
+            return DecoderState(split, B, "f16x3")
         return DecoderState(programs, B)
 
     @torch.no_grad()
@@ -221,7 +221,7 @@ class Implicit(nn.Module):
         M = pts.shape[1]
         out = torch.empty(state.batch, M, dtype=torch.float32, device=pts.device)
         attn, extra = None, 0
-        if state.precision == "bf16x3":
+        if state.precision == "f16x3":
             if need_attn:
                 raise ValueError("the attention map needs an fp32 DecoderState (prepare(..., precision='f32'))")
             with torch.cuda.device(pts.device):
@@ -258,7 +258,7 @@ class Implicit(nn.Module):
         slice_end = G if slice_end is None else slice_end
         out = torch.empty(state.batch, slice_end - slice_begin, G, G, dtype=torch.float32,
                           device=axis.device)
-        if state.precision == "bf16x3":
+        if state.precision == "f16x3":
             with torch.cuda.device(axis.device):
                 rc = lib.zs_sdf_query_grid_split(_lib.ptr(state.programs), state.stride_bytes, state.batch,
                                                  _lib.ptr(axis), G, slice_begin, slice_end,

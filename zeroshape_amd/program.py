@@ -353,10 +353,10 @@ SCRATCH_FLOATS = LPAD * (3 * C + 3 * C + C + HID + 2 * C)
 
 
 # ----------------------------------------------------------------------------- #
-# split-bf16 program (csrc/sdf_decoder_split.hip) - host mirror of zs_sdf_split_programs
+# split-fp16 program (csrc/sdf_decoder_split.hip) - host mirror of zs_sdf_split_programs
 # ----------------------------------------------------------------------------- #
-# One K-block (K = 16, three bf16 MFMAs) = two fp32 groups = records 8j..8j+7 of a 32x32 weight
-# unit; per lane [hi: 8 bf16][lo: 8 bf16] with x = hi + lo.  Same units and byte size as the fp32
+# One K-block (K = 16, three fp16 MFMAs) = two fp32 groups = records 8j..8j+7 of a 32x32 weight
+# unit; per lane [hi: 8 fp16][lo: 8 fp16] with x ~= hi + lo (both rounded toward zero).  Same units and byte size as the fp32
 # program; the product derives it on the device, this mirror exists for tests and documentation.
 KB_TOTAL = G_TOTAL // 2                 # 4,928 K-blocks per wave tile
 KB_WORDS = 512                          # 32-bit words per K-block (2 x 64 lanes x 16 B)
@@ -380,11 +380,15 @@ def split_source_kblocks(n=None):
     return src
 
 
-def bf16_rne(x):
-    """fp32 -> bf16 (round to nearest even): (uint16 bits, value as fp32)."""
-    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
-    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32)
-    return r.astype(np.uint16), (r << 16).astype(np.uint32).view(np.float32)
+def f16_rtz(x):
+    """fp32 -> fp16 rounded toward zero, saturating at +-65504 (v_cvt_pkrtz_f16_f32):
+    (uint16 bits, value as fp32)."""
+    x = np.ascontiguousarray(x, np.float32)
+    with np.errstate(over="ignore"):
+        h = x.astype(np.float16)
+    away = np.abs(h.astype(np.float32)) > np.abs(x)          # rounded away from zero (or to inf)
+    h = np.where(away, np.nextafter(h, np.float16(0)), h).astype(np.float16)
+    return h.view(np.uint16), h.astype(np.float32)
 
 
 def split_program(prog):
@@ -394,8 +398,8 @@ def split_program(prog):
     rec = prog[:REC_FLOATS].reshape(-1, 2, 64, 4)                  # [kb][group][lane][j]
     rec = rec[split_source_kblocks(rec.shape[0])]
     vals = rec.transpose(0, 2, 1, 3).reshape(-1, 64, 8)             # [kb][lane][e = 4 g + j]
-    hi16, hif = bf16_rne(vals)
-    lo16, _ = bf16_rne(vals - hif)
+    hi16, hif = f16_rtz(vals)
+    lo16, _ = f16_rtz(vals - hif)
     out = np.stack([hi16, lo16], axis=1)                            # [kb][hi | lo][lane][8]
     words = np.ascontiguousarray(out).reshape(-1).view(np.uint32)
     return np.concatenate([words, prog[REC_FLOATS:].view(np.uint32)])
