@@ -4,9 +4,10 @@
 The kernel's LDS-DMA statements write M0 without saving it and count their own vmcnt, so:
   * M0 may only be touched inside ;;#ASMSTART/;;#ASMEND (hipcc must have no use of its own);
   * no scratch traffic / no private segment (a spill would also upset the counted waits);
-  * every MFMA is the VGPR form (-mllvm -amdgpu-mfma-vgpr-form) of v_mfma_f32_32x32x16_f16,
-    14,784 / 3 K-blocks are not checked here - the instruction counters in profiles/ are;
-  * each decode kernel carries LDS-DMAs and raw barriers, and allocates all 160 KiB of LDS.
+  * every MFMA is a v_mfma_f32_32x32x16_f16 accumulating in place (the VGPR form where the
+    registers allow, -mllvm -amdgpu-mfma-vgpr-form); the dynamic count (14,784 per wave tile) is
+    in the instruction counters of profiles/;
+  * each decode kernel carries LDS-DMAs and raw barriers, and allocates 152 KiB of LDS.
 
     python tools/check_split_isa.py            (compiles with the flags of zeroshape_amd/build.py)
 """
@@ -64,7 +65,7 @@ def check(path):
             errors.append("%d: scratch traffic: %s" % (no, l))
         if l.startswith("v_mfma"):
             st["mfma"] += 1
-            if not re.match(r"v_mfma_f32_32x32x16_f16 v\[\d+:\d+\], [va]\[\d+:\d+\], [va]\[\d+:\d+\], (v\[\d+:\d+\]|0)", l):
+            if not re.match(r"v_mfma_f32_32x32x16_f16 ([va])\[\d+:\d+\], [va]\[\d+:\d+\], [va]\[\d+:\d+\], (\1\[\d+:\d+\]|0)", l):
                 errors.append("%d: unexpected MFMA form: %s" % (no, l))
         if l.startswith("global_load_lds_dwordx4"):
             st["dma"] += 1
@@ -75,8 +76,8 @@ def check(path):
     if len(stats) != 2:
         errors.append("expected the <GRID> and the point-list kernels, found %s" % list(stats))
     for k, st in stats.items():
-        if st["lds"] != 160 * 1024:
-            errors.append("%s: LDS %s, expected 163840" % (k, st["lds"]))
+        if st["lds"] != 152 * 1024:
+            errors.append("%s: LDS %s, expected 155648" % (k, st["lds"]))
         if st["private"] != 0:
             errors.append("%s: private segment %s" % (k, st["private"]))
         if not (st["mfma"] and st["dma"] and st["barrier"]):

@@ -22,14 +22,15 @@
 //    (split_program_kernel), K/V records of the image included.
 //  * Weight stream.  At this rate four waves streaming private copies of the 10 MB program would
 //    pull ~50 TB/s through the vector memory path (64 B/clk/CU, L2 34 TB/s).  The four waves of a
-//    workgroup run the same program in lock step, so each 8 KiB chunk (4 K-blocks) is staged ONCE
-//    per workgroup into LDS by LDS-DMA (global_load_lds_dwordx4, one K-block per wave, three
+//    workgroup run the same program in lock step, so each 16 KiB chunk (8 K-blocks) is staged ONCE
+//    per workgroup into LDS by LDS-DMA (global_load_lds_dwordx4, two K-blocks per wave, two
 //    buffers) and read back as A operands with conflict-free ds_read_b128 by all four waves.
 //    One raw s_barrier per chunk (AStream below).  Ordering rules: cdna_hip_programming.md
 //    section 5 (counted vmcnt by the issuing wave, then a barrier the reader has passed; restage
 //    after an lgkmcnt-retired read + barrier).
-//  * LDS: [params window 8 KiB][A staging 3 x 8 KiB][4 x 32 KiB activation slabs] = 160 KiB.
-//    Params are paged in nine windows per tile instead of two.
+//  * LDS: [params window 8 KiB][A staging 2 x 16 KiB][4 x 28 KiB activation slabs] = 152 KiB
+//    (tile 7 of a slab-resident array lives in registers).  Params are paged in nine windows
+//    per tile instead of two.
 //  * No asm register ring: LDS reads and MFMAs are builtins, scheduled and hazard-padded by
 //    hipcc (VGPR-form accumulators: -mllvm -amdgpu-mfma-vgpr-form, zeroshape_amd/build.py); only
 //    the DMA, the barrier and the prefetch pin are asm.
@@ -44,6 +45,7 @@
 
 #include <math.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace {
 
@@ -62,17 +64,20 @@ constexpr int PTS_PER_WAVE = 32;
 constexpr int PTS_PER_BLOCK = WAVES * PTS_PER_WAVE;
 constexpr int MAX_WGS = 256;                        // one persistent workgroup per CU
 constexpr int KB_U4 = 128;                          // one K-block: [hi: 64 lanes x 16 B][lo: 64 lanes x 16 B]
-constexpr int CK = 4;                               // K-blocks per staged chunk (= WAVES: one per wave)
-constexpr int CHUNK_BYTES = CK * KB_U4 * 16;        // 8 KiB
-constexpr int NBUF = 3;
+constexpr int CK = 8;                               // K-blocks per staged chunk: two per wave
+constexpr int KPW = CK / WAVES;                     // K-blocks a wave stages per chunk
+constexpr int CHUNK_BYTES = CK * KB_U4 * 16;        // 16 KiB
+constexpr int NBUF = 2;
 constexpr int KB_TOTAL = G_TOTAL / 2;               // 4,928 K-blocks = 14,784 MFMAs per wave tile
 constexpr int PRM_WINDOW = 2048;                    // floats of params resident in LDS at a time
 constexpr int STAGE_FLOATS = NBUF * CHUNK_BYTES / 4;
-constexpr int SLAB_U4 = NT * 4 * 64;                // one activation array as packed (hi, lo) K-blocks: 32 KiB
-constexpr int ZSLAB_F4 = 3 * SLAB_U4;               // fp32 feat partial products of the three skip layers
+constexpr int SLAB_TILES = NT - 1;                  // tiles of an activation array kept in LDS (the last: registers)
+constexpr int SLAB_U4 = SLAB_TILES * 4 * 64;        // ... as packed (hi, lo) K-blocks: 28 KiB per wave
+constexpr int ZTILES_F4 = NT * 4 * 64;              // one skip layer's fp32 feat partial products (workspace)
+constexpr int ZSLAB_F4 = 3 * ZTILES_F4;
 constexpr int LDS_FLOATS = PRM_WINDOW + STAGE_FLOATS + WAVES * SLAB_U4 * 4;
-static_assert(LDS_FLOATS * 4 == 160 * 1024, "the kernel owns the whole LDS of a CU");
-static_assert(KB_TOTAL % CK == 0 && CK == WAVES, "chunking");
+static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS of a CU");
+static_assert(KB_TOTAL % CK == 0 && CK % WAVES == 0 && KPW * 2048 <= 4096, "chunking");
 // the stream prefetches NBUF chunks past its position: the last reads run into the zero tail of
 // the records and (harmlessly) the params section behind it
 static_assert((RING * GROUP_FLOATS + PARAM_FLOATS) * 4 >= NBUF * CHUNK_BYTES, "prefetch stays inside the program");
@@ -136,54 +141,57 @@ DEV PT pack_tile(const T &x) {
 // The instruction offset moves the global and the LDS address alike.  M0 (the LDS-DMA destination
 // base) is not saved: hipcc has no use for it in this kernel (no LDS-direct, GWS, movrel or
 // interpolation instructions; tools/check_split_isa.py audits the ISA for it).
-DEV void glds_kblock(const char *gsrc, unsigned lds_dst) {
+DEV void glds_kblocks(const char *gsrc, unsigned lds_dst) {  // this wave's two K-blocks of a chunk
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                  "\n\tglobal_load_lds_dwordx4 %0, off offset:1024"
+                 "\n\tglobal_load_lds_dwordx4 %0, off offset:2048"
+                 "\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
                  :
                  : "v"(gsrc), "s"(lds_dst)
                  : "memory");
 }
 
 // ---- weight stream: LDS-DMA staged chunks shared by the four waves ------------------ //
-// Three buffers: while chunk c is consumed, chunk c+1 has (nearly) landed and chunk c+2 is in
-// flight.  One synchronisation per chunk, before its LAST K-block is multiplied (that K-block's
-// A operand is already in registers): own share of chunk c+1 landed (counted vmcnt: only the two
-// DMAs of chunk c+2 may remain) and own reads of chunk c retired -> s_barrier -> chunk c+3 is
-// staged into the buffer just freed and the first A read of chunk c+1 is issued.
+// Two buffers of 8 K-blocks: while chunk c is consumed, chunk c+1 lands.  One synchronisation per
+// chunk, before its LAST K-block is multiplied (that K-block's A operand is already in registers):
+// own share of chunk c+1 landed (vmcnt) and own reads of chunk c retired (lgkmcnt) -> s_barrier ->
+// chunk c+2 is staged into the buffer just freed and the first A read of chunk c+1 is issued.
+// Lead time of a chunk: one chunk period = 8 K-blocks.
 // tools/ubench/mfma_f16_stream.hip prices the pieces (cycles per K-block of 3 MFMAs, one wave
-// per SIMD, all CUs busy): MFMAs alone 96.1; + two ds_read_b128 105.5; + the barrier every four
-// K-blocks 124.1 (~74 cycles per barrier: the skew of four waves); + the LDS-DMA 131.6; + two
-// more ds_read_b128 for B operands from the slab 143.6.
-// Measured alternatives on the whole kernel (129^3 grid): two buffers, lead one chunk period:
-// +6 ms (DMA latency exposed at every barrier); register staging (global_load ->
-// ds_write_b128 behind the barrier): +3 ms; the DMAs moved from behind the barrier into the
-// shadows of the first MFMAs of the chunk: +0.5 ms; reads two K-blocks ahead: +0.6 ms; two
-// alternating accumulator chains: +2 ms (extra adds; a single chain already issues back to back).
+// per SIMD, all CUs busy, 4-K-block chunks): MFMAs alone 96.1; + two ds_read_b128 105.5; + the
+// barrier every four K-blocks 124.1 (~74 cycles per barrier: the skew of four waves); + the
+// LDS-DMA 131.6; + two more ds_read_b128 for B operands from the slab 146.9.
+// Measured alternatives on the whole kernel (129^3 grid): 4-K-block chunks: two buffers (lead 4
+// K-blocks) +6 ms - the DMA latency is exposed at every barrier - three buffers the baseline of
+// the 8-K-block version; register staging (global_load -> ds_write_b128 behind the barrier) +3
+// ms; the DMAs moved from behind the barrier into the shadows of the first MFMAs of the chunk
+// +0.5 ms; reads two K-blocks ahead +0.6 ms; two alternating accumulator chains +2 ms (extra
+// adds; a single chain already issues back to back).
 struct AStream {
     const u32x4 *buf[NBUF];   // this lane's view of the buffers, buf[0] = chunk being consumed
-    unsigned dst[NBUF];       // LDS byte address of this wave's K-block in each (wave-uniform)
+    unsigned dst[NBUF];       // LDS byte address of this wave's K-blocks in each (wave-uniform)
     u32x4 hi, lo;             // A operand of the next K-block (read in flight)
-    const char *gsrc;         // this lane's source of this wave's K-block of the next chunk to stage
+    const char *gsrc;         // this lane's source of this wave's K-blocks of the next chunk to stage
 
     DEV void init(const char *prog, u32x4 *stage, unsigned stage_addr, int wave, int lane) {
-        const char *g = prog + wave * (KB_U4 * 16) + lane * 16;
+        const char *g = prog + wave * (KPW * KB_U4 * 16) + lane * 16;
         // the previous tile's reads and DMAs are retired in every wave before the buffers are reused
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
         for (int i = 0; i < NBUF; i++) {
             buf[i] = stage + i * (CK * KB_U4) + lane;
-            dst[i] = stage_addr + i * CHUNK_BYTES + wave * (KB_U4 * 16);
-            glds_kblock(g + i * CHUNK_BYTES, dst[i]);
+            dst[i] = stage_addr + i * CHUNK_BYTES + wave * (KPW * KB_U4 * 16);
+            glds_kblocks(g + i * CHUNK_BYTES, dst[i]);
         }
         gsrc = g + NBUF * CHUNK_BYTES;
         asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");  // chunk 0 landed everywhere
         hi = buf[0][0];
         lo = buf[0][64];
     }
-    // A operand of the K-block at position `pos` (0..3) of the current chunk; issues the read of
-    // the next (a distance of two K-blocks measured no better).  EXTRA_VM: vector-memory loads
-    // the caller has issued since the previous synchronisation and does not need yet (they are
-    // younger than the DMAs waited for here: the counted wait lets them stay in flight).
+    // A operand of the K-block at position `pos` (0..7) of the current chunk; issues the read of
+    // the next.  EXTRA_VM: vector-memory loads the caller has issued since the previous
+    // synchronisation and does not need yet (they are younger than the DMAs waited for here:
+    // the counted wait lets them stay in flight).
     template <int EXTRA_VM = 0>
     DEV void step(int pos, u32x4 &ahi, u32x4 &alo) {
         ahi = hi;
@@ -191,20 +199,17 @@ struct AStream {
         if (pos == CK - 1) {
             static_assert(EXTRA_VM == 0 || EXTRA_VM == 4, "wait-count variants");
             if (EXTRA_VM == 4)
-                asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else
-                asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            glds_kblock(gsrc, dst[0]);
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            glds_kblocks(gsrc, dst[0]);
             gsrc += CHUNK_BYTES;
             const u32x4 *t = buf[0];
             const unsigned u = dst[0];
-#pragma unroll
-            for (int i = 0; i + 1 < NBUF; i++) {
-                buf[i] = buf[i + 1];
-                dst[i] = dst[i + 1];
-            }
-            buf[NBUF - 1] = t;
-            dst[NBUF - 1] = u;
+            buf[0] = buf[1];
+            dst[0] = dst[1];
+            buf[1] = t;
+            dst[1] = u;
             hi = buf[0][0];
             lo = buf[0][64];
         } else {
@@ -213,6 +218,21 @@ struct AStream {
         }
     }
     DEV void drain() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+};
+
+// The LDS-resident activation array of a wave: tiles 0..6 in the slab, tile 7 in registers (those
+// 4 KiB per wave are what lets the staging buffers hold 8 K-blocks, i.e. half the barriers).
+struct Slab {
+    u32x4 *fl;  // this lane's view: [(tile * 4 + j * 2 + hl) * 64]
+    PT t7;
+    DEV void store(int tile, const PT &p) {
+        if (tile == SLAB_TILES) {
+            t7 = p;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) fl[(tile * 4 + q) * 64] = p.v[q];
+        }
+    }
 };
 
 // One K-block: three dependent MFMAs on one accumulator.  A dependent v_mfma_f32_32x32x16_f16
@@ -255,7 +275,7 @@ struct TilePacker {
 
 // SIDE: side(kb) runs behind the MFMAs of K-block kb
 template <int KT, int EXTRA_VM = 0, typename SIDE = NoSide>
-DEV void gemm_reg(AStream &s, const PT *X, f32x16 &acc, SIDE side = SIDE()) {
+DEV void gemm_reg(AStream &s, const PT *X, f32x16 &acc, SIDE side = SIDE()) {  // starts chunk-aligned
 #pragma unroll
     for (int kt = 0; kt < KT; kt++)
 #pragma unroll
@@ -270,30 +290,39 @@ DEV void gemm_reg(AStream &s, const PT *X, f32x16 &acc, SIDE side = SIDE()) {
             side(kt * 2 + j);
         }
 }
-// one input tile (2 K-blocks) starting at chunk position pos0 (0 or 2)
+// one input tile (2 K-blocks) starting at chunk position pos0 (even)
 DEV void gemm_one(AStream &s, const PT &X, f32x16 &acc, int pos0) {
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         u32x4 ahi, alo;
-        s.step(pos0 + j, ahi, alo);
+        s.step((pos0 + j) & (CK - 1), ahi, alo);
         pin(ahi, alo);
         mfma3(acc, ahi, alo, X.v[2 * j], X.v[2 * j + 1]);
     }
 }
 // 8 input tiles with the B operands read from the wave's LDS slab ([k-block][hi | lo][lane]),
 // one K-block ahead of their use
+// B operand of K-block kb of the slab-resident array (tile 7 lives in registers)
+DEV void slab_b(const Slab &sl, int kb, u32x4 &bh, u32x4 &bl) {
+    if (kb >= SLAB_TILES * 2) {
+        bh = sl.t7.v[(kb & 1) * 2];
+        bl = sl.t7.v[(kb & 1) * 2 + 1];
+    } else {
+        bh = sl.fl[kb * KB_U4];
+        bl = sl.fl[kb * KB_U4 + 64];
+    }
+}
+// pos0: chunk position of the first K-block (0 or 4: a head consumes 92 K-blocks)
 template <typename SIDE = NoSide>
-DEV void gemm_lds(AStream &s, const u32x4 *fl, f32x16 &acc, SIDE side = SIDE()) {
-    u32x4 bh = fl[0], bl = fl[64];
+DEV void gemm_lds(AStream &s, const Slab &sl, f32x16 &acc, int pos0 = 0, SIDE side = SIDE()) {
+    u32x4 bh, bl;
+    slab_b(sl, 0, bh, bl);
 #pragma unroll
     for (int kb = 0; kb < NT * 2; kb++) {
         u32x4 ahi, alo;
-        s.step(kb & (CK - 1), ahi, alo);
+        s.step((pos0 + kb) & (CK - 1), ahi, alo);
         u32x4 nh = bh, nl = bl;
-        if (kb + 1 < NT * 2) {  // after the step: its lgkmcnt(0) must not wait for this read
-            nh = fl[(kb + 1) * KB_U4];
-            nl = fl[(kb + 1) * KB_U4 + 64];
-        }
+        if (kb + 1 < NT * 2) slab_b(sl, kb + 1, nh, nl);  // after the step: its lgkmcnt(0) must not wait for this read
         pin(ahi, alo);
         mfma3(acc, ahi, alo, bh, bl);
         bh = nh;
@@ -307,31 +336,10 @@ DEV void gemm_lds(AStream &s, const u32x4 *fl, f32x16 &acc, SIDE side = SIDE()) 
 // the K-blocks: one value per K-block, one packed pair every second K-block.  The VALU work sits
 // between the MFMA groups in program order, where the in-order wave can issue it in their shadow
 // (~5 issue slots per 32-cycle MFMA); done after the GEMM it ran with the matrix pipe idle.
-DEV void fc1_gelu(AStream &s, const u32x4 *fl, f32x16 &nxt, const f32x16 &cur, PT &hp) {
-    u32x4 bh = fl[0], bl = fl[64];
-    float g_prev = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < NT * 2; kb++) {
-        u32x4 ahi, alo;
-        s.step(kb & (CK - 1), ahi, alo);
-        u32x4 nh = bh, nl = bl;
-        if (kb + 1 < NT * 2) {
-            nh = fl[(kb + 1) * KB_U4];
-            nl = fl[(kb + 1) * KB_U4 + 64];
-        }
-        pin(ahi, alo);
-        mfma3(nxt, ahi, alo, bh, bl);
-        bh = nh;
-        bl = nl;
-        const float g = gelu_erf(cur[kb]);
-        if (kb & 1) {
-            unsigned h, l;
-            split2(g_prev, g, h, l);
-            hp.v[2 * (kb >> 3)][(kb & 7) >> 1] = h;
-            hp.v[2 * (kb >> 3) + 1][(kb & 7) >> 1] = l;
-        }
-        g_prev = g;
-    }
+DEV void fc1_gelu(AStream &s, const Slab &sl, f32x16 &nxt, const f32x16 &cur, PT &hp) {
+    TilePacker e;
+    gemm_lds(s, sl, nxt, 0, [&](int kb) { e.feed(kb, gelu_erf(cur[kb])); });
+    hp = e.p;
 }
 
 DEV float xhalf(float v) { return __shfl_xor(v, 32, 64); }  // value of lane l ^ 32
@@ -384,12 +392,8 @@ DEV void ln_stats(const f32x16 *x, float &mean, float &rstd) {
     v += xhalf(v);
     rstd = 1.0f / sqrtf(v * (1.0f / 256.0f) + 1e-6f);
 }
-DEV void store_tile_lds(u32x4 *fl, int tile, const PT &p) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) fl[(tile * 4 + q) * 64] = p.v[q];
-}
 // LayerNorm -> packed B operands in the wave's LDS slab
-DEV void layer_norm_lds(const f32x16 *x, u32x4 *fl, const float *prm, int g_off, int b_off, int hi) {
+DEV void layer_norm_lds(const f32x16 *x, Slab &sl, const float *prm, int g_off, int b_off, int hi) {
     float mean, rstd;
     ln_stats(x, mean, rstd);
 #pragma unroll
@@ -399,7 +403,7 @@ DEV void layer_norm_lds(const f32x16 *x, u32x4 *fl, const float *prm, int g_off,
         rp(prm, b_off, kt, hi, b);
 #pragma unroll
         for (int r = 0; r < 16; r++) t[r] = fmaf((x[kt][r] - mean) * rstd, g[r], b[r]);
-        store_tile_lds(fl, kt, pack_tile(t));
+        sl.store(kt, pack_tile(t));
     }
 }
 
@@ -416,9 +420,10 @@ DEV void load_params(float *prm, const float *prog_params, int start, int count)
 // softmax update in the log2 domain, o += V_tile^T P (2 K-blocks).  MASK: last tile, rows >= 197
 // are padding.
 template <bool MASK>
-DEV void attn_tile(AStream &s, const PT &q, f32x16 &o, float &m_run, float &z_run, float c, int hi) {
+DEV void attn_tile(AStream &s, const PT &q, f32x16 &o, float &m_run, float &z_run, float c, int hi,
+                   int pos0) {
     f32x16 S = zero16();
-    gemm_one(s, q, S, 0);
+    gemm_one(s, q, S, pos0);
     float mt = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
@@ -441,7 +446,7 @@ DEV void attn_tile(AStream &s, const PT &q, f32x16 &o, float &m_run, float &z_ru
     z_run = fmaf(z_run, alpha, zs_);
 #pragma unroll
     for (int r = 0; r < 16; r++) o[r] *= alpha;
-    gemm_one(s, pack_tile(S), o, 2);
+    gemm_one(s, pack_tile(S), o, pos0 + 2);
     m_run = m_new;
 }
 
@@ -451,13 +456,15 @@ DEV void attn_tile(AStream &s, const PT &q, f32x16 &o, float &m_run, float &z_ru
 #define ZS_STAMP(i) do { } while (0)
 #endif
 // One wave: 32 points (lane & 31; both lane halves carry the same point).
-DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage_addr, u32x4 *fl,
+DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage_addr, u32x4 *fl_,
                       f32x4 *zs, float px, float py, float pz, int wave, int lane,
                       unsigned long long *dbg) {
     const int hi = lane >> 5;
     const float *prog_params = reinterpret_cast<const float *>(prog) + REC_FLOATS;
     AStream s;
     s.init(prog, stage, stage_addr, wave, lane);
+    Slab sl;
+    sl.fl = fl_;
     ZS_STAMP(0);
 
     // point_proj (implicit.py:128-131); y is the residual stream, kept as accumulators
@@ -473,20 +480,22 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
 #pragma unroll 1
     for (int blk = 0; blk < BLOCKS; blk++) {
         load_params(prm, prog_params, W_ATT + blk * P_BLK_STRIDE, PB_LN2G);
-        layer_norm_lds(y, fl, prm, PB_LN1G, PB_LN1B, hi);
+        layer_norm_lds(y, sl, prm, PB_LN1G, PB_LN1B, hi);
         ZS_STAMP(2 + blk * 4);
         // y = x + proj_bias + sum_heads Wproj_h o_h
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) y[nt] += rp16(prm, PB_BPROJ, nt, hi);
 
-#pragma unroll 1
-        for (int hd = 0; hd < HEADS; hd++) {
+        // one head: 48 (q, k, v) + 28 (7 latent tiles) + 16 (proj) = 92 K-blocks = 11.5 chunks, so
+        // heads alternate between chunk positions 0 and 4 (P); all positions are compile-time
+        auto head = [&](int hd, auto Ptag) {
+            constexpr int P = decltype(Ptag)::value;
             f32x16 q = rp16(prm, PB_BQKV, hd * 3 + 0, hi);
-            gemm_lds(s, fl, q);
+            gemm_lds(s, sl, q, P);
             f32x16 k = rp16(prm, PB_BQKV, hd * 3 + 1, hi);
-            gemm_lds(s, fl, k);
+            gemm_lds(s, sl, k, P);
             f32x16 v = rp16(prm, PB_BQKV, hd * 3 + 2, hi);
-            gemm_lds(s, fl, v);
+            gemm_lds(s, sl, v, P);
 
             // logits are kept in the log2 domain: c = d^-1/2 * log2(e), softmax = 2^(c s - m)
             const float c = scale * 1.44269504088896340736f;
@@ -499,8 +508,11 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
             float m_run = -INFINITY, z_run = 0.f;
             f32x16 o = zero16();
 #pragma unroll 1
-            for (int lt = 0; lt < LT - 1; lt++) attn_tile<false>(s, qp, o, m_run, z_run, c, hi);
-            attn_tile<true>(s, qp, o, m_run, z_run, c, hi);
+            for (int l2 = 0; l2 < (LT - 1) / 2; l2++) {
+                attn_tile<false>(s, qp, o, m_run, z_run, c, hi, P);
+                attn_tile<false>(s, qp, o, m_run, z_run, c, hi, (P + 4) & (CK - 1));
+            }
+            attn_tile<true>(s, qp, o, m_run, z_run, c, hi, P);
             {
                 const float m_new = fmaxf(m_run, s_self);
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -514,26 +526,32 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
             // y += Wproj[:, head] o_h
             const PT op = pack_tile(o);
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++) gemm_one(s, op, y[nt], (nt & 1) * 2);
+            for (int nt = 0; nt < NT; nt++) gemm_one(s, op, y[nt], (P + 4 + 2 * nt) & (CK - 1));
+        };
+        static_assert((LT - 1) % 2 == 0 && (3 * NT * 2 + LT * 4 + NT * 2) % CK == 4, "head = 11.5 chunks");
+#pragma unroll 1
+        for (int hd = 0; hd < HEADS; hd += 2) {
+            head(hd, std::integral_constant<int, 0>());
+            head(hd + 1, std::integral_constant<int, 4>());
         }
 
         ZS_STAMP(3 + blk * 4);
         // MLP (timm Mlp): y += b2 + W2 gelu(W1 LN2(y) + b1), one hidden tile at a time
         load_params(prm, prog_params, W_MLP + blk * P_BLK_STRIDE, P_BLK_STRIDE - PB_LN2G);
-        layer_norm_lds(y, fl, prm, PB_LN2G - PB_LN2G, PB_LN2B - PB_LN2G, hi);
+        layer_norm_lds(y, sl, prm, PB_LN2G - PB_LN2G, PB_LN2B - PB_LN2G, hi);
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) y[nt] += rp16(prm, PB_B2 - PB_LN2G, nt, hi);
         ZS_STAMP(4 + blk * 4);
         // software pipeline over the hidden tiles (stream order: fc1(0), [fc1(t+1), fc2(t)]..., fc2(31))
         f32x16 hid = rp16(prm, PB_B1 - PB_LN2G, 0, hi);
-        gemm_lds(s, fl, hid);
+        gemm_lds(s, sl, hid);
 #pragma unroll 1
         for (int ht = 0; ht < HT - 1; ht++) {
             f32x16 nxt = rp16(prm, PB_B1 - PB_LN2G, ht + 1, hi);
             PT hp;
-            fc1_gelu(s, fl, nxt, hid, hp);
+            fc1_gelu(s, sl, nxt, hid, hp);
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++) gemm_one(s, hp, y[nt], (nt & 1) * 2);
+            for (int nt = 0; nt < NT; nt++) gemm_one(s, hp, y[nt], (2 * nt) & (CK - 1));
             hid = nxt;
         }
         {
@@ -541,7 +559,7 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
             for (int r = 0; r < 16; r++) hid[r] = gelu_erf(hid[r]);
             const PT hp = pack_tile(hid);
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++) gemm_one(s, hp, y[nt], (nt & 1) * 2);
+            for (int nt = 0; nt < NT; nt++) gemm_one(s, hp, y[nt], (2 * nt) & (CK - 1));
         }
         ZS_STAMP(5 + blk * 4);
     }
@@ -580,12 +598,12 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
                     gemm_reg<NT>(s, hp, acc);
                 else
                     gemm_reg<NT, 0>(s, hp, acc, side);
-                if (nt > 0) store_tile_lds(fl, nt - 1, e.p);
+                if (nt > 0) sl.store(nt - 1, e.p);
                 prev = acc;
             } else {
 #pragma unroll
                 for (int kb = 0; kb < 16; kb++) side(kb);
-                store_tile_lds(fl, nt - 1, e.p);
+                sl.store(nt - 1, e.p);
             }
         }
     }
@@ -613,7 +631,7 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
             for (int j = 0; j < 4; j++) {
                 f32x4 t;
                 t.x = acc[4 * j + 0]; t.y = acc[4 * j + 1]; t.z = acc[4 * j + 2]; t.w = acc[4 * j + 3];
-                zs[(li * SLAB_U4) + (nt * 4 + j) * 64] = t;
+                zs[(li * ZTILES_F4) + (nt * 4 + j) * 64] = t;
             }
         }
     }
@@ -630,9 +648,9 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
             if (nt < NT) {
                 f32x16 acc = rp16(prm, P_IMPL1 - W_I1, nt, hi);
                 if (nt == 0)
-                    gemm_lds(s, fl, acc);
+                    gemm_lds(s, sl, acc);
                 else
-                    gemm_lds(s, fl, acc, side);
+                    gemm_lds(s, sl, acc, 0, side);
                 if (nt > 0) hp[nt - 1] = e.p;
                 prev = acc;
             } else {
@@ -649,7 +667,7 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
         if (i == 1) load_params(prm, prog_params, W_I2, W_I3 - W_I2);
         if (i == 2) load_params(prm, prog_params, W_I3, P_USED - W_I3);
         const int pp = i == 0 ? P_IMPL_PAIR - W_I1 : 0;
-        const f32x4 *zl = zs + i * SLAB_U4;
+        const f32x4 *zl = zs + i * ZTILES_F4;
         // skip layer 2+2i: registers (x / sqrt(2)) + parked feat half -> LDS
         {
             f32x16 prev;
@@ -670,14 +688,14 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
                         gemm_reg<NT, 4>(s, hp, acc);
                     else
                         gemm_reg<NT, 4>(s, hp, acc, side);
-                    if (nt > 0) store_tile_lds(fl, nt - 1, e.p);
+                    if (nt > 0) sl.store(nt - 1, e.p);
                     prev = acc;
 #pragma unroll
                     for (int j = 0; j < 4; j++) zprev[j] = z[j];
                 } else {
 #pragma unroll
                     for (int kb = 0; kb < 16; kb++) side(kb);
-                    store_tile_lds(fl, nt - 1, e.p);
+                    sl.store(nt - 1, e.p);
                 }
             }
         }
@@ -706,9 +724,9 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
                 if (nt < NT) {
                     f32x16 acc = rp16(prm, pp + 1024, nt, hi);
                     if (nt == 0)
-                        gemm_lds(s, fl, acc);
+                        gemm_lds(s, sl, acc);
                     else
-                        gemm_lds(s, fl, acc, side);
+                        gemm_lds(s, sl, acc, 0, side);
                     if (nt > 0) hp[nt - 1] = e.p;
                     prev = acc;
                 } else {
