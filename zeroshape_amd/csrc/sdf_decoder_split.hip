@@ -28,8 +28,8 @@
 //    One raw s_barrier per chunk (AStream below).  Ordering rules: cdna_hip_programming.md
 //    section 5 (counted vmcnt by the issuing wave, then a barrier the reader has passed; restage
 //    after an lgkmcnt-retired read + barrier).
-//  * LDS: [params window 8 KiB][A staging 2 x 16 KiB][4 x 28 KiB activation slabs] = 152 KiB
-//    (tile 7 of a slab-resident array lives in registers).  Params are paged in nine windows
+//  * LDS: [params window 16 KiB][A staging 2 x 16 KiB][4 x 28 KiB activation slabs] = 160 KiB
+//    (tile 7 of a slab-resident array lives in registers).  Params are paged in five windows
 //    per tile instead of two.
 //  * No asm register ring: LDS reads and MFMAs are builtins, scheduled and hazard-padded by
 //    hipcc (VGPR-form accumulators: -mllvm -amdgpu-mfma-vgpr-form, zeroshape_amd/build.py); only
@@ -69,14 +69,14 @@ constexpr int KPW = CK / WAVES;                     // K-blocks a wave stages pe
 constexpr int CHUNK_BYTES = CK * KB_U4 * 16;        // 16 KiB
 constexpr int NBUF = 2;
 constexpr int KB_TOTAL = G_TOTAL / 2;               // 4,928 K-blocks = 14,784 MFMAs per wave tile
-constexpr int PRM_WINDOW = 2048;                    // floats of params resident in LDS at a time
+constexpr int PRM_WINDOW = 4096;                    // floats of params resident in LDS at a time
 constexpr int STAGE_FLOATS = NBUF * CHUNK_BYTES / 4;
 constexpr int SLAB_TILES = NT - 1;                  // tiles of an activation array kept in LDS (the last: registers)
 constexpr int SLAB_U4 = SLAB_TILES * 4 * 64;        // ... as packed (hi, lo) K-blocks: 28 KiB per wave
 constexpr int ZTILES_F4 = NT * 4 * 64;              // one skip layer's fp32 feat partial products (workspace)
 constexpr int ZSLAB_F4 = 3 * ZTILES_F4;
 constexpr int LDS_FLOATS = PRM_WINDOW + STAGE_FLOATS + WAVES * SLAB_U4 * 4;
-static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS of a CU");
+static_assert(LDS_FLOATS * 4 == 160 * 1024, "the kernel owns the whole LDS of a CU");
 static_assert(KB_TOTAL % CK == 0 && CK % WAVES == 0 && KPW * 2048 <= 4096, "chunking");
 // the stream prefetches NBUF chunks past its position: the last reads run into the zero tail of
 // the records and (harmlessly) the params section behind it
@@ -84,14 +84,10 @@ static_assert((RING * GROUP_FLOATS + PARAM_FLOATS) * 4 >= NBUF * CHUNK_BYTES, "p
 
 // params windows (floats, relative to the params section of the program; <= PRM_WINDOW each)
 constexpr int W_PP = P_PP;                                   // point_proj table (1,024)
-constexpr int W_ATT = P_BLK0;                                // + blk * P_BLK_STRIDE: ln1, bproj, bqkv (1,536)
-constexpr int W_MLP = P_BLK0 + PB_LN2G;                      // + blk * P_BLK_STRIDE: ln2, b2, b1 (1,792)
-constexpr int W_I0 = P_LNFG;                                 // final norm + impl layer 0 (1,536)
-constexpr int W_I1 = P_IMPL1;                                // impl layer 1 + pair 0 (1,536)
-constexpr int W_I2 = P_IMPL_PAIR + P_IMPL_PAIR_STRIDE;       // pair 1 (1,280)
-constexpr int W_I3 = P_IMPL_PAIR + 2 * P_IMPL_PAIR_STRIDE;   // pair 2 + layer 8 (1,552)
-static_assert(PB_LN2G <= PRM_WINDOW && P_BLK_STRIDE - PB_LN2G <= PRM_WINDOW && W_I1 - W_I0 <= PRM_WINDOW &&
-              W_I2 - W_I1 <= PRM_WINDOW && W_I3 - W_I2 <= PRM_WINDOW && P_USED - W_I3 <= PRM_WINDOW,
+constexpr int W_BLK = P_BLK0;                                // + blk * P_BLK_STRIDE: one attention block (3,328)
+constexpr int W_IA = P_LNFG;                                 // final norm, impl layers 0, 1, pair 0 (3,072)
+constexpr int W_IB = P_IMPL_PAIR + P_IMPL_PAIR_STRIDE;       // pairs 1, 2, layer 8 (2,832)
+static_assert(P_BLK_STRIDE <= PRM_WINDOW && W_IB - W_IA <= PRM_WINDOW && P_USED - W_IB <= PRM_WINDOW,
               "params windows");
 
 #define DEV __device__ __forceinline__
@@ -479,7 +475,7 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
 
 #pragma unroll 1
     for (int blk = 0; blk < BLOCKS; blk++) {
-        load_params(prm, prog_params, W_ATT + blk * P_BLK_STRIDE, PB_LN2G);
+        load_params(prm, prog_params, W_BLK + blk * P_BLK_STRIDE, P_BLK_STRIDE);
         layer_norm_lds(y, sl, prm, PB_LN1G, PB_LN1B, hi);
         ZS_STAMP(2 + blk * 4);
         // y = x + proj_bias + sum_heads Wproj_h o_h
@@ -537,17 +533,16 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
 
         ZS_STAMP(3 + blk * 4);
         // MLP (timm Mlp): y += b2 + W2 gelu(W1 LN2(y) + b1), one hidden tile at a time
-        load_params(prm, prog_params, W_MLP + blk * P_BLK_STRIDE, P_BLK_STRIDE - PB_LN2G);
-        layer_norm_lds(y, sl, prm, PB_LN2G - PB_LN2G, PB_LN2B - PB_LN2G, hi);
+        layer_norm_lds(y, sl, prm, PB_LN2G, PB_LN2B, hi);
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++) y[nt] += rp16(prm, PB_B2 - PB_LN2G, nt, hi);
+        for (int nt = 0; nt < NT; nt++) y[nt] += rp16(prm, PB_B2, nt, hi);
         ZS_STAMP(4 + blk * 4);
         // software pipeline over the hidden tiles (stream order: fc1(0), [fc1(t+1), fc2(t)]..., fc2(31))
-        f32x16 hid = rp16(prm, PB_B1 - PB_LN2G, 0, hi);
+        f32x16 hid = rp16(prm, PB_B1, 0, hi);
         gemm_lds(s, sl, hid);
 #pragma unroll 1
         for (int ht = 0; ht < HT - 1; ht++) {
-            f32x16 nxt = rp16(prm, PB_B1 - PB_LN2G, ht + 1, hi);
+            f32x16 nxt = rp16(prm, PB_B1, ht + 1, hi);
             PT hp;
             fc1_gelu(s, sl, nxt, hid, hp);
 #pragma unroll
@@ -565,7 +560,7 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
     }
 
     // final norm (implicit.py:275) -> feat, fp32 in registers
-    load_params(prm, prog_params, W_I0, W_I1 - W_I0);
+    load_params(prm, prog_params, W_IA, W_IB - W_IA);
     float h[NT * 16];
     {
         float mean, rstd;
@@ -573,8 +568,8 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
 #pragma unroll
         for (int kt = 0; kt < NT; kt++) {
             float g[16], b[16];
-            rp(prm, P_LNFG - W_I0, kt, hi, g);
-            rp(prm, P_LNFB - W_I0, kt, hi, b);
+            rp(prm, P_LNFG - W_IA, kt, hi, g);
+            rp(prm, P_LNFB - W_IA, kt, hi, b);
 #pragma unroll
             for (int r = 0; r < 16; r++) h[kt * 16 + r] = fmaf((y[kt][r] - mean) * rstd, g[r], b[r]);
         }
@@ -593,7 +588,7 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
             TilePacker e;
             auto side = [&](int kb) { e.feed(kb, softplus100(prev[kb])); };
             if (nt < NT) {
-                f32x16 acc = xyz_affine(prm, P_IMPL0 - W_I0, nt, hi, px, py, pz);
+                f32x16 acc = xyz_affine(prm, P_IMPL0 - W_IA, nt, hi, px, py, pz);
                 if (nt == 0)
                     gemm_reg<NT>(s, hp, acc);
                 else
@@ -638,7 +633,6 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
 
     ZS_STAMP(12);
     // layer 1 (plain): LDS -> registers, pre-divided by sqrt(2) because layer 2 is a skip layer
-    load_params(prm, prog_params, W_I1, W_I2 - W_I1);
     {
         f32x16 prev;
 #pragma unroll
@@ -646,7 +640,7 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
             TilePacker e;
             auto side = [&](int kb) { e.feed(kb, softplus100(prev[kb]) * rsqrt2); };
             if (nt < NT) {
-                f32x16 acc = rp16(prm, P_IMPL1 - W_I1, nt, hi);
+                f32x16 acc = rp16(prm, P_IMPL1 - W_IA, nt, hi);
                 if (nt == 0)
                     gemm_lds(s, sl, acc);
                 else
@@ -664,9 +658,8 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
     float out = 0.f;
 #pragma unroll 1
     for (int i = 0; i < 3; i++) {
-        if (i == 1) load_params(prm, prog_params, W_I2, W_I3 - W_I2);
-        if (i == 2) load_params(prm, prog_params, W_I3, P_USED - W_I3);
-        const int pp = i == 0 ? P_IMPL_PAIR - W_I1 : 0;
+        if (i == 1) load_params(prm, prog_params, W_IB, P_USED - W_IB);
+        const int pp = i == 0 ? P_IMPL_PAIR - W_IA : (i - 1) * P_IMPL_PAIR_STRIDE;
         const f32x4 *zl = zs + i * ZTILES_F4;
         // skip layer 2+2i: registers (x / sqrt(2)) + parked feat half -> LDS
         {
@@ -715,7 +708,7 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
                 };
                 if (nt > 0) {
                     if (i == 2) {
-                        rp(prm, P_W8 - W_I3, nt - 1, hi, w);
+                        rp(prm, P_W8 - W_IB, nt - 1, hi, w);
                     } else {
 #pragma unroll
                         for (int r = 0; r < 16; r++) w[r] = 0.f;
@@ -741,7 +734,7 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
     s.drain();
     out += xhalf(out);
     ZS_STAMP(15);
-    return out + prm[P_B8 - W_I3];
+    return out + prm[P_B8 - W_IB];
 }
 
 template <bool GRID>
