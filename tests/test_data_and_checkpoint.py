@@ -1,6 +1,9 @@
 """CPU checks: the analytic dataset honours the reference's sample-dict contract and is
 geometrically self-consistent; checkpoints round-trip through the reference's layout."""
+import os
+
 import numpy as np
+import pytest
 import torch
 
 from tests.test_encoder_contract import make_opt
@@ -51,7 +54,24 @@ def test_depth_unprojects_onto_the_gt_surface():
     assert 0.01 < (sdf < 0).mean() < 0.5
 
 
-def test_checkpoint_roundtrip_in_reference_layout(tmp_path):
+@pytest.fixture
+def big_tmp_path(tmp_path):
+    """~2 GB of checkpoints: in memory where /dev/shm exists (disk writes took minutes on slow hosts)."""
+    import shutil
+    import tempfile
+    from pathlib import Path
+    if os.path.isdir("/dev/shm"):
+        d = tempfile.mkdtemp(dir="/dev/shm", prefix="zs_ckpt_")
+        try:
+            yield Path(d)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    else:
+        yield tmp_path
+
+
+def test_checkpoint_roundtrip_in_reference_layout(big_tmp_path):
+    tmp_path = big_tmp_path
     from zeroshape_amd.model.compute_graph.graph_shape import Graph
     from zeroshape_amd.utils import util
 
