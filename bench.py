@@ -6,9 +6,10 @@
 
 A "step" is one pass of the hot path over one batch of synthetic input with inputs
 resident in HBM: for a batch of n_gpus images (one per rank's worth of work, "weak"
-scaling) the per-image prologue + the fused decoder over every rank's x-slab of each
-image's (128+1)^3 grid, then - for N > 1 - one RCCL all_gather that rebuilds the full
-occupancy grids on every rank (zeroshape_amd/parallel.py).  N = 1: one image, one full
+scaling) the per-image prologue + the fused decoder over every rank's share of each
+image's (128+1)^3 grid (equal point ranges in memory order, rounded to kernel tiles), then -
+for N > 1 - one RCCL all_gather that rebuilds the full occupancy grids on every rank
+(zeroshape_amd/parallel.py).  N = 1: one image, one full
 129^3 grid, no collective.  value = grid points evaluated by all ranks / max-over-ranks
 time.  Weights: seeded random (no checkpoint ships with the reference); latent_depth:
 seeded N(0,1).
@@ -107,9 +108,8 @@ def main():
 
     def step():
         st = net.prepare(latent)                   # per-image prologue (all images, every rank)
-        return parallel.sharded_level_grid(
-            lambda b, e: net.query_grid(latent, axis, apply_sigmoid=True, slice_begin=b,
-                                        slice_end=e, state=st), G)
+        return parallel.sharded_level_grid_points(
+            lambda b, e: net.query_grid_range(latent, axis, b, e, apply_sigmoid=True, state=st), G)
 
     def barrier():
         if world > 1:
@@ -133,18 +133,18 @@ def main():
     value = points_per_step * args.steps / dt
 
     # ---- roofline of the dominant kernel: HIP events around decoder launches only -------
-    b, e, _ = parallel.slab_bounds(G, world, rank)
+    b, e, _ = parallel.point_bounds(G ** 3, world, rank)
     stream = torch.cuda.current_stream(dev)       # the stream the C ABI launches on
-    pts_launch = batch * (e - b) * G * G
+    pts_launch = batch * (e - b)
 
     def time_launches(precision, reps):
         st = net.prepare(latent, precision)
-        net.query_grid(latent, axis, apply_sigmoid=True, slice_begin=b, slice_end=e, state=st)
+        net.query_grid_range(latent, axis, b, e, apply_sigmoid=True, state=st)
         torch.cuda.synchronize()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
         ev[0].record(stream)
         for i in range(reps):
-            net.query_grid(latent, axis, apply_sigmoid=True, slice_begin=b, slice_end=e, state=st)
+            net.query_grid_range(latent, axis, b, e, apply_sigmoid=True, state=st)
             ev[i + 1].record(stream)
         torch.cuda.synchronize()
         return sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps)), st
@@ -222,7 +222,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "compute_level_grid vox_res=%d: (%d+1)^3 = %d points/image, "
                                    "range [-1.5,1.5], prologue + fused decoder (%s) + sigmoid; batch = "
-                                   "n_gpus images, x-slab sharded, RCCL all_gather for n_gpus>1"
+                                   "n_gpus images, each sharded into equal point ranges, RCCL all_gather for n_gpus>1"
                                    % (N, N, G ** 3, args.precision),
                        "global_batch_images": batch, "points_per_step": points_per_step,
                        "weights": "seeded random (zeroshape_amd/synthetic.py)"},

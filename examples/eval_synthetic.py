@@ -119,8 +119,8 @@ def main():
         G = args.vox_res + 1
         axis = torch.linspace(-1.5, 1.5, G, device=dev)
         state = net.prepare(latent)
-        occ = parallel.sharded_level_grid(
-            lambda b, e: net.query_grid(latent, axis, slice_begin=b, slice_end=e, state=state), G)
+        occ = parallel.sharded_level_grid_points(
+            lambda b, e: net.query_grid_range(latent, axis, b, e, state=state), G)
         _, cloud = E._surface_clouds(opt, occ)            # identical on every rank (same seed)
         if args.brute_force:
             sl = parallel.rotation_range(6912, world, rank)

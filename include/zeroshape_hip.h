@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 16
+#define ZS_ABI_VERSION 17
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -159,6 +159,18 @@ int zs_sdf_query_points_split(const void *split_programs, size_t program_stride_
 int zs_sdf_query_grid_split(const void *split_programs, size_t program_stride_bytes, int batch,
                             const float *axis, int G, int slice_begin, int slice_end,
                             int apply_sigmoid, float *out, void *workspace, void *stream);
+
+/* As zs_sdf_query_grid / zs_sdf_query_grid_split, for the points [point_begin, point_end) of
+ * the grid in its memory order (x slowest, z fastest): out[batch][point_end - point_begin].
+ * This is the unit of the multi-GPU sharding (zeroshape_amd/parallel.py): equal point ranges
+ * instead of whole x-slices (129 slices over 8 ranks would leave 17-17-...-10). */
+int zs_sdf_query_grid_range(const void *programs, size_t program_stride_bytes, int batch,
+                            const float *axis, int G, long long point_begin, long long point_end,
+                            int apply_sigmoid, float *out, void *workspace, void *stream);
+int zs_sdf_query_grid_range_split(const void *split_programs, size_t program_stride_bytes, int batch,
+                                  const float *axis, int G, long long point_begin,
+                                  long long point_end, int apply_sigmoid, float *out,
+                                  void *workspace, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Brute-force pose search support (brute_force_search, utils/eval_3D.py:140-170).

@@ -130,3 +130,20 @@ def test_bad_precision_raises(net):
     st = net.prepare(torch.zeros(1, 197, 256).cuda(), "f16x3")
     with pytest.raises(ValueError):
         net.query_points(st, torch.zeros(1, 4, 3).cuda(), need_attn=True)
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f32"])
+def test_point_range_query_equals_grid(net, prec):
+    """zs_sdf_query_grid_range[_split]: any point range of the grid in memory order, bit for bit
+    (the unit of the multi-GPU sharding), including ranges that start and end inside a tile."""
+    latent = torch.from_numpy(syn.seeded_latent(seed=4, batch=2)).cuda()
+    G = 33
+    axis = torch.linspace(-1.5, 1.5, G, device="cuda")
+    st = net.prepare(latent, prec)
+    full = net.query_grid(latent, axis, apply_sigmoid=True, state=st).reshape(2, -1)
+    for b, e in ((0, G ** 3), (0, 1), (1000, 1001), (4481, 17999), (G ** 3 - 77, G ** 3), (500, 500)):
+        got = net.query_grid_range(latent, axis, b, e, apply_sigmoid=True, state=st)
+        assert got.shape == (2, e - b) and torch.equal(got, full[:, b:e])
+    from zeroshape_amd import _lib
+    with pytest.raises(_lib.ZeroShapeHipError):
+        net.query_grid_range(latent, axis, 10, G ** 3 + 1, state=st)

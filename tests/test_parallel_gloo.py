@@ -1,5 +1,6 @@
 """Multi-process (world_size 2 and 3, gloo, CPU tensors) tests of the sharding logic in
-zeroshape_amd/parallel.py: uneven x-slab partition + padded all_gather == unsharded grid;
+zeroshape_amd/parallel.py: uneven x-slab / balanced point-range partition + padded all_gather ==
+unsharded grid;
 rotation-range sharding + lexicographic reduce == sequential first-strict-minimum scan."""
 import os
 import tempfile
@@ -25,6 +26,13 @@ def _worker(rank, world, initfile, G, B):
         got = parallel.sharded_level_grid(query_slab, G)
         assert got.shape == (B, G, G, G)
         assert torch.equal(got, full), "rank %d: gathered grid differs" % rank
+
+        def query_range(b, e):         # ... on this rank's point range (memory order)
+            return full.reshape(B, -1)[:, b:e].clone()
+
+        got = parallel.sharded_level_grid_points(query_range, G)
+        assert got.shape == (B, G, G, G)
+        assert torch.equal(got, full), "rank %d: gathered grid (point ranges) differs" % rank
 
         # rotation sharding: every rank scans its range, winner = first strict minimum overall
         n_rot = 6912
@@ -67,6 +75,24 @@ def test_slab_bounds_cover_and_match_reference_layout():
                 assert 0 <= b <= e <= G and e - b <= per
                 seen += list(range(b, e))
             assert seen == list(range(G))
+
+
+def test_point_bounds_cover_tile_aligned_and_balanced():
+    for G in (1, 2, 33, 129, 257):
+        P = G ** 3
+        for W in (1, 2, 3, 4, 8):
+            seen, sizes = 0, []
+            for r in range(W):
+                b, e, per = parallel.point_bounds(P, W, r)
+                assert b == min(P, seen) and b <= e <= P and e - b <= per and per % 128 == 0
+                seen = e
+                sizes.append(e - b)
+            assert seen == P
+            assert max(sizes) - P / W < 128 + 1e-9       # within one kernel tile of the ideal share
+    # the case of the headline benchmark: 129^3 over 8 ranks, against whole x-slices
+    sizes = [parallel.point_bounds(129 ** 3, 8, r)[1] - parallel.point_bounds(129 ** 3, 8, r)[0] for r in range(8)]
+    slabs = [(parallel.slab_bounds(129, 8, r)[1] - parallel.slab_bounds(129, 8, r)[0]) * 129 * 129 for r in range(8)]
+    assert max(sizes) < 1.001 * 129 ** 3 / 8 and max(slabs) > 1.05 * 129 ** 3 / 8
 
 
 def test_single_process_passthrough():

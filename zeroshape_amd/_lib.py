@@ -42,6 +42,11 @@ SIGNATURES = {
                                            _c_void_p, _c_void_p, _c_void_p]),
     "zs_sdf_query_grid_split": (_c_int, [_c_void_p, _c_size_t, _c_int, _c_void_p, _c_int, _c_int,
                                          _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "zs_sdf_query_grid_range": (_c_int, [_c_void_p, _c_size_t, _c_int, _c_void_p, _c_int, ctypes.c_longlong,
+                                         ctypes.c_longlong, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "zs_sdf_query_grid_range_split": (_c_int, [_c_void_p, _c_size_t, _c_int, _c_void_p, _c_int,
+                                               ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_void_p,
+                                               _c_void_p, _c_void_p]),
     "zs_bf_grid_bytes": (_c_size_t, []),
     "zs_bf_scratch_bytes": (_c_size_t, []),
     "zs_bf_lower_bounds": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
@@ -130,7 +135,7 @@ SIGNATURES = {
     "zs_readout_concat_bwd": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
 }
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 _lib = None
 
 

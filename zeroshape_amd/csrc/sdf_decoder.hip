@@ -805,6 +805,39 @@ extern "C" int zs_sdf_query_points(const void *programs, size_t program_stride_b
     return zs::check_launch("zs_sdf_query_points") ? 1 : 0;
 }
 
+extern "C" int zs_sdf_query_grid_range(const void *programs, size_t program_stride_bytes, int batch,
+                                       const float *axis, int G, long long point_begin,
+                                       long long point_end, int apply_sigmoid, float *out,
+                                       void *workspace, void *stream) {
+    const long long P = (long long)G * G * G;
+    if (batch < 0 || G <= 0 || point_begin < 0 || point_end > P || point_begin > point_end) {
+        zs::set_err("zs_sdf_query_grid_range: bad range (batch=%d G=%d points=[%lld,%lld))", batch, G,
+                    point_begin, point_end);
+        return 0;
+    }
+    const long long mm = point_end - point_begin;
+    if (batch == 0 || mm == 0) return 1;
+    if (!programs || !axis || !out || !workspace) {
+        zs::set_err("zs_sdf_query_grid_range: null pointer");
+        return 0;
+    }
+    if (mm > 0x7fffffffLL - PTS_PER_BLOCK) {
+        zs::set_err("zs_sdf_query_grid_range: %lld points per launch exceed 2^31; split the range", mm);
+        return 0;
+    }
+    if (program_stride_bytes % 16 != 0 || program_stride_bytes < zs_sdf_program_bytes()) {
+        zs::set_err("zs_sdf_query_grid_range: bad program stride %zu", program_stride_bytes);
+        return 0;
+    }
+    const int m = (int)mm;
+    hipLaunchKernelGGL((sdf_decode_kernel<true, false>), dim3(decode_grid_size(batch, m)),
+                       dim3(WAVES * 64), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float *>(programs), program_stride_bytes / sizeof(float), batch,
+                       nullptr, axis, G, point_begin, m, out, apply_sigmoid,
+                       static_cast<f32x4 *>(workspace), nullptr);
+    return zs::check_launch("zs_sdf_query_grid_range") ? 1 : 0;
+}
+
 extern "C" int zs_sdf_query_grid(const void *programs, size_t program_stride_bytes, int batch,
                                  const float *axis, int G, int slice_begin, int slice_end,
                                  int apply_sigmoid, float *out, void *workspace, void *stream) {

@@ -903,6 +903,35 @@ extern "C" int zs_sdf_query_points_split(const void *split_programs, size_t prog
     return zs::check_launch("zs_sdf_query_points_split") ? 1 : 0;
 }
 
+extern "C" int zs_sdf_query_grid_range_split(const void *split_programs, size_t program_stride_bytes,
+                                             int batch, const float *axis, int G, long long point_begin,
+                                             long long point_end, int apply_sigmoid, float *out,
+                                             void *workspace, void *stream) {
+    const long long P = (long long)G * G * G;
+    if (batch < 0 || G <= 0 || point_begin < 0 || point_end > P || point_begin > point_end) {
+        zs::set_err("zs_sdf_query_grid_range_split: bad range (batch=%d G=%d points=[%lld,%lld))", batch, G,
+                    point_begin, point_end);
+        return 0;
+    }
+    const long long mm = point_end - point_begin;
+    if (batch == 0 || mm == 0) return 1;
+    if (!axis || !out || !workspace) {
+        zs::set_err("zs_sdf_query_grid_range_split: null pointer");
+        return 0;
+    }
+    if (mm > 0x7fffffffLL - PTS_PER_BLOCK) {
+        zs::set_err("zs_sdf_query_grid_range_split: %lld points per launch exceed 2^31; split the range", mm);
+        return 0;
+    }
+    if (!check_programs("zs_sdf_query_grid_range_split", split_programs, program_stride_bytes)) return 0;
+    const int m = (int)mm;
+    hipLaunchKernelGGL((sdf_decode_split_kernel<true>), dim3(decode_grid_size(batch, m)),
+                       dim3(WAVES * 64), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const char *>(split_programs), program_stride_bytes, batch, nullptr,
+                       axis, G, point_begin, m, out, apply_sigmoid, static_cast<f32x4 *>(workspace));
+    return zs::check_launch("zs_sdf_query_grid_range_split") ? 1 : 0;
+}
+
 extern "C" int zs_sdf_query_grid_split(const void *split_programs, size_t program_stride_bytes,
                                        int batch, const float *axis, int G, int slice_begin,
                                        int slice_end, int apply_sigmoid, float *out, void *workspace,

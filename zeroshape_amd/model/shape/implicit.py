@@ -276,6 +276,26 @@ class Implicit(nn.Module):
         _lib.check(rc, "zs_sdf_query_grid")
         return out
 
+    @torch.no_grad()
+    def query_grid_range(self, latent_depth, axis, point_begin, point_end, apply_sigmoid=True, state=None):
+        """Points [point_begin, point_end) of the dense grid in memory order (x slowest, z fastest):
+        [B, point_end - point_begin].  The unit of the multi-GPU sharding (parallel.py)."""
+        lib = _lib.load()
+        if state is None:
+            state = self.prepare(latent_depth)
+        axis = axis.detach().to(torch.float32).contiguous()
+        if axis.device != state.programs.device:
+            raise ValueError("axis and latent_depth live on different devices")
+        G = axis.numel()
+        out = torch.empty(state.batch, point_end - point_begin, dtype=torch.float32, device=axis.device)
+        fn = lib.zs_sdf_query_grid_range_split if state.precision == "f16x3" else lib.zs_sdf_query_grid_range
+        with torch.cuda.device(axis.device):
+            rc = fn(_lib.ptr(state.programs), state.stride_bytes, state.batch, _lib.ptr(axis), G,
+                    point_begin, point_end, 1 if apply_sigmoid else 0, _lib.ptr(out),
+                    _lib.ptr(self.workspace(axis.device)), _lib.current_stream_ptr(axis.device))
+        _lib.check(rc, "zs_sdf_query_grid_range")
+        return out
+
     def forward(self, latent_depth, latent_semantic, points_3D, need_attn=True):
         """implicit.py:251-288.  Returns (logits [B,M], attn [B,M,197]) like the reference;
         callers that drop the attention map (our compute_level_grid without vis, training-shape

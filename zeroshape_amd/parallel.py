@@ -71,6 +71,43 @@ def sharded_level_grid(query_slab, G, group=None):
     return gather_slabs(local, G, group)
 
 
+def point_bounds(n_points, world_size, rank, align=128):
+    """Point range [begin, end) of ``rank`` in the grid's memory order: ceil(P/W) points rounded up to
+    whole kernel tiles (``align``) for every rank but the last ones, which get what is left.
+    Balanced to a tile where whole x-slices are not (129 slices over 8 ranks: 17, ..., 17, 10)."""
+    per = int(math.ceil(n_points / float(world_size)))
+    per = (per + align - 1) // align * align
+    b = min(n_points, rank * per)
+    e = min(n_points, b + per)
+    return b, e, per
+
+
+def gather_points(local, n_points, group=None):
+    """local: [B, n_local] points of this rank's range.  Returns [B, n_points] on every rank with
+    ONE all_gather_into_tensor of equally padded ranges."""
+    rank, W = world(group)
+    if W == 1:
+        return local
+    b, e, per = point_bounds(n_points, W, rank)
+    B = local.shape[0]
+    assert local.shape[1] == e - b
+    padded = local.new_zeros((B, per))
+    padded[:, : e - b] = local
+    out = local.new_empty((W, B, per))
+    dist.all_gather_into_tensor(out.view(-1), padded.view(-1), group=group)
+    return out.permute(1, 0, 2).reshape(B, W * per)[:, :n_points].contiguous()
+
+
+def sharded_level_grid_points(query_range, G, group=None):
+    """query_range(begin, end) -> [B, end-begin] for this rank's point range; returns the full
+    occupancy grid [B,G,G,G] on every rank."""
+    rank, W = world(group)
+    P = G * G * G
+    b, e, _ = point_bounds(P, W, rank)
+    local = query_range(b, e)
+    return gather_points(local, P, group).view(local.shape[0], G, G, G)
+
+
 def rotation_range(n_rot, world_size, rank, batch=24):
     """contiguous rotation range of ``rank``, aligned to the reference's batches of 24
     so every rank evaluates whole batches (utils/eval_3D.py:149-152)."""
