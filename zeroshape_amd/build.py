@@ -28,7 +28,9 @@ EXTRA = {
     # packed f32 VALU ops beside 16-bit MFMAs cost more than the scalar forms they replace
     # ... and MFMA accumulators in VGPRs: the activation code reads and writes them in place
     # (with AGPR accumulators every tile paid 32 v_accvgpr moves; 484 -> 352 registers)
-    "sdf_decoder_split.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"],
+    # ... and no NaN canonicalisation (v_max x, x in front of every fmaxf on an MFMA result;
+    # infinities - the softmax mask - keep their meaning)
+    "sdf_decoder_split.hip": ["-fno-slp-vectorize", "-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form"],
     # vertices / sampled points reproducible op for op by oracle/mc_ref.py
     "marching_cubes.hip": ["-ffp-contract=off"],
 }
