@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 17
+#define ZS_ABI_VERSION 18
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -299,6 +299,9 @@ int zs_depth_metrics(const float *prediction, const float *target, const float *
 #define ZS_CONV_IN_RELU 1
 #define ZS_CONV_FORCE_LARGE 2 /* tiling override (tests / tuning): 128x128 tiles */
 #define ZS_CONV_FORCE_SMALL 4 /* 32x64 tiles with the K range split over the 4 waves */
+#define ZS_CONV_F16X3 16      /* split-fp16 arithmetic on the 16-bit matrix pipe (csrc/zs_split16.h): operands
+                               carried as two fp16 halves (~2^-21 relative, |x| <= 131008), three
+                               K = 16 MFMAs per eight fp32 ones; inference */
 #define ZS_CONV_IN_DILATE2 8  /* read the input as if zero-stuffed x2 ([B][2H-1][2W-1][Cin] virtual): the
                                  data gradient of a stride-2 convolution as a stride-1 convolution */
 size_t zs_conv2d_packed_floats(int Cin, int Cout, int kh, int kw);

@@ -1,6 +1,7 @@
 """GPU parity of the encoder layers (csrc/nn_conv.hip, csrc/nn_ops.hip) through the C ABI vs the
 same op in PyTorch fp32 on the CPU (torch.nn.functional).  fp32 MFMA accumulates in a different
-order than the CPU kernels, so comparisons are relative to the output scale: <= 2e-5 of max|y|."""
+order than the CPU kernels, so comparisons are relative to the output scale: <= 2e-5 of max|y| -
+for the exact-fp32 and for the split-fp16 (ZS_CONV_F16X3) arithmetic of the convolution engine alike."""
 import numpy as np
 import pytest
 import torch
@@ -58,13 +59,21 @@ def test_conv2d_matches_torch(B, Cin, H, W, Cout, k, stride, padding):
     else:
         want = F.conv2d(x, w, b, stride=stride, padding=padding)
     pc = pack.pack_conv(w, b, stride=stride, padding=padding).to("cuda")
-    for tiling in (None, "large", "small"):
-        got = ops.conv2d(nhwc(x).cuda(), pc, tiling=tiling)
-        close(got, nhwc(want))
+    prev = ops.CONV_PRECISION
+    try:
+        for prec in ("f32", "f16x3"):          # exact fp32 MFMA / split-fp16 (ZS_CONV_F16X3), every tiling
+            ops.set_conv_precision(prec)
+            for tiling in (None, "large", "small"):
+                got = ops.conv2d(nhwc(x).cuda(), pc, tiling=tiling)
+                close(got, nhwc(want))
+    finally:
+        ops.set_conv_precision(prev)
 
 
-def test_conv2d_fused_epilogue_and_input_transforms():
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_conv2d_fused_epilogue_and_input_transforms(prec, monkeypatch):
     from zeroshape_amd.nn import ops, pack
+    monkeypatch.setattr(ops, "CONV_PRECISION", prec)
     g = torch.Generator().manual_seed(7)
     x = torch.randn(2, 64, 10, 10, generator=g)
     w = torch.randn(160, 64, 3, 3, generator=g) / 24

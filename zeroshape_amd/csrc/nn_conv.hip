@@ -21,6 +21,7 @@
 // taps, e.g. DPT's 2x-1), per-channel scale/shift (bias or folded BatchNorm), up to two residual
 // adds, activation (ReLU / GELU(erf) / ReLU+clamp1).
 #include "zs_common.h"
+#include "zs_split16.h"
 #include "../../include/zeroshape_hip.h"
 
 #include <math.h>
@@ -31,6 +32,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128, BK = 16, KQ = BK / 4;
 
@@ -119,7 +121,11 @@ struct AQuad { f32x4 v; bool ok; };
 // and bottleneck 1x1): the operand address is pixel * Cin + k, no tap bookkeeping and no transform, which
 // removes most of the VALU work that the fp32 MFMA pipe cannot hide.
 // MODE 0: generic taps.  MODE 2 (TM): tap-major walk, Cin % 16 == 0.  PLAIN: no input transform.
-template <bool PW, int MODE = 0, bool PLAIN = false>
+// F16: split-fp16 arithmetic (zs_split16.h).  A thread stages the quads kq_lo and kq_lo + 2 of its row -
+// exactly the eight k values the MFMA lane (row, half = kq_lo) contracts over - so it splits them
+// once into the hi / lo operand halves and stores those where the two fp32 quads went; the MFMA
+// loop then issues 3 K = 16 MFMAs per tile pair instead of 8 K = 2 ones at a quarter of the rate.
+template <bool PW, int MODE = 0, bool PLAIN = false, bool F16 = false>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     constexpr bool TM = MODE == 2;
     __shared__ f32x4 lds_a[2][KQ][BM];
@@ -200,10 +206,23 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     ra[1] = PW ? load_pw(ka1) : (TM ? load_tm(kq_lo + 2) : load_a(it1));
     rb[0] = load_b(kq_lo, prow);
     rb[1] = load_b(kq_lo + 2, prow);
-    lds_a[0][kq_lo][prow] = finish_any(ra[0]);
-    lds_a[0][kq_lo + 2][prow] = finish_any(ra[1]);
-    lds_b[0][kq_lo][prow] = rb[0];
-    lds_b[0][kq_lo + 2][prow] = rb[1];
+    auto stage = [&](int buf) {
+        if (F16) {
+            u32x4 hi, lo;
+            zs::s16::split8(finish_any(ra[0]), finish_any(ra[1]), hi, lo);
+            lds_a[buf][kq_lo][prow] = __builtin_bit_cast(f32x4, hi);
+            lds_a[buf][kq_lo + 2][prow] = __builtin_bit_cast(f32x4, lo);
+            zs::s16::split8(rb[0], rb[1], hi, lo);
+            lds_b[buf][kq_lo][prow] = __builtin_bit_cast(f32x4, hi);
+            lds_b[buf][kq_lo + 2][prow] = __builtin_bit_cast(f32x4, lo);
+        } else {
+            lds_a[buf][kq_lo][prow] = finish_any(ra[0]);
+            lds_a[buf][kq_lo + 2][prow] = finish_any(ra[1]);
+            lds_b[buf][kq_lo][prow] = rb[0];
+            lds_b[buf][kq_lo + 2][prow] = rb[1];
+        }
+    };
+    stage(0);
     __syncthreads();
 
     const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64, l32 = lane & 31, half = lane >> 5;
@@ -229,6 +248,20 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
             rb[0] = load_b((ks + 1) * KQ + kq_lo, prow);
             rb[1] = load_b((ks + 1) * KQ + kq_lo + 2, prow);
         }
+        if (F16) {
+            u32x4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                ah[i] = __builtin_bit_cast(u32x4, lds_a[cur][half][wm + 32 * i + l32]);
+                al[i] = __builtin_bit_cast(u32x4, lds_a[cur][2 + half][wm + 32 * i + l32]);
+                bh[i] = __builtin_bit_cast(u32x4, lds_b[cur][half][wn + 32 * i + l32]);
+                bl[i] = __builtin_bit_cast(u32x4, lds_b[cur][2 + half][wn + 32 * i + l32]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) zs::s16::mfma3(acc[i][j], ah[i], al[i], bh[j], bl[j]);
+        } else
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             f32x4 fa[2], fb[2];
@@ -244,12 +277,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
                     for (int j = 0; j < 2; j++)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
         }
-        if (more) {
-            lds_a[cur ^ 1][kq_lo][prow] = finish_any(ra[0]);
-            lds_a[cur ^ 1][kq_lo + 2][prow] = finish_any(ra[1]);
-            lds_b[cur ^ 1][kq_lo][prow] = rb[0];
-            lds_b[cur ^ 1][kq_lo + 2][prow] = rb[1];
-        }
+        if (more) stage(cur ^ 1);
         __syncthreads();
     }
 
@@ -286,7 +314,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 constexpr int SM = 32, SU = 4;       // tile rows, and t-steps (8 k each) per prefetch chunk
 // NJ = 32-column MFMA tiles per wave: the tile is 32 x 32*NJ (NJ = 1 when even 32x64 tiles leave CUs idle)
 
-template <int NJ, bool PW, int MODE = 0, bool PLAIN = false>
+// F16: two consecutive t-steps give a lane the eight k values of one K = 16 MFMA operand (A and B in
+// the same order), split into hi / lo halves in registers.
+template <int NJ, bool PW, int MODE = 0, bool PLAIN = false, bool F16 = false>
 __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
     constexpr bool TM = MODE == 2;            // tap-major walk, Cin % 8 == 0
     constexpr int SN = 32 * NJ;
@@ -359,14 +389,33 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
             for (int j = 0; j < NJ; j++) fb[buf][u][j] = wlane[(size_t)kq * a.CoutPad + 32 * j];
         }
     };
+    auto a_quad = [&](int buf, int u) -> f32x4 {
+        f32x4 av;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            av[e] = (PW || PLAIN) ? (fa[buf][u].ok ? fa[buf][u].v[e] : 0.f)
+                                  : (fa[buf][u].ok ? fmaxf(fa[buf][u].v[e], relu_floor) * a.in_scale + a.in_shift : 0.f);
+        return av;
+    };
     auto consume = [&](int buf) {
+        if (F16) {
+            static_assert(SU % 2 == 0, "pairs of t-steps");
+#pragma unroll
+            for (int u = 0; u < SU; u += 2) {
+                u32x4 ah, al;
+                zs::s16::split8(a_quad(buf, u), a_quad(buf, u + 1), ah, al);
+#pragma unroll
+                for (int j = 0; j < NJ; j++) {
+                    u32x4 bh, bl;
+                    zs::s16::split8(fb[buf][u][j], fb[buf][u + 1][j], bh, bl);
+                    zs::s16::mfma3(acc[j], ah, al, bh, bl);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < SU; u++) {
-            f32x4 av;
-#pragma unroll
-            for (int e = 0; e < 4; e++)
-                av[e] = (PW || PLAIN) ? (fa[buf][u].ok ? fa[buf][u].v[e] : 0.f)
-                                      : (fa[buf][u].ok ? fmaxf(fa[buf][u].v[e], relu_floor) * a.in_scale + a.in_shift : 0.f);
+            const f32x4 av = a_quad(buf, u);
 #pragma unroll
             for (int s = 0; s < 4; s++)
 #pragma unroll
@@ -435,12 +484,18 @@ extern "C" int zs_conv2d_nhwc(const float *in, const float *packed_w, const floa
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool plain = !a.in_relu && in_scale == 1.0f && in_shift == 0.0f;
     static const bool no_tm = getenv("ZS_CONV_NO_TAPMAJOR") != nullptr;       // A/B switch for measurements
-#define ZS_LAUNCH(KERNEL, ...)                                                              \
-    do {                                                                                    \
-        if (pw) hipLaunchKernelGGL((KERNEL<__VA_ARGS__ true>), grid, dim3(256), 0, st, a);     \
-        else if (tm && plain) hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, 2, true>), grid, dim3(256), 0, st, a);  \
-        else if (tm) hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, 2, false>), grid, dim3(256), 0, st, a);          \
-        else hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false>), grid, dim3(256), 0, st, a);      \
+    const bool f16 = (flags & ZS_CONV_F16X3) != 0;
+#define ZS_LAUNCH1(KERNEL, F, ...)                                                                                  \
+    do {                                                                                                            \
+        if (pw) hipLaunchKernelGGL((KERNEL<__VA_ARGS__ true, 0, false, F>), grid, dim3(256), 0, st, a);              \
+        else if (tm && plain) hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, 2, true, F>), grid, dim3(256), 0, st, a); \
+        else if (tm) hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, 2, false, F>), grid, dim3(256), 0, st, a);        \
+        else hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, 0, false, F>), grid, dim3(256), 0, st, a);                \
+    } while (0)
+#define ZS_LAUNCH(KERNEL, ...)                            \
+    do {                                                  \
+        if (f16) ZS_LAUNCH1(KERNEL, true, __VA_ARGS__);   \
+        else ZS_LAUNCH1(KERNEL, false, __VA_ARGS__);      \
     } while (0)
     if (small) {
         static const long long narrow_below = getenv("ZS_CONV_NARROW_BELOW") ? atoll(getenv("ZS_CONV_NARROW_BELOW")) : 384;
@@ -459,6 +514,7 @@ extern "C" int zs_conv2d_nhwc(const float *in, const float *packed_w, const floa
         ZS_LAUNCH(conv_gemm_kernel, );
     }
 #undef ZS_LAUNCH
+#undef ZS_LAUNCH1
     return zs::check_launch("zs_conv2d_nhwc") ? 1 : 0;
 }
 

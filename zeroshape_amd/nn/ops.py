@@ -1,5 +1,7 @@
 """Launch wrappers for the encoder layers (include/zeroshape_hip.h, "Encoder layers").
 Tensors are fp32 channels-last GPU tensors [B,H,W,C]; token matrices are [B,L,C]."""
+import os
+
 import torch
 
 from .. import _lib
@@ -19,6 +21,18 @@ def _stream(t):
 
 _TILING = {None: 0, "large": 2, "small": 4}
 
+# Arithmetic of the inference convolutions / linear layers (zs_conv2d_nhwc): "f32" = exact fp32 MFMA,
+# "f16x3" = split-fp16 on the 16-bit matrix pipe (ZS_CONV_F16X3; operands as two fp16 halves, ~2^-21
+# relative, saturating at |x| = 131008).  The training path (nn/autograd.py) is always fp32.
+CONV_PRECISION = os.environ.get("ZS_ENCODER_PRECISION", "f16x3")
+
+
+def set_conv_precision(p):
+    global CONV_PRECISION
+    if p not in ("f32", "f16x3"):
+        raise ValueError("conv precision must be 'f32' or 'f16x3', got %r" % (p,))
+    CONV_PRECISION = p
+
 
 def conv2d(x, pc, res1=None, res2=None, act=ACT_NONE, in_relu=False, in_scale=1.0, in_shift=0.0, tiling=None):
     """x [B,H,W,Cin] -> [B,Ho,Wo,Cout] with the fused epilogue of zs_conv2d_nhwc.  `tiling`
@@ -37,7 +51,8 @@ def conv2d(x, pc, res1=None, res2=None, act=ACT_NONE, in_relu=False, in_scale=1.
     with torch.cuda.device(x.device):
         _lib.check(lib.zs_conv2d_nhwc(_lib.ptr(x), _lib.ptr(pc.w), _lib.ptr(pc.scale), _lib.ptr(pc.shift),
                                       _lib.ptr(res1), _lib.ptr(res2), _lib.ptr(out), B, H, W, C, Ho, Wo, pc.cout,
-                                      pc.kh, pc.kw, pc.stride, pt, pl, (1 if in_relu else 0) | _TILING[tiling],
+                                      pc.kh, pc.kw, pc.stride, pt, pl,
+                                      (1 if in_relu else 0) | _TILING[tiling] | (16 if CONV_PRECISION == "f16x3" else 0),
                                       float(in_scale),
                                       float(in_shift), act, _stream(x)), "zs_conv2d_nhwc")
     return out
