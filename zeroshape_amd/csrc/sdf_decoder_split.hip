@@ -41,6 +41,7 @@
 #include "zs_common.h"
 #include "sdf_layout.h"
 #include "sdf_math.h"
+#include "zs_split16.h"
 #include "../../include/zeroshape_hip.h"
 
 #include <math.h>
@@ -57,7 +58,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int WAVES = 4;
 constexpr int PTS_PER_WAVE = 32;
@@ -98,20 +98,10 @@ static_assert(P_BLK_STRIDE <= PRM_WINDOW && W_IB - W_IA <= PRM_WINDOW && P_USED 
 // independent VALU work is around - either way the LDS latency is exposed at every K-block.
 DEV void pin(u32x4 &a, u32x4 &b) { asm volatile("" : "+v"(a), "+v"(b) : : "memory"); }
 
-DEV f16x8 as_h(const u32x4 &v) { return __builtin_bit_cast(f16x8, v); }
-DEV unsigned pk_f16(float a, float b) {  // v_cvt_pkrtz_f16_f32: toward zero, saturating at +-65504
-    return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
-}
-// two fp32 values -> packed fp16 heads and packed fp16 remainders: x ~= hi + lo to ~2^-21.
-// The remainder x - hi comes from one v_fma_mix_f32 per value (fp16 operand read in place from
-// the packed register, exact in fp32): 2 VALU instructions per value.
-DEV void split2(float a, float b, unsigned &h, unsigned &l) {
-    h = pk_f16(a, b);
-    float ra, rb;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(h), "v"(a));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(h), "v"(b));
-    l = pk_f16(ra, rb);
-}
+// as_h / pk_f16 / split2 (x -> packed fp16 hi, lo: v_cvt_pkrtz_f16_f32 + v_fma_mix_f32, 2 VALU per
+// value) / mfma3: csrc/zs_split16.h, shared with the convolution engine
+using zs::s16::mfma3;
+using zs::s16::split2;
 
 // a 32-feature x 32-point activation tile as the B operands of its two K-blocks:
 // v[2 j + 0] = hi, v[2 j + 1] = lo of K-block j (accumulator registers 8 j .. 8 j + 7)
@@ -231,14 +221,10 @@ struct Slab {
     }
 };
 
-// One K-block: three dependent MFMAs on one accumulator.  A dependent v_mfma_f32_32x32x16_f16
-// issues 32 cycles behind its producer (tools/ubench/mfma_f16_stream.hip: one chain and two
-// alternating chains both run 96.1 cycles per K-block), so a second chain buys nothing.
-DEV void mfma3(f32x16 &acc, const u32x4 &ahi, const u32x4 &alo, const u32x4 &bhi, const u32x4 &blo) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(alo), as_h(bhi), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(ahi), as_h(blo), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(ahi), as_h(bhi), acc, 0, 0, 0);
-}
+// One K-block = zs::s16::mfma3: three dependent MFMAs on one accumulator.  A dependent
+// v_mfma_f32_32x32x16_f16 issues 32 cycles behind its producer (tools/ubench/mfma_f16_stream.hip:
+// one chain and two alternating chains both run 96.1 cycles per K-block), so a second chain buys
+// nothing.
 DEV f32x16 zero16() {
     f32x16 v;
 #pragma unroll

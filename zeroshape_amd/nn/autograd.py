@@ -9,12 +9,21 @@ change (zs_pack_conv_weight), so optimiser steps need no host work.
 Reference behaviour reproduced: what torch.autograd gives train.py for Graph.forward(training=True)
 (model/compute_graph/graph_shape.py:115-204) and Loss.shape_loss (utils/loss.py:18-28).
 """
+import os
+
 import torch
 
 from .. import _lib
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_CLAMP1, ACT_SOFTPLUS = 0, 1, 2, 3, 4
 _CONV_IN_RELU, _CONV_IN_DILATE2 = 1, 8
+_CONV_F16X3 = 16
+# Arithmetic of the FORWARD convolutions / linear layers of the training path: "f32" (default) or
+# "f16x3" = split-fp16 (opt-in: 15.4 -> 14.4 ms forward per step at batch 4, but the 1e-6 forward
+# differences are amplified by the batch-statistics BatchNorms to ~2e-3 relative in some gradients,
+# beyond this repository's gradient parity bar).  The data- and weight-gradient GEMMs are always
+# exact fp32: gradient magnitudes reach far below fp16's range.
+FWD_CONV_PRECISION = os.environ.get("ZS_TRAIN_FWD_PRECISION", "f32")
 
 # Bumped whenever parameters are updated through raw pointers (the fused optimiser): tensor
 # ._version does not see those writes, so every pack cache also keys on this counter.
@@ -242,7 +251,7 @@ class _Conv(torch.autograd.Function):
         Ho, pt = _out_size(H, kh, stride, padding)
         Wo, pl = _out_size(W, kw, stride, padding)
         out = torch.empty(B, Ho, Wo, cout, dtype=torch.float32, device=x.device)
-        flags = _CONV_IN_RELU if cfg.get("in_relu") else 0
+        flags = (_CONV_IN_RELU if cfg.get("in_relu") else 0) | (_CONV_F16X3 if FWD_CONV_PRECISION == "f16x3" else 0)
         _conv_launch(x, _pack(weight, cin0, cin, False, std_eps), None if bias is None else bias.detach(),
                      None if res1 is None else _f32c(res1, "res1"), None if res2 is None else _f32c(res2, "res2"),
                      out, kh, kw, stride, pt, pl, flags, cfg.get("in_scale", 1.0), cfg.get("in_shift", 0.0), act)
