@@ -26,7 +26,9 @@ def net(seeded_sd):
                  n_blocks_attn=syn.ATT_BLOCKS, n_layers_mlp=syn.MLP_LAYERS, num_heads=syn.NUM_HEADS,
                  posenc_3D=0, mlp_ratio=syn.MLP_RATIO, skip_in=list(syn.SKIP_IN), pos_perlayer=False)
     m.load_state_dict(seeded_sd, strict=True)
-    return m.cuda().eval()
+    m = m.cuda().eval()
+    m.precision = "f32"          # this file pins the exact-fp32 kernels; test_gpu_decoder_split.py the default
+    return m
 
 
 def test_state_dict_contract(net, seeded_sd):

@@ -98,6 +98,7 @@ def test_eval_metrics_split_fp16_decoder_within_contract(net):
     gt = torch.from_numpy(syn.seeded_cloud(5, 2, 1500, -1, 1))
     pose = torch.eye(3, 4)[None].repeat(2, 1, 1)
     out = {}
+    prev = net.precision
     try:
         for prec in ("f32", "f16x3"):
             net.precision = prec
@@ -105,7 +106,7 @@ def test_eval_metrics_split_fp16_decoder_within_contract(net):
             E.eval_metrics(_opt(N, False, P), var, net)
             out[prec] = var
     finally:
-        net.precision = "f32"
+        net.precision = prev
     a, b = out["f32"], out["f16x3"]
     assert float((a.cd_acc - b.cd_acc).abs().max()) < 1e-4
     assert float((a.cd_comp - b.cd_comp).abs().max()) < 1e-4
