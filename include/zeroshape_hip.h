@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 18
+#define ZS_ABI_VERSION 19
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -447,6 +447,10 @@ int zs_bce_logits_bwd(const float *logits, const float *sdf, size_t n, float imp
  *       the median element, the deviations and the 2x2 least-squares solve, like torch.autograd.
  *   zs_intr_loss(_bwd) : Loss.intr_loss (utils/loss.py:36-43): seen_* [n][3], mask [n] over the
  *       whole batch; out2 = (loss, sum of the mask) on the device. */
+/* MidasLoss.erode_mask (model/depth/midas_loss.py:153-162; training.depth_loss.mask_shrink):
+ * out[b][y][x] = 1 iff every value of the pool x pool block of mask[b] that holds (y, x) equals 1
+ * (max_pool2d with stride = kernel, then F.interpolate(mode='nearest') back), else 0.  [B][H][W] fp32. */
+int zs_erode_mask(const float *mask, int batch, int H, int W, int pool, float *out, void *stream);
 size_t zs_midas_loss_workspace_bytes(int batch);
 int zs_midas_loss(const float *prediction, const float *target, const float *mask, int batch, int H, int W, float alpha,
                   int scales, int inverse_depth, float *loss, void *workspace, void *stream);

@@ -64,9 +64,18 @@ def gradient_loss_image_based(prediction, target, mask):
     return image_loss.mean()
 
 
-def midas_loss(prediction_raw, target_raw, mask_raw, alpha=0.1, scales=4, inverse_depth=True):
-    """MidasLoss.forward (:166-185), shrink_mask False; inputs [B,1,H,W]."""
-    valid = mask_raw > 0.5
+def erode_mask(mask, max_pool_size=4):
+    """MidasLoss.erode_mask (:153-162): valid iff the whole 4x4 block is valid."""
+    h, w = mask.shape[2], mask.shape[3]
+    m = 1 - mask.float()
+    m = torch.nn.functional.max_pool2d(m, kernel_size=max_pool_size)
+    m = torch.nn.functional.interpolate(m, (h, w), mode="nearest")
+    return m == 0
+
+
+def midas_loss(prediction_raw, target_raw, mask_raw, alpha=0.1, scales=4, inverse_depth=True, shrink_mask=False):
+    """MidasLoss.forward (:164-185); inputs [B,1,H,W]."""
+    valid = erode_mask(mask_raw) if shrink_mask else mask_raw > 0.5
     total = ssi_mae(prediction_raw, target_raw, valid)
     if alpha <= 0:
         return total

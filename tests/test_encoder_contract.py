@@ -82,8 +82,8 @@ def test_unsupported_configurations_raise():
     from zeroshape_amd.utils.loss import Loss
     lopt = edict(training=dict(shape_loss=dict(impt_weight=1, impt_thres=0.01),
                                depth_loss=dict(grad_reg=0.1, depth_inv=True, mask_shrink=True)))
-    with pytest.raises(NotImplementedError):              # eroded masks: not on the HIP path
-        Loss(lopt).depth_loss(torch.zeros(1, 1, 2, 2), torch.zeros(1, 1, 2, 2), torch.zeros(1, 1, 2, 2))
+    with pytest.raises(ValueError):                       # eroded masks run on the GPU too: no CPU path
+        Loss(lopt).depth_loss(torch.zeros(1, 1, 8, 8), torch.zeros(1, 1, 8, 8), torch.zeros(1, 1, 8, 8))
     with pytest.raises(NotImplementedError):              # train mode: BN folding is eval-only
         g.dpt_depth.train().packed("cpu")
 

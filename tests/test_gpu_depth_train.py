@@ -117,3 +117,34 @@ def test_depth_engine_trains(tmp_path, encoder_sd):
     r.save_checkpoint(opt, ep=0, it=r.it, latest=True)
     ck = torch.load(os.path.join(opt.output_path, "latest.ckpt"), map_location="cpu")
     assert "optim" in ck and set(k.split(".")[0] for k in ck["graph"]) == {"dpt_depth", "intr_head", "intr_proj"}
+
+
+def test_mask_shrink_matches_reference_golden_and_oracle():
+    """training.depth_loss.mask_shrink: zs_erode_mask bit for bit (golden of MidasLoss.erode_mask and the
+    oracle on ragged sizes / fractional masks), and Loss.depth_loss on the eroded mask vs the golden."""
+    from make_loss_golden import inputs
+    from zeroshape_amd.nn import autograd as A
+    from zeroshape_amd.utils.loss import Loss
+    from zeroshape_amd.utils.options import EasyDict as edict
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "loss_golden.npz")))
+    pred, target, mask, _, _, _ = inputs()
+    er = A.erode_mask(mask.cuda())
+    assert er.shape == mask.shape and int(er.sum()) == int(g["eroded_count"])
+    np.testing.assert_array_equal(np.packbits(er.cpu().numpy().reshape(-1) > 0.5), g["eroded_bits"])
+    gen = torch.Generator().manual_seed(3)
+    for shape in ((2, 1, 9, 13), (1, 1, 4, 4), (3, 1, 31, 18), (1, 1, 225, 227)):
+        m = (torch.rand(shape, generator=gen) > 0.1).float()
+        m[0, 0, 0, 0] = 0.75                                   # fractional values are not "valid"
+        want = R.erode_mask(m).float()
+        assert torch.equal(A.erode_mask(m.cuda()).cpu(), want), shape
+    opt = edict(training=edict(shape_loss=edict(impt_weight=1, impt_thres=0.01),
+                               depth_loss=edict(grad_reg=0.1, depth_inv=True, mask_shrink=True)))
+    p = pred.cuda().requires_grad_(True)
+    loss = Loss(opt).depth_loss(p, target.cuda(), mask.cuda())
+    assert abs(float(loss) - float(g["depth_loss_shrink"])) < 2e-5 * float(g["depth_loss_shrink"])
+    loss.backward()
+    np.testing.assert_allclose(p.grad.reshape(-1)[::97].cpu().numpy(), g["depth_grad_shrink_s97"],
+                               atol=5e-5 * float(np.abs(g["depth_grad_shrink_s97"]).max()))
+    from zeroshape_amd import _lib
+    with pytest.raises(_lib.ZeroShapeHipError):
+        A.erode_mask(torch.ones(1, 1, 3, 8).cuda())            # smaller than one pool window

@@ -39,3 +39,19 @@ def test_midas_and_intr_loss_match_reference():
     np.testing.assert_allclose(p.grad.reshape(-1)[::97].numpy(), g["depth_grad_empty_s97"],
                                atol=2e-5 * float(np.abs(g["depth_grad_empty_s97"]).max()))
     assert float(p.grad[1].abs().max()) == 0
+
+
+def test_mask_shrink_matches_reference():
+    """training.depth_loss.mask_shrink: MidasLoss.erode_mask + the loss on the eroded mask."""
+    from make_loss_golden import inputs
+    g = golden()
+    pred, target, mask, _, _, _ = inputs()
+    er = R.erode_mask(mask)
+    assert int(er.sum()) == int(g["eroded_count"])
+    np.testing.assert_array_equal(np.packbits(er.numpy().reshape(-1)), g["eroded_bits"])
+    p = pred.clone().requires_grad_(True)
+    l = R.midas_loss(p, target, mask, shrink_mask=True)
+    l.backward()
+    assert abs(float(l) - float(g["depth_loss_shrink"])) < 1e-6
+    np.testing.assert_allclose(p.grad.reshape(-1)[::97].numpy(), g["depth_grad_shrink_s97"],
+                               atol=2e-5 * float(np.abs(g["depth_grad_shrink_s97"]).max()))

@@ -309,6 +309,39 @@ __global__ __launch_bounds__(256) void intr_loss_bwd_kernel(const float *__restr
         }                                \
     } while (0)
 
+// MidasLoss.erode_mask (model/depth/midas_loss.py:153-162): a pixel stays valid iff every mask value
+// of its pool x pool block (max_pool2d, stride = kernel, floor) equals 1; pixels map to blocks the
+// way F.interpolate(mode='nearest') maps them back: src = min(floor(dst * (float)(in / out)), in - 1).
+__global__ __launch_bounds__(256) void erode_mask_kernel(const float *__restrict__ mask, int batch, int H, int W,
+                                                         int pool, float *__restrict__ out) {
+    const int Hp = H / pool, Wp = W / pool;
+    const float sy = (float)Hp / (float)H, sx = (float)Wp / (float)W;
+    const size_t n = (size_t)batch * H * W;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const int x = (int)(e % W), y = (int)((e / W) % H);
+        const size_t b = e / ((size_t)W * H);
+        const int by = min((int)floorf(y * sy), Hp - 1), bx = min((int)floorf(x * sx), Wp - 1);
+        const float *M = mask + b * H * W + (size_t)by * pool * W + bx * pool;
+        bool ok = true;
+        for (int i = 0; i < pool; i++)
+            for (int j = 0; j < pool; j++) ok = ok && (1.0f - M[(size_t)i * W + j] == 0.0f);
+        out[e] = ok ? 1.0f : 0.0f;
+    }
+}
+
+extern "C" int zs_erode_mask(const float *mask, int batch, int H, int W, int pool, float *out, void *stream) {
+    ZS_REQUIRE(batch >= 0 && H > 0 && W > 0 && pool > 0 && H >= pool && W >= pool,
+               "zs_erode_mask: bad arguments (B=%d H=%d W=%d pool=%d; the map must hold one pool window)", batch, H, W,
+               pool);
+    if (batch == 0) return 1;
+    ZS_REQUIRE(mask && out, "zs_erode_mask: null pointer");
+    const size_t n = (size_t)batch * H * W;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(erode_mask_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), mask, batch, H,
+                       W, pool, out);
+    return zs::check_launch("zs_erode_mask") ? 1 : 0;
+}
+
 extern "C" size_t zs_midas_loss_workspace_bytes(int batch) { return ((size_t)batch * S_STRIDE + 4) * sizeof(float); }
 
 extern "C" int zs_midas_loss(const float *prediction, const float *target, const float *mask, int batch, int H, int W,

@@ -988,6 +988,18 @@ class _MidasLoss(torch.autograd.Function):
         return dp, None, None, None, None, None
 
 
+@torch.no_grad()
+def erode_mask(mask, pool=4):
+    """MidasLoss.erode_mask (model/depth/midas_loss.py:153-162): [B,1,H,W] -> [B,1,H,W] in {0, 1}."""
+    lib = _lib.load()
+    m = _f32c(mask.float(), "mask")
+    B, _, H, W = m.shape
+    out = torch.empty_like(m)
+    with torch.cuda.device(m.device):
+        _lib.check(lib.zs_erode_mask(_lib.ptr(m), B, H, W, pool, _lib.ptr(out), _stream(m)), "zs_erode_mask")
+    return out
+
+
 def midas_loss(prediction, target, mask, alpha=0.1, scales=4, inverse_depth=True):
     return _MidasLoss.apply(prediction, target, mask, alpha, scales, inverse_depth)
 

@@ -7,8 +7,8 @@
   intr_loss(seen_pred, seen_gt [B,HW,3], mask [B,HW])     utils/loss.py:36-43   zs_intr_loss(+_bwd)
 
 The shape recipe (options/shape.yaml:84-87) trains with the shape loss only; options/depth.yaml
-with depth + 10 x intr.  training.depth_loss.mask_shrink (min-pooled masks, false in both yaml files)
-raises - never silently approximated."""
+with depth + 10 x intr.  training.depth_loss.mask_shrink (min-pooled masks, false in both yaml files):
+zs_erode_mask in front of the loss."""
 from copy import deepcopy
 
 import torch.nn as nn
@@ -31,8 +31,8 @@ class Loss(nn.Module):
         assert len(pred_depth.shape) == len(gt_depth.shape) == len(mask.shape) == 4
         assert pred_depth.shape[1] == gt_depth.shape[1] == mask.shape[1] == 1
         dl = self.opt.training.depth_loss
-        if dl.mask_shrink:
-            raise NotImplementedError("training.depth_loss.mask_shrink (eroded masks) is not on the HIP path")
+        if dl.mask_shrink:                      # midas_loss.py:153-166: min-pooled (4 x 4) validity
+            mask = A.erode_mask(mask)
         return A.midas_loss(pred_depth, gt_depth, mask, alpha=float(dl.grad_reg), scales=4, inverse_depth=bool(dl.depth_inv))
 
     def intr_loss(self, seen_pred, seen_gt, mask):
