@@ -143,8 +143,8 @@ int zs_sdf_query_grid(const void *programs, size_t program_stride_bytes, int bat
 
 /* Split-fp16 ("f16x3") decoder: the same network with every contraction on the 16-bit matrix
  * pipe, both operands split into two fp16 halves (A B ~= Ah Bh + Ah Bl + Al Bh, fp32
- * accumulation; halves rounded toward zero, saturating at +-65504, i.e. |x| <= 131008 and
- * ~2^-21 relative operand error): max |logit difference| to the exact-fp32 kernels ~3e-6
+ * accumulation; halves rounded toward zero, saturating at +-65504: ~2^-21 relative operand error
+ * for |x| <= 65504): max |logit difference| to the exact-fp32 kernels ~3e-6
  * (contract 1e-4), 2.6x their throughput.
  *   zs_sdf_split_programs     fp32 programs (after zs_sdf_prologue) -> split programs of the
  *                             same size and stride rules (split_programs must not alias programs)
@@ -300,7 +300,7 @@ int zs_depth_metrics(const float *prediction, const float *target, const float *
 #define ZS_CONV_FORCE_LARGE 2 /* tiling override (tests / tuning): 128x128 tiles */
 #define ZS_CONV_FORCE_SMALL 4 /* 32x64 tiles with the K range split over the 4 waves */
 #define ZS_CONV_F16X3 16      /* split-fp16 arithmetic on the 16-bit matrix pipe (csrc/zs_split16.h): operands
-                               carried as two fp16 halves (~2^-21 relative, |x| <= 131008), three
+                               carried as two fp16 halves (~2^-21 relative for 2e-4 <~ |x| <= 65504), three
                                K = 16 MFMAs per eight fp32 ones; inference */
 #define ZS_CONV_IN_DILATE2 8  /* read the input as if zero-stuffed x2 ([B][2H-1][2W-1][Cin] virtual): the
                                  data gradient of a stride-2 convolution as a stride-1 convolution */

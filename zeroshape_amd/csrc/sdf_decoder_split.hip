@@ -9,8 +9,9 @@
 // cycles at ~2^-21 relative operand error: max |logit difference| to the fp32 kernel 3.4e-6 and
 // no occupancy flip on the 129^3 grid (fp32 itself is 1e-6 from fp64; the same scheme on bf16
 // halves, same cost, measured 1.9e-5 and 10 flips; plain bf16 8e-3).  Halves are rounded toward
-// zero (v_cvt_pkrtz_f16_f32), which also saturates instead of overflowing: |x| <= 131,008 is
-// representable, far beyond what LayerNorm-ed activations and these weights reach; values below
+// zero (v_cvt_pkrtz_f16_f32), which also saturates instead of overflowing: |x| <= 65,504 keeps the
+// full precision (to 131,008 representable at fp16 precision), far beyond what LayerNorm-ed
+// activations and these weights reach; values below
 // ~1e-4 lose relative (not absolute) precision to fp16 subnormals.  tests/test_gpu_decoder_split.py.
 //
 // What changes against the fp32 kernel, and why:

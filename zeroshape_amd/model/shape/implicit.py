@@ -121,7 +121,7 @@ class Implicit(nn.Module):
         # .precision = "f32" selects the exact one): "f32" = exact fp32 MFMA (bitwise an fmaf
         # chain); "f16x3" = split-fp16 on the 16-bit matrix pipe (csrc/sdf_decoder_split.hip:
         # |logit difference| ~3e-6 to the fp32 kernel, contract 1e-4, 2.6x faster; operands
-        # saturate at |x| = 131008).  The attention map and the training path always use fp32.
+        # keep full precision for |x| <= 65504 and saturate beyond 131008).  The attention map and the training path always use fp32.
         self.precision = os.environ.get("ZS_DECODER_PRECISION", "f16x3")
         self._workspace = {}      # device -> scratch tensor for the query kernels
 

@@ -23,7 +23,7 @@ _TILING = {None: 0, "large": 2, "small": 4}
 
 # Arithmetic of the inference convolutions / linear layers (zs_conv2d_nhwc): "f32" = exact fp32 MFMA,
 # "f16x3" = split-fp16 on the 16-bit matrix pipe (ZS_CONV_F16X3; operands as two fp16 halves, ~2^-21
-# relative, saturating at |x| = 131008).  The training path (nn/autograd.py) is always fp32.
+# relative for 2e-4 <~ |x| <= 65504, saturating beyond 131008).  The training path (nn/autograd.py) is always fp32.
 CONV_PRECISION = os.environ.get("ZS_ENCODER_PRECISION", "f16x3")
 
 
