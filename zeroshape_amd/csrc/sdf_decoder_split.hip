@@ -439,7 +439,7 @@ DEV void attn_tile(AStream &s, const PT &q, f32x16 &o, float &m_run, float &z_ru
 #define ZS_STAMP(i) do { } while (0)
 #endif
 // One wave: 32 points (lane & 31; both lane halves carry the same point).
-DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage_addr, u32x4 *fl_,
+DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage_addr, u32x4 *slab,
                       f32x4 *zs, float px, float py, float pz, int wave, int lane,
                       unsigned long long *dbg) {
     const int hi = lane >> 5;
@@ -447,7 +447,7 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
     AStream s;
     s.init(prog, stage, stage_addr, wave, lane);
     Slab sl;
-    sl.fl = fl_;
+    sl.fl = slab;
     ZS_STAMP(0);
 
     // point_proj (implicit.py:128-131); y is the residual stream, kept as accumulators
@@ -784,7 +784,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void sdf_decode_split_kernel(
 // kernel runs a software pipeline over the 32 hidden tiles (fc1 of tile t+1 before fc2 of tile
 // t): fc1(0), [fc1(1), fc2(0)], ..., [fc1(31), fc2(30)], fc2(31), 16 K-blocks each.
 __host__ __device__ inline int split_source_kblock(int kb) {
-    constexpr int KB_BLOCK = G_BLOCK / 2, KB_ATT = HEADS * G_HEAD / 2, KB_MLP = HT * G_MLP_TILE / 2;
+    constexpr int KB_BLOCK = G_BLOCK / 2, KB_ATT = HEADS * G_HEAD / 2;
+    static_assert(KB_BLOCK - KB_ATT == HT * 32, "an MLP section is 32 K-blocks per hidden tile");
     if (kb >= BLOCKS * KB_BLOCK) return kb;
     const int blk = kb / KB_BLOCK, p = kb - blk * KB_BLOCK - KB_ATT;
     if (p < 16) return kb;  // attention section, or fc1(0)
@@ -794,7 +795,6 @@ __host__ __device__ inline int split_source_kblock(int kb) {
         src = r < 16 ? (it + 1) * 32 + r : it * 32 + r;  // fc1(it + 1) | fc2(it)
     else
         src = it * 32 + 16 + r;                          // fc2(31)
-    (void)KB_MLP;
     return blk * KB_BLOCK + KB_ATT + src;
 }
 
