@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 19
+#define ZS_ABI_VERSION 20
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -125,10 +125,14 @@ int zs_sdf_prologue(void *programs, size_t program_stride_bytes, const float *la
  * attn (optional, may be NULL): [batch][m][197] = mean over heads and blocks of the
  * point->latent attention probabilities (implicit.py:63,79,277; the self column is
  * excluded after the softmax over 198, so rows sum to < 1).  When given, `workspace` must
- * hold zs_sdf_workspace_bytes() + zs_sdf_attn_scratch_bytes(batch, m) bytes. */
+ * hold zs_sdf_workspace_bytes() + zs_sdf_attn_scratch_bytes(batch, m) bytes.
+ * tile_mask (optional, NULL = every tile; here and in the two grid entry points below):
+ * int32[batch * ceil(m / 128)], one entry per 128-point tile of each image in point order; a zero
+ * entry leaves that tile's outputs untouched.  It is how the exact-fp32 kernel re-evaluates the
+ * tiles the split-fp16 kernel flagged (see below); not combinable with attn. */
 int zs_sdf_query_points(const void *programs, size_t program_stride_bytes, int batch,
                         const float *points, int m, float *logits, float *attn,
-                        void *workspace, void *stream);
+                        const int *tile_mask, void *workspace, void *stream);
 
 /* Dense-grid query without materialising the points tensor.  Evaluates x-slices
  * [slice_begin, slice_end) of the G^3 grid (G = vox_res+1 samples per axis; coordinate
@@ -139,7 +143,8 @@ int zs_sdf_query_points(const void *programs, size_t program_stride_bytes, int b
  * return), else the logit. */
 int zs_sdf_query_grid(const void *programs, size_t program_stride_bytes, int batch,
                       const float *axis, int G, int slice_begin, int slice_end,
-                      int apply_sigmoid, float *out, void *workspace, void *stream);
+                      int apply_sigmoid, float *out, const int *tile_mask, void *workspace,
+                      void *stream);
 
 /* Split-fp16 ("f16x3") decoder: the same network with every contraction on the 16-bit matrix
  * pipe, both operands split into two fp16 halves (A B ~= Ah Bh + Ah Bl + Al Bh, fp32
@@ -150,15 +155,23 @@ int zs_sdf_query_grid(const void *programs, size_t program_stride_bytes, int bat
  *                             same size and stride rules (split_programs must not alias programs)
  *   zs_sdf_query_points_split / zs_sdf_query_grid_split
  *                             as zs_sdf_query_points (without the attention map) / _grid, on
- *                             split programs; same workspace */
+ *                             split programs; same workspace
+ * Envelope guard.  The operand error acts on the attention logits in absolute terms,
+ * |dS| <= 2.5 * 2^-21 * d^-1/2 |q| |k|, and operands beyond +-65504 saturate.  tile_flags (optional,
+ * NULL = no guard): int32[batch * ceil(m / 128)] ZEROED by the caller; the kernel sets the entry
+ * of every 128-point tile in which some point and head reach d^-1/2 |q| max_l |k_l| > 64, or whose
+ * program holds an operand that is not finite or outside the fp16 range (those tiles' outputs
+ * are NaN).  Passing the same array as tile_mask to the exact-fp32 entry point on the same
+ * stream re-evaluates exactly those tiles - no host round trip (Implicit.query_* does this). */
 int zs_sdf_split_programs(const void *programs, size_t program_stride_bytes, void *split_programs,
                           size_t split_stride_bytes, int batch, void *stream);
 int zs_sdf_query_points_split(const void *split_programs, size_t program_stride_bytes, int batch,
-                              const float *points, int m, float *logits, void *workspace,
-                              void *stream);
+                              const float *points, int m, float *logits, int *tile_flags,
+                              void *workspace, void *stream);
 int zs_sdf_query_grid_split(const void *split_programs, size_t program_stride_bytes, int batch,
                             const float *axis, int G, int slice_begin, int slice_end,
-                            int apply_sigmoid, float *out, void *workspace, void *stream);
+                            int apply_sigmoid, float *out, int *tile_flags, void *workspace,
+                            void *stream);
 
 /* As zs_sdf_query_grid / zs_sdf_query_grid_split, for the points [point_begin, point_end) of
  * the grid in its memory order (x slowest, z fastest): out[batch][point_end - point_begin].
@@ -166,11 +179,12 @@ int zs_sdf_query_grid_split(const void *split_programs, size_t program_stride_by
  * instead of whole x-slices (129 slices over 8 ranks would leave 17-17-...-10). */
 int zs_sdf_query_grid_range(const void *programs, size_t program_stride_bytes, int batch,
                             const float *axis, int G, long long point_begin, long long point_end,
-                            int apply_sigmoid, float *out, void *workspace, void *stream);
+                            int apply_sigmoid, float *out, const int *tile_mask, void *workspace,
+                            void *stream);
 int zs_sdf_query_grid_range_split(const void *split_programs, size_t program_stride_bytes, int batch,
                                   const float *axis, int G, long long point_begin,
                                   long long point_end, int apply_sigmoid, float *out,
-                                  void *workspace, void *stream);
+                                  int *tile_flags, void *workspace, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Brute-force pose search support (brute_force_search, utils/eval_3D.py:140-170).

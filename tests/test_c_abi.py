@@ -54,11 +54,11 @@ def test_argument_errors_are_reported_without_touching_the_gpu(lib):
     assert b"negative" in lib.zs_last_error()
     assert lib.zs_chamfer_forward(None, None, 1, 4, 3, None, None, None, None, None) == 0
     assert b"null" in lib.zs_last_error()
-    assert lib.zs_sdf_query_grid(None, 0, 1, None, 9, 3, 2, 1, None, None, None) == 0
+    assert lib.zs_sdf_query_grid(None, 0, 1, None, 9, 3, 2, 1, None, None, None, None) == 0
     assert b"bad range" in lib.zs_last_error()
     # empty problems succeed trivially (nothing to launch)
     assert lib.zs_chamfer_forward(None, None, 0, 4, 3, None, None, None, None, None) == 1
-    assert lib.zs_sdf_query_points(None, 0, 0, None, 5, None, None, None, None) == 1
+    assert lib.zs_sdf_query_points(None, 0, 0, None, 5, None, None, None, None, None) == 1
 
 
 def test_product_path_fails_loudly_without_library(monkeypatch):

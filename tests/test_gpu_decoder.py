@@ -138,6 +138,12 @@ def test_generic_slice_loop_equals_fused_grid(net):
     plain = grid.clone()            # loses the _zs_grid tag
     loop, _ = E.compute_level_grid(opt, net, latent, None, plain, None)
     assert torch.equal(fused, loop)
+    # a tagged tensor that was modified in place is read, not regenerated from its axis
+    moved = E.get_dense_3D_grid(opt, var)
+    moved[..., 0] += 0.25
+    got, _ = E.compute_level_grid(opt, net, latent, None, moved, None)
+    want, _ = E.compute_level_grid(opt, net, latent, None, moved.clone(), None)
+    assert torch.equal(got, want) and not torch.equal(got, fused)
 
 
 @pytest.mark.parametrize("N", [64, 128])

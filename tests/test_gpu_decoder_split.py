@@ -36,10 +36,17 @@ def test_split_program_layout(net, seeded_sd):
     f32 = net.prepare(latent, "f32")
     sp = net.prepare(latent, "f16x3")
     assert sp.precision == "f16x3" and sp.programs.shape == f32.programs.shape
+    assert sp.exact is not None and torch.equal(sp.exact, f32.programs)
+    km = slice(P.REC_FLOATS + P.P_KMAX, P.REC_FLOATS + P.P_KMAX + P.BLOCKS * P.HEADS)
     for b in range(2):
         want = P.split_program(f32.programs[b].cpu().numpy())
         got = sp.programs[b].cpu().numpy().view(np.uint32)
+        # the K-norm bounds of the envelope guard are fp32 sums on the device, fp64 in the mirror
+        np.testing.assert_allclose(got[km].view(np.float32), want[km].view(np.float32), rtol=1e-6)
+        assert 0.5 < float(got[km].view(np.float32).min())
+        got[km], want[km] = 0, 0
         np.testing.assert_array_equal(got, want)
+        assert got[P.REC_FLOATS + P.P_FLAG] == 0
 
 
 @pytest.mark.parametrize("m", [1, 31, 32, 33, 127, 128, 129, 1000])
@@ -61,9 +68,12 @@ def test_training_shape_points_vs_golden_and_fp32_kernel(net, decoder_golden):
     exact = net.query_points(net.prepare(latent, "f32"), pts)
     err = (lg - exact).abs()
     assert float(err.max()) < ATOL and float(err.mean()) < 2e-6
-    # the reference's default call (with the attention map) is served by the fp32 kernel
+    # the reference's default call (with the attention map): the map comes from the fp32 kernel,
+    # the logits are the same numbers as without it
     lg2, attn = net(latent, None, pts)
-    assert torch.equal(lg2, exact) and attn.shape == (2, 4096, 197)
+    assert torch.equal(lg2, lg) and attn.shape == (2, 4096, 197)
+    np.testing.assert_allclose(attn[:, ::512].cpu().numpy(), decoder_golden["pts4096_attn_rows"], atol=2e-7, rtol=0)
+    assert int(net.last_tile_flags.sum()) == 0            # the seeded network is inside the envelope
 
 
 def test_grid32_full_vs_golden(net, decoder_golden):
@@ -169,6 +179,7 @@ def test_other_weights_and_scales_vs_fp32_kernel(seed, gain, tol):
                  posenc_3D=0, mlp_ratio=syn.MLP_RATIO, skip_in=list(syn.SKIP_IN), pos_perlayer=False)
     m.load_state_dict(sd, strict=True)
     m = m.cuda().eval()
+    m.envelope_guard = False        # this test measures the arithmetic itself, also outside its envelope
     latent = torch.from_numpy(syn.seeded_latent(seed=seed, batch=2))
     pts = torch.from_numpy(syn.seeded_cloud(seed + 50, 2, 1500, -1.5, 1.5))
     exact = m.query_points(m.prepare(latent.cuda(), "f32"), pts.cuda())
@@ -181,3 +192,137 @@ def test_other_weights_and_scales_vs_fp32_kernel(seed, gain, tol):
     # the CPU oracle - already differ by 1.8e-4: the split arithmetic is not the limit there)
     assert float((exact.cpu() - want).abs().max()) < max(1e-4, tol) * scale
     assert float((split.cpu() - want).abs().max()) < max(1e-4, tol) * scale
+
+
+# --------------------------------------------------------------------------------------------- #
+# f16x3 on the larger goldens of the real reference (tests/golden/make_golden.py)
+# --------------------------------------------------------------------------------------------- #
+@pytest.mark.parametrize("N", [64, 128])
+def test_grid_slices_vs_golden(net, decoder_golden, N):
+    latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=2))[:1].cuda()
+    axis = torch.linspace(-1.5, 1.5, N + 1, device="cuda")
+    st = net.prepare(latent)
+    assert st.precision == "f16x3"
+    for i in (0, N // 2, N):
+        lg = net.query_grid(latent, axis, apply_sigmoid=False, slice_begin=i, slice_end=i + 1, state=st)
+        got = lg[0, 0].reshape(-1)[::16].cpu().numpy()
+        np.testing.assert_allclose(got, decoder_golden["logit%d_slice%d_s16" % (N, i)], atol=ATOL, rtol=0)
+        assert int(net.last_tile_flags.sum()) == 0
+
+
+def test_vox256_slab_and_batched_grid(net, seeded_sd):
+    """BASELINE config 5 geometry (257^3, sharded): one rank's slab of a batch of 2 images against
+    the oracle on random points; slab launches of a batch equal per-image launches."""
+    N = 256
+    latent_c = torch.from_numpy(syn.seeded_latent(seed=2, batch=2))
+    latent = latent_c.cuda()
+    axis = torch.linspace(-1.5, 1.5, N + 1, device="cuda")
+    st = net.prepare(latent)
+    slab = net.query_grid(latent, axis, apply_sigmoid=False, slice_begin=224, slice_end=226, state=st)
+    assert slab.shape == (2, 2, N + 1, N + 1)
+    one = net.query_grid(latent[1:], axis, apply_sigmoid=False, slice_begin=224, slice_end=226)
+    assert torch.equal(slab[1:], one)
+    rs = np.random.RandomState(5)
+    jj, kk = rs.randint(0, N + 1, 500), rs.randint(0, N + 1, 500)
+    ax = axis.cpu()
+    pts = torch.stack([ax[225].expand(500), ax[jj], ax[kk]], -1)[None].repeat(2, 1, 1)
+    want, _ = R.implicit_forward(seeded_sd, latent_c, pts)
+    got = slab[:, 1, jj, kk].cpu().numpy()
+    np.testing.assert_allclose(got, want.numpy(), atol=ATOL, rtol=0)
+
+
+# --------------------------------------------------------------------------------------------- #
+# envelope guard (program.py: S_GUARD, W_MAX)
+# --------------------------------------------------------------------------------------------- #
+def _scaled_net(seed, gain):
+    from zeroshape_amd.model.shape.implicit import Implicit
+    from zeroshape_amd.utils.pos_embed import get_2d_sincos_pos_embed
+    pe = get_2d_sincos_pos_embed(256, 14, cls_token=True).astype(np.float32)
+    sd = {k: torch.from_numpy(v) for k, v in syn.seeded_state_dict(seed, pos_embed=pe).items()}
+    for k in sd:
+        if k.endswith("attn.qkv.weight") or k.endswith("mlp.fc1.weight") or k.endswith("latent_proj.weight"):
+            sd[k] = sd[k] * gain
+    m = Implicit(syn.NUM_PATCHES, latent_dim=syn.LATENT_DIM, semantic=False, n_channels=syn.N_CHANNELS,
+                 n_blocks_attn=syn.ATT_BLOCKS, n_layers_mlp=syn.MLP_LAYERS, num_heads=syn.NUM_HEADS,
+                 posenc_3D=0, mlp_ratio=syn.MLP_RATIO, skip_in=list(syn.SKIP_IN), pos_perlayer=False)
+    m.load_state_dict(sd, strict=True)
+    return m.cuda().eval(), sd
+
+
+def test_guard_reevaluates_out_of_envelope_tiles_in_fp32():
+    """Attention weights x10 (|q||k| d^-1/2 in the hundreds, where the raw split arithmetic is 3e-4
+    off): the device guard flags those tiles and the exact kernel rewrites them - the guarded
+    result equals the fp32 kernel there and the split kernel elsewhere."""
+    m, sd = _scaled_net(3, 10.0)
+    latent = torch.from_numpy(syn.seeded_latent(seed=3, batch=2)).cuda()
+    pts = torch.from_numpy(syn.seeded_cloud(53, 2, 1500, -1.5, 1.5)).cuda()
+    st = m.prepare(latent)
+    assert st.precision == "f16x3"
+    guarded = m.query_points(st, pts)
+    flags = m.last_tile_flags.clone().view(2, -1).bool()
+    assert flags.shape[1] == 12 and bool(flags.any())
+    exact = m.query_points(m.prepare(latent, "f32"), pts)
+    m.envelope_guard = False
+    raw = m.query_points(st, pts)
+    per_point = flags.repeat_interleave(128, dim=1)[:, :1500]
+    assert torch.equal(guarded[per_point], exact[per_point])
+    assert torch.equal(guarded[~per_point], raw[~per_point])
+    # the flag is the documented bound: d^-1/2 |q| max_l |k_l| > S_GUARD for some head of some point
+    lp = R.latent_path(sd, latent.cpu())
+    kmax = torch.stack([lp["k%d" % b].norm(dim=-1).amax(-1) for b in range(2)], 1)          # [B, blk, head]
+    got = st.programs[:, P.REC_FLOATS + P.P_KMAX: P.REC_FLOATS + P.P_KMAX + 16].view(2, 2, 8).cpu()
+    np.testing.assert_allclose(got.numpy(), kmax.numpy(), rtol=2e-5)
+    # the same network with the seeded scale stays entirely on the split kernel
+    m1, _ = _scaled_net(3, 1.0)
+    m1.query_points(m1.prepare(latent), pts)
+    assert int(m1.last_tile_flags.sum()) == 0
+
+
+def test_guard_grid_and_range_paths():
+    m, _ = _scaled_net(2, 10.0)
+    latent = torch.from_numpy(syn.seeded_latent(seed=2, batch=1)).cuda()
+    axis = torch.linspace(-1.5, 1.5, 17, device="cuda")
+    st = m.prepare(latent)
+    g = m.query_grid(latent, axis, apply_sigmoid=True, state=st)
+    fl = m.last_tile_flags.clone().bool()
+    r = m.query_grid_range(latent, axis, 0, 17 ** 3, apply_sigmoid=True, state=st)
+    assert torch.equal(g.reshape(1, -1), r) and torch.equal(fl, m.last_tile_flags.bool()) and bool(fl.any())
+    exact = m.query_grid(latent, axis, apply_sigmoid=True, state=m.prepare(latent, "f32")).reshape(-1)
+    pp = fl.repeat_interleave(128)[: 17 ** 3]
+    assert torch.equal(g.reshape(-1)[pp], exact[pp])
+
+
+def test_non_finite_inputs_give_nan_like_the_reference(net):
+    latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=2)).cuda()
+    pts = torch.from_numpy(syn.seeded_cloud(9, 2, 300, -1, 1)).cuda()
+    bad = latent.clone()
+    bad[1, 5, 7] = float("nan")
+    st = net.prepare(bad)
+    assert int(st.programs[1].view(torch.int32)[P.REC_FLOATS + P.P_FLAG]) != 0
+    assert int(st.programs[0].view(torch.int32)[P.REC_FLOATS + P.P_FLAG]) == 0
+    out = net.query_points(st, pts)
+    assert bool(torch.isnan(out[1]).all()) and bool(torch.isfinite(out[0]).all())
+    good = net.query_points(net.prepare(latent), pts)
+    assert torch.equal(out[0], good[0])
+    # a non-finite query coordinate poisons that point only
+    p2 = pts.clone()
+    p2[0, 17, 1] = float("inf")
+    out2 = net.query_points(net.prepare(latent), p2)
+    assert bool(torch.isnan(out2[0, 17])) and int(torch.isnan(out2).sum()) == 1
+    for prec_guard in (True, False):
+        net.envelope_guard = prec_guard
+        o = net.query_points(net.prepare(bad), pts)
+        assert bool(torch.isnan(o[1]).all())
+    net.envelope_guard = True
+
+
+def test_weights_beyond_w_max_select_the_exact_kernels():
+    m, _ = _scaled_net(1, 1.0)
+    with torch.no_grad():
+        m.blocks_attn[0].mlp.fc2.weight[3, 5] = 40.0
+    latent = torch.from_numpy(syn.seeded_latent(seed=1, batch=1)).cuda()
+    st = m.prepare(latent)                 # asked for the default (f16x3), got the exact kernels
+    assert st.precision == "f32" and st.exact is None
+    with torch.no_grad():
+        m.blocks_attn[0].mlp.fc2.weight[3, 5] = 0.04
+    assert m.prepare(latent).precision == "f16x3"

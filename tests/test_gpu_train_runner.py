@@ -133,3 +133,27 @@ def test_grad_reducer_rehearsal_on_one_gpu(tmp_path, encoder_sd, seeded_sd):
             assert torch.equal(results[0][k], results[1][k]), k
     finally:
         dist.destroy_process_group()
+
+
+def test_train_loop_checkpoints_and_resume_skip(tmp_path, encoder_sd, seeded_sd):
+    """Runner.train like the reference's (model/shape_engine.py:164-246, 283-284): an evaluation before
+    the first step of a fresh run, latest.ckpt every freq.ckpt_latest iterations, checkpoint/ep<N>.ckpt at
+    the end, and a resumed run skips the slots of its first epoch that were trained before."""
+    opt = train_opt(tmp_path, "--max_epoch=2", "--freq.ckpt_latest=3", "--optim.fix_dpt", "--freq.eval=1000")
+    r = make_runner(opt, encoder_sd, seeded_sd, n_train=16)          # 4 iterations per epoch
+    saves, evals = [], []
+    r.save_checkpoint = lambda opt, **kw: saves.append(kw)
+    ev = r.evaluate
+    r.evaluate = lambda *a, **kw: (evals.append(kw), ev(*a, **kw))[1]
+    r.train(opt)
+    assert r.it == 8 and evals == [dict(ep=0, training=True)]
+    assert [(s["it"], s.get("latest", False)) for s in saves] == [(3, True), (6, True), (8, False)]
+    assert saves[-1]["ep"] == 1
+    # resume from iteration 6 of 8: epoch 1 has two slots left
+    r.epoch_start, r.iter_start = 1, 6
+    opt.resume = True
+    saves.clear(), evals.clear()
+    r.best_val = 0.25
+    r.train(opt)
+    assert r.it == 8 and evals == [] and r.best_val == 0.25
+    assert [(s["it"], s.get("latest", False)) for s in saves] == [(6, True), (8, False)]

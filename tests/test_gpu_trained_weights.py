@@ -1,0 +1,124 @@
+"""The split-fp16 decoder on TRAINED weights: the reference's recipe
+(options/shape.yaml, AdamW, DropPath, BatchNorm on batch statistics) is trained for >= 300
+iterations on the analytic data set (examples/train_synthetic.py does the same), then the full
+129^3 grid of a test image is evaluated by the f16x3 kernel, the exact-fp32 kernel and - on a
+sample - the fp32 CPU oracle.  Bars: logits within 1e-4 (asserted tighter), occupancy flips only
+inside the rounding band, Chamfer-L1 of the extracted surfaces within 1e-4."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import decoder_ref as R
+from zeroshape_amd.data.synthetic import Dataset
+from zeroshape_amd.utils import options, util
+from zeroshape_amd.utils.options import EasyDict as edict
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ITERATIONS = 304
+
+
+@pytest.fixture(scope="module")
+def trained(tmp_path_factory):
+    out = tmp_path_factory.mktemp("trained")
+    cmd = options.parse_arguments(["--yaml=%s/options/shape.yaml" % ROOT, "--output_root=%s" % out, "--batch_size=4",
+                                   "--max_epoch=38", "--pretrain.depth=", "--arch.depth.pretrained=",
+                                   "--eval.vox_res=32", "--eval.num_points=2000", "--eval.batch_size=4",
+                                   "--training.n_sdf_points=2048", "--optim.lr=3.e-4", "--optim.lr_ft=1.e-4",
+                                   "--freq.eval=1000"])
+    opt = options.set(cmd)
+    opt.world_size = 1
+    from zeroshape_amd.model.shape_engine import Runner
+    torch.manual_seed(0)
+    r = Runner(opt)
+    r.load_dataset(opt, dataset=Dataset(opt, split="train", n_items=4, n_points=4000),
+                   train_dataset=Dataset(opt, split="train", n_items=32, n_points=4000))
+    r.build_networks(opt)
+    r.setup_optimizer(opt)
+    r.restore_checkpoint(opt)
+    r.graph.train()
+    first, last = [], []
+    for ep in range(38):
+        for batch in r.train_loader:
+            var = util.move_to_device(edict(batch), opt.device)
+            loss = r.train_iteration(opt, var).all.detach()
+            (first if ep == 0 else last if ep == 37 else []).append(loss)
+    assert r.it >= ITERATIONS >= 300
+    l0, l1 = float(torch.stack(first).mean()), float(torch.stack(last).mean())
+    assert l1 < 0.75 * l0, "training did not reduce the shape loss (%.3f -> %.3f)" % (l0, l1)
+    r.graph.eval()
+    batch = next(iter(r.test_loader))
+    var = util.move_to_device(edict(batch), opt.device)
+    with torch.no_grad():
+        var = r.graph.forward(opt, var, training=False, get_loss=False)
+    return opt, r.graph.impl_network, var.latent_depth[:1].detach().clone()
+
+
+def test_trained_weights_full_grid_f16x3_vs_f32_vs_oracle(trained):
+    opt, net, latent = trained
+    assert net.precision == "f16x3"
+    N = 128
+    axis = torch.linspace(-1.5, 1.5, N + 1, device="cuda")
+    st = net.prepare(latent)
+    assert st.precision == "f16x3", "trained weights left the host envelope (W_MAX)"
+    split = net.query_grid(latent, axis, apply_sigmoid=False, state=st)
+    flagged = int(net.last_tile_flags.sum())
+    exact = net.query_grid(latent, axis, apply_sigmoid=False, state=net.prepare(latent, "f32"))
+    err = (split - exact).abs()
+    flips = (split > 0) != (exact > 0)
+    print("trained weights: max |f16x3 - f32| = %.2e, mean %.2e, flips %d of %d, tiles re-evaluated %d of %d, "
+          "occupied %.3f" % (float(err.max()), float(err.mean()), int(flips.sum()), split.numel(), flagged,
+                             net.last_tile_flags.numel(), float((exact > 0).float().mean())))
+    assert float(err.max()) < 5e-5                      # contract 1e-4
+    assert bool(torch.all(exact[flips].abs() < 5e-5))   # a flip only where the level set passes within the error
+    assert int(flips.sum()) <= 8
+    assert 0.0 < float((exact > 0).float().mean()) < 0.5, "the trained network should predict a bounded shape"
+    # the raw split arithmetic (guard off) is what the bound is about: measure it too
+    net.envelope_guard = False
+    try:
+        raw = net.query_grid(latent, axis, apply_sigmoid=False, state=st)
+    finally:
+        net.envelope_guard = True
+    assert float((raw - exact).abs().max()) < 1e-4
+    # fp32 CPU oracle on 4096 random grid points
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    rs = np.random.RandomState(11)
+    idx = rs.randint(0, N + 1, size=(4096, 3))
+    ax = axis.cpu()
+    pts = torch.stack([ax[idx[:, 0]], ax[idx[:, 1]], ax[idx[:, 2]]], -1)[None]
+    want, _ = R.implicit_forward(sd, latent.cpu(), pts)
+    scale = max(1.0, float(want.abs().max()))
+    for name, grid in (("f16x3", split), ("f32", exact)):
+        got = grid[0, idx[:, 0], idx[:, 1], idx[:, 2]].cpu()
+        e = float((got - want[0]).abs().max())
+        print("trained weights: max |%s kernel - oracle| = %.2e (logit scale %.1f)" % (name, e, scale))
+        assert e < 1e-4 * scale
+
+
+def test_trained_weights_chamfer_l1_delta(trained):
+    """Surface extraction + sampling + Chamfer-L1 of the two arithmetics' 129^3 grids."""
+    from zeroshape_amd.utils import eval_3D as E
+    opt, net, latent = trained
+    o = edict(dict(device="cuda", H=224, W=224, arch=dict(win_size=16), data=dict(dataset_test="synthetic"),
+                   eval=dict(vox_res=128, range=[-1.5, 1.5], num_points=10000, icp=False, brute_force=False,
+                             f_thresholds=[0.005, 0.01, 0.02, 0.05, 0.1, 0.2])))
+    rs = np.random.RandomState(3)
+    gt = torch.from_numpy(rs.uniform(-0.6, 0.6, size=(1, 10000, 3)).astype(np.float32))
+    res = {}
+    for prec in ("f32", "f16x3"):
+        net.precision = prec
+        var = edict(dict(idx=[0], latent_depth=latent, latent_semantic=None,
+                         rgb_input_map=torch.zeros(1, 3, 224, 224).cuda(),
+                         pose_gt=torch.eye(3, 4)[None].cuda(), dpc=dict(points=gt.clone().cuda())))
+        E.eval_metrics(o, var, net)
+        res[prec] = var
+    net.precision = "f16x3"
+    a, b = res["f32"], res["f16x3"]
+    d_acc = float((a.cd_acc - b.cd_acc).abs().max())
+    d_comp = float((a.cd_comp - b.cd_comp).abs().max())
+    print("trained weights: Chamfer-L1 delta f16x3 vs f32: acc %.2e comp %.2e (cd %.4f)" %
+          (d_acc, d_comp, float((a.cd_acc + a.cd_comp) / 2)))
+    assert d_acc < 1e-4 and d_comp < 1e-4
+    assert float((a.f_score - b.f_score).abs().max()) < 2e-3

@@ -34,19 +34,19 @@ SIGNATURES = {
     "zs_sdf_prologue": (_c_int, [_c_void_p, _c_size_t, _c_void_p, _c_void_p, _c_int,
                                  _c_void_p, _c_void_p]),
     "zs_sdf_query_points": (_c_int, [_c_void_p, _c_size_t, _c_int, _c_void_p, _c_int,
-                                     _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+                                     _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "zs_sdf_query_grid": (_c_int, [_c_void_p, _c_size_t, _c_int, _c_void_p, _c_int, _c_int,
-                                   _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+                                   _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "zs_sdf_split_programs": (_c_int, [_c_void_p, _c_size_t, _c_void_p, _c_size_t, _c_int, _c_void_p]),
     "zs_sdf_query_points_split": (_c_int, [_c_void_p, _c_size_t, _c_int, _c_void_p, _c_int,
-                                           _c_void_p, _c_void_p, _c_void_p]),
+                                           _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "zs_sdf_query_grid_split": (_c_int, [_c_void_p, _c_size_t, _c_int, _c_void_p, _c_int, _c_int,
-                                         _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+                                         _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "zs_sdf_query_grid_range": (_c_int, [_c_void_p, _c_size_t, _c_int, _c_void_p, _c_int, ctypes.c_longlong,
-                                         ctypes.c_longlong, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+                                         ctypes.c_longlong, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "zs_sdf_query_grid_range_split": (_c_int, [_c_void_p, _c_size_t, _c_int, _c_void_p, _c_int,
                                                ctypes.c_longlong, ctypes.c_longlong, _c_int, _c_void_p,
-                                               _c_void_p, _c_void_p]),
+                                               _c_void_p, _c_void_p, _c_void_p]),
     "zs_erode_mask": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
     "zs_bf_grid_bytes": (_c_size_t, []),
     "zs_bf_scratch_bytes": (_c_size_t, []),
@@ -136,7 +136,7 @@ SIGNATURES = {
     "zs_readout_concat_bwd": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
 }
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 _lib = None
 
 

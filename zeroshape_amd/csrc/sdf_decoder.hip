@@ -662,7 +662,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) __attribute__((amdgpu_num_vgpr(240))
     int G, long long first_point,      //  GRID: linear index of the first grid point
     int m,                             // points per image handled by this launch
     float *__restrict__ out, int apply_sigmoid, f32x4 *__restrict__ workspace,
-    f32x4 *__restrict__ attn_raw) {  // ATTN: [wave tile][ATTN_WT_F4]
+    f32x4 *__restrict__ attn_raw,    // ATTN: [wave tile][ATTN_WT_F4]
+    const int *__restrict__ tile_mask) {  // non-null: only the 128-point tiles with a non-zero entry
     // LDS: [params 32 KiB][4 x 32 KiB activation slabs] = 160 KiB, one workgroup per CU
     __shared__ __attribute__((aligned(16))) float lds[P_PHASE_B + WAVES * SLAB_F4 * 4];
     float *prm = lds;
@@ -675,6 +676,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) __attribute__((amdgpu_num_vgpr(240))
     const int tiles_per_img = (m + PTS_PER_BLOCK - 1) / PTS_PER_BLOCK;
     const int total = tiles_per_img * batch;
     for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        if (tile_mask && tile_mask[tile] == 0) continue;  // workgroup-uniform
         const int img = tile / tiles_per_img;
         const int t = tile - img * tiles_per_img;
         const float *prog = programs + (size_t)img * program_stride_floats;
@@ -767,7 +769,7 @@ extern "C" size_t zs_sdf_attn_scratch_bytes(int batch, int m) {
 
 extern "C" int zs_sdf_query_points(const void *programs, size_t program_stride_bytes, int batch,
                                    const float *points, int m, float *logits, float *attn,
-                                   void *workspace, void *stream) {
+                                   const int *tile_mask, void *workspace, void *stream) {
     if (batch < 0 || m < 0) {
         zs::set_err("zs_sdf_query_points: negative size (batch=%d m=%d)", batch, m);
         return 0;
@@ -790,14 +792,18 @@ extern "C" int zs_sdf_query_points(const void *programs, size_t program_stride_b
         hipLaunchKernelGGL((sdf_decode_kernel<false, false>), dim3(decode_grid_size(batch, m)),
                            dim3(WAVES * 64), 0, st, static_cast<const float *>(programs),
                            program_stride_bytes / sizeof(float), batch, points, nullptr, 0, 0LL, m, logits,
-                           0, static_cast<f32x4 *>(workspace), nullptr);
+                           0, static_cast<f32x4 *>(workspace), nullptr, tile_mask);
     } else {
+        if (tile_mask) {
+            zs::set_err("zs_sdf_query_points: the attention map cannot be combined with a tile mask");
+            return 0;
+        }
         // raw tiles live behind the fixed part of the workspace (zs_sdf_attn_scratch_bytes)
         f32x4 *raw = reinterpret_cast<f32x4 *>(static_cast<char *>(workspace) + WORKSPACE_BYTES);
         hipLaunchKernelGGL((sdf_decode_kernel<false, true>), dim3(decode_grid_size(batch, m)),
                            dim3(WAVES * 64), 0, st, static_cast<const float *>(programs),
                            program_stride_bytes / sizeof(float), batch, points, nullptr, 0, 0LL, m, logits,
-                           0, static_cast<f32x4 *>(workspace), raw);
+                           0, static_cast<f32x4 *>(workspace), raw, nullptr);
         const long long total = (long long)batch * m * L;
         int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
         hipLaunchKernelGGL(attn_reduce_kernel, dim3(blocks), dim3(256), 0, st, raw, attn, batch, m);
@@ -808,7 +814,7 @@ extern "C" int zs_sdf_query_points(const void *programs, size_t program_stride_b
 extern "C" int zs_sdf_query_grid_range(const void *programs, size_t program_stride_bytes, int batch,
                                        const float *axis, int G, long long point_begin,
                                        long long point_end, int apply_sigmoid, float *out,
-                                       void *workspace, void *stream) {
+                                       const int *tile_mask, void *workspace, void *stream) {
     const long long P = (long long)G * G * G;
     if (batch < 0 || G <= 0 || point_begin < 0 || point_end > P || point_begin > point_end) {
         zs::set_err("zs_sdf_query_grid_range: bad range (batch=%d G=%d points=[%lld,%lld))", batch, G,
@@ -834,13 +840,14 @@ extern "C" int zs_sdf_query_grid_range(const void *programs, size_t program_stri
                        dim3(WAVES * 64), 0, static_cast<hipStream_t>(stream),
                        static_cast<const float *>(programs), program_stride_bytes / sizeof(float), batch,
                        nullptr, axis, G, point_begin, m, out, apply_sigmoid,
-                       static_cast<f32x4 *>(workspace), nullptr);
+                       static_cast<f32x4 *>(workspace), nullptr, tile_mask);
     return zs::check_launch("zs_sdf_query_grid_range") ? 1 : 0;
 }
 
 extern "C" int zs_sdf_query_grid(const void *programs, size_t program_stride_bytes, int batch,
                                  const float *axis, int G, int slice_begin, int slice_end,
-                                 int apply_sigmoid, float *out, void *workspace, void *stream) {
+                                 int apply_sigmoid, float *out, const int *tile_mask, void *workspace,
+                                 void *stream) {
     if (batch < 0 || G <= 0 || slice_begin < 0 || slice_end > G || slice_begin > slice_end) {
         zs::set_err("zs_sdf_query_grid: bad range (batch=%d G=%d slices=[%d,%d))", batch, G,
                     slice_begin, slice_end);
@@ -865,6 +872,6 @@ extern "C" int zs_sdf_query_grid(const void *programs, size_t program_stride_byt
                        dim3(WAVES * 64), 0, static_cast<hipStream_t>(stream),
                        static_cast<const float *>(programs), program_stride_bytes / sizeof(float), batch,
                        nullptr, axis, G, (long long)slice_begin * G * G, m, out, apply_sigmoid,
-                       static_cast<f32x4 *>(workspace), nullptr);
+                       static_cast<f32x4 *>(workspace), nullptr, tile_mask);
     return zs::check_launch("zs_sdf_query_grid") ? 1 : 0;
 }

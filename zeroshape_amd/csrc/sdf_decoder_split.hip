@@ -60,6 +60,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+constexpr float S_GUARD = 64.0f;  // program.py: S_GUARD
 constexpr int WAVES = 4;
 constexpr int PTS_PER_WAVE = 32;
 constexpr int PTS_PER_BLOCK = WAVES * PTS_PER_WAVE;
@@ -440,7 +441,7 @@ DEV void attn_tile(AStream &s, const PT &q, f32x16 &o, float &m_run, float &z_ru
 #endif
 // One wave: 32 points (lane & 31; both lane halves carry the same point).
 DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage_addr, u32x4 *slab,
-                      f32x4 *zs, float px, float py, float pz, int wave, int lane,
+                      f32x4 *zs, float px, float py, float pz, int wave, int lane, float &guard,
                       unsigned long long *dbg) {
     const int hi = lane >> 5;
     const float *prog_params = reinterpret_cast<const float *>(prog) + REC_FLOATS;
@@ -483,9 +484,17 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
             // logits are kept in the log2 domain: c = d^-1/2 * log2(e), softmax = 2^(c s - m)
             const float c = scale * 1.44269504088896340736f;
             float s_self = 0.f;  // self logit (implicit.py:44), fp32
+            float qq = 0.f;      // |q|^2: envelope guard, see ENVELOPE below
 #pragma unroll
-            for (int r = 0; r < 16; r++) s_self = fmaf(q[r], k[r], s_self);
+            for (int r = 0; r < 16; r++) {
+                s_self = fmaf(q[r], k[r], s_self);
+                qq = fmaf(q[r], q[r], qq);
+            }
             s_self = (s_self + xhalf(s_self)) * c;
+            {   // (scale |q| max_l |k_l|)^2, the Cauchy-Schwarz bound of this head's latent logits
+                const float km = prog_params[P_KMAX + blk * HEADS + hd] * scale;  // scalar load
+                guard = fmaxf(guard, (qq + xhalf(qq)) * (km * km));
+            }
             const PT qp = pack_tile(q);
 
             float m_run = -INFINITY, z_run = 0.f;
@@ -731,7 +740,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void sdf_decode_split_kernel(
     const float *__restrict__ axis,    //  GRID: [G]
     int G, long long first_point,      //  GRID: linear index of the first grid point
     int m,                             // points per image handled by this launch
-    float *__restrict__ out, int apply_sigmoid, f32x4 *__restrict__ workspace) {
+    float *__restrict__ out, int apply_sigmoid, f32x4 *__restrict__ workspace,
+    int *__restrict__ tile_flags) {  // [tiles] zeroed by the caller, or null
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     float *prm = lds;
     const int lane = threadIdx.x & 63;
@@ -774,10 +784,30 @@ __global__ __launch_bounds__(WAVES * 64, 1) void sdf_decode_split_kernel(
 #else
         unsigned long long *dbg = nullptr;
 #endif
-        float logit = decode_tile(prog, prm, stage, stage_addr, fl, zslab, px, py, pz, wave, lane, dbg);
+        float guard = 0.f;
+        float logit = decode_tile(prog, prm, stage, stage_addr, fl, zslab, px, py, pz, wave, lane, guard, dbg);
         if (apply_sigmoid) logit = 1.0f / (1.0f + expf(-logit));
+        // ENVELOPE (zeroshape_amd/program.py, S_GUARD): outside it the tile is flagged for the
+        // exact-fp32 kernel, and a program with non-finite / out-of-range operands yields NaN like
+        // the reference's arithmetic would (integer tests: this file is built with -fno-honor-nans)
+        const unsigned bad = reinterpret_cast<const unsigned *>(prog)[REC_FLOATS + P_FLAG];
+        const bool pt_bad = (__builtin_bit_cast(unsigned, px) & 0x7f800000u) == 0x7f800000u ||
+                            (__builtin_bit_cast(unsigned, py) & 0x7f800000u) == 0x7f800000u ||
+                            (__builtin_bit_cast(unsigned, pz) & 0x7f800000u) == 0x7f800000u;
+        if (bad || pt_bad) logit = __builtin_bit_cast(float, 0x7fc00000u);
+        if (tile_flags) {
+            const bool over = !(__builtin_bit_cast(unsigned, guard) <= __builtin_bit_cast(unsigned, S_GUARD * S_GUARD));
+            if (__builtin_amdgcn_ballot_w64(over || bad != 0) != 0 && lane == 0) tile_flags[tile] = 1;
+        }
         if (lane < 32 && p < m) out[(size_t)img * m + p] = logit;
     }
+}
+
+// not finite, or beyond the fp16 range the split operands saturate at (integer test: NaN-proof)
+DEV bool out_of_range(const f32x4 &v) {
+    const unsigned lim = 0x477fe000u;  // 65504.0f
+    return (__builtin_bit_cast(unsigned, v.x) & 0x7fffffffu) > lim || (__builtin_bit_cast(unsigned, v.y) & 0x7fffffffu) > lim ||
+           (__builtin_bit_cast(unsigned, v.z) & 0x7fffffffu) > lim || (__builtin_bit_cast(unsigned, v.w) & 0x7fffffffu) > lim;
 }
 
 // Order of the split stream: the fp32 program's, except inside the two MLP sections, where the
@@ -813,6 +843,7 @@ __global__ __launch_bounds__(256) void split_program_kernel(const float *__restr
         const int kb = e >> 6, lane = e & 63;
         const f32x4 *g = reinterpret_cast<const f32x4 *>(s) + (size_t)split_source_kblock(kb) * 128;  // two fp32 groups
         const f32x4 a = g[lane], b = g[64 + lane];
+        if (out_of_range(a) || out_of_range(b)) atomicOr(reinterpret_cast<unsigned *>(d) + REC_FLOATS + P_FLAG, 1u);
         unsigned h[4], l[4];
         split2(a.x, a.y, h[0], l[0]);
         split2(a.z, a.w, h[1], l[1]);
@@ -823,9 +854,44 @@ __global__ __launch_bounds__(256) void split_program_kernel(const float *__restr
         d[(size_t)kb * KB_U4 + 64 + lane] = lo;
     } else {
         const int i = e - REC_KB * 64;
-        if (i < PARAM_FLOATS / 4)
-            d[REC_FLOATS / 4 + i] = reinterpret_cast<const u32x4 *>(s + REC_FLOATS)[i];
+        // (the quads of P_FLAG - zeroed by the launcher - and P_KMAX are written elsewhere)
+        if (i < PARAM_FLOATS / 4 && i != P_FLAG / 4 && (i < P_KMAX / 4 || i >= (P_KMAX + BLOCKS * HEADS) / 4)) {
+            const f32x4 v = reinterpret_cast<const f32x4 *>(s + REC_FLOATS)[i];
+            if (i < (P_USED + 3) / 4 && out_of_range(v))
+                atomicOr(reinterpret_cast<unsigned *>(d) + REC_FLOATS + P_FLAG, 1u);
+            d[REC_FLOATS / 4 + i] = __builtin_bit_cast(u32x4, v);
+        }
     }
+}
+
+// largest |k_l| over the latent rows of (image, block, head), from the K records of the fp32
+// program (record (lt, r) of lane l holds K[32 lt + (l & 31)][row(r, l >> 5)]) -> params[P_KMAX]
+__global__ __launch_bounds__(256) void k_bound_kernel(const float *__restrict__ src, size_t src_stride_floats,
+                                                      u32x4 *__restrict__ dst, size_t dst_stride_u4) {
+    __shared__ float red[256];
+    const int img = blockIdx.y, bh = blockIdx.x, blk = bh / HEADS, hd = bh - blk * HEADS;
+    const float *kv = src + (size_t)img * src_stride_floats +
+                      (size_t)(blk * G_BLOCK + hd * G_HEAD + G_QKV_HEAD) * GROUP_FLOATS;
+    float sq = 0.f;
+    const int t = threadIdx.x;
+    if (t < LT * 32) {
+        const int lt = t >> 5;
+#pragma unroll
+        for (int half = 0; half < 2; half++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const f32x4 v = reinterpret_cast<const f32x4 *>(kv + (lt * 8 + g) * GROUP_FLOATS)[(t & 31) + 32 * half];
+                sq = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, sq))));
+            }
+    }
+    red[t] = sq;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) red[t] = fmaxf(red[t], red[t + o]);
+        __syncthreads();
+    }
+    if (t == 0)
+        reinterpret_cast<float *>(dst + (size_t)img * dst_stride_u4)[REC_FLOATS + P_KMAX + bh] = sqrtf(red[0]);
 }
 
 int decode_grid_size(int batch, int m) {
@@ -859,16 +925,24 @@ extern "C" int zs_sdf_split_programs(const void *programs, size_t program_stride
         !check_programs("zs_sdf_split_programs", split_programs, split_stride_bytes))
         return 0;
     const int elems = (REC_FLOATS / (KB_U4 * 4)) * 64 + PARAM_FLOATS / 4;
-    hipLaunchKernelGGL(split_program_kernel, dim3((elems + 255) / 256, batch), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), static_cast<const float *>(programs),
-                       program_stride_bytes / sizeof(float), static_cast<u32x4 *>(split_programs),
-                       split_stride_bytes / sizeof(u32x4));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemset2DAsync(static_cast<char *>(split_programs) + (size_t)(REC_FLOATS + P_FLAG) * 4, split_stride_bytes,
+                         0, 16, batch, st) != hipSuccess) {
+        zs::set_err("zs_sdf_split_programs: hipMemset2DAsync failed");
+        return 0;
+    }
+    hipLaunchKernelGGL(split_program_kernel, dim3((elems + 255) / 256, batch), dim3(256), 0, st,
+                       static_cast<const float *>(programs), program_stride_bytes / sizeof(float),
+                       static_cast<u32x4 *>(split_programs), split_stride_bytes / sizeof(u32x4));
+    hipLaunchKernelGGL(k_bound_kernel, dim3(BLOCKS * HEADS, batch), dim3(256), 0, st,
+                       static_cast<const float *>(programs), program_stride_bytes / sizeof(float),
+                       static_cast<u32x4 *>(split_programs), split_stride_bytes / sizeof(u32x4));
     return zs::check_launch("zs_sdf_split_programs") ? 1 : 0;
 }
 
 extern "C" int zs_sdf_query_points_split(const void *split_programs, size_t program_stride_bytes,
                                          int batch, const float *points, int m, float *logits,
-                                         void *workspace, void *stream) {
+                                         int *tile_flags, void *workspace, void *stream) {
     if (batch < 0 || m < 0) {
         zs::set_err("zs_sdf_query_points_split: negative size (batch=%d m=%d)", batch, m);
         return 0;
@@ -886,14 +960,14 @@ extern "C" int zs_sdf_query_points_split(const void *split_programs, size_t prog
     hipLaunchKernelGGL((sdf_decode_split_kernel<false>), dim3(decode_grid_size(batch, m)),
                        dim3(WAVES * 64), 0, static_cast<hipStream_t>(stream),
                        static_cast<const char *>(split_programs), program_stride_bytes, batch, points,
-                       nullptr, 0, 0LL, m, logits, 0, static_cast<f32x4 *>(workspace));
+                       nullptr, 0, 0LL, m, logits, 0, static_cast<f32x4 *>(workspace), tile_flags);
     return zs::check_launch("zs_sdf_query_points_split") ? 1 : 0;
 }
 
 extern "C" int zs_sdf_query_grid_range_split(const void *split_programs, size_t program_stride_bytes,
                                              int batch, const float *axis, int G, long long point_begin,
                                              long long point_end, int apply_sigmoid, float *out,
-                                             void *workspace, void *stream) {
+                                             int *tile_flags, void *workspace, void *stream) {
     const long long P = (long long)G * G * G;
     if (batch < 0 || G <= 0 || point_begin < 0 || point_end > P || point_begin > point_end) {
         zs::set_err("zs_sdf_query_grid_range_split: bad range (batch=%d G=%d points=[%lld,%lld))", batch, G,
@@ -915,14 +989,14 @@ extern "C" int zs_sdf_query_grid_range_split(const void *split_programs, size_t 
     hipLaunchKernelGGL((sdf_decode_split_kernel<true>), dim3(decode_grid_size(batch, m)),
                        dim3(WAVES * 64), 0, static_cast<hipStream_t>(stream),
                        static_cast<const char *>(split_programs), program_stride_bytes, batch, nullptr,
-                       axis, G, point_begin, m, out, apply_sigmoid, static_cast<f32x4 *>(workspace));
+                       axis, G, point_begin, m, out, apply_sigmoid, static_cast<f32x4 *>(workspace), tile_flags);
     return zs::check_launch("zs_sdf_query_grid_range_split") ? 1 : 0;
 }
 
 extern "C" int zs_sdf_query_grid_split(const void *split_programs, size_t program_stride_bytes,
                                        int batch, const float *axis, int G, int slice_begin,
-                                       int slice_end, int apply_sigmoid, float *out, void *workspace,
-                                       void *stream) {
+                                       int slice_end, int apply_sigmoid, float *out, int *tile_flags,
+                                       void *workspace, void *stream) {
     if (batch < 0 || G <= 0 || slice_begin < 0 || slice_end > G || slice_begin > slice_end) {
         zs::set_err("zs_sdf_query_grid_split: bad range (batch=%d G=%d slices=[%d,%d))", batch, G,
                     slice_begin, slice_end);
@@ -944,6 +1018,6 @@ extern "C" int zs_sdf_query_grid_split(const void *split_programs, size_t progra
                        dim3(WAVES * 64), 0, static_cast<hipStream_t>(stream),
                        static_cast<const char *>(split_programs), program_stride_bytes, batch, nullptr,
                        axis, G, (long long)slice_begin * G * G, m, out, apply_sigmoid,
-                       static_cast<f32x4 *>(workspace));
+                       static_cast<f32x4 *>(workspace), tile_flags);
     return zs::check_launch("zs_sdf_query_grid_split") ? 1 : 0;
 }

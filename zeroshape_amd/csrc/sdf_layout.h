@@ -35,6 +35,9 @@ constexpr int P_IMPL_PAIR = 9472;  // layers (2,3), (4,5), (6,7): [xyz4 table 10
 constexpr int P_IMPL_PAIR_STRIDE = 1280;
 constexpr int P_W8 = 13312, P_B8 = 13568;
 constexpr int P_USED = 13584;
+// split program only (written by zs_sdf_split_programs, read through scalar loads):
+constexpr int P_FLAG = 13600;   // uint32, non-zero: an operand is not finite or outside the fp16 range
+constexpr int P_KMAX = 13616;   // [BLOCKS][HEADS] largest |k_l| over the latent rows of the image
 constexpr int P_PHASE_B = 8192;  // params [0, 8192) serve the attention blocks, the rest impl_mlp
 
 // latent-path parameter block (prologue), weights transposed to [K][N]

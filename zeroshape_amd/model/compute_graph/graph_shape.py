@@ -126,8 +126,10 @@ class Graph(nn.Module):
         return camera.intr_param2mtx(opt, intr_params)
 
     def enable_hip_graph(self, on=True):
-        """Replay the encoder as one captured hipGraph per input shape instead of ~350 launches
-        (weights must not change while enabled; disabling drops the captures)."""
+        """Replay the encoder as one captured hipGraph per input shape instead of ~350 launches.
+        A capture bakes in the packed weights of its moment: the key carries the weights' version
+        (in-place updates, re-assignment, the fused optimiser's generation counter), so a
+        load_state_dict / optimiser step / resume re-captures instead of replaying stale weights."""
         self._use_hip_graph = bool(on)
         self._captured = {}
         return self
@@ -154,10 +156,15 @@ class Graph(nn.Module):
         if not self._use_hip_graph:
             return run(rgb, mask)
         from ...nn.capture import CapturedCall
+        from ...nn import autograd as A
+        wkey = (A.GENERATION[0],) + tuple((t.data_ptr(), t._version) for m in (self.dpt_depth, self.intr_head,
+                                                                                self.intr_proj, self.coord_encoder)
+                                          for t in list(m.parameters()) + list(m.buffers()))
         key = (tuple(rgb.shape), str(rgb.device), dsp, resnet)
-        if key not in self._captured:
-            self._captured[key] = CapturedCall(run, [rgb, mask])
-        return self._captured[key](rgb, mask)
+        hit = self._captured.get(key)
+        if hit is None or hit[0] != wkey:
+            self._captured[key] = hit = (wkey, CapturedCall(run, [rgb, mask]))
+        return hit[1](rgb, mask)
 
     def forward(self, opt, var, training=False, get_loss=True):
         """graph_shape.py:115-192.  training / get_loss / GT samples select the autograd branch."""

@@ -76,10 +76,12 @@ class _MLPBlocks(nn.Module):
 
 class DecoderState(object):
     """Per-batch device state produced by Implicit.prepare(): one decoder program per
-    image (weights + that image's K/V records)."""
+    image (weights + that image's K/V records).  A split-fp16 state also keeps the fp32
+    programs it was derived from: the exact kernel re-evaluates the tiles the split kernel
+    flags as outside its envelope (program.py: S_GUARD)."""
 
-    def __init__(self, programs, batch, precision="f32"):
-        self.programs, self.batch, self.precision = programs, batch, precision
+    def __init__(self, programs, batch, precision="f32", exact=None):
+        self.programs, self.batch, self.precision, self.exact = programs, batch, precision, exact
 
     @property
     def stride_bytes(self):
@@ -120,10 +122,15 @@ class Implicit(nn.Module):
         # arithmetic of the fused inference kernels (default "f16x3"; ZS_DECODER_PRECISION=f32 or
         # .precision = "f32" selects the exact one): "f32" = exact fp32 MFMA (bitwise an fmaf
         # chain); "f16x3" = split-fp16 on the 16-bit matrix pipe (csrc/sdf_decoder_split.hip:
-        # |logit difference| ~3e-6 to the fp32 kernel, contract 1e-4, 2.6x faster; operands
-        # keep full precision for |x| <= 65504 and saturate beyond 131008).  The attention map and the training path always use fp32.
+        # |logit difference| ~3e-6 to the fp32 kernel, contract 1e-4, 2.6x faster) INSIDE its
+        # tested envelope (program.py: W_MAX on the host, S_GUARD per 128-point tile on the
+        # device); outside it the exact kernel runs - whole calls or single tiles.  Logits come
+        # from the same arithmetic whether or not the attention map is requested; the map itself
+        # and the training path always use fp32.
         self.precision = os.environ.get("ZS_DECODER_PRECISION", "f16x3")
         self._workspace = {}      # device -> scratch tensor for the query kernels
+        self.last_tile_flags = None   # int32 per 128-point tile of the last split-fp16 query (1 = re-evaluated in fp32)
+        self.envelope_guard = True    # False: raw split-fp16 results everywhere (measurements of the arithmetic itself)
 
     # ---- init (implicit.py:232-249) -------------------------------------------------
     def initialize_weights(self):
@@ -164,8 +171,13 @@ class Implicit(nn.Module):
             sd = {k: v.detach().float().cpu().numpy() for k, v in self.state_dict().items()}
             prog = torch.from_numpy(P.pack_program(sd)).to(device)
             lat = torch.from_numpy(P.pack_latent_params(sd)).to(device)
-            self._packed = (key, prog, lat)
+            self._packed = (key, prog, lat, P.split_envelope(sd)[0])
         return self._packed[1], self._packed[2]
+
+    def split_allowed(self, device):
+        """Host half of the envelope guard: weights finite and within program.W_MAX."""
+        self.packed(device)
+        return self._packed[3]
 
     def workspace(self, device, extra_bytes=0):
         """Scratch for the query kernels (zs_sdf_workspace_bytes() [+ the attention dump], one
@@ -200,14 +212,19 @@ class Implicit(nn.Module):
                                      _lib.ptr(lat), B, _lib.ptr(scratch),
                                      _lib.current_stream_ptr(lat.device))
         _lib.check(rc, "zs_sdf_prologue")
-        if precision == "f16x3":
+        if precision == "f16x3" and self.split_allowed(lat.device):
             split = torch.empty_like(programs)
             with torch.cuda.device(lat.device):
                 rc = lib.zs_sdf_split_programs(_lib.ptr(programs), programs.stride(0) * 4, _lib.ptr(split),
                                                split.stride(0) * 4, B, _lib.current_stream_ptr(lat.device))
             _lib.check(rc, "zs_sdf_split_programs")
-            return DecoderState(split, B, "f16x3")
+            return DecoderState(split, B, "f16x3", exact=programs)
         return DecoderState(programs, B)
+
+    def _tile_flags(self, batch, m, device):
+        if not self.envelope_guard:
+            return None
+        return torch.zeros(batch * ((m + 127) // 128), dtype=torch.int32, device=device)
 
     @torch.no_grad()
     def query_points(self, state, points_3D, need_attn=False):
@@ -225,19 +242,25 @@ class Implicit(nn.Module):
         if state.precision == "f16x3":
             if need_attn:
                 raise ValueError("the attention map needs an fp32 DecoderState (prepare(..., precision='f32'))")
+            flags = self._tile_flags(state.batch, M, pts.device)
+            ws, st = _lib.ptr(self.workspace(pts.device)), _lib.current_stream_ptr(pts.device)
             with torch.cuda.device(pts.device):
                 rc = lib.zs_sdf_query_points_split(_lib.ptr(state.programs), state.stride_bytes, state.batch,
-                                                   _lib.ptr(pts), M, _lib.ptr(out),
-                                                   _lib.ptr(self.workspace(pts.device)),
-                                                   _lib.current_stream_ptr(pts.device))
-            _lib.check(rc, "zs_sdf_query_points_split")
+                                                   _lib.ptr(pts), M, _lib.ptr(out), _lib.ptr(flags), ws, st)
+                _lib.check(rc, "zs_sdf_query_points_split")
+                # flagged tiles (outside the split arithmetic's envelope) again, exactly
+                if flags is not None:
+                    rc = lib.zs_sdf_query_points(_lib.ptr(state.exact), state.exact.stride(0) * 4, state.batch,
+                                                 _lib.ptr(pts), M, _lib.ptr(out), None, _lib.ptr(flags), ws, st)
+            _lib.check(rc, "zs_sdf_query_points")
+            self.last_tile_flags = flags
             return out
         if need_attn:
             attn = torch.empty(state.batch, M, P.L, dtype=torch.float32, device=pts.device)
             extra = lib.zs_sdf_attn_scratch_bytes(state.batch, M)
         with torch.cuda.device(pts.device):
             rc = lib.zs_sdf_query_points(_lib.ptr(state.programs), state.stride_bytes, state.batch,
-                                         _lib.ptr(pts), M, _lib.ptr(out), _lib.ptr(attn),
+                                         _lib.ptr(pts), M, _lib.ptr(out), _lib.ptr(attn), None,
                                          _lib.ptr(self.workspace(pts.device, extra)),
                                          _lib.current_stream_ptr(pts.device))
         _lib.check(rc, "zs_sdf_query_points")
@@ -260,18 +283,24 @@ class Implicit(nn.Module):
         out = torch.empty(state.batch, slice_end - slice_begin, G, G, dtype=torch.float32,
                           device=axis.device)
         if state.precision == "f16x3":
+            flags = self._tile_flags(state.batch, (slice_end - slice_begin) * G * G, axis.device)
+            ws, st = _lib.ptr(self.workspace(axis.device)), _lib.current_stream_ptr(axis.device)
             with torch.cuda.device(axis.device):
                 rc = lib.zs_sdf_query_grid_split(_lib.ptr(state.programs), state.stride_bytes, state.batch,
                                                  _lib.ptr(axis), G, slice_begin, slice_end,
-                                                 1 if apply_sigmoid else 0, _lib.ptr(out),
-                                                 _lib.ptr(self.workspace(axis.device)),
-                                                 _lib.current_stream_ptr(axis.device))
-            _lib.check(rc, "zs_sdf_query_grid_split")
+                                                 1 if apply_sigmoid else 0, _lib.ptr(out), _lib.ptr(flags), ws, st)
+                _lib.check(rc, "zs_sdf_query_grid_split")
+                if flags is not None:
+                    rc = lib.zs_sdf_query_grid(_lib.ptr(state.exact), state.exact.stride(0) * 4, state.batch,
+                                               _lib.ptr(axis), G, slice_begin, slice_end,
+                                               1 if apply_sigmoid else 0, _lib.ptr(out), _lib.ptr(flags), ws, st)
+            _lib.check(rc, "zs_sdf_query_grid")
+            self.last_tile_flags = flags
             return out
         with torch.cuda.device(axis.device):
             rc = lib.zs_sdf_query_grid(_lib.ptr(state.programs), state.stride_bytes, state.batch,
                                        _lib.ptr(axis), G, slice_begin, slice_end,
-                                       1 if apply_sigmoid else 0, _lib.ptr(out),
+                                       1 if apply_sigmoid else 0, _lib.ptr(out), None,
                                        _lib.ptr(self.workspace(axis.device)),
                                        _lib.current_stream_ptr(axis.device))
         _lib.check(rc, "zs_sdf_query_grid")
@@ -289,11 +318,24 @@ class Implicit(nn.Module):
             raise ValueError("axis and latent_depth live on different devices")
         G = axis.numel()
         out = torch.empty(state.batch, point_end - point_begin, dtype=torch.float32, device=axis.device)
-        fn = lib.zs_sdf_query_grid_range_split if state.precision == "f16x3" else lib.zs_sdf_query_grid_range
+        ws, st = _lib.ptr(self.workspace(axis.device)), _lib.current_stream_ptr(axis.device)
+        sig = 1 if apply_sigmoid else 0
         with torch.cuda.device(axis.device):
-            rc = fn(_lib.ptr(state.programs), state.stride_bytes, state.batch, _lib.ptr(axis), G,
-                    point_begin, point_end, 1 if apply_sigmoid else 0, _lib.ptr(out),
-                    _lib.ptr(self.workspace(axis.device)), _lib.current_stream_ptr(axis.device))
+            if state.precision == "f16x3":
+                flags = self._tile_flags(state.batch, point_end - point_begin, axis.device)
+                rc = lib.zs_sdf_query_grid_range_split(_lib.ptr(state.programs), state.stride_bytes, state.batch,
+                                                       _lib.ptr(axis), G, point_begin, point_end, sig, _lib.ptr(out),
+                                                       _lib.ptr(flags), ws, st)
+                _lib.check(rc, "zs_sdf_query_grid_range_split")
+                if flags is not None:
+                    rc = lib.zs_sdf_query_grid_range(_lib.ptr(state.exact), state.exact.stride(0) * 4, state.batch,
+                                                     _lib.ptr(axis), G, point_begin, point_end, sig, _lib.ptr(out),
+                                                     _lib.ptr(flags), ws, st)
+                self.last_tile_flags = flags
+            else:
+                rc = lib.zs_sdf_query_grid_range(_lib.ptr(state.programs), state.stride_bytes, state.batch,
+                                                 _lib.ptr(axis), G, point_begin, point_end, sig, _lib.ptr(out),
+                                                 None, ws, st)
         _lib.check(rc, "zs_sdf_query_grid_range")
         return out
 
@@ -309,9 +351,15 @@ class Implicit(nn.Module):
                 return logits, None
             with torch.no_grad():      # the attention map carries no gradient in the reference's losses
                 return logits, self.query_points(self.prepare(latent_depth, "f32"), points_3D, need_attn=True)[1]
-        if need_attn:                  # the map comes from the fp32 kernel, and the logits with it
-            return self.query_points(self.prepare(latent_depth, "f32"), points_3D, need_attn=True)
-        return self.query_points(self.prepare(latent_depth), points_3D), None
+        state = self.prepare(latent_depth)
+        if need_attn and state.precision == "f32":
+            return self.query_points(state, points_3D, need_attn=True)
+        logits = self.query_points(state, points_3D)
+        if not need_attn:
+            return logits, None
+        # the map only exists in the exact kernel; the logits stay those of the configured arithmetic,
+        # so a caller gets the same numbers with and without the map
+        return logits, self.query_points(DecoderState(state.exact, state.batch), points_3D, need_attn=True)[1]
 
     # ---- training path (layer by layer, autograd over HIP kernels) -------------------------
     def _drop_scale(self, B, device):

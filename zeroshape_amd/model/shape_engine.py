@@ -110,26 +110,36 @@ class Runner:
         if opt.optim.amp:
             raise NotImplementedError("optim.amp: the HIP training path is fp32 (options/shape.yaml:95 amp false)")
         if getattr(opt, "world_size", 1) > 1:
-            self.reducer = parallel.GradReducer(self.graph.parameters(),
+            self.reducer = parallel.GradReducer(self.graph.parameters(), module=self.graph,
                                                 bucket_mb=getattr(opt.optim, "bucket_mb", 64.0))
 
     def train(self, opt):
-        """:186-199."""
+        """:164-190: resume skips the part of the first epoch that was already trained, a fresh run
+        validates once before the first step, and the final state goes to checkpoint/ep<N>.ckpt."""
         self.ep = self.epoch_start
         self.it = self.iter_start
+        self.iter_skip = self.iter_start % len(self.train_loader)                       # :171
+        if not getattr(opt, "resume", False):                                            # :174-176
+            self.best_val, self.best_ep = np.inf, 1
+        if self.iter_start == 0 and not getattr(opt, "debug", False) and self.test_loader is not None:   # :178
+            self.evaluate(opt, ep=0, training=True)
         self.graph.train()
         for self.ep in range(self.epoch_start, opt.max_epoch):
             self.train_epoch(opt)
-        if getattr(opt, "output_path", None) and self._rank() == 0:
-            self.save_checkpoint(opt, ep=self.ep, it=self.it, best_val=self.best_val, best_ep=self.best_ep, latest=True)
+        if getattr(opt, "output_path", None) and self._rank() == 0:                      # :182
+            self.save_checkpoint(opt, ep=self.ep, it=self.it, best_val=self.best_val, best_ep=self.best_ep)
 
     def train_epoch(self, opt):
-        """:201-246."""
+        """:192-246."""
         if isinstance(self.train_loader.sampler, torch.utils.data.distributed.DistributedSampler):
             self.train_loader.sampler.set_epoch(self.ep)
         self.graph.train()
-        for batch in self.train_loader:
-            var = edict(batch)
+        loader = iter(self.train_loader)
+        for _ in range(len(self.train_loader)):
+            if getattr(self, "iter_skip", 0) > 0:      # :223-226: slots of this epoch trained before the restart
+                self.iter_skip -= 1
+                continue
+            var = edict(next(loader))
             opt.H, opt.W = opt.image_size
             var = util.move_to_device(var, opt.device)
             self.train_iteration(opt, var)
@@ -171,6 +181,11 @@ class Runner:
                 self.optim.clip_grad_norm_(opt.optim.clip_norm)
             self.optim.step()
             self.optim.zero_grad()
+        # :283-284: latest.ckpt every freq.ckpt_latest iterations (rank 0), so a crash loses at most that
+        # many (the reference also writes one at iteration 0, i.e. the initial weights: skipped)
+        if self._rank() == 0 and getattr(opt, "output_path", None) and not getattr(opt, "debug", False) \
+                and self.it > 0 and self.it % opt.freq.ckpt_latest == 0:
+            self.save_checkpoint(opt, ep=self.ep, it=self.it, best_val=self.best_val, best_ep=self.best_ep, latest=True)
         self.it += 1
         return loss
 
@@ -206,6 +221,8 @@ class Runner:
         rank 0 with `opt.output_path`, writes <dataset>_full_results.txt / quantitative_<dataset>.txt /
         cd_cat.txt in the reference's formats."""
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        if self.reducer is not None and training:      # every rank validates with rank 0's BatchNorm statistics
+            self.reducer.sync_buffers()
         self.graph.eval()                                                    # :337
         cd_accs, cd_comps, f_scores, cats, ids = [], [], [], [], []
         for it, batch in enumerate(self.test_loader):

@@ -194,15 +194,24 @@ class GradReducer(object):
       every p.grad at its slice of the reduced flat buffer (no copy back).
     * Parameters that receive no gradient (the ViT's unused `norm` / `head`, vit.py:57-154) are
       discovered in the first iteration - which therefore reduces after the backward pass, without
-      overlap - and left with grad None, as DDP leaves globally unused parameters.
+      overlap - and left with grad None, as DDP leaves globally unused parameters.  The used-parameter
+      mask is MAX-reduced over the ranks first, so every rank derives the same bucket layout.
+    * Collectives are issued in bucket order on every rank whatever order the gradients arrive in
+      (a bucket that completes early waits for its predecessors), so ranks cannot mismatch.
+    * Construction broadcasts every parameter and buffer from rank 0 (what DDP's constructor does:
+      replicas must not depend on identical seeding); sync_buffers() repeats it for the buffers
+      (BatchNorm running statistics, DDP's broadcast_buffers) before evaluation / checkpoints.
 
     pack_fn(entries, scale, device) copies gradients into the flat buffer; the default is the HIP
     multi-tensor kernel, CPU tests inject a torch one."""
 
-    def __init__(self, params, group=None, bucket_mb=64.0, pack_fn=None, always=False):
+    def __init__(self, params, group=None, bucket_mb=64.0, pack_fn=None, always=False, module=None):
         """always=True runs the bucket / all-reduce path even in a 1-rank group (single-GPU rehearsal
-        of the multi-GPU path; the all-reduce is then the identity)."""
+        of the multi-GPU path; the all-reduce is then the identity).  module: the nn.Module the
+        parameters belong to, for its buffers."""
         self.always = always
+        params = list(params)
+        self.module = module
         self.params = [p for p in params if p.requires_grad]
         self.group, self.bucket_bytes = group, int(bucket_mb * 2 ** 20)
         self.pack_fn = pack_fn or hip_pack
@@ -211,6 +220,23 @@ class GradReducer(object):
         self.works = []
         self._hooks = []
         self.armed = True              # False during gradient-accumulation micro-steps: hooks stay quiet
+        self.next_launch = 0           # collectives go out in bucket order
+        if self.world > 1 or self.always:
+            with torch.no_grad():
+                for p in params:
+                    dist.broadcast(p.data, self._src(), group=self.group)
+            self.sync_buffers()
+
+    def _src(self):
+        return dist.get_global_rank(self.group, 0) if self.group is not None else 0
+
+    def sync_buffers(self):
+        """Rank 0's buffers (BatchNorm running statistics, counters) on every rank."""
+        if self.module is None or not (self.world > 1 or self.always):
+            return
+        with torch.no_grad():
+            for b in self.module.buffers():
+                dist.broadcast(b.data, self._src(), group=self.group)
 
     # ---- bucket layout ----
     def _build(self, used):
@@ -256,13 +282,19 @@ class GradReducer(object):
         self.works.append(dist.all_reduce(flat, group=self.group, async_op=True))
         self.pending[bi] = -1
 
+    def _launch_ready(self, flush=False):
+        """Issue buckets next_launch, next_launch + 1, ... while they are complete (all, with flush)."""
+        while self.next_launch < len(self.buckets) and (flush or self.pending[self.next_launch] == 0):
+            self._launch(self.next_launch)
+            self.next_launch += 1
+
     def _on_grad(self, p):
         if not self.armed:
             return
         bi, _ = self.slot[id(p)]
         self.pending[bi] -= 1
         if self.pending[bi] == 0:
-            self._launch(bi)
+            self._launch_ready()
 
     # ---- per-iteration API ----
     def finish(self):
@@ -270,16 +302,16 @@ class GradReducer(object):
         if self.world == 1 and not self.always:
             return
         if self.buckets is None:
-            self._build({id(p) for p in self.params if p.grad is not None})
-            for bi in range(len(self.buckets)):
-                self._launch(bi)
-        else:
-            for bi in range(len(self.buckets)):
-                if self.pending[bi] >= 0:       # a gradient did not arrive this time: flush with zeros
-                    self._launch(bi)
+            mask = torch.tensor([0 if p.grad is None else 1 for p in self.params], dtype=torch.int32,
+                                device=self.params[0].device)
+            dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)    # one layout on every rank
+            mask = mask.cpu().tolist()
+            self._build({id(p) for p, u in zip(self.params, mask) if u})
+        self._launch_ready(flush=True)          # incl. buckets a gradient did not reach this time (zeros)
         for w in self.works:
             w.wait()
         self.works = []
+        self.next_launch = 0
         for bi, plist in enumerate(self.buckets):
             for p in plist:
                 _, off = self.slot[id(p)]

@@ -229,6 +229,9 @@ class ParamLayout(object):
 
 PARAMS = ParamLayout()
 assert PARAMS.total <= PARAM_FLOATS
+P_FLAG = 13600   # split program only: uint32, non-zero = an operand outside the fp16 range (or not finite)
+P_KMAX = 13616   # split program only: [BLOCKS][HEADS] largest |k_l| over the latent rows of the image
+assert PARAMS.total <= P_FLAG and P_FLAG + 4 <= P_KMAX and P_KMAX + BLOCKS * HEADS <= PARAM_FLOATS
 BLOCK_PARAM_FLOATS = 3 * C + HEADS * 96 + 3 * C + HID
 
 
@@ -402,4 +405,49 @@ def split_program(prog):
     lo16, _ = f16_rtz(vals - hif)
     out = np.stack([hi16, lo16], axis=1)                            # [kb][hi | lo][lane][8]
     words = np.ascontiguousarray(out).reshape(-1).view(np.uint32)
-    return np.concatenate([words, prog[REC_FLOATS:].view(np.uint32)])
+    params = prog[REC_FLOATS:].copy()
+    params[P_KMAX:P_KMAX + BLOCKS * HEADS] = latent_k_bounds(prog).reshape(-1)
+    bad = not (np.all(np.isfinite(prog)) and float(np.abs(prog).max()) <= F16_MAX)
+    params[P_FLAG:P_FLAG + 1].view(np.uint32)[0] = 1 if bad else 0
+    return np.concatenate([words, params.view(np.uint32)])
+
+
+# ----------------------------------------------------------------------------- #
+# tested envelope of the split-fp16 arithmetic (tests/test_gpu_decoder_split.py)
+# ----------------------------------------------------------------------------- #
+# The 2^-21 operand error of the split acts on the attention logits in absolute terms:
+# |dS| <= 2.5 * 2^-21 * scale * |q| |k|.  Measured against the exact-fp32 kernel: 3.4e-6 on the
+# seeded weights (scale |q||k| ~ 5), 2e-5 with the attention weights x4, 3e-4 at x10.  The contract
+# is 1e-4 on the logits, so:
+#   * on the DEVICE, every 128-point tile whose points reach  scale * |q_h| * max_l |k_h,l| > S_GUARD
+#     in any head, or whose program holds an operand that is not finite / outside the fp16 range, is
+#     flagged by the split kernel and re-evaluated by the exact-fp32 kernel (same stream, no host
+#     round trip: Implicit.query_* enqueue both launches);
+#   * on the HOST, weights beyond W_MAX (hidden activations could leave the fp16 range) select the
+#     exact-fp32 kernels for the whole call (Implicit.prepare).
+S_GUARD = 64.0
+W_MAX = 16.0
+F16_MAX = 65504.0
+
+
+def split_envelope(sd):
+    """(inside, report) for the weights alone: finite and |w| <= W_MAX."""
+    vals = [np.asarray(v, np.float32) for k, v in sd.items() if k != "pos_embed"]
+    wmax = max(float(np.max(np.abs(v))) if np.all(np.isfinite(v)) else float("inf") for v in vals)
+    return wmax <= W_MAX, dict(max_abs_weight=wmax)
+
+
+def latent_k_bounds(prog):
+    """[BLOCKS, HEADS] largest |k_l| over the latent rows, from the K records of one fp32 program
+    (host mirror of what zs_sdf_split_programs writes at P_KMAX)."""
+    prog = np.ascontiguousarray(prog, np.float32)
+    out = np.zeros((BLOCKS, HEADS), np.float32)
+    for blk in range(BLOCKS):
+        for h in range(HEADS):
+            o = kv_group_offset(blk, h) * GROUP_FLOATS
+            g = prog[o:o + G_KV_HEAD * GROUP_FLOATS].reshape(LT, 8, 64, 4)[:, :4]      # K groups of every tile
+            rec = g.transpose(0, 1, 3, 2).reshape(LT, 16, 64)                          # [lt][r][lane]
+            sq = (rec.astype(np.float64) ** 2).sum(1)                                  # over r: half the dims per lane
+            row = sq[:, :32] + sq[:, 32:]                                              # lanes l, l + 32: the two halves
+            out[blk, h] = np.sqrt(row.max())
+    return out

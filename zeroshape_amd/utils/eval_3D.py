@@ -32,10 +32,10 @@ class _GridInfo(object):
     """Metadata attached to tensors made by get_dense_3D_grid so that
     compute_level_grid can use the fused grid kernel (coordinates generated in the
     kernel from the linspace axis) instead of re-reading the points tensor."""
-    __slots__ = ("axis", "G")
+    __slots__ = ("axis", "G", "version")
 
-    def __init__(self, axis, G):
-        self.axis, self.G = axis, G
+    def __init__(self, axis, G, version):
+        self.axis, self.G, self.version = axis, G, version   # version: the tensor's in-place counter at tagging
 
 
 @torch.no_grad()
@@ -47,7 +47,7 @@ def get_dense_3D_grid(opt, var, N=None):
     grid = torch.linspace(range_min, range_max, N + 1, device=opt.device)
     points_3D = torch.stack(torch.meshgrid(grid, grid, grid, indexing='ij'), dim=-1)
     points_3D = points_3D.repeat(batch_size, 1, 1, 1, 1)
-    points_3D._zs_grid = _GridInfo(grid, N + 1)
+    points_3D._zs_grid = _GridInfo(grid, N + 1, points_3D._version)
     return points_3D
 
 
@@ -68,6 +68,8 @@ def compute_level_grid(opt, impl_network, latent_depth, latent_semantic, points_
     assert points_3D.shape[4] == 3
 
     info = getattr(points_3D, "_zs_grid", None)
+    if info is not None and (info.version != points_3D._version or info.G != N):
+        info = None            # modified in place since get_dense_3D_grid made it: read the points
     if info is not None and hasattr(impl_network, "query_grid") and not vis_attn \
             and latent_semantic is None:
         occ = impl_network.query_grid(latent_depth, info.axis, apply_sigmoid=True)
