@@ -18,6 +18,9 @@
  *                           driven by compute_level_grid, utils/eval_3D.py:22-45, and
  *                           get_dense_3D_grid, utils/eval_3D.py:11-20
  *   zs_bf_lower_bounds   <- pruning for brute_force_search, utils/eval_3D.py:140-170
+ *   zs_pose_search_batch <- one batch of brute_force_search, utils/eval_3D.py:149-168
+ *   zs_normalize_pc      <- normalize_pc, utils/eval_3D.py:93-102
+ *   zs_fscore            <- compute_fscore, utils/eval_3D.py:215-231
  *   zs_mc_*, zs_mesh_*   <- convert_to_explicit, utils/eval_3D.py:233-263 (PyMCubes
  *                           marching_cubes + trimesh.sample on the host)
  *   zs_seen_surface, zs_unproj_depth, zs_valid_norm_fac, zs_masked_resample,
@@ -200,6 +203,41 @@ size_t zs_bf_scratch_bytes(void);
 int zs_bf_lower_bounds(const float *pred, int n, const float *gt_normalized, int m,
                        const float *rotations, int k, float *grid_gt, float *grid_pred,
                        void *scratch, float *lower_bounds, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Fused pose search (brute_force_search, utils/eval_3D.py:140-170) and its helpers
+ * normalize_pc (:93-102) and compute_fscore (:215-231).
+ *
+ * zs_pose_search_batch evaluates `count` (<= zs_pose_max_batch()) rotations exactly - rotate
+ * pred[n][3], normalize_pc, nearest neighbours both ways against gt_normalized[m][3] with the
+ * arithmetic of zs_chamfer_forward, sqrt, means, the six F-score thresholds - and merges the
+ * lexicographic (Chamfer-L1, rotation index) minimum into the running record `best`
+ * (zs_pose_best_bytes(), device; zs_pose_best_init first): float cd, int32 index, float acc,
+ * comp, f[6], int32 rotations evaluated.  That minimum over all batches is the reference's first
+ * strict minimum (:161-168).  Rotation b of the batch is rotations[order ? order[b] : b]
+ * ([..][3][3]); its reported index is that number + index_offset.  lower_bound (optional,
+ * device): one float, the smallest zs_bf_lower_bounds value in this batch - when it proves the
+ * batch cannot beat `best`, the kernels return at once, so all batches can be enqueued without
+ * a host synchronisation.  No rotated cloud, distance or index array is materialised; results
+ * are bit-reproducible (fixed reduction order) whatever batch a rotation is evaluated in.
+ * scratch: zs_pose_scratch_bytes(n, m, count).
+ * zs_pose_apply: out[n][3] = normalize_pc(rotations[index[0]] pred) (index: device int32;
+ * scratch: 64 bytes).  zs_normalize_pc: out[b][n][3] = normalize_pc(pc[b][n][3]) (scratch: 64 b
+ * bytes).  zs_fscore: out[b][n_thresholds] from UN-squared distances dist1[b][n], dist2[b][m].
+ * ------------------------------------------------------------------------- */
+int zs_pose_max_batch(void);
+size_t zs_pose_scratch_bytes(int n, int m, int count);
+size_t zs_pose_best_bytes(void);
+int zs_pose_best_init(float *best, void *stream);
+int zs_pose_search_batch(const float *pred, int n, const float *gt_normalized, int m,
+                         const float *rotations, const int *order, int count, int index_offset,
+                         const float *lower_bound, const float *thresholds6, float *best,
+                         void *scratch, void *stream);
+int zs_pose_apply(const float *pred, int n, const float *rotations, const int *index, float *out,
+                  void *scratch, void *stream);
+int zs_normalize_pc(const float *pc, int b, int n, float *out, void *scratch, void *stream);
+int zs_fscore(const float *dist1, int n, const float *dist2, int m, int b, const float *thresholds,
+              int n_thresholds, float *out, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Iso-surface extraction + surface sampling (replaces convert_to_explicit,

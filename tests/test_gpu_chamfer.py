@@ -195,3 +195,64 @@ def test_brute_force_search_matches_oracle_scan():
     np.testing.assert_allclose(float(acc), float(oacc), rtol=1e-5)
     np.testing.assert_allclose(float(comp), float(ocomp), rtol=1e-5)
     np.testing.assert_allclose(f.cpu().numpy(), of.numpy(), atol=1e-6)
+
+
+def test_normalize_pc_and_fscore_kernels_vs_reference_goldens(geometry_golden):
+    """zs_normalize_pc / zs_fscore against the outputs of the real reference's normalize_pc /
+    compute_fscore (tests/golden/make_golden.py): F-score bit for bit (integer counts, same
+    division order, 0/0 -> 0), normalize_pc to 1 ulp (the mean is a double sum rounded once)."""
+    from zeroshape_amd.utils import eval_3D as E
+    pc = torch.from_numpy(syn.seeded_cloud(3, 2, 64)) * torch.tensor([1.0, 2.0, 3.0])
+    got = E.normalize_pc(pc.cuda()).cpu().numpy()
+    np.testing.assert_allclose(got, geometry_golden["normalize_pc_out"], rtol=0, atol=1.2e-7)
+    d1 = torch.from_numpy(np.random.RandomState(5).uniform(0, 0.25, size=(3, 50)).astype(np.float32))
+    d2 = torch.from_numpy(np.random.RandomState(6).uniform(0, 0.25, size=(3, 70)).astype(np.float32))
+    d1[2] = 1.0
+    d2[2] = 1.0
+    f = E.compute_fscore(d1.cuda(), d2.cuda()).cpu().numpy()
+    np.testing.assert_array_equal(f, geometry_golden["fscore_out"])
+    assert np.all(f[2] == 0)
+    with pytest.raises(ValueError):
+        E.normalize_pc(pc)                      # CPU tensors are rejected, not emulated
+    # larger, ragged, batched: against the oracle
+    a = torch.from_numpy(syn.seeded_cloud(8, 5, 3001)) * torch.tensor([0.3, 1.7, 5.0]) + 0.4
+    np.testing.assert_allclose(E.normalize_pc(a.cuda()).cpu().numpy(), G.normalize_pc(a).numpy(), rtol=4e-7, atol=2e-7)  # the oracle's own fp32 mean is ~1e-7 off
+
+
+def test_fused_pose_search_equals_the_unfused_kernels():
+    """The fused batch kernels (csrc/pose_search.hip) against the same steps as separate launches:
+    zs_pose_apply (rotate + normalize_pc) -> chamfer kernel -> sqrt / mean -> zs_fscore, per
+    rotation.  Same winner, F-score bit for bit, distances to the last bits of the mean's
+    summation order; and the search leaves the running record on the device (no sync needed)."""
+    from zeroshape_amd.utils import eval_3D as E
+    from zeroshape_amd.utils.camera import get_rotation_sphere
+    from zeroshape_amd import _lib
+    lib = _lib.load()
+    R = get_rotation_sphere(24, 24, 12, device="cuda").float().contiguous()
+    rs = np.random.RandomState(12)
+    pred = torch.from_numpy((rs.randn(1777, 3) * np.array([0.5, 0.3, 0.2]) + rs.rand(1777, 1) * 0.3).astype(np.float32)).cuda()
+    gt = (R[700] @ pred.T).T.contiguous()[:1500] + 3e-3 * torch.randn(1500, 3, device="cuda")
+    sl = (660, 760)
+    acc, comp, f, best_pred, gt_n, idx, cd = E.brute_force_search(pred, gt, device="cuda", rotations=R, rot_slice=sl,
+                                                                  return_index=True, prune=False, batch_size=37)
+    assert E.brute_force_search.last_evaluated == 100
+    rows = []
+    scratch = torch.empty(64, device="cuda")
+    for k in range(*sl):
+        rot = torch.empty(1777, 3, device="cuda")
+        ki = torch.tensor([k], dtype=torch.int32, device="cuda")
+        _lib.check(lib.zs_pose_apply(_lib.ptr(pred), 1777, _lib.ptr(R), _lib.ptr(ki), _lib.ptr(rot), _lib.ptr(scratch),
+                                     _lib.current_stream_ptr(pred.device)), "zs_pose_apply")
+        d1, d2, _, _ = E.chamfer_distance(None, rot[None], gt_n, method="brute")
+        rows.append((float((d1.double().mean() + d2.double().mean()) / 2), k, d1, d2, rot))
+    want = min(rows, key=lambda r: (r[0], r[1]))
+    assert idx == want[1]
+    assert abs(cd - want[0]) < 2e-7 * max(1.0, want[0]) and abs(float(acc) - float(want[2].mean())) < 1e-6
+    assert torch.equal(best_pred, want[4])
+    assert torch.equal(f, E.compute_fscore(want[2], want[3])[0])
+    # the un-indexed call returns device tensors only
+    out = E.brute_force_search(pred, gt, device="cuda", rotations=R, rot_slice=sl)
+    assert len(out) == 5 and all(t.is_cuda for t in out) and torch.equal(out[0], acc) and torch.equal(out[3], best_pred)
+    # fewer thresholds than six
+    f2 = E.brute_force_search(pred, gt, [0.01, 0.1], device="cuda", rotations=R, rot_slice=sl)[2]
+    assert f2.shape == (2,) and torch.equal(f2, f[[1, 4]])

@@ -40,11 +40,20 @@ class Net(torch.nn.Module):
 def _worker(rank, world, initfile):
     dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
     try:
+        torch.manual_seed(rank)                       # replicas start DIFFERENT: the reducer must fix that
+        net = Net()
+        net.register_buffer("stat", torch.full((3,), float(rank)))
+        red = parallel.GradReducer(net.parameters(), bucket_mb=0.3, pack_fn=torch_pack, module=net)   # several buckets
         torch.manual_seed(0)
-        net = Net()                                   # same weights on every rank
+        want = Net()                                  # rank 0's initialisation
+        for (n, p), (_, q) in zip(net.named_parameters(), want.named_parameters()):
+            assert torch.equal(p, q), n
+        assert float(net.stat.sum()) == 0.0           # rank 0's buffer everywhere
+        net.stat.fill_(float(rank) + 5)
+        red.sync_buffers()
+        assert float(net.stat.mean()) == 5.0
         ref = Net()
-        ref.load_state_dict(net.state_dict())
-        red = parallel.GradReducer(net.parameters(), bucket_mb=0.3, pack_fn=torch_pack)   # several buckets
+        ref.load_state_dict(net.state_dict(), strict=False)
         data = [torch.randn(world, 6, 40, generator=torch.Generator().manual_seed(100 + it)) for it in range(4)]
         for it in range(4):
             use = it != 2                             # iteration 2: `sometimes` gets no gradient
@@ -83,6 +92,41 @@ def _worker(rank, world, initfile):
         red.close()
     finally:
         dist.destroy_process_group()
+
+
+def _worker_uneven(rank, world, initfile):
+    """First iteration: only rank 0's graph reaches `sometimes`.  The used-parameter mask is reduced
+    over the ranks, so both build the same buckets (and rank 1 contributes zeros) instead of
+    mismatching collective sizes; later iterations complete their buckets in different orders."""
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    try:
+        torch.manual_seed(3)
+        net = Net()
+        red = parallel.GradReducer(net.parameters(), bucket_mb=0.05, pack_fn=torch_pack, module=net)
+        x = torch.randn(6, 40, generator=torch.Generator().manual_seed(50 + rank))
+        for it in range(3):
+            net.zero_grad(set_to_none=True)
+            use = rank == 0 if it == 0 else (rank + it) % 2 == 0
+            net(x, use).pow(2).mean().backward()
+            red.finish()
+            assert net.sometimes.grad is not None
+            g = [torch.zeros_like(net.c.weight.grad) for _ in range(world)]
+            dist.all_gather(g, net.c.weight.grad.contiguous())
+            s = [torch.zeros_like(net.sometimes.grad) for _ in range(world)]
+            dist.all_gather(s, net.sometimes.grad.contiguous())
+            assert all(torch.equal(g[0], t) for t in g) and all(torch.equal(s[0], t) for t in s)
+        layout = torch.tensor([len(b) for b in red.buckets])
+        lay = [torch.zeros_like(layout) for _ in range(world)]
+        dist.all_gather(lay, layout)
+        assert all(torch.equal(lay[0], t) for t in lay) and len(red.buckets) >= 3, layout
+        red.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_reducer_uneven_usage_across_ranks():
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_uneven, args=(2, os.path.join(d, "init")), nprocs=2, join=True)
 
 
 @pytest.mark.parametrize("world", [2, 3])

@@ -52,6 +52,15 @@ SIGNATURES = {
     "zs_bf_scratch_bytes": (_c_size_t, []),
     "zs_bf_lower_bounds": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
                                     _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "zs_pose_max_batch": (_c_int, []),
+    "zs_pose_scratch_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
+    "zs_pose_best_bytes": (_c_size_t, []),
+    "zs_pose_best_init": (_c_int, [_c_void_p, _c_void_p]),
+    "zs_pose_search_batch": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_int,
+                                      _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "zs_pose_apply": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "zs_normalize_pc": (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "zs_fscore": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p]),
     "zs_mc_scratch_bytes": (_c_size_t, [_c_int]),
     "zs_mc_count": (_c_int, [_c_void_p, _c_int, ctypes.c_float, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "zs_mc_emit": (_c_int, [_c_void_p, _c_int, ctypes.c_float, _c_void_p, _c_int, _c_void_p, _c_void_p,

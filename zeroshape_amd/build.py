@@ -25,6 +25,8 @@ EXTRA = {
     # on gfx950 and costs extra v_mov: off)
     "chamfer.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
     "chamfer_grid.hip": ["-ffp-contract=off"],
+    # the same distance arithmetic as chamfer.hip, and normalize_pc / F-score exactly as written
+    "pose_search.hip": ["-ffp-contract=off"],
     # packed f32 VALU ops beside 16-bit MFMAs cost more than the scalar forms they replace
     # ... and MFMA accumulators in VGPRs: the activation code reads and writes them in place
     # (with AGPR accumulators every tile paid 32 v_accvgpr moves; 484 -> 352 registers)

@@ -1,0 +1,487 @@
+// Fused brute-force pose search for MI355X (gfx950): one batch of rotations = three launches and
+// no tensor of rotated clouds, distances or indices.
+//
+// Replaces, per batch of rotations, the reference's (utils/eval_3D.py:149-168)
+//     rotate (bmm) -> normalize_pc (:93-102) -> chamfer_distance (:265-269, the NN kernels of
+//     external/chamfer3D/chamfer3D.cu:12-134 + sqrt) -> compute_fscore (:215-231) -> means ->
+//     strict-minimum update of the running best
+// and, stand-alone, normalize_pc and compute_fscore themselves (zs_normalize_pc / zs_fscore).
+//
+//   pose_stats_kernel   one workgroup per rotation: R p for every prediction point (fmaf chain
+//                       in k order), mean (double sums, rounded once), x / y extents of the
+//                       zero-meaned cloud -> the normalize_pc scale; 16 floats per rotation.
+//   pose_nn_kernel      the Chamfer scan of csrc/chamfer.hip (same arithmetic: d = fma(dz,dz,
+//                       fma(dy,dy,dx*dx)), lowest index wins ties) with the rotated + normalised
+//                       prediction generated on the fly - as queries (direction 0) and while
+//                       staging candidates into LDS (direction 1) - and an epilogue that reduces
+//                       sqrt(d) and the six F-score counters per workgroup in a FIXED order
+//                       (bit-reproducible: the same rotation gives the same bits in any batch).
+//   pose_finish_kernel  per batch: sums the partials in order, acc / comp / cd / F-score per
+//                       rotation, lexicographic (cd, rotation index) winner, merged into the running
+//                       best record on the device.
+// Every kernel first compares the batch's smallest lower bound (csrc/bf_prune.hip) with the
+// running best and returns if the batch cannot win: the host enqueues all batches without a
+// single synchronisation and reads the record once at the end.
+#include "zs_common.h"
+#include "../../include/zeroshape_hip.h"
+
+#include <math.h>
+#include <stdint.h>
+
+namespace {
+
+constexpr int PS_THREADS = 256;
+constexpr int PS_Q = 2;                       // queries per lane
+constexpr int PS_TILE = 1024;                 // candidates per LDS tile
+constexpr int PS_STRIDE = PS_TILE + 4;
+constexpr int PS_STAT = 16;                   // floats per rotation: R[9], mean[3], denom, pad
+constexpr int PS_PART = 8;                    // per workgroup: sum sqrt(d), 6 counts, pad
+constexpr int PS_BEST = 16;                   // cd, index (int bits), acc, comp, f[6], evaluated (int), pad
+
+struct Xform {  // normalize_pc(R p): ((R p) - mean) / denom
+    float r[9], mu[3], den;
+    __device__ __forceinline__ void load(const float *s) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) r[i] = s[i];
+        mu[0] = s[9]; mu[1] = s[10]; mu[2] = s[11];
+        den = s[12];
+    }
+    __device__ __forceinline__ void rotate(float x, float y, float z, float &ox, float &oy, float &oz) const {
+        ox = fmaf(r[2], z, fmaf(r[1], y, r[0] * x));
+        oy = fmaf(r[5], z, fmaf(r[4], y, r[3] * x));
+        oz = fmaf(r[8], z, fmaf(r[7], y, r[6] * x));
+    }
+    __device__ __forceinline__ void apply(float x, float y, float z, float &ox, float &oy, float &oz) const {
+        rotate(x, y, z, ox, oy, oz);
+        ox = (ox - mu[0]) / den;
+        oy = (oy - mu[1]) / den;
+        oz = (oz - mu[2]) / den;
+    }
+};
+
+// the batch cannot beat the running best (margin: the roundings of the bound and of the exact path;
+// zeroshape_amd/utils/eval_3D.py)
+__device__ __forceinline__ bool batch_pruned(const float *lower_bound, const float *best) {
+    return lower_bound && lower_bound[0] * (1.0f - 1e-3f) - 1e-6f > best[0];
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- statistics of R p: mean and the normalize_pc scale ----------------------------------- //
+// rotations == nullptr: identity (plain normalize_pc of cloud[b]); order == nullptr: rotation b
+__global__ __launch_bounds__(PS_THREADS) void pose_stats_kernel(
+    const float *__restrict__ cloud, size_t cloud_stride, int n, const float *__restrict__ rotations,
+    const int *__restrict__ order, float *__restrict__ stats, const float *__restrict__ lower_bound,
+    const float *__restrict__ best) {
+    if (batch_pruned(lower_bound, best)) return;
+    __shared__ double sd[3][PS_THREADS / 64];
+    __shared__ float sf[4][PS_THREADS / 64];
+    const int b = blockIdx.x;
+    const float *p = cloud + (size_t)b * cloud_stride;
+    Xform t;
+    if (rotations) {
+        const float *r = rotations + (size_t)(order ? order[b] : b) * 9;
+#pragma unroll
+        for (int i = 0; i < 9; i++) t.r[i] = r[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; i++) t.r[i] = (i % 4 == 0) ? 1.f : 0.f;
+    }
+    double sx = 0, sy = 0, sz = 0;
+    float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += PS_THREADS) {
+        float x = p[(size_t)i * 3], y = p[(size_t)i * 3 + 1], z = p[(size_t)i * 3 + 2];
+        if (rotations) {
+            float ox, oy, oz;
+            t.rotate(x, y, z, ox, oy, oz);
+            x = ox; y = oy; z = oz;
+        }
+        sx += x; sy += y; sz += z;
+        xmin = fminf(xmin, x); xmax = fmaxf(xmax, x);
+        ymin = fminf(ymin, y); ymax = fmaxf(ymax, y);
+    }
+    sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        xmin = fminf(xmin, __shfl_xor(xmin, o, 64)); xmax = fmaxf(xmax, __shfl_xor(xmax, o, 64));
+        ymin = fminf(ymin, __shfl_xor(ymin, o, 64)); ymax = fmaxf(ymax, __shfl_xor(ymax, o, 64));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        sd[0][wave] = sx; sd[1][wave] = sy; sd[2][wave] = sz;
+        sf[0][wave] = xmin; sf[1][wave] = xmax; sf[2][wave] = ymin; sf[3][wave] = ymax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < PS_THREADS / 64; w++) {
+            sx += sd[0][w]; sy += sd[1][w]; sz += sd[2][w];
+            xmin = fminf(xmin, sf[0][w]); xmax = fmaxf(xmax, sf[1][w]);
+            ymin = fminf(ymin, sf[2][w]); ymax = fmaxf(ymax, sf[3][w]);
+        }
+        const float mx = (float)(sx / n), my = (float)(sy / n), mz = (float)(sz / n);
+        // extents of the zero-meaned coordinates, as the reference forms them (:97-100)
+        const float lx = (xmax - mx) - (xmin - mx), ly = (ymax - my) - (ymin - my);
+        float *s = stats + (size_t)b * PS_STAT;
+#pragma unroll
+        for (int i = 0; i < 9; i++) s[i] = t.r[i];
+        s[9] = mx; s[10] = my; s[11] = mz;
+        s[12] = fmaxf(lx, ly) + 1.e-7f;
+        s[13] = s[14] = s[15] = 0.f;
+    }
+}
+
+// out[b][i] = normalize_pc(R_b cloud[b])[i]
+__global__ __launch_bounds__(PS_THREADS) void pose_apply_kernel(const float *__restrict__ cloud, size_t cloud_stride,
+                                                                int n, const float *__restrict__ stats,
+                                                                float *__restrict__ out) {
+    const int b = blockIdx.y;
+    Xform t;
+    t.load(stats + (size_t)b * PS_STAT);
+    const float *p = cloud + (size_t)b * cloud_stride;
+    float *o = out + (size_t)b * n * 3;
+    for (int i = blockIdx.x * PS_THREADS + threadIdx.x; i < n; i += gridDim.x * PS_THREADS) {
+        float x, y, z;
+        t.apply(p[(size_t)i * 3], p[(size_t)i * 3 + 1], p[(size_t)i * 3 + 2], x, y, z);
+        o[(size_t)i * 3] = x; o[(size_t)i * 3 + 1] = y; o[(size_t)i * 3 + 2] = z;
+    }
+}
+
+// ---- nearest neighbours both ways + per-workgroup metric partials ------------------------- //
+// grid (ceil(max(n, m) / (256 Q)), rotations in the batch, 2)
+__global__ __launch_bounds__(PS_THREADS) void pose_nn_kernel(
+    const float *__restrict__ pred, int n, const float *__restrict__ gt, int m,
+    const float *__restrict__ stats, const float *__restrict__ thresholds, float *__restrict__ partial,
+    const float *__restrict__ lower_bound, const float *__restrict__ best) {
+    if (batch_pruned(lower_bound, best)) return;
+    __shared__ __attribute__((aligned(16))) float tile[3 * PS_STRIDE];
+    __shared__ float red[PS_PART][PS_THREADS / 64];
+    const int dir = blockIdx.z, rot = blockIdx.y;
+    const int nq = dir == 0 ? n : m;      // queries
+    const int nc = dir == 0 ? m : n;      // candidates
+    const int q_base = blockIdx.x * (PS_THREADS * PS_Q);
+    if (q_base >= nq) return;
+    Xform t;
+    t.load(stats + (size_t)rot * PS_STAT);
+
+    float qx[PS_Q], qy[PS_Q], qz[PS_Q], bestd[PS_Q];
+#pragma unroll
+    for (int q = 0; q < PS_Q; q++) {
+        int j = q_base + q * PS_THREADS + threadIdx.x;
+        j = j < nq ? j : nq - 1;
+        if (dir == 0) {
+            t.apply(pred[(size_t)j * 3], pred[(size_t)j * 3 + 1], pred[(size_t)j * 3 + 2], qx[q], qy[q], qz[q]);
+        } else {
+            qx[q] = gt[(size_t)j * 3]; qy[q] = gt[(size_t)j * 3 + 1]; qz[q] = gt[(size_t)j * 3 + 2];
+        }
+        bestd[q] = INFINITY;
+    }
+    for (int k0 = 0; k0 < nc; k0 += PS_TILE) {
+        const int cnt = min(PS_TILE, nc - k0);
+        const int cnt4 = (cnt + 3) & ~3;
+        __syncthreads();
+        for (int c = threadIdx.x; c < cnt4; c += PS_THREADS) {
+            float x = INFINITY, y = INFINITY, z = INFINITY;
+            if (c < cnt) {
+                const size_t o = (size_t)(k0 + c) * 3;
+                if (dir == 0) {
+                    x = gt[o]; y = gt[o + 1]; z = gt[o + 2];
+                } else {
+                    t.apply(pred[o], pred[o + 1], pred[o + 2], x, y, z);
+                }
+            }
+            tile[c] = x;
+            tile[PS_STRIDE + c] = y;
+            tile[2 * PS_STRIDE + c] = z;
+        }
+        __syncthreads();
+        float4 cx = *reinterpret_cast<const float4 *>(&tile[0]);
+        float4 cy = *reinterpret_cast<const float4 *>(&tile[PS_STRIDE]);
+        float4 cz = *reinterpret_cast<const float4 *>(&tile[2 * PS_STRIDE]);
+        for (int k = 0; k < cnt4; k += 4) {
+            const float4 nx = *reinterpret_cast<const float4 *>(&tile[k + 4]);
+            const float4 ny = *reinterpret_cast<const float4 *>(&tile[PS_STRIDE + k + 4]);
+            const float4 nz = *reinterpret_cast<const float4 *>(&tile[2 * PS_STRIDE + k + 4]);
+            const float ax[4] = {cx.x, cx.y, cx.z, cx.w};
+            const float ay[4] = {cy.x, cy.y, cy.z, cy.w};
+            const float az[4] = {cz.x, cz.y, cz.z, cz.w};
+            // only the minimum is needed here (no argmin): min is order-independent, so no
+            // compare/select chain at all
+#pragma unroll
+            for (int q = 0; q < PS_Q; q++) {
+                float d[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float dx = ax[c] - qx[q];
+                    const float dy = ay[c] - qy[q];
+                    const float dz = az[c] - qz[q];
+                    d[c] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                }
+                bestd[q] = fminf(bestd[q], fminf(fminf(d[0], d[1]), fminf(d[2], d[3])));
+            }
+            cx = nx; cy = ny; cz = nz;
+        }
+    }
+    // epilogue: sum of sqrt(d) and the threshold counters of this workgroup's queries, fixed order
+    float v[PS_PART];
+#pragma unroll
+    for (int i = 0; i < PS_PART; i++) v[i] = 0.f;
+    float thr[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) thr[i] = thresholds[i];
+#pragma unroll
+    for (int q = 0; q < PS_Q; q++) {
+        const int j = q_base + q * PS_THREADS + threadIdx.x;
+        if (j < nq) {
+            const float s = sqrtf(bestd[q]);
+            v[0] += s;
+#pragma unroll
+            for (int i = 0; i < 6; i++) v[1 + i] += s < thr[i] ? 1.f : 0.f;   // counts <= 512: exact in fp32
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 7; i++) v[i] = wave_sum(v[i]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < 7; i++) red[i][wave] = v[i];
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        float s = red[threadIdx.x][0];
+        for (int w = 1; w < PS_THREADS / 64; w++) s += red[threadIdx.x][w];
+        partial[(((size_t)rot * 2 + dir) * gridDim.x + blockIdx.x) * PS_PART + threadIdx.x] = s;
+    }
+}
+
+// F-score of utils/eval_3D.py:215-231 from the two hit fractions
+__device__ __forceinline__ float fscore_of(float precision, float recall) {
+    const float f = 2.f * precision * recall / (precision + recall);
+    return f != f ? 0.f : f;   // 0 / 0 -> 0
+}
+
+// one workgroup per batch: per-rotation metrics (thread = rotation), then the batch winner
+__global__ __launch_bounds__(PS_THREADS) void pose_finish_kernel(
+    const float *__restrict__ partial, int count, int n, int m, int blocks_x, const int *__restrict__ order,
+    int index_offset, float *__restrict__ best, const float *__restrict__ lower_bound) {
+    if (batch_pruned(lower_bound, best)) return;
+    __shared__ float s_cd[PS_THREADS];
+    __shared__ int s_idx[PS_THREADS];
+    const int tid = threadIdx.x;
+    float cd = INFINITY, acc = 0.f, comp = 0.f, f[6];
+    int gidx = 0x7fffffff;
+    if (tid < count) {
+        float tot[2][7];
+        const int nb[2] = {(n + PS_THREADS * PS_Q - 1) / (PS_THREADS * PS_Q), (m + PS_THREADS * PS_Q - 1) / (PS_THREADS * PS_Q)};
+        for (int dir = 0; dir < 2; dir++) {
+#pragma unroll
+            for (int i = 0; i < 7; i++) tot[dir][i] = 0.f;
+            for (int b = 0; b < nb[dir]; b++) {
+                const float *p = partial + (((size_t)tid * 2 + dir) * blocks_x + b) * PS_PART;
+#pragma unroll
+                for (int i = 0; i < 7; i++) tot[dir][i] += p[i];
+            }
+        }
+        acc = tot[0][0] / (float)n;
+        comp = tot[1][0] / (float)m;
+        cd = (acc + comp) / 2.f;
+#pragma unroll
+        for (int i = 0; i < 6; i++) f[i] = fscore_of(tot[0][1 + i] / (float)n, tot[1][1 + i] / (float)m);
+        gidx = (order ? order[tid] : tid) + index_offset;
+        if (cd != cd) cd = INFINITY;   // a NaN distance never wins (`cd < best_cd`, :162) and must not shadow the others
+    }
+    s_cd[tid] = cd;
+    s_idx[tid] = gidx;
+    __syncthreads();
+    for (int o = PS_THREADS / 2; o > 0; o >>= 1) {   // lexicographic minimum of (cd, index)
+        if (tid < o) {
+            const float c2 = s_cd[tid + o];
+            const int i2 = s_idx[tid + o];
+            if (c2 < s_cd[tid] || (c2 == s_cd[tid] && i2 < s_idx[tid])) {
+                s_cd[tid] = c2;
+                s_idx[tid] = i2;
+            }
+        }
+        __syncthreads();
+    }
+    const float win_cd = s_cd[0];
+    const int win_idx = s_idx[0];
+    __syncthreads();
+    int *ibest = reinterpret_cast<int *>(best);
+    if (tid == 0) ibest[10] += count;   // rotations evaluated exactly (diagnostics)
+    if (tid < count && gidx == win_idx) {
+        const float old_cd = best[0];
+        const int old_idx = ibest[1];
+        if (win_cd < old_cd || (win_cd == old_cd && win_idx < old_idx)) {   // NaN never wins, like `cd < best`
+            best[0] = cd;
+            ibest[1] = gidx;
+            best[2] = acc;
+            best[3] = comp;
+#pragma unroll
+            for (int i = 0; i < 6; i++) best[4 + i] = f[i];
+        }
+    }
+}
+
+// compute_fscore (utils/eval_3D.py:215-231) on un-squared distances: one workgroup per batch row
+__global__ __launch_bounds__(PS_THREADS) void fscore_kernel(const float *__restrict__ d1, int n,
+                                                            const float *__restrict__ d2, int m,
+                                                            const float *__restrict__ thresholds, int nt,
+                                                            float *__restrict__ out) {
+    __shared__ int cnt[2][PS_THREADS / 64];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int t = 0; t < nt; t++) {
+        const float thr = thresholds[t];
+        int c1 = 0, c2 = 0;
+        for (int i = threadIdx.x; i < n; i += PS_THREADS) c1 += d1[(size_t)b * n + i] < thr ? 1 : 0;
+        for (int i = threadIdx.x; i < m; i += PS_THREADS) c2 += d2[(size_t)b * m + i] < thr ? 1 : 0;
+        c1 = wave_sum(c1);
+        c2 = wave_sum(c2);
+        __syncthreads();
+        if (lane == 0) {
+            cnt[0][wave] = c1;
+            cnt[1][wave] = c2;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < PS_THREADS / 64; w++) {
+                c1 += cnt[0][w];
+                c2 += cnt[1][w];
+            }
+            out[(size_t)b * nt + t] = fscore_of((float)c1 / (float)n, (float)c2 / (float)m);
+        }
+    }
+}
+
+int blocks_x_of(int n, int m) {
+    const int nmax = n > m ? n : m;
+    return (nmax + PS_THREADS * PS_Q - 1) / (PS_THREADS * PS_Q);
+}
+
+}  // namespace
+
+extern "C" int zs_pose_max_batch(void) { return PS_THREADS; }
+
+extern "C" size_t zs_pose_scratch_bytes(int n, int m, int count) {
+    if (n <= 0 || m <= 0 || count <= 0) return 0;
+    return ((size_t)count * PS_STAT + (size_t)count * 2 * blocks_x_of(n, m) * PS_PART) * sizeof(float);
+}
+
+extern "C" size_t zs_pose_best_bytes(void) { return PS_BEST * sizeof(float); }
+
+extern "C" int zs_pose_best_init(float *best, void *stream) {
+    if (!best) {
+        zs::set_err("zs_pose_best_init: null pointer");
+        return 0;
+    }
+    float h[PS_BEST];
+    for (int i = 0; i < PS_BEST; i++) h[i] = 0.f;
+    h[0] = INFINITY;
+    const int big = 0x7fffffff;
+    __builtin_memcpy(&h[1], &big, 4);
+    // (pageable host source: the copy is staged before the call returns)
+    if (hipMemcpyAsync(best, h, sizeof(h), hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)) != hipSuccess) {
+        zs::set_err("zs_pose_best_init: hipMemcpyAsync failed");
+        return 0;
+    }
+    return 1;
+}
+
+extern "C" int zs_pose_search_batch(const float *pred, int n, const float *gt_normalized, int m,
+                                    const float *rotations, const int *order, int count, int index_offset,
+                                    const float *lower_bound, const float *thresholds6, float *best,
+                                    void *scratch, void *stream) {
+    if (n < 0 || m < 0 || count < 0) {
+        zs::set_err("zs_pose_search_batch: negative size (n=%d m=%d count=%d)", n, m, count);
+        return 0;
+    }
+    if (count == 0) return 1;
+    if (n == 0 || m == 0) {
+        zs::set_err("zs_pose_search_batch: empty cloud (n=%d m=%d)", n, m);
+        return 0;
+    }
+    if (count > PS_THREADS) {
+        zs::set_err("zs_pose_search_batch: %d rotations per batch exceed %d", count, PS_THREADS);
+        return 0;
+    }
+    if (!pred || !gt_normalized || !rotations || !thresholds6 || !best || !scratch) {
+        zs::set_err("zs_pose_search_batch: null pointer");
+        return 0;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *stats = static_cast<float *>(scratch);
+    float *partial = stats + (size_t)count * PS_STAT;
+    const int bx = blocks_x_of(n, m);
+    hipLaunchKernelGGL(pose_stats_kernel, dim3(count), dim3(PS_THREADS), 0, st, pred, (size_t)0, n, rotations, order,
+                       stats, lower_bound, best);
+    hipLaunchKernelGGL(pose_nn_kernel, dim3(bx, count, 2), dim3(PS_THREADS), 0, st, pred, n, gt_normalized, m, stats,
+                       thresholds6, partial, lower_bound, best);
+    hipLaunchKernelGGL(pose_finish_kernel, dim3(1), dim3(PS_THREADS), 0, st, partial, count, n, m, bx, order,
+                       index_offset, best, lower_bound);
+    return zs::check_launch("zs_pose_search_batch") ? 1 : 0;
+}
+
+extern "C" int zs_pose_apply(const float *pred, int n, const float *rotations, const int *index, float *out,
+                             void *scratch, void *stream) {
+    if (n < 0) {
+        zs::set_err("zs_pose_apply: negative size");
+        return 0;
+    }
+    if (n == 0) return 1;
+    if (!pred || !rotations || !out || !scratch) {
+        zs::set_err("zs_pose_apply: null pointer");
+        return 0;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *stats = static_cast<float *>(scratch);
+    hipLaunchKernelGGL(pose_stats_kernel, dim3(1), dim3(PS_THREADS), 0, st, pred, (size_t)0, n, rotations, index, stats,
+                       static_cast<const float *>(nullptr), static_cast<const float *>(nullptr));
+    hipLaunchKernelGGL(pose_apply_kernel, dim3((n + PS_THREADS - 1) / PS_THREADS, 1), dim3(PS_THREADS), 0, st, pred,
+                       (size_t)0, n, stats, out);
+    return zs::check_launch("zs_pose_apply") ? 1 : 0;
+}
+
+extern "C" int zs_normalize_pc(const float *pc, int b, int n, float *out, void *scratch, void *stream) {
+    if (b < 0 || n < 0) {
+        zs::set_err("zs_normalize_pc: negative size (b=%d n=%d)", b, n);
+        return 0;
+    }
+    if (b == 0 || n == 0) return 1;
+    if (b > 65535) {
+        zs::set_err("zs_normalize_pc: batch %d > 65535", b);
+        return 0;
+    }
+    if (!pc || !out || !scratch) {
+        zs::set_err("zs_normalize_pc: null pointer");
+        return 0;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *stats = static_cast<float *>(scratch);
+    hipLaunchKernelGGL(pose_stats_kernel, dim3(b), dim3(PS_THREADS), 0, st, pc, (size_t)n * 3, n,
+                       static_cast<const float *>(nullptr), static_cast<const int *>(nullptr), stats,
+                       static_cast<const float *>(nullptr), static_cast<const float *>(nullptr));
+    int bx = (n + PS_THREADS - 1) / PS_THREADS;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(pose_apply_kernel, dim3(bx, b), dim3(PS_THREADS), 0, st, pc, (size_t)n * 3, n, stats, out);
+    return zs::check_launch("zs_normalize_pc") ? 1 : 0;
+}
+
+extern "C" int zs_fscore(const float *dist1, int n, const float *dist2, int m, int b, const float *thresholds,
+                         int n_thresholds, float *out, void *stream) {
+    if (b < 0 || n < 0 || m < 0 || n_thresholds < 0) {
+        zs::set_err("zs_fscore: negative size");
+        return 0;
+    }
+    if (b == 0 || n_thresholds == 0) return 1;
+    if (!dist1 || !dist2 || !thresholds || !out) {
+        zs::set_err("zs_fscore: null pointer");
+        return 0;
+    }
+    hipLaunchKernelGGL(fscore_kernel, dim3(b), dim3(PS_THREADS), 0, static_cast<hipStream_t>(stream), dist1, n, dist2,
+                       m, thresholds, n_thresholds, out);
+    return zs::check_launch("zs_fscore") ? 1 : 0;
+}

@@ -134,28 +134,53 @@ def standardize_pc(pc):
     return pc_zmean / (scale * 2)
 
 
+def _gpu_f32(t, what):
+    if not t.is_cuda:
+        raise ValueError("%s must be a GPU tensor; zeroshape_amd has no CPU path" % what)
+    return t.detach().to(torch.float32).contiguous()
+
+
 @torch.no_grad()
 def normalize_pc(pc):
-    """utils/eval_3D.py:93-102 (z extent ignored, like the reference)."""
-    assert len(pc.shape) == 3
-    pc_mean = pc.mean(dim=1, keepdim=True)
-    pc_zmean = pc - pc_mean
-    length_x = pc_zmean[:, :, 0].max(dim=-1)[0] - pc_zmean[:, :, 0].min(dim=-1)[0]
-    length_y = pc_zmean[:, :, 1].max(dim=-1)[0] - pc_zmean[:, :, 1].min(dim=-1)[0]
-    length_max = torch.stack([length_x, length_y], dim=-1).max(dim=-1)[0].unsqueeze(-1).unsqueeze(-1)
-    return pc_zmean / (length_max + 1.e-7)
+    """utils/eval_3D.py:93-102 (z extent ignored, like the reference): zs_normalize_pc."""
+    from .. import _lib
+    assert len(pc.shape) == 3 and pc.shape[2] == 3
+    lib = _lib.load()
+    x = _gpu_f32(pc, "pc")
+    B, n = x.shape[0], x.shape[1]
+    out = torch.empty_like(x)
+    scratch = torch.empty(16 * max(B, 1), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.zs_normalize_pc(_lib.ptr(x), B, n, _lib.ptr(out), _lib.ptr(scratch), _lib.current_stream_ptr(x.device))
+    _lib.check(rc, "zs_normalize_pc")
+    return out
 
 
+_THRESHOLDS = {}
+
+
+def _threshold_tensor(thresholds, device, pad_to=None):
+    key = (tuple(float(t) for t in thresholds), str(device), pad_to)
+    if key not in _THRESHOLDS:
+        vals = list(key[0]) + [0.0] * max(0, (pad_to or 0) - len(key[0]))   # d < 0 never holds: padded entries score 0
+        _THRESHOLDS[key] = torch.tensor(vals, dtype=torch.float32, device=device)
+    return _THRESHOLDS[key]
+
+
+@torch.no_grad()
 def compute_fscore(dist1, dist2, thresholds=[0.005, 0.01, 0.02, 0.05, 0.1, 0.2]):
-    """utils/eval_3D.py:215-231."""
-    fscores = []
-    for threshold in thresholds:
-        precision = torch.mean((dist1 < threshold).float(), dim=1)
-        recall = torch.mean((dist2 < threshold).float(), dim=1)
-        fscore = 2 * precision * recall / (precision + recall)
-        fscore[torch.isnan(fscore)] = 0
-        fscores.append(fscore)
-    return torch.stack(fscores, dim=1)
+    """utils/eval_3D.py:215-231 on un-squared distances [B,n], [B,m] -> [B, len(thresholds)]: zs_fscore."""
+    from .. import _lib
+    lib = _lib.load()
+    d1, d2 = _gpu_f32(dist1, "dist1"), _gpu_f32(dist2, "dist2")
+    B = d1.shape[0]
+    thr = _threshold_tensor(thresholds, d1.device)
+    out = torch.empty(B, len(thresholds), dtype=torch.float32, device=d1.device)
+    with torch.cuda.device(d1.device):
+        rc = lib.zs_fscore(_lib.ptr(d1), d1.shape[1], _lib.ptr(d2), d2.shape[1], B, _lib.ptr(thr), len(thresholds),
+                           _lib.ptr(out), _lib.current_stream_ptr(d1.device))
+    _lib.check(rc, "zs_fscore")
+    return out
 
 
 _CHAMFER = chamfer_3DDist()  # stateless; the reference builds a new module per call (:267)
@@ -189,70 +214,84 @@ def _bf_lower_bounds(pc_pred, pc_gt_n, rotations):
     return lb
 
 
+_ROTATIONS = {}
+
+
+def _rotation_sphere(device):
+    key = str(torch.device(device))
+    if key not in _ROTATIONS:       # 6912 x 3 x 3, built once per device (the reference rebuilds it per call, :148)
+        _ROTATIONS[key] = get_rotation_sphere(azim_sample=24, elev_sample=24, roll_sample=12, scales=[1.0],
+                                              device=device).float().contiguous()
+    return _ROTATIONS[key]
+
+
+@torch.no_grad()
 def brute_force_search(pc_pred, pc_gt, f_thresholds=[0.005, 0.01, 0.02, 0.05, 0.1, 0.2], device="cuda",
                        rotations=None, rot_slice=None, return_index=False, batch_size=192, prune=True):
     """utils/eval_3D.py:140-170: best rigid alignment over the 6912-rotation sphere by
     Chamfer-L1, with the reference's first-strict-minimum rule (:161-168).
 
     Same result as the exhaustive scan, less work: every rotation first gets a rigorous lower
-    bound of its Chamfer-L1 (``prune``; csrc/bf_prune.hip), rotations are then evaluated
-    exactly - rotate, normalize_pc, Chamfer kernel, F-score, exactly the reference's
-    arithmetic - in order of increasing bound, ``batch_size`` at a time (the reference: 24 in
-    index order, :149), and the scan stops as soon as the smallest remaining bound exceeds the
-    best exact distance.  The winner is the lexicographic minimum of (cd, rotation index) over
-    the evaluated rotations; pruned ones are strictly worse, so this IS the first strict
-    minimum of the full scan.  The winner of each batch is picked on the device (one sync per
-    batch instead of one per rotation) and the rotation table is cached.
+    bound of its Chamfer-L1 (``prune``; csrc/bf_prune.hip); rotations are then evaluated exactly
+    in order of increasing bound, ``batch_size`` at a time (the reference: 24 in index order,
+    :149), by the fused kernels of csrc/pose_search.hip - rotate, normalize_pc, nearest
+    neighbours both ways, sqrt / means / F-score, running (cd, rotation index) minimum, all on
+    the device - and a batch whose smallest bound already exceeds the best exact distance returns
+    at once.  Every batch is enqueued up front: no synchronisation, no rotated clouds, no
+    PyTorch or BLAS launch inside the search.  The winner is the lexicographic minimum of
+    (cd, rotation index) over the evaluated rotations; pruned ones are strictly worse, so this IS
+    the first strict minimum of the full scan.
     ``rot_slice=(start, stop)`` restricts the scan to a contiguous index range (multi-GPU
     sharding, zeroshape_amd/parallel.py); ``return_index`` appends the winning global rotation
-    index and its cd."""
-    pc_pred = pc_pred.to(device).unsqueeze(0).float()
-    pc_gt = pc_gt.to(device).unsqueeze(0).float().contiguous()
-    pc_gt = normalize_pc(pc_gt)
-    if rotations is None:
-        rotations = get_rotation_sphere(azim_sample=24, elev_sample=24, roll_sample=12, scales=[1.0],
-                                        device=device)
+    index and its cd (one host read of the 64-byte record)."""
+    from .. import _lib
+    lib = _lib.load()
+    if len(f_thresholds) > 6:
+        raise ValueError("the fused pose search carries six F-score thresholds (options/shape.yaml:54)")
+    dev = torch.device(device)
+    pred = pc_pred.to(dev).float().contiguous()
+    pc_gt = normalize_pc(pc_gt.to(dev).unsqueeze(0).float().contiguous())
+    rotations = _rotation_sphere(dev) if rotations is None else rotations.to(dev).float().contiguous()
     start, stop = (0, len(rotations)) if rot_slice is None else rot_slice
     if stop <= start:
         raise ValueError("empty rotation range")
-    rotations = rotations.to(device)
+    batch_size = min(int(batch_size), lib.zs_pose_max_batch())
     K = stop - start
+    n, m = pred.shape[0], pc_gt.shape[1]
+    order = lb_sorted = None
     if prune and K > batch_size:
-        lb = _bf_lower_bounds(pc_pred[0], pc_gt[0], rotations[start:stop])
+        lb = _bf_lower_bounds(pred, pc_gt[0], rotations[start:stop])
         lb_sorted, order = torch.sort(lb, stable=True)
-        lb_host = lb_sorted.cpu().numpy()
-    else:
-        order = torch.arange(K, device=rotations.device)
-        lb_host = np.zeros(K, np.float32)
-    best_cd, best_idx, best = np.inf, -1, None
-    n_eval = 0
-    for pos in range(0, K, batch_size):
-        # bound * (1 - 1e-3) - 1e-6: margin for the roundings of both the bound and the exact path
-        if best is not None and float(lb_host[pos]) * (1.0 - 1e-3) - 1e-6 > best_cd:
-            break
-        sel = order[pos:pos + batch_size]
-        gidx = sel + start                                   # global rotation indices of the batch
-        rotation_batch = rotations[gidx]
-        nb = rotation_batch.shape[0]
-        pc_pred_rotated = (rotation_batch @ pc_pred.repeat(nb, 1, 1).permute(0, 2, 1)).permute(0, 2, 1)
-        pc_pred_rotated = normalize_pc(pc_pred_rotated).contiguous()
-        # most surviving rotations still leave the clouds apart, where the plain scan beats the grid kernel
-        acc, comp, _, _ = chamfer_distance(None, pc_pred_rotated, pc_gt.repeat(nb, 1, 1).contiguous(),
-                                           method="brute")
-        f_score = compute_fscore(acc, comp, f_thresholds)
-        acc, comp = acc.mean(dim=1), comp.mean(dim=1)
-        cd = (acc + comp) / 2
-        n_eval += nb
-        cd_min = cd.min()
-        j = int(torch.where(cd == cd_min, gidx, torch.full_like(gidx, 1 << 30)).argmin())  # lowest index among ties
-        cd_j, g_j = float(cd[j]), int(gidx[j])
-        if cd_j < best_cd or (cd_j == best_cd and g_j < best_idx):
-            best_cd, best_idx = cd_j, g_j
-            best = (acc[j], comp[j], f_score[j], pc_pred_rotated[j].clone())
-    brute_force_search.last_evaluated = n_eval               # diagnostics: rotations evaluated exactly
-    out = (best[0], best[1], best[2], best[3], pc_gt)
+        order = order.to(torch.int32)
+    thr = _threshold_tensor(f_thresholds, dev, pad_to=6)
+    best = torch.empty(lib.zs_pose_best_bytes() // 4, dtype=torch.float32, device=dev)
+    scratch = torch.empty(lib.zs_pose_scratch_bytes(n, m, min(batch_size, K)) // 4, dtype=torch.float32, device=dev)
+    st = _lib.current_stream_ptr(dev)
+    rot_base = rotations.data_ptr() + 36 * start
+    with torch.cuda.device(dev):
+        _lib.check(lib.zs_pose_best_init(_lib.ptr(best), st), "zs_pose_best_init")
+        for pos in range(0, K, batch_size):
+            count = min(batch_size, K - pos)
+            if order is not None:      # rotation b of the batch = rotations[start + order[pos + b]]
+                rc = lib.zs_pose_search_batch(_lib.ptr(pred), n, _lib.ptr(pc_gt), m, rot_base, order.data_ptr() + 4 * pos,
+                                              count, start, lb_sorted.data_ptr() + 4 * pos, _lib.ptr(thr),
+                                              _lib.ptr(best), _lib.ptr(scratch), st)
+            else:                      # index order
+                rc = lib.zs_pose_search_batch(_lib.ptr(pred), n, _lib.ptr(pc_gt), m, rot_base + 36 * pos, None, count,
+                                              start + pos, None, _lib.ptr(thr), _lib.ptr(best), _lib.ptr(scratch), st)
+            _lib.check(rc, "zs_pose_search_batch")
+        ibest = best.view(torch.int32)
+        best_pred = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        rc = lib.zs_pose_apply(_lib.ptr(pred), n, _lib.ptr(rotations), ibest.data_ptr() + 4, _lib.ptr(best_pred),
+                               _lib.ptr(scratch), st)
+        _lib.check(rc, "zs_pose_apply")
+    out = (best[2].clone(), best[3].clone(), best[4:4 + len(f_thresholds)].clone(), best_pred, pc_gt)
+    brute_force_search.last_evaluated = None
     if return_index:
-        out = out + (best_idx, best_cd)
+        rec = best.cpu()
+        irec = rec.view(torch.int32)
+        brute_force_search.last_evaluated = int(irec[10])        # diagnostics: rotations evaluated exactly
+        out = out + (int(irec[1]), float(rec[0]))
     return out
 
 
