@@ -30,6 +30,13 @@ Extra objects on the JSON line:
                  and the occupancy flips between the two arithmetics on the full grid.
   cpu_baseline - the oracle (torch-CPU fp32 restatement of the reference, "port") timed on
                  this host's cores on a bounded sample of x-slices of the same grid.
+  chamfer / pose_search / chamfer_l1 / encoder / train_step
+               - (N = 1, outside the timed region; tools/bench_legs.py) the rest of the BASELINE metric: the
+                 Chamfer NN kernel on [24,10k]x[24,10k] with its fp32-VALU roofline fraction, bit equality
+                 to the oracle and the oracle timed on the host (CPU leg ii); the 6912-rotation pose search
+                 exhaustive and pruned; Chamfer-L1 against the oracle pipeline and across the two decoder
+                 arithmetics; encoder forward B = 1 / 28 with the CPU restatement at B = 1 (CPU leg iii);
+                 one training step at per-GPU batch 4.  --no-extras skips them.
 """
 import argparse
 import json
@@ -49,10 +56,24 @@ PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_{f16
 # matrix work the kernels really execute per point (197 -> 224 latent padding included):
 EXEC_FLOP_PER_POINT = {"f32": 39424 * 4096 / 32.0,        # 39,424 MFMAs of 32x32x2 per 32 points
                        "f16x3": 14784 * 32768 / 32.0}    # 14,784 MFMAs of 32x32x16 per 32 points
-# HBM-side bytes per 129^3 launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the
-# gfx950 correction + WRITE_SIZE; profiles/README.md)
-TRAFFIC = {"f32": (1.88e10, "profiles/r01_v3_decoder_rocprofv3_summary.txt"),
-           "f16x3": (1.84e10, "profiles/r01_split_decoder_rocprofv3_summary.txt")}
+# HBM-side bytes per 129^3 launch come from a rocprofv3 PMC pass (FETCH_SIZE x2 per the gfx950
+# correction + WRITE_SIZE, profiles/README.md) recorded in profiles/decoder_traffic.json together with
+# the sha1 of the kernel source it was measured on: reported only while that source is unchanged,
+# null (with the stale profile named) otherwise - never a constant that outlives the kernel.
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "decoder_traffic.json")
+KERNEL_SOURCE = {"f32": "zeroshape_amd/csrc/sdf_decoder.hip", "f16x3": "zeroshape_amd/csrc/sdf_decoder_split.hip"}
+
+
+def measured_traffic(precision):
+    import hashlib
+    try:
+        rec = json.load(open(TRAFFIC_FILE))[precision]
+        sha = hashlib.sha1(open(os.path.join(ROOT, KERNEL_SOURCE[precision]), "rb").read()).hexdigest()
+    except (OSError, KeyError, ValueError):
+        return None, None
+    if rec.get("source_sha1") != sha:
+        return None, "%s (stale: kernel source changed since)" % rec.get("profile")
+    return rec["bytes_per_launch"], rec.get("profile")
 
 
 def main():
@@ -63,6 +84,8 @@ def main():
     ap.add_argument("--vox-res", type=int, default=VOX_RES)
     ap.add_argument("--precision", choices=("f16x3", "f32"), default="f16x3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the Chamfer / pose-search / evaluation / encoder / training legs (tools/bench_legs.py)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -154,7 +177,7 @@ def main():
         peak = PEAK_F16_MFMA_TFLOPS if precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
         achieved = pts_launch * FLOP_PER_POINT / (mean * 1e-3) / 1e12
         executed = pts_launch * EXEC_FLOP_PER_POINT[precision] / (mean * 1e-3) / 1e12
-        traffic, src = TRAFFIC[precision] if (N == 128 and world == 1) else (None, None)
+        traffic, src = measured_traffic(precision) if (N == 128 and world == 1) else (None, None)
         return {"bound": "mfma",
                 "kernel": "sdf_decode_split_kernel<GRID>" if precision == "f16x3" else "sdf_decode_kernel<GRID>",
                 "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
@@ -214,6 +237,18 @@ def main():
                         "sample": "%d evenly spaced x-slices of the %d^3 grid (%d points), oracle/"
                                   "decoder_ref.level_grid, torch-CPU fp32, %.1f s" % (done, G, done * G * G, cdt)}
 
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras and N == VOX_RES:
+        from tools import bench_legs as legs
+        cpu = not args.no_cpu_baseline
+        for name, fn in (("chamfer", lambda: legs.chamfer_leg(dev, cpu)), ("pose_search", lambda: legs.pose_search_leg(dev)),
+                         ("chamfer_l1", lambda: legs.eval_leg(dev, net, sd)), ("encoder", lambda: legs.encoder_leg(dev, cpu)),
+                         ("train_step", lambda: legs.train_leg(dev))):
+            try:
+                extras[name] = fn()
+            except Exception as e:                      # a leg must never take the headline line down
+                extras[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+
     if rank == 0:
         line = {
             "metric": "sdf_query_points_per_sec_vox%d" % N, "value": round(value, 1),
@@ -230,6 +265,7 @@ def main():
         }
         if exact_f32 is not None:
             line["exact_f32"] = exact_f32
+        line.update(extras)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

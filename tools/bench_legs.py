@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""The rest of the BASELINE metric beside bench.py's timed region (N = 1, rank 0, outside the timed
+steps): Chamfer NN kernel, 6912-rotation pose search, Chamfer-L1 of a whole evaluation sample
+against the oracle pipeline and across the two decoder arithmetics, encoder forward (B = 1 / 28),
+one training step (B = 4), and SURVEY.md section 8d's CPU legs (ii) Chamfer and (iii) encoder B = 1.
+Every function returns one JSON-able dict and bounds its own run time; bench.py prints them as
+extra objects of its line.  Stand-alone:  python tools/bench_legs.py [chamfer pose eval encoder train]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_VALU_TFLOPS = 157.3        # MI355X_MICROARCH.md
+FLOP_PER_PAIR = 8                   # 3 sub, 1 mul, 2 fma, 1 cmp, 1 select
+GFLOP_DPT, GFLOP_RES, GFLOP_INTR = 2 * 41.3, 2 * 5.0, 2 * 1.0     # per 224^2 image, DESIGN.md 10.3
+
+
+def _events(fn, reps, stream=None):
+    fn()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record(stream)
+    for i in range(reps):
+        fn()
+        ev[i + 1].record(stream)
+    torch.cuda.synchronize()
+    ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps))
+    return sum(ms) / len(ms), ms[0]
+
+
+def chamfer_leg(dev, cpu=True):
+    """[24,10k] x [24,10k]: the brute-force scan kernel (roofline-graded: fp32 VALU, 8 flop per
+    pair), the grid-accelerated exact kernel, bit equality against the oracle, and the oracle itself timed
+    on this host's cores (CPU leg ii: plain C + OpenMP port of chamfer3D.cu:12-134)."""
+    from zeroshape_amd import synthetic as syn
+    from zeroshape_amd.external.chamfer3D.dist_chamfer_3D import chamfer_3DDist
+    B, n, m = 24, 10000, 10000
+    a_h, b_h = syn.seeded_cloud(1, B, n), syn.seeded_cloud(2, B, m)
+    a, b = torch.from_numpy(a_h).to(dev), torch.from_numpy(b_h).to(dev)
+    ch = chamfer_3DDist()
+    ms_brute, min_brute = _events(lambda: ch(a, b, "brute"), 10)
+    ms_grid, _ = _events(lambda: ch(a, b, "grid"), 10)
+    pairs = 2.0 * B * n * m
+    out = {"shape": [B, n, m], "ms": round(ms_brute, 4), "ms_min": round(min_brute, 4),
+           "tpairs_per_s": round(pairs / (ms_brute * 1e-3) / 1e12, 3),
+           "roofline": {"bound": "valu_f32", "achieved": round(pairs * FLOP_PER_PAIR / (ms_brute * 1e-3) / 1e12, 2),
+                        "peak": PEAK_F32_VALU_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(pairs * FLOP_PER_PAIR / (ms_brute * 1e-3) / 1e12 / PEAK_F32_VALU_TFLOPS, 4),
+                        "kernel": "nn_both_kernel<2>", "flop_per_pair": FLOP_PER_PAIR},
+           "grid_accelerated_ms": round(ms_grid, 4)}
+    if cpu:
+        from oracle import chamfer_ref
+        t0 = time.perf_counter()
+        w = chamfer_ref.chamfer_forward(a_h, b_h)
+        dt = time.perf_counter() - t0
+        d1, d2, i1, i2 = ch(a, b, "brute")
+        g1, g2, j1, j2 = ch(a, b, "grid")
+        out["bit_equal_to_oracle"] = bool(
+            np.array_equal(d1.cpu().numpy(), w[0]) and np.array_equal(d2.cpu().numpy(), w[1]) and
+            np.array_equal(i1.cpu().numpy(), w[2]) and np.array_equal(i2.cpu().numpy(), w[3]) and
+            torch.equal(d1, g1) and torch.equal(i1, j1) and torch.equal(d2, g2) and torch.equal(i2, j2))
+        out["cpu_baseline"] = {"value": round(pairs / dt / 1e12, 5), "unit": "Tpairs/s", "seconds": round(dt, 2),
+                               "cores": os.cpu_count(), "kind": "port",
+                               "sample": "one [24,10000]x[24,10000] call, oracle/chamfer_ref.c (C + OpenMP, all cores)"}
+    return out
+
+
+def pose_search_leg(dev):
+    """brute_force_search (utils/eval_3D.py:140-170) over the 6912-rotation sphere, 10k x 10k points: the
+    exhaustive scan, and the lower-bound pruned scan for an alignable and for an unrelated ground truth."""
+    from zeroshape_amd import synthetic as syn
+    from zeroshape_amd.utils import eval_3D as E
+    n = 10000
+    pred = torch.from_numpy(syn.ellipsoid_cloud(0, n)).to(dev)
+    R = E._rotation_sphere(dev)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    gt = ((R[1234] @ pred.T).T.contiguous().cpu() + 1e-3 * torch.randn(n, 3, generator=g)).to(dev)
+    far = torch.from_numpy(syn.seeded_cloud(9, 1, n)[0]).to(dev)
+
+    def run(gt_, prune):
+        E.brute_force_search(pred, gt_, device=dev, prune=prune)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        o = E.brute_force_search(pred, gt_, device=dev, prune=prune, return_index=True)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3, o
+    ms_ex, o_ex = run(gt, False)
+    ms_pr, o_pr = run(gt, True)
+    n_pr = E.brute_force_search.last_evaluated
+    ms_far, o_far = run(far, True)
+    n_far = E.brute_force_search.last_evaluated
+    pairs = 6912 * 2.0 * n * n
+    return {"rotations": 6912, "points": [n, n], "exhaustive_ms": round(ms_ex, 2),
+            "exhaustive_tpairs_per_s": round(pairs / (ms_ex * 1e-3) / 1e12, 3),
+            "exhaustive_frac_of_fp32_valu_peak": round(pairs * FLOP_PER_PAIR / (ms_ex * 1e-3) / 1e12 / PEAK_F32_VALU_TFLOPS, 4),
+            "pruned_ms": round(ms_pr, 2), "pruned_rotations_evaluated": n_pr,
+            "pruned_equals_exhaustive": bool(o_ex[5] == o_pr[5] and o_ex[6] == o_pr[6] and torch.equal(o_ex[3], o_pr[3])),
+            "best_index": int(o_ex[5]), "best_cd": float(o_ex[6]),
+            "unalignable_gt_pruned_ms": round(ms_far, 2), "unalignable_gt_rotations_evaluated": n_far}
+
+
+def eval_leg(dev, net, sd):
+    """Chamfer-L1 (utils/eval_3D.py:136-137) of whole evaluation samples: (a) the HIP pipeline (decoder ->
+    marching cubes -> sampling -> normalise -> Chamfer) against the same pipeline built from the oracle's
+    pieces on the CPU at vox_res 16 (tests/test_gpu_eval_pipeline.py); (b) the split-fp16 against the
+    exact-fp32 decoder on the 129^3 grid of the headline workload."""
+    from oracle import decoder_ref as R, geometry_ref as G, mc_ref as M
+    from zeroshape_amd import synthetic as syn
+    from zeroshape_amd.utils import eval_3D as E
+    from zeroshape_amd.utils.options import EasyDict as edict
+
+    def opt_of(N, P):
+        return edict(dict(device=str(dev), H=224, W=224, arch=dict(win_size=16), data=dict(dataset_test="synthetic"),
+                          eval=dict(vox_res=N, range=[-1.5, 1.5], num_points=P, icp=False, brute_force=False,
+                                    f_thresholds=[0.005, 0.01, 0.02, 0.05, 0.1, 0.2])))
+
+    def var_of(latent, gt):
+        B = latent.shape[0]
+        return edict(dict(idx=list(range(B)), latent_depth=latent.to(dev), latent_semantic=None,
+                          rgb_input_map=torch.zeros(B, 3, 224, 224, device=dev),
+                          pose_gt=torch.eye(3, 4)[None].repeat(B, 1, 1).to(dev), dpc=dict(points=gt.clone().to(dev))))
+    N, P = 16, 2000
+    latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=2))
+    gt = torch.from_numpy(syn.seeded_cloud(5, 2, 1500, -1, 1))
+    var = var_of(latent, gt)
+    E.eval_metrics(opt_of(N, P), var, net)
+    occ = R.level_grid(sd, latent, R.dense_grid(-1.5, 1.5, N, 2))
+    worst = 0.0
+    for b in range(2):
+        tris = M.marching_cubes(occ[b].numpy(), 0.5, np.float32(3.0 / (N + 1)), -1.5)
+        pts, _ = M.sample_surface(tris, P, seed=b)
+        d1, d2, _, _ = G.chamfer_distance(G.normalize_pc(torch.from_numpy(pts)[None]), G.normalize_pc(gt[b][None]))
+        worst = max(worst, abs(float(d1.mean()) - float(var.cd_acc[b])), abs(float(d2.mean()) - float(var.cd_comp[b])))
+    res = {}
+    prev = net.precision
+    try:
+        for prec in ("f32", "f16x3"):
+            net.precision = prec
+            v = var_of(latent[:1], torch.from_numpy(syn.seeded_cloud(6, 1, 10000, -0.6, 0.6)))
+            E.eval_metrics(opt_of(128, 10000), v, net)
+            res[prec] = v
+    finally:
+        net.precision = prev
+    a, b = res["f32"], res["f16x3"]
+    return {"chamfer_l1_vs_oracle_pipeline_vox16": float(worst), "contract": 1e-4,
+            "chamfer_l1_f16x3_vs_f32_vox128": float(max((a.cd_acc - b.cd_acc).abs().max(), (a.cd_comp - b.cd_comp).abs().max())),
+            "chamfer_l1_vox128": float((a.cd_acc + a.cd_comp) / 2)}
+
+
+def _graph(dev):
+    from zeroshape_amd.model.compute_graph.graph_shape import Graph
+    from zeroshape_amd.utils.options import EasyDict as edict
+    opt = edict(dict(H=224, W=224, device=str(dev), pretrain=dict(depth=None),
+                     arch=dict(num_heads=8, latent_dim=256, win_size=16,
+                               depth=dict(encoder="resnet", n_blocks=12, dsp=2, pretrained=None),
+                               rgb=dict(encoder=None, n_blocks=12),
+                               impl=dict(n_channels=256, att_blocks=2, mlp_ratio=4., posenc_perlayer=False,
+                                         mlp_layers=8, posenc_3D=0, skip_in=[2, 4, 6]))))
+    torch.manual_seed(0)
+    g = Graph(opt)
+    with torch.no_grad():
+        torch.nn.init.normal_(g.intr_proj.weight, std=0.01)
+    return opt, g.to(dev).eval()
+
+
+def encoder_leg(dev, cpu=True):
+    """Encoder half of Graph.forward (graph_shape.py:117-150: DPT-hybrid depth + intrinsics head + seen-surface
+    geometry + ResNet-50 coordinate encoder), replayed as one hipGraph, batch 1 and options/shape.yaml's 28;
+    CPU leg iii: the oracle's functional restatement (oracle/encoder_ref.graph_forward, torch-CPU fp32), B = 1."""
+    from zeroshape_amd import synthetic as syn
+    from zeroshape_amd.utils.options import EasyDict as edict
+    opt, g = _graph(dev)
+    gflop = GFLOP_DPT + GFLOP_RES + GFLOP_INTR
+    out = {"gflop_per_image": gflop, "peak": 2500.0, "unit": "TFLOP/s (algorithmic; split-fp16 on the 16-bit matrix pipe)"}
+    g.enable_hip_graph(True)
+    for B in (1, 28):
+        rgb, mask = [torch.from_numpy(x).to(dev) for x in syn.seeded_rgb_scene(0, B)]
+        var = edict(dict(idx=list(range(B)), rgb_input_map=rgb, mask_input_map=mask))
+        ms, mn = _events(lambda: g.forward(opt, var, training=False, get_loss=False), 10 if B == 1 else 5)
+        out["b%d" % B] = {"ms": round(ms, 3), "ms_min": round(mn, 3), "tflops": round(gflop * B / ms, 1),
+                          "frac_of_peak": round(gflop * B / ms / 2500.0, 4)}
+    g.enable_hip_graph(False)
+    if cpu:
+        from oracle import encoder_ref
+        sd = {k: v.detach().cpu() for k, v in g.state_dict().items()}
+        rgb, mask = [torch.from_numpy(x) for x in syn.seeded_rgb_scene(0, 1)]
+        ncpu = os.cpu_count() or 1
+        best = None
+        with torch.no_grad():
+            for th in sorted(set(min(t, ncpu) for t in (16, 32, 64))):
+                torch.set_num_threads(th)
+                encoder_ref.graph_forward(sd, rgb, mask)
+                t0 = time.perf_counter()
+                encoder_ref.graph_forward(sd, rgb, mask)
+                dt = time.perf_counter() - t0
+                if best is None or dt < best[1]:
+                    best = (th, dt)
+        out["cpu_baseline"] = {"value": round(best[1] * 1e3, 1), "unit": "ms per image", "cores": best[0], "kind": "port",
+                               "sample": "one 224x224 image, oracle/encoder_ref.graph_forward (torch-CPU fp32), best of 16/32/64 threads"}
+    del g
+    torch.cuda.empty_cache()
+    return out
+
+
+def train_leg(dev, steps=8, warmup=3):
+    """Runner.train_iteration (model/shape_engine.py:248-297) on BASELINE config 4's per-GPU batch: 4 images,
+    4096 SDF samples each, fp32, forward + backward + fused AdamW."""
+    from zeroshape_amd.data.synthetic import Dataset
+    from zeroshape_amd.utils import options, util
+    from zeroshape_amd.utils.options import EasyDict as edict
+    cmd = options.parse_arguments(["--yaml=%s/options/shape.yaml" % ROOT, "--output_root=/tmp/zs_bench_train",
+                                   "--batch_size=4", "--pretrain.depth=", "--arch.depth.pretrained=",
+                                   "--training.n_sdf_points=4096"])
+    opt = options.set(cmd)
+    opt.world_size = 1
+    opt.output_path = None                      # no checkpoints from a benchmark
+    from zeroshape_amd.model.shape_engine import Runner
+    r = Runner(opt)
+    r.load_train_dataset(opt, dataset=Dataset(opt, split="train", n_items=4, n_points=100, seed=0))
+    r.build_networks(opt)
+    r.setup_optimizer(opt)
+    r.graph.train()
+    var0 = util.move_to_device(edict(next(iter(r.train_loader))), opt.device)
+
+    def step():
+        r.train_iteration(opt, edict({k: (v.clone() if torch.is_tensor(v) else v) for k, v in var0.items()}))
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    tflop = 3 * 4 * (GFLOP_DPT + GFLOP_RES + GFLOP_INTR + 4096 * 5.0e-3) / 1e3      # forward + 2x backward
+    del r
+    torch.cuda.empty_cache()
+    return {"per_gpu_batch": 4, "sdf_points": 4096, "ms": round(ms, 2), "images_per_s": round(4 / ms * 1e3, 1),
+            "tflops": round(tflop / (ms * 1e-3), 1), "frac_of_f32_mfma_peak": round(tflop / (ms * 1e-3) / 157.3, 4)}
+
+
+if __name__ == "__main__":
+    dev = torch.device("cuda:0")
+    want = sys.argv[1:] or ["chamfer", "pose", "encoder", "train"]
+    if "chamfer" in want:
+        print(json.dumps({"chamfer": chamfer_leg(dev)}), flush=True)
+    if "pose" in want:
+        print(json.dumps({"pose_search": pose_search_leg(dev)}), flush=True)
+    if "encoder" in want:
+        print(json.dumps({"encoder": encoder_leg(dev)}), flush=True)
+    if "train" in want:
+        print(json.dumps({"train_step": train_leg(dev)}), flush=True)
