@@ -102,3 +102,42 @@ def test_checkpoint_roundtrip_in_reference_layout(big_tmp_path):
     util.load_checkpoint(opt, c, str(tmp_path / "latest.ckpt"))
     assert torch.equal(c.graph.intr_proj.weight, a.graph.intr_proj.weight)
     assert torch.equal(c.graph.coord_encoder.encoder.conv1.weight, before)
+
+
+def test_pix3d_and_omniobj3d_shaped_items():
+    """Sample-dict keys of the reference's data/pix3d.py:86-113 and data/omniobj3d.py:129-165, and the
+    Pix3D camera convention: the GT cloud reaches the view frame only through the xy flip of
+    utils/eval_3D.py:122-123 (oracle/geometry check on the CPU; the HIP path runs it in
+    tests/test_gpu_entry_scripts.py)."""
+    import importlib
+    opt = edict(dict(H=224, W=224, data=dict(pix3d=dict(cat=None), bgcolor=1), training=dict(n_sdf_points=256)))
+    pix = importlib.import_module("zeroshape_amd.data.pix3d").Dataset(opt, split="test", n_items=11, n_points=500)
+    omn = importlib.import_module("zeroshape_amd.data.omniobj3d").Dataset(opt, split="test", n_items=4, n_points=500)
+    p, o = pix[10], omn[3]
+    assert set(p) == {"idx", "rgb_input_map", "mask_input_map", "category_label", "pose_gt", "intr", "dpc"}
+    assert set(o) == {"idx", "category_label", "pose_gt", "intr", "rgb_input_map", "mask_input_map",
+                      "depth_input_map", "dpc"}
+    assert set(importlib.import_module("zeroshape_amd.data.omniobj3d").Dataset(opt, load_3D=False, n_items=1)[0]) == \
+        set(o) - {"dpc"}
+    assert len(pix.label2cat) == 9 and p["category_label"] == 10 % 9 and pix.cat2label["chair"] == 2
+    assert tuple(p["pose_gt"].shape) == (3, 4) and tuple(p["dpc"]["points"].shape) == (500, 3)
+    assert torch.equal(o["mask_input_map"], (o["depth_input_map"] != 0).float())
+    opt2 = edict(dict(H=224, W=224, data=dict(pix3d=dict(cat="chair,sofa")), training=dict(n_sdf_points=256)))
+    assert importlib.import_module("zeroshape_amd.data.pix3d").Dataset(opt2, n_items=2).label2cat == ["chair", "sofa"]
+    # geometry: depth unprojected into the camera frame == flip(R_pix3d @ gt) + t, but not without the flip
+    from scipy.spatial import cKDTree
+    K, pose = p["intr"].numpy(), p["pose_gt"].numpy()
+    v, u = np.nonzero(p["mask_input_map"][0].numpy())
+    base = importlib.import_module("zeroshape_amd.data.synthetic").Dataset(opt, split="test", n_items=11, n_points=500, seed=7)[10]
+    z = base["depth_input_map"][0].numpy()[v, u]
+    cam = np.stack([(u - K[0, 2]) / K[0, 0] * z, (v - K[1, 2]) / K[1, 1] * z, z], 1)
+    gt = p["dpc"]["points"].numpy().astype(np.float64)
+    rot = gt @ pose[:, :3].T
+    flipped = rot * np.array([-1.0, -1.0, 1.0]) + base["pose_gt"].numpy()[:, 3]
+    d_flip = cKDTree(flipped).query(cam[::50])[0]
+    assert np.median(d_flip) < 0.05                                    # the visible surface lies on the flipped cloud
+    view = gt @ base["pose_gt"].numpy()[:, :3].T.astype(np.float64) + base["pose_gt"].numpy()[:, 3]
+    np.testing.assert_allclose(flipped, view, atol=1e-5)               # = the render's own view-frame cloud
+    assert np.abs(rot + base["pose_gt"].numpy()[:, 3] - view).max() > 0.1      # ... and only with the flip
+    pix.id_filename_mapping(opt, "/tmp/zs_pix3d_map.txt")
+    assert len(open("/tmp/zs_pix3d_map.txt").read().strip().split("\n")[0].split(" ")) == 4

@@ -36,6 +36,29 @@ def test_train_then_evaluate_scripts(tmp_path):
     q = open(os.path.join(run_dir, "quantitative_synthetic.txt")).read().split("\n")
     assert q[0].startswith("CD     Acc    Comp") and np.isfinite(float(q[1].split()[0]))
     assert len(open(os.path.join(run_dir, "data_list.txt")).read().strip().split("\n")) == 4
+    # BASELINE config 3, literally (README.md:108): Pix3D-shaped items, vox_res 128, brute-force alignment - incl.
+    # the Pix3D-only xy flip of utils/eval_3D.py:122-123 - and config 5: OmniObject3D-shaped items at vox_res 256
+    base = ["--pretrain.depth=", "--arch.depth.pretrained=", "--load=%s/latest.ckpt" % run_dir, out]
+    run("evaluate.py", "--yaml=options/shape.yaml", "--data.dataset_test=pix3d", "--eval.vox_res=128", "--eval.brute_force",
+        "--eval.batch_size=1", *base)
+    rows = open(os.path.join(run_dir, "pix3d_full_results.txt")).read().strip().split("\n")
+    assert len(rows) == 1 + 4 and all(np.isfinite(float(v)) for r in rows[1:] for v in r.split("\t")[1:])
+    cats = open(os.path.join(run_dir, "cd_cat.txt")).read()
+    assert "bed" in cats and "desk" in cats
+    run("evaluate.py", "--yaml=options/shape.yaml", "--data.dataset_test=omniobj3d", "--eval.vox_res=256", "--eval.batch_size=2",
+        *base)
+    q = open(os.path.join(run_dir, "quantitative_omniobj3d.txt")).read().split("\n")
+    assert np.isfinite(float(q[1].split()[0]))
+
+
+def test_sharded_grid_rehearsal_on_one_gpu():
+    """zeroshape_amd/parallel.py's grid sharding with 4 virtual ranks on this GPU (tools/rehearse_sharded_grid.py;
+    the 8-rank vox-256 run of BASELINE config 5 is recorded in profiles/)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import rehearse_sharded_grid as rh
+    rec = rh.main(["--world", "4", "--vox-res", "64", "--points", "512"])
+    assert rec["gathered_equals_single_launch"] and rec["max_abs_occupancy_error_vs_oracle"] < 1e-4
+    assert sum(rec["points_per_rank"]) == 65 ** 3 and max(rec["points_per_rank"]) - min(rec["points_per_rank"]) < 128 * 4
 
 
 def test_depth_engine_evaluates(tmp_path, encoder_sd):

@@ -7,8 +7,8 @@ names (utils, model, data, external) to their zeroshape_amd mirrors in sys.modul
         --yaml=options/shape.yaml
 or simply `python train.py ...` with the train.py / evaluate.py of this repository, which do that.
 
-Only names that exist here are aliased; importing anything else of the reference (data.pix3d,
-data.ocrtoc, ...) fails loudly with ModuleNotFoundError instead of silently falling back.
+Only names that exist here are aliased; importing anything else of the reference (data.ocrtoc,
+...) fails loudly with ModuleNotFoundError instead of silently falling back.
 """
 import importlib
 import sys
@@ -37,6 +37,8 @@ _ALIASES = {
     "model.shape.seen_coord_enc": "zeroshape_amd.model.shape.seen_coord_enc",
     "data": "zeroshape_amd.data",
     "data.synthetic": "zeroshape_amd.data.synthetic",
+    "data.pix3d": "zeroshape_amd.data.pix3d",
+    "data.omniobj3d": "zeroshape_amd.data.omniobj3d",
     "external": "zeroshape_amd.external",
     "external.chamfer3D": "zeroshape_amd.external.chamfer3D",
     "external.chamfer3D.dist_chamfer_3D": "zeroshape_amd.external.chamfer3D.dist_chamfer_3D",
