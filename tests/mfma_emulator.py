@@ -220,17 +220,23 @@ def _decode_wave(st, gemm_tile, params, xyz, split):
         cur.append(softplus100(gemm_tile(st, feat, acc)))
     feat_s = [t / sq2 for t in feat]
     sx, sy, sz = px / sq2, py / sq2, pz / sq2
-    # feat halves of the skip layers (workspace "Z" tiles on the device)
+    # feat halves of the skip layers: fp32 kernel = workspace "Z" tiles computed up front; split
+    # kernel = 16 more K-blocks per output tile inside the skip layer (feat / sqrt(2) stays packed)
     Z = {}
-    for l in P.SKIP_IN:
-        Z[l] = [gemm_tile(st, feat_s, np.zeros((16, 64))) for nt in range(8)]
+    if not split:
+        for l in P.SKIP_IN:
+            Z[l] = [gemm_tile(st, feat_s, np.zeros((16, 64))) for nt in range(8)]
     for l in range(1, P.MLP_LAYERS - 1):
         nxt = []
         if l in P.SKIP_IN:
             for nt in range(8):
                 acc = xyz_affine(L.impl[l], nt, sx, sy, sz)
                 gemm_tile(st, cur, acc)          # cur already holds x / sqrt(2)
-                nxt.append(softplus100(acc + Z[l][nt]))
+                if split:
+                    gemm_tile(st, feat_s, acc)
+                    nxt.append(softplus100(acc))
+                else:
+                    nxt.append(softplus100(acc + Z[l][nt]))
         else:
             post = sq2 if (l + 1) in P.SKIP_IN else 1.0
             for nt in range(8):

@@ -67,7 +67,12 @@ def test_split_stream_order_and_layout():
     assert list(m[:16]) == list(range(16))                         # fc1(0)
     assert list(m[16:32]) == list(range(32, 48))                   # fc1(1)
     assert list(m[32:48]) == list(range(16, 32))                   # fc2(0)
-    assert np.array_equal(src[2 * kb_block:], np.arange(2 * kb_block, src.size))   # impl_mlp + tail
+    # impl_mlp: L0 | L1 | per pair [x part | feat part] per output tile, plain layer; then the zero tail
+    b0, kl = 2 * kb_block, 128
+    assert np.array_equal(src[b0:b0 + kl], b0 + np.arange(kl)) and np.array_equal(src[b0 + kl:b0 + 2 * kl], b0 + 4 * kl + np.arange(kl))
+    assert list(src[b0 + 2 * kl:b0 + 2 * kl + 34] - b0) == list(range(5 * kl, 5 * kl + 16)) + list(range(kl, kl + 16)) + [5 * kl + 16, 5 * kl + 17]
+    assert np.array_equal(src[b0 + 4 * kl:b0 + 5 * kl], b0 + 6 * kl + np.arange(kl))                     # layer 3
+    assert np.array_equal(src[b0 + 11 * kl:], np.arange(b0 + 11 * kl, src.size))                        # tail
     # one 32x32 unit: K-block j holds records 8j..8j+7, hi + lo ~ the weight
     rs = np.random.RandomState(1)
     prog = np.zeros(P.PROGRAM_FLOATS, np.float32)

@@ -93,6 +93,13 @@ static_assert(P_BLK_STRIDE <= PRM_WINDOW && W_IB - W_IA <= PRM_WINDOW && P_USED 
               "params windows");
 
 #define DEV __device__ __forceinline__
+// fence between the MFMAs of a K-block and the side work placed in their dependency gaps
+// (ZS_FENCE_SCHED: a hard scheduling barrier; default: source order only, which hipcc keeps)
+#ifdef ZS_FENCE_SCHED
+#define ZS_FENCE __builtin_amdgcn_sched_barrier(0)
+#else
+#define ZS_FENCE do { } while (0)
+#endif
 
 // pin(ahi, alo): the prefetch reads issued above stay above (memory clobber) and the MFMAs that
 // consume this K-block's A operand stay below (they read the statement's outputs).  Without it
@@ -234,15 +241,42 @@ DEV f32x16 zero16() {
     return v;
 }
 
-// acc += W_tile X, X = KT packed tiles in registers; starts at a chunk boundary
+// ---- side work in the dependency gaps ---------------------------------------------------- //
+// The three MFMAs of a K-block form a dependent chain (one accumulator): the 2nd and 3rd each wait
+// ~32 cycles for their predecessor, and an in-order wave issues NOTHING behind a waiting MFMA.
+// hipcc keeps source order (MFMA MFMA MFMA, then the activation code), so round 1's side work ran
+// with only the third MFMA in flight.  tools/ubench/mfma_valu_place.hip (cycles per K-block, ideal
+// 96): 12 plain VALU behind the three MFMAs 126.6, the same 12 as 4 + 4 + 4 in the gaps 101.6;
+// 18: 138.6 vs 113.1; but 24: 157 either way, and a transcendental shares a gap with at most one
+// plain instruction (exp + 1: 99.6; exp + 2: 124.6; exp + 3: 135-156).  Hence: side(kb, g) is
+// called behind the g-th MFMA of K-block kb, fenced by sched_barrier(0) so hipcc cannot regroup
+// it, and the activations are cut into gap-sized stages (GeluStager, SoftplusStager below).
 struct NoSide {
-    DEV void operator()(int) const {}
+    DEV void operator()(int, int) const {}
 };
-// Activation of the PREVIOUS output tile, fed one value per K-block of the current tile's GEMM
-// (16 values per lane, 16 K-blocks per 256-wide GEMM): the VALU work then sits between the MFMA
-// groups in program order, where the in-order wave issues it in their shadow (~5 issue slots per
-// 32-cycle MFMA) instead of behind the GEMM with the matrix pipe idle.  Collects the split
-// B operands of the tile.
+template <typename SIDE>
+DEV void mfma3_gaps(f32x16 &acc, const u32x4 &ahi, const u32x4 &alo, const u32x4 &bhi, const u32x4 &blo, int kb,
+                    SIDE &side) {
+    using zs::s16::as_h;
+    if (std::is_same<SIDE, NoSide>::value) {   // nothing to place: leave the three MFMAs to hipcc
+        mfma3(acc, ahi, alo, bhi, blo);
+        return;
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(alo), as_h(bhi), acc, 0, 0, 0);
+    ZS_FENCE;
+    side(kb, 0);
+    ZS_FENCE;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(ahi), as_h(blo), acc, 0, 0, 0);
+    ZS_FENCE;
+    side(kb, 1);
+    ZS_FENCE;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(ahi), as_h(bhi), acc, 0, 0, 0);
+    ZS_FENCE;
+    side(kb, 2);
+    ZS_FENCE;
+}
+
+// Collects the split B operands of an activation tile, one value at a time (index 0..15)
 struct TilePacker {
     PT p;
     float prev;
@@ -257,7 +291,54 @@ struct TilePacker {
     }
 };
 
-// SIDE: side(kb) runs behind the MFMAs of K-block kb
+// zs::dm::gelu_erf (same operations in the same order: bit-identical) cut into five stages:
+// 3 plain | 1 plain + rcp | exp + 1 plain | 5 plain | 2 plain
+struct GeluStager {
+    float x, u, q, t, e, p;
+    DEV void s0(float v) {
+        x = v;
+        u = fabsf(v) * 0.70710678118654752440f;
+        q = (u * u) * -1.44269504088896340736f;
+    }
+    DEV void s1() { t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f)); }
+    DEV void s2() {
+        e = __builtin_amdgcn_exp2f(q);
+        p = fmaf(0.75052702f, t, -1.02753365f);
+    }
+    DEV void s3() {
+        p = fmaf(p, t, 1.00509130f);
+        p = fmaf(p, t, -0.20116957f);
+        p = fmaf(p, t, 0.18019173f);
+        p = p * t;
+        u = u * p;
+    }
+    DEV float s4() const { return fmaf(-u, e, fmaxf(x, 0.0f)); }
+    DEV float all(float v) {
+        s0(v); s1(); s2(); s3();
+        return s4();
+    }
+    // stage st (0..5; 5 = idle) of value `v`; the finished value goes to e.feed(idx, .)
+    DEV void stage(int st, float v, int idx, TilePacker &pk) {
+        if (st == 0) s0(v);
+        else if (st == 1) s1();
+        else if (st == 2) s2();
+        else if (st == 3) s3();
+        else if (st == 4) pk.feed(idx, s4());
+    }
+};
+// zs::dm::softplus100 in three stages: 1 plain + exp | 1 plain + log | 2 plain
+struct SoftplusStager {
+    float x, t;
+    DEV void s0(float v) {
+        x = v;
+        t = __builtin_amdgcn_exp2f(fabsf(v) * -144.26950408889634074f);
+    }
+    DEV void s1() { t = __builtin_amdgcn_logf(1.0f + t); }
+    DEV float s2() const { return fmaf(t, 0.0069314718055994530942f, fmaxf(x, 0.0f)); }
+};
+
+// acc += W_tile X, X = KT packed tiles in registers; starts at a chunk boundary.
+// SIDE: side(kb, g) runs behind the g-th MFMA of K-block kb
 template <int KT, int EXTRA_VM = 0, typename SIDE = NoSide>
 DEV void gemm_reg(AStream &s, const PT *X, f32x16 &acc, SIDE side = SIDE()) {  // starts chunk-aligned
 #pragma unroll
@@ -265,23 +346,78 @@ DEV void gemm_reg(AStream &s, const PT *X, f32x16 &acc, SIDE side = SIDE()) {  /
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             u32x4 ahi, alo;
-            if (kt * 2 + j < CK)  // the first synchronisation leaves the caller's loads in flight
-                s.template step<EXTRA_VM>((kt * 2 + j) & (CK - 1), ahi, alo);
-            else
-                s.step((kt * 2 + j) & (CK - 1), ahi, alo);
+            s.step((kt * 2 + j) & (CK - 1), ahi, alo);
             pin(ahi, alo);
-            mfma3(acc, ahi, alo, X[kt].v[2 * j], X[kt].v[2 * j + 1]);
-            side(kt * 2 + j);
+            mfma3_gaps(acc, ahi, alo, X[kt].v[2 * j], X[kt].v[2 * j + 1], kt * 2 + j, side);
         }
 }
-// one input tile (2 K-blocks) starting at chunk position pos0 (even)
-DEV void gemm_one(AStream &s, const PT &X, f32x16 &acc, int pos0) {
+// ... with X pinned in the ACCUMULATOR half of the register file (B operands of an MFMA may be AGPRs).
+// For an array that lives through a whole phase and is only ever a B operand - feat / sqrt(2) in
+// impl_mlp - this tells hipcc where it belongs: left to itself it shuffled such arrays between the
+// two halves (hundreds of v_accvgpr moves per phase) and spilled.  Hazards hipcc does not pad for
+// asm: the A operands arrive through its own s_waitcnt (they are asm inputs), the leading s_nop
+// covers a VALU write of the accumulator just before the statement.
+template <typename SIDE>
+DEV void mfma3_breg(f32x16 &acc, const u32x4 &ahi, const u32x4 &alo, const u32x4 &bhi, const u32x4 &blo, int kb,
+                    SIDE &side) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(alo), "a"(bhi));
+    ZS_FENCE;
+    side(kb, 0);
+    ZS_FENCE;
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(ahi), "a"(blo));
+    ZS_FENCE;
+    side(kb, 1);
+    ZS_FENCE;
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(ahi), "a"(bhi));
+    ZS_FENCE;
+    side(kb, 2);
+    ZS_FENCE;
+}
+template <int KT, typename SIDE = NoSide>
+DEV void gemm_areg(AStream &s, const PT *X, f32x16 &acc, SIDE side = SIDE()) {  // starts chunk-aligned
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            u32x4 ahi, alo;
+            s.step((kt * 2 + j) & (CK - 1), ahi, alo);
+            pin(ahi, alo);
+            mfma3_breg(acc, ahi, alo, X[kt].v[2 * j], X[kt].v[2 * j + 1], kt * 2 + j, side);
+        }
+}
+// ... with the ACCUMULATOR pinned in the accumulator half of the register file: the residual stream
+// y (128 registers, only ever updated by MFMAs and read by the LayerNorms) belongs there.  Left to
+// hipcc (-amdgpu-mfma-vgpr-form) every update of a y tile moved it to VGPRs and back, and with
+// side work between those MFMAs its "Rewrite AGPR-Copy-MFMA" pass crashes (ROCm 7.2).
+template <typename SIDE>
+DEV void mfma3_cacc(f32x16 &acc, const u32x4 &ahi, const u32x4 &alo, const u32x4 &bhi, const u32x4 &blo, int kb,
+                    SIDE &side) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(alo), "v"(bhi));
+    ZS_FENCE;
+    side(kb, 0);
+    ZS_FENCE;
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(ahi), "v"(blo));
+    ZS_FENCE;
+    side(kb, 1);
+    ZS_FENCE;
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(ahi), "v"(bhi));
+    ZS_FENCE;
+    side(kb, 2);
+    ZS_FENCE;
+}
+// one input tile (2 K-blocks) starting at chunk position pos0 (even); side sees K-blocks kb0, kb0 + 1.
+// YACC: acc is a tile of the residual stream (AGPR-resident, see mfma3_cacc)
+template <bool YACC = false, typename SIDE = NoSide>
+DEV void gemm_one(AStream &s, const PT &X, f32x16 &acc, int pos0, int kb0 = 0, SIDE side = SIDE()) {
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         u32x4 ahi, alo;
         s.step((pos0 + j) & (CK - 1), ahi, alo);
         pin(ahi, alo);
-        mfma3(acc, ahi, alo, X.v[2 * j], X.v[2 * j + 1]);
+        if (YACC)
+            mfma3_cacc(acc, ahi, alo, X.v[2 * j], X.v[2 * j + 1], kb0 + j, side);
+        else
+            mfma3_gaps(acc, ahi, alo, X.v[2 * j], X.v[2 * j + 1], kb0 + j, side);
     }
 }
 // 8 input tiles with the B operands read from the wave's LDS slab ([k-block][hi | lo][lane]),
@@ -308,22 +444,10 @@ DEV void gemm_lds(AStream &s, const Slab &sl, f32x16 &acc, int pos0 = 0, SIDE si
         u32x4 nh = bh, nl = bl;
         if (kb + 1 < NT * 2) slab_b(sl, kb + 1, nh, nl);  // after the step: its lgkmcnt(0) must not wait for this read
         pin(ahi, alo);
-        mfma3(acc, ahi, alo, bh, bl);
+        mfma3_gaps(acc, ahi, alo, bh, bl, kb, side);
         bh = nh;
         bl = nl;
-        side(kb);
     }
-}
-
-// MLP software pipeline: nxt += W1[tile t+1] LN2(y) (16 K-blocks, B from the slab) with the
-// activation of the PREVIOUS hidden tile - gelu(cur) and its split into B operands - spread over
-// the K-blocks: one value per K-block, one packed pair every second K-block.  The VALU work sits
-// between the MFMA groups in program order, where the in-order wave can issue it in their shadow
-// (~5 issue slots per 32-cycle MFMA); done after the GEMM it ran with the matrix pipe idle.
-DEV void fc1_gelu(AStream &s, const Slab &sl, f32x16 &nxt, const f32x16 &cur, PT &hp) {
-    TilePacker e;
-    gemm_lds(s, sl, nxt, 0, [&](int kb) { e.feed(kb, gelu_erf(cur[kb])); });
-    hp = e.p;
 }
 
 DEV float xhalf(float v) { return __shfl_xor(v, 32, 64); }  // value of lane l ^ 32
@@ -356,6 +480,40 @@ DEV f32x16 xyz_affine(const float *prm, int off, int tile, int hi, float x, floa
     }
     return v;
 }
+
+// Accumulator initialisers of the NEXT output tile, produced one step per K-block beside the current
+// tile's GEMM (gemm side work).  A wave alone on its SIMD has nobody to hide an LDS round trip
+// behind, and hipcc cannot hoist these reads over the stream's asm statements: the read of step
+// r + 1 is issued in step r, ~100 cycles before its use.  (Round 1 read the whole table in front of
+// every tile: 16 serialised round trips, ~1,000 cycles per tile with the matrix pipe idle.)
+struct XyzInit {  // w.w + w.x x + w.y y + w.z z for the 16 registers of (tile, hi): [tile][hi][r][4] table
+    const f32x4 *q;
+    f32x4 w;
+    f32x16 v;
+    DEV void start(const float *prm, int off, int tile, int hi) {
+        q = reinterpret_cast<const f32x4 *>(prm + off + tile * 128 + hi * 64);
+        w = q[0];
+    }
+    DEV void step(int r, float x, float y, float z) {
+        v[r] = fmaf(w.z, z, fmaf(w.y, y, fmaf(w.x, x, w.w)));
+        if (r + 1 < 16) w = q[r + 1];
+    }
+};
+struct RowInit {  // 16 floats of a row-param vector (bias) for (tile, hi)
+    const f32x4 *q;
+    f32x4 w;
+    f32x16 v;
+    DEV void start(const float *prm, int off, int tile, int hi) {
+        q = reinterpret_cast<const f32x4 *>(prm + off + tile * 32 + hi * 16);
+        w = q[0];
+    }
+    DEV void step(int r) {
+        if ((r & 3) == 0) {
+            v[r] = w.x; v[r + 1] = w.y; v[r + 2] = w.z; v[r + 3] = w.w;
+            if (r + 4 < 16) w = q[(r >> 2) + 1];
+        }
+    }
+};
 
 DEV void ln_stats(const f32x16 *x, float &mean, float &rstd) {
     float s = 0.f;
@@ -533,16 +691,27 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) y[nt] += rp16(prm, PB_B2, nt, hi);
         ZS_STAMP(4 + blk * 4);
-        // software pipeline over the hidden tiles (stream order: fc1(0), [fc1(t+1), fc2(t)]..., fc2(31))
+        // software pipeline over the hidden tiles (stream order: fc1(0), [fc1(t+1), fc2(t)]..., fc2(31)):
+        // fc1 of tile t+1 carries the GELU + operand split of tile t and the bias fetch of tile t+2
+        RowInit bi;
         f32x16 hid = rp16(prm, PB_B1, 0, hi);
-        gemm_lds(s, sl, hid);
+        bi.start(prm, PB_B1, 1, hi);
+        gemm_lds(s, sl, hid, 0, [&](int kb, int g) {
+            if (g == 2 && (kb & 3) == 1) bi.step(kb & ~3);
+        });
 #pragma unroll 1
         for (int ht = 0; ht < HT - 1; ht++) {
-            f32x16 nxt = rp16(prm, PB_B1, ht + 1, hi);
-            PT hp;
-            fc1_gelu(s, sl, nxt, hid, hp);
+            f32x16 nxt = bi.v;
+            bi.start(prm, PB_B1, ht + 2 < HT ? ht + 2 : HT - 1, hi);
+            TilePacker e;
+            gemm_lds(s, sl, nxt, 0, [&](int kb, int g) {
+                if (g == 2) {
+                    e.feed(kb, gelu_erf(hid[kb]));
+                    if ((kb & 3) == 1) bi.step(kb & ~3);
+                }
+            });
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++) gemm_one(s, hp, y[nt], (2 * nt) & (CK - 1));
+            for (int nt = 0; nt < NT; nt++) gemm_one(s, e.p, y[nt], (2 * nt) & (CK - 1));
             hid = nxt;
         }
         {
@@ -579,73 +748,67 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
     // (software pipeline over the output tiles: tile nt's GEMM carries tile nt-1's activation)
     {
         f32x16 prev;
+        XyzInit ini;
+        ini.v = xyz_affine(prm, P_IMPL0 - W_IA, 0, hi, px, py, pz);
 #pragma unroll
         for (int nt = 0; nt <= NT; nt++) {
             TilePacker e;
-            auto side = [&](int kb) { e.feed(kb, softplus100(prev[kb])); };
             if (nt < NT) {
-                f32x16 acc = xyz_affine(prm, P_IMPL0 - W_IA, nt, hi, px, py, pz);
-                if (nt == 0)
-                    gemm_reg<NT>(s, hp, acc);
-                else
-                    gemm_reg<NT, 0>(s, hp, acc, side);
+                f32x16 acc = ini.v;
+                if (nt + 1 < NT) ini.start(prm, P_IMPL0 - W_IA, nt + 1, hi);
+                gemm_reg<NT, 0>(s, hp, acc, [&](int kb, int g) {
+                    if (g != 2) return;
+                    if (nt > 0) e.feed(kb, softplus100(prev[kb]));
+                    if (nt + 1 < NT) ini.step(kb, px, py, pz);
+                });
                 if (nt > 0) sl.store(nt - 1, e.p);
                 prev = acc;
             } else {
 #pragma unroll
-                for (int kb = 0; kb < 16; kb++) side(kb);
+                for (int kb = 0; kb < 16; kb++) e.feed(kb, softplus100(prev[kb]));
                 sl.store(nt - 1, e.p);
             }
         }
     }
     ZS_STAMP(11);
-    // the skip layers consume cat[x, xyz, feat] / sqrt(2): their feat halves are computed now,
-    // while feat is in registers, and parked in the workspace (fp32 Z tiles)
+    // the skip layers consume cat[x, xyz, feat] / sqrt(2): feat / sqrt(2) stays packed in registers
+    // (the residual stream is dead by now) and is contracted inside each skip layer as 16 more
+    // K-blocks per output tile - the split stream interleaves [x part | feat part] per tile
+    // (split_source_kblock) - so nothing is parked in memory (round 1 parked 96 KiB of fp32
+    // partial products per wave tile: 12.8 GB per 129^3 launch)
     const float rsqrt2 = 0.70710678118654752440f;
+    PT fp[NT];
 #pragma unroll
     for (int kt = 0; kt < NT; kt++) {
         float t[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) t[r] = h[kt * 16 + r] * rsqrt2;
-        hp[kt] = pack_tile(t);
+        fp[kt] = pack_tile(t);
     }
     const float sx = px * rsqrt2, sy = py * rsqrt2, sz = pz * rsqrt2;
-#pragma unroll 1
-    for (int li = 0; li < 3; li++) {
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) {
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = 0.f;
-            gemm_reg<NT>(s, hp, acc);
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                f32x4 t;
-                t.x = acc[4 * j + 0]; t.y = acc[4 * j + 1]; t.z = acc[4 * j + 2]; t.w = acc[4 * j + 3];
-                zs[(li * ZTILES_F4) + (nt * 4 + j) * 64] = t;
-            }
-        }
-    }
 
     ZS_STAMP(12);
     // layer 1 (plain): LDS -> registers, pre-divided by sqrt(2) because layer 2 is a skip layer
     {
         f32x16 prev;
+        RowInit ini;
+        ini.v = rp16(prm, P_IMPL1 - W_IA, 0, hi);
 #pragma unroll
         for (int nt = 0; nt <= NT; nt++) {
             TilePacker e;
-            auto side = [&](int kb) { e.feed(kb, softplus100(prev[kb]) * rsqrt2); };
             if (nt < NT) {
-                f32x16 acc = rp16(prm, P_IMPL1 - W_IA, nt, hi);
-                if (nt == 0)
-                    gemm_lds(s, sl, acc);
-                else
-                    gemm_lds(s, sl, acc, 0, side);
+                f32x16 acc = ini.v;
+                if (nt + 1 < NT) ini.start(prm, P_IMPL1 - W_IA, nt + 1, hi);
+                gemm_lds(s, sl, acc, 0, [&](int kb, int g) {
+                    if (g != 2) return;
+                    if (nt > 0) e.feed(kb, softplus100(prev[kb]) * rsqrt2);
+                    if (nt + 1 < NT) ini.step(kb);
+                });
                 if (nt > 0) hp[nt - 1] = e.p;
                 prev = acc;
             } else {
 #pragma unroll
-                for (int kb = 0; kb < 16; kb++) side(kb);
+                for (int kb = 0; kb < 16; kb++) e.feed(kb, softplus100(prev[kb]) * rsqrt2);
                 hp[nt - 1] = e.p;
             }
         }
@@ -656,34 +819,29 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
     for (int i = 0; i < 3; i++) {
         if (i == 1) load_params(prm, prog_params, W_IB, P_USED - W_IB);
         const int pp = i == 0 ? P_IMPL_PAIR - W_IA : (i - 1) * P_IMPL_PAIR_STRIDE;
-        const f32x4 *zl = zs + i * ZTILES_F4;
-        // skip layer 2+2i: registers (x / sqrt(2)) + parked feat half -> LDS
+        // skip layer 2+2i: registers (x / sqrt(2)) and feat / sqrt(2) -> LDS
         {
             f32x16 prev;
-            f32x4 zprev[4];
+            XyzInit ini;
+            ini.v = xyz_affine(prm, pp, 0, hi, sx, sy, sz);
 #pragma unroll
             for (int nt = 0; nt <= NT; nt++) {
                 TilePacker e;
-                auto side = [&](int kb) { e.feed(kb, softplus100(prev[kb] + zprev[kb >> 2][kb & 3])); };
                 if (nt < NT) {
-                    // the parked tile is fetched first (L1-bypassing loads: this wave wrote it earlier
-                    // in the launch); the stream's asm statements keep the loads from sinking behind
-                    // the GEMM, whose first synchronisation leaves them in flight
-                    f32x4 z[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) z[j] = __builtin_nontemporal_load(zl + (nt * 4 + j) * 64);
-                    f32x16 acc = xyz_affine(prm, pp, nt, hi, sx, sy, sz);
-                    if (nt == 0)
-                        gemm_reg<NT, 4>(s, hp, acc);
-                    else
-                        gemm_reg<NT, 4>(s, hp, acc, side);
+                    f32x16 acc = ini.v;
+                    if (nt + 1 < NT) ini.start(prm, pp, nt + 1, hi);
+                    // the x part carries the previous tile's activation, the feat part the next tile's initialiser
+                    gemm_reg<NT, 0>(s, hp, acc, [&](int kb, int g) {
+                        if (g == 2 && nt > 0) e.feed(kb, softplus100(prev[kb]));
+                    });
+                    gemm_areg<NT>(s, fp, acc, [&](int kb, int g) {
+                        if (g == 2 && nt + 1 < NT) ini.step(kb, sx, sy, sz);
+                    });
                     if (nt > 0) sl.store(nt - 1, e.p);
                     prev = acc;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) zprev[j] = z[j];
                 } else {
 #pragma unroll
-                    for (int kb = 0; kb < 16; kb++) side(kb);
+                    for (int kb = 0; kb < 16; kb++) e.feed(kb, softplus100(prev[kb]));
                     sl.store(nt - 1, e.p);
                 }
             }
@@ -693,34 +851,38 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
         const float post = i < 2 ? rsqrt2 : 1.0f;
         {
             f32x16 prev;
-            float w[16];  // layer 8 weights of the previous tile (last pair only)
+            RowInit ini, w8;  // bias of the next tile; layer 8 weights of the previous tile (last pair only)
+            const float wsel = i == 2 ? 1.0f : 0.0f;
+            ini.v = rp16(prm, pp + 1024, 0, hi);
+#pragma unroll
+            for (int r = 0; r < 16; r++) w8.v[r] = 0.f;
 #pragma unroll
             for (int nt = 0; nt <= NT; nt++) {
                 TilePacker e;
-                auto side = [&](int kb) {
-                    const float t = softplus100(prev[kb]) * post;
+                // weights of tile nt - 1, fetched beside the previous GEMM; pairs 0 and 1 read whatever
+                // finite parameters sit at that offset of their window and scale them away (a
+                // branch on i here crashes hipcc's AGPR-copy rewrite pass, ROCm 7.2)
+                const f32x16 w = w8.v * wsel;
+                auto finish = [&](int kb, float v) {
+                    const float t = v * post;
                     e.feed(kb, t);
                     out = fmaf(t, w[kb], out);
                 };
-                if (nt > 0) {
-                    if (i == 2) {
-                        rp(prm, P_W8 - W_IB, nt - 1, hi, w);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 16; r++) w[r] = 0.f;
-                    }
-                }
                 if (nt < NT) {
-                    f32x16 acc = rp16(prm, pp + 1024, nt, hi);
-                    if (nt == 0)
-                        gemm_lds(s, sl, acc);
-                    else
-                        gemm_lds(s, sl, acc, 0, side);
+                    f32x16 acc = ini.v;
+                    if (nt + 1 < NT) ini.start(prm, pp + 1024, nt + 1, hi);
+                    w8.start(prm, P_W8 - W_IB, nt, hi);
+                    gemm_lds(s, sl, acc, 0, [&](int kb, int g) {
+                        if (g != 2) return;
+                        if (nt > 0) finish(kb, softplus100(prev[kb]));
+                        if (nt + 1 < NT) ini.step(kb);
+                        w8.step(kb);
+                    });
                     if (nt > 0) hp[nt - 1] = e.p;
                     prev = acc;
                 } else {
 #pragma unroll
-                    for (int kb = 0; kb < 16; kb++) side(kb);
+                    for (int kb = 0; kb < 16; kb++) finish(kb, softplus100(prev[kb]));
                     hp[nt - 1] = e.p;
                 }
             }
@@ -810,13 +972,27 @@ DEV bool out_of_range(const f32x4 &v) {
            (__builtin_bit_cast(unsigned, v.z) & 0x7fffffffu) > lim || (__builtin_bit_cast(unsigned, v.w) & 0x7fffffffu) > lim;
 }
 
-// Order of the split stream: the fp32 program's, except inside the two MLP sections, where the
+// Order of the split stream: the fp32 program's, except (a) inside the two MLP sections, where the
 // kernel runs a software pipeline over the 32 hidden tiles (fc1 of tile t+1 before fc2 of tile
-// t): fc1(0), [fc1(1), fc2(0)], ..., [fc1(31), fc2(30)], fc2(31), 16 K-blocks each.
+// t): fc1(0), [fc1(1), fc2(0)], ..., [fc1(31), fc2(30)], fc2(31), 16 K-blocks each; (b) in
+// impl_mlp, where the feat halves of the skip layers are contracted inside their layers.
 __host__ __device__ inline int split_source_kblock(int kb) {
     constexpr int KB_BLOCK = G_BLOCK / 2, KB_ATT = HEADS * G_HEAD / 2;
     static_assert(KB_BLOCK - KB_ATT == HT * 32, "an MLP section is 32 K-blocks per hidden tile");
-    if (kb >= BLOCKS * KB_BLOCK) return kb;
+    constexpr int KB_IMPL0 = BLOCKS * KB_BLOCK, KB_L = NT * NT * 2;  // impl_mlp section; K-blocks of a 256 x 256 layer
+    if (kb >= KB_IMPL0 + G_IMPL / 2) return kb;  // zero tail
+    if (kb >= KB_IMPL0) {
+        // fp32 program: L0 | Z2 Z4 Z6 (feat halves of the skip layers) | L1 | L2x L3 | L4x L5 | L6x L7
+        // split stream: L0 | L1 | for each pair: for each output tile [L(2+2i)x tile | Z(2+2i) tile], L(3+2i)
+        const int p = kb - KB_IMPL0;
+        if (p < KB_L) return kb;                                  // layer 0
+        if (p < 2 * KB_L) return KB_IMPL0 + 4 * KB_L + (p - KB_L);  // layer 1
+        const int q = p - 2 * KB_L, pair = q / (3 * KB_L), r = q - pair * 3 * KB_L;
+        if (r >= 2 * KB_L) return KB_IMPL0 + (5 + 2 * pair + 1) * KB_L + (r - 2 * KB_L);  // plain layer 3 + 2 pair
+        const int nt = r / (4 * NT), w = r - nt * 4 * NT;         // 16 x-part + 16 feat-part K-blocks per tile
+        return w < 2 * NT ? KB_IMPL0 + (5 + 2 * pair) * KB_L + nt * 2 * NT + w
+                          : KB_IMPL0 + (1 + pair) * KB_L + nt * 2 * NT + (w - 2 * NT);
+    }
     const int blk = kb / KB_BLOCK, p = kb - blk * KB_BLOCK - KB_ATT;
     if (p < 16) return kb;  // attention section, or fc1(0)
     const int q = p - 16, it = q >> 5, r = q & 31;

@@ -368,7 +368,8 @@ KB_WORDS = 512                          # 32-bit words per K-block (2 x 64 lanes
 def split_source_kblocks(n=None):
     """dst K-block -> src K-block (in fp32-program order).  Identity except inside the two MLP
     sections, where the kernel runs a software pipeline over the 32 hidden tiles (fc1 of tile
-    t+1 before fc2 of tile t): fc1(0), [fc1(1), fc2(0)], ..., [fc1(31), fc2(30)], fc2(31)."""
+    t+1 before fc2 of tile t): fc1(0), [fc1(1), fc2(0)], ..., [fc1(31), fc2(30)], fc2(31), and in
+    impl_mlp, where the skip layers contract their feat halves in place."""
     n = REC_FLOATS // GROUP_FLOATS // 2 if n is None else n
     src = np.arange(n)
     kb_block, kb_att = G_BLOCK // 2, HEADS * G_HEAD // 2
@@ -380,6 +381,17 @@ def split_source_kblocks(n=None):
     for blk in range(BLOCKS):
         base = blk * kb_block + kb_att
         src[base:base + HT * 32] = base + np.array(order)
+    # impl_mlp.  fp32 program: L0 | Z2 Z4 Z6 (feat halves of the skip layers) | L1 | L2x L3 | L4x L5 | L6x L7;
+    # split stream: L0 | L1 | per pair: for each output tile [x part | feat part] (16 + 16 K-blocks), plain layer
+    b0, kl = BLOCKS * kb_block, NT * NT * 2
+    impl = list(range(kl)) + [4 * kl + i for i in range(kl)]
+    for pair in range(3):
+        for nt in range(NT):
+            impl += [(5 + 2 * pair) * kl + nt * 2 * NT + w for w in range(2 * NT)]
+            impl += [(1 + pair) * kl + nt * 2 * NT + w for w in range(2 * NT)]
+        impl += [(6 + 2 * pair) * kl + i for i in range(kl)]
+    assert sorted(impl) == list(range(G_IMPL // 2))
+    src[b0:b0 + G_IMPL // 2] = b0 + np.array(impl)
     return src
 
 
