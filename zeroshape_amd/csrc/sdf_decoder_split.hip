@@ -337,6 +337,57 @@ struct SoftplusStager {
     DEV float s2() const { return fmaf(t, 0.0069314718055994530942f, fmaxf(x, 0.0f)); }
 };
 
+// K-blocks with the activation of ONE value written into the dependency gaps by hand (inline asm:
+// hipcc neither places side work there by itself nor survives being fenced into it - register
+// spills, and its AGPR-copy rewrite pass crashes).  Same operations in the same order as
+// zs::dm::gelu_erf / softplus100: bit-identical results.  The A / B operands are ordinary asm inputs
+// (hipcc waits for their LDS reads in front of the statement); the VALU part touches no MFMA operand.
+// gelu: 4 plain | rcp, exp, 1 plain | 7 plain
+DEV float kblock_gelu(f32x16 &acc, const u32x4 &ahi, const u32x4 &alo, const u32x4 &bhi, const u32x4 &blo, float x) {
+    float u, q, d, t, e, m, p;
+    const float c0 = 0.70710678118654752440f, c1 = 0.3275911f, c2 = -1.02753365f;
+    asm volatile("v_mfma_f32_32x32x16_f16 %[acc], %[alo], %[bh], %[acc]\n\t"
+                 "v_mul_f32_e64 %[u], |%[x]|, %[c0]\n\t"
+                 "v_mul_f32_e32 %[q], %[u], %[u]\n\t"
+                 "v_mul_f32_e32 %[q], 0xbfb8aa3b, %[q]\n\t"
+                 "v_fma_f32 %[d], %[u], %[c1], 1.0\n\t"
+                 "v_mfma_f32_32x32x16_f16 %[acc], %[ahi], %[bl], %[acc]\n\t"
+                 "v_rcp_f32_e32 %[t], %[d]\n\t"
+                 "v_exp_f32_e32 %[e], %[q]\n\t"
+                 "v_max_f32_e32 %[m], 0, %[x]\n\t"
+                 "v_mfma_f32_32x32x16_f16 %[acc], %[ahi], %[bh], %[acc]\n\t"
+                 "v_fmamk_f32 %[p], %[t], 0x3f40228a, %[c2]\n\t"
+                 "v_fmaak_f32 %[p], %[p], %[t], 0x3f80a6d5\n\t"
+                 "v_fmaak_f32 %[p], %[p], %[t], 0xbe4dff65\n\t"
+                 "v_fmaak_f32 %[p], %[p], %[t], 0x3e38842e\n\t"
+                 "v_mul_f32_e64 %[p], %[t], -%[p]\n\t"
+                 "v_mul_f32_e32 %[p], %[u], %[p]\n\t"
+                 "v_fmac_f32_e32 %[m], %[p], %[e]"
+                 : [acc] "+v"(acc), [u] "=&v"(u), [q] "=&v"(q), [d] "=&v"(d), [t] "=&v"(t), [e] "=&v"(e), [m] "=&v"(m),
+                   [p] "=&v"(p)
+                 : [alo] "v"(alo), [ahi] "v"(ahi), [bh] "v"(bhi), [bl] "v"(blo), [x] "v"(x), [c0] "s"(c0), [c1] "s"(c1),
+                   [c2] "v"(c2));
+    return m;
+}
+// softplus100: 1 plain + exp | 2 plain + log | 1 plain
+DEV float kblock_softplus(f32x16 &acc, const u32x4 &ahi, const u32x4 &alo, const u32x4 &bhi, const u32x4 &blo, float x) {
+    float t, m;
+    const float c0 = -144.26950408889634074f;
+    asm volatile("v_mfma_f32_32x32x16_f16 %[acc], %[alo], %[bh], %[acc]\n\t"
+                 "v_mul_f32_e64 %[t], |%[x]|, %[c0]\n\t"
+                 "v_exp_f32_e32 %[t], %[t]\n\t"
+                 "v_mfma_f32_32x32x16_f16 %[acc], %[ahi], %[bl], %[acc]\n\t"
+                 "v_max_f32_e32 %[m], 0, %[x]\n\t"
+                 "v_add_f32_e32 %[t], 1.0, %[t]\n\t"
+                 "v_log_f32_e32 %[t], %[t]\n\t"
+                 "v_mfma_f32_32x32x16_f16 %[acc], %[ahi], %[bh], %[acc]\n\t"
+                 "s_nop 0\n\t"
+                 "v_fmac_f32_e32 %[m], 0x3be32166, %[t]"
+                 : [acc] "+v"(acc), [t] "=&v"(t), [m] "=&v"(m)
+                 : [alo] "v"(alo), [ahi] "v"(ahi), [bh] "v"(bhi), [bl] "v"(blo), [x] "v"(x), [c0] "s"(c0));
+    return m;
+}
+
 // acc += W_tile X, X = KT packed tiles in registers; starts at a chunk boundary.
 // SIDE: side(kb, g) runs behind the g-th MFMA of K-block kb
 template <int KT, int EXTRA_VM = 0, typename SIDE = NoSide>
@@ -448,6 +499,41 @@ DEV void gemm_lds(AStream &s, const Slab &sl, f32x16 &acc, int pos0 = 0, SIDE si
         bh = nh;
         bl = nl;
     }
+}
+
+// gemm_lds / gemm_reg with the activation ACT (0 gelu, 1 softplus100) of cur[kb] computed in the gaps of
+// K-block kb (kblock_* above); fin(kb, value) receives the result, tail(kb) runs behind the K-block
+template <int ACT, typename FIN, typename TAIL>
+DEV void gemm_lds_act(AStream &s, const Slab &sl, f32x16 &acc, const f32x16 &cur, FIN fin, TAIL tail) {
+    u32x4 bh, bl;
+    slab_b(sl, 0, bh, bl);
+#pragma unroll
+    for (int kb = 0; kb < NT * 2; kb++) {
+        u32x4 ahi, alo;
+        s.step(kb & (CK - 1), ahi, alo);
+        u32x4 nh = bh, nl = bl;
+        if (kb + 1 < NT * 2) slab_b(sl, kb + 1, nh, nl);
+        const float r = ACT == 0 ? kblock_gelu(acc, ahi, alo, bh, bl, cur[kb]) : kblock_softplus(acc, ahi, alo, bh, bl, cur[kb]);
+        bh = nh;
+        bl = nl;
+        fin(kb, r);
+        tail(kb);
+    }
+}
+template <int ACT, typename FIN, typename TAIL>
+DEV void gemm_reg_act(AStream &s, const PT *X, f32x16 &acc, const f32x16 &cur, FIN fin, TAIL tail) {
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            u32x4 ahi, alo;
+            const int kb = kt * 2 + j;
+            s.step(kb & (CK - 1), ahi, alo);
+            const float r = ACT == 0 ? kblock_gelu(acc, ahi, alo, X[kt].v[2 * j], X[kt].v[2 * j + 1], cur[kb])
+                                     : kblock_softplus(acc, ahi, alo, X[kt].v[2 * j], X[kt].v[2 * j + 1], cur[kb]);
+            fin(kb, r);
+            tail(kb);
+        }
 }
 
 DEV float xhalf(float v) { return __shfl_xor(v, 32, 64); }  // value of lane l ^ 32
@@ -704,12 +790,8 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
             f32x16 nxt = bi.v;
             bi.start(prm, PB_B1, ht + 2 < HT ? ht + 2 : HT - 1, hi);
             TilePacker e;
-            gemm_lds(s, sl, nxt, 0, [&](int kb, int g) {
-                if (g == 2) {
-                    e.feed(kb, gelu_erf(hid[kb]));
-                    if ((kb & 3) == 1) bi.step(kb & ~3);
-                }
-            });
+            gemm_lds_act<0>(s, sl, nxt, hid, [&](int kb, float r) { e.feed(kb, r); },
+                            [&](int kb) { if ((kb & 3) == 1) bi.step(kb & ~3); });
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) gemm_one(s, e.p, y[nt], (2 * nt) & (CK - 1));
             hid = nxt;
@@ -756,11 +838,11 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
             if (nt < NT) {
                 f32x16 acc = ini.v;
                 if (nt + 1 < NT) ini.start(prm, P_IMPL0 - W_IA, nt + 1, hi);
-                gemm_reg<NT, 0>(s, hp, acc, [&](int kb, int g) {
-                    if (g != 2) return;
-                    if (nt > 0) e.feed(kb, softplus100(prev[kb]));
-                    if (nt + 1 < NT) ini.step(kb, px, py, pz);
-                });
+                if (nt > 0)
+                    gemm_reg_act<1>(s, hp, acc, prev, [&](int kb, float r) { e.feed(kb, r); },
+                                    [&](int kb) { if (nt + 1 < NT) ini.step(kb, px, py, pz); });
+                else
+                    gemm_reg<NT, 0>(s, hp, acc, [&](int kb, int g) { if (g == 2) ini.step(kb, px, py, pz); });
                 if (nt > 0) sl.store(nt - 1, e.p);
                 prev = acc;
             } else {
@@ -799,11 +881,11 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
             if (nt < NT) {
                 f32x16 acc = ini.v;
                 if (nt + 1 < NT) ini.start(prm, P_IMPL1 - W_IA, nt + 1, hi);
-                gemm_lds(s, sl, acc, 0, [&](int kb, int g) {
-                    if (g != 2) return;
-                    if (nt > 0) e.feed(kb, softplus100(prev[kb]) * rsqrt2);
-                    if (nt + 1 < NT) ini.step(kb);
-                });
+                if (nt > 0)
+                    gemm_lds_act<1>(s, sl, acc, prev, [&](int kb, float r) { e.feed(kb, r * rsqrt2); },
+                                    [&](int kb) { if (nt + 1 < NT) ini.step(kb); });
+                else
+                    gemm_lds(s, sl, acc, 0, [&](int kb, int g) { if (g == 2) ini.step(kb); });
                 if (nt > 0) hp[nt - 1] = e.p;
                 prev = acc;
             } else {
@@ -831,9 +913,10 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
                     f32x16 acc = ini.v;
                     if (nt + 1 < NT) ini.start(prm, pp, nt + 1, hi);
                     // the x part carries the previous tile's activation, the feat part the next tile's initialiser
-                    gemm_reg<NT, 0>(s, hp, acc, [&](int kb, int g) {
-                        if (g == 2 && nt > 0) e.feed(kb, softplus100(prev[kb]));
-                    });
+                    if (nt > 0)
+                        gemm_reg_act<1>(s, hp, acc, prev, [&](int kb, float r) { e.feed(kb, r); }, [&](int) {});
+                    else
+                        gemm_reg<NT>(s, hp, acc);
                     gemm_areg<NT>(s, fp, acc, [&](int kb, int g) {
                         if (g == 2 && nt + 1 < NT) ini.step(kb, sx, sy, sz);
                     });
@@ -872,12 +955,14 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
                     f32x16 acc = ini.v;
                     if (nt + 1 < NT) ini.start(prm, pp + 1024, nt + 1, hi);
                     w8.start(prm, P_W8 - W_IB, nt, hi);
-                    gemm_lds(s, sl, acc, 0, [&](int kb, int g) {
-                        if (g != 2) return;
-                        if (nt > 0) finish(kb, softplus100(prev[kb]));
+                    auto tail = [&](int kb) {
                         if (nt + 1 < NT) ini.step(kb);
                         w8.step(kb);
-                    });
+                    };
+                    if (nt > 0)
+                        gemm_lds_act<1>(s, sl, acc, prev, [&](int kb, float r) { finish(kb, r); }, tail);
+                    else
+                        gemm_lds(s, sl, acc, 0, [&](int kb, int g) { if (g == 2) tail(kb); });
                     if (nt > 0) hp[nt - 1] = e.p;
                     prev = acc;
                 } else {
