@@ -346,7 +346,10 @@ struct SoftplusStager {
 DEV float kblock_gelu(f32x16 &acc, const u32x4 &ahi, const u32x4 &alo, const u32x4 &bhi, const u32x4 &blo, float x) {
     float u, q, d, t, e, m, p;
     const float c0 = 0.70710678118654752440f, c1 = 0.3275911f, c2 = -1.02753365f;
-    asm volatile("v_mfma_f32_32x32x16_f16 %[acc], %[alo], %[bh], %[acc]\n\t"
+    asm volatile(
+#ifndef ZS_EXP_TWO_TERM
+                 "v_mfma_f32_32x32x16_f16 %[acc], %[alo], %[bh], %[acc]\n\t"
+#endif
                  "v_mul_f32_e64 %[u], |%[x]|, %[c0]\n\t"
                  "v_mul_f32_e32 %[q], %[u], %[u]\n\t"
                  "v_mul_f32_e32 %[q], 0xbfb8aa3b, %[q]\n\t"
@@ -373,7 +376,10 @@ DEV float kblock_gelu(f32x16 &acc, const u32x4 &ahi, const u32x4 &alo, const u32
 DEV float kblock_softplus(f32x16 &acc, const u32x4 &ahi, const u32x4 &alo, const u32x4 &bhi, const u32x4 &blo, float x) {
     float t, m;
     const float c0 = -144.26950408889634074f;
-    asm volatile("v_mfma_f32_32x32x16_f16 %[acc], %[alo], %[bh], %[acc]\n\t"
+    asm volatile(
+#ifndef ZS_EXP_TWO_TERM
+                 "v_mfma_f32_32x32x16_f16 %[acc], %[alo], %[bh], %[acc]\n\t"
+#endif
                  "v_mul_f32_e64 %[t], |%[x]|, %[c0]\n\t"
                  "v_exp_f32_e32 %[t], %[t]\n\t"
                  "v_mfma_f32_32x32x16_f16 %[acc], %[ahi], %[bl], %[acc]\n\t"

@@ -42,7 +42,9 @@ ZS_S16 void split8(const f32x4 &q0, const f32x4 &q1, u32x4 &hi, u32x4 &lo) {
     lo = u32x4{l[0], l[1], l[2], l[3]};
 }
 ZS_S16 void mfma3(f32x16 &acc, const u32x4 &ahi, const u32x4 &alo, const u32x4 &bhi, const u32x4 &blo) {
+#ifndef ZS_EXP_TWO_TERM   // timing experiment only (tools/build_variant_lib.py): what does the third MFMA cost in wall time?
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(alo), as_h(bhi), acc, 0, 0, 0);
+#endif
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(ahi), as_h(blo), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(ahi), as_h(bhi), acc, 0, 0, 0);
 }
