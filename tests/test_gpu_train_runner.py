@@ -139,8 +139,10 @@ def test_train_loop_checkpoints_and_resume_skip(tmp_path, encoder_sd, seeded_sd)
     """Runner.train like the reference's (model/shape_engine.py:164-246, 283-284): an evaluation before
     the first step of a fresh run, latest.ckpt every freq.ckpt_latest iterations, checkpoint/ep<N>.ckpt at
     the end, and a resumed run skips the slots of its first epoch that were trained before."""
-    opt = train_opt(tmp_path, "--max_epoch=2", "--freq.ckpt_latest=3", "--optim.fix_dpt", "--freq.eval=1000")
-    r = make_runner(opt, encoder_sd, seeded_sd, n_train=16)          # 4 iterations per epoch
+    opt = train_opt(tmp_path, "--freq.ckpt_latest=3", "--optim.fix_dpt", "--freq.eval=1000")
+    opt.max_epoch = 2
+    r = make_runner(opt, encoder_sd, seeded_sd)
+    r.load_train_dataset(opt, dataset=Dataset(opt, split="train", n_items=16, n_points=1000, seed=1))   # 4 iterations per epoch
     saves, evals = [], []
     r.save_checkpoint = lambda opt, **kw: saves.append(kw)
     ev = r.evaluate
