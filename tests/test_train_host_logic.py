@@ -74,8 +74,10 @@ def test_compat_aliases_cover_what_the_reference_scripts_import():
         import data.synthetic
         assert callable(data.synthetic.Dataset.id_filename_mapping)       # evaluate.py:17
         assert "external.chamfer3D.dist_chamfer_3D" in names
+        assert callable(importlib.import_module("data.pix3d").Dataset.id_filename_mapping)      # configs 3 and 5
+        assert callable(importlib.import_module("data.omniobj3d").Dataset.id_filename_mapping)
         with pytest.raises(ModuleNotFoundError):
-            importlib.import_module("data.pix3d")                          # not mirrored: fails loudly
+            importlib.import_module("data.ocrtoc")                         # not mirrored: fails loudly
     finally:
         for k, v in saved.items():
             if v is None:
