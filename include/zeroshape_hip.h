@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 20
+#define ZS_ABI_VERSION 21
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -361,6 +361,16 @@ int zs_conv2d_nhwc(const float *in, const float *packed_w, const float *scale, c
                    const float *res1, const float *res2, float *out, int batch, int Hin, int Win, int Cin,
                    int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad_t, int pad_l, int flags,
                    float in_scale, float in_shift, int act, void *stream);
+/* As zs_conv2d_nhwc, with a workspace of zs_conv2d_splitk_workspace_bytes() bytes (16-byte aligned, may be
+ * shared by launches on one stream; NULL = zs_conv2d_nhwc).  Problems that would launch fewer than 256
+ * workgroups (14x14 feature maps, 197-token matrices at small batch) split K across workgroups - partial
+ * tiles go through the workspace and a second kernel sums them in split order (deterministic) and applies
+ * the fused epilogue. */
+size_t zs_conv2d_splitk_workspace_bytes(void);
+int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const float *scale, const float *shift,
+                   const float *res1, const float *res2, float *out, int batch, int Hin, int Win, int Cin,
+                   int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad_t, int pad_l, int flags,
+                   float in_scale, float in_shift, int act, void *workspace, void *stream);
 int zs_group_norm_nhwc(const float *x, const float *gamma, const float *beta, const float *residual, float *y,
                        int batch, int HW, int C, int groups, float eps, int relu, void *stream);
 int zs_layer_norm(const float *x, const float *gamma, const float *beta, float *y, int rows, int C, float eps,

@@ -237,3 +237,33 @@ def test_conv2d_split_fp16_range():
         close(ops.conv2d(nhwc(x * 1e7).cuda(), pc), nhwc(F.conv2d(x * 1e7, w, None, padding=1)))
     finally:
         ops.set_conv_precision(prev)
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k", [(1, 1024, 14, 14, 256, 1), (1, 768, 7, 7, 768, 3), (1, 256, 14, 14, 2304, 1),
+                                             (1, 64, 5, 5, 40, 3), (4, 768, 14, 14, 768, 1)])
+def test_conv2d_split_k_across_workgroups(B, Cin, H, W, Cout, k, monkeypatch):
+    """zs_conv2d_nhwc_ws: K split across workgroups for launches of fewer than 256 workgroups (partials
+    through the workspace, summed in split order by a second kernel) - same result as the single-kernel
+    path to the last bits of the summation order, bit-reproducible, fused epilogue included."""
+    from zeroshape_amd.nn import ops, pack
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = nhwc(torch.randn(B, Cin, H, W, generator=g)).cuda()
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    pc = pack.pack_conv(w, b, stride=1, padding=k // 2).to("cuda")
+    res = torch.randn(B, H, W, Cout, generator=g).cuda()
+    want = nhwc(F.relu(F.conv2d(x.permute(0, 3, 1, 2).cpu(), w, b, padding=k // 2) + res.permute(0, 3, 1, 2).cpu()))
+    prev = ops.CONV_PRECISION
+    try:
+        for prec in ("f32", "f16x3"):
+            ops.set_conv_precision(prec)
+            monkeypatch.setattr(ops, "SPLIT_K", True)
+            a1 = ops.conv2d(x, pc, res1=res, act=ops.ACT_RELU)
+            a2 = ops.conv2d(x, pc, res1=res, act=ops.ACT_RELU)
+            monkeypatch.setattr(ops, "SPLIT_K", False)
+            single = ops.conv2d(x, pc, res1=res, act=ops.ACT_RELU)
+            assert torch.equal(a1, a2)
+            close(a1, want)
+            assert float((a1 - single).abs().max()) < 2e-5 * max(1.0, float(single.abs().max()))
+    finally:
+        ops.set_conv_precision(prev)

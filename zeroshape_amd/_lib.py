@@ -79,6 +79,9 @@ SIGNATURES = {
     "zs_conv2d_packed_floats": (_c_size_t, [_c_int, _c_int, _c_int, _c_int]),
     "zs_conv2d_nhwc": (_c_int, [_c_void_p] * 7 + [_c_int] * 13 + [ctypes.c_float, ctypes.c_float, _c_int,
                                                                   _c_void_p]),
+    "zs_conv2d_splitk_workspace_bytes": (_c_size_t, []),
+    "zs_conv2d_nhwc_ws": (_c_int, [_c_void_p] * 7 + [_c_int] * 13 + [ctypes.c_float, ctypes.c_float, _c_int,
+                                                                     _c_void_p, _c_void_p]),
     "zs_group_norm_nhwc": (_c_int, [_c_void_p] * 5 + [_c_int, _c_int, _c_int, _c_int, ctypes.c_float, _c_int,
                                                       _c_void_p]),
     "zs_layer_norm": (_c_int, [_c_void_p] * 4 + [_c_int, _c_int, ctypes.c_float, _c_void_p]),
@@ -145,7 +148,7 @@ SIGNATURES = {
     "zs_readout_concat_bwd": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
 }
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 _lib = None
 
 

@@ -44,6 +44,10 @@ struct ConvArgs {
     float in_scale, in_shift;
     int dil;   // 1, or 2: the input is read as if zero-stuffed to (H-1)*2+1 rows / columns (the
                // data-gradient of a stride-2 convolution is a stride-1 convolution over that)
+    // split-K across workgroups (small-tile variant): blockIdx.z takes one of `splits` ranges of K and
+    // writes its raw partial tile to ws[split][M][Cout]; conv_splitk_reduce_kernel sums them in order
+    float *ws;
+    int splits;
 };
 
 __device__ __forceinline__ float activate(float v, int act) {
@@ -347,7 +351,9 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
     const f32x4 *wq = reinterpret_cast<const f32x4 *>(a.w);
 
     const int T = (a.K + BK - 1) / BK * 2;                 // t-steps of 8 k (= 2 weight quads)
-    const int per = (T + 3) / 4, t_begin = wave * per, t_end = min(T, t_begin + per);
+    // this workgroup's share of K (all of it unless split across workgroups), then a quarter per wave
+    const int tsplit = (T + a.splits - 1) / a.splits, ts0 = blockIdx.z * tsplit, ts1 = min(T, ts0 + tsplit);
+    const int per = (max(ts1 - ts0, 0) + 3) / 4, t_begin = ts0 + wave * per, t_end = min(ts1, t_begin + per);
     f32x16 acc[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; j++)
@@ -442,8 +448,26 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
         const int row = e / SN, col = e % SN, m = m0 + row, n = n0 + col;
         if (m >= a.M || n >= a.Cout) continue;
         float v = (part[0][row][col] + part[1][row][col]) + (part[2][row][col] + part[3][row][col]);
-        v = v * (a.scale ? a.scale[n] : 1.0f) + (a.shift ? a.shift[n] : 0.0f);
         const size_t o = (size_t)m * a.Cout + n;
+        if (a.splits > 1) {       // raw partial; the epilogue runs in conv_splitk_reduce_kernel
+            a.ws[(size_t)blockIdx.z * a.M * a.Cout + o] = v;
+            continue;
+        }
+        v = v * (a.scale ? a.scale[n] : 1.0f) + (a.shift ? a.shift[n] : 0.0f);
+        if (a.res1) v += a.res1[o];
+        if (a.res2) v += a.res2[o];
+        a.out[o] = activate(v, a.act);
+    }
+}
+
+// out = epilogue(sum over the splits, in split order: deterministic)
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs a) {
+    const size_t total = (size_t)a.M * a.Cout;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+        const int n = (int)(o % a.Cout);
+        float v = a.ws[o];
+        for (int sp = 1; sp < a.splits; sp++) v += a.ws[(size_t)sp * total + o];
+        v = v * (a.scale ? a.scale[n] : 1.0f) + (a.shift ? a.shift[n] : 0.0f);
         if (a.res1) v += a.res1[o];
         if (a.res2) v += a.res2[o];
         a.out[o] = activate(v, a.act);
@@ -452,10 +476,21 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
 
 }  // namespace
 
+extern "C" size_t zs_conv2d_splitk_workspace_bytes(void) { return (size_t)16 << 20; }
+
 extern "C" int zs_conv2d_nhwc(const float *in, const float *packed_w, const float *scale, const float *shift,
                               const float *res1, const float *res2, float *out, int batch, int Hin, int Win,
                               int Cin, int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad_t,
                               int pad_l, int flags, float in_scale, float in_shift, int act, void *stream) {
+    return zs_conv2d_nhwc_ws(in, packed_w, scale, shift, res1, res2, out, batch, Hin, Win, Cin, Hout, Wout, Cout, kh, kw,
+                             stride, pad_t, pad_l, flags, in_scale, in_shift, act, nullptr, stream);
+}
+
+extern "C" int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const float *scale, const float *shift,
+                                 const float *res1, const float *res2, float *out, int batch, int Hin, int Win,
+                                 int Cin, int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad_t,
+                                 int pad_l, int flags, float in_scale, float in_shift, int act, void *workspace,
+                                 void *stream) {
     if (batch < 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || (Cin & 3) || Hout <= 0 || Wout <= 0 || Cout <= 0 ||
         kh <= 0 || kw <= 0 || stride <= 0 || act < 0 || act > ZS_ACT_RELU_CLAMP1) {
         zs::set_err("zs_conv2d_nhwc: bad geometry (B=%d in %dx%dx%d out %dx%dx%d k %dx%d s %d act %d; Cin must be "
@@ -475,6 +510,8 @@ extern "C" int zs_conv2d_nhwc(const float *in, const float *packed_w, const floa
     a.in_relu = (flags & ZS_CONV_IN_RELU) ? 1 : 0;
     a.act = act; a.in_scale = in_scale; a.in_shift = in_shift;
     a.dil = (flags & ZS_CONV_IN_DILATE2) ? 2 : 1;
+    a.ws = static_cast<float *>(workspace);
+    a.splits = 1;
     // fewer than ~3/4 of a wave of 128x128 tiles over the 256 CUs: use the small-tile split-K variant
     const long long big_tiles = ((M + BM - 1) / BM) * (a.CoutPad / BN);
     static const long long big_min = getenv("ZS_CONV_BIG_MIN") ? atoll(getenv("ZS_CONV_BIG_MIN")) : 192;
@@ -501,12 +538,32 @@ extern "C" int zs_conv2d_nhwc(const float *in, const float *packed_w, const floa
         static const long long narrow_below = getenv("ZS_CONV_NARROW_BELOW") ? atoll(getenv("ZS_CONV_NARROW_BELOW")) : 384;
         const long long wide = ((M + SM - 1) / SM) * ((Cout + 63) / 64);
         const bool tm = !pw && !no_tm && (Cin % 8) == 0;
-        if (wide < narrow_below) {            // 32x32 tiles: twice the workgroups for the smallest problems
-            const dim3 grid((unsigned)((M + SM - 1) / SM), (unsigned)((Cout + 31) / 32));
+        const bool narrow = wide < narrow_below;   // 32x32 tiles: twice the workgroups for the smallest problems
+        const long long wgs = ((M + SM - 1) / SM) * ((Cout + (narrow ? 31 : 63)) / (narrow ? 32 : 64));
+        // Split K across workgroups while the launch would leave most of the 256 CUs idle (14x14 maps,
+        // 197-token matrices at batch 1: 28-84 workgroups): ~512 workgroups, >= 16 t-steps (K = 128) per
+        // split, partial tiles inside the caller's workspace (zs_conv2d_splitk_workspace_bytes()).
+        static const int split_target = getenv("ZS_CONV_SPLIT_TARGET") ? atoi(getenv("ZS_CONV_SPLIT_TARGET")) : 512;
+        if (workspace && wgs < 256) {
+            const int T = (a.K + BK - 1) / BK * 2;
+            long long sp = (split_target + wgs - 1) / wgs;
+            if (sp > T / 16) sp = T / 16;
+            if (sp > 16) sp = 16;
+            const long long cap = (long long)(zs_conv2d_splitk_workspace_bytes() / 4) / (M * (long long)Cout);
+            if (sp > cap) sp = cap;
+            if (sp > 1) a.splits = (int)sp;
+        }
+        if (narrow) {
+            const dim3 grid((unsigned)((M + SM - 1) / SM), (unsigned)((Cout + 31) / 32), (unsigned)a.splits);
             ZS_LAUNCH(conv_gemm_small_kernel, 1,);
         } else {
-            const dim3 grid((unsigned)((M + SM - 1) / SM), (unsigned)((Cout + 63) / 64));
+            const dim3 grid((unsigned)((M + SM - 1) / SM), (unsigned)((Cout + 63) / 64), (unsigned)a.splits);
             ZS_LAUNCH(conv_gemm_small_kernel, 2,);
+        }
+        if (a.splits > 1) {
+            const long long total = M * (long long)Cout;
+            const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+            hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
         }
     } else {
         const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(a.CoutPad / BN));

@@ -25,6 +25,11 @@ _TILING = {None: 0, "large": 2, "small": 4}
 # "f16x3" = split-fp16 on the 16-bit matrix pipe (ZS_CONV_F16X3; operands as two fp16 halves, ~2^-21
 # relative for 2e-4 <~ |x| <= 65504, saturating beyond 131008).  The training path (nn/autograd.py) is always fp32.
 CONV_PRECISION = os.environ.get("ZS_ENCODER_PRECISION", "f16x3")
+# K split across workgroups for launches that would leave most CUs idle (zs_conv2d_nhwc_ws).  OFF by default:
+# measured at batch 1 (profiles/r02_encoder_b1_splitk*.txt) the 3x3 small-tile launches drop 16.7 -> 11.3 us but
+# the pointwise ones stay at 11.5 us (bound by their dependent first loads, not by workgroup count) and the
+# reduction kernel costs 4.5 us per layer: 4.65 vs 4.37 ms of kernel time per forward.  ZS_CONV_SPLIT_K=1 enables it.
+SPLIT_K = os.environ.get("ZS_CONV_SPLIT_K", "0") != "0"
 
 
 def set_conv_precision(p):
@@ -32,6 +37,19 @@ def set_conv_precision(p):
     if p not in ("f32", "f16x3"):
         raise ValueError("conv precision must be 'f32' or 'f16x3', got %r" % (p,))
     CONV_PRECISION = p
+
+
+_SPLITK_WS = {}
+
+
+def splitk_workspace(device):
+    """Per-device scratch for the split-K partial tiles of zs_conv2d_nhwc_ws (fixed size and address:
+    a captured hipGraph bakes the pointer in; launches on one stream serialise, so sharing is safe)."""
+    key = str(device)
+    if key not in _SPLITK_WS:
+        _SPLITK_WS[key] = torch.empty(_lib.load().zs_conv2d_splitk_workspace_bytes() // 4, dtype=torch.float32,
+                                      device=device)
+    return _SPLITK_WS[key]
 
 
 def conv2d(x, pc, res1=None, res2=None, act=ACT_NONE, in_relu=False, in_scale=1.0, in_shift=0.0, tiling=None):
@@ -49,12 +67,13 @@ def conv2d(x, pc, res1=None, res2=None, act=ACT_NONE, in_relu=False, in_scale=1.
             _chk(r, "conv2d residual")
             assert r.shape == out.shape
     with torch.cuda.device(x.device):
-        _lib.check(lib.zs_conv2d_nhwc(_lib.ptr(x), _lib.ptr(pc.w), _lib.ptr(pc.scale), _lib.ptr(pc.shift),
-                                      _lib.ptr(res1), _lib.ptr(res2), _lib.ptr(out), B, H, W, C, Ho, Wo, pc.cout,
-                                      pc.kh, pc.kw, pc.stride, pt, pl,
-                                      (1 if in_relu else 0) | _TILING[tiling] | (16 if CONV_PRECISION == "f16x3" else 0),
-                                      float(in_scale),
-                                      float(in_shift), act, _stream(x)), "zs_conv2d_nhwc")
+        _lib.check(lib.zs_conv2d_nhwc_ws(_lib.ptr(x), _lib.ptr(pc.w), _lib.ptr(pc.scale), _lib.ptr(pc.shift),
+                                         _lib.ptr(res1), _lib.ptr(res2), _lib.ptr(out), B, H, W, C, Ho, Wo, pc.cout,
+                                         pc.kh, pc.kw, pc.stride, pt, pl,
+                                         (1 if in_relu else 0) | _TILING[tiling] | (16 if CONV_PRECISION == "f16x3" else 0),
+                                         float(in_scale), float(in_shift), act,
+                                         _lib.ptr(splitk_workspace(x.device)) if SPLIT_K else None, _stream(x)),
+                   "zs_conv2d_nhwc_ws")
     return out
 
 
