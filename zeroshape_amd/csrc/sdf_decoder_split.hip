@@ -667,21 +667,32 @@ DEV void attn_tile(AStream &s, const PT &q, f32x16 &o, float &m_run, float &z_ru
         }
         mt = fmaxf(mt, S[r]);
     }
-    mt = fmaxf(mt, xhalf(mt)) * c;
-    const float m_new = fmaxf(m_run, mt);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    mt *= c;
+    // Lazy reference: the running maximum (shared by the two lane halves of a point) is only moved -
+    // with the exchange of the halves' maxima through LDS, the rescale factor and the rescaling of o -
+    // when some logit of the wave exceeds it by more than 2^LAZY; otherwise the probabilities of this
+    // tile are taken relative to the old reference (p <= 2^8: far inside the fp16 halves' range and
+    // exact to the same relative precision).  After the first tile that is the rule, and it saves the
+    // ~150-cycle LDS round trip and ~20 VALU instructions per tile.
+    constexpr float LAZY = 8.0f;
+    if (__builtin_amdgcn_ballot_w64(mt > m_run + LAZY) != 0) {   // wave-uniform
+        mt = fmaxf(mt, xhalf(mt));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        z_run *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[r] *= alpha;
+        m_run = m_new;
+    }
     float zs_ = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(S[r], c, -m_new));
+        const float p = __builtin_amdgcn_exp2f(fmaf(S[r], c, -m_run));
         S[r] = p;
         zs_ += p;
     }
-    z_run = fmaf(z_run, alpha, zs_);
-#pragma unroll
-    for (int r = 0; r < 16; r++) o[r] *= alpha;
+    z_run += zs_;
     gemm_one(s, pack_tile(S), o, pos0 + 2);
-    m_run = m_new;
 }
 
 #ifdef ZS_EXP_TIMING  // tools/phase_timing_split.py: cycle stamps of (block 0, wave 0, first tile) -> workspace tail
