@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 21
+#define ZS_ABI_VERSION 22
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -569,6 +569,17 @@ int zs_seen_surface_bwd(const float *depth, const float *intr, const float *mask
                         float *d_intr, void *stream);
 int zs_intr_param2mtx_bwd(const float *params, const float *d_intr, int batch, int H, int W, float *d_params,
                           void *stream);
+/* Training of the transformer coordinate encoder (CoordEmb / CoordEncAtt, seen_coord_enc.py:13-139):
+ *   zs_window_tokens_bwd : adjoint of zs_window_tokens in gather form - d_out [B*nwy*nwx][win*win+1][C] ->
+ *       d_emb [B][H][W][C] (valid pixels), d_inv_rows [B][H][W][C] (the rows that fed invalid_coord_token) and
+ *       d_cls_rows [B*nwy*nwx][C]; their column sums (zs_column_sum) are the two token gradients.
+ *   zs_coord_dsp2_bwd : adjoint of the 2x down-sampling of the seen-surface coordinate map (interpolate_coordmap,
+ *       utils/util.py:336-345, dsp = 2) as the same-size gradient zs_seen_surface_bwd takes: d_dsp [B][3][H/2][W/2],
+ *       mask [B][H][W], mask_dsp [B][H/2][W/2] -> d_full [B][3][H][W]. */
+int zs_window_tokens_bwd(const float *d_out, const uint8_t *mask, float *d_emb, float *d_inv_rows, float *d_cls_rows,
+                         int batch, int H, int W, int C, int win, void *stream);
+int zs_coord_dsp2_bwd(const float *d_dsp, const float *mask, const float *mask_dsp, float *d_full, int batch, int H,
+                      int W, void *stream);
 /* Bilinear resize (align_corners=False) of a channels-last grid [Hi][Wi][C] -> [Ho][Wo][C]
  * (vit.py:103-120 _resize_pos_embed); backward != 0: x is the gradient of the [Ho][Wo][C] output
  * and y receives the gradient of the [Hi][Wi][C] input.  zs_readout_concat_bwd: adjoint of

@@ -473,3 +473,187 @@ def test_fix_dpt_freezes_depth_model_and_skips_its_backward(encoder_sd, seeded_s
     for k, p in graph.named_parameters():
         frozen = k.startswith(("dpt_depth.", "intr_head.", "intr_proj."))
         assert (p.grad is None) == (frozen or k == "impl_network.pos_embed"), k
+
+
+# ---- the transformer coordinate encoder (arch.depth.encoder != 'resnet', dsp = 2) under autograd ----
+def test_seen_surface_dsp2_backward():
+    """graph_shape.py:131-144 with arch.depth.dsp = 2: the half-size masked resample
+    (utils/util.py:336-345) and its adjoint, chained into the same-size geometry backward."""
+    from zeroshape_amd import synthetic as syn
+    from zeroshape_amd.nn import autograd as A
+    depth, mask, params = [torch.from_numpy(a) for a in syn.seeded_depth_scene(seed=4, batch=3)]
+    H = W = depth.shape[-1]
+    g = torch.Generator().manual_seed(18)
+    pr, dr = params.clone().requires_grad_(True), depth.clone().requires_grad_(True)
+    with train_ref.differentiable():
+        K = frontend_ref.intr_param2mtx(H, W, pr)
+        seen, coord, mask_dsp, _, _ = frontend_ref.seen_surface(dr, K, mask, 2)
+        gs, gc = torch.randn(seen.shape, generator=g), torch.randn(coord.shape, generator=g)
+        ((seen * gs).sum() + (coord * gc).sum()).backward()
+    pg, dg = params.cuda().requires_grad_(True), depth.cuda().requires_grad_(True)
+    Kg = A.intr_param2mtx(pg, H, W)
+    seen_g, coord_g, mask_g = A.seen_surface_dsp2(dg, Kg, mask.cuda())
+    assert coord_g.shape == (3, 3, H // 2, W // 2) and mask_g.shape == (3, 1, H // 2, W // 2)
+    close(seen_g, seen, rtol=5e-5, what="seen")
+    close(coord_g, coord, rtol=5e-5, what="coord (dsp 2)")
+    close(mask_g, mask_dsp, what="mask (dsp 2)")
+    ((seen_g * gs.cuda()).sum() + (coord_g * gc.cuda()).sum()).backward()
+    close(dg.grad, dr.grad, rtol=2e-4, what="d_depth")
+    close(pg.grad, pr.grad, rtol=2e-4, what="d_params")
+
+
+def test_window_tokens_backward():
+    """CoordEmb's token preparation (seen_coord_enc.py:50-66): where(mask, emb, invalid) -> windows -> + pos,
+    cls + pos[0] in front; gradients to the embedding, the invalid token and the class token."""
+    from zeroshape_amd.nn import autograd as A
+    g = torch.Generator().manual_seed(19)
+    B, H, W, C, win = 2, 16, 24, 32, 8
+    emb, inv, cls = torch.randn(B, H, W, C, generator=g), torch.randn(C, generator=g), torch.randn(C, generator=g)
+    pos = torch.randn(win * win + 1, C, generator=g)
+    mask = torch.rand(B, H, W, generator=g) > 0.4
+    er, ir, cr = [t.clone().requires_grad_(True) for t in (emb, inv, cls)]
+    x = torch.where(mask[..., None], er, ir.expand_as(er))
+    x = x.view(B, H // win, win, W // win, win, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, win * win, C) + pos[1:]
+    want = torch.cat(((cr + pos[0]).expand(x.shape[0], 1, C), x), 1)
+    gy = torch.randn(want.shape, generator=g)
+    want.backward(gy)
+    eg, ig, cg = [t.cuda().requires_grad_(True) for t in (emb, inv, cls)]
+    got = A.window_tokens(eg, mask.cuda(), ig, cg, pos.cuda(), win)
+    close(got, want, what="window tokens")
+    got.backward(gy.cuda())
+    close(eg.grad, er.grad, what="d_emb")
+    close(ig.grad, ir.grad, rtol=1e-5, what="d_invalid_coord_token")
+    close(cg.grad, cr.grad, rtol=1e-5, what="d_cls_token")
+
+
+def _att_reference(sd, coord, mask, scales, heads=8, win=8, n_blocks=12):
+    """oracle/encoder_ref.coord_enc_att with timm's per-sample DropPath factors on the two residual branches of
+    the global blocks (seen_coord_enc.py:93-97; timm layers/drop.py: x * bernoulli(keep) / keep), given explicitly."""
+    E = encoder_ref
+    emb = F.linear(coord, sd["coord_embed.pos_embed.weight"], sd["coord_embed.pos_embed.bias"])
+    emb = torch.where(mask[..., None], emb, sd["coord_embed.invalid_coord_token"].expand_as(emb))
+    B, H, W, C = emb.shape
+    emb = emb.view(B, H // win, win, W // win, win, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, win * win, C)
+    pe = sd["coord_embed.two_d_pos_embed"]
+    cls = (sd["coord_embed.cls_token"] + pe[:, :1]).expand(emb.shape[0], -1, -1)
+    emb = E.vit_block(sd, "coord_embed.blocks.0", torch.cat((cls, emb + pe[:, 1:]), 1), heads)
+    x = torch.cat((sd["cls_token"].expand(B, -1, -1), emb[:, 0].view(B, -1, C)), 1)
+    for i in range(n_blocks):
+        p = "blocks.%d" % i
+        h = F.layer_norm(x, (C,), sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-6)
+        qkv = F.linear(h, sd[p + ".attn.qkv.weight"], sd[p + ".attn.qkv.bias"])
+        q, k, v = qkv.reshape(B, -1, 3, heads, C // heads).permute(2, 0, 3, 1, 4).unbind(0)
+        a = ((q @ k.transpose(-2, -1)) * (C // heads) ** -0.5).softmax(dim=-1) @ v
+        a = F.linear(a.transpose(1, 2).reshape(B, -1, C), sd[p + ".attn.proj.weight"], sd[p + ".attn.proj.bias"])
+        x = x + a * scales[2 * i].view(B, 1, 1)
+        h = F.layer_norm(x, (C,), sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-6)
+        h = F.linear(F.gelu(F.linear(h, sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"])),
+                     sd[p + ".mlp.fc2.weight"], sd[p + ".mlp.fc2.bias"])
+        x = x + h * scales[2 * i + 1].view(B, 1, 1)
+    return F.layer_norm(x, (C,), sd["norm.weight"], sd["norm.bias"], 1e-6)
+
+
+@pytest.mark.parametrize("drop", [False, True])
+def test_coord_enc_att_train_step(att_sd, drop):
+    """CoordEncAtt in .train() mode: forward + every parameter gradient + d_coord against torch CPU autograd
+    of the oracle (drop = False: oracle/encoder_ref.coord_enc_att itself; True: the same with DropPath factors,
+    three of four samples dropped somewhere).  LayerNorm network: well conditioned, tight tolerance."""
+    from zeroshape_amd.model.shape.seen_coord_enc import CoordEncAtt
+    g = torch.Generator().manual_seed(21)
+    B, S = 4, 112
+    coord = torch.rand(B, S, S, 3, generator=g) * 2 - 1
+    mask = torch.rand(B, S, S, generator=g) > 0.45
+    mask[1, :16] = False                                  # whole windows of invalid pixels
+    keep = 0.9
+    scales = [(torch.rand(B, generator=g) < (0.7 if drop else 2.0)).float() / (keep if drop else 1.0) for _ in range(24)]
+    sd = {k: v.clone() for k, v in att_sd.items()}
+    for k, v in sd.items():
+        if k != "coord_embed.two_d_pos_embed":
+            v.requires_grad_(True)
+    cr = coord.clone().requires_grad_(True)
+    if drop:
+        want = _att_reference(sd, cr, mask, scales)
+    else:
+        with train_ref.differentiable():
+            want = encoder_ref.coord_enc_att(sd, cr, mask)
+    gy = torch.randn(want.shape, generator=g)
+    want.backward(gy)
+    enc = CoordEncAtt(embed_dim=256, n_blocks=12, num_heads=8, win_size=8)
+    enc.load_state_dict(att_sd, strict=True)
+    enc = enc.cuda().train()
+    enc.drop_scales = [s.cuda() for s in scales] if drop else [None] * 24
+    cg = coord.cuda().requires_grad_(True)
+    got = enc(cg, mask.cuda())
+    assert got.shape == (B, 1 + (S // 8) ** 2, 256) and got.requires_grad
+    assert _rel(got, want) < 2e-5, _rel(got, want)
+    got.backward(gy.cuda())
+    errs = {"d_coord": _rel(cg.grad, cr.grad)}
+    for name, p in enc.named_parameters():
+        if name == "coord_embed.two_d_pos_embed":
+            assert p.grad is None
+            continue
+        assert p.grad is not None, name
+        errs[name] = _rel(p.grad, sd[name].grad)
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    print("CoordEncAtt train (drop_path %s): forward %.2e, worst gradient %.2e (%s)" % (drop, _rel(got, want), worst[1], worst[0]))
+    assert worst[1] < 1e-4, {k: v for k, v in errs.items() if v > 1e-4}
+
+
+def test_coord_enc_att_drop_path_sampling(att_sd):
+    """Without explicit factors the module draws bernoulli(0.9)/0.9 per sample and branch (timm DropPath):
+    seeded -> reproducible; eval mode and no_grad take the packed inference path (no DropPath)."""
+    from zeroshape_amd.model.shape.seen_coord_enc import CoordEncAtt
+    enc = CoordEncAtt(embed_dim=256, n_blocks=12, num_heads=8, win_size=8)
+    enc.load_state_dict(att_sd, strict=True)
+    enc = enc.cuda().train()
+    g = torch.Generator().manual_seed(22)
+    coord = (torch.rand(8, 32, 32, 3, generator=g) * 2 - 1).cuda()
+    mask = (torch.rand(8, 32, 32, generator=g) > 0.3).cuda()
+    s = enc._drop_scale(4096, coord.device)
+    assert set(s.unique().tolist()) <= {0.0, 1.0 / 0.9} and 0.86 < float((s > 0).float().mean()) < 0.94
+    torch.manual_seed(5)
+    a = enc(coord, mask)
+    torch.manual_seed(5)
+    b = enc(coord, mask)
+    torch.manual_seed(6)
+    c = enc(coord, mask)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    with torch.no_grad():
+        d = enc(coord, mask)
+    e = enc.eval()(coord, mask)
+    assert torch.equal(d, e)
+
+
+def test_graph_trains_with_the_transformer_coordinate_encoder(encoder_sd, seeded_sd, graph_train_golden):
+    """Graph.forward(training=True) with arch.depth.encoder = 'att', dsp = 2 (graph_shape.py:41-47, :131-150):
+    the latent equals the oracle's encoder on the oracle's half-size seen-surface map of the predicted depth, and
+    the shape loss reaches every trainable parameter of the coordinate encoder and the depth model."""
+    from zeroshape_amd.model.compute_graph.graph_shape import Graph
+    from zeroshape_amd.utils.options import EasyDict as edict
+    g = graph_train_golden
+    opt = _opt()
+    opt.arch.depth.encoder, opt.arch.depth.dsp = "att", 2
+    torch.manual_seed(3)
+    graph = Graph(opt)
+    sd = {k: v for k, v in full_state_dict(encoder_sd, seeded_sd).items() if not k.startswith("coord_encoder.")}
+    missing = graph.load_state_dict(sd, strict=False)
+    assert all(k.startswith("coord_encoder.") for k in missing.missing_keys) and not missing.unexpected_keys
+    graph = graph.cuda().train()
+    graph.coord_encoder.drop_scales = [None] * 24
+    var = edict({k: v.cuda()[:2] for k, v in graph_train_inputs(g).items()})
+    var.idx = torch.arange(2)
+    var, loss = graph.forward(opt, var, training=True, get_loss=True)
+    assert var.latent_depth.shape == (2, 197, 256) and bool(torch.isfinite(loss.shape))
+    att = {k: v.detach().cpu() for k, v in graph.coord_encoder.state_dict().items()}
+    _, coord, mask_dsp, _, _ = frontend_ref.seen_surface(var.depth_pred.detach().cpu(), var.intr_pred.detach().cpu(),
+                                                         var.mask_input_map.cpu(), 2)
+    want = encoder_ref.coord_enc_att(att, coord.permute(0, 2, 3, 1).contiguous(), mask_dsp.squeeze(1) > 0.5)
+    assert _rel(var.latent_depth, want) < 1e-4, _rel(var.latent_depth, want)
+    loss.shape.backward()
+    for k, p in graph.named_parameters():
+        if k in ("impl_network.pos_embed", "coord_encoder.coord_embed.two_d_pos_embed"):
+            assert p.grad is None, k
+        else:
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+    assert float(graph.coord_encoder.coord_embed.invalid_coord_token.grad.abs().max()) > 0
+    assert float(graph.dpt_depth.scratch.output_conv[4].weight.grad.abs().max()) > 0

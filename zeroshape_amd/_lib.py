@@ -143,12 +143,14 @@ SIGNATURES = {
     "zs_nhwc_to_nchw_masked": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
     "zs_seen_surface_bwd": (_c_int, [_c_void_p] * 7 + [_c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "zs_intr_param2mtx_bwd": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "zs_window_tokens_bwd": (_c_int, [_c_void_p] * 5 + [_c_int] * 5 + [_c_void_p]),
+    "zs_coord_dsp2_bwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 3 + [_c_void_p]),
     "zs_transform_points": (_c_int, [_c_void_p] * 5 + [_c_int, _c_int, _c_void_p]),
     "zs_resize_bilinear_nhwc": (_c_int, [_c_void_p, _c_void_p] + [_c_int] * 6 + [_c_void_p]),
     "zs_readout_concat_bwd": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
 }
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 _lib = None
 
 

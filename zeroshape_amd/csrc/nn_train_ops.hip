@@ -291,6 +291,53 @@ __global__ __launch_bounds__(64) void attention_bwd_mfma_kernel(const float *__r
     }
 }
 
+
+// ---- CoordEmb token preparation, backward (adjoint of window_tokens_kernel, csrc/nn_ops.hip) ----
+// d_out [B*nwy*nwx][win*win+1][C] -> per pixel (each pixel belongs to exactly one window token: a gather,
+// no atomics): d_emb [B][H][W][C] = the token's gradient where the pixel is valid, else 0; d_inv_rows
+// [B][H][W][C] = the complement (rows that fed the learned invalid-coordinate token); d_cls_rows
+// [B*nwy*nwx][C] = the gradient of every window's class token.  Their column sums (zs_column_sum) are the
+// gradients of invalid_coord_token and cls_token (seen_coord_enc.py:52-66).
+__global__ __launch_bounds__(256) void window_tokens_bwd_kernel(const float *__restrict__ d_out,
+                                                                const uint8_t *__restrict__ mask, float *__restrict__ d_emb,
+                                                                float *__restrict__ d_inv_rows,
+                                                                float *__restrict__ d_cls_rows, int B, int H, int W, int C,
+                                                                int win) {
+    const int T = win * win + 1, nwx = W / win, nwy = H / win;
+    const size_t n_pix = (size_t)B * H * W * C, n_cls = (size_t)B * nwy * nwx * C;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_pix) {
+        const int c = i % C;
+        const size_t pix = i / C;
+        const int px = pix % W, py = (pix / W) % H, b = pix / W / H;
+        const size_t wdx = ((size_t)b * nwy + py / win) * nwx + px / win;
+        const int t = 1 + (py % win) * win + (px % win);
+        const float g = d_out[(wdx * T + t) * C + c];
+        const bool ok = mask[pix] != 0;
+        d_emb[i] = ok ? g : 0.f;
+        d_inv_rows[i] = ok ? 0.f : g;
+    } else if (i < n_pix + n_cls) {
+        const size_t j = i - n_pix;
+        d_cls_rows[j] = d_out[(j / C) * T * C + (j % C)];
+    }
+}
+
+// Adjoint of the 2x down-sampling of the seen-surface coordinate map (interpolate_coordmap, utils/util.py:336-345,
+// dsp = 2: bilinear with align_corners=False at exactly half the size = the mean of a 2 x 2 block, divided by the
+// resampled mask + 1e-6), expressed as the SAME-SIZE coordinate-map gradient zs_seen_surface_bwd expects (which
+// divides by mask + 1e-6 itself): d_full[y][x] = 0.25 d_dsp[y/2][x/2] (mask[y][x] + 1e-6) / (mask_dsp[y/2][x/2] + 1e-6)
+__global__ __launch_bounds__(256) void coord_dsp2_bwd_kernel(const float *__restrict__ d_dsp, const float *__restrict__ mask,
+                                                             const float *__restrict__ mask_dsp, float *__restrict__ d_full,
+                                                             int B, int H, int W) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)B * 3 * H * W;
+    if (i >= total) return;
+    const int x = i % W, y = (i / W) % H, c = (i / W / H) % 3, b = i / W / H / 3;
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t o = ((size_t)b * Ho + y / 2) * Wo + x / 2;
+    d_full[i] = 0.25f * d_dsp[((size_t)b * 3 + c) * Ho * Wo + (size_t)(y / 2) * Wo + x / 2] *
+                (mask[((size_t)b * H + y) * W + x] + 1e-6f) / (mask_dsp[o] + 1e-6f);
+}
+
 }  // namespace
 
 #define ZS_REQUIRE(cond, ...)            \
@@ -408,4 +455,37 @@ extern "C" int zs_attention_bwd(const float *qkv, const float *dout, float *dqkv
                            scale);
     }
     return zs::check_launch("zs_attention_bwd") ? 1 : 0;
+}
+
+extern "C" int zs_window_tokens_bwd(const float *d_out, const uint8_t *mask, float *d_emb, float *d_inv_rows,
+                                    float *d_cls_rows, int batch, int H, int W, int C, int win, void *stream) {
+    if (batch < 0 || H <= 0 || W <= 0 || C <= 0 || win <= 0 || H % win || W % win) {
+        zs::set_err("zs_window_tokens_bwd: bad geometry (batch=%d %dx%dx%d win %d)", batch, H, W, C, win);
+        return 0;
+    }
+    if (batch == 0) return 1;
+    if (!d_out || !mask || !d_emb || !d_inv_rows || !d_cls_rows) {
+        zs::set_err("zs_window_tokens_bwd: null pointer");
+        return 0;
+    }
+    const size_t total = (size_t)batch * H * W * C + (size_t)batch * (H / win) * (W / win) * C;
+    hipLaunchKernelGGL(window_tokens_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, S(stream), d_out, mask, d_emb,
+                       d_inv_rows, d_cls_rows, batch, H, W, C, win);
+    return zs::check_launch("zs_window_tokens_bwd") ? 1 : 0;
+}
+
+extern "C" int zs_coord_dsp2_bwd(const float *d_dsp, const float *mask, const float *mask_dsp, float *d_full, int batch,
+                                 int H, int W, void *stream) {
+    if (batch < 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) {
+        zs::set_err("zs_coord_dsp2_bwd: bad size (batch=%d H=%d W=%d; even sizes)", batch, H, W);
+        return 0;
+    }
+    if (batch == 0) return 1;
+    if (!d_dsp || !mask || !mask_dsp || !d_full) {
+        zs::set_err("zs_coord_dsp2_bwd: null pointer");
+        return 0;
+    }
+    hipLaunchKernelGGL(coord_dsp2_bwd_kernel, dim3(blocks_for((size_t)batch * 3 * H * W)), dim3(256), 0, S(stream), d_dsp,
+                       mask, mask_dsp, d_full, batch, H, W);
+    return zs::check_launch("zs_coord_dsp2_bwd") ? 1 : 0;
 }

@@ -203,10 +203,15 @@ class Graph(nn.Module):
                 intr_params = self._intr.run(ops.to_nchw(layer_4))
         var.intr_pred = A.intr_param2mtx(intr_params, H, W)                                            # :129
         var.validity_mask = (mask > 0.5).float().view(batch_size, -1)
-        assert opt.arch.depth.dsp == 1 and opt.arch.depth.encoder == 'resnet', \
-            "the autograd branch is built for the default ResNet coordinate encoder (options/shape.yaml:26)"
-        var.seen_points, seen_3D_dsp, mask_dsp = A.seen_surface(var.depth_pred, var.intr_pred, mask)   # :131-144
-        var.latent_depth = self.coord_encoder(seen_3D_dsp, mask_dsp)                                   # :147-150
+        if opt.arch.depth.encoder == 'resnet':
+            assert opt.arch.depth.dsp == 1
+            var.seen_points, seen_3D_dsp, mask_dsp = A.seen_surface(var.depth_pred, var.intr_pred, mask)   # :131-144
+            var.latent_depth = self.coord_encoder(seen_3D_dsp, mask_dsp)                               # :147-150
+        else:                                              # transformer coordinate encoder
+            assert opt.arch.depth.dsp == 2, "the transformer coordinate encoder trains with arch.depth.dsp = 2 (options/shape.yaml:28)"
+            var.seen_points, seen_3D_dsp, mask_dsp = A.seen_surface_dsp2(var.depth_pred, var.intr_pred, mask)
+            var.latent_depth = self.coord_encoder(seen_3D_dsp.permute(0, 2, 3, 1).contiguous(),
+                                                  mask_dsp.squeeze(1) > 0.5)
         var.pose = var.pose_gt if 'pose_gt' in var else None
         if with_samples:
             with torch.no_grad():

@@ -1,6 +1,7 @@
 """Mirror of the reference's model/shape/seen_coord_enc.py (CoordEncRes :141-194, the default
 seen-surface encoder; CoordEmb + CoordEncAtt :13-139, the transformer alternative) on the HIP
-encoder layers.  Same constructor arguments and state-dict names; inference only."""
+encoder layers.  Same constructor arguments and state-dict names; inference through the packed
+layers, training (both encoders) through nn/autograd.py."""
 from functools import partial
 
 import torch
@@ -138,6 +139,8 @@ class CoordEncAtt(HipModule):
         if embed_dim // num_heads not in (32, 64):
             raise NotImplementedError("zs_attention supports head_dim 32 or 64")
         self.num_heads, self.win_size = num_heads, win_size
+        self.drop_path = float(drop_path)
+        self.drop_scales = None    # tests: explicit list of 2 * n_blocks per-sample scale tensors [B]
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
         self.coord_embed = CoordEmb(embed_dim, win_size, num_heads)
         self.blocks = nn.ModuleList([ViTBlock(embed_dim, mlp_ratio) for _ in range(n_blocks)])
@@ -164,10 +167,43 @@ class CoordEncAtt(HipModule):
                     blocks=[blocks.pack_vit_block(sd, "blocks.%d" % i, device) for i in range(len(self.blocks))],
                     nw=d(sd["norm.weight"]), nb=d(sd["norm.bias"]))
 
-    @torch.no_grad()
     def forward(self, coord_obj, mask_obj):
-        """coord_obj [B,H,W,3], mask_obj [B,H,W] bool -> [B, 1 + (H/ws)*(W/ws), C]."""
+        """coord_obj [B,H,W,3], mask_obj [B,H,W] bool -> [B, 1 + (H/ws)*(W/ws), C].  In .train() mode under
+        autograd: every layer through nn/autograd.py (gradients to all parameters and to coord_obj), with
+        timm's per-sample DropPath on the 12 global blocks (seen_coord_enc.py:93-97, drop_path 0.1)."""
         self._need_gpu(coord_obj, "coord_obj")
+        if self.training and torch.is_grad_enabled():
+            return self._forward_train(coord_obj, mask_obj)
+        with torch.no_grad():
+            return self._forward_eval(coord_obj, mask_obj)
+
+    def _drop_scale(self, B, device):
+        if self.drop_path <= 0.0:
+            return None
+        keep = 1.0 - self.drop_path
+        return torch.empty(B, dtype=torch.float32, device=device).bernoulli_(keep).div_(keep)
+
+    def _forward_train(self, coord_obj, mask_obj):
+        ce = self.coord_embed
+        B, H, W, _ = coord_obj.shape
+        win, C = self.win_size, self.cls_token.shape[-1]
+        x4 = A.pad_channels(coord_obj.float().contiguous(), 4)
+        emb = A.linear(x4, ce.pos_embed.weight, ce.pos_embed.bias, cin=3)                        # :51
+        tok = A.window_tokens(emb, mask_obj, ce.invalid_coord_token, ce.cls_token.view(-1),      # :52-66
+                              ce.two_d_pos_embed.detach()[0], win)
+        tok = train_blocks.vit_block(tok, ce.blocks[0], self.num_heads)                          # :68-69
+        n = (H // win) * (W // win)
+        feat = tok[:, 0].reshape(B, n, C)                                                        # :71
+        zero_pos = torch.zeros(n + 1, C, device=emb.device)
+        x = A.assemble_tokens(feat, self.cls_token.view(-1), zero_pos)                           # :127-131
+        nb = len(self.blocks)
+        scales = list(self.drop_scales) if self.drop_scales is not None else \
+            [self._drop_scale(B, emb.device) for _ in range(2 * nb)]
+        for i, blk in enumerate(self.blocks):
+            x = train_blocks.vit_block(x, blk, self.num_heads, (scales[2 * i], scales[2 * i + 1]))
+        return A.layer_norm(x, self.norm.weight, self.norm.bias, 1e-6)
+
+    def _forward_eval(self, coord_obj, mask_obj):
         pk = self.packed(coord_obj.device)
         B, H, W, _ = coord_obj.shape
         win, C = self.win_size, pk["C"]

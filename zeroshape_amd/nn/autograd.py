@@ -233,6 +233,23 @@ def _pad_channels(x, cpad):
     return y
 
 
+class _PadChannels(torch.autograd.Function):
+    """[..., C] -> [..., cpad] with zero padding channels (the channel count the convolution engine stages)."""
+
+    @staticmethod
+    def forward(ctx, x, cpad):
+        ctx.C = x.shape[-1]
+        return _pad_channels(_f32c(x, "pad input"), cpad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy[..., :ctx.C].contiguous(), None
+
+
+def pad_channels(x, cpad):
+    return x if x.shape[-1] == cpad else _PadChannels.apply(x, cpad)
+
+
 class _Conv(torch.autograd.Function):
     """y = act(conv(T(x), W[:, cin0:cin0+cin]) + bias + res1 + res2), T = input ReLU / affine."""
 
@@ -923,6 +940,93 @@ class _AssembleTokens(torch.autograd.Function):
 
 def assemble_tokens(feat, cls, pos):
     return _AssembleTokens.apply(feat, cls, pos)
+
+
+class _WindowTokens(torch.autograd.Function):
+    """CoordEmb's token preparation (seen_coord_enc.py:50-71; zs_window_tokens): emb [B,H,W,C], mask [B,H,W] bool,
+    invalid_token [C], cls [C], pos [win*win+1, C] (fixed) -> [B*(H/win)*(W/win), win*win+1, C]."""
+
+    @staticmethod
+    def forward(ctx, emb, mask, invalid_token, cls, pos, win):
+        lib = _lib.load()
+        emb, invalid_token = _f32c(emb, "window_tokens input"), _f32c(invalid_token, "invalid_coord_token")
+        cls, pos = _f32c(cls, "cls_token"), _f32c(pos, "two_d_pos_embed")
+        B, H, W, C = emb.shape
+        m = mask.to(torch.uint8).contiguous()
+        out = torch.empty(B * (H // win) * (W // win), win * win + 1, C, dtype=torch.float32, device=emb.device)
+        with torch.cuda.device(emb.device):
+            _lib.check(lib.zs_window_tokens(_lib.ptr(emb), _lib.ptr(m), _lib.ptr(invalid_token), _lib.ptr(cls), _lib.ptr(pos),
+                                            _lib.ptr(out), B, H, W, C, win, _stream(emb)), "zs_window_tokens")
+        ctx.save_for_backward(m)
+        ctx.geom = (B, H, W, C, win)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (m,) = ctx.saved_tensors
+        B, H, W, C, win = ctx.geom
+        dy = _f32c(dy, "window_tokens grad")
+        d_emb = torch.empty(B, H, W, C, dtype=torch.float32, device=dy.device)
+        d_inv = torch.empty_like(d_emb)
+        d_cls = torch.empty(B * (H // win) * (W // win), C, dtype=torch.float32, device=dy.device)
+        with torch.cuda.device(dy.device):
+            _lib.check(lib.zs_window_tokens_bwd(_lib.ptr(dy), _lib.ptr(m), _lib.ptr(d_emb), _lib.ptr(d_inv), _lib.ptr(d_cls),
+                                                B, H, W, C, win, _stream(dy)), "zs_window_tokens_bwd")
+        return d_emb, None, column_sum(d_inv.view(-1, C)), column_sum(d_cls), None, None
+
+
+def window_tokens(emb, mask, invalid_token, cls, pos, win):
+    return _WindowTokens.apply(emb, mask, invalid_token, cls, pos, win)
+
+
+class _SeenSurfaceDsp2(torch.autograd.Function):
+    """graph_shape.py:131-144 with arch.depth.dsp = 2 (the transformer coordinate encoder): as _SeenSurface, the
+    coordinate map and its mask resampled to half the size (interpolate_coordmap, utils/util.py:336-345)."""
+
+    @staticmethod
+    def forward(ctx, depth, intr, mask):
+        lib = _lib.load()
+        depth, intr = _f32c(depth, "depth"), _f32c(intr, "intr")
+        m = _f32c(mask.float(), "mask")
+        B, _, H, W = depth.shape
+        Ho, Wo = H // 2, W // 2
+        dev = depth.device
+        seen = torch.empty(B, H * W, 3, dtype=torch.float32, device=dev)
+        mean = torch.empty(B, 3, dtype=torch.float32, device=dev)
+        scale = torch.empty(B, dtype=torch.float32, device=dev)
+        coord = torch.empty(B, 3, Ho, Wo, dtype=torch.float32, device=dev)
+        mask_dsp = torch.empty(B, 1, Ho, Wo, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.zs_seen_surface(_lib.ptr(depth), _lib.ptr(intr), _lib.ptr(m), B, H, W, Ho, Wo, _lib.ptr(seen),
+                                           _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(coord), _lib.ptr(mask_dsp),
+                                           _stream(depth)), "zs_seen_surface")
+        ctx.save_for_backward(depth, intr, m, mean, scale, mask_dsp)
+        ctx.mark_non_differentiable(mask_dsp)
+        return seen, coord, mask_dsp
+
+    @staticmethod
+    def backward(ctx, d_seen, d_coord, _d_mask):
+        lib = _lib.load()
+        depth, intr, m, mean, scale, mask_dsp = ctx.saved_tensors
+        B, _, H, W = depth.shape
+        d_seen = None if d_seen is None else _f32c(d_seen, "seen grad")
+        d_full = None
+        with torch.cuda.device(depth.device):
+            if d_coord is not None:
+                d_full = torch.empty(B, 3, H, W, dtype=torch.float32, device=depth.device)
+                _lib.check(lib.zs_coord_dsp2_bwd(_lib.ptr(_f32c(d_coord, "coord grad")), _lib.ptr(m), _lib.ptr(mask_dsp),
+                                                 _lib.ptr(d_full), B, H, W, _stream(depth)), "zs_coord_dsp2_bwd")
+            dd = torch.empty_like(depth)
+            dk = torch.empty_like(intr)
+            _lib.check(lib.zs_seen_surface_bwd(_lib.ptr(depth), _lib.ptr(intr), _lib.ptr(m), _lib.ptr(mean),
+                                               _lib.ptr(scale), _lib.ptr(d_seen), _lib.ptr(d_full), B, H, W,
+                                               _lib.ptr(dd), _lib.ptr(dk), _stream(depth)), "zs_seen_surface_bwd")
+        return dd, dk, None
+
+
+def seen_surface_dsp2(depth, intr, mask):
+    return _SeenSurfaceDsp2.apply(depth, intr, mask)
 
 
 class _ReadoutConcat(torch.autograd.Function):

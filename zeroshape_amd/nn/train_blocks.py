@@ -39,14 +39,21 @@ def resnet50(x, enc):
     return feats
 
 
-def vit_block(x, blk, heads):
-    """timm Block: x + proj(attn(LN x)); x + fc2(gelu(fc1(LN x)))  (drop_path 0)."""
+def vit_block(x, blk, heads, scales=None):
+    """timm Block: x + drop_path(proj(attn(LN x))); x + drop_path(fc2(gelu(fc1(LN x)))).  scales = (s_attn, s_mlp):
+    per-sample DropPath factors [B] (bernoulli(keep) / keep, timm layers/drop.py) or None for drop_path 0 / eval."""
+    s_attn, s_mlp = scales if scales is not None else (None, None)
     h = A.layer_norm(x, blk.norm1.weight, blk.norm1.bias, 1e-6)
     a = A.attention(A.linear(h, blk.attn.qkv.weight, blk.attn.qkv.bias), heads)
-    x = A.linear(a, blk.attn.proj.weight, blk.attn.proj.bias, res1=x)
+    if s_attn is None:
+        x = A.linear(a, blk.attn.proj.weight, blk.attn.proj.bias, res1=x)
+    else:
+        x = A.add_scaled_rows(x, A.linear(a, blk.attn.proj.weight, blk.attn.proj.bias), s_attn)
     h = A.layer_norm(x, blk.norm2.weight, blk.norm2.bias, 1e-6)
     h = A.gelu(A.linear(h, blk.mlp.fc1.weight, blk.mlp.fc1.bias))
-    return A.linear(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias, res1=x)
+    if s_mlp is None:
+        return A.linear(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias, res1=x)
+    return A.add_scaled_rows(x, A.linear(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias), s_mlp)
 
 
 STD_EPS = 1e-8      # timm StdConv2dSame
