@@ -322,20 +322,28 @@ __global__ __launch_bounds__(256) void window_tokens_bwd_kernel(const float *__r
     }
 }
 
-// Adjoint of the 2x down-sampling of the seen-surface coordinate map (interpolate_coordmap, utils/util.py:336-345,
-// dsp = 2: bilinear with align_corners=False at exactly half the size = the mean of a 2 x 2 block, divided by the
-// resampled mask + 1e-6), expressed as the SAME-SIZE coordinate-map gradient zs_seen_surface_bwd expects (which
-// divides by mask + 1e-6 itself): d_full[y][x] = 0.25 d_dsp[y/2][x/2] (mask[y][x] + 1e-6) / (mask_dsp[y/2][x/2] + 1e-6)
+// Adjoint of interpolate_coordmap at half size (utils/util.py:336-345; bilinear, align_corners=False, exact
+// factor 2 = the 2x2 mean): coord_dsp[o] = keep[o] * mean4(seen * m) / (mean4(m) + 1e-6), keep = mean4(m) > 0.5.
+// Expressed as the SAME-SIZE coordinate-map gradient zs_seen_surface_bwd expects at valid pixels (it multiplies by
+// 1 / (1 + 1e-6) itself): d_full[y][x] = 0.25 d_dsp[o] keep[o] (1 + 1e-6) / (mean4(m) + 1e-6); 0 at invalid pixels.
 __global__ __launch_bounds__(256) void coord_dsp2_bwd_kernel(const float *__restrict__ d_dsp, const float *__restrict__ mask,
                                                              const float *__restrict__ mask_dsp, float *__restrict__ d_full,
                                                              int B, int H, int W) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)B * 3 * H * W;
     if (i >= total) return;
     const int x = i % W, y = (i / W) % H, c = (i / W / H) % 3, b = i / W / H / 3;
-    const int Ho = H / 2, Wo = W / 2;
-    const size_t o = ((size_t)b * Ho + y / 2) * Wo + x / 2;
-    d_full[i] = 0.25f * d_dsp[((size_t)b * 3 + c) * Ho * Wo + (size_t)(y / 2) * Wo + x / 2] *
-                (mask[((size_t)b * H + y) * W + x] + 1e-6f) / (mask_dsp[o] + 1e-6f);
+    const int Ho = H / 2, Wo = W / 2, yo = y / 2, xo = x / 2;
+    const float *M = mask + (size_t)b * H * W;
+    if (yo >= Ho || xo >= Wo || !(M[(size_t)y * W + x] > 0.5f)) {
+        d_full[i] = 0.f;
+        return;
+    }
+    const float *m0 = M + (size_t)(2 * yo) * W + 2 * xo;
+    const float den = 0.25f * ((m0[0] > 0.5f ? 1.f : 0.f) + (m0[1] > 0.5f ? 1.f : 0.f) + (m0[W] > 0.5f ? 1.f : 0.f) +
+                               (m0[W + 1] > 0.5f ? 1.f : 0.f));
+    const size_t o = ((size_t)b * Ho + yo) * Wo + xo;
+    const float keep = mask_dsp[o] > 0.5f ? 1.f : 0.f;
+    d_full[i] = 0.25f * d_dsp[((size_t)b * 3 + c) * Ho * Wo + (size_t)yo * Wo + xo] * keep * (1.0f + 1.e-6f) / (den + 1.e-6f);
 }
 
 }  // namespace
