@@ -137,10 +137,16 @@ DEV PT pack_tile(const T &x) {
 // base) is not saved: hipcc has no use for it in this kernel (no LDS-direct, GWS, movrel or
 // interpolation instructions; tools/check_split_isa.py audits the ISA for it).
 DEV void glds_kblocks(const char *gsrc, unsigned lds_dst) {  // this wave's two K-blocks of a chunk
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                 "\n\tglobal_load_lds_dwordx4 %0, off offset:1024"
-                 "\n\tglobal_load_lds_dwordx4 %0, off offset:2048"
-                 "\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
+#ifdef ZS_EXP_NO_DMA   // energy ablation (tools/energy_ablation.sh): results are garbage, the timing is the point
+    if (gsrc != nullptr) return;
+#endif
+#ifndef ZS_DMA_MOD      // cache-policy modifiers of the weight stream's loads (experiments: " nt", " sc1", ...)
+#define ZS_DMA_MOD ""
+#endif
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ZS_DMA_MOD
+                 "\n\tglobal_load_lds_dwordx4 %0, off offset:1024" ZS_DMA_MOD
+                 "\n\tglobal_load_lds_dwordx4 %0, off offset:2048" ZS_DMA_MOD
+                 "\n\tglobal_load_lds_dwordx4 %0, off offset:3072" ZS_DMA_MOD
                  :
                  : "v"(gsrc), "s"(lds_dst)
                  : "memory");
@@ -208,8 +214,10 @@ struct AStream {
             hi = buf[0][0];
             lo = buf[0][64];
         } else {
+#ifndef ZS_EXP_NO_AREAD   // energy ablation: one A read per chunk instead of eight
             hi = buf[0][(pos + 1) * KB_U4];
             lo = buf[0][(pos + 1) * KB_U4 + 64];
+#endif
         }
     }
     DEV void drain() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
