@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 22
+#define ZS_ABI_VERSION 24
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -354,18 +354,32 @@ int zs_depth_metrics(const float *prediction, const float *target, const float *
 #define ZS_CONV_F16X3 16      /* split-fp16 arithmetic on the 16-bit matrix pipe (csrc/zs_split16.h): operands
                                carried as two fp16 halves (~2^-21 relative for 2e-4 <~ |x| <= 65504), three
                                K = 16 MFMAs per eight fp32 ones; inference */
+#define ZS_CONV_SPLIT_SMALL 32 /* with a workspace: small-tile layers that would leave most CUs idle split K across
+                               * workgroups (partial sums in the workspace, fixed-order reduction kernel) */
+#define ZS_CONV_STREAM_K 64   /* with a workspace: 128x128-tile layers run as a fixed number of workgroups that share the
+                               * (tile, k-step) iteration space evenly; shared tiles are summed in k order by the
+                               * workgroup that arrives last (deterministic) */
+#define ZS_CONV_STREAM_K_ALWAYS 256 /* tests / tuning: with ZS_CONV_STREAM_K, stream-K wherever the kernels support it (by
+                                     * default only where it was measured to pay: see csrc/nn_conv.hip) */
+#define ZS_CONV_W_PRESPLIT 128 /* with ZS_CONV_F16X3: packed_w is the output of zs_conv2d_presplit_weight (the weights'
+                               * fp16 halves, same size and indexing as the fp32 packing) - no operand split of the
+                               * weights at run time */
 #define ZS_CONV_IN_DILATE2 8  /* read the input as if zero-stuffed x2 ([B][2H-1][2W-1][Cin] virtual): the
                                  data gradient of a stride-2 convolution as a stride-1 convolution */
 size_t zs_conv2d_packed_floats(int Cin, int Cout, int kh, int kw);
+/* packed_w (zs_pack_conv_weight / nn/pack.py layout, zs_conv2d_packed_floats() floats) -> split_w, same size: the
+ * split-fp16 halves of every weight in the order the ZS_CONV_F16X3 kernels consume them (ZS_CONV_W_PRESPLIT). */
+int zs_conv2d_presplit_weight(const float *packed_w, float *split_w, int Cin, int Cout, int kh, int kw, void *stream);
 int zs_conv2d_nhwc(const float *in, const float *packed_w, const float *scale, const float *shift,
                    const float *res1, const float *res2, float *out, int batch, int Hin, int Win, int Cin,
                    int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad_t, int pad_l, int flags,
                    float in_scale, float in_shift, int act, void *stream);
-/* As zs_conv2d_nhwc, with a workspace of zs_conv2d_splitk_workspace_bytes() bytes (16-byte aligned, may be
- * shared by launches on one stream; NULL = zs_conv2d_nhwc).  Problems that would launch fewer than 256
- * workgroups (14x14 feature maps, 197-token matrices at small batch) split K across workgroups - partial
- * tiles go through the workspace and a second kernel sums them in split order (deterministic) and applies
- * the fused epilogue. */
+/* As zs_conv2d_nhwc, with a workspace of zs_conv2d_splitk_workspace_bytes() bytes (16-byte aligned, ZEROED ONCE by
+ * the caller when allocated - its first 1 MiB are arrival counters the kernels leave at zero - and used by one
+ * stream at a time; NULL = zs_conv2d_nhwc).  What uses it is chosen by the flags: ZS_CONV_SPLIT_SMALL (problems
+ * that would launch fewer than 256 small-tile workgroups - 14x14 feature maps, 197-token matrices at small
+ * batch - split K across workgroups; a second kernel sums the partial tiles in split order and applies the
+ * fused epilogue) and ZS_CONV_STREAM_K (128x128-tile problems; see above).  Both are deterministic. */
 size_t zs_conv2d_splitk_workspace_bytes(void);
 int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const float *scale, const float *shift,
                    const float *res1, const float *res2, float *out, int batch, int Hin, int Win, int Cin,

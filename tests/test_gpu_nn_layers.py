@@ -267,3 +267,41 @@ def test_conv2d_split_k_across_workgroups(B, Cin, H, W, Cout, k, monkeypatch):
             assert float((a1 - single).abs().max()) < 2e-5 * max(1.0, float(single.abs().max()))
     finally:
         ops.set_conv_precision(prev)
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,stride,in_relu", [
+    (28, 768, 14, 14, 768, 1, 1, False), (6, 3072, 14, 14, 768, 1, 1, False), (3, 64, 56, 56, 256, 3, 1, False),
+    (2, 32, 57, 41, 200, 3, 2, False), (5, 20, 31, 33, 130, 5, 1, False), (1, 256, 64, 64, 128, 1, 1, False),
+    (8, 256, 28, 28, 320, 3, 1, True), (3, 128, 40, 36, 256, 3, 2, False), (28, 768, 14, 14, 2304, 1, 1, False)])
+def test_conv2d_stream_k(B, Cin, H, W, Cout, k, stride, in_relu, monkeypatch):
+    """ZS_CONV_STREAM_K: the large-tile kernels as a fixed number of workgroups sharing the (tile, k-step) space
+    (128 x 128 tiles over 768 workgroups; 256 x 256 tiles over 256 for layers with >= 192 output channels); tiles
+    cut across workgroups are summed in k order by whichever arrives last.  Same result as one workgroup per tile
+    up to the summation order, bit-reproducible over repeated launches (counters return to zero), every operand
+    path (pointwise, tap-major with / without input ReLU, generic taps; ragged M and Cout), fused epilogue."""
+    from zeroshape_amd.nn import ops, pack
+    g = torch.Generator().manual_seed(Cin + Cout + k)
+    xc = torch.randn(B, Cin, H, W, generator=g)
+    x = nhwc(xc).cuda()
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    pc = pack.pack_conv(w, b, stride=stride, padding=k // 2).to("cuda")
+    ref = F.conv2d(F.relu(xc) if in_relu else xc, w, b, stride=stride, padding=k // 2)
+    res = torch.randn(ref.shape, generator=g)
+    want = nhwc(F.relu(ref + res))
+    res = nhwc(res).cuda()
+    prev = ops.CONV_PRECISION
+    try:
+        for prec in ("f32", "f16x3"):
+            ops.set_conv_precision(prec)
+            monkeypatch.setattr(ops, "STREAM_K", "always")
+            runs = [ops.conv2d(x, pc, res1=res, act=ops.ACT_RELU, in_relu=in_relu, tiling="large") for _ in range(4)]
+            monkeypatch.setattr(ops, "STREAM_K", False)
+            single = ops.conv2d(x, pc, res1=res, act=ops.ACT_RELU, in_relu=in_relu, tiling="large")
+            for r in runs[1:]:
+                assert torch.equal(runs[0], r)
+            close(runs[0], want)
+            assert float((runs[0] - single).abs().max()) < 2e-5 * max(1.0, float(single.abs().max()))
+        assert int(ops.splitk_workspace(x.device)[:1 << 18].view(torch.int32).abs().max()) == 0    # counters at rest
+    finally:
+        ops.set_conv_precision(prev)

@@ -18,7 +18,25 @@ def main():
     for n, d in (("B", 4), ("H", 14), ("Cin", 256), ("Cout", 256), ("k", 3), ("stride", 1), ("iters", 50)):
         ap.add_argument("--" + n, type=int, default=d)
     ap.add_argument("--mode", default="all")
+    ap.add_argument("--engine", default="autograd", help="autograd (training path, nn/autograd.py) | ops (inference path, nn/ops.py)")
     a = ap.parse_args()
+    if a.engine == "ops":
+        from zeroshape_amd.nn import ops, pack
+        x = torch.randn(a.B, a.H, a.H, a.Cin, device="cuda")
+        w = torch.randn(a.Cout, a.Cin, a.k, a.k) / (a.Cin * a.k * a.k) ** 0.5
+        pc = pack.pack_conv(w, None, stride=a.stride, padding=a.k // 2).to("cuda")
+        y = ops.conv2d(x, pc)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            ops.conv2d(x, pc)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / a.iters * 1e3
+        print("M=%d N=%d K=%d: ops.conv2d %.1f us (%.1f TFLOP/s)" % (y.numel() // a.Cout, a.Cout, a.Cin * a.k * a.k, us,
+                                                                     2.0 * y.numel() * a.Cin * a.k * a.k / us / 1e6))
+        return
     x = torch.randn(a.B, a.H, a.H, a.Cin, device="cuda", requires_grad=True)
     w = (torch.randn(a.Cout, a.Cin, a.k, a.k, device="cuda") / (a.Cin * a.k * a.k) ** 0.5).requires_grad_(True)
     y = A.conv2d(x, w, None, stride=a.stride, padding=a.k // 2)

@@ -77,6 +77,7 @@ SIGNATURES = {
                                   ctypes.POINTER(ctypes.c_float), _c_int, _c_void_p, _c_void_p, _c_void_p,
                                   _c_void_p]),
     "zs_conv2d_packed_floats": (_c_size_t, [_c_int, _c_int, _c_int, _c_int]),
+    "zs_conv2d_presplit_weight": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
     "zs_conv2d_nhwc": (_c_int, [_c_void_p] * 7 + [_c_int] * 13 + [ctypes.c_float, ctypes.c_float, _c_int,
                                                                   _c_void_p]),
     "zs_conv2d_splitk_workspace_bytes": (_c_size_t, []),
@@ -150,7 +151,7 @@ SIGNATURES = {
     "zs_readout_concat_bwd": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
 }
 
-ABI_VERSION = 22
+ABI_VERSION = 24
 _lib = None
 
 

@@ -48,7 +48,17 @@ struct ConvArgs {
     // writes its raw partial tile to ws[split][M][Cout]; conv_splitk_reduce_kernel sums them in order
     float *ws;
     int splits;
+    // stream-K (large-tile variant): the (tile, k-step) iteration space is cut into gridDim.x equal contiguous
+    // ranges; sk_per = iterations per workgroup, ws = [tile arrival counters | partial tiles]
+    int sk_per;
+    int w_split;   // F16: the weights are already split (zs_conv2d_presplit_weight): quads 4s+q hold the hi halves and
+                   // 4s+q+2 the lo halves of the K = 16 operand the lane half q contracts, q = 0, 1
 };
+
+// workspace layout (floats): [SK_COUNTERS ints, zero between launches][partial tiles / split-K partial sums]
+constexpr size_t WS_COUNTER_FLOATS = (size_t)1 << 18;          // 1 MiB: up to 262,144 tiles
+constexpr int SK_MAX_WGS = 1024;
+constexpr size_t WS_SPLITK_BYTES = (size_t)16 << 20;           // small-tile split-K partial sums
 
 __device__ __forceinline__ float activate(float v, int act) {
     if (act == ZS_ACT_RELU) return fmaxf(v, 0.f);
@@ -129,16 +139,32 @@ struct AQuad { f32x4 v; bool ok; };
 // exactly the eight k values the MFMA lane (row, half = kq_lo) contracts over - so it splits them
 // once into the hi / lo operand halves and stores those where the two fp32 quads went; the MFMA
 // loop then issues 3 K = 16 MFMAs per tile pair instead of 8 K = 2 ones at a quarter of the rate.
-template <bool PW, int MODE = 0, bool PLAIN = false, bool F16 = false>
+template <bool PW, int MODE = 0, bool PLAIN = false, bool F16 = false, bool SK = false>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     constexpr bool TM = MODE == 2;
     __shared__ f32x4 lds_a[2][KQ][BM];
     __shared__ f32x4 lds_b[2][KQ][BN];
+    __shared__ int sk_last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int ksteps = (a.K + BK - 1) / BK;
+    const int ntiles = a.CoutPad / BN;
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64, l32 = lane & 31, half = lane >> 5;
+    const int prow = tid & (BM - 1), kq_lo = tid >> 7;       // this thread stages row prow, k-quads kq_lo and kq_lo + 2
+    const float relu_floor = a.in_relu ? 0.f : -INFINITY;
+    const int adv_tap = BK / a.Cin, adv_c = BK % a.Cin;
+    const f32x4 *wq = reinterpret_cast<const f32x4 *>(a.w);
 
-    // this thread's two A pixels (rows tid%128 of k-quads tid/128 and tid/128 + 2)
-    const int prow = tid & (BM - 1), kq_lo = tid >> 7;
+    // stream-K: this workgroup's contiguous range of the iteration space (tile-major, n fastest, then k-steps);
+    // otherwise one tile per workgroup, all of K
+    int it = SK ? (int)blockIdx.x * a.sk_per : ((int)blockIdx.x * ntiles + (int)blockIdx.y) * ksteps;
+    const int it_begin = it;
+    const int it_end = SK ? min(it + a.sk_per, (int)(((a.M + BM - 1) / BM) * ntiles) * ksteps) : it + ksteps;
+
+    while (it < it_end) {
+    const int tile = it / ksteps, kb = it - tile * ksteps, ke = min(ksteps, kb + (it_end - it));
+    const int m0 = (tile / ntiles) * BM, n0 = (tile % ntiles) * BN;
+
+    // this thread's A pixel
     const int pix = m0 + prow;
     const bool pix_ok = pix < a.M;
     int pb = 0, py = 0, px = 0;
@@ -151,13 +177,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     const int iy0 = py * a.stride - a.pad_t, ix0 = px * a.stride - a.pad_l;
     const float *in_b = a.in + (size_t)pb * a.Hin * a.Win * a.Cin;
 
-    const float relu_floor = a.in_relu ? 0.f : -INFINITY;
-    auto load_a = [&](const TapIter &it) -> AQuad {            // 4 consecutive channels of one tap
-        const int vy = iy0 + it.ky, vx = ix0 + it.kx, sh = a.dil - 1;      // dil 1 -> 0, dil 2 -> 1
+    auto load_a = [&](const TapIter &ti) -> AQuad {            // 4 consecutive channels of one tap
+        const int vy = iy0 + ti.ky, vx = ix0 + ti.kx, sh = a.dil - 1;      // dil 1 -> 0, dil 2 -> 1
         const int iy = vy >> sh, ix = vx >> sh;
         AQuad q;
-        q.ok = pix_ok && it.ky < a.kh && vy >= 0 && iy < a.Hin && vx >= 0 && ix < a.Win && ((vy | vx) & sh) == 0;
-        const size_t off = q.ok ? ((size_t)iy * a.Win + ix) * a.Cin + it.c : 0;
+        q.ok = pix_ok && ti.ky < a.kh && vy >= 0 && iy < a.Hin && vx >= 0 && ix < a.Win && ((vy | vx) & sh) == 0;
+        const size_t off = q.ok ? ((size_t)iy * a.Win + ix) * a.Cin + ti.c : 0;
         q.v = *reinterpret_cast<const f32x4 *>(in_b + off);
         return q;
     };
@@ -167,12 +192,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
         for (int e = 0; e < 4; e++) v[e] = q.ok ? fmaxf(q.v[e], relu_floor) * a.in_scale + a.in_shift : 0.f;
         return v;
     };
-    const int adv_tap = BK / a.Cin, adv_c = BK % a.Cin;
     TapIter it0, it1;
-    it0.init(4 * kq_lo, a.Cin, a.kw);
-    it1.init(4 * (kq_lo + 2), a.Cin, a.kw);
+    if (!PW && !TM) {
+        it0.init(BK * kb + 4 * kq_lo, a.Cin, a.kw);
+        it1.init(BK * kb + 4 * (kq_lo + 2), a.Cin, a.kw);
+    }
     const float *in_pix = a.in + (size_t)(pix_ok ? pix : 0) * a.Cin;       // PW
-    int ka0 = 4 * kq_lo, ka1 = 4 * (kq_lo + 2);
+    int ka0 = BK * kb + 4 * kq_lo, ka1 = BK * kb + 4 * (kq_lo + 2);
     auto load_pw = [&](int k) -> AQuad {
         AQuad q;
         q.ok = pix_ok && k < a.K;
@@ -181,7 +207,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     };
     auto finish_pw = [&](const AQuad &q) -> f32x4 { return q.ok ? q.v : f32x4{0.f, 0.f, 0.f, 0.f}; };
     TapWalk tw;                                                             // TM
-    if (TM) tw.init(a, 0, pix_ok, iy0, ix0);
+    if (TM) tw.init(a, BK * kb, pix_ok, iy0, ix0);
     auto load_tm = [&](int kq) -> AQuad {                                   // quad kq (0..3) of the current 16-chunk
         AQuad q;
         q.ok = tw.ok;
@@ -192,7 +218,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
         if (PW || PLAIN) return finish_pw(q);
         return finish_a(q);
     };
-    const f32x4 *wq = reinterpret_cast<const f32x4 *>(a.w);
     auto load_b = [&](int kq, int n) -> f32x4 { return wq[(size_t)kq * a.CoutPad + n0 + n]; };
 
     f32x16 acc[2][2];
@@ -203,22 +228,26 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    const int ksteps = (a.K + BK - 1) / BK;
     AQuad ra[2];
     f32x4 rb[2];
     ra[0] = PW ? load_pw(ka0) : (TM ? load_tm(kq_lo) : load_a(it0));
     ra[1] = PW ? load_pw(ka1) : (TM ? load_tm(kq_lo + 2) : load_a(it1));
-    rb[0] = load_b(kq_lo, prow);
-    rb[1] = load_b(kq_lo + 2, prow);
+    rb[0] = load_b(kb * KQ + kq_lo, prow);
+    rb[1] = load_b(kb * KQ + kq_lo + 2, prow);
     auto stage = [&](int buf) {
         if (F16) {
             u32x4 hi, lo;
             zs::s16::split8(finish_any(ra[0]), finish_any(ra[1]), hi, lo);
             lds_a[buf][kq_lo][prow] = __builtin_bit_cast(f32x4, hi);
             lds_a[buf][kq_lo + 2][prow] = __builtin_bit_cast(f32x4, lo);
-            zs::s16::split8(rb[0], rb[1], hi, lo);
-            lds_b[buf][kq_lo][prow] = __builtin_bit_cast(f32x4, hi);
-            lds_b[buf][kq_lo + 2][prow] = __builtin_bit_cast(f32x4, lo);
+            if (a.w_split) {
+                lds_b[buf][kq_lo][prow] = rb[0];
+                lds_b[buf][kq_lo + 2][prow] = rb[1];
+            } else {
+                zs::s16::split8(rb[0], rb[1], hi, lo);
+                lds_b[buf][kq_lo][prow] = __builtin_bit_cast(f32x4, hi);
+                lds_b[buf][kq_lo + 2][prow] = __builtin_bit_cast(f32x4, lo);
+            }
         } else {
             lds_a[buf][kq_lo][prow] = finish_any(ra[0]);
             lds_a[buf][kq_lo + 2][prow] = finish_any(ra[1]);
@@ -229,10 +258,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     stage(0);
     __syncthreads();
 
-    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64, l32 = lane & 31, half = lane >> 5;
-    for (int ks = 0; ks < ksteps; ks++) {
-        const int cur = ks & 1;
-        const bool more = ks + 1 < ksteps;
+    for (int ks = kb; ks < ke; ks++) {
+        const int cur = (ks - kb) & 1;
+        const bool more = ks + 1 < ke;
         if (more) {
             if (PW) {
                 ka0 += BK;
@@ -285,27 +313,535 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
         __syncthreads();
     }
 
-    // epilogue: D[row = 8*(r/4) + 4*half + r%4][col = l32] per 32x32 tile
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
+    // epilogue of one 32x32 tile: D[row = 8*(r/4) + 4*half + r%4][col = l32]
+    auto epilogue = [&](int i, int j, const f32x16 &d) {
         const int n = n0 + wn + 32 * j + l32;
-        if (n >= a.Cout) continue;
+        if (n >= a.Cout) return;
         const float sc = a.scale ? a.scale[n] : 1.0f, sh = a.shift ? a.shift[n] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int m = m0 + wm + 32 * i + 8 * (r >> 2) + 4 * half + (r & 3);
+            if (m >= a.M) continue;
+            const size_t o = (size_t)m * a.Cout + n;
+            float v = d[r] * sc + sh;
+            if (a.res1) v += a.res1[o];
+            if (a.res2) v += a.res2[o];
+            a.out[o] = activate(v, a.act);
+        }
+    };
+    if (!SK || (kb == 0 && ke == ksteps)) {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) epilogue(i, j, acc[i][j]);
+    } else {
+        // A share of a tile: park the raw accumulators (slot 0 = this workgroup's first segment, slot 1 = its last),
+        // count arrivals; the workgroup that arrives last sums all shares in k order - the same sum whoever does
+        // it - and runs the epilogue.  No workgroup ever waits for another.  Shares and counters move as agent-scope
+        // relaxed atomics (sc1: written through to / read from memory, the coherence point of the eight XCDs' L2s)
+        // ordered by the store counter, so no cache-wide writeback / invalidate (what a __threadfence() costs
+        // here: 3x the whole kernel, measured) is needed.  The sum is formed in fresh registers, tile by tile: the
+        // accumulators stay in the AGPR half and the kernel keeps three workgroups per CU.
+        float *parts = a.ws + WS_COUNTER_FLOATS;
+        int *counters = reinterpret_cast<int *>(a.ws);
+        float *mine = parts + ((size_t)blockIdx.x * 2 + (it == it_begin ? 0 : 1)) * (BM * BN) + tid;
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = m0 + wm + 32 * i + 8 * (r >> 2) + 4 * half + (r & 3);
-                if (m >= a.M) continue;
-                const size_t o = (size_t)m * a.Cout + n;
-                float v = acc[i][j][r] * sc + sh;
-                if (a.res1) v += a.res1[o];
-                if (a.res2) v += a.res2[o];
-                a.out[o] = activate(v, a.act);
+            for (int j = 0; j < 2; j++) {
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    __hip_atomic_store(&mine[((i * 2 + j) * 16 + r) * 256], acc[i][j][r], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("" ::: "memory");                 // one tile's registers at a time
             }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's shares have reached memory
+        __syncthreads();
+        const int w_first = (tile * ksteps) / a.sk_per, w_last = ((tile + 1) * ksteps - 1) / a.sk_per;
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(&counters[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sk_last = old == w_last - w_first;
+            if (sk_last)                                      // ready for the next launch
+                __hip_atomic_store(&counters[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (sk_last) {
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    f32x16 d;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) d[r] = 0.f;
+#pragma unroll 1
+                    for (int w = w_first; w <= w_last; w++) {
+                        const int w_tile0 = (w * a.sk_per) / ksteps;   // the tile of w's first iteration
+                        const float *p = parts + ((size_t)w * 2 + (w_tile0 == tile ? 0 : 1)) * (BM * BN) + tid;
+#pragma unroll
+                        for (int r = 0; r < 16; r++)
+                            d[r] += __hip_atomic_load(&p[((i * 2 + j) * 16 + r) * 256], __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    epilogue(i, j, d);
+                    asm volatile("" ::: "memory");
+                }
+        }
+        __syncthreads();          // sk_last is rewritten by the next segment
+    }
+    it += ke - kb;
     }
 }
 
+
+// ---- split-fp16, LDS-DMA pipelined variant of the 128x128 tiling ----------------------------------------- //
+// The kernel above keeps one k-step of operands in flight in registers; measured (tools/prof_conv.sh, ViT fc1 at
+// batch 28) a wave spends ~2,800 cycles per step of 384 MFMA cycles waiting for those loads, three waves per SIMD
+// do not cover it (MFMA pipe 25 % busy).  Here both operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4:
+// no registers, no VALU), NS stages deep, DEPTH = NS - 1 steps ahead: A as raw fp32 quads (split into the fp16
+// halves by the consuming wave, on the LDS -> register path), B from the pre-split weights
+// (zs_conv2d_presplit_weight).  Out-of-range rows / taps read a 16-byte zero page.  Per step and wave: wait for
+// the own DMAs of this step (counted vmcnt) -> s_barrier (everybody's landed; everybody is done reading the
+// stage about to be refilled) -> issue the DMAs of step + DEPTH -> 8 ds_read_b128 -> 2 split8 -> 12 MFMAs.
+// Handles the pointwise and the tap-major (Cin % 16 == 0) geometries without input scale / shift.
+__device__ f32x4 zs_zero_page[4];
+
+constexpr int DMA_STAGE_BYTES = (BM + BN) * BK * 4;          // A: 4 quads x 128 rows x 16 B, then B the same
+
+__device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst) {   // 64 lanes x 16 B -> LDS[dst + 16 lane]
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm_then_barrier() {       // all but the N youngest vector-memory operations done
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"(N) : "memory");
+}
+
+// DMA_NS stages of 16 KiB: 3 -> three workgroups per CU, two steps of lead.  (9 stages, one workgroup per CU, eight
+// steps of lead measured SLOWER - 632 vs 471 us on the 3x3 layer: the limit is the rate of the stream, not its latency.)
+template <bool PW, bool RELU, bool SK, int DMA_NS>
+__global__ __launch_bounds__(256) void conv_gemm_dma_kernel(ConvArgs a) {
+    constexpr int DMA_DEPTH = DMA_NS - 1;
+    __shared__ f32x4 lds[DMA_NS][2][KQ][BM];                  // [stage][A | B][k-quad][row]
+    __shared__ int sk_last;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) f32x4 *)&lds[0][0][0][0]);
+    const int ksteps = (a.K + BK - 1) / BK;
+    const int ntiles = a.CoutPad / BN;
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64, l32 = lane & 31, half = lane >> 5;
+    const char *zero = reinterpret_cast<const char *>(zs_zero_page);
+    const f32x4 *wq = reinterpret_cast<const f32x4 *>(a.w);
+
+    int it = SK ? (int)blockIdx.x * a.sk_per : ((int)blockIdx.x * ntiles + (int)blockIdx.y) * ksteps;
+    const int it_begin = it;
+    const int it_end = SK ? min(it + a.sk_per, (int)(((a.M + BM - 1) / BM) * ntiles) * ksteps) : it + ksteps;
+
+    while (it < it_end) {
+    const int tile = it / ksteps, kb = it - tile * ksteps, ke = min(ksteps, kb + (it_end - it));
+    const int m0 = (tile / ntiles) * BM, n0 = (tile % ntiles) * BN;
+
+    // this wave stages k-quad `wave` of every step: A rows lane and lane + 64, B columns lane and lane + 64
+    TapWalk tw[2];
+    const float *src[2];                                      // PW: the pixel's row; TM: the image
+    bool pok[2];
+    int iy0[2], ix0[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int pix = m0 + lane + 64 * h;
+        pok[h] = pix < a.M;
+        if (PW) {
+            src[h] = a.in + (size_t)(pok[h] ? pix : 0) * a.Cin;
+        } else {
+            int pb = 0, py = 0, px = 0;
+            if (pok[h]) {
+                pb = pix / (a.Hout * a.Wout);
+                const int rem = pix - pb * a.Hout * a.Wout;
+                py = rem / a.Wout;
+                px = rem - py * a.Wout;
+            }
+            iy0[h] = py * a.stride - a.pad_t;
+            ix0[h] = px * a.stride - a.pad_l;
+            src[h] = a.in + (size_t)pb * a.Hin * a.Win * a.Cin;
+            tw[h].init(a, BK * kb, pok[h], iy0[h], ix0[h]);
+        }
+    }
+    const f32x4 *wcol = wq + n0 + lane;
+    int ks_issue = kb;                                        // next step to stage
+    auto issue = [&]() {                                      // 4 DMAs: A rows x 2, B columns x 2 (k-quad = wave)
+        const int st = (ks_issue - kb) % DMA_NS;
+        const unsigned dst = lds_base + st * DMA_STAGE_BYTES + wave * (BM * 16);
+        const bool live = ks_issue < ke;                      // past the end: keep the vmcnt arithmetic, fetch zeros
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const char *g;
+            if (PW) {
+                const int k = BK * ks_issue + 4 * wave;
+                g = (live && pok[h] && k < a.K) ? reinterpret_cast<const char *>(src[h] + k) : zero;
+            } else {
+                g = (live && tw[h].ok) ? reinterpret_cast<const char *>(src[h] + tw[h].base + tw[h].cc + 4 * wave) : zero;
+                if (live) tw[h].advance(a, BK, pok[h], iy0[h], ix0[h]);
+            }
+#ifndef ZS_EXP_CONV_NO_DMA
+            dma16(g, dst + h * 1024);
+#endif
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const char *g = live ? reinterpret_cast<const char *>(wcol + (size_t)(ks_issue * KQ + wave) * a.CoutPad + 64 * h) : zero;
+#ifndef ZS_EXP_CONV_NO_DMA
+            dma16(g, dst + KQ * BM * 16 + h * 1024);
+#endif
+        }
+        ks_issue++;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    // everybody is done with the stages (previous segment's reads) before they are refilled
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int d = 0; d < DMA_DEPTH; d++) issue();
+
+    const float relu_floor = RELU ? 0.f : -INFINITY;
+    for (int ks = kb; ks < ke; ks++) {
+        static_assert(4 * (DMA_DEPTH - 1) < 64, "vmcnt is a 6-bit counter");
+        wait_vm_then_barrier<4 * (DMA_DEPTH - 1)>();          // the younger steps' DMAs (4 each) may stay in flight
+        issue();
+        const int st = (ks - kb) % DMA_NS;
+        u32x4 ah[2], al[2], bh[2], bl[2];
+        f32x4 fa[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            fa[i][0] = lds[st][0][half][wm + 32 * i + l32];
+            fa[i][1] = lds[st][0][half + 2][wm + 32 * i + l32];
+            bh[i] = __builtin_bit_cast(u32x4, lds[st][1][half][wn + 32 * i + l32]);
+            bl[i] = __builtin_bit_cast(u32x4, lds[st][1][half + 2][wn + 32 * i + l32]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            if (RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    fa[i][0][e] = fmaxf(fa[i][0][e], relu_floor);
+                    fa[i][1][e] = fmaxf(fa[i][1][e], relu_floor);
+                }
+            }
+#ifdef ZS_EXP_CONV_NO_SPLIT
+            ah[i] = __builtin_bit_cast(u32x4, fa[i][0]);
+            al[i] = __builtin_bit_cast(u32x4, fa[i][1]);
+#else
+            zs::s16::split8(fa[i][0], fa[i][1], ah[i], al[i]);
+#endif
+        }
+#ifdef ZS_EXP_CONV_NO_MFMA
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[i][j][e] += __builtin_bit_cast(float, ah[i][e] ^ al[i][e] ^ bh[j][e] ^ bl[j][e]);
+#else
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) zs::s16::mfma3(acc[i][j], ah[i], al[i], bh[j], bl[j]);
+#endif
+    }
+
+    auto epilogue = [&](int i, int j, const f32x16 &d) {
+        const int n = n0 + wn + 32 * j + l32;
+        if (n >= a.Cout) return;
+        const float sc = a.scale ? a.scale[n] : 1.0f, sh = a.shift ? a.shift[n] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int m = m0 + wm + 32 * i + 8 * (r >> 2) + 4 * half + (r & 3);
+            if (m >= a.M) continue;
+            const size_t o = (size_t)m * a.Cout + n;
+            float v = d[r] * sc + sh;
+            if (a.res1) v += a.res1[o];
+            if (a.res2) v += a.res2[o];
+            a.out[o] = activate(v, a.act);
+        }
+    };
+    if (!SK || (kb == 0 && ke == ksteps)) {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) epilogue(i, j, acc[i][j]);
+    } else {   // a share of a tile: see conv_gemm_kernel
+        float *parts = a.ws + WS_COUNTER_FLOATS;
+        int *counters = reinterpret_cast<int *>(a.ws);
+        float *mine = parts + ((size_t)blockIdx.x * 2 + (it == it_begin ? 0 : 1)) * (BM * BN) + tid;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    __hip_atomic_store(&mine[((i * 2 + j) * 16 + r) * 256], acc[i][j][r], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("" ::: "memory");
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int w_first = (tile * ksteps) / a.sk_per, w_last = ((tile + 1) * ksteps - 1) / a.sk_per;
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(&counters[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sk_last = old == w_last - w_first;
+            if (sk_last) __hip_atomic_store(&counters[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (sk_last) {
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    f32x16 d;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) d[r] = 0.f;
+#pragma unroll 1
+                    for (int w = w_first; w <= w_last; w++) {
+                        const int w_tile0 = (w * a.sk_per) / ksteps;
+                        const float *p = parts + ((size_t)w * 2 + (w_tile0 == tile ? 0 : 1)) * (BM * BN) + tid;
+#pragma unroll
+                        for (int r = 0; r < 16; r++)
+                            d[r] += __hip_atomic_load(&p[((i * 2 + j) * 16 + r) * 256], __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    epilogue(i, j, d);
+                    asm volatile("" ::: "memory");
+                }
+        }
+        __syncthreads();
+    }
+    it += ke - kb;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the zero-page DMAs issued past the end
+}
+
+// ---- 256 x 256 tiles, eight waves, stream-K: the variant for large layers ------------------------------------ //
+// tools/conv_abl.sh: with the DMAs removed the 128 x 128 kernel above runs 2.6x faster (3x3 256 -> 256 at 56 x 56 x
+// 28: 186 vs 490 us) - it is bound by the bytes it moves from L2 into LDS (1 KiB per k for 128 x 128 outputs, ~9 TB/s
+// in aggregate), not by latency or the matrix pipe.  A 256 x 256 tile moves half the bytes per MFMA.  One workgroup
+// of eight waves per CU (wave tile 64 x 128, two waves per SIMD), four 32 KiB stages, three steps of lead, always
+// as stream-K over 256 persistent workgroups (with 256 slots every layer shape would otherwise round up badly).
+constexpr int TM2 = 256, TN2 = 256, NS2 = 4, DEPTH2 = NS2 - 1;
+constexpr int STAGE2_BYTES = (TM2 + TN2) * BK * 4;           // 32 KiB: A [4 quads][256 rows][16 B], then B the same
+
+template <bool PW, bool RELU>
+__global__ __launch_bounds__(512) void conv_gemm_dma256_kernel(ConvArgs a) {
+    __shared__ f32x4 lds[NS2][2][KQ][TM2];
+    __shared__ int sk_last;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) f32x4 *)&lds[0][0][0][0]);
+    const int ksteps = (a.K + BK - 1) / BK;
+    const int ntiles = (a.CoutPad + TN2 - 1) / TN2;
+    const int wm = (wave & 3) * 64, wn = (wave >> 2) * 128, l32 = lane & 31, half = lane >> 5;
+    const int kq_w = wave & 3, blk_w = wave >> 2;              // this wave stages k-quad kq_w of row / column block blk_w
+    const char *zero = reinterpret_cast<const char *>(zs_zero_page);
+    const f32x4 *wq = reinterpret_cast<const f32x4 *>(a.w);
+
+    // workgroups are dealt to the eight XCDs round-robin: give each XCD one contiguous eighth of the iteration space
+    // (neighbouring tiles share A rows / B columns through that XCD's own L2)
+#ifdef ZS_EXP_CONV_NO_XCD_MAP
+    const int wg = (int)blockIdx.x;
+#else
+    const int wg = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+#endif
+    int it = wg * a.sk_per;
+    const int it_begin = it;
+    const int it_end = min(it + a.sk_per, (int)(((a.M + TM2 - 1) / TM2) * ntiles) * ksteps);
+
+    while (it < it_end) {
+    const int tile = it / ksteps, kb = it - tile * ksteps, ke = min(ksteps, kb + (it_end - it));
+    const int m0 = (tile / ntiles) * TM2, n0 = (tile % ntiles) * TN2;
+
+    TapWalk tw[2];
+    const float *src[2];
+    bool pok[2], nok[2];
+    int iy0[2], ix0[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int pix = m0 + blk_w * 128 + 64 * h + lane;
+        pok[h] = pix < a.M;
+        nok[h] = n0 + blk_w * 128 + 64 * h + lane < a.CoutPad;
+        if (PW) {
+            src[h] = a.in + (size_t)(pok[h] ? pix : 0) * a.Cin;
+        } else {
+            int pb = 0, py = 0, px = 0;
+            if (pok[h]) {
+                pb = pix / (a.Hout * a.Wout);
+                const int rem = pix - pb * a.Hout * a.Wout;
+                py = rem / a.Wout;
+                px = rem - py * a.Wout;
+            }
+            iy0[h] = py * a.stride - a.pad_t;
+            ix0[h] = px * a.stride - a.pad_l;
+            src[h] = a.in + (size_t)pb * a.Hin * a.Win * a.Cin;
+            tw[h].init(a, BK * kb, pok[h], iy0[h], ix0[h]);
+        }
+    }
+    const f32x4 *wcol = wq + n0 + blk_w * 128 + lane;
+    int ks_issue = kb;
+    auto issue = [&]() {                                      // 4 DMAs per wave: A rows x 2, B columns x 2
+        const int st = (ks_issue - kb) % NS2;
+        const unsigned dst = lds_base + st * STAGE2_BYTES + (kq_w * TM2 + blk_w * 128) * 16;
+        const bool live = ks_issue < ke;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const char *g;
+            if (PW) {
+                const int k = BK * ks_issue + 4 * kq_w;
+                g = (live && pok[h] && k < a.K) ? reinterpret_cast<const char *>(src[h] + k) : zero;
+            } else {
+                g = (live && tw[h].ok) ? reinterpret_cast<const char *>(src[h] + tw[h].base + tw[h].cc + 4 * kq_w) : zero;
+                if (live) tw[h].advance(a, BK, pok[h], iy0[h], ix0[h]);
+            }
+#ifndef ZS_EXP_CONV_NO_DMA
+            dma16(g, dst + h * 1024);
+#endif
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const char *g = (live && nok[h]) ? reinterpret_cast<const char *>(wcol + (size_t)(ks_issue * KQ + kq_w) * a.CoutPad + 64 * h) : zero;
+#ifndef ZS_EXP_CONV_NO_DMA
+            dma16(g, dst + KQ * TM2 * 16 + h * 1024);
+#endif
+        }
+        ks_issue++;
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int d = 0; d < DEPTH2; d++) issue();
+
+    for (int ks = kb; ks < ke; ks++) {
+        wait_vm_then_barrier<4 * (DEPTH2 - 1)>();
+        issue();
+        const int st = (ks - kb) % NS2;
+        u32x4 ah[2], al[2], bh[4], bl[4];
+        f32x4 fa[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            fa[i][0] = lds[st][0][half][wm + 32 * i + l32];
+            fa[i][1] = lds[st][0][half + 2][wm + 32 * i + l32];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            bh[j] = __builtin_bit_cast(u32x4, lds[st][1][half][wn + 32 * j + l32]);
+            bl[j] = __builtin_bit_cast(u32x4, lds[st][1][half + 2][wn + 32 * j + l32]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            if (RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    fa[i][0][e] = fmaxf(fa[i][0][e], 0.f);
+                    fa[i][1][e] = fmaxf(fa[i][1][e], 0.f);
+                }
+            }
+            zs::s16::split8(fa[i][0], fa[i][1], ah[i], al[i]);
+        }
+#ifdef ZS_EXP_CONV_NO_MFMA
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[i][j][e] += __builtin_bit_cast(float, ah[i][e] ^ al[i][e] ^ bh[j][e] ^ bl[j][e]);
+#else
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) zs::s16::mfma3(acc[i][j], ah[i], al[i], bh[j], bl[j]);
+#endif
+    }
+
+    auto epilogue = [&](int i, int j, const f32x16 &d) {
+        const int n = n0 + wn + 32 * j + l32;
+        if (n >= a.Cout) return;
+        const float sc = a.scale ? a.scale[n] : 1.0f, sh = a.shift ? a.shift[n] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int m = m0 + wm + 32 * i + 8 * (r >> 2) + 4 * half + (r & 3);
+            if (m >= a.M) continue;
+            const size_t o = (size_t)m * a.Cout + n;
+            float v = d[r] * sc + sh;
+            if (a.res1) v += a.res1[o];
+            if (a.res2) v += a.res2[o];
+            a.out[o] = activate(v, a.act);
+        }
+    };
+    if (kb == 0 && ke == ksteps) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) epilogue(i, j, acc[i][j]);
+    } else {   // a share of a tile: see conv_gemm_kernel
+        float *parts = a.ws + WS_COUNTER_FLOATS;
+        int *counters = reinterpret_cast<int *>(a.ws);
+        float *mine = parts + ((size_t)wg * 2 + (it == it_begin ? 0 : 1)) * (TM2 * TN2) + tid;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    __hip_atomic_store(&mine[((i * 4 + j) * 16 + r) * 512], acc[i][j][r], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("" ::: "memory");
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int w_first = (tile * ksteps) / a.sk_per, w_last = ((tile + 1) * ksteps - 1) / a.sk_per;
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(&counters[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sk_last = old == w_last - w_first;
+            if (sk_last) __hip_atomic_store(&counters[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (sk_last) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    f32x16 d;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) d[r] = 0.f;
+#pragma unroll 1
+                    for (int w = w_first; w <= w_last; w++) {
+                        const int w_tile0 = (w * a.sk_per) / ksteps;
+                        const float *p = parts + ((size_t)w * 2 + (w_tile0 == tile ? 0 : 1)) * (TM2 * TN2) + tid;
+#pragma unroll
+                        for (int r = 0; r < 16; r++)
+                            d[r] += __hip_atomic_load(&p[((i * 4 + j) * 16 + r) * 512], __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    epilogue(i, j, d);
+                    asm volatile("" ::: "memory");
+                }
+        }
+        __syncthreads();
+    }
+    it += ke - kb;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 
 // ---- small-problem variant: many small tiles, K split across the four waves ----
 // The 128x128 tiling needs >= ~256 tiles to fill 256 CUs; a 14x14 feature map or a 197-token
@@ -352,8 +888,9 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
 
     const int T = (a.K + BK - 1) / BK * 2;                 // t-steps of 8 k (= 2 weight quads)
     // this workgroup's share of K (all of it unless split across workgroups), then a quarter per wave
-    const int tsplit = (T + a.splits - 1) / a.splits, ts0 = blockIdx.z * tsplit, ts1 = min(T, ts0 + tsplit);
-    const int per = (max(ts1 - ts0, 0) + 3) / 4, t_begin = ts0 + wave * per, t_end = min(ts1, t_begin + per);
+    // (ranges start at even t: a pair of t-steps is one K = 16 operand, and pre-split weights are stored per pair)
+    const int tsplit = ((T + a.splits - 1) / a.splits + 1) & ~1, ts0 = blockIdx.z * tsplit, ts1 = min(T, ts0 + tsplit);
+    const int per = ((max(ts1 - ts0, 0) + 3) / 4 + 1) & ~1, t_begin = ts0 + wave * per, t_end = min(ts1, t_begin + per);
     f32x16 acc[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; j++)
@@ -413,7 +950,12 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < NJ; j++) {
                     u32x4 bh, bl;
-                    zs::s16::split8(fb[buf][u][j], fb[buf][u + 1][j], bh, bl);
+                    if (a.w_split) {
+                        bh = __builtin_bit_cast(u32x4, fb[buf][u][j]);
+                        bl = __builtin_bit_cast(u32x4, fb[buf][u + 1][j]);
+                    } else {
+                        zs::s16::split8(fb[buf][u][j], fb[buf][u + 1][j], bh, bl);
+                    }
                     zs::s16::mfma3(acc[j], ah, al, bh, bl);
                 }
             }
@@ -450,7 +992,7 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
         float v = (part[0][row][col] + part[1][row][col]) + (part[2][row][col] + part[3][row][col]);
         const size_t o = (size_t)m * a.Cout + n;
         if (a.splits > 1) {       // raw partial; the epilogue runs in conv_splitk_reduce_kernel
-            a.ws[(size_t)blockIdx.z * a.M * a.Cout + o] = v;
+            a.ws[WS_COUNTER_FLOATS + (size_t)blockIdx.z * a.M * a.Cout + o] = v;
             continue;
         }
         v = v * (a.scale ? a.scale[n] : 1.0f) + (a.shift ? a.shift[n] : 0.0f);
@@ -460,13 +1002,28 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
     }
 }
 
+// fp32 packed weights [K16/4][CoutPad][4] -> the same shape with, per K = 16 step s and lane half q, the hi halves of
+// the eight k values {4q..4q+3, 4q+8..4q+11} in quad 4s+q and their lo halves in quad 4s+q+2 (what the F16 kernels
+// otherwise compute from the fp32 quads on every use)
+__global__ __launch_bounds__(256) void presplit_weight_kernel(const f32x4 *__restrict__ w, f32x4 *__restrict__ out,
+                                                              size_t pairs, int CoutPad) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;         // (s, q, n)
+    if (i >= pairs) return;
+    const size_t n = i % CoutPad, q = (i / CoutPad) & 1, s = i / CoutPad / 2;
+    u32x4 hi, lo;
+    zs::s16::split8(w[(4 * s + q) * CoutPad + n], w[(4 * s + q + 2) * CoutPad + n], hi, lo);
+    out[(4 * s + q) * CoutPad + n] = __builtin_bit_cast(f32x4, hi);
+    out[(4 * s + q + 2) * CoutPad + n] = __builtin_bit_cast(f32x4, lo);
+}
+
 // out = epilogue(sum over the splits, in split order: deterministic)
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs a) {
     const size_t total = (size_t)a.M * a.Cout;
     for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
         const int n = (int)(o % a.Cout);
-        float v = a.ws[o];
-        for (int sp = 1; sp < a.splits; sp++) v += a.ws[(size_t)sp * total + o];
+        const float *ws = a.ws + WS_COUNTER_FLOATS;
+        float v = ws[o];
+        for (int sp = 1; sp < a.splits; sp++) v += ws[(size_t)sp * total + o];
         v = v * (a.scale ? a.scale[n] : 1.0f) + (a.shift ? a.shift[n] : 0.0f);
         if (a.res1) v += a.res1[o];
         if (a.res2) v += a.res2[o];
@@ -476,7 +1033,10 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs a) {
 
 }  // namespace
 
-extern "C" size_t zs_conv2d_splitk_workspace_bytes(void) { return (size_t)16 << 20; }
+extern "C" size_t zs_conv2d_splitk_workspace_bytes(void) {
+    const size_t parts = (size_t)SK_MAX_WGS * 2 * BM * BN * 4;
+    return WS_COUNTER_FLOATS * 4 + (parts > WS_SPLITK_BYTES ? parts : WS_SPLITK_BYTES);
+}
 
 extern "C" int zs_conv2d_nhwc(const float *in, const float *packed_w, const float *scale, const float *shift,
                               const float *res1, const float *res2, float *out, int batch, int Hin, int Win,
@@ -512,6 +1072,9 @@ extern "C" int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const f
     a.dil = (flags & ZS_CONV_IN_DILATE2) ? 2 : 1;
     a.ws = static_cast<float *>(workspace);
     a.splits = 1;
+    a.sk_per = 0;
+    a.w_split = (flags & ZS_CONV_W_PRESPLIT) ? 1 : 0;
+    if (a.w_split && !(flags & ZS_CONV_F16X3)) { zs::set_err("zs_conv2d_nhwc: ZS_CONV_W_PRESPLIT needs ZS_CONV_F16X3"); return 0; }
     // fewer than ~3/4 of a wave of 128x128 tiles over the 256 CUs: use the small-tile split-K variant
     const long long big_tiles = ((M + BM - 1) / BM) * (a.CoutPad / BN);
     static const long long big_min = getenv("ZS_CONV_BIG_MIN") ? atoll(getenv("ZS_CONV_BIG_MIN")) : 192;
@@ -534,6 +1097,13 @@ extern "C" int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const f
         if (f16) ZS_LAUNCH1(KERNEL, true, __VA_ARGS__);   \
         else ZS_LAUNCH1(KERNEL, false, __VA_ARGS__);      \
     } while (0)
+#define ZS_LAUNCH_BIG(F, SKF)                                                                                              \
+    do {                                                                                                                   \
+        if (pw) hipLaunchKernelGGL((conv_gemm_kernel<true, 0, false, F, SKF>), grid, dim3(256), 0, st, a);                  \
+        else if (tm && plain) hipLaunchKernelGGL((conv_gemm_kernel<false, 2, true, F, SKF>), grid, dim3(256), 0, st, a);    \
+        else if (tm) hipLaunchKernelGGL((conv_gemm_kernel<false, 2, false, F, SKF>), grid, dim3(256), 0, st, a);            \
+        else hipLaunchKernelGGL((conv_gemm_kernel<false, 0, false, F, SKF>), grid, dim3(256), 0, st, a);                    \
+    } while (0)
     if (small) {
         static const long long narrow_below = getenv("ZS_CONV_NARROW_BELOW") ? atoll(getenv("ZS_CONV_NARROW_BELOW")) : 384;
         const long long wide = ((M + SM - 1) / SM) * ((Cout + 63) / 64);
@@ -544,12 +1114,12 @@ extern "C" int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const f
         // 197-token matrices at batch 1: 28-84 workgroups): ~512 workgroups, >= 16 t-steps (K = 128) per
         // split, partial tiles inside the caller's workspace (zs_conv2d_splitk_workspace_bytes()).
         static const int split_target = getenv("ZS_CONV_SPLIT_TARGET") ? atoi(getenv("ZS_CONV_SPLIT_TARGET")) : 512;
-        if (workspace && wgs < 256) {
+        if (workspace && (flags & ZS_CONV_SPLIT_SMALL) && wgs < 256) {
             const int T = (a.K + BK - 1) / BK * 2;
             long long sp = (split_target + wgs - 1) / wgs;
             if (sp > T / 16) sp = T / 16;
             if (sp > 16) sp = 16;
-            const long long cap = (long long)(zs_conv2d_splitk_workspace_bytes() / 4) / (M * (long long)Cout);
+            const long long cap = (long long)(WS_SPLITK_BYTES / 4) / (M * (long long)Cout);
             if (sp > cap) sp = cap;
             if (sp > 1) a.splits = (int)sp;
         }
@@ -566,13 +1136,80 @@ extern "C" int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const f
             hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
         }
     } else {
-        const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(a.CoutPad / BN));
         const bool tm = !pw && !no_tm && (Cin % BK) == 0;
-        ZS_LAUNCH(conv_gemm_kernel, );
+        // Stream-K (ZS_CONV_STREAM_K + a workspace): a fixed number of workgroups share the (tile, k-step) space
+        // evenly, so a layer whose tile count is 1.03 x the number of CUs (ViT fc2 / proj at batch 28: 264 tiles)
+        // does not run a second, almost empty round.  Whole multiples of the machine keep one tile per workgroup.
+        static const int sk_wgs = getenv("ZS_CONV_SK_WGS") ? atoi(getenv("ZS_CONV_SK_WGS")) : 512;
+        const long long ksteps = (a.K + BK - 1) / BK, iters = big_tiles * ksteps;
+        // (for the 128 x 128 kernels only where one round would leave most of the 768 slots empty and K is long:
+        // elsewhere the kernels are bound by the bytes they move, a short last round runs faster, and the exchange of
+        // shares costs more than the balance gains - measured, tools/conv_ns.sh)
+        static const bool sk_env = getenv("ZS_CONV_SK_ALWAYS") != nullptr;
+        const bool sk_always = sk_env || (flags & ZS_CONV_STREAM_K_ALWAYS);
+        const bool sk = workspace && (flags & ZS_CONV_STREAM_K) && sk_wgs >= 1 && sk_wgs <= SK_MAX_WGS &&
+                        big_tiles <= (long long)WS_COUNTER_FLOATS && iters < (1LL << 30) && iters >= 4LL * sk_wgs &&
+                        (sk_always || (big_tiles * 2 <= sk_wgs && ksteps >= 128));
+        // split-fp16 with pre-split weights, pointwise or tap-major geometry, no input scale / shift: the LDS-DMA
+        // pipelined kernel (ZS_CONV_NO_DMA=1: the register-staged one, for A/B measurements)
+        static const bool no_dma = getenv("ZS_CONV_NO_DMA") != nullptr;
+        const bool dma = f16 && a.w_split && !no_dma && (pw || tm) && in_scale == 1.0f && in_shift == 0.0f && (Cin % BK) == 0;
+#define ZS_LAUNCH_DMA1(SKF, NS)                                                                                     \
+    do {                                                                                                            \
+        if (pw) hipLaunchKernelGGL((conv_gemm_dma_kernel<true, false, SKF, NS>), grid, dim3(256), 0, st, a);         \
+        else if (a.in_relu) hipLaunchKernelGGL((conv_gemm_dma_kernel<false, true, SKF, NS>), grid, dim3(256), 0, st, a); \
+        else hipLaunchKernelGGL((conv_gemm_dma_kernel<false, false, SKF, NS>), grid, dim3(256), 0, st, a);           \
+    } while (0)
+#define ZS_LAUNCH_DMA(SKF) ZS_LAUNCH_DMA1(SKF, 3)
+        // 256 x 256 tiles over 256 persistent workgroups (layers with >= 192 output channels): OPT-IN
+        // (ZS_CONV_256_MIN_KSTEPS=128 selects it for K >= 2048).  Run back to back on hot caches it beats the
+        // 128 x 128 kernel on the long contractions (tools/conv_ns.sh, batch 28: ViT fc2 152 vs 177 us, 3x3 256 -> 256
+        // at 56 x 56 419 vs 476 us; fc1 158 vs 142, proj 95 vs 57: the exchange of 256 KiB tile shares), but inside
+        // the encoder, where every layer's input has just been written, it loses everywhere (tools/conv_shapes.py:
+        // fc2 242 vs 195 us, the 3x3 462 vs 424 us): one workgroup per CU has a third of the loads in flight.
+        static const bool no_256 = getenv("ZS_CONV_NO_256") != nullptr;
+        static const long long min_ksteps_256 = getenv("ZS_CONV_256_MIN_KSTEPS") ? atoll(getenv("ZS_CONV_256_MIN_KSTEPS")) : (1LL << 40);
+        const long long tiles2 = ((M + TM2 - 1) / TM2) * ((a.CoutPad + TN2 - 1) / TN2), iters2 = tiles2 * ksteps;
+        if (dma && workspace && (flags & ZS_CONV_STREAM_K) && !no_256 && Cout >= 192 && (ksteps >= min_ksteps_256 || sk_always) && iters2 >= 8LL * 256 &&
+            iters2 < (1LL << 30) && tiles2 <= (long long)WS_COUNTER_FLOATS) {
+            a.sk_per = (int)((iters2 + 255) / 256);
+            const dim3 grid((unsigned)((iters2 + a.sk_per - 1) / a.sk_per));
+            if (pw) hipLaunchKernelGGL((conv_gemm_dma256_kernel<true, false>), grid, dim3(512), 0, st, a);
+            else if (a.in_relu) hipLaunchKernelGGL((conv_gemm_dma256_kernel<false, true>), grid, dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((conv_gemm_dma256_kernel<false, false>), grid, dim3(512), 0, st, a);
+        } else if (sk) {
+            a.sk_per = (int)((iters + sk_wgs - 1) / sk_wgs);
+            const dim3 grid((unsigned)((iters + a.sk_per - 1) / a.sk_per));
+            if (dma) ZS_LAUNCH_DMA(true);
+            else if (f16) ZS_LAUNCH_BIG(true, true);
+            else ZS_LAUNCH_BIG(false, true);
+        } else {
+            const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(a.CoutPad / BN));
+            if (dma) ZS_LAUNCH_DMA(false);
+            else if (f16) ZS_LAUNCH_BIG(true, false);
+            else ZS_LAUNCH_BIG(false, false);
+        }
+#undef ZS_LAUNCH_DMA
+#undef ZS_LAUNCH_DMA1
     }
+#undef ZS_LAUNCH_BIG
 #undef ZS_LAUNCH
 #undef ZS_LAUNCH1
     return zs::check_launch("zs_conv2d_nhwc") ? 1 : 0;
+}
+
+extern "C" int zs_conv2d_presplit_weight(const float *packed_w, float *split_w, int Cin, int Cout, int kh, int kw,
+                                         void *stream) {
+    if (!packed_w || !split_w || packed_w == split_w || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0) {
+        zs::set_err("zs_conv2d_presplit_weight: bad arguments");
+        return 0;
+    }
+    const size_t K16 = ((size_t)kh * kw * Cin + BK - 1) / BK * BK, CoutPad = ((size_t)Cout + BN - 1) / BN * BN;
+    const size_t pairs = K16 / BK * 2 * CoutPad;
+    hipLaunchKernelGGL(presplit_weight_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), reinterpret_cast<const f32x4 *>(packed_w),
+                       reinterpret_cast<f32x4 *>(split_w), pairs, (int)CoutPad);
+    return zs::check_launch("zs_conv2d_presplit_weight") ? 1 : 0;
 }
 
 extern "C" size_t zs_conv2d_packed_floats(int Cin, int Cout, int kh, int kw) {

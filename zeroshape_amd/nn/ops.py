@@ -30,6 +30,17 @@ CONV_PRECISION = os.environ.get("ZS_ENCODER_PRECISION", "f16x3")
 # the pointwise ones stay at 11.5 us (bound by their dependent first loads, not by workgroup count) and the
 # reduction kernel costs 4.5 us per layer: 4.65 vs 4.37 ms of kernel time per forward.  ZS_CONV_SPLIT_K=1 enables it.
 SPLIT_K = os.environ.get("ZS_CONV_SPLIT_K", "0") != "0"
+# Stream-K for the large-tile launches (ZS_CONV_STREAM_K): a fixed number of workgroups share the (tile, k-step)
+# space evenly instead of one tile each.  Built, tested (test_conv2d_stream_k) and OFF by default: measured inside the
+# batch-28 encoder (tools/conv_shapes.py) the large-tile kernels are bound by the bytes they pull into LDS, a short
+# last round simply runs faster, and the exchange of tile shares costs more than the balance gains (22.9 vs 20.6 ms
+# of convolution time with it everywhere).  ZS_CONV_STREAM_K=1 enables the kernel's own shape rule,
+# "always" (tests) forces it wherever supported.
+STREAM_K = {"0": False, "1": True, "always": "always"}[os.environ.get("ZS_CONV_STREAM_K", "0")]
+_CONV_SPLIT_SMALL, _CONV_STREAM_K, _CONV_W_PRESPLIT, _CONV_STREAM_K_ALWAYS = 32, 64, 128, 256
+# f16x3: the weights' fp16 halves are computed once per layer (zs_conv2d_presplit_weight) instead of in every
+# workgroup of every launch.  ZS_CONV_PRESPLIT=0: split at run time (A/B measurements).
+PRESPLIT = os.environ.get("ZS_CONV_PRESPLIT", "1") != "0"
 
 
 def set_conv_precision(p):
@@ -43,13 +54,20 @@ _SPLITK_WS = {}
 
 
 def splitk_workspace(device):
-    """Per-device scratch for the split-K partial tiles of zs_conv2d_nhwc_ws (fixed size and address:
-    a captured hipGraph bakes the pointer in; launches on one stream serialise, so sharing is safe)."""
+    """Per-device scratch of zs_conv2d_nhwc_ws: arrival counters (zeroed here once, left at zero by every launch)
+    + partial tiles.  Fixed size and address: a captured hipGraph bakes the pointer in (the warm-up runs of
+    nn.capture allocate it before the capture starts).  Launches on one stream serialise, so sharing it is safe;
+    two streams running convolutions on one device at the same time would need one each."""
     key = str(device)
     if key not in _SPLITK_WS:
-        _SPLITK_WS[key] = torch.empty(_lib.load().zs_conv2d_splitk_workspace_bytes() // 4, dtype=torch.float32,
+        _SPLITK_WS[key] = torch.zeros(_lib.load().zs_conv2d_splitk_workspace_bytes() // 4, dtype=torch.float32,
                                       device=device)
     return _SPLITK_WS[key]
+
+
+def conv_flags():
+    return (16 if CONV_PRECISION == "f16x3" else 0) | (_CONV_SPLIT_SMALL if SPLIT_K else 0) | \
+        (_CONV_STREAM_K if STREAM_K else 0) | (_CONV_STREAM_K_ALWAYS if STREAM_K == "always" else 0)
 
 
 def conv2d(x, pc, res1=None, res2=None, act=ACT_NONE, in_relu=False, in_scale=1.0, in_shift=0.0, tiling=None):
@@ -66,13 +84,21 @@ def conv2d(x, pc, res1=None, res2=None, act=ACT_NONE, in_relu=False, in_scale=1.
         if r is not None:
             _chk(r, "conv2d residual")
             assert r.shape == out.shape
+    flags = (1 if in_relu else 0) | _TILING[tiling] | conv_flags()
+    w = pc.w
+    if PRESPLIT and CONV_PRECISION == "f16x3":
+        if pc.w16 is None:
+            pc.w16 = torch.empty_like(pc.w)
+            with torch.cuda.device(x.device):
+                _lib.check(lib.zs_conv2d_presplit_weight(_lib.ptr(pc.w), _lib.ptr(pc.w16), C, pc.cout, pc.kh, pc.kw,
+                                                         _stream(x)), "zs_conv2d_presplit_weight")
+        w, flags = pc.w16, flags | _CONV_W_PRESPLIT
     with torch.cuda.device(x.device):
-        _lib.check(lib.zs_conv2d_nhwc_ws(_lib.ptr(x), _lib.ptr(pc.w), _lib.ptr(pc.scale), _lib.ptr(pc.shift),
+        _lib.check(lib.zs_conv2d_nhwc_ws(_lib.ptr(x), _lib.ptr(w), _lib.ptr(pc.scale), _lib.ptr(pc.shift),
                                          _lib.ptr(res1), _lib.ptr(res2), _lib.ptr(out), B, H, W, C, Ho, Wo, pc.cout,
                                          pc.kh, pc.kw, pc.stride, pt, pl,
-                                         (1 if in_relu else 0) | _TILING[tiling] | (16 if CONV_PRECISION == "f16x3" else 0),
-                                         float(in_scale), float(in_shift), act,
-                                         _lib.ptr(splitk_workspace(x.device)) if SPLIT_K else None, _stream(x)),
+                                         flags, float(in_scale), float(in_shift), act,
+                                         _lib.ptr(splitk_workspace(x.device)) if (SPLIT_K or STREAM_K) else None, _stream(x)),
                    "zs_conv2d_nhwc_ws")
     return out
 

@@ -16,6 +16,7 @@ class PackedConv:
 
     def __init__(self, w, scale, shift, cin, cout, kh, kw, stride, padding):
         self.w, self.scale, self.shift = w, scale, shift
+        self.w16 = None                     # split-fp16 halves of w (ops.conv2d, built on first f16x3 use)
         self.cin, self.cout, self.kh, self.kw, self.stride = cin, cout, kh, kw, stride
         self.padding = padding              # int (torch symmetric zero padding) or "same" (timm / TF)
 
@@ -29,6 +30,7 @@ class PackedConv:
 
     def to(self, device):
         self.w = self.w.to(device)
+        self.w16 = None
         self.scale = None if self.scale is None else self.scale.to(device)
         self.shift = None if self.shift is None else self.shift.to(device)
         return self
