@@ -159,3 +159,27 @@ def test_train_loop_checkpoints_and_resume_skip(tmp_path, encoder_sd, seeded_sd)
     r.train(opt)
     assert r.it == 8 and evals == [] and r.best_val == 0.25
     assert [(s["it"], s.get("latest", False)) for s in saves] == [(6, True), (8, False)]
+
+
+def test_optim_amp_runs_the_forward_convolutions_in_split_fp16(tmp_path, encoder_sd, seeded_sd):
+    """--optim.amp (the reference: fp16 autocast + GradScaler, model/shape_engine.py:135-136, :252-269): the encoders'
+    forward GEMMs on the 16-bit matrix pipe with split operands, everything else fp32 - same loss to 1e-4 relative,
+    the step updates the weights, and a runner built without the flag is back on fp32."""
+    from zeroshape_amd.nn import autograd as A
+    from zeroshape_amd.utils import util
+    from zeroshape_amd.utils.options import EasyDict as edict
+    losses = {}
+    try:
+        for amp in (False, True):
+            opt = train_opt(tmp_path, *(["--optim.amp"] if amp else []))
+            r = make_runner(opt, encoder_sd, seeded_sd, n_train=4)
+            assert A.FWD_CONV_PRECISION == ("f16x3" if amp else "f32")
+            r.graph.train()
+            batch = next(iter(torch.utils.data.DataLoader(r.train_data, batch_size=4, shuffle=False)))
+            before = r.graph.coord_encoder.encoder.conv1.weight.detach().clone()
+            torch.manual_seed(3)
+            losses[amp] = float(r.train_iteration(opt, util.move_to_device(edict(batch), opt.device)).all)
+            assert not torch.equal(before, r.graph.coord_encoder.encoder.conv1.weight)
+        assert np.isfinite(losses[True]) and abs(losses[True] - losses[False]) < 1e-4 * max(1.0, abs(losses[False])), losses
+    finally:
+        A.set_forward_precision("f32")

@@ -57,8 +57,12 @@ class Runner(shape_engine.Runner):
                                 betas=(0.9, 0.95))
         if opt.optim.sched:
             self.sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.optim, opt.max_epoch)
-        if opt.optim.amp:
-            raise NotImplementedError("optim.amp: the HIP training path is fp32 (options/depth.yaml amp false)")
+        # optim.amp (model/shape_engine.py:135-136, :252-269: fp16 autocast + GradScaler): here the forward
+        # convolutions / linear layers of the encoders move to the 16-bit matrix pipe with split-fp16 operands
+        # (~2^-21 relative instead of fp16's 2^-11); gradients and accumulations stay fp32, so there is nothing
+        # to scale and no scaler state in the checkpoint
+        from ..nn import autograd as A
+        A.set_forward_precision("f16x3" if opt.optim.amp else os.environ.get("ZS_TRAIN_FWD_PRECISION", "f32"))
         if getattr(opt, "world_size", 1) > 1:
             self.reducer = parallel.GradReducer(self.graph.parameters(),
                                                 bucket_mb=getattr(opt.optim, "bucket_mb", 64.0))

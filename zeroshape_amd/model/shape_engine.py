@@ -7,7 +7,7 @@ Training runs one process per GPU: Graph.forward(training=True) on the HIP autog
 averaged over the ranks by parallel.GradReducer (bucketed RCCL all-reduce under the backward pass -
 the role torch DDP has in the reference), one fused AdamW launch (zeroshape_amd/optim.py) with the
 reference's four parameter groups.  Not rebuilt (control plane): tensorboard
-scalars, visual dumps, AMP (optim.amp is false in options/shape.yaml and the path is fp32)."""
+scalars, visual dumps.  optim.amp = split-fp16 forward GEMMs (see setup_optimizer)."""
 import os
 
 import numpy as np
@@ -107,8 +107,12 @@ class Runner:
         self.optim = FusedAdamW(groups, betas=(0.9, 0.95))
         if opt.optim.sched:
             self.sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.optim, opt.max_epoch)
-        if opt.optim.amp:
-            raise NotImplementedError("optim.amp: the HIP training path is fp32 (options/shape.yaml:95 amp false)")
+        # optim.amp (model/shape_engine.py:135-136, :252-269: fp16 autocast + GradScaler): here the forward
+        # convolutions / linear layers of the encoders move to the 16-bit matrix pipe with split-fp16 operands
+        # (~2^-21 relative instead of fp16's 2^-11); gradients and accumulations stay fp32, so there is nothing
+        # to scale and no scaler state in the checkpoint
+        from ..nn import autograd as A
+        A.set_forward_precision("f16x3" if opt.optim.amp else os.environ.get("ZS_TRAIN_FWD_PRECISION", "f32"))
         if getattr(opt, "world_size", 1) > 1:
             self.reducer = parallel.GradReducer(self.graph.parameters(), module=self.graph,
                                                 bucket_mb=getattr(opt.optim, "bucket_mb", 64.0))

@@ -25,6 +25,15 @@ _CONV_F16X3 = 16
 # exact fp32: gradient magnitudes reach far below fp16's range.
 FWD_CONV_PRECISION = os.environ.get("ZS_TRAIN_FWD_PRECISION", "f32")
 
+
+def set_forward_precision(p):
+    """"f32" | "f16x3": arithmetic of the forward convolutions / linear layers under autograd (optim.amp selects
+    "f16x3": the 16-bit matrix pipe with split operands; gradients and accumulations stay fp32, so no loss scaling)."""
+    global FWD_CONV_PRECISION
+    if p not in ("f32", "f16x3"):
+        raise ValueError("forward precision must be 'f32' or 'f16x3', got %r" % (p,))
+    FWD_CONV_PRECISION = p
+
 # Bumped whenever parameters are updated through raw pointers (the fused optimiser): tensor
 # ._version does not see those writes, so every pack cache also keys on this counter.
 GENERATION = [0]
