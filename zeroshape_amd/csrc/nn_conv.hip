@@ -405,7 +405,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 // Handles the pointwise and the tap-major (Cin % 16 == 0) geometries without input scale / shift.
 __device__ f32x4 zs_zero_page[4];
 
-constexpr int DMA_STAGE_BYTES = (BM + BN) * BK * 4;          // A: 4 quads x 128 rows x 16 B, then B the same
 
 __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst) {   // 64 lanes x 16 B -> LDS[dst + 16 lane]
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory");
@@ -418,35 +417,40 @@ __device__ __forceinline__ void wait_vm_then_barrier() {       // all but the N 
 
 // DMA_NS stages of 16 KiB: 3 -> three workgroups per CU, two steps of lead.  (9 stages, one workgroup per CU, eight
 // steps of lead measured SLOWER - 632 vs 471 us on the 3x3 layer: the limit is the rate of the stream, not its latency.)
-template <bool PW, bool RELU, bool SK, int DMA_NS>
-__global__ __launch_bounds__(256) void conv_gemm_dma_kernel(ConvArgs a) {
+// MI = 32-row MFMA tiles per wave along M: 2 -> 128 x 128 workgroup tile (three workgroups per CU), 4 -> 256 x 128 (two
+// per CU, 25 % fewer bytes through LDS per MFMA: 24 KiB instead of 2 x 16 per 256 x 128 outputs and k-step)
+template <bool PW, bool RELU, bool SK, int DMA_NS, int MI = 2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DMA_NS == 2 ? 4 : 2, 8))) void conv_gemm_dma_kernel(ConvArgs a) {
     constexpr int DMA_DEPTH = DMA_NS - 1;
-    __shared__ f32x4 lds[DMA_NS][2][KQ][BM];                  // [stage][A | B][k-quad][row]
+    constexpr int TMB = 64 * MI;                              // rows of the workgroup tile
+    constexpr int NDMA = MI + 2;                              // DMAs per wave and step: A row blocks of 64, B columns x 2
+    constexpr int STAGE_BYTES = (TMB + BN) * BK * 4;
+    __shared__ f32x4 lds[DMA_NS][KQ * (TMB + BN)];            // [stage][A: [k-quad][row] | B: [k-quad][column]]
     __shared__ int sk_last;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) f32x4 *)&lds[0][0][0][0]);
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) f32x4 *)&lds[0][0]);
     const int ksteps = (a.K + BK - 1) / BK;
     const int ntiles = a.CoutPad / BN;
-    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64, l32 = lane & 31, half = lane >> 5;
+    const int wm = (wave & 1) * (32 * MI), wn = (wave >> 1) * 64, l32 = lane & 31, half = lane >> 5;
     const char *zero = reinterpret_cast<const char *>(zs_zero_page);
     const f32x4 *wq = reinterpret_cast<const f32x4 *>(a.w);
 
     int it = SK ? (int)blockIdx.x * a.sk_per : ((int)blockIdx.x * ntiles + (int)blockIdx.y) * ksteps;
     const int it_begin = it;
-    const int it_end = SK ? min(it + a.sk_per, (int)(((a.M + BM - 1) / BM) * ntiles) * ksteps) : it + ksteps;
+    const int it_end = SK ? min(it + a.sk_per, (int)(((a.M + TMB - 1) / TMB) * ntiles) * ksteps) : it + ksteps;
 
     while (it < it_end) {
     const int tile = it / ksteps, kb = it - tile * ksteps, ke = min(ksteps, kb + (it_end - it));
-    const int m0 = (tile / ntiles) * BM, n0 = (tile % ntiles) * BN;
+    const int m0 = (tile / ntiles) * TMB, n0 = (tile % ntiles) * BN;
 
-    // this wave stages k-quad `wave` of every step: A rows lane and lane + 64, B columns lane and lane + 64
-    TapWalk tw[2];
-    const float *src[2];                                      // PW: the pixel's row; TM: the image
-    bool pok[2];
-    int iy0[2], ix0[2];
+    // this wave stages k-quad `wave` of every step: A rows lane + 64 h (h < MI), B columns lane and lane + 64
+    TapWalk tw[MI];
+    const float *src[MI];                                     // PW: the pixel's row; TM: the image
+    bool pok[MI];
+    int iy0[MI], ix0[MI];
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
+    for (int h = 0; h < MI; h++) {
         const int pix = m0 + lane + 64 * h;
         pok[h] = pix < a.M;
         if (PW) {
@@ -467,12 +471,13 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(ConvArgs a) {
     }
     const f32x4 *wcol = wq + n0 + lane;
     int ks_issue = kb;                                        // next step to stage
-    auto issue = [&]() {                                      // 4 DMAs: A rows x 2, B columns x 2 (k-quad = wave)
+    auto issue = [&]() {                                      // NDMA DMAs: A row blocks x MI, B columns x 2 (k-quad = wave)
         const int st = (ks_issue - kb) % DMA_NS;
-        const unsigned dst = lds_base + st * DMA_STAGE_BYTES + wave * (BM * 16);
+        const unsigned dst = lds_base + st * STAGE_BYTES + wave * (TMB * 16);
+        const unsigned dst_b = lds_base + st * STAGE_BYTES + KQ * TMB * 16 + wave * (BN * 16);
         const bool live = ks_issue < ke;                      // past the end: keep the vmcnt arithmetic, fetch zeros
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < MI; h++) {
             const char *g;
             if (PW) {
                 const int k = BK * ks_issue + 4 * wave;
@@ -489,15 +494,15 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(ConvArgs a) {
         for (int h = 0; h < 2; h++) {
             const char *g = live ? reinterpret_cast<const char *>(wcol + (size_t)(ks_issue * KQ + wave) * a.CoutPad + 64 * h) : zero;
 #ifndef ZS_EXP_CONV_NO_DMA
-            dma16(g, dst + KQ * BM * 16 + h * 1024);
+            dma16(g, dst_b + h * 1024);
 #endif
         }
         ks_issue++;
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < MI; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -510,21 +515,25 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(ConvArgs a) {
 
     const float relu_floor = RELU ? 0.f : -INFINITY;
     for (int ks = kb; ks < ke; ks++) {
-        static_assert(4 * (DMA_DEPTH - 1) < 64, "vmcnt is a 6-bit counter");
-        wait_vm_then_barrier<4 * (DMA_DEPTH - 1)>();          // the younger steps' DMAs (4 each) may stay in flight
+        static_assert(NDMA * (DMA_DEPTH - 1) < 64, "vmcnt is a 6-bit counter");
+        wait_vm_then_barrier<NDMA * (DMA_DEPTH - 1)>();       // the younger steps' DMAs (NDMA each) may stay in flight
         issue();
         const int st = (ks - kb) % DMA_NS;
-        u32x4 ah[2], al[2], bh[2], bl[2];
-        f32x4 fa[2][2];
+        u32x4 ah[MI], al[MI], bh[2], bl[2];
+        f32x4 fa[MI][2];
+        const f32x4 *sa = &lds[st][0], *sb = &lds[st][KQ * TMB];
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            fa[i][0] = lds[st][0][half][wm + 32 * i + l32];
-            fa[i][1] = lds[st][0][half + 2][wm + 32 * i + l32];
-            bh[i] = __builtin_bit_cast(u32x4, lds[st][1][half][wn + 32 * i + l32]);
-            bl[i] = __builtin_bit_cast(u32x4, lds[st][1][half + 2][wn + 32 * i + l32]);
+        for (int i = 0; i < MI; i++) {
+            fa[i][0] = sa[half * TMB + wm + 32 * i + l32];
+            fa[i][1] = sa[(half + 2) * TMB + wm + 32 * i + l32];
         }
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int j = 0; j < 2; j++) {
+            bh[j] = __builtin_bit_cast(u32x4, sb[half * BN + wn + 32 * j + l32]);
+            bl[j] = __builtin_bit_cast(u32x4, sb[(half + 2) * BN + wn + 32 * j + l32]);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; i++) {
             if (RELU) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -541,14 +550,14 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(ConvArgs a) {
         }
 #ifdef ZS_EXP_CONV_NO_MFMA
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < MI; i++)
 #pragma unroll
             for (int j = 0; j < 2; j++)
 #pragma unroll
                 for (int e = 0; e < 4; e++) acc[i][j][e] += __builtin_bit_cast(float, ah[i][e] ^ al[i][e] ^ bh[j][e] ^ bl[j][e]);
 #else
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < MI; i++)
 #pragma unroll
             for (int j = 0; j < 2; j++) zs::s16::mfma3(acc[i][j], ah[i], al[i], bh[j], bl[j]);
 #endif
@@ -573,13 +582,13 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int i = 0; i < 2; i++) epilogue(i, j, acc[i][j]);
+            for (int i = 0; i < MI; i++) epilogue(i, j, acc[i][j]);
     } else {   // a share of a tile: see conv_gemm_kernel
         float *parts = a.ws + WS_COUNTER_FLOATS;
         int *counters = reinterpret_cast<int *>(a.ws);
-        float *mine = parts + ((size_t)blockIdx.x * 2 + (it == it_begin ? 0 : 1)) * (BM * BN) + tid;
+        float *mine = parts + ((size_t)blockIdx.x * 2 + (it == it_begin ? 0 : 1)) * (TMB * BN) + tid;
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < MI; i++)
 #pragma unroll
             for (int j = 0; j < 2; j++) {
 #pragma unroll
@@ -601,14 +610,14 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(ConvArgs a) {
 #pragma unroll
             for (int j = 0; j < 2; j++)
 #pragma unroll
-                for (int i = 0; i < 2; i++) {
+                for (int i = 0; i < MI; i++) {
                     f32x16 d;
 #pragma unroll
                     for (int r = 0; r < 16; r++) d[r] = 0.f;
 #pragma unroll 1
                     for (int w = w_first; w <= w_last; w++) {
                         const int w_tile0 = (w * a.sk_per) / ksteps;
-                        const float *p = parts + ((size_t)w * 2 + (w_tile0 == tile ? 0 : 1)) * (BM * BN) + tid;
+                        const float *p = parts + ((size_t)w * 2 + (w_tile0 == tile ? 0 : 1)) * (TMB * BN) + tid;
 #pragma unroll
                         for (int r = 0; r < 16; r++)
                             d[r] += __hip_atomic_load(&p[((i * 2 + j) * 16 + r) * 256], __ATOMIC_RELAXED,
@@ -1154,13 +1163,26 @@ extern "C" int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const f
         // pipelined kernel (ZS_CONV_NO_DMA=1: the register-staged one, for A/B measurements)
         static const bool no_dma = getenv("ZS_CONV_NO_DMA") != nullptr;
         const bool dma = f16 && a.w_split && !no_dma && (pw || tm) && in_scale == 1.0f && in_shift == 0.0f && (Cin % BK) == 0;
-#define ZS_LAUNCH_DMA1(SKF, NS)                                                                                     \
-    do {                                                                                                            \
-        if (pw) hipLaunchKernelGGL((conv_gemm_dma_kernel<true, false, SKF, NS>), grid, dim3(256), 0, st, a);         \
-        else if (a.in_relu) hipLaunchKernelGGL((conv_gemm_dma_kernel<false, true, SKF, NS>), grid, dim3(256), 0, st, a); \
-        else hipLaunchKernelGGL((conv_gemm_dma_kernel<false, false, SKF, NS>), grid, dim3(256), 0, st, a);           \
+        // Variants kept for A/B runs, all measured inside the batch-28 encoder (tools/conv_shapes.py, 19.8 ms of
+        // GEMM time with the default): ZS_CONV_DMA_MI=4 = 256 x 128 workgroup tiles (wave tile 128 x 64, two workgroups
+        // per CU, 25 % fewer bytes through LDS per MFMA): SLOWER, 21.1 ms (3x3 476 vs 425 us, fc1 179 vs 140 us);
+        // ZS_CONV_DMA_NS=2 = two stages, four workgroups per CU, one step of lead: the same, 19.7 ms.  Fewer bytes with
+        // fewer loads in flight loses; more workgroups with less lead changes nothing.
+        static const int dma_mi = getenv("ZS_CONV_DMA_MI") ? atoi(getenv("ZS_CONV_DMA_MI")) : 2;
+        const long long tall_tiles = ((M + 255) / 256) * (a.CoutPad / BN);
+        const bool tall = dma_mi == 4 && tall_tiles >= 1;
+#define ZS_LAUNCH_DMA1(SKF, NS, MI_)                                                                                     \
+    do {                                                                                                                 \
+        if (pw) hipLaunchKernelGGL((conv_gemm_dma_kernel<true, false, SKF, NS, MI_>), grid, dim3(256), 0, st, a);         \
+        else if (a.in_relu) hipLaunchKernelGGL((conv_gemm_dma_kernel<false, true, SKF, NS, MI_>), grid, dim3(256), 0, st, a); \
+        else hipLaunchKernelGGL((conv_gemm_dma_kernel<false, false, SKF, NS, MI_>), grid, dim3(256), 0, st, a);           \
     } while (0)
-#define ZS_LAUNCH_DMA(SKF) ZS_LAUNCH_DMA1(SKF, 3)
+        static const int dma_ns = getenv("ZS_CONV_DMA_NS") ? atoi(getenv("ZS_CONV_DMA_NS")) : 3;
+#define ZS_LAUNCH_DMA(SKF)                              \
+    do {                                                \
+        if (dma_ns == 2) ZS_LAUNCH_DMA1(SKF, 2, 2);     \
+        else ZS_LAUNCH_DMA1(SKF, 3, 2);                 \
+    } while (0)
         // 256 x 256 tiles over 256 persistent workgroups (layers with >= 192 output channels): OPT-IN
         // (ZS_CONV_256_MIN_KSTEPS=128 selects it for K >= 2048).  Run back to back on hot caches it beats the
         // 128 x 128 kernel on the long contractions (tools/conv_ns.sh, batch 28: ViT fc2 152 vs 177 us, 3x3 256 -> 256
@@ -1183,6 +1205,9 @@ extern "C" int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const f
             if (dma) ZS_LAUNCH_DMA(true);
             else if (f16) ZS_LAUNCH_BIG(true, true);
             else ZS_LAUNCH_BIG(false, true);
+        } else if (dma && tall) {
+            const dim3 grid((unsigned)((M + 255) / 256), (unsigned)(a.CoutPad / BN));
+            ZS_LAUNCH_DMA1(false, 3, 4);
         } else {
             const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(a.CoutPad / BN));
             if (dma) ZS_LAUNCH_DMA(false);
