@@ -167,19 +167,26 @@ __global__ __launch_bounds__(BLOCK) void seen_surface_kernel(
     float Ki[9];
     inverse3x3(intr + (size_t)b * 9, Ki);
 
+    // pixel i = tid + k BLOCK as (x, y), advanced without a division per pixel
+    const int step_x = BLOCK % W, step_y = BLOCK / W, x0 = tid % W, y0 = tid / W;
+    auto advance = [&](int &x, int &y) {
+        x += step_x;
+        y += step_y;
+        if (x >= W) { x -= W; y++; }
+    };
     float sx = 0.f, sy = 0.f, sz = 0.f, cnt = 0.f;
-    for (int i = tid; i < n; i += BLOCK)
+    for (int i = tid, x = x0, y = y0; i < n; i += BLOCK, advance(x, y))
         if (M[i] > 0.5f) {
-            const Point p = unproject(Ki, i % W, i / W, D[i]);
+            const Point p = unproject(Ki, x, y, D[i]);
             sx += p.x; sy += p.y; sz += p.z; cnt += 1.f;
         }
     cnt = block_reduce(cnt, lds, false);
     const float mx = block_reduce(sx, lds, false) / cnt, my = block_reduce(sy, lds, false) / cnt,
                 mz = block_reduce(sz, lds, false) / cnt;
     float r = -INFINITY;
-    for (int i = tid; i < n; i += BLOCK)
+    for (int i = tid, x = x0, y = y0; i < n; i += BLOCK, advance(x, y))
         if (M[i] > 0.5f) {
-            const Point p = unproject(Ki, i % W, i / W, D[i]);
+            const Point p = unproject(Ki, x, y, D[i]);
             const float dx = p.x - mx, dy = p.y - my, dz = p.z - mz;
             r = fmaxf(r, sqrtf(dx * dx + dy * dy + dz * dz));
         }
@@ -189,21 +196,35 @@ __global__ __launch_bounds__(BLOCK) void seen_surface_kernel(
         mean[b * 3] = mx; mean[b * 3 + 1] = my; mean[b * 3 + 2] = mz;
         scale[b] = r;
     }
-    // normalised point of pixel i (0 where invalid) - the value written to `seen`
-    auto normalised = [&](int i) -> Point {
+    // normalised point of pixel i = (x, y) (0 where invalid) - the value written to `seen`
+    auto normalised_xy = [&](int i, int x, int y) -> Point {
         Point q = {0.f, 0.f, 0.f};
         if (M[i] > 0.5f) {
-            const Point p = unproject(Ki, i % W, i / W, D[i]);
+            const Point p = unproject(Ki, x, y, D[i]);
             q.x = (p.x - mx) / r; q.y = (p.y - my) / r; q.z = (p.z - mz) / r;
         }
         return q;
     };
+    auto normalised = [&](int i) -> Point { return normalised_xy(i, i % W, i / W); };
     float *S = seen + (size_t)b * n * 3;
-    for (int i = tid; i < n; i += BLOCK) {
-        const Point q = normalised(i);
+    // Same-size coordinate map (arch.depth.dsp = 1, the default encoder): the bilinear taps are (1, 0) x (1, 0), so
+    // interpolate_coordmap reduces to q / (1 + 1e-6) on valid pixels - written in this pass instead of a fourth one
+    // that unprojects every pixel four more times.
+    const bool same = coord_dsp && Ho == H && Wo == W;
+    const float inv_eps = 1.0f + 1.e-6f;
+    for (int i = tid, x = x0, y = y0; i < n; i += BLOCK, advance(x, y)) {
+        const Point q = normalised_xy(i, x, y);
         S[i * 3] = q.x; S[i * 3 + 1] = q.y; S[i * 3 + 2] = q.z;
+        if (same) {
+            const bool valid = M[i] > 0.5f;
+            float *O = coord_dsp + (size_t)b * 3 * n;
+            O[i] = valid ? q.x / inv_eps : 0.f;
+            O[n + i] = valid ? q.y / inv_eps : 0.f;
+            O[2 * n + i] = valid ? q.z / inv_eps : 0.f;
+            mask_dsp[(size_t)b * n + i] = valid ? 1.f : 0.f;
+        }
     }
-    if (!coord_dsp) return;
+    if (!coord_dsp || same) return;
     const int no = Ho * Wo;
     const float sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
     float *O = coord_dsp + (size_t)b * 3 * no;
