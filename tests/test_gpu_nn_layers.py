@@ -2,6 +2,8 @@
 same op in PyTorch fp32 on the CPU (torch.nn.functional).  fp32 MFMA accumulates in a different
 order than the CPU kernels, so comparisons are relative to the output scale: <= 2e-5 of max|y| -
 for the exact-fp32 and for the split-fp16 (ZS_CONV_F16X3) arithmetic of the convolution engine alike."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -305,3 +307,15 @@ def test_conv2d_stream_k(B, Cin, H, W, Cout, k, stride, in_relu, monkeypatch):
         assert int(ops.splitk_workspace(x.device)[:1 << 18].view(torch.int32).abs().max()) == 0    # counters at rest
     finally:
         ops.set_conv_precision(prev)
+
+
+def test_conv2d_random_shape_sweep():
+    """tools/fuzz_conv.py: 80 random layer shapes (kernel 1 / 3 / 5, stride 1 / 2, ragged M and Cout, 4..320 input
+    channels, input ReLU, three activations, forced tilings, stream-K on every other case) - split-fp16 against the
+    exact-fp32 kernels at 2e-5 of the output scale, the fp32 kernels against torch CPU on every tenth case."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_conv.py"), "80", "11"], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "80 cases ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
