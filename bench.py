@@ -76,6 +76,55 @@ def measured_traffic(precision):
     return rec["bytes_per_launch"], rec.get("profile")
 
 
+def power_under_load(launch, seconds=1.6):
+    """Socket power and engine clock (rocm-smi) while `launch` runs back to back: the split-fp16 decoder sits at the
+    board's power limit, which is what caps its roofline fraction - reported next to it.  None where
+    rocm-smi is missing."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+
+    import torch
+    if shutil.which("rocm-smi") is None:
+        return None
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--csv"], capture_output=True, text=True,
+                                     timeout=5).stdout.strip().split("\n")
+                head, row = out[-2].split(","), out[-1].split(",")
+                rec = dict(zip(head, row))
+                pw = [float(v) for k, v in rec.items() if "Power" in k and re.match(r"^[0-9.]+$", v)]
+                ck = [float(re.sub(r"[^0-9.]", "", v)) for k, v in rec.items() if k.startswith("sclk clock speed")]
+                if pw and ck:
+                    samples.append((pw[0], ck[0]))
+            except Exception:
+                pass
+            stop.wait(0.15)
+
+    for _ in range(5):
+        launch()
+    torch.cuda.synchronize()
+    th = threading.Thread(target=sampler)
+    th.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(8):
+            launch()
+        torch.cuda.synchronize()
+    stop.set()
+    th.join()
+    samples = samples[1:] if len(samples) > 2 else samples        # the first reading may predate the load
+    if not samples:
+        return None
+    return {"socket_w": round(sum(p for p, _ in samples) / len(samples), 1), "sclk_mhz": round(sum(c for _, c in samples) / len(samples)),
+            "samples": len(samples), "board_limit_w": 1400, "peak_sclk_mhz": 2400,
+            "how": "rocm-smi every 0.15 s over %.1f s of back-to-back decoder launches" % seconds}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,6 +238,9 @@ def main():
 
     kern_ms, st = time_launches(args.precision, max(3, min(args.steps, 10)))
     roofline = roofline_of(args.precision, kern_ms)
+    if world == 1 and not args.no_extras:
+        roofline["power"] = power_under_load(
+            lambda: net.query_grid_range(latent, axis, b, e, apply_sigmoid=True, state=st))
 
     exact_f32 = None
     if args.precision == "f16x3" and world == 1:
