@@ -444,14 +444,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DMA_NS == 2
     const int tile = it / ksteps, kb = it - tile * ksteps, ke = min(ksteps, kb + (it_end - it));
     const int m0 = (tile / ntiles) * TMB, n0 = (tile % ntiles) * BN;
 
-    // this wave stages k-quad `wave` of every step: A rows lane + 64 h (h < MI), B columns lane and lane + 64
+    // A is staged COALESCED: one DMA covers 16 rows x 64 B (lane = 4 (row % 16) + slot: each row's 16 channels of the
+    // step are one contiguous 64 B run - 16 cache lines per instruction; a lane per row, the obvious mapping, touches 64
+    // lines per instruction and is bound by the vector cache's tag rate, not by bytes).  LDS holds A as
+    // [row][4 slots], slot = quad ^ ((row >> 2) & 3): the MFMA fragment reads (32 rows, one quad) stay conflict-free.
+    // This wave issues instructions wave * MI + h (rows 16 (wave MI + h) + lane / 4), B: k-quad `wave`, columns lane, + 64.
+    const int a_slot = lane & 3;
     TapWalk tw[MI];
     const float *src[MI];                                     // PW: the pixel's row; TM: the image
     bool pok[MI];
     int iy0[MI], ix0[MI];
 #pragma unroll
     for (int h = 0; h < MI; h++) {
-        const int pix = m0 + lane + 64 * h;
+        const int arow = 16 * (wave * MI + h) + (lane >> 2);
+        const int pix = m0 + arow;
         pok[h] = pix < a.M;
         if (PW) {
             src[h] = a.in + (size_t)(pok[h] ? pix : 0) * a.Cin;
@@ -471,19 +477,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DMA_NS == 2
     }
     const f32x4 *wcol = wq + n0 + lane;
     int ks_issue = kb;                                        // next step to stage
+    // the k-quad this lane fetches of its rows (the slot it lands in is lane & 3); rows of one instruction share row >> 2 & 3
+    // only pairwise, so the quad is per lane: quad = slot ^ ((row >> 2) & 3), row = 16 (..) + lane / 4 -> (lane >> 4) & 3
+    const int a_quad = a_slot ^ ((lane >> 4) & 3);
     auto issue = [&]() {                                      // NDMA DMAs: A row blocks x MI, B columns x 2 (k-quad = wave)
         const int st = (ks_issue - kb) % DMA_NS;
-        const unsigned dst = lds_base + st * STAGE_BYTES + wave * (TMB * 16);
+        const unsigned dst = lds_base + st * STAGE_BYTES + wave * (MI * 1024);
         const unsigned dst_b = lds_base + st * STAGE_BYTES + KQ * TMB * 16 + wave * (BN * 16);
         const bool live = ks_issue < ke;                      // past the end: keep the vmcnt arithmetic, fetch zeros
 #pragma unroll
         for (int h = 0; h < MI; h++) {
             const char *g;
             if (PW) {
-                const int k = BK * ks_issue + 4 * wave;
+                const int k = BK * ks_issue + 4 * a_quad;
                 g = (live && pok[h] && k < a.K) ? reinterpret_cast<const char *>(src[h] + k) : zero;
             } else {
-                g = (live && tw[h].ok) ? reinterpret_cast<const char *>(src[h] + tw[h].base + tw[h].cc + 4 * wave) : zero;
+                g = (live && tw[h].ok) ? reinterpret_cast<const char *>(src[h] + tw[h].base + tw[h].cc + 4 * a_quad) : zero;
                 if (live) tw[h].advance(a, BK, pok[h], iy0[h], ix0[h]);
             }
 #ifndef ZS_EXP_CONV_NO_DMA
@@ -524,8 +533,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DMA_NS == 2
         const f32x4 *sa = &lds[st][0], *sb = &lds[st][KQ * TMB];
 #pragma unroll
         for (int i = 0; i < MI; i++) {
-            fa[i][0] = sa[half * TMB + wm + 32 * i + l32];
-            fa[i][1] = sa[(half + 2) * TMB + wm + 32 * i + l32];
+            const int R = wm + 32 * i + l32, sw = (R >> 2) & 3;
+            fa[i][0] = sa[R * 4 + (half ^ sw)];
+            fa[i][1] = sa[R * 4 + ((half + 2) ^ sw)];
         }
 #pragma unroll
         for (int j = 0; j < 2; j++) {
