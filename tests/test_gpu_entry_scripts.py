@@ -109,3 +109,31 @@ def test_demo_script_shape_and_depth(tmp_path, encoder_sd, seeded_sd):
     run("demo.py", "--yaml=options/depth.yaml", "--task=depth", "--datadir=%s/data" % tmp_path,
         "--ckpt=%s/depth.ckpt" % tmp_path, "--output_root=%s" % tmp_path)
     assert (preds / "blob_depth_est.png").exists() and not (preds / "blob_mesh.obj").exists()
+
+
+def test_bench_line_contract():
+    """`python bench.py` (short run, no CPU legs): ONE JSON line with the driver's keys, the roofline object consistent
+    with itself (achieved = points x algorithmic flop / launch time, frac = achieved / peak) and with the timed
+    region, measured traffic only from a profile of the current kernel source, and the evaluation legs."""
+    import json
+    out = run("bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
+    lines = [ln for ln in out.strip().split("\n") if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["dtype"] == "f16x3" and d["vs_baseline"] is None
+    assert d["scaling"] == "weak" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    pts = 129 ** 3
+    assert d["config"]["points_per_step"] == pts and abs(d["value"] - pts / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["peak"] == 2500.0 and r["unit"] == "TFLOP/s"
+    achieved = pts * r["algorithmic_flop_per_point"] / (r["launch_ms_mean"] * 1e-3) / 1e12
+    assert abs(r["achieved"] - achieved) < 1e-2 * achieved and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["launch_ms_mean"] <= d["ms_per_step"] * 1.02           # the kernel is inside the step
+    assert r["traffic"] is None or (r["traffic"] > pts * 4 and "stale" not in r["traffic_source"])
+    assert d["exact_f32"]["occupancy_flips"] <= 2 and d["exact_f32"]["max_abs_logit_diff"] < 1e-4
+    for leg in ("chamfer", "pose_search", "chamfer_l1", "encoder", "train_step"):
+        assert leg in d, leg
+    assert d["pose_search"]["pruned_equals_exhaustive"] is True and d["chamfer_l1"]["chamfer_l1_vs_oracle_pipeline_vox16"] < 1e-4
