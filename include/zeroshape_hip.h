@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 24
+#define ZS_ABI_VERSION 25
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -233,6 +233,15 @@ int zs_pose_search_batch(const float *pred, int n, const float *gt_normalized, i
                          const float *rotations, const int *order, int count, int index_offset,
                          const float *lower_bound, const float *thresholds6, float *best,
                          void *scratch, void *stream);
+/* The same batch through uniform grids (csrc/zs_point_grid.h): the ground truth binned once per search
+ * (zs_pose_gt_grid into the first part of `grids`, zs_pose_grid_bytes(n, m, max batch) bytes, 16-byte aligned), the
+ * rotated + normalised prediction once per rotation; ~10^2 instead of 10^4 distance evaluations per query and
+ * bit-identical records (a skipped candidate provably has a strictly larger distance; sums formed in the same order). */
+size_t zs_pose_grid_bytes(int n, int m, int count);
+int zs_pose_gt_grid(const float *gt_normalized, int m, void *grids, void *stream);
+int zs_pose_search_batch_grid(const float *pred, int n, const float *gt_normalized, int m, const float *rotations,
+                              const int *order, int count, int index_offset, const float *lower_bound,
+                              const float *thresholds6, float *best, void *scratch, void *grids, void *stream);
 int zs_pose_apply(const float *pred, int n, const float *rotations, const int *index, float *out,
                   void *scratch, void *stream);
 int zs_normalize_pc(const float *pc, int b, int n, float *out, void *scratch, void *stream);

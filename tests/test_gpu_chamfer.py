@@ -256,3 +256,43 @@ def test_fused_pose_search_equals_the_unfused_kernels():
     # fewer thresholds than six
     f2 = E.brute_force_search(pred, gt, [0.01, 0.1], device="cuda", rotations=R, rot_slice=sl)[2]
     assert f2.shape == (2,) and torch.equal(f2, f[[1, 4]])
+
+
+@pytest.mark.parametrize("shape,n,m", [("asym", 1500, 1500), ("ellipsoid", 4000, 3100), ("sphere", 900, 1200),
+                                       ("flat", 1000, 1000), ("dup", 700, 650), ("tiny", 5, 3)])
+def test_grid_pose_search_equals_the_pairwise_scan(shape, n, m):
+    """brute_force_search(nn="grid"): the exact evaluations walk uniform grids (ground truth binned once, the
+    rotated + normalised prediction once per rotation) instead of scanning all pairs - same record bit for bit
+    (Chamfer-L1, index, accuracy, completeness, six F-scores), exhaustive and pruned, also on degenerate clouds (a
+    plane, duplicated points, fewer points than grid cells, every rotation tying on a sphere)."""
+    from zeroshape_amd.utils import eval_3D as E
+    from zeroshape_amd.utils.camera import get_rotation_sphere
+    R = get_rotation_sphere(24, 24, 12, device="cuda")
+    rs = np.random.RandomState(n + m)
+    if shape == "asym":
+        p = rs.randn(n, 3) * np.array([0.5, 0.25, 0.1]) + rs.rand(n, 1) * np.array([0.4, 0.0, 0.2])
+    elif shape == "ellipsoid":
+        p = syn.ellipsoid_cloud(2, n)
+    elif shape == "sphere":
+        p = rs.randn(n, 3); p /= np.linalg.norm(p, axis=1, keepdims=True)
+    elif shape == "flat":
+        p = rs.uniform(-1, 1, (n, 3)) * np.array([1.0, 0.6, 0.0])
+    elif shape == "dup":
+        p = np.repeat(rs.uniform(-1, 1, (n // 7, 3)), 7, axis=0)[:n]
+    else:
+        p = rs.uniform(-1, 1, (n, 3))
+    pred = torch.from_numpy(p.astype(np.float32))
+    gt = ((R[4321].cpu() @ pred.T).T.contiguous() + 2e-3 * torch.from_numpy(rs.randn(n, 3).astype(np.float32)))[
+        torch.from_numpy(rs.permutation(n)[:m] if m <= n else rs.randint(0, n, m))]
+    sl = (4000, 4700)
+    for prune in (False, True):
+        for bs in (192, 50):
+            a = E.brute_force_search(pred, gt, device="cuda", rotations=R, rot_slice=sl, return_index=True, prune=prune,
+                                     batch_size=bs, nn="grid")
+            ea = E.brute_force_search.last_evaluated
+            b = E.brute_force_search(pred, gt, device="cuda", rotations=R, rot_slice=sl, return_index=True, prune=prune,
+                                     batch_size=bs, nn="brute")
+            assert ea == E.brute_force_search.last_evaluated
+            assert a[5] == b[5] and a[6] == b[6], (shape, prune, bs, a[5], b[5], a[6], b[6])
+            for x, y in zip(a[:5], b[:5]):
+                assert torch.equal(x, y), (shape, prune, bs)

@@ -58,6 +58,10 @@ SIGNATURES = {
     "zs_pose_best_init": (_c_int, [_c_void_p, _c_void_p]),
     "zs_pose_search_batch": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_int,
                                       _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "zs_pose_grid_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
+    "zs_pose_gt_grid": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p]),
+    "zs_pose_search_batch_grid": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_int,
+                                           _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "zs_pose_apply": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "zs_normalize_pc": (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "zs_fscore": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p]),
@@ -151,7 +155,7 @@ SIGNATURES = {
     "zs_readout_concat_bwd": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
 }
 
-ABI_VERSION = 24
+ABI_VERSION = 25
 _lib = None
 
 

@@ -23,6 +23,7 @@
 // running best and returns if the batch cannot win: the host enqueues all batches without a
 // single synchronisation and reads the record once at the end.
 #include "zs_common.h"
+#include "zs_point_grid.h"
 #include "../../include/zeroshape_hip.h"
 
 #include <math.h>
@@ -257,6 +258,99 @@ __global__ __launch_bounds__(PS_THREADS) void pose_nn_kernel(
     }
 }
 
+// ---- the same search through uniform grids (csrc/zs_point_grid.h): ~10^2 instead of 10^4 distance evaluations per
+// query, the same minima bit for bit (a skipped candidate provably has a strictly larger d) ------------------------ //
+// The ground truth is binned once per search, normalize_pc(R p) once per rotation; queries and the per-workgroup
+// partial sums are laid out exactly as in pose_nn_kernel, so pose_finish_kernel forms the same sums in the same order.
+__global__ __launch_bounds__(zs::pgrid::BUILD_THREADS) void pose_gt_grid_kernel(const float *__restrict__ gt, int m,
+                                                                                float *__restrict__ slot) {
+    using namespace zs::pgrid;
+    __shared__ int cnt[GRID_MAX_CELLS];
+    __shared__ float red[6][BUILD_THREADS / 64];
+    __shared__ int wsum[BUILD_THREADS / 64];
+    point_grid_build([&](int i, float &x, float &y, float &z) {
+        x = gt[(size_t)i * 3];
+        y = gt[(size_t)i * 3 + 1];
+        z = gt[(size_t)i * 3 + 2];
+    }, m, slot, cnt, red, wsum);
+}
+
+__global__ __launch_bounds__(zs::pgrid::BUILD_THREADS) void pose_pred_grid_kernel(
+    const float *__restrict__ pred, int n, const float *__restrict__ stats, float *__restrict__ slots, size_t slot_words_n,
+    const float *__restrict__ lower_bound, const float *__restrict__ best) {
+    using namespace zs::pgrid;
+    if (batch_pruned(lower_bound, best)) return;
+    __shared__ int cnt[GRID_MAX_CELLS];
+    __shared__ float red[6][BUILD_THREADS / 64];
+    __shared__ int wsum[BUILD_THREADS / 64];
+    const int rot = blockIdx.x;
+    Xform t;
+    t.load(stats + (size_t)rot * PS_STAT);
+    point_grid_build([&](int i, float &x, float &y, float &z) {
+        t.apply(pred[(size_t)i * 3], pred[(size_t)i * 3 + 1], pred[(size_t)i * 3 + 2], x, y, z);
+    }, n, slots + (size_t)rot * slot_words_n, cnt, red, wsum);
+}
+
+// grid (ceil(max(n, m) / (256 Q)), rotations in the batch, 2): pose_nn_kernel with the scan replaced by the grid walk
+__global__ __launch_bounds__(PS_THREADS) void pose_nn_grid_kernel(
+    const float *__restrict__ pred, int n, const float *__restrict__ gt, int m, const float *__restrict__ stats,
+    const float *__restrict__ thresholds, float *__restrict__ partial, const float *__restrict__ gt_slot,
+    const float *__restrict__ pred_slots, size_t slot_words_n, const float *__restrict__ lower_bound,
+    const float *__restrict__ best) {
+    if (batch_pruned(lower_bound, best)) return;
+    __shared__ float red[PS_PART][PS_THREADS / 64];
+    const int dir = blockIdx.z, rot = blockIdx.y;
+    const int nq = dir == 0 ? n : m;      // queries
+    const int q_base = blockIdx.x * (PS_THREADS * PS_Q);
+    if (q_base >= nq) return;
+    Xform t;
+    t.load(stats + (size_t)rot * PS_STAT);
+    const float *slot = dir == 0 ? gt_slot : pred_slots + (size_t)rot * slot_words_n;
+    float bestd[PS_Q];
+#pragma unroll
+    for (int q = 0; q < PS_Q; q++) {
+        int j = q_base + q * PS_THREADS + threadIdx.x;
+        j = j < nq ? j : nq - 1;
+        float qx, qy, qz;
+        if (dir == 0) {
+            t.apply(pred[(size_t)j * 3], pred[(size_t)j * 3 + 1], pred[(size_t)j * 3 + 2], qx, qy, qz);
+        } else {
+            qx = gt[(size_t)j * 3]; qy = gt[(size_t)j * 3 + 1]; qz = gt[(size_t)j * 3 + 2];
+        }
+        int who;
+        zs::pgrid::point_grid_nearest(slot, qx, qy, qz, bestd[q], who);
+    }
+    // epilogue: pose_nn_kernel's, statement for statement
+    float v[PS_PART];
+#pragma unroll
+    for (int i = 0; i < PS_PART; i++) v[i] = 0.f;
+    float thr[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) thr[i] = thresholds[i];
+#pragma unroll
+    for (int q = 0; q < PS_Q; q++) {
+        const int j = q_base + q * PS_THREADS + threadIdx.x;
+        if (j < nq) {
+            const float s = sqrtf(bestd[q]);
+            v[0] += s;
+#pragma unroll
+            for (int i = 0; i < 6; i++) v[1 + i] += s < thr[i] ? 1.f : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 7; i++) v[i] = wave_sum(v[i]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < 7; i++) red[i][wave] = v[i];
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        float s = red[threadIdx.x][0];
+        for (int w = 1; w < PS_THREADS / 64; w++) s += red[threadIdx.x][w];
+        partial[(((size_t)rot * 2 + dir) * gridDim.x + blockIdx.x) * PS_PART + threadIdx.x] = s;
+    }
+}
+
 // F-score of utils/eval_3D.py:215-231 from the two hit fractions
 __device__ __forceinline__ float fscore_of(float precision, float recall) {
     const float f = 2.f * precision * recall / (precision + recall);
@@ -423,6 +517,57 @@ extern "C" int zs_pose_search_batch(const float *pred, int n, const float *gt_no
     hipLaunchKernelGGL(pose_finish_kernel, dim3(1), dim3(PS_THREADS), 0, st, partial, count, n, m, bx, order,
                        index_offset, best, lower_bound);
     return zs::check_launch("zs_pose_search_batch") ? 1 : 0;
+}
+
+extern "C" size_t zs_pose_grid_bytes(int n, int m, int count) {
+    if (n <= 0 || m <= 0 || count <= 0) return 0;
+    return (zs::pgrid::slot_words(m) + (size_t)count * zs::pgrid::slot_words(n)) * sizeof(float);
+}
+
+extern "C" int zs_pose_gt_grid(const float *gt_normalized, int m, void *grids, void *stream) {
+    if (m <= 0 || !gt_normalized || !grids || (reinterpret_cast<uintptr_t>(grids) & 15)) {
+        zs::set_err("zs_pose_gt_grid: bad arguments (m=%d; 16-byte aligned buffer)", m);
+        return 0;
+    }
+    hipLaunchKernelGGL(pose_gt_grid_kernel, dim3(1), dim3(zs::pgrid::BUILD_THREADS), 0, static_cast<hipStream_t>(stream),
+                       gt_normalized, m, static_cast<float *>(grids));
+    return zs::check_launch("zs_pose_gt_grid") ? 1 : 0;
+}
+
+extern "C" int zs_pose_search_batch_grid(const float *pred, int n, const float *gt_normalized, int m,
+                                         const float *rotations, const int *order, int count, int index_offset,
+                                         const float *lower_bound, const float *thresholds6, float *best,
+                                         void *scratch, void *grids, void *stream) {
+    if (n <= 0 || m <= 0 || count < 0) {
+        zs::set_err("zs_pose_search_batch_grid: bad size (n=%d m=%d count=%d)", n, m, count);
+        return 0;
+    }
+    if (count == 0) return 1;
+    if (count > PS_THREADS) {
+        zs::set_err("zs_pose_search_batch_grid: %d rotations per batch exceed %d", count, PS_THREADS);
+        return 0;
+    }
+    if (!pred || !gt_normalized || !rotations || !thresholds6 || !best || !scratch || !grids ||
+        (reinterpret_cast<uintptr_t>(grids) & 15)) {
+        zs::set_err("zs_pose_search_batch_grid: null or misaligned pointer");
+        return 0;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *stats = static_cast<float *>(scratch);
+    float *partial = stats + (size_t)count * PS_STAT;
+    float *gt_slot = static_cast<float *>(grids);
+    float *pred_slots = gt_slot + zs::pgrid::slot_words(m);
+    const size_t sw = zs::pgrid::slot_words(n);
+    const int bx = blocks_x_of(n, m);
+    hipLaunchKernelGGL(pose_stats_kernel, dim3(count), dim3(PS_THREADS), 0, st, pred, (size_t)0, n, rotations, order,
+                       stats, lower_bound, best);
+    hipLaunchKernelGGL(pose_pred_grid_kernel, dim3(count), dim3(zs::pgrid::BUILD_THREADS), 0, st, pred, n, stats, pred_slots,
+                       sw, lower_bound, best);
+    hipLaunchKernelGGL(pose_nn_grid_kernel, dim3(bx, count, 2), dim3(PS_THREADS), 0, st, pred, n, gt_normalized, m, stats,
+                       thresholds6, partial, gt_slot, pred_slots, sw, lower_bound, best);
+    hipLaunchKernelGGL(pose_finish_kernel, dim3(1), dim3(PS_THREADS), 0, st, partial, count, n, m, bx, order,
+                       index_offset, best, lower_bound);
+    return zs::check_launch("zs_pose_search_batch_grid") ? 1 : 0;
 }
 
 extern "C" int zs_pose_apply(const float *pred, int n, const float *rotations, const int *index, float *out,
