@@ -154,17 +154,21 @@ __global__ __launch_bounds__(PS_THREADS) void pose_apply_kernel(const float *__r
 
 // ---- nearest neighbours both ways + per-workgroup metric partials ------------------------- //
 // grid (ceil(max(n, m) / (256 Q)), rotations in the batch, 2)
+// The launch covers query blocks x_begin .. x_begin + gridDim.x - 1 of blocks_x; `dead` (nullable): rotations that the
+// probe (block 0, see zs_pose_search_batch) has already shown to lose - they are skipped.
 __global__ __launch_bounds__(PS_THREADS) void pose_nn_kernel(
     const float *__restrict__ pred, int n, const float *__restrict__ gt, int m,
     const float *__restrict__ stats, const float *__restrict__ thresholds, float *__restrict__ partial,
-    const float *__restrict__ lower_bound, const float *__restrict__ best) {
+    const float *__restrict__ lower_bound, const float *__restrict__ best, int x_begin, int blocks_x,
+    const int *__restrict__ dead) {
     if (batch_pruned(lower_bound, best)) return;
     __shared__ __attribute__((aligned(16))) float tile[3 * PS_STRIDE];
     __shared__ float red[PS_PART][PS_THREADS / 64];
-    const int dir = blockIdx.z, rot = blockIdx.y;
+    const int dir = blockIdx.z, rot = blockIdx.y, bx = x_begin + blockIdx.x;
+    if (dead && dead[rot]) return;
     const int nq = dir == 0 ? n : m;      // queries
     const int nc = dir == 0 ? m : n;      // candidates
-    const int q_base = blockIdx.x * (PS_THREADS * PS_Q);
+    const int q_base = bx * (PS_THREADS * PS_Q);
     if (q_base >= nq) return;
     Xform t;
     t.load(stats + (size_t)rot * PS_STAT);
@@ -254,8 +258,26 @@ __global__ __launch_bounds__(PS_THREADS) void pose_nn_kernel(
     if (threadIdx.x < 7) {
         float s = red[threadIdx.x][0];
         for (int w = 1; w < PS_THREADS / 64; w++) s += red[threadIdx.x][w];
-        partial[(((size_t)rot * 2 + dir) * gridDim.x + blockIdx.x) * PS_PART + threadIdx.x] = s;
+        partial[(((size_t)rot * 2 + dir) * blocks_x + bx) * PS_PART + threadIdx.x] = s;
     }
+}
+
+// A rotation whose first `done` query blocks alone already give (s0 / n + s1 / m) / 2 > best cannot win: acc >= s0 / n and
+// comp >= s1 / m (fixed-order sums of non-negative terms only grow; division, addition and halving are monotone under
+// rounding), so cd = (acc + comp) / 2 is at least that - strictly above the running best, so ties are not affected.  First batch of a search: best = +inf, nobody dies.
+__global__ __launch_bounds__(PS_THREADS) void pose_kill_kernel(const float *__restrict__ partial, int count, int n, int m,
+                                                               int blocks_x, int done, const float *__restrict__ best,
+                                                               int *__restrict__ dead,
+                                                               const float *__restrict__ lower_bound) {
+    if (batch_pruned(lower_bound, best)) return;
+    const int rot = threadIdx.x;
+    if (rot >= count) return;
+    const int nb[2] = {(n + PS_THREADS * PS_Q - 1) / (PS_THREADS * PS_Q), (m + PS_THREADS * PS_Q - 1) / (PS_THREADS * PS_Q)};
+    float s[2] = {0.f, 0.f};
+    for (int dir = 0; dir < 2; dir++)
+        for (int b = 0; b < min(done, nb[dir]); b++) s[dir] += partial[(((size_t)rot * 2 + dir) * blocks_x + b) * PS_PART];
+    const float bst = best[0];
+    if ((s[0] / (float)n + s[1] / (float)m) / 2.f > bst) dead[rot] = 1;
 }
 
 // ---- the same search through uniform grids (csrc/zs_point_grid.h): ~10^2 instead of 10^4 distance evaluations per
@@ -360,14 +382,20 @@ __device__ __forceinline__ float fscore_of(float precision, float recall) {
 // one workgroup per batch: per-rotation metrics (thread = rotation), then the batch winner
 __global__ __launch_bounds__(PS_THREADS) void pose_finish_kernel(
     const float *__restrict__ partial, int count, int n, int m, int blocks_x, const int *__restrict__ order,
-    int index_offset, float *__restrict__ best, const float *__restrict__ lower_bound) {
+    int index_offset, float *__restrict__ best, const float *__restrict__ lower_bound, const int *__restrict__ dead) {
     if (batch_pruned(lower_bound, best)) return;
     __shared__ float s_cd[PS_THREADS];
     __shared__ int s_idx[PS_THREADS];
+    __shared__ int s_alive;
     const int tid = threadIdx.x;
+    if (tid == 0) s_alive = 0;
+    __syncthreads();
     float cd = INFINITY, acc = 0.f, comp = 0.f, f[6];
     int gidx = 0x7fffffff;
-    if (tid < count) {
+    const bool alive = tid < count && !(dead && dead[tid]);
+    if (alive) atomicAdd(&s_alive, 1);
+    if (tid < count && !alive) gidx = (order ? order[tid] : tid) + index_offset;    // cd stays +inf
+    if (alive) {
         float tot[2][7];
         const int nb[2] = {(n + PS_THREADS * PS_Q - 1) / (PS_THREADS * PS_Q), (m + PS_THREADS * PS_Q - 1) / (PS_THREADS * PS_Q)};
         for (int dir = 0; dir < 2; dir++) {
@@ -405,7 +433,10 @@ __global__ __launch_bounds__(PS_THREADS) void pose_finish_kernel(
     const int win_idx = s_idx[0];
     __syncthreads();
     int *ibest = reinterpret_cast<int *>(best);
-    if (tid == 0) ibest[10] += count;   // rotations evaluated exactly (diagnostics)
+    if (tid == 0) {
+        ibest[10] += count;     // rotations of batches that the lower bounds did not prune (diagnostics)
+        ibest[11] += s_alive;   // ... of which scanned in full (the others lost after their first query block)
+    }
     if (tid < count && gidx == win_idx) {
         const float old_cd = best[0];
         const int old_idx = ibest[1];
@@ -462,7 +493,7 @@ extern "C" int zs_pose_max_batch(void) { return PS_THREADS; }
 
 extern "C" size_t zs_pose_scratch_bytes(int n, int m, int count) {
     if (n <= 0 || m <= 0 || count <= 0) return 0;
-    return ((size_t)count * PS_STAT + (size_t)count * 2 * blocks_x_of(n, m) * PS_PART) * sizeof(float);
+    return ((size_t)count * PS_STAT + (size_t)count * 2 * blocks_x_of(n, m) * PS_PART + (size_t)PS_THREADS) * sizeof(float);
 }
 
 extern "C" size_t zs_pose_best_bytes(void) { return PS_BEST * sizeof(float); }
@@ -512,10 +543,29 @@ extern "C" int zs_pose_search_batch(const float *pred, int n, const float *gt_no
     const int bx = blocks_x_of(n, m);
     hipLaunchKernelGGL(pose_stats_kernel, dim3(count), dim3(PS_THREADS), 0, st, pred, (size_t)0, n, rotations, order,
                        stats, lower_bound, best);
-    hipLaunchKernelGGL(pose_nn_kernel, dim3(bx, count, 2), dim3(PS_THREADS), 0, st, pred, n, gt_normalized, m, stats,
-                       thresholds6, partial, lower_bound, best);
+    // The query blocks are scanned in stages of 1, 2, 4 and the rest; after each stage the rotations whose partial sums
+    // already prove them worse than the running best are dropped (pose_kill_kernel).  Exact: a dropped rotation could
+    // not have won, and the survivors' sums are formed as before.  On an alignable ground truth most of the sphere dies
+    // after 5-15 % of its queries.
+    int *dead = reinterpret_cast<int *>(partial + (size_t)count * 2 * bx * PS_PART);
+    if (hipMemsetAsync(dead, 0, (size_t)PS_THREADS * sizeof(int), st) != hipSuccess) {
+        zs::set_err("zs_pose_search_batch: hipMemsetAsync failed");
+        return 0;
+    }
+    const int stage_end[4] = {1, 3, 7, bx};
+    int lo = 0;
+    for (int sidx = 0; sidx < 4 && lo < bx; sidx++) {
+        const int hi = stage_end[sidx] < bx ? stage_end[sidx] : bx;
+        if (hi <= lo) continue;
+        hipLaunchKernelGGL(pose_nn_kernel, dim3(hi - lo, count, 2), dim3(PS_THREADS), 0, st, pred, n, gt_normalized, m,
+                           stats, thresholds6, partial, lower_bound, best, lo, bx, static_cast<const int *>(dead));
+        if (hi < bx)
+            hipLaunchKernelGGL(pose_kill_kernel, dim3(1), dim3(PS_THREADS), 0, st, partial, count, n, m, bx, hi, best, dead,
+                               lower_bound);
+        lo = hi;
+    }
     hipLaunchKernelGGL(pose_finish_kernel, dim3(1), dim3(PS_THREADS), 0, st, partial, count, n, m, bx, order,
-                       index_offset, best, lower_bound);
+                       index_offset, best, lower_bound, static_cast<const int *>(dead));
     return zs::check_launch("zs_pose_search_batch") ? 1 : 0;
 }
 
@@ -566,7 +616,7 @@ extern "C" int zs_pose_search_batch_grid(const float *pred, int n, const float *
     hipLaunchKernelGGL(pose_nn_grid_kernel, dim3(bx, count, 2), dim3(PS_THREADS), 0, st, pred, n, gt_normalized, m, stats,
                        thresholds6, partial, gt_slot, pred_slots, sw, lower_bound, best);
     hipLaunchKernelGGL(pose_finish_kernel, dim3(1), dim3(PS_THREADS), 0, st, partial, count, n, m, bx, order,
-                       index_offset, best, lower_bound);
+                       index_offset, best, lower_bound, static_cast<const int *>(nullptr));
     return zs::check_launch("zs_pose_search_batch_grid") ? 1 : 0;
 }
 

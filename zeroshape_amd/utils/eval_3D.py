@@ -229,7 +229,8 @@ def _rotation_sphere(device):
 
 @torch.no_grad()
 def brute_force_search(pc_pred, pc_gt, f_thresholds=[0.005, 0.01, 0.02, 0.05, 0.1, 0.2], device="cuda",
-                       rotations=None, rot_slice=None, return_index=False, batch_size=192, prune=True, nn=None):
+                       rotations=None, rot_slice=None, return_index=False, batch_size=192, prune=True, nn=None,
+                       first_batch=None):
     """utils/eval_3D.py:140-170: best rigid alignment over the 6912-rotation sphere by
     Chamfer-L1, with the reference's first-strict-minimum rule (:161-168).
 
@@ -264,6 +265,7 @@ def brute_force_search(pc_pred, pc_gt, f_thresholds=[0.005, 0.01, 0.02, 0.05, 0.
     if stop <= start:
         raise ValueError("empty rotation range")
     batch_size = min(int(batch_size), lib.zs_pose_max_batch())
+    first_batch = min(batch_size, 32) if first_batch is None else max(1, min(int(first_batch), batch_size))
     K = stop - start
     n, m = pred.shape[0], pc_gt.shape[1]
     order = lb_sorted = None
@@ -294,8 +296,12 @@ def brute_force_search(pc_pred, pc_gt, f_thresholds=[0.005, 0.01, 0.02, 0.05, 0.
         _lib.check(lib.zs_pose_best_init(_lib.ptr(best), st), "zs_pose_best_init")
         if grids is not None:
             _lib.check(lib.zs_pose_gt_grid(_lib.ptr(pc_gt), m, _lib.ptr(grids), st), "zs_pose_gt_grid")
-        for pos in range(0, K, batch_size):
-            count = min(batch_size, K - pos)
+        # a small first batch: its winner lets the staged drop (csrc/pose_search.hip) thin out every later batch
+        starts, pos = [], 0
+        while pos < K:
+            starts.append((pos, min(first_batch if pos == 0 else batch_size, K - pos)))
+            pos += starts[-1][1]
+        for pos, count in starts:
             if order is not None:      # rotation b of the batch = rotations[start + order[pos + b]]
                 rc = launch(rot_base, order.data_ptr() + 4 * pos, count, start, lb_sorted.data_ptr() + 4 * pos)
             else:                      # index order
@@ -307,11 +313,12 @@ def brute_force_search(pc_pred, pc_gt, f_thresholds=[0.005, 0.01, 0.02, 0.05, 0.
                                _lib.ptr(scratch), st)
         _lib.check(rc, "zs_pose_apply")
     out = (best[2].clone(), best[3].clone(), best[4:4 + len(f_thresholds)].clone(), best_pred, pc_gt)
-    brute_force_search.last_evaluated = None
+    brute_force_search.last_evaluated = brute_force_search.last_scanned = None
     if return_index:
         rec = best.cpu()
         irec = rec.view(torch.int32)
-        brute_force_search.last_evaluated = int(irec[10])        # diagnostics: rotations evaluated exactly
+        brute_force_search.last_evaluated = int(irec[10])        # diagnostics: rotations the lower bounds let through
+        brute_force_search.last_scanned = int(irec[11])          # ... of which scanned in full (not killed by the probe)
         out = out + (int(irec[1]), float(rec[0]))
     return out
 
