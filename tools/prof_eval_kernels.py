@@ -26,8 +26,8 @@ for _ in range(5):
 for _ in range(5):
     ch(a, b, "grid")
 pred = torch.from_numpy(syn.ellipsoid_cloud(0, 10000)).to(dev)
-gt = (E._rotation_sphere(dev)[1234] @ pred.T).T.contiguous()
-E.brute_force_search(pred, gt, device=dev, prune=False)
+gt = torch.from_numpy(syn.seeded_cloud(9, 1, 10000)[0]).to(dev)      # unrelated: no rotation can be dropped early, full scans
+E.brute_force_search(pred, gt, device=dev, prune=False, first_batch=192)
 pe = get_2d_sincos_pos_embed(256, 14, cls_token=True).astype(np.float32)
 sd = {k: torch.from_numpy(v) for k, v in syn.seeded_state_dict(0, pos_embed=pe).items()}
 net = Implicit(196, latent_dim=256, n_channels=256, n_blocks_attn=2, n_layers_mlp=8, num_heads=8, skip_in=[2, 4, 6],
