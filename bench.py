@@ -295,6 +295,7 @@ def main():
         cpu = not args.no_cpu_baseline
         for name, fn in (("chamfer", lambda: legs.chamfer_leg(dev, cpu)), ("pose_search", lambda: legs.pose_search_leg(dev)),
                          ("chamfer_l1", lambda: legs.eval_leg(dev, net, sd)), ("encoder", lambda: legs.encoder_leg(dev, cpu)),
+                         ("inference", lambda: legs.inference_leg(dev)),
                          ("train_step", lambda: legs.train_leg(dev))):
             try:
                 extras[name] = fn()

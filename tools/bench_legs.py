@@ -213,6 +213,35 @@ def encoder_leg(dev, cpu=True):
     return out
 
 
+def inference_leg(dev):
+    """BASELINE config 2 ("shape_engine inference, synthetic 224x224 RGB + mask, vox_res=64", one image): image ->
+    latent (Graph.forward as one hipGraph) -> 65^3 occupancy grid (prologue + fused decoder), and the evaluation
+    setting of config 3 (vox_res 128) for comparison; milliseconds per image, HIP events."""
+    from zeroshape_amd import synthetic as syn
+    from zeroshape_amd.utils import eval_3D as E
+    from zeroshape_amd.utils.options import EasyDict as edict
+    opt, g = _graph(dev)
+    g.enable_hip_graph(True)
+    rgb, mask = [torch.from_numpy(x).to(dev) for x in syn.seeded_rgb_scene(0, 1)]
+    var = edict(dict(idx=[0], rgb_input_map=rgb, mask_input_map=mask))
+    out = {}
+    for N in (64, 128):
+        o = edict(dict(opt, eval=dict(vox_res=N, range=[-1.5, 1.5])))
+        o.device = str(dev)
+
+        def run():
+            v = g.forward(opt, var, training=False, get_loss=False)
+            v = v[0] if isinstance(v, tuple) else v
+            pts = E.get_dense_3D_grid(o, v, N)
+            return E.compute_level_grid(o, g.impl_network, v.latent_depth, None, pts, None)[0]
+        ms, mn = _events(run, 8)
+        out["vox%d" % N] = {"ms": round(ms, 3), "ms_min": round(mn, 3), "points": (N + 1) ** 3}
+    g.enable_hip_graph(False)
+    del g
+    torch.cuda.empty_cache()
+    return out
+
+
 def train_leg(dev, steps=8, warmup=3):
     """Runner.train_iteration (model/shape_engine.py:248-297) on BASELINE config 4's per-GPU batch: 4 images,
     4096 SDF samples each, fp32, forward + backward + fused AdamW."""
