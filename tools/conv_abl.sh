@@ -1,7 +1,7 @@
 #!/bin/bash
 # Ablation of the LDS-DMA convolution kernels: what does the kernel cost without its DMAs / its MFMAs?
 # Build the variants first (results are garbage, the timing is the point):
-#   for v in 'base' 'nodma -DZS_EXP_CONV_NO_DMA' 'nomfma -DZS_EXP_CONV_NO_MFMA' 'nosplit -DZS_EXP_CONV_NO_SPLIT'; do set -- $v; n=$1; shift;
+#   for v in 'base' 'nodma -DZS_EXP_CONV_NO_DMA' 'noa -DZS_EXP_CONV_NO_DMA_A' 'nob -DZS_EXP_CONV_NO_DMA_B' 'nomfma -DZS_EXP_CONV_NO_MFMA' 'nosplit -DZS_EXP_CONV_NO_SPLIT'; do set -- $v; n=$1; shift;
 #     python tools/build_variant_lib.py cv_$n nn_conv.hip zeroshape_amd/csrc/nn_conv.hip "$@"; done
 for f in tools/_timing/cv_*.so; do
   echo "== $f"

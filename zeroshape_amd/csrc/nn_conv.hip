@@ -495,14 +495,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DMA_NS == 2
                 g = (live && tw[h].ok) ? reinterpret_cast<const char *>(src[h] + tw[h].base + tw[h].cc + 4 * a_quad) : zero;
                 if (live) tw[h].advance(a, BK, pok[h], iy0[h], ix0[h]);
             }
-#ifndef ZS_EXP_CONV_NO_DMA
+#if !defined(ZS_EXP_CONV_NO_DMA) && !defined(ZS_EXP_CONV_NO_DMA_A)
             dma16(g, dst + h * 1024);
 #endif
         }
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const char *g = live ? reinterpret_cast<const char *>(wcol + (size_t)(ks_issue * KQ + wave) * a.CoutPad + 64 * h) : zero;
-#ifndef ZS_EXP_CONV_NO_DMA
+#if !defined(ZS_EXP_CONV_NO_DMA) && !defined(ZS_EXP_CONV_NO_DMA_B)
             dma16(g, dst_b + h * 1024);
 #endif
         }
