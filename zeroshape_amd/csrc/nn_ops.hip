@@ -11,6 +11,7 @@
 #include "../../include/zeroshape_hip.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 namespace {
@@ -47,6 +48,8 @@ __device__ __forceinline__ double block_sum_d(double v, double *lds) {
 
 // ---- GroupNorm over (HW x C/groups) of one sample, then affine, optional residual, optional ReLU ----
 constexpr int GN_BLOCK = 1024;
+constexpr int GN_CACHE_BYTES = 112 * 1024;     // a (sample, group) slice up to this size is read from HBM once
+// generic form: any group width, two passes over global memory
 __global__ __launch_bounds__(GN_BLOCK) void group_norm_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                          const float *__restrict__ beta,
                                                          const float *__restrict__ res, float *__restrict__ y,
@@ -76,6 +79,57 @@ __global__ __launch_bounds__(GN_BLOCK) void group_norm_kernel(const float *__res
     }
 }
 
+// Group width a power of two (every layer of the encoders: 2, 8, 16, 32, 64 channels per group): VEC-wide loads
+// (VEC = min(4, cg)), pixel / channel split by shift and mask instead of a division per element, and - CACHE - the
+// slice kept in LDS between the statistics pass and the output pass (<= 112 KiB: all of the encoders' layers up to
+// batch-independent 56 x 56 x 8-channel slices), so x is read from HBM once.  Same formulae, double sums.
+template <int VEC, bool CACHE>
+__global__ __launch_bounds__(GN_BLOCK) void group_norm_pow2_kernel(const float *__restrict__ x,
+                                                                   const float *__restrict__ gamma,
+                                                                   const float *__restrict__ beta,
+                                                                   const float *__restrict__ res, float *__restrict__ y,
+                                                                   int HW, int C, int groups, int cgv_shift, float eps,
+                                                                   int relu) {
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    extern __shared__ __attribute__((aligned(16))) float gn_cache[];
+    __shared__ double ldsd[GN_BLOCK / 64];
+    const int b = blockIdx.x / groups, g = blockIdx.x % groups, cg = C / groups;
+    const int nv = (HW * cg) / VEC, cgv_mask = (1 << cgv_shift) - 1;          // cg / VEC = 1 << cgv_shift vectors per pixel
+    const size_t base = (size_t)b * HW * C + (size_t)g * cg;
+    auto at = [&](int ev) -> size_t { return base + (size_t)(ev >> cgv_shift) * C + (size_t)(ev & cgv_mask) * VEC; };
+    double s = 0.0, q = 0.0;
+    for (int ev = threadIdx.x; ev < nv; ev += GN_BLOCK) {
+        const vec_t v = *reinterpret_cast<const vec_t *>(x + at(ev));
+        if (CACHE) reinterpret_cast<vec_t *>(gn_cache)[ev] = v;
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+            const float f = VEC == 1 ? ((const float *)&v)[0] : v[i];
+            s += f;
+            q += (double)f * f;
+        }
+    }
+    const double S = block_sum_d(s, ldsd), Q = block_sum_d(q, ldsd);
+    const double n = (double)HW * cg, mean_d = S / n;
+    double var = Q / n - mean_d * mean_d;
+    var = var < 0.0 ? 0.0 : var;
+    const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int ev = threadIdx.x; ev < nv; ev += GN_BLOCK) {
+        const size_t o = at(ev);
+        const int c = g * cg + (ev & cgv_mask) * VEC;
+        const vec_t xv = CACHE ? reinterpret_cast<const vec_t *>(gn_cache)[ev] : *reinterpret_cast<const vec_t *>(x + o);
+        const vec_t ga = *reinterpret_cast<const vec_t *>(gamma + c), be = *reinterpret_cast<const vec_t *>(beta + c);
+        vec_t v = (xv - mean) * rstd * ga + be;
+        if (res) v += *reinterpret_cast<const vec_t *>(res + o);
+        if (relu)
+#pragma unroll
+            for (int i = 0; i < VEC; i++) {
+                if (VEC == 1) ((float *)&v)[0] = fmaxf(((float *)&v)[0], 0.f);
+                else v[i] = fmaxf(v[i], 0.f);
+            }
+        *reinterpret_cast<vec_t *>(y + o) = v;
+    }
+}
+
 // ---- LayerNorm over the last dimension, one wave per row ----
 __global__ __launch_bounds__(256) void layer_norm_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                          const float *__restrict__ beta, float *__restrict__ y,
@@ -90,6 +144,39 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float *__restrict
     for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; q += d * d; }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / C + eps);
     for (int c = lane; c < C; c += 64) y[(size_t)row * C + c] = (xr[c] - mean) * rstd * gamma[c] + beta[c];
+}
+// C % 4 == 0 and C <= 256 NV: the row stays in registers (NV float4 per lane) between the three sweeps - one read of x
+template <int NV>
+__global__ __launch_bounds__(256) void layer_norm_reg_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta, float *__restrict__ y,
+                                                             int rows, int C, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, nq = C >> 2;
+    if (row >= rows) return;
+    const f32x4 *xr = reinterpret_cast<const f32x4 *>(x + (size_t)row * C);
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const int idx = lane + 64 * i;
+        v[i] = idx < nq ? xr[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; i++)
+        if (lane + 64 * i < nq) {
+            const f32x4 d = v[i] - mean;
+            q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / C + eps);
+    f32x4 *yr = reinterpret_cast<f32x4 *>(y + (size_t)row * C);
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const int idx = lane + 64 * i;
+        if (idx < nq)
+            yr[idx] = (v[i] - mean) * rstd * reinterpret_cast<const f32x4 *>(gamma)[idx] + reinterpret_cast<const f32x4 *>(beta)[idx];
+    }
 }
 
 // ---- attention on the MFMA pipe: one wave per (sample, head, 32-query tile) ----
@@ -301,8 +388,36 @@ extern "C" int zs_group_norm_nhwc(const float *x, const float *gamma, const floa
                "zs_group_norm_nhwc: bad size (B=%d HW=%d C=%d groups=%d)", batch, HW, C, groups);
     if (batch == 0) return 1;
     ZS_REQUIRE(x && gamma && beta && y, "zs_group_norm_nhwc: null pointer");
-    hipLaunchKernelGGL(group_norm_kernel, dim3(batch * groups), dim3(GN_BLOCK), 0, S(stream), x, gamma, beta, residual, y,
-                       HW, C, groups, eps, relu);
+    const int cg = C / groups;
+    const bool pow2 = (cg & (cg - 1)) == 0 && (long long)HW * cg < (1LL << 30);
+    static const bool gn_generic = getenv("ZS_GN_GENERIC") != nullptr;         // A/B switch for measurements
+    if (!pow2 || gn_generic) {
+        hipLaunchKernelGGL(group_norm_kernel, dim3(batch * groups), dim3(GN_BLOCK), 0, S(stream), x, gamma, beta, residual,
+                           y, HW, C, groups, eps, relu);
+        return zs::check_launch("zs_group_norm_nhwc") ? 1 : 0;
+    }
+    const int vec = cg >= 4 ? 4 : cg;
+    int shift = 0;
+    while ((vec << shift) < cg) shift++;
+    const size_t bytes = (size_t)HW * cg * sizeof(float);
+    const bool cache = bytes <= (size_t)GN_CACHE_BYTES;
+#define ZS_GN_LAUNCH(V, CA)                                                                                          \
+    do {                                                                                                             \
+        if (CA) {                                                                                                    \
+            static bool once = false;                                                                                \
+            if (!once) {                                                                                             \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(group_norm_pow2_kernel<V, CA>),            \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, GN_CACHE_BYTES);               \
+                once = true;                                                                                         \
+            }                                                                                                        \
+        }                                                                                                            \
+        hipLaunchKernelGGL((group_norm_pow2_kernel<V, CA>), dim3(batch * groups), dim3(GN_BLOCK), (CA) ? bytes : 0,  \
+                           S(stream), x, gamma, beta, residual, y, HW, C, groups, shift, eps, relu);                 \
+    } while (0)
+    if (vec == 4) { if (cache) ZS_GN_LAUNCH(4, true); else ZS_GN_LAUNCH(4, false); }
+    else if (vec == 2) { if (cache) ZS_GN_LAUNCH(2, true); else ZS_GN_LAUNCH(2, false); }
+    else { if (cache) ZS_GN_LAUNCH(1, true); else ZS_GN_LAUNCH(1, false); }
+#undef ZS_GN_LAUNCH
     return zs::check_launch("zs_group_norm_nhwc") ? 1 : 0;
 }
 
@@ -311,8 +426,15 @@ extern "C" int zs_layer_norm(const float *x, const float *gamma, const float *be
     ZS_REQUIRE(rows >= 0 && C > 0, "zs_layer_norm: bad size (rows=%d C=%d)", rows, C);
     if (rows == 0) return 1;
     ZS_REQUIRE(x && gamma && beta && y, "zs_layer_norm: null pointer");
-    hipLaunchKernelGGL(layer_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, S(stream), x, gamma, beta, y, rows, C,
-                       eps);
+    const dim3 grid((rows + 3) / 4);
+    if ((C & 3) == 0 && C <= 256)
+        hipLaunchKernelGGL(layer_norm_reg_kernel<1>, grid, dim3(256), 0, S(stream), x, gamma, beta, y, rows, C, eps);
+    else if ((C & 3) == 0 && C <= 512)
+        hipLaunchKernelGGL(layer_norm_reg_kernel<2>, grid, dim3(256), 0, S(stream), x, gamma, beta, y, rows, C, eps);
+    else if ((C & 3) == 0 && C <= 1024)
+        hipLaunchKernelGGL(layer_norm_reg_kernel<4>, grid, dim3(256), 0, S(stream), x, gamma, beta, y, rows, C, eps);
+    else
+        hipLaunchKernelGGL(layer_norm_kernel, grid, dim3(256), 0, S(stream), x, gamma, beta, y, rows, C, eps);
     return zs::check_launch("zs_layer_norm") ? 1 : 0;
 }
 
