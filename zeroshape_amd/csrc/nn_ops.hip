@@ -304,6 +304,26 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float *__restrict
     y[i] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
 }
 
+// the same, four channels per lane and no 64-bit divisions: grid (ceil(Wout * C / 4 / 256), Hout, B)
+__global__ __launch_bounds__(256) void upsample2x_vec_kernel(const float *__restrict__ x, float *__restrict__ y, int Hin,
+                                                             int Win, int C) {
+    const int Hout = 2 * Hin, Wout = 2 * Win, cq = C >> 2;
+    const int j = blockIdx.x * 256 + threadIdx.x;                  // (ox, channel quad)
+    if (j >= Wout * cq) return;
+    const int ox = j / cq, c = (j - ox * cq) * 4, oy = blockIdx.y, b = blockIdx.z;
+    const float sy = Hout > 1 ? (float)(Hin - 1) / (float)(Hout - 1) : 0.f, sx = Wout > 1 ? (float)(Win - 1) / (float)(Wout - 1) : 0.f;
+    const float fy = sy * oy, fx = sx * ox;
+    const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + (y0 < Hin - 1 ? 1 : 0), x1 = x0 + (x0 < Win - 1 ? 1 : 0);
+    const float ly = fy - y0, lx = fx - x0;
+    const float *X = x + (size_t)b * Hin * Win * C + c;
+    const f32x4 v00 = *reinterpret_cast<const f32x4 *>(X + ((size_t)y0 * Win + x0) * C),
+                v01 = *reinterpret_cast<const f32x4 *>(X + ((size_t)y0 * Win + x1) * C),
+                v10 = *reinterpret_cast<const f32x4 *>(X + ((size_t)y1 * Win + x0) * C),
+                v11 = *reinterpret_cast<const f32x4 *>(X + ((size_t)y1 * Win + x1) * C);
+    *reinterpret_cast<f32x4 *>(y + (((size_t)b * Hout + oy) * Wout + ox) * C + c) =
+        (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+}
+
 // NCHW [B][C][H][W] -> NHWC [B][H][W][Cpad] (extra channels zero), optionally times mask [B][HW]
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restrict__ x,
                                                            const float *__restrict__ mask, float *__restrict__ y,
@@ -477,8 +497,12 @@ extern "C" int zs_upsample2x_nhwc(const float *x, float *y, int batch, int Hin, 
     ZS_REQUIRE(batch >= 0 && Hin > 0 && Win > 0 && C > 0, "zs_upsample2x_nhwc: bad size");
     if (batch == 0) return 1;
     ZS_REQUIRE(x && y, "zs_upsample2x_nhwc: null pointer");
-    hipLaunchKernelGGL(upsample2x_kernel, dim3(blocks_for((size_t)batch * 4 * Hin * Win * C)), dim3(256), 0, S(stream),
-                       x, y, batch, Hin, Win, C);
+    if ((C & 3) == 0 && 2 * Hin <= 65535 && batch <= 65535 && (long long)2 * Win * (C / 4) < (1LL << 30))
+        hipLaunchKernelGGL(upsample2x_vec_kernel, dim3((unsigned)((2 * Win * (C / 4) + 255) / 256), 2 * Hin, batch), dim3(256),
+                           0, S(stream), x, y, Hin, Win, C);
+    else
+        hipLaunchKernelGGL(upsample2x_kernel, dim3(blocks_for((size_t)batch * 4 * Hin * Win * C)), dim3(256), 0, S(stream),
+                           x, y, batch, Hin, Win, C);
     return zs::check_launch("zs_upsample2x_nhwc") ? 1 : 0;
 }
 
