@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 25
+#define ZS_ABI_VERSION 26
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -399,6 +399,9 @@ int zs_group_norm_nhwc(const float *x, const float *gamma, const float *beta, co
 int zs_layer_norm(const float *x, const float *gamma, const float *beta, float *y, int rows, int C, float eps,
                   void *stream);
 int zs_attention(const float *qkv, float *out, int batch, int L, int heads, int head_dim, void *stream);
+/* zs_attention in split-fp16 arithmetic (three 16-bit MFMAs per product, ~2^-21 relative; csrc/zs_split16.h): the
+ * inference encoders' default, like ZS_CONV_F16X3 for the convolutions. */
+int zs_attention_split(const float *qkv, float *out, int batch, int L, int heads, int head_dim, void *stream);
 int zs_max_pool_nhwc(const float *x, float *y, int batch, int Hin, int Win, int C, int Hout, int Wout, int k,
                      int stride, int pad_t, int pad_l, void *stream);
 int zs_global_mean_nhwc(const float *x, float *y, int batch, int HW, int C, void *stream);

@@ -169,7 +169,15 @@ def test_attention(L, heads, d):
     q, k, v = qkv.reshape(2, L, 3, heads, d).permute(2, 0, 3, 1, 4)
     attn = ((q * d ** -0.5) @ k.transpose(-2, -1)).softmax(-1)
     want = (attn @ v).transpose(1, 2).reshape(2, L, C)
-    close(ops.attention(qkv.cuda(), heads), want)
+    prev = ops.CONV_PRECISION
+    try:
+        for prec in ("f32", "f16x3"):              # zs_attention (fp32 MFMA) and zs_attention_split (three fp16 MFMAs)
+            ops.set_conv_precision(prec)
+            close(ops.attention(qkv.cuda(), heads), want)
+            close(ops.attention((qkv * 4.0).cuda(), heads),
+                  (((q * 4 * d ** -0.5) @ (k * 4).transpose(-2, -1)).softmax(-1) @ (v * 4)).transpose(1, 2).reshape(2, L, C))
+    finally:
+        ops.set_conv_precision(prev)
 
 
 def test_pooling_and_resampling():

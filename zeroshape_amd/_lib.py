@@ -91,6 +91,7 @@ SIGNATURES = {
                                                       _c_void_p]),
     "zs_layer_norm": (_c_int, [_c_void_p] * 4 + [_c_int, _c_int, ctypes.c_float, _c_void_p]),
     "zs_attention": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
+    "zs_attention_split": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
     "zs_max_pool_nhwc": (_c_int, [_c_void_p, _c_void_p] + [_c_int] * 10 + [_c_void_p]),
     "zs_global_mean_nhwc": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
     "zs_upsample2x_nhwc": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
@@ -155,7 +156,7 @@ SIGNATURES = {
     "zs_readout_concat_bwd": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
 }
 
-ABI_VERSION = 25
+ABI_VERSION = 26
 _lib = None
 
 

@@ -8,6 +8,7 @@
 //   NCHW <-> NHWC                  boundary conversions (the reference's tensors are NCHW)
 //   token assembly / readout cat   model/depth/vit.py:127-148 / :31-43
 #include "zs_common.h"
+#include "zs_split16.h"
 #include "../../include/zeroshape_hip.h"
 
 #include <math.h>
@@ -17,6 +18,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -261,6 +263,104 @@ __global__ __launch_bounds__(64) void attention_kernel(const float *__restrict__
     }
 }
 
+// The same attention in split-fp16 arithmetic (csrc/zs_split16.h: every product as three 16-bit MFMAs on hi / lo
+// operand halves, ~2^-21 relative): 24 K = 16 MFMAs of 32 cycles per key tile instead of 64 K = 2 ones of 64.  The
+// transposed formulation survives the wider contraction step because a lane's eight k values of one step may be any
+// eight, as long as both operands use the same: for S^T they are two of the d quads it loads anyway, for O^T the keys
+// of accumulator registers 8 s .. 8 s + 7 - the probabilities never leave the lane that computed them.
+template <int D>
+__global__ __launch_bounds__(64) void attention_split_kernel(const float *__restrict__ qkv, float *__restrict__ out, int L,
+                                                             int heads, float scale) {
+    using zs::s16::mfma3;
+    using zs::s16::split8;
+    constexpr int DS = D / 16;                // K = 16 steps along d
+    constexpr int DT = D / 32;                // 32-row tiles of O^T
+    const int lane = threadIdx.x, l32 = lane & 31, half = lane >> 5;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads, C = heads * D, q0 = blockIdx.y * 32;
+    const float *base = qkv + (size_t)b * L * 3 * C + h * D;
+    const int qrow = min(q0 + l32, L - 1);
+    u32x4 qh[DS], ql[DS];                     // step s: d quads 4 s + half and 4 s + 2 + half of the query row, scaled
+#pragma unroll
+    for (int t = 0; t < DS; t++) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(base + (size_t)qrow * 3 * C + 4 * (4 * t + half)) * scale;
+        const f32x4 a1 = *reinterpret_cast<const f32x4 *>(base + (size_t)qrow * 3 * C + 4 * (4 * t + 2 + half)) * scale;
+        split8(a0, a1, qh[t], ql[t]);
+    }
+    f32x16 o[DT];
+#pragma unroll
+    for (int i = 0; i < DT; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[i][r] = 0.f;
+    float mx = -INFINITY, den = 0.f;
+    for (int k0 = 0; k0 < L; k0 += 32) {
+        const int krow = min(k0 + l32, L - 1);
+        f32x16 sT;
+#pragma unroll
+        for (int r = 0; r < 16; r++) sT[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < DS; t++) {
+            const f32x4 k0q = *reinterpret_cast<const f32x4 *>(base + (size_t)krow * 3 * C + C + 4 * (4 * t + half));
+            const f32x4 k1q = *reinterpret_cast<const f32x4 *>(base + (size_t)krow * 3 * C + C + 4 * (4 * t + 2 + half));
+            u32x4 kh, kl;
+            split8(k0q, k1q, kh, kl);
+            mfma3(sT, kh, kl, qh[t], ql[t]);
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int key = k0 + 8 * (r >> 2) + 4 * half + (r & 3);
+            sT[r] = key < L ? sT[r] : -INFINITY;
+            tmax = fmaxf(tmax, sT[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float nm = fmaxf(mx, tmax), corr = __expf(mx - nm);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            sT[r] = __expf(sT[r] - nm);
+            psum += sT[r];
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        den = den * corr + psum;
+        mx = nm;
+        // O^T += V^T P^T: step s contracts the keys of accumulator registers 8 s .. 8 s + 7
+        u32x4 ph[2], pl[2];
+#pragma unroll
+        for (int sidx = 0; sidx < 2; sidx++)
+            split8(f32x4{sT[8 * sidx], sT[8 * sidx + 1], sT[8 * sidx + 2], sT[8 * sidx + 3]},
+                   f32x4{sT[8 * sidx + 4], sT[8 * sidx + 5], sT[8 * sidx + 6], sT[8 * sidx + 7]}, ph[sidx], pl[sidx]);
+#pragma unroll
+        for (int i = 0; i < DT; i++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[i][r] *= corr;
+#pragma unroll
+            for (int sidx = 0; sidx < 2; sidx++) {
+                float vf[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int r = 8 * sidx + e;
+                    const int key = min(k0 + 8 * (r >> 2) + 4 * half + (r & 3), L - 1);
+                    vf[e] = base[(size_t)key * 3 * C + 2 * C + 32 * i + l32];
+                }
+                u32x4 vh, vl;
+                split8(f32x4{vf[0], vf[1], vf[2], vf[3]}, f32x4{vf[4], vf[5], vf[6], vf[7]}, vh, vl);
+                mfma3(o[i], vh, vl, ph[sidx], pl[sidx]);
+            }
+        }
+    }
+    if (q0 + l32 < L) {
+        const float inv = 1.0f / den;
+        float *dst = out + ((size_t)b * L + q0 + l32) * C + h * D;
+#pragma unroll
+        for (int i = 0; i < DT; i++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const f32x4 v = {o[i][4 * g] * inv, o[i][4 * g + 1] * inv, o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv};
+                *reinterpret_cast<f32x4 *>(dst + 32 * i + 8 * g + 4 * half) = v;
+            }
+    }
+}
+
 // ---- pooling / resampling / layout ----
 __global__ __launch_bounds__(256) void max_pool_kernel(const float *__restrict__ x, float *__restrict__ y, int B,
                                                        int Hin, int Win, int C, int Hout, int Wout, int k, int stride,
@@ -456,6 +556,22 @@ extern "C" int zs_layer_norm(const float *x, const float *gamma, const float *be
     else
         hipLaunchKernelGGL(layer_norm_kernel, grid, dim3(256), 0, S(stream), x, gamma, beta, y, rows, C, eps);
     return zs::check_launch("zs_layer_norm") ? 1 : 0;
+}
+
+extern "C" int zs_attention_split(const float *qkv, float *out, int batch, int L, int heads, int head_dim, void *stream) {
+    ZS_REQUIRE(batch >= 0 && L > 0 && heads > 0 && (head_dim == 32 || head_dim == 64),
+               "zs_attention_split: bad size (B=%d L=%d heads=%d head_dim=%d; head_dim must be 32 or 64)", batch, L, heads,
+               head_dim);
+    if (batch == 0) return 1;
+    ZS_REQUIRE(qkv && out, "zs_attention_split: null pointer");
+    const float scale = 1.0f / sqrtf((float)head_dim);
+    ZS_REQUIRE(L <= 32 * 65535, "zs_attention_split: L = %d too long", L);
+    const dim3 grid(batch * heads, (L + 31) / 32);
+    if (head_dim == 64)
+        hipLaunchKernelGGL(attention_split_kernel<64>, grid, dim3(64), 0, S(stream), qkv, out, L, heads, scale);
+    else
+        hipLaunchKernelGGL(attention_split_kernel<32>, grid, dim3(64), 0, S(stream), qkv, out, L, heads, scale);
+    return zs::check_launch("zs_attention_split") ? 1 : 0;
 }
 
 extern "C" int zs_attention(const float *qkv, float *out, int batch, int L, int heads, int head_dim, void *stream) {

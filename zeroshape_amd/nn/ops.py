@@ -146,8 +146,8 @@ def attention(qkv, heads):
     C = C3 // 3
     out = torch.empty(B, L, C, dtype=torch.float32, device=qkv.device)
     with torch.cuda.device(qkv.device):
-        _lib.check(lib.zs_attention(_lib.ptr(qkv), _lib.ptr(out), B, L, heads, C // heads, _stream(qkv)),
-                   "zs_attention")
+        fn = lib.zs_attention_split if CONV_PRECISION == "f16x3" else lib.zs_attention
+        _lib.check(fn(_lib.ptr(qkv), _lib.ptr(out), B, L, heads, C // heads, _stream(qkv)), "zs_attention")
     return out
 
 
