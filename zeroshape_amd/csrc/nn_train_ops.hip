@@ -8,6 +8,7 @@
 #include "../../include/zeroshape_hip.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 namespace {
@@ -243,6 +244,98 @@ __global__ __launch_bounds__(256) void attention_bwd_rows_kernel(const float *__
     }
 }
 
+// pass 1 on the MFMA pipe (L <= 256): one wave per (b, h, 32-query tile), transposed like the forward kernel
+// (csrc/nn_ops.hip): S^T[key][query] = K Q^T and dP^T[key][query] = V dO^T for all key tiles stay in the accumulators
+// (2 x 8 tiles x 16 registers), the softmax statistics and delta = sum_j P dP are sums over a lane's registers + its
+// partner half; P and dS = P (dP - delta) leave as float4 row segments.  Replaces attention_bwd_rows_kernel, whose dot
+// products run on the vector ALU with one LDS read per multiply-add (103 us per ViT block at batch 4).
+constexpr int ATT_MFMA_TILES = 8;
+template <int D>
+__global__ __launch_bounds__(64) void attention_bwd_probs_kernel(const float *__restrict__ qkv,
+                                                                 const float *__restrict__ dout,
+                                                                 float *__restrict__ Pbuf, float *__restrict__ dSbuf,
+                                                                 int L, int heads, float scale) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int DQ = D / 8;
+    const int lane = threadIdx.x, l32 = lane & 31, half = lane >> 5;
+    const int bh = blockIdx.x, h = bh % heads, b = bh / heads, C = heads * D, q0 = blockIdx.y * 32;
+    const int LT = (L + 31) / 32;
+    const float *base = qkv + (size_t)b * L * 3 * C + h * D;
+    const int qrow = min(q0 + l32, L - 1);
+    f32x4 qf[DQ], gf[DQ];
+#pragma unroll
+    for (int t = 0; t < DQ; t++) {
+        qf[t] = *reinterpret_cast<const f32x4 *>(base + (size_t)qrow * 3 * C + 4 * (2 * t + half)) * scale;
+        gf[t] = *reinterpret_cast<const f32x4 *>(dout + ((size_t)b * L + qrow) * C + h * D + 4 * (2 * t + half));
+    }
+    f32x16 sT[ATT_MFMA_TILES], dT[ATT_MFMA_TILES];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < ATT_MFMA_TILES; kt++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) { sT[kt][r] = -INFINITY; dT[kt][r] = 0.f; }
+        if (kt < LT) {
+            const int krow = min(kt * 32 + l32, L - 1);
+            f32x16 a, c;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { a[r] = 0.f; c[r] = 0.f; }
+#pragma unroll
+            for (int t = 0; t < DQ; t++) {
+                const f32x4 kf = *reinterpret_cast<const f32x4 *>(base + (size_t)krow * 3 * C + C + 4 * (2 * t + half));
+                const f32x4 vf = *reinterpret_cast<const f32x4 *>(base + (size_t)krow * 3 * C + 2 * C + 4 * (2 * t + half));
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++) {
+                    a = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s4], qf[t][s4], a, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[s4], gf[t][s4], c, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int key = kt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+                sT[kt][r] = key < L ? a[r] : -INFINITY;
+                dT[kt][r] = c[r];
+                mx = fmaxf(mx, sT[kt][r]);
+            }
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float den = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < ATT_MFMA_TILES; kt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            sT[kt][r] = expf(sT[kt][r] - mx);          // exp(-inf) = 0 for padded keys / unused tiles
+            den += sT[kt][r];
+        }
+    den += __shfl_xor(den, 32, 64);
+    const float inv = 1.0f / den;
+    float delta = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < ATT_MFMA_TILES; kt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            sT[kt][r] *= inv;
+            delta += sT[kt][r] * dT[kt][r];
+        }
+    delta += __shfl_xor(delta, 32, 64);
+    if (q0 + l32 >= L) return;
+    float *Prow = Pbuf + ((size_t)bh * L + q0 + l32) * L, *dSrow = dSbuf + ((size_t)bh * L + q0 + l32) * L;
+#pragma unroll
+    for (int kt = 0; kt < ATT_MFMA_TILES; kt++)
+        if (kt < LT)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int key0 = kt * 32 + 8 * g + 4 * half;
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (key0 + e < L) {
+                        const float pv = sT[kt][4 * g + e];
+                        Prow[key0 + e] = pv;
+                        dSrow[key0 + e] = pv * (dT[kt][4 * g + e] - delta);
+                    }
+            }
+}
+
 template <int D>
 __global__ __launch_bounds__(64) void attention_bwd_mfma_kernel(const float *__restrict__ qkv,
                                                                 const float *__restrict__ dout, float *__restrict__ dqkv,
@@ -452,6 +545,21 @@ extern "C" int zs_attention_bwd(const float *qkv, const float *dout, float *dqkv
         hipFuncSetAttribute(reinterpret_cast<const void *>(attention_bwd_rows_kernel<32>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
+    }
+    static const bool rows_valu = getenv("ZS_ATTN_BWD_VALU") != nullptr;     // A/B switch: the vector-ALU pass 1
+    if (L <= 32 * ATT_MFMA_TILES && !rows_valu) {
+        const dim3 gridp(BH, (L + 31) / 32);
+        if (head_dim == 64)
+            hipLaunchKernelGGL(attention_bwd_probs_kernel<64>, gridp, dim3(64), 0, S(stream), qkv, dout, P, dS, L, heads, scale);
+        else
+            hipLaunchKernelGGL(attention_bwd_probs_kernel<32>, gridp, dim3(64), 0, S(stream), qkv, dout, P, dS, L, heads, scale);
+        if (head_dim == 64)
+            hipLaunchKernelGGL(attention_bwd_mfma_kernel<64>, grid2, dim3(64), 0, S(stream), qkv, dout, dqkv, P, dS, L, heads,
+                               scale);
+        else
+            hipLaunchKernelGGL(attention_bwd_mfma_kernel<32>, grid2, dim3(64), 0, S(stream), qkv, dout, dqkv, P, dS, L, heads,
+                               scale);
+        return zs::check_launch("zs_attention_bwd") ? 1 : 0;
     }
     if (head_dim == 64) {
         hipLaunchKernelGGL(attention_bwd_rows_kernel<64>, grid1, dim3(256), lds, S(stream), qkv, dout, P, dS, L, heads, scale);
