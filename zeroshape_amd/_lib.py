@@ -3,6 +3,7 @@
 There is NO fallback: if the library is missing or a symbol is absent this module
 raises, and every product entry point that needs the GPU path raises with it.
 """
+import contextlib
 import ctypes
 import os
 
@@ -204,5 +205,23 @@ def ptr(t):
 
 
 def current_stream_ptr(device=None):
+    """The HIP stream torch would launch on for `device` right now, as a ctypes pointer (the raw-stream query: a third
+    of the cost of torch.cuda.current_stream(...).cuda_stream - it is paid once per launch, ~2,000 times per training step)."""
     import torch
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    idx = getattr(device, "index", device)
+    if idx is None:
+        idx = torch.cuda.current_device()
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(idx))
+
+
+_NULL_GUARD = contextlib.nullcontext()
+
+
+def on(device):
+    """`with _lib.on(t.device):` = `with torch.cuda.device(t.device):` without the context switch when that device is
+    already current (one process per GPU: always) - 0.4 instead of 1.4 us per launch on the host."""
+    import torch
+    idx = getattr(device, "index", device)
+    if idx is None or idx == torch.cuda.current_device():
+        return _NULL_GUARD
+    return torch.cuda.device(device)

@@ -207,14 +207,14 @@ class Implicit(nn.Module):
         programs = template.unsqueeze(0).repeat(B, 1)
         scratch = torch.empty(B * (lib.zs_sdf_prologue_scratch_bytes() // 4), dtype=torch.float32,
                               device=lat.device)
-        with torch.cuda.device(lat.device):
+        with _lib.on(lat.device):
             rc = lib.zs_sdf_prologue(_lib.ptr(programs), programs.stride(0) * 4, _lib.ptr(lat_params),
                                      _lib.ptr(lat), B, _lib.ptr(scratch),
                                      _lib.current_stream_ptr(lat.device))
         _lib.check(rc, "zs_sdf_prologue")
         if precision == "f16x3" and self.split_allowed(lat.device):
             split = torch.empty_like(programs)
-            with torch.cuda.device(lat.device):
+            with _lib.on(lat.device):
                 rc = lib.zs_sdf_split_programs(_lib.ptr(programs), programs.stride(0) * 4, _lib.ptr(split),
                                                split.stride(0) * 4, B, _lib.current_stream_ptr(lat.device))
             _lib.check(rc, "zs_sdf_split_programs")
@@ -244,7 +244,7 @@ class Implicit(nn.Module):
                 raise ValueError("the attention map needs an fp32 DecoderState (prepare(..., precision='f32'))")
             flags = self._tile_flags(state.batch, M, pts.device)
             ws, st = _lib.ptr(self.workspace(pts.device)), _lib.current_stream_ptr(pts.device)
-            with torch.cuda.device(pts.device):
+            with _lib.on(pts.device):
                 rc = lib.zs_sdf_query_points_split(_lib.ptr(state.programs), state.stride_bytes, state.batch,
                                                    _lib.ptr(pts), M, _lib.ptr(out), _lib.ptr(flags), ws, st)
                 _lib.check(rc, "zs_sdf_query_points_split")
@@ -258,7 +258,7 @@ class Implicit(nn.Module):
         if need_attn:
             attn = torch.empty(state.batch, M, P.L, dtype=torch.float32, device=pts.device)
             extra = lib.zs_sdf_attn_scratch_bytes(state.batch, M)
-        with torch.cuda.device(pts.device):
+        with _lib.on(pts.device):
             rc = lib.zs_sdf_query_points(_lib.ptr(state.programs), state.stride_bytes, state.batch,
                                          _lib.ptr(pts), M, _lib.ptr(out), _lib.ptr(attn), None,
                                          _lib.ptr(self.workspace(pts.device, extra)),
@@ -285,7 +285,7 @@ class Implicit(nn.Module):
         if state.precision == "f16x3":
             flags = self._tile_flags(state.batch, (slice_end - slice_begin) * G * G, axis.device)
             ws, st = _lib.ptr(self.workspace(axis.device)), _lib.current_stream_ptr(axis.device)
-            with torch.cuda.device(axis.device):
+            with _lib.on(axis.device):
                 rc = lib.zs_sdf_query_grid_split(_lib.ptr(state.programs), state.stride_bytes, state.batch,
                                                  _lib.ptr(axis), G, slice_begin, slice_end,
                                                  1 if apply_sigmoid else 0, _lib.ptr(out), _lib.ptr(flags), ws, st)
@@ -297,7 +297,7 @@ class Implicit(nn.Module):
             _lib.check(rc, "zs_sdf_query_grid")
             self.last_tile_flags = flags
             return out
-        with torch.cuda.device(axis.device):
+        with _lib.on(axis.device):
             rc = lib.zs_sdf_query_grid(_lib.ptr(state.programs), state.stride_bytes, state.batch,
                                        _lib.ptr(axis), G, slice_begin, slice_end,
                                        1 if apply_sigmoid else 0, _lib.ptr(out), None,
@@ -320,7 +320,7 @@ class Implicit(nn.Module):
         out = torch.empty(state.batch, point_end - point_begin, dtype=torch.float32, device=axis.device)
         ws, st = _lib.ptr(self.workspace(axis.device)), _lib.current_stream_ptr(axis.device)
         sig = 1 if apply_sigmoid else 0
-        with torch.cuda.device(axis.device):
+        with _lib.on(axis.device):
             if state.precision == "f16x3":
                 flags = self._tile_flags(state.batch, point_end - point_begin, axis.device)
                 rc = lib.zs_sdf_query_grid_range_split(_lib.ptr(state.programs), state.stride_bytes, state.batch,

@@ -89,7 +89,7 @@ def standardize(weight, eps):
     if rec[3] != _stamp(weight):
         lib = _lib.load()
         w = weight.detach()
-        with torch.cuda.device(w.device):
+        with _lib.on(w.device):
             _lib.check(lib.zs_standardize_weight(_lib.ptr(w), _lib.ptr(rec[2]), w.shape[0], w[0].numel(), float(eps),
                                                  _stream(w)), "zs_standardize_weight")
         rec[3] = _stamp(weight)
@@ -158,7 +158,7 @@ def _refresh_all_packs(device):
                   torch.from_numpy(cs.view(np.int64)).to(device), len(ce))
         _PACK_TABLE[device] = cached
     _, tab_d, ce_d, cs_d, n = cached
-    with torch.cuda.device(device):
+    with _lib.on(device):
         _lib.check(lib.zs_pack_conv_weight_multi(_lib.ptr(tab_d), _lib.ptr(ce_d), _lib.ptr(cs_d), n,
                                                  _lib.current_stream_ptr(device)), "zs_pack_conv_weight_multi")
     for rec, w in recs:
@@ -186,7 +186,7 @@ def _pack(weight, cin0, cin, dgrad, std_eps=None):
     rec.ref = weakref.ref(weight, lambda _r, k=key: _PACKS.pop(k, None))
     rec.key, rec.dims = key, dims
     rec.packed = torch.empty(K16 * NPad, dtype=torch.float32, device=w.device)
-    with torch.cuda.device(w.device):
+    with _lib.on(w.device):
         _lib.check(lib.zs_pack_conv_weight(_lib.ptr(w), _lib.ptr(rec.packed), cout, cin, cin0, cintot, kh, kw,
                                            1 if dgrad else 0, _stream(w)), "zs_pack_conv_weight")
     rec.stamp = _stamp(weight)
@@ -205,7 +205,7 @@ def _conv_launch(x, packed, shift, res1, res2, out, kh, kw, stride, pt, pl, flag
     lib = _lib.load()
     B, H, W, C = x.shape
     _, Ho, Wo, Co = out.shape
-    with torch.cuda.device(x.device):
+    with _lib.on(x.device):
         _lib.check(lib.zs_conv2d_nhwc(_lib.ptr(x), _lib.ptr(packed), None, _lib.ptr(shift), _lib.ptr(res1),
                                       _lib.ptr(res2), _lib.ptr(out), B, H, W, C, Ho, Wo, Co, kh, kw, stride, pt, pl,
                                       flags, float(in_scale), float(in_shift), act, _stream(x)), "zs_conv2d_nhwc")
@@ -217,7 +217,7 @@ def column_sum(x2d, scale=1.0):
     rows, C = x2d.shape
     out = torch.empty(C, dtype=torch.float32, device=x2d.device)
     ws = scratch(x2d.device, "colsum", lib.zs_column_sum_workspace_bytes(rows, C))
-    with torch.cuda.device(x2d.device):
+    with _lib.on(x2d.device):
         _lib.check(lib.zs_column_sum(_lib.ptr(x2d), _lib.ptr(out), rows, C, float(scale), _lib.ptr(ws), _stream(x2d)),
                    "zs_column_sum")
     return out
@@ -226,7 +226,7 @@ def column_sum(x2d, scale=1.0):
 def _act_backward(dy, ref, act, beta=0.0):
     lib = _lib.load()
     dx = torch.empty_like(dy)
-    with torch.cuda.device(dy.device):
+    with _lib.on(dy.device):
         _lib.check(lib.zs_act_backward(_lib.ptr(dy), _lib.ptr(ref), _lib.ptr(dx), dy.numel(), act, float(beta),
                                        _stream(dy)), "zs_act_backward")
     return dx
@@ -237,7 +237,7 @@ def _pad_channels(x, cpad):
     C = x.shape[-1]
     rows = x.numel() // C
     y = torch.empty(*x.shape[:-1], cpad, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _lib.on(x.device):
         _lib.check(lib.zs_nchw_to_nhwc(_lib.ptr(x), None, _lib.ptr(y), rows, C, 1, cpad, _stream(x)), "zs_nchw_to_nhwc")
     return y
 
@@ -313,14 +313,14 @@ class _Conv(torch.autograd.Function):
                 db = torch.empty(cout, dtype=torch.float32, device=x.device)
             ws = scratch(x.device, "wgrad", lib.zs_conv2d_wgrad_workspace_bytes(B, Ho, Wo, Cx, cout, kh, kw))
             flags = _CONV_IN_RELU if in_relu else 0
-            with torch.cuda.device(x.device):
+            with _lib.on(x.device):
                 _lib.check(lib.zs_conv2d_wgrad(_lib.ptr(x), _lib.ptr(gp), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws), B, H, W, Cx, Ho,
                                                Wo, cout, kh, kw, stride, pt, pl, flags, float(in_scale),
                                                float(in_shift), cin, cin0, weight.shape[1], 0, _stream(x)),
                            "zs_conv2d_wgrad")
             if std_eps is not None:
                 dws = torch.empty_like(weight)
-                with torch.cuda.device(x.device):
+                with _lib.on(x.device):
                     _lib.check(lib.zs_standardize_weight_bwd(_lib.ptr(weight.detach()), _lib.ptr(dw), _lib.ptr(dws),
                                                              weight.shape[0], weight[0].numel(), float(std_eps),
                                                              _stream(x)), "zs_standardize_weight_bwd")
@@ -332,7 +332,7 @@ class _Conv(torch.autograd.Function):
                 # a network stem: direct gather kernel instead of a GEMM with 3 useful columns
                 w_used = standardize(weight, std_eps) if std_eps is not None else weight.detach()
                 dx = torch.empty(B, H, W, Cx, dtype=torch.float32, device=x.device)
-                with torch.cuda.device(x.device):
+                with _lib.on(x.device):
                     _lib.check(lib.zs_conv2d_dgrad_small_cin(_lib.ptr(g), _lib.ptr(w_used), _lib.ptr(dx), B, H, W, Cx, Ho, Wo,
                                                              cout, kh, kw, stride, pt, pl, cin, cin0, weight.shape[1],
                                                              float(in_scale), _stream(x)), "zs_conv2d_dgrad_small_cin")
@@ -372,7 +372,7 @@ class _Act(torch.autograd.Function):
         lib = _lib.load()
         x = _f32c(x, "activation input")
         y = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _lib.on(x.device):
             _lib.check(lib.zs_act_forward(_lib.ptr(x), _lib.ptr(y), x.numel(), act, float(beta), _stream(x)),
                        "zs_act_forward")
         ctx.act, ctx.beta = act, beta
@@ -404,7 +404,7 @@ class _LayerNorm(torch.autograd.Function):
         x = _f32c(x, "layer_norm input")
         C = x.shape[-1]
         y = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _lib.on(x.device):
             _lib.check(lib.zs_layer_norm(_lib.ptr(x), _lib.ptr(gamma.detach()), _lib.ptr(beta.detach()), _lib.ptr(y),
                                          x.numel() // C, C, float(eps), _stream(x)), "zs_layer_norm")
         ctx.eps = eps
@@ -422,7 +422,7 @@ class _LayerNorm(torch.autograd.Function):
         dg = torch.empty(C, dtype=torch.float32, device=x.device)
         db = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = scratch(x.device, "ln_bwd", lib.zs_layer_norm_bwd_workspace_bytes(rows, C))
-        with torch.cuda.device(x.device):
+        with _lib.on(x.device):
             _lib.check(lib.zs_layer_norm_bwd(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(gamma.detach()), _lib.ptr(dx),
                                              _lib.ptr(dg), _lib.ptr(db), rows, C, float(ctx.eps), _lib.ptr(ws),
                                              _stream(x)), "zs_layer_norm_bwd")
@@ -441,7 +441,7 @@ class _Attention(torch.autograd.Function):
         B, L, C3 = qkv.shape
         C = C3 // 3
         out = torch.empty(B, L, C, dtype=torch.float32, device=qkv.device)
-        with torch.cuda.device(qkv.device):
+        with _lib.on(qkv.device):
             _lib.check(lib.zs_attention(_lib.ptr(qkv), _lib.ptr(out), B, L, heads, C // heads, _stream(qkv)),
                        "zs_attention")
         ctx.heads = heads
@@ -457,7 +457,7 @@ class _Attention(torch.autograd.Function):
         heads = ctx.heads
         dqkv = torch.empty_like(qkv)
         ws = scratch(qkv.device, "attn_bwd", lib.zs_attention_bwd_workspace_bytes(B, L, heads))
-        with torch.cuda.device(qkv.device):
+        with _lib.on(qkv.device):
             _lib.check(lib.zs_attention_bwd(_lib.ptr(qkv), _lib.ptr(dout), _lib.ptr(dqkv), _lib.ptr(ws), B, L, heads,
                                             C3 // 3 // heads, _stream(qkv)), "zs_attention_bwd")
         return dqkv, None
@@ -477,7 +477,7 @@ class _PointAttention(torch.autograd.Function):
         B, M, C3 = qkv_p.shape
         Ll, C = qkv_l.shape[1], C3 // 3
         out = torch.empty(B, M, C, dtype=torch.float32, device=qkv_p.device)
-        with torch.cuda.device(qkv_p.device):
+        with _lib.on(qkv_p.device):
             _lib.check(lib.zs_point_attention(_lib.ptr(qkv_p), _lib.ptr(qkv_l), _lib.ptr(out), B, M, Ll, heads,
                                               C // heads, _stream(qkv_p)), "zs_point_attention")
         ctx.heads = heads
@@ -493,7 +493,7 @@ class _PointAttention(torch.autograd.Function):
         Ll, C, heads = qkv_l.shape[1], C3 // 3, ctx.heads
         dp, dl = torch.empty_like(qkv_p), torch.empty_like(qkv_l)
         ws = scratch(qkv_p.device, "pa_bwd", lib.zs_point_attention_bwd_workspace_bytes(B, M, Ll, heads))
-        with torch.cuda.device(qkv_p.device):
+        with _lib.on(qkv_p.device):
             _lib.check(lib.zs_point_attention_bwd(_lib.ptr(qkv_p), _lib.ptr(qkv_l), _lib.ptr(dout), _lib.ptr(dp),
                                                   _lib.ptr(dl), 0, _lib.ptr(ws), B, M, Ll, heads, C // heads,
                                                   _stream(qkv_p)), "zs_point_attention_bwd")
@@ -508,7 +508,7 @@ def _scaled_rows(x, branch, scale):
     lib = _lib.load()
     B = branch.shape[0]
     y = torch.empty_like(branch)
-    with torch.cuda.device(branch.device):
+    with _lib.on(branch.device):
         _lib.check(lib.zs_add_scaled_rows(_lib.ptr(x), _lib.ptr(branch), _lib.ptr(scale), _lib.ptr(y), B,
                                           branch.numel() // B, _stream(branch)), "zs_add_scaled_rows")
     return y
@@ -544,7 +544,7 @@ class _BCELogits(torch.autograd.Function):
         n = logits.numel()
         loss = torch.empty((), dtype=torch.float32, device=logits.device)
         ws = scratch(logits.device, "bce", lib.zs_bce_logits_workspace_bytes(n))
-        with torch.cuda.device(logits.device):
+        with _lib.on(logits.device):
             _lib.check(lib.zs_bce_logits(_lib.ptr(logits), _lib.ptr(sdf), n, float(thres), float(weight),
                                          _lib.ptr(loss), _lib.ptr(ws), _stream(logits)), "zs_bce_logits")
         ctx.thres, ctx.weight = thres, weight
@@ -557,7 +557,7 @@ class _BCELogits(torch.autograd.Function):
         logits, sdf = ctx.saved_tensors
         dloss = _f32c(dloss, "loss grad")
         dx = torch.empty_like(logits)
-        with torch.cuda.device(logits.device):
+        with _lib.on(logits.device):
             _lib.check(lib.zs_bce_logits_bwd(_lib.ptr(logits), _lib.ptr(sdf), logits.numel(), float(ctx.thres),
                                              float(ctx.weight), _lib.ptr(dloss), _lib.ptr(dx), _stream(logits)),
                        "zs_bce_logits_bwd")
@@ -586,7 +586,7 @@ class _BatchNormTrain(torch.autograd.Function):
         rstd = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = scratch(x.device, "bn", lib.zs_batch_norm_workspace_bytes(rows, C))
         res = None if residual is None else _f32c(residual, "batch_norm residual")
-        with torch.cuda.device(x.device):
+        with _lib.on(x.device):
             _lib.check(lib.zs_batch_norm_train(_lib.ptr(x), _lib.ptr(gamma.detach()), _lib.ptr(beta.detach()),
                                                _lib.ptr(res), _lib.ptr(y), _lib.ptr(running_mean),
                                                _lib.ptr(running_var), _lib.ptr(mean), _lib.ptr(rstd), rows, C,
@@ -608,7 +608,7 @@ class _BatchNormTrain(torch.autograd.Function):
         dg = torch.empty(C, dtype=torch.float32, device=x.device)
         db = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = scratch(x.device, "bn", lib.zs_batch_norm_workspace_bytes(rows, C))
-        with torch.cuda.device(x.device):
+        with _lib.on(x.device):
             _lib.check(lib.zs_batch_norm_bwd(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(y), _lib.ptr(gamma.detach()),
                                              _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dg),
                                              _lib.ptr(db), rows, C, _lib.ptr(ws), _stream(x)), "zs_batch_norm_bwd")
@@ -634,7 +634,7 @@ class _GroupNorm(torch.autograd.Function):
         B, H, W, C = x.shape
         y = torch.empty_like(x)
         res = None if residual is None else _f32c(residual, "group_norm residual")
-        with torch.cuda.device(x.device):
+        with _lib.on(x.device):
             _lib.check(lib.zs_group_norm_nhwc(_lib.ptr(x), _lib.ptr(gamma.detach()), _lib.ptr(beta.detach()),
                                               _lib.ptr(res), _lib.ptr(y), B, H * W, C, groups, float(eps),
                                               1 if relu else 0, _stream(x)), "zs_group_norm_nhwc")
@@ -654,7 +654,7 @@ class _GroupNorm(torch.autograd.Function):
         dg = torch.empty(C, dtype=torch.float32, device=x.device)
         db = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = scratch(x.device, "gn_bwd", lib.zs_group_norm_bwd_workspace_bytes(B, C))
-        with torch.cuda.device(x.device):
+        with _lib.on(x.device):
             _lib.check(lib.zs_group_norm_bwd(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(y), _lib.ptr(gamma.detach()),
                                              _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dg), _lib.ptr(db), B, H * W, C,
                                              groups, float(eps), _lib.ptr(ws), _stream(x)), "zs_group_norm_bwd")
@@ -676,7 +676,7 @@ class _MaxPool(torch.autograd.Function):
         Ho, pt = _out_size(H, k, stride, padding)
         Wo, pl = _out_size(W, k, stride, padding)
         y = torch.empty(B, Ho, Wo, C, dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on(x.device):
             _lib.check(lib.zs_max_pool_nhwc(_lib.ptr(x), _lib.ptr(y), B, H, W, C, Ho, Wo, k, stride, pt, pl,
                                             _stream(x)), "zs_max_pool_nhwc")
         ctx.cfg = (k, stride, pt, pl, Ho, Wo)
@@ -691,7 +691,7 @@ class _MaxPool(torch.autograd.Function):
         dy = _f32c(dy, "max_pool grad")
         B, H, W, C = x.shape
         dx = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _lib.on(x.device):
             _lib.check(lib.zs_max_pool_bwd_nhwc(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dx), B, H, W, C, Ho, Wo, k, stride,
                                                 pt, pl, _stream(x)), "zs_max_pool_bwd_nhwc")
         return dx, None, None, None
@@ -708,7 +708,7 @@ class _GlobalMean(torch.autograd.Function):
         x = _f32c(x, "global_mean input")
         B, H, W, C = x.shape
         y = torch.empty(B, C, dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on(x.device):
             _lib.check(lib.zs_global_mean_nhwc(_lib.ptr(x), _lib.ptr(y), B, H * W, C, _stream(x)),
                        "zs_global_mean_nhwc")
         ctx.shape = (B, H, W, C)
@@ -720,7 +720,7 @@ class _GlobalMean(torch.autograd.Function):
         B, H, W, C = ctx.shape
         dy = _f32c(dy, "global_mean grad")
         dx = torch.empty(B, H, W, C, dtype=torch.float32, device=dy.device)
-        with torch.cuda.device(dy.device):
+        with _lib.on(dy.device):
             _lib.check(lib.zs_global_mean_bwd_nhwc(_lib.ptr(dy), _lib.ptr(dx), B, H * W, C, _stream(dy)),
                        "zs_global_mean_bwd_nhwc")
         return dx
@@ -737,7 +737,7 @@ class _Upsample2x(torch.autograd.Function):
         x = _f32c(x, "upsample2x input")
         B, H, W, C = x.shape
         y = torch.empty(B, 2 * H, 2 * W, C, dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on(x.device):
             _lib.check(lib.zs_upsample2x_nhwc(_lib.ptr(x), _lib.ptr(y), B, H, W, C, _stream(x)), "zs_upsample2x_nhwc")
         ctx.shape = (B, H, W, C)
         return y
@@ -748,7 +748,7 @@ class _Upsample2x(torch.autograd.Function):
         B, H, W, C = ctx.shape
         dy = _f32c(dy, "upsample2x grad")
         dx = torch.empty(B, H, W, C, dtype=torch.float32, device=dy.device)
-        with torch.cuda.device(dy.device):
+        with _lib.on(dy.device):
             _lib.check(lib.zs_upsample2x_bwd_nhwc(_lib.ptr(dy), _lib.ptr(dx), B, H, W, C, _stream(dy)),
                        "zs_upsample2x_bwd_nhwc")
         return dx
@@ -768,7 +768,7 @@ class _ToNHWC(torch.autograd.Function):
         B, C, H, W = x.shape
         m = None if mask is None else _f32c(mask.float(), "to_nhwc mask")
         y = torch.empty(B, H, W, cpad, dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on(x.device):
             _lib.check(lib.zs_nchw_to_nhwc(_lib.ptr(x), _lib.ptr(m), _lib.ptr(y), B, C, H * W, cpad, _stream(x)),
                        "zs_nchw_to_nhwc")
         ctx.shape = (B, C, H, W, cpad)
@@ -782,7 +782,7 @@ class _ToNHWC(torch.autograd.Function):
         B, C, H, W, cpad = ctx.shape
         dy = _f32c(dy, "to_nhwc grad")
         dx = torch.empty(B, C, H, W, dtype=torch.float32, device=dy.device)
-        with torch.cuda.device(dy.device):
+        with _lib.on(dy.device):
             _lib.check(lib.zs_nhwc_to_nchw_masked(_lib.ptr(dy), _lib.ptr(m), _lib.ptr(dx), B, C, H * W, cpad,
                                                   _stream(dy)), "zs_nhwc_to_nchw_masked")
         return dx, None, None
@@ -799,7 +799,7 @@ class _ToNCHW(torch.autograd.Function):
         x = _f32c(x, "to_nchw input")
         B, H, W, C = x.shape
         y = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on(x.device):
             _lib.check(lib.zs_nhwc_to_nchw(_lib.ptr(x), _lib.ptr(y), B, C, H * W, _stream(x)), "zs_nhwc_to_nchw")
         return y
 
@@ -809,7 +809,7 @@ class _ToNCHW(torch.autograd.Function):
         dy = _f32c(dy, "to_nchw grad")
         B, C, H, W = dy.shape
         dx = torch.empty(B, H, W, C, dtype=torch.float32, device=dy.device)
-        with torch.cuda.device(dy.device):
+        with _lib.on(dy.device):
             _lib.check(lib.zs_nchw_to_nhwc(_lib.ptr(dy), None, _lib.ptr(dx), B, C, H * W, C, _stream(dy)),
                        "zs_nchw_to_nhwc")
         return dx
@@ -835,7 +835,7 @@ class _SeenSurface(torch.autograd.Function):
         scale = torch.empty(B, dtype=torch.float32, device=dev)
         coord = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
         mask_dsp = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on(dev):
             _lib.check(lib.zs_seen_surface(_lib.ptr(depth), _lib.ptr(intr), _lib.ptr(m), B, H, W, H, W, _lib.ptr(seen),
                                            _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(coord), _lib.ptr(mask_dsp),
                                            _stream(depth)), "zs_seen_surface")
@@ -852,7 +852,7 @@ class _SeenSurface(torch.autograd.Function):
         d_coord = None if d_coord is None else _f32c(d_coord, "coord grad")
         dd = torch.empty_like(depth)
         dk = torch.empty_like(intr)
-        with torch.cuda.device(depth.device):
+        with _lib.on(depth.device):
             _lib.check(lib.zs_seen_surface_bwd(_lib.ptr(depth), _lib.ptr(intr), _lib.ptr(m), _lib.ptr(mean),
                                                _lib.ptr(scale), _lib.ptr(d_seen), _lib.ptr(d_coord), B, H, W,
                                                _lib.ptr(dd), _lib.ptr(dk), _stream(depth)), "zs_seen_surface_bwd")
@@ -870,7 +870,7 @@ class _IntrParam2Mtx(torch.autograd.Function):
         params = _f32c(params, "intr params")
         B = params.shape[0]
         intr = torch.empty(B, 3, 3, dtype=torch.float32, device=params.device)
-        with torch.cuda.device(params.device):
+        with _lib.on(params.device):
             _lib.check(lib.zs_intr_param2mtx(_lib.ptr(params), B, H, W, _lib.ptr(intr), _stream(params)),
                        "zs_intr_param2mtx")
         ctx.hw = (H, W)
@@ -883,7 +883,7 @@ class _IntrParam2Mtx(torch.autograd.Function):
         (params,) = ctx.saved_tensors
         d_intr = _f32c(d_intr, "intr grad")
         dp = torch.empty_like(params)
-        with torch.cuda.device(params.device):
+        with _lib.on(params.device):
             _lib.check(lib.zs_intr_param2mtx_bwd(_lib.ptr(params), _lib.ptr(d_intr), params.shape[0], ctx.hw[0],
                                                  ctx.hw[1], _lib.ptr(dp), _stream(params)), "zs_intr_param2mtx_bwd")
         return dp, None, None
@@ -903,7 +903,7 @@ class _ResizeGrid(torch.autograd.Function):
         x = _f32c(x, "resize input")
         Hi, Wi, C = x.shape
         y = torch.empty(Ho, Wo, C, dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on(x.device):
             _lib.check(lib.zs_resize_bilinear_nhwc(_lib.ptr(x), _lib.ptr(y), Hi, Wi, Ho, Wo, C, 0, _stream(x)),
                        "zs_resize_bilinear_nhwc")
         ctx.shape = (Hi, Wi, Ho, Wo, C)
@@ -915,7 +915,7 @@ class _ResizeGrid(torch.autograd.Function):
         Hi, Wi, Ho, Wo, C = ctx.shape
         dy = _f32c(dy, "resize grad")
         dx = torch.empty(Hi, Wi, C, dtype=torch.float32, device=dy.device)
-        with torch.cuda.device(dy.device):
+        with _lib.on(dy.device):
             _lib.check(lib.zs_resize_bilinear_nhwc(_lib.ptr(dy), _lib.ptr(dx), Hi, Wi, Ho, Wo, C, 1, _stream(dy)),
                        "zs_resize_bilinear_nhwc(bwd)")
         return dx, None, None
@@ -934,7 +934,7 @@ class _AssembleTokens(torch.autograd.Function):
         feat, cls, pos = _f32c(feat, "tokens"), _f32c(cls, "cls"), _f32c(pos, "pos")
         B, n, C = feat.shape
         y = torch.empty(B, n + 1, C, dtype=torch.float32, device=feat.device)
-        with torch.cuda.device(feat.device):
+        with _lib.on(feat.device):
             _lib.check(lib.zs_assemble_tokens(_lib.ptr(feat), _lib.ptr(cls), _lib.ptr(pos), _lib.ptr(y), B, n, C,
                                               _stream(feat)), "zs_assemble_tokens")
         return y
@@ -963,7 +963,7 @@ class _WindowTokens(torch.autograd.Function):
         B, H, W, C = emb.shape
         m = mask.to(torch.uint8).contiguous()
         out = torch.empty(B * (H // win) * (W // win), win * win + 1, C, dtype=torch.float32, device=emb.device)
-        with torch.cuda.device(emb.device):
+        with _lib.on(emb.device):
             _lib.check(lib.zs_window_tokens(_lib.ptr(emb), _lib.ptr(m), _lib.ptr(invalid_token), _lib.ptr(cls), _lib.ptr(pos),
                                             _lib.ptr(out), B, H, W, C, win, _stream(emb)), "zs_window_tokens")
         ctx.save_for_backward(m)
@@ -979,7 +979,7 @@ class _WindowTokens(torch.autograd.Function):
         d_emb = torch.empty(B, H, W, C, dtype=torch.float32, device=dy.device)
         d_inv = torch.empty_like(d_emb)
         d_cls = torch.empty(B * (H // win) * (W // win), C, dtype=torch.float32, device=dy.device)
-        with torch.cuda.device(dy.device):
+        with _lib.on(dy.device):
             _lib.check(lib.zs_window_tokens_bwd(_lib.ptr(dy), _lib.ptr(m), _lib.ptr(d_emb), _lib.ptr(d_inv), _lib.ptr(d_cls),
                                                 B, H, W, C, win, _stream(dy)), "zs_window_tokens_bwd")
         return d_emb, None, column_sum(d_inv.view(-1, C)), column_sum(d_cls), None, None
@@ -1006,7 +1006,7 @@ class _SeenSurfaceDsp2(torch.autograd.Function):
         scale = torch.empty(B, dtype=torch.float32, device=dev)
         coord = torch.empty(B, 3, Ho, Wo, dtype=torch.float32, device=dev)
         mask_dsp = torch.empty(B, 1, Ho, Wo, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on(dev):
             _lib.check(lib.zs_seen_surface(_lib.ptr(depth), _lib.ptr(intr), _lib.ptr(m), B, H, W, Ho, Wo, _lib.ptr(seen),
                                            _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(coord), _lib.ptr(mask_dsp),
                                            _stream(depth)), "zs_seen_surface")
@@ -1021,7 +1021,7 @@ class _SeenSurfaceDsp2(torch.autograd.Function):
         B, _, H, W = depth.shape
         d_seen = None if d_seen is None else _f32c(d_seen, "seen grad")
         d_full = None
-        with torch.cuda.device(depth.device):
+        with _lib.on(depth.device):
             if d_coord is not None:
                 d_full = torch.empty(B, 3, H, W, dtype=torch.float32, device=depth.device)
                 _lib.check(lib.zs_coord_dsp2_bwd(_lib.ptr(_f32c(d_coord, "coord grad")), _lib.ptr(m), _lib.ptr(mask_dsp),
@@ -1045,7 +1045,7 @@ class _ReadoutConcat(torch.autograd.Function):
         tokens = _f32c(tokens, "readout input")
         B, n1, C = tokens.shape
         y = torch.empty(B, n1 - 1, 2 * C, dtype=torch.float32, device=tokens.device)
-        with torch.cuda.device(tokens.device):
+        with _lib.on(tokens.device):
             _lib.check(lib.zs_readout_concat(_lib.ptr(tokens), _lib.ptr(y), B, n1 - 1, C, _stream(tokens)),
                        "zs_readout_concat")
         return y
@@ -1056,7 +1056,7 @@ class _ReadoutConcat(torch.autograd.Function):
         dy = _f32c(dy, "readout grad")
         B, n, C2 = dy.shape
         dt = torch.empty(B, n + 1, C2 // 2, dtype=torch.float32, device=dy.device)
-        with torch.cuda.device(dy.device):
+        with _lib.on(dy.device):
             _lib.check(lib.zs_readout_concat_bwd(_lib.ptr(dy), _lib.ptr(dt), B, n, C2 // 2, _stream(dy)),
                        "zs_readout_concat_bwd")
         return dt
@@ -1078,7 +1078,7 @@ class _MidasLoss(torch.autograd.Function):
         B, _, H, W = p.shape
         loss = torch.empty((), dtype=torch.float32, device=p.device)
         ws = torch.empty((lib.zs_midas_loss_workspace_bytes(B) + 3) // 4, dtype=torch.float32, device=p.device)
-        with torch.cuda.device(p.device):
+        with _lib.on(p.device):
             _lib.check(lib.zs_midas_loss(_lib.ptr(p), _lib.ptr(t), _lib.ptr(m), B, H, W, float(alpha), int(scales),
                                          1 if inverse_depth else 0, _lib.ptr(loss), _lib.ptr(ws), _stream(p)),
                        "zs_midas_loss")
@@ -1094,7 +1094,7 @@ class _MidasLoss(torch.autograd.Function):
         B, _, H, W = p.shape
         dloss = _f32c(dloss, "loss grad")
         dp = torch.empty_like(p)
-        with torch.cuda.device(p.device):
+        with _lib.on(p.device):
             _lib.check(lib.zs_midas_loss_bwd(_lib.ptr(p), _lib.ptr(t), _lib.ptr(m), B, H, W, float(alpha), int(scales),
                                              1 if inverse_depth else 0, _lib.ptr(ws), _lib.ptr(dloss), _lib.ptr(dp),
                                              _stream(p)), "zs_midas_loss_bwd")
@@ -1108,7 +1108,7 @@ def erode_mask(mask, pool=4):
     m = _f32c(mask.float(), "mask")
     B, _, H, W = m.shape
     out = torch.empty_like(m)
-    with torch.cuda.device(m.device):
+    with _lib.on(m.device):
         _lib.check(lib.zs_erode_mask(_lib.ptr(m), B, H, W, pool, _lib.ptr(out), _stream(m)), "zs_erode_mask")
     return out
 
@@ -1127,7 +1127,7 @@ class _IntrLoss(torch.autograd.Function):
         n = m.numel()
         assert a.numel() == 3 * n and b.numel() == 3 * n
         out = torch.empty(2, dtype=torch.float32, device=a.device)
-        with torch.cuda.device(a.device):
+        with _lib.on(a.device):
             _lib.check(lib.zs_intr_loss(_lib.ptr(a), _lib.ptr(b), _lib.ptr(m), n, _lib.ptr(out), _stream(a)), "zs_intr_loss")
         ctx.save_for_backward(a, b, m, out)
         return out[0].clone()
@@ -1138,7 +1138,7 @@ class _IntrLoss(torch.autograd.Function):
         a, b, m, out = ctx.saved_tensors
         dloss = _f32c(dloss, "loss grad")
         da = torch.empty_like(a)
-        with torch.cuda.device(a.device):
+        with _lib.on(a.device):
             _lib.check(lib.zs_intr_loss_bwd(_lib.ptr(a), _lib.ptr(b), _lib.ptr(m), m.numel(), _lib.ptr(out), _lib.ptr(dloss),
                                             _lib.ptr(da), _stream(a)), "zs_intr_loss_bwd")
         return da, None, None

@@ -89,11 +89,11 @@ def conv2d(x, pc, res1=None, res2=None, act=ACT_NONE, in_relu=False, in_scale=1.
     if PRESPLIT and CONV_PRECISION == "f16x3":
         if pc.w16 is None:
             pc.w16 = torch.empty_like(pc.w)
-            with torch.cuda.device(x.device):
+            with _lib.on(x.device):
                 _lib.check(lib.zs_conv2d_presplit_weight(_lib.ptr(pc.w), _lib.ptr(pc.w16), C, pc.cout, pc.kh, pc.kw,
                                                          _stream(x)), "zs_conv2d_presplit_weight")
         w, flags = pc.w16, flags | _CONV_W_PRESPLIT
-    with torch.cuda.device(x.device):
+    with _lib.on(x.device):
         _lib.check(lib.zs_conv2d_nhwc_ws(_lib.ptr(x), _lib.ptr(w), _lib.ptr(pc.scale), _lib.ptr(pc.shift),
                                          _lib.ptr(res1), _lib.ptr(res2), _lib.ptr(out), B, H, W, C, Ho, Wo, pc.cout,
                                          pc.kh, pc.kw, pc.stride, pt, pl,
@@ -119,7 +119,7 @@ def group_norm(x, gamma, beta, groups=32, eps=1e-5, relu=False, residual=None):
     _chk(x, "group_norm input")
     B, H, W, C = x.shape
     y = torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with _lib.on(x.device):
         _lib.check(lib.zs_group_norm_nhwc(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(residual),
                                           _lib.ptr(y), B, H * W, C, groups, float(eps), 1 if relu else 0,
                                           _stream(x)), "zs_group_norm_nhwc")
@@ -132,7 +132,7 @@ def layer_norm(x, gamma, beta, eps=1e-6):
     C = x.shape[-1]
     rows = x.numel() // C
     y = torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with _lib.on(x.device):
         _lib.check(lib.zs_layer_norm(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(y), rows, C, float(eps),
                                      _stream(x)), "zs_layer_norm")
     return y
@@ -145,7 +145,7 @@ def attention(qkv, heads):
     B, L, C3 = qkv.shape
     C = C3 // 3
     out = torch.empty(B, L, C, dtype=torch.float32, device=qkv.device)
-    with torch.cuda.device(qkv.device):
+    with _lib.on(qkv.device):
         fn = lib.zs_attention_split if CONV_PRECISION == "f16x3" else lib.zs_attention
         _lib.check(fn(_lib.ptr(qkv), _lib.ptr(out), B, L, heads, C // heads, _stream(qkv)), "zs_attention")
     return out
@@ -165,7 +165,7 @@ def max_pool(x, k=3, stride=2, padding=1):
     Ho, pt = size(H)
     Wo, pl = size(W)
     y = torch.empty(B, Ho, Wo, C, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _lib.on(x.device):
         _lib.check(lib.zs_max_pool_nhwc(_lib.ptr(x), _lib.ptr(y), B, H, W, C, Ho, Wo, k, stride, pt, pl, _stream(x)),
                    "zs_max_pool_nhwc")
     return y
@@ -177,7 +177,7 @@ def global_mean(x):
     _chk(x, "global_mean input")
     B, H, W, C = x.shape
     y = torch.empty(B, C, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _lib.on(x.device):
         _lib.check(lib.zs_global_mean_nhwc(_lib.ptr(x), _lib.ptr(y), B, H * W, C, _stream(x)), "zs_global_mean_nhwc")
     return y
 
@@ -187,7 +187,7 @@ def upsample2x(x):
     _chk(x, "upsample2x input")
     B, H, W, C = x.shape
     y = torch.empty(B, 2 * H, 2 * W, C, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _lib.on(x.device):
         _lib.check(lib.zs_upsample2x_nhwc(_lib.ptr(x), _lib.ptr(y), B, H, W, C, _stream(x)), "zs_upsample2x_nhwc")
     return y
 
@@ -203,7 +203,7 @@ def to_nhwc(x, cpad=None, mask=None):
         mask = _chk(mask.float().contiguous(), "to_nhwc mask")
         assert mask.numel() == B * H * W
     y = torch.empty(B, H, W, cp, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _lib.on(x.device):
         _lib.check(lib.zs_nchw_to_nhwc(_lib.ptr(x), _lib.ptr(mask), _lib.ptr(y), B, C, H * W, cp, _stream(x)),
                    "zs_nchw_to_nhwc")
     return y
@@ -216,7 +216,7 @@ def pad_channels(x, cpad):
     C = x.shape[-1]
     rows = x.numel() // C
     y = torch.empty(*x.shape[:-1], cpad, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _lib.on(x.device):
         _lib.check(lib.zs_nchw_to_nhwc(_lib.ptr(x), None, _lib.ptr(y), rows, C, 1, cpad, _stream(x)),
                    "zs_nchw_to_nhwc")
     return y
@@ -229,7 +229,7 @@ def window_tokens(emb, mask, invalid_token, cls, pos, win):
     B, H, W, C = emb.shape
     m = mask.to(torch.uint8).contiguous()
     out = torch.empty(B * (H // win) * (W // win), win * win + 1, C, dtype=torch.float32, device=emb.device)
-    with torch.cuda.device(emb.device):
+    with _lib.on(emb.device):
         _lib.check(lib.zs_window_tokens(_lib.ptr(emb), _lib.ptr(m), _lib.ptr(invalid_token), _lib.ptr(cls),
                                         _lib.ptr(pos), _lib.ptr(out), B, H, W, C, win, _stream(emb)),
                    "zs_window_tokens")
@@ -241,7 +241,7 @@ def to_nchw(x):
     _chk(x, "to_nchw input")
     B, H, W, C = x.shape
     y = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _lib.on(x.device):
         _lib.check(lib.zs_nhwc_to_nchw(_lib.ptr(x), _lib.ptr(y), B, C, H * W, _stream(x)), "zs_nhwc_to_nchw")
     return y
 
@@ -252,7 +252,7 @@ def assemble_tokens(feat, cls, pos):
     _chk(feat, "assemble_tokens input")
     B, n, C = feat.shape
     y = torch.empty(B, n + 1, C, dtype=torch.float32, device=feat.device)
-    with torch.cuda.device(feat.device):
+    with _lib.on(feat.device):
         _lib.check(lib.zs_assemble_tokens(_lib.ptr(feat), _lib.ptr(cls), _lib.ptr(pos), _lib.ptr(y), B, n, C,
                                           _stream(feat)), "zs_assemble_tokens")
     return y
@@ -264,7 +264,7 @@ def readout_concat(tokens):
     _chk(tokens, "readout_concat input")
     B, n1, C = tokens.shape
     y = torch.empty(B, n1 - 1, 2 * C, dtype=torch.float32, device=tokens.device)
-    with torch.cuda.device(tokens.device):
+    with _lib.on(tokens.device):
         _lib.check(lib.zs_readout_concat(_lib.ptr(tokens), _lib.ptr(y), B, n1 - 1, C, _stream(tokens)),
                    "zs_readout_concat")
     return y

@@ -71,7 +71,7 @@ class FusedAdamW(torch.optim.Optimizer):
         tab, ct, cs, nchunks = build_table(entries, dev)
         partial = torch.empty(nchunks, dtype=torch.float32, device=dev)
         out = torch.empty((), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on(dev):
             _lib.check(lib.zs_sumsq_multi(_lib.ptr(tab), _lib.ptr(ct), _lib.ptr(cs), nchunks, _lib.ptr(partial),
                                           _lib.ptr(out), _lib.current_stream_ptr(dev)), "zs_sumsq_multi")
         return out.sqrt_()
@@ -112,7 +112,7 @@ class FusedAdamW(torch.optim.Optimizer):
                                                group["weight_decay"]))
         for (step, betas, eps, dev), entries in by_key.items():
             tab, ct, cs, nchunks = build_table(entries, dev)
-            with torch.cuda.device(dev):
+            with _lib.on(dev):
                 _lib.check(lib.zs_adamw_multi(_lib.ptr(tab), _lib.ptr(ct), _lib.ptr(cs), nchunks, betas[0], betas[1],
                                               eps, step, _lib.ptr(self._clip), _lib.current_stream_ptr(dev)),
                            "zs_adamw_multi")
