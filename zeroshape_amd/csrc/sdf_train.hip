@@ -12,6 +12,7 @@
 #include "../../include/zeroshape_hip.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 namespace {
@@ -112,6 +113,89 @@ __global__ __launch_bounds__(256) void point_attention_kernel(const float *__res
         for (int j = part; j < Ll; j += 2) acc += pw[j] * Vs[j * KS + d];
         acc += __shfl_xor(acc, 32, 64);
         if (part == 0) out[((size_t)b * M + i) * C + h * D + d] = acc + r.p_self * src[2 * C + d];
+    }
+}
+
+// The same on the MFMA pipe: one wave per (b, h, 32 points), transposed like the encoder's attention kernel
+// (csrc/nn_ops.hip): S^T[latent][point] = K_l Q^T per 32-latent tile, online softmax over a lane's registers + its
+// partner half, O^T[d][point] += V_l^T P^T with the probabilities staying in the lane that computed them; the point's
+// own (k, v) pair joins the softmax at the end (one more logit per point, its value row added to the accumulators).
+// fp32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32 products and sums).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(64) void point_attention_mfma_kernel(const float *__restrict__ qkv_p,
+                                                                  const float *__restrict__ qkv_l, float *__restrict__ out,
+                                                                  int M, int Ll, int heads, float scale) {
+    constexpr int DQ = D / 8;                 // float4 operand quads per lane along d
+    const int lane = threadIdx.x, l32 = lane & 31, half = lane >> 5;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads, C = heads * D, p0 = blockIdx.y * 32;
+    const float *lbase = qkv_l + (size_t)b * Ll * 3 * C + h * D;
+    const int prow = min(p0 + l32, M - 1);
+    const float *src = qkv_p + ((size_t)b * M + prow) * 3 * C + h * D;
+    f32x4v qf[DQ];
+    float s_self = 0.f;
+#pragma unroll
+    for (int t = 0; t < DQ; t++) {
+        qf[t] = *reinterpret_cast<const f32x4v *>(src + 4 * (2 * t + half)) * scale;
+        const f32x4v ks = *reinterpret_cast<const f32x4v *>(src + C + 4 * (2 * t + half));
+        s_self += (qf[t].x * ks.x + qf[t].y * ks.y) + (qf[t].z * ks.z + qf[t].w * ks.w);
+    }
+    s_self += __shfl_xor(s_self, 32, 64);
+    f32x16v o;
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[r] = 0.f;
+    float mx = -INFINITY, den = 0.f;
+    for (int k0 = 0; k0 < Ll; k0 += 32) {
+        const int krow = min(k0 + l32, Ll - 1);
+        f32x16v sT;
+#pragma unroll
+        for (int r = 0; r < 16; r++) sT[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < DQ; t++) {
+            const f32x4v kf = *reinterpret_cast<const f32x4v *>(lbase + (size_t)krow * 3 * C + C + 4 * (2 * t + half));
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) sT = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s4], qf[t][s4], sT, 0, 0, 0);
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int key = k0 + 8 * (r >> 2) + 4 * half + (r & 3);
+            sT[r] = key < Ll ? sT[r] : -INFINITY;
+            tmax = fmaxf(tmax, sT[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float nm = fmaxf(mx, tmax), corr = expf(mx - nm);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            sT[r] = expf(sT[r] - nm);
+            psum += sT[r];
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        den = den * corr + psum;
+        mx = nm;
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[r] *= corr;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int key = min(k0 + 8 * (r >> 2) + 4 * half + (r & 3), Ll - 1);
+            const float vf = lbase[(size_t)key * 3 * C + 2 * C + l32];
+            o = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, sT[r], o, 0, 0, 0);
+        }
+    }
+    // the point itself: logit s_self, value row v_self
+    const float nm = fmaxf(mx, s_self), corr = expf(mx - nm), p_self = expf(s_self - nm);
+    den = den * corr + p_self;
+    const float inv = 1.0f / den;
+    if (p0 + l32 < M) {
+        float *dst = out + ((size_t)b * M + p0 + l32) * C + h * D;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const f32x4v vs = *reinterpret_cast<const f32x4v *>(src + 2 * C + 8 * g + 4 * half);
+            const f32x4v v = {(o[4 * g] * corr + p_self * vs.x) * inv, (o[4 * g + 1] * corr + p_self * vs.y) * inv,
+                              (o[4 * g + 2] * corr + p_self * vs.z) * inv, (o[4 * g + 3] * corr + p_self * vs.w) * inv};
+            *reinterpret_cast<f32x4v *>(dst + 8 * g + 4 * half) = v;
+        }
     }
 }
 
@@ -356,6 +440,12 @@ extern "C" int zs_point_attention(const float *qkv_points, const float *qkv_late
                heads, head_dim, 64 * PA_MAXJ, D);
     if (batch == 0) return 1;
     ZS_REQUIRE(qkv_points && qkv_latent && out, "zs_point_attention: null pointer");
+    static const bool valu = getenv("ZS_POINT_ATTN_VALU") != nullptr;        // A/B switch: the vector-ALU kernel
+    if (!valu && (M + 31) / 32 <= 65535) {
+        hipLaunchKernelGGL(point_attention_mfma_kernel, dim3(batch * heads, (M + 31) / 32), dim3(64), 0, S(stream),
+                           qkv_points, qkv_latent, out, M, Ll, heads, 1.0f / sqrtf((float)head_dim));
+        return zs::check_launch("zs_point_attention") ? 1 : 0;
+    }
     const dim3 grid(batch * heads, (M + PT - 1) / PT);
     hipLaunchKernelGGL(point_attention_kernel, grid, dim3(256), pa_lds_bytes(Ll, false), S(stream), qkv_points,
                        qkv_latent, out, M, Ll, heads, 1.0f / sqrtf((float)head_dim));
