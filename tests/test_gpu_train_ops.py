@@ -177,7 +177,7 @@ def test_attention_backward(B, L, heads, d):
     close(qg.grad, qr.grad, what="dqkv")
 
 
-@pytest.mark.parametrize("B,M,Ll", [(2, 300, 197), (1, 1000, 197), (3, 7, 50)])
+@pytest.mark.parametrize("B,M,Ll", [(2, 300, 197), (1, 1000, 197), (3, 7, 50), (1, 4099, 197)])
 def test_point_attention(B, M, Ll):
     """ImplFuncAttention's point rows (implicit.py:44-66) incl. the gradient to the latent k / v."""
     from zeroshape_amd.nn import autograd as A

@@ -304,6 +304,193 @@ __global__ __launch_bounds__(256) void point_attention_bwd_kernel(const float *_
     }
 }
 
+// ---- the backward on the MFMA pipe --------------------------------------------------------------------------- //
+// pass 1, one wave per (b, h, 32 points), transposed like the forward kernel: S^T = K_l Q^T and dP^T = V_l dO^T of
+// all latent tiles stay in the accumulators; with the point's own logit and dO . v_self they give the probabilities,
+// delta = sum P dP and dS = P (dP - delta).  Written: dS [BH][M][Ll] (rows, for dq), dS^T and P^T [BH][Ll][M] (for
+// dK_l / dV_l: the accumulator layout IS the transposed one - consecutive lanes are consecutive points), and the
+// self parts of the point gradients (dq += scale ds_self k_self, dk_self = scale ds_self q, dv_self = p_self dO).
+// pass 2, one wave per 32 x 32 output tile: dq = scale dS K_l (added to the self part), dK_l = scale dS^T Q and
+// dV_l = P^T dO over chunks of PA2_CHUNK points -> partial tiles, summed in chunk order by point_attention_reduce_kernel.
+constexpr int PA2_TILES = 8;          // Ll <= 256
+constexpr int PA2_CHUNK = 512;        // points per dK_l / dV_l partial
+__global__ __launch_bounds__(64) void point_attention_bwd_probs_kernel(
+    const float *__restrict__ qkv_p, const float *__restrict__ qkv_l, const float *__restrict__ dout,
+    float *__restrict__ dqkv_p, float *__restrict__ dSbuf, float *__restrict__ dSTbuf, float *__restrict__ PTbuf, int M,
+    int Ll, int heads, float scale) {
+    constexpr int DQ = D / 8;
+    const int lane = threadIdx.x, l32 = lane & 31, half = lane >> 5;
+    const int bh = blockIdx.x, b = bh / heads, h = bh % heads, C = heads * D, p0 = blockIdx.y * 32;
+    const int LT = (Ll + 31) / 32;
+    const float *lbase = qkv_l + (size_t)b * Ll * 3 * C + h * D;
+    const int prow = min(p0 + l32, M - 1);
+    const float *src = qkv_p + ((size_t)b * M + prow) * 3 * C + h * D;
+    const float *gsrc = dout + ((size_t)b * M + prow) * C + h * D;
+    f32x4v qf[DQ], gf[DQ], qr[DQ], ksf[DQ];
+    float s_self = 0.f, dp_self = 0.f;
+#pragma unroll
+    for (int t = 0; t < DQ; t++) {
+        qr[t] = *reinterpret_cast<const f32x4v *>(src + 4 * (2 * t + half));
+        qf[t] = qr[t] * scale;
+        gf[t] = *reinterpret_cast<const f32x4v *>(gsrc + 4 * (2 * t + half));
+        ksf[t] = *reinterpret_cast<const f32x4v *>(src + C + 4 * (2 * t + half));
+        const f32x4v vs = *reinterpret_cast<const f32x4v *>(src + 2 * C + 4 * (2 * t + half));
+        s_self += (qf[t].x * ksf[t].x + qf[t].y * ksf[t].y) + (qf[t].z * ksf[t].z + qf[t].w * ksf[t].w);
+        dp_self += (gf[t].x * vs.x + gf[t].y * vs.y) + (gf[t].z * vs.z + gf[t].w * vs.w);
+    }
+    s_self += __shfl_xor(s_self, 32, 64);
+    dp_self += __shfl_xor(dp_self, 32, 64);
+    f32x16v sT[PA2_TILES], dT[PA2_TILES];
+    float mx = s_self;
+#pragma unroll
+    for (int kt = 0; kt < PA2_TILES; kt++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) { sT[kt][r] = -INFINITY; dT[kt][r] = 0.f; }
+        if (kt < LT) {
+            const int krow = min(kt * 32 + l32, Ll - 1);
+            f32x16v a, c;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { a[r] = 0.f; c[r] = 0.f; }
+#pragma unroll
+            for (int t = 0; t < DQ; t++) {
+                const f32x4v kf = *reinterpret_cast<const f32x4v *>(lbase + (size_t)krow * 3 * C + C + 4 * (2 * t + half));
+                const f32x4v vf = *reinterpret_cast<const f32x4v *>(lbase + (size_t)krow * 3 * C + 2 * C + 4 * (2 * t + half));
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++) {
+                    a = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s4], qf[t][s4], a, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[s4], gf[t][s4], c, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int key = kt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+                sT[kt][r] = key < Ll ? a[r] : -INFINITY;
+                dT[kt][r] = c[r];
+                mx = fmaxf(mx, sT[kt][r]);
+            }
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float den = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < PA2_TILES; kt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            sT[kt][r] = expf(sT[kt][r] - mx);
+            den += sT[kt][r];
+        }
+    den += __shfl_xor(den, 32, 64);
+    float p_self = expf(s_self - mx);
+    den += p_self;
+    const float inv = 1.0f / den;
+    p_self *= inv;
+    float delta = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < PA2_TILES; kt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            sT[kt][r] *= inv;
+            delta += sT[kt][r] * dT[kt][r];
+        }
+    delta += __shfl_xor(delta, 32, 64);
+    delta += p_self * dp_self;
+    const float ds_self = p_self * (dp_self - delta);
+    const bool live = p0 + l32 < M;
+    if (live) {
+        float *o = dqkv_p + ((size_t)b * M + p0 + l32) * 3 * C + h * D;
+#pragma unroll
+        for (int t = 0; t < DQ; t++) {
+            *reinterpret_cast<f32x4v *>(o + 4 * (2 * t + half)) = ksf[t] * (scale * ds_self);
+            *reinterpret_cast<f32x4v *>(o + C + 4 * (2 * t + half)) = qr[t] * (scale * ds_self);
+            *reinterpret_cast<f32x4v *>(o + 2 * C + 4 * (2 * t + half)) = gf[t] * p_self;
+        }
+    }
+    float *dSrow = dSbuf + ((size_t)bh * M + min(p0 + l32, M - 1)) * Ll;
+#pragma unroll
+    for (int kt = 0; kt < PA2_TILES; kt++)
+        if (kt < LT)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int key = kt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+                if (key < Ll && live) {
+                    const float pv = sT[kt][r], ds = pv * (dT[kt][r] - delta);
+                    dSrow[key] = ds;
+                    dSTbuf[((size_t)bh * Ll + key) * M + p0 + l32] = ds;
+                    PTbuf[((size_t)bh * Ll + key) * M + p0 + l32] = pv;
+                }
+            }
+}
+
+// which 0: dq tile (32 points);  which 1 / 2: a dK_l / dV_l partial (32 latents x one chunk of points)
+__global__ __launch_bounds__(64) void point_attention_bwd_gemm_kernel(
+    const float *__restrict__ qkv_p, const float *__restrict__ qkv_l, const float *__restrict__ dout,
+    float *__restrict__ dqkv_p, float *__restrict__ partial, const float *__restrict__ dSbuf,
+    const float *__restrict__ dSTbuf, const float *__restrict__ PTbuf, int M, int Ll, int heads, float scale, int MT,
+    int LT, int MS) {
+    const int lane = threadIdx.x, l32 = lane & 31, half = lane >> 5;
+    const int bh = blockIdx.x, b = bh / heads, h = bh % heads, C = heads * D;
+    int t = blockIdx.y, which, r0, ms = 0;
+    if (t < MT) { which = 0; r0 = t * 32; }
+    else { t -= MT; which = 1 + t / (LT * MS); t %= LT * MS; r0 = (t / MS) * 32; ms = t % MS; }
+    f32x16v acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    const int m = r0 + l32;                                    // this lane's A row
+    constexpr int U = 8;
+    if (which == 0) {
+        const bool m_ok = m < M;
+        const float *A = dSbuf + ((size_t)bh * M + min(m, M - 1)) * Ll;
+        const float *Bp = qkv_l + (size_t)b * Ll * 3 * C + C + h * D + l32;
+        for (int k0 = 0; k0 < Ll; k0 += 2 * U) {
+            float av[U], bv[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int k = k0 + 2 * u + half;
+                const bool ok = k < Ll;
+                const int kc = ok ? k : Ll - 1;
+                av[u] = (ok && m_ok) ? A[kc] : 0.f;
+                bv[u] = ok ? Bp[(size_t)kc * 3 * C] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = r0 + 8 * (r >> 2) + 4 * half + (r & 3);
+            if (row < M) {
+                float *o = dqkv_p + ((size_t)b * M + row) * 3 * C + h * D + l32;
+                *o = *o + scale * acc[r];                      // the self part is already there (pass 1)
+            }
+        }
+        return;
+    }
+    const bool m_ok = m < Ll;
+    const float *A = (which == 1 ? dSTbuf : PTbuf) + ((size_t)bh * Ll + min(m, Ll - 1)) * M;
+    const float *Bp = which == 1 ? qkv_p + (size_t)b * M * 3 * C + h * D + l32 : dout + (size_t)b * M * C + h * D + l32;
+    const size_t b_step = which == 1 ? 3 * C : C;
+    const int k_end = min(M, (ms + 1) * PA2_CHUNK);
+    for (int k0 = ms * PA2_CHUNK; k0 < k_end; k0 += 2 * U) {
+        float av[U], bv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int k = k0 + 2 * u + half;
+            const bool ok = k < k_end;
+            const int kc = ok ? k : k_end - 1;
+            av[u] = (ok && m_ok) ? A[kc] : 0.f;
+            bv[u] = ok ? Bp[(size_t)kc * b_step] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+    float *dst = partial + (((size_t)ms * gridDim.x + bh) * 2 + (which - 1)) * Ll * D;
+    const float mul = which == 1 ? scale : 1.0f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int row = r0 + 8 * (r >> 2) + 4 * half + (r & 3);
+        if (row < Ll) dst[(size_t)row * D + l32] = acc[r] * mul;
+    }
+}
+
 // dqkv_l[b][j][{1,2}][h][d] (+)= sum over tiles; the q columns are zeroed when not accumulating
 __global__ __launch_bounds__(256) void point_attention_reduce_kernel(const float *__restrict__ partial,
                                                                      float *__restrict__ dqkv_l, int tiles, int BH,
@@ -452,8 +639,13 @@ extern "C" int zs_point_attention(const float *qkv_points, const float *qkv_late
     return zs::check_launch("zs_point_attention") ? 1 : 0;
 }
 
+static size_t pa_partial_floats(int batch, int M, int Ll, int heads) {
+    const int tiles = (M + PT - 1) / PT, chunks = (M + PA2_CHUNK - 1) / PA2_CHUNK;
+    return (size_t)(tiles > chunks ? tiles : chunks) * batch * heads * 2 * Ll * D;
+}
 extern "C" size_t zs_point_attention_bwd_workspace_bytes(int batch, int M, int Ll, int heads) {
-    return (size_t)((M + PT - 1) / PT) * batch * heads * 2 * Ll * D * sizeof(float);
+    // [partial tiles of dK_l / dV_l][dS rows][dS^T][P^T]
+    return (pa_partial_floats(batch, M, Ll, heads) + (size_t)3 * batch * heads * M * Ll) * sizeof(float);
 }
 
 extern "C" int zs_point_attention_bwd(const float *qkv_points, const float *qkv_latent, const float *dout,
@@ -464,9 +656,25 @@ extern "C" int zs_point_attention_bwd(const float *qkv_points, const float *qkv_
     if (batch == 0) return 1;
     ZS_REQUIRE(qkv_points && qkv_latent && dout && dqkv_points && dqkv_latent && workspace,
                "zs_point_attention_bwd: null pointer");
-    const int tiles = (M + PT - 1) / PT, BH = batch * heads;
-    const dim3 grid(BH, tiles);
+    const int BH = batch * heads;
     float *partial = static_cast<float *>(workspace);
+    static const bool bwd_valu = getenv("ZS_POINT_ATTN_VALU") != nullptr;    // A/B switch: the vector-ALU kernel
+    const int MT = (M + 31) / 32, LT = (Ll + 31) / 32, MS = (M + PA2_CHUNK - 1) / PA2_CHUNK;
+    if (!bwd_valu && LT <= PA2_TILES && MT + 2 * LT * MS <= 65535) {
+        const float scale = 1.0f / sqrtf((float)head_dim);
+        float *dS = partial + pa_partial_floats(batch, M, Ll, heads), *dST = dS + (size_t)BH * M * Ll,
+              *PTb = dST + (size_t)BH * M * Ll;
+        hipLaunchKernelGGL(point_attention_bwd_probs_kernel, dim3(BH, MT), dim3(64), 0, S(stream), qkv_points, qkv_latent,
+                           dout, dqkv_points, dS, dST, PTb, M, Ll, heads, scale);
+        hipLaunchKernelGGL(point_attention_bwd_gemm_kernel, dim3(BH, MT + 2 * LT * MS), dim3(64), 0, S(stream), qkv_points,
+                           qkv_latent, dout, dqkv_points, partial, dS, dST, PTb, M, Ll, heads, scale, MT, LT, MS);
+        if (!zs::check_launch("zs_point_attention_bwd")) return 0;
+        hipLaunchKernelGGL(point_attention_reduce_kernel, dim3(blocks_for((size_t)BH * 3 * Ll * D)), dim3(256), 0, S(stream),
+                           partial, dqkv_latent, MS, BH, Ll, heads, accumulate_latent ? 1 : 0);
+        return zs::check_launch("zs_point_attention_bwd(reduce)") ? 1 : 0;
+    }
+    const int tiles = (M + PT - 1) / PT;
+    const dim3 grid(BH, tiles);
     hipLaunchKernelGGL(point_attention_bwd_kernel, grid, dim3(256), pa_lds_bytes(Ll, true), S(stream), qkv_points,
                        qkv_latent, dout, dqkv_points, partial, M, Ll, heads, 1.0f / sqrtf((float)head_dim));
     if (!zs::check_launch("zs_point_attention_bwd")) return 0;
