@@ -64,18 +64,33 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackEntry 
     const size_t total = (size_t)t.K16 * t.NPad, s0 = chunk_start[blockIdx.x];
     const size_t s1 = s0 + PACK_CHUNK < total ? s0 + PACK_CHUNK : total;
     const int CinP = (t.Cin + 3) & ~3, CoutP = (t.Cout + 3) & ~3;
-    for (size_t i = s0 + threadIdx.x; i < s1; i += 256) {
-        const int e = i & 3, n = (i >> 2) % t.NPad, k = (int)((i >> 2) / t.NPad) * 4 + e;
-        float v = 0.f;
+    // a thread writes the four k of one (k-group, n) as one 16-byte store (chunks start on multiples of 4); its reads
+    // are one 16-byte load where the four k are contiguous in the source (pointwise forward packs), else four loads
+    // that are each contiguous across the lanes (dgrad: consecutive n = consecutive input channels)
+    const bool vec_src = !t.dgrad && t.taps == 1 && (t.ld & 3) == 0 && (t.cin0 & 3) == 0 &&
+                         (reinterpret_cast<size_t>(t.src) & 15) == 0;
+    for (size_t i = s0 + 4 * (size_t)threadIdx.x; i < s1; i += 1024) {
+        const int n = (i >> 2) % t.NPad, k = (int)((i >> 2) / t.NPad) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (!t.dgrad) {
-            const int tap = k / CinP, c = k - tap * CinP;
-            if (tap < t.taps && c < t.Cin && n < t.Cout) v = t.src[(size_t)n * t.ld + (size_t)(t.cin0 + c) * t.taps + tap];
+            if (n < t.Cout) {
+                if (vec_src && k + 3 < t.Cin) v = *reinterpret_cast<const f32x4 *>(t.src + (size_t)n * t.ld + t.cin0 + k);
+                else {
+                    const int tap = k / CinP, c = k - tap * CinP;          // CinP % 4 == 0: one tap per k-group
+                    if (tap < t.taps)
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (c + e < t.Cin) v[e] = t.src[(size_t)n * t.ld + (size_t)(t.cin0 + c + e) * t.taps + tap];
+                }
+            }
         } else {
             const int tap = k / CoutP, co = k - tap * CoutP;
-            if (tap < t.taps && co < t.Cout && n < t.Cin)
-                v = t.src[(size_t)co * t.ld + (size_t)(t.cin0 + n) * t.taps + (t.taps - 1 - tap)];
+            if (tap < t.taps && n < t.Cin)
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (co + e < t.Cout) v[e] = t.src[(size_t)(co + e) * t.ld + (size_t)(t.cin0 + n) * t.taps + (t.taps - 1 - tap)];
         }
-        t.dst[i] = v;
+        *reinterpret_cast<f32x4 *>(t.dst + i) = v;
     }
 }
 
@@ -268,25 +283,48 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     }
 }
 
-// partial [splits][CoutP][K] (k = tap*CinP + c) -> dw[cout*ld + (cin0+c)*taps + tap], cout < Cout, c < Cin
+// partial [splits][CoutP][K] (k = tap*CinP + c) -> dw[cout*ld + (cin0+c)*taps + tap], cout < Cout, c < Cin; the bias
+// gradient (column sums of dY per split) rides as Cout extra outputs.  An output is summed by ZL adjacent lanes
+// (splits strided over them, combined by a fixed butterfly): small weights with hundreds of splits must not be a
+// serial walk on one workgroup.  A thread covers all taps of its (cout, c): the taps of one weight row are
+// contiguous in dw, so a wave writes one contiguous span instead of every ninth float of nine.
+template <int ZL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, float *__restrict__ dw,
                                                            int splits, int CoutP, int K, int Cout, int Cin, int CinP,
                                                            int cin0, int ld, int taps, int accumulate,
                                                            const float *__restrict__ bias_partial,
                                                            float *__restrict__ db) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)Cout * K;
-    if (db && i < (size_t)Cout) {
-        float t = 0.f;
-        for (int z = 0; z < splits; z++) t += bias_partial[(size_t)z * CoutP + i];
-        db[i] = t;
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, i = t / ZL, n_w = (size_t)Cout * CinP;
+    const int zl = (int)(t % ZL);
+    const size_t n_all = n_w + (db ? (size_t)Cout : 0);
+    if (i >= n_all) return;                                   // whole ZL groups leave together
+    if (i >= n_w) {
+        const size_t co = i - n_w;
+        float sb = 0.f;
+        for (int z = zl; z < splits; z += ZL) sb += bias_partial[(size_t)z * CoutP + co];
+#pragma unroll
+        for (int o = ZL / 2; o > 0; o >>= 1) sb += __shfl_xor(sb, o, 64);
+        if (zl == 0) db[co] = sb;
+        return;
     }
-    if (i >= total) return;
-    const int k = i % K, co = i / K, tap = k / CinP, c = k - tap * CinP;
+    const int c = (int)(i % CinP), co = (int)(i / CinP);
     if (c >= Cin) return;
-    float s = 0.f;
-    for (int z = 0; z < splits; z++) s += partial[((size_t)z * CoutP + co) * K + k];
-    float *o = dw + (size_t)co * ld + (size_t)(cin0 + c) * taps + tap;
-    *o = accumulate ? *o + s : s;
+    float *o = dw + (size_t)co * ld + (size_t)(cin0 + c) * taps;
+    const size_t zstride = (size_t)CoutP * K;
+    for (int tap = 0; tap < taps; tap++) {
+        const float *src = partial + (size_t)co * K + (size_t)tap * CinP + c;
+        float s0 = 0.f, s1 = 0.f;
+        int z = zl;
+        for (; z + ZL < splits; z += 2 * ZL) {
+            s0 += src[(size_t)z * zstride];
+            s1 += src[(size_t)(z + ZL) * zstride];
+        }
+        if (z < splits) s0 += src[(size_t)z * zstride];
+        float sum = s0 + s1;
+#pragma unroll
+        for (int off = ZL / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        if (zl == 0) o[tap] = accumulate ? o[tap] + sum : sum;
+    }
 }
 
 // ---- StdConv2d weight standardisation: per output channel (w - mean) / sqrt(biased var + eps) ----
@@ -488,9 +526,25 @@ extern "C" int zs_conv2d_wgrad(const float *in, const float *dy, float *dw, floa
     else ZS_WGRAD(128);
 #undef ZS_WGRAD
     if (!zs::check_launch("zs_conv2d_wgrad")) return 0;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for((size_t)Cout * a.K)), dim3(256), 0, S(stream), a.partial, dw,
-                       splits, a.CoutP, a.K, Cout, Cin, CinP, cin0, CinTot * kh * kw, kh * kw, accumulate ? 1 : 0, a.bias_partial,
-                       db);
+    {
+        const size_t outs = (size_t)Cout * CinP + (db ? Cout : 0);
+        int zl = 1;                                            // lanes per output: enough threads for a few waves per CU
+        while (zl < 64 && 2 * zl <= splits && outs * zl < (size_t)(1 << 17)) zl *= 2;
+#define ZS_WRED(Z)                                                                                                     \
+        hipLaunchKernelGGL((wgrad_reduce_kernel<Z>), dim3(blocks_for(outs * Z)), dim3(256), 0, S(stream), a.partial, dw,    \
+                           splits, a.CoutP, a.K, Cout, Cin, CinP, cin0, CinTot * kh * kw, kh * kw, accumulate ? 1 : 0,      \
+                           a.bias_partial, db)
+        switch (zl) {
+            case 1: ZS_WRED(1); break;
+            case 2: ZS_WRED(2); break;
+            case 4: ZS_WRED(4); break;
+            case 8: ZS_WRED(8); break;
+            case 16: ZS_WRED(16); break;
+            case 32: ZS_WRED(32); break;
+            default: ZS_WRED(64); break;
+        }
+#undef ZS_WRED
+    }
     return zs::check_launch("zs_conv2d_wgrad(reduce)") ? 1 : 0;
 }
 

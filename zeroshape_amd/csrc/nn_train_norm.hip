@@ -195,60 +195,118 @@ __device__ __forceinline__ double gn_block_sum(double v, double *lds) {
     for (int w = 1; w < GN_BLOCK / 64; w++) r += lds[w];
     return r;
 }
+// VEC channels per thread (min(cg, 4): one 4 / 8 / 16-byte load per tensor and pixel); the threads of a pixel are
+// adjacent lanes, so a wave reads whole group rows.
+template <int VEC>
 __global__ __launch_bounds__(GN_BLOCK) void group_norm_bwd_kernel(
     const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ y,
     const float *__restrict__ gamma, float *__restrict__ dx, float *__restrict__ dres,
     float *__restrict__ dgamma_part, float *__restrict__ dbeta_part, int HW, int C, int groups, float eps) {
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
     __shared__ double lds[GN_BLOCK / 64];
-    __shared__ double col[2][GN_BLOCK];
-    const int b = blockIdx.x / groups, g = blockIdx.x % groups, cg = C / groups;
-    const int ch = threadIdx.x % cg, p0 = threadIdx.x / cg, pstep = GN_BLOCK / cg;
-    const size_t base = (size_t)b * HW * C + (size_t)g * cg + ch;
-    const float gam = gamma[g * cg + ch];
-    double sx = 0, sxx = 0, sr = 0, srx = 0;                   // per thread: one channel
-    for (int p = p0; p < HW; p += pstep) {
-        const size_t o = base + (size_t)p * C;
-        const float xv = x[o], gr = (y && !(y[o] > 0.f)) ? 0.f : dy[o];
-        sx += xv;
-        sxx += (double)xv * xv;
-        sr += gr;
-        srx += (double)gr * xv;
+    __shared__ double col[GN_BLOCK / 64][2][64];               // [wave][dy | dy x][channel of the group]
+    const int b = blockIdx.x / groups, g = blockIdx.x % groups, cg = C / groups, qn = cg / VEC;
+    const int cq = threadIdx.x % qn, p0 = threadIdx.x / qn, pstep = GN_BLOCK / qn;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t base = (size_t)b * HW * C + (size_t)g * cg + cq * VEC;
+    float gam[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; e++) gam[e] = gamma[g * cg + cq * VEC + e];
+    double sx = 0, sxx = 0, sg = 0, sgx = 0, sr[VEC], srx[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; e++) sr[e] = srx[e] = 0;
+    auto load = [&](const float *ptr, size_t o, float *v) {
+        if constexpr (VEC == 1) v[0] = ptr[o];
+        else {
+            const vec_t t = *reinterpret_cast<const vec_t *>(ptr + o);
+#pragma unroll
+            for (int e = 0; e < VEC; e++) v[e] = t[e];
+        }
+    };
+    auto accumulate = [&](const float *xv, const float *gv, const float *yv) {
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            const float gr = (y && !(yv[e] > 0.f)) ? 0.f : gv[e];
+            sx += xv[e];
+            sxx += (double)xv[e] * xv[e];
+            sr[e] += gr;
+            srx[e] += (double)gr * xv[e];
+        }
+    };
+    int p = p0;
+    for (; p + pstep < HW; p += 2 * pstep) {                   // two pixels in flight
+        const size_t o0 = base + (size_t)p * C, o1 = o0 + (size_t)pstep * C;
+        float x0[VEC], g0[VEC], y0[VEC], x1[VEC], g1[VEC], y1[VEC];
+        load(x, o0, x0); load(dy, o0, g0); load(x, o1, x1); load(dy, o1, g1);
+        if (y) { load(y, o0, y0); load(y, o1, y1); }
+        accumulate(x0, g0, y0);
+        accumulate(x1, g1, y1);
     }
+    if (p < HW) {
+        const size_t o0 = base + (size_t)p * C;
+        float x0[VEC], g0[VEC], y0[VEC];
+        load(x, o0, x0); load(dy, o0, g0);
+        if (y) load(y, o0, y0);
+        accumulate(x0, g0, y0);
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; e++) { sg += sr[e] * gam[e]; sgx += srx[e] * gam[e]; }
     const double n = (double)HW * cg;
     const double Sx = gn_block_sum(sx, lds), Sxx = gn_block_sum(sxx, lds);
-    const double Sg = gn_block_sum(sr * gam, lds), Sgx = gn_block_sum(srx * gam, lds);
+    const double Sg = gn_block_sum(sg, lds), Sgx = gn_block_sum(sgx, lds);
     const double mean = Sx / n;
     double var = Sxx / n - mean * mean;
     var = var < 0.0 ? 0.0 : var;
     const double rstd = 1.0 / sqrt(var + (double)eps);
     const float mg = (float)(Sg / n), mgx = (float)((Sgx - mean * Sg) * rstd / n);
     const float meanf = (float)mean, rstdf = (float)rstd;
-    // per-channel sums over the pixel lanes of this channel (fixed order)
-    __syncthreads();
-    col[0][threadIdx.x] = sr;
-    col[1][threadIdx.x] = srx;
+    // per-channel sums: butterfly over the lanes of a wave that hold the same channels (fixed order), then the waves
+#pragma unroll
+    for (int e = 0; e < VEC; e++)
+        for (int off = 32; off >= qn; off >>= 1) {
+            sr[e] += __shfl_xor(sr[e], off, 64);
+            srx[e] += __shfl_xor(srx[e], off, 64);
+        }
+    if (lane < qn)
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            col[wave][0][lane * VEC + e] = sr[e];
+            col[wave][1][lane * VEC + e] = srx[e];
+        }
     __syncthreads();
     if (threadIdx.x < cg) {
         double tr = 0, trx = 0;
-        for (int k = threadIdx.x; k < GN_BLOCK; k += cg) { tr += col[0][k]; trx += col[1][k]; }
-        dbeta_part[(size_t)b * C + g * cg + threadIdx.x] = (float)tr;
-        dgamma_part[(size_t)b * C + g * cg + threadIdx.x] = (float)((trx - mean * tr) * rstd);
+        for (int w = 0; w < GN_BLOCK / 64; w++) { tr += col[w][0][threadIdx.x]; trx += col[w][1][threadIdx.x]; }
+        // rows of [dgamma | dbeta], one per sample
+        dgamma_part[(size_t)b * 2 * C + g * cg + threadIdx.x] = (float)((trx - mean * tr) * rstd);
+        dbeta_part[(size_t)b * 2 * C + g * cg + threadIdx.x] = (float)tr;
     }
-    for (int p = p0; p < HW; p += pstep) {
+    for (p = p0; p < HW; p += pstep) {
         const size_t o = base + (size_t)p * C;
-        const float gr = (y && !(y[o] > 0.f)) ? 0.f : dy[o], xh = (x[o] - meanf) * rstdf;
-        dx[o] = rstdf * (gr * gam - mg - xh * mgx);
-        if (dres) dres[o] = gr;
+        float xv[VEC], gv[VEC], yv[VEC];
+        load(x, o, xv); load(dy, o, gv);
+        if (y) load(y, o, yv);
+        vec_t out, res;
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            const float gr = (y && !(yv[e] > 0.f)) ? 0.f : gv[e], xh = (xv[e] - meanf) * rstdf;
+            out[e] = rstdf * (gr * gam[e] - mg - xh * mgx);
+            res[e] = gr;
+        }
+        *reinterpret_cast<vec_t *>(dx + o) = out;
+        if (dres) *reinterpret_cast<vec_t *>(dres + o) = res;
     }
 }
 
-__global__ __launch_bounds__(256) void sum_rows_kernel(const float *__restrict__ part, float *__restrict__ out, int rows,
-                                                       int C) {
+// out[c] = sum_r part[r][c], c < C; columns C .. 2C-1 (the second vector of the same rows) go to out2
+__global__ __launch_bounds__(256) void sum_rows_kernel(const float *__restrict__ part, float *__restrict__ out,
+                                                       float *__restrict__ out2, int rows, int C, int C2) {
     const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    if (c >= C2) return;
     float s = 0.f;
-    for (int r = 0; r < rows; r++) s += part[(size_t)r * C + c];
-    out[c] = s;
+    for (int r = 0; r < rows; r++) s += part[(size_t)r * C2 + c];
+    if (c < C) out[c] = s;
+    else out2[c - C] = s;
 }
 
 // ---------------- pooling / resampling backward (gather form, no atomics) ----------------
@@ -457,11 +515,17 @@ extern "C" int zs_group_norm_bwd(const float *x, const float *dy, const float *y
                "zs_group_norm_bwd: bad size (B=%d HW=%d C=%d groups=%d; channels per group: a power of two <= 64)", batch,
                HW, C, groups);
     ZS_REQUIRE(x && dy && gamma && dx && dgamma && dbeta && workspace, "zs_group_norm_bwd: null pointer");
-    float *pg = static_cast<float *>(workspace), *pb = pg + (size_t)batch * C;
-    hipLaunchKernelGGL(group_norm_bwd_kernel, dim3(batch * groups), dim3(GN_BLOCK), 0, S(stream), x, dy, y_relu, gamma, dx,
-                       dresidual, pg, pb, HW, C, groups, eps);
-    hipLaunchKernelGGL(sum_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, S(stream), pg, dgamma, batch, C);
-    hipLaunchKernelGGL(sum_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, S(stream), pb, dbeta, batch, C);
+    float *pg = static_cast<float *>(workspace), *pb = pg + C;
+    const int cg = C / groups;
+#define ZS_GNB(V)                                                                                                          \
+    hipLaunchKernelGGL((group_norm_bwd_kernel<V>), dim3(batch * groups), dim3(GN_BLOCK), 0, S(stream), x, dy, y_relu, gamma, \
+                       dx, dresidual, pg, pb, HW, C, groups, eps)
+    if (cg >= 4) ZS_GNB(4);
+    else if (cg == 2) ZS_GNB(2);
+    else ZS_GNB(1);
+#undef ZS_GNB
+    hipLaunchKernelGGL(sum_rows_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, S(stream), pg, dgamma, dbeta, batch, C,
+                       2 * C);
     return zs::check_launch("zs_group_norm_bwd") ? 1 : 0;
 }
 

@@ -87,18 +87,34 @@ __global__ __launch_bounds__(256) void column_partial_kernel(const float *__rest
     __syncthreads();
     if (ry == 0 && c < C) partial[(size_t)blockIdx.y * C + c] = (lds[0][cx] + lds[1][cx]) + (lds[2][cx] + lds[3][cx]);
 }
-// out[c] = scale * sum_k partial[k * stride + c]: 64 columns per workgroup, the chunks strided over 4
-// row-lanes and combined in a fixed order
+// out[c] = scale * sum_k partial[k * stride + c], c < C  (columns C .. C2-1 go to out2 - a second vector in the same
+// partial rows, e.g. dbeta beside dgamma): 16 columns per workgroup, the chunks strided over 16 row-lanes and
+// combined in a fixed order (a pass over a few thousand chunks must not run on four workgroups)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partial, float *__restrict__ out,
-                                                              int chunks, int C, int stride, float scale) {
-    __shared__ float lds[4][64];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6, c = blockIdx.x * 64 + cx;
-    float s = 0.f;
-    if (c < C)
-        for (int k = ry; k < chunks; k += 4) s += partial[(size_t)k * stride + c];
-    lds[ry][cx] = s;
+                                                              float *__restrict__ out2, int chunks, int C, int C2,
+                                                              int stride, float scale) {
+    __shared__ float lds[16][17];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4, c = blockIdx.x * 16 + cx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < C2) {
+        int k = ry;
+        for (; k + 48 < chunks; k += 64) {
+            s0 += partial[(size_t)k * stride + c];
+            s1 += partial[(size_t)(k + 16) * stride + c];
+            s2 += partial[(size_t)(k + 32) * stride + c];
+            s3 += partial[(size_t)(k + 48) * stride + c];
+        }
+        for (; k < chunks; k += 16) s0 += partial[(size_t)k * stride + c];
+    }
+    lds[ry][cx] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (ry == 0 && c < C) out[c] = ((lds[0][cx] + lds[1][cx]) + (lds[2][cx] + lds[3][cx])) * scale;
+    if (ry == 0 && c < C2) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) t += lds[r][cx];
+        if (c < C) out[c] = t * scale;
+        else out2[c - C] = t * scale;
+    }
 }
 
 // ---- LayerNorm backward: wave per row for dx, per-workgroup partial dgamma / dbeta ----
@@ -495,8 +511,8 @@ extern "C" int zs_column_sum(const float *x, float *out, int rows, int C, float 
     float *partial = static_cast<float *>(workspace);
     hipLaunchKernelGGL(column_partial_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, S(stream), x, partial, rows, C,
                        per);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 63) / 64), dim3(256), 0, S(stream), partial, out, chunks, C,
-                       C, scale);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 15) / 16), dim3(256), 0, S(stream), partial, out,
+                       static_cast<float *>(nullptr), chunks, C, C, C, scale);
     return zs::check_launch("zs_column_sum") ? 1 : 0;
 }
 
@@ -514,10 +530,8 @@ extern "C" int zs_layer_norm_bwd(const float *dy, const float *x, const float *g
     hipLaunchKernelGGL(layer_norm_bwd_kernel, dim3(wgs), dim3(256), 8 * C * sizeof(float), S(stream), dy, x, gamma, dx,
                        partial, rows, C, eps);
     // partial is [wg][2][C]: rows of stride 2C, dgamma in the first half, dbeta in the second
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 63) / 64), dim3(256), 0, S(stream), partial, dgamma, wgs, C,
-                       2 * C, 1.0f);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 63) / 64), dim3(256), 0, S(stream), partial + C, dbeta, wgs,
-                       C, 2 * C, 1.0f);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, S(stream), partial, dgamma, dbeta,
+                       wgs, C, 2 * C, 2 * C, 1.0f);
     return zs::check_launch("zs_layer_norm_bwd") ? 1 : 0;
 }
 
