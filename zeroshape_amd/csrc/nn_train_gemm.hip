@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackEntry 
     const bool vec_src = !t.dgrad && t.taps == 1 && (t.ld & 3) == 0 && (t.cin0 & 3) == 0 &&
                          (reinterpret_cast<size_t>(t.src) & 15) == 0;
     for (size_t i = s0 + 4 * (size_t)threadIdx.x; i < s1; i += 1024) {
-        const int n = (i >> 2) % t.NPad, k = (int)((i >> 2) / t.NPad) * 4;
+        const unsigned q = (unsigned)(i >> 2);                 // 32-bit divisions: K16 * NPad / 4 < 2^32
+        const int n = (int)(q % (unsigned)t.NPad), k = (int)(q / (unsigned)t.NPad) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (!t.dgrad) {
             if (n < t.Cout) {
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
         if (zl == 0) db[co] = sb;
         return;
     }
-    const int c = (int)(i % CinP), co = (int)(i / CinP);
+    const int c = (int)((unsigned)i % (unsigned)CinP), co = (int)((unsigned)i / (unsigned)CinP);   // Cout * CinP < 2^32
     if (c >= Cin) return;
     float *o = dw + (size_t)co * ld + (size_t)(cin0 + c) * taps;
     const size_t zstride = (size_t)CoutP * K;

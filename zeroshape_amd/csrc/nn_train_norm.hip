@@ -177,52 +177,39 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restri
     if (dres) *reinterpret_cast<f32x4 *>(dres + i) = g;
 }
 
-// ---------------- GroupNorm backward: one workgroup per (sample, group), two passes ----------------
-// Pass A gathers every sum at once (x, x^2, g, g x with g = gamma * masked dy, and per channel
-// dy, dy x) in double; statistics and the projections follow algebraically
-// (sum g xhat = rstd (sum g x - mean sum g)).  Pass B writes dx (and the masked dy for the residual).
-// A thread keeps ONE channel (c = tid % cg, cg a power of two <= 64) and strides over the pixels.
-constexpr int GN_BLOCK = 1024;
-__device__ __forceinline__ double gn_block_sum(double v, double *lds) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    __syncthreads();
-    if (lane == 0) lds[wave] = v;
-    __syncthreads();
-    double r = lds[0];
-#pragma unroll
-    for (int w = 1; w < GN_BLOCK / 64; w++) r += lds[w];
-    return r;
-}
-// VEC channels per thread (min(cg, 4): one 4 / 8 / 16-byte load per tensor and pixel); the threads of a pixel are
-// adjacent lanes, so a wave reads whole group rows.
+// ---------------- GroupNorm backward: (sample, group) x pixel slices, two launches ----------------
+// A (sample, group) holds HW * cg values behind one stride-C gather; on one workgroup it runs at one CU's bandwidth
+// with half the chip idle (28 us per layer at batch 4), so its pixels are cut into `slices` slices.  Launch 1 sums
+// every slice at once (x, x^2 and per channel dy, dy x with dy masked by the fused ReLU) in double into
+// stat[bg][slice][2 + 2 cg]; launch 2 adds the slices in slice order - statistics and the projections follow
+// algebraically (sum g xhat = rstd (sum g x - mean sum g), g = gamma dy) - and writes dx (and the masked dy for the
+// residual) of its slice.  VEC = min(cg, 4) channels per thread (one 4 / 8 / 16-byte load per tensor and pixel); the
+// threads of a pixel are adjacent lanes, so a wave reads whole group rows.
+constexpr int GNB_BLOCK = 256;
 template <int VEC>
-__global__ __launch_bounds__(GN_BLOCK) void group_norm_bwd_kernel(
-    const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ y,
-    const float *__restrict__ gamma, float *__restrict__ dx, float *__restrict__ dres,
-    float *__restrict__ dgamma_part, float *__restrict__ dbeta_part, int HW, int C, int groups, float eps) {
+__device__ __forceinline__ void gn_load(const float *ptr, size_t o, float *v) {
     typedef float vec_t __attribute__((ext_vector_type(VEC)));
-    __shared__ double lds[GN_BLOCK / 64];
-    __shared__ double col[GN_BLOCK / 64][2][64];               // [wave][dy | dy x][channel of the group]
-    const int b = blockIdx.x / groups, g = blockIdx.x % groups, cg = C / groups, qn = cg / VEC;
-    const int cq = threadIdx.x % qn, p0 = threadIdx.x / qn, pstep = GN_BLOCK / qn;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t base = (size_t)b * HW * C + (size_t)g * cg + cq * VEC;
-    float gam[VEC];
+    if constexpr (VEC == 1) v[0] = ptr[o];
+    else {
+        const vec_t t = *reinterpret_cast<const vec_t *>(ptr + o);
 #pragma unroll
-    for (int e = 0; e < VEC; e++) gam[e] = gamma[g * cg + cq * VEC + e];
-    double sx = 0, sxx = 0, sg = 0, sgx = 0, sr[VEC], srx[VEC];
+        for (int e = 0; e < VEC; e++) v[e] = t[e];
+    }
+}
+template <int VEC>
+__global__ __launch_bounds__(GNB_BLOCK) void group_norm_bwd_stats_kernel(
+    const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ y, double *__restrict__ stat,
+    int HW, int C, int groups, int per_slice) {
+    __shared__ double red[GNB_BLOCK / 64][2];
+    __shared__ double col[GNB_BLOCK / 64][2][64];              // [wave][dy | dy x][channel of the group]
+    const int cg = C / groups, qn = cg / VEC, b = blockIdx.x / groups, g = blockIdx.x % groups;
+    const int cq = threadIdx.x % qn, p0 = threadIdx.x / qn, pstep = GNB_BLOCK / qn;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p_begin = blockIdx.y * per_slice, p_end = min(HW, p_begin + per_slice);
+    const size_t base = (size_t)b * HW * C + (size_t)g * cg + cq * VEC;
+    double sx = 0, sxx = 0, sr[VEC], srx[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; e++) sr[e] = srx[e] = 0;
-    auto load = [&](const float *ptr, size_t o, float *v) {
-        if constexpr (VEC == 1) v[0] = ptr[o];
-        else {
-            const vec_t t = *reinterpret_cast<const vec_t *>(ptr + o);
-#pragma unroll
-            for (int e = 0; e < VEC; e++) v[e] = t[e];
-        }
-    };
     auto accumulate = [&](const float *xv, const float *gv, const float *yv) {
 #pragma unroll
         for (int e = 0; e < VEC; e++) {
@@ -233,40 +220,32 @@ __global__ __launch_bounds__(GN_BLOCK) void group_norm_bwd_kernel(
             srx[e] += (double)gr * xv[e];
         }
     };
-    int p = p0;
-    for (; p + pstep < HW; p += 2 * pstep) {                   // two pixels in flight
+    int p = p_begin + p0;
+    for (; p + pstep < p_end; p += 2 * pstep) {                // two pixels in flight
         const size_t o0 = base + (size_t)p * C, o1 = o0 + (size_t)pstep * C;
         float x0[VEC], g0[VEC], y0[VEC], x1[VEC], g1[VEC], y1[VEC];
-        load(x, o0, x0); load(dy, o0, g0); load(x, o1, x1); load(dy, o1, g1);
-        if (y) { load(y, o0, y0); load(y, o1, y1); }
+        gn_load<VEC>(x, o0, x0); gn_load<VEC>(dy, o0, g0); gn_load<VEC>(x, o1, x1); gn_load<VEC>(dy, o1, g1);
+        if (y) { gn_load<VEC>(y, o0, y0); gn_load<VEC>(y, o1, y1); }
         accumulate(x0, g0, y0);
         accumulate(x1, g1, y1);
     }
-    if (p < HW) {
+    if (p < p_end) {
         const size_t o0 = base + (size_t)p * C;
         float x0[VEC], g0[VEC], y0[VEC];
-        load(x, o0, x0); load(dy, o0, g0);
-        if (y) load(y, o0, y0);
+        gn_load<VEC>(x, o0, x0); gn_load<VEC>(dy, o0, g0);
+        if (y) gn_load<VEC>(y, o0, y0);
         accumulate(x0, g0, y0);
     }
+    // fixed-order sums: butterflies inside a wave (all lanes for x, the lanes of the same channels for dy), then the waves
 #pragma unroll
-    for (int e = 0; e < VEC; e++) { sg += sr[e] * gam[e]; sgx += srx[e] * gam[e]; }
-    const double n = (double)HW * cg;
-    const double Sx = gn_block_sum(sx, lds), Sxx = gn_block_sum(sxx, lds);
-    const double Sg = gn_block_sum(sg, lds), Sgx = gn_block_sum(sgx, lds);
-    const double mean = Sx / n;
-    double var = Sxx / n - mean * mean;
-    var = var < 0.0 ? 0.0 : var;
-    const double rstd = 1.0 / sqrt(var + (double)eps);
-    const float mg = (float)(Sg / n), mgx = (float)((Sgx - mean * Sg) * rstd / n);
-    const float meanf = (float)mean, rstdf = (float)rstd;
-    // per-channel sums: butterfly over the lanes of a wave that hold the same channels (fixed order), then the waves
+    for (int off = 32; off > 0; off >>= 1) { sx += __shfl_xor(sx, off, 64); sxx += __shfl_xor(sxx, off, 64); }
 #pragma unroll
     for (int e = 0; e < VEC; e++)
         for (int off = 32; off >= qn; off >>= 1) {
             sr[e] += __shfl_xor(sr[e], off, 64);
             srx[e] += __shfl_xor(srx[e], off, 64);
         }
+    if (lane == 0) { red[wave][0] = sx; red[wave][1] = sxx; }
     if (lane < qn)
 #pragma unroll
         for (int e = 0; e < VEC; e++) {
@@ -274,18 +253,69 @@ __global__ __launch_bounds__(GN_BLOCK) void group_norm_bwd_kernel(
             col[wave][1][lane * VEC + e] = srx[e];
         }
     __syncthreads();
-    if (threadIdx.x < cg) {
-        double tr = 0, trx = 0;
-        for (int w = 0; w < GN_BLOCK / 64; w++) { tr += col[w][0][threadIdx.x]; trx += col[w][1][threadIdx.x]; }
-        // rows of [dgamma | dbeta], one per sample
-        dgamma_part[(size_t)b * 2 * C + g * cg + threadIdx.x] = (float)((trx - mean * tr) * rstd);
-        dbeta_part[(size_t)b * 2 * C + g * cg + threadIdx.x] = (float)tr;
+    double *out = stat + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (2 + 2 * cg);
+    const int t = threadIdx.x;
+    if (t < 2) out[t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    else if (t < 2 + 2 * cg) {
+        const int which = (t - 2) / cg, c = (t - 2) % cg;
+        out[t] = (col[0][which][c] + col[1][which][c]) + (col[2][which][c] + col[3][which][c]);
     }
-    for (p = p0; p < HW; p += pstep) {
+}
+
+template <int VEC>
+__global__ __launch_bounds__(GNB_BLOCK) void group_norm_bwd_apply_kernel(
+    const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ y,
+    const float *__restrict__ gamma, const double *__restrict__ stat, float *__restrict__ dx, float *__restrict__ dres,
+    float *__restrict__ dgamma_part, float *__restrict__ dbeta_part, int HW, int C, int groups, int per_slice, float eps) {
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    __shared__ double tot[2 + 2 * 64];
+    __shared__ float bc[4];                                    // mean, rstd, mean of g, mean of g xhat
+    const int cg = C / groups, qn = cg / VEC, b = blockIdx.x / groups, g = blockIdx.x % groups;
+    const int cq = threadIdx.x % qn, p0 = threadIdx.x / qn, pstep = GNB_BLOCK / qn, n_stat = 2 + 2 * cg;
+    const int slices = gridDim.y;
+    if (threadIdx.x < n_stat) {
+        const double *src = stat + (size_t)blockIdx.x * slices * n_stat + threadIdx.x;
+        double t = 0;
+        for (int sl = 0; sl < slices; sl++) t += src[(size_t)sl * n_stat];
+        tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const double n = (double)HW * cg, mean = tot[0] / n;
+        double var = tot[1] / n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        double sg = 0, sgx = 0;
+        if ((int)threadIdx.x < cg) {
+            const double gm = gamma[g * cg + threadIdx.x], tr = tot[2 + threadIdx.x], trx = tot[2 + cg + threadIdx.x];
+            sg = tr * gm;
+            sgx = trx * gm;
+            if (blockIdx.y == 0) {                             // rows of [dgamma | dbeta], one per sample
+                dgamma_part[(size_t)b * 2 * C + g * cg + threadIdx.x] = (float)((trx - mean * tr) * rstd);
+                dbeta_part[(size_t)b * 2 * C + g * cg + threadIdx.x] = (float)tr;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { sg += __shfl_xor(sg, off, 64); sgx += __shfl_xor(sgx, off, 64); }
+        if (threadIdx.x == 0) {
+            bc[0] = (float)mean;
+            bc[1] = (float)rstd;
+            bc[2] = (float)(sg / n);
+            bc[3] = (float)((sgx - mean * sg) * rstd / n);
+        }
+    }
+    __syncthreads();
+    const float meanf = bc[0], rstdf = bc[1], mg = bc[2], mgx = bc[3];
+    float gam[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; e++) gam[e] = gamma[g * cg + cq * VEC + e];
+    const int p_begin = blockIdx.y * per_slice, p_end = min(HW, p_begin + per_slice);
+    const size_t base = (size_t)b * HW * C + (size_t)g * cg + cq * VEC;
+    for (int p = p_begin + p0; p < p_end; p += pstep) {
         const size_t o = base + (size_t)p * C;
         float xv[VEC], gv[VEC], yv[VEC];
-        load(x, o, xv); load(dy, o, gv);
-        if (y) load(y, o, yv);
+        gn_load<VEC>(x, o, xv); gn_load<VEC>(dy, o, gv);
+        if (y) gn_load<VEC>(y, o, yv);
         vec_t out, res;
 #pragma unroll
         for (int e = 0; e < VEC; e++) {
@@ -507,6 +537,15 @@ extern "C" int zs_batch_norm_bwd(const float *x, const float *dy, const float *y
     return zs::check_launch("zs_batch_norm_bwd") ? 1 : 0;
 }
 
+constexpr int GNB_MAX_SLICES = 16;
+// pixel slices per (sample, group): ~1024 workgroups in all, at least 64 pixels each
+static int gn_bwd_slices(int batch, int HW, int groups) {
+    int s = (1024 + batch * groups - 1) / (batch * groups);
+    if (s > HW / 64) s = HW / 64;
+    if (s > GNB_MAX_SLICES) s = GNB_MAX_SLICES;
+    return s < 1 ? 1 : s;
+}
+
 extern "C" int zs_group_norm_bwd(const float *x, const float *dy, const float *y_relu, const float *gamma, float *dx,
                                  float *dresidual, float *dgamma, float *dbeta, int batch, int HW, int C, int groups,
                                  float eps, void *workspace, void *stream) {
@@ -515,11 +554,17 @@ extern "C" int zs_group_norm_bwd(const float *x, const float *dy, const float *y
                "zs_group_norm_bwd: bad size (B=%d HW=%d C=%d groups=%d; channels per group: a power of two <= 64)", batch,
                HW, C, groups);
     ZS_REQUIRE(x && dy && gamma && dx && dgamma && dbeta && workspace, "zs_group_norm_bwd: null pointer");
-    float *pg = static_cast<float *>(workspace), *pb = pg + C;
-    const int cg = C / groups;
+    const int cg = C / groups, slices = gn_bwd_slices(batch, HW, groups), per_slice = (HW + slices - 1) / slices;
+    double *stat = static_cast<double *>(workspace);
+    float *pg = reinterpret_cast<float *>(stat + (size_t)batch * groups * slices * (2 + 2 * cg)), *pb = pg + C;
+    const dim3 grid(batch * groups, slices);
 #define ZS_GNB(V)                                                                                                          \
-    hipLaunchKernelGGL((group_norm_bwd_kernel<V>), dim3(batch * groups), dim3(GN_BLOCK), 0, S(stream), x, dy, y_relu, gamma, \
-                       dx, dresidual, pg, pb, HW, C, groups, eps)
+    do {                                                                                                                   \
+        hipLaunchKernelGGL((group_norm_bwd_stats_kernel<V>), grid, dim3(GNB_BLOCK), 0, S(stream), x, dy, y_relu, stat, HW,  \
+                           C, groups, per_slice);                                                                          \
+        hipLaunchKernelGGL((group_norm_bwd_apply_kernel<V>), grid, dim3(GNB_BLOCK), 0, S(stream), x, dy, y_relu, gamma,     \
+                           stat, dx, dresidual, pg, pb, HW, C, groups, per_slice, eps);                                    \
+    } while (0)
     if (cg >= 4) ZS_GNB(4);
     else if (cg == 2) ZS_GNB(2);
     else ZS_GNB(1);
@@ -529,7 +574,11 @@ extern "C" int zs_group_norm_bwd(const float *x, const float *dy, const float *y
     return zs::check_launch("zs_group_norm_bwd") ? 1 : 0;
 }
 
-extern "C" size_t zs_group_norm_bwd_workspace_bytes(int batch, int C) { return (size_t)2 * batch * C * sizeof(float); }
+extern "C" size_t zs_group_norm_bwd_workspace_bytes(int batch, int C) {
+    // slice statistics (at most GNB_MAX_SLICES slices of 2 + 2 cg doubles per (sample, group): <= 4 C + 2 C doubles
+    // per sample and slice whatever the group count) + the per-sample [dgamma | dbeta] rows
+    return (size_t)batch * GNB_MAX_SLICES * 6 * C * sizeof(double) + (size_t)2 * batch * C * sizeof(float);
+}
 
 extern "C" int zs_max_pool_bwd_nhwc(const float *x, const float *dy, float *dx, int batch, int Hin, int Win, int C,
                                     int Hout, int Wout, int k, int stride, int pad_t, int pad_l, void *stream) {
