@@ -183,3 +183,31 @@ def test_optim_amp_runs_the_forward_convolutions_in_split_fp16(tmp_path, encoder
         assert np.isfinite(losses[True]) and abs(losses[True] - losses[False]) < 1e-4 * max(1.0, abs(losses[False])), losses
     finally:
         A.set_forward_precision("f32")
+
+
+def test_captured_step_matches_the_eager_step(tmp_path, encoder_sd, seeded_sd):
+    """--optim.hip_graph: forward + loss + backward replayed as one captured hipGraph (two eager warm-up steps, then the
+    capture), the optimiser behind it.  With DropPath off (its draws differ between the two modes only by the state
+    of the generator) the same batches give the same losses and the same weights as the eager step."""
+    from zeroshape_amd.utils import util
+    from zeroshape_amd.utils.options import EasyDict as edict
+    results = {}
+    for captured in (False, True):
+        opt = train_opt(tmp_path, *(["--optim.hip_graph"] if captured else []))
+        r = make_runner(opt, encoder_sd, seeded_sd, n_train=8)
+        for m in r.graph.modules():
+            if hasattr(m, "drop_path") and isinstance(m.drop_path, float):
+                m.drop_path = 0.0
+        r.graph.train()
+        batches = list(torch.utils.data.DataLoader(r.train_data, batch_size=4, shuffle=False))
+        losses = []
+        for it in range(6):
+            var = util.move_to_device(edict(batches[it % 2]), opt.device)
+            losses.append(float(r.train_iteration(opt, var).all))
+        assert (getattr(r, "_captured", None) is not None) == captured and r.it == 6
+        results[captured] = (losses, {k: v.detach().clone() for k, v in r.graph.state_dict().items()})
+    (l0, sd0), (l1, sd1) = results[False], results[True]
+    assert np.allclose(l0, l1, rtol=1e-6, atol=0), (l0, l1)
+    assert l0[4] != l0[0]                                      # the weights move
+    worst = max(float((sd0[k].float() - sd1[k].float()).abs().max()) for k in sd0)
+    assert worst <= 1e-6, worst

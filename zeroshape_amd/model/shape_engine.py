@@ -172,6 +172,10 @@ class Runner:
     def train_iteration(self, opt, var, batch_progress=None):
         """:248-297 without its per-iteration barrier (the all-reduce already orders the ranks) and
         without the tensorboard / visualiser calls."""
+        if self._step_capture_enabled(opt):
+            loss = self._train_iteration_captured(opt, var)
+            if loss is not None:
+                return loss
         var, loss = self.graph.forward(opt, var, training=True, get_loss=True)
         loss = self.summarize_loss(opt, var, loss)
         loss_scaled = loss.all / opt.optim.accum
@@ -192,6 +196,58 @@ class Runner:
             self.save_checkpoint(opt, ep=self.ep, it=self.it, best_val=self.best_val, best_ep=self.best_ep, latest=True)
         self.it += 1
         return loss
+
+    # ---- the step as one hipGraph --------------------------------------------------------------------------- #
+    # Forward + loss + backward are ~1500 launches whose Python / ctypes / allocator enqueue cost (31-37 ms at 4
+    # images per GPU) is as long as their GPU time.  With `optim.hip_graph` (or ZS_TRAIN_HIP_GRAPH=1) the launch
+    # sequence is stream-captured once per input signature and replayed: the batch is copied into the capture's
+    # static inputs, the gradients land in the capture's static .grad tensors, and gradient clipping + the one-launch
+    # AdamW run eagerly behind it (their scalars - step count, learning rate - change every step).  Everything the
+    # sequence reads besides the inputs is addressed in place (parameters, buffers, packed operands, workspaces);
+    # DropPath draws come from torch's graph-safe device generator.  Not captured: gradient accumulation windows
+    # and the multi-process reducer (the eager path below handles both).
+    def _step_capture_enabled(self, opt):
+        flag = os.environ.get("ZS_TRAIN_HIP_GRAPH")
+        on = flag not in ("0", "") if flag is not None else bool(opt.optim.get("hip_graph", False))
+        return on and opt.optim.accum == 1 and self.reducer is None
+
+    def _train_iteration_captured(self, opt, var):
+        """One step through the captured launch sequence; None while it is still warming up eagerly (the first
+        two steps of a signature allocate workspaces, pack operands and build the launch tables)."""
+        from ..nn import autograd as A
+        tensors = {k: v for k, v in var.items() if torch.is_tensor(v)}
+        trainable = tuple(id(p) for p in self.graph.parameters() if p.requires_grad)
+        sig = (tuple((k, tuple(v.shape), v.dtype, str(v.device)) for k, v in sorted(tensors.items())), trainable)
+        st = getattr(self, "_captured", None)
+        if st is not None and (st["sig"] != sig or st["scratch"] != A.SCRATCH_GENERATION[0]):
+            st = self._captured = None             # other shapes, or a workspace moved (an evaluation in between)
+            self._capture_warm = 0
+        if st is None:
+            if getattr(self, "_capture_warm", 0) < 2:
+                self._capture_warm = getattr(self, "_capture_warm", 0) + 1
+                return None
+            static = {k: v.clone() for k, v in tensors.items()}
+            static_var = edict({k: static.get(k, v) for k, v in var.items()})
+            self.optim.zero_grad(set_to_none=True)
+            A.bump_generation()                    # the capture must contain the operand re-pack
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out_var, loss = self.graph.forward(opt, static_var, training=True, get_loss=True)
+                loss = self.summarize_loss(opt, out_var, loss)
+                loss.all.backward()
+            st = self._captured = dict(sig=sig, scratch=A.SCRATCH_GENERATION[0], graph=graph, static=static, loss=loss)
+        for k, t in st["static"].items():
+            t.copy_(tensors[k], non_blocking=True)
+        st["graph"].replay()
+        if opt.optim.clip_norm:
+            self.optim.clip_grad_norm_(opt.optim.clip_norm)
+        self.optim.step()                          # no zero_grad: the replay overwrites the static gradients
+        if self._rank() == 0 and getattr(opt, "output_path", None) and not getattr(opt, "debug", False) \
+                and self.it > 0 and self.it % opt.freq.ckpt_latest == 0:
+            self.save_checkpoint(opt, ep=self.ep, it=self.it, best_val=self.best_val, best_ep=self.best_ep, latest=True)
+        self.it += 1
+        return st["loss"]
 
     def save_checkpoint(self, opt, ep=0, it=0, best_val=np.inf, best_ep=1, latest=False, best=False):
         """:525-529."""

@@ -57,6 +57,9 @@ def _f32c(t, what):
 _SCRATCH = {}
 
 
+SCRATCH_GENERATION = [0]     # bumped when a workspace is (re)allocated: a captured step holds the old address
+
+
 def scratch(device, name, nbytes):
     key = (str(device), name)
     n = (int(nbytes) + 3) // 4
@@ -64,6 +67,7 @@ def scratch(device, name, nbytes):
     if buf is None or buf.numel() < n:
         buf = torch.empty(max(n, 1), dtype=torch.float32, device=device)
         _SCRATCH[key] = buf
+        SCRATCH_GENERATION[0] += 1
     return buf
 
 

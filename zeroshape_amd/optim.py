@@ -111,12 +111,15 @@ class FusedAdamW(torch.optim.Optimizer):
                                                st["exp_avg_sq"].data_ptr(), p.numel(), group["lr"],
                                                group["weight_decay"]))
         for (step, betas, eps, dev), entries in by_key.items():
-            tab, ct, cs, nchunks = build_table(entries, dev)
+            cache = self.__dict__.setdefault("_tables", {})
+            hit = cache.get((betas, eps, dev))
+            if hit is None or hit[0] != entries:   # same tensors, learning rates and decays as last step: same table
+                hit = cache[(betas, eps, dev)] = (entries, build_table(entries, dev))
+            tab, ct, cs, nchunks = hit[1]
             with _lib.on(dev):
                 _lib.check(lib.zs_adamw_multi(_lib.ptr(tab), _lib.ptr(ct), _lib.ptr(cs), nchunks, betas[0], betas[1],
                                               eps, step, _lib.ptr(self._clip), _lib.current_stream_ptr(dev)),
                            "zs_adamw_multi")
-            self._keep = (tab, ct, cs)        # keep the tables alive until the launch has consumed them
         self._clip = None
         A.bump_generation()                   # parameters changed behind torch's version counters
         return None
