@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 26
+#define ZS_ABI_VERSION 27
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -476,14 +476,18 @@ int zs_pack_conv_weight(const float *w, float *packed, int Cout, int Cin, int ci
                         int dgrad, void *stream);
 /* zs_pack_conv_weight over a DEVICE table of layers in one launch (every operand of a model after
  * an optimiser step): ld = CinTot*kh*kw, taps = kh*kw, K16 / NPad = the padded operand dimensions
- * (K rounded up to 16, N rounded up to 128); chunk c = elements [chunk_start[c],
- * +zs_pack_chunk_elems()) of the operand of entry chunk_entry[c]. */
+ * (K rounded up to 16, N rounded up to 128); chunk c = the chunk_start[c]-th of the
+ * zs_pack_entry_chunks(...) chunks of entry chunk_entry[c] (an LDS tile of 64 operand columns x 16 or 64
+ * channels x all taps for kernels up to 3x3, zs_pack_chunk_elems() consecutive elements otherwise), every chunk
+ * of an entry exactly once.  The operand must have been packed once by zs_pack_conv_weight (its K padding rows
+ * are not rewritten). */
 typedef struct zs_pack_entry {
     const float *src;
     float *dst;
     int Cout, Cin, cin0, ld, taps, dgrad, K16, NPad;
 } zs_pack_entry;
 int zs_pack_chunk_elems(void);
+int zs_pack_entry_chunks(int Cout, int Cin, int taps, int dgrad, int K16, int NPad);
 int zs_pack_conv_weight_multi(const zs_pack_entry *table, const int *chunk_entry, const unsigned long long *chunk_start,
                               int n_chunks, void *stream);
 size_t zs_conv2d_wgrad_workspace_bytes(int batch, int Hout, int Wout, int Cin, int Cout, int kh, int kw);

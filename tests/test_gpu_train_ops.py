@@ -280,3 +280,37 @@ def test_stem_data_gradient_small_cin(k, stride, pad, H, Cout, std):
     close(xg.grad[..., :3].permute(0, 3, 1, 2), xr.grad, what="dx")
     assert float(xg.grad[..., 3].abs().max()) == 0
     close(wg.grad, wr.grad, rtol=1e-4, what="dW")
+
+
+def test_repack_of_all_operands_in_one_launch_equals_the_single_packs():
+    """zs_pack_conv_weight_multi (the re-pack after an optimiser step: LDS tiles for kernels up to 3x3, element chunks
+    otherwise) writes exactly what zs_pack_conv_weight writes, forward and data-gradient operands, channel
+    sub-ranges, ragged channel counts."""
+    from zeroshape_amd import _lib
+    from zeroshape_amd.nn import autograd as A
+    g = torch.Generator().manual_seed(5)
+    shapes = [(3072, 768, 1, 1), (768, 3072, 1, 1), (256, 256, 3, 3), (64, 3, 7, 7), (10, 6, 3, 3), (130, 70, 1, 1),
+              (32, 128, 3, 3), (1, 32, 1, 1), (96, 67, 2, 2)]
+    weights = [torch.nn.Parameter(torch.randn(s, generator=g).cuda()) for s in shapes]
+    keys = []
+    for w in weights:
+        for dgrad in (False, True):
+            keys.append((w, 0, w.shape[1], dgrad))
+    sub = weights[2]
+    keys.append((sub, 64, 128, False))           # channels [64, 192) of 256, like the decoder's concatenated inputs
+    keys.append((sub, 64, 128, True))
+    first = [A._pack(w, c0, c, d).clone() for w, c0, c, d in keys]
+    with torch.no_grad():
+        for w in weights:
+            w.copy_(torch.randn(w.shape, generator=g).cuda())
+    A.bump_generation()
+    again = [A._pack(w, c0, c, d) for w, c0, c, d in keys]          # the first call re-packs every stale operand
+    lib = _lib.load()
+    for (w, c0, c, d), old, new in zip(keys, first, again):
+        want = torch.empty_like(new)
+        kh, kw = w.shape[2], w.shape[3]
+        with torch.cuda.device(w.device):
+            _lib.check(lib.zs_pack_conv_weight(_lib.ptr(w.detach()), _lib.ptr(want), w.shape[0], c, c0, w.shape[1], kh, kw,
+                                               1 if d else 0, _lib.current_stream_ptr(w.device)), "zs_pack_conv_weight")
+        assert not torch.equal(old, new)
+        assert torch.equal(new, want), (tuple(w.shape), c0, c, d)

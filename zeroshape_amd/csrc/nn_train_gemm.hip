@@ -57,41 +57,89 @@ struct PackEntry {               // mirrors include/zeroshape_hip.h zs_pack_entr
     int Cout, Cin, cin0, ld, taps, dgrad, K16, NPad;
 };
 constexpr int PACK_CHUNK = 16384;
+constexpr int PACK_TILE_TAPS = 9;          // kernels up to 3x3 repack through LDS tiles
+constexpr int PACK_ROWS = 64;              // operand columns (n) per tile
+__host__ __device__ inline int pack_ct(int taps) { return taps == 1 ? 64 : 16; }      // K-side channels per tile
+// chunks of one entry: LDS tiles (64 n x CT channels x all taps) for small kernels, PACK_CHUNK elements otherwise
+static int pack_entry_chunks(int Cout, int Cin, int taps, int dgrad, int K16, int NPad) {
+    if (taps > PACK_TILE_TAPS) return (int)(((size_t)K16 * NPad + PACK_CHUNK - 1) / PACK_CHUNK);
+    const int Kc = ((dgrad ? Cout : Cin) + 3) / 4 * 4, CT = pack_ct(taps);
+    return ((Kc + CT - 1) / CT) * (NPad / PACK_ROWS);
+}
+constexpr int PACK_LDS_FLOATS = 64 * 145;  // >= 64 x (16*9 | 1), 16 x 64*9, 64 x 65
+
+// A repack is a transpose: the source is contiguous along (channel, tap) of one output channel, the operand along n.
+// A tile is read with whole contiguous source spans per row (64 B .. 2.3 KB) into LDS and written as 16-byte
+// (k-group, n) cells that are contiguous over n (1 KB runs).  Reading the source cell by cell instead made every
+// 64-byte line travel to four (pointwise) or nine (3x3) workgroups on different XCDs.
+// The K padding rows of the operand (k >= taps * Kc) are written once by zs_pack_conv_weight and never change.
 __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackEntry *__restrict__ tab,
                                                                 const int *__restrict__ chunk_entry,
                                                                 const unsigned long long *__restrict__ chunk_start) {
+    extern __shared__ float plds[];
     const PackEntry t = tab[chunk_entry[blockIdx.x]];
-    const size_t total = (size_t)t.K16 * t.NPad, s0 = chunk_start[blockIdx.x];
-    const size_t s1 = s0 + PACK_CHUNK < total ? s0 + PACK_CHUNK : total;
     const int CinP = (t.Cin + 3) & ~3, CoutP = (t.Cout + 3) & ~3;
-    // a thread writes the four k of one (k-group, n) as one 16-byte store (chunks start on multiples of 4); its reads
-    // are one 16-byte load where the four k are contiguous in the source (pointwise forward packs), else four loads
-    // that are each contiguous across the lanes (dgrad: consecutive n = consecutive input channels)
-    const bool vec_src = !t.dgrad && t.taps == 1 && (t.ld & 3) == 0 && (t.cin0 & 3) == 0 &&
-                         (reinterpret_cast<size_t>(t.src) & 15) == 0;
-    for (size_t i = s0 + 4 * (size_t)threadIdx.x; i < s1; i += 1024) {
-        const unsigned q = (unsigned)(i >> 2);                 // 32-bit divisions: K16 * NPad / 4 < 2^32
-        const int n = (int)(q % (unsigned)t.NPad), k = (int)(q / (unsigned)t.NPad) * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (!t.dgrad) {
-            if (n < t.Cout) {
-                if (vec_src && k + 3 < t.Cin) v = *reinterpret_cast<const f32x4 *>(t.src + (size_t)n * t.ld + t.cin0 + k);
-                else {
-                    const int tap = k / CinP, c = k - tap * CinP;          // CinP % 4 == 0: one tap per k-group
-                    if (tap < t.taps)
+    const unsigned ord = (unsigned)chunk_start[blockIdx.x];
+    if (t.taps > PACK_TILE_TAPS) {
+        const size_t total = (size_t)t.K16 * t.NPad, s0 = (size_t)ord * PACK_CHUNK;
+        const size_t s1 = s0 + PACK_CHUNK < total ? s0 + PACK_CHUNK : total;
+        for (size_t i = s0 + 4 * (size_t)threadIdx.x; i < s1; i += 1024) {
+            const unsigned q = (unsigned)(i >> 2);                 // 32-bit divisions: K16 * NPad / 4 < 2^32
+            const int n = (int)(q % (unsigned)t.NPad), k = (int)(q / (unsigned)t.NPad) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (!t.dgrad) {
+                const int tap = k / CinP, c = k - tap * CinP;      // CinP % 4 == 0: one tap per k-group
+                if (tap < t.taps && n < t.Cout)
 #pragma unroll
-                        for (int e = 0; e < 4; e++)
-                            if (c + e < t.Cin) v[e] = t.src[(size_t)n * t.ld + (size_t)(t.cin0 + c + e) * t.taps + tap];
-                }
+                    for (int e = 0; e < 4; e++)
+                        if (c + e < t.Cin) v[e] = t.src[(size_t)n * t.ld + (size_t)(t.cin0 + c + e) * t.taps + tap];
+            } else {
+                const int tap = k / CoutP, co = k - tap * CoutP;
+                if (tap < t.taps && n < t.Cin)
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (co + e < t.Cout)
+                            v[e] = t.src[(size_t)(co + e) * t.ld + (size_t)(t.cin0 + n) * t.taps + (t.taps - 1 - tap)];
             }
-        } else {
-            const int tap = k / CoutP, co = k - tap * CoutP;
-            if (tap < t.taps && n < t.Cin)
-#pragma unroll
-                for (int e = 0; e < 4; e++)
-                    if (co + e < t.Cout) v[e] = t.src[(size_t)(co + e) * t.ld + (size_t)(t.cin0 + n) * t.taps + (t.taps - 1 - tap)];
+            *reinterpret_cast<f32x4 *>(t.dst + i) = v;
         }
-        *reinterpret_cast<f32x4 *>(t.dst + i) = v;
+        return;
+    }
+    const int taps = t.taps, CT = pack_ct(taps), NT = t.NPad / PACK_ROWS;
+    const int n0 = (int)(ord % (unsigned)NT) * PACK_ROWS, c0 = (int)(ord / (unsigned)NT) * CT;
+    const int quads = CT / 4, cells = taps * quads * PACK_ROWS;
+    if (!t.dgrad) {
+        // rows = output channels n, span = CT channels x taps of one row
+        const int span = CT * taps, stride = span | 1;             // odd row stride: the cell gather below walks rows
+        const float *src = t.src + (size_t)(t.cin0 + c0) * taps;
+        for (int idx = threadIdx.x; idx < PACK_ROWS * span; idx += 256) {
+            const int r = idx / span, j = idx - r * span, n = n0 + r, c = c0 + j / taps;
+            plds[r * stride + j] = (n < t.Cout && c < t.Cin) ? src[(size_t)n * t.ld + j] : 0.f;
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < cells; idx += 256) {
+            const int nl = idx & (PACK_ROWS - 1), q = idx >> 6, cq = q % quads, tap = q / quads, c = c0 + 4 * cq;
+            if (c >= CinP) continue;
+            const float *cell = plds + nl * stride + 4 * cq * taps + tap;
+            const f32x4 v = {cell[0], cell[taps], cell[2 * taps], cell[3 * taps]};
+            *reinterpret_cast<f32x4 *>(t.dst + ((size_t)(tap * (CinP / 4) + c / 4) * t.NPad + n0 + nl) * 4) = v;
+        }
+    } else {
+        // rows = output channels co (the K side), span = 64 input channels n x taps of one row; taps flipped
+        const int span = PACK_ROWS * taps;
+        const float *src = t.src + (size_t)(t.cin0 + n0) * taps;
+        for (int idx = threadIdx.x; idx < CT * span; idx += 256) {
+            const int r = idx / span, j = idx - r * span, co = c0 + r, n = n0 + j / taps;
+            plds[r * span + j] = (co < t.Cout && n < t.Cin) ? src[(size_t)co * t.ld + j] : 0.f;
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < cells; idx += 256) {
+            const int nl = idx & (PACK_ROWS - 1), q = idx >> 6, cq = q % quads, tap = q / quads, co = c0 + 4 * cq;
+            if (co >= CoutP) continue;
+            const float *cell = plds + 4 * cq * span + nl * taps + (taps - 1 - tap);
+            const f32x4 v = {cell[0], cell[span], cell[2 * span], cell[3 * span]};
+            *reinterpret_cast<f32x4 *>(t.dst + ((size_t)(tap * (CoutP / 4) + co / 4) * t.NPad + n0 + nl) * 4) = v;
+        }
     }
 }
 
@@ -450,12 +498,18 @@ static_assert(sizeof(PackEntry) == sizeof(zs_pack_entry), "PackEntry must mirror
 
 extern "C" int zs_pack_chunk_elems(void) { return PACK_CHUNK; }
 
+extern "C" int zs_pack_entry_chunks(int Cout, int Cin, int taps, int dgrad, int K16, int NPad) {
+    ZS_REQUIRE(Cout > 0 && Cin > 0 && taps > 0 && K16 > 0 && NPad > 0 && NPad % 128 == 0,
+               "zs_pack_entry_chunks: bad operand (Cout=%d Cin=%d taps=%d K16=%d NPad=%d)", Cout, Cin, taps, K16, NPad);
+    return pack_entry_chunks(Cout, Cin, taps, dgrad, K16, NPad);
+}
+
 extern "C" int zs_pack_conv_weight_multi(const zs_pack_entry *table, const int *chunk_entry,
                                          const unsigned long long *chunk_start, int n_chunks, void *stream) {
     ZS_REQUIRE(n_chunks >= 0, "zs_pack_conv_weight_multi: bad arguments");
     if (n_chunks == 0) return 1;
     ZS_REQUIRE(table && chunk_entry && chunk_start, "zs_pack_conv_weight_multi: null pointer");
-    hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(n_chunks), dim3(256), 0, S(stream),
+    hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(n_chunks), dim3(256), PACK_LDS_FLOATS * sizeof(float), S(stream),
                        reinterpret_cast<const PackEntry *>(table), chunk_entry, chunk_start);
     return zs::check_launch("zs_pack_conv_weight_multi") ? 1 : 0;
 }

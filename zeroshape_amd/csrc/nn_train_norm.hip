@@ -10,6 +10,7 @@
 
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -175,6 +176,138 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restri
     *reinterpret_cast<f32x4 *>(dx + i) = *reinterpret_cast<const f32x4 *>(gamma + c) * rs *
         (g - *reinterpret_cast<const f32x4 *>(dbeta + c) * inv_n - xh * *reinterpret_cast<const f32x4 *>(dgamma + c) * inv_n);
     if (dres) *reinterpret_cast<f32x4 *>(dres + i) = g;
+}
+
+// ---------------- BatchNorm of a short tensor in ONE launch ----------------
+// At 4 images per GPU most ResNet-50 BatchNorms see 196 - 3136 rows: three launches of 4 - 11 us each (partials,
+// statistics, apply) for a few hundred KB.  A channel never needs another channel's rows, so a workgroup that owns
+// 16 channels (a 64-byte column strip: 4 channel quads x 64 row lanes) can do the whole layer on its strip: sum it
+// (double, fixed order), finish the statistics, and walk it again (the strip is a few hundred KB, the second walk
+// hits the cache) to write the output.  Used for rows <= bn_fused_rows(); longer tensors keep the chunked path, whose
+// row chunks spread over more workgroups than C / 16.
+static int bn_fused_rows() {           // A/B switch: ZS_BN_FUSED_ROWS=0 is always the three-launch path
+    static const int v = getenv("ZS_BN_FUSED_ROWS") ? atoi(getenv("ZS_BN_FUSED_ROWS")) : 1024;
+    return v;
+}
+// sum over the 64 row lanes of per-thread a[4], b[4] -> tot[2][16] (threads 0..31 hold one total each, in LDS)
+__device__ __forceinline__ void bn_strip_totals(const double *a, const double *b, double (*lds)[64][17], double (*tot)[16]) {
+    const int cq = threadIdx.x & 3, ry = threadIdx.x >> 2;
+#pragma unroll
+    for (int e = 0; e < 4; e++) { lds[0][ry][4 * cq + e] = a[e]; lds[1][ry][4 * cq + e] = b[e]; }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int which = threadIdx.x >> 4, col = threadIdx.x & 15;
+        double t = 0.0;
+        for (int k = 0; k < 64; k++) t += lds[which][k][col];
+        tot[which][col] = t;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void bn_fused_train_kernel(
+    const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+    const float *__restrict__ res, float *__restrict__ y, float *__restrict__ running_mean,
+    float *__restrict__ running_var, float *__restrict__ save_mean, float *__restrict__ save_rstd, int rows, int C,
+    float eps, float momentum, int relu) {
+    __shared__ double lds[2][64][17];
+    __shared__ double tot[2][16];
+    __shared__ __attribute__((aligned(16))) float stat[2][16];
+    const int cq = threadIdx.x & 3, ry = threadIdx.x >> 2, c = blockIdx.x * 16 + 4 * cq;
+    const bool live = c < C;                                   // C % 4 == 0: a quad is in range as a whole
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    if (live)
+        for (int r = ry; r < rows; r += 64) {
+            const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + (size_t)r * C + c);
+#pragma unroll
+            for (int e = 0; e < 4; e++) { a[e] += xv[e]; b[e] += (double)xv[e] * xv[e]; }
+        }
+    bn_strip_totals(a, b, lds, tot);
+    if (threadIdx.x < 16) {
+        const int cc = blockIdx.x * 16 + threadIdx.x;
+        const double mean = tot[0][threadIdx.x] / rows;
+        double var = tot[1][threadIdx.x] / rows - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + (double)eps));
+        stat[0][threadIdx.x] = mf;
+        stat[1][threadIdx.x] = rf;
+        if (cc < C) {
+            save_mean[cc] = mf;
+            save_rstd[cc] = rf;
+            if (running_mean) {      // torch: running = (1 - m) * running + m * batch, unbiased variance
+                const double unbiased = rows > 1 ? var * rows / (rows - 1.0) : var;
+                running_mean[cc] = (float)((1.0 - momentum) * running_mean[cc] + momentum * mean);
+                running_var[cc] = (float)((1.0 - momentum) * running_var[cc] + momentum * unbiased);
+            }
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    const f32x4 mu = *reinterpret_cast<const f32x4 *>(&stat[0][4 * cq]), rs = *reinterpret_cast<const f32x4 *>(&stat[1][4 * cq]),
+                ga = *reinterpret_cast<const f32x4 *>(gamma + c), be = *reinterpret_cast<const f32x4 *>(beta + c);
+    for (int r = ry; r < rows; r += 64) {
+        const size_t o = (size_t)r * C + c;
+        f32x4 v = (*reinterpret_cast<const f32x4 *>(x + o) - mu) * rs * ga + be;
+        if (res) v += *reinterpret_cast<const f32x4 *>(res + o);
+        if (relu)
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+        *reinterpret_cast<f32x4 *>(y + o) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_fused_bwd_kernel(
+    const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ y,
+    const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ rstd,
+    float *__restrict__ dx, float *__restrict__ dres, float *__restrict__ dgamma, float *__restrict__ dbeta, int rows,
+    int C) {
+    __shared__ double lds[2][64][17];
+    __shared__ double tot[2][16];
+    __shared__ __attribute__((aligned(16))) float sums[2][16];
+    const int cq = threadIdx.x & 3, ry = threadIdx.x >> 2, c = blockIdx.x * 16 + 4 * cq;
+    const bool live = c < C;
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    f32x4 mu = {0, 0, 0, 0}, rs = {0, 0, 0, 0};
+    if (live) {
+        mu = *reinterpret_cast<const f32x4 *>(mean + c);
+        rs = *reinterpret_cast<const f32x4 *>(rstd + c);
+        for (int r = ry; r < rows; r += 64) {
+            const size_t o = (size_t)r * C + c;
+            const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + o);
+            f32x4 g = *reinterpret_cast<const f32x4 *>(dy + o);
+            if (y) {
+                const f32x4 yv = *reinterpret_cast<const f32x4 *>(y + o);
+#pragma unroll
+                for (int e = 0; e < 4; e++) g[e] = yv[e] > 0.f ? g[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) { a[e] += g[e]; b[e] += (double)g[e] * ((xv[e] - mu[e]) * rs[e]); }
+        }
+    }
+    bn_strip_totals(a, b, lds, tot);
+    if (threadIdx.x < 16) {
+        const int cc = blockIdx.x * 16 + threadIdx.x;
+        const float sb = (float)tot[0][threadIdx.x], sg = (float)tot[1][threadIdx.x];
+        sums[0][threadIdx.x] = sb;
+        sums[1][threadIdx.x] = sg;
+        if (cc < C) { dbeta[cc] = sb; dgamma[cc] = sg; }
+    }
+    __syncthreads();
+    if (!live) return;
+    const float inv_n = 1.0f / rows;
+    const f32x4 db = *reinterpret_cast<const f32x4 *>(&sums[0][4 * cq]), dg = *reinterpret_cast<const f32x4 *>(&sums[1][4 * cq]),
+                ga = *reinterpret_cast<const f32x4 *>(gamma + c);
+    for (int r = ry; r < rows; r += 64) {
+        const size_t o = (size_t)r * C + c;
+        f32x4 g = *reinterpret_cast<const f32x4 *>(dy + o);
+        if (y) {
+            const f32x4 yv = *reinterpret_cast<const f32x4 *>(y + o);
+#pragma unroll
+            for (int e = 0; e < 4; e++) g[e] = yv[e] > 0.f ? g[e] : 0.f;
+        }
+        const f32x4 xh = (*reinterpret_cast<const f32x4 *>(x + o) - mu) * rs;
+        *reinterpret_cast<f32x4 *>(dx + o) = ga * rs * (g - db * inv_n - xh * dg * inv_n);
+        if (dres) *reinterpret_cast<f32x4 *>(dres + o) = g;
+    }
 }
 
 // ---------------- GroupNorm backward: (sample, group) x pixel slices, two launches ----------------
@@ -509,6 +642,11 @@ extern "C" int zs_batch_norm_train(const float *x, const float *gamma, const flo
     ZS_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0, "zs_batch_norm_train: bad size (rows=%d C=%d; C %% 4 == 0)", rows, C);
     ZS_REQUIRE(x && gamma && beta && y && save_mean && save_rstd && workspace, "zs_batch_norm_train: null pointer");
     ZS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "zs_batch_norm_train: running stats come in pairs");
+    if (rows <= bn_fused_rows()) {
+        hipLaunchKernelGGL(bn_fused_train_kernel, dim3((C + 15) / 16), dim3(256), 0, S(stream), x, gamma, beta, residual, y,
+                           running_mean, running_var, save_mean, save_rstd, rows, C, eps, momentum, relu);
+        return zs::check_launch("zs_batch_norm_train") ? 1 : 0;
+    }
     const int chunks = bn_chunks(rows), per = (rows + chunks - 1) / chunks;
     double *partial = static_cast<double *>(workspace);
     hipLaunchKernelGGL(bn_partial_kernel<0>, dim3((C + 63) / 64, chunks), dim3(256), 0, S(stream), x, nullptr, nullptr,
@@ -526,6 +664,11 @@ extern "C" int zs_batch_norm_bwd(const float *x, const float *dy, const float *y
     ZS_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0, "zs_batch_norm_bwd: bad size (rows=%d C=%d; C %% 4 == 0)", rows, C);
     ZS_REQUIRE(x && dy && gamma && save_mean && save_rstd && dx && dgamma && dbeta && workspace,
                "zs_batch_norm_bwd: null pointer");
+    if (rows <= bn_fused_rows()) {
+        hipLaunchKernelGGL(bn_fused_bwd_kernel, dim3((C + 15) / 16), dim3(256), 0, S(stream), x, dy, y_relu, gamma, save_mean,
+                           save_rstd, dx, dresidual, dgamma, dbeta, rows, C);
+        return zs::check_launch("zs_batch_norm_bwd") ? 1 : 0;
+    }
     const int chunks = bn_chunks(rows), per = (rows + chunks - 1) / chunks;
     double *partial = static_cast<double *>(workspace);
     hipLaunchKernelGGL(bn_partial_kernel<1>, dim3((C + 63) / 64, chunks), dim3(256), 0, S(stream), x, dy, y_relu,

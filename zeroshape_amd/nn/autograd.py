@@ -150,11 +150,12 @@ def _refresh_all_packs(device):
                                                                              "K16", "NPad")])
         assert dt.itemsize == 48
         tab = np.zeros(len(entries), dt)
-        chunk = lib.zs_pack_chunk_elems()
         ce, cs = [], []
         for i, e in enumerate(entries):
             tab[i] = e
-            starts = np.arange(0, e[8] * e[9], chunk, dtype=np.uint64)
+            n_chunks = lib.zs_pack_entry_chunks(e[2], e[3], e[6], e[7], e[8], e[9])
+            _lib.check(1 if n_chunks > 0 else 0, "zs_pack_entry_chunks")
+            starts = np.arange(n_chunks, dtype=np.uint64)
             ce.append(np.full(len(starts), i, np.int32))
             cs.append(starts)
         ce, cs = np.concatenate(ce), np.concatenate(cs)
