@@ -307,16 +307,18 @@ __global__ __launch_bounds__(256) void point_attention_bwd_kernel(const float *_
 // ---- the backward on the MFMA pipe --------------------------------------------------------------------------- //
 // pass 1, one wave per (b, h, 32 points), transposed like the forward kernel: S^T = K_l Q^T and dP^T = V_l dO^T of
 // all latent tiles stay in the accumulators; with the point's own logit and dO . v_self they give the probabilities,
-// delta = sum P dP and dS = P (dP - delta).  Written: dS [BH][M][Ll] (rows, for dq), dS^T and P^T [BH][Ll][M] (for
-// dK_l / dV_l: the accumulator layout IS the transposed one - consecutive lanes are consecutive points), and the
-// self parts of the point gradients (dq += scale ds_self k_self, dk_self = scale ds_self q, dv_self = p_self dO).
+// delta = sum P dP and dS = P (dP - delta).  Written: dS^T [BH][Ll][M] (the accumulator layout IS the transposed one -
+// consecutive lanes are consecutive points), dS and P as rows [BH][M][Ll], and the self parts of the point gradients
+// (dq += scale ds_self k_self, dk_self = scale ds_self q, dv_self = p_self dO).  Pass 2 reads each product's A
+// operand from the copy in which the 32 rows of its tile are adjacent (dq: points -> dS^T; dK_l / dV_l: latents ->
+// the row copies), so a wave's loads are whole lines.
 // pass 2, one wave per 32 x 32 output tile: dq = scale dS K_l (added to the self part), dK_l = scale dS^T Q and
 // dV_l = P^T dO over chunks of PA2_CHUNK points -> partial tiles, summed in chunk order by point_attention_reduce_kernel.
 constexpr int PA2_TILES = 8;          // Ll <= 256
 constexpr int PA2_CHUNK = 512;        // points per dK_l / dV_l partial
 __global__ __launch_bounds__(64) void point_attention_bwd_probs_kernel(
     const float *__restrict__ qkv_p, const float *__restrict__ qkv_l, const float *__restrict__ dout,
-    float *__restrict__ dqkv_p, float *__restrict__ dSbuf, float *__restrict__ dSTbuf, float *__restrict__ PTbuf, int M,
+    float *__restrict__ dqkv_p, float *__restrict__ dSbuf, float *__restrict__ dSTbuf, float *__restrict__ Pbuf, int M,
     int Ll, int heads, float scale) {
     constexpr int DQ = D / 8;
     const int lane = threadIdx.x, l32 = lane & 31, half = lane >> 5;
@@ -406,6 +408,7 @@ __global__ __launch_bounds__(64) void point_attention_bwd_probs_kernel(
         }
     }
     float *dSrow = dSbuf + ((size_t)bh * M + min(p0 + l32, M - 1)) * Ll;
+    float *Prow = Pbuf + ((size_t)bh * M + min(p0 + l32, M - 1)) * Ll;
 #pragma unroll
     for (int kt = 0; kt < PA2_TILES; kt++)
         if (kt < LT)
@@ -415,8 +418,8 @@ __global__ __launch_bounds__(64) void point_attention_bwd_probs_kernel(
                 if (key < Ll && live) {
                     const float pv = sT[kt][r], ds = pv * (dT[kt][r] - delta);
                     dSrow[key] = ds;
+                    Prow[key] = pv;
                     dSTbuf[((size_t)bh * Ll + key) * M + p0 + l32] = ds;
-                    PTbuf[((size_t)bh * Ll + key) * M + p0 + l32] = pv;
                 }
             }
 }
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(64) void point_attention_bwd_probs_kernel(
 __global__ __launch_bounds__(64) void point_attention_bwd_gemm_kernel(
     const float *__restrict__ qkv_p, const float *__restrict__ qkv_l, const float *__restrict__ dout,
     float *__restrict__ dqkv_p, float *__restrict__ partial, const float *__restrict__ dSbuf,
-    const float *__restrict__ dSTbuf, const float *__restrict__ PTbuf, int M, int Ll, int heads, float scale, int MT,
+    const float *__restrict__ dSTbuf, const float *__restrict__ Pbuf, int M, int Ll, int heads, float scale, int MT,
     int LT, int MS) {
     const int lane = threadIdx.x, l32 = lane & 31, half = lane >> 5;
     const int bh = blockIdx.x, b = bh / heads, h = bh % heads, C = heads * D;
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(64) void point_attention_bwd_gemm_kernel(
     constexpr int U = 8;
     if (which == 0) {
         const bool m_ok = m < M;
-        const float *A = dSbuf + ((size_t)bh * M + min(m, M - 1)) * Ll;
+        const float *A = dSTbuf + (size_t)bh * Ll * M + min(m, M - 1);           // A[m = point][k = latent] = dS^T[k][m]
         const float *Bp = qkv_l + (size_t)b * Ll * 3 * C + C + h * D + l32;
         for (int k0 = 0; k0 < Ll; k0 += 2 * U) {
             float av[U], bv[U];
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(64) void point_attention_bwd_gemm_kernel(
                 const int k = k0 + 2 * u + half;
                 const bool ok = k < Ll;
                 const int kc = ok ? k : Ll - 1;
-                av[u] = (ok && m_ok) ? A[kc] : 0.f;
+                av[u] = (ok && m_ok) ? A[(size_t)kc * M] : 0.f;
                 bv[u] = ok ? Bp[(size_t)kc * 3 * C] : 0.f;
             }
 #pragma unroll
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(64) void point_attention_bwd_gemm_kernel(
         return;
     }
     const bool m_ok = m < Ll;
-    const float *A = (which == 1 ? dSTbuf : PTbuf) + ((size_t)bh * Ll + min(m, Ll - 1)) * M;
+    const float *A = (which == 1 ? dSbuf : Pbuf) + (size_t)bh * M * Ll + min(m, Ll - 1);   // A[m = latent][k = point]
     const float *Bp = which == 1 ? qkv_p + (size_t)b * M * 3 * C + h * D + l32 : dout + (size_t)b * M * C + h * D + l32;
     const size_t b_step = which == 1 ? 3 * C : C;
     const int k_end = min(M, (ms + 1) * PA2_CHUNK);
@@ -476,7 +479,7 @@ __global__ __launch_bounds__(64) void point_attention_bwd_gemm_kernel(
             const int k = k0 + 2 * u + half;
             const bool ok = k < k_end;
             const int kc = ok ? k : k_end - 1;
-            av[u] = (ok && m_ok) ? A[kc] : 0.f;
+            av[u] = (ok && m_ok) ? A[(size_t)kc * Ll] : 0.f;
             bv[u] = ok ? Bp[(size_t)kc * b_step] : 0.f;
         }
 #pragma unroll
