@@ -460,7 +460,8 @@ int zs_window_tokens(const float *emb, const uint8_t *mask, const float *invalid
  *   zs_adamw_multi : torch.optim.AdamW (decoupled decay, bias correction, eps outside the
  *       sqrt) over a DEVICE table of tensors in one launch; chunk c = elements
  *       [chunk_start[c], +zs_multi_tensor_chunk_elems()) of tensor chunk_tensor[c].
- *       grad_scale (device scalar, may be NULL) multiplies every gradient (clipping).
+ *       grad_scale (device scalar, may be NULL) multiplies every gradient (clipping, loss-scale removal);
+ *       a grad_scale of 0 or nan skips the whole update (an overflowed gradient under loss scaling).
  *   zs_copy_multi  : entry.param[i] = entry.grad[i] * scale (gradient bucketing for all-reduce).
  *   zs_sumsq_multi : *sumsq = sum of entry.grad[i]^2 over the table (partial: n_chunks floats).
  * ------------------------------------------------------------------------- */

@@ -173,7 +173,8 @@ def test_optim_amp_runs_the_forward_convolutions_in_split_fp16(tmp_path, encoder
         for amp in (False, True):
             opt = train_opt(tmp_path, *(["--optim.amp"] if amp else []))
             r = make_runner(opt, encoder_sd, seeded_sd, n_train=4)
-            assert A.FWD_CONV_PRECISION == ("f16x3" if amp else "f32")
+            assert A.FWD_CONV_PRECISION == A.BWD_DATA_PRECISION == ("f16x3" if amp else "f32")
+            assert hasattr(r, "scaler") == amp
             r.graph.train()
             batch = next(iter(torch.utils.data.DataLoader(r.train_data, batch_size=4, shuffle=False)))
             before = r.graph.coord_encoder.encoder.conv1.weight.detach().clone()
@@ -183,6 +184,54 @@ def test_optim_amp_runs_the_forward_convolutions_in_split_fp16(tmp_path, encoder
         assert np.isfinite(losses[True]) and abs(losses[True] - losses[False]) < 1e-4 * max(1.0, abs(losses[False])), losses
     finally:
         A.set_forward_precision("f32")
+        A.set_backward_precision("f32")
+
+
+def test_optim_amp_gradients_and_the_loss_scaler(tmp_path, encoder_sd, seeded_sd):
+    """optim.amp data gradients on the split-fp16 convolution engine under the dynamic loss scale: every parameter's
+    gradient (unscaled) within 3e-4 of the one the exact-fp32 data-gradient kernels give for the same forward pass,
+    relative to the tensor's largest entry (measured 1.1e-4 at the initial scale 2^16, 4.5e-3 at 2^10: the error is
+    the fp16 subnormal floor under the scaled gradients, it shrinks as the scale grows).  A clean step grows the
+    tracker, an overflowing scale skips the step - weights and moments untouched - and halves."""
+    from zeroshape_amd.nn import autograd as A
+    from zeroshape_amd.utils import util
+    from zeroshape_amd.utils.options import EasyDict as edict
+    grads = {}
+    try:
+        for split_bwd in (False, True):
+            opt = train_opt(tmp_path, "--optim.amp")
+            r = make_runner(opt, encoder_sd, seeded_sd, n_train=4)
+            if not split_bwd:
+                A.set_backward_precision("f32")
+            for m in r.graph.modules():
+                if hasattr(m, "drop_path") and isinstance(m.drop_path, float):
+                    m.drop_path = 0.0
+            r.graph.train()
+            batch = next(iter(torch.utils.data.DataLoader(r.train_data, batch_size=4, shuffle=False)))
+            var, loss = r.graph.forward(opt, util.move_to_device(edict(batch), opt.device), training=True, get_loss=True)
+            loss = r.summarize_loss(opt, var, loss)
+            r.scaler.scale_loss(loss.all).backward()
+            inv = 1.0 / float(r.scaler.scale)
+            grads[split_bwd] = {n: p.grad.detach().double().cpu() * inv for n, p in r.graph.named_parameters()
+                                if p.grad is not None}
+        assert grads[True].keys() == grads[False].keys() and len(grads[True]) > 300
+        worst = max((float((grads[True][n] - g).abs().max()) / (float(g.abs().max()) + 1e-30), n) for n, g in grads[False].items())
+        assert 0 < worst[0] < 3e-4, worst
+        # r is the amp runner, its gradients are in place: a clean step, then an overflowing one
+        w = r.graph.coord_encoder.encoder.conv1.weight
+        before = w.detach().clone()
+        r.scaler.step(r.optim, None)
+        assert not torch.equal(before, w) and int(r.scaler.tracker) == 1 and float(r.scaler.scale) == 65536.0
+        r.optim.zero_grad()
+        r.scaler.scale.fill_(2.0 ** 100)
+        before = w.detach().clone()
+        m_before = r.optim.state[w]["exp_avg"].clone()
+        r.train_iteration(opt, util.move_to_device(edict(batch), opt.device))
+        assert torch.equal(before, w) and torch.equal(m_before, r.optim.state[w]["exp_avg"])
+        assert float(r.scaler.scale) == 2.0 ** 99 and int(r.scaler.tracker) == 0 and float(r.scaler.found_inf) == 1.0
+    finally:
+        A.set_forward_precision("f32")
+        A.set_backward_precision("f32")
 
 
 def test_captured_step_matches_the_eager_step(tmp_path, encoder_sd, seeded_sd):

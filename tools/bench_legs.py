@@ -244,45 +244,56 @@ def inference_leg(dev):
 
 def train_leg(dev, steps=8, warmup=3):
     """Runner.train_iteration (model/shape_engine.py:248-297) on BASELINE config 4's per-GPU batch: 4 images,
-    4096 SDF samples each, fp32, forward + backward + fused AdamW; eager launches, then the captured step."""
+    4096 SDF samples each, forward + backward + fused AdamW: fp32 with eager launches, fp32 as the captured step
+    (optim.hip_graph), and optim.amp (split-fp16 forward / data-gradient GEMMs under the loss scaler) captured."""
     from zeroshape_amd.data.synthetic import Dataset
+    from zeroshape_amd.nn import autograd as A
     from zeroshape_amd.utils import options, util
     from zeroshape_amd.utils.options import EasyDict as edict
-    cmd = options.parse_arguments(["--yaml=%s/options/shape.yaml" % ROOT, "--output_root=/tmp/zs_bench_train",
-                                   "--batch_size=4", "--pretrain.depth=", "--arch.depth.pretrained=",
-                                   "--training.n_sdf_points=4096"])
-    opt = options.set(cmd)
-    opt.world_size = 1
-    opt.output_path = None                      # no checkpoints from a benchmark
     from zeroshape_amd.model.shape_engine import Runner
-    r = Runner(opt)
-    r.load_train_dataset(opt, dataset=Dataset(opt, split="train", n_items=4, n_points=100, seed=0))
-    r.build_networks(opt)
-    r.setup_optimizer(opt)
-    r.graph.train()
-    var0 = util.move_to_device(edict(next(iter(r.train_loader))), opt.device)
 
-    def step():
-        r.train_iteration(opt, edict({k: (v.clone() if torch.is_tensor(v) else v) for k, v in var0.items()}))
+    def run(amp):
+        cmd = options.parse_arguments(["--yaml=%s/options/shape.yaml" % ROOT, "--output_root=/tmp/zs_bench_train",
+                                       "--batch_size=4", "--pretrain.depth=", "--arch.depth.pretrained=",
+                                       "--training.n_sdf_points=4096"] + (["--optim.amp"] if amp else []))
+        opt = options.set(cmd)
+        opt.world_size = 1
+        opt.output_path = None                      # no checkpoints from a benchmark
+        r = Runner(opt)
+        r.load_train_dataset(opt, dataset=Dataset(opt, split="train", n_items=4, n_points=100, seed=0))
+        r.build_networks(opt)
+        r.setup_optimizer(opt)
+        r.graph.train()
+        var0 = util.move_to_device(edict(next(iter(r.train_loader))), opt.device)
 
-    def timed(n_warm):
-        for _ in range(n_warm):
-            step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / steps * 1e3
-    ms_eager = timed(warmup)
-    opt.optim.hip_graph = True                  # forward + loss + backward replayed as one captured hipGraph
-    ms = timed(warmup + 3)                      # two more eager steps, the capture, then replays
-    assert getattr(r, "_captured", None) is not None
+        def step():
+            r.train_iteration(opt, edict({k: (v.clone() if torch.is_tensor(v) else v) for k, v in var0.items()}))
+
+        def timed(n_warm):
+            for _ in range(n_warm):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / steps * 1e3
+        ms_eager = None if amp else timed(warmup)
+        opt.optim.hip_graph = True                  # forward + loss + backward replayed as one captured hipGraph
+        ms = timed(warmup + 3)                      # two more eager steps, the capture, then replays
+        assert getattr(r, "_captured", None) is not None
+        del r
+        torch.cuda.empty_cache()
+        return ms_eager, ms
+    try:
+        ms_eager, ms = run(False)
+        _, ms_amp = run(True)
+    finally:
+        A.set_forward_precision("f32")
+        A.set_backward_precision("f32")
     tflop = 3 * 4 * (GFLOP_DPT + GFLOP_RES + GFLOP_INTR + 4096 * 5.0e-3) / 1e3      # forward + 2x backward
-    del r
-    torch.cuda.empty_cache()
-    return {"per_gpu_batch": 4, "sdf_points": 4096, "ms": round(ms, 2), "mode": "optim.hip_graph (captured step)",
-            "ms_eager": round(ms_eager, 2), "images_per_s": round(4 / ms * 1e3, 1),
+    return {"per_gpu_batch": 4, "sdf_points": 4096, "ms": round(ms, 2), "mode": "fp32, optim.hip_graph (captured step)",
+            "ms_eager": round(ms_eager, 2), "ms_amp": round(ms_amp, 2), "images_per_s": round(4 / ms * 1e3, 1),
             "tflops": round(tflop / (ms * 1e-3), 1), "frac_of_f32_mfma_peak": round(tflop / (ms * 1e-3) / 157.3, 4)}
 
 

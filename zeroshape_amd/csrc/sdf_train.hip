@@ -570,6 +570,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const TensorEntry *__r
     const TensorEntry t = tab[chunk_tensor[blockIdx.x]];
     const unsigned long long s0 = chunk_start[blockIdx.x], s1 = min(t.n, s0 + (unsigned long long)MT_CHUNK);
     const float gs = grad_scale ? *grad_scale : 1.0f;
+    if (!(gs > 0.0f || gs < 0.0f)) return;      // 0 or nan: a loss scaler found an overflowed gradient - skip the step
     for (unsigned long long i = s0 + threadIdx.x; i < s1; i += 256) {
         // torch.optim.AdamW (single-tensor path): decoupled decay, then Adam with bias correction
         const float g = t.grad[i] * gs;

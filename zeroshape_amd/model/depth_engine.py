@@ -58,11 +58,17 @@ class Runner(shape_engine.Runner):
         if opt.optim.sched:
             self.sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.optim, opt.max_epoch)
         # optim.amp (model/shape_engine.py:135-136, :252-269: fp16 autocast + GradScaler): here the forward
-        # convolutions / linear layers of the encoders move to the 16-bit matrix pipe with split-fp16 operands
-        # (~2^-21 relative instead of fp16's 2^-11); gradients and accumulations stay fp32, so there is nothing
-        # to scale and no scaler state in the checkpoint
+        # AND data-gradient convolutions / linear layers move to the 16-bit matrix pipe with split-fp16 operands
+        # (~2^-21 relative instead of fp16's 2^-11, fp32 accumulation); weight gradients and everything else stay
+        # fp32.  The data gradients need the loss scaled into fp16's range: optim.LossScaler, GradScaler's rules
+        # with the scalars on the device
         from ..nn import autograd as A
+        from ..optim import LossScaler
         A.set_forward_precision("f16x3" if opt.optim.amp else os.environ.get("ZS_TRAIN_FWD_PRECISION", "f32"))
+        A.set_backward_precision("f16x3" if opt.optim.amp else "f32")
+        self.__dict__.pop("scaler", None)          # (checkpoints carry every attribute named scaler*, like the reference's)
+        if opt.optim.amp:
+            self.scaler = LossScaler(opt.device)
         if getattr(opt, "world_size", 1) > 1:
             self.reducer = parallel.GradReducer(self.graph.parameters(),
                                                 bucket_mb=getattr(opt.optim, "bucket_mb", 64.0))

@@ -7,7 +7,8 @@ Training runs one process per GPU: Graph.forward(training=True) on the HIP autog
 averaged over the ranks by parallel.GradReducer (bucketed RCCL all-reduce under the backward pass -
 the role torch DDP has in the reference), one fused AdamW launch (zeroshape_amd/optim.py) with the
 reference's four parameter groups.  Not rebuilt (control plane): tensorboard
-scalars, visual dumps.  optim.amp = split-fp16 forward GEMMs (see setup_optimizer)."""
+scalars, visual dumps.  optim.amp = split-fp16 forward and data-gradient GEMMs under a dynamic loss scale
+(see setup_optimizer)."""
 import os
 
 import numpy as np
@@ -108,11 +109,17 @@ class Runner:
         if opt.optim.sched:
             self.sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.optim, opt.max_epoch)
         # optim.amp (model/shape_engine.py:135-136, :252-269: fp16 autocast + GradScaler): here the forward
-        # convolutions / linear layers of the encoders move to the 16-bit matrix pipe with split-fp16 operands
-        # (~2^-21 relative instead of fp16's 2^-11); gradients and accumulations stay fp32, so there is nothing
-        # to scale and no scaler state in the checkpoint
+        # AND data-gradient convolutions / linear layers move to the 16-bit matrix pipe with split-fp16 operands
+        # (~2^-21 relative instead of fp16's 2^-11, fp32 accumulation); weight gradients and everything else stay
+        # fp32.  The data gradients need the loss scaled into fp16's range: optim.LossScaler, GradScaler's rules
+        # with the scalars on the device
         from ..nn import autograd as A
+        from ..optim import LossScaler
         A.set_forward_precision("f16x3" if opt.optim.amp else os.environ.get("ZS_TRAIN_FWD_PRECISION", "f32"))
+        A.set_backward_precision("f16x3" if opt.optim.amp else "f32")
+        self.__dict__.pop("scaler", None)          # (checkpoints carry every attribute named scaler*, like the reference's)
+        if opt.optim.amp:
+            self.scaler = LossScaler(opt.device)
         if getattr(opt, "world_size", 1) > 1:
             self.reducer = parallel.GradReducer(self.graph.parameters(), module=self.graph,
                                                 bucket_mb=getattr(opt.optim, "bucket_mb", 64.0))
@@ -179,15 +186,16 @@ class Runner:
         var, loss = self.graph.forward(opt, var, training=True, get_loss=True)
         loss = self.summarize_loss(opt, var, loss)
         loss_scaled = loss.all / opt.optim.accum
+        scaler = getattr(self, "scaler", None)
+        if scaler is not None:
+            loss_scaled = scaler.scale_loss(loss_scaled)
         if self.reducer is not None:          # only the last micro-step of an accumulation window is reduced
             self.reducer.armed = (self.it + 1) % opt.optim.accum == 0
         loss_scaled.backward()
         if (self.it + 1) % opt.optim.accum == 0:
             if self.reducer is not None:
                 self.reducer.finish()
-            if opt.optim.clip_norm:
-                self.optim.clip_grad_norm_(opt.optim.clip_norm)
-            self.optim.step()
+            self._optimizer_step(opt)
             self.optim.zero_grad()
         # :283-284: latest.ckpt every freq.ckpt_latest iterations (rank 0), so a crash loses at most that
         # many (the reference also writes one at iteration 0, i.e. the initial weights: skipped)
@@ -206,6 +214,16 @@ class Runner:
     # sequence reads besides the inputs is addressed in place (parameters, buffers, packed operands, workspaces);
     # DropPath draws come from torch's graph-safe device generator.  Not captured: gradient accumulation windows
     # and the multi-process reducer (the eager path below handles both).
+    def _optimizer_step(self, opt):
+        """:270-277: clip, step; under optim.amp through the loss scaler (unscale, skip on overflow, update the scale)."""
+        scaler = getattr(self, "scaler", None)
+        if scaler is not None:
+            scaler.step(self.optim, opt.optim.clip_norm)
+            return
+        if opt.optim.clip_norm:
+            self.optim.clip_grad_norm_(opt.optim.clip_norm)
+        self.optim.step()
+
     def _step_capture_enabled(self, opt):
         flag = os.environ.get("ZS_TRAIN_HIP_GRAPH")
         on = flag not in ("0", "") if flag is not None else bool(opt.optim.get("hip_graph", False))
@@ -235,14 +253,13 @@ class Runner:
             with torch.cuda.graph(graph):
                 out_var, loss = self.graph.forward(opt, static_var, training=True, get_loss=True)
                 loss = self.summarize_loss(opt, out_var, loss)
-                loss.all.backward()
+                scaler = getattr(self, "scaler", None)
+                (loss.all if scaler is None else scaler.scale_loss(loss.all)).backward()
             st = self._captured = dict(sig=sig, scratch=A.SCRATCH_GENERATION[0], graph=graph, static=static, loss=loss)
         for k, t in st["static"].items():
             t.copy_(tensors[k], non_blocking=True)
         st["graph"].replay()
-        if opt.optim.clip_norm:
-            self.optim.clip_grad_norm_(opt.optim.clip_norm)
-        self.optim.step()                          # no zero_grad: the replay overwrites the static gradients
+        self._optimizer_step(opt)                  # no zero_grad: the replay overwrites the static gradients
         if self._rank() == 0 and getattr(opt, "output_path", None) and not getattr(opt, "debug", False) \
                 and self.it > 0 and self.it % opt.freq.ckpt_latest == 0:
             self.save_checkpoint(opt, ep=self.ep, it=self.it, best_val=self.best_val, best_ep=self.best_ep, latest=True)

@@ -21,18 +21,31 @@ _CONV_F16X3 = 16
 # Arithmetic of the FORWARD convolutions / linear layers of the training path: "f32" (default) or
 # "f16x3" = split-fp16 (opt-in: 15.4 -> 14.4 ms forward per step at batch 4, but the 1e-6 forward
 # differences are amplified by the batch-statistics BatchNorms to ~2e-3 relative in some gradients,
-# beyond this repository's gradient parity bar).  The data- and weight-gradient GEMMs are always
-# exact fp32: gradient magnitudes reach far below fp16's range.
+# beyond this repository's gradient parity bar).
 FWD_CONV_PRECISION = os.environ.get("ZS_TRAIN_FWD_PRECISION", "f32")
 
 
 def set_forward_precision(p):
     """"f32" | "f16x3": arithmetic of the forward convolutions / linear layers under autograd (optim.amp selects
-    "f16x3": the 16-bit matrix pipe with split operands; gradients and accumulations stay fp32, so no loss scaling)."""
+    "f16x3": the 16-bit matrix pipe with split operands, fp32 accumulation)."""
     global FWD_CONV_PRECISION
     if p not in ("f32", "f16x3"):
         raise ValueError("forward precision must be 'f32' or 'f16x3', got %r" % (p,))
     FWD_CONV_PRECISION = p
+
+# Data gradients (dx = dy * W^T through the same convolution engine).  "f16x3" needs the incoming gradients inside
+# fp16's range: the Runner multiplies the loss by a dynamic power of two (optim.LossScaler, torch's GradScaler
+# rules) and the optimiser divides it out, an overflow (inf / nan in any gradient) skips the step and halves the
+# scale.  Weight gradients stay exact fp32 (they sum over every pixel of the batch).
+BWD_DATA_PRECISION = os.environ.get("ZS_TRAIN_BWD_PRECISION", "f32")
+
+
+def set_backward_precision(p):
+    global BWD_DATA_PRECISION
+    if p not in ("f32", "f16x3"):
+        raise ValueError("data-gradient precision must be 'f32' or 'f16x3', got %r" % (p,))
+    BWD_DATA_PRECISION = p
+
 
 # Bumped whenever parameters are updated through raw pointers (the fused optimiser): tensor
 # ._version does not see those writes, so every pack cache also keys on this counter.
@@ -343,7 +356,7 @@ class _Conv(torch.autograd.Function):
                                                              float(in_scale), _stream(x)), "zs_conv2d_dgrad_small_cin")
             else:
                 dx = torch.empty(B, H, W, cin, dtype=torch.float32, device=x.device)
-                flags = _CONV_IN_DILATE2 if stride == 2 else 0
+                flags = (_CONV_IN_DILATE2 if stride == 2 else 0) | (_CONV_F16X3 if BWD_DATA_PRECISION == "f16x3" else 0)
                 _conv_launch(gp, _pack(weight, cin0, cin, True, std_eps), None, None, None, dx, kh, kw, 1, kh - 1 - pt,
                              kw - 1 - pl, flags, in_scale, 0.0, ACT_NONE)
                 if cin != Cx:                       # the input carried zero padding channels

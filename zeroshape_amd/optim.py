@@ -123,3 +123,51 @@ class FusedAdamW(torch.optim.Optimizer):
         self._clip = None
         A.bump_generation()                   # parameters changed behind torch's version counters
         return None
+
+
+class LossScaler:
+    """Dynamic loss scale for split-fp16 data gradients (optim.amp), torch.cuda.amp.GradScaler's rules (the
+    reference: model/shape_engine.py:135-136, :252-269) with every scalar on the device - no host read-back, so
+    the step stays capturable: scale 2^16 at the start, x 0.5 and the step skipped when any gradient is inf / nan,
+    x 2 after `growth_interval` clean steps in a row."""
+
+    def __init__(self, device, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self.scale = torch.full((), float(init_scale), dtype=torch.float32, device=device)
+        self.tracker = torch.zeros((), dtype=torch.int32, device=device)
+        self.found_inf = torch.zeros((), dtype=torch.float32, device=device)
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+
+    def scale_loss(self, loss):
+        return loss * self.scale
+
+    @torch.no_grad()
+    def step(self, optim, clip_norm=None):
+        """Unscale (folded into the optimiser's gradient multiplier), clip, step - or skip on overflow - and update
+        the scale.  Returns the unscaled gradient norm (device scalar)."""
+        norm = optim.grad_norm()                         # of the scaled gradients: inf / nan if any overflowed
+        if norm is None:
+            return None
+        inv = 1.0 / self.scale
+        true_norm = norm * inv
+        mult = inv if not clip_norm else inv * (clip_norm / (true_norm + 1e-6)).clamp(max=1.0)
+        finite = torch.isfinite(norm)
+        self.found_inf.copy_((~finite).float())
+        optim._clip = torch.where(finite, mult, torch.zeros_like(mult))      # 0: zs_adamw_multi leaves everything as is
+        optim.step()
+        torch._amp_update_scale_(self.scale, self.tracker, self.found_inf, self.growth_factor, self.backoff_factor,
+                                 self.growth_interval)
+        return true_norm
+
+    def state_dict(self):
+        """torch.cuda.amp.GradScaler.state_dict()'s keys: the `scaler` entry of a reference checkpoint loads unchanged."""
+        return {"scale": float(self.scale), "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": int(self.tracker)}
+
+    def load_state_dict(self, sd):
+        if not sd:                                   # a disabled GradScaler saves {}
+            return
+        self.scale.fill_(float(sd["scale"]))
+        self.tracker.fill_(int(sd.get("_growth_tracker", 0)))
+        self.growth_factor = sd.get("growth_factor", self.growth_factor)
+        self.backoff_factor = sd.get("backoff_factor", self.backoff_factor)
+        self.growth_interval = sd.get("growth_interval", self.growth_interval)
