@@ -83,11 +83,24 @@ def depth_opt(tmp_path, *extra):
     return opt
 
 
-def test_depth_engine_trains(tmp_path, encoder_sd):
+@pytest.mark.parametrize("extra", [(), ("--optim.hip_graph",), ("--optim.hip_graph", "--optim.amp")],
+                         ids=["eager", "captured", "captured-amp"])
+def test_depth_engine_trains(tmp_path, encoder_sd, extra):
+    """eager launches; the step as a captured hipGraph (optim.hip_graph: the MiDaS loss with its device-side medians is
+    part of the capture); the same with split-fp16 forward / data gradients under the loss scaler."""
+    from zeroshape_amd.nn import autograd as A
+    try:
+        _depth_engine_trains(tmp_path, encoder_sd, extra)
+    finally:
+        A.set_forward_precision("f32")
+        A.set_backward_precision("f32")
+
+
+def _depth_engine_trains(tmp_path, encoder_sd, extra):
     from zeroshape_amd.model.depth_engine import Runner
     from zeroshape_amd.utils import util
     from zeroshape_amd.utils.options import EasyDict as edict
-    opt = depth_opt(tmp_path)
+    opt = depth_opt(tmp_path, *extra)
     r = Runner(opt)
     r.load_dataset(opt, dataset=Dataset(opt, n_items=2, load_3D=False),
                    train_dataset=Dataset(opt, split="train", n_items=4, load_3D=False, seed=1))
@@ -108,6 +121,9 @@ def test_depth_engine_trains(tmp_path, encoder_sd):
         losses.append((float(loss.depth), float(loss.intr), float(loss.all)))
         assert abs(losses[-1][2] - (losses[-1][0] + 10 * losses[-1][1])) < 1e-4 * abs(losses[-1][2])    # loss_weight 1 / 10
     assert np.isfinite(losses).all() and losses[-1][2] < losses[0][2], losses
+    assert (getattr(r, "_captured", None) is not None) == ("--optim.hip_graph" in extra)
+    if "--optim.amp" in extra:
+        assert float(r.scaler.found_inf) == 0.0 and int(r.scaler.tracker) == 5
     after = r.graph.state_dict()
     moved = [k for k in before if before[k].is_floating_point() and not torch.equal(before[k], after[k])]
     assert any(k.startswith("intr_proj") for k in moved) and any(k.startswith("dpt_depth.scratch.output_conv") for k in moved)
@@ -117,6 +133,9 @@ def test_depth_engine_trains(tmp_path, encoder_sd):
     r.save_checkpoint(opt, ep=0, it=r.it, latest=True)
     ck = torch.load(os.path.join(opt.output_path, "latest.ckpt"), map_location="cpu")
     assert "optim" in ck and set(k.split(".")[0] for k in ck["graph"]) == {"dpt_depth", "intr_head", "intr_proj"}
+    assert ("scaler" in ck) == ("--optim.amp" in extra)
+    if "scaler" in ck:
+        assert ck["scaler"]["scale"] == 65536.0 and ck["scaler"]["_growth_tracker"] == 5
 
 
 def test_mask_shrink_matches_reference_golden_and_oracle():
