@@ -180,9 +180,10 @@ class Runner:
         """:248-297 without its per-iteration barrier (the all-reduce already orders the ranks) and
         without the tensorboard / visualiser calls."""
         if self._step_capture_enabled(opt):
-            loss = self._train_iteration_captured(opt, var)
-            if loss is not None:
-                return loss
+            return self._train_iteration_captured(opt, var)
+        return self._train_iteration_eager(opt, var)
+
+    def _train_iteration_eager(self, opt, var):
         var, loss = self.graph.forward(opt, var, training=True, get_loss=True)
         loss = self.summarize_loss(opt, var, loss)
         loss_scaled = loss.all / opt.optim.accum
@@ -230,9 +231,19 @@ class Runner:
         return on and opt.optim.accum == 1 and self.reducer is None
 
     def _train_iteration_captured(self, opt, var):
-        """One step through the captured launch sequence; None while it is still warming up eagerly (the first
-        two steps of a signature allocate workspaces, pack operands and build the launch tables)."""
+        """One step through the captured launch sequence; the first two steps of a signature run eagerly (they
+        allocate workspaces, pack operands and build the launch tables).
+
+        Warm-up steps and the capture share ONE side stream, and warm-up losses are returned detached: autograd
+        binds a parameter's gradient accumulator to the stream it was first used on and keeps it for as long as any
+        graph that reaches it is alive.  An accumulator born on the default stream (a caller still holding the loss
+        of an eager step) would pull the default stream into the capture - hipStreamEndCapture does not survive
+        that."""
         from ..nn import autograd as A
+        dev = next(self.graph.parameters()).device
+        if getattr(self, "_capture_stream", None) is None:
+            self._capture_stream = torch.cuda.Stream(device=dev)
+        cs = self._capture_stream
         tensors = {k: v for k, v in var.items() if torch.is_tensor(v)}
         trainable = tuple(id(p) for p in self.graph.parameters() if p.requires_grad)
         sig = (tuple((k, tuple(v.shape), v.dtype, str(v.device)) for k, v in sorted(tensors.items())), trainable)
@@ -243,18 +254,28 @@ class Runner:
         if st is None:
             if getattr(self, "_capture_warm", 0) < 2:
                 self._capture_warm = getattr(self, "_capture_warm", 0) + 1
-                return None
+                main = torch.cuda.current_stream(dev)
+                cs.wait_stream(main)
+                with torch.cuda.stream(cs):
+                    loss = self._train_iteration_eager(opt, var)
+                    loss = edict({k: (v.detach() if torch.is_tensor(v) else v) for k, v in loss.items()})
+                main.wait_stream(cs)
+                return loss
             static = {k: v.clone() for k, v in tensors.items()}
             static_var = edict({k: static.get(k, v) for k, v in var.items()})
             self.optim.zero_grad(set_to_none=True)
+            import gc
+            gc.collect()                           # (torch.cuda.graph collects too: operands of dead modules must
+            A.refresh_packs(dev)                   # leave the re-pack table before it is cached, not inside)
             A.bump_generation()                    # the capture must contain the operand re-pack
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, stream=cs):
                 out_var, loss = self.graph.forward(opt, static_var, training=True, get_loss=True)
                 loss = self.summarize_loss(opt, out_var, loss)
                 scaler = getattr(self, "scaler", None)
                 (loss.all if scaler is None else scaler.scale_loss(loss.all)).backward()
+            loss = edict({k: (v.detach() if torch.is_tensor(v) else v) for k, v in loss.items()})
             st = self._captured = dict(sig=sig, scratch=A.SCRATCH_GENERATION[0], graph=graph, static=static, loss=loss)
         for k, t in st["static"].items():
             t.copy_(tensors[k], non_blocking=True)

@@ -159,6 +159,11 @@ def _refresh_all_packs(device):
     sig = tuple(entries)
     cached = _PACK_TABLE.get(device)
     if cached is None or cached[0] != sig:
+        if torch.cuda.is_current_stream_capturing():
+            # the table would travel by a host-to-device copy from pageable memory: not capturable (the graph
+            # would keep the host address).  refresh_packs() before the capture builds it.
+            raise RuntimeError("the set of packed operands changed inside a stream capture; call "
+                               "zeroshape_amd.nn.autograd.refresh_packs(device) before capturing")
         dt = np.dtype([("src", "<u8"), ("dst", "<u8")] + [(n, "<i4") for n in ("Cout", "Cin", "cin0", "ld", "taps", "dgrad",
                                                                              "K16", "NPad")])
         assert dt.itemsize == 48
@@ -181,6 +186,13 @@ def _refresh_all_packs(device):
                                                  _lib.current_stream_ptr(device)), "zs_pack_conv_weight_multi")
     for rec, w in recs:
         rec.stamp = _stamp(w)
+
+
+def refresh_packs(device):
+    """Re-pack every registered operand on `device` now (and leave the launch table of that set cached): what a
+    stream capture of a training step must do first, so that the re-pack inside the capture finds its table."""
+    bump_generation()
+    _refresh_all_packs(torch.device(device) if not isinstance(device, torch.device) else device)
 
 
 def _pack(weight, cin0, cin, dgrad, std_eps=None):
