@@ -296,7 +296,7 @@ def main():
         for name, fn in (("chamfer", lambda: legs.chamfer_leg(dev, cpu)), ("pose_search", lambda: legs.pose_search_leg(dev)),
                          ("chamfer_l1", lambda: legs.eval_leg(dev, net, sd)), ("encoder", lambda: legs.encoder_leg(dev, cpu)),
                          ("inference", lambda: legs.inference_leg(dev)),
-                         ("train_step", lambda: legs.train_leg(dev))):
+                         ("train_step", lambda: legs.in_subprocess("train", "train_step"))):
             try:
                 extras[name] = fn()
             except Exception as e:                      # a leg must never take the headline line down

@@ -297,6 +297,17 @@ def train_leg(dev, steps=8, warmup=3):
             "tflops": round(tflop / (ms * 1e-3), 1), "frac_of_f32_mfma_peak": round(tflop / (ms * 1e-3) / 157.3, 4)}
 
 
+def in_subprocess(leg, key, timeout=600):
+    """Run `python tools/bench_legs.py <leg>` and return its JSON entry: the training leg captures hipGraphs of
+    ~1500 launches - a fault inside the HIP runtime there must not take bench.py's headline line down with it."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), leg], capture_output=True, text=True, timeout=timeout)
+    for ln in reversed(r.stdout.strip().splitlines()):
+        if ln.startswith("{"):
+            return json.loads(ln)[key]
+    raise RuntimeError("leg %s: exit code %d: %s" % (leg, r.returncode, r.stderr.strip()[-300:]))
+
+
 if __name__ == "__main__":
     dev = torch.device("cuda:0")
     want = sys.argv[1:] or ["chamfer", "pose", "encoder", "train"]
