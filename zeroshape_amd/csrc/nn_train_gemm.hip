@@ -76,7 +76,7 @@ constexpr int PACK_LDS_FLOATS = 64 * 145;  // >= 64 x (16*9 | 1), 16 x 64*9, 64 
 __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackEntry *__restrict__ tab,
                                                                 const int *__restrict__ chunk_entry,
                                                                 const unsigned long long *__restrict__ chunk_start) {
-    extern __shared__ float plds[];
+    extern __shared__ __attribute__((aligned(16))) float plds[];
     const PackEntry t = tab[chunk_entry[blockIdx.x]];
     const int CinP = (t.Cin + 3) & ~3, CoutP = (t.Cout + 3) & ~3;
     const unsigned ord = (unsigned)chunk_start[blockIdx.x];
@@ -108,13 +108,24 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackEntry 
     const int taps = t.taps, CT = pack_ct(taps), NT = t.NPad / PACK_ROWS;
     const int n0 = (int)(ord % (unsigned)NT) * PACK_ROWS, c0 = (int)(ord / (unsigned)NT) * CT;
     const int quads = CT / 4, cells = taps * quads * PACK_ROWS;
+    const bool vec_ok = (t.ld & 3) == 0 && (t.cin0 & 3) == 0 && (reinterpret_cast<size_t>(t.src) & 15) == 0;
     if (!t.dgrad) {
         // rows = output channels n, span = CT channels x taps of one row
         const int span = CT * taps, stride = span | 1;             // odd row stride: the cell gather below walks rows
         const float *src = t.src + (size_t)(t.cin0 + c0) * taps;
-        for (int idx = threadIdx.x; idx < PACK_ROWS * span; idx += 256) {
-            const int r = idx / span, j = idx - r * span, n = n0 + r, c = c0 + j / taps;
-            plds[r * stride + j] = (n < t.Cout && c < t.Cin) ? src[(size_t)n * t.ld + j] : 0.f;
+        if (taps == 1 && vec_ok && c0 + CT <= t.Cin) {            // pointwise: 16-byte loads of whole 256-byte rows
+            for (int idx = threadIdx.x; idx < PACK_ROWS * (CT / 4); idx += 256) {
+                const int r = idx / (CT / 4), j = 4 * (idx - r * (CT / 4)), n = n0 + r;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (n < t.Cout) v = *reinterpret_cast<const f32x4 *>(src + (size_t)n * t.ld + j);
+#pragma unroll
+                for (int e = 0; e < 4; e++) plds[r * stride + j + e] = v[e];
+            }
+        } else {
+            for (int idx = threadIdx.x; idx < PACK_ROWS * span; idx += 256) {
+                const int r = idx / span, j = idx - r * span, n = n0 + r, c = c0 + j / taps;
+                plds[r * stride + j] = (n < t.Cout && c < t.Cin) ? src[(size_t)n * t.ld + j] : 0.f;
+            }
         }
         __syncthreads();
         for (int idx = threadIdx.x; idx < cells; idx += 256) {
@@ -128,9 +139,18 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackEntry 
         // rows = output channels co (the K side), span = 64 input channels n x taps of one row; taps flipped
         const int span = PACK_ROWS * taps;
         const float *src = t.src + (size_t)(t.cin0 + n0) * taps;
-        for (int idx = threadIdx.x; idx < CT * span; idx += 256) {
-            const int r = idx / span, j = idx - r * span, co = c0 + r, n = n0 + j / taps;
-            plds[r * span + j] = (co < t.Cout && n < t.Cin) ? src[(size_t)co * t.ld + j] : 0.f;
+        if (taps == 1 && vec_ok && n0 + PACK_ROWS <= t.Cin) {
+            for (int idx = threadIdx.x; idx < CT * (PACK_ROWS / 4); idx += 256) {
+                const int r = idx / (PACK_ROWS / 4), j = 4 * (idx - r * (PACK_ROWS / 4)), co = c0 + r;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (co < t.Cout) v = *reinterpret_cast<const f32x4 *>(src + (size_t)co * t.ld + j);
+                *reinterpret_cast<f32x4 *>(plds + r * span + j) = v;
+            }
+        } else {
+            for (int idx = threadIdx.x; idx < CT * span; idx += 256) {
+                const int r = idx / span, j = idx - r * span, co = c0 + r, n = n0 + j / taps;
+                plds[r * span + j] = (co < t.Cout && n < t.Cin) ? src[(size_t)co * t.ld + j] : 0.f;
+            }
         }
         __syncthreads();
         for (int idx = threadIdx.x; idx < cells; idx += 256) {
