@@ -17,12 +17,22 @@ COMMON = ["--pretrain.depth=", "--arch.depth.pretrained=", "--eval.vox_res=16", 
           "--training.n_sdf_points=256", "--max_epoch=1", "--batch_size=4"]
 
 
-def run(script, *args):
-    env = dict(os.environ, HIP_VISIBLE_DEVICES="0", ZS_SYNTHETIC_ITEMS="4")
+def run(script, *args, items=4):
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="0", ZS_SYNTHETIC_ITEMS=str(items))
     r = subprocess.run([sys.executable, os.path.join(ROOT, script)] + list(args), cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     return r.stdout
+
+
+def test_train_script_with_the_captured_amp_step(tmp_path):
+    """train.py --optim.hip_graph --optim.amp: an epoch of four steps (two eager, the capture, a replay), the
+    validation pass behind it and the checkpoint with the loss scaler's state."""
+    out = "--output_root=%s" % tmp_path
+    run("train.py", "--yaml=options/shape.yaml", out, "--optim.hip_graph", "--optim.amp", *COMMON, items=16)
+    ck = torch.load(os.path.join(str(tmp_path), "shape", "shape_recon", "latest.ckpt"), map_location="cpu")
+    assert ck["iter"] == 4 and "optim" in ck and ck["scaler"]["scale"] > 0 and ck["scaler"]["_growth_tracker"] <= 4
+    assert all(np.isfinite(v.float().numpy()).all() for v in ck["graph"].values())
 
 
 def test_train_then_evaluate_scripts(tmp_path):
