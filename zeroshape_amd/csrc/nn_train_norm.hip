@@ -511,13 +511,16 @@ __global__ __launch_bounds__(256) void global_mean_bwd_kernel(const float *__res
     dx[i] = dy[b * C + c] / HW;
 }
 
-// x2 bilinear, align_corners=True: adjoint by gathering from the (few) outputs that read this input
+// x2 bilinear, align_corners=True: adjoint by gathering from the (few) outputs that read this input; a thread owns
+// VEC channels of one input pixel (VEC = 4 when C % 4 == 0: the tap weights are computed once per four channels)
+template <int VEC>
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float *__restrict__ dy, float *__restrict__ dx, int B,
                                                              int Hin, int Win, int C) {
-    const int Hout = 2 * Hin, Wout = 2 * Win;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)B * Hin * Win * C;
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    const int Hout = 2 * Hin, Wout = 2 * Win, CV = C / VEC;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)B * Hin * Win * CV;
     if (i >= total) return;
-    const int c = i % C, ix = (i / C) % Win, iy = (i / C / Win) % Hin, b = i / C / Win / Hin;
+    const int c = (int)(i % CV) * VEC, ix = (i / CV) % Win, iy = (i / CV / Win) % Hin, b = i / CV / Win / Hin;
     const float sy = Hout > 1 ? (float)(Hin - 1) / (float)(Hout - 1) : 0.f,
                 sx = Wout > 1 ? (float)(Win - 1) / (float)(Wout - 1) : 0.f;
     // forward taps of output o: y0 = (int)(sy*o), y1 = y0 + (y0 < Hin-1), weights (1-l, l), l = sy*o - y0
@@ -533,16 +536,27 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float *__rest
     const int oy_lo = max(0, 2 * iy - 3), oy_hi = min(Hout - 1, 2 * iy + 4);
     const int ox_lo = max(0, 2 * ix - 3), ox_hi = min(Wout - 1, 2 * ix + 4);
     const float *G = dy + (size_t)b * Hout * Wout * C + c;
-    float acc = 0.f;
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; e++) acc[e] = 0.f;
     for (int oy = oy_lo; oy <= oy_hi; oy++) {
         const float wy = weight(oy, iy, sy, Hin);
         if (wy == 0.f) continue;
         for (int ox = ox_lo; ox <= ox_hi; ox++) {
             const float wx = weight(ox, ix, sx, Win);
-            if (wx != 0.f) acc += wy * wx * G[((size_t)oy * Wout + ox) * C];
+            if (wx == 0.f) continue;
+            const float *g = G + ((size_t)oy * Wout + ox) * C;
+            if constexpr (VEC == 1) acc[0] += wy * wx * g[0];
+            else {
+                const vec_t v = *reinterpret_cast<const vec_t *>(g);
+#pragma unroll
+                for (int e = 0; e < VEC; e++) acc[e] += wy * wx * v[e];
+            }
         }
     }
-    dx[i] = acc;
+    float *o = dx + (((size_t)b * Hin + iy) * Win + ix) * C + c;
+#pragma unroll
+    for (int e = 0; e < VEC; e++) o[e] = acc[e];
 }
 
 // NHWC [B][HW][Cpad] -> NCHW [B][C][HW] (first C channels), optionally times mask [B][HW]
@@ -747,8 +761,12 @@ extern "C" int zs_upsample2x_bwd_nhwc(const float *dy, float *dx, int batch, int
     ZS_REQUIRE(batch >= 0 && Hin > 0 && Win > 0 && C > 0, "zs_upsample2x_bwd_nhwc: bad size");
     if (batch == 0) return 1;
     ZS_REQUIRE(dy && dx, "zs_upsample2x_bwd_nhwc: null pointer");
-    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(blocks_for((size_t)batch * Hin * Win * C)), dim3(256), 0, S(stream),
-                       dy, dx, batch, Hin, Win, C);
+    if ((C & 3) == 0 && ((reinterpret_cast<size_t>(dy) | reinterpret_cast<size_t>(dx)) & 15) == 0)
+        hipLaunchKernelGGL(upsample2x_bwd_kernel<4>, dim3(blocks_for((size_t)batch * Hin * Win * C / 4)), dim3(256), 0,
+                           S(stream), dy, dx, batch, Hin, Win, C);
+    else
+        hipLaunchKernelGGL(upsample2x_bwd_kernel<1>, dim3(blocks_for((size_t)batch * Hin * Win * C)), dim3(256), 0,
+                           S(stream), dy, dx, batch, Hin, Win, C);
     return zs::check_launch("zs_upsample2x_bwd_nhwc") ? 1 : 0;
 }
 

@@ -52,15 +52,33 @@ __device__ __forceinline__ float act_bwd(float dy, float ref, int act, float bet
     return dy;
 }
 
+// four elements per thread (one 16-byte access per tensor); the tail and unaligned tensors go element by element
+typedef float act_f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void act_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, size_t n,
-                                                      int act, float beta) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) y[i] = act_fwd(x[i], act, beta);
+                                                      int act, float beta, int vec) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * (vec ? 4 : 1);
+    if (vec && i + 3 < n) {
+        const act_f32x4 v = *reinterpret_cast<const act_f32x4 *>(x + i);
+        act_f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] = act_fwd(v[e], act, beta);
+        *reinterpret_cast<act_f32x4 *>(y + i) = o;
+        return;
+    }
+    for (size_t j = i; j < n && j < i + (vec ? 4 : 1); j++) y[j] = act_fwd(x[j], act, beta);
 }
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ ref,
-                                                      float *__restrict__ dx, size_t n, int act, float beta) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) dx[i] = act_bwd(dy[i], ref[i], act, beta);
+                                                      float *__restrict__ dx, size_t n, int act, float beta, int vec) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * (vec ? 4 : 1);
+    if (vec && i + 3 < n) {
+        const act_f32x4 g = *reinterpret_cast<const act_f32x4 *>(dy + i), r = *reinterpret_cast<const act_f32x4 *>(ref + i);
+        act_f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] = act_bwd(g[e], r[e], act, beta);
+        *reinterpret_cast<act_f32x4 *>(dx + i) = o;
+        return;
+    }
+    for (size_t j = i; j < n && j < i + (vec ? 4 : 1); j++) dx[j] = act_bwd(dy[j], ref[j], act, beta);
 }
 
 // ---- y = x + scale[b] * branch   /   y = scale[b] * x   (per-sample stochastic depth) ----
@@ -469,7 +487,9 @@ extern "C" int zs_act_forward(const float *x, float *y, size_t n, int act, float
     ZS_REQUIRE(act >= 0 && act <= ZS_ACT_SOFTPLUS, "zs_act_forward: unknown activation %d", act);
     if (n == 0) return 1;
     ZS_REQUIRE(x && y, "zs_act_forward: null pointer");
-    hipLaunchKernelGGL(act_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, S(stream), x, y, n, act, beta);
+    const int vec = ((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(y)) & 15) == 0 ? 1 : 0;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(blocks_for(vec ? (n + 3) / 4 : n)), dim3(256), 0, S(stream), x, y, n, act, beta,
+                       vec);
     return zs::check_launch("zs_act_forward") ? 1 : 0;
 }
 
@@ -478,7 +498,9 @@ extern "C" int zs_act_backward(const float *dy, const float *ref, float *dx, siz
     ZS_REQUIRE(act >= 0 && act <= ZS_ACT_SOFTPLUS, "zs_act_backward: unknown activation %d", act);
     if (n == 0) return 1;
     ZS_REQUIRE(dy && ref && dx, "zs_act_backward: null pointer");
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, S(stream), dy, ref, dx, n, act, beta);
+    const int vec = ((reinterpret_cast<size_t>(dy) | reinterpret_cast<size_t>(ref) | reinterpret_cast<size_t>(dx)) & 15) == 0;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for(vec ? (n + 3) / 4 : n)), dim3(256), 0, S(stream), dy, ref, dx, n, act,
+                       beta, vec);
     return zs::check_launch("zs_act_backward") ? 1 : 0;
 }
 
