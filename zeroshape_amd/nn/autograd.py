@@ -120,12 +120,21 @@ class _PackRec(object):
 
 _PACKS = {}     # (id(weight), cin0, cin, dgrad, std_eps) -> _PackRec
 _PACK_TABLE = {}    # device -> (signature, table tensors)
+_PACK_EPOCH = [0]   # bumped whenever _PACKS gains or loses a record
+_PACK_FAST = {}     # device -> dict(epoch, generation, recs, std): the last complete re-pack, for its replay
+
+
+def _drop_pack(key):
+    if _PACKS.pop(key, None) is not None:
+        _PACK_EPOCH[0] += 1
 
 
 def clear_pack_cache():
     _PACKS.clear()
     _STD.clear()
     _PACK_TABLE.clear()
+    _PACK_FAST.clear()
+    _PACK_EPOCH[0] += 1
 
 
 def _pack_dims(w, cin, dgrad):
@@ -140,15 +149,34 @@ def _refresh_all_packs(device):
     """Re-pack every registered operand on `device` whose weight changed, in ONE launch."""
     import numpy as np
     lib = _lib.load()
+    # The state after an optimiser step (every step of a training run): the same records as the last time, all of
+    # them stale because the generation moved.  Replay that re-pack - standardise the StdConv weights into their
+    # persistent buffers, launch over the cached table - without rebuilding the entry list.
+    fast = _PACK_FAST.get(device)
+    if fast is not None and fast["epoch"] == _PACK_EPOCH[0] and fast["generation"] != GENERATION[0]:
+        live = [(rec, rec.ref()) for rec in fast["recs"]]
+        if all(w is not None and w.data_ptr() == ptr for (rec, w), ptr in zip(live, fast["ptrs"])):
+            for rec, w in live:
+                if rec.key[4] is not None:
+                    standardize(w, rec.key[4])
+            _, tab_d, ce_d, cs_d, n = _PACK_TABLE[device]
+            with _lib.on(device):
+                _lib.check(lib.zs_pack_conv_weight_multi(_lib.ptr(tab_d), _lib.ptr(ce_d), _lib.ptr(cs_d), n,
+                                                         _lib.current_stream_ptr(device)), "zs_pack_conv_weight_multi")
+            for rec, w in live:
+                rec.stamp = _stamp(w)
+            fast["generation"] = GENERATION[0]
+            return
     recs = []
     for key, rec in list(_PACKS.items()):
         w = rec.ref()
         if w is None:
-            del _PACKS[key]
+            _drop_pack(key)
         elif w.device == device and rec.stamp != _stamp(w):
             recs.append((rec, w))
     if not recs:
         return
+    complete = len(recs) == sum(1 for rec in _PACKS.values() if rec.ref() is not None and rec.ref().device == device)
     entries = []
     for rec, w in recs:
         _, cin0, cin, dgrad, std_eps = rec.key
@@ -186,6 +214,11 @@ def _refresh_all_packs(device):
                                                  _lib.current_stream_ptr(device)), "zs_pack_conv_weight_multi")
     for rec, w in recs:
         rec.stamp = _stamp(w)
+    if complete:
+        _PACK_FAST[device] = dict(epoch=_PACK_EPOCH[0], generation=GENERATION[0], recs=[rec for rec, _ in recs],
+                                  ptrs=[w.data_ptr() for _, w in recs])
+    else:
+        _PACK_FAST.pop(device, None)
 
 
 def refresh_packs(device):
@@ -213,7 +246,7 @@ def _pack(weight, cin0, cin, dgrad, std_eps=None):
     dims = _pack_dims(w, cin, dgrad)
     cout, cintot, kh, kw, taps, K16, NPad = dims
     rec = _PackRec()
-    rec.ref = weakref.ref(weight, lambda _r, k=key: _PACKS.pop(k, None))
+    rec.ref = weakref.ref(weight, lambda _r, k=key: _drop_pack(k))
     rec.key, rec.dims = key, dims
     rec.packed = torch.empty(K16 * NPad, dtype=torch.float32, device=w.device)
     with _lib.on(w.device):
@@ -221,6 +254,7 @@ def _pack(weight, cin0, cin, dgrad, std_eps=None):
                                            1 if dgrad else 0, _stream(w)), "zs_pack_conv_weight")
     rec.stamp = _stamp(weight)
     _PACKS[key] = rec
+    _PACK_EPOCH[0] += 1
     return rec.packed
 
 

@@ -43,12 +43,6 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._clip = None          # device scalar multiplying every gradient in the next step()
 
-    def _live(self):
-        for group in self.param_groups:
-            for p in group["params"]:
-                if p.grad is not None:
-                    yield group, p
-
     def _init_state(self, p):
         st = self.state[p]
         if len(st) == 0:
@@ -59,22 +53,22 @@ class FusedAdamW(torch.optim.Optimizer):
 
     @torch.no_grad()
     def grad_norm(self):
-        """L2 norm of all gradients (device scalar), one launch (zs_sumsq_multi)."""
+        """L2 norm of all gradients (device scalar), one launch per parameter class (zs_sumsq_multi over the
+        optimiser's own table: it reads the gradient pointers and sizes only)."""
         lib = _lib.load()
-        live = [p for _, p in self._live()]
-        if not live:
+        plan = self._prepare()
+        if not plan["classes"]:
             return None
-        dev = live[0].device
-        for p in live:
-            self._check(p)
-        entries = [(0, p.grad.data_ptr(), 0, 0, p.numel(), 0.0, 0.0) for p in live]
-        tab, ct, cs, nchunks = build_table(entries, dev)
-        partial = torch.empty(nchunks, dtype=torch.float32, device=dev)
-        out = torch.empty((), dtype=torch.float32, device=dev)
-        with _lib.on(dev):
-            _lib.check(lib.zs_sumsq_multi(_lib.ptr(tab), _lib.ptr(ct), _lib.ptr(cs), nchunks, _lib.ptr(partial),
-                                          _lib.ptr(out), _lib.current_stream_ptr(dev)), "zs_sumsq_multi")
-        return out.sqrt_()
+        total = None
+        for cls in plan["classes"]:
+            dev = cls["device"]
+            partial = torch.empty(cls["nchunks"], dtype=torch.float32, device=dev)
+            out = torch.empty((), dtype=torch.float32, device=dev)
+            with _lib.on(dev):
+                _lib.check(lib.zs_sumsq_multi(_lib.ptr(cls["tab_dev"]), _lib.ptr(cls["ct"]), _lib.ptr(cls["cs"]), cls["nchunks"],
+                                              _lib.ptr(partial), _lib.ptr(out), _lib.current_stream_ptr(dev)), "zs_sumsq_multi")
+            total = out if total is None else total + out.to(total.device)
+        return total.sqrt_()
 
     @torch.no_grad()
     def clip_grad_norm_(self, max_norm):
@@ -85,44 +79,100 @@ class FusedAdamW(torch.optim.Optimizer):
             self._clip = (max_norm / (norm + 1e-6)).clamp_(max=1.0)
         return norm
 
-    @staticmethod
-    def _check(p):
-        if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
-            raise ValueError("FusedAdamW: contiguous fp32 GPU parameters required (no CPU path)")
-        if not (p.grad.is_cuda and p.grad.dtype == torch.float32):
-            raise ValueError("FusedAdamW: fp32 GPU gradients required")
-        if not p.grad.is_contiguous():
-            p.grad = p.grad.contiguous()
-
     @torch.no_grad()
     def step(self, closure=None):
+        """One zs_adamw_multi launch per (step count, betas, eps, device) class - one in all for a model trained from
+        the start.  The per-parameter bookkeeping is cached while the set of parameters with gradients stays the
+        same: per step only the gradient pointers and the groups' lr / weight_decay are refreshed in the host table,
+        and the table travels to the device only if a byte of it changed (eager steps get fresh gradient buffers,
+        a captured step keeps them).  Step counts are Python integers, mirrored into the torch-format `step` tensors
+        when the state is read (state_dict)."""
         assert closure is None
         lib = _lib.load()
+        plan = self._prepare()
+        counts = self.__dict__.setdefault("_counts", {})
+        for cls in plan["classes"]:
+            cls["step"] += 1
+            for p in cls["params"]:
+                counts[p] = cls["step"]
+            betas, eps = cls["betas"], cls["eps"]
+            with _lib.on(cls["device"]):
+                _lib.check(lib.zs_adamw_multi(_lib.ptr(cls["tab_dev"]), _lib.ptr(cls["ct"]), _lib.ptr(cls["cs"]), cls["nchunks"],
+                                              betas[0], betas[1], eps, cls["step"], _lib.ptr(self._clip),
+                                              _lib.current_stream_ptr(cls["device"])), "zs_adamw_multi")
+        self._clip = None
+        A.bump_generation()                   # parameters changed behind torch's version counters
+        return None
+
+    def _prepare(self):
+        """The plan for the parameters that have gradients now, its device tables current."""
+        groups = self.param_groups
+        live = [(gi, p) for gi, g in enumerate(groups) for p in g["params"] if p.grad is not None]
+        ids = tuple(id(p) for _, p in live)
+        plan = self.__dict__.get("_plan")
+        if plan is None or plan["ids"] != ids:
+            plan = self._build_plan(live)
+        for cls in plan["classes"]:
+            params = cls["params"]
+            for p in params:
+                g = p.grad
+                if not (g.is_cuda and g.dtype == torch.float32):
+                    raise ValueError("FusedAdamW: fp32 GPU gradients required")
+                if not g.is_contiguous():
+                    p.grad = g.contiguous()
+            tab = cls["tab"]
+            tab["grad"] = [p.grad.data_ptr() for p in params]
+            tab["lr"] = np.asarray([groups[gi]["lr"] for gi in cls["gidx"]], np.float32)
+            tab["wd"] = np.asarray([groups[gi]["weight_decay"] for gi in cls["gidx"]], np.float32)
+            raw = tab.tobytes()
+            if raw != cls["sent"]:
+                cls["tab_dev"] = torch.from_numpy(tab.view(np.uint8).reshape(-1).copy()).to(cls["device"], non_blocking=True)
+                cls["sent"] = raw
+        return plan
+
+    def _build_plan(self, live):
+        """Classes of parameters that share (step count, betas, eps, device), each with its host table, chunk tables
+        on the device and the group index of every parameter."""
+        counts = self.__dict__.setdefault("_counts", {})
         by_key = {}
-        for group, p in self._live():
-            self._check(p)
+        for gi, p in live:
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                raise ValueError("FusedAdamW: contiguous fp32 GPU parameters required (no CPU path)")
             st = self._init_state(p)
             for k in ("exp_avg", "exp_avg_sq"):
                 if st[k].device != p.device or not st[k].is_contiguous():
                     st[k] = st[k].to(p.device).contiguous()
-            st["step"] += 1
-            key = (int(st["step"]), group["betas"], group["eps"], p.device)
-            by_key.setdefault(key, []).append((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(),
-                                               st["exp_avg_sq"].data_ptr(), p.numel(), group["lr"],
-                                               group["weight_decay"]))
-        for (step, betas, eps, dev), entries in by_key.items():
-            cache = self.__dict__.setdefault("_tables", {})
-            hit = cache.get((betas, eps, dev))
-            if hit is None or hit[0] != entries:   # same tensors, learning rates and decays as last step: same table
-                hit = cache[(betas, eps, dev)] = (entries, build_table(entries, dev))
-            tab, ct, cs, nchunks = hit[1]
-            with _lib.on(dev):
-                _lib.check(lib.zs_adamw_multi(_lib.ptr(tab), _lib.ptr(ct), _lib.ptr(cs), nchunks, betas[0], betas[1],
-                                              eps, step, _lib.ptr(self._clip), _lib.current_stream_ptr(dev)),
-                           "zs_adamw_multi")
-        self._clip = None
-        A.bump_generation()                   # parameters changed behind torch's version counters
-        return None
+            if p not in counts:
+                counts[p] = int(st["step"])
+            g = self.param_groups[gi]
+            by_key.setdefault((counts[p], g["betas"], g["eps"], p.device), []).append((gi, p))
+        classes = []
+        for (step, betas, eps, dev), members in by_key.items():
+            params = [p for _, p in members]
+            entries = [(p.data_ptr(), 0, self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(),
+                        p.numel(), 0.0, 0.0) for p in params]
+            _, ct, cs, nchunks = build_table(entries, dev)
+            tab = np.zeros(len(entries), _ENTRY)
+            for i, e in enumerate(entries):
+                tab[i] = e
+            classes.append(dict(params=params, gidx=[gi for gi, _ in members], tab=tab, ct=ct, cs=cs, nchunks=nchunks,
+                                betas=betas, eps=eps, device=dev, step=step, sent=None, tab_dev=None))
+        plan = self._plan = dict(ids=tuple(id(p) for _, p in live), classes=classes)
+        return plan
+
+    def _sync_step_tensors(self):
+        for p, n in self.__dict__.get("_counts", {}).items():
+            if p in self.state and "step" in self.state[p]:
+                self.state[p]["step"] = torch.tensor(float(n), dtype=torch.float32)
+
+    def state_dict(self):
+        self._sync_step_tensors()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self.__dict__.pop("_plan", None)       # moments were replaced: new pointers, and the step counts of the file
+        self._counts = {p: int(st["step"]) for p, st in self.state.items() if "step" in st}
 
 
 class LossScaler:
