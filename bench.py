@@ -30,7 +30,7 @@ Extra objects on the JSON line:
                  and the occupancy flips between the two arithmetics on the full grid.
   cpu_baseline - the oracle (torch-CPU fp32 restatement of the reference, "port") timed on
                  this host's cores on a bounded sample of x-slices of the same grid.
-  chamfer / pose_search / chamfer_l1 / encoder / train_step
+  chamfer / pose_search / chamfer_l1 / encoder / inference / iso_surface / train_step
                - (N = 1, outside the timed region; tools/bench_legs.py) the rest of the BASELINE metric: the
                  Chamfer NN kernel on [24,10k]x[24,10k] with its fp32-VALU roofline fraction, bit equality
                  to the oracle and the oracle timed on the host (CPU leg ii); the 6912-rotation pose search
@@ -295,7 +295,7 @@ def main():
         cpu = not args.no_cpu_baseline
         for name, fn in (("chamfer", lambda: legs.chamfer_leg(dev, cpu)), ("pose_search", lambda: legs.pose_search_leg(dev)),
                          ("chamfer_l1", lambda: legs.eval_leg(dev, net, sd)), ("encoder", lambda: legs.encoder_leg(dev, cpu)),
-                         ("inference", lambda: legs.inference_leg(dev)),
+                         ("inference", lambda: legs.inference_leg(dev)), ("iso_surface", lambda: legs.surface_leg(dev)),
                          ("train_step", lambda: legs.in_subprocess("train", "train_step"))):
             try:
                 extras[name] = fn()

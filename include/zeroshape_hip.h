@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 27
+#define ZS_ABI_VERSION 28
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -259,10 +259,12 @@ int zs_fscore(const float *dist1, int n, const float *dist2, int m, int b, const
  *   zs_mc_emit   : tris[n_tris][3][3] fp32 triangle soup in world space
  *                  (index * scale + offset), cube order x-slowest, deterministic
  *   zs_mesh_sample: n_samples area-weighted points (counter-based RNG, `seed`);
- *                  cum_area = scratch of n_tris doubles; an empty mesh yields zeros
+ *                  cum_area = scratch of zs_mesh_sample_scratch_doubles(n_tris) doubles (the cumulative
+ *                  areas and the tile totals of their scan); an empty mesh yields zeros
  * vol is [G][G][G] fp32 (x slowest), a cube corner is "inside" when value < iso.
  * ------------------------------------------------------------------------- */
 size_t zs_mc_scratch_bytes(int G);
+size_t zs_mesh_sample_scratch_doubles(int n_tris);
 int zs_mc_count(const float *vol, int G, float iso, const uint8_t *tri_count, void *scratch,
                 int *total, void *stream);
 int zs_mc_emit(const float *vol, int G, float iso, const int8_t *tri_table, int table_stride,

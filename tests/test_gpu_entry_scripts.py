@@ -144,8 +144,9 @@ def test_bench_line_contract():
     assert r["launch_ms_mean"] <= d["ms_per_step"] * 1.02           # the kernel is inside the step
     assert r["traffic"] is None or (r["traffic"] > pts * 4 and "stale" not in r["traffic_source"])
     assert d["exact_f32"]["occupancy_flips"] <= 2 and d["exact_f32"]["max_abs_logit_diff"] < 1e-4
-    for leg in ("chamfer", "pose_search", "chamfer_l1", "encoder", "inference", "train_step"):
+    for leg in ("chamfer", "pose_search", "chamfer_l1", "encoder", "inference", "iso_surface", "train_step"):
         assert leg in d, leg
+    assert d["iso_surface"]["vox128"]["triangles"] > 1000 and 0 < d["iso_surface"]["vox128"]["ms"] < 5
     assert 0 < d["train_step"]["ms_amp"] < d["train_step"]["ms"] <= d["train_step"]["ms_eager"] * 1.05
     assert d["inference"]["vox64"]["points"] == 65 ** 3 and 0 < d["inference"]["vox64"]["ms"] < d["inference"]["vox128"]["ms"]
     assert d["pose_search"]["pruned_equals_exhaustive"] is True and d["chamfer_l1"]["chamfer_l1_vs_oracle_pipeline_vox16"] < 1e-4

@@ -158,6 +158,46 @@ def eval_leg(dev, net, sd):
             "chamfer_l1_vox128": float((a.cd_acc + a.cd_comp) / 2)}
 
 
+def surface_leg(dev, iters=10):
+    """convert_to_explicit's device path (utils/eval_3D.py:233-263): marching cubes + 10k area-weighted samples of a
+    level grid resident in HBM, vox_res 128 and 256 (BASELINE configs 3 / 5).  The two grid passes (count, emit)
+    read G^3 * 4 B each; `grid_gb_per_s` prices them against the whole call, `count_gb_per_s` the first pass alone
+    (HIP events around zs_mc_count's launches)."""
+    from zeroshape_amd import _lib
+    from zeroshape_amd.utils import eval_3D as E
+    out = {}
+    lib = _lib.load()
+    for N in (128, 256):
+        G = N + 1
+        ax = torch.linspace(-1.5, 1.5, G, device=dev)
+        x, y, z = torch.meshgrid(ax, ax, ax, indexing="ij")
+        vol = torch.sigmoid(-20.0 * (torch.sqrt(x * x + 1.3 * y * y + 0.8 * z * z) - 0.9)).contiguous()   # an ellipsoid
+        tris, pts = E.extract_surface(vol, 0.5, -1.5, 1.5, num_points=10000)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            tris, pts = E.extract_surface(vol, 0.5, -1.5, 1.5, num_points=10000)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / iters * 1e3
+        tab, cnt, stride = E._mc_tables(dev)
+        scratch = torch.empty(lib.zs_mc_scratch_bytes(G) // 4 + 1, dtype=torch.int32, device=dev)
+        total = torch.zeros(1, dtype=torch.int32, device=dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for _ in range(iters):
+            _lib.check(lib.zs_mc_count(_lib.ptr(vol), G, 0.5, _lib.ptr(cnt), _lib.ptr(scratch), _lib.ptr(total),
+                                       _lib.current_stream_ptr(dev)), "zs_mc_count")
+        ev[1].record()
+        torch.cuda.synchronize()
+        count_ms = ev[0].elapsed_time(ev[1]) / iters
+        gbytes = G ** 3 * 4 / 1e9
+        out["vox%d" % N] = {"ms": round(ms, 3), "triangles": int(tris.shape[0]), "grid_mb": round(gbytes * 1e3, 1),
+                            "grid_gb_per_s": round(2 * gbytes / (ms * 1e-3), 1),
+                            "count_pass_ms": round(count_ms, 4), "count_gb_per_s": round(gbytes / (count_ms * 1e-3), 1)}
+    out["hbm_peak_gb_per_s"] = 8000.0
+    return out
+
+
 def _graph(dev):
     from zeroshape_amd.model.compute_graph.graph_shape import Graph
     from zeroshape_amd.utils.options import EasyDict as edict
@@ -317,5 +357,7 @@ if __name__ == "__main__":
         print(json.dumps({"pose_search": pose_search_leg(dev)}), flush=True)
     if "encoder" in want:
         print(json.dumps({"encoder": encoder_leg(dev)}), flush=True)
+    if "surface" in want:
+        print(json.dumps({"iso_surface": surface_leg(dev)}), flush=True)
     if "train" in want:
         print(json.dumps({"train_step": train_leg(dev)}), flush=True)

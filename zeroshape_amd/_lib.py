@@ -67,6 +67,7 @@ SIGNATURES = {
     "zs_normalize_pc": (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "zs_fscore": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p]),
     "zs_mc_scratch_bytes": (_c_size_t, [_c_int]),
+    "zs_mesh_sample_scratch_doubles": (_c_size_t, [_c_int]),
     "zs_mc_count": (_c_int, [_c_void_p, _c_int, ctypes.c_float, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "zs_mc_emit": (_c_int, [_c_void_p, _c_int, ctypes.c_float, _c_void_p, _c_int, _c_void_p, _c_void_p,
                             ctypes.c_float, ctypes.c_float, _c_void_p, _c_int, _c_void_p]),
@@ -158,7 +159,7 @@ SIGNATURES = {
     "zs_readout_concat_bwd": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
 }
 
-ABI_VERSION = 27
+ABI_VERSION = 28
 _lib = None
 
 

@@ -53,6 +53,21 @@ __device__ __forceinline__ int cube_case(const float *__restrict__ vol, int G, i
     return c;
 }
 
+// linear cube index (k fastest) -> (i, j, k); 32-bit divisions whenever the index fits (G <= 1291): the 64-bit ones
+// cost more than the eight loads of the cube
+__device__ __forceinline__ void cube_ijk(long long cube, int C, int &i, int &j, int &k) {
+    if ((long long)C * C * C < (1LL << 31)) {
+        const unsigned c = (unsigned)cube, q = c / (unsigned)C;
+        k = (int)(c - q * (unsigned)C);
+        i = (int)(q / (unsigned)C);
+        j = (int)(q - (unsigned)i * (unsigned)C);
+    } else {
+        k = (int)(cube % C);
+        j = (int)((cube / C) % C);
+        i = (int)(cube / ((long long)C * C));
+    }
+}
+
 // block-wide exclusive scan of one int per thread (MC_THREADS threads); returns the block total
 __device__ __forceinline__ int block_exclusive_scan(int v, int *lds, int &total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -85,7 +100,8 @@ __global__ __launch_bounds__(MC_THREADS) void mc_count_kernel(const float *__res
     const long long cube = (long long)blockIdx.x * MC_THREADS + threadIdx.x;
     int n = 0;
     if (cube < (long long)C * C * C) {
-        const int k = (int)(cube % C), j = (int)((cube / C) % C), i = (int)(cube / ((long long)C * C));
+        int i, j, k;
+        cube_ijk(cube, C, i, j, k);
         float f[8];
         n = tri_count[cube_case(vol, G, i, j, k, iso, f)];
     }
@@ -94,33 +110,75 @@ __global__ __launch_bounds__(MC_THREADS) void mc_count_kernel(const float *__res
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-// exclusive scan of `n` ints in place by ONE block (n <= a few 10^4); writes the grand total
-__global__ __launch_bounds__(1024) void scan_small_kernel(int *__restrict__ data, int n,
-                                                          int *__restrict__ total_out) {
-    __shared__ int lds[1024];
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int idx = base + threadIdx.x;
-        const int v = idx < n ? data[idx] : 0;
-        lds[threadIdx.x] = v;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            const int y = threadIdx.x >= o ? lds[threadIdx.x - o] : 0;
-            __syncthreads();
-            lds[threadIdx.x] += y;
-            __syncthreads();
-        }
-        const int incl = lds[threadIdx.x];
-        const int c = carry;
-        if (idx < n) data[idx] = c + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = c + incl;
-        __syncthreads();
+// ---- scans over many workgroups, two launches -------------------------------------------------------------- //
+// launch 1: a workgroup scans SCAN_TILE consecutive elements in place (a thread loads SCAN_ITEMS adjacent ones, so
+// a wave reads one contiguous span; wave shuffles + one LDS exchange) and leaves its total in tile_tot[tile];
+// launch 2: every workgroup adds the sum of the tile totals before its own (a few hundred values, summed in index
+// order by each workgroup alike - deterministic) to its elements.  A single workgroup walking 10^5 elements took
+// 50-240 us; this takes two launches of a few microseconds.
+constexpr int SCAN_ITEMS = 8, SCAN_TILE = 256 * SCAN_ITEMS;
+template <typename T>
+__device__ __forceinline__ T block256_exclusive(T v, T *lds, T &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const T y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
     }
-    if (threadIdx.x == 0) *total_out = carry;
+    if (lane == 63) lds[wave] = x;
+    __syncthreads();
+    T base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const T t = lds[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    total = tot;
+    return base + x - v;
 }
+// INCLUSIVE = false: data[i] <- sum of data[tile start .. i);  true: .. i]
+template <typename T, bool INCLUSIVE>
+__global__ __launch_bounds__(256) void scan_tiles_kernel(T *__restrict__ data, long long n, T *__restrict__ tile_tot) {
+    __shared__ T lds[4];
+    const long long b = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+    T v[SCAN_ITEMS], s = 0;
+#pragma unroll
+    for (int e = 0; e < SCAN_ITEMS; e++) {
+        v[e] = b + e < n ? data[b + e] : (T)0;
+        s += v[e];
+    }
+    T total;
+    T run = block256_exclusive<T>(s, lds, total);
+#pragma unroll
+    for (int e = 0; e < SCAN_ITEMS; e++) {
+        if (INCLUSIVE) run += v[e];
+        if (b + e < n) data[b + e] = run;
+        if (!INCLUSIVE) run += v[e];
+    }
+    if (threadIdx.x == 0) tile_tot[blockIdx.x] = total;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void scan_offsets_kernel(T *__restrict__ data, long long n, const T *__restrict__ tile_tot,
+                                                           int tiles, T *__restrict__ total_out) {
+    __shared__ T lds[4];
+    __shared__ T offset;
+    // sum of the totals of the tiles before this one, in a fixed order: 256 strided partial sums, then the scan's tree
+    T part = 0;
+    for (int t = threadIdx.x; t < (int)blockIdx.x; t += 256) part += tile_tot[t];
+    T total;
+    (void)block256_exclusive<T>(part, lds, total);
+    if (threadIdx.x == 0) offset = total;
+    __syncthreads();
+    const T off = offset;
+    const long long b = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+    for (int e = 0; e < SCAN_ITEMS; e++)
+        if (b + e < n) data[b + e] += off;
+    if (total_out && blockIdx.x == tiles - 1 && threadIdx.x == 0) *total_out = off + tile_tot[tiles - 1];
+}
+static inline int scan_tiles(long long n) { return (int)((n + SCAN_TILE - 1) / SCAN_TILE); }
 
 __global__ __launch_bounds__(MC_THREADS) void mc_emit_kernel(
     const float *__restrict__ vol, int G, float iso, const int8_t *__restrict__ tri_table,
@@ -132,9 +190,7 @@ __global__ __launch_bounds__(MC_THREADS) void mc_emit_kernel(
     int n = 0, cs = 0, i = 0, j = 0, k = 0;
     float f[8];
     if (cube < (long long)C * C * C) {
-        k = (int)(cube % C);
-        j = (int)((cube / C) % C);
-        i = (int)(cube / ((long long)C * C));
+        cube_ijk(cube, C, i, j, k);
         cs = cube_case(vol, G, i, j, k, iso, f);
         n = tri_count[cs];
     }
@@ -171,30 +227,6 @@ __global__ __launch_bounds__(256) void tri_area_kernel(const float *__restrict__
     const float vx = p[6] - p[0], vy = p[7] - p[1], vz = p[8] - p[2];
     const float nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
     area[t] = 0.5 * sqrt((double)nx * nx + (double)ny * ny + (double)nz * nz);
-}
-
-// inclusive scan of doubles in place, one block, sequential chunks (n ~ 10^5: a few 100 us)
-__global__ __launch_bounds__(1024) void scan_f64_kernel(double *__restrict__ data, int n) {
-    __shared__ double lds[1024];
-    __shared__ double carry;
-    if (threadIdx.x == 0) carry = 0.0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int idx = base + threadIdx.x;
-        lds[threadIdx.x] = idx < n ? data[idx] : 0.0;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            const double y = threadIdx.x >= o ? lds[threadIdx.x - o] : 0.0;
-            __syncthreads();
-            lds[threadIdx.x] += y;
-            __syncthreads();
-        }
-        const double incl = lds[threadIdx.x] + carry;
-        if (idx < n) data[idx] = incl;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = incl;
-        __syncthreads();
-    }
 }
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
@@ -236,7 +268,12 @@ __global__ __launch_bounds__(256) void mesh_sample_kernel(const float *__restric
 extern "C" size_t zs_mc_scratch_bytes(int G) {
     if (G < 2) return 0;
     const long long cubes = (long long)(G - 1) * (G - 1) * (G - 1);
-    return (size_t)((cubes + MC_THREADS - 1) / MC_THREADS + 1) * sizeof(int);
+    const long long nb = (cubes + MC_THREADS - 1) / MC_THREADS;
+    return (size_t)(nb + 1 + scan_tiles(nb) + 1) * sizeof(int);        // block offsets | totals of the scan's tiles
+}
+
+extern "C" size_t zs_mesh_sample_scratch_doubles(int n_tris) {
+    return n_tris < 0 ? 0 : (size_t)n_tris + scan_tiles(n_tris) + 1;     // cumulative areas | totals of the scan's tiles
 }
 
 extern "C" int zs_mc_count(const float *vol, int G, float iso, const uint8_t *tri_count,
@@ -254,7 +291,10 @@ extern "C" int zs_mc_count(const float *vol, int G, float iso, const uint8_t *tr
     const int nb = (int)((cubes + MC_THREADS - 1) / MC_THREADS);
     int *sums = static_cast<int *>(scratch);
     hipLaunchKernelGGL(mc_count_kernel, dim3(nb), dim3(MC_THREADS), 0, s, vol, G, iso, tri_count, sums);
-    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, s, sums, nb, total);
+    int *tile_tot = sums + nb + 1;
+    const int tiles = scan_tiles(nb);
+    hipLaunchKernelGGL((scan_tiles_kernel<int, false>), dim3(tiles), dim3(256), 0, s, sums, (long long)nb, tile_tot);
+    hipLaunchKernelGGL(scan_offsets_kernel<int>, dim3(tiles), dim3(256), 0, s, sums, (long long)nb, tile_tot, tiles, total);
     return zs::check_launch("zs_mc_count") ? 1 : 0;
 }
 
@@ -299,7 +339,11 @@ extern "C" int zs_mesh_sample(const float *tris, int n_tris, int n_samples, uint
         return 0;
     }
     hipLaunchKernelGGL(tri_area_kernel, dim3((n_tris + 255) / 256), dim3(256), 0, s, tris, n_tris, cum_area);
-    hipLaunchKernelGGL(scan_f64_kernel, dim3(1), dim3(1024), 0, s, cum_area, n_tris);
+    double *tile_tot = cum_area + n_tris;
+    const int tiles = scan_tiles(n_tris);
+    hipLaunchKernelGGL((scan_tiles_kernel<double, true>), dim3(tiles), dim3(256), 0, s, cum_area, (long long)n_tris, tile_tot);
+    hipLaunchKernelGGL(scan_offsets_kernel<double>, dim3(tiles), dim3(256), 0, s, cum_area, (long long)n_tris, tile_tot, tiles,
+                       static_cast<double *>(nullptr));
     hipLaunchKernelGGL(mesh_sample_kernel, dim3((n_samples + 255) / 256), dim3(256), 0, s, tris, n_tris,
                        cum_area, seed, n_samples, points);
     return zs::check_launch("zs_mesh_sample") ? 1 : 0;

@@ -476,7 +476,7 @@ def extract_surface(level_vox, isoval, range_min, range_max, num_points=0, seed=
         pts = None
         if num_points:
             pts = torch.empty(num_points, 3, dtype=torch.float32, device=dev)
-            cum = torch.empty(max(n_tris, 1), dtype=torch.float64, device=dev)
+            cum = torch.empty(max(lib.zs_mesh_sample_scratch_doubles(n_tris), 1), dtype=torch.float64, device=dev)
             _lib.check(lib.zs_mesh_sample(_lib.ptr(tris), n_tris, num_points, int(seed) & ((1 << 64) - 1),
                                           _lib.ptr(cum), _lib.ptr(pts), stream), "zs_mesh_sample")
     return tris, pts
