@@ -19,18 +19,19 @@ def main():
         ap.add_argument("--" + n, type=int, default=d)
     ap.add_argument("--mode", default="all")
     ap.add_argument("--engine", default="autograd", help="autograd (training path, nn/autograd.py) | ops (inference path, nn/ops.py)")
+    ap.add_argument("--tiling", default=None, help="ops engine: large | small (default: the size-based choice)")
     a = ap.parse_args()
     if a.engine == "ops":
         from zeroshape_amd.nn import ops, pack
         x = torch.randn(a.B, a.H, a.H, a.Cin, device="cuda")
         w = torch.randn(a.Cout, a.Cin, a.k, a.k) / (a.Cin * a.k * a.k) ** 0.5
         pc = pack.pack_conv(w, None, stride=a.stride, padding=a.k // 2).to("cuda")
-        y = ops.conv2d(x, pc)
+        y = ops.conv2d(x, pc, tiling=a.tiling)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(a.iters):
-            ops.conv2d(x, pc)
+            ops.conv2d(x, pc, tiling=a.tiling)
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / a.iters * 1e3
