@@ -25,6 +25,8 @@
 namespace {
 
 constexpr int MC_THREADS = 256;
+constexpr int MC_PER = 4;                  // consecutive cubes per thread: four cubes' corner loads in flight per lane
+constexpr int MC_BLOCK = MC_THREADS * MC_PER;   // cubes per workgroup (the unit of the block offsets)
 
 // edge e: (corner a, corner b) listed low-coordinate endpoint first, its axis, and the
 // corner offsets (mc_tables.py numbering)
@@ -35,8 +37,7 @@ __device__ const int kCornerX[8] = {0, 1, 1, 0, 0, 1, 1, 0};
 __device__ const int kCornerY[8] = {0, 0, 1, 1, 0, 0, 1, 1};
 __device__ const int kCornerZ[8] = {0, 0, 0, 0, 1, 1, 1, 1};
 
-__device__ __forceinline__ int cube_case(const float *__restrict__ vol, int G, int i, int j, int k,
-                                         float iso, float f[8]) {
+__device__ __forceinline__ void cube_corners(const float *__restrict__ vol, int G, int i, int j, int k, float f[8]) {
     const size_t gg = (size_t)G * G;
     const float *p = vol + (size_t)i * gg + (size_t)j * G + k;
     f[0] = p[0];
@@ -47,6 +48,8 @@ __device__ __forceinline__ int cube_case(const float *__restrict__ vol, int G, i
     f[5] = p[gg + 1];
     f[6] = p[gg + G + 1];
     f[7] = p[G + 1];
+}
+__device__ __forceinline__ int case_of(const float f[8], float iso) {
     int c = 0;
 #pragma unroll
     for (int b = 0; b < 8; b++) c |= (f[b] < iso) ? (1 << b) : 0;
@@ -68,7 +71,8 @@ __device__ __forceinline__ void cube_ijk(long long cube, int C, int &i, int &j, 
     }
 }
 
-// block-wide exclusive scan of one int per thread (MC_THREADS threads); returns the block total
+// block-wide exclusive scan of one int per thread (64 * NW threads); returns the block total
+template <int NW = MC_THREADS / 64>
 __device__ __forceinline__ int block_exclusive_scan(int v, int *lds, int &total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int x = v;
@@ -81,7 +85,7 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *lds, int &total)
     __syncthreads();
     int base = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < MC_THREADS / 64; w++) {
+    for (int w = 0; w < NW; w++) {
         const int s = lds[w];
         if (w < wave) base += s;
         tot += s;
@@ -95,19 +99,28 @@ __global__ __launch_bounds__(MC_THREADS) void mc_count_kernel(const float *__res
                                                               float iso,
                                                               const uint8_t *__restrict__ tri_count,
                                                               int *__restrict__ block_sums) {
-    __shared__ int lds[MC_THREADS / 64];
     const int C = G - 1;
-    const long long cube = (long long)blockIdx.x * MC_THREADS + threadIdx.x;
-    int n = 0;
-    if (cube < (long long)C * C * C) {
+    const long long cubes = (long long)C * C * C;
+    const long long first = (long long)blockIdx.x * MC_BLOCK + (long long)threadIdx.x * MC_PER;
+    // the grid is tiny next to the chip (8.6 MB at 129^3): what bounds the pass is latency x occupancy, so a lane
+    // keeps the corner loads of four cubes in flight before it looks at any of them
+    float f[MC_PER][8];
+#pragma unroll
+    for (int q = 0; q < MC_PER; q++) {
         int i, j, k;
-        cube_ijk(cube, C, i, j, k);
-        float f[8];
-        n = tri_count[cube_case(vol, G, i, j, k, iso, f)];
+        cube_ijk(first + q < cubes ? first + q : 0, C, i, j, k);
+        cube_corners(vol, G, i, j, k, f[q]);
     }
-    int total;
-    block_exclusive_scan(n, lds, total);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+    int n = 0;
+#pragma unroll
+    for (int q = 0; q < MC_PER; q++)
+        if (first + q < cubes) n += tri_count[case_of(f[q], iso)];
+    // a wave's 64 x MC_PER consecutive cubes are one block of MC_THREADS cubes of the emit pass: its sum is that
+    // block's entry, no exchange between the waves
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+    const long long blk = (long long)blockIdx.x * (MC_BLOCK / MC_THREADS) + (threadIdx.x >> 6);
+    if ((threadIdx.x & 63) == 0 && blk * MC_THREADS < cubes) block_sums[blk] = n;
 }
 
 // ---- scans over many workgroups, two launches -------------------------------------------------------------- //
@@ -180,6 +193,7 @@ __global__ __launch_bounds__(256) void scan_offsets_kernel(T *__restrict__ data,
 }
 static inline int scan_tiles(long long n) { return (int)((n + SCAN_TILE - 1) / SCAN_TILE); }
 
+// one cube per thread; a workgroup's MC_THREADS cubes are one entry of the count pass's block offsets
 __global__ __launch_bounds__(MC_THREADS) void mc_emit_kernel(
     const float *__restrict__ vol, int G, float iso, const int8_t *__restrict__ tri_table,
     int table_stride, const uint8_t *__restrict__ tri_count, const int *__restrict__ block_offsets,
@@ -191,7 +205,8 @@ __global__ __launch_bounds__(MC_THREADS) void mc_emit_kernel(
     float f[8];
     if (cube < (long long)C * C * C) {
         cube_ijk(cube, C, i, j, k);
-        cs = cube_case(vol, G, i, j, k, iso, f);
+        cube_corners(vol, G, i, j, k, f);
+        cs = case_of(f, iso);
         n = tri_count[cs];
     }
     int total;
@@ -209,10 +224,9 @@ __global__ __launch_bounds__(MC_THREADS) void mc_emit_kernel(
             const float px = (float)(i + kCornerX[a]) + (axis == 0 ? tt : 0.0f);
             const float py = (float)(j + kCornerY[a]) + (axis == 1 ? tt : 0.0f);
             const float pz = (float)(k + kCornerZ[a]) + (axis == 2 ? tt : 0.0f);
-            const float p[3] = {px, py, pz};
-            o[3 * v + 0] = fmaf(p[0], scale, offset);
-            o[3 * v + 1] = fmaf(p[1], scale, offset);
-            o[3 * v + 2] = fmaf(p[2], scale, offset);
+            o[3 * v + 0] = fmaf(px, scale, offset);
+            o[3 * v + 1] = fmaf(py, scale, offset);
+            o[3 * v + 2] = fmaf(pz, scale, offset);
         }
     }
 }
@@ -290,7 +304,8 @@ extern "C" int zs_mc_count(const float *vol, int G, float iso, const uint8_t *tr
     const long long cubes = (long long)(G - 1) * (G - 1) * (G - 1);
     const int nb = (int)((cubes + MC_THREADS - 1) / MC_THREADS);
     int *sums = static_cast<int *>(scratch);
-    hipLaunchKernelGGL(mc_count_kernel, dim3(nb), dim3(MC_THREADS), 0, s, vol, G, iso, tri_count, sums);
+    hipLaunchKernelGGL(mc_count_kernel, dim3((unsigned)((cubes + MC_BLOCK - 1) / MC_BLOCK)), dim3(MC_THREADS), 0, s, vol, G, iso,
+                       tri_count, sums);
     int *tile_tot = sums + nb + 1;
     const int tiles = scan_tiles(nb);
     hipLaunchKernelGGL((scan_tiles_kernel<int, false>), dim3(tiles), dim3(256), 0, s, sums, (long long)nb, tile_tot);
