@@ -260,3 +260,35 @@ def test_captured_step_matches_the_eager_step(tmp_path, encoder_sd, seeded_sd):
     assert l0[4] != l0[0]                                      # the weights move
     worst = max(float((sd0[k].float() - sd1[k].float()).abs().max()) for k in sd0)
     assert worst <= 1e-6, worst
+
+
+def test_captured_step_is_recaptured_when_a_workspace_moves_or_the_batch_changes(tmp_path, encoder_sd, seeded_sd):
+    """A capture holds the addresses of the workspaces and the shapes of its inputs: when a workspace is reallocated
+    (an evaluation between epochs can grow one) or another batch shape arrives, the runner drops it, warms up eagerly
+    twice and captures again - training goes on, gradients keep flowing into the optimiser."""
+    from zeroshape_amd.nn import autograd as A
+    from zeroshape_amd.utils import util
+    from zeroshape_amd.utils.options import EasyDict as edict
+    opt = train_opt(tmp_path, "--optim.hip_graph")
+    r = make_runner(opt, encoder_sd, seeded_sd, n_train=8)
+    r.graph.train()
+    batch = next(iter(torch.utils.data.DataLoader(r.train_data, batch_size=4, shuffle=False)))
+    half = {k: (v[:2] if torch.is_tensor(v) else v[:2] if isinstance(v, list) else v) for k, v in batch.items()}
+
+    def steps(b, n):
+        return [float(r.train_iteration(opt, util.move_to_device(edict(b), opt.device)).all) for _ in range(n)]
+    first = steps(batch, 4)
+    cap0 = r._captured
+    assert cap0 is not None
+    A.SCRATCH_GENERATION[0] += 1                     # what a reallocated workspace does
+    second = steps(batch, 4)
+    cap1 = r._captured
+    assert cap1 is not None and cap1 is not cap0
+    w = r.graph.impl_network.point_proj.proj.weight.detach().clone() if hasattr(r.graph.impl_network, "point_proj") else None
+    third = steps(half, 4)                           # two images per step: another input signature
+    cap2 = r._captured
+    assert cap2 is not None and cap2 is not cap1 and cap2["static"]["rgb_input_map"].shape[0] == 2
+    assert np.isfinite(first + second + third).all() and r.it == 12
+    assert second[-1] < first[0]                     # eight steps on the same batch: the loss went down
+    if w is not None:
+        assert not torch.equal(w, r.graph.impl_network.point_proj.proj.weight)
