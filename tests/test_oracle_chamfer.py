@@ -95,3 +95,20 @@ def test_backward_matches_analytic():
             ea[bi, i2[bi, j]] -= v
     np.testing.assert_allclose(ga, ea, rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(gb, eb, rtol=1e-5, atol=1e-5)
+
+
+def test_evaluation_size_clouds_vs_scipy_kdtree():
+    """An independent implementation at the evaluation's size ([.,10000] x [.,10000] points, utils/eval_3D.py:136):
+    scipy's cKDTree (exact nearest neighbour, float64).  Squared distances agree to fp32 rounding; indices agree
+    wherever the runner-up is not within rounding of the winner."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(11)
+    a = rng.uniform(-0.5, 0.5, (2, 10000, 3)).astype(np.float32)
+    b = (a[:, rng.permutation(10000)] + rng.normal(0, 0.01, (2, 10000, 3))).astype(np.float32)
+    d1, d2, i1, i2 = C.chamfer_forward(a, b)
+    for k in range(2):
+        for x, y, d, i in ((a[k], b[k], d1[k], i1[k]), (b[k], a[k], d2[k], i2[k])):
+            dist, idx = cKDTree(y.astype(np.float64)).query(x.astype(np.float64), k=2)
+            np.testing.assert_allclose(d, dist[:, 0] ** 2, rtol=2e-5, atol=1e-12)
+            clear = dist[:, 1] ** 2 - dist[:, 0] ** 2 > 1e-6 * (1.0 + dist[:, 1] ** 2)
+            assert clear.mean() > 0.99 and np.array_equal(i[clear], idx[clear, 0])
