@@ -292,3 +292,23 @@ def test_captured_step_is_recaptured_when_a_workspace_moves_or_the_batch_changes
     assert second[-1] < first[0]                     # eight steps on the same batch: the loss went down
     if w is not None:
         assert not torch.equal(w, r.graph.impl_network.point_proj.proj.weight)
+
+
+def test_training_steps_are_bit_reproducible(tmp_path, encoder_sd, seeded_sd):
+    """Every reduction of the training kernels has a fixed order (no atomics) and DropPath draws from the seeded device
+    generator: two runs of five steps (two eager, the capture, two replays) from the same state give bit-identical
+    losses, parameters and BatchNorm buffers."""
+    from zeroshape_amd.utils import util
+    from zeroshape_amd.utils.options import EasyDict as edict
+    runs = []
+    for _ in range(2):
+        opt = train_opt(tmp_path, "--optim.hip_graph")
+        r = make_runner(opt, encoder_sd, seeded_sd, n_train=8)
+        r.graph.train()
+        batches = list(torch.utils.data.DataLoader(r.train_data, batch_size=4, shuffle=False))
+        torch.manual_seed(7)
+        losses = [r.train_iteration(opt, util.move_to_device(edict(batches[it % 2]), opt.device)).all.detach().clone()
+                  for it in range(5)]
+        runs.append((torch.stack(losses).cpu(), {k: v.detach().cpu().clone() for k, v in r.graph.state_dict().items()}))
+    assert torch.equal(runs[0][0], runs[1][0]), (runs[0][0], runs[1][0])
+    assert [k for k in runs[0][1] if not torch.equal(runs[0][1][k], runs[1][1][k])] == []
