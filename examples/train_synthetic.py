@@ -32,12 +32,15 @@ def main():
     ap.add_argument("--lr", type=float, default=3e-4)
     ap.add_argument("--vox", type=int, default=32)
     ap.add_argument("--out", default="/tmp/zs_train_demo")
+    ap.add_argument("--amp", action="store_true", help="optim.amp: split-fp16 forward / data-gradient GEMMs under the loss scaler")
+    ap.add_argument("--hip-graph", action="store_true", help="optim.hip_graph: the step as one captured hipGraph")
     a = ap.parse_args()
     cmd = options.parse_arguments(["--yaml=%s/options/shape.yaml" % ROOT, "--output_root=%s" % a.out,
                                    "--batch_size=%d" % a.batch, "--max_epoch=%d" % a.epochs, "--pretrain.depth=",
                                    "--arch.depth.pretrained=", "--eval.vox_res=%d" % a.vox, "--eval.num_points=2000",
                                    "--eval.batch_size=4", "--training.n_sdf_points=2048", "--optim.lr=%g" % a.lr,
-                                   "--optim.lr_ft=%g" % (a.lr / 3), "--freq.eval=1000"])
+                                   "--optim.lr_ft=%g" % (a.lr / 3), "--freq.eval=1000"] +
+                                  (["--optim.amp"] if a.amp else []) + (["--optim.hip_graph"] if a.hip_graph else []))
     opt = options.set(cmd)
     opt.world_size = 1
     from zeroshape_amd.model.shape_engine import Runner
@@ -57,7 +60,7 @@ def main():
         losses = []
         for batch in r.train_loader:
             var = util.move_to_device(edict(batch), opt.device)
-            losses.append(r.train_iteration(opt, var).all.detach())
+            losses.append(r.train_iteration(opt, var).all.detach().clone())     # (a captured step reuses its loss tensor)
         curve.append(float(torch.stack(losses).mean()))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -66,7 +69,10 @@ def main():
                           images_per_sec=round(r.it * a.batch / dt, 1), loss_first_epoch=round(curve[0], 4),
                           loss_last_epoch=round(curve[-1], 4), loss_curve=[round(c, 4) for c in curve],
                           chamfer_before=round(before["cd"], 4), chamfer_after=round(after["cd"], 4),
-                          fscore_005_before=round(before["f_scores"][3], 4), fscore_005_after=round(after["f_scores"][3], 4))))
+                          fscore_005_before=round(before["f_scores"][3], 4), fscore_005_after=round(after["f_scores"][3], 4),
+                          non_finite_parameters=sum(int(not torch.isfinite(p).all()) for p in r.graph.parameters()),
+                          loss_scale=(float(r.scaler.scale) if hasattr(r, "scaler") else None),
+                          captured=getattr(r, "_captured", None) is not None)))
 
 
 if __name__ == "__main__":

@@ -186,6 +186,7 @@ class LossScaler:
         self.tracker = torch.zeros((), dtype=torch.int32, device=device)
         self.found_inf = torch.zeros((), dtype=torch.float32, device=device)
         self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+        self.min_scale = 2.0 ** -24
 
     def scale_loss(self, loss):
         return loss * self.scale
@@ -206,6 +207,10 @@ class LossScaler:
         optim.step()
         torch._amp_update_scale_(self.scale, self.tracker, self.found_inf, self.growth_factor, self.backoff_factor,
                                  self.growth_interval)
+        # (not in GradScaler) gradients that are nan at ANY scale - a collapsed depth map makes the reference's
+        # max-radius normalisation 0 / 0 - would halve the scale to 0 in 150 steps, and 1 / 0 then poisons every later
+        # step; with a floor the run recovers when the gradients do
+        self.scale.clamp_(min=self.min_scale)
         return true_norm
 
     def state_dict(self):
