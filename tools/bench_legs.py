@@ -295,7 +295,11 @@ def train_leg(dev, steps=8, warmup=3):
     def run(amp):
         cmd = options.parse_arguments(["--yaml=%s/options/shape.yaml" % ROOT, "--output_root=/tmp/zs_bench_train",
                                        "--batch_size=4", "--pretrain.depth=", "--arch.depth.pretrained=",
-                                       "--training.n_sdf_points=4096"] + (["--optim.amp"] if amp else []))
+                                       "--training.n_sdf_points=4096",
+                                       # random weights, no calibrated depth head: at the recipe's learning rate the
+                                       # untrained head collapses within ~20 steps; the step's work
+                                       # does not depend on the rate
+                                       "--optim.lr=1.e-7", "--optim.lr_ft=1.e-7"] + (["--optim.amp"] if amp else []))
         opt = options.set(cmd)
         opt.world_size = 1
         opt.output_path = None                      # no checkpoints from a benchmark
@@ -322,6 +326,7 @@ def train_leg(dev, steps=8, warmup=3):
         opt.optim.hip_graph = True                  # forward + loss + backward replayed as one captured hipGraph
         ms = timed(warmup + 3)                      # two more eager steps, the capture, then replays
         assert getattr(r, "_captured", None) is not None
+        assert all(bool(torch.isfinite(p).all()) for p in r.graph.parameters()), "non-finite parameters after the timed steps"
         del r
         torch.cuda.empty_cache()
         return ms_eager, ms

@@ -14,7 +14,8 @@ from zeroshape_amd.utils import options, util          # noqa: E402
 from zeroshape_amd.utils.options import EasyDict as edict   # noqa: E402
 
 cmd = options.parse_arguments(["--yaml=%s/options/shape.yaml" % ROOT, "--output_root=/tmp/zs_bench_train", "--batch_size=4",
-                               "--pretrain.depth=", "--arch.depth.pretrained=", "--training.n_sdf_points=4096"] +
+                               "--pretrain.depth=", "--arch.depth.pretrained=", "--training.n_sdf_points=4096",
+                               "--optim.lr=1.e-7", "--optim.lr_ft=1.e-7"] +     # (random weights: keep them where they are)
                               (["--optim.amp"] if os.environ.get("ZS_TRAIN_AMP") else []))
 opt = options.set(cmd)
 opt.world_size = 1
