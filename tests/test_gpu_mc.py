@@ -15,7 +15,8 @@ def _noise_vol(G, seed):
     return rs.uniform(0, 1, (G, G, G)).astype(np.float32)       # every case, incl. ambiguous ones
 
 
-@pytest.mark.parametrize("G,kind", [(2, "noise"), (3, "noise"), (9, "noise"), (17, "sphere"), (12, "noise")])
+@pytest.mark.parametrize("G,kind", [(2, "noise"), (3, "noise"), (9, "noise"), (17, "sphere"), (12, "noise"), (23, "noise"), (33, "sphere"),
+                                    (41, "noise")])
 def test_triangles_bit_exact(G, kind):
     from zeroshape_amd.utils import eval_3D as E
     vol = _noise_vol(G, G) if kind == "noise" else _sphere(G, 0.8)[0]
