@@ -151,9 +151,10 @@ int zs_sdf_query_grid(const void *programs, size_t program_stride_bytes, int bat
 
 /* Split-fp16 ("f16x3") decoder: the same network with every contraction on the 16-bit matrix
  * pipe, both operands split into two fp16 halves (A B ~= Ah Bh + Ah Bl + Al Bh, fp32
- * accumulation; halves rounded toward zero, saturating at +-65504: ~2^-21 relative operand error
- * for |x| <= 65504): max |logit difference| to the exact-fp32 kernels ~3e-6
- * (contract 1e-4), 2.6x their throughput.
+ * accumulation; halves rounded to nearest even: <= 2^-22 relative operand error without a sign
+ * preference for |x| < 65520, inf / nan beyond): max |logit difference| to the exact-fp32 kernels
+ * ~3e-6 on the seeded network, 1.5e-5 on a trained one with logits up to 17 - as far from the fp32
+ * CPU oracle as the fp32 kernels are (contract 1e-4); 2.8x their throughput.
  *   zs_sdf_split_programs     fp32 programs (after zs_sdf_prologue) -> split programs of the
  *                             same size and stride rules (split_programs must not alias programs)
  *   zs_sdf_query_points_split / zs_sdf_query_grid_split
@@ -464,6 +465,8 @@ int zs_window_tokens(const float *emb, const uint8_t *mask, const float *invalid
  *       [chunk_start[c], +zs_multi_tensor_chunk_elems()) of tensor chunk_tensor[c].
  *       grad_scale (device scalar, may be NULL) multiplies every gradient (clipping, loss-scale removal);
  *       a grad_scale of 0 or nan skips the whole update (an overflowed gradient under loss scaling).
+ *       `step` counts the calls; *skipped_steps (device int, may be NULL) the calls that were skipped that way:
+ *       the bias corrections use step - *skipped_steps, as torch's GradScaler never steps on an overflow.
  *   zs_copy_multi  : entry.param[i] = entry.grad[i] * scale (gradient bucketing for all-reduce).
  *   zs_sumsq_multi : *sumsq = sum of entry.grad[i]^2 over the table (partial: n_chunks floats).
  * ------------------------------------------------------------------------- */
@@ -557,7 +560,8 @@ int zs_intr_loss_bwd(const float *seen_pred, const float *seen_gt, const float *
                      const float *grad_loss, float *dseen_pred, void *stream);
 int zs_multi_tensor_chunk_elems(void);
 int zs_adamw_multi(const zs_tensor_entry *table, const int *chunk_tensor, const unsigned long long *chunk_start,
-                   int n_chunks, float beta1, float beta2, float eps, int step, const float *grad_scale, void *stream);
+                   int n_chunks, float beta1, float beta2, float eps, int step, const float *grad_scale,
+                   const int *skipped_steps, void *stream);
 int zs_copy_multi(const zs_tensor_entry *table, const int *chunk_tensor, const unsigned long long *chunk_start,
                   int n_chunks, float scale, void *stream);
 int zs_sumsq_multi(const zs_tensor_entry *table, const int *chunk_tensor, const unsigned long long *chunk_start,

@@ -105,8 +105,8 @@ class SplitStream(object):
 
 
 def _split_f16(x):
-    _, hi = P.f16_rtz(x.astype(np.float32))
-    _, lo = P.f16_rtz(x.astype(np.float32) - hi)
+    _, hi = P.f16_round(x.astype(np.float32))
+    _, lo = P.f16_round(x.astype(np.float32) - hi)
     return hi.astype(np.float64), lo.astype(np.float64)
 
 

@@ -183,7 +183,7 @@ def test_other_weights_and_scales_vs_fp32_kernel(seed, gain, tol):
     latent = torch.from_numpy(syn.seeded_latent(seed=seed, batch=2))
     pts = torch.from_numpy(syn.seeded_cloud(seed + 50, 2, 1500, -1.5, 1.5))
     exact = m.query_points(m.prepare(latent.cuda(), "f32"), pts.cuda())
-    split = m.query_points(m.prepare(latent.cuda(), "f16x3"), pts.cuda())
+    split = m.query_points(m.prepare(latent.cuda(), "f16x3", calibrate=False), pts.cuda())
     assert bool(torch.isfinite(split).all())
     scale = max(1.0, float(exact.abs().max()))
     assert float((split - exact).abs().max()) < tol * scale
@@ -256,7 +256,7 @@ def test_guard_reevaluates_out_of_envelope_tiles_in_fp32():
     m, sd = _scaled_net(3, 10.0)
     latent = torch.from_numpy(syn.seeded_latent(seed=3, batch=2)).cuda()
     pts = torch.from_numpy(syn.seeded_cloud(53, 2, 1500, -1.5, 1.5)).cuda()
-    st = m.prepare(latent)
+    st = m.prepare(latent, calibrate=False)      # (the calibration would hand these weights to the fp32 kernels)
     assert st.precision == "f16x3"
     guarded = m.query_points(st, pts)
     flags = m.last_tile_flags.clone().view(2, -1).bool()
@@ -282,7 +282,7 @@ def test_guard_grid_and_range_paths():
     m, _ = _scaled_net(2, 10.0)
     latent = torch.from_numpy(syn.seeded_latent(seed=2, batch=1)).cuda()
     axis = torch.linspace(-1.5, 1.5, 17, device="cuda")
-    st = m.prepare(latent)
+    st = m.prepare(latent, calibrate=False)
     g = m.query_grid(latent, axis, apply_sigmoid=True, state=st)
     fl = m.last_tile_flags.clone().bool()
     r = m.query_grid_range(latent, axis, 0, 17 ** 3, apply_sigmoid=True, state=st)
@@ -314,6 +314,33 @@ def test_non_finite_inputs_give_nan_like_the_reference(net):
         o = net.query_points(net.prepare(bad), pts)
         assert bool(torch.isnan(o[1]).all())
     net.envelope_guard = True
+
+
+def test_calibration_hands_out_of_contract_weights_to_the_exact_kernels():
+    """Implicit.prepare measures the output error of the split arithmetic once per weight version (4096 probe
+    points through both kernels) and keeps "f16x3" only within CALIBRATION_TOL: the seeded network stays, the
+    same network with its attention weights x10 (raw error 3e-4) is evaluated by the fp32 kernels, and a non-finite
+    first image does not poison the verdict."""
+    latent = torch.from_numpy(syn.seeded_latent(seed=3, batch=1)).cuda()
+    m1, _ = _scaled_net(3, 1.0)
+    assert m1.prepare(latent).precision == "f16x3"
+    c1 = m1.last_calibration
+    assert c1["selected"] == "f16x3" and 0 < c1["max_abs_diff"] <= m1.CALIBRATION_TOL and c1["points"] == 4096
+    m10, _ = _scaled_net(3, 10.0)
+    st = m10.prepare(latent)
+    c10 = m10.last_calibration
+    assert st.precision == "f32" and st.exact is None and c10["selected"] == "f32" and c10["max_abs_diff"] > 2.5e-5
+    pts = torch.from_numpy(syn.seeded_cloud(53, 1, 700, -1.5, 1.5)).cuda()
+    assert torch.equal(m10.query_points(st, pts), m10.query_points(m10.prepare(latent, "f32"), pts))
+    assert m10.prepare(latent, calibrate=False).precision == "f16x3"        # the unchecked state, for measurements
+    m10.calibrate = False
+    assert m10.prepare(latent).precision == "f16x3"
+    # a NaN image first: fp32 state for that call, nothing cached, the next good image calibrates
+    m2, _ = _scaled_net(2, 1.0)
+    bad = latent.clone()
+    bad[0, 3, 3] = float("nan")
+    assert m2.prepare(bad).precision == "f32" and m2._calibration is None
+    assert m2.prepare(latent).precision == "f16x3" and m2._calibration is not None
 
 
 def test_weights_beyond_w_max_select_the_exact_kernels():

@@ -1,8 +1,11 @@
 """GPU parity of the encoder mirrors (DPTDepthModel, intrinsics head, CoordEncRes, CoordEncAtt,
 Graph.forward) through the HIP layers vs oracle/encoder_ref.py and the golden outputs of the
-reference's own modules.  fp32 throughout; a ~100-layer stack accumulates rounding, so
-activations are compared relative to their scale: max|err| <= 1e-4 * max|want| (north_star's
-1e-4), the depth map absolutely (values in [0,1])."""
+reference's own modules.  The layers run in the engine's default arithmetic (zeroshape_amd/nn/ops.py:
+CONV_PRECISION, "f16x3" = split-fp16 with round-to-nearest halves unless ZS_ENCODER_PRECISION=f32); a
+~100-layer stack accumulates rounding, so activations are compared relative to their scale:
+max|err| <= 1e-4 * max|want| (north_star's 1e-4), the depth map absolutely (values in [0,1]).  The chain
+image -> latent -> occupancy grid is held to 1e-4 absolute for both arithmetics in
+tests/test_gpu_image_to_occupancy.py."""
 import numpy as np
 import pytest
 import torch
@@ -73,8 +76,8 @@ def test_graph_forward_vs_oracle_and_golden(graph, encoder_sd, encoder_golden):
     np.testing.assert_allclose(var.seen_points.cpu().numpy(), want["seen_points"].numpy(), atol=2e-4, rtol=0)
     np.testing.assert_allclose(sample(var.seen_points, 101), encoder_golden["g_seen_points_s101"], atol=2e-4, rtol=0)
     assert var.latent_depth.shape == (2, 197, 256)
-    close(var.latent_depth, want["latent_depth"], tol=2e-4, msg="latent_depth")
-    close(sample(var.latent_depth, 37), encoder_golden["g_latent_depth_s37"], tol=2e-4, msg="golden latent")
+    close(var.latent_depth, want["latent_depth"], msg="latent_depth")
+    close(sample(var.latent_depth, 37), encoder_golden["g_latent_depth_s37"], msg="golden latent")
     assert torch.equal(var.validity_mask.cpu(), (mask > 0.5).float().view(2, -1))
     assert var.latent_semantic is None
     # the decoder takes the latent as is (graph_shape.py:185 call shape)

@@ -248,6 +248,46 @@ def test_adamw_multi_tensor_matches_torch():
     assert sd["state"][0]["step"] == 4 and sd["state"][0]["exp_avg"].shape == (300, 70)
 
 
+def test_overflow_steps_do_not_count_as_adamw_steps():
+    """GradScaler semantics: on an overflow torch never calls optimizer.step(), so neither the bias
+    correction nor the checkpointed `step` advance.  Two of five LossScaler steps carry an inf gradient: parameters
+    and state equal torch.optim.AdamW stepped three times on the clean gradients."""
+    from zeroshape_amd.optim import FusedAdamW, LossScaler
+    g = torch.Generator().manual_seed(4)
+    ref = [torch.randn(s, generator=g).requires_grad_(True) for s in ((33, 17), (17,), (20000,))]
+    mine = [p.detach().clone().cuda().requires_grad_(True) for p in ref]
+    o_ref = torch.optim.AdamW([dict(params=ref, lr=2e-3, weight_decay=0.05)], betas=(0.9, 0.95))
+    o_mine = FusedAdamW([dict(params=mine, lr=2e-3, weight_decay=0.05)], betas=(0.9, 0.95))
+    scaler = LossScaler("cuda", init_scale=1024.0)
+    scales = []
+    for step in range(5):
+        overflow = step in (0, 3)
+        scale = float(scaler.scale)
+        scales.append(scale)
+        for pr, pm in zip(ref, mine):
+            gr = torch.randn(pr.shape, generator=g)
+            pm.grad = gr.cuda() * scale                       # what backward of the scaled loss leaves
+            if overflow:
+                pm.grad.view(-1)[0] = float("inf")
+            else:
+                pr.grad = gr.clone()
+        scaler.step(o_mine)
+        if not overflow:
+            o_ref.step()
+        o_ref.zero_grad()
+        o_mine.zero_grad()
+    assert scales == [1024.0, 512.0, 512.0, 512.0, 256.0]     # halved after each overflow
+    for pr, pm in zip(ref, mine):
+        close(pm, pr, rtol=1e-6, what="param")
+    sd = o_mine.state_dict()
+    assert sd["state"][0]["step"] == 3
+    close(sd["state"][0]["exp_avg"], o_ref.state_dict()["state"][0]["exp_avg"], rtol=1e-5, what="exp_avg")
+    # a reloaded state continues from the applied count
+    o2 = FusedAdamW([dict(params=mine, lr=2e-3, weight_decay=0.05)], betas=(0.9, 0.95))
+    o2.load_state_dict(sd)
+    assert o2.state_dict()["state"][0]["step"] == 3
+
+
 @pytest.mark.parametrize("k,stride,pad,H,Cout,std", [(7, 2, 3, 32, 64, False), (7, 2, "same", 30, 64, True), (3, 1, 1, 9, 32, False)])
 def test_stem_data_gradient_small_cin(k, stride, pad, H, Cout, std):
     """Convolutions with 3 input channels (zero-padded to 4): the data gradient takes the direct

@@ -61,7 +61,7 @@ def test_trained_weights_full_grid_f16x3_vs_f32_vs_oracle(trained):
     assert net.precision == "f16x3"
     N = 128
     axis = torch.linspace(-1.5, 1.5, N + 1, device="cuda")
-    st = net.prepare(latent)
+    st = net.prepare(latent, calibrate=False)
     assert st.precision == "f16x3", "trained weights left the host envelope (W_MAX)"
     split = net.query_grid(latent, axis, apply_sigmoid=False, state=st)
     flagged = int(net.last_tile_flags.sum())
@@ -95,6 +95,61 @@ def test_trained_weights_full_grid_f16x3_vs_f32_vs_oracle(trained):
         e = float((got - want[0]).abs().max())
         print("trained weights: max |%s kernel - oracle| = %.2e (logit scale %.1f)" % (name, e, scale))
         assert e < 1e-4 * scale
+
+
+def test_calibration_selects_fp32_exactly_when_the_contract_would_break(trained):
+    """Implicit.prepare's output-error calibration.  The last layer of the trained
+    network is scaled until the logit scale passes 50 and beyond (a 15-epoch checkpoint has larger logits than a
+    304-step one); the raw split error grows with it.  At every scale: the probe measurement must predict the
+    full-grid error, "f16x3" may only survive while the full 129^3 grid is inside the 1e-4 contract, and what the
+    default path returns is always inside it."""
+    opt, net, latent = trained
+    N = 128
+    axis = torch.linspace(-1.5, 1.5, N + 1, device="cuda")
+    w, b = net.impl_mlp.layers[8].weight, net.impl_mlp.layers[8].bias
+    w0, b0 = w.detach().clone(), b.detach().clone()
+    base = float(net.query_grid(latent, axis, apply_sigmoid=False, state=net.prepare(latent, "f32")).abs().max())
+    seen = set()
+    try:
+        for target in (None, 50.0, 200.0, 1000.0):
+            gain = 1.0 if target is None else target / base
+            with torch.no_grad():
+                w.copy_(w0 * gain)
+                b.copy_(b0 * gain)
+            st = net.prepare(latent)                                     # calibrates: new weight version
+            cal = dict(net.last_calibration)
+            exact = net.query_grid(latent, axis, apply_sigmoid=False, state=net.prepare(latent, "f32"))
+            raw_state = net.prepare(latent, calibrate=False)
+            net.envelope_guard = False
+            try:
+                raw = net.query_grid(latent, axis, apply_sigmoid=False, state=raw_state)
+            finally:
+                net.envelope_guard = True
+            full = float((raw - exact).abs().max())
+            got = net.query_grid(latent, axis, apply_sigmoid=False, state=st)
+            scale = float(exact.abs().max())
+            print("calibration at logit scale %.1f: probe max |f16x3 - f32| = %.2e (mean %.2e), full grid %.2e -> %s"
+                  % (scale, cal["max_abs_diff"], cal["mean_abs_diff"], full, cal["selected"]))
+            assert target is None or scale >= 0.99 * target
+            assert cal["selected"] == st.precision == ("f16x3" if cal["max_abs_diff"] <= net.CALIBRATION_TOL else "f32")
+            assert cal["points"] == 4096 and cal["tol"] == 2.5e-5
+            # 4096 probes see the bulk of the error distribution: the full grid's maximum stays within 4x of it
+            assert full <= 4.0 * max(cal["max_abs_diff"], 1e-7)
+            if full > 1e-4:
+                assert st.precision == "f32", "the contract is violated on the grid and the split kernel was kept"
+            if st.precision == "f16x3":
+                assert full <= 1e-4
+            assert float((got - exact).abs().max()) <= 1e-4           # what the default path returns
+            # cached per weight version: a second prepare() does not measure again
+            marker = net._calibration
+            net.prepare(latent)
+            assert net._calibration is marker
+            seen.add(st.precision)
+    finally:
+        with torch.no_grad():
+            w.copy_(w0)
+            b.copy_(b0)
+    assert seen == {"f16x3", "f32"}, "the sweep must cross the switch-over (saw %s)" % sorted(seen)
 
 
 def test_trained_weights_chamfer_l1_delta(trained):

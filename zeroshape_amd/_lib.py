@@ -137,7 +137,7 @@ SIGNATURES = {
     "zs_intr_loss_bwd": (_c_int, [_c_void_p] * 3 + [_c_size_t] + [_c_void_p] * 4),
     "zs_multi_tensor_chunk_elems": (_c_int, []),
     "zs_adamw_multi": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_float, _c_float, _c_float, _c_int,
-                                _c_void_p, _c_void_p]),
+                                _c_void_p, _c_void_p, _c_void_p]),
     "zs_copy_multi": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_float, _c_void_p]),
     "zs_sumsq_multi": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "zs_batch_norm_workspace_bytes": (_c_size_t, [_c_int, _c_int]),

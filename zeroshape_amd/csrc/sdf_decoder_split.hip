@@ -6,13 +6,13 @@
 // fp32 MFMA) with both operands split into two fp16 halves, x ~= hi + lo:
 //     A B  ~=  A_hi B_hi + A_hi B_lo + A_lo B_hi          (fp32 accumulation; A_lo B_lo dropped)
 // 3 MFMAs of 32 cycles per K = 16 instead of 8 fp32 MFMAs of 64 cycles: 5.3x fewer matrix
-// cycles at ~2^-21 relative operand error: max |logit difference| to the fp32 kernel 3.4e-6 and
-// no occupancy flip on the 129^3 grid (fp32 itself is 1e-6 from fp64; the same scheme on bf16
-// halves, same cost, measured 1.9e-5 and 10 flips; plain bf16 8e-3).  Halves are rounded toward
-// zero (v_cvt_pkrtz_f16_f32), which also saturates instead of overflowing: |x| <= 65,504 keeps the
-// full precision (to 131,008 representable at fp16 precision), far beyond what LayerNorm-ed
-// activations and these weights reach; values below
-// ~1e-4 lose relative (not absolute) precision to fp16 subnormals.  tests/test_gpu_decoder_split.py.
+// cycles at ~2^-22 relative operand error (fp32 itself is 1e-6 from fp64 on the seeded network; the
+// same scheme on bf16 halves, same cost, measured 1.9e-5 and 10 flips; plain bf16 8e-3).  Halves
+// are rounded to nearest even (v_cvt_pk_f16_f32, round 3; rounds 1-2 truncated with
+// v_cvt_pkrtz_f16_f32, whose one-signed errors accumulate - csrc/zs_split16.h has the numbers):
+// |x| < 65,520 keeps the full precision, far beyond what LayerNorm-ed activations and these weights
+// reach (beyond it hi is inf and the result NaN); values below ~1e-4 lose relative (not absolute)
+// precision to fp16 subnormals.  tests/test_gpu_decoder_split.py.
 //
 // What changes against the fp32 kernel, and why:
 //  * The transposed chain survives: accumulator registers 8j..8j+7 of a 32x32 output tile are,
@@ -107,7 +107,7 @@ static_assert(P_BLK_STRIDE <= PRM_WINDOW && W_IB - W_IA <= PRM_WINDOW && P_USED 
 // independent VALU work is around - either way the LDS latency is exposed at every K-block.
 DEV void pin(u32x4 &a, u32x4 &b) { asm volatile("" : "+v"(a), "+v"(b) : : "memory"); }
 
-// as_h / pk_f16 / split2 (x -> packed fp16 hi, lo: v_cvt_pkrtz_f16_f32 + v_fma_mix_f32, 2 VALU per
+// as_h / pk_f16 / split2 (x -> packed fp16 hi, lo: v_cvt_pk_f16_f32 + v_fma_mix_f32, 2 VALU per
 // value) / mfma3: csrc/zs_split16.h, shared with the convolution engine
 using zs::s16::mfma3;
 using zs::s16::split2;

@@ -565,12 +565,18 @@ constexpr int MT_CHUNK = 16384;  // elements per workgroup
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const TensorEntry *__restrict__ tab,
                                                           const int *__restrict__ chunk_tensor,
                                                           const unsigned long long *__restrict__ chunk_start,
-                                                          float beta1, float beta2, float eps, float bias1, float bias2_sqrt,
-                                                          const float *__restrict__ grad_scale) {
+                                                          float beta1, float beta2, float eps, int step,
+                                                          const float *__restrict__ grad_scale,
+                                                          const int *__restrict__ skipped_steps) {
     const TensorEntry t = tab[chunk_tensor[blockIdx.x]];
     const unsigned long long s0 = chunk_start[blockIdx.x], s1 = min(t.n, s0 + (unsigned long long)MT_CHUNK);
     const float gs = grad_scale ? *grad_scale : 1.0f;
     if (!(gs > 0.0f || gs < 0.0f)) return;      // 0 or nan: a loss scaler found an overflowed gradient - skip the step
+    // a skipped step is no step: torch's GradScaler never calls optimizer.step() on an overflow, so the bias
+    // correction counts the steps that were APPLIED (host count minus the device-side count of skips)
+    const int applied = max(1, step - (skipped_steps ? *skipped_steps : 0));
+    const float bias1 = (float)(1.0 - pow((double)beta1, (double)applied));
+    const float bias2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)applied));
     for (unsigned long long i = s0 + threadIdx.x; i < s1; i += 256) {
         // torch.optim.AdamW (single-tensor path): decoupled decay, then Adam with bias correction
         const float g = t.grad[i] * gs;
@@ -721,15 +727,13 @@ extern "C" int zs_multi_tensor_chunk_elems(void) { return MT_CHUNK; }
 
 extern "C" int zs_adamw_multi(const zs_tensor_entry *table, const int *chunk_tensor,
                               const unsigned long long *chunk_start, int n_chunks, float beta1, float beta2, float eps,
-                              int step, const float *grad_scale, void *stream) {
+                              int step, const float *grad_scale, const int *skipped_steps, void *stream) {
     ZS_REQUIRE(n_chunks >= 0 && step >= 1, "zs_adamw_multi: bad arguments (chunks=%d step=%d)", n_chunks, step);
     if (n_chunks == 0) return 1;
     ZS_REQUIRE(table && chunk_tensor && chunk_start, "zs_adamw_multi: null pointer");
-    const float bias1 = (float)(1.0 - pow((double)beta1, (double)step));
-    const float bias2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     hipLaunchKernelGGL(adamw_multi_kernel, dim3(n_chunks), dim3(256), 0, S(stream),
-                       reinterpret_cast<const TensorEntry *>(table), chunk_tensor, chunk_start, beta1, beta2, eps, bias1,
-                       bias2_sqrt, grad_scale);
+                       reinterpret_cast<const TensorEntry *>(table), chunk_tensor, chunk_start, beta1, beta2, eps, step,
+                       grad_scale, skipped_steps);
     return zs::check_launch("zs_adamw_multi") ? 1 : 0;
 }
 

@@ -1,6 +1,12 @@
 // Split-fp16 operand helpers shared by the kernels that run fp32 contractions on the 16-bit matrix
 // pipe (csrc/sdf_decoder_split.hip, csrc/nn_conv.hip): x ~= hi + lo with both halves fp16, rounded
-// toward zero (v_cvt_pkrtz_f16_f32: saturates at +-65504 instead of overflowing), ~2^-21 relative;
+// to nearest even (gfx950's v_cvt_pk_f16_f32), |x - hi - lo| <= 2^-22 |x| and the error has no sign
+// preference.  Rounds 1-2 rounded toward zero (v_cvt_pkrtz_f16_f32): 2^-20 worst case and every operand
+// error of one sign, which accumulated coherently over the K = 256..1024 sums and the ~25 dependent
+// layers - on trained weights (logit scale 15) 4.2e-5 from the fp32 kernel with a mean of 1.4e-5; the CPU
+// emulation of both roundings (tests/mfma_emulator.py) gives 7.2e-5 / mean -3.6e-5 (toward zero) against
+// 1.8e-5 / mean -5.7e-6 (nearest) at that scale.  Same instruction count.  Range: |x| < 65,520 (beyond
+// that hi is +-inf and the products NaN - loud, where the truncating form saturated silently);
 //     A B ~= A_hi B_hi + A_hi B_lo + A_lo B_hi     (fp32 accumulation)
 // = three v_mfma_f32_32x32x16_f16 per K = 16 instead of eight v_mfma_f32_32x32x2_f32 at a quarter
 // of the rate each.
@@ -19,7 +25,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 ZS_S16 f16x8 as_h(const u32x4 &v) { return __builtin_bit_cast(f16x8, v); }
 ZS_S16 unsigned pk_f16(float a, float b) {
+#ifdef ZS_SPLIT_RTZ   // A/B measurements of the rounding only (tools/build_variant_lib.py)
     return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+#else
+    unsigned h;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(a), "v"(b));
+    return h;
+#endif
 }
 // two fp32 values -> packed fp16 heads and packed fp16 remainders.  The remainder x - hi comes from
 // one v_fma_mix_f32 per value (fp16 operand read in place from the packed register, exact in fp32):

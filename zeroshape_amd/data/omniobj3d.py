@@ -11,6 +11,8 @@ It is a test-split-only data set in the reference too (`self.get_list(opt, "test
 Reading the real files is not built: there is nothing here to pin it against."""
 from . import synthetic
 
+SYNTHETIC_STANDIN = True     # data/__init__.py: load_by_name's fence
+
 
 class Dataset(synthetic.Dataset):
     cat_names = ["ellipsoid_flat", "ellipsoid_long", "ellipsoid_round"]

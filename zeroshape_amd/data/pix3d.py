@@ -17,6 +17,8 @@ import torch
 
 from . import synthetic
 
+SYNTHETIC_STANDIN = True     # data/__init__.py: load_by_name's fence
+
 FLIP = np.diag([-1.0, -1.0, 1.0])
 
 

@@ -12,6 +12,8 @@ Host-side numpy: this is input synthesis, not part of the measured path."""
 import numpy as np
 import torch
 
+SYNTHETIC_STANDIN = True     # data/__init__.py: load_by_name's fence
+
 
 def _rotation(rs):
     q = rs.randn(4)

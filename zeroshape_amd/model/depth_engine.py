@@ -23,10 +23,9 @@ class Runner(shape_engine.Runner):
 
     def load_dataset(self, opt, eval_split="test", dataset=None, train_dataset=None):
         """:46-68 (datasets without 3-D annotations: load_3D=False)."""
-        import importlib
-        pkg = __name__.rsplit(".", 2)[0] + ".data."
+        from ..data import load_by_name
         if dataset is None:
-            dataset = importlib.import_module(pkg + opt.data.dataset_test).Dataset(opt, split=eval_split, load_3D=False)
+            dataset = load_by_name(opt, opt.data.dataset_test, split=eval_split, load_3D=False)
         self.test_data = dataset
         sampler = None
         if getattr(opt, "world_size", 1) > 1:
@@ -35,8 +34,7 @@ class Runner(shape_engine.Runner):
                                                        sampler=sampler, num_workers=0, drop_last=False)
         if train_dataset is not None or ("batch_size" in opt and "dataset_train" in opt.data and "optim" in opt):
             if train_dataset is None:
-                train_dataset = importlib.import_module(pkg + opt.data.dataset_train).Dataset(opt, split="train",
-                                                                                              load_3D=False)
+                train_dataset = load_by_name(opt, opt.data.dataset_train, split="train", load_3D=False)
             self.load_train_dataset(opt, dataset=train_dataset)
 
     def build_networks(self, opt):

@@ -131,6 +131,15 @@ class Implicit(nn.Module):
         self._workspace = {}      # device -> scratch tensor for the query kernels
         self.last_tile_flags = None   # int32 per 128-point tile of the last split-fp16 query (1 = re-evaluated in fp32)
         self.envelope_guard = True    # False: raw split-fp16 results everywhere (measurements of the arithmetic itself)
+        # Output-error calibration of the default arithmetic (prepare()): once per weight version the raw split
+        # kernel and the exact kernel evaluate the same CALIBRATION_POINTS probe points of the first image seen;
+        # "f16x3" is kept only while max |logit difference| <= CALIBRATION_TOL (a quarter of the 1e-4 contract),
+        # otherwise every later prepare() of these weights returns an fp32 state.  The envelope fences above look
+        # at operands; this one looks at the result.  ZS_DECODER_CALIBRATE=0 / .calibrate = False turns it off.
+        self.calibrate = os.environ.get("ZS_DECODER_CALIBRATE", "1") != "0"
+        self.calibration_range = (-1.5, 1.5)      # probe cube (options/shape.yaml:52 eval.range)
+        self.last_calibration = None  # dict(max_abs_diff, mean_abs_diff, max_abs_logit, points, tol, selected)
+        self._calibration = None      # (weights key, last_calibration)
 
     # ---- init (implicit.py:232-249) -------------------------------------------------
     def initialize_weights(self):
@@ -188,11 +197,62 @@ class Implicit(nn.Module):
             self._workspace[key] = torch.empty(need, dtype=torch.float32, device=device)
         return self._workspace[key]
 
+    CALIBRATION_POINTS = 4096
+    CALIBRATION_TOL = 2.5e-5
+
+    def _probe_points(self, device):
+        """Deterministic probe cloud in the evaluation cube: a scrambled lattice (golden-ratio steps per axis), so
+        every call and every box uses the same 4096 points."""
+        i = torch.arange(self.CALIBRATION_POINTS, dtype=torch.float64)
+        lo, hi = self.calibration_range
+        frac = torch.stack([(i * a + b) % 1.0 for a, b in ((0.7548776662466927, 0.5), (0.5698402909980532, 0.25),
+                                                            (0.4301597090019468, 0.75))], -1)
+        return (lo + (hi - lo) * frac).to(torch.float32)[None].to(device)
+
     @torch.no_grad()
-    def prepare(self, latent_depth, precision=None):
+    def _calibrate(self, split, exact):
+        """max |raw f16x3 logit - fp32 logit| over the probe points of image 0 -> last_calibration (one host read).
+        Cached per weight version: an optimizer step or load_state_dict() triggers the next measurement."""
+        key = self._weights_key()
+        if self._calibration is not None and self._calibration[0] == key:
+            self.last_calibration = self._calibration[1]
+            return self.last_calibration["selected"] == "f16x3"
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("Implicit.prepare: the f16x3 calibration of new weights needs one host read; run one "
+                               "eager prepare() before capturing, or request precision='f32'")
+        pts = self._probe_points(split.device)
+        guard, flags = self.envelope_guard, self.last_tile_flags
+        self.envelope_guard = False                 # the raw arithmetic is what is being measured
+        try:
+            got = self.query_points(DecoderState(split[:1], 1, "f16x3", exact=exact[:1]), pts)
+        finally:
+            self.envelope_guard, self.last_tile_flags = guard, flags
+        want = self.query_points(DecoderState(exact[:1], 1), pts)
+        diff = (got - want).abs()
+        stats = torch.stack([diff.max(), diff.mean(), want.abs().max(),
+                             (torch.sigmoid(got) - torch.sigmoid(want)).abs().max()]).cpu()
+        if not bool(torch.isfinite(stats[2])):
+            # the exact kernel itself is not finite on this image (NaN latent): no verdict on the weights - this
+            # call gets the fp32 state (NaN like the reference), the next image calibrates
+            self.last_calibration = None
+            return False
+        ok = bool(torch.isfinite(stats).all()) and float(stats[0]) <= self.CALIBRATION_TOL
+        self.last_calibration = dict(max_abs_diff=float(stats[0]), mean_abs_diff=float(stats[1]),
+                                     max_abs_logit=float(stats[2]), max_abs_occ_diff=float(stats[3]),
+                                     points=self.CALIBRATION_POINTS, tol=self.CALIBRATION_TOL,
+                                     selected="f16x3" if ok else "f32")
+        self._calibration = (key, self.last_calibration)
+        return ok
+
+    @torch.no_grad()
+    def prepare(self, latent_depth, precision=None, calibrate=None):
         """Per-image prologue: latent_depth [B,197,C] (any float dtype, GPU) -> DecoderState.
-        ``precision``: None = self.precision."""
+        ``precision``: None = self.precision.  "f16x3" is a request: outside the host envelope (W_MAX), or when
+        the calibration of these weights measured more than CALIBRATION_TOL between the two arithmetics, the
+        state returned is an fp32 one (``state.precision`` says which).  ``calibrate``: None = self.calibrate;
+        False returns the split state unchecked (measurements of the arithmetic itself)."""
         precision = self.precision if precision is None else precision
+        calibrate = self.calibrate if calibrate is None else calibrate
         if precision not in ("f32", "f16x3"):
             raise ValueError("decoder precision must be 'f32' or 'f16x3', got %r" % (precision,))
         if not latent_depth.is_cuda:
@@ -218,7 +278,8 @@ class Implicit(nn.Module):
                 rc = lib.zs_sdf_split_programs(_lib.ptr(programs), programs.stride(0) * 4, _lib.ptr(split),
                                                split.stride(0) * 4, B, _lib.current_stream_ptr(lat.device))
             _lib.check(rc, "zs_sdf_split_programs")
-            return DecoderState(split, B, "f16x3", exact=programs)
+            if not calibrate or self._calibrate(split, programs):
+                return DecoderState(split, B, "f16x3", exact=programs)
         return DecoderState(programs, B)
 
     def _tile_flags(self, batch, m, device):

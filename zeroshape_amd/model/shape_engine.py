@@ -39,13 +39,13 @@ class Runner:
 
     def load_dataset(self, opt, eval_split="test", dataset=None, train_dataset=None):
         """:52-81.  Datasets are the modules data.<opt.data.dataset_train|dataset_test> (importlib,
-        like the reference); this repository ships data.synthetic (an analytic stand-in, the real
-        renders live on Dropbox).  `dataset` / `train_dataset` inject Dataset objects directly.
+        like the reference); this repository ships analytic stand-ins under those names (the real files live on
+        Dropbox), handed out only on an explicit opt-in and tagged in every result file (data/__init__.py).
+        `dataset` / `train_dataset` inject Dataset objects directly.
         The train side is loaded when the options describe a training run (batch_size present)."""
-        import importlib
-        pkg = __name__.rsplit(".", 2)[0] + ".data."
+        from ..data import load_by_name
         if dataset is None:
-            dataset = importlib.import_module(pkg + opt.data.dataset_test).Dataset(opt, split=eval_split)
+            dataset = load_by_name(opt, opt.data.dataset_test, split=eval_split)
         self.test_data = dataset
         sampler = None
         if getattr(opt, "world_size", 1) > 1:
@@ -54,7 +54,7 @@ class Runner:
                                                        sampler=sampler, num_workers=0, drop_last=False)
         if train_dataset is not None or ("batch_size" in opt and "dataset_train" in opt.data and "optim" in opt):
             if train_dataset is None:
-                train_dataset = importlib.import_module(pkg + opt.data.dataset_train).Dataset(opt, split="train")
+                train_dataset = load_by_name(opt, opt.data.dataset_train, split="train")
             self.load_train_dataset(opt, dataset=train_dataset)
 
     def setup_visualizer(self, opt, test=False):
@@ -344,8 +344,10 @@ class Runner:
         if rank == 0 and path and not training:
             os.makedirs(path, exist_ok=True)
             name = opt.data.dataset_test
+            tag = getattr(self.test_data, "synthetic_standin", None)       # data/__init__.py: stand-in data says so
+            tag = tag + "\n" if tag else ""
             with open(os.path.join(path, "{}_full_results.txt".format(name)), "w") as f:
-                f.write("IND, CD, ACC, COMP, ")
+                f.write(tag + "IND, CD, ACC, COMP, ")
                 f.write(", ".join("F-score@{:.2f}".format(t * 100) for t in opt.eval.f_thresholds))
                 for i in range(len(ids)):
                     f.write("\n{:d}".format(int(ids[i])))
@@ -353,13 +355,13 @@ class Runner:
                     f.write("\t{:.4f}\t{:.4f}".format(cd_accs[i].item(), cd_comps[i].item()))
                     f.write("\t" + "\t".join("{:.4f}".format(v) for v in f_scores[i].tolist()))
             with open(os.path.join(path, "quantitative_{}.txt".format(name)), "w") as f:
-                f.write("CD     Acc    Comp \n")
+                f.write(tag + "CD     Acc    Comp \n")
                 f.write("%.4f %.4f %.4f\n" % (out["cd"], out["dist_acc"], out["dist_cov"]))
                 for t, v in zip(opt.eval.f_thresholds, out["f_scores"]):
                     f.write("F-score @ %.2f: %.4f\n" % (t * 100, v))
             label2cat = getattr(self.test_data, "label2cat", None)
             with open(os.path.join(path, "cd_cat.txt"), "w") as f:
-                f.write("CD     Acc    Comp   Count Cat\n")
+                f.write(tag + "CD     Acc    Comp   Count Cat\n")
                 for i in torch.unique(cats).tolist():
                     sel = cats == i
                     a, c = cd_accs[sel].mean().item(), cd_comps[sel].mean().item()

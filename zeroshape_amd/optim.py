@@ -99,6 +99,7 @@ class FusedAdamW(torch.optim.Optimizer):
             with _lib.on(cls["device"]):
                 _lib.check(lib.zs_adamw_multi(_lib.ptr(cls["tab_dev"]), _lib.ptr(cls["ct"]), _lib.ptr(cls["cs"]), cls["nchunks"],
                                               betas[0], betas[1], eps, cls["step"], _lib.ptr(self._clip),
+                                              _lib.ptr(self.__dict__.get("_skipped")),
                                               _lib.current_stream_ptr(cls["device"])), "zs_adamw_multi")
         self._clip = None
         A.bump_generation()                   # parameters changed behind torch's version counters
@@ -160,10 +161,19 @@ class FusedAdamW(torch.optim.Optimizer):
         plan = self._plan = dict(ids=tuple(id(p) for _, p in live), classes=classes)
         return plan
 
+    def count_skipped_steps(self, found_inf):
+        """A loss scaler's overflow flag (device scalar, 1.0 = this step() call was skipped): accumulated on the device,
+        subtracted from the call count in the kernel's bias correction and in the `step` values of state_dict()."""
+        if self.__dict__.get("_skipped") is None:
+            self._skipped = torch.zeros((), dtype=torch.int32, device=found_inf.device)
+        self._skipped.add_(found_inf.to(torch.int32))
+
     def _sync_step_tensors(self):
+        skipped = self.__dict__.get("_skipped")
+        skipped = int(skipped) if skipped is not None else 0              # one host read, when the state is saved
         for p, n in self.__dict__.get("_counts", {}).items():
             if p in self.state and "step" in self.state[p]:
-                self.state[p]["step"] = torch.tensor(float(n), dtype=torch.float32)
+                self.state[p]["step"] = torch.tensor(float(max(n - skipped, 0)), dtype=torch.float32)
 
     def state_dict(self):
         self._sync_step_tensors()
@@ -172,6 +182,7 @@ class FusedAdamW(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self.__dict__.pop("_plan", None)       # moments were replaced: new pointers, and the step counts of the file
+        self.__dict__.pop("_skipped", None)    # (the file's counts are applied steps)
         self._counts = {p: int(st["step"]) for p, st in self.state.items() if "step" in st}
 
 
@@ -204,6 +215,7 @@ class LossScaler:
         finite = torch.isfinite(norm)
         self.found_inf.copy_((~finite).float())
         optim._clip = torch.where(finite, mult, torch.zeros_like(mult))      # 0: zs_adamw_multi leaves everything as is
+        optim.count_skipped_steps(self.found_inf)      # before the launch: the kernel's bias correction reads the total
         optim.step()
         torch._amp_update_scale_(self.scale, self.tracker, self.found_inf, self.growth_factor, self.backoff_factor,
                                  self.growth_interval)

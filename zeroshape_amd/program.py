@@ -359,7 +359,7 @@ SCRATCH_FLOATS = LPAD * (3 * C + 3 * C + C + HID + 2 * C)
 # split-fp16 program (csrc/sdf_decoder_split.hip) - host mirror of zs_sdf_split_programs
 # ----------------------------------------------------------------------------- #
 # One K-block (K = 16, three fp16 MFMAs) = two fp32 groups = records 8j..8j+7 of a 32x32 weight
-# unit; per lane [hi: 8 fp16][lo: 8 fp16] with x ~= hi + lo (both rounded toward zero).  Same units and byte size as the fp32
+# unit; per lane [hi: 8 fp16][lo: 8 fp16] with x ~= hi + lo (both rounded to nearest even).  Same units and byte size as the fp32
 # program; the product derives it on the device, this mirror exists for tests and documentation.
 KB_TOTAL = G_TOTAL // 2                 # 4,928 K-blocks per wave tile
 KB_WORDS = 512                          # 32-bit words per K-block (2 x 64 lanes x 16 B)
@@ -395,9 +395,18 @@ def split_source_kblocks(n=None):
     return src
 
 
-def f16_rtz(x):
-    """fp32 -> fp16 rounded toward zero, saturating at +-65504 (v_cvt_pkrtz_f16_f32):
+def f16_round(x):
+    """fp32 -> fp16 rounded to nearest even, overflowing to +-inf from 65520 (v_cvt_pk_f16_f32):
     (uint16 bits, value as fp32)."""
+    x = np.ascontiguousarray(x, np.float32)
+    with np.errstate(over="ignore"):
+        h = x.astype(np.float16)
+    return h.view(np.uint16), h.astype(np.float32)
+
+
+def f16_rtz(x):
+    """fp32 -> fp16 rounded toward zero, saturating at +-65504 (v_cvt_pkrtz_f16_f32) - the rounding of
+    rounds 1-2, kept for the A/B comparison in tests/test_program_packing.py."""
     x = np.ascontiguousarray(x, np.float32)
     with np.errstate(over="ignore"):
         h = x.astype(np.float16)
@@ -413,8 +422,9 @@ def split_program(prog):
     rec = prog[:REC_FLOATS].reshape(-1, 2, 64, 4)                  # [kb][group][lane][j]
     rec = rec[split_source_kblocks(rec.shape[0])]
     vals = rec.transpose(0, 2, 1, 3).reshape(-1, 64, 8)             # [kb][lane][e = 4 g + j]
-    hi16, hif = f16_rtz(vals)
-    lo16, _ = f16_rtz(vals - hif)
+    hi16, hif = f16_round(vals)
+    with np.errstate(invalid="ignore"):
+        lo16, _ = f16_round(vals - hif)
     out = np.stack([hi16, lo16], axis=1)                            # [kb][hi | lo][lane][8]
     words = np.ascontiguousarray(out).reshape(-1).view(np.uint32)
     params = prog[REC_FLOATS:].copy()
