@@ -5,8 +5,12 @@
         --data.dataset_test=synthetic [--load=path/to/shape.ckpt]
 
 Unlike the reference (whose evaluate() asserts a single process, model/shape_engine.py:350) every
-visible GPU takes a shard of the test set; per-sample metrics are gathered before the result files
-are written.
+visible GPU takes part: a shard of the test set each, per-sample metrics gathered before the result
+files are written - or, with --eval.shard_image (automatic when there are more GPUs than test images),
+a share of EVERY image: point ranges of its occupancy grid, one RCCL all-gather, and a share of the pose
+search's rotations (BASELINE config 5: "SDF grid sharded 8-way with RCCL all-gather").
+
+ZS_VIRTUAL_RANKS=N (with ZS_DEVICE_OVERRIDE=0 ZS_DIST_BACKEND=gloo) rehearses the N-rank path on one GPU.
 """
 import importlib
 import os
@@ -24,7 +28,7 @@ from utils.util import is_port_in_use    # noqa: E402
 
 def main_worker(rank, world_size, port, opt):
     opt.device, opt.world_size, opt.port = rank, world_size, port
-    torch.cuda.set_device(rank)
+    torch.cuda.set_device(int(os.environ.get("ZS_DEVICE_OVERRIDE", rank)))
     engine = importlib.import_module('model.{}_engine'.format(os.path.basename(opt.yaml).split('.')[0]))
     evaluator = engine.Runner(opt)
     evaluator.load_dataset(opt)
@@ -42,7 +46,7 @@ def main():
     port = (os.getpid() % 32000) + 32768
     while is_port_in_use(port):
         port += 1
-    world_size = torch.cuda.device_count()
+    world_size = int(os.environ.get("ZS_VIRTUAL_RANKS", torch.cuda.device_count()))
     if world_size == 1:
         main_worker(0, world_size, port, opt)
     else:

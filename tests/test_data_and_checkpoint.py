@@ -141,3 +141,25 @@ def test_pix3d_and_omniobj3d_shaped_items():
     assert np.abs(rot + base["pose_gt"].numpy()[:, 3] - view).max() > 0.1      # ... and only with the flip
     pix.id_filename_mapping(opt, "/tmp/zs_pix3d_map.txt")
     assert len(open("/tmp/zs_pix3d_map.txt").read().strip().split("\n")[0].split(" ")) == 4
+
+
+def test_stand_in_datasets_need_an_opt_in(monkeypatch, capsys):
+    """the data.* modules are analytic stand-ins under the reference's loader names - the engines' way in
+    (data.load_by_name) refuses them without ZS_SYNTHETIC_STANDIN / opt.data.synthetic_standin, warns with it, and the
+    Dataset carries the line that tags every result file."""
+    import pytest
+    from zeroshape_amd import data
+    opt = edict(dict(H=224, W=224, data=dict(pix3d=dict(cat=None), bgcolor=1), training=dict(n_sdf_points=256)))
+    monkeypatch.delenv("ZS_SYNTHETIC_STANDIN", raising=False)
+    for name in ("synthetic", "pix3d", "omniobj3d"):
+        with pytest.raises(RuntimeError, match="analytic stand-in"):
+            data.load_by_name(opt, name, split="test")
+    with pytest.raises(ModuleNotFoundError):
+        data.load_by_name(opt, "ocrtoc", split="test")
+    monkeypatch.setenv("ZS_SYNTHETIC_STANDIN", "1")
+    d = data.load_by_name(opt, "pix3d", split="test")
+    assert "SYNTHETIC STAND-IN" in capsys.readouterr().err
+    assert d.synthetic_standin.startswith("# SYNTHETIC STAND-IN DATA") and "pix3d" in d.synthetic_standin
+    monkeypatch.delenv("ZS_SYNTHETIC_STANDIN")
+    opt.data.synthetic_standin = True
+    assert "omniobj3d" in data.load_by_name(opt, "omniobj3d", split="test").synthetic_standin

@@ -36,11 +36,13 @@ def test_runner_evaluate_end_to_end(tmp_path, encoder_sd, seeded_sd):
     assert set(out) == {"cd", "dist_acc", "dist_cov", "f_scores"} and len(out["f_scores"]) == 6
     assert np.isfinite([out["cd"], out["dist_acc"], out["dist_cov"]]).all() and out["cd"] > 0
     lines = open(os.path.join(str(tmp_path), "synthetic_full_results.txt")).read().split("\n")
+    assert lines[0].startswith("# SYNTHETIC STAND-IN DATA")      # stand-in data says so on top of every result file
+    lines = lines[1:]
     assert lines[0].startswith("IND, CD, ACC, COMP, F-score@0.50") and len(lines) == 4
     assert [int(l.split("\t")[0]) for l in lines[1:]] == [0, 1, 2]
     per = np.array([[float(x) for x in l.split("\t")[1:4]] for l in lines[1:]])
     assert abs(per[:, 1].mean() - out["dist_acc"]) < 1e-3 and abs(per[:, 2].mean() - out["dist_cov"]) < 1e-3
-    q = open(os.path.join(str(tmp_path), "quantitative_synthetic.txt")).read().split("\n")
+    q = open(os.path.join(str(tmp_path), "quantitative_synthetic.txt")).read().split("\n")[1:]
     assert q[0].startswith("CD     Acc    Comp") and q[2].startswith("F-score @ 0.50:")
     assert "ellipsoid" in open(os.path.join(str(tmp_path), "cd_cat.txt")).read()
     # same numbers from the hand-written loop evaluate.py's users would write

@@ -136,3 +136,53 @@ def test_gather_sample_rows_single_process():
     vals = torch.tensor([[20.], [0.], [10.], [11.]])
     out_ids, (out,) = parallel.gather_sample_rows(ids, [vals])
     assert out_ids.tolist() == [0, 1, 2] and out[:, 0].tolist() == [0., 10., 20.]   # first occurrence kept
+
+
+def _records_worker(rank, world, initfile):
+    """Device-side record reduce of the sharded pose search (parallel.reduce_best_records): 16-float records, index
+    as int32 bits, interleaved shares order[r::W] of a sorted sphere; cross-rank ties, NaN records and an empty
+    share (more ranks than rotations) included."""
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    try:
+        n_rot = 6912
+        rs = np.random.RandomState(3)
+        cds = rs.rand(n_rot).astype(np.float32)
+        cds[[4000, 77, 6000]] = np.float32(-1.0)       # tie over (most likely) different ranks: index 77 must win
+        order = np.argsort(rs.rand(n_rot), kind="stable")          # the bound-sorted order every rank derives
+        for case, mine in (("interleaved", order[rank::world]), ("empty", order[:1] if rank == 0 else order[:0])):
+            rec = torch.zeros(16)
+            rec[0], rec[12] = float("inf"), float("inf")
+            rec[1:2] = torch.tensor([0x7fffffff], dtype=torch.int32).view(torch.float32)
+            if len(mine):
+                loc = cds[mine]
+                j = np.lexsort((mine, loc))[0]
+                rec[0] = float(loc[j])
+                rec[1:2] = torch.tensor([int(mine[j])], dtype=torch.int32).view(torch.float32)
+                rec[2:10] = torch.arange(8) + float(mine[j])           # payload tagged with the winner's index
+            rec[10:12] = torch.tensor([len(mine), rank + 1], dtype=torch.int32).view(torch.float32)
+            out = parallel.reduce_best_records(rec)
+            idx = int(out[1:2].view(torch.int32))
+            want = 77 if case == "interleaved" else int(order[0])
+            assert idx == want and float(out[0]) == float(cds[want]) and float(out[2]) == float(want), (case, rank, idx)
+            counters = out[10:12].view(torch.int32).tolist()
+            total = n_rot if case == "interleaved" else 1
+            assert counters == [total, world * (world + 1) // 2]
+        # a NaN record never wins (`cd < best_cd`, utils/eval_3D.py:162)
+        rec = torch.zeros(16)
+        rec[0] = float("nan") if rank == 0 else 0.5 + rank
+        rec[1:2] = torch.tensor([rank], dtype=torch.int32).view(torch.float32)
+        out = parallel.reduce_best_records(rec)
+        assert int(out[1:2].view(torch.int32)) == 1 and float(out[0]) == 1.5
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_reduce_best_records(world):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_records_worker, args=(world, os.path.join(d, "init")), nprocs=world, join=True)
+
+
+def test_reduce_best_records_single_process_passthrough():
+    rec = torch.arange(16, dtype=torch.float32)
+    assert parallel.reduce_best_records(rec) is rec

@@ -37,7 +37,8 @@ constexpr int PS_TILE = 1024;                 // candidates per LDS tile
 constexpr int PS_STRIDE = PS_TILE + 4;
 constexpr int PS_STAT = 16;                   // floats per rotation: R[9], mean[3], denom, pad
 constexpr int PS_PART = 8;                    // per workgroup: sum sqrt(d), 6 counts, pad
-constexpr int PS_BEST = 16;                   // cd, index (int bits), acc, comp, f[6], evaluated (int), pad
+constexpr int PS_BEST = 16;                   // cd, index (int bits), acc, comp, f[6], evaluated, scanned (ints),
+                                              // [12] external bound: the best cd another rank has already found
 
 struct Xform {  // normalize_pc(R p): ((R p) - mean) / denom
     float r[9], mu[3], den;
@@ -62,8 +63,12 @@ struct Xform {  // normalize_pc(R p): ((R p) - mean) / denom
 
 // the batch cannot beat the running best (margin: the roundings of the bound and of the exact path;
 // zeroshape_amd/utils/eval_3D.py)
+// best[12] (+inf unless a multi-GPU search stored the other ranks' best there, zeroshape_amd/utils/eval_3D.py) tightens
+// every pruning decision: a rotation strictly worse than ANY rank's best cannot be the global lexicographic minimum.
+// It never enters the record this rank reports (pose_finish_kernel compares with best[0] alone).
+__device__ __forceinline__ float prune_bound(const float *best) { return fminf(best[0], best[12]); }
 __device__ __forceinline__ bool batch_pruned(const float *lower_bound, const float *best) {
-    return lower_bound && lower_bound[0] * (1.0f - 1e-3f) - 1e-6f > best[0];
+    return lower_bound && lower_bound[0] * (1.0f - 1e-3f) - 1e-6f > prune_bound(best);
 }
 
 template <typename T>
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(PS_THREADS) void pose_kill_kernel(const float *__re
     float s[2] = {0.f, 0.f};
     for (int dir = 0; dir < 2; dir++)
         for (int b = 0; b < min(done, nb[dir]); b++) s[dir] += partial[(((size_t)rot * 2 + dir) * blocks_x + b) * PS_PART];
-    const float bst = best[0];
+    const float bst = prune_bound(best);
     if ((s[0] / (float)n + s[1] / (float)m) / 2.f > bst) dead[rot] = 1;
 }
 
@@ -506,6 +511,7 @@ extern "C" int zs_pose_best_init(float *best, void *stream) {
     float h[PS_BEST];
     for (int i = 0; i < PS_BEST; i++) h[i] = 0.f;
     h[0] = INFINITY;
+    h[12] = INFINITY;
     const int big = 0x7fffffff;
     __builtin_memcpy(&h[1], &big, 4);
     // (pageable host source: the copy is staged before the call returns)

@@ -5,12 +5,11 @@ Every module here is an ANALYTIC STAND-IN registered under the name of one of th
 exist so the engines and entry scripts run on a box without the (Dropbox-hosted) data; their scores are not
 benchmark numbers.  ``load_by_name`` - the engines' way in - therefore refuses to hand one out unless the caller
 opted in (``ZS_SYNTHETIC_STANDIN=1`` in the environment or ``opt.data.synthetic_standin``), warns when it does,
-and marks the Dataset so the engines tag every result file they write (``STANDIN_TAG``)."""
+and the Dataset objects carry ``synthetic_standin``, the line the engines put at the top of every result file."""
 import importlib
 import os
 import sys
 
-STANDIN_TAG = "# SYNTHETIC STAND-IN DATA (analytic ellipsoids under the %s loader's keys) - NOT %s benchmark numbers"
 _REAL_DIRS = {"synthetic": "data/train_data", "pix3d": "data/Pix3D", "omniobj3d": "data/OmniObject3D"}
 
 
@@ -34,7 +33,4 @@ def load_by_name(opt, name, **kwargs):
                 "on the stand-in on purpose; result files are then tagged as synthetic." % (name, name, found))
         print("WARNING: data.%s is a SYNTHETIC STAND-IN (analytic ellipsoids), not %s%s; scores are not benchmark "
               "numbers" % (name, name, found), file=sys.stderr, flush=True)
-    dataset = module.Dataset(opt, **kwargs)
-    if getattr(module, "SYNTHETIC_STANDIN", False):
-        dataset.synthetic_standin = STANDIN_TAG % (name, name)
-    return dataset
+    return module.Dataset(opt, **kwargs)

@@ -28,6 +28,13 @@ class Dataset(torch.utils.data.Dataset):
     label2cat = ["ellipsoid"]
     cat2label = {"ellipsoid": 0}
 
+    @property
+    def synthetic_standin(self):
+        """First line of every result file an engine writes from this data (model/shape_engine.py: evaluate)."""
+        name = type(self).__module__.rsplit(".", 1)[-1]
+        return ("# SYNTHETIC STAND-IN DATA (analytic ellipsoids under the %s loader's keys) - NOT %s benchmark numbers"
+                % (name, name))
+
     def __init__(self, opt, split="test", n_items=None, load_3D=True, n_points=16384, seed=0):
         super().__init__()
         import os

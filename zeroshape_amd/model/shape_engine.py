@@ -33,6 +33,7 @@ class Runner:
         if world > 1:
             if "port" in opt and isinstance(opt.device, int):             # launched like train.py:14-16 does
                 util.setup(opt.device, world, opt.port)                    # :32
+                opt.device = int(os.environ.get("ZS_DEVICE_OVERRIDE", opt.device))   # (one-GPU rehearsal of N ranks)
             if "batch_size" in opt and not getattr(opt, "_batch_divided", False):
                 opt.batch_size = opt.batch_size // world                  # :33
                 opt._batch_divided = True
@@ -48,7 +49,14 @@ class Runner:
             dataset = load_by_name(opt, opt.data.dataset_test, split=eval_split)
         self.test_data = dataset
         sampler = None
-        if getattr(opt, "world_size", 1) > 1:
+        world = getattr(opt, "world_size", 1) or 1
+        # eval.shard_image (not in the reference; SURVEY.md section 8e, BASELINE config 5): the ranks share every test
+        # image - point ranges of its grid, rotations of its pose search - instead of taking different images.
+        # Unset = auto: on when there are more ranks than test images (a DistributedSampler would pad the shards
+        # with duplicates and most GPUs would repeat each other's work).
+        shard = opt.eval.get("shard_image", None) if hasattr(opt.eval, "get") else getattr(opt.eval, "shard_image", None)
+        opt.eval.shard_image = world > 1 and (world > len(self.test_data) if shard is None else bool(shard))
+        if world > 1 and not opt.eval.shard_image:
             sampler = torch.utils.data.distributed.DistributedSampler(self.test_data, shuffle=False, drop_last=False)
         self.test_loader = torch.utils.data.DataLoader(self.test_data, batch_size=opt.eval.batch_size, shuffle=False,
                                                        sampler=sampler, num_workers=0, drop_last=False)
@@ -334,8 +342,9 @@ class Runner:
         cd_accs, cd_comps, f_scores = torch.cat(cd_accs), torch.cat(cd_comps), torch.cat(f_scores)
         cats, ids = torch.cat(cats).long(), torch.cat(ids).long()
         from .. import parallel
-        ids, (cd_accs, cd_comps, f_scores, cats) = parallel.gather_sample_rows(   # :414-432
-            ids, [cd_accs, cd_comps, f_scores, cats])
+        if not getattr(opt.eval, "shard_image", False):     # (image sharding: every rank already holds every row)
+            ids, (cd_accs, cd_comps, f_scores, cats) = parallel.gather_sample_rows(   # :414-432
+                ids, [cd_accs, cd_comps, f_scores, cats])
         assert cd_accs.shape[0] == len(self.test_data)
         out = dict(dist_acc=cd_accs.mean().item(), dist_cov=cd_comps.mean().item(),
                    f_scores=f_scores.mean(0).tolist())

@@ -137,6 +137,28 @@ def reduce_best_rotation(local_cd, local_idx, payload, group=None):
     return out[best, 2:].to(payload.dtype).reshape(payload.shape), float(cds[best]), int(idxs[best])
 
 
+def reduce_best_records(best, group=None):
+    """Device-side form of reduce_best_rotation for the fused pose search's 16-float record (csrc/pose_search.hip:
+    [0] cd, [1] rotation index as int32 bits, [2:10] acc, comp, fscore[6], [10], [11] int32 counters): ONE
+    all_gather_into_tensor, then the lexicographic (cd, index) minimum picked with tensor ops - no host read, so the
+    caller's launches stay asynchronous.  Returns the winning record with the two counters summed over the ranks."""
+    rank, W = world(group)
+    if W == 1:
+        return best
+    out = best.new_empty((W, best.numel()))
+    dist.all_gather_into_tensor(out.view(-1), best.contiguous(), group=group)
+    cds = out[:, 0]
+    idx = out[:, 1].contiguous().view(torch.int32).to(torch.int64)
+    cds = torch.where(torch.isnan(cds), torch.full_like(cds, float("inf")), cds)      # NaN never wins (`cd < best`, :162)
+    tied = cds == cds.min()
+    big = torch.iinfo(torch.int64).max
+    winner = torch.argmin(torch.where(tied, idx, torch.full_like(idx, big)))
+    rec = out.index_select(0, winner.view(1))[0].clone()
+    counters = out[:, 10:12].contiguous().view(torch.int32).sum(0, dtype=torch.int32)
+    rec[10:12] = counters.view(torch.float32)
+    return rec
+
+
 def gather_sample_rows(ids, tensors, group=None):
     """Dataset-sharded evaluation (model/shape_engine.py:414-432): every rank holds the metric
     rows of its samples (ids [n_r] int64, each tensor [n_r, ...]).  Returns (ids, tensors) of ALL

@@ -53,6 +53,20 @@ def get_dense_3D_grid(opt, var, N=None):
     return points_3D
 
 
+def image_sharding(opt):
+    """(rank, world) of the per-image sharding of SURVEY.md section 8e - the grid's point ranges and the pose
+    search's rotations split over the ranks of ONE image - or None: on when ``opt.eval.shard_image`` is set (the
+    engine resolves its "auto" default: more ranks than test images, model/shape_engine.py) and a process group of more
+    than one rank exists."""
+    from .. import parallel
+    try:
+        on = bool(opt.eval.shard_image)
+    except (AttributeError, KeyError):
+        on = False
+    rank, world = parallel.world()
+    return (rank, world) if on and world > 1 else None
+
+
 @torch.no_grad()
 def compute_level_grid(opt, impl_network, latent_depth, latent_semantic, points_3D, images,
                        vis_attn=False):
@@ -74,6 +88,15 @@ def compute_level_grid(opt, impl_network, latent_depth, latent_semantic, points_
         info = None            # modified in place since get_dense_3D_grid made it: read the points
     if info is not None and hasattr(impl_network, "query_grid") and not vis_attn \
             and latent_semantic is None:
+        if image_sharding(opt) is not None:
+            # every rank holds the same images (and ran the same prologue); rank r evaluates its tile-aligned
+            # point range of every image and ONE all_gather_into_tensor rebuilds the grids everywhere
+            from .. import parallel
+            state = impl_network.prepare(latent_depth)
+            occ = parallel.sharded_level_grid_points(
+                lambda b, e: impl_network.query_grid_range(latent_depth, info.axis, b, e, apply_sigmoid=True,
+                                                           state=state), N)
+            return occ, None
         occ = impl_network.query_grid(latent_depth, info.axis, apply_sigmoid=True)
         return occ, None
 
@@ -230,7 +253,7 @@ def _rotation_sphere(device):
 @torch.no_grad()
 def brute_force_search(pc_pred, pc_gt, f_thresholds=[0.005, 0.01, 0.02, 0.05, 0.1, 0.2], device="cuda",
                        rotations=None, rot_slice=None, return_index=False, batch_size=192, prune=True, nn=None,
-                       first_batch=None):
+                       first_batch=None, rot_shard=None, group=None):
     """utils/eval_3D.py:140-170: best rigid alignment over the 6912-rotation sphere by
     Chamfer-L1, with the reference's first-strict-minimum rule (:161-168).
 
@@ -250,9 +273,15 @@ def brute_force_search(pc_pred, pc_gt, f_thresholds=[0.005, 0.01, 0.02, 0.05, 0.
     already lie on each other (the Chamfer call of the final metrics), but most of the 6,912 rotations do NOT, their
     queries walk many rings, and the whole search is slower: 1,139 vs 154 ms exhaustive, 13.7 vs 11.1 ms pruned at
     10k x 10k points - hence opt-in.
-    ``rot_slice=(start, stop)`` restricts the scan to a contiguous index range (multi-GPU
-    sharding, zeroshape_amd/parallel.py); ``return_index`` appends the winning global rotation
-    index and its cd (one host read of the 64-byte record)."""
+    ``rot_slice=(start, stop)`` restricts the scan to a contiguous index range; ``return_index`` appends the
+    winning global rotation index and its cd (one host read of the 64-byte record).
+    ``rot_shard=(rank, world)`` is the multi-GPU form (every rank of ``group`` calls with the
+    same clouds): every rank bounds and sorts the whole sphere (1 ms, identical on all of them), rank r takes
+    positions r, r + W, ... of that order - equal shares of promising and hopeless rotations - and after its first
+    batch the ranks exchange their best distance (ONE 4-byte all-reduce MIN on the stream, no host read) so every
+    later batch is pruned against the GLOBAL best; at the end the 64-byte records are all-gathered and the
+    lexicographic (cd, index) minimum taken on the device - the same record, bit for bit, as the single-rank scan
+    (a rotation's record does not depend on the batch it was evaluated in)."""
     from .. import _lib
     lib = _lib.load()
     if len(f_thresholds) > 6:
@@ -269,19 +298,26 @@ def brute_force_search(pc_pred, pc_gt, f_thresholds=[0.005, 0.01, 0.02, 0.05, 0.
     K = stop - start
     n, m = pred.shape[0], pc_gt.shape[1]
     order = lb_sorted = None
-    if prune and K > batch_size:
+    if prune and (K > batch_size or rot_shard is not None):
         lb = _bf_lower_bounds(pred, pc_gt[0], rotations[start:stop])
         lb_sorted, order = torch.sort(lb, stable=True)
         order = order.to(torch.int32)
+    if rot_shard is not None:
+        srank, sworld = rot_shard
+        if order is None:
+            order = torch.arange(K, dtype=torch.int32, device=dev)
+        order = order[srank::sworld].contiguous()
+        lb_sorted = lb_sorted[srank::sworld].contiguous() if lb_sorted is not None else None
+        K = int(order.numel())
     thr = _threshold_tensor(f_thresholds, dev, pad_to=6)
     best = torch.empty(lib.zs_pose_best_bytes() // 4, dtype=torch.float32, device=dev)
-    scratch = torch.empty(lib.zs_pose_scratch_bytes(n, m, min(batch_size, K)) // 4, dtype=torch.float32, device=dev)
+    scratch = torch.empty(lib.zs_pose_scratch_bytes(n, m, max(1, min(batch_size, K))) // 4, dtype=torch.float32, device=dev)
     nn = (nn or os.environ.get("ZS_POSE_NN", "brute")).lower()
     if nn not in ("grid", "brute"):
         raise ValueError("nn must be 'grid' or 'brute', got %r" % (nn,))
     grids = None
     if nn == "grid":
-        grids = torch.empty(lib.zs_pose_grid_bytes(n, m, min(batch_size, K)) // 4, dtype=torch.float32, device=dev)
+        grids = torch.empty(lib.zs_pose_grid_bytes(n, m, max(1, min(batch_size, K))) // 4, dtype=torch.float32, device=dev)
     st = _lib.current_stream_ptr(dev)
     rot_base = rotations.data_ptr() + 36 * start
 
@@ -301,12 +337,19 @@ def brute_force_search(pc_pred, pc_gt, f_thresholds=[0.005, 0.01, 0.02, 0.05, 0.
         while pos < K:
             starts.append((pos, min(first_batch if pos == 0 else batch_size, K - pos)))
             pos += starts[-1][1]
-        for pos, count in starts:
+        for bi, (pos, count) in enumerate(starts):
             if order is not None:      # rotation b of the batch = rotations[start + order[pos + b]]
-                rc = launch(rot_base, order.data_ptr() + 4 * pos, count, start, lb_sorted.data_ptr() + 4 * pos)
+                rc = launch(rot_base, order.data_ptr() + 4 * pos, count, start,
+                            lb_sorted.data_ptr() + 4 * pos if lb_sorted is not None else None)
             else:                      # index order
                 rc = launch(rot_base + 36 * pos, None, count, start + pos, None)
             _lib.check(rc, "zs_pose_search_batch")
+            if rot_shard is not None and bi == 0:
+                _share_running_best(best, group)
+        if rot_shard is not None:
+            if K == 0:                 # more ranks than rotations: this rank reports the neutral record
+                _share_running_best(best, group)
+            best = _reduce_best_records(best, group)
         ibest = best.view(torch.int32)
         best_pred = torch.empty(n, 3, dtype=torch.float32, device=dev)
         rc = lib.zs_pose_apply(_lib.ptr(pred), n, _lib.ptr(rotations), ibest.data_ptr() + 4, _lib.ptr(best_pred),
@@ -321,6 +364,22 @@ def brute_force_search(pc_pred, pc_gt, f_thresholds=[0.005, 0.01, 0.02, 0.05, 0.
         brute_force_search.last_scanned = int(irec[11])          # ... of which scanned in full (not killed by the probe)
         out = out + (int(irec[1]), float(rec[0]))
     return out
+
+
+def _share_running_best(best, group=None):
+    """best[12] <- min over the ranks of best[0] (csrc/pose_search.hip: prune_bound).  Stream-ordered, no host read."""
+    import torch.distributed as dist
+    bound = best[0:1].clone()
+    dist.all_reduce(bound, op=dist.ReduceOp.MIN, group=group)
+    best[12:13].copy_(bound)
+
+
+def _reduce_best_records(best, group=None):
+    """The ranks' 64-byte records all-gathered; returns the record of the lexicographic (cd, rotation index) minimum
+    - the first strict minimum of the sequential scan (utils/eval_3D.py:161-168) - with the evaluated / scanned
+    counters summed over the ranks.  Device-side throughout."""
+    from .. import parallel
+    return parallel.reduce_best_records(best, group)
 
 
 def _surface_clouds(opt, level_vox, seed=0):
@@ -384,9 +443,10 @@ def eval_metrics_BF(opt, var, impl_network, vis_only=False):
     if vis_only:
         return
     cd_acc, cd_comp, f_score = [], [], []
+    shard = image_sharding(opt)
     for i in range(batch_size):
         best_acc, best_comp, best_fscore, best_pred, best_gt = \
-            brute_force_search(var.dpc_pred[i], var.dpc.points[i], opt.eval.f_thresholds, opt.device)
+            brute_force_search(var.dpc_pred[i], var.dpc.points[i], opt.eval.f_thresholds, opt.device, rot_shard=shard)
         var.dpc_pred[i] = best_pred.clone()
         var.dpc.points[i] = best_gt.clone()
         cd_acc.append(best_acc)

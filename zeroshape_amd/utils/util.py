@@ -150,8 +150,10 @@ def setup(rank, world_size, port_no):
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', str(port_no))
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    torch.cuda.set_device(rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world_size)
+    # ZS_DEVICE_OVERRIDE / ZS_DIST_BACKEND exist only to rehearse the multi-rank code paths on a single-GPU box
+    # (all ranks on one device, gloo instead of RCCL; evaluate.py: ZS_VIRTUAL_RANKS)
+    torch.cuda.set_device(int(os.environ.get("ZS_DEVICE_OVERRIDE", rank)))
+    dist.init_process_group(os.environ.get("ZS_DIST_BACKEND", "nccl"), rank=rank, world_size=world_size)
 
 
 def cleanup():
