@@ -23,6 +23,7 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("ZS_SYNTHETIC_STANDIN", "1")   # this example runs on the analytic stand-in data on purpose
 import numpy as np
 import torch
 import torch.distributed as dist
