@@ -214,7 +214,9 @@ int zs_bf_lower_bounds(const float *pred, int n, const float *gt_normalized, int
  * arithmetic of zs_chamfer_forward, sqrt, means, the six F-score thresholds - and merges the
  * lexicographic (Chamfer-L1, rotation index) minimum into the running record `best`
  * (zs_pose_best_bytes(), device; zs_pose_best_init first): float cd, int32 index, float acc,
- * comp, f[6], int32 rotations evaluated.  That minimum over all batches is the reference's first
+ * comp, f[6], int32 rotations evaluated, int32 rotations scanned in full, float external bound (slot 12: +inf,
+ * or the best distance other ranks have found - it tightens every pruning decision of later batches and never
+ * enters the record; zeroshape_amd/utils/eval_3D.py shares it once per search).  That minimum over all batches is the reference's first
  * strict minimum (:161-168).  Rotation b of the batch is rotations[order ? order[b] : b]
  * ([..][3][3]); its reported index is that number + index_offset.  lower_bound (optional,
  * device): one float, the smallest zs_bf_lower_bounds value in this batch - when it proves the
@@ -240,9 +242,39 @@ int zs_pose_search_batch(const float *pred, int n, const float *gt_normalized, i
  * bit-identical records (a skipped candidate provably has a strictly larger distance; sums formed in the same order). */
 size_t zs_pose_grid_bytes(int n, int m, int count);
 int zs_pose_gt_grid(const float *gt_normalized, int m, void *grids, void *stream);
+/* pred_stats (may be NULL = pred): the prediction in the order its mean is summed in (see zs_pose_search_batch_sorted). */
 int zs_pose_search_batch_grid(const float *pred, int n, const float *gt_normalized, int m, const float *rotations,
                               const int *order, int count, int index_offset, const float *lower_bound,
-                              const float *thresholds6, float *best, void *scratch, void *grids, void *stream);
+                              const float *thresholds6, float *best, void *scratch, void *grids, const float *pred_stats,
+                              void *stream);
+/* Box-culled scan (round 3, the default of brute_force_search).  zs_morton_sort orders a cloud along the Z-order curve
+ * of its bounding box (30-bit keys, stable radix sort: the permutation is a pure function of the coordinates); perm
+ * (may be NULL) receives sorted[i] = points[perm[i]], tile_boxes (may be NULL) the boxes lo[3], hi[3] of every `tile`
+ * consecutive sorted points.  scratch: zs_morton_scratch_bytes(n).
+ * zs_pose_pack writes a sorted cloud as a PACK (zs_pose_pack_bytes(points)): [sub-tile of 64][x | y | z][64]
+ * coordinates, the exact box of every sub-tile and of every tile of 16 - the form in which a wave reads candidates
+ * through the scalar cache.  zs_pose_search_batch_sorted is zs_pose_search_batch on such clouds: statistics from `pred`
+ * in the caller's order - the order zs_pose_apply sees - nearest neighbours from the sorted ones.  mode 0: the all-pairs
+ * kernel of zs_pose_search_batch (gt_sorted; gt_pack unused); mode 1: all pairs on packs; mode 2: every (query,
+ * 64 candidates) block whose box is farther than the query's current nearest neighbour is skipped, tiles nearest first.
+ * All three give the same minima and the same fixed-order sums - the same record, bit for bit; mode 2 from a fraction of
+ * the distance evaluations (utils/eval_3D.py:140-170 evaluates them all).
+ * scratch: zs_pose_sorted_scratch_bytes(n, m, count) (one pack of the prediction per rotation of the batch). */
+size_t zs_morton_scratch_bytes(int n);
+int zs_morton_sort(const float *points, int n, float *sorted, int *perm, float *tile_boxes, int tile, void *scratch,
+                   void *stream);
+/* Sort-tile-recursive order (x slabs, y strips inside a slab, z inside a strip; cuts at whole leaves of 64 points, three
+ * stable radix sorts): leaves with near-cubic boxes - the default order of the pose search, which then evaluates about
+ * half the pairs it needs with the Z-order.  scratch: zs_str_scratch_bytes(n); perm may be NULL. */
+size_t zs_str_scratch_bytes(int n);
+int zs_str_sort(const float *points, int n, float *sorted, int *perm, void *scratch, void *stream);
+size_t zs_pose_pack_bytes(int points);
+int zs_pose_pack(const float *sorted_points, int points, float *pack, void *stream);
+size_t zs_pose_sorted_scratch_bytes(int n, int m, int count);
+int zs_pose_search_batch_sorted(const float *pred, const float *pred_sorted, int n, const float *gt_sorted,
+                                const float *gt_pack, int m, const float *rotations, const int *order, int count,
+                                int index_offset, const float *lower_bound, const float *thresholds6, float *best,
+                                void *scratch, int mode, void *stream);
 int zs_pose_apply(const float *pred, int n, const float *rotations, const int *index, float *out,
                   void *scratch, void *stream);
 int zs_normalize_pc(const float *pc, int b, int n, float *out, void *scratch, void *stream);

@@ -287,12 +287,136 @@ def test_grid_pose_search_equals_the_pairwise_scan(shape, n, m):
     sl = (4000, 4700)
     for prune in (False, True):
         for bs in (192, 50):
-            a = E.brute_force_search(pred, gt, device="cuda", rotations=R, rot_slice=sl, return_index=True, prune=prune,
-                                     batch_size=bs, nn="grid")
-            ea = E.brute_force_search.last_evaluated
             b = E.brute_force_search(pred, gt, device="cuda", rotations=R, rot_slice=sl, return_index=True, prune=prune,
                                      batch_size=bs, nn="brute")
-            assert ea == E.brute_force_search.last_evaluated
-            assert a[5] == b[5] and a[6] == b[6], (shape, prune, bs, a[5], b[5], a[6], b[6])
-            for x, y in zip(a[:5], b[:5]):
-                assert torch.equal(x, y), (shape, prune, bs)
+            eb = E.brute_force_search.last_evaluated
+            for nn in ("grid", "cull", "pairs"):   # the box-culled scan (the default) against the same all-pairs scan
+                a = E.brute_force_search(pred, gt, device="cuda", rotations=R, rot_slice=sl, return_index=True, prune=prune,
+                                         batch_size=bs, nn=nn)
+                assert eb == E.brute_force_search.last_evaluated
+                assert a[5] == b[5] and a[6] == b[6], (shape, nn, prune, bs, a[5], b[5], a[6], b[6])
+                for x, y in zip(a[:5], b[:5]):
+                    assert torch.equal(x, y), (shape, nn, prune, bs)
+
+
+def test_morton_sort_is_a_stable_permutation_with_tile_boxes():
+    """zs_morton_sort: a permutation of the cloud ordered by the 30-bit Z-order key of its bounding box (stable: equal
+    keys keep their order, so the result is a pure function of the coordinates), non-finite points last, and the exact
+    box of every tile of consecutive sorted points; consecutive points are close (that is what the culled scan needs)."""
+    from zeroshape_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(4)
+    for n, tile in ((10000, 1024), (1000, 64), (1, 1024), (1500, 1024)):
+        p = rs.uniform(-1, 1, (n, 3)).astype(np.float32) * np.array([1.0, 0.5, 0.25], np.float32)
+        if n >= 1000:
+            p[7] = p[3]                                   # duplicates: equal keys
+            p[11, 1] = np.nan
+            p[13, 0] = np.inf
+        pts = torch.from_numpy(p).cuda()
+        out, perm = torch.empty_like(pts), torch.empty(n, dtype=torch.int32, device="cuda")
+        nt = (n + tile - 1) // tile
+        boxes = torch.empty(nt, 6, device="cuda")
+        scratch = torch.empty(lib.zs_morton_scratch_bytes(n) // 4 + 1, device="cuda")
+        _lib.check(lib.zs_morton_sort(_lib.ptr(pts), n, _lib.ptr(out), _lib.ptr(perm), _lib.ptr(boxes), tile,
+                                      _lib.ptr(scratch), _lib.current_stream_ptr(pts.device)), "zs_morton_sort")
+        perm_h, out_h = perm.cpu().numpy(), out.cpu().numpy()
+        assert sorted(perm_h.tolist()) == list(range(n))
+        assert np.array_equal(out_h, p[perm_h], equal_nan=True)
+        fin = np.isfinite(p).all(1)
+        lo, hi = p[fin].min(0), p[fin].max(0)
+        cell = np.clip(((p - lo) / np.where(hi > lo, hi - lo, 1) * 1024).astype(np.int64), 0, 1023)
+        key = np.zeros(n, np.int64)
+        for b in range(10):
+            for a in range(3):
+                key |= ((cell[:, a] >> b) & 1) << (3 * b + a)
+        key[~fin] = 0x7fffffff
+        want = np.argsort(key, kind="stable")
+        # (the float division may land a point that sits exactly on a cell boundary in the neighbouring cell)
+        assert (perm_h == want).mean() > 0.99 or n < 4
+        assert fin[perm_h][:fin.sum()].all() and not fin[perm_h][fin.sum():].any()
+        for t in range(nt):
+            blk = out_h[t * tile:(t + 1) * tile]
+            blk = np.where(np.isfinite(blk), blk, np.nan)
+            if np.isfinite(blk).any():
+                np.testing.assert_array_equal(boxes[t, :3].cpu().numpy(), np.nanmin(blk, 0))
+                np.testing.assert_array_equal(boxes[t, 3:].cpu().numpy(), np.nanmax(blk, 0))
+        if n == 10000:
+            step = np.linalg.norm(np.diff(out_h[:fin.sum() - 2], axis=0), axis=1)
+            assert np.median(step) < 0.25 * np.median(np.linalg.norm(np.diff(p[fin], axis=0), axis=1))
+        # deterministic: a second call gives the same permutation
+        perm2 = torch.empty_like(perm)
+        _lib.check(lib.zs_morton_sort(_lib.ptr(pts), n, _lib.ptr(out), _lib.ptr(perm2), _lib.ptr(boxes), tile,
+                                      _lib.ptr(scratch), _lib.current_stream_ptr(pts.device)), "zs_morton_sort")
+        assert torch.equal(perm, perm2)
+
+
+def test_str_sort_is_a_permutation_into_compact_leaves():
+    """zs_str_sort (sort-tile-recursive: x slabs, y strips, z inside; three stable sorts): a permutation, reproducible,
+    non-finite points at the end, and leaves of 64 consecutive points with far smaller boxes than the input order - and
+    smaller than the Z-order's, which is why it is the pose search's default."""
+    from zeroshape_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(5)
+
+    def run(fn_sort, p):
+        pts = torch.from_numpy(p).cuda()
+        n = len(p)
+        out, perm = torch.empty_like(pts), torch.empty(n, dtype=torch.int32, device="cuda")
+        if fn_sort == "str":
+            scratch = torch.empty(lib.zs_str_scratch_bytes(n) // 4 + 1, device="cuda")
+            rc = lib.zs_str_sort(_lib.ptr(pts), n, _lib.ptr(out), _lib.ptr(perm), _lib.ptr(scratch), _lib.current_stream_ptr(pts.device))
+        else:
+            scratch = torch.empty(lib.zs_morton_scratch_bytes(n) // 4 + 1, device="cuda")
+            rc = lib.zs_morton_sort(_lib.ptr(pts), n, _lib.ptr(out), _lib.ptr(perm), None, 0, _lib.ptr(scratch),
+                                    _lib.current_stream_ptr(pts.device))
+        _lib.check(rc, "sort")
+        return out.cpu().numpy(), perm.cpu().numpy()
+
+    def leaf_diag(q):
+        q = q[: len(q) // 64 * 64].reshape(-1, 64, 3)
+        return float(np.linalg.norm(q.max(1) - q.min(1), axis=1).mean())
+
+    for n in (10000, 4097, 63, 1):
+        p = syn.ellipsoid_cloud(3, n) if n != 4097 else rs.uniform(-1, 1, (n, 3)).astype(np.float32)
+        if n >= 4097:
+            p[5, 2] = np.nan
+            p[9] = p[2]
+        out, perm = run("str", p)
+        assert sorted(perm.tolist()) == list(range(n)) and np.array_equal(out, p[perm], equal_nan=True)
+        out2, perm2 = run("str", p)
+        assert np.array_equal(perm, perm2)
+        if n >= 4097:
+            assert perm[-1] == 5                      # the non-finite point closes the last leaf
+            fin = np.delete(p, 5, axis=0)
+            mo, _ = run("morton", p)
+            assert leaf_diag(out[:-1]) < 0.35 * leaf_diag(fin) and leaf_diag(out[:-1]) < 0.9 * leaf_diag(mo[:-1])
+
+
+@pytest.mark.parametrize("case", ["far", "aligned", "interior", "ragged"])
+def test_culled_scan_equals_all_pairs_on_10k_points(case):
+    """The benchmark geometries at full size (10k x 10k, a few dozen rotations): the box-culled scan returns the
+    all-pairs record bit for bit where nothing can be pruned ("far": an ellipsoid shell against a uniform cube),
+    where almost everything can ("aligned"), for queries deep inside the other cloud's hull ("interior") and for
+    ragged sizes that leave partial tiles and sub-tiles."""
+    from zeroshape_amd.utils import eval_3D as E
+    R = E._rotation_sphere("cuda")
+    n, m = (10000, 10000) if case != "ragged" else (4097, 1031)
+    pred = torch.from_numpy(syn.ellipsoid_cloud(0, n)).cuda()
+    if case == "far":
+        gt = torch.from_numpy(syn.seeded_cloud(9, 1, m)[0]).cuda()
+    elif case == "interior":
+        gt = torch.from_numpy(syn.seeded_cloud(9, 1, m)[0] * 0.2).cuda()
+    else:
+        g = torch.Generator().manual_seed(0)
+        gt = ((R[1234] @ pred.T).T.contiguous().cpu() + 1e-3 * torch.randn(n, 3, generator=g))[:m].cuda()
+    for sl in ((1200, 1260), (0, 48)):
+        b = E.brute_force_search(pred, gt, device="cuda", rot_slice=sl, return_index=True, prune=False, nn="brute")
+        a = E.brute_force_search(pred, gt, device="cuda", rot_slice=sl, return_index=True, prune=False, nn="cull")
+        assert a[5] == b[5] and a[6] == b[6], (case, sl, a[5], b[5], a[6], b[6])
+        for x, y in zip(a[:5], b[:5]):
+            assert torch.equal(x, y), (case, sl)
+    # every rotation's own record, not only the winner's
+    for k in range(3000, 3012):
+        b = E.brute_force_search(pred, gt, device="cuda", rot_slice=(k, k + 1), return_index=True, prune=False, nn="brute")
+        a = E.brute_force_search(pred, gt, device="cuda", rot_slice=(k, k + 1), return_index=True, prune=False, nn="cull")
+        assert a[6] == b[6] and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), (case, k)

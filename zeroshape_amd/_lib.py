@@ -62,7 +62,17 @@ SIGNATURES = {
     "zs_pose_grid_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "zs_pose_gt_grid": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p]),
     "zs_pose_search_batch_grid": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_int,
-                                           _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+                                           _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "zs_morton_scratch_bytes": (_c_size_t, [_c_int]),
+    "zs_morton_sort": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p]),
+    "zs_str_scratch_bytes": (_c_size_t, [_c_int]),
+    "zs_str_sort": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "zs_pose_pack_bytes": (_c_size_t, [_c_int]),
+    "zs_pose_pack": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p]),
+    "zs_pose_sorted_scratch_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
+    "zs_pose_search_batch_sorted": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p,
+                                             _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                                             _c_int, _c_void_p]),
     "zs_pose_apply": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "zs_normalize_pc": (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "zs_fscore": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p]),

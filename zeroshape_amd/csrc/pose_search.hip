@@ -16,6 +16,11 @@
 //                       staging candidates into LDS (direction 1) - and an epilogue that reduces
 //                       sqrt(d) and the six F-score counters per workgroup in a FIXED order
 //                       (bit-reproducible: the same rotation gives the same bits in any batch).
+//   pose_nn_cull_kernel the same scan over MORTON-SORTED clouds (csrc/morton_sort.hip) that skips the
+//                       (run of 64 queries, sub-tile of 64 candidates) blocks whose bounding boxes are
+//                       farther apart than the worst nearest neighbour the run has found so far, tiles
+//                       visited nearest first: the same minima - a skipped candidate is provably not
+//                       closer - from a fraction of the pairs (round 3; the default).
 //   pose_finish_kernel  per batch: sums the partials in order, acc / comp / cd / F-score per
 //                       rotation, lexicographic (cd, rotation index) winner, merged into the running
 //                       best record on the device.
@@ -264,6 +269,290 @@ __global__ __launch_bounds__(PS_THREADS) void pose_nn_kernel(
         float s = red[threadIdx.x][0];
         for (int w = 1; w < PS_THREADS / 64; w++) s += red[threadIdx.x][w];
         partial[(((size_t)rot * 2 + dir) * blocks_x + bx) * PS_PART + threadIdx.x] = s;
+    }
+}
+
+// ---- the same scan with box culling (round 3) --------------------------------------------- //
+// Both clouds arrive Morton-sorted in their own frames (zs_morton_sort): 64 consecutive points ("sub-tile") are a
+// compact patch, also after the rotation.  pose_pack_kernel writes a cloud - the ground truth once per search, the
+// rotated + normalised prediction once per rotation of the batch - as a PACK:
+//     [sub-tile][x | y | z][64] coordinates (+inf padded)   |   [sub-tile] lo[3], hi[3] exact box   |   [tile of 16] box
+// pose_nn_soa_kernel keeps pose_nn_kernel's grid, query mapping and epilogue, but its four waves walk the candidates
+// independently, without LDS and without barriers:
+//   * a candidate sub-tile is UNIFORM data for the wave: its box and its 192 coordinates come through the scalar
+//     cache into SGPRs (s_load_dwordx8) and enter the distance arithmetic as scalar operands - the role the LDS
+//     broadcast reads play in pose_nn_kernel;
+//   * tiles are visited in order of increasing box distance from the wave's 128 queries, and the walk ends at the
+//     first tile that is farther than every query's current nearest neighbour;
+//   * inside a tile, lane l first measures sub-tile l against the boxes of the wave's two runs of 64 queries; the
+//     sub-tiles that can still matter to a run are taken nearest first, each tested per QUERY - point-to-box distance
+//     against the lane's own running minimum - and scanned only if some lane still needs it.
+// d = fma(dz,dz,fma(dy,dy,dx*dx)) is evaluated exactly as in pose_nn_kernel for every pair that is not skipped, and a
+// skipped candidate has d >= (point-to-box distance)^2 (1 - 8 * 2^-24) > the query's running minimum (PS_SKIP leaves
+// a 16x margin for the roundings of both sides) - so every query ends with the same minimum, bit for bit, and the
+// epilogue sums them in the same fixed order: same record as the all-pairs scan of the same sorted clouds.
+constexpr int PS_SUB = 64;
+constexpr int PS_NSUB = PS_TILE / PS_SUB;            // 16 sub-tiles per tile
+constexpr int PS_SUB_FLOATS = 3 * PS_SUB;
+constexpr float PS_SKIP = 1.0f - 0x1p-20f;
+static_assert(PS_Q == 2 && PS_NSUB == 16, "pose_nn_soa_kernel: two query runs per wave, 16 sub-tiles per tile");
+
+__host__ __device__ inline int pack_subs(int n) { return (n + PS_TILE - 1) / PS_TILE * PS_NSUB; }
+__host__ __device__ inline size_t pack_floats(int n) {
+    const size_t ns = (size_t)pack_subs(n);
+    return ns * PS_SUB_FLOATS + ns * 8 + ns / PS_NSUB * 8;
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_f(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+// wave-wide min / max at VALU speed: quad swaps, half-row and row mirrors, then the four row results (wave-uniform)
+__device__ __forceinline__ float wave_minf(float v) {
+    v = fminf(v, dpp_f<0xB1>(v));
+    v = fminf(v, dpp_f<0x4E>(v));
+    v = fminf(v, dpp_f<0x141>(v));
+    v = fminf(v, dpp_f<0x140>(v));
+    return fminf(fminf(lane_f(v, 0), lane_f(v, 16)), fminf(lane_f(v, 32), lane_f(v, 48)));
+}
+__device__ __forceinline__ float wave_maxf(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    return fmaxf(fmaxf(lane_f(v, 0), lane_f(v, 16)), fmaxf(lane_f(v, 32), lane_f(v, 48)));
+}
+// squared distance between two axis-aligned boxes (0 when they overlap; +inf when one is empty: lo = +inf, hi = -inf)
+__device__ __forceinline__ float box_gap2(const float *alo, const float *ahi, const float *blo, const float *bhi) {
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float g = fmaxf(0.f, fmaxf(alo[a] - bhi[a], blo[a] - ahi[a]));
+        s = fmaf(g, g, s);
+    }
+    return s;
+}
+__device__ __forceinline__ float point_gap2(float x, float y, float z, const float *lo, const float *hi) {
+    const float gx = fmaxf(0.f, fmaxf(lo[0] - x, x - hi[0]));
+    const float gy = fmaxf(0.f, fmaxf(lo[1] - y, y - hi[1]));
+    const float gz = fmaxf(0.f, fmaxf(lo[2] - z, z - hi[2]));
+    return fmaf(gz, gz, fmaf(gy, gy, gx * gx));
+}
+
+// grid (tiles of the cloud, clouds): cloud b = normalize_pc(R_b src) (stats) or src itself (stats == nullptr) -> pack b
+__global__ __launch_bounds__(PS_TILE) void pose_pack_kernel(const float *__restrict__ src, int n,
+                                                            const float *__restrict__ stats, float *__restrict__ packs,
+                                                            size_t pack_stride, const float *__restrict__ lower_bound,
+                                                            const float *__restrict__ best) {
+    if (batch_pruned(lower_bound, best)) return;
+    __shared__ float s_box[PS_NSUB][6];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ns = pack_subs(n), sub = blockIdx.x * PS_NSUB + wave;
+    float *pack = packs + (size_t)blockIdx.y * pack_stride;
+    const int i = sub * PS_SUB + lane;
+    const bool in = i < n;
+    float x = INFINITY, y = INFINITY, z = INFINITY;
+    if (in) {
+        x = src[(size_t)i * 3]; y = src[(size_t)i * 3 + 1]; z = src[(size_t)i * 3 + 2];
+        if (stats) {
+            Xform t;
+            t.load(stats + (size_t)blockIdx.y * PS_STAT);
+            float ox, oy, oz;
+            t.apply(x, y, z, ox, oy, oz);
+            x = ox; y = oy; z = oz;
+        }
+    }
+    float *c = pack + (size_t)sub * PS_SUB_FLOATS;
+    c[lane] = x;
+    c[PS_SUB + lane] = y;
+    c[2 * PS_SUB + lane] = z;
+    // exact box of the finite coordinates (fminf / fmaxf drop NaN; infinities and the padding are masked)
+    const bool fx = in && fabsf(x) < INFINITY, fy = in && fabsf(y) < INFINITY, fz = in && fabsf(z) < INFINITY;
+    const float b[6] = {wave_minf(fx ? x : INFINITY), wave_minf(fy ? y : INFINITY), wave_minf(fz ? z : INFINITY),
+                        wave_maxf(fx ? x : -INFINITY), wave_maxf(fy ? y : -INFINITY), wave_maxf(fz ? z : -INFINITY)};
+    if (lane < 8) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; k++) v = lane == k ? b[k] : v;
+        pack[(size_t)ns * PS_SUB_FLOATS + (size_t)sub * 8 + lane] = v;
+        if (lane < 6) s_box[wave][lane] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        float v = 0.f;
+        if (threadIdx.x < 6) {
+            v = s_box[0][threadIdx.x];
+            for (int w = 1; w < PS_NSUB; w++) v = threadIdx.x < 3 ? fminf(v, s_box[w][threadIdx.x]) : fmaxf(v, s_box[w][threadIdx.x]);
+        }
+        pack[(size_t)ns * (PS_SUB_FLOATS + 8) + (size_t)blockIdx.x * 8 + threadIdx.x] = v;
+    }
+}
+
+// 64 candidates of one sub-tile (uniform address -> scalar loads) against this lane's queries
+template <bool D0, bool D1>
+__device__ __forceinline__ void scan_subtile(const float *__restrict__ c, const float (&qx)[PS_Q], const float (&qy)[PS_Q],
+                                             const float (&qz)[PS_Q], float (&bestd)[PS_Q]) {
+#pragma unroll 2
+    for (int k = 0; k < PS_SUB; k += 8) {
+        float ax[8], ay[8], az[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            ax[e] = c[k + e];
+            ay[e] = c[PS_SUB + k + e];
+            az[e] = c[2 * PS_SUB + k + e];
+        }
+#pragma unroll
+        for (int h = 0; h < 8; h += 4)
+#pragma unroll
+            for (int q = 0; q < PS_Q; q++) {
+                if ((q == 0 && !D0) || (q == 1 && !D1)) continue;
+                float d[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float dx = ax[h + e] - qx[q];
+                    const float dy = ay[h + e] - qy[q];
+                    const float dz = az[h + e] - qz[q];
+                    d[e] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                }
+                bestd[q] = fminf(bestd[q], fminf(fminf(d[0], d[1]), fminf(d[2], d[3])));
+            }
+    }
+}
+
+// grid and partial layout of pose_nn_kernel.  pred_packs: one pack per rotation of the batch (pose_pack_kernel);
+// gt_pack: the ground truth's.  CULL = false scans every sub-tile in index order (the all-pairs scan on packs).
+template <bool CULL>
+__global__ __launch_bounds__(PS_THREADS) void pose_nn_soa_kernel(
+    const float *__restrict__ pred_packs, size_t pack_stride, int n, const float *__restrict__ gt_pack, int m,
+    const float *__restrict__ thresholds, float *__restrict__ partial, const float *__restrict__ lower_bound,
+    const float *__restrict__ best, int x_begin, int blocks_x, const int *__restrict__ dead) {
+    if (batch_pruned(lower_bound, best)) return;
+    __shared__ float red[PS_PART][PS_THREADS / 64];
+    const int dir = blockIdx.z, rot = blockIdx.y, bx = x_begin + blockIdx.x;
+    if (dead && dead[rot]) return;
+    const int nq = dir == 0 ? n : m;      // queries
+    const int nc = dir == 0 ? m : n;      // candidates
+    const int q_base = bx * (PS_THREADS * PS_Q);
+    if (q_base >= nq) return;
+    const float *ppack = pred_packs + (size_t)rot * pack_stride;
+    const float *Q = dir == 0 ? ppack : gt_pack;
+    const float *C = dir == 0 ? gt_pack : ppack;
+    const int ncs = pack_subs(nc);
+    const float *Csub = C + (size_t)ncs * PS_SUB_FLOATS, *Ctile = Csub + (size_t)ncs * 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    float qx[PS_Q], qy[PS_Q], qz[PS_Q], bestd[PS_Q];
+    float rlo[PS_Q][3], rhi[PS_Q][3];       // boxes of this wave's two runs of 64 queries (wave-uniform)
+#pragma unroll
+    for (int q = 0; q < PS_Q; q++) {
+        int j = q_base + q * PS_THREADS + threadIdx.x;
+        j = j < nq ? j : nq - 1;          // (a duplicate of the last query: inside the cloud, harmless for the boxes)
+        const float *src = Q + (size_t)(j >> 6) * PS_SUB_FLOATS + (j & 63);
+        qx[q] = src[0]; qy[q] = src[PS_SUB]; qz[q] = src[2 * PS_SUB];
+        bestd[q] = INFINITY;
+        if (CULL) {
+            rlo[q][0] = wave_minf(qx[q]); rhi[q][0] = wave_maxf(qx[q]);
+            rlo[q][1] = wave_minf(qy[q]); rhi[q][1] = wave_maxf(qy[q]);
+            rlo[q][2] = wave_minf(qz[q]); rhi[q][2] = wave_maxf(qz[q]);
+        }
+    }
+    const int T = ncs / PS_NSUB;
+    if (!CULL || T > 64) {
+        for (int sidx = 0; sidx < ncs; sidx++)
+            scan_subtile<true, true>(C + (size_t)sidx * PS_SUB_FLOATS, qx, qy, qz, bestd);
+    } else {
+        float wlo[3], whi[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            wlo[a] = fminf(rlo[0][a], rlo[1][a]);
+            whi[a] = fmaxf(rhi[0][a], rhi[1][a]);
+        }
+        // lane t holds the distance from the wave's queries to tile t; tiles are taken nearest first
+        float tg = INFINITY;
+        if (lane < T) {
+            float lo[3], hi[3];
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                lo[a] = Ctile[(size_t)lane * 8 + a];
+                hi[a] = Ctile[(size_t)lane * 8 + 3 + a];
+            }
+            tg = box_gap2(wlo, whi, lo, hi);
+        }
+        bool todo = lane < T;
+        float w0 = INFINITY, w1 = INFINITY;
+        for (int ti = 0; ti < T; ti++) {
+            const float nearest = wave_minf(todo ? tg : INFINITY);
+            if (!(nearest * PS_SKIP <= fmaxf(w0, w1))) break;      // ... and every remaining tile is farther still
+            const unsigned long long pick = __ballot(todo && tg == nearest);
+            const int t = __builtin_ctzll(pick);                   // (the lowest index among equals)
+            todo = todo && lane != t;
+            // lane l keeps the box of sub-tile l of this tile and its distance to the wave's two run boxes; the sub-tiles
+            // that can still matter to a run are then taken nearest first (every scan shrinks the running minima and
+            // with them the set of sub-tiles that survive the per-query test), their boxes broadcast with v_readlane
+            float slo[3] = {INFINITY, INFINITY, INFINITY}, shi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            float gm = INFINITY;
+            bool cand = false;
+            if (lane < PS_NSUB) {
+                const float *bsub = Csub + ((size_t)t * PS_NSUB + lane) * 8;
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    slo[a] = bsub[a];
+                    shi[a] = bsub[3 + a];
+                }
+                const float g0 = box_gap2(rlo[0], rhi[0], slo, shi), g1 = box_gap2(rlo[1], rhi[1], slo, shi);
+                cand = g0 * PS_SKIP <= w0 || g1 * PS_SKIP <= w1;
+                gm = fminf(g0, g1);
+            }
+            while (__ballot(cand) != 0ull) {
+                const float near_sub = wave_minf(cand ? gm : INFINITY);
+                const int sl = __builtin_ctzll(__ballot(cand && gm == near_sub));
+                cand = cand && lane != sl;
+                const float lo[3] = {lane_f(slo[0], sl), lane_f(slo[1], sl), lane_f(slo[2], sl)};
+                const float hi[3] = {lane_f(shi[0], sl), lane_f(shi[1], sl), lane_f(shi[2], sl)};
+                const bool d0 = __ballot(point_gap2(qx[0], qy[0], qz[0], lo, hi) * PS_SKIP <= bestd[0]) != 0ull;
+                const bool d1 = __ballot(point_gap2(qx[1], qy[1], qz[1], lo, hi) * PS_SKIP <= bestd[1]) != 0ull;
+                const float *c = C + ((size_t)t * PS_NSUB + sl) * PS_SUB_FLOATS;        // uniform: scalar loads
+                if (d0 && d1)
+                    scan_subtile<true, true>(c, qx, qy, qz, bestd);
+                else if (d0)
+                    scan_subtile<true, false>(c, qx, qy, qz, bestd);
+                else if (d1)
+                    scan_subtile<false, true>(c, qx, qy, qz, bestd);
+            }
+            w0 = wave_maxf(bestd[0]);
+            w1 = wave_maxf(bestd[1]);
+        }
+    }
+    // epilogue: pose_nn_kernel's, statement for statement
+    float v[PS_PART];
+#pragma unroll
+    for (int i = 0; i < PS_PART; i++) v[i] = 0.f;
+    float thr[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) thr[i] = thresholds[i];
+#pragma unroll
+    for (int q = 0; q < PS_Q; q++) {
+        const int j = q_base + q * PS_THREADS + threadIdx.x;
+        if (j < nq) {
+            const float sq = sqrtf(bestd[q]);
+            v[0] += sq;
+#pragma unroll
+            for (int i = 0; i < 6; i++) v[1 + i] += sq < thr[i] ? 1.f : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 7; i++) v[i] = wave_sum(v[i]);
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < 7; i++) red[i][wave] = v[i];
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        float sum = red[threadIdx.x][0];
+        for (int w = 1; w < PS_THREADS / 64; w++) sum += red[threadIdx.x][w];
+        partial[(((size_t)rot * 2 + dir) * blocks_x + bx) * PS_PART + threadIdx.x] = sum;
     }
 }
 
@@ -522,10 +811,13 @@ extern "C" int zs_pose_best_init(float *best, void *stream) {
     return 1;
 }
 
-extern "C" int zs_pose_search_batch(const float *pred, int n, const float *gt_normalized, int m,
-                                    const float *rotations, const int *order, int count, int index_offset,
-                                    const float *lower_bound, const float *thresholds6, float *best,
-                                    void *scratch, void *stream) {
+namespace {
+// pred: the cloud in its caller's order (statistics: the mean's double sum depends on the order, and zs_pose_apply
+// runs on this order); pred_nn / gt_nn: the clouds the scans read (the same, or Morton-sorted).  mode 0: pose_nn_kernel
+// (all pairs, candidates staged in LDS); 1 / 2: pose_nn_soa_kernel on packs, all pairs / box-culled.
+int search_batch(const float *pred, const float *pred_nn, int n, const float *gt_nn, const float *gt_pack, int m, int mode,
+                 const float *rotations, const int *order, int count, int index_offset, const float *lower_bound,
+                 const float *thresholds6, float *best, void *scratch, void *stream) {
     if (n < 0 || m < 0 || count < 0) {
         zs::set_err("zs_pose_search_batch: negative size (n=%d m=%d count=%d)", n, m, count);
         return 0;
@@ -539,8 +831,9 @@ extern "C" int zs_pose_search_batch(const float *pred, int n, const float *gt_no
         zs::set_err("zs_pose_search_batch: %d rotations per batch exceed %d", count, PS_THREADS);
         return 0;
     }
-    if (!pred || !gt_normalized || !rotations || !thresholds6 || !best || !scratch) {
-        zs::set_err("zs_pose_search_batch: null pointer");
+    if (!pred || !pred_nn || !rotations || !thresholds6 || !best || !scratch || (mode == 0 ? !gt_nn : !gt_pack) || mode < 0 ||
+        mode > 2) {
+        zs::set_err("zs_pose_search_batch: null pointer or bad mode");
         return 0;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -558,13 +851,28 @@ extern "C" int zs_pose_search_batch(const float *pred, int n, const float *gt_no
         zs::set_err("zs_pose_search_batch: hipMemsetAsync failed");
         return 0;
     }
+    float *packs = reinterpret_cast<float *>(dead + PS_THREADS);
+    const size_t pstride = pack_floats(n);
+    if (mode != 0)
+        hipLaunchKernelGGL(pose_pack_kernel, dim3(pack_subs(n) / PS_NSUB, count), dim3(PS_TILE), 0, st, pred_nn, n,
+                           static_cast<const float *>(stats), packs, pstride, lower_bound, static_cast<const float *>(best));
     const int stage_end[4] = {1, 3, 7, bx};
     int lo = 0;
     for (int sidx = 0; sidx < 4 && lo < bx; sidx++) {
         const int hi = stage_end[sidx] < bx ? stage_end[sidx] : bx;
         if (hi <= lo) continue;
-        hipLaunchKernelGGL(pose_nn_kernel, dim3(hi - lo, count, 2), dim3(PS_THREADS), 0, st, pred, n, gt_normalized, m,
-                           stats, thresholds6, partial, lower_bound, best, lo, bx, static_cast<const int *>(dead));
+        const dim3 grid(hi - lo, count, 2);
+        if (mode == 2)
+            hipLaunchKernelGGL(pose_nn_soa_kernel<true>, grid, dim3(PS_THREADS), 0, st, static_cast<const float *>(packs), pstride,
+                               n, gt_pack, m, thresholds6, partial, lower_bound, static_cast<const float *>(best), lo, bx,
+                               static_cast<const int *>(dead));
+        else if (mode == 1)
+            hipLaunchKernelGGL(pose_nn_soa_kernel<false>, grid, dim3(PS_THREADS), 0, st, static_cast<const float *>(packs), pstride,
+                               n, gt_pack, m, thresholds6, partial, lower_bound, static_cast<const float *>(best), lo, bx,
+                               static_cast<const int *>(dead));
+        else
+            hipLaunchKernelGGL(pose_nn_kernel, grid, dim3(PS_THREADS), 0, st, pred_nn, n, gt_nn, m, stats, thresholds6, partial,
+                               lower_bound, best, lo, bx, static_cast<const int *>(dead));
         if (hi < bx)
             hipLaunchKernelGGL(pose_kill_kernel, dim3(1), dim3(PS_THREADS), 0, st, partial, count, n, m, bx, hi, best, dead,
                                lower_bound);
@@ -573,6 +881,41 @@ extern "C" int zs_pose_search_batch(const float *pred, int n, const float *gt_no
     hipLaunchKernelGGL(pose_finish_kernel, dim3(1), dim3(PS_THREADS), 0, st, partial, count, n, m, bx, order,
                        index_offset, best, lower_bound, static_cast<const int *>(dead));
     return zs::check_launch("zs_pose_search_batch") ? 1 : 0;
+}
+}  // namespace
+
+extern "C" int zs_pose_search_batch(const float *pred, int n, const float *gt_normalized, int m,
+                                    const float *rotations, const int *order, int count, int index_offset,
+                                    const float *lower_bound, const float *thresholds6, float *best,
+                                    void *scratch, void *stream) {
+    return search_batch(pred, pred, n, gt_normalized, nullptr, m, 0, rotations, order, count, index_offset, lower_bound,
+                        thresholds6, best, scratch, stream);
+}
+
+extern "C" size_t zs_pose_pack_bytes(int points) { return points > 0 ? pack_floats(points) * sizeof(float) : 0; }
+
+extern "C" size_t zs_pose_sorted_scratch_bytes(int n, int m, int count) {
+    if (n <= 0 || m <= 0 || count <= 0) return 0;
+    return zs_pose_scratch_bytes(n, m, count) + (size_t)count * zs_pose_pack_bytes(n);
+}
+
+extern "C" int zs_pose_pack(const float *sorted_points, int points, float *pack, void *stream) {
+    if (points <= 0 || !sorted_points || !pack) {
+        zs::set_err("zs_pose_pack: bad arguments (points=%d)", points);
+        return 0;
+    }
+    hipLaunchKernelGGL(pose_pack_kernel, dim3(pack_subs(points) / PS_NSUB, 1), dim3(PS_TILE), 0, static_cast<hipStream_t>(stream),
+                       sorted_points, points, static_cast<const float *>(nullptr), pack, (size_t)0,
+                       static_cast<const float *>(nullptr), static_cast<const float *>(nullptr));
+    return zs::check_launch("zs_pose_pack") ? 1 : 0;
+}
+
+extern "C" int zs_pose_search_batch_sorted(const float *pred, const float *pred_sorted, int n, const float *gt_sorted,
+                                           const float *gt_pack, int m, const float *rotations, const int *order, int count,
+                                           int index_offset, const float *lower_bound, const float *thresholds6, float *best,
+                                           void *scratch, int mode, void *stream) {
+    return search_batch(pred, pred_sorted, n, gt_sorted, gt_pack, m, mode, rotations, order, count, index_offset, lower_bound,
+                        thresholds6, best, scratch, stream);
 }
 
 extern "C" size_t zs_pose_grid_bytes(int n, int m, int count) {
@@ -593,7 +936,7 @@ extern "C" int zs_pose_gt_grid(const float *gt_normalized, int m, void *grids, v
 extern "C" int zs_pose_search_batch_grid(const float *pred, int n, const float *gt_normalized, int m,
                                          const float *rotations, const int *order, int count, int index_offset,
                                          const float *lower_bound, const float *thresholds6, float *best,
-                                         void *scratch, void *grids, void *stream) {
+                                         void *scratch, void *grids, const float *pred_stats, void *stream) {
     if (n <= 0 || m <= 0 || count < 0) {
         zs::set_err("zs_pose_search_batch_grid: bad size (n=%d m=%d count=%d)", n, m, count);
         return 0;
@@ -615,8 +958,8 @@ extern "C" int zs_pose_search_batch_grid(const float *pred, int n, const float *
     float *pred_slots = gt_slot + zs::pgrid::slot_words(m);
     const size_t sw = zs::pgrid::slot_words(n);
     const int bx = blocks_x_of(n, m);
-    hipLaunchKernelGGL(pose_stats_kernel, dim3(count), dim3(PS_THREADS), 0, st, pred, (size_t)0, n, rotations, order,
-                       stats, lower_bound, best);
+    hipLaunchKernelGGL(pose_stats_kernel, dim3(count), dim3(PS_THREADS), 0, st, pred_stats ? pred_stats : pred, (size_t)0, n,
+                       rotations, order, stats, lower_bound, best);
     hipLaunchKernelGGL(pose_pred_grid_kernel, dim3(count), dim3(zs::pgrid::BUILD_THREADS), 0, st, pred, n, stats, pred_slots,
                        sw, lower_bound, best);
     hipLaunchKernelGGL(pose_nn_grid_kernel, dim3(bx, count, 2), dim3(PS_THREADS), 0, st, pred, n, gt_normalized, m, stats,

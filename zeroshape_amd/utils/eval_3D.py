@@ -239,6 +239,32 @@ def _bf_lower_bounds(pc_pred, pc_gt_n, rotations):
     return lb
 
 
+_POSE_MODES = {"brute": 0, "pairs": 1, "cull": 2}     # zs_pose_search_batch_sorted: mode
+
+
+def _spatially_sorted(points, order=None):
+    """points [n,3] (GPU, fp32) -> the same points in an order whose runs of 64 are compact boxes: "str" (default;
+    sort-tile-recursive, zs_str_sort) or "morton" (Z-order curve, zs_morton_sort); ZS_POSE_ORDER overrides."""
+    from .. import _lib
+    lib = _lib.load()
+    order = (order or os.environ.get("ZS_POSE_ORDER", "str")).lower()
+    pts = points.contiguous()
+    n = pts.shape[0]
+    out = torch.empty_like(pts)
+    st = _lib.current_stream_ptr(pts.device)
+    with torch.cuda.device(pts.device):
+        if order == "str":
+            scratch = torch.empty(max(1, lib.zs_str_scratch_bytes(n) // 4), dtype=torch.float32, device=pts.device)
+            rc = lib.zs_str_sort(_lib.ptr(pts), n, _lib.ptr(out), None, _lib.ptr(scratch), st)
+        elif order == "morton":
+            scratch = torch.empty(max(1, lib.zs_morton_scratch_bytes(n) // 4), dtype=torch.float32, device=pts.device)
+            rc = lib.zs_morton_sort(_lib.ptr(pts), n, _lib.ptr(out), None, None, 0, _lib.ptr(scratch), st)
+        else:
+            raise ValueError("point order must be 'str' or 'morton', got %r" % (order,))
+    _lib.check(rc, "zs_%s_sort" % order)
+    return out
+
+
 _ROTATIONS = {}
 
 
@@ -267,12 +293,19 @@ def brute_force_search(pc_pred, pc_gt, f_thresholds=[0.005, 0.01, 0.02, 0.05, 0.
     PyTorch or BLAS launch inside the search.  The winner is the lexicographic minimum of
     (cd, rotation index) over the evaluated rotations; pruned ones are strictly worse, so this IS
     the first strict minimum of the full scan.
-    ``nn`` picks the nearest-neighbour kernels of the exact evaluations: "brute" (default; ZS_POSE_NN overrides) scans
-    all pairs, "grid" walks uniform grids - the ground truth binned once per search, the rotated prediction once per
-    rotation; the records are bit-identical (tests/test_gpu_chamfer.py).  The grid walk wins 3.6x on clouds that
-    already lie on each other (the Chamfer call of the final metrics), but most of the 6,912 rotations do NOT, their
-    queries walk many rings, and the whole search is slower: 1,139 vs 154 ms exhaustive, 13.7 vs 11.1 ms pruned at
-    10k x 10k points - hence opt-in.
+    ``nn`` picks the nearest-neighbour kernels of the exact evaluations (ZS_POSE_NN overrides the default).  Both
+    clouds are first put into a spatial order (sort-tile-recursive, zs_str_sort; once per search), so that 64
+    consecutive points fill a compact box - also after the rotation; the statistics of normalize_pc and
+    the returned clouds keep the caller's order.  "cull" (default, round 3) reads candidates 64 at a time
+    through the scalar cache and skips every block whose bounding box is farther from a query than its current
+    nearest neighbour, nearest tiles first; "pairs" is the same kernel without the skipping, "brute" round 2's
+    LDS-staged scan of every pair of the same sorted clouds; "grid" walks uniform grids - the ground
+    truth binned once per search, the rotated prediction once per rotation.  The records are bit-identical
+    (tests/test_gpu_chamfer.py): every query ends with the same minimum and the sums keep their fixed order.  The
+    grid walk wins 3.6x on clouds that already lie on each other (the Chamfer call of the final metrics), but most
+    of the 6,912 rotations do NOT, their queries walk many rings (divergent lanes), and the whole search is
+    slower than the plain scan (round 2: 1,139 vs 154 ms exhaustive) - the culled scan keeps the regular
+    wave-wide inner loop and drops whole blocks instead.
     ``rot_slice=(start, stop)`` restricts the scan to a contiguous index range; ``return_index`` appends the
     winning global rotation index and its cd (one host read of the 64-byte record).
     ``rot_shard=(rank, world)`` is the multi-GPU form (every rank of ``group`` calls with the
@@ -312,9 +345,15 @@ def brute_force_search(pc_pred, pc_gt, f_thresholds=[0.005, 0.01, 0.02, 0.05, 0.
     thr = _threshold_tensor(f_thresholds, dev, pad_to=6)
     best = torch.empty(lib.zs_pose_best_bytes() // 4, dtype=torch.float32, device=dev)
     scratch = torch.empty(lib.zs_pose_scratch_bytes(n, m, max(1, min(batch_size, K))) // 4, dtype=torch.float32, device=dev)
-    nn = (nn or os.environ.get("ZS_POSE_NN", "brute")).lower()
-    if nn not in ("grid", "brute"):
-        raise ValueError("nn must be 'grid' or 'brute', got %r" % (nn,))
+    nn = (nn or os.environ.get("ZS_POSE_NN", "cull")).lower()
+    if nn not in ("grid", "brute", "cull", "pairs"):
+        raise ValueError("nn must be 'cull', 'pairs', 'grid' or 'brute', got %r" % (nn,))
+    pred_s, gt_s = _spatially_sorted(pred), _spatially_sorted(pc_gt[0])
+    gt_pack = None
+    if nn != "grid":
+        gt_pack = torch.empty(lib.zs_pose_pack_bytes(m) // 4, dtype=torch.float32, device=dev)
+        scratch = torch.empty(lib.zs_pose_sorted_scratch_bytes(n, m, max(1, min(batch_size, K))) // 4, dtype=torch.float32,
+                              device=dev)
     grids = None
     if nn == "grid":
         grids = torch.empty(lib.zs_pose_grid_bytes(n, m, max(1, min(batch_size, K))) // 4, dtype=torch.float32, device=dev)
@@ -323,15 +362,19 @@ def brute_force_search(pc_pred, pc_gt, f_thresholds=[0.005, 0.01, 0.02, 0.05, 0.
 
     def launch(rot_ptr, order_ptr, count, offset, lb_ptr):
         if grids is None:
-            return lib.zs_pose_search_batch(_lib.ptr(pred), n, _lib.ptr(pc_gt), m, rot_ptr, order_ptr, count, offset, lb_ptr,
-                                            _lib.ptr(thr), _lib.ptr(best), _lib.ptr(scratch), st)
-        return lib.zs_pose_search_batch_grid(_lib.ptr(pred), n, _lib.ptr(pc_gt), m, rot_ptr, order_ptr, count, offset, lb_ptr,
-                                             _lib.ptr(thr), _lib.ptr(best), _lib.ptr(scratch), _lib.ptr(grids), st)
+            return lib.zs_pose_search_batch_sorted(_lib.ptr(pred), _lib.ptr(pred_s), n, _lib.ptr(gt_s), _lib.ptr(gt_pack), m,
+                                                   rot_ptr, order_ptr, count, offset, lb_ptr, _lib.ptr(thr), _lib.ptr(best),
+                                                   _lib.ptr(scratch), _POSE_MODES[nn], st)
+        return lib.zs_pose_search_batch_grid(_lib.ptr(pred_s), n, _lib.ptr(gt_s), m, rot_ptr, order_ptr, count, offset, lb_ptr,
+                                             _lib.ptr(thr), _lib.ptr(best), _lib.ptr(scratch), _lib.ptr(grids),
+                                             _lib.ptr(pred), st)
 
     with torch.cuda.device(dev):
         _lib.check(lib.zs_pose_best_init(_lib.ptr(best), st), "zs_pose_best_init")
         if grids is not None:
-            _lib.check(lib.zs_pose_gt_grid(_lib.ptr(pc_gt), m, _lib.ptr(grids), st), "zs_pose_gt_grid")
+            _lib.check(lib.zs_pose_gt_grid(_lib.ptr(gt_s), m, _lib.ptr(grids), st), "zs_pose_gt_grid")
+        else:
+            _lib.check(lib.zs_pose_pack(_lib.ptr(gt_s), m, _lib.ptr(gt_pack), st), "zs_pose_pack")
         # a small first batch: its winner lets the staged drop (csrc/pose_search.hip) thin out every later batch
         starts, pos = [], 0
         while pos < K:
