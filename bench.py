@@ -33,13 +33,16 @@ Extra objects on the JSON line:
                  and the occupancy flips between the two arithmetics on the full grid.
   cpu_baseline - the oracle (torch-CPU fp32 restatement of the reference, "port") timed on
                  this host's cores on a bounded sample of x-slices of the same grid.
-  chamfer / pose_search / chamfer_l1 / encoder / inference / iso_surface / train_step
+  calibration  - Implicit.prepare's once-per-weight-version verdict on the requested arithmetic: max |f16x3 - f32| logit
+                 over 4096 probe points and the arithmetic it selected (2.5e-5 keeps f16x3, else the fp32 kernels run).
+  chamfer / pose_search / chamfer_l1 / encoder / inference / iso_surface / train_step / trained_weights
                - (N = 1, outside the timed region; tools/bench_legs.py) the rest of the BASELINE metric: the
                  Chamfer NN kernel on [24,10k]x[24,10k] with its fp32-VALU roofline fraction, bit equality
                  to the oracle and the oracle timed on the host (CPU leg ii); the 6912-rotation pose search
                  exhaustive and pruned; Chamfer-L1 against the oracle pipeline and across the two decoder
                  arithmetics; encoder forward B = 1 / 28 with the CPU restatement at B = 1 (CPU leg iii);
-                 one training step at per-GPU batch 4.  --no-extras skips them.
+                 one training step at per-GPU batch 4; the two decoder arithmetics on weights trained for 304
+                 iterations (full-grid difference + calibration verdict).  --no-extras skips them.
 """
 import argparse
 import json
@@ -325,7 +328,20 @@ def main():
         cpu_baseline = {"value": round(done * G * G / cdt, 1), "unit": "points/s", "cores": cores,
                         "kind": "port",
                         "sample": "%d evenly spaced x-slices of the %d^3 grid (%d points), oracle/"
-                                  "decoder_ref.level_grid, torch-CPU fp32, %.1f s" % (done, G, done * G * G, cdt)}
+                                  "decoder_ref.level_grid, torch-CPU fp32, %.1f s; %d of the host's %d cores: the fastest of "
+                                  "8/16/32/64 torch intra-op threads on one slice (these small per-slice ops stop "
+                                  "scaling beyond that)" % (done, G, done * G * G, cdt, cores, ncpu)}
+        # the same restatement over the FULL grids of configs 0 / 2 (vox_res 32 and 64)
+        if N == VOX_RES:
+            full = {}
+            for n_small in (32, 64):
+                g_small = decoder_ref.dense_grid(RANGE[0], RANGE[1], n_small)
+                t1 = time.perf_counter()
+                decoder_ref.level_grid(sd, lat_c, g_small)
+                el = time.perf_counter() - t1
+                full["vox%d" % n_small] = {"points": (n_small + 1) ** 3, "seconds": round(el, 2),
+                                           "value": round((n_small + 1) ** 3 / el, 1), "unit": "points/s"}
+            cpu_baseline["full_grids"] = full
 
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras and N == VOX_RES:
@@ -334,7 +350,8 @@ def main():
         for name, fn in (("chamfer", lambda: legs.chamfer_leg(dev, cpu)), ("pose_search", lambda: legs.pose_search_leg(dev)),
                          ("chamfer_l1", lambda: legs.eval_leg(dev, net, sd)), ("encoder", lambda: legs.encoder_leg(dev, cpu)),
                          ("inference", lambda: legs.inference_leg(dev)), ("iso_surface", lambda: legs.surface_leg(dev)),
-                         ("train_step", lambda: legs.in_subprocess("train", "train_step"))):
+                         ("train_step", lambda: legs.in_subprocess("train", "train_step")),
+                         ("trained_weights", lambda: legs.in_subprocess("trained", "trained_weights"))):
             try:
                 extras[name] = fn()
             except Exception as e:                      # a leg must never take the headline line down

@@ -17,14 +17,15 @@ COMMON = ["--pretrain.depth=", "--arch.depth.pretrained=", "--eval.vox_res=16", 
           "--training.n_sdf_points=256", "--max_epoch=1", "--batch_size=4"]
 
 
-def run(script, *args, items=4):
+def run(script, *args, items=4, standin=None):
     # ZS_SYNTHETIC_STANDIN: the data.* modules of this repository are analytic stand-ins, handed out on an explicit
     # opt-in only (zeroshape_amd/data/__init__.py)
     env = dict(os.environ, HIP_VISIBLE_DEVICES="0", ZS_SYNTHETIC_ITEMS=str(items), ZS_SYNTHETIC_STANDIN="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, script)] + list(args), cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    assert "SYNTHETIC STAND-IN" in r.stderr
+    if script in ("train.py", "evaluate.py") if standin is None else standin:     # the launchers that load data by name
+        assert "SYNTHETIC STAND-IN" in r.stderr
     return r.stdout
 
 

@@ -25,8 +25,34 @@
 namespace {
 
 constexpr int MC_THREADS = 256;
-constexpr int MC_PER = 4;                  // consecutive cubes per thread: four cubes' corner loads in flight per lane
-constexpr int MC_BLOCK = MC_THREADS * MC_PER;   // cubes per workgroup (the unit of the block offsets)
+constexpr int MC_PER = 4;                  // consecutive cubes of one k-row per thread (count pass)
+constexpr int MC_BLOCK = MC_THREADS * MC_PER;   // cubes per workgroup of the count pass
+
+// Cubes are enumerated row by row (a row = the C cubes of one (i, j), k fastest), every row padded to a multiple of
+// MC_PER "virtual" cubes, so that a thread of the count pass owns MC_PER cubes of ONE row and reads their corners as
+// four 16-byte loads (round 3; the output order - x slowest, z fastest - does not change: padding cubes emit nothing).
+struct CubeSpace {
+    int C, per_row;            // cubes per row, virtual cubes per row
+    long long total;           // virtual cubes
+};
+__host__ __device__ inline CubeSpace cube_space(int G) {
+    const int C = G - 1, per_row = (C + MC_PER - 1) / MC_PER * MC_PER;
+    return CubeSpace{C, per_row, (long long)C * C * per_row};
+}
+// virtual cube -> (i, j, k); k >= C marks padding
+__device__ __forceinline__ void virtual_ijk(const CubeSpace &cs, long long v, int &i, int &j, int &k) {
+    if (cs.total < (1LL << 31)) {
+        const unsigned c = (unsigned)v, row = c / (unsigned)cs.per_row;
+        k = (int)(c - row * (unsigned)cs.per_row);
+        i = (int)(row / (unsigned)cs.C);
+        j = (int)(row - (unsigned)i * (unsigned)cs.C);
+    } else {
+        const long long row = v / cs.per_row;
+        k = (int)(v - row * cs.per_row);
+        i = (int)(row / cs.C);
+        j = (int)(row - (long long)i * cs.C);
+    }
+}
 
 // edge e: (corner a, corner b) listed low-coordinate endpoint first, its axis, and the
 // corner offsets (mc_tables.py numbering)
@@ -95,32 +121,73 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *lds, int &total)
     return base + x - v;
 }
 
+// Count pass.  Round 2 read every corner with its own 4-byte load (32 loads per thread, each wave instruction a
+// 1 KiB span with a quarter of it used): 1.4 TB/s at 257^3, bound by the texture-address path, not by HBM.  Now a
+// thread owns four consecutive cubes of one k-row: the four corner rows (i | i+1, j | j+1) arrive as four
+// global_load_dwordx4 (a wave covers 1 KiB contiguous per instruction), the fifth value of each row comes from the
+// next lane (same row) or one extra load at a row's end, and the 20 comparisons against iso are formed once.
 __global__ __launch_bounds__(MC_THREADS) void mc_count_kernel(const float *__restrict__ vol, int G,
                                                               float iso,
                                                               const uint8_t *__restrict__ tri_count,
-                                                              int *__restrict__ block_sums) {
-    const int C = G - 1;
-    const long long cubes = (long long)C * C * C;
-    const long long first = (long long)blockIdx.x * MC_BLOCK + (long long)threadIdx.x * MC_PER;
-    // the grid is tiny next to the chip (8.6 MB at 129^3): what bounds the pass is latency x occupancy, so a lane
-    // keeps the corner loads of four cubes in flight before it looks at any of them
-    float f[MC_PER][8];
-#pragma unroll
-    for (int q = 0; q < MC_PER; q++) {
-        int i, j, k;
-        cube_ijk(first + q < cubes ? first + q : 0, C, i, j, k);
-        cube_corners(vol, G, i, j, k, f[q]);
-    }
+                                                              int *__restrict__ block_sums, long long n_blocks) {
+    const CubeSpace cs = cube_space(G);
+    const long long first = ((long long)blockIdx.x * MC_THREADS + threadIdx.x) * MC_PER;
+    const int lane = threadIdx.x & 63;
     int n = 0;
+    const bool live = first < cs.total;
+    int i = 0, j = 0, k0 = 0;
+    if (live) virtual_ijk(cs, first, i, j, k0);
+    const size_t gg = (size_t)G * G;
+    const float *p = vol + (size_t)i * gg + (size_t)j * G + k0;
+    const float *rows[4] = {p, p + gg, p + gg + G, p + G};      // corners 0/4, 1/5, 2/6, 3/7 at k and k + 1
+    unsigned below[4];                                          // bit e: value k0 + e of the row is below iso
+    const bool wide = live && k0 + MC_PER - 1 <= G - 1;         // the 16-byte load stays inside the row
+    float head[4];
 #pragma unroll
-    for (int q = 0; q < MC_PER; q++)
-        if (first + q < cubes) n += tri_count[case_of(f[q], iso)];
-    // a wave's 64 x MC_PER consecutive cubes are one block of MC_THREADS cubes of the emit pass: its sum is that
+    for (int r = 0; r < 4; r++) {
+        float v[MC_PER] = {0.f, 0.f, 0.f, 0.f};
+        if (wide) {
+            // (rows are G floats apart: 4-byte aligned only, which global_load_dwordx4 accepts)
+            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+            const f4u q = *reinterpret_cast<const f4u *>(rows[r]);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else if (live) {
+#pragma unroll
+            for (int e = 0; e < MC_PER; e++) v[e] = rows[r][min(e, G - 1 - k0)];
+        }
+        head[r] = v[0];
+        below[r] = 0;
+#pragma unroll
+        for (int e = 0; e < MC_PER; e++) below[r] |= (v[e] < iso) ? (1u << e) : 0u;
+    }
+    // value k0 + 4 of every row: the next lane's first value when that lane continues this row
+    const bool next_same_row = lane < 63 && k0 + MC_PER < cs.per_row && first + MC_PER < cs.total;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        float v = __shfl_down(head[r], 1, 64);
+        if (live && !next_same_row) v = rows[r][min(MC_PER, G - 1 - k0)];
+        below[r] |= (v < iso) ? (1u << MC_PER) : 0u;
+    }
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < MC_PER; q++) {
+            if (k0 + q >= cs.C) break;
+            int c = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                c |= ((below[r] >> q) & 1u) << r;
+                c |= ((below[r] >> (q + 1)) & 1u) << (4 + r);
+            }
+            n += tri_count[c];
+        }
+    }
+    // a wave's 64 x MC_PER consecutive virtual cubes are one block of MC_THREADS cubes of the emit pass: its sum is that
     // block's entry, no exchange between the waves
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
     const long long blk = (long long)blockIdx.x * (MC_BLOCK / MC_THREADS) + (threadIdx.x >> 6);
-    if ((threadIdx.x & 63) == 0 && blk * MC_THREADS < cubes) block_sums[blk] = n;
+    if (lane == 0 && blk < n_blocks) block_sums[blk] = n;
+    if (blockIdx.x == 0 && threadIdx.x == 0) block_sums[n_blocks] = 0;     // the scan turns it into the total
 }
 
 // ---- scans over many workgroups, two launches -------------------------------------------------------------- //
@@ -199,20 +266,26 @@ __global__ __launch_bounds__(MC_THREADS) void mc_emit_kernel(
     int table_stride, const uint8_t *__restrict__ tri_count, const int *__restrict__ block_offsets,
     float scale, float offset, float *__restrict__ tris, int max_tris) {
     __shared__ int lds[MC_THREADS / 64];
-    const int C = G - 1;
+    // a block without triangles (most of them: the surface meets a few per cent of the k-rows) leaves at once, without
+    // touching the volume - the count pass already knows
+    const int block_first = block_offsets[blockIdx.x];
+    if (block_offsets[blockIdx.x + 1] == block_first) return;
+    const CubeSpace space = cube_space(G);
     const long long cube = (long long)blockIdx.x * MC_THREADS + threadIdx.x;
     int n = 0, cs = 0, i = 0, j = 0, k = 0;
     float f[8];
-    if (cube < (long long)C * C * C) {
-        cube_ijk(cube, C, i, j, k);
-        cube_corners(vol, G, i, j, k, f);
-        cs = case_of(f, iso);
-        n = tri_count[cs];
+    if (cube < space.total) {
+        virtual_ijk(space, cube, i, j, k);
+        if (k < space.C) {
+            cube_corners(vol, G, i, j, k, f);
+            cs = case_of(f, iso);
+            n = tri_count[cs];
+        }
     }
     int total;
     const int local = block_exclusive_scan(n, lds, total);
     if (n == 0) return;
-    const int first = block_offsets[blockIdx.x] + local;
+    const int first = block_first + local;
     for (int t = 0; t < n; t++) {
         if (first + t >= max_tris) return;
         float *o = tris + (size_t)(first + t) * 9;
@@ -279,11 +352,12 @@ __global__ __launch_bounds__(256) void mesh_sample_kernel(const float *__restric
 
 }  // namespace
 
+static inline long long mc_blocks(int G) { return (cube_space(G).total + MC_THREADS - 1) / MC_THREADS; }
+
 extern "C" size_t zs_mc_scratch_bytes(int G) {
     if (G < 2) return 0;
-    const long long cubes = (long long)(G - 1) * (G - 1) * (G - 1);
-    const long long nb = (cubes + MC_THREADS - 1) / MC_THREADS;
-    return (size_t)(nb + 1 + scan_tiles(nb) + 1) * sizeof(int);        // block offsets | totals of the scan's tiles
+    const long long nb = mc_blocks(G);
+    return (size_t)(nb + 2 + scan_tiles(nb + 1) + 1) * sizeof(int);    // block offsets + total | totals of the scan's tiles
 }
 
 extern "C" size_t zs_mesh_sample_scratch_doubles(int n_tris) {
@@ -301,15 +375,16 @@ extern "C" int zs_mc_count(const float *vol, int G, float iso, const uint8_t *tr
         return 0;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const long long cubes = (long long)(G - 1) * (G - 1) * (G - 1);
-    const int nb = (int)((cubes + MC_THREADS - 1) / MC_THREADS);
+    const long long cubes = cube_space(G).total;
+    const long long nb = mc_blocks(G);
     int *sums = static_cast<int *>(scratch);
     hipLaunchKernelGGL(mc_count_kernel, dim3((unsigned)((cubes + MC_BLOCK - 1) / MC_BLOCK)), dim3(MC_THREADS), 0, s, vol, G, iso,
-                       tri_count, sums);
-    int *tile_tot = sums + nb + 1;
-    const int tiles = scan_tiles(nb);
-    hipLaunchKernelGGL((scan_tiles_kernel<int, false>), dim3(tiles), dim3(256), 0, s, sums, (long long)nb, tile_tot);
-    hipLaunchKernelGGL(scan_offsets_kernel<int>, dim3(tiles), dim3(256), 0, s, sums, (long long)nb, tile_tot, tiles, total);
+                       tri_count, sums, nb);
+    // exclusive scan over the nb block sums and one trailing zero: offsets[b + 1] - offsets[b] = triangles of block b
+    int *tile_tot = sums + nb + 2;
+    const int tiles = scan_tiles(nb + 1);
+    hipLaunchKernelGGL((scan_tiles_kernel<int, false>), dim3(tiles), dim3(256), 0, s, sums, nb + 1, tile_tot);
+    hipLaunchKernelGGL(scan_offsets_kernel<int>, dim3(tiles), dim3(256), 0, s, sums, nb + 1, tile_tot, tiles, total);
     return zs::check_launch("zs_mc_count") ? 1 : 0;
 }
 
@@ -325,8 +400,7 @@ extern "C" int zs_mc_emit(const float *vol, int G, float iso, const int8_t *tri_
         zs::set_err("zs_mc_emit: null pointer");
         return 0;
     }
-    const long long cubes = (long long)(G - 1) * (G - 1) * (G - 1);
-    const int nb = (int)((cubes + MC_THREADS - 1) / MC_THREADS);
+    const int nb = (int)mc_blocks(G);
     hipLaunchKernelGGL(mc_emit_kernel, dim3(nb), dim3(MC_THREADS), 0, static_cast<hipStream_t>(stream),
                        vol, G, iso, tri_table, table_stride, tri_count, static_cast<const int *>(scratch),
                        scale, offset, tris, n_tris);

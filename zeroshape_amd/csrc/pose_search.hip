@@ -391,6 +391,10 @@ __global__ __launch_bounds__(PS_TILE) void pose_pack_kernel(const float *__restr
     }
 }
 
+#ifdef ZS_POSE_COUNT   // measurement build only (tools/pose_pairs.py): (run of 64 queries) x (64 candidates) blocks
+__device__ unsigned long long g_pose_blocks[2];   // [0] evaluated, [1] all
+#endif
+
 // 64 candidates of one sub-tile (uniform address -> scalar loads) against this lane's queries
 template <bool D0, bool D1>
 __device__ __forceinline__ void scan_subtile(const float *__restrict__ c, const float (&qx)[PS_Q], const float (&qy)[PS_Q],
@@ -460,9 +464,16 @@ __global__ __launch_bounds__(PS_THREADS) void pose_nn_soa_kernel(
         }
     }
     const int T = ncs / PS_NSUB;
+#ifdef ZS_POSE_COUNT
+    unsigned scanned = 0;
+#define ZS_COUNT(k) scanned += (k)
+#else
+#define ZS_COUNT(k)
+#endif
     if (!CULL || T > 64) {
         for (int sidx = 0; sidx < ncs; sidx++)
             scan_subtile<true, true>(C + (size_t)sidx * PS_SUB_FLOATS, qx, qy, qz, bestd);
+        ZS_COUNT(2 * ncs);
     } else {
         float wlo[3], whi[3];
 #pragma unroll
@@ -521,11 +532,19 @@ __global__ __launch_bounds__(PS_THREADS) void pose_nn_soa_kernel(
                     scan_subtile<true, false>(c, qx, qy, qz, bestd);
                 else if (d1)
                     scan_subtile<false, true>(c, qx, qy, qz, bestd);
+                ZS_COUNT((d0 ? 1 : 0) + (d1 ? 1 : 0));
             }
             w0 = wave_maxf(bestd[0]);
             w1 = wave_maxf(bestd[1]);
         }
     }
+#ifdef ZS_POSE_COUNT
+    if (lane == 0) {
+        atomicAdd(&g_pose_blocks[0], (unsigned long long)scanned);
+        atomicAdd(&g_pose_blocks[1], (unsigned long long)(2 * ((nc + PS_SUB - 1) / PS_SUB)));
+    }
+#endif
+#undef ZS_COUNT
     // epilogue: pose_nn_kernel's, statement for statement
     float v[PS_PART];
 #pragma unroll
@@ -891,6 +910,17 @@ extern "C" int zs_pose_search_batch(const float *pred, int n, const float *gt_no
     return search_batch(pred, pred, n, gt_normalized, nullptr, m, 0, rotations, order, count, index_offset, lower_bound,
                         thresholds6, best, scratch, stream);
 }
+
+#ifdef ZS_POSE_COUNT
+extern "C" int zs_pose_debug_counters(unsigned long long *out2, int reset) {
+    if (hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_pose_blocks), 16) != hipSuccess) return 0;
+    if (reset) {
+        const unsigned long long z[2] = {0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_pose_blocks), z, 16) != hipSuccess) return 0;
+    }
+    return 1;
+}
+#endif
 
 extern "C" size_t zs_pose_pack_bytes(int points) { return points > 0 ? pack_floats(points) * sizeof(float) : 0; }
 
