@@ -287,10 +287,12 @@ int zs_fscore(const float *dist1, int n, const float *dist2, int m, int b, const
  * Case tables come from the caller (zeroshape_amd/mc_tables.py): tri_table int8
  * [256][table_stride] (edge ids, -1 padded), tri_count uint8 [256].
  *
- *   zs_mc_count  : per-cube triangle counts -> exclusive block offsets in `scratch`
- *                  (zs_mc_scratch_bytes(G)) and the grand total in *total (device int)
+ *   zs_mc_count  : triangle counts per unit of 256 cubes -> exclusive offsets and the list of non-empty
+ *                  units in `scratch` (zs_mc_scratch_bytes(G), 8-byte aligned) and the grand total in
+ *                  *total (device int); one read of the volume with 16-byte row loads
  *   zs_mc_emit   : tris[n_tris][3][3] fp32 triangle soup in world space
- *                  (index * scale + offset), cube order x-slowest, deterministic
+ *                  (index * scale + offset), cube order x-slowest, deterministic; reads the volume
+ *                  only in the non-empty units (one wave each, a lane per triangle)
  *   zs_mesh_sample: n_samples area-weighted points (counter-based RNG, `seed`);
  *                  cum_area = scratch of zs_mesh_sample_scratch_doubles(n_tris) doubles (the cumulative
  *                  areas and the tile totals of their scan); an empty mesh yields zeros

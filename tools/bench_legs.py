@@ -96,11 +96,11 @@ def pose_search_leg(dev):
     gt = ((R[1234] @ pred.T).T.contiguous().cpu() + 1e-3 * torch.randn(n, 3, generator=g)).to(dev)
     far = torch.from_numpy(syn.seeded_cloud(9, 1, n)[0]).to(dev)
 
-    def run(gt_, prune):
-        E.brute_force_search(pred, gt_, device=dev, prune=prune)
+    def run(gt_, prune, nn=None):
+        E.brute_force_search(pred, gt_, device=dev, prune=prune, nn=nn)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        o = E.brute_force_search(pred, gt_, device=dev, prune=prune, return_index=True)
+        o = E.brute_force_search(pred, gt_, device=dev, prune=prune, return_index=True, nn=nn)
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) * 1e3, o
     ms_ex, o_ex = run(gt, False)
@@ -110,16 +110,34 @@ def pose_search_leg(dev):
     ms_far, o_far = run(far, True)
     n_far, s_far = E.brute_force_search.last_evaluated, E.brute_force_search.last_scanned
     pairs = 6912 * 2.0 * n * n
-    # rate and roofline fraction from the search that cannot skip anything (unrelated ground truth: every rotation is
-    # scanned in full); the alignable searches drop most rotations after 5-35 % of their queries (staged drop, exact)
-    return {"rotations": 6912, "points": [n, n], "exhaustive_ms": round(ms_ex, 2), "exhaustive_rotations_scanned_in_full": s_ex,
+    # the search that cannot drop a rotation (unrelated ground truth: all 6912 are scanned in full).  Since round 3 the
+    # scan is box-culled: ALGORITHMIC pairs (what the reference's all-pairs kernels evaluate, 2 n m per rotation) per
+    # second, the fraction of them the kernel really evaluates (from the counting build, profiles/r03_pose_pairs.json:
+    # tools/pose_pairs.py) and the executed rate against the fp32 VALU peak; the alignable searches also drop most
+    # rotations after 5-35 % of their queries (staged drop, exact)
+    evaluated = None
+    try:
+        evaluated = json.load(open(os.path.join(ROOT, "profiles", "r03_pose_pairs.json")))["str/unalignable"]["fraction"]
+    except (OSError, KeyError, ValueError):
+        pass
+    ms_brute, _ = run(far, False, "brute")
+    executed = pairs * (s_far / 6912.0) * (evaluated or 1.0)
+    return {"rotations": 6912, "points": [n, n], "nn": "cull (box-culled scan on STR-sorted clouds)",
+            "exhaustive_ms": round(ms_ex, 2), "exhaustive_rotations_scanned_in_full": s_ex,
             "pruned_ms": round(ms_pr, 2), "pruned_rotations_evaluated": n_pr, "pruned_rotations_scanned_in_full": s_pr,
             "pruned_equals_exhaustive": bool(o_ex[5] == o_pr[5] and o_ex[6] == o_pr[6] and torch.equal(o_ex[3], o_pr[3])),
             "best_index": int(o_ex[5]), "best_cd": float(o_ex[6]),
             "unalignable_gt_pruned_ms": round(ms_far, 2), "unalignable_gt_rotations_evaluated": n_far,
             "unalignable_gt_rotations_scanned_in_full": s_far,
-            "full_scan_tpairs_per_s": round(pairs * (s_far / 6912.0) / (ms_far * 1e-3) / 1e12, 3),
-            "full_scan_frac_of_fp32_valu_peak": round(pairs * (s_far / 6912.0) * FLOP_PER_PAIR / (ms_far * 1e-3) / 1e12 / PEAK_F32_VALU_TFLOPS, 4)}
+            "full_scan_algorithmic_tpairs_per_s": round(pairs * (s_far / 6912.0) / (ms_far * 1e-3) / 1e12, 3),
+            "full_scan_pairs_evaluated_fraction": evaluated,
+            "full_scan_pairs_evaluated_source": "profiles/r03_pose_pairs.json (counting build of csrc/pose_search.hip)",
+            "full_scan_executed_tpairs_per_s": round(executed / (ms_far * 1e-3) / 1e12, 3),
+            "full_scan_executed_frac_of_fp32_valu_peak": round(executed * FLOP_PER_PAIR / (ms_far * 1e-3) / 1e12 / PEAK_F32_VALU_TFLOPS, 4),
+            # round 2's LDS-staged all-pairs kernel on the same sorted clouds (bit-identical record): the roofline-graded form
+            "all_pairs_kernel_unalignable_ms": round(ms_brute, 2),
+            "all_pairs_kernel_tpairs_per_s": round(pairs / (ms_brute * 1e-3) / 1e12, 3),
+            "all_pairs_kernel_frac_of_fp32_valu_peak": round(pairs * FLOP_PER_PAIR / (ms_brute * 1e-3) / 1e12 / PEAK_F32_VALU_TFLOPS, 4)}
 
 
 def eval_leg(dev, net, sd):

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Driver for the rocprofv3 passes over the evaluation kernels other than the decoder (profiles/r02_eval_*):
 the Chamfer scan nn_both_kernel<2> on [24,10k]x[24,10k], the grid-accelerated exact kernel, one exhaustive
-6912-rotation pose search (pose_stats / pose_nn / pose_finish), and the iso-surface kernels (mc_count,
-mc_emit, mesh sampling) on a 129^3 level grid."""
+6912-rotation pose search (pose_stats / pose_pack / pose_nn_soa / pose_kill / pose_finish), and the iso-surface
+kernels (mc_count, mc_emit, mesh sampling) on a 129^3 level grid of the decoder and on a 257^3 analytic one."""
 import os
 import sys
 
@@ -42,5 +42,11 @@ v = edict(dict(idx=[0]))
 lv, _ = E.compute_level_grid(opt, net, lat, None, E.get_dense_3D_grid(opt, v), None)
 for i in range(3):
     E._surface_clouds(opt, lv, seed=i)
+# the iso-surface kernels at BASELINE config 5's size (257^3, an analytic ellipsoid level set: the bench leg's volume)
+ax = torch.linspace(-1.5, 1.5, 257, device=dev)
+x, y, z = torch.meshgrid(ax, ax, ax, indexing="ij")
+vol = torch.sigmoid(-20.0 * (torch.sqrt(x * x + 1.3 * y * y + 0.8 * z * z) - 0.9)).contiguous()
+for i in range(3):
+    E.extract_surface(vol, 0.5, -1.5, 1.5, num_points=10000, seed=i)
 torch.cuda.synchronize()
 print("done")

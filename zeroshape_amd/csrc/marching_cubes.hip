@@ -54,140 +54,81 @@ __device__ __forceinline__ void virtual_ijk(const CubeSpace &cs, long long v, in
     }
 }
 
-// edge e: (corner a, corner b) listed low-coordinate endpoint first, its axis, and the
-// corner offsets (mc_tables.py numbering)
-__device__ const int kEdgeA[12] = {0, 1, 3, 0, 4, 5, 7, 4, 0, 1, 2, 3};
-__device__ const int kEdgeB[12] = {1, 2, 2, 3, 5, 6, 6, 7, 4, 5, 6, 7};
-__device__ const int kEdgeAxis[12] = {0, 1, 0, 1, 0, 1, 0, 1, 2, 2, 2, 2};
-__device__ const int kCornerX[8] = {0, 1, 1, 0, 0, 1, 1, 0};
-__device__ const int kCornerY[8] = {0, 0, 1, 1, 0, 0, 1, 1};
-__device__ const int kCornerZ[8] = {0, 0, 0, 0, 1, 1, 1, 1};
-
-__device__ __forceinline__ void cube_corners(const float *__restrict__ vol, int G, int i, int j, int k, float f[8]) {
-    const size_t gg = (size_t)G * G;
-    const float *p = vol + (size_t)i * gg + (size_t)j * G + k;
-    f[0] = p[0];
-    f[1] = p[gg];
-    f[2] = p[gg + G];
-    f[3] = p[G];
-    f[4] = p[1];
-    f[5] = p[gg + 1];
-    f[6] = p[gg + G + 1];
-    f[7] = p[G + 1];
-}
-__device__ __forceinline__ int case_of(const float f[8], float iso) {
-    int c = 0;
-#pragma unroll
-    for (int b = 0; b < 8; b++) c |= (f[b] < iso) ? (1 << b) : 0;
-    return c;
-}
-
-// linear cube index (k fastest) -> (i, j, k); 32-bit divisions whenever the index fits (G <= 1291): the 64-bit ones
-// cost more than the eight loads of the cube
-__device__ __forceinline__ void cube_ijk(long long cube, int C, int &i, int &j, int &k) {
-    if ((long long)C * C * C < (1LL << 31)) {
-        const unsigned c = (unsigned)cube, q = c / (unsigned)C;
-        k = (int)(c - q * (unsigned)C);
-        i = (int)(q / (unsigned)C);
-        j = (int)(q - (unsigned)i * (unsigned)C);
-    } else {
-        k = (int)(cube % C);
-        j = (int)((cube / C) % C);
-        i = (int)(cube / ((long long)C * C));
-    }
-}
-
-// block-wide exclusive scan of one int per thread (64 * NW threads); returns the block total
-template <int NW = MC_THREADS / 64>
-__device__ __forceinline__ int block_exclusive_scan(int v, int *lds, int &total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int y = __shfl_up(x, o, 64);
-        if (lane >= o) x += y;
-    }
-    if (lane == 63) lds[wave] = x;
-    __syncthreads();
-    int base = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < NW; w++) {
-        const int s = lds[w];
-        if (w < wave) base += s;
-        tot += s;
-    }
-    __syncthreads();
-    total = tot;
-    return base + x - v;
-}
-
-// Count pass.  Round 2 read every corner with its own 4-byte load (32 loads per thread, each wave instruction a
-// 1 KiB span with a quarter of it used): 1.4 TB/s at 257^3, bound by the texture-address path, not by HBM.  Now a
-// thread owns four consecutive cubes of one k-row: the four corner rows (i | i+1, j | j+1) arrive as four
-// global_load_dwordx4 (a wave covers 1 KiB contiguous per instruction), the fifth value of each row comes from the
-// next lane (same row) or one extra load at a row's end, and the 20 comparisons against iso are formed once.
-__global__ __launch_bounds__(MC_THREADS) void mc_count_kernel(const float *__restrict__ vol, int G,
-                                                              float iso,
-                                                              const uint8_t *__restrict__ tri_count,
-                                                              int *__restrict__ block_sums, long long n_blocks) {
-    const CubeSpace cs = cube_space(G);
-    const long long first = ((long long)blockIdx.x * MC_THREADS + threadIdx.x) * MC_PER;
-    const int lane = threadIdx.x & 63;
-    int n = 0;
+// edge e joins corner a (its low-coordinate endpoint) and corner b along `axis` (mc_tables.py numbering):
+//   a    = {0, 1, 3, 0, 4, 5, 7, 4, 0, 1, 2, 3}, axis = {0, 1, 0, 1, 0, 1, 0, 1, 2, 2, 2, 2}   (packed below, kEdge*Packed)
+//   corner c sits at (x, y, z) = ((0x66 >> c) & 1, (0xCC >> c) & 1, (0xF0 >> c) & 1)
+// The corner values of the MC_PER cubes a lane owns: rows[r][e] = value e (k0 .. k0 + MC_PER) of corner row r
+// (corners 0/4, 1/5, 2/6, 3/7 at k and k + 1).  Round 2 read every corner with its own 4-byte load (32 loads per
+// thread, each wave instruction a 1 KiB span with a quarter of it used): 1.4 TB/s at 257^3, bound by the
+// texture-address path, not by HBM.  Now the four rows arrive as four global_load_dwordx4 (a wave covers 1 KiB
+// contiguous per instruction) and the fifth value of each row comes from the next lane (same row) or one extra load at
+// a row's end.  `first` = the lane's first virtual cube; lanes of one wave own consecutive groups.
+__device__ __forceinline__ bool load_cube_rows(const float *__restrict__ vol, int G, const CubeSpace &cs, long long first,
+                                               int lane, int &i, int &j, int &k0, float (&rows)[4][MC_PER + 1]) {
     const bool live = first < cs.total;
-    int i = 0, j = 0, k0 = 0;
+    i = j = k0 = 0;
     if (live) virtual_ijk(cs, first, i, j, k0);
     const size_t gg = (size_t)G * G;
     const float *p = vol + (size_t)i * gg + (size_t)j * G + k0;
-    const float *rows[4] = {p, p + gg, p + gg + G, p + G};      // corners 0/4, 1/5, 2/6, 3/7 at k and k + 1
-    unsigned below[4];                                          // bit e: value k0 + e of the row is below iso
+    const float *src[4] = {p, p + gg, p + gg + G, p + G};
     const bool wide = live && k0 + MC_PER - 1 <= G - 1;         // the 16-byte load stays inside the row
-    float head[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        float v[MC_PER] = {0.f, 0.f, 0.f, 0.f};
-        if (wide) {
-            // (rows are G floats apart: 4-byte aligned only, which global_load_dwordx4 accepts)
-            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-            const f4u q = *reinterpret_cast<const f4u *>(rows[r]);
-            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-        } else if (live) {
-#pragma unroll
-            for (int e = 0; e < MC_PER; e++) v[e] = rows[r][min(e, G - 1 - k0)];
-        }
-        head[r] = v[0];
-        below[r] = 0;
-#pragma unroll
-        for (int e = 0; e < MC_PER; e++) below[r] |= (v[e] < iso) ? (1u << e) : 0u;
-    }
-    // value k0 + 4 of every row: the next lane's first value when that lane continues this row
     const bool next_same_row = lane < 63 && k0 + MC_PER < cs.per_row && first + MC_PER < cs.total;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        float v = __shfl_down(head[r], 1, 64);
-        if (live && !next_same_row) v = rows[r][min(MC_PER, G - 1 - k0)];
-        below[r] |= (v < iso) ? (1u << MC_PER) : 0u;
-    }
-    if (live) {
 #pragma unroll
-        for (int q = 0; q < MC_PER; q++) {
-            if (k0 + q >= cs.C) break;
-            int c = 0;
+        for (int e = 0; e < MC_PER; e++) rows[r][e] = 0.f;
+        if (wide) {
+            // (rows are G floats apart: 4-byte aligned only, which global_load_dwordx4 accepts)
+            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+            const f4u q = *reinterpret_cast<const f4u *>(src[r]);
+            rows[r][0] = q.x; rows[r][1] = q.y; rows[r][2] = q.z; rows[r][3] = q.w;
+        } else if (live) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                c |= ((below[r] >> q) & 1u) << r;
-                c |= ((below[r] >> (q + 1)) & 1u) << (4 + r);
-            }
-            n += tri_count[c];
+            for (int e = 0; e < MC_PER; e++) rows[r][e] = src[r][min(e, G - 1 - k0)];
         }
     }
-    // a wave's 64 x MC_PER consecutive virtual cubes are one block of MC_THREADS cubes of the emit pass: its sum is that
-    // block's entry, no exchange between the waves
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        float v = __shfl_down(rows[r][0], 1, 64);     // value k0 + MC_PER: the next lane's first one ...
+        if (live && !next_same_row) v = src[r][min(MC_PER, G - 1 - k0)];     // ... unless that lane starts another row
+        rows[r][MC_PER] = v;
+    }
+    return live;
+}
+// case index of cube q of the lane: bit c set when corner c is below iso (corner c = rows[c & 3][q + (c >> 2)])
+__device__ __forceinline__ int case_of_rows(const float (&rows)[4][MC_PER + 1], int q, float iso) {
+    int c = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        c |= (rows[r][q] < iso) ? (1 << r) : 0;
+        c |= (rows[r][q + 1] < iso) ? (1 << (4 + r)) : 0;
+    }
+    return c;
+}
+
+// Count pass: a wave's 64 x MC_PER consecutive virtual cubes are one UNIT of the emit pass; its entry is
+// (unit has triangles) << 32 | triangles, so one scan yields the triangle offsets and the list of non-empty units.
+__global__ __launch_bounds__(MC_THREADS) void mc_count_kernel(const float *__restrict__ vol, int G,
+                                                              float iso,
+                                                              const uint8_t *__restrict__ tri_count,
+                                                              unsigned long long *__restrict__ unit_sums, long long n_units) {
+    const CubeSpace cs = cube_space(G);
+    const long long first = ((long long)blockIdx.x * MC_THREADS + threadIdx.x) * MC_PER;
+    const int lane = threadIdx.x & 63;
+    int i, j, k0;
+    float rows[4][MC_PER + 1];
+    const bool live = load_cube_rows(vol, G, cs, first, lane, i, j, k0, rows);
+    int n = 0;
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < MC_PER; q++)
+            if (k0 + q < cs.C) n += tri_count[case_of_rows(rows, q, iso)];
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
-    const long long blk = (long long)blockIdx.x * (MC_BLOCK / MC_THREADS) + (threadIdx.x >> 6);
-    if (lane == 0 && blk < n_blocks) block_sums[blk] = n;
-    if (blockIdx.x == 0 && threadIdx.x == 0) block_sums[n_blocks] = 0;     // the scan turns it into the total
+    const long long unit = (long long)blockIdx.x * (MC_BLOCK / MC_THREADS) + (threadIdx.x >> 6);
+    if (lane == 0 && unit < n_units) unit_sums[unit] = ((unsigned long long)(n > 0 ? 1 : 0) << 32) | (unsigned)n;
+    if (blockIdx.x == 0 && threadIdx.x == 0) unit_sums[n_units] = 0;     // the scan turns it into the totals
 }
 
 // ---- scans over many workgroups, two launches -------------------------------------------------------------- //
@@ -260,43 +201,142 @@ __global__ __launch_bounds__(256) void scan_offsets_kernel(T *__restrict__ data,
 }
 static inline int scan_tiles(long long n) { return (int)((n + SCAN_TILE - 1) / SCAN_TILE); }
 
-// one cube per thread; a workgroup's MC_THREADS cubes are one entry of the count pass's block offsets
+// second scan launch of the count pass: offsets of the units (exclusive, both halves) and the list of non-empty ones
+__global__ __launch_bounds__(256) void mc_scan_offsets_kernel(const unsigned long long *__restrict__ sums,
+                                                              unsigned long long *__restrict__ offsets, long long n,
+                                                              const unsigned long long *__restrict__ tile_tot, int tiles,
+                                                              int *__restrict__ active_list, int *__restrict__ total_out,
+                                                              int *__restrict__ active_out) {
+    __shared__ unsigned long long lds[4];
+    __shared__ unsigned long long offset;
+    unsigned long long part = 0;
+    for (int t = threadIdx.x; t < (int)blockIdx.x; t += 256) part += tile_tot[t];
+    unsigned long long total;
+    (void)block256_exclusive<unsigned long long>(part, lds, total);
+    if (threadIdx.x == 0) offset = total;
+    __syncthreads();
+    const unsigned long long off = offset;
+    const long long b = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+    for (int e = 0; e < SCAN_ITEMS; e++)
+        if (b + e < n) {
+            const unsigned long long x = offsets[b + e] + off;
+            offsets[b + e] = x;
+            if (sums[b + e] >> 32) active_list[x >> 32] = (int)(b + e);
+        }
+    if (blockIdx.x == tiles - 1 && threadIdx.x == 0) {
+        const unsigned long long all = off + tile_tot[tiles - 1];
+        *total_out = (int)(all & 0xffffffffull);
+        *active_out = (int)(all >> 32);
+    }
+}
+// first scan launch with separate input and output (the unit sums stay intact for the second one)
+__global__ __launch_bounds__(256) void mc_scan_tiles_kernel(const unsigned long long *__restrict__ src,
+                                                            unsigned long long *__restrict__ dst, long long n,
+                                                            unsigned long long *__restrict__ tile_tot) {
+    __shared__ unsigned long long lds[4];
+    const long long b = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+    unsigned long long v[SCAN_ITEMS], sum = 0;
+#pragma unroll
+    for (int e = 0; e < SCAN_ITEMS; e++) {
+        v[e] = b + e < n ? src[b + e] : 0ull;
+        sum += v[e];
+    }
+    unsigned long long total;
+    unsigned long long run = block256_exclusive<unsigned long long>(sum, lds, total);
+#pragma unroll
+    for (int e = 0; e < SCAN_ITEMS; e++) {
+        if (b + e < n) dst[b + e] = run;
+        run += v[e];
+    }
+    if (threadIdx.x == 0) tile_tot[blockIdx.x] = total;
+}
+
+// Emit pass (round 3): one WAVE per non-empty unit (the count pass's list), so the volume is read only where the
+// surface is, with the count pass's 16-byte row loads; the unit's triangles are then spread over the lanes - lane t
+// builds triangle t of the unit from the owner cube's corner values in LDS - instead of every owner lane looping
+// over its own (most lanes of a unit own none).  Same vertex arithmetic, same order: bit-identical soup.
+constexpr unsigned long long kEdgeAPacked = 0x321047540310ull;      // edge e -> low-coordinate corner, 4 bits each
+constexpr unsigned kEdgeAxisPacked = 0xAA4444u;                      // edge e -> axis, 2 bits each
+constexpr int EMIT_VALS = 4 * (MC_PER + 1) + 1;                      // floats per lane in LDS (+1: bank skew)
+
 __global__ __launch_bounds__(MC_THREADS) void mc_emit_kernel(
     const float *__restrict__ vol, int G, float iso, const int8_t *__restrict__ tri_table,
-    int table_stride, const uint8_t *__restrict__ tri_count, const int *__restrict__ block_offsets,
-    float scale, float offset, float *__restrict__ tris, int max_tris) {
-    __shared__ int lds[MC_THREADS / 64];
-    // a block without triangles (most of them: the surface meets a few per cent of the k-rows) leaves at once, without
-    // touching the volume - the count pass already knows
-    const int block_first = block_offsets[blockIdx.x];
-    if (block_offsets[blockIdx.x + 1] == block_first) return;
-    const CubeSpace space = cube_space(G);
-    const long long cube = (long long)blockIdx.x * MC_THREADS + threadIdx.x;
-    int n = 0, cs = 0, i = 0, j = 0, k = 0;
-    float f[8];
-    if (cube < space.total) {
-        virtual_ijk(space, cube, i, j, k);
-        if (k < space.C) {
-            cube_corners(vol, G, i, j, k, f);
-            cs = case_of(f, iso);
-            n = tri_count[cs];
+    int table_stride, const uint8_t *__restrict__ tri_count, const unsigned long long *__restrict__ offsets,
+    const int *__restrict__ active_list, const int *__restrict__ n_active, float scale, float offset,
+    float *__restrict__ tris, int max_tris) {
+    __shared__ float s_vals[MC_THREADS / 64][64 * EMIT_VALS];
+    __shared__ unsigned short s_rec[MC_THREADS / 64][64 * MC_PER * 5];      // per triangle: lane << 5 | q << 3 | t
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long w = (long long)blockIdx.x * (MC_THREADS / 64) + wave;
+    if (w >= *n_active) return;
+    const int unit = active_list[w];
+    const int base = (int)(offsets[unit] & 0xffffffffull);
+    const CubeSpace cs = cube_space(G);
+    const long long first = ((long long)unit * 64 + lane) * MC_PER;
+    int i, j, k0;
+    float rows[4][MC_PER + 1];
+    const bool live = load_cube_rows(vol, G, cs, first, lane, i, j, k0, rows);
+    int cases[MC_PER], n[MC_PER], mine = 0;
+#pragma unroll
+    for (int q = 0; q < MC_PER; q++) {
+        cases[q] = 0;
+        n[q] = 0;
+        if (live && k0 + q < cs.C) {
+            cases[q] = case_of_rows(rows, q, iso);
+            n[q] = tri_count[cases[q]];
         }
+        mine += n[q];
     }
-    int total;
-    const int local = block_exclusive_scan(n, lds, total);
-    if (n == 0) return;
-    const int first = block_first + local;
-    for (int t = 0; t < n; t++) {
-        if (first + t >= max_tris) return;
-        float *o = tris + (size_t)(first + t) * 9;
+    int incl = mine;                                    // wave-inclusive scan of the lanes' triangle counts
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += y;
+    }
+    const int total = __shfl(incl, 63, 64);
+    float *sv = &s_vals[wave][lane * EMIT_VALS];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int e = 0; e <= MC_PER; e++) sv[r * (MC_PER + 1) + e] = rows[r][e];
+    int at = incl - mine;
+#pragma unroll
+    for (int q = 0; q < MC_PER; q++)
+        for (int t = 0; t < n[q]; t++) s_rec[wave][at++] = (unsigned short)((lane << 5) | (q << 3) | t);
+    // (one wave: LDS writes above are ordered before the reads below by the s_waitcnt the compiler places; no barrier)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int t0 = 0; t0 < total; t0 += 64) {
+        const int tix = t0 + lane;
+        if (tix >= total || base + tix >= max_tris) continue;
+        const int rec = s_rec[wave][tix];
+        const int owner = rec >> 5, q = (rec >> 3) & 3, t = rec & 7;
+        const float *ov = &s_vals[wave][owner * EMIT_VALS];
+        // the owner lane's cube: its case and position (all lanes of a unit share the row unless the unit wraps)
+        const long long ofirst = ((long long)unit * 64 + owner) * MC_PER;
+        int oi, oj, ok;
+        virtual_ijk(cs, ofirst, oi, oj, ok);
+        ok += q;
+        int cse = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            cse |= (ov[r * (MC_PER + 1) + q] < iso) ? (1 << r) : 0;
+            cse |= (ov[r * (MC_PER + 1) + q + 1] < iso) ? (1 << (4 + r)) : 0;
+        }
+        float *o = tris + (size_t)(base + tix) * 9;
 #pragma unroll
         for (int v = 0; v < 3; v++) {
-            const int e = tri_table[cs * table_stride + 3 * t + v];
-            const int a = kEdgeA[e], b = kEdgeB[e], axis = kEdgeAxis[e];
-            const float tt = (iso - f[a]) / (f[b] - f[a]);
-            const float px = (float)(i + kCornerX[a]) + (axis == 0 ? tt : 0.0f);
-            const float py = (float)(j + kCornerY[a]) + (axis == 1 ? tt : 0.0f);
-            const float pz = (float)(k + kCornerZ[a]) + (axis == 2 ? tt : 0.0f);
+            const int e = tri_table[cse * table_stride + 3 * t + v];
+            const int ca = (int)((kEdgeAPacked >> (4 * e)) & 15ull), axis = (int)((kEdgeAxisPacked >> (2 * e)) & 3u);
+            const int cb = ca + (axis == 0 ? ((ca & 3) == 0 ? 1 : -1) : axis == 1 ? ((ca & 3) == 0 ? 3 : 1) : 4);
+            const float fa = ov[(ca & 3) * (MC_PER + 1) + q + (ca >> 2)];
+            const float fb = ov[(cb & 3) * (MC_PER + 1) + q + (cb >> 2)];
+            const float tt = (iso - fa) / (fb - fa);
+            const float px = (float)(oi + ((0x66 >> ca) & 1)) + (axis == 0 ? tt : 0.0f);
+            const float py = (float)(oj + ((0xCC >> ca) & 1)) + (axis == 1 ? tt : 0.0f);
+            const float pz = (float)(ok + ((0xF0 >> ca) & 1)) + (axis == 2 ? tt : 0.0f);
             o[3 * v + 0] = fmaf(px, scale, offset);
             o[3 * v + 1] = fmaf(py, scale, offset);
             o[3 * v + 2] = fmaf(pz, scale, offset);
@@ -352,12 +392,32 @@ __global__ __launch_bounds__(256) void mesh_sample_kernel(const float *__restric
 
 }  // namespace
 
-static inline long long mc_blocks(int G) { return (cube_space(G).total + MC_THREADS - 1) / MC_THREADS; }
+static inline long long mc_units(int G) { return (cube_space(G).total + MC_THREADS - 1) / MC_THREADS; }
+
+// scratch of the count / emit passes, in 8-byte words: unit sums [nu + 1] | unit offsets [nu + 1] | scan tile totals |
+// active-unit list (ints) | n_active (int)
+struct McScratch {
+    unsigned long long *sums, *offsets, *tile_tot;
+    int *active, *n_active;
+    size_t bytes;
+};
+static inline McScratch mc_scratch(void *base, int G) {
+    const long long nu = mc_units(G);
+    const int tiles = scan_tiles(nu + 1);
+    unsigned long long *w = static_cast<unsigned long long *>(base);
+    McScratch m;
+    m.sums = w;
+    m.offsets = w + nu + 1;
+    m.tile_tot = m.offsets + nu + 1;
+    m.active = reinterpret_cast<int *>(m.tile_tot + tiles + 1);
+    m.n_active = m.active + nu + 1;
+    m.bytes = (size_t)(2 * (nu + 1) + tiles + 1) * 8 + (size_t)(nu + 4) * 4;
+    return m;
+}
 
 extern "C" size_t zs_mc_scratch_bytes(int G) {
     if (G < 2) return 0;
-    const long long nb = mc_blocks(G);
-    return (size_t)(nb + 2 + scan_tiles(nb + 1) + 1) * sizeof(int);    // block offsets + total | totals of the scan's tiles
+    return mc_scratch(nullptr, G).bytes;
 }
 
 extern "C" size_t zs_mesh_sample_scratch_doubles(int n_tris) {
@@ -374,17 +434,23 @@ extern "C" int zs_mc_count(const float *vol, int G, float iso, const uint8_t *tr
         zs::set_err("zs_mc_count: null pointer");
         return 0;
     }
+    if (reinterpret_cast<uintptr_t>(scratch) & 7) {
+        zs::set_err("zs_mc_count: scratch must be 8-byte aligned");
+        return 0;
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long long cubes = cube_space(G).total;
-    const long long nb = mc_blocks(G);
-    int *sums = static_cast<int *>(scratch);
+    const long long nu = mc_units(G);
+    const McScratch m = mc_scratch(scratch, G);
     hipLaunchKernelGGL(mc_count_kernel, dim3((unsigned)((cubes + MC_BLOCK - 1) / MC_BLOCK)), dim3(MC_THREADS), 0, s, vol, G, iso,
-                       tri_count, sums, nb);
-    // exclusive scan over the nb block sums and one trailing zero: offsets[b + 1] - offsets[b] = triangles of block b
-    int *tile_tot = sums + nb + 2;
-    const int tiles = scan_tiles(nb + 1);
-    hipLaunchKernelGGL((scan_tiles_kernel<int, false>), dim3(tiles), dim3(256), 0, s, sums, nb + 1, tile_tot);
-    hipLaunchKernelGGL(scan_offsets_kernel<int>, dim3(tiles), dim3(256), 0, s, sums, nb + 1, tile_tot, tiles, total);
+                       tri_count, m.sums, nu);
+    // exclusive scan over the nu unit sums and one trailing zero: triangle offsets in the low halves, the index of every
+    // non-empty unit among the non-empty ones in the high halves
+    const int tiles = scan_tiles(nu + 1);
+    hipLaunchKernelGGL(mc_scan_tiles_kernel, dim3(tiles), dim3(256), 0, s, static_cast<const unsigned long long *>(m.sums),
+                       m.offsets, nu + 1, m.tile_tot);
+    hipLaunchKernelGGL(mc_scan_offsets_kernel, dim3(tiles), dim3(256), 0, s, static_cast<const unsigned long long *>(m.sums),
+                       m.offsets, nu + 1, static_cast<const unsigned long long *>(m.tile_tot), tiles, m.active, total, m.n_active);
     return zs::check_launch("zs_mc_count") ? 1 : 0;
 }
 
@@ -400,10 +466,13 @@ extern "C" int zs_mc_emit(const float *vol, int G, float iso, const int8_t *tri_
         zs::set_err("zs_mc_emit: null pointer");
         return 0;
     }
-    const int nb = (int)mc_blocks(G);
-    hipLaunchKernelGGL(mc_emit_kernel, dim3(nb), dim3(MC_THREADS), 0, static_cast<hipStream_t>(stream),
-                       vol, G, iso, tri_table, table_stride, tri_count, static_cast<const int *>(scratch),
-                       scale, offset, tris, n_tris);
+    // one wave per non-empty unit; their number stays on the device (at most min(units, triangles))
+    const McScratch m = mc_scratch(const_cast<void *>(scratch), G);
+    const long long waves = mc_units(G) < (long long)n_tris ? mc_units(G) : (long long)n_tris;
+    hipLaunchKernelGGL(mc_emit_kernel, dim3((unsigned)((waves + MC_THREADS / 64 - 1) / (MC_THREADS / 64))), dim3(MC_THREADS), 0,
+                       static_cast<hipStream_t>(stream), vol, G, iso, tri_table, table_stride, tri_count,
+                       static_cast<const unsigned long long *>(m.offsets), static_cast<const int *>(m.active),
+                       static_cast<const int *>(m.n_active), scale, offset, tris, n_tris);
     return zs::check_launch("zs_mc_emit") ? 1 : 0;
 }
 
