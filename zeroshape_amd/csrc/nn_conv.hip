@@ -53,6 +53,7 @@ struct ConvArgs {
     int sk_per;
     int w_split;   // F16: the weights are already split (zs_conv2d_presplit_weight): quads 4s+q hold the hi halves and
                    // 4s+q+2 the lo halves of the K = 16 operand the lane half q contracts, q = 0, 1
+    int slab_major;   // LDS-DMA kernel, kh * kw > 1: walk K as (16-channel slab, tap) instead of (tap, channel) - see SlabWalk
 };
 
 // workspace layout (floats): [SK_COUNTERS ints, zero between launches][partial tiles / split-K partial sums]
@@ -123,6 +124,62 @@ struct TapWalk {
             kx++;
             if (kx == a.kw) { kx = 0; ky++; }
             set_tap(a, pix_ok, iy0, ix0);
+        }
+    }
+};
+
+// Slab-major walk (round 3 experiment, LDS-DMA kernel, opt-in ZS_CONV_SLAB_MAJOR=1): the k steps of a kh x kw layer in
+// the order (16-channel slab outer, tap inner) instead of (tap outer, channels inner).  Hypothesis: the
+// tap-major order streams all channels of a tap - 131 KiB per 128-row tile at 56 x 56 x 256 - before the next tap touches
+// the same input pixels again, 32 concurrent tiles per XCD overflow its 4 MiB L2, so every tap re-reads its activations
+// from beyond L2; slab-major puts the nine reads of an input pixel's 64-byte slab back to back.  MEASURED (tools/
+// conv_shapes.py, batch 28, same box): SLOWER - the 3 x 3 256 -> 256 layer at 56 x 56 516 vs 432 us, the 128 -> 32 head
+// at 224 x 224 1,611 vs 1,370 us, 20.2 vs 19.3 ms of convolutions per forward.  Where the re-reads are served from does
+// not matter: the kernel is bound by the BYTES it moves into LDS (the same in both orders), and tap-major reads each
+// pixel's channels as one sequential run over consecutive steps.  Only staging fewer bytes helps (an input patch kept
+// in LDS across the nine taps) - not built.  Same products, summed in another order; weights addressed by (tap, slab).
+struct SlabWalk {
+    int tap, cc, ky, kx;          // uniform across the workgroup / wave
+    bool ok;
+    size_t base;
+    __device__ __forceinline__ void set_tap(const ConvArgs &a, bool pix_ok, int iy0, int ix0) {
+        const int vy = iy0 + ky, vx = ix0 + kx, sh = a.dil - 1;
+        const int iy = vy >> sh, ix = vx >> sh;
+        ok = pix_ok && ky < a.kh && vy >= 0 && iy < a.Hin && vx >= 0 && ix < a.Win && ((vy | vx) & sh) == 0;
+        base = ok ? ((size_t)iy * a.Win + ix) * a.Cin : 0;
+    }
+    __device__ __forceinline__ void init(const ConvArgs &a, int step, bool pix_ok, int iy0, int ix0) {
+        const int ntaps = a.kh * a.kw;
+        if (a.slab_major) {
+            const int slab = step / ntaps;
+            tap = step - slab * ntaps;
+            cc = slab * BK;
+        } else {
+            const int k = BK * step;
+            tap = k / a.Cin;
+            cc = k - tap * a.Cin;
+        }
+        ky = tap / a.kw;
+        kx = tap - ky * a.kw;
+        set_tap(a, pix_ok, iy0, ix0);
+    }
+    __device__ __forceinline__ int kquad(const ConvArgs &a) const { return (tap * a.Cin + cc) >> 2; }   // row quad of the weights
+    __device__ __forceinline__ void advance(const ConvArgs &a, bool pix_ok, int iy0, int ix0) {
+        if (a.slab_major) {       // uniform
+            tap++;
+            kx++;
+            if (kx == a.kw) { kx = 0; ky++; }
+            if (tap == a.kh * a.kw) { tap = 0; kx = 0; ky = 0; cc += BK; }
+            set_tap(a, pix_ok, iy0, ix0);
+        } else {
+            cc += BK;
+            if (cc >= a.Cin) {
+                cc -= a.Cin;
+                tap++;
+                kx++;
+                if (kx == a.kw) { kx = 0; ky++; }
+                set_tap(a, pix_ok, iy0, ix0);
+            }
         }
     }
 };
@@ -450,7 +507,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DMA_NS == 2
     // [row][4 slots], slot = quad ^ ((row >> 2) & 3): the MFMA fragment reads (32 rows, one quad) stay conflict-free.
     // This wave issues instructions wave * MI + h (rows 16 (wave MI + h) + lane / 4), B: k-quad `wave`, columns lane, + 64.
     const int a_slot = lane & 3;
-    TapWalk tw[MI];
+    SlabWalk tw[MI];
     const float *src[MI];                                     // PW: the pixel's row; TM: the image
     bool pok[MI];
     int iy0[MI], ix0[MI];
@@ -472,7 +529,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DMA_NS == 2
             iy0[h] = py * a.stride - a.pad_t;
             ix0[h] = px * a.stride - a.pad_l;
             src[h] = a.in + (size_t)pb * a.Hin * a.Win * a.Cin;
-            tw[h].init(a, BK * kb, pok[h], iy0[h], ix0[h]);
+            tw[h].init(a, kb, pok[h], iy0[h], ix0[h]);
         }
     }
     const f32x4 *wcol = wq + n0 + lane;
@@ -485,6 +542,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DMA_NS == 2
         const unsigned dst = lds_base + st * STAGE_BYTES + wave * (MI * 1024);
         const unsigned dst_b = lds_base + st * STAGE_BYTES + KQ * TMB * 16 + wave * (BN * 16);
         const bool live = ks_issue < ke;                      // past the end: keep the vmcnt arithmetic, fetch zeros
+        const int wquad = PW ? ks_issue * KQ : tw[0].kquad(a);    // first weight row quad of this step (uniform)
 #pragma unroll
         for (int h = 0; h < MI; h++) {
             const char *g;
@@ -493,7 +551,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DMA_NS == 2
                 g = (live && pok[h] && k < a.K) ? reinterpret_cast<const char *>(src[h] + k) : zero;
             } else {
                 g = (live && tw[h].ok) ? reinterpret_cast<const char *>(src[h] + tw[h].base + tw[h].cc + 4 * a_quad) : zero;
-                if (live) tw[h].advance(a, BK, pok[h], iy0[h], ix0[h]);
+                if (live) tw[h].advance(a, pok[h], iy0[h], ix0[h]);
             }
 #if !defined(ZS_EXP_CONV_NO_DMA) && !defined(ZS_EXP_CONV_NO_DMA_A)
             dma16(g, dst + h * 1024);
@@ -501,7 +559,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DMA_NS == 2
         }
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const char *g = live ? reinterpret_cast<const char *>(wcol + (size_t)(ks_issue * KQ + wave) * a.CoutPad + 64 * h) : zero;
+            const char *g = live ? reinterpret_cast<const char *>(wcol + (size_t)(wquad + wave) * a.CoutPad + 64 * h) : zero;
 #if !defined(ZS_EXP_CONV_NO_DMA) && !defined(ZS_EXP_CONV_NO_DMA_B)
             dma16(g, dst_b + h * 1024);
 #endif
@@ -1081,6 +1139,7 @@ extern "C" int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const f
     const long long M = (long long)batch * Hout * Wout;
     if (M > (1LL << 30)) { zs::set_err("zs_conv2d_nhwc: %lld output pixels", M); return 0; }
     ConvArgs a;
+    a.slab_major = 0;
     a.in = in; a.w = packed_w; a.scale = scale; a.shift = shift; a.res1 = res1; a.res2 = res2; a.out = out;
     a.B = batch; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout;
     a.CoutPad = (Cout + BN - 1) / BN * BN;
@@ -1173,6 +1232,9 @@ extern "C" int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const f
         // pipelined kernel (ZS_CONV_NO_DMA=1: the register-staged one, for A/B measurements)
         static const bool no_dma = getenv("ZS_CONV_NO_DMA") != nullptr;
         const bool dma = f16 && a.w_split && !no_dma && (pw || tm) && in_scale == 1.0f && in_shift == 0.0f && (Cin % BK) == 0;
+        // ZS_CONV_SLAB_MAJOR=1: kh x kw layers walk K slab-major (SlabWalk).  OFF: measured slower (see SlabWalk)
+        static const bool slab_major = getenv("ZS_CONV_SLAB_MAJOR") && atoi(getenv("ZS_CONV_SLAB_MAJOR")) != 0;
+        a.slab_major = dma && !pw && slab_major && a.kh * a.kw > 1 ? 1 : 0;
         // Variants kept for A/B runs, all measured inside the batch-28 encoder (tools/conv_shapes.py, 19.8 ms of
         // GEMM time with the default): ZS_CONV_DMA_MI=4 = 256 x 128 workgroup tiles (wave tile 128 x 64, two workgroups
         // per CU, 25 % fewer bytes through LDS per MFMA): SLOWER, 21.1 ms (3x3 476 vs 425 us, fc1 179 vs 140 us);
