@@ -433,6 +433,12 @@ int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const float *scale
                    float in_scale, float in_shift, int act, void *workspace, void *stream);
 int zs_group_norm_nhwc(const float *x, const float *gamma, const float *beta, const float *residual, float *y,
                        int batch, int HW, int C, int groups, float eps, int relu, void *stream);
+/* The same with a workspace (zs_group_norm_workspace_bytes; NULL = zs_group_norm_nhwc): tensors of >= 8 MiB take two
+ * coalesced launches - per (sample, pixel chunk) group sums, then the normalisation - instead of one workgroup per
+ * (sample, group) slice (whose loads use a quarter of every cache line in NHWC).  Deterministic (fixed-order sums). */
+size_t zs_group_norm_workspace_bytes(int batch, int HW, int C, int groups);
+int zs_group_norm_nhwc_ws(const float *x, const float *gamma, const float *beta, const float *residual, float *y,
+                          int batch, int HW, int C, int groups, float eps, int relu, void *workspace, void *stream);
 int zs_layer_norm(const float *x, const float *gamma, const float *beta, float *y, int rows, int C, float eps,
                   void *stream);
 int zs_attention(const float *qkv, float *out, int batch, int L, int heads, int head_dim, void *stream);

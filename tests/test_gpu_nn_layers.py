@@ -151,6 +151,33 @@ def test_group_norm(C, HW, relu, res):
     close(got, nhwc(want))
 
 
+@pytest.mark.parametrize("B,C,HW,relu,res", [(9, 256, (56, 56), True, False), (5, 64, (112, 112), False, True),
+                                             (6, 128, (56, 60), True, True), (12, 64, (57, 43), False, False),
+                                             (3, 1024, (28, 28), True, True)])
+def test_group_norm_large_tensors_take_the_coalesced_two_launch_form(B, C, HW, relu, res, monkeypatch):
+    """Tensors of >= 8 MiB (the batch-28 encoder's ResNetV2 stages): zs_group_norm_nhwc_ws - per (sample, pixel chunk)
+    group sums, then the normalisation, both with full-line loads - against torch, against the one-launch kernel (same
+    double-precision statistics: a few ulp), reproducible run to run, ragged last chunks included."""
+    from zeroshape_amd.nn import ops
+    g = torch.Generator().manual_seed(C + B)
+    x = torch.randn(B, C, *HW, generator=g) * 3 + 1
+    assert x.numel() * 4 >= 8 << 20
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    r = torch.randn(B, C, *HW, generator=g) if res else None
+    want = F.group_norm(x, 32, gamma, beta, 1e-5)
+    if res:
+        want = want + r
+    if relu:
+        want = F.relu(want)
+    args = (nhwc(x).cuda(), gamma.cuda(), beta.cuda(), 32, 1e-5, relu, nhwc(r).cuda() if res else None)
+    got = ops.group_norm(*args)
+    close(got, nhwc(want))
+    assert torch.equal(got, ops.group_norm(*args))
+    monkeypatch.setattr(ops, "_group_norm_workspace", lambda device, nbytes: None)     # NULL workspace: one launch
+    one = ops.group_norm(*args)
+    assert float((one - got).abs().max()) <= 4e-6 * float(want.abs().max())
+
+
 def test_layer_norm():
     from zeroshape_amd.nn import ops
     g = torch.Generator().manual_seed(1)

@@ -101,6 +101,9 @@ SIGNATURES = {
                                                                      _c_void_p, _c_void_p]),
     "zs_group_norm_nhwc": (_c_int, [_c_void_p] * 5 + [_c_int, _c_int, _c_int, _c_int, ctypes.c_float, _c_int,
                                                       _c_void_p]),
+    "zs_group_norm_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int, _c_int]),
+    "zs_group_norm_nhwc_ws": (_c_int, [_c_void_p] * 5 + [_c_int, _c_int, _c_int, _c_int, ctypes.c_float, _c_int,
+                                       _c_void_p, _c_void_p]),
     "zs_layer_norm": (_c_int, [_c_void_p] * 4 + [_c_int, _c_int, ctypes.c_float, _c_void_p]),
     "zs_attention": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),
     "zs_attention_split": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p]),

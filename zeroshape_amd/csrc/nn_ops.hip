@@ -132,6 +132,107 @@ __global__ __launch_bounds__(GN_BLOCK) void group_norm_pow2_kernel(const float *
     }
 }
 
+// ---- large tensors (round 3): two coalesced launches instead of one workgroup per (sample, group) -------------- //
+// The kernels above give a (sample, group) slice to one workgroup.  In NHWC a slice is cg channels (32 bytes at
+// cg = 8) of every pixel, C * 4 bytes apart: a wave instruction touches 32 cache lines and uses a quarter of each, a
+// slice up to 112 KiB fills the LDS of a CU with ONE workgroup, and the big layers of the batch-28 encoder ran at
+// 1.4-2.1 TB/s (2.1 ms of 21 per forward).  Here a workgroup owns a run of PIXELS with all their channels: every load
+// is a full contiguous line, many workgroups per CU.  Launch 1 (gn_partial_kernel): per (sample, pixel chunk) the
+// sum and sum of squares of every group, in double, combined in a fixed order.  Launch 2 (gn_apply_kernel): every
+// workgroup adds up the chunks' partials of its sample (fixed order: deterministic), then normalises its own chunk.
+// x is read twice (the second time mostly from the Infinity Cache) and written once.  Same formulae as above.
+constexpr int GN2_THREADS = 256;
+__host__ __device__ inline int gn2_chunk_pixels(int C) {          // ~64 KiB of input per workgroup
+    const int p = 16384 / C;
+    return p < 16 ? 16 : p;
+}
+// thread t owns channel quad (t % quads) of the pixels po, po + step, ...; quads = C / 4 <= 256; a quad lies inside one
+// group (cg >= 4) or covers two (cg = 2: halves xy | zw)
+__global__ __launch_bounds__(GN2_THREADS) void gn_partial_kernel(const float *__restrict__ x, int HW, int C, int groups,
+                                                                 double *__restrict__ partial, int chunks) {
+    __shared__ double ss[2 * GN2_THREADS], sq[2 * GN2_THREADS];       // [half][thread]
+    const int b = blockIdx.y, chunk = blockIdx.x, quads = C >> 2, step = GN2_THREADS / quads;
+    const int cq = threadIdx.x % quads, po = threadIdx.x / quads;
+    const int cp = gn2_chunk_pixels(C), p0 = chunk * cp, p1 = min(HW, p0 + cp);
+    const f32x4 *xr = reinterpret_cast<const f32x4 *>(x + (size_t)b * HW * C);
+    double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
+    if (po < step)
+        for (int p = p0 + po; p < p1; p += step) {
+            const f32x4 v = xr[(size_t)p * quads + cq];
+            s0 += (double)v.x + (double)v.y;
+            q0 += (double)v.x * v.x + (double)v.y * v.y;
+            s1 += (double)v.z + (double)v.w;
+            q1 += (double)v.z * v.z + (double)v.w * v.w;
+        }
+    ss[threadIdx.x] = s0;
+    sq[threadIdx.x] = q0;
+    ss[GN2_THREADS + threadIdx.x] = s1;
+    sq[GN2_THREADS + threadIdx.x] = q1;
+    __syncthreads();
+    if ((int)threadIdx.x < groups) {
+        const int cg = C / groups;
+        double S = 0.0, Q = 0.0;
+        if (cg >= 4) {
+            const int qg = cg >> 2;                           // quads per group, both halves of each
+            for (int r = 0; r < step; r++)
+                for (int k = 0; k < qg; k++) {
+                    const int t = r * quads + threadIdx.x * qg + k;
+                    S += ss[t] + ss[GN2_THREADS + t];
+                    Q += sq[t] + sq[GN2_THREADS + t];
+                }
+        } else {                                              // cg = 2: group g = half (g & 1) of quad g / 2
+            const int h = (threadIdx.x & 1) * GN2_THREADS;
+            for (int r = 0; r < step; r++) {
+                S += ss[h + r * quads + (threadIdx.x >> 1)];
+                Q += sq[h + r * quads + (threadIdx.x >> 1)];
+            }
+        }
+        double *o = partial + (((size_t)b * chunks + chunk) * groups + threadIdx.x) * 2;
+        o[0] = S;
+        o[1] = Q;
+    }
+}
+__global__ __launch_bounds__(GN2_THREADS) void gn_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                               const float *__restrict__ beta, const float *__restrict__ res,
+                                                               float *__restrict__ y, int HW, int C, int groups, float eps,
+                                                               int relu, const double *__restrict__ partial, int chunks) {
+    __shared__ float s_mean[GN2_THREADS], s_rstd[GN2_THREADS];
+    const int b = blockIdx.y, chunk = blockIdx.x, quads = C >> 2, step = GN2_THREADS / quads;
+    if ((int)threadIdx.x < groups) {
+        double S = 0.0, Q = 0.0;
+        for (int c = 0; c < chunks; c++) {
+            const double *o = partial + (((size_t)b * chunks + c) * groups + threadIdx.x) * 2;
+            S += o[0];
+            Q += o[1];
+        }
+        const double n = (double)HW * (C / groups), mean_d = S / n;
+        double var = Q / n - mean_d * mean_d;
+        var = var < 0.0 ? 0.0 : var;
+        s_mean[threadIdx.x] = (float)mean_d;
+        s_rstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int cq = threadIdx.x % quads, po = threadIdx.x / quads;
+    if (po >= step) return;
+    const int cg = C / groups, g0 = (cq << 2) / cg, g1 = ((cq << 2) + 2) / cg;      // groups of the quad's halves
+    const f32x4 mean = {s_mean[g0], s_mean[g0], s_mean[g1], s_mean[g1]}, rstd = {s_rstd[g0], s_rstd[g0], s_rstd[g1], s_rstd[g1]};
+    const f32x4 ga = reinterpret_cast<const f32x4 *>(gamma)[cq], be = reinterpret_cast<const f32x4 *>(beta)[cq];
+    const int cp = gn2_chunk_pixels(C), p0 = chunk * cp, p1 = min(HW, p0 + cp);
+    const size_t base = (size_t)b * HW * quads;
+    const f32x4 *xr = reinterpret_cast<const f32x4 *>(x) + base;
+    const f32x4 *rr = res ? reinterpret_cast<const f32x4 *>(res) + base : nullptr;
+    f32x4 *yr = reinterpret_cast<f32x4 *>(y) + base;
+    for (int p = p0 + po; p < p1; p += step) {
+        const size_t o = (size_t)p * quads + cq;
+        f32x4 v = (xr[o] - mean) * rstd * ga + be;
+        if (rr) v += rr[o];
+        if (relu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        yr[o] = v;
+    }
+}
+
 // ---- LayerNorm over the last dimension, one wave per row ----
 __global__ __launch_bounds__(256) void layer_norm_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                          const float *__restrict__ beta, float *__restrict__ y,
@@ -501,6 +602,38 @@ inline hipStream_t S(void *s) { return static_cast<hipStream_t>(s); }
             return 0;                    \
         }                                \
     } while (0)
+
+extern "C" size_t zs_group_norm_workspace_bytes(int batch, int HW, int C, int groups) {
+    if (batch <= 0 || HW <= 0 || C <= 0 || groups <= 0) return 0;
+    const int chunks = (HW + gn2_chunk_pixels(C) - 1) / gn2_chunk_pixels(C);
+    return (size_t)batch * chunks * groups * 2 * sizeof(double);
+}
+
+// workspace (may be NULL: the one-launch kernels; else >= zs_group_norm_workspace_bytes): enables the coalesced two-launch
+// form for tensors of >= 8 MiB with 2, 4 or 8 channels per group (narrower slices than a cache line per pixel: where the
+// one-launch kernels waste most of every line; from 16 channels per group on they are as fast - measured, tools/bench_gn.py)
+extern "C" int zs_group_norm_nhwc_ws(const float *x, const float *gamma, const float *beta, const float *residual,
+                                     float *y, int batch, int HW, int C, int groups, float eps, int relu, void *workspace,
+                                     void *stream) {
+    ZS_REQUIRE(batch >= 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0,
+               "zs_group_norm_nhwc: bad size (B=%d HW=%d C=%d groups=%d)", batch, HW, C, groups);
+    if (batch == 0) return 1;
+    ZS_REQUIRE(x && gamma && beta && y, "zs_group_norm_nhwc: null pointer");
+    static const bool no_two = getenv("ZS_GN_ONE_LAUNCH") != nullptr;          // A/B switch for measurements
+    const int cg0 = C / groups;
+    if (workspace && !no_two && (C & 3) == 0 && C <= 4 * GN2_THREADS && (cg0 == 2 || cg0 == 4 || cg0 == 8) &&
+        groups <= GN2_THREADS && GN2_THREADS % (C >> 2) == 0 && batch <= 65535 &&
+        (size_t)batch * HW * C * sizeof(float) >= ((size_t)8 << 20)) {
+        const int chunks = (HW + gn2_chunk_pixels(C) - 1) / gn2_chunk_pixels(C);
+        double *partial = static_cast<double *>(workspace);
+        hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, batch), dim3(GN2_THREADS), 0, S(stream), x, HW, C, groups, partial,
+                           chunks);
+        hipLaunchKernelGGL(gn_apply_kernel, dim3(chunks, batch), dim3(GN2_THREADS), 0, S(stream), x, gamma, beta, residual, y,
+                           HW, C, groups, eps, relu, static_cast<const double *>(partial), chunks);
+        return zs::check_launch("zs_group_norm_nhwc") ? 1 : 0;
+    }
+    return zs_group_norm_nhwc(x, gamma, beta, residual, y, batch, HW, C, groups, eps, relu, stream);
+}
 
 extern "C" int zs_group_norm_nhwc(const float *x, const float *gamma, const float *beta, const float *residual,
                                   float *y, int batch, int HW, int C, int groups, float eps, int relu, void *stream) {

@@ -114,15 +114,30 @@ def linear(x, pc, res1=None, act=ACT_NONE):
     return y.view(*lead, pc.cout)
 
 
+_GN_WS = {}
+
+
+def _group_norm_workspace(device, nbytes):
+    """Per-device scratch of zs_group_norm_nhwc_ws (group sums per pixel chunk; grown on demand, address stable
+    between growths: a captured hipGraph bakes the pointer in, and nn.capture's warm-up runs size it first)."""
+    key = str(device)
+    if key not in _GN_WS or _GN_WS[key].numel() * 8 < nbytes:
+        _GN_WS[key] = torch.empty(max(nbytes // 8, 1 << 16), dtype=torch.float64, device=device)
+    return _GN_WS[key]
+
+
 def group_norm(x, gamma, beta, groups=32, eps=1e-5, relu=False, residual=None):
     lib = _lib.load()
     _chk(x, "group_norm input")
     B, H, W, C = x.shape
     y = torch.empty_like(x)
+    ws = None
+    if x.numel() * 4 >= (8 << 20):      # large tensors: the coalesced two-launch form (csrc/nn_ops.hip: gn_partial / gn_apply)
+        ws = _group_norm_workspace(x.device, lib.zs_group_norm_workspace_bytes(B, H * W, C, groups))
     with _lib.on(x.device):
-        _lib.check(lib.zs_group_norm_nhwc(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(residual),
-                                          _lib.ptr(y), B, H * W, C, groups, float(eps), 1 if relu else 0,
-                                          _stream(x)), "zs_group_norm_nhwc")
+        _lib.check(lib.zs_group_norm_nhwc_ws(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(residual),
+                                             _lib.ptr(y), B, H * W, C, groups, float(eps), 1 if relu else 0,
+                                             _lib.ptr(ws), _stream(x)), "zs_group_norm_nhwc")
     return y
 
 
