@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 28
+#define ZS_ABI_VERSION 29
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
