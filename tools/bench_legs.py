@@ -322,6 +322,8 @@ def train_leg(dev, steps=8, warmup=3):
     from zeroshape_amd.utils.options import EasyDict as edict
     from zeroshape_amd.model.shape_engine import Runner
 
+    counts = {}
+
     def run(amp):
         cmd = options.parse_arguments(["--yaml=%s/options/shape.yaml" % ROOT, "--output_root=/tmp/zs_bench_train",
                                        "--batch_size=4", "--pretrain.depth=", "--arch.depth.pretrained=",
@@ -353,6 +355,9 @@ def train_leg(dev, steps=8, warmup=3):
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / steps * 1e3
         ms_eager = None if amp else timed(warmup)
+        if not amp:                                 # C-ABI calls of one eager step (each is one to a few kernel launches)
+            counts["abi_calls"] = _count_abi_calls(step)
+            counts["grad_bytes"] = sum(p.numel() * 4 for p in r.graph.parameters() if p.requires_grad)
         opt.optim.hip_graph = True                  # forward + loss + backward replayed as one captured hipGraph
         ms = timed(warmup + 3)                      # two more eager steps, the capture, then replays
         assert getattr(r, "_captured", None) is not None
@@ -369,7 +374,36 @@ def train_leg(dev, steps=8, warmup=3):
     tflop = 3 * 4 * (GFLOP_DPT + GFLOP_RES + GFLOP_INTR + 4096 * 5.0e-3) / 1e3      # forward + 2x backward
     return {"per_gpu_batch": 4, "sdf_points": 4096, "ms": round(ms, 2), "mode": "fp32, optim.hip_graph (captured step)",
             "ms_eager": round(ms_eager, 2), "ms_amp": round(ms_amp, 2), "images_per_s": round(4 / ms * 1e3, 1),
-            "tflops": round(tflop / (ms * 1e-3), 1), "frac_of_f32_mfma_peak": round(tflop / (ms * 1e-3) / 157.3, 4)}
+            "tflops": round(tflop / (ms * 1e-3), 1), "frac_of_f32_mfma_peak": round(tflop / (ms * 1e-3) / 157.3, 4),
+            # one eager step's calls into libzeroshape_hip.so (a call is one to a few launches; a kernel trace counts
+            # ~2,000 launches per step, profiles/r02_train_b4_final_*) and what a data-parallel step all-reduces
+            "abi_calls_per_step": counts.get("abi_calls"), "allreduce_bytes_per_step": counts.get("grad_bytes"),
+            "allreduce": "fp32 gradients in 64 MB buckets under the backward pass (parallel.GradReducer); never run on > 1 GPU"}
+
+
+def _count_abi_calls(fn):
+    """Number of C-ABI calls fn() makes (the library handle is swapped for a counting proxy meanwhile)."""
+    from zeroshape_amd import _lib
+    real = _lib.load()
+    n = [0]
+
+    class Proxy(object):
+        def __getattr__(self, name):
+            f = getattr(real, name)
+            if not callable(f):
+                return f
+
+            def call(*a):
+                n[0] += 1
+                return f(*a)
+            return call
+    _lib._lib = Proxy()
+    try:
+        fn()
+        torch.cuda.synchronize()
+    finally:
+        _lib._lib = real
+    return n[0]
 
 
 def trained_leg(dev, iterations=304):
