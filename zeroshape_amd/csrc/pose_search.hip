@@ -395,34 +395,61 @@ __global__ __launch_bounds__(PS_TILE) void pose_pack_kernel(const float *__restr
 __device__ unsigned long long g_pose_blocks[2];   // [0] evaluated, [1] all
 #endif
 
-// 64 candidates of one sub-tile (uniform address -> scalar loads) against this lane's queries
+// 64 candidates of one sub-tile (uniform address -> scalar loads) against this lane's queries.  Two buffers of eight
+// candidates in ping-pong: the coordinates of the next eight are requested before the current eight are used.  hipcc
+// merges and sinks plain loads next to their use (one s_load_dwordx16 triple per 16 candidates, waited for at once), so
+// the loads and their wait are asm: scalar loads return out of order, only lgkmcnt(0) can wait for them, and with one
+// chunk in flight that wait covers exactly the chunk needed next.  The wait statement "returns" the chunk's registers, so
+// every consumer is ordered behind it.  (No LDS operation is outstanding inside the walk; all loads are drained on return.)
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+struct Chunk8 {
+    f32x8 x, y, z;
+    __device__ __forceinline__ void request(const float *c) {
+        asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx8 %1, %3, 0x100\n\ts_load_dwordx8 %2, %3, 0x200"
+                     : "=&s"(x), "=&s"(y), "=&s"(z) : "s"(c) : "memory");
+    }
+    // the same, pinned IN FRONT of the arithmetic on `held`: the statement "returns" held's registers too, so hipcc cannot
+    // sink the request below the distance code that overlaps its latency
+    __device__ __forceinline__ void request_before(const float *c, Chunk8 &held) {
+        asm volatile("s_load_dwordx8 %0, %6, 0x0\n\ts_load_dwordx8 %1, %6, 0x100\n\ts_load_dwordx8 %2, %6, 0x200"
+                     : "=&s"(x), "=&s"(y), "=&s"(z), "+s"(held.x), "+s"(held.y), "+s"(held.z) : "s"(c) : "memory");
+    }
+    __device__ __forceinline__ void arrived() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(x), "+s"(y), "+s"(z) : : "memory"); }
+};
+static_assert(PS_SUB * sizeof(float) == 0x100, "Chunk8::request addresses the y / z rows as immediates");
+template <bool D0, bool D1>
+__device__ __forceinline__ void scan_chunk(const Chunk8 &a, const float (&qx)[PS_Q], const float (&qy)[PS_Q],
+                                           const float (&qz)[PS_Q], float (&bestd)[PS_Q]) {
+#pragma unroll
+    for (int h = 0; h < 8; h += 4)
+#pragma unroll
+        for (int q = 0; q < PS_Q; q++) {
+            if ((q == 0 && !D0) || (q == 1 && !D1)) continue;
+            float d[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float dx = a.x[h + e] - qx[q];
+                const float dy = a.y[h + e] - qy[q];
+                const float dz = a.z[h + e] - qz[q];
+                d[e] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+            }
+            bestd[q] = fminf(bestd[q], fminf(fminf(d[0], d[1]), fminf(d[2], d[3])));
+        }
+}
 template <bool D0, bool D1>
 __device__ __forceinline__ void scan_subtile(const float *__restrict__ c, const float (&qx)[PS_Q], const float (&qy)[PS_Q],
                                              const float (&qz)[PS_Q], float (&bestd)[PS_Q]) {
-#pragma unroll 2
-    for (int k = 0; k < PS_SUB; k += 8) {
-        float ax[8], ay[8], az[8];
+    Chunk8 a, b;
+    a.request(c);
+    a.arrived();
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            ax[e] = c[k + e];
-            ay[e] = c[PS_SUB + k + e];
-            az[e] = c[2 * PS_SUB + k + e];
-        }
-#pragma unroll
-        for (int h = 0; h < 8; h += 4)
-#pragma unroll
-            for (int q = 0; q < PS_Q; q++) {
-                if ((q == 0 && !D0) || (q == 1 && !D1)) continue;
-                float d[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const float dx = ax[h + e] - qx[q];
-                    const float dy = ay[h + e] - qy[q];
-                    const float dz = az[h + e] - qz[q];
-                    d[e] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                }
-                bestd[q] = fminf(bestd[q], fminf(fminf(d[0], d[1]), fminf(d[2], d[3])));
-            }
+    for (int k = 0; k < PS_SUB; k += 16) {
+        b.request_before(c + k + 8, a);
+        scan_chunk<D0, D1>(a, qx, qy, qz, bestd);
+        b.arrived();
+        if (k + 16 < PS_SUB) a.request_before(c + k + 16, b);
+        scan_chunk<D0, D1>(b, qx, qy, qz, bestd);
+        if (k + 16 < PS_SUB) a.arrived();
     }
 }
 
@@ -447,7 +474,6 @@ __global__ __launch_bounds__(PS_THREADS) void pose_nn_soa_kernel(
     const int ncs = pack_subs(nc);
     const float *Csub = C + (size_t)ncs * PS_SUB_FLOATS, *Ctile = Csub + (size_t)ncs * 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-
     float qx[PS_Q], qy[PS_Q], qz[PS_Q], bestd[PS_Q];
     float rlo[PS_Q][3], rhi[PS_Q][3];       // boxes of this wave's two runs of 64 queries (wave-uniform)
 #pragma unroll
@@ -507,6 +533,8 @@ __global__ __launch_bounds__(PS_THREADS) void pose_nn_soa_kernel(
             float gm = INFINITY;
             bool cand = false;
             if (lane < PS_NSUB) {
+                // (read from global memory per tile; a copy of all boxes in LDS was measured: no faster, the other waves
+                // of the SIMD cover this round trip)
                 const float *bsub = Csub + ((size_t)t * PS_NSUB + lane) * 8;
 #pragma unroll
                 for (int a = 0; a < 3; a++) {
