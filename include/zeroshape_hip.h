@@ -20,6 +20,7 @@
  *   zs_bf_lower_bounds   <- pruning for brute_force_search, utils/eval_3D.py:140-170
  *   zs_pose_search_batch <- one batch of brute_force_search, utils/eval_3D.py:149-168
  *   zs_normalize_pc      <- normalize_pc, utils/eval_3D.py:93-102
+ *   zs_standardize_pc, zs_icp_step <- standardize_pc, ICP, utils/eval_3D.py:83-91, 271-284
  *   zs_fscore            <- compute_fscore, utils/eval_3D.py:215-231
  *   zs_mc_*, zs_mesh_*   <- convert_to_explicit, utils/eval_3D.py:233-263 (PyMCubes
  *                           marching_cubes + trimesh.sample on the host)
@@ -278,6 +279,15 @@ int zs_pose_search_batch_sorted(const float *pred, const float *pred_sorted, int
 int zs_pose_apply(const float *pred, int n, const float *rotations, const int *index, float *out,
                   void *scratch, void *stream);
 int zs_normalize_pc(const float *pc, int b, int n, float *out, void *scratch, void *stream);
+/* standardize_pc (utils/eval_3D.py:83-91): zero mean, RMS distance from the origin 1/2; pc, out [b][n][3].
+ * zs_icp_step: one iteration of the reference's ICP (utils/eval_3D.py:276-283) after its Chamfer call: idx1 [b][n] =
+ * nearest neighbour of x1's points in x2 (zs_chamfer_forward's idx1) -> centroids, 3x3 cross-covariance (double sums),
+ * R = V U^T from its SVD (Jacobi on the device) with the reference's sign rule, x1_out = (x1 - t1) R^T + t2.  x1_out
+ * must not alias x1.  scratch: zs_icp_scratch_bytes(b) (R, t1, t2 per batch element stay there). */
+int zs_standardize_pc(const float *pc, int b, int n, float *out, void *stream);
+size_t zs_icp_scratch_bytes(int b);
+int zs_icp_step(const float *x1, int n, const float *x2, int m, const int *idx1, int b, float *x1_out, void *scratch,
+                void *stream);
 int zs_fscore(const float *dist1, int n, const float *dist2, int m, int b, const float *thresholds,
               int n_thresholds, float *out, void *stream);
 

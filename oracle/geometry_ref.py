@@ -53,6 +53,31 @@ def chamfer_distance(X1, X2):
             torch.from_numpy(i1), torch.from_numpy(i2))
 
 
+def standardize_pc(pc):
+    """utils/eval_3D.py:83-91: zero mean, RMS distance from the origin 1/2."""
+    assert len(pc.shape) == 3
+    pc_zmean = pc - pc.mean(dim=1, keepdim=True)
+    origin_distance = (pc_zmean ** 2).sum(dim=2, keepdim=True).sqrt()
+    scale = torch.sqrt(torch.sum(origin_distance ** 2, dim=1, keepdim=True) / pc.shape[1])
+    return pc_zmean / (scale * 2)
+
+
+def icp(X1, X2, num_iter=50):
+    """utils/eval_3D.py:271-284: point-to-point ICP of X1 [B,n,3] onto X2 [B,m,3] - nearest neighbours (the Chamfer
+    kernel's indices), centroids, R = V U^T from the SVD of the 3x3 cross-covariance, the reference's own sign rule
+    (row 2 of R negated when det R < 0), X1 <- (X1 - t1) R^T + t2."""
+    assert len(X1) == len(X2)
+    for _ in range(num_iter):
+        _, _, idx, _ = chamfer_distance(X1, X2)
+        X2c = torch.stack([X2[i][idx[i].long()] for i in range(len(X1))])
+        t1, t2 = X1.mean(dim=-2, keepdim=True), X2c.mean(dim=-2, keepdim=True)
+        U, S, V = ((X1 - t1).transpose(1, 2) @ (X2c - t2)).svd(some=True)
+        R = V @ U.transpose(1, 2)
+        R[R.det() < 0, 2] *= -1
+        X1 = (X1 - t1) @ R.transpose(1, 2) + t2
+    return X1
+
+
 def _rot_y(azim_deg):
     # utils/camera.py:150-167 ('angle')
     a = torch.tensor([azim_deg]) * np.pi / 180

@@ -420,3 +420,30 @@ def test_culled_scan_equals_all_pairs_on_10k_points(case):
         b = E.brute_force_search(pred, gt, device="cuda", rot_slice=(k, k + 1), return_index=True, prune=False, nn="brute")
         a = E.brute_force_search(pred, gt, device="cuda", rot_slice=(k, k + 1), return_index=True, prune=False, nn="cull")
         assert a[6] == b[6] and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), (case, k)
+
+
+def test_standardize_pc_and_icp_vs_oracle_and_reference_golden():
+    """zs_standardize_pc / zs_icp_step (the reference's utils/eval_3D.py:83-91, :271-284 without ATen or LAPACK in the
+    loop) against the outputs of the REAL reference (tests/golden/icp_golden.npz) and the oracle: the rotation comes
+    from a device-side Jacobi SVD in double, the reference's from torch.svd on an fp32 matrix - 1e-5 after 50 iterations."""
+    import os
+    from zeroshape_amd.utils import eval_3D as E
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "icp_golden.npz")))
+    a, b = syn.icp_clouds()
+    A, B = torch.from_numpy(a), torch.from_numpy(b)
+    x = A * torch.tensor([2.0, 1.0, 3.0]) + 0.3
+    got = E.standardize_pc(x.cuda()).cpu()
+    np.testing.assert_allclose(got.numpy(), g["standardize_pc_out"], rtol=0, atol=3e-7)
+    np.testing.assert_allclose(got.numpy(), G.standardize_pc(x).numpy(), rtol=0, atol=3e-7)
+    for it in (1, 3, 50):
+        out = E.ICP(None, A.cuda(), B.cuda(), num_iter=it).cpu().numpy()
+        np.testing.assert_allclose(out, g["icp_%d" % it], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(out, G.icp(A.clone(), B.clone(), it).numpy(), rtol=0, atol=1e-5)
+    # reflections and degenerate clouds: the sign rule is the reference's (row 2 negated), a planar cloud does not blow up
+    flat = A.clone()
+    flat[..., 2] = 0
+    out = E.ICP(None, flat.cuda(), (flat * torch.tensor([1.0, -1.0, 1.0])).cuda(), num_iter=3).cpu()
+    assert bool(torch.isfinite(out).all())
+    np.testing.assert_allclose(out.numpy(), G.icp(flat.clone(), flat * torch.tensor([1.0, -1.0, 1.0]), 3).numpy(), rtol=0, atol=2e-4)
+    with pytest.raises(ValueError):
+        E.standardize_pc(x)                      # CPU tensors are rejected, not emulated

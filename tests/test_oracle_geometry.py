@@ -44,3 +44,19 @@ def test_brute_force_search_recovers_known_rotation():
     # duplicated rotation later in the list must NOT replace the first minimum
     sub2 = torch.cat([sub, sub[30:31]], 0)
     assert G.brute_force_search(pred, gt, rotations=sub2)[5] == 30
+
+
+def test_standardize_pc_and_icp_vs_reference_golden():
+    """oracle/geometry_ref.standardize_pc / icp against the outputs of the real reference's utils/eval_3D.py:83-91,
+    :271-284 (tests/golden/make_icp_golden.py; the reference's Chamfer plugin replaced there by a float64 cdist)."""
+    import os
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "icp_golden.npz")))
+    a, b = syn.icp_clouds()
+    A, B = torch.from_numpy(a), torch.from_numpy(b)
+    got = G.standardize_pc(A * torch.tensor([2.0, 1.0, 3.0]) + 0.3)
+    np.testing.assert_allclose(got.numpy(), g["standardize_pc_out"], rtol=0, atol=2e-7)
+    for it in (1, 3, 50):
+        np.testing.assert_allclose(G.icp(A.clone(), B.clone(), it).numpy(), g["icp_%d" % it], rtol=0, atol=2e-6)
+    # it converges onto the rotated copy: residual at the noise level
+    d1, _, _, _ = G.chamfer_distance(torch.from_numpy(g["icp_50"]), B)
+    assert float(d1.mean()) < 0.02

@@ -74,6 +74,9 @@ SIGNATURES = {
                                              _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                                              _c_int, _c_void_p]),
     "zs_pose_apply": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "zs_standardize_pc": (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "zs_icp_scratch_bytes": (_c_size_t, [_c_int]),
+    "zs_icp_step": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "zs_normalize_pc": (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "zs_fscore": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p]),
     "zs_mc_scratch_bytes": (_c_size_t, [_c_int]),

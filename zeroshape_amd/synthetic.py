@@ -97,6 +97,18 @@ def seeded_cloud(seed, batch, n, lo=-0.5, hi=0.5):
     return rs.uniform(lo, hi, size=(batch, n, 3)).astype(np.float32)
 
 
+def icp_clouds():
+    """(a [2,400,3], b [2,350,3]): a flattened uniform cloud and a rotated (0.35 rad about z), shifted, slightly noisy
+    subset of it - the ICP fixture (tests/golden/make_icp_golden.py; well separated points, no near ties)."""
+    rs = np.random.RandomState(21)
+    a = seeded_cloud(31, 2, 400, -0.5, 0.5) * np.array([1.0, 0.7, 0.4], np.float32)
+    ang = 0.35
+    R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], np.float32)
+    b = a @ R.T + np.array([0.05, -0.03, 0.02], np.float32) + 2e-3 * rs.randn(*a.shape).astype(np.float32)
+    b = b[:, rs.permutation(400)[:350]]
+    return a.astype(np.float32), b.astype(np.float32)
+
+
 def ellipsoid_cloud(seed, n, radii=(0.5, 0.35, 0.25)):
     """points on an axis-aligned ellipsoid surface (brute-force-search test shape)."""
     rs = np.random.RandomState(seed + 15485863)

@@ -12,10 +12,10 @@ argument meaning and return values, running on the hand-written HIP kernels.
   eval_metrics(_default|_BF)  utils/eval_3D.py:104-138,172-213
   convert_to_explicit utils/eval_3D.py:233-263  (GPU marching cubes + sampling)
 
-torch is used here for device memory, streams and the tiny elementwise glue the
-reference also does in torch (means, extents, thresholds); the heavy steps - the
-decoder over the dense grid and the nearest-neighbour search - are the HIP
-kernels, and they raise if libzeroshape_hip.so is missing (no fallback).
+torch is used here for device memory, streams and orchestration; every numeric step -
+the decoder over the dense grid, the nearest-neighbour searches, normalisation, F-score,
+ICP, iso-surface extraction - is a HIP kernel behind the C ABI and raises if
+libzeroshape_hip.so is missing (no fallback).
 
 ``convert_to_explicit`` (utils/eval_3D.py:233-263: PyMCubes + trimesh on the host in the
 reference) runs on the GPU here: csrc/marching_cubes.hip.
@@ -148,21 +148,24 @@ def _attention_frames(opt, attn, images, batch_size, N):
     return images_vis
 
 
-@torch.no_grad()
-def standardize_pc(pc):
-    """utils/eval_3D.py:83-91."""
-    assert len(pc.shape) == 3
-    pc_mean = pc.mean(dim=1, keepdim=True)
-    pc_zmean = pc - pc_mean
-    origin_distance = (pc_zmean ** 2).sum(dim=2, keepdim=True).sqrt()
-    scale = torch.sqrt(torch.sum(origin_distance ** 2, dim=1, keepdim=True) / pc.shape[1])
-    return pc_zmean / (scale * 2)
-
-
 def _gpu_f32(t, what):
     if not t.is_cuda:
         raise ValueError("%s must be a GPU tensor; zeroshape_amd has no CPU path" % what)
     return t.detach().to(torch.float32).contiguous()
+
+
+@torch.no_grad()
+def standardize_pc(pc):
+    """utils/eval_3D.py:83-91: zs_standardize_pc."""
+    from .. import _lib
+    assert len(pc.shape) == 3 and pc.shape[2] == 3
+    lib = _lib.load()
+    x = _gpu_f32(pc, "pc")
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = lib.zs_standardize_pc(_lib.ptr(x), x.shape[0], x.shape[1], _lib.ptr(out), _lib.current_stream_ptr(x.device))
+    _lib.check(rc, "zs_standardize_pc")
+    return out
 
 
 @torch.no_grad()
@@ -508,21 +511,28 @@ def eval_metrics(opt, var, impl_network, vis_only=False):
     return eval_metrics_default(opt, var, impl_network, vis_only)
 
 
+@torch.no_grad()
 def ICP(opt, X1, X2, num_iter=50):
-    """utils/eval_3D.py:271-284."""
+    """utils/eval_3D.py:271-284: every iteration is the Chamfer call + zs_icp_step (centroids, 3x3 cross-covariance, its SVD
+    by Jacobi rotations, the reference's sign rule and the rigid update on the device: no ATen / LAPACK call, no host
+    read in the loop)."""
+    from .. import _lib
     assert len(X1) == len(X2)
+    lib = _lib.load()
+    x1, x2 = _gpu_f32(X1, "X1"), _gpu_f32(X2, "X2")
+    B, n, m = x1.shape[0], x1.shape[1], x2.shape[1]
+    scratch = torch.empty(max(1, lib.zs_icp_scratch_bytes(B) // 4), dtype=torch.float32, device=x1.device)
+    nxt = torch.empty_like(x1)
+    if x1.data_ptr() == X1.data_ptr():
+        x1 = x1.clone()                         # the caller's tensor is not updated in place (the reference rebinds X1)
     for it in range(num_iter):
-        d1, d2, idx, _ = chamfer_distance(opt, X1, X2)
-        X2_corresp = torch.zeros_like(X1)
-        for i in range(len(X1)):
-            X2_corresp[i] = X2[i][idx[i].long()]
-        t1 = X1.mean(dim=-2, keepdim=True)
-        t2 = X2_corresp.mean(dim=-2, keepdim=True)
-        U, S, V = ((X1 - t1).transpose(1, 2) @ (X2_corresp - t2)).svd(some=True)
-        R = V @ U.transpose(1, 2)
-        R[R.det() < 0, 2] *= -1
-        X1 = (X1 - t1) @ R.transpose(1, 2) + t2
-    return X1
+        _, _, idx, _ = chamfer_distance(opt, x1, x2)
+        with torch.cuda.device(x1.device):
+            rc = lib.zs_icp_step(_lib.ptr(x1), n, _lib.ptr(x2), m, _lib.ptr(idx), B, _lib.ptr(nxt), _lib.ptr(scratch),
+                                 _lib.current_stream_ptr(x1.device))
+        _lib.check(rc, "zs_icp_step")
+        x1, nxt = nxt, x1
+    return x1
 
 
 class SimpleMesh(object):
