@@ -248,6 +248,50 @@ def test_adamw_multi_tensor_matches_torch():
     assert sd["state"][0]["step"] == 4 and sd["state"][0]["exp_avg"].shape == (300, 70)
 
 
+@pytest.mark.parametrize("cfg", [
+    # B, H, W, Cin, Cout, k, stride, pad, bias, in_relu, in_scale      (tile 128 / 64, pointwise / fast / generic loaders)
+    (4, 56, 56, 64, 256, 1, 1, 0, True, False, 1.0),
+    (4, 14, 14, 256, 256, 3, 1, 1, False, False, 1.0),
+    (2, 28, 28, 128, 128, 3, 2, 1, True, False, 1.0),
+    (4, 1, 197, 768, 3072, 1, 1, 0, True, False, 1.0),
+    (2, 12, 12, 64, 64, 3, 1, 1, True, True, 0.70710678),
+    (3, 5, 7, 36, 20, 3, 1, 1, False, False, 1.0),
+    (1, 9, 9, 32, 3, 1, 1, 0, True, False, 1.0),
+])
+def test_weight_gradient_in_split_fp16(cfg, monkeypatch):
+    """zs_conv2d_wgrad with ZS_CONV_F16X3 (wgrad_split_kernel: the loader splits into fp16 halves and stores pixel pairs,
+    three 16-bit MFMAs per 16 pixels) against torch autograd and against the fp32-MFMA kernel: the operand error of the
+    split is 2^-22, so the two kernels agree to a few 1e-7 of the gradient's scale; ragged channel counts, partial pixel
+    splits, strides, padding and the input transform included; the bias gradient is the same fp32 sum in both."""
+    from zeroshape_amd.nn import autograd as A
+    B, H, W, Cin, Cout, k, stride, pad, use_bias, in_relu, in_scale = cfg
+    g = torch.Generator().manual_seed(B * 1000 + H * 37 + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g) if use_bias else None
+    xr, wr = x.clone(), w.clone().requires_grad_(True)
+    br = None if b is None else b.clone().requires_grad_(True)
+    y = F.conv2d((F.relu(xr) if in_relu else xr) * in_scale, wr, br, stride=stride, padding=pad)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    grads = {}
+    for prec in ("f32", "f16x3"):
+        monkeypatch.setattr(A, "BWD_WGRAD_PRECISION", prec)
+        xg = nhwc(x).cuda()
+        wg = w.cuda().requires_grad_(True)
+        bg = None if b is None else b.cuda().requires_grad_(True)
+        yg = A.conv2d(xg, wg, bg, stride=stride, padding=pad, in_relu=in_relu, in_scale=in_scale)
+        yg.backward(nhwc(gy).cuda())
+        grads[prec] = (wg.grad.clone(), None if bg is None else bg.grad.clone())
+        close(wg.grad, wr.grad, what="wgrad " + prec)
+        if b is not None:
+            close(bg.grad, br.grad, what="dbias " + prec)
+    scale = float(wr.grad.abs().max())
+    assert float((grads["f32"][0] - grads["f16x3"][0]).abs().max()) <= 3e-6 * scale
+    if b is not None:
+        assert torch.equal(grads["f32"][1], grads["f16x3"][1])
+
+
 def test_overflow_steps_do_not_count_as_adamw_steps():
     """GradScaler semantics: on an overflow torch never calls optimizer.step(), so neither the bias
     correction nor the checkpointed `step` advance.  Two of five LossScaler steps carry an inf gradient: parameters

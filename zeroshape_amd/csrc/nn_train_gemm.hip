@@ -9,6 +9,7 @@
 // stride 2).  Used by: Implicit (model/shape/implicit.py) in training, DPT / ResNet encoders
 // (training half).
 #include "zs_common.h"
+#include "zs_split16.h"
 #include "../../include/zeroshape_hip.h"
 
 #include <math.h>
@@ -352,6 +353,208 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same weight gradient in split-fp16 arithmetic (round 3; optim.amp): dW = dY^T A contracts over PIXELS, the
+// row index of both operands in memory, so the MFMA operands (eight consecutive k = pixels per lane) are columns of
+// the staged tiles.  Gathering them at the MFMA (8 LDS reads + a split per operand and K-block) is VALU-bound - why
+// round 2 priced this kernel and did not build it.  Here the LOADER splits once and stores PIXEL PAIRS: a thread that
+// holds the channel quad of two adjacent pixels packs (pixel p, pixel p + 1) of each channel into one 32-bit word of
+// fp16 heads and one of fp16 remainders (csrc/zs_split16.h); LDS is [pixel pair 0..7][column], so its four channels
+// are ONE ds_write_b128 per operand half (a wave writes 1 KiB contiguous), and the MFMA operand of a lane - eight
+// consecutive pixels of one column - is the four words (pair 4 half + t, column), t = 0..3: plain ds_read_b32 with
+// consecutive lanes on consecutive banks (rows of T + 8 words put the two lane halves on disjoint banks), no VALU.
+// A step of 16 pixels is 3 MFMAs of 32 cycles per 32 x 32 output tile instead of 8 fp32 MFMAs of 64.  Same tiles,
+// pixel splits, partial layout and reduce kernel as wgrad_kernel; the bias gradient stays an fp32 sum.
+// ---------------------------------------------------------------------------------------------
+template <int T, int MODE>
+__global__ __launch_bounds__(256) void wgrad_split_kernel(WgradArgs a) {
+    using zs::s16::u32x4;
+    constexpr bool PW = MODE == 1, FAST = MODE == 2;
+    constexpr int QUADS = T / 4, ROWS = 256 / QUADS, PASSES = WP / ROWS, NI = T / 64;
+    static_assert(WP == 16 && (PASSES == 1 || PASSES == 2), "one K-block of 16 pixels per step");
+    constexpr int RS = T + 8;                   // words per pixel-pair row
+    // [buffer][operand: dY | A][half: hi | lo][pixel pair][column], a word = fp16 (pixel 2 w) | fp16 (pixel 2 w + 1) << 16
+    __shared__ __attribute__((aligned(16))) unsigned lds[2][2][2][(WP / 2) * RS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, half = lane >> 5;
+    const int c0 = blockIdx.x * T, k0 = blockIdx.y * T;
+    const int p_begin = blockIdx.z * a.pix_per_split, p_end = min(a.M, p_begin + a.pix_per_split);
+    // loader role: column quad tid % QUADS of the pixel rows PASSES * (tid / QUADS) + q of the step (adjacent rows)
+    const int prow = tid / QUADS, quad = tid % QUADS;
+    const int yc = c0 + 4 * quad;
+    const bool yc_ok = yc < a.CoutP;
+    const int kk = k0 + 4 * quad;
+    const bool k_ok = kk < a.K;
+    int kc = 0, ky = 0, kx = 0;
+    if (k_ok) {
+        const int tap = kk / a.Cin;
+        kc = kk - tap * a.Cin;
+        ky = tap / a.kw;
+        kx = tap - ky * a.kw;
+    }
+    const float relu_floor = a.in_relu ? 0.f : -INFINITY;
+    const int HW = a.Hout * a.Wout;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    struct Frag { f32x4 y, x; bool ok; };
+    int qb[PASSES], qy[PASSES], qx[PASSES];
+#pragma unroll
+    for (int q = 0; q < PASSES; q++) {
+        const int p = p_begin + PASSES * prow + q;
+        qb[q] = p / HW;
+        const int rem = p - qb[q] * HW;
+        qy[q] = rem / a.Wout;
+        qx[q] = rem - qy[q] * a.Wout;
+    }
+    auto load = [&](int p, int q) -> Frag {
+        Frag f;
+        const bool p_ok = p < p_end;
+        const int pc = p_ok ? p : p_begin;
+        f.y = (yc_ok && p_ok) ? *reinterpret_cast<const f32x4 *>(a.dy + (size_t)pc * a.CoutP + yc) : f32x4{0, 0, 0, 0};
+        if (PW) {
+            f.ok = p_ok && k_ok;
+            f.x = *reinterpret_cast<const f32x4 *>(a.in + (f.ok ? (size_t)pc * a.Cin + kk : 0));
+            return f;
+        }
+        int pb, py, px;
+        if (FAST) {
+            pb = qb[q]; py = qy[q]; px = qx[q];
+            qx[q] += WP;
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+                if (qx[q] >= a.Wout) { qx[q] -= a.Wout; qy[q]++; }
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+                if (qy[q] >= a.Hout) { qy[q] -= a.Hout; qb[q]++; }
+        } else {
+            pb = pc / HW;
+            const int rem = pc - pb * HW;
+            py = rem / a.Wout;
+            px = rem - py * a.Wout;
+        }
+        const int iy = py * a.stride - a.pad_t + ky, ix = px * a.stride - a.pad_l + kx;
+        f.ok = p_ok && k_ok && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        if (FAST) {
+            const int off = f.ok ? ((pb * a.Hin + iy) * a.Win + ix) * a.Cin + kc : 0;
+            f.x = *reinterpret_cast<const f32x4 *>(a.in + off);
+        } else {
+            const size_t off = f.ok ? (((size_t)pb * a.Hin + iy) * a.Win + ix) * a.Cin + kc : 0;
+            f.x = *reinterpret_cast<const f32x4 *>(a.in + off);
+        }
+        return f;
+    };
+    auto operand = [&](const Frag &f) -> f32x4 {       // the A operand's values of one pixel (transform + padding applied)
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            v[e] = (PW || FAST) ? (f.ok ? f.x[e] : 0.f) : (f.ok ? fmaxf(f.x[e], relu_floor) * a.in_scale + a.in_shift : 0.f);
+        return v;
+    };
+    auto store = [&](int buf, const Frag (&f)[PASSES]) {
+        if (PASSES == 2) {       // words of (pixel 2 prow, pixel 2 prow + 1) of the thread's four columns: one b128 each
+            const f32x4 x0 = operand(f[0]), x1 = operand(f[PASSES - 1]);
+            u32x4 hy, ly, hx, lx;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                unsigned h, l;
+                zs::s16::split2(f[0].y[e], f[PASSES - 1].y[e], h, l);
+                hy[e] = h; ly[e] = l;
+                zs::s16::split2(x0[e], x1[e], h, l);
+                hx[e] = h; lx[e] = l;
+            }
+            const int w = prow * RS + 4 * quad;
+            *reinterpret_cast<u32x4 *>(&lds[buf][0][0][w]) = hy;
+            *reinterpret_cast<u32x4 *>(&lds[buf][0][1][w]) = ly;
+            *reinterpret_cast<u32x4 *>(&lds[buf][1][0][w]) = hx;
+            *reinterpret_cast<u32x4 *>(&lds[buf][1][1][w]) = lx;
+            bsum += f[0].y + f[PASSES - 1].y;
+        } else {                 // one pixel per thread: its half of each word, 16-bit stores
+            const f32x4 x0 = operand(f[0]);
+            const int base = ((prow >> 1) * RS + 4 * quad) * 2 + (prow & 1);
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                unsigned h, l;
+                zs::s16::split2(f[0].y[e], f[0].y[e + 1], h, l);
+                reinterpret_cast<unsigned short *>(lds[buf][0][0])[base + 2 * e] = (unsigned short)(h & 0xffffu);
+                reinterpret_cast<unsigned short *>(lds[buf][0][0])[base + 2 * e + 2] = (unsigned short)(h >> 16);
+                reinterpret_cast<unsigned short *>(lds[buf][0][1])[base + 2 * e] = (unsigned short)(l & 0xffffu);
+                reinterpret_cast<unsigned short *>(lds[buf][0][1])[base + 2 * e + 2] = (unsigned short)(l >> 16);
+                zs::s16::split2(x0[e], x0[e + 1], h, l);
+                reinterpret_cast<unsigned short *>(lds[buf][1][0])[base + 2 * e] = (unsigned short)(h & 0xffffu);
+                reinterpret_cast<unsigned short *>(lds[buf][1][0])[base + 2 * e + 2] = (unsigned short)(h >> 16);
+                reinterpret_cast<unsigned short *>(lds[buf][1][1])[base + 2 * e] = (unsigned short)(l & 0xffffu);
+                reinterpret_cast<unsigned short *>(lds[buf][1][1])[base + 2 * e + 2] = (unsigned short)(l >> 16);
+            }
+            bsum += f[0].y;
+        }
+    };
+
+    f32x16 acc[NI][NI];
+#pragma unroll
+    for (int i = 0; i < NI; i++)
+#pragma unroll
+        for (int j = 0; j < NI; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    const int wm = (wave & 1) * (T / 2), wn = (wave >> 1) * (T / 2);
+    const int steps = (p_end - p_begin + WP - 1) / WP;
+    if (steps > 0) {
+        Frag f[PASSES];
+#pragma unroll
+        for (int q = 0; q < PASSES; q++) f[q] = load(p_begin + PASSES * prow + q, q);
+        store(0, f);
+        __syncthreads();
+        for (int s = 0; s < steps; s++) {
+            const int cur = s & 1;
+            const bool more = s + 1 < steps;
+            if (more) {
+#pragma unroll
+                for (int q = 0; q < PASSES; q++) f[q] = load(p_begin + (s + 1) * WP + PASSES * prow + q, q);
+            }
+            u32x4 ah[NI], al[NI], bh[NI], bl[NI];
+#pragma unroll
+            for (int i = 0; i < NI; i++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int oa = (4 * half + t) * RS + wm + 32 * i + l32, ob = (4 * half + t) * RS + wn + 32 * i + l32;
+                    ah[i][t] = lds[cur][0][0][oa];
+                    al[i][t] = lds[cur][0][1][oa];
+                    bh[i][t] = lds[cur][1][0][ob];
+                    bl[i][t] = lds[cur][1][1][ob];
+                }
+#pragma unroll
+            for (int i = 0; i < NI; i++)
+#pragma unroll
+                for (int j = 0; j < NI; j++) zs::s16::mfma3(acc[i][j], ah[i], al[i], bh[j], bl[j]);
+            if (more) store(cur ^ 1, f);
+            __syncthreads();
+        }
+    }
+    if (a.bias_partial && blockIdx.y == 0) {          // bias gradient: column sums of this tile's dY rows (fp32)
+        __shared__ __attribute__((aligned(16))) float bred[256 / (T / 4)][T];
+        __syncthreads();
+        *reinterpret_cast<f32x4 *>(&bred[prow][4 * quad]) = bsum;
+        __syncthreads();
+        if (prow == 0 && yc_ok) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) t += *reinterpret_cast<const f32x4 *>(&bred[r][4 * quad]);
+            *reinterpret_cast<f32x4 *>(a.bias_partial + (size_t)blockIdx.z * a.CoutP + yc) = t;
+        }
+    }
+    float *dst = a.partial + (size_t)blockIdx.z * a.CoutP * a.K;
+#pragma unroll
+    for (int j = 0; j < NI; j++) {
+        const int k = k0 + wn + 32 * j + l32;
+        if (k >= a.K) continue;
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int co = c0 + wm + 32 * i + 8 * (r >> 2) + 4 * half + (r & 3);
+                if (co < a.CoutP) dst[(size_t)co * a.K + k] = acc[i][j][r];
+            }
+    }
+}
+
 // partial [splits][CoutP][K] (k = tap*CinP + c) -> dw[cout*ld + (cin0+c)*taps + tap], cout < Cout, c < Cin; the bias
 // gradient (column sums of dY per split) rides as Cout extra outputs.  An output is summed by ZL adjacent lanes
 // (splits strided over them, combined by a fixed butterfly): small weights with hundreds of splits must not be a
@@ -591,14 +794,19 @@ extern "C" int zs_conv2d_wgrad(const float *in, const float *dy, float *dw, floa
     const bool pw = kh == 1 && kw == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && plain && Hin == Hout && Win == Wout;
     const bool fast = !pw && plain && Wout >= 6 && Hout >= 2 && (long long)batch * Hin * Win * CinP < (1LL << 31);
     const int mode = pw ? 1 : (fast ? 2 : 0);
-#define ZS_WGRAD(TT)                                                                                          \
+#define ZS_WGRAD(KERNEL, TT)                                                                                  \
     do {                                                                                                      \
-        if (mode == 1) hipLaunchKernelGGL((wgrad_kernel<TT, 1>), grid, dim3(256), 0, S(stream), a);            \
-        else if (mode == 2) hipLaunchKernelGGL((wgrad_kernel<TT, 2>), grid, dim3(256), 0, S(stream), a);       \
-        else hipLaunchKernelGGL((wgrad_kernel<TT, 0>), grid, dim3(256), 0, S(stream), a);                      \
+        if (mode == 1) hipLaunchKernelGGL((KERNEL<TT, 1>), grid, dim3(256), 0, S(stream), a);                  \
+        else if (mode == 2) hipLaunchKernelGGL((KERNEL<TT, 2>), grid, dim3(256), 0, S(stream), a);             \
+        else hipLaunchKernelGGL((KERNEL<TT, 0>), grid, dim3(256), 0, S(stream), a);                            \
     } while (0)
-    if (tile == 64) ZS_WGRAD(64);
-    else ZS_WGRAD(128);
+    if (flags & ZS_CONV_F16X3) {                 // split-fp16 arithmetic (optim.amp)
+        if (tile == 64) ZS_WGRAD(wgrad_split_kernel, 64);
+        else ZS_WGRAD(wgrad_split_kernel, 128);
+    } else {
+        if (tile == 64) ZS_WGRAD(wgrad_kernel, 64);
+        else ZS_WGRAD(wgrad_kernel, 128);
+    }
 #undef ZS_WGRAD
     if (!zs::check_launch("zs_conv2d_wgrad")) return 0;
     {

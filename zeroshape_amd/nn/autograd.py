@@ -40,6 +40,15 @@ def set_forward_precision(p):
 BWD_DATA_PRECISION = os.environ.get("ZS_TRAIN_BWD_PRECISION", "f32")
 
 
+# ... and of the weight-gradient GEMMs (zs_conv2d_wgrad with ZS_CONV_F16X3: wgrad_split_kernel, round 3).  Follows the
+# data-gradient setting (optim.amp) unless ZS_TRAIN_WGRAD_PRECISION pins it (A/B measurements).
+BWD_WGRAD_PRECISION = os.environ.get("ZS_TRAIN_WGRAD_PRECISION")
+
+
+def wgrad_precision():
+    return BWD_WGRAD_PRECISION or BWD_DATA_PRECISION
+
+
 def set_backward_precision(p):
     global BWD_DATA_PRECISION
     if p not in ("f32", "f16x3"):
@@ -376,7 +385,7 @@ class _Conv(torch.autograd.Function):
             if want_b:          # the bias gradient rides on the weight-gradient kernel (it stages dY anyway)
                 db = torch.empty(cout, dtype=torch.float32, device=x.device)
             ws = scratch(x.device, "wgrad", lib.zs_conv2d_wgrad_workspace_bytes(B, Ho, Wo, Cx, cout, kh, kw))
-            flags = _CONV_IN_RELU if in_relu else 0
+            flags = (_CONV_IN_RELU if in_relu else 0) | (_CONV_F16X3 if wgrad_precision() == "f16x3" else 0)
             with _lib.on(x.device):
                 _lib.check(lib.zs_conv2d_wgrad(_lib.ptr(x), _lib.ptr(gp), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws), B, H, W, Cx, Ho,
                                                Wo, cout, kh, kw, stride, pt, pl, flags, float(in_scale),
