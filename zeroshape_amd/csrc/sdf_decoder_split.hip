@@ -550,7 +550,47 @@ DEV void gemm_reg_act(AStream &s, const PT *X, f32x16 &acc, const f32x16 &cur, F
         }
 }
 
-DEV float xhalf(float v) { return __shfl_xor(v, 32, 64); }  // value of lane l ^ 32
+// Sum / maximum of a value over the two lane halves of a point (lanes l and l ^ 32), on every lane:
+// __shfl_xor(v, 32) = ds_bpermute, a ~150-cycle LDS round trip exposed on a lone wave, 60-70 times per wave tile.
+// gfx950 has v_permlane32_swap: with two copies (a, b) of v it leaves a = [lo | lo], b = [hi | hi], so the sum is a + b
+// without LDS.  Round 2 measured 1.2 % of the cycles for it and could not make it correct; round 3 pinned it down
+// (tools/ubench/permlane_check.hip, 4 M lanes per form; tools/ab_permlane.py, tools/race_screen_split.py):
+//   * __builtin_amdgcn_permlane32_swap is MISCOMPILED by this hipcc (ROCm 7.2): the generated code adds the first
+//     result to itself (r[0] + r[0]) - every lane wrong, with or without wait states in front.  That is round 2's
+//     "upper halves come back un-swapped";
+//   * the asm form with `s_nop 4` on both sides (operands are two fresh v_mov copies, which hipcc pads against MFMA
+//     results itself) is correct in isolation - 0 mismatches for VALU- and MFMA-produced values - and inside this kernel
+//     the full grid stays 3.46e-6 from the fp32 kernel, the same maximum as the LDS form.  But identical launches are
+//     then no longer BIT-reproducible: 0.6 % of the values differ in their last bits from run to run (40 repeats, 1.1 M
+//     of 172 M values; also with only the sums switched over), where the LDS form differs in none.  The cause is not
+//     identified (suspect: the swap issued under an MFMA that is still in flight); a fused decoder whose occupancy
+//     indices are a parity contract cannot ship that.
+//   * the gain it would buy: 28.66 vs 28.80 ms per grid (0.5 %) - the kernel's time is its energy.
+// So the LDS form stays; -DZS_SPLIT_PERMLANE builds the asm form for whoever continues (ZS_SPLIT_PERMLANE_SUM_ONLY: sums only).
+#ifndef ZS_SPLIT_PERMLANE
+DEV float half_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+DEV float half_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
+#else
+DEV void half_pair(float v, float &lo, float &hi) {
+    lo = v;
+    hi = v;
+    asm volatile("s_nop 4\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 4" : "+v"(lo), "+v"(hi));
+}
+DEV float half_sum(float v) {
+    float lo, hi;
+    half_pair(v, lo, hi);
+    return lo + hi;
+}
+#ifdef ZS_SPLIT_PERMLANE_SUM_ONLY
+DEV float half_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
+#else
+DEV float half_max(float v) {
+    float lo, hi;
+    half_pair(v, lo, hi);
+    return fmaxf(lo, hi);
+}
+#endif
+#endif
 
 // row-param read from LDS: 16 floats for (tile, lane half)
 DEV void rp(const float *prm, int off, int tile, int hi, float *v) {
@@ -621,7 +661,7 @@ DEV void ln_stats(const f32x16 *x, float &mean, float &rstd) {
     for (int kt = 0; kt < NT; kt++)
 #pragma unroll
         for (int r = 0; r < 16; r++) s += x[kt][r];
-    s += xhalf(s);
+    s = half_sum(s);
     mean = s * (1.0f / 256.0f);
     float v = 0.f;
 #pragma unroll
@@ -631,7 +671,7 @@ DEV void ln_stats(const f32x16 *x, float &mean, float &rstd) {
             const float d = x[kt][r] - mean;
             v = fmaf(d, d, v);
         }
-    v += xhalf(v);
+    v = half_sum(v);
     rstd = 1.0f / sqrtf(v * (1.0f / 256.0f) + 1e-6f);
 }
 // LayerNorm -> packed B operands in the wave's LDS slab
@@ -684,7 +724,7 @@ DEV void attn_tile(AStream &s, const PT &q, f32x16 &o, float &m_run, float &z_ru
     // ~150-cycle LDS round trip and ~20 VALU instructions per tile.
     constexpr float LAZY = 8.0f;
     if (__builtin_amdgcn_ballot_w64(mt > m_run + LAZY) != 0) {   // wave-uniform
-        mt = fmaxf(mt, xhalf(mt));
+        mt = half_max(mt);
         const float m_new = fmaxf(m_run, mt);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         z_run *= alpha;
@@ -759,10 +799,10 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
                 s_self = fmaf(q[r], k[r], s_self);
                 qq = fmaf(q[r], q[r], qq);
             }
-            s_self = (s_self + xhalf(s_self)) * c;
+            s_self = half_sum(s_self) * c;
             {   // (scale |q| max_l |k_l|)^2, the Cauchy-Schwarz bound of this head's latent logits
                 const float km = prog_params[P_KMAX + blk * HEADS + hd] * scale;  // scalar load
-                guard = fmaxf(guard, (qq + xhalf(qq)) * (km * km));
+                guard = fmaxf(guard, half_sum(qq) * (km * km));
             }
             const PT qp = pack_tile(q);
 
@@ -778,7 +818,7 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
                 const float m_new = fmaxf(m_run, s_self);
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
                 const float p_self = __builtin_amdgcn_exp2f(s_self - m_new);
-                const float z = fmaf(z_run + xhalf(z_run), alpha, p_self);
+                const float z = fmaf(half_sum(z_run), alpha, p_self);
                 const float inv = 1.0f / z;
                 const float a_i = alpha * inv, p_i = p_self * inv;
 #pragma unroll
@@ -1000,7 +1040,7 @@ DEV float decode_tile(const char *prog, float *prm, u32x4 *stage, unsigned stage
     }
     ZS_STAMP(14);
     s.drain();
-    out += xhalf(out);
+    out = half_sum(out);
     ZS_STAMP(15);
     return out + prm[P_B8 - W_IB];
 }

@@ -68,7 +68,7 @@ class Runner(shape_engine.Runner):
         if opt.optim.amp:
             self.scaler = LossScaler(opt.device)
         if getattr(opt, "world_size", 1) > 1:
-            self.reducer = parallel.GradReducer(self.graph.parameters(),
+            self.reducer = parallel.GradReducer(self.graph.parameters(), module=self.graph,
                                                 bucket_mb=getattr(opt.optim, "bucket_mb", 64.0))
 
     @torch.no_grad()
