@@ -354,3 +354,43 @@ def test_conv2d_random_shape_sweep():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_conv.py"), "80", "11"], capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0 and "80 cases ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+PATCH_CASES = [
+    # B, Cin, H, W, Cout, in_relu, residual, act     (3 x 3, stride 1, pad 1: the input-patch kernels of nn_conv_patch.h)
+    (3, 128, 40, 40, 32, False, False, "relu"),       # DPT head layer geometry: tiles overhang the image (40 = 2.5 x 16)
+    (2, 16, 9, 23, 7, True, True, "none"),            # one slab, ragged Cout, image smaller than a tile in one direction
+    (1, 64, 16, 16, 32, False, True, "none"),         # exactly one tile: every halo pixel is padding
+    (2, 48, 33, 17, 20, True, False, "relu"),
+]
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,in_relu,residual,act", PATCH_CASES)
+def test_conv3x3_input_patch_kernels(B, Cin, H, W, Cout, in_relu, residual, act, monkeypatch):
+    """3 x 3 stride-1 layers in split-fp16 take the input-patch kernels (the tile's input patch staged once per
+    16-channel slab, split in place, read at nine shifted offsets): same 2e-5 parity against torch as the GEMM kernels,
+    agreement with the GEMM kernel (ZS_CONV_FORCE_LARGE bypasses the patch path) to summation order, bit-reproducible."""
+    from zeroshape_amd.nn import ops, pack
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(9 * Cin)
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(B, Cout, H, W, generator=g) if residual else None
+    want = F.conv2d(F.relu(x) if in_relu else x, w, b, padding=1)
+    if residual:
+        want = want + res
+    if act == "relu":
+        want = F.relu(want)
+    pc = pack.pack_conv(w, b, stride=1, padding=1).to("cuda")
+    kw = dict(res1=None if res is None else nhwc(res).cuda(), act=ops.ACT_RELU if act == "relu" else ops.ACT_NONE, in_relu=in_relu)
+    prev = ops.CONV_PRECISION
+    try:
+        ops.set_conv_precision("f16x3")
+        xg = nhwc(x).cuda()
+        got = ops.conv2d(xg, pc, **kw)
+        close(got, nhwc(want))
+        assert torch.equal(got, ops.conv2d(xg, pc, **kw))
+        gemm = ops.conv2d(xg, pc, tiling="large", **kw)
+        close(got, gemm.cpu(), tol=5e-6)
+    finally:
+        ops.set_conv_precision(prev)

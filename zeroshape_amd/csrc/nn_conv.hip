@@ -920,6 +920,8 @@ __global__ __launch_bounds__(512) void conv_gemm_dma256_kernel(ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+#include "nn_conv_patch.h"
+
 // ---- small-problem variant: many small tiles, K split across the four waves ----
 // The 128x128 tiling needs >= ~256 tiles to fill 256 CUs; a 14x14 feature map or a 197-token
 // matrix gives a handful.  Here a workgroup owns 32 pixels x 64 couts and its four waves each
@@ -1182,6 +1184,24 @@ extern "C" int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const f
         else if (tm) hipLaunchKernelGGL((conv_gemm_kernel<false, 2, false, F, SKF>), grid, dim3(256), 0, st, a);            \
         else hipLaunchKernelGGL((conv_gemm_kernel<false, 0, false, F, SKF>), grid, dim3(256), 0, st, a);                    \
     } while (0)
+    // 3 x 3 stride-1 pad-1 layers in split-fp16 with pre-split weights: the input-patch kernels (nn_conv_patch.h)
+    static const bool no_patch = getenv("ZS_CONV_NO_PATCH") != nullptr;          // A/B switch for measurements
+    const bool patch_geom = f16 && a.w_split && !no_patch && kh == 3 && kw == 3 && stride == 1 && a.dil == 1 && pad_t == 1 &&
+                            pad_l == 1 && Hin == Hout && Win == Wout && (Cin % BK) == 0 && in_scale == 1.0f && in_shift == 0.0f &&
+                            !(flags & (ZS_CONV_FORCE_SMALL | ZS_CONV_FORCE_LARGE));
+    if (patch_geom && Cout <= 32 && Hout >= 8 && Wout >= 8) {
+        const int tx = (Wout + patch32::PT - 1) / patch32::PT, ty = (Hout + patch32::PT - 1) / patch32::PT;
+        const dim3 grid((unsigned)((long long)batch * tx * ty));
+        static const int nw = getenv("ZS_CONV_PATCH_WAVES") ? atoi(getenv("ZS_CONV_PATCH_WAVES")) : 8;      // A/B: 4 or 8
+        if (nw == 4) {
+            if (a.in_relu) hipLaunchKernelGGL((conv3x3_patch32_kernel<true, 4>), grid, dim3(256), 0, st, a, tx, ty);
+            else hipLaunchKernelGGL((conv3x3_patch32_kernel<false, 4>), grid, dim3(256), 0, st, a, tx, ty);
+        } else {
+            if (a.in_relu) hipLaunchKernelGGL((conv3x3_patch32_kernel<true, 8>), grid, dim3(512), 0, st, a, tx, ty);
+            else hipLaunchKernelGGL((conv3x3_patch32_kernel<false, 8>), grid, dim3(512), 0, st, a, tx, ty);
+        }
+        return zs::check_launch("zs_conv2d_nhwc") ? 1 : 0;
+    }
     if (small) {
         static const long long narrow_below = getenv("ZS_CONV_NARROW_BELOW") ? atoll(getenv("ZS_CONV_NARROW_BELOW")) : 384;
         const long long wide = ((M + SM - 1) / SM) * ((Cout + 63) / 64);

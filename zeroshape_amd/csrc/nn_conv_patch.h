@@ -1,0 +1,222 @@
+// 3 x 3, stride-1, pad-1 layers of the split-fp16 convolution engine with the INPUT PATCH kept in LDS across the nine taps.
+// Included by nn_conv.hip inside its anonymous namespace (ConvArgs, dma16, zs_zero_page, activate, the vector types).
+//
+// conv_gemm_dma_kernel is bound by the bytes it moves L2 -> LDS (2.6x faster with the DMAs compiled out), and as
+// an implicit GEMM it moves every input value nine times - once per tap - as a row of the A operand.  Here a workgroup
+// owns a 2-D tile of output pixels of ONE image and stages, per 16-channel slab, the tile's input patch (tile + halo)
+// once: the A fragments of the nine taps are the same LDS bytes read at nine shifted pixel offsets.  The patch is split
+// into its fp16 halves once per slab, in place (a pixel's 16 fp32 channels = 64 B become 2 x 16 B of hi and 2 x 16 B of
+// lo halves: the fragment reads fetch finished MFMA operands, where the GEMM kernel splits every value once per tap and
+// consuming wave).  K is walked (slab outer, tap inner); the weights are the pre-split [K16/4][CoutPad][4] array
+// addressed by (tap, slab), so nothing is re-packed.  Same products as the GEMM kernels, summed in another order.
+//
+// conv3x3_patch32_kernel: Cout <= 32 (DPT's 128 -> 32 head layer at 224 x 224: the GEMM kernel pads N to 128 and moves
+// 16 KiB per k-step for 128 x 32 useful outputs).  Tile 16 x 16 pixels (M = 256), wave w = tile rows 4w .. 4w+3 (two
+// 32 x 32 MFMA blocks), N = 32.  Per slab a stage holds the split 18 x 18 patch (20.25 KiB, padded to 21 KiB) and the nine
+// taps' weights (9 x 4 row quads x 32 columns = 18 KiB); two stages = 78 KiB, two workgroups per CU.
+// The weights go global -> LDS by DMA; the patch goes through REGISTERS: four lanes per pixel load its 64-byte slab (the
+// DMA's coalescing), hold it across the current slab's MFMAs, split it and write the halves where the fragment reads expect
+// them.  (First version: patch by DMA as raw fp32 + an in-place split pass: 515 us on the head layer - 220 us for the DMAs
+// alone, i.e. the same ~8 TB/s the GEMM kernel's DMA stream saturates at, + 95 us for the split pass and its barrier, not
+// overlapped with the 300 us of fragment reads and MFMAs; tools/bench_patch.py with the ZS_EXP_P32_* builds.)  Per slab:
+//   barrier -> issue the next slab's patch loads (6 x 16 B per lane) and weight DMAs (18 KiB) -> nine taps x (4 A + 2 B
+//   ds_read_b128, 6 MFMAs) per wave from this stage -> loads landed: split, 2 ds_write_b64 per quad into the other stage.
+// Bytes into LDS per 256 x 32 outputs and slab: 39 KiB (GEMM kernel: 2 x 9 x 16 = 288 KiB).
+
+namespace patch32 {
+constexpr int PT = 16, PP = PT + 2, PPIX = PP * PP;        // tile side, patch side, patch pixels (324)
+constexpr int A_PIX = 336;                                 // patch pixels padded to whole waves of the loader (21 x 16)
+constexpr int A_QUADS = A_PIX * 4;                         // f32x4 slots of the (padded) patch
+constexpr int A_ROUNDS = (PPIX * 4 + 255) / 256;           // loader rounds of 256 (pixel, k-quad) units: 5 full + 16 lanes
+constexpr int B_DMAS = 18;                                 // 9 taps x 2 (row-quad pairs) x 32 columns x 16 B
+constexpr int B_QUADS = B_DMAS * 64;
+constexpr int STAGE_QUADS = A_QUADS + B_QUADS;             // 2,496 x 16 B = 39,936 B
+}  // namespace patch32
+
+// Row m (0..31) of a 32 x 32 MFMA block -> pixel 16 ty + tx of the block's 2 x 16 pixels.  ds_read_b128 serves a wave in
+// the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32) (MI355X_MICROARCH.md, LDS): a group must touch 64
+// distinct banks.  With the obvious mapping (ty = m / 16) a group reads 8 pixels of one patch row and 8 of the next, 18
+// pixels further - two of them on the same banks whatever the swizzle (2 LDS cycles per group, measured as 2x the
+// fragment-read time).  Here a group IS one row of 16 consecutive patch pixels, conflict-free under slot ^= (pixel >> 2) & 3
+// at any alignment: group {0-3, 12-15, 20-27} = tile row 0, x = 0..15; group {4-11, 16-19, 28-31} = tile row 1.
+__device__ __forceinline__ int block_pixel(int m) {
+    return m < 4 ? m : m < 12 ? 16 + m - 4 : m < 16 ? m - 8 : m < 20 ? 16 + m - 8 : m < 28 ? m - 12 : 16 + m - 16;
+}
+
+// NW waves per workgroup share the tile's eight 2 x 16-pixel MFMA blocks: NW = 8 -> one block per wave, four waves per SIMD
+// with two workgroups per CU (a wave's slab is barrier, issue, 27 MFMAs, land, one after the other: the other waves of
+// the SIMD are what keeps the matrix pipe busy meanwhile; four waves, two blocks each: 475 vs ... us on the head layer).
+template <bool RELU, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 2, NW / 2))) void conv3x3_patch32_kernel(ConvArgs a, int tiles_x, int tiles_y) {
+    using namespace patch32;
+    constexpr int NT = 64 * NW, MB = 8 / NW;                   // threads, MFMA blocks per wave
+    constexpr int AR = (PPIX * 4 + NT - 1) / NT;               // loader rounds of NT (pixel, k-quad) units; the last one is partial
+    constexpr int BR = (B_DMAS + NW - 1) / NW;
+    static_assert(AR * NT <= A_PIX * 4 + NT - 64 && (AR == 6 || AR == 3), "loader rounds");
+    __shared__ f32x4 lds[2][STAGE_QUADS];
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) f32x4 *)&lds[0][0]);
+    const f32x4 *zero = zs_zero_page;
+
+    const int per_image = tiles_x * tiles_y;
+    const int b = (int)blockIdx.x / per_image, trem = (int)blockIdx.x - b * per_image;
+    const int y0 = (trem / tiles_x) * PT, x0 = (trem % tiles_x) * PT;
+    const int slabs = a.Cin / BK;
+
+    // A: unit u = tid + NT r = (patch pixel u / 4, k-quad u % 4): four lanes read a pixel's 64-byte slab.  The quad's four
+    // values become 8 B of the hi operand and 8 B of the lo operand of lane half h = quad & 1 (its k values 4h..4h+3 first,
+    // 4h+8..4h+11 second): slot h ^ ((pixel >> 2) & 3) of the pixel holds hi, that slot ^ 2 lo (conflict-free fragment
+    // reads, as in conv_gemm_dma_kernel).  Halo pixels outside the image read the zero page (increment 0).
+    const f32x4 *ga[AR];
+    int ga_inc[AR];
+    int a_dst[AR];                                             // 8-byte units inside the stage
+#pragma unroll
+    for (int r = 0; r < AR; r++) {
+        const int u = tid + NT * r, p = u >> 2, quad = u & 3;
+        const int py = p / PP, px = p - py * PP, iy = y0 - 1 + py, ix = x0 - 1 + px;
+        const bool ok = p < PPIX && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        ga[r] = ok ? reinterpret_cast<const f32x4 *>(a.in + (((size_t)b * a.Hin + iy) * a.Win + ix) * a.Cin + 4 * quad) : zero;
+        ga_inc[r] = ok ? BK / 4 : 0;
+        a_dst[r] = p * 8 + ((quad & 1) ^ ((p >> 2) & 3)) * 2 + (quad >> 1);
+    }
+    const bool last_round = 64 * wave + NT * (AR - 1) < PPIX * 4;      // waves with units in the partial round (uniform)
+    // B: DMA db = (tap, e) covers the row quads 2e, 2e + 1 (lane / 32) of the tap's K = 16 step, columns lane % 32
+    const char *gb[BR];
+#pragma unroll
+    for (int i = 0; i < BR; i++) {
+        const int db = wave + NW * i, tap = db >> 1, q = 2 * (db & 1) + (lane >> 5);
+        gb[i] = reinterpret_cast<const char *>(reinterpret_cast<const f32x4 *>(a.w) + (size_t)(tap * (a.Cin >> 2) + q) * a.CoutPad + (lane & 31));
+    }
+    const int gb_inc = KQ * a.CoutPad * 16;
+
+    // Workgroups start their walk over the slabs at different slabs (and wrap): a slab is the same 64 bytes of every pixel's
+    // channel vector, so workgroups that run in step - they all start together - would all be reading the same few address
+    // bits 6.. of every pixel at any one time, i.e. the same few memory channels.
+#ifndef ZS_EXP_P32_NO_ROTATE
+    int slab_at = (int)((blockIdx.x >> 3) % (unsigned)slabs);
+#else
+    int slab_at = 0;
+#endif
+#pragma unroll
+    for (int r = 0; r < AR; r++) ga[r] += (size_t)slab_at * ga_inc[r];
+#pragma unroll
+    for (int i = 0; i < BR; i++) gb[i] += (size_t)slab_at * gb_inc;
+    f32x4 stage_a[AR];
+    auto issue = [&](int stage) {                              // patch loads -> registers, weight DMAs -> LDS
+        const bool wrap = ++slab_at == slabs;
+        if (wrap) slab_at = 0;
+#pragma unroll
+        for (int r = 0; r < AR; r++) {
+            if (r < AR - 1 || last_round)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(stage_a[r]) : "v"(ga[r]) : "memory");
+            ga[r] += wrap ? -(ptrdiff_t)(slabs - 1) * ga_inc[r] : ga_inc[r];
+        }
+        const unsigned dst = lds_base + stage * (STAGE_QUADS * 16) + A_QUADS * 16;
+#pragma unroll
+        for (int i = 0; i < BR; i++) {
+            if (wave + NW * i < B_DMAS) dma16(gb[i], dst + (wave + NW * i) * 1024);
+            gb[i] += wrap ? -(ptrdiff_t)(slabs - 1) * gb_inc : gb_inc;
+        }
+    };
+    auto land = [&](int stage) {                               // loads landed: split, write the halves
+        if constexpr (AR == 6)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(stage_a[0]), "+v"(stage_a[1]), "+v"(stage_a[2]), "+v"(stage_a[3]),
+                         "+v"(stage_a[4]), "+v"(stage_a[5]) : : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(stage_a[0]), "+v"(stage_a[1]), "+v"(stage_a[2]) : : "memory");
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 *sa = reinterpret_cast<u32x2 *>(&lds[stage][0]);
+#pragma unroll
+        for (int r = 0; r < AR; r++) {
+            if (r < AR - 1 || last_round) {
+                f32x4 q = stage_a[r];
+                if (RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) q[e] = fmaxf(q[e], 0.f);
+                }
+                unsigned h0, l0, h1, l1;
+                zs::s16::split2(q.x, q.y, h0, l0);
+                zs::s16::split2(q.z, q.w, h1, l1);
+                sa[a_dst[r]] = u32x2{h0, h1};
+                sa[a_dst[r] ^ 4] = u32x2{l0, l1};
+            }
+        }
+    };
+
+    f32x16 acc[MB];
+#pragma unroll
+    for (int i = 0; i < MB; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+
+    // patch pixel under this lane's output pixel at tap (0, 0), per MFMA block (two tile rows, see block_pixel)
+    int pb[MB];
+#pragma unroll
+    for (int i = 0; i < MB; i++) pb[i] = (2 * (MB * wave + i) + (block_pixel(l32) >> 4)) * PP + (block_pixel(l32) & 15);
+
+#ifdef ZS_EXP_P32_STAMPS   // tools/stamp_patch.py: s_memtime of (block ZS_EXP_P32_STAMPS, every wave) per slab phase -> workspace
+    unsigned long long *dbg = (a.ws && (int)blockIdx.x == ZS_EXP_P32_STAMPS && lane == 0)
+                                  ? reinterpret_cast<unsigned long long *>(a.ws + WS_COUNTER_FLOATS) + wave * 64 : nullptr;
+#define ZS_P32_STAMP(i) do { if (dbg) dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ZS_P32_STAMP(i) do { } while (0)
+#endif
+    ZS_P32_STAMP(62);
+    issue(0);
+    land(0);
+    for (int s = 0; s < slabs; s++) {
+        const f32x4 *sa = &lds[s & 1][0];
+        const f32x4 *sb = sa + A_QUADS;
+        ZS_P32_STAMP(5 * s + 0);
+        __syncthreads();                  // this stage is complete (own DMAs and writes, then everybody's); the other one is free
+        ZS_P32_STAMP(5 * s + 1);
+        if (s + 1 < slabs) issue((s + 1) & 1);
+        ZS_P32_STAMP(5 * s + 2);
+        // fragments of tap t + 1 are requested before the MFMAs of tap t are issued (sched_barrier keeps the scheduler from
+        // sinking the reads next to their use, one wait per read)
+        u32x4 ah[2][MB], al[2][MB], bh[2], bl[2];
+        auto fetch = [&](int tap, int buf) {
+            const int shift = (tap / 3) * PP + tap % 3;
+#pragma unroll
+            for (int i = 0; i < MB; i++) {
+                const int p = pb[i] + shift, s0 = p * 4 + (half ^ ((p >> 2) & 3));
+                ah[buf][i] = __builtin_bit_cast(u32x4, sa[s0]);
+                al[buf][i] = __builtin_bit_cast(u32x4, sa[s0 ^ 2]);
+            }
+            bh[buf] = __builtin_bit_cast(u32x4, sb[tap * 128 + half * 32 + l32]);
+            bl[buf] = __builtin_bit_cast(u32x4, sb[tap * 128 + (half + 2) * 32 + l32]);
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            if (tap + 1 < 9) fetch(tap + 1, (tap + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MB; i++) zs::s16::mfma3(acc[i], ah[tap & 1][i], al[tap & 1][i], bh[tap & 1], bl[tap & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ZS_P32_STAMP(5 * s + 3);
+        if (s + 1 < slabs) land((s + 1) & 1);
+        ZS_P32_STAMP(5 * s + 4);
+    }
+
+    if (l32 < a.Cout) {
+        const float sc = a.scale ? a.scale[l32] : 1.0f, sh = a.shift ? a.shift[l32] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < MB; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int rr = block_pixel(8 * (r >> 2) + 4 * half + (r & 3));
+                const int y = y0 + 2 * (MB * wave + i) + (rr >> 4), x = x0 + (rr & 15);
+                if (y >= a.Hout || x >= a.Wout) continue;
+                const size_t o = (((size_t)b * a.Hout + y) * a.Wout + x) * a.Cout + l32;
+                float v = acc[i][r] * sc + sh;
+                if (a.res1) v += a.res1[o];
+                if (a.res2) v += a.res2[o];
+                a.out[o] = activate(v, a.act);
+            }
+    }
+    ZS_P32_STAMP(63);
+#undef ZS_P32_STAMP
+}
