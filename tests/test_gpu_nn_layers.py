@@ -362,6 +362,11 @@ PATCH_CASES = [
     (2, 16, 9, 23, 7, True, True, "none"),            # one slab, ragged Cout, image smaller than a tile in one direction
     (1, 64, 16, 16, 32, False, True, "none"),         # exactly one tile: every halo pixel is padding
     (2, 48, 33, 17, 20, True, False, "relu"),
+    # more than 32 output channels, >= 192 workgroups: the 128-column kernel (8 x 16-pixel tiles, weights streamed per tap)
+    (8, 32, 48, 48, 256, False, False, "relu"),
+    (6, 48, 41, 37, 160, True, True, "none"),         # ragged tiles in both directions, second column tile 32 of 128 wide
+    (50, 16, 16, 24, 64, False, True, "relu"),        # one slab: prologue and the last-slab path only
+    (3, 256, 56, 56, 256, True, False, "none"),       # the DPT fusion layer: 16 slabs
 ]
 
 

@@ -28,6 +28,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1201,6 +1203,17 @@ extern "C" int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const f
             else hipLaunchKernelGGL((conv3x3_patch32_kernel<false, 8>), grid, dim3(512), 0, st, a, tx, ty);
         }
         return zs::check_launch("zs_conv2d_nhwc") ? 1 : 0;
+    }
+    static const long long patch_min = getenv("ZS_CONV_PATCH_MIN") ? atoll(getenv("ZS_CONV_PATCH_MIN")) : 192;
+    if (patch_geom && Cout > 32 && Hout >= 8 && Wout >= 8) {
+        const int tx = (Wout + patch128::TW - 1) / patch128::TW, ty = (Hout + patch128::TH - 1) / patch128::TH;
+        const long long wgs = (long long)batch * tx * ty * (a.CoutPad / BN);
+        if (wgs >= patch_min) {
+            const dim3 grid((unsigned)((long long)batch * tx * ty), (unsigned)(a.CoutPad / BN));
+            if (a.in_relu) hipLaunchKernelGGL((conv3x3_patch128_kernel<true>), grid, dim3(256), 0, st, a, tx, ty);
+            else hipLaunchKernelGGL((conv3x3_patch128_kernel<false>), grid, dim3(256), 0, st, a, tx, ty);
+            return zs::check_launch("zs_conv2d_nhwc") ? 1 : 0;
+        }
     }
     if (small) {
         static const long long narrow_below = getenv("ZS_CONV_NARROW_BELOW") ? atoll(getenv("ZS_CONV_NARROW_BELOW")) : 384;

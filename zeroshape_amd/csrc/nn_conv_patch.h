@@ -220,3 +220,185 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 2,
     ZS_P32_STAMP(63);
 #undef ZS_P32_STAMP
 }
+
+// ---- conv3x3_patch128_kernel: 128 output channels per workgroup ---------------------------------------------------- //
+// The 128 x 128 tiling of conv_gemm_dma_kernel (four waves, wave tile 64 x 64, weights streamed tap by tap through a three-
+// stage LDS ring by DMA, one barrier per tap-step) with the A operand taken from a patch: the workgroup's 128 rows are an
+// 8 x 16-pixel tile of one image, its 10 x 18 patch of a 16-channel slab goes global -> registers -> split -> LDS once per
+// slab (three 16-byte loads per lane, issued at taps 0..2 of the previous slab, landed at tap 6; two patch stages), and the
+// nine taps read it at shifted offsets.  Per slab and workgroup 72 KiB of weights + 11.25 KiB of patch enter LDS; the GEMM
+// kernel moves 144 KiB and splits every A value once per tap.  48 KiB of LDS, three workgroups per CU.
+namespace patch128 {
+constexpr int TH = 8, TW = 16, PH = TH + 2, PW = TW + 2, PPIX = PH * PW;   // tile, patch (180 pixels)
+constexpr int A_PIX = 192;                                                 // padded to the loader's 3 rounds of 256 units
+constexpr int A_QUADS = A_PIX * 4;
+constexpr int B_QUADS = KQ * BN;                                           // one tap-step of weights: 4 row quads x 128 columns
+constexpr int NS = 3, DEPTH = NS - 1;
+}  // namespace patch128
+
+template <bool RELU>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void conv3x3_patch128_kernel(ConvArgs a, int tiles_x, int tiles_y) {
+    using namespace patch128;
+    __shared__ f32x4 lds_a[2][A_QUADS];
+    __shared__ f32x4 lds_b[NS][B_QUADS];
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned ldsb_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) f32x4 *)&lds_b[0][0]);
+    const f32x4 *zero = zs_zero_page;
+
+    const int per_image = tiles_x * tiles_y;
+    const int b = (int)blockIdx.x / per_image, trem = (int)blockIdx.x - b * per_image;
+    const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+    const int n0 = (int)blockIdx.y * BN;
+    const int slabs = a.Cin / BK;
+    const int wm = wave & 1, wn = (wave >> 1) * 64;            // wave tile: tile rows 4 wm .. 4 wm + 3, columns wn .. wn + 63
+
+    // patch loader: unit u = tid + 256 r = (patch pixel u / 4, k-quad u % 4), as in conv3x3_patch32_kernel
+    const f32x4 *ga[3];
+    int ga_inc[3], a_dst[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const int u = tid + 256 * r, p = u >> 2, quad = u & 3;
+        const int py = p / PW, px = p - py * PW, iy = y0 - 1 + py, ix = x0 - 1 + px;
+        const bool ok = p < PPIX && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        ga[r] = ok ? reinterpret_cast<const f32x4 *>(a.in + (((size_t)b * a.Hin + iy) * a.Win + ix) * a.Cin + 4 * quad) : zero;
+        ga_inc[r] = ok ? BK / 4 : 0;
+        a_dst[r] = p * 8 + ((quad & 1) ^ ((p >> 2) & 3)) * 2 + (quad >> 1);
+    }
+    // weights: per tap-step this wave fetches row quad `wave` of the step, columns n0 + lane and n0 + 64 + lane
+    const f32x4 *gb = reinterpret_cast<const f32x4 *>(a.w) + (size_t)wave * a.CoutPad + n0 + lane;
+    const size_t b_tap = (size_t)(a.Cin >> 2) * a.CoutPad, b_slab = (size_t)KQ * a.CoutPad;     // f32x4 units
+    // workgroups start at different slabs and wrap (see conv3x3_patch32_kernel)
+    int slab_at = (int)((blockIdx.x >> 3) % (unsigned)slabs);
+#pragma unroll
+    for (int r = 0; r < 3; r++) ga[r] += (size_t)slab_at * ga_inc[r];
+    gb += (size_t)slab_at * b_slab;
+
+    f32x4 stage_a[3];
+    auto load_a = [&](int r) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(stage_a[r]) : "v"(ga[r]) : "memory"); };
+    int a_at = slab_at;                                        // the slab the patch pointers are at (one ahead of the weights)
+    auto next_slab_a = [&]() {                                 // after the three loads of a slab: pointers to the following one
+        const bool wrap = a_at + 1 == slabs;
+#pragma unroll
+        for (int r = 0; r < 3; r++) ga[r] += wrap ? -(ptrdiff_t)(slabs - 1) * ga_inc[r] : ga_inc[r];
+        a_at = wrap ? 0 : a_at + 1;
+    };
+    auto land_a = [&](int stage) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 *sa = reinterpret_cast<u32x2 *>(&lds_a[stage][0]);
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            f32x4 q = stage_a[r];
+            if (RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) q[e] = fmaxf(q[e], 0.f);
+            }
+            unsigned h0, l0, h1, l1;
+            zs::s16::split2(q.x, q.y, h0, l0);
+            zs::s16::split2(q.z, q.w, h1, l1);
+            sa[a_dst[r]] = u32x2{h0, h1};
+            sa[a_dst[r] ^ 4] = u32x2{l0, l1};
+        }
+    };
+    auto dma_b = [&](const f32x4 *g, int stage, bool live) {   // 2 DMAs: this wave's row quad of a step
+        const unsigned dst = ldsb_base + stage * (B_QUADS * 16) + wave * (BN * 16);
+        dma16(live ? reinterpret_cast<const char *>(g) : reinterpret_cast<const char *>(zero), dst);
+        dma16(live ? reinterpret_cast<const char *>(g + 64) : reinterpret_cast<const char *>(zero), dst + 1024);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    int pb[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) pb[i] = (2 * (2 * wm + i) + (block_pixel(l32) >> 4)) * PW + (block_pixel(l32) & 15);
+
+    // prologue: patch of the first slab, weights of its first two taps
+#pragma unroll
+    for (int r = 0; r < 3; r++) load_a(r);
+    next_slab_a();
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(stage_a[0]), "+v"(stage_a[1]), "+v"(stage_a[2]) : : "memory");
+    land_a(0);
+    dma_b(gb, 0, true);
+    dma_b(gb + b_tap, 1, true);
+
+    for (int s = 0; s < slabs; s++) {
+        const f32x4 *sa = &lds_a[s & 1][0];
+        const bool last = s + 1 == slabs;
+        const bool wrap = slab_at + 1 == slabs;
+        const f32x4 *gb_next = gb + (wrap ? -(ptrdiff_t)(slabs - 1) * (ptrdiff_t)b_slab : (ptrdiff_t)b_slab);
+        auto tap_step = [&](auto tc) {
+            constexpr int T = decltype(tc)::value;
+            // vector-memory operations younger than the DMAs of this step: the patch load of tap T - 2 (if it had one), the
+            // two DMAs and the patch load of tap T - 1
+            constexpr int YOUNGER = ((T >= 2 && T - 2 < 3) ? 1 : 0) + 2 + ((T >= 1 && T - 1 < 3) ? 1 : 0);
+            if (T == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" : : "n"(YOUNGER) : "memory");   // + the patch writes of tap 6
+            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"(YOUNGER) : "memory");
+            // the step two ahead: taps T + 2 of this slab, or taps 0 / 1 of the next one
+            if (T + DEPTH < 9) dma_b(gb + (size_t)(T + DEPTH) * b_tap, (T + DEPTH) % NS, true);
+            else dma_b(gb_next + (size_t)(T + DEPTH - 9) * b_tap, (T + DEPTH) % NS, !last);
+            if (T < 3) load_a(T);                              // next slab's patch (the last slab re-reads its own: the counts stay)
+            if (T == 2) next_slab_a();
+            if (T == 6) {
+                asm volatile("" : "+v"(stage_a[0]), "+v"(stage_a[1]), "+v"(stage_a[2]));   // loads retired by this step's wait
+                if (!last) land_a((s + 1) & 1);
+            }
+            // (reading the patch fragments above the barrier - they do not depend on it - costs six registers, the third wave
+            // per SIMD with them, and was slower: 384 vs 359 us on the 256 -> 256 layer at 56 x 56 x 28)
+            const f32x4 *sb = &lds_b[T % NS][0];
+            const int shift = (T / 3) * PW + T % 3;
+            u32x4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int p = pb[i] + shift, s0 = p * 4 + (half ^ ((p >> 2) & 3));
+                ah[i] = __builtin_bit_cast(u32x4, sa[s0]);
+                al[i] = __builtin_bit_cast(u32x4, sa[s0 ^ 2]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                bh[j] = __builtin_bit_cast(u32x4, sb[half * BN + wn + 32 * j + l32]);
+                bl[j] = __builtin_bit_cast(u32x4, sb[(half + 2) * BN + wn + 32 * j + l32]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) zs::s16::mfma3(acc[i][j], ah[i], al[i], bh[j], bl[j]);
+        };
+        tap_step(std::integral_constant<int, 0>());
+        tap_step(std::integral_constant<int, 1>());
+        tap_step(std::integral_constant<int, 2>());
+        tap_step(std::integral_constant<int, 3>());
+        tap_step(std::integral_constant<int, 4>());
+        tap_step(std::integral_constant<int, 5>());
+        tap_step(std::integral_constant<int, 6>());
+        tap_step(std::integral_constant<int, 7>());
+        tap_step(std::integral_constant<int, 8>());
+        gb = gb_next;
+        slab_at = wrap ? 0 : slab_at + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the zero-page DMAs and the spare patch loads of the last slab
+
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int n = n0 + wn + 32 * j + l32;
+        if (n >= a.Cout) continue;
+        const float sc = a.scale ? a.scale[n] : 1.0f, sh = a.shift ? a.shift[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int rr = block_pixel(8 * (r >> 2) + 4 * half + (r & 3));
+                const int y = y0 + 2 * (2 * wm + i) + (rr >> 4), x = x0 + (rr & 15);
+                if (y >= a.Hout || x >= a.Wout) continue;
+                const size_t o = (((size_t)b * a.Hout + y) * a.Wout + x) * a.Cout + n;
+                float v = acc[i][j][r] * sc + sh;
+                if (a.res1) v += a.res1[o];
+                if (a.res2) v += a.res2[o];
+                a.out[o] = activate(v, a.act);
+            }
+    }
+}
