@@ -1276,6 +1276,11 @@ extern "C" int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const f
         static const int dma_mi = getenv("ZS_CONV_DMA_MI") ? atoi(getenv("ZS_CONV_DMA_MI")) : 2;
         const long long tall_tiles = ((M + 255) / 256) * (a.CoutPad / BN);
         const bool tall = dma_mi == 4 && tall_tiles >= 1;
+        // 64 x 128 tiles (MI = 1, four workgroups per CU) where 128-row tiles give most CUs a single workgroup - ViT fc2 /
+        // proj at batch 28: 264 tiles on 256 CUs, four waves per CU.  tools/conv_shapes.py, batch 28, threshold 0 / 300 / 600 / 1200:
+        // 17.17 / 16.83 / 16.44 / 16.94 ms of convolutions (fc2 167 -> 148 us, proj 73 -> 55, the 344-tile 1x1 layers 43 -> 32)
+        static const long long half_below = getenv("ZS_CONV_HALF_BELOW") ? atoll(getenv("ZS_CONV_HALF_BELOW")) : 600;
+        const bool half_tall = dma_mi == 1 || (dma_mi == 2 && big_tiles < half_below);
 #define ZS_LAUNCH_DMA1(SKF, NS, MI_)                                                                                     \
     do {                                                                                                                 \
         if (pw) hipLaunchKernelGGL((conv_gemm_dma_kernel<true, false, SKF, NS, MI_>), grid, dim3(256), 0, st, a);         \
@@ -1313,6 +1318,9 @@ extern "C" int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const f
         } else if (dma && tall) {
             const dim3 grid((unsigned)((M + 255) / 256), (unsigned)(a.CoutPad / BN));
             ZS_LAUNCH_DMA1(false, 3, 4);
+        } else if (dma && half_tall) {
+            const dim3 grid((unsigned)((M + 63) / 64), (unsigned)(a.CoutPad / BN));
+            ZS_LAUNCH_DMA1(false, 3, 1);
         } else {
             const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(a.CoutPad / BN));
             if (dma) ZS_LAUNCH_DMA(false);
