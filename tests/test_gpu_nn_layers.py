@@ -367,6 +367,10 @@ PATCH_CASES = [
     (6, 48, 41, 37, 160, True, True, "none"),         # ragged tiles in both directions, second column tile 32 of 128 wide
     (50, 16, 16, 24, 64, False, True, "relu"),        # one slab: prologue and the last-slab path only
     (3, 256, 56, 56, 256, True, False, "none"),       # the DPT fusion layer: 16 slabs
+    # fewer than 192 workgroups: the slabs are split across blockIdx.z, partial tiles summed by the reduce kernel
+    (28, 256, 14, 14, 256, True, True, "relu"),       # 112 workgroups x 4 ranges of 4 slabs
+    (1, 256, 56, 56, 256, False, False, "none"),      # 56 workgroups x 7 uneven ranges
+    (4, 64, 14, 14, 200, False, True, "relu"),        # 16 workgroups x 2 ranges, ragged column tile
 ]
 
 
@@ -397,5 +401,36 @@ def test_conv3x3_input_patch_kernels(B, Cin, H, W, Cout, in_relu, residual, act,
         assert torch.equal(got, ops.conv2d(xg, pc, **kw))
         gemm = ops.conv2d(xg, pc, tiling="large", **kw)
         close(got, gemm.cpu(), tol=5e-6)
+    finally:
+        ops.set_conv_precision(prev)
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,stride,in_relu", [
+    (28, 768, 7, 7, 768, 3, 1, False),        # intrinsics head at batch 28: 66 tiles x 432 k-steps -> 6 ranges
+    (6, 2048, 14, 14, 512, 1, 1, False),      # pointwise, 40 tiles x 128 k-steps -> 5 ranges
+    (13, 256, 28, 28, 256, 3, 2, True),       # stride 2, input ReLU, 40 tiles x 144 k-steps -> 6 ranges
+    (3, 512, 9, 11, 130, 3, 1, False),        # ragged rows and columns, 6 tiles: below the 40-tile floor, the small-tile kernel
+])
+def test_conv2d_long_k_layers_split_the_contraction(B, Cin, H, W, Cout, k, stride, in_relu):
+    """Layers of few 128 x 128 tiles and >= 96 k-steps run the LDS-DMA kernel with the k-steps split across blockIdx.z
+    (partial tiles through the workspace, summed in order by the reduce kernel with the fused epilogue): parity with
+    torch, agreement with the small-tile kernel, bit-reproducible."""
+    from zeroshape_amd.nn import ops, pack
+    g = torch.Generator().manual_seed(Cin + Cout + B)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    want = F.conv2d(F.relu(x) if in_relu else x, w, b, stride=stride, padding=k // 2)
+    res = torch.randn(want.shape, generator=g)
+    want = F.relu(want + res)
+    pc = pack.pack_conv(w, b, stride=stride, padding=k // 2).to("cuda")
+    prev = ops.CONV_PRECISION
+    try:
+        ops.set_conv_precision("f16x3")
+        xg, rg = nhwc(x).cuda(), nhwc(res).cuda()
+        got = ops.conv2d(xg, pc, res1=rg, act=ops.ACT_RELU, in_relu=in_relu)
+        close(got, nhwc(want))
+        assert torch.equal(got, ops.conv2d(xg, pc, res1=rg, act=ops.ACT_RELU, in_relu=in_relu))
+        close(got, ops.conv2d(xg, pc, res1=rg, act=ops.ACT_RELU, in_relu=in_relu, tiling="small").cpu(), tol=5e-6)
     finally:
         ops.set_conv_precision(prev)

@@ -62,6 +62,7 @@ struct ConvArgs {
 constexpr size_t WS_COUNTER_FLOATS = (size_t)1 << 18;          // 1 MiB: up to 262,144 tiles
 constexpr int SK_MAX_WGS = 1024;
 constexpr size_t WS_SPLITK_BYTES = (size_t)16 << 20;           // small-tile split-K partial sums
+constexpr size_t WS_PARTS_BYTES = (size_t)SK_MAX_WGS * 2 * 128 * 128 * 4;     // the partial-tile region (stream-K shares, patch-kernel split-K)
 
 __device__ __forceinline__ float activate(float v, int act) {
     if (act == ZS_ACT_RELU) return fmaxf(v, 0.f);
@@ -495,9 +496,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DMA_NS == 2
     const char *zero = reinterpret_cast<const char *>(zs_zero_page);
     const f32x4 *wq = reinterpret_cast<const f32x4 *>(a.w);
 
-    int it = SK ? (int)blockIdx.x * a.sk_per : ((int)blockIdx.x * ntiles + (int)blockIdx.y) * ksteps;
+    // plain split-K (a.splits > 1, not SK): blockIdx.z owns the k-steps [z, z + 1) * ksteps / splits of its tile and writes the
+    // raw partial tile to ws[z][M][Cout]; conv_splitk_reduce_kernel sums the ranges in order and applies the epilogue
+    const int split_lo = (!SK && a.splits > 1) ? (int)(((long long)blockIdx.z * ksteps) / a.splits) : 0;
+    const int split_n = (!SK && a.splits > 1) ? (int)(((long long)(blockIdx.z + 1) * ksteps) / a.splits) - split_lo : ksteps;
+    int it = SK ? (int)blockIdx.x * a.sk_per : ((int)blockIdx.x * ntiles + (int)blockIdx.y) * ksteps + split_lo;
     const int it_begin = it;
-    const int it_end = SK ? min(it + a.sk_per, (int)(((a.M + TMB - 1) / TMB) * ntiles) * ksteps) : it + ksteps;
+    const int it_end = SK ? min(it + a.sk_per, (int)(((a.M + TMB - 1) / TMB) * ntiles) * ksteps) : it + split_n;
 
     while (it < it_end) {
     const int tile = it / ksteps, kb = it - tile * ksteps, ke = min(ksteps, kb + (it_end - it));
@@ -637,11 +642,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DMA_NS == 2
         const int n = n0 + wn + 32 * j + l32;
         if (n >= a.Cout) return;
         const float sc = a.scale ? a.scale[n] : 1.0f, sh = a.shift ? a.shift[n] : 0.0f;
+        float *part = (!SK && a.splits > 1) ? a.ws + WS_COUNTER_FLOATS + (size_t)blockIdx.z * a.M * a.Cout : nullptr;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int m = m0 + wm + 32 * i + 8 * (r >> 2) + 4 * half + (r & 3);
             if (m >= a.M) continue;
             const size_t o = (size_t)m * a.Cout + n;
+            if (part) { part[o] = d[r]; continue; }
             float v = d[r] * sc + sh;
             if (a.res1) v += a.res1[o];
             if (a.res2) v += a.res2[o];
@@ -1115,8 +1122,8 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs a) {
 }  // namespace
 
 extern "C" size_t zs_conv2d_splitk_workspace_bytes(void) {
-    const size_t parts = (size_t)SK_MAX_WGS * 2 * BM * BN * 4;
-    return WS_COUNTER_FLOATS * 4 + (parts > WS_SPLITK_BYTES ? parts : WS_SPLITK_BYTES);
+    static_assert(WS_PARTS_BYTES == (size_t)SK_MAX_WGS * 2 * BM * BN * 4 && WS_PARTS_BYTES >= WS_SPLITK_BYTES, "workspace regions");
+    return WS_COUNTER_FLOATS * 4 + WS_PARTS_BYTES;
 }
 
 extern "C" int zs_conv2d_nhwc(const float *in, const float *packed_w, const float *scale, const float *shift,
@@ -1208,11 +1215,58 @@ extern "C" int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const f
     if (patch_geom && Cout > 32 && Hout >= 8 && Wout >= 8) {
         const int tx = (Wout + patch128::TW - 1) / patch128::TW, ty = (Hout + patch128::TH - 1) / patch128::TH;
         const long long wgs = (long long)batch * tx * ty * (a.CoutPad / BN);
-        if (wgs >= patch_min) {
-            const dim3 grid((unsigned)((long long)batch * tx * ty), (unsigned)(a.CoutPad / BN));
+        // few tiles (14 x 14 maps at batch 28: 112; everything at batch 1): split the slabs across ~384 workgroups, partial
+        // tiles through the workspace, summed in range order by conv_splitk_reduce_kernel (which applies the epilogue)
+        static const long long split_target = getenv("ZS_CONV_PATCH_SPLIT_TARGET") ? atoll(getenv("ZS_CONV_PATCH_SPLIT_TARGET")) : 384;
+        static const long long split_min = getenv("ZS_CONV_PATCH_SPLIT_MIN") ? atoll(getenv("ZS_CONV_PATCH_SPLIT_MIN")) : 64;
+        long long sp = 1;
+        if (wgs < patch_min && workspace && wgs >= split_min) {
+            sp = (split_target + wgs - 1) / wgs;
+            const long long slabs = Cin / BK, cap = (long long)(WS_PARTS_BYTES / 4) / (M * (long long)Cout);
+            if (sp > slabs / 2) sp = slabs / 2;            // at least two slabs (18 tap-steps) per range
+            if (sp > cap) sp = cap;
+        }
+        if (wgs >= patch_min || sp > 1) {
+            a.splits = (int)(sp > 1 ? sp : 1);
+            const dim3 grid((unsigned)((long long)batch * tx * ty), (unsigned)(a.CoutPad / BN), (unsigned)a.splits);
             if (a.in_relu) hipLaunchKernelGGL((conv3x3_patch128_kernel<true>), grid, dim3(256), 0, st, a, tx, ty);
             else hipLaunchKernelGGL((conv3x3_patch128_kernel<false>), grid, dim3(256), 0, st, a, tx, ty);
+            if (a.splits > 1) {
+                const long long total = M * (long long)Cout;
+                const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+                hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
+            }
             return zs::check_launch("zs_conv2d_nhwc") ? 1 : 0;
+        }
+    }
+    // few 128 x 128 tiles but a long contraction (3 x 3 768 -> 768 on 7 x 7 maps at batch 28: 66 tiles, 432 k-steps): the
+    // LDS-DMA kernel with the k-steps split across blockIdx.z, ~384 workgroups, >= 24 steps each
+    // (tools/conv_shapes.py + tools/bench_encoder.py, same box: batch 28 18.23 -> 17.89 ms - the 768 -> 768 head layers 156 ->
+    // 100 us; below ~40 tiles - the ViT fc2 at batch 1: 12 tiles - the reduce launch costs more than the ranges save)
+    static const long long dsplit_min_steps = getenv("ZS_CONV_DMA_SPLIT_MIN_STEPS") ? atoll(getenv("ZS_CONV_DMA_SPLIT_MIN_STEPS")) : 96;
+    static const long long dsplit_min_tiles = getenv("ZS_CONV_DMA_SPLIT_MIN_TILES") ? atoll(getenv("ZS_CONV_DMA_SPLIT_MIN_TILES")) : 40;
+    {
+        const bool pw_ = kh == 1 && kw == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && a.dil == 1 && !a.in_relu &&
+                         in_scale == 1.0f && in_shift == 0.0f && Hin == Hout && Win == Wout;
+        const bool dma_ok = f16 && a.w_split && (Cin % BK) == 0 && in_scale == 1.0f && in_shift == 0.0f && a.dil == 1 &&
+                            getenv("ZS_CONV_NO_DMA") == nullptr;
+        const long long ksteps = (a.K + BK - 1) / BK;
+        if (small && !(flags & ZS_CONV_FORCE_SMALL) && workspace && dma_ok && ksteps >= dsplit_min_steps && big_tiles >= dsplit_min_tiles) {
+            long long sp = (384 + big_tiles - 1) / big_tiles;
+            const long long cap = (long long)(WS_PARTS_BYTES / 4) / (M * (long long)Cout);
+            if (sp > ksteps / 24) sp = ksteps / 24;
+            if (sp > cap) sp = cap;
+            if (sp > 1) {
+                a.splits = (int)sp;
+                const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(a.CoutPad / BN), (unsigned)sp);
+                if (pw_) hipLaunchKernelGGL((conv_gemm_dma_kernel<true, false, false, 3, 2>), grid, dim3(256), 0, st, a);
+                else if (a.in_relu) hipLaunchKernelGGL((conv_gemm_dma_kernel<false, true, false, 3, 2>), grid, dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((conv_gemm_dma_kernel<false, false, false, 3, 2>), grid, dim3(256), 0, st, a);
+                const long long total = M * (long long)Cout;
+                const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+                hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
+                return zs::check_launch("zs_conv2d_nhwc") ? 1 : 0;
+            }
         }
     }
     if (small) {

@@ -250,7 +250,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     const int b = (int)blockIdx.x / per_image, trem = (int)blockIdx.x - b * per_image;
     const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
     const int n0 = (int)blockIdx.y * BN;
-    const int slabs = a.Cin / BK;
+    // split-K (a.splits > 1, layers of few tiles - 14 x 14 maps, batch 1): blockIdx.z owns a contiguous range of the slabs and
+    // writes its raw partial tile to ws[z][pixel][cout]; conv_splitk_reduce_kernel sums the ranges in order (deterministic)
+    const int all_slabs = a.Cin / BK;
+    const int slab_lo = (int)(((long long)blockIdx.z * all_slabs) / a.splits);
+    const int slabs = (int)(((long long)(blockIdx.z + 1) * all_slabs) / a.splits) - slab_lo;
     const int wm = wave & 1, wn = (wave >> 1) * 64;            // wave tile: tile rows 4 wm .. 4 wm + 3, columns wn .. wn + 63
 
     // patch loader: unit u = tid + 256 r = (patch pixel u / 4, k-quad u % 4), as in conv3x3_patch32_kernel
@@ -268,11 +272,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     // weights: per tap-step this wave fetches row quad `wave` of the step, columns n0 + lane and n0 + 64 + lane
     const f32x4 *gb = reinterpret_cast<const f32x4 *>(a.w) + (size_t)wave * a.CoutPad + n0 + lane;
     const size_t b_tap = (size_t)(a.Cin >> 2) * a.CoutPad, b_slab = (size_t)KQ * a.CoutPad;     // f32x4 units
-    // workgroups start at different slabs and wrap (see conv3x3_patch32_kernel)
+    // workgroups start at different slabs of their range and wrap (see conv3x3_patch32_kernel); slab_at counts inside the range
     int slab_at = (int)((blockIdx.x >> 3) % (unsigned)slabs);
 #pragma unroll
-    for (int r = 0; r < 3; r++) ga[r] += (size_t)slab_at * ga_inc[r];
-    gb += (size_t)slab_at * b_slab;
+    for (int r = 0; r < 3; r++) ga[r] += (size_t)(slab_lo + slab_at) * ga_inc[r];
+    gb += (size_t)(slab_lo + slab_at) * b_slab;
 
     f32x4 stage_a[3];
     auto load_a = [&](int r) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(stage_a[r]) : "v"(ga[r]) : "memory"); };
@@ -382,6 +386,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the zero-page DMAs and the spare patch loads of the last slab
 
+    float *part = a.splits > 1 ? a.ws + WS_COUNTER_FLOATS + (size_t)blockIdx.z * a.M * a.Cout : nullptr;
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int n = n0 + wn + 32 * j + l32;
@@ -395,6 +400,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
                 const int y = y0 + 2 * (2 * wm + i) + (rr >> 4), x = x0 + (rr & 15);
                 if (y >= a.Hout || x >= a.Wout) continue;
                 const size_t o = (((size_t)b * a.Hout + y) * a.Wout + x) * a.Cout + n;
+                if (part) { part[o] = acc[i][j][r]; continue; }
                 float v = acc[i][j][r] * sc + sh;
                 if (a.res1) v += a.res1[o];
                 if (a.res2) v += a.res2[o];

@@ -98,7 +98,7 @@ def conv2d(x, pc, res1=None, res2=None, act=ACT_NONE, in_relu=False, in_scale=1.
                                          _lib.ptr(res1), _lib.ptr(res2), _lib.ptr(out), B, H, W, C, Ho, Wo, pc.cout,
                                          pc.kh, pc.kw, pc.stride, pt, pl,
                                          flags, float(in_scale), float(in_shift), act,
-                                         _lib.ptr(splitk_workspace(x.device)) if (SPLIT_K or STREAM_K) else None, _stream(x)),
+                                         _lib.ptr(splitk_workspace(x.device)), _stream(x)),
                    "zs_conv2d_nhwc_ws")
     return out
 
