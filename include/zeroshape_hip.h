@@ -435,7 +435,10 @@ int zs_conv2d_nhwc(const float *in, const float *packed_w, const float *scale, c
  * stream at a time; NULL = zs_conv2d_nhwc).  What uses it is chosen by the flags: ZS_CONV_SPLIT_SMALL (problems
  * that would launch fewer than 256 small-tile workgroups - 14x14 feature maps, 197-token matrices at small
  * batch - split K across workgroups; a second kernel sums the partial tiles in split order and applies the
- * fused epilogue) and ZS_CONV_STREAM_K (128x128-tile problems; see above).  Both are deterministic. */
+ * fused epilogue) and ZS_CONV_STREAM_K (128x128-tile problems; see above).  Independently of those flags, with
+ * ZS_CONV_F16X3 | ZS_CONV_W_PRESPLIT a workspace lets two more paths split the contraction across workgroups the same
+ * way (partial tiles, summed in order): 3x3 stride-1 layers of 64..191 input-patch workgroups (nn_conv_patch.h) and
+ * layers of 40..191 tiles with >= 96 k-steps on the LDS-DMA kernel.  All of it is deterministic. */
 size_t zs_conv2d_splitk_workspace_bytes(void);
 int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const float *scale, const float *shift,
                    const float *res1, const float *res2, float *out, int batch, int Hin, int Win, int Cin,

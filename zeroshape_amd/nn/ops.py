@@ -30,6 +30,8 @@ CONV_PRECISION = os.environ.get("ZS_ENCODER_PRECISION", "f16x3")
 # the pointwise ones stay at 11.5 us (bound by their dependent first loads, not by workgroup count) and the
 # reduction kernel costs 4.5 us per layer: 4.65 vs 4.37 ms of kernel time per forward.  ZS_CONV_SPLIT_K=1 enables it.
 SPLIT_K = os.environ.get("ZS_CONV_SPLIT_K", "0") != "0"
+# (The workspace itself is always passed: the 3x3 input-patch kernels and the LDS-DMA kernel split the contraction of layers
+# with few tiles through it by their own rules - csrc/nn_conv.hip, round 3.)
 # Stream-K for the large-tile launches (ZS_CONV_STREAM_K): a fixed number of workgroups share the (tile, k-step)
 # space evenly instead of one tile each.  Built, tested (test_conv2d_stream_k) and OFF by default: measured inside the
 # batch-28 encoder (tools/conv_shapes.py) the large-tile kernels are bound by the bytes they pull into LDS, a short
