@@ -1228,7 +1228,13 @@ extern "C" int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const f
         }
         if (wgs >= patch_min || sp > 1) {
             a.splits = (int)(sp > 1 ? sp : 1);
-            const dim3 grid((unsigned)((long long)batch * tx * ty), (unsigned)(a.CoutPad / BN), (unsigned)a.splits);
+            static const bool xcd_map = getenv("ZS_CONV_PATCH_XCD") ? atoi(getenv("ZS_CONV_PATCH_XCD")) != 0 : true;
+            const long long mtiles = (long long)batch * tx * ty, ntl = a.CoutPad / BN;
+            dim3 grid((unsigned)mtiles, (unsigned)ntl, (unsigned)a.splits);
+            if (xcd_map && ntl > 1) {
+                a.sk_per = (int)ntl;
+                grid = dim3((unsigned)((mtiles + 7) / 8 * 8 * ntl), 1, (unsigned)a.splits);
+            }
             if (a.in_relu) hipLaunchKernelGGL((conv3x3_patch128_kernel<true>), grid, dim3(256), 0, st, a, tx, ty);
             else hipLaunchKernelGGL((conv3x3_patch128_kernel<false>), grid, dim3(256), 0, st, a, tx, ty);
             if (a.splits > 1) {

@@ -247,9 +247,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     const f32x4 *zero = zs_zero_page;
 
     const int per_image = tiles_x * tiles_y;
-    const int b = (int)blockIdx.x / per_image, trem = (int)blockIdx.x - b * per_image;
+    // a.sk_per = number of column tiles when the launch is 1-D and XCD-aware: workgroup L runs on XCD L % 8 (round-robin
+    // dispatch), so the column tiles of one pixel tile are given consecutive slots of ONE XCD - the second one finds the patch in
+    // that XCD's L2 - and consecutive pixel tiles (shared halos) go round the XCDs as before.  0: grid (pixel tiles, column tiles)
+    int mt = (int)blockIdx.x, nt = (int)blockIdx.y;
+    if (a.sk_per > 0) {
+        const int k = (int)blockIdx.x >> 3;
+        nt = k % a.sk_per;
+        mt = (k / a.sk_per) * 8 + ((int)blockIdx.x & 7);
+        if (mt >= a.B * per_image) return;
+    }
+    const int b = mt / per_image, trem = mt - b * per_image;
     const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
-    const int n0 = (int)blockIdx.y * BN;
+    const int n0 = nt * BN;
     // split-K (a.splits > 1, layers of few tiles - 14 x 14 maps, batch 1): blockIdx.z owns a contiguous range of the slabs and
     // writes its raw partial tile to ws[z][pixel][cout]; conv_splitk_reduce_kernel sums the ranges in order (deterministic)
     const int all_slabs = a.Cin / BK;
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     const f32x4 *gb = reinterpret_cast<const f32x4 *>(a.w) + (size_t)wave * a.CoutPad + n0 + lane;
     const size_t b_tap = (size_t)(a.Cin >> 2) * a.CoutPad, b_slab = (size_t)KQ * a.CoutPad;     // f32x4 units
     // workgroups start at different slabs of their range and wrap (see conv3x3_patch32_kernel); slab_at counts inside the range
-    int slab_at = (int)((blockIdx.x >> 3) % (unsigned)slabs);
+    int slab_at = (int)(((unsigned)mt >> 3) % (unsigned)slabs);
 #pragma unroll
     for (int r = 0; r < 3; r++) ga[r] += (size_t)(slab_lo + slab_at) * ga_inc[r];
     gb += (size_t)(slab_lo + slab_at) * b_slab;
