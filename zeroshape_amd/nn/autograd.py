@@ -274,10 +274,35 @@ def _out_size(n, k, stride, padding):
     return (n + 2 * padding - k) // stride + 1, padding
 
 
+_CONV_W_PRESPLIT = 128
+_PRESPLIT = {}          # packed.data_ptr() -> (generation, split operand)
+# optim.amp: layers large enough for the LDS-DMA GEMM kernel or the 3x3 input-patch kernels (>= 192 tiles of 128 x 128,
+# channels a multiple of 16, no input affine) get their packed operand split into fp16 halves once per optimiser step
+# (zs_conv2d_presplit_weight), which is what those kernels consume; the other layers split on the fly as before.
+PRESPLIT_MIN_TILES = int(os.environ.get("ZS_TRAIN_PRESPLIT_MIN_TILES", "192"))
+
+
+def _presplit(packed, C, Co, kh, kw, device):
+    lib = _lib.load()
+    rec = _PRESPLIT.get(packed.data_ptr())
+    if rec is None or rec[0] != GENERATION[0] or rec[1].numel() != packed.numel():
+        split = rec[1] if rec is not None and rec[1].numel() == packed.numel() else torch.empty_like(packed)
+        with _lib.on(device):
+            _lib.check(lib.zs_conv2d_presplit_weight(_lib.ptr(packed), _lib.ptr(split), C, Co, kh, kw,
+                                                     _lib.current_stream_ptr(device)), "zs_conv2d_presplit_weight")
+        rec = (GENERATION[0], split)
+        _PRESPLIT[packed.data_ptr()] = rec
+    return rec[1]
+
+
 def _conv_launch(x, packed, shift, res1, res2, out, kh, kw, stride, pt, pl, flags, in_scale, in_shift, act):
     lib = _lib.load()
     B, H, W, C = x.shape
     _, Ho, Wo, Co = out.shape
+    if (flags & _CONV_F16X3) and not (flags & _CONV_IN_DILATE2) and C % 16 == 0 and in_scale == 1.0 and in_shift == 0.0 and \
+            -(-(B * Ho * Wo) // 128) * -(-Co // 128) >= PRESPLIT_MIN_TILES:
+        packed = _presplit(packed, C, Co, kh, kw, x.device)
+        flags |= _CONV_W_PRESPLIT
     with _lib.on(x.device):
         _lib.check(lib.zs_conv2d_nhwc(_lib.ptr(x), _lib.ptr(packed), None, _lib.ptr(shift), _lib.ptr(res1),
                                       _lib.ptr(res2), _lib.ptr(out), B, H, W, C, Ho, Wo, Co, kh, kw, stride, pt, pl,
