@@ -12,7 +12,7 @@ CMD="python3 $ROOT/tools/bench_patch.py --iters 3 --shape $SHAPE"
 pass() {
   local name=$1; shift
   rm -rf /tmp/pp_$name
-  rocprofv3 --pmc "$@" -d /tmp/pp_$name/pmc -- $CMD > /dev/null 2>&1
+  timeout 120 rocprofv3 --pmc "$@" -d /tmp/pp_$name/pmc -- $CMD > /dev/null 2>&1
   python3 $ROOT/tools/rocpd_summary.py /tmp/pp_$name 2>&1 | grep -E "patch|conv_gemm_dma" | head -12 > $OUT/${TAG}_$name.txt
   rm -rf /tmp/pp_$name
 }

@@ -15,9 +15,9 @@ run() {  # name, command..., then counters
     local cmd=$1; shift
     rm -rf /tmp/prof_$name
     if [ $# -eq 0 ]; then
-        rocprofv3 --kernel-trace --stats -d /tmp/prof_$name/trace -- $cmd > /tmp/prof_$name.log 2>&1
+        timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$name/trace -- $cmd > /tmp/prof_$name.log 2>&1
     else
-        rocprofv3 --pmc "$@" -d /tmp/prof_$name/pmc -- $cmd > /tmp/prof_$name.log 2>&1
+        timeout 300 rocprofv3 --pmc "$@" -d /tmp/prof_$name/pmc -- $cmd > /tmp/prof_$name.log 2>&1
     fi
     python3 $ROOT/tools/rocpd_summary.py /tmp/prof_$name > $OUT/${TAG}_$name.txt 2>&1
     rm -rf /tmp/prof_$name

@@ -634,25 +634,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DMA_NS == 2
 #pragma unroll
         for (int i = 0; i < MI; i++)
 #pragma unroll
-            for (int j = 0; j < 2; j++) zs::s16::mfma3(acc[i][j], ah[i], al[i], bh[j], bl[j]);
+            for (int j = 0; j < 2; j++) zs::s16::mfma3(acc[i][j], bh[j], bl[j], ah[i], al[i]);   // transposed: rows = channels
 #endif
     }
 
+    // The MFMAs take the weights as their A operand: register 4 q + e of lane (l32, half) is output channel 8 q + 4 half + e
+    // of row l32 of the block - four consecutive channels of one pixel, moved as 16 bytes per lane (a quarter of the
+    // epilogue's vector-memory instructions; the 1x1 layers with K = 64..256 are mostly epilogue).
     auto epilogue = [&](int i, int j, const f32x16 &d) {
-        const int n = n0 + wn + 32 * j + l32;
-        if (n >= a.Cout) return;
-        const float sc = a.scale ? a.scale[n] : 1.0f, sh = a.shift ? a.shift[n] : 0.0f;
+        const int m = m0 + wm + 32 * i + l32;
+        if (m >= a.M) return;
         float *part = (!SK && a.splits > 1) ? a.ws + WS_COUNTER_FLOATS + (size_t)blockIdx.z * a.M * a.Cout : nullptr;
+        const size_t row = (size_t)m * a.Cout;
+        const bool vec = (a.Cout & 3) == 0;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int m = m0 + wm + 32 * i + 8 * (r >> 2) + 4 * half + (r & 3);
-            if (m >= a.M) continue;
-            const size_t o = (size_t)m * a.Cout + n;
-            if (part) { part[o] = d[r]; continue; }
-            float v = d[r] * sc + sh;
-            if (a.res1) v += a.res1[o];
-            if (a.res2) v += a.res2[o];
-            a.out[o] = activate(v, a.act);
+        for (int q = 0; q < 4; q++) {
+            const int n = n0 + wn + 32 * j + 8 * q + 4 * half;
+            if (n >= a.Cout) continue;
+            f32x4 v = {d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
+            if (vec) {
+                if (part) { *reinterpret_cast<f32x4 *>(part + row + n) = v; continue; }
+                if (a.scale) v *= *reinterpret_cast<const f32x4 *>(a.scale + n);
+                if (a.shift) v += *reinterpret_cast<const f32x4 *>(a.shift + n);
+                if (a.res1) v += *reinterpret_cast<const f32x4 *>(a.res1 + row + n);
+                if (a.res2) v += *reinterpret_cast<const f32x4 *>(a.res2 + row + n);
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = activate(v[e], a.act);
+                *reinterpret_cast<f32x4 *>(a.out + row + n) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if (n + e >= a.Cout) continue;
+                    const size_t o = row + n + e;
+                    if (part) { part[o] = v[e]; continue; }
+                    float t = v[e] * (a.scale ? a.scale[n + e] : 1.0f) + (a.shift ? a.shift[n + e] : 0.0f);
+                    if (a.res1) t += a.res1[o];
+                    if (a.res2) t += a.res2[o];
+                    a.out[o] = activate(t, a.act);
+                }
+            }
         }
     };
     if (!SK || (kb == 0 && ke == ksteps)) {

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 2,
             if (tap + 1 < 9) fetch(tap + 1, (tap + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < MB; i++) zs::s16::mfma3(acc[i], ah[tap & 1][i], al[tap & 1][i], bh[tap & 1], bl[tap & 1]);
+            for (int i = 0; i < MB; i++) zs::s16::mfma3(acc[i], bh[tap & 1], bl[tap & 1], ah[tap & 1][i], al[tap & 1][i]);   // rows = channels
             __builtin_amdgcn_sched_barrier(0);
         }
         ZS_P32_STAMP(5 * s + 3);
@@ -201,21 +201,42 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 2,
         ZS_P32_STAMP(5 * s + 4);
     }
 
-    if (l32 < a.Cout) {
-        const float sc = a.scale ? a.scale[l32] : 1.0f, sh = a.shift ? a.shift[l32] : 0.0f;
+    // transposed products (weights as the MFMA's A operand): register 4 q + e of lane (l32, half) = channel 8 q + 4 half + e of
+    // pixel l32 of the block; 16 bytes per lane and instruction (see conv3x3_patch128_kernel)
+    {
+        const int rr = block_pixel(l32);
+        const bool vec = (a.Cout & 3) == 0;
 #pragma unroll
-        for (int i = 0; i < MB; i++)
+        for (int i = 0; i < MB; i++) {
+            const int y = y0 + 2 * (MB * wave + i) + (rr >> 4), x = x0 + (rr & 15);
+            if (y >= a.Hout || x >= a.Wout) continue;
+            const size_t pix = (((size_t)b * a.Hout + y) * a.Wout + x) * a.Cout;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int rr = block_pixel(8 * (r >> 2) + 4 * half + (r & 3));
-                const int y = y0 + 2 * (MB * wave + i) + (rr >> 4), x = x0 + (rr & 15);
-                if (y >= a.Hout || x >= a.Wout) continue;
-                const size_t o = (((size_t)b * a.Hout + y) * a.Wout + x) * a.Cout + l32;
-                float v = acc[i][r] * sc + sh;
-                if (a.res1) v += a.res1[o];
-                if (a.res2) v += a.res2[o];
-                a.out[o] = activate(v, a.act);
+            for (int q = 0; q < 4; q++) {
+                const int n = 8 * q + 4 * half;
+                if (n >= a.Cout) continue;
+                f32x4 v = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+                if (vec) {
+                    if (a.scale) v *= *reinterpret_cast<const f32x4 *>(a.scale + n);
+                    if (a.shift) v += *reinterpret_cast<const f32x4 *>(a.shift + n);
+                    if (a.res1) v += *reinterpret_cast<const f32x4 *>(a.res1 + pix + n);
+                    if (a.res2) v += *reinterpret_cast<const f32x4 *>(a.res2 + pix + n);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = activate(v[e], a.act);
+                    *reinterpret_cast<f32x4 *>(a.out + pix + n) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        if (n + e >= a.Cout) continue;
+                        const size_t o = pix + n + e;
+                        float t = v[e] * (a.scale ? a.scale[n + e] : 1.0f) + (a.shift ? a.shift[n + e] : 0.0f);
+                        if (a.res1) t += a.res1[o];
+                        if (a.res2) t += a.res2[o];
+                        a.out[o] = activate(t, a.act);
+                    }
+                }
             }
+        }
     }
     ZS_P32_STAMP(63);
 #undef ZS_P32_STAMP
@@ -380,7 +401,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
-                for (int j = 0; j < 2; j++) zs::s16::mfma3(acc[i][j], ah[i], al[i], bh[j], bl[j]);
+                for (int j = 0; j < 2; j++) zs::s16::mfma3(acc[i][j], bh[j], bl[j], ah[i], al[i]);   // D = W^T A^T: rows = channels
         };
         tap_step(std::integral_constant<int, 0>());
         tap_step(std::integral_constant<int, 1>());
@@ -396,25 +417,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the zero-page DMAs and the spare patch loads of the last slab
 
+    // The products are formed transposed (weights as the MFMA's A operand): accumulator register 4 q + e of lane (l32, half) is
+    // channel 8 q + 4 half + e of pixel l32 - four consecutive channels of ONE pixel per register quad, so the epilogue moves
+    // 16 bytes per lane and instruction (residuals in, result out) instead of 4: a quarter of the vector-memory instructions,
+    // which is what the tiles' last phase queues behind (tools/stamp_patch.py).
     float *part = a.splits > 1 ? a.ws + WS_COUNTER_FLOATS + (size_t)blockIdx.z * a.M * a.Cout : nullptr;
+    const bool vec = (a.Cout & 3) == 0;
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int n = n0 + wn + 32 * j + l32;
-        if (n >= a.Cout) continue;
-        const float sc = a.scale ? a.scale[n] : 1.0f, sh = a.shift ? a.shift[n] : 0.0f;
+    for (int i = 0; i < 2; i++) {
+        const int rr = block_pixel(l32);
+        const int y = y0 + 2 * (2 * wm + i) + (rr >> 4), x = x0 + (rr & 15);
+        if (y >= a.Hout || x >= a.Wout) continue;
+        const size_t pix = (((size_t)b * a.Hout + y) * a.Wout + x) * a.Cout;
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int rr = block_pixel(8 * (r >> 2) + 4 * half + (r & 3));
-                const int y = y0 + 2 * (2 * wm + i) + (rr >> 4), x = x0 + (rr & 15);
-                if (y >= a.Hout || x >= a.Wout) continue;
-                const size_t o = (((size_t)b * a.Hout + y) * a.Wout + x) * a.Cout + n;
-                if (part) { part[o] = acc[i][j][r]; continue; }
-                float v = acc[i][j][r] * sc + sh;
-                if (a.res1) v += a.res1[o];
-                if (a.res2) v += a.res2[o];
-                a.out[o] = activate(v, a.act);
+            for (int q = 0; q < 4; q++) {
+                const int n = n0 + wn + 32 * j + 8 * q + 4 * half;
+                if (n >= a.Cout) continue;
+                f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                if (vec) {                                     // n + 3 < Cout as well
+                    if (part) { *reinterpret_cast<f32x4 *>(part + pix + n) = v; continue; }
+                    if (a.scale) v *= *reinterpret_cast<const f32x4 *>(a.scale + n);
+                    if (a.shift) v += *reinterpret_cast<const f32x4 *>(a.shift + n);
+                    if (a.res1) v += *reinterpret_cast<const f32x4 *>(a.res1 + pix + n);
+                    if (a.res2) v += *reinterpret_cast<const f32x4 *>(a.res2 + pix + n);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = activate(v[e], a.act);
+                    *reinterpret_cast<f32x4 *>(a.out + pix + n) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        if (n + e >= a.Cout) continue;
+                        const size_t o = pix + n + e;
+                        if (part) { part[o] = v[e]; continue; }
+                        float t = v[e] * (a.scale ? a.scale[n + e] : 1.0f) + (a.shift ? a.shift[n + e] : 0.0f);
+                        if (a.res1) t += a.res1[o];
+                        if (a.res2) t += a.res2[o];
+                        a.out[o] = activate(t, a.act);
+                    }
+                }
             }
     }
 }
