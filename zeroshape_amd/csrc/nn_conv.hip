@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
-                for (int j = 0; j < 2; j++) zs::s16::mfma3(acc[i][j], ah[i], al[i], bh[j], bl[j]);
+                for (int j = 0; j < 2; j++) zs::s16::mfma3(acc[i][j], bh[j], bl[j], ah[i], al[i]);   // transposed: rows = channels
         } else
 #pragma unroll
         for (int t = 0; t < 2; t++) {
@@ -367,26 +367,44 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
                 for (int i = 0; i < 2; i++)
 #pragma unroll
                     for (int j = 0; j < 2; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][s], fa[i][s], acc[i][j], 0, 0, 0);   // D^T
         }
         if (more) stage(cur ^ 1);
         __syncthreads();
     }
 
-    // epilogue of one 32x32 tile: D[row = 8*(r/4) + 4*half + r%4][col = l32]
+    // epilogue of one 32x32 tile.  The products are formed transposed (the weights are the MFMA's A operand): register
+    // 4 q + e of lane (l32, half) = D[pixel row l32][channel 8 q + 4 half + e] - four consecutive channels of one pixel,
+    // moved as 16 bytes per lane (a quarter of the epilogue's vector-memory instructions; same sums, same order)
     auto epilogue = [&](int i, int j, const f32x16 &d) {
-        const int n = n0 + wn + 32 * j + l32;
-        if (n >= a.Cout) return;
-        const float sc = a.scale ? a.scale[n] : 1.0f, sh = a.shift ? a.shift[n] : 0.0f;
+        const int m = m0 + wm + 32 * i + l32;
+        if (m >= a.M) return;
+        const size_t row = (size_t)m * a.Cout;
+        const bool vec = (a.Cout & 3) == 0;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int m = m0 + wm + 32 * i + 8 * (r >> 2) + 4 * half + (r & 3);
-            if (m >= a.M) continue;
-            const size_t o = (size_t)m * a.Cout + n;
-            float v = d[r] * sc + sh;
-            if (a.res1) v += a.res1[o];
-            if (a.res2) v += a.res2[o];
-            a.out[o] = activate(v, a.act);
+        for (int q = 0; q < 4; q++) {
+            const int n = n0 + wn + 32 * j + 8 * q + 4 * half;
+            if (n >= a.Cout) continue;
+            f32x4 v = {d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
+            if (vec) {
+                if (a.scale) v *= *reinterpret_cast<const f32x4 *>(a.scale + n);
+                if (a.shift) v += *reinterpret_cast<const f32x4 *>(a.shift + n);
+                if (a.res1) v += *reinterpret_cast<const f32x4 *>(a.res1 + row + n);
+                if (a.res2) v += *reinterpret_cast<const f32x4 *>(a.res2 + row + n);
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = activate(v[e], a.act);
+                *reinterpret_cast<f32x4 *>(a.out + row + n) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if (n + e >= a.Cout) continue;
+                    const size_t o = row + n + e;
+                    float t = v[e] * (a.scale ? a.scale[n + e] : 1.0f) + (a.shift ? a.shift[n + e] : 0.0f);
+                    if (a.res1) t += a.res1[o];
+                    if (a.res2) t += a.res2[o];
+                    a.out[o] = activate(t, a.act);
+                }
+            }
         }
     };
     if (!SK || (kb == 0 && ke == ksteps)) {
