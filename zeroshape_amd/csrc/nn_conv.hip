@@ -1112,6 +1112,29 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; r++) part[wave][8 * (r >> 2) + 4 * half + (r & 3)][32 * j + l32] = acc[j][r];
     __syncthreads();
+    if ((a.Cout & 3) == 0) {      // four consecutive channels per thread: 16-byte residual loads and stores
+        for (int e = tid; e < SM * SN / 4; e += 256) {
+            const int row = e / (SN / 4), col = 4 * (e % (SN / 4)), m = m0 + row, n = n0 + col;
+            if (m >= a.M || n >= a.Cout) continue;
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                v[c] = (part[0][row][col + c] + part[1][row][col + c]) + (part[2][row][col + c] + part[3][row][col + c]);
+            const size_t o = (size_t)m * a.Cout + n;
+            if (a.splits > 1) {       // raw partial; the epilogue runs in conv_splitk_reduce_kernel
+                *reinterpret_cast<f32x4 *>(a.ws + WS_COUNTER_FLOATS + (size_t)blockIdx.z * a.M * a.Cout + o) = v;
+                continue;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) v[c] = v[c] * (a.scale ? a.scale[n + c] : 1.0f) + (a.shift ? a.shift[n + c] : 0.0f);
+            if (a.res1) v += *reinterpret_cast<const f32x4 *>(a.res1 + o);
+            if (a.res2) v += *reinterpret_cast<const f32x4 *>(a.res2 + o);
+#pragma unroll
+            for (int c = 0; c < 4; c++) v[c] = activate(v[c], a.act);
+            *reinterpret_cast<f32x4 *>(a.out + o) = v;
+        }
+        return;
+    }
     for (int e = tid; e < SM * SN; e += 256) {
         const int row = e / SN, col = e % SN, m = m0 + row, n = n0 + col;
         if (m >= a.M || n >= a.Cout) continue;
