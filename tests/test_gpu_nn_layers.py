@@ -434,3 +434,30 @@ def test_conv2d_long_k_layers_split_the_contraction(B, Cin, H, W, Cout, k, strid
         close(got, ops.conv2d(xg, pc, res1=rg, act=ops.ACT_RELU, in_relu=in_relu, tiling="small").cpu(), tol=5e-6)
     finally:
         ops.set_conv_precision(prev)
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k", [
+    (50, 16, 16, 24, 50, 3),          # input-patch kernel, 128-column tiles, Cout % 4 = 2
+    (8, 64, 56, 56, 130, 1),          # LDS-DMA GEMM kernel (392 tiles), Cout % 4 = 2
+    (2, 32, 40, 40, 31, 3),           # input-patch kernel for <= 32 channels, odd Cout
+    (2, 64, 20, 20, 70, 3),           # few tiles: small-tile kernel, Cout % 4 = 2
+])
+def test_conv2d_channel_counts_that_are_no_multiple_of_four(B, Cin, H, W, Cout, k):
+    """The kernels form their products transposed and move four consecutive output channels per lane; Cout % 4 != 0
+    takes their scalar epilogue: same parity, in both arithmetics and both tilings."""
+    from zeroshape_amd.nn import ops, pack
+    g = torch.Generator().manual_seed(Cout * 7 + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(B, Cout, H, W, generator=g)
+    want = nhwc(F.relu(F.conv2d(x, w, b, padding=k // 2) + res))
+    pc = pack.pack_conv(w, b, stride=1, padding=k // 2).to("cuda")
+    prev = ops.CONV_PRECISION
+    try:
+        for prec in ("f32", "f16x3"):
+            ops.set_conv_precision(prec)
+            for tiling in (None, "large"):
+                close(ops.conv2d(nhwc(x).cuda(), pc, res1=nhwc(res).cuda(), act=ops.ACT_RELU, tiling=tiling), want)
+    finally:
+        ops.set_conv_precision(prev)

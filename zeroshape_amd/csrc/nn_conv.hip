@@ -977,7 +977,10 @@ __global__ __launch_bounds__(512) void conv_gemm_dma256_kernel(ConvArgs a) {
 // float4 per lane = 4 channels of one tap), so a layer launches (M/32)*(Cout/64) workgroups and
 // a wave's dependent MFMA chain is K/4 long instead of K.  Partials are summed through LDS in a
 // fixed order (deterministic), then the same fused epilogue.
-constexpr int SM = 32, SU = 4;       // tile rows, and t-steps (8 k each) per prefetch chunk
+#ifndef ZS_SMALL_SU
+#define ZS_SMALL_SU 4
+#endif
+constexpr int SM = 32, SU = ZS_SMALL_SU;       // tile rows, and t-steps (8 k each) per prefetch chunk
 // NJ = 32-column MFMA tiles per wave: the tile is 32 x 32*NJ (NJ = 1 when even 32x64 tiles leave CUs idle)
 
 // F16: two consecutive t-steps give a lane the eight k values of one K = 16 MFMA operand (A and B in
