@@ -415,10 +415,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     } else {
         // A share of a tile: park the raw accumulators (slot 0 = this workgroup's first segment, slot 1 = its last),
         // count arrivals; the workgroup that arrives last sums all shares in k order - the same sum whoever does
-        // it - and runs the epilogue.  No workgroup ever waits for another.  Shares and counters move as agent-scope
-        // relaxed atomics (sc1: written through to / read from memory, the coherence point of the eight XCDs' L2s)
-        // ordered by the store counter, so no cache-wide writeback / invalidate (what a __threadfence() costs
-        // here: 3x the whole kernel, measured) is needed.  The sum is formed in fresh registers, tile by tile: the
+        // it - and runs the epilogue.  No workgroup ever waits for another.  Shares move as agent-scope relaxed atomics
+        // (sc1: written through to / read from memory, the coherence point of the eight XCDs' L2s), drained by the store
+        // counter before the workgroup barrier; the arrival counter is an ACQ_REL read-modify-write by one thread per
+        // workgroup (release: the shares written before the barrier; acquire: the last arriver reads the others' shares) -
+        // the ordering no longer rests on what gfx950 and hipcc happen to do.  (A __threadfence() in every
+        // thread costs 3x the whole kernel here, measured.)  The sum is formed in fresh registers, tile by tile: the
         // accumulators stay in the AGPR half and the kernel keeps three workgroups per CU.
         float *parts = a.ws + WS_COUNTER_FLOATS;
         int *counters = reinterpret_cast<int *>(a.ws);
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
         __syncthreads();
         const int w_first = (tile * ksteps) / a.sk_per, w_last = ((tile + 1) * ksteps - 1) / a.sk_per;
         if (tid == 0) {
-            const int old = __hip_atomic_fetch_add(&counters[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int old = __hip_atomic_fetch_add(&counters[tile], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             sk_last = old == w_last - w_first;
             if (sk_last)                                      // ready for the next launch
                 __hip_atomic_store(&counters[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -716,7 +718,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DMA_NS == 2
         __syncthreads();
         const int w_first = (tile * ksteps) / a.sk_per, w_last = ((tile + 1) * ksteps - 1) / a.sk_per;
         if (tid == 0) {
-            const int old = __hip_atomic_fetch_add(&counters[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int old = __hip_atomic_fetch_add(&counters[tile], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             sk_last = old == w_last - w_first;
             if (sk_last) __hip_atomic_store(&counters[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -934,7 +936,7 @@ __global__ __launch_bounds__(512) void conv_gemm_dma256_kernel(ConvArgs a) {
         __syncthreads();
         const int w_first = (tile * ksteps) / a.sk_per, w_last = ((tile + 1) * ksteps - 1) / a.sk_per;
         if (tid == 0) {
-            const int old = __hip_atomic_fetch_add(&counters[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int old = __hip_atomic_fetch_add(&counters[tile], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             sk_last = old == w_last - w_first;
             if (sk_last) __hip_atomic_store(&counters[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
