@@ -63,6 +63,10 @@ __device__ __forceinline__ void virtual_ijk(const CubeSpace &cs, long long v, in
 // texture-address path, not by HBM.  Now the four rows arrive as four global_load_dwordx4 (a wave covers 1 KiB
 // contiguous per instruction) and the fifth value of each row comes from the next lane (same row) or one extra load at
 // a row's end.  `first` = the lane's first virtual cube; lanes of one wave own consecutive groups.
+// ROWWAVE (cs.per_row == 64 * MC_PER, e.g. 257^3): a wave is exactly one k-row, so the one value no lane's 16-byte load
+// covers - the row's last - sits at a wave-uniform address and is read through the scalar cache (s_load_dword) instead
+// of a vector-memory instruction with one live lane.
+template <bool ROWWAVE = false>
 __device__ __forceinline__ bool load_cube_rows(const float *__restrict__ vol, int G, const CubeSpace &cs, long long first,
                                                int lane, int &i, int &j, int &k0, float (&rows)[4][MC_PER + 1]) {
     const bool live = first < cs.total;
@@ -74,18 +78,38 @@ __device__ __forceinline__ bool load_cube_rows(const float *__restrict__ vol, in
     const bool wide = live && k0 + MC_PER - 1 <= G - 1;         // the 16-byte load stays inside the row
     const bool next_same_row = lane < 63 && k0 + MC_PER < cs.per_row && first + MC_PER < cs.total;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < 4; r++)
 #pragma unroll
         for (int e = 0; e < MC_PER; e++) rows[r][e] = 0.f;
-        if (wide) {
-            // (rows are G floats apart: 4-byte aligned only, which global_load_dwordx4 accepts)
-            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-            const f4u q = *reinterpret_cast<const f4u *>(src[r]);
-            rows[r][0] = q.x; rows[r][1] = q.y; rows[r][2] = q.z; rows[r][3] = q.w;
-        } else if (live) {
+    // ONE branch around all four rows: with the branch inside the row loop hipcc closes every row's region with its own
+    // s_waitcnt vmcnt(0) - four dependent round trips per thread instead of four loads in flight
+    if (wide) {
+        // (rows are G floats apart: 4-byte aligned only, which global_load_dwordx4 accepts)
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        const f4u q0 = *reinterpret_cast<const f4u *>(src[0]), q1 = *reinterpret_cast<const f4u *>(src[1]);
+        const f4u q2 = *reinterpret_cast<const f4u *>(src[2]), q3 = *reinterpret_cast<const f4u *>(src[3]);
+        rows[0][0] = q0.x; rows[0][1] = q0.y; rows[0][2] = q0.z; rows[0][3] = q0.w;
+        rows[1][0] = q1.x; rows[1][1] = q1.y; rows[1][2] = q1.z; rows[1][3] = q1.w;
+        rows[2][0] = q2.x; rows[2][1] = q2.y; rows[2][2] = q2.z; rows[2][3] = q2.w;
+        rows[3][0] = q3.x; rows[3][1] = q3.y; rows[3][2] = q3.z; rows[3][3] = q3.w;
+    } else if (live) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
 #pragma unroll
             for (int e = 0; e < MC_PER; e++) rows[r][e] = src[r][min(e, G - 1 - k0)];
+    }
+    if (ROWWAVE) {
+        // all lanes of the wave are live or none (whole rows); lane 0's (i, j) is the wave's
+        const int wi = __builtin_amdgcn_readfirstlane(i), wj = __builtin_amdgcn_readfirstlane(j);
+        const bool wlive = __builtin_amdgcn_readfirstlane(live ? 1 : 0) != 0;
+        const float *pe = vol + (wlive ? (size_t)wi * gg + (size_t)wj * G + (G - 1) : 0);
+        const float last[4] = {pe[0], pe[gg], pe[gg + G], pe[G]};        // a dead wave reads row (0, 0): in range, unused
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float v = __shfl_down(rows[r][0], 1, 64);
+            rows[r][MC_PER] = lane == 63 ? last[r] : v;
         }
+        return live;
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -108,21 +132,29 @@ __device__ __forceinline__ int case_of_rows(const float (&rows)[4][MC_PER + 1], 
 
 // Count pass: a wave's 64 x MC_PER consecutive virtual cubes are one UNIT of the emit pass; its entry is
 // (unit has triangles) << 32 | triangles, so one scan yields the triangle offsets and the list of non-empty units.
+// The 256-entry triangle-count table is copied to LDS once per workgroup: the four look-ups per lane are ds_read_u8 instead
+// of four more vector-memory gathers (the pass is bound by its vector-memory instructions - 4 row loads, 4 row-end loads and
+// 4 table gathers per wave before round 3's last change - not by HBM).
+template <bool ROWWAVE>
 __global__ __launch_bounds__(MC_THREADS) void mc_count_kernel(const float *__restrict__ vol, int G,
                                                               float iso,
                                                               const uint8_t *__restrict__ tri_count,
                                                               unsigned long long *__restrict__ unit_sums, long long n_units) {
+    __shared__ uint8_t tri_lds[256];
+    static_assert(MC_THREADS == 256, "one table entry per thread");
+    tri_lds[threadIdx.x] = tri_count[threadIdx.x];
     const CubeSpace cs = cube_space(G);
     const long long first = ((long long)blockIdx.x * MC_THREADS + threadIdx.x) * MC_PER;
     const int lane = threadIdx.x & 63;
     int i, j, k0;
     float rows[4][MC_PER + 1];
-    const bool live = load_cube_rows(vol, G, cs, first, lane, i, j, k0, rows);
+    const bool live = load_cube_rows<ROWWAVE>(vol, G, cs, first, lane, i, j, k0, rows);
+    __syncthreads();
     int n = 0;
     if (live) {
 #pragma unroll
         for (int q = 0; q < MC_PER; q++)
-            if (k0 + q < cs.C) n += tri_count[case_of_rows(rows, q, iso)];
+            if (k0 + q < cs.C) n += tri_lds[case_of_rows(rows, q, iso)];
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
@@ -442,7 +474,9 @@ extern "C" int zs_mc_count(const float *vol, int G, float iso, const uint8_t *tr
     const long long cubes = cube_space(G).total;
     const long long nu = mc_units(G);
     const McScratch m = mc_scratch(scratch, G);
-    hipLaunchKernelGGL(mc_count_kernel, dim3((unsigned)((cubes + MC_BLOCK - 1) / MC_BLOCK)), dim3(MC_THREADS), 0, s, vol, G, iso,
+    if (cube_space(G).per_row == 64 * MC_PER) hipLaunchKernelGGL(mc_count_kernel<true>, dim3((unsigned)((cubes + MC_BLOCK - 1) / MC_BLOCK)), dim3(MC_THREADS), 0, s, vol, G, iso,
+                       tri_count, m.sums, nu);
+    else hipLaunchKernelGGL(mc_count_kernel<false>, dim3((unsigned)((cubes + MC_BLOCK - 1) / MC_BLOCK)), dim3(MC_THREADS), 0, s, vol, G, iso,
                        tri_count, m.sums, nu);
     // exclusive scan over the nu unit sums and one trailing zero: triangle offsets in the low halves, the index of every
     // non-empty unit among the non-empty ones in the high halves
