@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 29
+#define ZS_ABI_VERSION 30
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -444,6 +444,16 @@ int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const float *scale
                    const float *res1, const float *res2, float *out, int batch, int Hin, int Win, int Cin,
                    int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad_t, int pad_l, int flags,
                    float in_scale, float in_shift, int act, void *workspace, void *stream);
+/* A 3x3 stride-1 pad-1 layer of at most 32 output channels with a fused pointwise TAIL to ONE channel - DPT's depth head,
+ * model/depth/dpt_depth.py (reference: DPT output_conv[2..5]: Conv 128 -> 32 3x3, ReLU, Conv 32 -> 1, ReLU):
+ *   out[b][y][x] = tail_act( tail_b[0] + sum_c tail_w[c] * act( conv3x3(in)[b][y][x][c] * scale[c] + shift[c] ) )
+ * in [B][H][W][Cin] (Cin % 16 == 0), out [B][H][W] floats; packed_w = zs_conv2d_presplit_weight output of the 3x3 layer
+ * (split-fp16 arithmetic only: flags must hold ZS_CONV_F16X3 | ZS_CONV_W_PRESPLIT, ZS_CONV_IN_RELU optional); tail_w [Cout],
+ * tail_b [1] (NULL = 0).  The 32-channel intermediate ([B][H][W][32], 180 MB at 224^2 x 28) is never written.  Returns 0 with
+ * zs_last_error set for geometries it does not take (the caller then issues the two layers separately). */
+int zs_conv3x3_tail_nhwc(const float *in, const float *packed_w, const float *scale, const float *shift, float *out,
+                         int batch, int H, int W, int Cin, int Cout, int flags, int act, const float *tail_w,
+                         const float *tail_b, int tail_act, void *stream);
 int zs_group_norm_nhwc(const float *x, const float *gamma, const float *beta, const float *residual, float *y,
                        int batch, int HW, int C, int groups, float eps, int relu, void *stream);
 /* The same with a workspace (zs_group_norm_workspace_bytes; NULL = zs_group_norm_nhwc): tensors of >= 8 MiB take two

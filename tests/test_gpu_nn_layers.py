@@ -461,3 +461,37 @@ def test_conv2d_channel_counts_that_are_no_multiple_of_four(B, Cin, H, W, Cout, 
                 close(ops.conv2d(nhwc(x).cuda(), pc, res1=nhwc(res).cuda(), act=ops.ACT_RELU, tiling=tiling), want)
     finally:
         ops.set_conv_precision(prev)
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cmid,in_relu", [(3, 128, 40, 40, 32, False), (2, 32, 19, 33, 20, True)])
+def test_conv3x3_with_fused_pointwise_tail(B, Cin, H, W, Cmid, in_relu, monkeypatch):
+    """zs_conv3x3_tail_nhwc (DPT's depth head: Conv 3x3 -> ReLU -> Conv 1x1 to one channel -> ReLU, clamp): one launch of
+    the input-patch kernel, the intermediate map never written; parity with torch and with the two separate launches."""
+    from zeroshape_amd.nn import ops, pack
+    g = torch.Generator().manual_seed(Cin + Cmid)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w1 = torch.randn(Cmid, Cin, 3, 3, generator=g) / np.sqrt(9 * Cin)
+    b1 = torch.randn(Cmid, generator=g) * 0.1
+    w2 = torch.randn(1, Cmid, 1, 1, generator=g) / np.sqrt(Cmid)
+    b2 = torch.randn(1, generator=g) * 0.1
+    mid = F.relu(F.conv2d(F.relu(x) if in_relu else x, w1, b1, padding=1))
+    want = nhwc(torch.clamp(F.relu(F.conv2d(mid, w2, b2)), max=1.0))
+    pc1 = pack.pack_conv(w1, b1, stride=1, padding=1).to("cuda")
+    pc2 = pack.pack_conv(w2, b2, stride=1, padding=0).to("cuda")
+    prev = ops.CONV_PRECISION
+    try:
+        ops.set_conv_precision("f16x3")
+        xg = nhwc(x).cuda()
+        fused = ops.conv2d_tail(xg, pc1, pc2, act=ops.ACT_RELU, tail_act=ops.ACT_RELU_CLAMP1, in_relu=in_relu)
+        assert fused.shape == (B, H, W, 1)
+        close(fused, want)
+        assert torch.equal(fused, ops.conv2d_tail(xg, pc1, pc2, act=ops.ACT_RELU, tail_act=ops.ACT_RELU_CLAMP1, in_relu=in_relu))
+        monkeypatch.setattr(ops, "FUSE_TAIL", False)
+        close(fused, ops.conv2d_tail(xg, pc1, pc2, act=ops.ACT_RELU, tail_act=ops.ACT_RELU_CLAMP1, in_relu=in_relu).cpu(), tol=5e-6)
+        ops.set_conv_precision("f32")                   # the exact engine has no fused form: two launches
+        close(ops.conv2d_tail(xg, pc1, pc2, act=ops.ACT_RELU, tail_act=ops.ACT_RELU_CLAMP1, in_relu=in_relu), want)
+    finally:
+        ops.set_conv_precision(prev)
+    lib = __import__("zeroshape_amd._lib", fromlist=["load"]).load()
+    assert lib.zs_conv3x3_tail_nhwc(None, None, None, None, None, 1, 16, 16, 20, 8, 16 | 128, 0, None, None, 0, None) == 0
+    assert b"Cin % 16" in lib.zs_last_error()

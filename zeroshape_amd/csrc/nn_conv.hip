@@ -56,6 +56,9 @@ struct ConvArgs {
     int w_split;   // F16: the weights are already split (zs_conv2d_presplit_weight): quads 4s+q hold the hi halves and
                    // 4s+q+2 the lo halves of the K = 16 operand the lane half q contracts, q = 0, 1
     int slab_major;   // LDS-DMA kernel, kh * kw > 1: walk K as (16-channel slab, tap) instead of (tap, channel) - see SlabWalk
+    // conv3x3_patch32_kernel only: fused pointwise tail to one channel (zs_conv3x3_tail_nhwc); out is then [B][H][W]
+    const float *tail_w, *tail_b;
+    int tail_act;
 };
 
 // workspace layout (floats): [SK_COUNTERS ints, zero between launches][partial tiles / split-K partial sums]
@@ -1217,6 +1220,8 @@ extern "C" int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const f
     if (M > (1LL << 30)) { zs::set_err("zs_conv2d_nhwc: %lld output pixels", M); return 0; }
     ConvArgs a;
     a.slab_major = 0;
+    a.tail_w = a.tail_b = nullptr;
+    a.tail_act = 0;
     a.in = in; a.w = packed_w; a.scale = scale; a.shift = shift; a.res1 = res1; a.res2 = res2; a.out = out;
     a.B = batch; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout;
     a.CoutPad = (Cout + BN - 1) / BN * BN;
@@ -1460,6 +1465,39 @@ extern "C" int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const f
 #undef ZS_LAUNCH
 #undef ZS_LAUNCH1
     return zs::check_launch("zs_conv2d_nhwc") ? 1 : 0;
+}
+
+extern "C" int zs_conv3x3_tail_nhwc(const float *in, const float *packed_w, const float *scale, const float *shift, float *out,
+                                    int batch, int H, int W, int Cin, int Cout, int flags, int act, const float *tail_w,
+                                    const float *tail_b, int tail_act, void *stream) {
+    const int need = ZS_CONV_F16X3 | ZS_CONV_W_PRESPLIT;
+    if (batch < 0 || H < 8 || W < 8 || Cin <= 0 || (Cin % BK) || Cout <= 0 || Cout > 32 || (flags & need) != need ||
+        (flags & ~(need | ZS_CONV_IN_RELU)) || act < 0 || act > ZS_ACT_RELU_CLAMP1 || tail_act < 0 ||
+        tail_act > ZS_ACT_RELU_CLAMP1) {
+        zs::set_err("zs_conv3x3_tail_nhwc: takes 3x3 stride-1 pad-1 layers of <= 32 output channels, Cin %% 16 == 0, maps >= 8x8, "
+                    "flags ZS_CONV_F16X3 | ZS_CONV_W_PRESPLIT [| ZS_CONV_IN_RELU] (B=%d %dx%dx%d -> %d, flags %d)", batch, H, W,
+                    Cin, Cout, flags);
+        return 0;
+    }
+    if (batch == 0) return 1;
+    if (!in || !packed_w || !out || !tail_w) { zs::set_err("zs_conv3x3_tail_nhwc: null pointer"); return 0; }
+    const long long M = (long long)batch * H * W;
+    if (M > (1LL << 30)) { zs::set_err("zs_conv3x3_tail_nhwc: %lld output pixels", M); return 0; }
+    ConvArgs a;
+    a.slab_major = 0;
+    a.in = in; a.w = packed_w; a.scale = scale; a.shift = shift; a.res1 = nullptr; a.res2 = nullptr; a.out = out;
+    a.B = batch; a.Hin = H; a.Win = W; a.Cin = Cin; a.Hout = H; a.Wout = W; a.Cout = Cout;
+    a.CoutPad = (Cout + BN - 1) / BN * BN;
+    a.kh = 3; a.kw = 3; a.stride = 1; a.pad_t = 1; a.pad_l = 1; a.K = 9 * Cin; a.M = (int)M;
+    a.in_relu = (flags & ZS_CONV_IN_RELU) ? 1 : 0;
+    a.act = act; a.in_scale = 1.0f; a.in_shift = 0.0f; a.dil = 1; a.ws = nullptr; a.splits = 1; a.sk_per = 0; a.w_split = 1;
+    a.tail_w = tail_w; a.tail_b = tail_b; a.tail_act = tail_act;
+    const int tx = (W + patch32::PT - 1) / patch32::PT, ty = (H + patch32::PT - 1) / patch32::PT;
+    const dim3 grid((unsigned)((long long)batch * tx * ty));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (a.in_relu) hipLaunchKernelGGL((conv3x3_patch32_kernel<true, 8>), grid, dim3(512), 0, st, a, tx, ty);
+    else hipLaunchKernelGGL((conv3x3_patch32_kernel<false, 8>), grid, dim3(512), 0, st, a, tx, ty);
+    return zs::check_launch("zs_conv3x3_tail_nhwc") ? 1 : 0;
 }
 
 extern "C" int zs_conv2d_presplit_weight(const float *packed_w, float *split_w, int Cin, int Cout, int kh, int kw,

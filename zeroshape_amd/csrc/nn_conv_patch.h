@@ -54,10 +54,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 2,
     constexpr int BR = (B_DMAS + NW - 1) / NW;
     static_assert(AR * NT <= A_PIX * 4 + NT - 64 && (AR == 6 || AR == 3), "loader rounds");
     __shared__ f32x4 lds[2][STAGE_QUADS];
+    __shared__ f32x4 tail_lds[3][8];                           // fused tail: scale | shift | tail weights of the 32 channels
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) f32x4 *)&lds[0][0]);
     const f32x4 *zero = zs_zero_page;
+    if (a.tail_w && tid < 96) {                                // read by the epilogue, many barriers from here
+        const int which = tid >> 5, n = tid & 31;
+        const float *src = which == 0 ? a.scale : which == 1 ? a.shift : a.tail_w;
+        reinterpret_cast<float *>(tail_lds)[tid] = (src && n < a.Cout) ? src[n] : (which == 0 ? 1.0f : 0.0f);
+    }
 
     const int per_image = tiles_x * tiles_y;
     const int b = (int)blockIdx.x / per_image, trem = (int)blockIdx.x - b * per_image;
@@ -210,6 +216,22 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 2,
         for (int i = 0; i < MB; i++) {
             const int y = y0 + 2 * (MB * wave + i) + (rr >> 4), x = x0 + (rr & 15);
             if (y >= a.Hout || x >= a.Wout) continue;
+            if (a.tail_w) {
+                // fused pointwise tail to one channel (zs_conv3x3_tail_nhwc): this lane's 16 channels, then the other lane
+                // half's (the pixel's other 16 channels sit in lane ^ 32); channels >= Cout contribute nothing
+                float t = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const f32x4 sc = tail_lds[0][2 * q + half], sh = tail_lds[1][2 * q + half], tw = tail_lds[2][2 * q + half];
+#pragma unroll
+                    for (int e = 0; e < 4; e++)                 // channels >= Cout: scale 1, shift 0, weight 0
+                        t = fmaf(activate(acc[i][4 * q + e] * sc[e] + sh[e], a.act), tw[e], t);
+                }
+                t += __shfl_xor(t, 32, 64);
+                if (half == 0)
+                    a.out[((size_t)b * a.Hout + y) * a.Wout + x] = activate(t + (a.tail_b ? a.tail_b[0] : 0.f), a.tail_act);
+                continue;
+            }
             const size_t pix = (((size_t)b * a.Hout + y) * a.Wout + x) * a.Cout;
 #pragma unroll
             for (int q = 0; q < 4; q++) {

@@ -105,6 +105,44 @@ def conv2d(x, pc, res1=None, res2=None, act=ACT_NONE, in_relu=False, in_scale=1.
     return out
 
 
+# DPT's depth head ends in Conv 3x3 (128 -> 32) + ReLU + Conv 1x1 (32 -> 1) + ReLU: zs_conv3x3_tail_nhwc runs both as one
+# launch of the input-patch kernel (the 32-channel map - 180 MB at 224 x 224 x 28 - is never written).  ZS_CONV_FUSE_TAIL=0: two
+# launches (A/B measurements).
+FUSE_TAIL = os.environ.get("ZS_CONV_FUSE_TAIL", "1") != "0"
+
+
+def conv2d_tail(x, pc, pc_tail, act=ACT_NONE, tail_act=ACT_NONE, in_relu=False):
+    """tail_act(conv1x1_to_one_channel(act(conv3x3(x)))) -> [B,H,W,1]; fused when the layer pair fits zs_conv3x3_tail_nhwc
+    (split-fp16 arithmetic, 3x3 stride 1 pad 1, <= 32 channels in between), two conv2d calls otherwise."""
+    B, H, W, C = x.shape
+    fits = (FUSE_TAIL and CONV_PRECISION == "f16x3" and PRESPLIT and pc.kh == 3 and pc.kw == 3 and pc.stride == 1 and
+            pc.padding == 1 and pc.cout <= 32 and C % 16 == 0 and H >= 8 and W >= 8 and pc_tail.kh == 1 and
+            pc_tail.kw == 1 and pc_tail.stride == 1 and pc_tail.cout == 1 and pc_tail.cin == pc.cout and
+            pc_tail.padding in (0, "same"))
+    if not fits:
+        return conv2d(conv2d(x, pc, act=act, in_relu=in_relu), pc_tail, act=tail_act)
+    lib = _lib.load()
+    _chk(x, "conv2d_tail input")
+    assert C == pc.cin
+    if pc.w16 is None:
+        pc.w16 = torch.empty_like(pc.w)
+        with _lib.on(x.device):
+            _lib.check(lib.zs_conv2d_presplit_weight(_lib.ptr(pc.w), _lib.ptr(pc.w16), C, pc.cout, pc.kh, pc.kw, _stream(x)),
+                       "zs_conv2d_presplit_weight")
+    if getattr(pc_tail, "tail_vec", None) is None:          # column 0 of the packed [K16/4][CoutPad][4] operand, scale folded in
+        wv = pc_tail.w.view(-1, pc_tail.w.numel() // (4 * ((pc_tail.cin + 15) // 16 * 4)), 4)[:, 0, :].reshape(-1)[:pc_tail.cin]
+        if pc_tail.scale is not None:
+            wv = wv * pc_tail.scale[0]
+        pc_tail.tail_vec = wv.contiguous()
+    out = torch.empty(B, H, W, 1, dtype=torch.float32, device=x.device)
+    flags = (1 if in_relu else 0) | 16 | _CONV_W_PRESPLIT
+    with _lib.on(x.device):
+        _lib.check(lib.zs_conv3x3_tail_nhwc(_lib.ptr(x), _lib.ptr(pc.w16), _lib.ptr(pc.scale), _lib.ptr(pc.shift), _lib.ptr(out),
+                                            B, H, W, C, pc.cout, flags, act, _lib.ptr(pc_tail.tail_vec),
+                                            _lib.ptr(pc_tail.shift), tail_act, _stream(x)), "zs_conv3x3_tail_nhwc")
+    return out
+
+
 def linear(x, pc, res1=None, act=ACT_NONE):
     """x [..., Cin] -> [..., Cout] through the same GEMM (1x1 geometry)."""
     lead = x.shape[:-1]
