@@ -509,6 +509,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DMA_NS == 2
     constexpr int NDMA = MI + 2;                              // DMAs per wave and step: A row blocks of 64, B columns x 2
     constexpr int STAGE_BYTES = (TMB + BN) * BK * 4;
     __shared__ f32x4 lds[DMA_NS][KQ * (TMB + BN)];            // [stage][A: [k-quad][row] | B: [k-quad][column]]
+    __shared__ __attribute__((aligned(16))) float ep_lds[2][BN];   // the tile's per-channel scale | shift (epilogue reads them as
+                                                                  // ds_read_b128: no vector-memory instructions for them)
     __shared__ int sk_last;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -530,6 +532,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DMA_NS == 2
     while (it < it_end) {
     const int tile = it / ksteps, kb = it - tile * ksteps, ke = min(ksteps, kb + (it_end - it));
     const int m0 = (tile / ntiles) * TMB, n0 = (tile % ntiles) * BN;
+    {   // visible to the epilogue through the barriers of the k loop (the previous tile's epilogue is behind a barrier too)
+        const int which = tid >> 7, c = tid & (BN - 1), n = n0 + c;
+        const float *src = which ? a.shift : a.scale;
+        ep_lds[which][c] = (src && n < a.Cout) ? src[n] : (which ? 0.0f : 1.0f);
+    }
 
     // A is staged COALESCED: one DMA covers 16 rows x 64 B (lane = 4 (row % 16) + slot: each row's 16 channels of the
     // step are one contiguous 64 B run - 16 cache lines per instruction; a lane per row, the obvious mapping, touches 64
@@ -677,8 +684,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DMA_NS == 2
             f32x4 v = {d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
             if (vec) {
                 if (part) { *reinterpret_cast<f32x4 *>(part + row + n) = v; continue; }
-                if (a.scale) v *= *reinterpret_cast<const f32x4 *>(a.scale + n);
-                if (a.shift) v += *reinterpret_cast<const f32x4 *>(a.shift + n);
+                v = v * *reinterpret_cast<const f32x4 *>(&ep_lds[0][n - n0]) + *reinterpret_cast<const f32x4 *>(&ep_lds[1][n - n0]);
                 if (a.res1) v += *reinterpret_cast<const f32x4 *>(a.res1 + row + n);
                 if (a.res2) v += *reinterpret_cast<const f32x4 *>(a.res2 + row + n);
 #pragma unroll

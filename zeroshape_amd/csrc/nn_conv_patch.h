@@ -284,6 +284,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     using namespace patch128;
     __shared__ f32x4 lds_a[2][A_QUADS];
     __shared__ f32x4 lds_b[NS][B_QUADS];
+    __shared__ __attribute__((aligned(16))) float ep_lds[2][BN];   // per-channel scale | shift of this column tile, for the epilogue
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned ldsb_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) f32x4 *)&lds_b[0][0]);
@@ -303,6 +304,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     const int b = mt / per_image, trem = mt - b * per_image;
     const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
     const int n0 = nt * BN;
+    {   // read by the epilogue, many barriers from here
+        const int which = tid >> 7, c = tid & (BN - 1), n = n0 + c;
+        const float *src = which ? a.shift : a.scale;
+        ep_lds[which][c] = (src && n < a.Cout) ? src[n] : (which ? 0.0f : 1.0f);
+    }
     // split-K (a.splits > 1, layers of few tiles - 14 x 14 maps, batch 1): blockIdx.z owns a contiguous range of the slabs and
     // writes its raw partial tile to ws[z][pixel][cout]; conv_splitk_reduce_kernel sums the ranges in order (deterministic)
     const int all_slabs = a.Cin / BK;
@@ -460,8 +466,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
                 f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
                 if (vec) {                                     // n + 3 < Cout as well
                     if (part) { *reinterpret_cast<f32x4 *>(part + pix + n) = v; continue; }
-                    if (a.scale) v *= *reinterpret_cast<const f32x4 *>(a.scale + n);
-                    if (a.shift) v += *reinterpret_cast<const f32x4 *>(a.shift + n);
+                    v = v * *reinterpret_cast<const f32x4 *>(&ep_lds[0][n - n0]) + *reinterpret_cast<const f32x4 *>(&ep_lds[1][n - n0]);
                     if (a.res1) v += *reinterpret_cast<const f32x4 *>(a.res1 + pix + n);
                     if (a.res2) v += *reinterpret_cast<const f32x4 *>(a.res2 + pix + n);
 #pragma unroll
