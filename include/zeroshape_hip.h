@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 30
+#define ZS_ABI_VERSION 31
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -426,6 +426,12 @@ size_t zs_conv2d_packed_floats(int Cin, int Cout, int kh, int kw);
 /* packed_w (zs_pack_conv_weight / nn/pack.py layout, zs_conv2d_packed_floats() floats) -> split_w, same size: the
  * split-fp16 halves of every weight in the order the ZS_CONV_F16X3 kernels consume them (ZS_CONV_W_PRESPLIT). */
 int zs_conv2d_presplit_weight(const float *packed_w, float *split_w, int Cin, int Cout, int kh, int kw, void *stream);
+/* The same for n operands in ONE launch (what optim.amp does after every optimiser step, right behind
+ * zs_pack_conv_weight_multi): device arrays packed[n], split[n], cout_pad[n] (the operands' padded column counts) and
+ * pair_prefix[n + 1] = running sum of pairs_i = K16_i / 16 * 2 * cout_pad_i (pair_prefix[n] == total_pairs). */
+int zs_conv2d_presplit_weight_multi(const void *const *packed, void *const *split, const int *cout_pad,
+                                    const unsigned long long *pair_prefix, int n, unsigned long long total_pairs,
+                                    void *stream);
 int zs_conv2d_nhwc(const float *in, const float *packed_w, const float *scale, const float *shift,
                    const float *res1, const float *res2, float *out, int batch, int Hin, int Win, int Cin,
                    int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad_t, int pad_l, int flags,

@@ -100,6 +100,7 @@ SIGNATURES = {
     "zs_conv2d_nhwc": (_c_int, [_c_void_p] * 7 + [_c_int] * 13 + [ctypes.c_float, ctypes.c_float, _c_int,
                                                                   _c_void_p]),
     "zs_conv2d_splitk_workspace_bytes": (_c_size_t, []),
+    "zs_conv2d_presplit_weight_multi": (_c_int, [_c_void_p] * 4 + [_c_int, ctypes.c_ulonglong, _c_void_p]),
     "zs_conv3x3_tail_nhwc": (_c_int, [_c_void_p] * 5 + [_c_int] * 7 + [_c_void_p, _c_void_p, _c_int, _c_void_p]),
     "zs_conv2d_nhwc_ws": (_c_int, [_c_void_p] * 7 + [_c_int] * 13 + [ctypes.c_float, ctypes.c_float, _c_int,
                                                                      _c_void_p, _c_void_p]),
@@ -176,7 +177,7 @@ SIGNATURES = {
     "zs_readout_concat_bwd": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
 }
 
-ABI_VERSION = 30
+ABI_VERSION = 31
 _lib = None
 
 

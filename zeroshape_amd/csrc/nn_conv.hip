@@ -1179,6 +1179,37 @@ __global__ __launch_bounds__(256) void presplit_weight_kernel(const f32x4 *__res
     out[(4 * s + q + 2) * CoutPad + n] = __builtin_bit_cast(f32x4, lo);
 }
 
+// the same for a table of operands in ONE launch (the training step splits every layer's operand after each optimiser step):
+// pair g of the concatenated pair space belongs to entry e with prefix[e] <= g < prefix[e + 1]
+constexpr int PRESPLIT_PER_THREAD = 16;
+__global__ __launch_bounds__(256) void presplit_weight_multi_kernel(const f32x4 *const *__restrict__ src, f32x4 *const *__restrict__ dst,
+                                                                    const int *__restrict__ cout_pad,
+                                                                    const unsigned long long *__restrict__ prefix, int n) {
+    const unsigned long long total = prefix[n];
+    unsigned long long g = (unsigned long long)blockIdx.x * (256 * PRESPLIT_PER_THREAD) + threadIdx.x;
+    int e = 0;
+#pragma unroll 1
+    for (int k = 0; k < PRESPLIT_PER_THREAD; k++, g += 256) {
+        if (g >= total) return;
+        if (k == 0 || g >= prefix[e + 1]) {           // binary search (the first pair; afterwards only when the entry changes)
+            int lo = 0, hi = n - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (prefix[mid] <= g) lo = mid; else hi = mid - 1;
+            }
+            e = lo;
+        }
+        const size_t i = (size_t)(g - prefix[e]), cp = (size_t)cout_pad[e];
+        const size_t col = i % cp, q = (i / cp) & 1, st = i / cp / 2;
+        const f32x4 *w = src[e];
+        f32x4 *out = dst[e];
+        u32x4 hi4, lo4;
+        zs::s16::split8(w[(4 * st + q) * cp + col], w[(4 * st + q + 2) * cp + col], hi4, lo4);
+        out[(4 * st + q) * cp + col] = __builtin_bit_cast(f32x4, hi4);
+        out[(4 * st + q + 2) * cp + col] = __builtin_bit_cast(f32x4, lo4);
+    }
+}
+
 // out = epilogue(sum over the splits, in split order: deterministic)
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs a) {
     const size_t total = (size_t)a.M * a.Cout;
@@ -1518,6 +1549,20 @@ extern "C" int zs_conv2d_presplit_weight(const float *packed_w, float *split_w, 
                        static_cast<hipStream_t>(stream), reinterpret_cast<const f32x4 *>(packed_w),
                        reinterpret_cast<f32x4 *>(split_w), pairs, (int)CoutPad);
     return zs::check_launch("zs_conv2d_presplit_weight") ? 1 : 0;
+}
+
+extern "C" int zs_conv2d_presplit_weight_multi(const void *const *packed, void *const *split, const int *cout_pad,
+                                               const unsigned long long *pair_prefix, int n, unsigned long long total_pairs,
+                                               void *stream) {
+    if (n < 0) { zs::set_err("zs_conv2d_presplit_weight_multi: bad arguments"); return 0; }
+    if (n == 0 || total_pairs == 0) return 1;
+    if (!packed || !split || !cout_pad || !pair_prefix) { zs::set_err("zs_conv2d_presplit_weight_multi: null pointer"); return 0; }
+    const unsigned long long per = 256ull * PRESPLIT_PER_THREAD, blocks = (total_pairs + per - 1) / per;
+    if (blocks > 0x7fffffffull) { zs::set_err("zs_conv2d_presplit_weight_multi: %llu pairs", total_pairs); return 0; }
+    hipLaunchKernelGGL(presplit_weight_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const f32x4 *const *>(packed), reinterpret_cast<f32x4 *const *>(split), cout_pad,
+                       pair_prefix, n);
+    return zs::check_launch("zs_conv2d_presplit_weight_multi") ? 1 : 0;
 }
 
 extern "C" size_t zs_conv2d_packed_floats(int Cin, int Cout, int kh, int kw) {

@@ -230,6 +230,15 @@ def _refresh_all_packs(device):
         _PACK_FAST.pop(device, None)
 
 
+_refresh_all_packs_only = _refresh_all_packs
+
+
+def _refresh_all_packs(device):      # noqa: F811 - the re-pack, then (optim.amp) the split of every operand
+    _refresh_all_packs_only(device)
+    if _amp_splits_operands():
+        _presplit_all(device)
+
+
 def refresh_packs(device):
     """Re-pack every registered operand on `device` now (and leave the launch table of that set cached): what a
     stream capture of a training step must do first, so that the re-pack inside the capture finds its table."""
@@ -276,6 +285,52 @@ def _out_size(n, k, stride, padding):
 
 _CONV_W_PRESPLIT = 128
 _PRESPLIT = {}          # packed.data_ptr() -> (generation, split operand)
+_PRESPLIT_TABLE = {}    # device -> (signature, device arrays of zs_conv2d_presplit_weight_multi, n, total pairs, splits)
+# ZS_TRAIN_PRESPLIT_ALL=1 (opt-in, measured SLOWER): ONE launch right behind the re-pack splits every registered operand
+# (zs_conv2d_presplit_weight_multi), so the small-tile and register-staged kernels skip the per-use split of their B fragments
+# as well and the 40 per-layer split launches go.  The kernel-time sum of the small-tile kernels does drop (7.9 -> 7.35 ms per
+# step in the trace), but they are latency-bound: in wall time the step goes 29.75 -> 30.1 ms, the 1.5 GB the split of 192 M
+# parameters moves costs more than it buys.  Default: only the >= 192-tile layers, per layer.
+PRESPLIT_ALL = os.environ.get("ZS_TRAIN_PRESPLIT_ALL", "0") != "0"
+
+
+def _amp_splits_operands():
+    return PRESPLIT_ALL and (FWD_CONV_PRECISION == "f16x3" or BWD_DATA_PRECISION == "f16x3")
+
+
+def _presplit_all(device):
+    """Split every registered packed operand on `device` (call right after they were re-packed)."""
+    lib = _lib.load()
+    recs = [rec for rec in _PACKS.values() if rec.ref() is not None and rec.packed.device == device]
+    if not recs:
+        return
+    sig = tuple((rec.packed.data_ptr(), rec.packed.numel()) for rec in recs)
+    cached = _PRESPLIT_TABLE.get(device)
+    if cached is None or cached[0] != sig:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the set of packed operands changed inside a stream capture; call "
+                               "zeroshape_amd.nn.autograd.refresh_packs(device) before capturing")
+        splits, src, dst, cps, prefix, tot = [], [], [], [], [0], 0
+        old = {k: v[1] for k, v in _PRESPLIT.items()}
+        for rec in recs:
+            K16, NPad = rec.dims[5], rec.dims[6]
+            sp = old.get(rec.packed.data_ptr())
+            if sp is None or sp.numel() != rec.packed.numel() or sp.device != device:
+                sp = torch.empty_like(rec.packed)
+            splits.append(sp)
+            src.append(rec.packed.data_ptr()); dst.append(sp.data_ptr()); cps.append(NPad)
+            tot += K16 // 16 * 2 * NPad
+            prefix.append(tot)
+        cached = (sig, torch.tensor(src, dtype=torch.int64).to(device), torch.tensor(dst, dtype=torch.int64).to(device),
+                  torch.tensor(cps, dtype=torch.int32).to(device), torch.tensor(prefix, dtype=torch.int64).to(device),
+                  len(recs), tot, splits)
+        _PRESPLIT_TABLE[device] = cached
+    _, src_d, dst_d, cp_d, pre_d, n, tot, splits = cached
+    with _lib.on(device):
+        _lib.check(lib.zs_conv2d_presplit_weight_multi(_lib.ptr(src_d), _lib.ptr(dst_d), _lib.ptr(cp_d), _lib.ptr(pre_d), n, tot,
+                                                       _lib.current_stream_ptr(device)), "zs_conv2d_presplit_weight_multi")
+    for rec, sp in zip(recs, splits):
+        _PRESPLIT[rec.packed.data_ptr()] = (GENERATION[0], sp)
 # optim.amp: layers large enough for the LDS-DMA GEMM kernel or the 3x3 input-patch kernels (>= 192 tiles of 128 x 128,
 # channels a multiple of 16, no input affine) get their packed operand split into fp16 halves once per optimiser step
 # (zs_conv2d_presplit_weight), which is what those kernels consume; the other layers split on the fly as before.
@@ -299,10 +354,15 @@ def _conv_launch(x, packed, shift, res1, res2, out, kh, kw, stride, pt, pl, flag
     lib = _lib.load()
     B, H, W, C = x.shape
     _, Ho, Wo, Co = out.shape
-    if (flags & _CONV_F16X3) and not (flags & _CONV_IN_DILATE2) and C % 16 == 0 and in_scale == 1.0 and in_shift == 0.0 and \
-            -(-(B * Ho * Wo) // 128) * -(-Co // 128) >= PRESPLIT_MIN_TILES:
-        packed = _presplit(packed, C, Co, kh, kw, x.device)
-        flags |= _CONV_W_PRESPLIT
+    if flags & _CONV_F16X3:
+        rec = _PRESPLIT.get(packed.data_ptr()) if _amp_splits_operands() else None
+        if rec is not None and rec[0] == GENERATION[0] and rec[1].numel() == packed.numel():
+            packed = rec[1]                        # split with every other operand right after the re-pack
+            flags |= _CONV_W_PRESPLIT
+        elif not (flags & _CONV_IN_DILATE2) and C % 16 == 0 and in_scale == 1.0 and in_shift == 0.0 and \
+                -(-(B * Ho * Wo) // 128) * -(-Co // 128) >= PRESPLIT_MIN_TILES:
+            packed = _presplit(packed, C, Co, kh, kw, x.device)
+            flags |= _CONV_W_PRESPLIT
     with _lib.on(x.device):
         _lib.check(lib.zs_conv2d_nhwc(_lib.ptr(x), _lib.ptr(packed), None, _lib.ptr(shift), _lib.ptr(res1),
                                       _lib.ptr(res2), _lib.ptr(out), B, H, W, C, Ho, Wo, Co, kh, kw, stride, pt, pl,
