@@ -495,3 +495,32 @@ def test_conv3x3_with_fused_pointwise_tail(B, Cin, H, W, Cmid, in_relu, monkeypa
     lib = __import__("zeroshape_amd._lib", fromlist=["load"]).load()
     assert lib.zs_conv3x3_tail_nhwc(None, None, None, None, None, 1, 16, 16, 20, 8, 16 | 128, 0, None, None, 0, None) == 0
     assert b"Cin % 16" in lib.zs_last_error()
+
+
+def test_presplit_of_many_operands_in_one_launch():
+    """zs_conv2d_presplit_weight_multi == zs_conv2d_presplit_weight per operand, bit for bit (three layers of different
+    shapes, pair ranges that straddle the 4096-pair chunks of a workgroup)."""
+    from zeroshape_amd import _lib
+    from zeroshape_amd.nn import pack
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(40, 32, 3), (200, 64, 1), (7, 16, 3)]                      # Cout, Cin, k
+    packed, single, multi, cps, prefix = [], [], [], [], [0]
+    for cout, cin, k in shapes:
+        pc = pack.pack_conv(torch.randn(cout, cin, k, k, generator=g), None, stride=1, padding=k // 2).to("cuda")
+        sp = torch.empty_like(pc.w)
+        _lib.check(lib.zs_conv2d_presplit_weight(_lib.ptr(pc.w), _lib.ptr(sp), cin, cout, k, k, None), "presplit")
+        packed.append(pc.w); single.append(sp); multi.append(torch.zeros_like(pc.w))
+        coutp = -(-cout // 128) * 128
+        cps.append(coutp)
+        prefix.append(prefix[-1] + pc.w.numel() // coutp // 16 * 2 * coutp)
+    dev = packed[0].device
+    src = torch.tensor([t.data_ptr() for t in packed], dtype=torch.int64).to(dev)
+    dst = torch.tensor([t.data_ptr() for t in multi], dtype=torch.int64).to(dev)
+    cp = torch.tensor(cps, dtype=torch.int32).to(dev)
+    pre = torch.tensor(prefix, dtype=torch.int64).to(dev)
+    _lib.check(lib.zs_conv2d_presplit_weight_multi(_lib.ptr(src), _lib.ptr(dst), _lib.ptr(cp), _lib.ptr(pre), len(shapes),
+                                                   prefix[-1], None), "presplit multi")
+    torch.cuda.synchronize()
+    for a, b in zip(single, multi):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
