@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 31
+#define ZS_ABI_VERSION 32
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -422,6 +422,8 @@ int zs_depth_metrics(const float *prediction, const float *target, const float *
                                * weights at run time */
 #define ZS_CONV_IN_DILATE2 8  /* read the input as if zero-stuffed x2 ([B][2H-1][2W-1][Cin] virtual): the
                                  data gradient of a stride-2 convolution as a stride-1 convolution */
+#define ZS_CONV_IN_UPSAMPLE2 512 /* zs_conv3x3_tail_nhwc only: `in` is [B][H/2][W/2][Cin] and the layer runs on its x2 bilinear
+                                    up-sampling (align_corners, zs_upsample2x_nhwc's formula), which is never written */
 size_t zs_conv2d_packed_floats(int Cin, int Cout, int kh, int kw);
 /* packed_w (zs_pack_conv_weight / nn/pack.py layout, zs_conv2d_packed_floats() floats) -> split_w, same size: the
  * split-fp16 halves of every weight in the order the ZS_CONV_F16X3 kernels consume them (ZS_CONV_W_PRESPLIT). */
@@ -454,7 +456,8 @@ int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const float *scale
  * model/depth/dpt_depth.py (reference: DPT output_conv[2..5]: Conv 128 -> 32 3x3, ReLU, Conv 32 -> 1, ReLU):
  *   out[b][y][x] = tail_act( tail_b[0] + sum_c tail_w[c] * act( conv3x3(in)[b][y][x][c] * scale[c] + shift[c] ) )
  * in [B][H][W][Cin] (Cin % 16 == 0), out [B][H][W] floats; packed_w = zs_conv2d_presplit_weight output of the 3x3 layer
- * (split-fp16 arithmetic only: flags must hold ZS_CONV_F16X3 | ZS_CONV_W_PRESPLIT, ZS_CONV_IN_RELU optional); tail_w [Cout],
+ * (split-fp16 arithmetic only: flags must hold ZS_CONV_F16X3 | ZS_CONV_W_PRESPLIT; ZS_CONV_IN_RELU and ZS_CONV_IN_UPSAMPLE2 - H, W
+ * even, the OUTPUT size - optional); tail_w [Cout],
  * tail_b [1] (NULL = 0).  The 32-channel intermediate ([B][H][W][32], 180 MB at 224^2 x 28) is never written.  Returns 0 with
  * zs_last_error set for geometries it does not take (the caller then issues the two layers separately). */
 int zs_conv3x3_tail_nhwc(const float *in, const float *packed_w, const float *scale, const float *shift, float *out,

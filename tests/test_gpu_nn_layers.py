@@ -524,3 +524,35 @@ def test_presplit_of_many_operands_in_one_launch():
     torch.cuda.synchronize()
     for a, b in zip(single, multi):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cmid", [(3, 128, 20, 24, 32), (2, 32, 9, 17, 20), (1, 64, 56, 56, 32)])
+def test_conv3x3_tail_on_the_upsampled_input(B, Cin, H, W, Cmid):
+    """ZS_CONV_IN_UPSAMPLE2: the 3x3 layer of the fused head runs on the x2 bilinear (align_corners) up-sampling of its input,
+    interpolated inside the patch loader: parity with torch's interpolate -> conv -> ReLU -> 1x1 -> clamp and with the
+    unfused launches (upsample2x, conv, conv)."""
+    from zeroshape_amd.nn import ops, pack
+    g = torch.Generator().manual_seed(Cin + H)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w1 = torch.randn(Cmid, Cin, 3, 3, generator=g) / np.sqrt(9 * Cin)
+    b1 = torch.randn(Cmid, generator=g) * 0.1
+    w2 = torch.randn(1, Cmid, 1, 1, generator=g) / np.sqrt(Cmid)
+    b2 = torch.randn(1, generator=g) * 0.1
+    up = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    want = nhwc(torch.clamp(F.relu(F.conv2d(F.relu(F.conv2d(up, w1, b1, padding=1)), w2, b2)), max=1.0))
+    pc1 = pack.pack_conv(w1, b1, stride=1, padding=1).to("cuda")
+    pc2 = pack.pack_conv(w2, b2, stride=1, padding=0).to("cuda")
+    prev, prev_up = ops.CONV_PRECISION, ops.FUSE_UPSAMPLE
+    try:
+        ops.set_conv_precision("f16x3")
+        xg = nhwc(x).cuda()
+        kw = dict(act=ops.ACT_RELU, tail_act=ops.ACT_RELU_CLAMP1, upsample=True)
+        fused = ops.conv2d_tail(xg, pc1, pc2, **kw)
+        assert fused.shape == (B, 2 * H, 2 * W, 1)
+        close(fused, want)
+        assert torch.equal(fused, ops.conv2d_tail(xg, pc1, pc2, **kw))
+        ops.FUSE_UPSAMPLE = False
+        close(fused, ops.conv2d_tail(xg, pc1, pc2, **kw).cpu(), tol=5e-6)
+    finally:
+        ops.set_conv_precision(prev)
+        ops.FUSE_UPSAMPLE = prev_up

@@ -177,7 +177,7 @@ SIGNATURES = {
     "zs_readout_concat_bwd": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
 }
 
-ABI_VERSION = 31
+ABI_VERSION = 32
 _lib = None
 
 

@@ -1509,8 +1509,8 @@ extern "C" int zs_conv3x3_tail_nhwc(const float *in, const float *packed_w, cons
                                     const float *tail_b, int tail_act, void *stream) {
     const int need = ZS_CONV_F16X3 | ZS_CONV_W_PRESPLIT;
     if (batch < 0 || H < 8 || W < 8 || Cin <= 0 || (Cin % BK) || Cout <= 0 || Cout > 32 || (flags & need) != need ||
-        (flags & ~(need | ZS_CONV_IN_RELU)) || act < 0 || act > ZS_ACT_RELU_CLAMP1 || tail_act < 0 ||
-        tail_act > ZS_ACT_RELU_CLAMP1) {
+        (flags & ~(need | ZS_CONV_IN_RELU | ZS_CONV_IN_UPSAMPLE2)) || act < 0 || act > ZS_ACT_RELU_CLAMP1 || tail_act < 0 ||
+        tail_act > ZS_ACT_RELU_CLAMP1 || ((flags & ZS_CONV_IN_UPSAMPLE2) && ((H | W) & 1))) {
         zs::set_err("zs_conv3x3_tail_nhwc: takes 3x3 stride-1 pad-1 layers of <= 32 output channels, Cin %% 16 == 0, maps >= 8x8, "
                     "flags ZS_CONV_F16X3 | ZS_CONV_W_PRESPLIT [| ZS_CONV_IN_RELU] (B=%d %dx%dx%d -> %d, flags %d)", batch, H, W,
                     Cin, Cout, flags);
@@ -1523,7 +1523,8 @@ extern "C" int zs_conv3x3_tail_nhwc(const float *in, const float *packed_w, cons
     ConvArgs a;
     a.slab_major = 0;
     a.in = in; a.w = packed_w; a.scale = scale; a.shift = shift; a.res1 = nullptr; a.res2 = nullptr; a.out = out;
-    a.B = batch; a.Hin = H; a.Win = W; a.Cin = Cin; a.Hout = H; a.Wout = W; a.Cout = Cout;
+    const bool up2 = (flags & ZS_CONV_IN_UPSAMPLE2) != 0;
+    a.B = batch; a.Hin = up2 ? H / 2 : H; a.Win = up2 ? W / 2 : W; a.Cin = Cin; a.Hout = H; a.Wout = W; a.Cout = Cout;
     a.CoutPad = (Cout + BN - 1) / BN * BN;
     a.kh = 3; a.kw = 3; a.stride = 1; a.pad_t = 1; a.pad_l = 1; a.K = 9 * Cin; a.M = (int)M;
     a.in_relu = (flags & ZS_CONV_IN_RELU) ? 1 : 0;
@@ -1532,7 +1533,10 @@ extern "C" int zs_conv3x3_tail_nhwc(const float *in, const float *packed_w, cons
     const int tx = (W + patch32::PT - 1) / patch32::PT, ty = (H + patch32::PT - 1) / patch32::PT;
     const dim3 grid((unsigned)((long long)batch * tx * ty));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (a.in_relu) hipLaunchKernelGGL((conv3x3_patch32_kernel<true, 8>), grid, dim3(512), 0, st, a, tx, ty);
+    if (up2) {
+        if (a.in_relu) hipLaunchKernelGGL((conv3x3_patch32_kernel<true, 8, true>), grid, dim3(512), 0, st, a, tx, ty);
+        else hipLaunchKernelGGL((conv3x3_patch32_kernel<false, 8, true>), grid, dim3(512), 0, st, a, tx, ty);
+    } else if (a.in_relu) hipLaunchKernelGGL((conv3x3_patch32_kernel<true, 8>), grid, dim3(512), 0, st, a, tx, ty);
     else hipLaunchKernelGGL((conv3x3_patch32_kernel<false, 8>), grid, dim3(512), 0, st, a, tx, ty);
     return zs::check_launch("zs_conv3x3_tail_nhwc") ? 1 : 0;
 }

@@ -46,10 +46,18 @@ __device__ __forceinline__ int block_pixel(int m) {
 // NW waves per workgroup share the tile's eight 2 x 16-pixel MFMA blocks: NW = 8 -> one block per wave, four waves per SIMD
 // with two workgroups per CU (a wave's slab is barrier, issue, 27 MFMAs, land, one after the other: the other waves of
 // the SIMD are what keeps the matrix pipe busy meanwhile; four waves, two blocks each: 475 vs ... us on the head layer).
-template <bool RELU, int NW>
+// UP2 (zs_conv3x3_tail_nhwc with ZS_CONV_IN_UPSAMPLE2; DPT's head: Interpolate(x2, bilinear, align_corners) in front of the
+// 128 -> 32 layer): the layer's input is the x2 up-sampling of a.in [B][Hin][Win][Cin] (a.Hout = 2 Hin, a.Wout = 2 Win), which is
+// never materialised (719 MB at 224 x 224 x 128 x 28).  An 18 x 18 patch of the up-sampled map needs at most 11 x 11 source
+// pixels: ONE 16-byte load per lane and slab (instead of three) brings the source patch; landing it = raw quads to LDS (the
+// start of the stage that is being filled), barrier, every lane interpolates its three (pixel, k-quad) units from there
+// (upsample2x_vec_kernel's formula), barrier, split halves written over the same stage.
+template <bool RELU, int NW, bool UP2 = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 2, NW / 2))) void conv3x3_patch32_kernel(ConvArgs a, int tiles_x, int tiles_y) {
     using namespace patch32;
+    static_assert(!UP2 || NW == 8, "the up-sampling loader is written for 512 lanes");
     constexpr int NT = 64 * NW, MB = 8 / NW;                   // threads, MFMA blocks per wave
+    constexpr int SRC = 11;                                    // UP2: source patch side
     constexpr int AR = (PPIX * 4 + NT - 1) / NT;               // loader rounds of NT (pixel, k-quad) units; the last one is partial
     constexpr int BR = (B_DMAS + NW - 1) / NW;
     static_assert(AR * NT <= A_PIX * 4 + NT - 64 && (AR == 6 || AR == 3), "loader rounds");
@@ -81,12 +89,36 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 2,
     for (int r = 0; r < AR; r++) {
         const int u = tid + NT * r, p = u >> 2, quad = u & 3;
         const int py = p / PP, px = p - py * PP, iy = y0 - 1 + py, ix = x0 - 1 + px;
-        const bool ok = p < PPIX && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-        ga[r] = ok ? reinterpret_cast<const f32x4 *>(a.in + (((size_t)b * a.Hin + iy) * a.Win + ix) * a.Cin + 4 * quad) : zero;
-        ga_inc[r] = ok ? BK / 4 : 0;
+        const bool ok = p < PPIX && iy >= 0 && iy < a.Hout && ix >= 0 && ix < a.Wout;       // (Hout == Hin unless UP2)
+        ga[r] = (ok && !UP2) ? reinterpret_cast<const f32x4 *>(a.in + (((size_t)b * a.Hin + iy) * a.Win + ix) * a.Cin + 4 * quad) : zero;
+        ga_inc[r] = (ok && !UP2) ? BK / 4 : 0;
         a_dst[r] = p * 8 + ((quad & 1) ^ ((p >> 2) & 3)) * 2 + (quad >> 1);
     }
+    // UP2: the taps of unit (patch pixel p, k-quad) inside the SRC x SRC source patch, recomputed at every landing (cheaper than
+    // nine registers held across the MFMA loop: the kernel sits at the 128-register line of four waves per SIMD)
+    const float up_sy = UP2 ? (float)(a.Hin - 1) / (float)(a.Hout - 1) : 0.f, up_sx = UP2 ? (float)(a.Win - 1) / (float)(a.Wout - 1) : 0.f;
+    const int up_y0 = (int)(up_sy * (float)max(y0 - 1, 0)), up_x0 = (int)(up_sx * (float)max(x0 - 1, 0));
+    auto up_taps = [&](int r, int &o, int &dx, int &dy, float &ly, float &lx) -> bool {
+        int t = tid;
+        asm volatile("" : "+v"(t));        // opaque: otherwise the taps are hoisted out of the slab loop and held (then spilled)
+        const int u = t + NT * r, p = u >> 2, py = p / PP, px = p - py * PP, iy = y0 - 1 + py, ix = x0 - 1 + px;
+        const float fy = up_sy * (float)max(iy, 0), fx = up_sx * (float)max(ix, 0);
+        const int ys = (int)fy, xs = (int)fx;
+        ly = fy - (float)ys;
+        lx = fx - (float)xs;
+        o = ((ys - up_y0) * SRC + (xs - up_x0)) * 4 + (u & 3);
+        dx = xs < a.Win - 1 ? 4 : 0;
+        dy = ys < a.Hin - 1 ? SRC * 4 : 0;
+        return p < PPIX && iy >= 0 && iy < a.Hout && ix >= 0 && ix < a.Wout;
+    };
     const bool last_round = 64 * wave + NT * (AR - 1) < PPIX * 4;      // waves with units in the partial round (uniform)
+    const f32x4 *gs = zero;                                    // UP2: this lane's (source pixel, k-quad) = tid
+    int gs_inc = 0;
+    if (UP2 && tid < SRC * SRC * 4) {
+        const int sp = tid >> 2, gy = min(up_y0 + sp / SRC, a.Hin - 1), gx = min(up_x0 + sp % SRC, a.Win - 1);
+        gs = reinterpret_cast<const f32x4 *>(a.in + (((size_t)b * a.Hin + gy) * a.Win + gx) * a.Cin + 4 * (tid & 3));
+        gs_inc = BK / 4;
+    }
     // B: DMA db = (tap, e) covers the row quads 2e, 2e + 1 (lane / 32) of the tap's K = 16 step, columns lane % 32
     const char *gb[BR];
 #pragma unroll
@@ -106,17 +138,23 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 2,
 #endif
 #pragma unroll
     for (int r = 0; r < AR; r++) ga[r] += (size_t)slab_at * ga_inc[r];
+    gs += (size_t)slab_at * gs_inc;
 #pragma unroll
     for (int i = 0; i < BR; i++) gb[i] += (size_t)slab_at * gb_inc;
     f32x4 stage_a[AR];
     auto issue = [&](int stage) {                              // patch loads -> registers, weight DMAs -> LDS
         const bool wrap = ++slab_at == slabs;
         if (wrap) slab_at = 0;
+        if (UP2) {
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(stage_a[0]) : "v"(gs) : "memory");
+            gs += wrap ? -(ptrdiff_t)(slabs - 1) * gs_inc : gs_inc;
+        } else {
 #pragma unroll
-        for (int r = 0; r < AR; r++) {
-            if (r < AR - 1 || last_round)
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(stage_a[r]) : "v"(ga[r]) : "memory");
-            ga[r] += wrap ? -(ptrdiff_t)(slabs - 1) * ga_inc[r] : ga_inc[r];
+            for (int r = 0; r < AR; r++) {
+                if (r < AR - 1 || last_round)
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(stage_a[r]) : "v"(ga[r]) : "memory");
+                ga[r] += wrap ? -(ptrdiff_t)(slabs - 1) * ga_inc[r] : ga_inc[r];
+            }
         }
         const unsigned dst = lds_base + stage * (STAGE_QUADS * 16) + A_QUADS * 16;
 #pragma unroll
@@ -126,6 +164,43 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 2,
         }
     };
     auto land = [&](int stage) {                               // loads landed: split, write the halves
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        if constexpr (UP2) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(stage_a[0]) : : "memory");
+            f32x4 *scratch = &lds[stage][0];                   // SRC x SRC source pixels x 4 quads (<= 512 f32x4) at the stage's start
+            scratch[tid] = stage_a[0];
+            __syncthreads();
+            u32x2_t hi[AR], lo[AR];
+#pragma unroll
+            for (int r = 0; r < AR; r++) {
+                f32x4 q = {0.f, 0.f, 0.f, 0.f};
+                int o, dx, dy;
+                float ly, lx;
+                if ((r < AR - 1 || last_round) && up_taps(r, o, dx, dy, ly, lx)) {
+                    const f32x4 v00 = scratch[o], v01 = scratch[o + dx], v10 = scratch[o + dy], v11 = scratch[o + dy + dx];
+                    q = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+                    if (RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) q[e] = fmaxf(q[e], 0.f);
+                    }
+                }
+                unsigned h0, l0, h1, l1;
+                zs::s16::split2(q.x, q.y, h0, l0);
+                zs::s16::split2(q.z, q.w, h1, l1);
+                hi[r] = u32x2_t{h0, h1};
+                lo[r] = u32x2_t{l0, l1};
+                __builtin_amdgcn_sched_barrier(0);             // one unit's sixteen tap registers at a time (no spills)
+            }
+            __syncthreads();                                   // every tap read before the halves overwrite the source patch
+            u32x2_t *sa = reinterpret_cast<u32x2_t *>(&lds[stage][0]);
+#pragma unroll
+            for (int r = 0; r < AR; r++)
+                if (r < AR - 1 || last_round) {
+                    sa[a_dst[r]] = hi[r];
+                    sa[a_dst[r] ^ 4] = lo[r];
+                }
+            return;
+        }
         if constexpr (AR == 6)
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(stage_a[0]), "+v"(stage_a[1]), "+v"(stage_a[2]), "+v"(stage_a[3]),
                          "+v"(stage_a[4]), "+v"(stage_a[5]) : : "memory");

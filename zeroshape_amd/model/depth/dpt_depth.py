@@ -291,8 +291,8 @@ class DPTDepthModel(HipModule):
         path2 = blocks.run_fusion(path3, pk["fusion"][1], rn[1])
         path = blocks.run_fusion(path2, pk["fusion"][0], rn[0])
         record(path4=path4, path3=path3, path2=path2, path1=path)
-        o = ops.upsample2x(ops.conv2d(path, pk["head0"]))
-        o = ops.conv2d_tail(o, pk["head2"], pk["head4"], act=ops.ACT_RELU, tail_act=ops.ACT_RELU_CLAMP1)   # [B,H,W,1]
+        o = ops.conv2d_tail(ops.conv2d(path, pk["head0"]), pk["head2"], pk["head4"], act=ops.ACT_RELU,
+                            tail_act=ops.ACT_RELU_CLAMP1, upsample=True)                                   # [B,H,W,1]
         depth = o.view(B, 1, H, W)                                               # C == 1: same memory order
         if get_feat:
             return depth, ops.to_nchw(layer_4)

@@ -111,15 +111,26 @@ def conv2d(x, pc, res1=None, res2=None, act=ACT_NONE, in_relu=False, in_scale=1.
 FUSE_TAIL = os.environ.get("ZS_CONV_FUSE_TAIL", "1") != "0"
 
 
-def conv2d_tail(x, pc, pc_tail, act=ACT_NONE, tail_act=ACT_NONE, in_relu=False):
+FUSE_UPSAMPLE = os.environ.get("ZS_CONV_FUSE_UPSAMPLE", "1") != "0"
+
+
+def conv2d_tail(x, pc, pc_tail, act=ACT_NONE, tail_act=ACT_NONE, in_relu=False, upsample=False):
     """tail_act(conv1x1_to_one_channel(act(conv3x3(x)))) -> [B,H,W,1]; fused when the layer pair fits zs_conv3x3_tail_nhwc
-    (split-fp16 arithmetic, 3x3 stride 1 pad 1, <= 32 channels in between), two conv2d calls otherwise."""
+    (split-fp16 arithmetic, 3x3 stride 1 pad 1, <= 32 channels in between), two conv2d calls otherwise.  upsample=True: the
+    3x3 layer runs on upsample2x(x) (DPT's head) - inside the same launch when fused (ZS_CONV_IN_UPSAMPLE2)."""
+    up_fused = upsample and FUSE_UPSAMPLE and FUSE_TAIL and CONV_PRECISION == "f16x3" and PRESPLIT
+    if upsample and not up_fused:
+        return conv2d_tail(upsample2x(x), pc, pc_tail, act=act, tail_act=tail_act, in_relu=in_relu)
     B, H, W, C = x.shape
+    if up_fused:
+        H, W = 2 * H, 2 * W
     fits = (FUSE_TAIL and CONV_PRECISION == "f16x3" and PRESPLIT and pc.kh == 3 and pc.kw == 3 and pc.stride == 1 and
             pc.padding == 1 and pc.cout <= 32 and C % 16 == 0 and H >= 8 and W >= 8 and pc_tail.kh == 1 and
             pc_tail.kw == 1 and pc_tail.stride == 1 and pc_tail.cout == 1 and pc_tail.cin == pc.cout and
             pc_tail.padding in (0, "same"))
     if not fits:
+        if up_fused:
+            x = upsample2x(x)
         return conv2d(conv2d(x, pc, act=act, in_relu=in_relu), pc_tail, act=tail_act)
     lib = _lib.load()
     _chk(x, "conv2d_tail input")
@@ -135,7 +146,7 @@ def conv2d_tail(x, pc, pc_tail, act=ACT_NONE, tail_act=ACT_NONE, in_relu=False):
             wv = wv * pc_tail.scale[0]
         pc_tail.tail_vec = wv.contiguous()
     out = torch.empty(B, H, W, 1, dtype=torch.float32, device=x.device)
-    flags = (1 if in_relu else 0) | 16 | _CONV_W_PRESPLIT
+    flags = (1 if in_relu else 0) | 16 | _CONV_W_PRESPLIT | (512 if up_fused else 0)
     with _lib.on(x.device):
         _lib.check(lib.zs_conv3x3_tail_nhwc(_lib.ptr(x), _lib.ptr(pc.w16), _lib.ptr(pc.scale), _lib.ptr(pc.shift), _lib.ptr(out),
                                             B, H, W, C, pc.cout, flags, act, _lib.ptr(pc_tail.tail_vec),
