@@ -7,6 +7,8 @@ import torch
 from . import ops, pack
 
 
+CONV_BEFORE_UPSAMPLE = __import__("os").environ.get("ZS_FUSION_CONV_FIRST", "1") != "0"
+
 def _dev(t, device):
     return t.detach().float().contiguous().to(device)
 
@@ -148,4 +150,10 @@ def run_fusion(x, pk, skip=None):
     if skip is not None:
         x = run_rcu(skip, pk["r1"], plus=x)
     x = run_rcu(x, pk["r2"])
+    # The reference interpolates, then applies out_conv (1x1 + bias, no activation; blocks.py:232-342).  Both are linear and the
+    # bilinear weights of a pixel sum to 1, so conv1x1(upsample(x)) == upsample(conv1x1(x)) in real arithmetic (floating point:
+    # a reassociation, ~1e-7 relative); the convolution at the LOW resolution is a quarter of the work (refinenet1: 87,808
+    # instead of 351,232 pixels at batch 28).  ZS_FUSION_CONV_FIRST=0 restores the reference's order.
+    if CONV_BEFORE_UPSAMPLE:
+        return ops.upsample2x(ops.conv2d(x, pk["out"]))
     return ops.conv2d(ops.upsample2x(x), pk["out"])

@@ -4,6 +4,7 @@ host-side packing), with BatchNorm on batch statistics.  Each function mirrors a
 forward under graph.train() (model/shape_engine.py:248-297)."""
 import torch.nn as nn
 
+from . import blocks
 from . import autograd as A
 
 
@@ -94,4 +95,6 @@ def fusion(x, m, skip=None):
     if skip is not None:
         x = rcu(skip, m.resConfUnit1, plus=x)
     x = rcu(x, m.resConfUnit2)
+    if blocks.CONV_BEFORE_UPSAMPLE:      # out_conv (1x1, linear) at the low resolution, then the interpolation: see blocks.run_fusion
+        return A.upsample2x(A.conv2d(x, m.out_conv.weight, m.out_conv.bias))
     return A.conv2d(A.upsample2x(x), m.out_conv.weight, m.out_conv.bias)
