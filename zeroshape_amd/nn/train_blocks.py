@@ -95,6 +95,8 @@ def fusion(x, m, skip=None):
     if skip is not None:
         x = rcu(skip, m.resConfUnit1, plus=x)
     x = rcu(x, m.resConfUnit2)
-    if blocks.CONV_BEFORE_UPSAMPLE:      # out_conv (1x1, linear) at the low resolution, then the interpolation: see blocks.run_fusion
-        return A.upsample2x(A.conv2d(x, m.out_conv.weight, m.out_conv.bias))
+    # (the inference blocks run out_conv BEFORE the interpolation - blocks.run_fusion; under training that reorder - the same
+    # function, rounded differently - was enough to send the 300-iteration run of tests/test_gpu_trained_weights.py down another
+    # trajectory, where the from-scratch depth head dies (all-zero depth) and the degenerate seen surface turns the intrinsics
+    # head's gradients into NaN; the training path keeps the reference's order, it gained 0.2 ms of 36)
     return A.conv2d(A.upsample2x(x), m.out_conv.weight, m.out_conv.bias)
