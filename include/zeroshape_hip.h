@@ -452,6 +452,42 @@ int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const float *scale
                    const float *res1, const float *res2, float *out, int batch, int Hin, int Win, int Cin,
                    int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad_t, int pad_l, int flags,
                    float in_scale, float in_shift, int act, void *workspace, void *stream);
+
+/* Fused normalisations around a small-tile launch of zs_conv2d_nhwc (batch-1 encoder: one launch per convolution instead
+ * of convolution + GroupNorm / LayerNorm; reference: timm ResNetV2's GroupNormAct behind every StdConv2dSame, restated in
+ * oracle/standins.py, and timm Block's norm1 / norm2, /root/reference/model/depth/vit.py:118-154).
+ *   out_mode 1: besides `out`, the launch writes out_stats [ceil(M / 32)][out_groups][2] = (sum, sum of squares) of the
+ *               stored values per 32-row tile and group of Cout / out_groups channels.
+ *   out_mode 2: out_stats [M][ceil(Cout / tile columns)][2] = (sum, M2 about the tile-row mean) per row and column tile
+ *               (zs_conv2d_fused_cols() columns per tile for this problem).
+ *   in_mode 1:  A = relu(GroupNorm_{in_groups}(in) * in_gamma + in_beta), statistics from in_stats [in_tiles][in_groups][2]
+ *               (a producer's out_mode 1 over the same tensor); zero padding stays zero.
+ *   in_mode 2:  A = (in - mean_row) * rstd_row from in_stats [M][in_tiles <= 32][2] (a producer's out_mode 2); gamma / beta are
+ *               expected inside packed_w / shift (W' = gamma * W, shift' = shift + beta W).  Pointwise layers only.
+ * Statistics tiles must not straddle samples (batch 1, or Hin * Win a multiple of 32).  Requires ZS_CONV_F16X3 |
+ * ZS_CONV_W_PRESPLIT, Cin % 8 == 0, Cin = 32 * 2^k <= 1024 for in_mode 1, Cout % 4 == 0; forces the small-tile kernel. */
+typedef struct zs_conv_fuse {
+    int in_mode, in_tiles, in_groups;
+    int in_gshift;            /* set by the library (log2 of the channels per group) */
+    const float *in_stats, *in_gamma, *in_beta;
+    float in_eps;
+    int out_mode, out_groups;
+    float *out_stats;
+} zs_conv_fuse;
+int zs_conv2d_nhwc_fused(const float *in, const float *packed_w, const float *scale, const float *shift,
+                         const float *res1, const float *res2, float *out, int batch, int Hin, int Win,
+                         int Cin, int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad_t,
+                         int pad_l, int flags, float in_scale, float in_shift, int act, const zs_conv_fuse *fuse,
+                         void *workspace, void *stream);
+/* columns per tile (32 or 64) the fused small-tile launch uses for a problem of M rows and Cout columns: the consumer of
+ * out_mode 2 statistics needs ceil(Cout / this) as its in_tiles */
+int zs_conv2d_fused_cols(int M, int Cout);
+/* y = [relu]( GroupNorm_32(x) * gamma + beta + r ) in ONE pass over x, from the (sum, sum of squares) tiles a fused launch wrote
+ * (out_mode 1; `tiles` per sample).  r = residual [B][HW][C] (may be NULL), or GroupNorm_32(residual) * res_gamma + res_beta when
+ * res_stats is given (the projection shortcut of a bottleneck's first block). */
+int zs_group_norm_apply_stats(const float *x, const float *stats, int tiles, const float *gamma, const float *beta,
+                              const float *residual, const float *res_stats, int res_tiles, const float *res_gamma,
+                              const float *res_beta, float *y, int batch, int HW, int C, float eps, int relu, void *stream);
 /* A 3x3 stride-1 pad-1 layer of at most 32 output channels with a fused pointwise TAIL to ONE channel - DPT's depth head,
  * model/depth/dpt_depth.py (reference: DPT output_conv[2..5]: Conv 128 -> 32 3x3, ReLU, Conv 32 -> 1, ReLU):
  *   out[b][y][x] = tail_act( tail_b[0] + sum_c tail_w[c] * act( conv3x3(in)[b][y][x][c] * scale[c] + shift[c] ) )

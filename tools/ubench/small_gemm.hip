@@ -1,0 +1,648 @@
+// Micro-benchmark behind the round-4 batch-1 GEMM kernel (csrc/nn_conv_stream.h): what does a latency-optimal
+// small-M GEMM cost inside a dependent chain of launches with COLD weights (the batch-1 encoder streams 764 MB of
+// weights per forward, more than the 256 MiB Infinity Cache)?
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -o small_gemm small_gemm.hip -L../../zeroshape_amd -lzeroshape_hip
+// Variants: the library's zs_conv2d_nhwc_ws (small-tile kernel) against `stream_gemm_kernel<NW, MI, NJ, DEPTH>`:
+// NW waves split K, each wave keeps DEPTH K=16 steps of both operands in flight in registers (all of its range when it
+// fits), tiles 32 MI x 32 NJ, optional split of K across blockIdx.z with the last arriver summing in z order.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "../../zeroshape_amd/csrc/zs_split16.h"
+#include "../../include/zeroshape_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+struct GArgs {
+    const float *a;       // [M][K]
+    const f32x4 *w;       // presplit [K16/4][CoutPad][4]
+    const float *bias;    // [N] or null
+    const float *res;     // [M][N] or null
+    float *out;           // [M][N]
+    float *ws;            // [splits][M][N] partials
+    int *counters;        // per tile
+    int M, K, N, CoutPad, splits, act, xcd_map, abl, lda;
+    unsigned long long *stamps;   // [blocks][8]
+};
+
+__device__ __forceinline__ float gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+template <int NW, int MI, int NJ, int DEPTH>
+__global__ __launch_bounds__(64 * NW) void stream_gemm_kernel(GArgs a) {
+    constexpr int SM = 32 * MI, SN = 32 * NJ, PAD = SN + 4;
+    __shared__ __attribute__((aligned(16))) float part[NW][SM][PAD];
+    __shared__ int last_flag;
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mtiles = (a.M + SM - 1) / SM, ntiles = (a.N + SN - 1) / SN;
+    // XCD-aware tile order: workgroup id b runs on XCD b % 8; the row tiles of one column slab share an XCD (the slab's
+    // weights are fetched into ONE L2)
+    int tm, tn;
+    const int z = blockIdx.y;
+    {
+        const int b = blockIdx.x;
+        if (a.xcd_map) {
+            const int T = mtiles * ntiles, xcd = b & 7, local = b >> 3;
+            const int lo = (int)((long long)xcd * T / 8), hi = (int)((long long)(xcd + 1) * T / 8);
+            const int t = lo + local;
+            if (t >= hi) return;
+            tn = t / mtiles;
+            tm = t - tn * mtiles;
+        } else {
+            tm = b % mtiles;
+            tn = b / mtiles;
+            if (tn >= ntiles) return;
+        }
+    }
+    const int m0 = tm * SM, n0 = tn * SN;
+    unsigned long long tstamp[8];
+    tstamp[0] = __builtin_amdgcn_s_memtime();
+    tstamp[6] = __builtin_amdgcn_s_memrealtime();
+    const int S = (a.K + 15) / 16;                        // K = 16 steps
+    const int zs0 = (int)((long long)z * S / a.splits), zs1 = (int)((long long)(z + 1) * S / a.splits);
+    const int per_w = (zs1 - zs0 + NW - 1) / NW;
+    const int s_begin = zs0 + wave * per_w, s_end = min(zs1, s_begin + per_w);
+    const int ns = max(s_end - s_begin, 0);
+
+    // operand addresses = uniform base (SGPR pair, advanced per step by scalar adds) + per-lane 32-bit offset (fixed): no
+    // vector address arithmetic in the loop
+    unsigned aoff[MI];
+    bool rok[MI];
+#pragma unroll
+    for (int i = 0; i < MI; i++) {
+        const int m = m0 + 32 * i + l32;
+        rok[i] = m < a.M;
+        aoff[i] = (unsigned)(((size_t)(rok[i] ? m : 0) * a.lda + 4 * half) * 4);
+        if (a.abl & 1) aoff[i] = 16 * half;
+    }
+    unsigned boff = (unsigned)(((size_t)half * a.CoutPad + n0 + l32) * 16);
+    if (a.abl & 2) boff = (unsigned)(l32 * 16);
+    const char *abase = reinterpret_cast<const char *>(a.a);
+    const char *bbase = reinterpret_cast<const char *>(a.w);
+    const size_t bstep2 = (size_t)2 * a.CoutPad * 16;              // two weight quad rows
+
+    constexpr int L = 2 * MI + 2 * NJ;
+    static_assert((DEPTH - 1) * L < 64, "vmcnt is a 6-bit counter");
+    f32x4 ra[DEPTH][MI][2];
+    f32x4 rb[DEPTH][NJ][2];
+#define GLDS(dst, voff, sbase, IMM) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "+v"(dst) : "v"(voff), "s"(sbase), "n"(IMM) : "memory")
+    auto load = [&](int slot, int s) {
+        int sc = min(s, S - 1);                     // clamped: always a valid address
+        const int sa = (a.abl & 1) ? 0 : sc;
+        if (a.abl & 2) sc = 0;
+        const char *pb0 = bbase + (size_t)sc * 2 * bstep2, *pb1 = pb0 + bstep2;
+        const char *pa = abase + (size_t)sa * 64;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            GLDS(rb[slot][j][0], boff, pb0, 512 * j);
+            GLDS(rb[slot][j][1], boff, pb1, 512 * j);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; i++) {
+            GLDS(ra[slot][i][0], aoff[i], pa, 0);
+            GLDS(ra[slot][i][1], aoff[i], pa, 32);
+        }
+    };
+    auto landed = [&](int slot) {
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"((DEPTH - 1) * L) : "memory");
+#pragma unroll
+        for (int j = 0; j < NJ; j++) asm volatile("" : "+v"(rb[slot][j][0]), "+v"(rb[slot][j][1]));
+#pragma unroll
+        for (int i = 0; i < MI; i++) asm volatile("" : "+v"(ra[slot][i][0]), "+v"(ra[slot][i][1]));
+    };
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) { rb[d][j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; rb[d][j][1] = rb[d][j][0]; }
+#pragma unroll
+        for (int i = 0; i < MI; i++) { ra[d][i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; ra[d][i][1] = ra[d][i][0]; }
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) load(d, s_begin + d);
+    tstamp[1] = __builtin_amdgcn_s_memtime();
+    tstamp[2] = 0;
+    for (int base = 0; base < ns; base += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            const bool live = base + d < ns;
+            landed(d);
+            if (base == 0 && d == 0) tstamp[2] = __builtin_amdgcn_s_memtime();
+            u32x4 ah[MI], al[MI];
+#pragma unroll
+            for (int i = 0; i < MI; i++) {
+                f32x4 q0 = ra[d][i][0], q1 = ra[d][i][1];
+                if (!(live && rok[i])) { q0 = f32x4{0.f, 0.f, 0.f, 0.f}; q1 = q0; }
+                zs::s16::split8(q0, q1, ah[i], al[i]);
+            }
+            if (!(a.abl & 4))
+#pragma unroll
+            for (int i = 0; i < MI; i++)
+#pragma unroll
+                for (int j = 0; j < NJ; j++)
+                    zs::s16::mfma3(acc[i][j], __builtin_bit_cast(u32x4, rb[d][j][0]), __builtin_bit_cast(u32x4, rb[d][j][1]), ah[i], al[i]);   // transposed: lane = pixel
+            load(d, s_begin + base + DEPTH + d);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tstamp[3] = __builtin_amdgcn_s_memtime();
+    // wave partials -> LDS: register 4q + e of lane (l32, half) = channel 8q + 4 half + e of pixel l32
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                *reinterpret_cast<f32x4 *>(&part[wave][32 * i + l32][32 * j + 8 * q + 4 * half]) =
+                    f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+    __syncthreads();
+    tstamp[4] = __builtin_amdgcn_s_memtime();
+    constexpr int QUADS = SM * SN / 4;
+    const int tile = tn * mtiles + tm;
+    auto finish = [&](int p, int c, f32x4 v) {
+        const int m = m0 + p, n = n0 + 4 * c;
+        if (m >= a.M || n >= a.N) return;
+        const size_t o = (size_t)m * a.N + n;
+        if (a.bias) v += *reinterpret_cast<const f32x4 *>(a.bias + n);
+        if (a.res) v += *reinterpret_cast<const f32x4 *>(a.res + o);
+        if (a.act == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = gelu(v[e]);
+        }
+        *reinterpret_cast<f32x4 *>(a.out + o) = v;
+    };
+    for (int e = tid; e < QUADS; e += 64 * NW) {
+        const int p = e / (SN / 4), c = e % (SN / 4);
+        f32x4 v = *reinterpret_cast<const f32x4 *>(&part[0][p][4 * c]);
+#pragma unroll
+        for (int w = 1; w < NW; w++) v += *reinterpret_cast<const f32x4 *>(&part[w][p][4 * c]);
+        if (a.splits == 1) { finish(p, c, v); continue; }
+        const int m = m0 + p, n = n0 + 4 * c;
+        if (m < a.M && n < a.N) {
+            float *dst = a.ws + ((size_t)z * a.M + m) * a.N + n;
+#pragma unroll
+            for (int k = 0; k < 4; k++) __hip_atomic_store(dst + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    tstamp[5] = __builtin_amdgcn_s_memtime();
+    tstamp[7] = __builtin_amdgcn_s_memrealtime();
+    if (a.stamps && lane == 0 && (wave == 0 || wave == NW - 1)) {
+        unsigned long long *dst = a.stamps + ((size_t)blockIdx.x * 2 + (wave ? 1 : 0)) * 8;
+        for (int k = 0; k < 8; k++) dst[k] = tstamp[k];
+    }
+    if (a.splits == 1) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const int old = __hip_atomic_fetch_add(&a.counters[tile], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = old == a.splits - 1;
+        if (last_flag) __hip_atomic_store(&a.counters[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    for (int e = tid; e < QUADS; e += 64 * NW) {
+        const int p = e / (SN / 4), c = e % (SN / 4);
+        const int m = m0 + p, n = n0 + 4 * c;
+        if (m >= a.M || n >= a.N) continue;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int zz = 0; zz < a.splits; zz++) {
+            const float *src = a.ws + ((size_t)zz * a.M + m) * a.N + n;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] += __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        finish(p, c, v);
+    }
+}
+
+template <int NW, int MI, int NJ, int DEPTH>
+__global__ __launch_bounds__(64 * NW) void stream_gemm_lds_kernel(GArgs a) {
+    constexpr int SM = 32 * MI, SN = 32 * NJ, PAD = SN + 4;
+    // one K = 32 super-step per ring slot: A 32 rows x 128 B per MI block, through LDS in full lines (per-wave ring, filled by
+    // LDS-DMA, swizzled so the fragment reads are conflict-free); B straight to registers
+    constexpr int A_STAGE = 4096 * MI, A_RING = A_STAGE * DEPTH;
+    constexpr int PART_BYTES = NW * SM * PAD * 4, RING_BYTES = NW * A_RING;
+    __shared__ __attribute__((aligned(16))) char lds_raw[(PART_BYTES > RING_BYTES ? PART_BYTES : RING_BYTES) + 16];
+    float (*part)[SM][PAD] = reinterpret_cast<float (*)[SM][PAD]>(lds_raw);
+    int &last_flag = *reinterpret_cast<int *>(lds_raw + (PART_BYTES > RING_BYTES ? PART_BYTES : RING_BYTES));
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mtiles = (a.M + SM - 1) / SM, ntiles = (a.N + SN - 1) / SN;
+    // XCD-aware tile order: workgroup id b runs on XCD b % 8; the row tiles of one column slab share an XCD (the slab's
+    // weights are fetched into ONE L2)
+    int tm, tn;
+    const int z = blockIdx.y;
+    {
+        const int b = blockIdx.x;
+        if (a.xcd_map) {
+            const int T = mtiles * ntiles, xcd = b & 7, local = b >> 3;
+            const int lo = (int)((long long)xcd * T / 8), hi = (int)((long long)(xcd + 1) * T / 8);
+            const int t = lo + local;
+            if (t >= hi) return;
+            tn = t / mtiles;
+            tm = t - tn * mtiles;
+        } else {
+            tm = b % mtiles;
+            tn = b / mtiles;
+            if (tn >= ntiles) return;
+        }
+    }
+    const int m0 = tm * SM, n0 = tn * SN;
+    unsigned long long tstamp[8];
+    tstamp[0] = __builtin_amdgcn_s_memtime();
+    tstamp[6] = __builtin_amdgcn_s_memrealtime();
+    const int S = (a.K + 15) / 16;                        // K = 16 steps
+    const int zs0 = (int)((long long)z * S / a.splits), zs1 = (int)((long long)(z + 1) * S / a.splits);
+    const int per_w = (zs1 - zs0 + NW - 1) / NW;
+    const int s_begin = zs0 + wave * per_w, s_end = min(zs1, s_begin + per_w);
+    const int ns = max(s_end - s_begin, 0);
+
+    const int S32 = S / 2;                                   // K = 32 super-steps (K % 32 == 0 assumed here)
+    unsigned aoff[MI][4];                                    // DMA q of block i: row 8q + lane / 8, 16-byte chunk (lane & 7) ^ f(row)
+    bool rok[MI];
+#pragma unroll
+    for (int i = 0; i < MI; i++) {
+        rok[i] = m0 + 32 * i + l32 < a.M;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = 8 * q + (lane >> 3), m = m0 + 32 * i + r;
+            const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+            aoff[i][q] = (unsigned)(((size_t)(m < a.M ? m : 0) * a.lda + 4 * chunk) * 4);
+        }
+    }
+    unsigned boff = (unsigned)(((size_t)half * a.CoutPad + n0 + l32) * 16);
+    const char *abase = reinterpret_cast<const char *>(a.a);
+    const char *bbase = reinterpret_cast<const char *>(a.w);
+    const size_t bstep2 = (size_t)2 * a.CoutPad * 16;              // two weight quad rows
+    const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds_raw) + wave * A_RING;
+    const char *lds_wave_p = lds_raw + wave * A_RING;
+    // fragment read offsets inside a stage: row l32, chunks (4t + half) and (4t + half + 2), t = 0, 1
+    unsigned frag[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        frag[t][0] = (unsigned)((l32 * 8 + ((4 * t + half) ^ ((l32 >> 1) & 7))) * 16);
+        frag[t][1] = (unsigned)((l32 * 8 + ((4 * t + half + 2) ^ ((l32 >> 1) & 7))) * 16);
+    }
+
+    constexpr int L = 4 * MI + 4 * NJ;                       // vector-memory operations per ring slot
+    static_assert((DEPTH - 1) * L < 64, "vmcnt is a 6-bit counter");
+    f32x4 rb[DEPTH][2][NJ][2];
+#define GLDS(dst, voff, sbase, IMM) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "+v"(dst) : "v"(voff), "s"(sbase), "n"(IMM) : "memory")
+#define GDMA(voff, sbase, ldsdst) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(ldsdst) : "memory")
+    auto load = [&](int slot, int s32) {
+        const int sc = min(s32, S32 - 1);                    // clamped: always a valid address
+        const char *pb = bbase + (size_t)sc * 4 * bstep2;
+        const char *pa = abase + (size_t)sc * 128;
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                GLDS(rb[slot][t][j][0], boff, pb + (2 * t) * bstep2, 512 * j);
+                GLDS(rb[slot][t][j][1], boff, pb + (2 * t + 1) * bstep2, 512 * j);
+            }
+#pragma unroll
+        for (int i = 0; i < MI; i++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) GDMA(aoff[i][q], pa, lds_wave + slot * A_STAGE + i * 4096 + q * 1024);
+    };
+    auto landed = [&](int slot) {
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"((DEPTH - 1) * L) : "memory");
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++) asm volatile("" : "+v"(rb[slot][t][j][0]), "+v"(rb[slot][t][j][1]));
+    };
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    const int ns32 = (ns + 1) / 2, s32_begin = s_begin / 2;
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++) { rb[d][t][j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; rb[d][t][j][1] = rb[d][t][j][0]; }
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) load(d, s32_begin + d);
+    tstamp[1] = __builtin_amdgcn_s_memtime();
+    tstamp[2] = 0;
+    for (int base = 0; base < ns32; base += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            const bool live = base + d < ns32;
+            landed(d);
+            if (base == 0 && d == 0) tstamp[2] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                u32x4 ah[MI], al[MI];
+#pragma unroll
+                for (int i = 0; i < MI; i++) {
+                    f32x4 q0 = *reinterpret_cast<const f32x4 *>(lds_wave_p + d * A_STAGE + i * 4096 + frag[t][0]);
+                    f32x4 q1 = *reinterpret_cast<const f32x4 *>(lds_wave_p + d * A_STAGE + i * 4096 + frag[t][1]);
+                    if (!(live && rok[i])) { q0 = f32x4{0.f, 0.f, 0.f, 0.f}; q1 = q0; }
+                    zs::s16::split8(q0, q1, ah[i], al[i]);
+                }
+                if (!(a.abl & 4))
+#pragma unroll
+                for (int i = 0; i < MI; i++)
+#pragma unroll
+                    for (int j = 0; j < NJ; j++)
+                        zs::s16::mfma3(acc[i][j], __builtin_bit_cast(u32x4, rb[d][t][j][0]), __builtin_bit_cast(u32x4, rb[d][t][j][1]), ah[i], al[i]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the stage's fragment reads are done before its refill is issued
+            load(d, s32_begin + base + DEPTH + d);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();      // every wave is done with its ring before the partials overwrite it
+    tstamp[3] = __builtin_amdgcn_s_memtime();
+    // wave partials -> LDS: register 4q + e of lane (l32, half) = channel 8q + 4 half + e of pixel l32
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                *reinterpret_cast<f32x4 *>(&part[wave][32 * i + l32][32 * j + 8 * q + 4 * half]) =
+                    f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+    __syncthreads();
+    tstamp[4] = __builtin_amdgcn_s_memtime();
+    constexpr int QUADS = SM * SN / 4;
+    const int tile = tn * mtiles + tm;
+    auto finish = [&](int p, int c, f32x4 v) {
+        const int m = m0 + p, n = n0 + 4 * c;
+        if (m >= a.M || n >= a.N) return;
+        const size_t o = (size_t)m * a.N + n;
+        if (a.bias) v += *reinterpret_cast<const f32x4 *>(a.bias + n);
+        if (a.res) v += *reinterpret_cast<const f32x4 *>(a.res + o);
+        if (a.act == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = gelu(v[e]);
+        }
+        *reinterpret_cast<f32x4 *>(a.out + o) = v;
+    };
+    for (int e = tid; e < QUADS; e += 64 * NW) {
+        const int p = e / (SN / 4), c = e % (SN / 4);
+        f32x4 v = *reinterpret_cast<const f32x4 *>(&part[0][p][4 * c]);
+#pragma unroll
+        for (int w = 1; w < NW; w++) v += *reinterpret_cast<const f32x4 *>(&part[w][p][4 * c]);
+        if (a.splits == 1) { finish(p, c, v); continue; }
+        const int m = m0 + p, n = n0 + 4 * c;
+        if (m < a.M && n < a.N) {
+            float *dst = a.ws + ((size_t)z * a.M + m) * a.N + n;
+#pragma unroll
+            for (int k = 0; k < 4; k++) __hip_atomic_store(dst + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    tstamp[5] = __builtin_amdgcn_s_memtime();
+    tstamp[7] = __builtin_amdgcn_s_memrealtime();
+    if (a.stamps && lane == 0 && (wave == 0 || wave == NW - 1)) {
+        unsigned long long *dst = a.stamps + ((size_t)blockIdx.x * 2 + (wave ? 1 : 0)) * 8;
+        for (int k = 0; k < 8; k++) dst[k] = tstamp[k];
+    }
+    if (a.splits == 1) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const int old = __hip_atomic_fetch_add(&a.counters[tile], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = old == a.splits - 1;
+        if (last_flag) __hip_atomic_store(&a.counters[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    for (int e = tid; e < QUADS; e += 64 * NW) {
+        const int p = e / (SN / 4), c = e % (SN / 4);
+        const int m = m0 + p, n = n0 + 4 * c;
+        if (m >= a.M || n >= a.N) continue;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int zz = 0; zz < a.splits; zz++) {
+            const float *src = a.ws + ((size_t)zz * a.M + m) * a.N + n;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] += __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        finish(p, c, v);
+    }
+}
+
+// naive fp32 reference
+__global__ void ref_kernel(const float *a, const float *wT, const float *bias, const float *res, float *out, int M, int K, int N, int act) {
+    const int n = blockIdx.x * 64 + threadIdx.x, m = blockIdx.y;
+    if (n >= N) return;
+    double s = 0;
+    for (int k = 0; k < K; k++) s += (double)a[(size_t)m * K + k] * wT[(size_t)k * N + n];
+    float v = (float)s + (bias ? bias[n] : 0.f) + (res ? res[(size_t)m * N + n] : 0.f);
+    if (act == 2) v = gelu(v);
+    out[(size_t)m * N + n] = v;
+}
+
+static void print_stamps(unsigned long long *d, int blocks) {
+    if (blocks <= 0 || blocks > 2048) return;
+    std::vector<unsigned long long> h((size_t)blocks * 16);
+    CK(hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost));
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    int n = 0;
+    double skew = 0, span = 0, life_max = 0;
+    unsigned long long r0min = ~0ull, r0max = 0, r5max = 0, r5min = ~0ull;
+    for (int b = 0; b < blocks; b++)
+        for (int w = 0; w < 2; w++) {
+            const unsigned long long *s = &h[((size_t)b * 2 + w) * 8];
+            if (!s[0]) continue;
+            r0min = std::min(r0min, s[6]); r0max = std::max(r0max, s[6]); r5max = std::max(r5max, s[7]); r5min = std::min(r5min, s[7]);
+            life_max = std::max(life_max, (double)(s[5] - s[0]));
+            for (int k = 1; k < 6; k++) acc[k] += (double)(s[k] - s[k - 1]);
+            n++;
+        }
+    skew = (double)(r0max - r0min) * 23.9;        // 100 MHz -> ticks
+    span = (double)(r5max - r0min) * 23.9;
+    const double first_exit = (double)(r5min - r0min) * 23.9 / 2390.0;
+    if (!n) return;
+    const double us = 1.0 / 2390.0;
+    printf("      stamps us (mean of %d waves): issue %.2f first-land %.2f loop %.2f lds+barrier %.2f finish %.2f | realtime: entry skew %.2f, first entry -> last exit %.2f (first exit %.2f), longest wave %.2f\n",
+           n, acc[1] / n * us, acc[2] / n * us, acc[3] / n * us, acc[4] / n * us, acc[5] / n * us, skew * us, span * us, first_exit, life_max * us);
+}
+
+struct Shape { int M, K, N, act, res; const char *name; };
+
+template <int NW, int MI, int NJ, int DEPTH>
+static void launch_stream(GArgs g, hipStream_t st) {
+    const int mt = (g.M + 32 * MI - 1) / (32 * MI), nt = (g.N + 32 * NJ - 1) / (32 * NJ);
+    const int blocks = g.xcd_map ? 8 * ((mt * nt + 7) / 8) : mt * nt;
+    hipLaunchKernelGGL((stream_gemm_kernel<NW, MI, NJ, DEPTH>), dim3(blocks, g.splits), dim3(64 * NW), 0, st, g);
+}
+
+template <int NW, int MI, int NJ, int DEPTH>
+static void launch_stream_lds(GArgs g, hipStream_t st) {
+    const int mt = (g.M + 32 * MI - 1) / (32 * MI), nt = (g.N + 32 * NJ - 1) / (32 * NJ);
+    const int blocks = g.xcd_map ? 8 * ((mt * nt + 7) / 8) : mt * nt;
+    hipLaunchKernelGGL((stream_gemm_lds_kernel<NW, MI, NJ, DEPTH>), dim3(blocks, g.splits), dim3(64 * NW), 0, st, g);
+}
+
+int main(int argc, char **argv) {
+    const int chain = argc > 1 ? atoi(argv[1]) : 24;          // dependent launches per graph
+    const int reps = argc > 2 ? atoi(argv[2]) : 20;
+    std::vector<Shape> shapes = {
+        {197, 768, 2304, 0, 0, "vit qkv"}, {197, 768, 768, 0, 1, "vit proj"}, {197, 768, 3072, 2, 0, "vit fc1"},
+        {197, 3072, 768, 0, 1, "vit fc2"}, {196, 1024, 256, 0, 0, "rn c1 14^2"}, {196, 256, 1024, 0, 0, "rn c3 14^2"},
+        {196, 2304, 256, 0, 0, "rn c2 14^2 (as pw)"}, {49, 6912, 768, 0, 0, "intr 3x3 7^2 (as pw)"},
+        {49, 2048, 512, 0, 0, "r50 l4 c1"}, {1, 2048, 2048, 0, 0, "fc head gemv"}, {784, 512, 128, 0, 0, "rn c1 28^2"},
+        {784, 1152, 128, 0, 0, "rn c2 28^2 (as pw)"}, {3136, 256, 64, 0, 0, "rn c1 56^2"},
+    };
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    void *wsp;
+    const size_t ws_bytes = zs_conv2d_splitk_workspace_bytes();
+    CK(hipMalloc(&wsp, ws_bytes));
+    CK(hipMemset(wsp, 0, ws_bytes));
+    float *ws2;
+    int *counters;
+    CK(hipMalloc(&ws2, (size_t)64 << 20));
+    CK(hipMalloc(&counters, 1 << 20));
+    CK(hipMemset(counters, 0, 1 << 20));
+    // a 512 MB buffer walked between timed graphs keeps everything cold
+    for (const Shape &sh : shapes) {
+        const int M = sh.M, K = sh.K, N = sh.N, CoutPad = (N + 127) / 128 * 128, K16 = (K + 15) / 16 * 16;
+        const size_t wfloats = (size_t)K16 * CoutPad;
+        const int NBUF = (int)std::min<size_t>(chain, std::max<size_t>(2, ((size_t)400 << 20) / (wfloats * 4)));
+        std::vector<float> ha((size_t)M * K), hw((size_t)K * N), hb(N), hr((size_t)M * N);
+        srand(1);
+        for (auto &v : ha) v = (rand() / (float)RAND_MAX - 0.5f) * 2.f;
+        for (auto &v : hw) v = (rand() / (float)RAND_MAX - 0.5f) * 0.1f;
+        for (auto &v : hb) v = (rand() / (float)RAND_MAX - 0.5f);
+        for (auto &v : hr) v = (rand() / (float)RAND_MAX - 0.5f);
+        std::vector<float> packed(wfloats, 0.f);
+        for (int k = 0; k < K; k++)
+            for (int n = 0; n < N; n++) packed[((size_t)(k / 4) * CoutPad + n) * 4 + (k & 3)] = hw[(size_t)k * N + n];
+        float *da, *dwT, *db, *dr, *dout, *dref, *dpacked;
+        std::vector<float *> dsplit(NBUF);
+        CK(hipMalloc(&da, ha.size() * 4)); CK(hipMalloc(&dwT, hw.size() * 4)); CK(hipMalloc(&db, N * 4));
+        CK(hipMalloc(&dr, hr.size() * 4)); CK(hipMalloc(&dout, hr.size() * 4)); CK(hipMalloc(&dref, hr.size() * 4));
+        CK(hipMalloc(&dpacked, wfloats * 4));
+        CK(hipMemcpy(da, ha.data(), ha.size() * 4, hipMemcpyHostToDevice));
+        float *dapad;
+        CK(hipMalloc(&dapad, (size_t)M * (K + 64) * 4));
+        CK(hipMemcpy2D(dapad, (size_t)(K + 16) * 4, ha.data(), (size_t)K * 4, (size_t)K * 4, M, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dwT, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(db, hb.data(), N * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dr, hr.data(), hr.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dpacked, packed.data(), wfloats * 4, hipMemcpyHostToDevice));
+        for (int i = 0; i < NBUF; i++) {
+            CK(hipMalloc(&dsplit[i], wfloats * 4));
+            if (!zs_conv2d_presplit_weight(dpacked, dsplit[i], K, N, 1, 1, st)) { printf("presplit failed: %s\n", zs_last_error()); return 1; }
+        }
+        hipLaunchKernelGGL(ref_kernel, dim3((N + 63) / 64, M), dim3(64), 0, st, da, dwT, db, sh.res ? dr : nullptr, dref, M, K, N, sh.act);
+        CK(hipStreamSynchronize(st));
+        std::vector<float> href(hr.size()), hout(hr.size());
+        CK(hipMemcpy(href.data(), dref, href.size() * 4, hipMemcpyDeviceToHost));
+        double scale = 0;
+        for (float v : href) scale = std::max(scale, (double)fabsf(v));
+
+        auto run_variant = [&](const char *label, auto &&launch) {
+            CK(hipMemsetAsync(dout, 0, hr.size() * 4, st));
+            launch(0);
+            CK(hipStreamSynchronize(st));
+            CK(hipMemcpy(hout.data(), dout, hout.size() * 4, hipMemcpyDeviceToHost));
+            double err = 0;
+            for (size_t i = 0; i < hout.size(); i++) err = std::max(err, (double)fabsf(hout[i] - href[i]));
+            hipGraph_t graph;
+            hipGraphExec_t exec;
+            CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+            for (int i = 0; i < chain; i++) launch(i % NBUF);
+            CK(hipStreamEndCapture(st, &graph));
+            CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            hipEvent_t e0, e1;
+            CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            for (int i = 0; i < 3; i++) CK(hipGraphLaunch(exec, st));
+            CK(hipStreamSynchronize(st));
+            float best = 1e9f, sum = 0;
+            for (int r = 0; r < reps; r++) {
+                CK(hipEventRecord(e0, st));
+                CK(hipGraphLaunch(exec, st));
+                CK(hipEventRecord(e1, st));
+                CK(hipStreamSynchronize(st));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                best = std::min(best, ms);
+                sum += ms;
+            }
+            printf("  %-34s %7.2f us/launch (min %7.2f)  err %.2e of %.2e\n", label, sum / reps / chain * 1e3, best / chain * 1e3, err, scale);
+            CK(hipGraphExecDestroy(exec));
+            CK(hipGraphDestroy(graph));
+        };
+        printf("%s: M %d K %d N %d (weights %.1f MB, %d buffers)\n", sh.name, M, K, N, wfloats * 4 / 1e6, NBUF);
+        run_variant("library zs_conv2d_nhwc_ws", [&](int b) {
+            if (!zs_conv2d_nhwc_ws(da, dsplit[b], nullptr, db, sh.res ? dr : nullptr, nullptr, dout, 1, 1, M, K, 1, M, N, 1, 1, 1, 0, 0,
+                                   ZS_CONV_F16X3 | ZS_CONV_W_PRESPLIT, 1.0f, 0.0f, sh.act, wsp, st)) { printf("conv failed: %s\n", zs_last_error()); exit(1); }
+        });
+        run_variant("library FORCE_LARGE (dma 64x128)", [&](int b) {
+            if (!zs_conv2d_nhwc_ws(da, dsplit[b], nullptr, db, sh.res ? dr : nullptr, nullptr, dout, 1, 1, M, K, 1, M, N, 1, 1, 1, 0, 0,
+                                   ZS_CONV_F16X3 | ZS_CONV_W_PRESPLIT | ZS_CONV_FORCE_LARGE, 1.0f, 0.0f, sh.act, wsp, st)) { printf("conv failed: %s\n", zs_last_error()); exit(1); }
+        });
+        if (getenv("LIB_ONLY")) goto cleanup;
+        {
+        GArgs g;
+        static unsigned long long *dstamps = nullptr;
+        if (!dstamps) CK(hipMalloc(&dstamps, 4096 * 16 * 8));
+        g.stamps = dstamps;
+        g.a = da; g.bias = db; g.res = sh.res ? dr : nullptr; g.out = dout; g.ws = ws2; g.counters = counters;
+        g.M = M; g.K = K; g.N = N; g.CoutPad = CoutPad; g.act = sh.act;
+#define VARL(NW, MI, NJ, DEPTH, SPL, XCD, ABL)                                                                        \
+        do {                                                                                                             \
+            if ((size_t)SPL * M * N * 4 <= ((size_t)64 << 20) && (K / 32) / (SPL * NW) >= 1 && K % (32 * NW * SPL) == 0) {  \
+                char label[96];                                                                                          \
+                snprintf(label, sizeof label, "lds-A  NW%d MI%d NJ%d D%d z%d xcd%d abl%d", NW, MI, NJ, DEPTH, SPL, XCD, ABL); \
+                CK(hipMemset(dstamps, 0, 4096 * 16 * 8));                                                                \
+                run_variant(label, [&](int b) {                                                                          \
+                    g.w = reinterpret_cast<const f32x4 *>(dsplit[b]); g.splits = SPL; g.xcd_map = XCD; g.abl = ABL; g.lda = K; g.a = da; \
+                    launch_stream_lds<NW, MI, NJ, DEPTH>(g, st);                                                         \
+                });                                                                                                      \
+                print_stamps(dstamps, 8 * ((((N + 32 * NJ - 1) / (32 * NJ)) * ((M + 32 * MI - 1) / (32 * MI)) + 7) / 8)); \
+            }                                                                                                            \
+        } while (0)
+#define VAR(NW, MI, NJ, DEPTH, SPL, XCD) VARA(NW, MI, NJ, DEPTH, SPL, XCD, 0, 0)
+#define VARA(NW, MI, NJ, DEPTH, SPL, XCD, ABL, PADK)                                                                           \
+        do {                                                                                                             \
+            if ((size_t)SPL * M * N * 4 <= ((size_t)64 << 20) && (K / 16) / (SPL) >= 1) {                                 \
+                char label[96];                                                                                          \
+                snprintf(label, sizeof label, "stream NW%d MI%d NJ%d D%d z%d xcd%d abl%d pad%d", NW, MI, NJ, DEPTH, SPL, XCD, ABL, PADK);       \
+                CK(hipMemset(dstamps, 0, 4096 * 16 * 8));                                                                \
+                run_variant(label, [&](int b) {                                                                          \
+                    g.w = reinterpret_cast<const f32x4 *>(dsplit[b]); g.splits = SPL; g.xcd_map = XCD; g.abl = ABL; g.lda = K + PADK; g.a = PADK ? dapad : da;                    \
+                    launch_stream<NW, MI, NJ, DEPTH>(g, st);                                                             \
+                });                                                                                                      \
+                print_stamps(dstamps, 8 * ((((N + 32 * NJ - 1) / (32 * NJ)) * ((M + 32 * MI - 1) / (32 * MI)) + 7) / 8)); \
+            }                                                                                                            \
+        } while (0)
+        VAR(8, 1, 2, 2, 1, 1);
+        VAR(4, 1, 2, 3, 1, 1);
+        VAR(8, 1, 3, 3, 1, 1);
+        VARL(4, 1, 2, 2, 1, 1, 0);
+        VARL(4, 1, 2, 3, 1, 1, 0);
+        VARL(8, 1, 2, 2, 1, 1, 0);
+        VARL(8, 1, 3, 2, 1, 1, 0);
+        VARL(4, 1, 3, 2, 1, 1, 0);
+        VARL(4, 2, 2, 2, 1, 1, 0);
+        VARL(4, 1, 2, 2, 1, 1, 4);
+        }
+    cleanup:
+        CK(hipFree(da)); CK(hipFree(dwT)); CK(hipFree(db)); CK(hipFree(dr)); CK(hipFree(dout)); CK(hipFree(dref)); CK(hipFree(dpacked));
+        for (auto p : dsplit) CK(hipFree(p));
+    }
+    return 0;
+}

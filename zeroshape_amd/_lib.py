@@ -15,6 +15,14 @@ _c_int = ctypes.c_int
 _c_size_t = ctypes.c_size_t
 _c_float = ctypes.c_float
 
+class ConvFuse(ctypes.Structure):
+    """include/zeroshape_hip.h: zs_conv_fuse."""
+    _fields_ = [("in_mode", ctypes.c_int), ("in_tiles", ctypes.c_int), ("in_groups", ctypes.c_int), ("in_gshift", ctypes.c_int),
+                ("in_stats", ctypes.c_void_p), ("in_gamma", ctypes.c_void_p), ("in_beta", ctypes.c_void_p),
+                ("in_eps", ctypes.c_float), ("out_mode", ctypes.c_int), ("out_groups", ctypes.c_int),
+                ("out_stats", ctypes.c_void_p)]
+
+
 # name -> (restype, argtypes); mirrors include/zeroshape_hip.h one to one
 SIGNATURES = {
     "zs_abi_version": (_c_int, []),
@@ -104,6 +112,11 @@ SIGNATURES = {
     "zs_conv3x3_tail_nhwc": (_c_int, [_c_void_p] * 5 + [_c_int] * 7 + [_c_void_p, _c_void_p, _c_int, _c_void_p]),
     "zs_conv2d_nhwc_ws": (_c_int, [_c_void_p] * 7 + [_c_int] * 13 + [ctypes.c_float, ctypes.c_float, _c_int,
                                                                      _c_void_p, _c_void_p]),
+    "zs_conv2d_nhwc_fused": (_c_int, [_c_void_p] * 7 + [_c_int] * 13 + [ctypes.c_float, ctypes.c_float, _c_int,
+                                                                        _c_void_p, _c_void_p, _c_void_p]),
+    "zs_conv2d_fused_cols": (_c_int, [_c_int, _c_int]),
+    "zs_group_norm_apply_stats": (_c_int, [_c_void_p, _c_void_p, _c_int] + [_c_void_p] * 4 + [_c_int] + [_c_void_p] * 3 +
+                                  [_c_int, _c_int, _c_int, ctypes.c_float, _c_int, _c_void_p]),
     "zs_group_norm_nhwc": (_c_int, [_c_void_p] * 5 + [_c_int, _c_int, _c_int, _c_int, ctypes.c_float, _c_int,
                                                       _c_void_p]),
     "zs_group_norm_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int, _c_int]),

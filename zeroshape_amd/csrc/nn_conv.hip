@@ -27,6 +27,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <type_traits>
 
@@ -59,6 +60,9 @@ struct ConvArgs {
     // conv3x3_patch32_kernel only: fused pointwise tail to one channel (zs_conv3x3_tail_nhwc); out is then [B][H][W]
     const float *tail_w, *tail_b;
     int tail_act;
+    // fused normalisations (zs_conv2d_nhwc_fused, small-tile kernel only; include/zeroshape_hip.h: zs_conv_fuse)
+    zs_conv_fuse fz;
+    int fz_tiles_per_sample;      // input-statistics tiles per sample (in_mode 1 / 3), output tiles per sample (out_mode 1)
 };
 
 // workspace layout (floats): [SK_COUNTERS ints, zero between launches][partial tiles / split-K partial sums]
@@ -996,11 +1000,20 @@ constexpr int SM = 32, SU = ZS_SMALL_SU;       // tile rows, and t-steps (8 k ea
 
 // F16: two consecutive t-steps give a lane the eight k values of one K = 16 MFMA operand (A and B in
 // the same order), split into hi / lo halves in registers.
-template <int NJ, bool PW, int MODE = 0, bool PLAIN = false, bool F16 = false>
+// XF: fused input normalisation (zs_conv_fuse.in_mode): 1 = GroupNorm + ReLU of the input from per-tile group sums,
+// 2 = LayerNorm of the input rows from per-tile row sums (gamma / beta live in the weights).  The statistics come from
+// the producing launch's epilogue (out_mode): no normalisation launch, no extra pass over the tensor.  (A third mode -
+// relu(GN(in) + residual) formed on load and written back by column tile 0 - was built and measured: every column
+// tile re-reads the residual, 21.7 vs 9.8 us for the 1,024 -> 256 layer at 14 x 14; zs_group_norm_apply_stats does
+// that step in one pass instead.)
+constexpr int XF_MAXC = 1024;     // channels of a normalised input
+template <int NJ, bool PW, int MODE = 0, bool PLAIN = false, bool F16 = false, int XF = 0>
 __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
     constexpr bool TM = MODE == 2;            // tap-major walk, Cin % 8 == 0
     constexpr int SN = 32 * NJ;
     __shared__ float part[4][SM][SN + 1];
+    __shared__ __attribute__((aligned(16))) float xf_tab[2][XF == 0 ? 4 : (XF == 2 ? SM : XF_MAXC)];
+    __shared__ float xf_red[XF == 1 ? 8 : 1][32][2], xf_stat[32][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, half = lane >> 5;
     const int m0 = blockIdx.x * SM, n0 = blockIdx.y * SN;
     const int pix = m0 + l32;
@@ -1072,12 +1085,27 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
             for (int j = 0; j < NJ; j++) fb[buf][u][j] = wlane[(size_t)kq * a.CoutPad + 32 * j];
         }
     };
+    float row_s = 1.0f, row_t = 0.0f;              // XF 2: this lane's row
+    // XF: channel of the t-step being consumed (uniform; a t-step of 8 lies inside one tap: Cin % 8 == 0)
+    int xc = XF == 1 ? (8 * t_begin) % a.Cin : 0;
     auto a_quad = [&](int buf, int u) -> f32x4 {
         f32x4 av;
+        if (XF == 1) {
+            const f32x4 sc = *reinterpret_cast<const f32x4 *>(&xf_tab[0][xc + 4 * half]);
+            const f32x4 sh = *reinterpret_cast<const f32x4 *>(&xf_tab[1][xc + 4 * half]);
 #pragma unroll
-        for (int e = 0; e < 4; e++)
-            av[e] = (PW || PLAIN) ? (fa[buf][u].ok ? fa[buf][u].v[e] : 0.f)
-                                  : (fa[buf][u].ok ? fmaxf(fa[buf][u].v[e], relu_floor) * a.in_scale + a.in_shift : 0.f);
+            for (int e = 0; e < 4; e++) av[e] = fa[buf][u].ok ? fmaxf(fa[buf][u].v[e] * sc[e] + sh[e], 0.f) : 0.f;
+            xc += 8;
+            if (xc >= a.Cin) xc -= a.Cin;
+        } else if (XF == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) av[e] = fa[buf][u].ok ? fa[buf][u].v[e] * row_s + row_t : 0.f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                av[e] = (PW || PLAIN) ? (fa[buf][u].ok ? fa[buf][u].v[e] : 0.f)
+                                      : (fa[buf][u].ok ? fmaxf(fa[buf][u].v[e], relu_floor) * a.in_scale + a.in_shift : 0.f);
+        }
         return av;
     };
     auto consume = [&](int buf) {
@@ -1086,7 +1114,9 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
 #pragma unroll
             for (int u = 0; u < SU; u += 2) {
                 u32x4 ah, al;
-                zs::s16::split8(a_quad(buf, u), a_quad(buf, u + 1), ah, al);
+                const f32x4 q0 = a_quad(buf, u);           // in t order: the XF walker advances per call
+                const f32x4 q1 = a_quad(buf, u + 1);
+                zs::s16::split8(q0, q1, ah, al);
 #pragma unroll
                 for (int j = 0; j < NJ; j++) {
                     u32x4 bh, bl;
@@ -1111,8 +1141,78 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], fb[buf][u][j][s], acc[j], 0, 0, 0);
         }
     };
+    if (t_begin < t_end) fetch(0, t_begin);       // the first operands travel while the statistics are turned into tables
+    if (XF == 1) {
+        // group statistics of this workgroup's sample: the producer wrote (sum, sum of squares) per 32-row tile and group;
+        // summed here in a fixed order (8 strided slices in float, the slices and the moments in double: the same value in
+        // every workgroup and on every run), then one (scale, shift) per channel
+        const int sample = a.fz_tiles_per_sample > 0 ? m0 / (a.Hout * a.Wout) : 0;
+        const int gshift = a.fz.in_gshift;                          // channels per group = 1 << gshift
+        const double cnt = (double)a.Hin * a.Win * (double)(1 << gshift);
+        const int tiles = a.fz.in_tiles, g = tid & 31, slice = tid >> 5;
+        float S = 0.f, Q = 0.f;
+        for (int tl = slice; tl < tiles; tl += 8) {
+            const float2 e = *reinterpret_cast<const float2 *>(a.fz.in_stats + ((size_t)(sample * tiles + tl) * 32 + g) * 2);
+            S += e.x;
+            Q += e.y;
+        }
+        xf_red[slice][g][0] = S;
+        xf_red[slice][g][1] = Q;
+        __syncthreads();
+        if (tid < 32) {
+            double s2 = 0.0, q2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { s2 += (double)xf_red[k][tid][0]; q2 += (double)xf_red[k][tid][1]; }
+            const double mean = s2 / cnt, var = fmax(q2 / cnt - mean * mean, 0.0);
+            xf_stat[tid][0] = (float)mean;
+            xf_stat[tid][1] = (float)(1.0 / sqrt(var + (double)a.fz.in_eps));
+        }
+        __syncthreads();
+        for (int c = tid; c < a.Cin; c += 256) {
+            const int g2 = c >> gshift;
+            const float sc = a.fz.in_gamma[c] * xf_stat[g2][1];
+            xf_tab[0][c] = sc;
+            xf_tab[1][c] = a.fz.in_beta[c] - xf_stat[g2][0] * sc;
+        }
+        __syncthreads();
+    }
+    if (XF == 2) {
+        // row statistics: the producer wrote (sum, M2 about its own mean) per row and column tile.  Eight lanes per row
+        // split the tiles; mean from the sums, then M2 = sum of (M2_t + n_t (mean_t - mean)^2): two xor-shuffle trees
+        const int row = tid >> 3, sub = tid & 7, m = m0 + row, tiles = a.fz.in_tiles;
+        const float nb = (float)a.Cin / (float)tiles;
+        float sums[4], m2s[4];                                      // up to 32 column tiles
+        float S = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int tl = sub + 8 * k;
+            float2 e = {0.f, 0.f};
+            if (m < a.M && tl < tiles) e = *reinterpret_cast<const float2 *>(a.fz.in_stats + ((size_t)m * tiles + tl) * 2);
+            sums[k] = e.x;
+            m2s[k] = e.y;
+            S += e.x;
+        }
+        S += __shfl_xor(S, 1, 64); S += __shfl_xor(S, 2, 64); S += __shfl_xor(S, 4, 64);
+        const float mean = S / (float)a.Cin;
+        float M2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float d = sums[k] / nb - mean;
+            if (sub + 8 * k < tiles) M2 += m2s[k] + nb * d * d;
+        }
+        M2 += __shfl_xor(M2, 1, 64); M2 += __shfl_xor(M2, 2, 64); M2 += __shfl_xor(M2, 4, 64);
+        if (sub == 0) {
+            const float rstd = 1.0f / sqrtf(M2 / (float)a.Cin + a.fz.in_eps);
+            xf_tab[0][row] = m < a.M ? rstd : 0.f;
+            xf_tab[1][row] = m < a.M ? -mean * rstd : 0.f;
+        }
+        __syncthreads();
+    }
+    if (XF == 2) {
+        row_s = xf_tab[0][l32];
+        row_t = xf_tab[1][l32];
+    }
     if (t_begin < t_end) {
-        fetch(0, t_begin);
         for (int t0 = t_begin; t0 < t_end; t0 += 2 * SU) {
             fetch(1, t0 + SU);
             consume(0);
@@ -1127,25 +1227,95 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
         for (int r = 0; r < 16; r++) part[wave][8 * (r >> 2) + 4 * half + (r & 3)][32 * j + l32] = acc[j][r];
     __syncthreads();
     if ((a.Cout & 3) == 0) {      // four consecutive channels per thread: 16-byte residual loads and stores
-        for (int e = tid; e < SM * SN / 4; e += 256) {
-            const int row = e / (SN / 4), col = 4 * (e % (SN / 4)), m = m0 + row, n = n0 + col;
-            if (m >= a.M || n >= a.Cout) continue;
+        // out_mode: statistics of the values this launch stores, for the consumer's fused normalisation.  1: (sum, sum of
+        // squares) per (32-row tile, group of Cout / groups channels); 2: (sum, M2 about the tile-row mean) per (row,
+        // column tile).  A thread's quads of all passes share their column quad, hence their group(s).
+        const int om = a.fz.out_mode, gw = om == 1 ? a.Cout / a.fz.out_groups : 4;
+        float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+        constexpr int QPR = SN / 4, PASSES = SM * QPR / 256;       // quads per row; NJ = 1: one pass, NJ = 2: two
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ps++) {
+            const int e = tid + 256 * ps;
+            const int row = e / QPR, col = 4 * (e % QPR), m = m0 + row, n = n0 + col;
+            const bool valid = m < a.M && n < a.Cout;
             f32x4 v;
 #pragma unroll
             for (int c = 0; c < 4; c++)
                 v[c] = (part[0][row][col + c] + part[1][row][col + c]) + (part[2][row][col + c] + part[3][row][col + c]);
-            const size_t o = (size_t)m * a.Cout + n;
+            const size_t o = (size_t)(valid ? m : 0) * a.Cout + (valid ? n : 0);
             if (a.splits > 1) {       // raw partial; the epilogue runs in conv_splitk_reduce_kernel
-                *reinterpret_cast<f32x4 *>(a.ws + WS_COUNTER_FLOATS + (size_t)blockIdx.z * a.M * a.Cout + o) = v;
+                if (valid) *reinterpret_cast<f32x4 *>(a.ws + WS_COUNTER_FLOATS + (size_t)blockIdx.z * a.M * a.Cout + o) = v;
                 continue;
             }
+            if (valid) {
 #pragma unroll
-            for (int c = 0; c < 4; c++) v[c] = v[c] * (a.scale ? a.scale[n + c] : 1.0f) + (a.shift ? a.shift[n + c] : 0.0f);
-            if (a.res1) v += *reinterpret_cast<const f32x4 *>(a.res1 + o);
-            if (a.res2) v += *reinterpret_cast<const f32x4 *>(a.res2 + o);
+                for (int c = 0; c < 4; c++) v[c] = v[c] * (a.scale ? a.scale[n + c] : 1.0f) + (a.shift ? a.shift[n + c] : 0.0f);
+                if (a.res1) v += *reinterpret_cast<const f32x4 *>(a.res1 + o);
+                if (a.res2) v += *reinterpret_cast<const f32x4 *>(a.res2 + o);
 #pragma unroll
-            for (int c = 0; c < 4; c++) v[c] = activate(v[c], a.act);
-            *reinterpret_cast<f32x4 *>(a.out + o) = v;
+                for (int c = 0; c < 4; c++) v[c] = activate(v[c], a.act);
+                *reinterpret_cast<f32x4 *>(a.out + o) = v;
+            } else {
+                v = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (om == 1) {
+                if (gw >= 4) {
+                    s0 += (v[0] + v[1]) + (v[2] + v[3]);
+                    q0 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                } else {               // two channels per group: two groups per quad
+                    s0 += v[0] + v[1]; q0 += v[0] * v[0] + v[1] * v[1];
+                    s1 += v[2] + v[3]; q1 += v[2] * v[2] + v[3] * v[3];
+                }
+            } else if (om == 2) {      // one pass per row here: rows of later passes are other rows
+                float rs = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+                for (int sh = 1; sh < QPR; sh <<= 1) rs += __shfl_xor(rs, sh, 64);
+                const float mean = rs * (1.0f / SN);
+                float d2 = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; c++) d2 += (v[c] - mean) * (v[c] - mean);
+#pragma unroll
+                for (int sh = 1; sh < QPR; sh <<= 1) d2 += __shfl_xor(d2, sh, 64);
+                if (valid && (e % QPR) == 0) {
+                    float *dst = a.fz.out_stats + ((size_t)m * gridDim.y + blockIdx.y) * 2;
+                    dst[0] = rs;
+                    dst[1] = d2;
+                }
+            }
+        }
+        if (om == 1 && a.splits == 1) {
+            // lanes of a wave: low bits = column quad (QPR of them), high bits = row.  Sum over the rows of the wave and
+            // over the quads of a group by xor shuffles (a fixed tree), then over the four waves through LDS in wave order.
+            const int qpg = gw >= 4 ? gw / 4 : 1;                   // quads per group (1, 2, 4, 8)
+#pragma unroll
+            for (int sh = QPR; sh < 64; sh <<= 1) {
+                s0 += __shfl_xor(s0, sh, 64); q0 += __shfl_xor(q0, sh, 64);
+                s1 += __shfl_xor(s1, sh, 64); q1 += __shfl_xor(q1, sh, 64);
+            }
+            for (int sh = 1; sh < qpg; sh <<= 1) { s0 += __shfl_xor(s0, sh, 64); q0 += __shfl_xor(q0, sh, 64); }
+            __syncthreads();                                        // the partial tiles have been read: reuse part[0]
+            float *wsum = &part[0][0][0];                           // [wave][group in tile][2 or 4]
+            const int gpt = gw >= 4 ? QPR / qpg : 2 * QPR;          // groups per tile
+            if (lane < QPR && (lane % qpg) == 0) {
+                if (gw >= 4) {
+                    wsum[(wave * gpt + lane / qpg) * 2] = s0;
+                    wsum[(wave * gpt + lane / qpg) * 2 + 1] = q0;
+                } else {
+                    wsum[(wave * gpt + 2 * lane) * 2] = s0;     wsum[(wave * gpt + 2 * lane) * 2 + 1] = q0;
+                    wsum[(wave * gpt + 2 * lane + 1) * 2] = s1; wsum[(wave * gpt + 2 * lane + 1) * 2 + 1] = q1;
+                }
+            }
+            __syncthreads();
+            if (tid < gpt) {
+                const int g = n0 / gw + tid;
+                if (g < a.fz.out_groups) {
+                    float ts = 0.f, tq = 0.f;
+                    for (int w = 0; w < 4; w++) { ts += wsum[(w * gpt + tid) * 2]; tq += wsum[(w * gpt + tid) * 2 + 1]; }
+                    float *dst = a.fz.out_stats + ((size_t)blockIdx.x * a.fz.out_groups + g) * 2;
+                    dst[0] = ts;
+                    dst[1] = tq;
+                }
+            }
         }
         return;
     }
@@ -1240,11 +1410,71 @@ extern "C" int zs_conv2d_nhwc(const float *in, const float *packed_w, const floa
                              stride, pad_t, pad_l, flags, in_scale, in_shift, act, nullptr, stream);
 }
 
+static int conv2d_impl(const float *in, const float *packed_w, const float *scale, const float *shift,
+                       const float *res1, const float *res2, float *out, int batch, int Hin, int Win,
+                       int Cin, int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad_t,
+                       int pad_l, int flags, float in_scale, float in_shift, int act, const zs_conv_fuse *fuse,
+                       void *workspace, void *stream);
+
 extern "C" int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const float *scale, const float *shift,
                                  const float *res1, const float *res2, float *out, int batch, int Hin, int Win,
                                  int Cin, int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad_t,
                                  int pad_l, int flags, float in_scale, float in_shift, int act, void *workspace,
                                  void *stream) {
+    return conv2d_impl(in, packed_w, scale, shift, res1, res2, out, batch, Hin, Win, Cin, Hout, Wout, Cout, kh, kw, stride,
+                       pad_t, pad_l, flags, in_scale, in_shift, act, nullptr, workspace, stream);
+}
+
+static bool small_is_narrow(long long M, int Cout) {
+    static const long long narrow_below = getenv("ZS_CONV_NARROW_BELOW") ? atoll(getenv("ZS_CONV_NARROW_BELOW")) : 384;
+    return ((M + SM - 1) / SM) * ((Cout + 63) / 64) < narrow_below;      // 32x32 tiles: twice the workgroups for the smallest problems
+}
+
+extern "C" int zs_conv2d_fused_cols(int M, int Cout) { return small_is_narrow(M, Cout) ? 32 : 64; }
+
+extern "C" int zs_conv2d_nhwc_fused(const float *in, const float *packed_w, const float *scale, const float *shift,
+                                    const float *res1, const float *res2, float *out, int batch, int Hin, int Win,
+                                    int Cin, int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad_t,
+                                    int pad_l, int flags, float in_scale, float in_shift, int act, const zs_conv_fuse *fuse,
+                                    void *workspace, void *stream) {
+    if (!fuse) { zs::set_err("zs_conv2d_nhwc_fused: null fuse descriptor"); return 0; }
+    const int need = ZS_CONV_F16X3 | ZS_CONV_W_PRESPLIT;
+    const zs_conv_fuse &f = *fuse;
+    const long long hw_in = (long long)Hin * Win, hw_out = (long long)Hout * Wout;
+    const bool pw = kh == 1 && kw == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && Hin == Hout && Win == Wout;
+    const bool gn_in = f.in_mode == 1;
+    int gshift = 0;
+    while ((32 << gshift) < Cin) gshift++;
+    if ((flags & need) != need || (flags & (ZS_CONV_IN_RELU | ZS_CONV_IN_DILATE2 | ZS_CONV_FORCE_LARGE)) || in_scale != 1.0f || in_shift != 0.0f ||
+        f.in_mode < 0 || f.in_mode > 2 || f.out_mode < 0 || f.out_mode > 2 || (Cout & 3) || (Cin & 7) ||
+        (f.in_mode && !f.in_stats) || (f.out_mode && !f.out_stats) ||
+        (gn_in && (!f.in_gamma || !f.in_beta || f.in_groups != 32 || (32 << gshift) != Cin || Cin > XF_MAXC || f.in_tiles <= 0 ||
+                   (batch > 1 && hw_in % SM) || (batch > 1 && hw_out % SM))) ||
+        (f.in_mode == 2 && (!pw || f.in_tiles <= 0 || f.in_tiles > 32 || Cin % f.in_tiles)) ||
+        (f.out_mode == 1 && (f.out_groups <= 0 || Cout % f.out_groups || (batch > 1 && hw_out % SM))) ||
+        (f.out_mode == 2 && Cout % zs_conv2d_fused_cols((int)(batch * hw_out), Cout))) {
+        zs::set_err("zs_conv2d_nhwc_fused: unsupported combination (flags %d in_mode %d out_mode %d Cin %d Cout %d k %dx%d s %d)",
+                    flags, f.in_mode, f.out_mode, Cin, Cout, kh, kw, stride);
+        return 0;
+    }
+    if (f.out_mode == 1) {
+        const int gw = Cout / f.out_groups;
+        if (!(gw == 2 || gw == 4 || gw == 8 || gw == 16 || gw == 32)) {
+            zs::set_err("zs_conv2d_nhwc_fused: out_mode 1 takes 2..32 channels per group (Cout %d, groups %d)", Cout, f.out_groups);
+            return 0;
+        }
+    }
+    zs_conv_fuse f2 = f;
+    f2.in_gshift = gshift;
+    return conv2d_impl(in, packed_w, scale, shift, res1, res2, out, batch, Hin, Win, Cin, Hout, Wout, Cout, kh, kw, stride,
+                       pad_t, pad_l, (flags | ZS_CONV_FORCE_SMALL) & ~ZS_CONV_SPLIT_SMALL, in_scale, in_shift, act, &f2, workspace, stream);
+}
+
+static int conv2d_impl(const float *in, const float *packed_w, const float *scale, const float *shift,
+                       const float *res1, const float *res2, float *out, int batch, int Hin, int Win,
+                       int Cin, int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad_t,
+                       int pad_l, int flags, float in_scale, float in_shift, int act, const zs_conv_fuse *fuse,
+                       void *workspace, void *stream) {
     if (batch < 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || (Cin & 3) || Hout <= 0 || Wout <= 0 || Cout <= 0 ||
         kh <= 0 || kw <= 0 || stride <= 0 || act < 0 || act > ZS_ACT_RELU_CLAMP1) {
         zs::set_err("zs_conv2d_nhwc: bad geometry (B=%d in %dx%dx%d out %dx%dx%d k %dx%d s %d act %d; Cin must be "
@@ -1259,6 +1489,8 @@ extern "C" int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const f
     a.slab_major = 0;
     a.tail_w = a.tail_b = nullptr;
     a.tail_act = 0;
+    if (fuse) a.fz = *fuse; else memset(&a.fz, 0, sizeof a.fz);
+    a.fz_tiles_per_sample = fuse && batch > 1 ? 1 : 0;
     a.in = in; a.w = packed_w; a.scale = scale; a.shift = shift; a.res1 = res1; a.res2 = res2; a.out = out;
     a.B = batch; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout;
     a.CoutPad = (Cout + BN - 1) / BN * BN;
@@ -1384,10 +1616,8 @@ extern "C" int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const f
         }
     }
     if (small) {
-        static const long long narrow_below = getenv("ZS_CONV_NARROW_BELOW") ? atoll(getenv("ZS_CONV_NARROW_BELOW")) : 384;
-        const long long wide = ((M + SM - 1) / SM) * ((Cout + 63) / 64);
         const bool tm = !pw && !no_tm && (Cin % 8) == 0;
-        const bool narrow = wide < narrow_below;   // 32x32 tiles: twice the workgroups for the smallest problems
+        const bool narrow = small_is_narrow(M, Cout);
         const long long wgs = ((M + SM - 1) / SM) * ((Cout + (narrow ? 31 : 63)) / (narrow ? 32 : 64));
         // Split K across workgroups while the launch would leave most of the 256 CUs idle (14x14 maps,
         // 197-token matrices at batch 1: 28-84 workgroups): ~512 workgroups, >= 16 t-steps (K = 128) per
@@ -1402,7 +1632,25 @@ extern "C" int zs_conv2d_nhwc_ws(const float *in, const float *packed_w, const f
             if (sp > cap) sp = cap;
             if (sp > 1) a.splits = (int)sp;
         }
-        if (narrow) {
+        if (fuse && fuse->in_mode) {
+            // fused input normalisation: pointwise (in_mode 1, 2, 3) or tap-major plain (in_mode 1) geometry, split-fp16
+            if (!(pw || (tm && plain && fuse->in_mode == 1)) || a.splits != 1) {
+                zs::set_err("zs_conv2d_nhwc_fused: in_mode %d needs a pointwise layer (or, for in_mode 1, Cin %% 8 == 0)", fuse->in_mode);
+                return 0;
+            }
+#define ZS_LAUNCH_XF(NJ_, XF_)                                                                                                 \
+    do {                                                                                                                       \
+        if (pw) hipLaunchKernelGGL((conv_gemm_small_kernel<NJ_, true, 0, false, true, XF_>), grid, dim3(256), 0, st, a);          \
+        else hipLaunchKernelGGL((conv_gemm_small_kernel<NJ_, false, 2, true, true, (XF_ == 1 ? 1 : 0)>), grid, dim3(256), 0, st, a); \
+    } while (0)
+            const dim3 grid((unsigned)((M + SM - 1) / SM), (unsigned)((Cout + (narrow ? 31 : 63)) / (narrow ? 32 : 64)), 1);
+            if (narrow) {
+                if (fuse->in_mode == 1) ZS_LAUNCH_XF(1, 1); else ZS_LAUNCH_XF(1, 2);
+            } else {
+                if (fuse->in_mode == 1) ZS_LAUNCH_XF(2, 1); else ZS_LAUNCH_XF(2, 2);
+            }
+#undef ZS_LAUNCH_XF
+        } else if (narrow) {
             const dim3 grid((unsigned)((M + SM - 1) / SM), (unsigned)((Cout + 31) / 32), (unsigned)a.splits);
             ZS_LAUNCH(conv_gemm_small_kernel, 1,);
         } else {
@@ -1522,6 +1770,8 @@ extern "C" int zs_conv3x3_tail_nhwc(const float *in, const float *packed_w, cons
     if (M > (1LL << 30)) { zs::set_err("zs_conv3x3_tail_nhwc: %lld output pixels", M); return 0; }
     ConvArgs a;
     a.slab_major = 0;
+    memset(&a.fz, 0, sizeof a.fz);
+    a.fz_tiles_per_sample = 0;
     a.in = in; a.w = packed_w; a.scale = scale; a.shift = shift; a.res1 = nullptr; a.res2 = nullptr; a.out = out;
     const bool up2 = (flags & ZS_CONV_IN_UPSAMPLE2) != 0;
     a.B = batch; a.Hin = up2 ? H / 2 : H; a.Win = up2 ? W / 2 : W; a.Cin = Cin; a.Hout = H; a.Wout = W; a.Cout = Cout;

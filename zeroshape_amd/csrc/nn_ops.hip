@@ -598,6 +598,70 @@ inline hipStream_t S(void *s) { return static_cast<hipStream_t>(s); }
 
 }  // namespace
 
+// ---- GroupNorm from statistics a convolution's epilogue already wrote (zs_conv_fuse.out_mode 1): ONE pass ----
+// Every workgroup turns the per-tile group sums of its sample into (mean, rstd) itself (a few KB, the same fixed-order
+// sum everywhere), then streams its share of the tensor: y = [relu](x * sc_c + sh_c + r [* ru_c]).
+__global__ __launch_bounds__(256) void gn_apply_stats_kernel(const float *__restrict__ x, const float *__restrict__ stats, int tiles,
+                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                             const float *__restrict__ res, const float *__restrict__ rstats, int rtiles,
+                                                             const float *__restrict__ rgamma, const float *__restrict__ rbeta,
+                                                             float *__restrict__ y, int HW, int C, int gshift, float eps, int relu,
+                                                             int blocks_per_sample) {
+    __shared__ float red[8][32][2], stat[2][32][2];
+    const int tid = threadIdx.x, sample = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
+    const double cnt = (double)HW * (double)(1 << gshift);
+    for (int which = 0; which < (rstats ? 2 : 1); which++) {
+        const float *st = which ? rstats : stats;
+        const int nt = which ? rtiles : tiles, g = tid & 31, slice = tid >> 5;
+        float S = 0.f, Q = 0.f;
+        for (int tl = slice; tl < nt; tl += 8) {
+            const float2 e = *reinterpret_cast<const float2 *>(st + ((size_t)(sample * nt + tl) * 32 + g) * 2);
+            S += e.x;
+            Q += e.y;
+        }
+        red[slice][g][0] = S;
+        red[slice][g][1] = Q;
+        __syncthreads();
+        if (tid < 32) {
+            double s2 = 0.0, q2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { s2 += (double)red[k][tid][0]; q2 += (double)red[k][tid][1]; }
+            const double mean = s2 / cnt, var = fmax(q2 / cnt - mean * mean, 0.0);
+            stat[which][tid][0] = (float)mean;
+            stat[which][tid][1] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+        __syncthreads();
+    }
+    const int cq = C >> 2;                                      // channel quads per pixel
+    const size_t total = (size_t)HW * cq, per = (total + blocks_per_sample - 1) / blocks_per_sample;
+    const size_t lo = (size_t)blk * per, hi = lo + per < total ? lo + per : total;
+    const f32x4 *xs = reinterpret_cast<const f32x4 *>(x) + (size_t)sample * total;
+    const f32x4 *rs = res ? reinterpret_cast<const f32x4 *>(res) + (size_t)sample * total : nullptr;
+    f32x4 *ys = reinterpret_cast<f32x4 *>(y) + (size_t)sample * total;
+    for (size_t i = lo + tid; i < hi; i += 256) {
+        const int c = (int)(i % cq) * 4, g = c >> gshift;            // a quad lies inside one group (>= 4 channels per group) ...
+        f32x4 v = xs[i];
+        const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + c), be = *reinterpret_cast<const f32x4 *>(beta + c);
+        f32x4 r = {0.f, 0.f, 0.f, 0.f}, rg = {1.f, 1.f, 1.f, 1.f}, rb = {0.f, 0.f, 0.f, 0.f};
+        if (rs) r = rs[i];
+        if (rstats) { rg = *reinterpret_cast<const f32x4 *>(rgamma + c); rb = *reinterpret_cast<const f32x4 *>(rbeta + c); }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int ge = gshift >= 2 ? g : (c + e) >> gshift;      // ... or two groups per quad (2 channels per group)
+            const float sc = ga[e] * stat[0][ge][1];
+            float o = v[e] * sc + (be[e] - stat[0][ge][0] * sc);
+            if (rstats) {
+                const float rsc = rg[e] * stat[1][ge][1];
+                o += r[e] * rsc + (rb[e] - stat[1][ge][0] * rsc);
+            } else {
+                o += r[e];
+            }
+            v[e] = relu ? fmaxf(o, 0.f) : o;
+        }
+        ys[i] = v;
+    }
+}
+
 #define ZS_REQUIRE(cond, ...)            \
     do {                                 \
         if (!(cond)) {                   \
@@ -675,6 +739,25 @@ extern "C" int zs_group_norm_nhwc(const float *x, const float *gamma, const floa
     else { if (cache) ZS_GN_LAUNCH(1, true); else ZS_GN_LAUNCH(1, false); }
 #undef ZS_GN_LAUNCH
     return zs::check_launch("zs_group_norm_nhwc") ? 1 : 0;
+}
+
+extern "C" int zs_group_norm_apply_stats(const float *x, const float *stats, int tiles, const float *gamma, const float *beta,
+                                         const float *residual, const float *res_stats, int res_tiles, const float *res_gamma,
+                                         const float *res_beta, float *y, int batch, int HW, int C, float eps, int relu,
+                                         void *stream) {
+    int gshift = 0;
+    while ((32 << gshift) < C) gshift++;
+    ZS_REQUIRE(batch >= 0 && HW > 0 && C >= 64 && (32 << gshift) == C && tiles > 0,
+               "zs_group_norm_apply_stats: bad size (B=%d HW=%d C=%d tiles=%d; C = 32 * 2^k >= 64)", batch, HW, C, tiles);
+    if (batch == 0) return 1;
+    ZS_REQUIRE(x && stats && gamma && beta && y, "zs_group_norm_apply_stats: null pointer");
+    ZS_REQUIRE(!res_stats || (residual && res_gamma && res_beta && res_tiles > 0), "zs_group_norm_apply_stats: residual statistics need residual, gamma, beta, tiles");
+    const size_t quads = (size_t)HW * (C >> 2);
+    int bps = (int)((quads + 1023) / 1024);                     // ~4 quads per thread
+    if (bps > 1024) bps = 1024;
+    hipLaunchKernelGGL(gn_apply_stats_kernel, dim3((unsigned)(batch * bps)), dim3(256), 0, S(stream), x, stats, tiles, gamma, beta,
+                       residual, res_stats, res_tiles, res_gamma, res_beta, y, HW, C, gshift, eps, relu, bps);
+    return zs::check_launch("zs_group_norm_apply_stats") ? 1 : 0;
 }
 
 extern "C" int zs_layer_norm(const float *x, const float *gamma, const float *beta, float *y, int rows, int C,

@@ -20,6 +20,8 @@ import torch.nn as nn
 
 from ...nn import autograd as A
 from ...nn import blocks, ops, pack, train_blocks
+from ...nn import branch
+from ...nn.branch import Branch
 from ...nn.module import HipModule
 from ...utils import camera
 from ...utils.loss import Loss
@@ -56,9 +58,12 @@ class _IntrHead(HipModule):
                     proj=pack.pack_conv(sd["intr_proj.weight"], sd["intr_proj.bias"]).to(device))
 
     def run(self, feat_nchw):
+        return self.run_nhwc(ops.to_nhwc(feat_nchw))
+
+    def run_nhwc(self, x):
+        """x [B,h,w,768] channels-last (DPT's tap-4 feature as the layers hold it)."""
         self.training = self._graph.intr_head.training        # not a submodule: follow the owner's mode
-        pk = self.packed(feat_nchw.device)
-        x = ops.to_nhwc(feat_nchw)
+        pk = self.packed(x.device)
         x = blocks.run_bottleneck_conv(blocks.run_bottleneck_conv(x, pk["b0"]), pk["b1"])
         pooled = ops.global_mean(x)                                            # [B,768]
         return ops.linear(pooled, pk["proj"])                                  # [B,3]
@@ -142,8 +147,15 @@ class Graph(nn.Module):
         resnet = opt.arch.depth.encoder == 'resnet'
 
         def run(rgb, mask):
-            depth_pred, intr_feat = self.dpt_depth(rgb, get_feat=True)
-            intr_pred = self.intr_param2mtx(opt, self._intr.run(intr_feat))
+            # the intrinsics head needs the tap-4 feature only: it runs beside DPT's fusion blocks (nn/branch.py)
+            intr = {}
+
+            def intr_branch(layer_4):
+                intr["br"] = Branch(layer_4, kind=branch.INTR)
+                with intr["br"]:
+                    intr["pred"] = self.intr_param2mtx(opt, self._intr.run_nhwc(layer_4))
+            depth_pred = self.dpt_depth(rgb, on_feat=intr_branch)
+            intr_pred = intr["br"].join(intr["pred"])
             # :131-144 in one launch
             seen_points, seen_3D_dsp, mask_dsp, _, _ = camera.seen_surface(opt, depth_pred, intr_pred, mask, dsp=dsp)
             if resnet:

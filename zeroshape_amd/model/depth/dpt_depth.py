@@ -24,6 +24,8 @@ import torch.nn.functional as F
 
 from ...nn import autograd as A
 from ...nn import blocks, ops, pack, train_blocks
+from ...nn import branch
+from ...nn.branch import Branch
 from ...nn.module import HipModule
 
 
@@ -205,10 +207,11 @@ class DPTDepthModel(HipModule):
         return pk["pos"][(gh, gw)]
 
     # ---- forward ----
-    def forward(self, image, get_feat=False, taps=None):
+    def forward(self, image, get_feat=False, taps=None, on_feat=None):
         """image [B,3,H,W] in [0,1] -> depth [B,1,H,W] in [0,1] (and the tap-4 feature
         [B,768,H/32,W/32] with get_feat), dpt_depth.py:115-122.  `taps` (a dict, tests only)
-        receives channels-last intermediates."""
+        receives channels-last intermediates; `on_feat` (inference only) is called with the channels-last
+        tap-4 feature as soon as it is queued."""
         self._need_gpu(image, "image")
         B, C, H, W = image.shape
         if C != 3 or H % 32 or W % 32:
@@ -217,7 +220,7 @@ class DPTDepthModel(HipModule):
             depth, layer_4 = self.forward_train(image, taps)
             return (depth, A.to_nchw(layer_4)) if get_feat else depth
         with torch.no_grad():
-            return self._forward_eval(image, get_feat, taps)
+            return self._forward_eval(image, get_feat, taps, on_feat)
 
     def forward_train(self, image, taps=None):
         """Autograd path: -> (depth [B,1,H,W], layer_4 channels-last [B,H/32,W/32,768])."""
@@ -262,34 +265,54 @@ class DPTDepthModel(HipModule):
         o = A.conv2d(o, oc[4].weight, oc[4].bias, act=A.ACT_RELU_CLAMP1)        # [B,H,W,1]
         return o.view(B, 1, H, W), layer_4
 
-    def _forward_eval(self, image, get_feat=False, taps=None):
+    def _forward_eval(self, image, get_feat=False, taps=None, on_feat=None):
         B, C, H, W = image.shape
         pk = self.packed(image.device)
         gh, gw = H // 16, W // 16
         x = ops.to_nhwc(image, cpad=4)
-        s0, s1, s2 = blocks.run_resnetv2(x, pk["backbone"], in_scale=2.0, in_shift=-1.0)
         record = (lambda **kw: taps.update(kw)) if taps is not None else (lambda **kw: None)
+        rn, heads, brs = [None] * 4, [None] * 4, [None] * 4
+
+        def skip_branch(i, src, fn):
+            """layerK_rn (+ the first convolution of refinenetK's skip unit) of tap i on a side branch: they depend on the
+            tap only and are needed much later (nn/branch.py)."""
+            brs[i] = Branch(src, kind=branch.SKIP)
+            with brs[i]:
+                rn[i] = ops.conv2d(fn(src), pk["rn"][i])
+                if i < 3:                                        # refinenet4 has no skip unit
+                    heads[i] = blocks.run_rcu_head(rn[i], pk["fusion"][i]["r1"])
+
+        def on_stage(si, feat):
+            if si < 2:
+                skip_branch(si, feat, lambda t: t)
+        s0, s1, s2 = blocks.run_resnetv2(x, pk["backbone"], in_scale=2.0, in_shift=-1.0, on_stage=on_stage)
         record(stage0=s0, stage1=s1, stage2=s2)
         feat = ops.conv2d(s2, pk["proj"]).view(B, gh * gw, 768)
         tok = ops.assemble_tokens(feat, pk["cls"], self._pos_embed(pk, gh, gw))
-        hooked = {}
-        for i, blk in enumerate(pk["blocks"]):
-            tok = blocks.run_vit_block(tok, blk, 12)
-            if i in (0, 8, 11):
-                hooked[i] = tok
-        record(block0=hooked[0], block8=hooked[8], block11=hooked[11])
 
         def reassemble(t, ro, pp):
             r = ops.linear(ops.readout_concat(t), ro, act=ops.ACT_GELU)          # [B, gh*gw, 768]
             return ops.conv2d(r.view(B, gh, gw, 768), pp)
-        layer_3 = reassemble(hooked[8], pk["ro3"], pk["pp3"])
+        hooked, st = {}, None
+        for i, blk in enumerate(pk["blocks"]):
+            tok, st = blocks.run_vit_block(tok, blk, 12, stats=st, want_stats=True)
+            if i in (0, 8, 11):
+                hooked[i] = tok
+            if i == 8:                                           # tap 3's reassemble branch beside ViT blocks 9-11
+                skip_branch(2, tok, lambda t: reassemble(t, pk["ro3"], pk["pp3"]))
+        record(block0=hooked[0], block8=hooked[8], block11=hooked[11])
         layer_4 = ops.conv2d(reassemble(hooked[11], pk["ro4"], pk["pp4"]), pk["pp4s"])
-        rn = [ops.conv2d(l, p) for l, p in zip((s0, s1, layer_3, layer_4), pk["rn"])]
-        record(layer3_rn=rn[2], layer4_rn=rn[3])
+        if on_feat is not None:            # eval only: the caller forks work on the channels-last tap-4 feature (graph_shape.encode)
+            on_feat(layer_4)
+        rn[3] = ops.conv2d(layer_4, pk["rn"][3])
         path4 = blocks.run_fusion(rn[3], pk["fusion"][3])
-        path3 = blocks.run_fusion(path4, pk["fusion"][2], rn[2])
-        path2 = blocks.run_fusion(path3, pk["fusion"][1], rn[1])
-        path = blocks.run_fusion(path2, pk["fusion"][0], rn[0])
+        rn[2], heads[2] = brs[2].join(rn[2], heads[2])
+        record(layer3_rn=rn[2], layer4_rn=rn[3])
+        path3 = blocks.run_fusion(path4, pk["fusion"][2], rn[2], heads[2])
+        rn[1], heads[1] = brs[1].join(rn[1], heads[1])
+        path2 = blocks.run_fusion(path3, pk["fusion"][1], rn[1], heads[1])
+        rn[0], heads[0] = brs[0].join(rn[0], heads[0])
+        path = blocks.run_fusion(path2, pk["fusion"][0], rn[0], heads[0])
         record(path4=path4, path3=path3, path2=path2, path1=path)
         o = ops.conv2d_tail(ops.conv2d(path, pk["head0"]), pk["head2"], pk["head4"], act=ops.ACT_RELU,
                             tail_act=ops.ACT_RELU_CLAMP1, upsample=True)                                   # [B,H,W,1]

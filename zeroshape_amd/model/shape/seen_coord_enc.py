@@ -9,6 +9,8 @@ import torch.nn as nn
 
 from ...nn import autograd as A
 from ...nn import blocks, ops, pack, train_blocks
+from ...nn import branch
+from ...nn.branch import Branch
 from ...nn.module import HipModule
 from ...utils.layers import Bottleneck_Conv
 from ...utils.pos_embed import get_2d_sincos_pos_embed
@@ -104,12 +106,23 @@ class CoordEncRes(HipModule):
         B = coord_obj.shape[0]
         pk = self.packed(coord_obj.device)
         x = ops.to_nhwc(coord_obj, cpad=4, mask=mask_obj)                       # coord * mask (:184)
-        feats = blocks.run_resnet50(x, pk["trunk"])
+        side = {}
+
+        def on_layer(li, feat):            # depth_feat_proj needs only its tap: beside the remaining layers and the fc head
+            if li == self.tap and li < 3:
+                side["br"] = Branch(feat, kind=branch.PROJ)
+                with side["br"]:
+                    loc = blocks.run_bottleneck_conv(blocks.run_bottleneck_conv(feat, pk["p0"]), pk["p1"])
+                    side["loc"] = ops.conv2d(loc, pk["p2"])
+        feats = blocks.run_resnet50(x, pk["trunk"], on_layer=on_layer)
         g = ops.global_mean(feats[3]).view(B, 1, 1, -1)                        # avgpool + flatten
         g = blocks.run_bottleneck_conv(blocks.run_bottleneck_conv(g, pk["fc0"]), pk["fc1"])
         g = ops.conv2d(g, pk["fc2"]).view(B, 1, -1)
-        loc = blocks.run_bottleneck_conv(blocks.run_bottleneck_conv(feats[self.tap], pk["p0"]), pk["p1"])
-        loc = ops.conv2d(loc, pk["p2"])
+        if "br" in side:
+            loc = side["br"].join(side["loc"])
+        else:
+            loc = blocks.run_bottleneck_conv(blocks.run_bottleneck_conv(feats[self.tap], pk["p0"]), pk["p1"])
+            loc = ops.conv2d(loc, pk["p2"])
         return torch.cat([g, loc.view(B, -1, loc.shape[-1])], dim=1)
 
 

@@ -12,16 +12,21 @@ class CapturedCall:
     """fn(*tensors) -> tensor | tuple of tensors, captured for the shapes of `example_inputs`."""
 
     def __init__(self, fn, example_inputs, warmup=2):
+        from . import branch
         self.static_in = [t.detach().clone() for t in example_inputs]
-        side = torch.cuda.Stream(device=self.static_in[0].device)
-        side.wait_stream(torch.cuda.current_stream(self.static_in[0].device))
+        dev = self.static_in[0].device
+        branch.warm(dev)
+        # warm-up and capture run on the SAME stream: the per-stream scratch buffers of nn/ops.py (and the side streams of
+        # nn/branch.py) are created by the warm-up and found again by the capture
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):                       # packs weights, primes caches
             for _ in range(warmup):
                 fn(*self.static_in)
-        torch.cuda.current_stream(self.static_in[0].device).wait_stream(side)
-        torch.cuda.synchronize(self.static_in[0].device)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=side):
             self.static_out = fn(*self.static_in)
 
     def __call__(self, *inputs):

@@ -1,5 +1,6 @@
 """Launch wrappers for the encoder layers (include/zeroshape_hip.h, "Encoder layers").
 Tensors are fp32 channels-last GPU tensors [B,H,W,C]; token matrices are [B,L,C]."""
+import ctypes
 import os
 
 import torch
@@ -55,12 +56,18 @@ def set_conv_precision(p):
 _SPLITK_WS = {}
 
 
+def _stream_key(device):
+    """(device, stream the next launch goes to): the scratch buffers below are per stream (two streams
+    running convolutions on one device would race on shared partial tiles; nn/branch.py does run two)."""
+    return (str(device), torch._C._cuda_getCurrentRawStream(device.index if device.index is not None
+                                                             else torch.cuda.current_device()))
+
+
 def splitk_workspace(device):
-    """Per-device scratch of zs_conv2d_nhwc_ws: arrival counters (zeroed here once, left at zero by every launch)
-    + partial tiles.  Fixed size and address: a captured hipGraph bakes the pointer in (the warm-up runs of
-    nn.capture allocate it before the capture starts).  Launches on one stream serialise, so sharing it is safe;
-    two streams running convolutions on one device at the same time would need one each."""
-    key = str(device)
+    """Per-(device, stream) scratch of zs_conv2d_nhwc_ws: arrival counters (zeroed here once, left at zero by every
+    launch) + partial tiles.  Fixed size and address: a captured hipGraph bakes the pointer in (the warm-up runs of
+    nn.capture allocate it before the capture starts).  Launches on one stream serialise, so sharing it is safe."""
+    key = _stream_key(device)
     if key not in _SPLITK_WS:
         _SPLITK_WS[key] = torch.zeros(_lib.load().zs_conv2d_splitk_workspace_bytes() // 4, dtype=torch.float32,
                                       device=device)
@@ -72,9 +79,33 @@ def conv_flags():
         (_CONV_STREAM_K if STREAM_K else 0) | (_CONV_STREAM_K_ALWAYS if STREAM_K == "always" else 0)
 
 
-def conv2d(x, pc, res1=None, res2=None, act=ACT_NONE, in_relu=False, in_scale=1.0, in_shift=0.0, tiling=None):
+class Stats:
+    """Statistics a fused launch wrote beside its output (zs_conv_fuse.out_mode): `group` = [row tiles][groups][2] (sum, sum of
+    squares) per 32-row tile, `row` = [M][column tiles][2] (sum, M2) per row; consumed by the next launch's in_mode."""
+
+    def __init__(self, kind, data, tiles, groups=0):
+        self.kind, self.data, self.tiles, self.groups = kind, data, tiles, groups
+
+
+def fused_ok(x, pc=None):
+    """The fused-normalisation launches (zs_conv2d_nhwc_fused) serve the split-fp16 inference engine when statistics tiles
+    do not straddle samples: batch 1, or maps of a multiple of 32 pixels.  ZS_CONV_FUSE_NORM=0 disables them (A/B)."""
+    B, H, W = x.shape[0], x.shape[1], x.shape[2]
+    return FUSE_NORM and CONV_PRECISION == "f16x3" and PRESPLIT and (B == 1 or (H * W) % 32 == 0)
+
+
+FUSE_NORM = os.environ.get("ZS_CONV_FUSE_NORM", "1") != "0"
+
+
+def conv2d(x, pc, res1=None, res2=None, act=ACT_NONE, in_relu=False, in_scale=1.0, in_shift=0.0, tiling=None,
+           gn_in=None, ln_in=None, stats_out=None, out_groups=32):
     """x [B,H,W,Cin] -> [B,Ho,Wo,Cout] with the fused epilogue of zs_conv2d_nhwc.  `tiling`
-    ("large" / "small") overrides the size-based choice of kernel variant (tests, tuning)."""
+    ("large" / "small") overrides the size-based choice of kernel variant (tests, tuning).
+
+    Fused normalisations (zs_conv2d_nhwc_fused; the caller checks fused_ok):
+      gn_in = (Stats 'group' of x, gamma, beta, eps): the layer runs on relu(GroupNorm(x));
+      ln_in = (Stats 'row' of x, eps): the layer runs on (x - mean) * rstd per row (gamma / beta folded into pc);
+      stats_out = 'group' | 'row': returns (out, Stats of out)."""
     lib = _lib.load()
     _chk(x, "conv2d input")
     B, H, W, C = x.shape
@@ -95,14 +126,48 @@ def conv2d(x, pc, res1=None, res2=None, act=ACT_NONE, in_relu=False, in_scale=1.
                 _lib.check(lib.zs_conv2d_presplit_weight(_lib.ptr(pc.w), _lib.ptr(pc.w16), C, pc.cout, pc.kh, pc.kw,
                                                          _stream(x)), "zs_conv2d_presplit_weight")
         w, flags = pc.w16, flags | _CONV_W_PRESPLIT
+    fused = gn_in is not None or ln_in is not None or stats_out is not None
+    if not fused:
+        with _lib.on(x.device):
+            _lib.check(lib.zs_conv2d_nhwc_ws(_lib.ptr(x), _lib.ptr(w), _lib.ptr(pc.scale), _lib.ptr(pc.shift),
+                                             _lib.ptr(res1), _lib.ptr(res2), _lib.ptr(out), B, H, W, C, Ho, Wo, pc.cout,
+                                             pc.kh, pc.kw, pc.stride, pt, pl,
+                                             flags, float(in_scale), float(in_shift), act,
+                                             _lib.ptr(splitk_workspace(x.device)), _stream(x)),
+                       "zs_conv2d_nhwc_ws")
+        return out
+    assert CONV_PRECISION == "f16x3" and PRESPLIT and not in_relu, "fused normalisations: split-fp16 inference engine only"
+    fz = _lib.ConvFuse()
+    st_out = None
+    if gn_in is not None:
+        st, gamma, beta, eps = gn_in
+        assert st.kind == "group" and st.groups == 32
+        fz.in_mode, fz.in_tiles, fz.in_groups, fz.in_eps = 1, st.tiles, 32, float(eps)
+        fz.in_stats, fz.in_gamma, fz.in_beta = st.data.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+    elif ln_in is not None:
+        st, eps = ln_in
+        assert st.kind == "row"
+        fz.in_mode, fz.in_tiles, fz.in_eps, fz.in_stats = 2, st.tiles, float(eps), st.data.data_ptr()
+    M = B * Ho * Wo
+    if stats_out == "group":
+        tiles = (M + 31) // 32
+        data = torch.empty(tiles, out_groups, 2, dtype=torch.float32, device=x.device)
+        fz.out_mode, fz.out_groups, fz.out_stats = 1, out_groups, data.data_ptr()
+        st_out = Stats("group", data, tiles // B, out_groups)
+    elif stats_out == "row":
+        cols = lib.zs_conv2d_fused_cols(M, pc.cout)
+        tiles = (pc.cout + cols - 1) // cols
+        data = torch.empty(M, tiles, 2, dtype=torch.float32, device=x.device)
+        fz.out_mode, fz.out_stats = 2, data.data_ptr()
+        st_out = Stats("row", data, tiles)
     with _lib.on(x.device):
-        _lib.check(lib.zs_conv2d_nhwc_ws(_lib.ptr(x), _lib.ptr(w), _lib.ptr(pc.scale), _lib.ptr(pc.shift),
-                                         _lib.ptr(res1), _lib.ptr(res2), _lib.ptr(out), B, H, W, C, Ho, Wo, pc.cout,
-                                         pc.kh, pc.kw, pc.stride, pt, pl,
-                                         flags, float(in_scale), float(in_shift), act,
-                                         _lib.ptr(splitk_workspace(x.device)), _stream(x)),
-                   "zs_conv2d_nhwc_ws")
-    return out
+        _lib.check(lib.zs_conv2d_nhwc_fused(_lib.ptr(x), _lib.ptr(w), _lib.ptr(pc.scale), _lib.ptr(pc.shift),
+                                            _lib.ptr(res1), _lib.ptr(res2), _lib.ptr(out), B, H, W, C, Ho, Wo, pc.cout,
+                                            pc.kh, pc.kw, pc.stride, pt, pl, flags & ~_CONV_SPLIT_SMALL, float(in_scale),
+                                            float(in_shift), act, ctypes.addressof(fz),
+                                            _lib.ptr(splitk_workspace(x.device)), _stream(x)),
+                   "zs_conv2d_nhwc_fused")
+    return out if st_out is None else (out, st_out)
 
 
 # DPT's depth head ends in Conv 3x3 (128 -> 32) + ReLU + Conv 1x1 (32 -> 1) + ReLU: zs_conv3x3_tail_nhwc runs both as one
@@ -154,14 +219,17 @@ def conv2d_tail(x, pc, pc_tail, act=ACT_NONE, tail_act=ACT_NONE, in_relu=False, 
     return out
 
 
-def linear(x, pc, res1=None, act=ACT_NONE):
-    """x [..., Cin] -> [..., Cout] through the same GEMM (1x1 geometry)."""
+def linear(x, pc, res1=None, act=ACT_NONE, ln_in=None, stats_out=None):
+    """x [..., Cin] -> [..., Cout] through the same GEMM (1x1 geometry).  ln_in / stats_out: see conv2d (rows = tokens);
+    with stats_out the result is (y, Stats)."""
     lead = x.shape[:-1]
     n = 1
     for d in lead:
         n *= d
     y = conv2d(x.reshape(1, 1, n, x.shape[-1]), pc,
-               res1=None if res1 is None else res1.reshape(1, 1, n, pc.cout), act=act)
+               res1=None if res1 is None else res1.reshape(1, 1, n, pc.cout), act=act, ln_in=ln_in, stats_out=stats_out)
+    if stats_out is not None:
+        return y[0].view(*lead, pc.cout), y[1]
     return y.view(*lead, pc.cout)
 
 
@@ -171,7 +239,7 @@ _GN_WS = {}
 def _group_norm_workspace(device, nbytes):
     """Per-device scratch of zs_group_norm_nhwc_ws (group sums per pixel chunk; grown on demand, address stable
     between growths: a captured hipGraph bakes the pointer in, and nn.capture's warm-up runs size it first)."""
-    key = str(device)
+    key = _stream_key(device)
     if key not in _GN_WS or _GN_WS[key].numel() * 8 < nbytes:
         _GN_WS[key] = torch.empty(max(nbytes // 8, 1 << 16), dtype=torch.float64, device=device)
     return _GN_WS[key]
@@ -189,6 +257,26 @@ def group_norm(x, gamma, beta, groups=32, eps=1e-5, relu=False, residual=None):
         _lib.check(lib.zs_group_norm_nhwc_ws(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(residual),
                                              _lib.ptr(y), B, H * W, C, groups, float(eps), 1 if relu else 0,
                                              _lib.ptr(ws), _stream(x)), "zs_group_norm_nhwc")
+    return y
+
+
+def group_norm_apply(x, st, gamma, beta, eps=1e-5, relu=False, residual=None, res_gn=None):
+    """GroupNorm(32) of x from the Stats 'group' a fused convolution wrote beside it, one pass: [relu](GN(x) + r) with
+    r = residual, or GroupNorm(residual) when res_gn = (Stats, gamma, beta) (zs_group_norm_apply_stats)."""
+    lib = _lib.load()
+    _chk(x, "group_norm_apply input")
+    B, H, W, C = x.shape
+    y = torch.empty_like(x)
+    rst = rg = rb = None
+    rt = 0
+    if res_gn is not None:
+        rst, rg, rb = res_gn[0].data, res_gn[1], res_gn[2]
+        rt = res_gn[0].tiles
+    with _lib.on(x.device):
+        _lib.check(lib.zs_group_norm_apply_stats(_lib.ptr(x), _lib.ptr(st.data), st.tiles, _lib.ptr(gamma), _lib.ptr(beta),
+                                                 _lib.ptr(residual), _lib.ptr(rst), rt, _lib.ptr(rg), _lib.ptr(rb), _lib.ptr(y),
+                                                 B, H * W, C, float(eps), 1 if relu else 0, _stream(x)),
+                   "zs_group_norm_apply_stats")
     return y
 
 
