@@ -20,7 +20,11 @@ SHAPES = [(128, 32, 224, 224, 3, 1, False, False), (256, 256, 56, 56, 3, 1, True
           (256, 256, 28, 28, 3, 1, True, False), (64, 64, 56, 56, 3, 1, False, True), (256, 256, 14, 14, 3, 1, False, True),
           (768, 768, 7, 7, 3, 1, False, False), (768, 3072, 1, 197, 1, 1, False, False), (3072, 768, 1, 197, 1, 1, False, True),
           (768, 2304, 1, 197, 1, 1, False, False), (64, 256, 56, 56, 1, 1, False, True), (1024, 256, 14, 14, 1, 1, False, False),
-          (256, 1024, 14, 14, 1, 1, False, True), (512, 128, 28, 28, 1, 1, False, False)]
+          (256, 1024, 14, 14, 1, 1, False, True), (512, 128, 28, 28, 1, 1, False, False),
+          # batch-1 shapes of the streaming kernel (nn_conv_stream.h): 7 x 7 maps, the one-pixel fc head, stride 2, readout
+          (768, 768, 14, 14, 3, 2, False, False), (512, 512, 7, 7, 3, 1, False, False), (2048, 512, 7, 7, 1, 1, False, False),
+          (512, 2048, 7, 7, 1, 1, False, True), (2048, 2048, 1, 1, 1, 1, False, False), (1536, 768, 1, 196, 1, 1, False, False),
+          (1024, 768, 14, 14, 1, 1, False, False), (768, 256, 14, 14, 3, 1, False, False), (1024, 1024, 14, 14, 1, 1, False, True)]
 
 
 def main():

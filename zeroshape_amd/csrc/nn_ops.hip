@@ -465,6 +465,129 @@ __global__ __launch_bounds__(64) void attention_split_kernel(const float *__rest
     }
 }
 
+// ---- few sequences (batch 1): the key tiles of one (sample, head, 32-query tile) spread over the waves of a workgroup ----
+// attention_split_kernel walks its key tiles one after the other, each a dependent pair of load round trips (K, then V):
+// 7 tiles at L = 197 = 21 us for 84 waves on 256 CUs.  Here every wave takes the key tiles kt = wave, wave + KW, ... (one
+// each at L <= 256), so all K / V loads of the workgroup are in flight at once; the partial (max, sum, O) triples are merged
+// through LDS in wave order (the flash-decoding merge: the same sums in another association, ~1e-7 relative).
+constexpr int ATT_KW = 8;                      // waves per workgroup
+template <int D>
+__global__ __launch_bounds__(64 * ATT_KW) void attention_split_kw_kernel(const float *__restrict__ qkv, float *__restrict__ out, int L,
+                                                                         int heads, float scale) {
+    using zs::s16::mfma3;
+    using zs::s16::split8;
+    constexpr int DS = D / 16, DT = D / 32, PADD = D + 4;
+    __shared__ __attribute__((aligned(16))) float opart[ATT_KW][32][PADD];
+    __shared__ float mpart[ATT_KW][32], dpart[ATT_KW][32];
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads, C = heads * D, q0 = blockIdx.y * 32;
+    const float *base = qkv + (size_t)b * L * 3 * C + h * D;
+    const int qrow = min(q0 + l32, L - 1);
+    u32x4 qh[DS], ql[DS];
+#pragma unroll
+    for (int t = 0; t < DS; t++) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(base + (size_t)qrow * 3 * C + 4 * (4 * t + half)) * scale;
+        const f32x4 a1 = *reinterpret_cast<const f32x4 *>(base + (size_t)qrow * 3 * C + 4 * (4 * t + 2 + half)) * scale;
+        split8(a0, a1, qh[t], ql[t]);
+    }
+    f32x16 o[DT];
+#pragma unroll
+    for (int i = 0; i < DT; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[i][r] = 0.f;
+    float mx = -INFINITY, den = 0.f;
+    for (int k0 = 32 * wave; k0 < L; k0 += 32 * ATT_KW) {
+        const int krow = min(k0 + l32, L - 1);
+        // all of this tile's loads first (K rows as quads, V columns as the accumulator's keys), then the arithmetic
+        f32x4 kq[DS][2];
+#pragma unroll
+        for (int t = 0; t < DS; t++) {
+            kq[t][0] = *reinterpret_cast<const f32x4 *>(base + (size_t)krow * 3 * C + C + 4 * (4 * t + half));
+            kq[t][1] = *reinterpret_cast<const f32x4 *>(base + (size_t)krow * 3 * C + C + 4 * (4 * t + 2 + half));
+        }
+        float vf[DT][16];
+#pragma unroll
+        for (int i = 0; i < DT; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int key = min(k0 + 8 * (r >> 2) + 4 * half + (r & 3), L - 1);
+                vf[i][r] = base[(size_t)key * 3 * C + 2 * C + 32 * i + l32];
+            }
+        f32x16 sT;
+#pragma unroll
+        for (int r = 0; r < 16; r++) sT[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < DS; t++) {
+            u32x4 kh, kl;
+            split8(kq[t][0], kq[t][1], kh, kl);
+            mfma3(sT, kh, kl, qh[t], ql[t]);
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int key = k0 + 8 * (r >> 2) + 4 * half + (r & 3);
+            sT[r] = key < L ? sT[r] : -INFINITY;
+            tmax = fmaxf(tmax, sT[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float nm = fmaxf(mx, tmax), corr = __expf(mx - nm);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            sT[r] = __expf(sT[r] - nm);
+            psum += sT[r];
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        den = den * corr + psum;
+        mx = nm;
+        u32x4 ph[2], pl[2];
+#pragma unroll
+        for (int sidx = 0; sidx < 2; sidx++)
+            split8(f32x4{sT[8 * sidx], sT[8 * sidx + 1], sT[8 * sidx + 2], sT[8 * sidx + 3]},
+                   f32x4{sT[8 * sidx + 4], sT[8 * sidx + 5], sT[8 * sidx + 6], sT[8 * sidx + 7]}, ph[sidx], pl[sidx]);
+#pragma unroll
+        for (int i = 0; i < DT; i++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[i][r] *= corr;
+#pragma unroll
+            for (int sidx = 0; sidx < 2; sidx++) {
+                u32x4 vh, vl;
+                split8(f32x4{vf[i][8 * sidx], vf[i][8 * sidx + 1], vf[i][8 * sidx + 2], vf[i][8 * sidx + 3]},
+                       f32x4{vf[i][8 * sidx + 4], vf[i][8 * sidx + 5], vf[i][8 * sidx + 6], vf[i][8 * sidx + 7]}, vh, vl);
+                mfma3(o[i], vh, vl, ph[sidx], pl[sidx]);
+            }
+        }
+    }
+    // partial (max, sum, O^T) of this wave's keys -> LDS: register 4 g + e of lane (query l32, half) = d 32 i + 8 g + 4 half + e
+#pragma unroll
+    for (int i = 0; i < DT; i++)
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            *reinterpret_cast<f32x4 *>(&opart[wave][l32][32 * i + 8 * g + 4 * half]) =
+                f32x4{o[i][4 * g], o[i][4 * g + 1], o[i][4 * g + 2], o[i][4 * g + 3]};
+    if (half == 0) {
+        mpart[wave][l32] = mx;
+        dpart[wave][l32] = den;
+    }
+    __syncthreads();
+    for (int e = tid; e < 32 * (D / 4); e += 64 * ATT_KW) {
+        const int q = e / (D / 4), dq = e % (D / 4);
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < ATT_KW; w++) M = fmaxf(M, mpart[w][q]);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float dsum = 0.f;
+#pragma unroll
+        for (int w = 0; w < ATT_KW; w++) {
+            const float f = mpart[w][q] == -INFINITY ? 0.f : __expf(mpart[w][q] - M);
+            dsum += f * dpart[w][q];
+            acc += f * *reinterpret_cast<const f32x4 *>(&opart[w][q][4 * dq]);
+        }
+        if (q0 + q < L) *reinterpret_cast<f32x4 *>(out + ((size_t)b * L + q0 + q) * C + h * D + 4 * dq) = acc * (1.0f / dsum);
+    }
+}
+
 // ---- pooling / resampling / layout ----
 __global__ __launch_bounds__(256) void max_pool_kernel(const float *__restrict__ x, float *__restrict__ y, int B,
                                                        int Hin, int Win, int C, int Hout, int Wout, int k, int stride,
@@ -786,6 +909,15 @@ extern "C" int zs_attention_split(const float *qkv, float *out, int batch, int L
     const float scale = 1.0f / sqrtf((float)head_dim);
     ZS_REQUIRE(L <= 32 * 65535, "zs_attention_split: L = %d too long", L);
     const dim3 grid(batch * heads, (L + 31) / 32);
+    // few (sample, head, query tile) triples and several key tiles: the key tiles across the waves of a workgroup
+    static const long long kw_below = getenv("ZS_ATT_KW_BELOW") ? atoll(getenv("ZS_ATT_KW_BELOW")) : 512;
+    if ((long long)grid.x * grid.y < kw_below && L > 64) {
+        if (head_dim == 64)
+            hipLaunchKernelGGL(attention_split_kw_kernel<64>, grid, dim3(64 * ATT_KW), 0, S(stream), qkv, out, L, heads, scale);
+        else
+            hipLaunchKernelGGL(attention_split_kw_kernel<32>, grid, dim3(64 * ATT_KW), 0, S(stream), qkv, out, L, heads, scale);
+        return zs::check_launch("zs_attention_split") ? 1 : 0;
+    }
     if (head_dim == 64)
         hipLaunchKernelGGL(attention_split_kernel<64>, grid, dim3(64), 0, S(stream), qkv, out, L, heads, scale);
     else
