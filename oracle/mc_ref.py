@@ -29,7 +29,43 @@ def _fma32(a, b, c):
 
 def marching_cubes(vol, iso, scale, offset):
     """vol [G,G,G] float32 (x slowest) -> triangle soup [n,3,3] float32, world space, in
-    cube order (x slowest, z fastest) and table order inside a cube."""
+    cube order (x slowest, z fastest) and table order inside a cube.  All cubes at once in numpy (the same fp32
+    operations in the same order as marching_cubes_loop, which tests/test_oracle_mc.py holds it to bit for bit):
+    the vox-64 / vox-128 grids of BASELINE configs 2 / 3 take seconds instead of hours."""
+    vol = np.asarray(vol, np.float32)
+    G = vol.shape[0]
+    C = G - 1
+    iso = np.float32(iso)
+    scale, offset = np.float32(scale), np.float32(offset)
+    corners = np.asarray(T.CORNERS)
+    f = np.stack([vol[c[0]:c[0] + C, c[1]:c[1] + C, c[2]:c[2] + C] for c in corners], -1)       # [C,C,C,8]
+    case = np.zeros((C, C, C), np.int64)
+    for b in range(8):
+        case |= (f[..., b] < iso).astype(np.int64) << b
+    count = np.asarray(T.TRI_COUNT)[case]
+    ii, jj, kk = np.nonzero(count)                       # C order: x slowest, z fastest
+    if len(ii) == 0:
+        return np.zeros((0, 3, 3), np.float32)
+    fc = f[ii, jj, kk]                                   # [n,8]
+    cs = case[ii, jj, kk]
+    e = np.asarray(T.TRI_TABLE)[cs][:, :15].astype(np.int64)          # [n,15] edge ids (-1 beyond the count)
+    live = np.arange(15)[None, :] < 3 * count[ii, jj, kk][:, None]
+    e = np.where(live, e, 0)
+    a, b, ax = _EA[e], _EB[e], _AXIS[e]
+    rows = np.arange(len(ii))[:, None]
+    fa, fb = fc[rows, a], fc[rows, b]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tt = (iso - fa).astype(np.float32) / (fb - fa).astype(np.float32)
+    base = np.stack([ii, jj, kk], -1).astype(np.float32)[:, None, :] + corners[a].astype(np.float32)     # [n,15,3]
+    add = np.zeros_like(base)
+    add[rows, np.arange(15)[None, :], ax] = tt
+    p = (base + add).astype(np.float32)                  # only the edge's axis moves; + 0 is exact elsewhere
+    world = _fma32(p, scale, offset)
+    return world[live].reshape(-1, 3, 3)
+
+
+def marching_cubes_loop(vol, iso, scale, offset):
+    """The same extraction cube by cube (the first form of this oracle; kept as the check of the vectorised one)."""
     vol = np.asarray(vol, np.float32)
     G = vol.shape[0]
     C = G - 1
@@ -74,7 +110,37 @@ def triangle_areas(tris):
     return 0.5 * np.sqrt(nx.astype(np.float64) ** 2 + ny.astype(np.float64) ** 2 + nz.astype(np.float64) ** 2)
 
 
+def _u01_many(seed, ctr):
+    """u01 for an array of counters (uint64 arithmetic wraps like the & M64 above)."""
+    def mix(x):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+    with np.errstate(over="ignore"):
+        h = mix(np.uint64(seed) ^ mix(np.asarray(ctr, np.uint64)))
+    return ((h >> np.uint64(40)).astype(np.float64) * (1.0 / 16777216.0)).astype(np.float32)
+
+
 def sample_surface(tris, n_samples, seed):
+    """area-weighted samples [n_samples,3] float32 + chosen triangle ids (all samples at once; sample_surface_loop is the
+    sample-by-sample form it is checked against)."""
+    if len(tris) == 0:
+        return np.zeros((n_samples, 3), np.float32), np.zeros(n_samples, np.int64)
+    cum = np.cumsum(triangle_areas(tris))
+    s = np.arange(n_samples, dtype=np.uint64)
+    target = _u01_many(seed, 3 * s).astype(np.float64) * cum[-1]
+    ids = np.minimum(np.searchsorted(cum, target, side="right"), len(tris) - 1).astype(np.int64)
+    r1, r2 = _u01_many(seed, 3 * s + np.uint64(1)), _u01_many(seed, 3 * s + np.uint64(2))
+    flip = (r1 + r2).astype(np.float32) > np.float32(1.0)
+    r1 = np.where(flip, np.float32(1.0) - r1, r1).astype(np.float32)
+    r2 = np.where(flip, np.float32(1.0) - r2, r2).astype(np.float32)
+    p = tris[ids].astype(np.float32)
+    pts = _fma32(r2[:, None], p[:, 2] - p[:, 0], _fma32(r1[:, None], p[:, 1] - p[:, 0], p[:, 0]))
+    return pts, ids
+
+
+def sample_surface_loop(tris, n_samples, seed):
     """area-weighted samples [n_samples,3] float32 + chosen triangle ids."""
     if len(tris) == 0:
         return np.zeros((n_samples, 3), np.float32), np.zeros(n_samples, np.int64)

@@ -353,3 +353,47 @@ def test_weights_beyond_w_max_select_the_exact_kernels():
     with torch.no_grad():
         m.blocks_attn[0].mlp.fc2.weight[3, 5] = 0.04
     assert m.prepare(latent).precision == "f16x3"
+
+
+def test_per_image_check_sends_an_outlier_image_to_the_exact_kernels():
+    """the f16x3 verdict was measured on the first image seen and cached per weight version, while the
+    error also depends on the image's K / V records.  prepare() now probes EVERY image through both kernels and flags, on the
+    device, the ones beyond CALIBRATION_TOL: their tiles start flagged, so the fp32 launch behind every split launch
+    re-evaluates them.  Here a network tuned close to the bound (attention weights x 5) calibrates on a normal image; in a
+    batch of that image and the same latent scaled up until its probe error passes the bound, image 1 comes back as the exact
+    kernel's numbers (within 1e-4 of the oracle), image 0 stays on the split arithmetic, bit for bit."""
+    m, sd = None, None
+    for gain in (4.0, 5.0, 6.0, 7.0):           # the largest gain whose own calibration still selects f16x3
+        cand, csd = _scaled_net(3, gain)
+        cand.precision = "f16x3"
+        if cand.prepare(torch.from_numpy(syn.seeded_latent(seed=3, batch=1)).cuda()).precision != "f16x3":
+            break
+        m, sd = cand, csd
+    assert m is not None
+    base = torch.from_numpy(syn.seeded_latent(seed=3, batch=1)).cuda()
+    pts = torch.from_numpy(syn.seeded_cloud(77, 2, 1500, -1.5, 1.5)).cuda()
+    hit = None
+    for scale in (1.5, 2.0, 3.0, 4.0, 6.0, 8.0, 12.0, 16.0):
+        lat = torch.cat([base, base * scale], 0)
+        st = m.prepare(lat)
+        assert st.precision == "f16x3" and st.image_flags is not None
+        maxima = m.last_calibration["per_image_max_abs_diff"].cpu()
+        assert maxima.shape == (2,) and float(maxima[0]) <= m.CALIBRATION_TOL
+        if float(maxima[1]) > m.CALIBRATION_TOL:
+            hit = (scale, lat, st)
+            break
+    assert hit is not None, "no latent scale pushed the split error past the bound"
+    scale, lat, st = hit
+    assert st.image_flags.cpu().tolist() == [0, 1]
+    out = m.query_points(st, pts)
+    exact = m.query_points(m.prepare(lat, "f32"), pts)
+    alone = m.query_points(m.prepare(base, "f16x3", calibrate=False), pts[:1])
+    assert torch.equal(out[1], exact[1]), "the flagged image must be the exact kernel's output"
+    assert torch.equal(out[0], alone[0]), "the unflagged image stays on the split arithmetic"
+    want, _ = R.implicit_forward(sd, lat[1:].cpu(), pts[1:].cpu())
+    np.testing.assert_allclose(out[1:].cpu().numpy(), want.numpy(), atol=1e-4 * max(1.0, float(want.abs().max())), rtol=0)
+    # the grid path honours the flags as well
+    axis = torch.linspace(-1.5, 1.5, 9).cuda()
+    g = m.query_grid(lat, axis, apply_sigmoid=False, state=st)
+    ge = m.query_grid(lat, axis, apply_sigmoid=False, state=m.prepare(lat, "f32"))
+    assert torch.equal(g[1], ge[1])

@@ -75,3 +75,22 @@ def test_sampling_is_area_weighted_and_on_surface():
     # empty mesh -> zeros
     z, _ = M.sample_surface(np.zeros((0, 3, 3), np.float32), 5, 0)
     assert z.shape == (5, 3) and not z.any()
+
+
+def test_vectorised_extraction_and_sampling_equal_the_loops_bit_for_bit():
+    """oracle/mc_ref.py extracts all cubes (and draws all samples) at once since round 4 so that the pipeline tests run at
+    vox 64 / 128; the cube-by-cube and sample-by-sample forms it replaced stay as its check."""
+    import numpy as np
+    from oracle import mc_ref as M
+    rs = np.random.RandomState(0)
+    for G in (5, 8, 11):
+        ax = np.linspace(-1.5, 1.5, G)
+        x, y, z = np.meshgrid(ax, ax, ax, indexing="ij")
+        vol = (1.0 / (1.0 + np.exp(20 * (np.sqrt(x * x + 1.3 * y * y + 0.8 * z * z) - 0.9))) + 0.05 * rs.randn(G, G, G)).astype(np.float32)
+        a = M.marching_cubes(vol, 0.5, np.float32(3.0 / G), -1.5)
+        b = M.marching_cubes_loop(vol, 0.5, np.float32(3.0 / G), -1.5)
+        assert a.shape == b.shape and len(a) > 0 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        p1, i1 = M.sample_surface(a, 300, seed=G)
+        p2, i2 = M.sample_surface_loop(b, 300, seed=G)
+        assert np.array_equal(i1, i2) and np.array_equal(p1.view(np.uint32), p2.view(np.uint32))
+    assert len(M.marching_cubes(np.zeros((4, 4, 4), np.float32), 0.5, np.float32(1.0), 0.0)) == 0

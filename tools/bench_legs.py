@@ -143,7 +143,7 @@ def pose_search_leg(dev):
 def eval_leg(dev, net, sd):
     """Chamfer-L1 (utils/eval_3D.py:136-137) of whole evaluation samples: (a) the HIP pipeline (decoder ->
     marching cubes -> sampling -> normalise -> Chamfer) against the same pipeline built from the oracle's
-    pieces on the CPU at vox_res 16 (tests/test_gpu_eval_pipeline.py); (b) the split-fp16 against the
+    pieces on the CPU at vox_res 16 and 64 (tests/test_gpu_eval_pipeline.py, which also runs one sample at vox 128); (b) the split-fp16 against the
     exact-fp32 decoder on the 129^3 grid of the headline workload."""
     from oracle import decoder_ref as R, geometry_ref as G, mc_ref as M
     from zeroshape_amd import synthetic as syn
@@ -160,18 +160,21 @@ def eval_leg(dev, net, sd):
         return edict(dict(idx=list(range(B)), latent_depth=latent.to(dev), latent_semantic=None,
                           rgb_input_map=torch.zeros(B, 3, 224, 224, device=dev),
                           pose_gt=torch.eye(3, 4)[None].repeat(B, 1, 1).to(dev), dpc=dict(points=gt.clone().to(dev))))
-    N, P = 16, 2000
     latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=2))
     gt = torch.from_numpy(syn.seeded_cloud(5, 2, 1500, -1, 1))
-    var = var_of(latent, gt)
-    E.eval_metrics(opt_of(N, P), var, net)
-    occ = R.level_grid(sd, latent, R.dense_grid(-1.5, 1.5, N, 2))
-    worst = 0.0
-    for b in range(2):
-        tris = M.marching_cubes(occ[b].numpy(), 0.5, np.float32(3.0 / (N + 1)), -1.5)
-        pts, _ = M.sample_surface(tris, P, seed=b)
-        d1, d2, _, _ = G.chamfer_distance(G.normalize_pc(torch.from_numpy(pts)[None]), G.normalize_pc(gt[b][None]))
-        worst = max(worst, abs(float(d1.mean()) - float(var.cd_acc[b])), abs(float(d2.mean()) - float(var.cd_comp[b])))
+    worst, tri_count = {}, {}
+    for N, P, B in ((16, 2000, 2), (64, 4000, 2)):      # vox 64 = BASELINE config 2 (vox 128: tests/test_gpu_eval_pipeline.py)
+        var = var_of(latent[:B], gt[:B])
+        E.eval_metrics(opt_of(N, P), var, net)
+        occ = R.level_grid(sd, latent[:B], R.dense_grid(-1.5, 1.5, N, B))
+        w = 0.0
+        for b in range(B):
+            tris = M.marching_cubes(occ[b].numpy(), 0.5, np.float32(3.0 / (N + 1)), -1.5)
+            pts, _ = M.sample_surface(tris, P, seed=b)
+            d1, d2, _, _ = G.chamfer_distance(G.normalize_pc(torch.from_numpy(pts)[None]), G.normalize_pc(gt[b][None]))
+            w = max(w, abs(float(d1.mean()) - float(var.cd_acc[b])), abs(float(d2.mean()) - float(var.cd_comp[b])))
+            tri_count[N] = len(tris)
+        worst[N] = w
     res = {}
     prev = net.precision
     try:
@@ -183,7 +186,8 @@ def eval_leg(dev, net, sd):
     finally:
         net.precision = prev
     a, b = res["f32"], res["f16x3"]
-    return {"chamfer_l1_vs_oracle_pipeline_vox16": float(worst), "contract": 1e-4,
+    return {"chamfer_l1_vs_oracle_pipeline_vox16": float(worst[16]), "chamfer_l1_vs_oracle_pipeline_vox64": float(worst[64]),
+            "oracle_triangles_vox64": int(tri_count[64]), "contract": 1e-4,
             "chamfer_l1_f16x3_vs_f32_vox128": float(max((a.cd_acc - b.cd_acc).abs().max(), (a.cd_comp - b.cd_comp).abs().max())),
             "chamfer_l1_vox128": float((a.cd_acc + a.cd_comp) / 2)}
 

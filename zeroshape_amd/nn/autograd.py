@@ -124,7 +124,10 @@ def standardize(weight, eps):
 
 # ---- packed GEMM operands: persistent buffers, re-packed for ALL layers in one launch ----
 class _PackRec(object):
-    __slots__ = ("ref", "key", "packed", "stamp", "dims")
+    # split / split_stamp: the operand's fp16 halves (optim.amp) and the stamp of the pack they were made from - a re-pack
+    # (in-place weight update, load_state_dict, optimiser step) moves `stamp` and so invalidates the split with it; the
+    # buffer dies with the record (a cache keyed by packed.data_ptr() + generation served stale weights)
+    __slots__ = ("ref", "key", "packed", "stamp", "dims", "split", "split_stamp", "__weakref__")
 
 
 _PACKS = {}     # (id(weight), cin0, cin, dgrad, std_eps) -> _PackRec
@@ -267,6 +270,8 @@ def _pack(weight, cin0, cin, dgrad, std_eps=None):
     rec.ref = weakref.ref(weight, lambda _r, k=key: _drop_pack(k))
     rec.key, rec.dims = key, dims
     rec.packed = torch.empty(K16 * NPad, dtype=torch.float32, device=w.device)
+    rec.split, rec.split_stamp = None, None
+    rec.packed._zs_rec = weakref.ref(rec)              # _conv_launch finds the record (and its split) from the operand
     with _lib.on(w.device):
         _lib.check(lib.zs_pack_conv_weight(_lib.ptr(w), _lib.ptr(rec.packed), cout, cin, cin0, cintot, kh, kw,
                                            1 if dgrad else 0, _stream(w)), "zs_pack_conv_weight")
@@ -284,7 +289,6 @@ def _out_size(n, k, stride, padding):
 
 
 _CONV_W_PRESPLIT = 128
-_PRESPLIT = {}          # packed.data_ptr() -> (generation, split operand)
 _PRESPLIT_TABLE = {}    # device -> (signature, device arrays of zs_conv2d_presplit_weight_multi, n, total pairs, splits)
 # ZS_TRAIN_PRESPLIT_ALL=1 (opt-in, measured SLOWER): ONE launch right behind the re-pack splits every registered operand
 # (zs_conv2d_presplit_weight_multi), so the small-tile and register-staged kernels skip the per-use split of their B fragments
@@ -311,10 +315,9 @@ def _presplit_all(device):
             raise RuntimeError("the set of packed operands changed inside a stream capture; call "
                                "zeroshape_amd.nn.autograd.refresh_packs(device) before capturing")
         splits, src, dst, cps, prefix, tot = [], [], [], [], [0], 0
-        old = {k: v[1] for k, v in _PRESPLIT.items()}
         for rec in recs:
             K16, NPad = rec.dims[5], rec.dims[6]
-            sp = old.get(rec.packed.data_ptr())
+            sp = rec.split
             if sp is None or sp.numel() != rec.packed.numel() or sp.device != device:
                 sp = torch.empty_like(rec.packed)
             splits.append(sp)
@@ -330,24 +333,39 @@ def _presplit_all(device):
         _lib.check(lib.zs_conv2d_presplit_weight_multi(_lib.ptr(src_d), _lib.ptr(dst_d), _lib.ptr(cp_d), _lib.ptr(pre_d), n, tot,
                                                        _lib.current_stream_ptr(device)), "zs_conv2d_presplit_weight_multi")
     for rec, sp in zip(recs, splits):
-        _PRESPLIT[rec.packed.data_ptr()] = (GENERATION[0], sp)
+        rec.split, rec.split_stamp = sp, rec.stamp
 # optim.amp: layers large enough for the LDS-DMA GEMM kernel or the 3x3 input-patch kernels (>= 192 tiles of 128 x 128,
 # channels a multiple of 16, no input affine) get their packed operand split into fp16 halves once per optimiser step
 # (zs_conv2d_presplit_weight), which is what those kernels consume; the other layers split on the fly as before.
 PRESPLIT_MIN_TILES = int(os.environ.get("ZS_TRAIN_PRESPLIT_MIN_TILES", "192"))
 
 
+def _rec_of(packed):
+    ref = getattr(packed, "_zs_rec", None)
+    return ref() if ref is not None else None
+
+
+def _split_of(packed):
+    """The operand's current fp16 halves, or None (never split, or split from an older pack)."""
+    rec = _rec_of(packed)
+    if rec is not None and rec.split is not None and rec.split_stamp == rec.stamp and rec.split.numel() == packed.numel():
+        return rec.split
+    return None
+
+
 def _presplit(packed, C, Co, kh, kw, device):
     lib = _lib.load()
-    rec = _PRESPLIT.get(packed.data_ptr())
-    if rec is None or rec[0] != GENERATION[0] or rec[1].numel() != packed.numel():
-        split = rec[1] if rec is not None and rec[1].numel() == packed.numel() else torch.empty_like(packed)
+    split = _split_of(packed)
+    if split is None:
+        rec = _rec_of(packed)
+        split = rec.split if rec is not None and rec.split is not None and rec.split.numel() == packed.numel() \
+            else torch.empty_like(packed)
         with _lib.on(device):
             _lib.check(lib.zs_conv2d_presplit_weight(_lib.ptr(packed), _lib.ptr(split), C, Co, kh, kw,
                                                      _lib.current_stream_ptr(device)), "zs_conv2d_presplit_weight")
-        rec = (GENERATION[0], split)
-        _PRESPLIT[packed.data_ptr()] = rec
-    return rec[1]
+        if rec is not None:                    # an operand without a record (none today) is split on every use
+            rec.split, rec.split_stamp = split, rec.stamp
+    return split
 
 
 def _conv_launch(x, packed, shift, res1, res2, out, kh, kw, stride, pt, pl, flags, in_scale, in_shift, act):
@@ -355,9 +373,9 @@ def _conv_launch(x, packed, shift, res1, res2, out, kh, kw, stride, pt, pl, flag
     B, H, W, C = x.shape
     _, Ho, Wo, Co = out.shape
     if flags & _CONV_F16X3:
-        rec = _PRESPLIT.get(packed.data_ptr()) if _amp_splits_operands() else None
-        if rec is not None and rec[0] == GENERATION[0] and rec[1].numel() == packed.numel():
-            packed = rec[1]                        # split with every other operand right after the re-pack
+        split = _split_of(packed) if _amp_splits_operands() else None
+        if split is not None:
+            packed = split                         # split with every other operand right after the re-pack
             flags |= _CONV_W_PRESPLIT
         elif not (flags & _CONV_IN_DILATE2) and C % 16 == 0 and in_scale == 1.0 and in_shift == 0.0 and \
                 -(-(B * Ho * Wo) // 128) * -(-Co // 128) >= PRESPLIT_MIN_TILES:

@@ -4,7 +4,6 @@ host-side packing), with BatchNorm on batch statistics.  Each function mirrors a
 forward under graph.train() (model/shape_engine.py:248-297)."""
 import torch.nn as nn
 
-from . import blocks
 from . import autograd as A
 
 
