@@ -35,7 +35,7 @@ Extra objects on the JSON line:
                  this host's cores on a bounded sample of x-slices of the same grid.
   calibration  - Implicit.prepare's once-per-weight-version verdict on the requested arithmetic: max |f16x3 - f32| logit
                  over 4096 probe points and the arithmetic it selected (2.5e-5 keeps f16x3, else the fp32 kernels run).
-  chamfer / pose_search / chamfer_l1 / encoder / inference / iso_surface / train_step / trained_weights
+  chamfer / pose_search / chamfer_l1 / encoder / encoder_att / vox256 / inference / iso_surface / train_step / trained_weights
                - (N = 1, outside the timed region; tools/bench_legs.py) the rest of the BASELINE metric: the
                  Chamfer NN kernel on [24,10k]x[24,10k] with its fp32-VALU roofline fraction, bit equality
                  to the oracle and the oracle timed on the host (CPU leg ii); the 6912-rotation pose search
@@ -349,6 +349,7 @@ def main():
         cpu = not args.no_cpu_baseline
         for name, fn in (("chamfer", lambda: legs.chamfer_leg(dev, cpu)), ("pose_search", lambda: legs.pose_search_leg(dev)),
                          ("chamfer_l1", lambda: legs.eval_leg(dev, net, sd)), ("encoder", lambda: legs.encoder_leg(dev, cpu)),
+                         ("encoder_att", lambda: legs.encoder_att_leg(dev)), ("vox256", lambda: legs.vox256_leg(dev, net)),
                          ("inference", lambda: legs.inference_leg(dev)), ("iso_surface", lambda: legs.surface_leg(dev)),
                          ("train_step", lambda: legs.in_subprocess("train", "train_step")),
                          ("trained_weights", lambda: legs.in_subprocess("trained", "trained_weights"))):

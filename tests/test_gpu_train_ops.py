@@ -404,7 +404,7 @@ def test_repack_of_all_operands_in_one_launch_equals_the_single_packs():
 @pytest.mark.parametrize("presplit_all", [False, True])
 def test_split_operand_follows_in_place_weight_updates(presplit_all, monkeypatch):
     """the fp16 halves of a packed operand (optim.amp forward) were cached by packed.data_ptr() + generation, so a
-    weight changed by torch without bump_generation() - load_state_dict, w.data.mul_(), a torch optimiser - kept computing
+    weight changed by torch without bump_generation() - load_state_dict, w.mul_() under no_grad, a torch optimiser - kept computing
     with the old split.  The split now lives on the pack record and is stamped with the pack it was made from."""
     from zeroshape_amd.nn import autograd as A
     monkeypatch.setattr(A, "FWD_CONV_PRECISION", "f16x3")
@@ -415,10 +415,10 @@ def test_split_operand_follows_in_place_weight_updates(presplit_all, monkeypatch
     w = (torch.randn(64, 32, 3, 3, generator=g) / 17.0).cuda().requires_grad_(True)
     with torch.no_grad():
         y0 = A.conv2d(x, w, None, padding=1).clone()
-        w.data.mul_(2.0)                                        # in place, no bump_generation()
+        w.mul_(2.0)                                             # in place (bumps w._version), no bump_generation()
         y1 = A.conv2d(x, w, None, padding=1).clone()
-        w.data.copy_(torch.zeros_like(w))
+        w.copy_(torch.zeros_like(w))                            # what load_state_dict does
         y2 = A.conv2d(x, w, None, padding=1).clone()
     scale = float(y0.abs().max())
-    assert float((y1 - 2.0 * y0).abs().max()) <= 1e-5 * scale, "the split operand did not follow w.data.mul_()"
-    assert float(y2.abs().max()) == 0.0, "the split operand did not follow w.data.copy_()"
+    assert float((y1 - 2.0 * y0).abs().max()) <= 1e-5 * scale, "the split operand did not follow w.mul_()"
+    assert float(y2.abs().max()) == 0.0, "the split operand did not follow w.copy_()"

@@ -232,12 +232,12 @@ def surface_leg(dev, iters=10):
     return out
 
 
-def _graph(dev):
+def _graph(dev, encoder="resnet"):
     from zeroshape_amd.model.compute_graph.graph_shape import Graph
     from zeroshape_amd.utils.options import EasyDict as edict
     opt = edict(dict(H=224, W=224, device=str(dev), pretrain=dict(depth=None),
                      arch=dict(num_heads=8, latent_dim=256, win_size=16,
-                               depth=dict(encoder="resnet", n_blocks=12, dsp=2, pretrained=None),
+                               depth=dict(encoder=encoder, n_blocks=12, dsp=2, pretrained=None),
                                rgb=dict(encoder=None, n_blocks=12),
                                impl=dict(n_channels=256, att_blocks=2, mlp_ratio=4., posenc_perlayer=False,
                                          mlp_layers=8, posenc_3D=0, skip_in=[2, 4, 6]))))
@@ -257,13 +257,19 @@ def encoder_leg(dev, cpu=True):
     opt, g = _graph(dev)
     gflop = GFLOP_DPT + GFLOP_RES + GFLOP_INTR
     out = {"gflop_per_image": gflop, "peak": 2500.0, "unit": "TFLOP/s (algorithmic; split-fp16 on the 16-bit matrix pipe)"}
-    g.enable_hip_graph(True)
+    from zeroshape_amd import _lib
     for B in (1, 28):
         rgb, mask = [torch.from_numpy(x).to(dev) for x in syn.seeded_rgb_scene(0, B)]
         var = edict(dict(idx=list(range(B)), rgb_input_map=rgb, mask_input_map=mask))
+        g.enable_hip_graph(False)
+        g.forward(opt, var, training=False, get_loss=False)              # packs the weights
+        c0 = _lib.CALLS[0]
+        g.forward(opt, var, training=False, get_loss=False)
+        calls = _lib.CALLS[0] - c0                                       # C-ABI calls (= launches, a few calls launch two) per forward
+        g.enable_hip_graph(True)
         ms, mn = _events(lambda: g.forward(opt, var, training=False, get_loss=False), 10 if B == 1 else 5)
         out["b%d" % B] = {"ms": round(ms, 3), "ms_min": round(mn, 3), "tflops": round(gflop * B / ms, 1),
-                          "frac_of_peak": round(gflop * B / ms / 2500.0, 4)}
+                          "frac_of_peak": round(gflop * B / ms / 2500.0, 4), "abi_calls_per_forward": calls}
     g.enable_hip_graph(False)
     if cpu:
         from oracle import encoder_ref
@@ -285,6 +291,90 @@ def encoder_leg(dev, cpu=True):
     del g
     torch.cuda.empty_cache()
     return out
+
+
+def encoder_att_leg(dev):
+    """The transformer coordinate encoder (arch.depth.encoder = 'att': CoordEmb + CoordEncAtt, /root/reference/model/shape/
+    seen_coord_enc.py:49-78,119-139; `north_star`: "window/global attention ... as CDNA4 kernels"): the encoder half of
+    Graph.forward with it, B = 1 / 28 as one replayed hipGraph, and its two stages alone - the window stage (Linear(3, C),
+    token gather, one ViT block over 196 B sequences of 65 tokens) and the 12 global blocks over B sequences of 197 tokens -
+    each captured and replayed, with the split-fp16 matrix work they execute against the 2,500 TFLOP/s 16-bit peak."""
+    from zeroshape_amd import synthetic as syn
+    from zeroshape_amd.nn import blocks, ops
+    from zeroshape_amd.nn.capture import CapturedCall
+    from zeroshape_amd.utils.options import EasyDict as edict
+    opt, g = _graph(dev, encoder="att")
+    enc = g.coord_encoder
+    C, heads, win = enc.cls_token.shape[-1], enc.num_heads, enc.win_size
+    out = {"embed_dim": C, "heads": heads, "win_size": win, "peak": 2500.0,
+           "unit": "TFLOP/s (algorithmic fp32 products; split-fp16 executes 3 MFMAs per product)"}
+    for B in (1, 28):
+        rgb, mask = [torch.from_numpy(x).to(dev) for x in syn.seeded_rgb_scene(0, B)]
+        var = edict(dict(idx=list(range(B)), rgb_input_map=rgb, mask_input_map=mask))
+        g.enable_hip_graph(True)
+        ms, mn = _events(lambda: g.forward(opt, var, training=False, get_loss=False), 10 if B == 1 else 5)
+        g.enable_hip_graph(False)
+        # the two stages alone, on the coordinate map the forward produced
+        H = W = 224 // opt.arch.depth.dsp
+        coord = torch.randn(B, H, W, 3, device=dev) * 0.3
+        maskb = (torch.rand(B, H, W, device=dev) > 0.3)
+        pk = enc.packed(dev)
+        n = (H // win) * (W // win)
+
+        def window_stage(c, m):
+            emb = ops.conv2d(ops.pad_channels(c, 4), pk["embed"])
+            tok = ops.window_tokens(emb, m > 0.5, pk["invalid"], pk["wcls"], pk["wpos"], win)
+            tok = blocks.run_vit_block(tok, pk["wblock"], heads)
+            return tok[:, 0].reshape(B, n, C).contiguous()
+
+        def global_stage(feat):
+            if pk["zero_pos"] is None or pk["zero_pos"].shape[0] != n + 1:
+                pk["zero_pos"] = torch.zeros(n + 1, C, device=dev)
+            x = ops.assemble_tokens(feat, pk["cls"], pk["zero_pos"])
+            st = None
+            for blk in pk["blocks"]:
+                x, st = blocks.run_vit_block(x, blk, heads, stats=st, want_stats=True)
+            return ops.layer_norm(x, pk["nw"], pk["nb"], 1e-6)
+        maskf = maskb.float()
+        feat = window_stage(coord, maskf)
+        cw = CapturedCall(window_stage, [coord, maskf])
+        cg = CapturedCall(global_stage, [feat])
+        w_ms, _ = _events(lambda: cw(coord, maskf), 10)
+        g_ms, _ = _events(lambda: cg(feat), 10)
+        tw, Lw = B * n, win * win + 1                       # window sequences, tokens each
+        w_flop = 2.0 * tw * Lw * (4 * C * C + 2 * 2 * C * C) + 4.0 * tw * Lw * Lw * C + 2.0 * B * H * W * 4 * C
+        g_flop = 12 * (2.0 * B * (n + 1) * (4 * C * C + 2 * 4 * C * C) + 4.0 * B * (n + 1) ** 2 * C)
+        out["b%d" % B] = {"ms": round(ms, 3), "ms_min": round(mn, 3),
+                          "window_stage": {"ms": round(w_ms, 4), "sequences": tw, "tokens": Lw, "gflop": round(w_flop / 1e9, 3),
+                                           "tflops": round(w_flop / w_ms / 1e9, 2), "frac_of_peak": round(w_flop / w_ms / 1e9 / 2500.0, 5)},
+                          "global_blocks": {"ms": round(g_ms, 4), "sequences": B, "tokens": n + 1, "gflop": round(g_flop / 1e9, 3),
+                                            "tflops": round(g_flop / g_ms / 1e9, 2), "frac_of_peak": round(g_flop / g_ms / 1e9 / 2500.0, 5)}}
+    del g
+    torch.cuda.empty_cache()
+    return out
+
+
+def vox256_leg(dev, net):
+    """BASELINE config 5 on ONE GPU (evaluate.py OmniObject3D, vox_res 256): the 257^3 grid of one image through the fused
+    decoder - ms and points/s - and the eight point ranges of the 8-GPU sharding (zeroshape_amd/parallel.point_bounds) each
+    timed alone on this GPU: the per-rank spread the all-gather would wait for.  (The RCCL gather itself has not run on
+    hardware: DESIGN.md section 7.)"""
+    from zeroshape_amd import parallel, synthetic as syn
+    N = 256
+    G = N + 1
+    latent = torch.from_numpy(syn.seeded_latent(2, 1)).to(dev)
+    axis = torch.linspace(-1.5, 1.5, G, device=dev)
+    st = net.prepare(latent)
+    ms, mn = _events(lambda: net.query_grid(latent, axis, apply_sigmoid=True, state=st), 3)
+    per = []
+    for r in range(8):
+        b, e, _ = parallel.point_bounds(G ** 3, 8, r)
+        t, _ = _events(lambda: net.query_grid_range(latent, axis, b, e, state=st), 3)
+        per.append(t)
+    return {"points": G ** 3, "ms": round(ms, 2), "ms_min": round(mn, 2), "points_per_s": round(G ** 3 / (ms * 1e-3), 0),
+            "precision": st.precision,
+            "virtual_ranks_8": {"ms_per_rank": [round(t, 2) for t in per], "max_over_min": round(max(per) / min(per), 3),
+                                "sum_over_whole": round(sum(per) / ms, 3)}}
 
 
 def inference_leg(dev):

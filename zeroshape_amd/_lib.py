@@ -226,7 +226,11 @@ def load():
     return lib
 
 
+CALLS = [0]         # C-ABI calls checked so far (launch counting: bench legs report calls per forward / per step)
+
+
 def check(rc, what):
+    CALLS[0] += 1
     if rc != 1:
         msg = load().zs_last_error()
         raise ZeroShapeHipError("%s failed: %s" % (what, (msg or b"").decode(errors="replace")))

@@ -228,6 +228,7 @@ class CoordEncAtt(HipModule):
         if pk["zero_pos"] is None or pk["zero_pos"].shape[0] != n + 1:
             pk["zero_pos"] = torch.zeros(n + 1, C, device=emb.device)
         x = ops.assemble_tokens(feat, pk["cls"], pk["zero_pos"])
+        st = None                          # row statistics of x from the previous block's fc2 (few rows: fused LayerNorms)
         for blk in pk["blocks"]:
-            x = blocks.run_vit_block(x, blk, self.num_heads)
+            x, st = blocks.run_vit_block(x, blk, self.num_heads, stats=st, want_stats=True)
         return ops.layer_norm(x, pk["nw"], pk["nb"], 1e-6)
