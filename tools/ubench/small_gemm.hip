@@ -502,7 +502,7 @@ int main(int argc, char **argv) {
         {197, 3072, 768, 0, 1, "vit fc2"}, {196, 1024, 256, 0, 0, "rn c1 14^2"}, {196, 256, 1024, 0, 0, "rn c3 14^2"},
         {196, 2304, 256, 0, 0, "rn c2 14^2 (as pw)"}, {49, 6912, 768, 0, 0, "intr 3x3 7^2 (as pw)"},
         {49, 2048, 512, 0, 0, "r50 l4 c1"}, {1, 2048, 2048, 0, 0, "fc head gemv"}, {784, 512, 128, 0, 0, "rn c1 28^2"},
-        {784, 1152, 128, 0, 0, "rn c2 28^2 (as pw)"}, {3136, 256, 64, 0, 0, "rn c1 56^2"},
+        {784, 1152, 128, 0, 0, "rn c2 28^2 (as pw)"}, {3136, 256, 64, 0, 0, "rn c1 56^2"}, {3136, 64, 256, 0, 0, "64->256 56^2"}, {784, 2304, 256, 0, 0, "3x3 28^2 as pw"},
     };
     hipStream_t st;
     CK(hipStreamCreate(&st));
@@ -560,6 +560,18 @@ int main(int argc, char **argv) {
             CK(hipMemcpy(hout.data(), dout, hout.size() * 4, hipMemcpyDeviceToHost));
             double err = 0;
             for (size_t i = 0; i < hout.size(); i++) err = std::max(err, (double)fabsf(hout[i] - href[i]));
+            if (getenv("RACE")) {          // repeat: every run must equal the first bit for bit
+                std::vector<float> h2(hout.size());
+                long bad = 0;
+                for (int r = 0; r < 60; r++) {
+                    for (int k = 0; k < 8; k++) launch(0);
+                    CK(hipStreamSynchronize(st));
+                    CK(hipMemcpy(h2.data(), dout, h2.size() * 4, hipMemcpyDeviceToHost));
+                    bad += memcmp(h2.data(), hout.data(), h2.size() * 4) != 0;
+                }
+                printf("  %-34s race screen: %ld of 60 runs differ from the first; err %.2e\n", label, bad, err);
+                return;
+            }
             hipGraph_t graph;
             hipGraphExec_t exec;
             CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
@@ -629,16 +641,10 @@ int main(int argc, char **argv) {
                 print_stamps(dstamps, 8 * ((((N + 32 * NJ - 1) / (32 * NJ)) * ((M + 32 * MI - 1) / (32 * MI)) + 7) / 8)); \
             }                                                                                                            \
         } while (0)
-        VAR(8, 1, 2, 2, 1, 1);
         VAR(4, 1, 2, 3, 1, 1);
-        VAR(8, 1, 3, 3, 1, 1);
-        VARL(4, 1, 2, 2, 1, 1, 0);
-        VARL(4, 1, 2, 3, 1, 1, 0);
-        VARL(8, 1, 2, 2, 1, 1, 0);
-        VARL(8, 1, 3, 2, 1, 1, 0);
-        VARL(4, 1, 3, 2, 1, 1, 0);
-        VARL(4, 2, 2, 2, 1, 1, 0);
-        VARL(4, 1, 2, 2, 1, 1, 4);
+        VAR(4, 1, 1, 3, 1, 1);
+        VAR(4, 1, 2, 3, 1, 0);
+        VAR(8, 1, 2, 3, 1, 1);
         }
     cleanup:
         CK(hipFree(da)); CK(hipFree(dwT)); CK(hipFree(db)); CK(hipFree(dr)); CK(hipFree(dout)); CK(hipFree(dref)); CK(hipFree(dpacked));

@@ -22,6 +22,7 @@
 // adds, activation (ReLU / GELU(erf) / ReLU+clamp1).
 #include "zs_common.h"
 #include "zs_split16.h"
+#include "nn_gemm_stream.h"
 #include "../../include/zeroshape_hip.h"
 
 #include <math.h>
@@ -1335,8 +1336,6 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
     }
 }
 
-#include "nn_conv_stream.h"
-
 // fp32 packed weights [K16/4][CoutPad][4] -> the same shape with, per K = 16 step s and lane half q, the hi halves of
 // the eight k values {4q..4q+3, 4q+8..4q+11} in quad 4s+q and their lo halves in quad 4s+q+2 (what the F16 kernels
 // otherwise compute from the fp32 quads on every use)
@@ -1621,42 +1620,26 @@ static int conv2d_impl(const float *in, const float *packed_w, const float *scal
     if (small) {
         const bool tm = !pw && !no_tm && (Cin % 8) == 0;
         const bool narrow = (fuse && fuse->out_mode == 2) ? zs_conv2d_fused_cols((int)M, Cout) == 32 : small_is_narrow(M, Cout);
-        // ---- the streaming kernel (nn_conv_stream.h): split-fp16, pre-split weights, pointwise or Cin % 16 == 0 taps ----
-        // EXPERIMENTAL, OFF by default (ZS_CONV_STREAM=1 enables it): in tools/ubench/small_gemm.hip the structure runs the ViT
-        // GEMMs 1.5-1.8x faster than the small-tile kernel (qkv 13.6 -> 9.0 us, fc1 19.3 -> 10.7 us in a chain of launches with
-        // cold weights), but inside the library tools/race_screen_conv.py --batch 1 finds sporadic whole-tile corruption as soon
-        // as two of its workgroups share a CU (64 -> 256 at 56 x 56; the 32 x 32 tiles everywhere) - cause not found in round 4 -
-        // and the encoder as a whole did not get faster with it (3.37 vs 3.19 ms).  Kept for the next round; never on a product path.
-        static const bool no_stream = getenv("ZS_CONV_STREAM") == nullptr || atoi(getenv("ZS_CONV_STREAM")) == 0;
-        const bool pw_geom0 = kh == 1 && kw == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && a.dil == 1 && Hin == Hout && Win == Wout;
-        const bool fuse_ok = !fuse || ((fuse->in_mode == 0 || (fuse->in_mode == 2 && pw_geom0)) && (fuse->out_mode == 0 || fuse->out_mode == 2));
-        if (!no_stream && f16 && a.w_split && workspace && in_scale == 1.0f && in_shift == 0.0f && a.dil == 1 && (Cout & 3) == 0 &&
-            (Cin % BK) == 0 && fuse_ok && !(flags & ZS_CONV_SPLIT_SMALL) &&
-            (size_t)Hin * Win * Cin * batch * 4 < ((size_t)1 << 32)) {
-            const int steps = a.K / BK;
-            const stream::Plan pl = stream::plan(M, Cout, a.CoutPad, steps, fuse && fuse->out_mode == 2 ? zs_conv2d_fused_cols((int)M, Cout) / 32 : 0);
-            stream::Geo g;
-            g.mtiles = pl.mtiles; g.ntiles = pl.ntiles; g.zsplit = pl.zsplit; g.steps = steps;
-            g.tickets = reinterpret_cast<int *>(workspace);
-            g.parts = static_cast<float *>(workspace) + WS_COUNTER_FLOATS;
-            const long long T = (long long)pl.mtiles * pl.ntiles;
-            if (T <= (long long)WS_COUNTER_FLOATS && (size_t)T * pl.zsplit * 32 * pl.mi * 32 * pl.nj * 4 <= WS_PARTS_BYTES) {
-                const dim3 grid((unsigned)(8 * ((T + 7) / 8)), (unsigned)pl.zsplit);
-                const int xf = fuse ? fuse->in_mode : 0;
-                // (the kernel's pointwise specialisation - template PW - gave wrong column blocks on the GPU and is not
-                // instantiated: the tap walk handles 1 x 1 geometry at the price of a few scalar instructions per step)
-#define ZS_STREAM(MI_, NJ_)                                                                                                  \
-    do {                                                                                                                     \
-        if (xf == 2) hipLaunchKernelGGL((stream::conv_stream_kernel<4, MI_, NJ_, 3, false, 2>), grid, dim3(256), 0, st, a, g);  \
-        else hipLaunchKernelGGL((stream::conv_stream_kernel<4, MI_, NJ_, 3, false, 0>), grid, dim3(256), 0, st, a, g);         \
-    } while (0)
-                if (pl.mi == 2) { if (pl.nj == 1) ZS_STREAM(2, 1); else ZS_STREAM(2, 2); }
-                else if (pl.nj == 1) ZS_STREAM(1, 1);
-                else if (pl.nj == 2) ZS_STREAM(1, 2);
-                else ZS_STREAM(1, 3);
-#undef ZS_STREAM
-                return zs::check_launch("zs_conv2d_nhwc") ? 1 : 0;
-            }
+        // ---- pointwise layers of few rows: the streaming GEMM kernel (csrc/nn_gemm_stream.hip) ----
+        static const bool use_stream = getenv("ZS_CONV_STREAM") == nullptr || atoi(getenv("ZS_CONV_STREAM")) != 0;
+        static const long long stream_max_rows = getenv("ZS_STREAM_MAX_ROWS") ? atoll(getenv("ZS_STREAM_MAX_ROWS")) : 1024;
+        const bool pw_geom = kh == 1 && kw == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && a.dil == 1 && Hin == Hout && Win == Wout;
+        if (use_stream && pw_geom && f16 && a.w_split && in_scale == 1.0f && in_shift == 0.0f && M <= stream_max_rows &&
+            (!fuse || ((fuse->in_mode == 0 || fuse->in_mode == 2) && (fuse->out_mode == 0 || fuse->out_mode == 2))) &&
+            !(flags & ZS_CONV_SPLIT_SMALL)) {
+            zs::stream_gemm::Args g;
+            g.a = in; g.w = packed_w; g.scale = scale; g.shift = shift; g.res1 = res1; g.res2 = res2; g.out = out;
+            g.M = (int)M; g.K = a.K; g.N = Cout; g.CoutPad = a.CoutPad; g.lda = Cin; g.act = act; g.in_relu = a.in_relu;
+            g.in_stats = fuse && fuse->in_mode == 2 ? fuse->in_stats : nullptr;
+            g.in_tiles = fuse ? fuse->in_tiles : 0;
+            g.in_eps = fuse ? fuse->in_eps : 0.f;
+            g.out_stats = fuse && fuse->out_mode == 2 ? fuse->out_stats : nullptr;
+            g.stats_cols = zs_conv2d_fused_cols((int)M, Cout);
+            g.parts = workspace ? static_cast<float *>(workspace) + WS_COUNTER_FLOATS : nullptr;
+            g.tickets = static_cast<int *>(workspace);
+            g.parts_bytes = WS_PARTS_BYTES;
+            g.max_tickets = (int)WS_COUNTER_FLOATS;
+            if (zs::stream_gemm::launch(g, st)) return zs::check_launch("zs_conv2d_nhwc") ? 1 : 0;
         }
         const long long wgs = ((M + SM - 1) / SM) * ((Cout + (narrow ? 31 : 63)) / (narrow ? 32 : 64));
         // Split K across workgroups while the launch would leave most of the 256 CUs idle (14x14 maps,

@@ -1,0 +1,283 @@
+// Batch-1 pointwise GEMM of the split-fp16 inference engine: the 197-token matrices of the ViT blocks, the 1 x 1 layers on 14 x 14
+// and 7 x 7 maps, the one-pixel fc head - problems whose 128 x 128 tiling would leave most CUs idle.
+//
+// What tools/ubench/small_gemm.hip measured on MI355X inside a dependent chain of launches with cold weights (round 4):
+//   * the CU's vector-memory path moves ~30 B/clk of streamed operands (64 B/clk on hits): a launch costs
+//     ~1.8 us + bytes through its busiest CU / ~77 GB/s, so the tiling must use all 256 CUs ONCE (a second round of
+//     workgroups costs a whole workgroup latency: 252 tiles dealt 35 to an XCD of 32 CUs ran 16.3 us, dealt evenly 8.8 us),
+//   * hipcc sinks every operand load next to its MFMA and waits vmcnt(0) (ISA of the first version) - the operand ring
+//     therefore lives in registers only inline asm writes, with counted waits,
+//   * a ring deeper than ~3 K = 16 steps buys nothing (the issue of the loads, not their latency, is the bound), per-step
+//     vector address arithmetic costs as much as the loads (operands are addressed as uniform base + fixed lane offset),
+//   * staging A through LDS in full lines (LDS-DMA, swizzled) measured no better than fragment-shaped register loads here.
+// Structure: workgroup = 32 MI rows x 32 NJ columns x a range of K; its NW waves split that range (operands straight from
+// global memory into MFMA registers, nothing shared), partial tiles summed through LDS in wave order.  The kernel body is
+// the micro-benchmark's, which tools/ubench/small_gemm.hip (RACE=1) screens bit-identical over 60 x 8 launches at every
+// shape; a first rewrite with a tap walker inside the same ring showed sporadic whole-tile corruption and is not used.
+#include "nn_gemm_stream.h"
+#include "zs_common.h"
+#include "zs_split16.h"
+#include "../../include/zeroshape_hip.h"
+
+#include <math.h>
+#include <stdlib.h>
+
+namespace zs {
+namespace stream_gemm {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct Geo { int mtiles, ntiles, splits; };
+
+__device__ __forceinline__ float activate(float v, int act) {
+    if (act == ZS_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ZS_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (act == ZS_ACT_RELU_CLAMP1) return fminf(fmaxf(v, 0.f), 1.f);
+    return v;
+}
+
+template <int NW, int MI, int NJ, int DEPTH, bool LN>
+__global__ __launch_bounds__(64 * NW) void stream_gemm_kernel(Args a, Geo g) {
+    constexpr int SM = 32 * MI, SN = 32 * NJ, PAD = SN + 4;
+    __shared__ __attribute__((aligned(16))) float part[NW][SM][PAD];
+    __shared__ float rowtab[LN ? 2 : 1][LN ? SM : 1];       // LN: (rstd, -mean rstd) of the tile's rows
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mtiles = g.mtiles, ntiles = g.ntiles;
+    // XCD-aware tile order: workgroup id b runs on XCD b % 8; the row tiles of one column slab share an XCD (the slab's
+    // weights are fetched into ONE L2)
+    int tm, tn;
+    const int z = blockIdx.y;
+    {
+        const int b = blockIdx.x;
+        const int T = mtiles * ntiles, xcd = b & 7, local = b >> 3;
+        const int lo = (int)((long long)xcd * T / 8), hi = (int)((long long)(xcd + 1) * T / 8);
+        const int t = lo + local;
+        if (t >= hi) return;
+        tn = t / mtiles;
+        tm = t - tn * mtiles;
+    }
+    const int m0 = tm * SM, n0 = tn * SN;
+    const int S = (a.K + 15) / 16;                        // K = 16 steps
+    const int zs0 = (int)((long long)z * S / g.splits), zs1 = (int)((long long)(z + 1) * S / g.splits);
+    const int per_w = (zs1 - zs0 + NW - 1) / NW;
+    const int s_begin = zs0 + wave * per_w, s_end = min(zs1, s_begin + per_w);
+    const int ns = max(s_end - s_begin, 0);
+
+    // operand addresses = uniform base (SGPR pair, advanced per step by scalar adds) + per-lane 32-bit offset (fixed): no
+    // vector address arithmetic in the loop
+    unsigned aoff[MI];
+    bool rok[MI];
+#pragma unroll
+    for (int i = 0; i < MI; i++) {
+        const int m = m0 + 32 * i + l32;
+        rok[i] = m < a.M;
+        aoff[i] = (unsigned)(((size_t)(rok[i] ? m : 0) * a.lda + 4 * half) * 4);
+    }
+    unsigned boff = (unsigned)(((size_t)half * a.CoutPad + n0 + l32) * 16);
+    const char *abase = reinterpret_cast<const char *>(a.a);
+    const char *bbase = reinterpret_cast<const char *>(a.w);
+    const size_t bstep2 = (size_t)2 * a.CoutPad * 16;              // two weight quad rows
+
+    constexpr int L = 2 * MI + 2 * NJ;
+    static_assert((DEPTH - 1) * L < 64, "vmcnt is a 6-bit counter");
+    f32x4 ra[DEPTH][MI][2];
+    f32x4 rb[DEPTH][NJ][2];
+#define ZS_GLDS(dst, voff, sbase, IMM) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "+v"(dst) : "v"(voff), "s"(sbase), "n"(IMM) : "memory")
+    auto load = [&](int slot, int s) {
+        const int sc = min(s, S - 1);               // clamped: always a valid address
+        const int sa = sc;
+        const char *pb0 = bbase + (size_t)sc * 2 * bstep2, *pb1 = pb0 + bstep2;
+        const char *pa = abase + (size_t)sa * 64;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            ZS_GLDS(rb[slot][j][0], boff, pb0, 512 * j);
+            ZS_GLDS(rb[slot][j][1], boff, pb1, 512 * j);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; i++) {
+            ZS_GLDS(ra[slot][i][0], aoff[i], pa, 0);
+            ZS_GLDS(ra[slot][i][1], aoff[i], pa, 32);
+        }
+    };
+    auto landed = [&](int slot) {
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"((DEPTH - 1) * L) : "memory");
+#pragma unroll
+        for (int j = 0; j < NJ; j++) asm volatile("" : "+v"(rb[slot][j][0]), "+v"(rb[slot][j][1]));
+#pragma unroll
+        for (int i = 0; i < MI; i++) asm volatile("" : "+v"(ra[slot][i][0]), "+v"(ra[slot][i][1]));
+    };
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) { rb[d][j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; rb[d][j][1] = rb[d][j][0]; }
+#pragma unroll
+        for (int i = 0; i < MI; i++) { ra[d][i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; ra[d][i][1] = ra[d][i][0]; }
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) load(d, s_begin + d);
+    // LN: LayerNorm of the input rows (gamma / beta live in the weights) from the producer's (sum, M2 about its own mean) per row
+    // and column tile: eight lanes per row split the tiles; mean from the sums, then M2 = sum of (M2_t + n_t (mean_t - mean)^2).
+    // The operand loads above are in flight meanwhile.
+    float row_s[MI], row_t[MI];
+#pragma unroll
+    for (int i = 0; i < MI; i++) { row_s[i] = 1.f; row_t[i] = 0.f; }
+    if (LN) {
+        const int tiles = a.in_tiles;
+        const float nb = (float)a.K / (float)tiles;
+        for (int r0 = 0; r0 < SM; r0 += 8 * NW) {
+            const int row = r0 + (tid >> 3), sub = tid & 7, m = m0 + row;
+            float sums[4], m2s[4], S1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int tl = sub + 8 * k;
+                float2 e = {0.f, 0.f};
+                if (row < SM && m < a.M && tl < tiles) e = *reinterpret_cast<const float2 *>(a.in_stats + ((size_t)m * tiles + tl) * 2);
+                sums[k] = e.x;
+                m2s[k] = e.y;
+                S1 += e.x;
+            }
+            S1 += __shfl_xor(S1, 1, 64); S1 += __shfl_xor(S1, 2, 64); S1 += __shfl_xor(S1, 4, 64);
+            const float mean = S1 / (float)a.K;
+            float M2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float dd = sums[k] / nb - mean;
+                if (sub + 8 * k < tiles) M2 += m2s[k] + nb * dd * dd;
+            }
+            M2 += __shfl_xor(M2, 1, 64); M2 += __shfl_xor(M2, 2, 64); M2 += __shfl_xor(M2, 4, 64);
+            if (sub == 0 && row < SM) {
+                const float rstd = 1.0f / sqrtf(M2 / (float)a.K + a.in_eps);
+                rowtab[0][row] = m < a.M ? rstd : 0.f;
+                rowtab[LN ? 1 : 0][row] = m < a.M ? -mean * rstd : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MI; i++) { row_s[i] = rowtab[0][32 * i + l32]; row_t[i] = rowtab[LN ? 1 : 0][32 * i + l32]; }
+    }
+    for (int base = 0; base < ns; base += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            const bool live = base + d < ns;
+            landed(d);
+            u32x4 ah[MI], al[MI];
+#pragma unroll
+            for (int i = 0; i < MI; i++) {
+                f32x4 q0 = ra[d][i][0], q1 = ra[d][i][1];
+                if (LN) { q0 = q0 * row_s[i] + row_t[i]; q1 = q1 * row_s[i] + row_t[i]; }
+                if (!(live && rok[i])) { q0 = f32x4{0.f, 0.f, 0.f, 0.f}; q1 = q0; }
+                if (a.in_relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { q0[e] = fmaxf(q0[e], 0.f); q1[e] = fmaxf(q1[e], 0.f); }
+                }
+                zs::s16::split8(q0, q1, ah[i], al[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; i++)
+#pragma unroll
+                for (int j = 0; j < NJ; j++)
+                    zs::s16::mfma3(acc[i][j], __builtin_bit_cast(u32x4, rb[d][j][0]), __builtin_bit_cast(u32x4, rb[d][j][1]), ah[i], al[i]);   // transposed: lane = pixel
+            load(d, s_begin + base + DEPTH + d);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // wave partials -> LDS: register 4q + e of lane (l32, half) = channel 8q + 4 half + e of pixel l32
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                *reinterpret_cast<f32x4 *>(&part[wave][32 * i + l32][32 * j + 8 * q + 4 * half]) =
+                    f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+    __syncthreads();
+    constexpr int QPR = SN / 4, QUADS = SM * QPR;
+    for (int e = tid; e < QUADS; e += 64 * NW) {
+        const int p = e / QPR, c = e % QPR;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(&part[0][p][4 * c]);
+#pragma unroll
+        for (int w = 1; w < NW; w++) v += *reinterpret_cast<const f32x4 *>(&part[w][p][4 * c]);
+        const int m = m0 + p, n = n0 + 4 * c;
+        if (m >= a.M || n >= a.N) continue;
+        const size_t o = (size_t)m * a.N + n;
+        if (a.scale) v *= *reinterpret_cast<const f32x4 *>(a.scale + n);
+        if (a.shift) v += *reinterpret_cast<const f32x4 *>(a.shift + n);
+        if (a.res1) v += *reinterpret_cast<const f32x4 *>(a.res1 + o);
+        if (a.res2) v += *reinterpret_cast<const f32x4 *>(a.res2 + o);
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = activate(v[k], a.act);
+        *reinterpret_cast<f32x4 *>(a.out + o) = v;
+    }
+}
+
+#undef ZS_GLDS
+
+// Tile shape of a problem.  Cost model from the measurements above: time ~ bytes through the busiest CU / 77 GB/s; more than
+// one workgroup per CU runs in rounds.
+struct Plan { int mi, nj, splits, mtiles, ntiles; };
+
+Plan plan(const Args &a) {
+    static const int cus = getenv("ZS_STREAM_CUS") ? atoi(getenv("ZS_STREAM_CUS")) : 256;
+    const int steps = (a.K + 15) / 16;
+    Plan best = {1, 2, 1, 0, 0};
+    double best_cost = 1e30;
+    const int mi = (a.M > 32 && a.M <= 64) ? 2 : 1;        // one row tile for 7 x 7 maps: the weights are read once
+    const long long mt = (a.M + 32 * mi - 1) / (32 * mi);
+    for (int nj = 1; nj <= 3; nj++) {
+        const long long nt = (a.N + 32 * nj - 1) / (32 * nj), T = mt * nt;
+        if (nj == 3 && (mi == 2 || nt * 96 > a.CoutPad)) continue;        // the weight rows are padded to 128 columns, not 96
+        if (a.out_stats && 32 * nj != a.stats_cols) continue;
+        const double rounds = (double)((T + cus - 1) / cus);
+        const double bytes = (32.0 * mi + 32.0 * nj) * 64.0 * steps;
+        const double cost = rounds * bytes / 77e3 + 0.4 * mi * nj;
+        if (cost < best_cost) { best_cost = cost; best = Plan{mi, nj, 1, (int)mt, (int)nt}; }
+    }
+    if (const char *f = getenv("ZS_STREAM_FORCE")) {       // measurement / debugging override: "nj"
+        const int nj = atoi(f);
+        const long long nt = (a.N + 32 * nj - 1) / (32 * nj);
+        if (nj >= 1 && nj <= 3 && !(nj == 3 && (mi == 2 || nt * 96 > a.CoutPad))) best = Plan{mi, nj, 1, (int)mt, (int)nt};
+    }
+    return best;
+}
+
+}  // namespace
+
+bool launch(const Args &a, hipStream_t st) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K & 15) || (a.N & 3) || (a.lda & 3) || a.out_stats) return false;
+    if (a.in_stats && (a.in_tiles <= 0 || a.in_tiles > 32 || a.lda != a.K)) return false;
+    if ((size_t)a.M * a.lda * 4 >= ((size_t)1 << 32)) return false;        // 32-bit lane offsets
+    const Plan p = plan(a);
+    const long long T = (long long)p.mtiles * p.ntiles;
+    // The kernel wins where its tiles fill the chip once (ViT qkv / fc1 at batch 1: 8.8 vs 13.6 us, 11 vs 19.6 us); with few
+    // tiles the small-tile kernel's narrower tiles (two workgroups per CU) are faster (proj 7.8 vs 8.6 us, 1 x 1 layers of
+    // 256 channels on 14 x 14 maps 4.9 vs 7.0 us) - tools/ubench/small_gemm.hip.  ZS_STREAM_MIN_TILES moves the line.
+    static const long long min_tiles = getenv("ZS_STREAM_MIN_TILES") ? atoll(getenv("ZS_STREAM_MIN_TILES")) : 192;
+    if (T < min_tiles) return false;
+    Geo g = {p.mtiles, p.ntiles, 1};
+    const dim3 grid((unsigned)(8 * ((T + 7) / 8)), 1);
+#define ZS_SG(MI_, NJ_)                                                                                              \
+    do {                                                                                                             \
+        if (a.in_stats) hipLaunchKernelGGL((stream_gemm_kernel<4, MI_, NJ_, 3, true>), grid, dim3(256), 0, st, a, g); \
+        else hipLaunchKernelGGL((stream_gemm_kernel<4, MI_, NJ_, 3, false>), grid, dim3(256), 0, st, a, g);           \
+    } while (0)
+    if (p.mi == 2) { if (p.nj == 1) ZS_SG(2, 1); else ZS_SG(2, 2); }
+    else if (p.nj == 1) ZS_SG(1, 1);
+    else if (p.nj == 2) ZS_SG(1, 2);
+    else ZS_SG(1, 3);
+#undef ZS_SG
+    return true;
+}
+
+}  // namespace stream_gemm
+}  // namespace zs
