@@ -351,6 +351,14 @@ int zs_masked_resample(const float *map, const float *mask, int batch, int chann
 int zs_seen_surface(const float *depth, const float *intr, const float *mask, int batch, int H, int W,
                     int Ho, int Wo, float *seen_points, float *mean, float *scale, float *coord_dsp,
                     float *mask_dsp, void *stream);
+/* The same chain cut into 64 pixel chunks per image (three launches: chunk sums -> mean + chunk max radius -> scale +
+ * normalise / resample): 80 -> ~12 us at batch 1, where one workgroup per image is a chain of dependent passes through one
+ * CU.  The chunk sums are added in chunk order (reproducible; a different association than the one-workgroup form, ~1e-7
+ * relative).  workspace: zs_seen_surface_workspace_bytes(batch) bytes; NULL = zs_seen_surface. */
+size_t zs_seen_surface_workspace_bytes(int batch);
+int zs_seen_surface_ws(const float *depth, const float *intr, const float *mask, int batch, int H, int W,
+                       int Ho, int Wo, float *seen_points, float *mean, float *scale, float *coord_dsp,
+                       float *mask_dsp, void *workspace, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Depth metrics with least-squares scale/shift alignment in disparity space
@@ -485,6 +493,12 @@ int zs_conv2d_fused_cols(int M, int Cout);
 /* y = [relu]( GroupNorm_32(x) * gamma + beta + r ) in ONE pass over x, from the (sum, sum of squares) tiles a fused launch wrote
  * (out_mode 1; `tiles` per sample).  r = residual [B][HW][C] (may be NULL), or GroupNorm_32(residual) * res_gamma + res_beta when
  * res_stats is given (the projection shortcut of a bottleneck's first block). */
+/* y = max_pool_{k, stride, -inf padding}( relu(GroupNorm_32(x) * gamma + beta) ) from a fused launch's group statistics (timm
+ * ResNetV2 stem: StdConv -> GroupNormAct -> MaxPool2dSame): one small launch turns the tile sums into `table` [B][C][2]
+ * (scale, shift; caller-provided scratch), the pooling launch applies them on load - the normalised map is never written. */
+int zs_gn_relu_max_pool_nhwc(const float *x, const float *stats, int tiles, const float *gamma, const float *beta,
+                             float *table, float *y, int batch, int Hin, int Win, int C, int Hout, int Wout, int k,
+                             int stride, int pad_t, int pad_l, float eps, void *stream);
 int zs_group_norm_apply_stats(const float *x, const float *stats, int tiles, const float *gamma, const float *beta,
                               const float *residual, const float *res_stats, int res_tiles, const float *res_gamma,
                               const float *res_beta, float *y, int batch, int HW, int C, float eps, int relu, void *stream);

@@ -100,6 +100,9 @@ SIGNATURES = {
                                     ctypes.c_float, _c_void_p, _c_void_p, _c_void_p]),
     "zs_seen_surface": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
                                  _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "zs_seen_surface_workspace_bytes": (_c_size_t, [_c_int]),
+    "zs_seen_surface_ws": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                    _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "zs_depth_metrics": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, ctypes.c_float,
                                   ctypes.POINTER(ctypes.c_float), _c_int, _c_void_p, _c_void_p, _c_void_p,
                                   _c_void_p]),
@@ -115,6 +118,7 @@ SIGNATURES = {
     "zs_conv2d_nhwc_fused": (_c_int, [_c_void_p] * 7 + [_c_int] * 13 + [ctypes.c_float, ctypes.c_float, _c_int,
                                                                         _c_void_p, _c_void_p, _c_void_p]),
     "zs_conv2d_fused_cols": (_c_int, [_c_int, _c_int]),
+    "zs_gn_relu_max_pool_nhwc": (_c_int, [_c_void_p, _c_void_p, _c_int] + [_c_void_p] * 4 + [_c_int] * 10 + [ctypes.c_float, _c_void_p]),
     "zs_group_norm_apply_stats": (_c_int, [_c_void_p, _c_void_p, _c_int] + [_c_void_p] * 4 + [_c_int] + [_c_void_p] * 3 +
                                   [_c_int, _c_int, _c_int, ctypes.c_float, _c_int, _c_void_p]),
     "zs_group_norm_nhwc": (_c_int, [_c_void_p] * 5 + [_c_int, _c_int, _c_int, _c_int, ctypes.c_float, _c_int,

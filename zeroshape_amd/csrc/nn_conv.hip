@@ -1447,8 +1447,9 @@ extern "C" int zs_conv2d_nhwc_fused(const float *in, const float *packed_w, cons
     const bool gn_in = f.in_mode == 1;
     int gshift = 0;
     while ((32 << gshift) < Cin) gshift++;
-    if ((flags & need) != need || (flags & (ZS_CONV_IN_RELU | ZS_CONV_IN_DILATE2 | ZS_CONV_FORCE_LARGE)) || in_scale != 1.0f || in_shift != 0.0f ||
-        f.in_mode < 0 || f.in_mode > 2 || f.out_mode < 0 || f.out_mode > 2 || (Cout & 3) || (Cin & 7) ||
+    if ((flags & need) != need || (flags & (ZS_CONV_IN_RELU | ZS_CONV_IN_DILATE2 | ZS_CONV_FORCE_LARGE)) ||
+        (f.in_mode && (in_scale != 1.0f || in_shift != 0.0f || (Cin & 7))) ||      // (without an input mode: any layer, e.g. the 7 x 7 stem)
+        f.in_mode < 0 || f.in_mode > 2 || f.out_mode < 0 || f.out_mode > 2 || (Cout & 3) ||
         (f.in_mode && !f.in_stats) || (f.out_mode && !f.out_stats) ||
         (gn_in && (!f.in_gamma || !f.in_beta || f.in_groups != 32 || (32 << gshift) != Cin || Cin > XF_MAXC || f.in_tiles <= 0 ||
                    (batch > 1 && hw_in % SM) || (batch > 1 && hw_out % SM))) ||

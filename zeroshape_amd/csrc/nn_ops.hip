@@ -605,13 +605,70 @@ __global__ __launch_bounds__(256) void max_pool_kernel(const float *__restrict__
     y[i] = m;
 }
 
+// 64 channels x 4 pixel slices per workgroup (a lane per channel walking all pixels alone was 13 us for a 7 x 7 map: a chain of
+// dependent adds on 8 workgroups); the four slice sums are added in slice order
 __global__ __launch_bounds__(256) void global_mean_kernel(const float *__restrict__ x, float *__restrict__ y, int HW,
                                                           int C) {
-    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float part[4][64];
+    const int b = blockIdx.y, cl = threadIdx.x & 63, slice = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
     float s = 0.f;
-    for (int p = 0; p < HW; p++) s += x[((size_t)b * HW + p) * C + c];
-    y[(size_t)b * C + c] = s / HW;
+    if (c < C)
+        for (int p = slice; p < HW; p += 4) s += x[((size_t)b * HW + p) * C + c];
+    part[slice][cl] = s;
+    __syncthreads();
+    if (slice == 0 && c < C) y[(size_t)b * C + c] = ((part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl])) / HW;
+}
+
+// ---- GroupNorm(32) + ReLU riding on the max pool behind it (timm ResNetV2 stem: conv -> GroupNormAct -> MaxPool2dSame) ----
+// The stem convolution's epilogue wrote per-tile group sums (zs_conv_fuse.out_mode 1); gn_table_kernel turns them into one
+// (scale, shift) per channel (one small workgroup per sample: 392 tiles at 112 x 112 would be too much for every pooling
+// workgroup to re-reduce), max_pool_affine_kernel pools relu(x * scale + shift): the normalised map is never written.
+__global__ __launch_bounds__(256) void gn_table_kernel(const float *__restrict__ stats, int tiles, const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta, float *__restrict__ table, int HW, int C,
+                                                       int gshift, float eps) {
+    __shared__ double red[8][32][2];
+    __shared__ float stat[32][2];
+    const int tid = threadIdx.x, sample = blockIdx.x, g = tid & 31, slice = tid >> 5;
+    double S = 0.0, Q = 0.0;
+    for (int tl = slice; tl < tiles; tl += 8) {
+        const float2 e = *reinterpret_cast<const float2 *>(stats + ((size_t)(sample * tiles + tl) * 32 + g) * 2);
+        S += (double)e.x;
+        Q += (double)e.y;
+    }
+    red[slice][g][0] = S;
+    red[slice][g][1] = Q;
+    __syncthreads();
+    if (tid < 32) {
+        double s2 = 0.0, q2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { s2 += red[k][tid][0]; q2 += red[k][tid][1]; }
+        const double cnt = (double)HW * (double)(1 << gshift), mean = s2 / cnt, var = fmax(q2 / cnt - mean * mean, 0.0);
+        stat[tid][0] = (float)mean;
+        stat[tid][1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const float sc = gamma[c] * stat[c >> gshift][1];
+        table[((size_t)sample * C + c) * 2] = sc;
+        table[((size_t)sample * C + c) * 2 + 1] = beta[c] - stat[c >> gshift][0] * sc;
+    }
+}
+
+__global__ __launch_bounds__(256) void max_pool_affine_kernel(const float *__restrict__ x, const float *__restrict__ table,
+                                                              float *__restrict__ y, int B, int Hin, int Win, int C, int Hout,
+                                                              int Wout, int k, int stride, int pad_t, int pad_l) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)B * Hout * Wout * C;
+    if (i >= total) return;
+    const int c = i % C, ox = (i / C) % Wout, oy = (i / C / Wout) % Hout, b = i / C / Wout / Hout;
+    const float sc = table[((size_t)b * C + c) * 2], sh = table[((size_t)b * C + c) * 2 + 1];
+    float m = -INFINITY;
+    for (int ky = 0; ky < k; ky++)
+        for (int kx = 0; kx < k; kx++) {
+            const int iy = oy * stride - pad_t + ky, ix = ox * stride - pad_l + kx;
+            if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win)
+                m = fmaxf(m, fmaxf(x[(((size_t)b * Hin + iy) * Win + ix) * C + c] * sc + sh, 0.f));
+        }
+    y[i] = m;
 }
 
 __global__ __launch_bounds__(256) void upsample2x_kernel(const float *__restrict__ x, float *__restrict__ y, int B,
@@ -883,6 +940,21 @@ extern "C" int zs_group_norm_apply_stats(const float *x, const float *stats, int
     return zs::check_launch("zs_group_norm_apply_stats") ? 1 : 0;
 }
 
+extern "C" int zs_gn_relu_max_pool_nhwc(const float *x, const float *stats, int tiles, const float *gamma, const float *beta,
+                                        float *table, float *y, int batch, int Hin, int Win, int C, int Hout, int Wout, int k,
+                                        int stride, int pad_t, int pad_l, float eps, void *stream) {
+    int gshift = 0;
+    while ((32 << gshift) < C) gshift++;
+    ZS_REQUIRE(batch >= 0 && Hin > 0 && Win > 0 && C >= 32 && (32 << gshift) == C && tiles > 0 && Hout > 0 && Wout > 0 && k > 0 && stride > 0,
+               "zs_gn_relu_max_pool_nhwc: bad size (B=%d %dx%dx%d tiles=%d; C = 32 * 2^k)", batch, Hin, Win, C, tiles);
+    if (batch == 0) return 1;
+    ZS_REQUIRE(x && stats && gamma && beta && table && y, "zs_gn_relu_max_pool_nhwc: null pointer");
+    hipLaunchKernelGGL(gn_table_kernel, dim3(batch), dim3(256), 0, S(stream), stats, tiles, gamma, beta, table, Hin * Win, C, gshift, eps);
+    hipLaunchKernelGGL(max_pool_affine_kernel, dim3(blocks_for((size_t)batch * Hout * Wout * C)), dim3(256), 0, S(stream), x, table, y,
+                       batch, Hin, Win, C, Hout, Wout, k, stride, pad_t, pad_l);
+    return zs::check_launch("zs_gn_relu_max_pool_nhwc") ? 1 : 0;
+}
+
 extern "C" int zs_layer_norm(const float *x, const float *gamma, const float *beta, float *y, int rows, int C,
                              float eps, void *stream) {
     ZS_REQUIRE(rows >= 0 && C > 0, "zs_layer_norm: bad size (rows=%d C=%d)", rows, C);
@@ -956,7 +1028,7 @@ extern "C" int zs_global_mean_nhwc(const float *x, float *y, int batch, int HW, 
     ZS_REQUIRE(batch >= 0 && batch <= 65535 && HW > 0 && C > 0, "zs_global_mean_nhwc: bad size");
     if (batch == 0) return 1;
     ZS_REQUIRE(x && y, "zs_global_mean_nhwc: null pointer");
-    hipLaunchKernelGGL(global_mean_kernel, dim3((C + 255) / 256, batch), dim3(256), 0, S(stream), x, y, HW, C);
+    hipLaunchKernelGGL(global_mean_kernel, dim3((C + 63) / 64, batch), dim3(256), 0, S(stream), x, y, HW, C);
     return zs::check_launch("zs_global_mean_nhwc") ? 1 : 0;
 }
 

@@ -241,6 +241,150 @@ __global__ __launch_bounds__(BLOCK) void seen_surface_kernel(
     }
 }
 
+// ---- the same chain on SEEN_CH workgroups per image (three launches) ----
+// One 1024-lane workgroup per image is 80 us at batch 1 (three dependent passes of 49 pixels per lane, and 1.4 MB of
+// stores through one CU).  Here every image is cut into SEEN_CH pixel chunks: launch 1 = per-chunk masked sums, launch 2 =
+// mean (the chunk sums in chunk order, the same value in every workgroup) + per-chunk max radius, launch 3 = scale (max of
+// the chunk maxima) + normalise / resample of the chunk.  ws: [B][SEEN_CH][8] floats.
+constexpr int SEEN_CH = 64, SEEN_T = 256;
+
+__device__ __forceinline__ float block_reduce256(float v, float *lds, bool is_max) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float y = __shfl_xor(v, o, 64);
+        v = is_max ? fmaxf(v, y) : v + y;
+    }
+    __syncthreads();
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    return is_max ? fmaxf(fmaxf(lds[0], lds[1]), fmaxf(lds[2], lds[3])) : (lds[0] + lds[1]) + (lds[2] + lds[3]);
+}
+
+__device__ __forceinline__ void chunk_range(int n, int c, int &lo, int &hi) {
+    const int per = (n + SEEN_CH - 1) / SEEN_CH;
+    lo = c * per;
+    hi = min(n, lo + per);
+}
+
+__global__ __launch_bounds__(SEEN_T) void seen_sums_kernel(const float *__restrict__ depth, const float *__restrict__ intr,
+                                                           const float *__restrict__ mask, int H, int W, float *__restrict__ ws) {
+    __shared__ float lds[4];
+    const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x, n = H * W;
+    const float *D = depth + (size_t)b * n, *M = mask + (size_t)b * n;
+    float Ki[9];
+    inverse3x3(intr + (size_t)b * 9, Ki);
+    int lo, hi;
+    chunk_range(n, c, lo, hi);
+    float sx = 0.f, sy = 0.f, sz = 0.f, cnt = 0.f;
+    for (int i = lo + tid; i < hi; i += SEEN_T)
+        if (M[i] > 0.5f) {
+            const Point p = unproject(Ki, i % W, i / W, D[i]);
+            sx += p.x; sy += p.y; sz += p.z; cnt += 1.f;
+        }
+    sx = block_reduce256(sx, lds, false);
+    sy = block_reduce256(sy, lds, false);
+    sz = block_reduce256(sz, lds, false);
+    cnt = block_reduce256(cnt, lds, false);
+    if (tid == 0) {
+        float *o = ws + ((size_t)b * SEEN_CH + c) * 8;
+        o[0] = sx; o[1] = sy; o[2] = sz; o[3] = cnt;
+    }
+}
+
+// mean of the image from the chunk sums, in chunk order
+__device__ __forceinline__ void seen_mean(const float *__restrict__ ws, int b, float &mx, float &my, float &mz, float &cnt) {
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    cnt = 0.f;
+    for (int c = 0; c < SEEN_CH; c++) {
+        const float *o = ws + ((size_t)b * SEEN_CH + c) * 8;
+        sx += o[0]; sy += o[1]; sz += o[2]; cnt += o[3];
+    }
+    mx = sx / cnt; my = sy / cnt; mz = sz / cnt;
+}
+
+__global__ __launch_bounds__(SEEN_T) void seen_radius_kernel(const float *__restrict__ depth, const float *__restrict__ intr,
+                                                             const float *__restrict__ mask, int H, int W, float *__restrict__ ws) {
+    __shared__ float lds[4];
+    const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x, n = H * W;
+    const float *D = depth + (size_t)b * n, *M = mask + (size_t)b * n;
+    float Ki[9];
+    inverse3x3(intr + (size_t)b * 9, Ki);
+    float mx, my, mz, cnt;
+    seen_mean(ws, b, mx, my, mz, cnt);
+    int lo, hi;
+    chunk_range(n, c, lo, hi);
+    float r = -INFINITY;
+    for (int i = lo + tid; i < hi; i += SEEN_T)
+        if (M[i] > 0.5f) {
+            const Point p = unproject(Ki, i % W, i / W, D[i]);
+            const float dx = p.x - mx, dy = p.y - my, dz = p.z - mz;
+            r = fmaxf(r, sqrtf(dx * dx + dy * dy + dz * dz));
+        }
+    r = block_reduce256(r, lds, true);
+    if (tid == 0) ws[((size_t)b * SEEN_CH + c) * 8 + 4] = r;
+}
+
+__global__ __launch_bounds__(SEEN_T) void seen_apply_kernel(
+    const float *__restrict__ depth, const float *__restrict__ intr, const float *__restrict__ mask, int H, int W,
+    int Ho, int Wo, const float *__restrict__ ws, float *__restrict__ seen, float *__restrict__ mean, float *__restrict__ scale,
+    float *__restrict__ coord_dsp, float *__restrict__ mask_dsp) {
+    const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x, n = H * W;
+    const float *D = depth + (size_t)b * n, *M = mask + (size_t)b * n;
+    float Ki[9];
+    inverse3x3(intr + (size_t)b * 9, Ki);
+    float mx, my, mz, cnt;
+    seen_mean(ws, b, mx, my, mz, cnt);
+    float r = -INFINITY;
+    for (int k = 0; k < SEEN_CH; k++) r = fmaxf(r, ws[((size_t)b * SEEN_CH + k) * 8 + 4]);
+    if (!(cnt > 0.f)) r = NAN;
+    if (c == 0 && tid == 0) {
+        mean[b * 3] = mx; mean[b * 3 + 1] = my; mean[b * 3 + 2] = mz;
+        scale[b] = r;
+    }
+    auto normalised = [&](int i) -> Point {
+        Point q = {0.f, 0.f, 0.f};
+        if (M[i] > 0.5f) {
+            const Point p = unproject(Ki, i % W, i / W, D[i]);
+            q.x = (p.x - mx) / r; q.y = (p.y - my) / r; q.z = (p.z - mz) / r;
+        }
+        return q;
+    };
+    float *S = seen + (size_t)b * n * 3;
+    const bool same = coord_dsp && Ho == H && Wo == W;
+    const float inv_eps = 1.0f + 1.e-6f;
+    int lo, hi;
+    chunk_range(n, c, lo, hi);
+    for (int i = lo + tid; i < hi; i += SEEN_T) {
+        const Point q = normalised(i);
+        S[i * 3] = q.x; S[i * 3 + 1] = q.y; S[i * 3 + 2] = q.z;
+        if (same) {
+            const bool valid = M[i] > 0.5f;
+            float *O = coord_dsp + (size_t)b * 3 * n;
+            O[i] = valid ? q.x / inv_eps : 0.f;
+            O[n + i] = valid ? q.y / inv_eps : 0.f;
+            O[2 * n + i] = valid ? q.z / inv_eps : 0.f;
+            mask_dsp[(size_t)b * n + i] = valid ? 1.f : 0.f;
+        }
+    }
+    if (!coord_dsp || same) return;
+    const int no = Ho * Wo;
+    const float sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
+    float *O = coord_dsp + (size_t)b * 3 * no;
+    chunk_range(no, c, lo, hi);
+    for (int o = lo + tid; o < hi; o += SEEN_T) {
+        const Tap ty = bilinear_tap(o / Wo, sh, H), tx = bilinear_tap(o % Wo, sw, W);
+        const int a00 = ty.i0 * W + tx.i0, a01 = ty.i0 * W + tx.i1, a10 = ty.i1 * W + tx.i0, a11 = ty.i1 * W + tx.i1;
+        const Point q00 = normalised(a00), q01 = normalised(a01), q10 = normalised(a10), q11 = normalised(a11);
+        const float m = bilinear_mix(ty, tx, M[a00] > 0.5f ? 1.f : 0.f, M[a01] > 0.5f ? 1.f : 0.f,
+                                     M[a10] > 0.5f ? 1.f : 0.f, M[a11] > 0.5f ? 1.f : 0.f);
+        O[o] = masked_out(bilinear_mix(ty, tx, q00.x, q01.x, q10.x, q11.x), m, 0.f);
+        O[no + o] = masked_out(bilinear_mix(ty, tx, q00.y, q01.y, q10.y, q11.y), m, 0.f);
+        O[2 * no + o] = masked_out(bilinear_mix(ty, tx, q00.z, q01.z, q10.z, q11.z), m, 0.f);
+        mask_dsp[(size_t)b * no + o] = m > 0.5f ? 1.f : 0.f;
+    }
+}
+
 bool bad_hw(const char *what, int batch, int H, int W) {
     if (batch < 0 || H <= 0 || W <= 0 || (long long)H * W > (1 << 28)) {
         zs::set_err("%s: bad size (batch=%d H=%d W=%d)", what, batch, H, W);
@@ -305,5 +449,32 @@ extern "C" int zs_seen_surface(const float *depth, const float *intr, const floa
     }
     hipLaunchKernelGGL(seen_surface_kernel, dim3(batch), dim3(BLOCK), 0, static_cast<hipStream_t>(stream), depth,
                        intr, mask, H, W, Ho, Wo, seen_points, mean, scale, coord_dsp, mask_dsp);
+    return zs::check_launch("zs_seen_surface") ? 1 : 0;
+}
+
+extern "C" size_t zs_seen_surface_workspace_bytes(int batch) {
+    return batch > 0 ? (size_t)batch * SEEN_CH * 8 * sizeof(float) : 0;
+}
+
+extern "C" int zs_seen_surface_ws(const float *depth, const float *intr, const float *mask, int batch, int H, int W,
+                                  int Ho, int Wo, float *seen_points, float *mean, float *scale, float *coord_dsp,
+                                  float *mask_dsp, void *workspace, void *stream) {
+    if (!workspace)
+        return zs_seen_surface(depth, intr, mask, batch, H, W, Ho, Wo, seen_points, mean, scale, coord_dsp, mask_dsp, stream);
+    if (bad_hw("zs_seen_surface", batch, H, W)) return 0;
+    if (coord_dsp && bad_hw("zs_seen_surface", batch, Ho, Wo)) return 0;
+    if (batch == 0) return 1;
+    if (!depth || !intr || !mask || !seen_points || !mean || !scale || (coord_dsp && !mask_dsp)) {
+        zs::set_err("zs_seen_surface: null pointer");
+        return 0;
+    }
+    if (batch > 65535) { zs::set_err("zs_seen_surface_ws: batch %d > 65535", batch); return 0; }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *ws = static_cast<float *>(workspace);
+    const dim3 grid(SEEN_CH, batch);
+    hipLaunchKernelGGL(seen_sums_kernel, grid, dim3(SEEN_T), 0, st, depth, intr, mask, H, W, ws);
+    hipLaunchKernelGGL(seen_radius_kernel, grid, dim3(SEEN_T), 0, st, depth, intr, mask, H, W, ws);
+    hipLaunchKernelGGL(seen_apply_kernel, grid, dim3(SEEN_T), 0, st, depth, intr, mask, H, W, Ho, Wo, ws, seen_points, mean, scale,
+                       coord_dsp, mask_dsp);
     return zs::check_launch("zs_seen_surface") ? 1 : 0;
 }

@@ -108,11 +108,15 @@ def pack_resnetv2(sd, p, device, layers=(3, 4, 9)):
 def run_resnetv2(x, pk, in_scale=1.0, in_shift=0.0, on_stage=None):
     """x [B,H,W,4] (RGB + zero channel) -> list of stage outputs.  on_stage(index, output) is called as soon as a stage's
     output is queued (the caller forks work that needs only that tap)."""
+    B, H, W = x.shape[0], x.shape[1], x.shape[2]
+    if ops.fused_ok(x) and B * (H // 4) * (W // 4) <= FUSED_GN_MAX_ROWS and (B == 1 or ((H // 2) * (W // 2)) % 32 == 0):
+        # the stem's GroupNorm + ReLU ride on the max pool (statistics from the convolution's epilogue), then the fused stages
+        x, st = ops.conv2d(x, pk["stem"], in_scale=in_scale, in_shift=in_shift, stats_out="group")
+        x = ops.gn_relu_max_pool(x, st, pk["stem_gn"][0], pk["stem_gn"][1], 3, 2, "same", GN_EPS)
+        return _run_resnetv2_fused(x, pk, on_stage)
     x = ops.conv2d(x, pk["stem"], in_scale=in_scale, in_shift=in_shift)
     x = ops.group_norm(x, *pk["stem_gn"], relu=True)
     x = ops.max_pool(x, 3, 2, "same")
-    if ops.fused_ok(x) and x.shape[0] * x.shape[1] * x.shape[2] <= FUSED_GN_MAX_ROWS:
-        return _run_resnetv2_fused(x, pk, on_stage)
     feats = []
     for blocks in pk["stages"]:
         for blk in blocks:

@@ -325,6 +325,29 @@ def max_pool(x, k=3, stride=2, padding=1):
     return y
 
 
+def gn_relu_max_pool(x, st, gamma, beta, k=3, stride=2, padding=1, eps=1e-5):
+    """max_pool(relu(GroupNorm(32)(x))) from the Stats 'group' the producing convolution wrote (zs_gn_relu_max_pool_nhwc: a
+    tiny table launch + the pooling launch; the normalised map is never written).  padding as max_pool."""
+    lib = _lib.load()
+    _chk(x, "gn_relu_max_pool input")
+    B, H, W, C = x.shape
+
+    def size(n):
+        if padding == "same":
+            out = -(-n // stride)
+            return out, max((out - 1) * stride + k - n, 0) // 2
+        return (n + 2 * padding - k) // stride + 1, padding
+    Ho, pt = size(H)
+    Wo, pl = size(W)
+    y = torch.empty(B, Ho, Wo, C, dtype=torch.float32, device=x.device)
+    table = torch.empty(B, C, 2, dtype=torch.float32, device=x.device)
+    with _lib.on(x.device):
+        _lib.check(lib.zs_gn_relu_max_pool_nhwc(_lib.ptr(x), _lib.ptr(st.data), st.tiles, _lib.ptr(gamma), _lib.ptr(beta),
+                                                _lib.ptr(table), _lib.ptr(y), B, H, W, C, Ho, Wo, k, stride, pt, pl, float(eps),
+                                                _stream(x)), "zs_gn_relu_max_pool_nhwc")
+    return y
+
+
 def global_mean(x):
     """[B,H,W,C] -> [B,C]."""
     lib = _lib.load()

@@ -137,10 +137,11 @@ def seen_surface(opt, depth_map, intr, mask_input_map, dsp=None):
     scale = torch.empty(batch_size, dtype=torch.float32, device=dev)
     coord = torch.empty(batch_size, 3, Ho, Wo, dtype=torch.float32, device=dev)
     mask_dsp = torch.empty(batch_size, 1, Ho, Wo, dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.zs_seen_surface_workspace_bytes(batch_size) // 4, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(lib.zs_seen_surface(_lib.ptr(d), _lib.ptr(K), _lib.ptr(m), batch_size, H, W, Ho, Wo,
-                                       _lib.ptr(seen), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(coord),
-                                       _lib.ptr(mask_dsp), _lib.current_stream_ptr(dev)), "zs_seen_surface")
+        _lib.check(lib.zs_seen_surface_ws(_lib.ptr(d), _lib.ptr(K), _lib.ptr(m), batch_size, H, W, Ho, Wo,
+                                          _lib.ptr(seen), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(coord),
+                                          _lib.ptr(mask_dsp), _lib.ptr(ws), _lib.current_stream_ptr(dev)), "zs_seen_surface")
     return seen, coord, mask_dsp, mean, scale
 
 
