@@ -373,7 +373,8 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             # Implicit.prepare's verdict on these weights: max |f16x3 - f32| logit over the probe points, and the
             # arithmetic it selected (requested: --precision)
-            "calibration": dict(calibration or {}, requested=args.precision),
+            "calibration": dict({k: (v.detach().cpu().tolist() if hasattr(v, "detach") else v) for k, v in (calibration or {}).items()},
+                                requested=args.precision),
         }
         if exact_f32 is not None:
             line["exact_f32"] = exact_f32

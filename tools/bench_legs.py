@@ -538,7 +538,7 @@ def trained_leg(dev, iterations=304):
     net, latent = r.graph.impl_network, var.latent_depth[:1].detach().clone()
     axis = torch.linspace(-1.5, 1.5, 129, device=dev)
     st = net.prepare(latent)
-    cal = dict(net.last_calibration)
+    cal = {k: (v.detach().cpu().tolist() if hasattr(v, "detach") else v) for k, v in net.last_calibration.items()}
     exact = net.query_grid(latent, axis, apply_sigmoid=False, state=net.prepare(latent, "f32"))
     net.envelope_guard = False
     try:

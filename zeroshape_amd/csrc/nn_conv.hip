@@ -1151,6 +1151,13 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
         const int gshift = a.fz.in_gshift;                          // channels per group = 1 << gshift
         const double cnt = (double)a.Hin * a.Win * (double)(1 << gshift);
         const int tiles = a.fz.in_tiles, g = tid & 31, slice = tid >> 5;
+        float gam[XF_MAXC / 256], bet[XF_MAXC / 256];             // this thread's channels' affine: requested before the sums are
+#pragma unroll                                                     // waited for (one memory round trip instead of two)
+        for (int k = 0; k < XF_MAXC / 256; k++) {
+            const int c = tid + 256 * k;
+            gam[k] = c < a.Cin ? a.fz.in_gamma[c] : 0.f;
+            bet[k] = c < a.Cin ? a.fz.in_beta[c] : 0.f;
+        }
         float S = 0.f, Q = 0.f;
         for (int tl = slice; tl < tiles; tl += 8) {
             const float2 e = *reinterpret_cast<const float2 *>(a.fz.in_stats + ((size_t)(sample * tiles + tl) * 32 + g) * 2);
@@ -1169,11 +1176,15 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
             xf_stat[tid][1] = (float)(1.0 / sqrt(var + (double)a.fz.in_eps));
         }
         __syncthreads();
-        for (int c = tid; c < a.Cin; c += 256) {
-            const int g2 = c >> gshift;
-            const float sc = a.fz.in_gamma[c] * xf_stat[g2][1];
-            xf_tab[0][c] = sc;
-            xf_tab[1][c] = a.fz.in_beta[c] - xf_stat[g2][0] * sc;
+#pragma unroll
+        for (int k = 0; k < XF_MAXC / 256; k++) {
+            const int c = tid + 256 * k;
+            if (c < a.Cin) {
+                const int g2 = c >> gshift;
+                const float sc = gam[k] * xf_stat[g2][1];
+                xf_tab[0][c] = sc;
+                xf_tab[1][c] = bet[k] - xf_stat[g2][0] * sc;
+            }
         }
         __syncthreads();
     }
