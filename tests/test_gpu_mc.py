@@ -57,7 +57,12 @@ def test_convert_to_explicit_contract_and_full_size():
     vol = torch.from_numpy(_sphere(G, 1.0, c=(0, 0, 0))[0]).cuda()
     meshes, clouds = E.convert_to_explicit(opt, [vol, vol.cpu().numpy()], isoval=0.5, to_pointcloud=True)
     assert len(meshes) == 2 and clouds.shape == (2, 10000, 3) and clouds.dtype == np.float64
-    assert meshes[0].faces.shape[1] == 3 and len(meshes[0].vertices) == 3 * len(meshes[0].faces)
+    # the indexed form of mcubes.marching_cubes (utils/eval_3D.py:250-256): welded vertices, the triangle set unchanged
+    m = meshes[0]
+    assert m.faces.shape[1] == 3 and len(m.faces) == len(m.triangles)
+    assert len(np.unique(m.vertices.view(np.uint32), axis=0)) == len(m.vertices) < 3 * len(m.faces)
+    assert np.array_equal(m.vertices[m.faces].view(np.uint32), (m.triangles + np.float32(0)).view(np.uint32))
+    assert len(m.vertices) - 3 * len(m.faces) // 2 + len(m.faces) in (2, 0, 4)      # Euler characteristic of a closed surface (V - E + F, E = 3F/2)
     # world coordinates use the reference's S = G scaling: radius 1.0 * (G-1)/G, centre -1.5/G
     r = np.linalg.norm(clouds[0] - (-1.5 / G), axis=1)
     assert abs(r.mean() - (G - 1) / G) < 2e-3 and r.std() < 2e-3

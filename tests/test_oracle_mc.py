@@ -94,3 +94,21 @@ def test_vectorised_extraction_and_sampling_equal_the_loops_bit_for_bit():
         p2, i2 = M.sample_surface_loop(b, 300, seed=G)
         assert np.array_equal(i1, i2) and np.array_equal(p1.view(np.uint32), p2.view(np.uint32))
     assert len(M.marching_cubes(np.zeros((4, 4, 4), np.float32), 0.5, np.float32(1.0), 0.0)) == 0
+
+
+def test_simple_mesh_is_indexed_like_mcubes():
+    """utils/eval_3D.py:250-256: mcubes.marching_cubes returns welded (vertices, triangles); SimpleMesh welds the kernel's soup
+    lazily (unique rows: shared vertices are bit-identical) and keeps the triangle set."""
+    import numpy as np
+    from oracle import mc_ref as M
+    from zeroshape_amd.utils.eval_3D import SimpleMesh
+    G = 20
+    vol = _sphere(G, 0.9, c=(0, 0, 0))[0]
+    tris = M.marching_cubes(vol, 0.5, np.float32(3.0 / G), -1.5)
+    m = SimpleMesh(tris)
+    assert len(m.faces) == len(tris) and len(m.vertices) < 3 * len(tris)
+    assert len(np.unique(m.vertices.view(np.uint32), axis=0)) == len(m.vertices)
+    assert np.array_equal(m.vertices[m.faces].view(np.uint32), (tris + np.float32(0)).view(np.uint32))
+    assert len(m.vertices) - len(m.faces) // 2 == 2          # closed genus-0 surface: V - E + F = 2 with E = 3F/2
+    e = SimpleMesh(np.zeros((0, 3, 3), np.float32))
+    assert e.vertices.shape == (0, 3) and e.faces.shape == (0, 3)

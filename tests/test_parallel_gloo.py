@@ -56,6 +56,19 @@ def _worker(rank, world, initfile, G, B):
         cover[b:e] = 1
         dist.all_reduce(cover)
         assert torch.all(cover == 1)
+        # the sharded pose search refuses ranks that hold different clouds
+        from zeroshape_amd.utils.eval_3D import _check_identical_inputs
+        pred, gt, order = torch.randn(50, 3), torch.randn(1, 40, 3), torch.arange(24, dtype=torch.int32)
+        _check_identical_inputs(pred, gt, order)                       # same seed on every rank: passes
+        bad = pred.clone()
+        if rank == world - 1:
+            bad[7, 1] += 1e-3
+        try:
+            _check_identical_inputs(bad, gt, order)
+            raised = False
+        except RuntimeError:
+            raised = True
+        assert raised, "rank %d: differing clouds were accepted" % rank
     finally:
         dist.destroy_process_group()
 

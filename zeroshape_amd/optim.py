@@ -99,7 +99,7 @@ class FusedAdamW(torch.optim.Optimizer):
             with _lib.on(cls["device"]):
                 _lib.check(lib.zs_adamw_multi(_lib.ptr(cls["tab_dev"]), _lib.ptr(cls["ct"]), _lib.ptr(cls["cs"]), cls["nchunks"],
                                               betas[0], betas[1], eps, cls["step"], _lib.ptr(self._clip),
-                                              _lib.ptr(self.__dict__.get("_skipped")),
+                                              _lib.ptr(cls["skipped"]),
                                               _lib.current_stream_ptr(cls["device"])), "zs_adamw_multi")
         self._clip = None
         A.bump_generation()                   # parameters changed behind torch's version counters
@@ -135,6 +135,7 @@ class FusedAdamW(torch.optim.Optimizer):
         """Classes of parameters that share (step count, betas, eps, device), each with its host table, chunk tables
         on the device and the group index of every parameter."""
         counts = self.__dict__.setdefault("_counts", {})
+        skip_of = self.__dict__.setdefault("_skip_of", {})
         by_key = {}
         for gi, p in live:
             if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
@@ -146,9 +147,12 @@ class FusedAdamW(torch.optim.Optimizer):
             if p not in counts:
                 counts[p] = int(st["step"])
             g = self.param_groups[gi]
-            by_key.setdefault((counts[p], g["betas"], g["eps"], p.device), []).append((gi, p))
+            # skipped (overflowed) step() calls are counted per CLASS, on the class's device (one optimiser-wide
+            # counter charged parameters that joined later - unfrozen, restored - with skips from before they joined): a
+            # parameter keeps the counter it first got; parameters with different counters never share a class
+            by_key.setdefault((counts[p], g["betas"], g["eps"], p.device, id(skip_of.get(p))), []).append((gi, p))
         classes = []
-        for (step, betas, eps, dev), members in by_key.items():
+        for (step, betas, eps, dev, _), members in by_key.items():
             params = [p for _, p in members]
             entries = [(p.data_ptr(), 0, self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(),
                         p.numel(), 0.0, 0.0) for p in params]
@@ -156,24 +160,36 @@ class FusedAdamW(torch.optim.Optimizer):
             tab = np.zeros(len(entries), _ENTRY)
             for i, e in enumerate(entries):
                 tab[i] = e
+            skipped = skip_of.get(params[0])
+            if skipped is None:
+                skipped = torch.zeros((), dtype=torch.int32, device=dev)
+            for p in params:
+                skip_of[p] = skipped
             classes.append(dict(params=params, gidx=[gi for gi, _ in members], tab=tab, ct=ct, cs=cs, nchunks=nchunks,
-                                betas=betas, eps=eps, device=dev, step=step, sent=None, tab_dev=None))
+                                betas=betas, eps=eps, device=dev, step=step, sent=None, tab_dev=None, skipped=skipped))
         plan = self._plan = dict(ids=tuple(id(p) for _, p in live), classes=classes)
         return plan
 
     def count_skipped_steps(self, found_inf):
-        """A loss scaler's overflow flag (device scalar, 1.0 = this step() call was skipped): accumulated on the device,
-        subtracted from the call count in the kernel's bias correction and in the `step` values of state_dict()."""
-        if self.__dict__.get("_skipped") is None:
-            self._skipped = torch.zeros((), dtype=torch.int32, device=found_inf.device)
-        self._skipped.add_(found_inf.to(torch.int32))
+        """A loss scaler's overflow flag (device scalar, 1.0 = this step() call was skipped): accumulated on the device in the
+        counter of every parameter class that exists now, subtracted from the call count in the kernel's bias correction and
+        in the `step` values of state_dict()."""
+        if self.__dict__.get("_plan") is None:
+            self._prepare()
+        seen = set()
+        for t in self.__dict__.get("_skip_of", {}).values():
+            if id(t) not in seen:
+                seen.add(id(t))
+                t.add_(found_inf.to(device=t.device, dtype=torch.int32))
 
     def _sync_step_tensors(self):
-        skipped = self.__dict__.get("_skipped")
-        skipped = int(skipped) if skipped is not None else 0              # one host read, when the state is saved
+        skip_of, host = self.__dict__.get("_skip_of", {}), {}
         for p, n in self.__dict__.get("_counts", {}).items():
             if p in self.state and "step" in self.state[p]:
-                self.state[p]["step"] = torch.tensor(float(max(n - skipped, 0)), dtype=torch.float32)
+                t = skip_of.get(p)
+                if t is not None and id(t) not in host:
+                    host[id(t)] = int(t)                                  # one host read per class, when the state is saved
+                self.state[p]["step"] = torch.tensor(float(max(n - (host[id(t)] if t is not None else 0), 0)), dtype=torch.float32)
 
     def state_dict(self):
         self._sync_step_tensors()
@@ -182,7 +198,7 @@ class FusedAdamW(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self.__dict__.pop("_plan", None)       # moments were replaced: new pointers, and the step counts of the file
-        self.__dict__.pop("_skipped", None)    # (the file's counts are applied steps)
+        self.__dict__.pop("_skip_of", None)    # (the file's counts are applied steps)
         self._counts = {p: int(st["step"]) for p, st in self.state.items() if "step" in st}
 
 

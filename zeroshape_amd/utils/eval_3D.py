@@ -342,6 +342,10 @@ def brute_force_search(pc_pred, pc_gt, f_thresholds=[0.005, 0.01, 0.02, 0.05, 0.
         srank, sworld = rot_shard
         if order is None:
             order = torch.arange(K, dtype=torch.int32, device=dev)
+        # The shares only partition the sphere - and the shared running best only prunes validly - if every rank holds
+        # bit-identical clouds (per-rank random weights, or a dataset that samples points per process, would
+        # silently return a wrong winner).  One 16-byte MIN/MAX all-reduce of a checksum per call; a mismatch raises.
+        _check_identical_inputs(pred, pc_gt, order, group)
         order = order[srank::sworld].contiguous()
         lb_sorted = lb_sorted[srank::sworld].contiguous() if lb_sorted is not None else None
         K = int(order.numel())
@@ -410,6 +414,22 @@ def brute_force_search(pc_pred, pc_gt, f_thresholds=[0.005, 0.01, 0.02, 0.05, 0.
         brute_force_search.last_scanned = int(irec[11])          # ... of which scanned in full (not killed by the probe)
         out = out + (int(irec[1]), float(rec[0]))
     return out
+
+
+def _check_identical_inputs(pred, gt, order, group=None):
+    """Raise unless every rank of `group` passed the same prediction / ground-truth clouds and derived the same rotation order
+    (bit patterns summed as int64: order-independent per tensor, but any differing element changes it)."""
+    import torch.distributed as dist
+    sums = torch.stack([pred.contiguous().view(torch.int32).to(torch.int64).sum(),
+                        gt.contiguous().view(torch.int32).to(torch.int64).sum(),
+                        (order.to(torch.int64) * torch.arange(1, order.numel() + 1, device=order.device)).sum()])
+    lo, hi = sums.clone(), sums.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    if not bool((lo == hi).all()):
+        raise RuntimeError("brute_force_search(rot_shard=...): the ranks hold different prediction / ground-truth clouds "
+                           "(checksums %s vs %s); sharding the rotation sphere needs identical inputs on every rank "
+                           "(same weights, same sample)" % (lo.tolist(), hi.tolist()))
 
 
 def _share_running_best(best, group=None):
@@ -536,14 +556,34 @@ def ICP(opt, X1, X2, num_iter=50):
 
 
 class SimpleMesh(object):
-    """Triangle-soup stand-in for the ``trimesh.Trimesh`` objects the reference stores in
-    ``var.mesh_pred`` (only used for dumps): ``vertices`` [3n,3], ``faces`` [n,3], ``triangles``
-    [n,3,3] as numpy arrays."""
+    """Stand-in for the ``trimesh.Trimesh`` objects the reference stores in ``var.mesh_pred`` (dumps and the demo's .obj):
+    ``triangles`` [n,3,3] = the iso-surface kernel's triangle soup (what sampling reads); ``vertices`` [v,3] / ``faces`` [n,3] =
+    the INDEXED form ``mcubes.marching_cubes`` returns (utils/eval_3D.py:250-256), welded lazily on first access: a vertex on
+    a grid edge is computed from the same two corner values by every cube sharing the edge, so equal vertices are equal bit
+    for bit and welding = unique rows of the soup (``vertices[faces]`` reproduces ``triangles`` exactly)."""
 
     def __init__(self, triangles):
         self.triangles = np.asarray(triangles, np.float32).reshape(-1, 3, 3)
-        self.vertices = self.triangles.reshape(-1, 3)
-        self.faces = np.arange(len(self.vertices)).reshape(-1, 3)
+        self._indexed = None
+
+    def _weld(self):
+        if self._indexed is None:
+            soup = np.ascontiguousarray(self.triangles.reshape(-1, 3))
+            if len(soup) == 0:
+                self._indexed = (np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int64))
+            else:
+                keys = (soup + np.float32(0.0)).view(np.uint32)          # -0.0 and 0.0 are one vertex
+                _, first, inverse = np.unique(keys, axis=0, return_index=True, return_inverse=True)
+                self._indexed = (soup[first], inverse.reshape(-1, 3).astype(np.int64))
+        return self._indexed
+
+    @property
+    def vertices(self):
+        return self._weld()[0]
+
+    @property
+    def faces(self):
+        return self._weld()[1]
 
 
 _MC_TABLES = {}

@@ -44,12 +44,10 @@ def dump_depths(opt, idx, name, depths, masks=None, rescale=False, folder="dump"
 
 
 def dump_meshes(opt, idx, name, meshes, folder="dump", **_):
-    """meshes: objects with .triangles [n,3,3] (eval_3D.SimpleMesh) -> OBJ, shared vertices welded
-    (the marching-cubes kernel emits bit-identical coordinates for shared vertices)."""
+    """meshes: eval_3D.SimpleMesh objects -> OBJ with shared vertices (the indexed form mcubes.marching_cubes returns in
+    the reference; the marching-cubes kernel emits bit-identical coordinates for shared vertices)."""
     for i, mesh in zip(idx, meshes):
-        tri = np.asarray(mesh.triangles, np.float32).reshape(-1, 3)
-        verts, inverse = np.unique(tri, axis=0, return_inverse=True) if len(tri) else (tri, np.zeros(0, int))
-        faces = inverse.reshape(-1, 3) + 1
+        verts, faces = mesh.vertices, mesh.faces + 1              # the indexed form (eval_3D.SimpleMesh welds the soup)
         with open(_path(opt, folder, i, name, "obj"), "w") as f:
             f.write("# zeroshape_amd mesh: %d vertices, %d faces\n" % (len(verts), len(faces)))
             for v in verts:
