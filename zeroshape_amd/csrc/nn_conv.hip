@@ -1443,7 +1443,22 @@ static bool small_is_narrow(long long M, int Cout) {
 }
 
 // out_mode 2 (row statistics per column tile): the small-tile kernel's own tile width; the streaming kernel follows it
-extern "C" int zs_conv2d_fused_cols(int M, int Cout) { return small_is_narrow(M, Cout) || Cout % 64 ? 32 : 64; }
+static bool stream_enabled() {
+    static const bool on = getenv("ZS_CONV_STREAM") == nullptr || atoi(getenv("ZS_CONV_STREAM")) != 0;
+    return on;
+}
+static long long stream_max_rows() {
+    static const long long rows = getenv("ZS_STREAM_MAX_ROWS") ? atoll(getenv("ZS_STREAM_MAX_ROWS")) : 1024;
+    return rows;
+}
+
+// Column-tile width of the row statistics (out_mode 2).  Layers the streaming GEMM kernel takes use 64 (fewer tiles, so the
+// contraction can be split further); the small-tile kernel prefers its narrow tiles on few rows.
+extern "C" int zs_conv2d_fused_cols(int M, int Cout) {
+    if (Cout % 64) return 32;
+    if (stream_enabled() && M <= stream_max_rows()) return 64;
+    return small_is_narrow(M, Cout) ? 32 : 64;
+}
 
 extern "C" int zs_conv2d_nhwc_fused(const float *in, const float *packed_w, const float *scale, const float *shift,
                                     const float *res1, const float *res2, float *out, int batch, int Hin, int Win,
@@ -1633,12 +1648,9 @@ static int conv2d_impl(const float *in, const float *packed_w, const float *scal
         const bool tm = !pw && !no_tm && (Cin % 8) == 0;
         const bool narrow = (fuse && fuse->out_mode == 2) ? zs_conv2d_fused_cols((int)M, Cout) == 32 : small_is_narrow(M, Cout);
         // ---- pointwise layers of few rows: the streaming GEMM kernel (csrc/nn_gemm_stream.hip) ----
-        static const bool use_stream = getenv("ZS_CONV_STREAM") == nullptr || atoi(getenv("ZS_CONV_STREAM")) != 0;
-        static const long long stream_max_rows = getenv("ZS_STREAM_MAX_ROWS") ? atoll(getenv("ZS_STREAM_MAX_ROWS")) : 1024;
         const bool pw_geom = kh == 1 && kw == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && a.dil == 1 && Hin == Hout && Win == Wout;
-        if (use_stream && pw_geom && f16 && a.w_split && in_scale == 1.0f && in_shift == 0.0f && M <= stream_max_rows &&
-            (!fuse || ((fuse->in_mode == 0 || fuse->in_mode == 2) && (fuse->out_mode == 0 || fuse->out_mode == 2))) &&
-            !(flags & ZS_CONV_SPLIT_SMALL)) {
+        if (stream_enabled() && pw_geom && f16 && a.w_split && in_scale == 1.0f && in_shift == 0.0f && M <= stream_max_rows() &&
+            (!fuse || ((fuse->in_mode == 0 || fuse->in_mode == 2) && (fuse->out_mode == 0 || fuse->out_mode == 2)))) {
             zs::stream_gemm::Args g;
             g.a = in; g.w = packed_w; g.scale = scale; g.shift = shift; g.res1 = res1; g.res2 = res2; g.out = out;
             g.M = (int)M; g.K = a.K; g.N = Cout; g.CoutPad = a.CoutPad; g.lda = Cin; g.act = act; g.in_relu = a.in_relu;

@@ -192,7 +192,19 @@ __global__ __launch_bounds__(64 * NW) void stream_gemm_kernel(Args a, Geo g) {
             load(d, s_begin + base + DEPTH + d);
         }
     }
+    // The refills of the last DEPTH steps are still in flight.  The compiler does not know that: to it a ring register is dead
+    // after its last MFMA, and it reused some for the epilogue's addresses AHEAD of this wait (tools/ring_audit.py on the ISA) - a
+    // load landing late then overwrote an LDS / global address.  Pinning every ring register after the wait keeps all of them
+    // allocated until the loads have landed.  (Root cause of the round-4 "layout dependent" faults of the K split and of the
+    // 32 x 96 tiles; the unsplit variants had the same window and were lucky.)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) asm volatile("" : "+v"(rb[d][j][0]), "+v"(rb[d][j][1]));
+#pragma unroll
+        for (int i = 0; i < MI; i++) asm volatile("" : "+v"(ra[d][i][0]), "+v"(ra[d][i][1]));
+    }
     // wave partials -> LDS: register 4q + e of lane (l32, half) = channel 8q + 4 half + e of pixel l32
 #pragma unroll
     for (int i = 0; i < MI; i++)
@@ -249,16 +261,40 @@ __global__ __launch_bounds__(64 * NW) void stream_gemm_kernel(Args a, Geo g) {
     for (int ps = 0; ps < PASSES; ps++) {
         const int e = tid + THREADS * ps, p = e / QPR, c = e % QPR;
         const int m = m0 + p, n = n0 + 4 * c;
-        if (m >= a.M || n >= a.N) continue;
-        const size_t o = (size_t)m * a.N + n;
+        const bool valid = m < a.M && n < a.N;
+        if (!valid && !a.out_stats) continue;
         f32x4 r = v[ps];
-        if (a.scale) r *= *reinterpret_cast<const f32x4 *>(a.scale + n);
-        if (a.shift) r += *reinterpret_cast<const f32x4 *>(a.shift + n);
-        if (a.res1) r += *reinterpret_cast<const f32x4 *>(a.res1 + o);
-        if (a.res2) r += *reinterpret_cast<const f32x4 *>(a.res2 + o);
+        if (valid) {
+            const size_t o = (size_t)m * a.N + n;
+            if (a.scale) r *= *reinterpret_cast<const f32x4 *>(a.scale + n);
+            if (a.shift) r += *reinterpret_cast<const f32x4 *>(a.shift + n);
+            if (a.res1) r += *reinterpret_cast<const f32x4 *>(a.res1 + o);
+            if (a.res2) r += *reinterpret_cast<const f32x4 *>(a.res2 + o);
 #pragma unroll
-        for (int k = 0; k < 4; k++) r[k] = activate(r[k], a.act);
-        *reinterpret_cast<f32x4 *>(a.out + o) = r;
+            for (int k = 0; k < 4; k++) r[k] = activate(r[k], a.act);
+            *reinterpret_cast<f32x4 *>(a.out + o) = r;
+        }
+        if constexpr ((QPR & (QPR - 1)) == 0) {
+            // statistics of the stored rows for the consumer's fused LayerNorm (zs_conv_fuse.out_mode 2): (sum, M2 about the
+            // mean of this column tile) per (row, column tile); the QPR lanes of a row are neighbours in the wave
+            if (a.out_stats) {
+                float rs = valid ? (r[0] + r[1]) + (r[2] + r[3]) : 0.f;
+#pragma unroll
+                for (int sh = 1; sh < QPR; sh <<= 1) rs += __shfl_xor(rs, sh, 64);
+                const float mean = rs * (1.0f / SN);
+                float d2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) d2 += (r[k] - mean) * (r[k] - mean);
+                if (!valid) d2 = 0.f;
+#pragma unroll
+                for (int sh = 1; sh < QPR; sh <<= 1) d2 += __shfl_xor(d2, sh, 64);
+                if (valid && c == 0) {
+                    float *dst = a.out_stats + ((size_t)m * ntiles + tn) * 2;
+                    dst[0] = rs;
+                    dst[1] = d2;
+                }
+            }
+        }
     }
 }
 
@@ -274,15 +310,14 @@ Plan plan(const Args &a) {
     Plan best = {1, 2, 1, 0, 0};
     double best_cost = 1e30;
     const bool can_split = a.parts && a.tickets;
-    // candidates: 32 x 32, 32 x 64, 64 x 32, 64 x 64 tiles.  (32 x 96 tiles - NJ = 3 - ran the ViT fc1 in 11 us but ended in GPU memory
-    // faults in some builds of this file, layout dependent, while every address it forms is inside its tensor by construction;
-    // not understood in round 4 and not instantiated.  64 x 64 tiles move the same bytes per workgroup.)
+    // candidates: 32 / 64 rows x 32 / 64 / 96 columns (96: the weight rows of the last tile must exist, nt * 96 <= CoutPad)
     for (int mi = 1; mi <= 2; mi++) {
         if (mi == 2 && a.M <= 32) continue;
         const long long mt = (a.M + 32 * mi - 1) / (32 * mi);
-        for (int nj = 1; nj <= 2; nj++) {
+        for (int nj = 1; nj <= 3; nj++) {
             const long long nt = (a.N + 32 * nj - 1) / (32 * nj), T = mt * nt;
             if (a.out_stats && 32 * nj != a.stats_cols) continue;
+            if (nj == 3 && nt * 96 > a.CoutPad) continue;
             if (T > a.max_tickets) continue;
             for (int z = 1; z <= 16; z++) {
                 if (z > 1 && (!can_split || steps / (z * 4) < 2 || T * z > cus ||
@@ -298,7 +333,8 @@ Plan plan(const Args &a) {
     if (const char *f = getenv("ZS_STREAM_FORCE")) {       // measurement / debugging override: "mi,nj,z"
         int mi = 0, nj = 0, z = 1;
         sscanf(f, "%d,%d,%d", &mi, &nj, &z);
-        if (mi >= 1 && mi <= 2 && nj >= 1 && nj <= 2 && z >= 1 && (z == 1 || can_split) && steps / (z * 4) >= 1)
+        if (mi >= 1 && mi <= 2 && nj >= 1 && nj <= 3 && (nj < 3 || (a.N + 95) / 96 * 96 <= a.CoutPad) && z >= 1 &&
+            (z == 1 || can_split) && steps / (z * 4) >= 1)
             best = Plan{mi, nj, z, (int)((a.M + 32 * mi - 1) / (32 * mi)), (int)((a.N + 32 * nj - 1) / (32 * nj))};
     }
     return best;
@@ -307,7 +343,8 @@ Plan plan(const Args &a) {
 }  // namespace
 
 bool launch(const Args &a, hipStream_t st) {
-    if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K & 15) || (a.N & 3) || (a.lda & 3) || a.out_stats) return false;
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K & 15) || (a.N & 3) || (a.lda & 3)) return false;
+    if (a.out_stats && (a.stats_cols != 32 && a.stats_cols != 64 || a.N % a.stats_cols)) return false;
     if (a.in_stats && (a.in_tiles <= 0 || a.in_tiles > 32 || a.lda != a.K)) return false;
     if ((size_t)a.M * a.lda * 4 >= ((size_t)1 << 32)) return false;        // 32-bit lane offsets
     if (const char *only = getenv("ZS_STREAM_ONLY")) {                // debugging: the kernel for one (K, N) only
@@ -315,17 +352,16 @@ bool launch(const Args &a, hipStream_t st) {
         if (sscanf(only, "%d,%d", &k, &n) == 2 && (k != a.K || n != a.N)) return false;
     }
     const Plan p = plan(a);
+    if (a.out_stats && 32 * p.nj != a.stats_cols) return false;
     const long long T = (long long)p.mtiles * p.ntiles;
     // The kernel wins where its tiles fill the chip once (ViT qkv / fc1 at batch 1: 8.8 vs 13.6 us, 11 vs 19.6 us); with few
     // tiles the small-tile kernel's narrower tiles (two workgroups per CU) are faster (proj 7.8 vs 8.6 us, 1 x 1 layers of
     // 256 channels on 14 x 14 maps 4.9 vs 7.0 us) - tools/ubench/small_gemm.hip.  ZS_STREAM_MIN_TILES moves the line.
     static const long long min_tiles = getenv("ZS_STREAM_MIN_TILES") ? atoll(getenv("ZS_STREAM_MIN_TILES")) : 192;
     // ... or where splitting a long contraction puts the whole chip on a layer that has few tiles (ViT fc2: 84 tiles x 3)
-    // OFF by default (ZS_STREAM_SPLIT=1 enables it): back-to-back split launches are bit-stable in isolation (tools/dbg_split.py,
-    // 500 launches), but inside the batch-1 encoder the split of the 2,048 -> 512 layers at 7 x 7 (64 x 32 tiles, 16 ranges)
-    // ends in a GPU memory fault after a few forwards unless every kernel is serialised (AMD_SERIALIZE_KERNEL=3) - not
-    // understood in round 4, so the product path does not use it.
-    static const bool allow_split = getenv("ZS_STREAM_SPLIT") != nullptr && atoi(getenv("ZS_STREAM_SPLIT")) != 0;
+    // (ZS_STREAM_SPLIT=0 disables it.  Round 4 shipped it disabled for a while: memory faults inside the encoder that turned out to
+    // be ring registers reused ahead of the final vmcnt wait - see the pin block after the K loop and tools/ring_audit.py.)
+    static const bool allow_split = getenv("ZS_STREAM_SPLIT") == nullptr || atoi(getenv("ZS_STREAM_SPLIT")) != 0;
     if (T * p.splits < min_tiles || (p.splits > 1 && !allow_split)) return false;
     if (const char *only = getenv("ZS_STREAM_SPLIT_ONLY")) {          // debugging: the K split for one (K, N) only
         int k = 0, n = 0;
@@ -338,9 +374,10 @@ bool launch(const Args &a, hipStream_t st) {
         if (a.in_stats) hipLaunchKernelGGL((stream_gemm_kernel<4, MI_, NJ_, 3, true>), grid, dim3(256), 0, st, a, g); \
         else hipLaunchKernelGGL((stream_gemm_kernel<4, MI_, NJ_, 3, false>), grid, dim3(256), 0, st, a, g);           \
     } while (0)
-    if (p.mi == 2) { if (p.nj == 1) ZS_SG(2, 1); else ZS_SG(2, 2); }
+    if (p.mi == 2) { if (p.nj == 1) ZS_SG(2, 1); else if (p.nj == 2) ZS_SG(2, 2); else ZS_SG(2, 3); }
     else if (p.nj == 1) ZS_SG(1, 1);
-    else ZS_SG(1, 2);
+    else if (p.nj == 2) ZS_SG(1, 2);
+    else ZS_SG(1, 3);
 #undef ZS_SG
     return true;
 }
