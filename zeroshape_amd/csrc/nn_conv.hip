@@ -1452,13 +1452,10 @@ static long long stream_max_rows() {
     return rows;
 }
 
-// Column-tile width of the row statistics (out_mode 2).  Layers the streaming GEMM kernel takes use 64 (fewer tiles, so the
-// contraction can be split further); the small-tile kernel prefers its narrow tiles on few rows.
-extern "C" int zs_conv2d_fused_cols(int M, int Cout) {
-    if (Cout % 64) return 32;
-    if (stream_enabled() && M <= stream_max_rows()) return 64;
-    return small_is_narrow(M, Cout) ? 32 : 64;
-}
+// Column-tile width of the row statistics (out_mode 2): the small-tile kernel's preference (the streaming kernel writes them
+// too - 32 or 64 columns - but with its K split off it refuses these few-tile layers, and the small kernel's narrow tiles are
+// faster on few rows: ViT proj 8.3 vs 9.7 us, fc2 20.4 vs 23.2 us, tools/stream_shapes.py)
+extern "C" int zs_conv2d_fused_cols(int M, int Cout) { return small_is_narrow(M, Cout) || Cout % 64 ? 32 : 64; }
 
 extern "C" int zs_conv2d_nhwc_fused(const float *in, const float *packed_w, const float *scale, const float *shift,
                                     const float *res1, const float *res2, float *out, int batch, int Hin, int Win,

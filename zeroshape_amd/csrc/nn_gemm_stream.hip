@@ -226,35 +226,54 @@ __global__ __launch_bounds__(64 * NW) void stream_gemm_kernel(Args a, Geo g) {
         for (int w = 1; w < NW; w++) v[ps] += *reinterpret_cast<const f32x4 *>(&part[w][p][4 * c]);
     }
     if (g.splits > 1) {
-        // K split across blockIdx.y: publish this range's partial tile (plain 16-byte stores, ONE agent-scope release per
-        // workgroup), take a ticket; the last arriver acquires and sums all ranges in range order - the same sum whoever it is
+        // K split across blockIdx.y: publish this range's partial tile, take a ticket; the last arriver sums all ranges in range
+        // order - the same sum whoever it is
         const int tile = tn * mtiles + tm;
         float *mine = a.parts + ((size_t)tile * g.splits + z) * (SM * SN);
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ps++) *reinterpret_cast<f32x4 *>(mine + (size_t)(tid + THREADS * ps) * 4) = v[ps];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                   // also: everybody has read `part`
         int *flag = reinterpret_cast<int *>(&part[0][0][0]);
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int old = __hip_atomic_fetch_add(&a.tickets[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = old == g.splits - 1;
-            if (last) {
-                __hip_atomic_store(&a.tickets[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ready for the next launch
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-            *flag = last;
-        }
-        __syncthreads();
-        if (!*flag) return;
-        const float *all = a.parts + (size_t)tile * g.splits * (SM * SN);
+        {
+            // partial tiles as agent-scope atomics (written through to / read at the coherence point of the eight L2s): no cache
+            // write-back or invalidate of a whole L2 per workgroup
 #pragma unroll
-        for (int ps = 0; ps < PASSES; ps++) {
-            f32x4 sum = *reinterpret_cast<const f32x4 *>(all + (size_t)(tid + THREADS * ps) * 4);
-            for (int zz = 1; zz < g.splits; zz++)
-                sum += *reinterpret_cast<const f32x4 *>(all + (size_t)zz * (SM * SN) + (size_t)(tid + THREADS * ps) * 4);
-            v[ps] = sum;
+            for (int ps = 0; ps < PASSES; ps++)
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    __hip_atomic_store(mine + (size_t)(tid + THREADS * ps) * 4 + k, v[ps][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                // ACQ_REL at agent scope: release = this workgroup's partial tile (drained above), acquire = the last arriver reads
+                // the others' (one thread per workgroup pays the L2 write-back / invalidate; +0.5-1 us over RELAXED, measured)
+                const int old = __hip_atomic_fetch_add(&a.tickets[tile], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = old == g.splits - 1;
+                if (last) __hip_atomic_store(&a.tickets[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *flag = last;
+            }
+            __syncthreads();
+            if (!*flag) return;
+            const float *all = a.parts + (size_t)tile * g.splits * (SM * SN);
+            // four ranges' loads in flight at a time (one range per trip costs a memory round trip per range); summed in range order
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ps++) v[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int z0 = 0; z0 < g.splits; z0 += 4) {
+                f32x4 t[4][PASSES];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int zz = min(z0 + u, g.splits - 1);
+#pragma unroll
+                    for (int ps = 0; ps < PASSES; ps++)
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            t[u][ps][k] = __hip_atomic_load(all + (size_t)zz * (SM * SN) + (size_t)(tid + THREADS * ps) * 4 + k,
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (z0 + u < g.splits) {
+#pragma unroll
+                        for (int ps = 0; ps < PASSES; ps++) v[ps] += t[u][ps];
+                    }
+            }
         }
     }
 #pragma unroll
@@ -359,9 +378,12 @@ bool launch(const Args &a, hipStream_t st) {
     // 256 channels on 14 x 14 maps 4.9 vs 7.0 us) - tools/ubench/small_gemm.hip.  ZS_STREAM_MIN_TILES moves the line.
     static const long long min_tiles = getenv("ZS_STREAM_MIN_TILES") ? atoll(getenv("ZS_STREAM_MIN_TILES")) : 192;
     // ... or where splitting a long contraction puts the whole chip on a layer that has few tiles (ViT fc2: 84 tiles x 3)
-    // (ZS_STREAM_SPLIT=0 disables it.  Round 4 shipped it disabled for a while: memory faults inside the encoder that turned out to
-    // be ring registers reused ahead of the final vmcnt wait - see the pin block after the K loop and tools/ring_audit.py.)
-    static const bool allow_split = getenv("ZS_STREAM_SPLIT") == nullptr || atoi(getenv("ZS_STREAM_SPLIT")) != 0;
+    // OFF by default (ZS_STREAM_SPLIT=1 enables it).  It is correct now (the round-4 faults were ring registers reused ahead of the
+    // final vmcnt wait - see the pin block after the K loop and tools/ring_audit.py; 900 back-to-back split launches and the
+    // encoder tests are clean with it on) but it does not pay: every extra range costs 2-3 us of exchange (write-through partial
+    // tile, agent-scope ticket, read-back) - ViT fc2 23.2 (no split) -> 18.8 (2 ranges) -> 21.8 (3) vs 20.4 us for the small-tile
+    // kernel; proj 9.7 -> 11.5 -> 14.7 vs 8.3; the 2,048 -> 512 layer at 7 x 7 15.9 -> 11.1 (4) vs 12.8 (tools/stream_shapes.py).
+    static const bool allow_split = getenv("ZS_STREAM_SPLIT") != nullptr && atoi(getenv("ZS_STREAM_SPLIT")) != 0;
     if (T * p.splits < min_tiles || (p.splits > 1 && !allow_split)) return false;
     if (const char *only = getenv("ZS_STREAM_SPLIT_ONLY")) {          // debugging: the K split for one (K, N) only
         int k = 0, n = 0;
