@@ -31,8 +31,10 @@ def timed(x, pc, *a, **k):
     y = orig(x, pc, *a, **k)
     e1.record()
     torch.cuda.synchronize()
-    M = y.numel() // pc.cout
-    key = (M, pc.cout, pc.cin * pc.kh * pc.kw, pc.kh, pc.stride)
+    M = (y[0] if isinstance(y, tuple) else y).numel() // pc.cout
+    fz = ("gn" if k.get("gn_in") is not None else "ln" if k.get("ln_in") is not None else "-") + ">" + \
+        ({"group": "gn", "row": "ln"}.get(k.get("stats_out"), "-"))
+    key = (M, pc.cout, pc.cin * pc.kh * pc.kw, pc.kh, pc.stride, fz)
     r = rec.setdefault(key, [0, 0.0])
     r[0] += 1
     r[1] += e0.elapsed_time(e1)
@@ -48,8 +50,9 @@ for _ in range(N):
     g.forward(opt, var, training=False, get_loss=False)
 tot = sum(v[1] for v in rec.values()) / N
 print("B=%d: %d conv calls per forward, %.2f ms" % (B, sum(v[0] for v in rec.values()) // N, tot))
-print("%8s %6s %6s %2s %2s %5s %9s %8s %7s %6s" % ("M", "N", "K", "k", "s", "calls", "us/call", "ms", "TFLOP/s", "tiles"))
-for (M, Nn, K, kh, st), (c, ms) in sorted(rec.items(), key=lambda kv: -kv[1][1]):
+print("(fused: normalisation applied on load > statistics written by the epilogue; times include ~3-5 us of event markers)")
+print("%8s %6s %6s %2s %2s %6s %5s %9s %8s %7s %9s" % ("M", "N", "K", "k", "s", "fused", "calls", "us/call", "ms", "TFLOP/s", "weight MB"))
+for (M, Nn, K, kh, st, fz), (c, ms) in sorted(rec.items(), key=lambda kv: -kv[1][1]):
     us = ms / c * 1e3
-    print("%8d %6d %6d %2d %2d %5d %9.1f %8.3f %7.1f %6d" % (M, Nn, K, kh, st, c // N, us, ms / N, 2.0 * M * Nn * K / us / 1e6,
-                                                          -(-M // 128) * -(-Nn // 128)))
+    print("%8d %6d %6d %2d %2d %6s %5d %9.1f %8.3f %7.1f %9.2f" % (M, Nn, K, kh, st, fz, c // N, us, ms / N, 2.0 * M * Nn * K / us / 1e6,
+                                                               Nn * K * 4 / 1e6))

@@ -234,11 +234,13 @@ __global__ __launch_bounds__(64 * NW) void stream_gemm_kernel(Args a, Geo g) {
         {
             // partial tiles as agent-scope atomics (written through to / read at the coherence point of the eight L2s): no cache
             // write-back or invalidate of a whole L2 per workgroup
+            // 16-byte stores with sc0 sc1 (system-coherent write-through: a wave writes whole 128-byte lines; the same data as dword
+            // atomics - what __hip_atomic_store gives - is a partial-line write per lane and 4x the instructions)
 #pragma unroll
-            for (int ps = 0; ps < PASSES; ps++)
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    __hip_atomic_store(mine + (size_t)(tid + THREADS * ps) * 4 + k, v[ps][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int ps = 0; ps < PASSES; ps++) {
+                const float *dst = mine + (size_t)(tid + THREADS * ps) * 4;
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(v[ps]) : "memory");
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
@@ -261,12 +263,17 @@ __global__ __launch_bounds__(64 * NW) void stream_gemm_kernel(Args a, Geo g) {
                 for (int u = 0; u < 4; u++) {
                     const int zz = min(z0 + u, g.splits - 1);
 #pragma unroll
-                    for (int ps = 0; ps < PASSES; ps++)
-#pragma unroll
-                        for (int k = 0; k < 4; k++)
-                            t[u][ps][k] = __hip_atomic_load(all + (size_t)zz * (SM * SN) + (size_t)(tid + THREADS * ps) * 4 + k,
-                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int ps = 0; ps < PASSES; ps++) {
+                        const float *src = all + (size_t)zz * (SM * SN) + (size_t)(tid + THREADS * ps) * 4;
+                        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(t[u][ps]) : "v"(src) : "memory");
+                    }
                 }
+                // the compiler does not know these loads are in flight: wait here, and "return" every destination from the wait
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int ps = 0; ps < PASSES; ps++) asm volatile("" : "+v"(t[u][ps]));
 #pragma unroll
                 for (int u = 0; u < 4; u++)
                     if (z0 + u < g.splits) {
