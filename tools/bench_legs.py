@@ -400,6 +400,11 @@ def inference_leg(dev):
             return E.compute_level_grid(o, g.impl_network, v.latent_depth, None, pts, None)[0]
         ms, mn = _events(run, 8)
         out["vox%d" % N] = {"ms": round(ms, 3), "ms_min": round(mn, 3), "points": (N + 1) ** 3}
+        if N == 64:         # the same without prepare()'s per-image output check (round 3's behaviour): what that guarantee costs
+            g.impl_network.image_check = False
+            ms, mn = _events(run, 8)
+            g.impl_network.image_check = True
+            out["vox64_without_image_check"] = {"ms": round(ms, 3), "ms_min": round(mn, 3)}
     g.enable_hip_graph(False)
     del g
     torch.cuda.empty_cache()

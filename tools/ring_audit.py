@@ -29,7 +29,7 @@ def regs_of(tok):
     return out
 
 
-def audit(name, lines):
+def audit(name, lines, quiet=False):
     inflight = {}          # reg -> serial number of its load
     issued = 0             # vector memory loads issued so far (vmcnt counts loads and stores returning data... loads only here)
     findings = []
@@ -74,16 +74,28 @@ def audit(name, lines):
             hit = [r for r in touched if r in inflight]
             if hit and rnd == 1:
                 findings.append((ln, ins, hit))
-    print("%-90s %s" % (name[:90], "CLEAN" if not findings else "%d finding(s)" % len(findings)))
-    for ln, ins, hit in findings[:12]:
-        print("    line %d: %s   <- in flight: %s" % (ln, ins, " ".join("%s%d" % r for r in hit[:6])))
+    if not quiet:
+        print("%-90s %s" % (name[:90], "CLEAN" if not findings else "%d finding(s)" % len(findings)))
+        for ln, ins, hit in findings[:12]:
+            print("    line %d: %s   <- in flight: %s" % (ln, ins, " ".join("%s%d" % r for r in hit[:6])))
     return len(findings)
 
 
-def main():
-    path = sys.argv[1]
-    want = sys.argv[2] if len(sys.argv) > 2 else ""
-    cur, body, total = None, [], 0
+def compile_to_asm(src, out, extra=()):
+    """hipcc -S of one translation unit of zeroshape_amd/csrc for gfx950 (no GPU needed)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(root, "include"), "--cuda-device-only", "-S",
+           os.path.join(root, "zeroshape_amd", "csrc", src), "-o", out] + list(extra)
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return out
+
+
+def audit_file(path, want="", quiet=False):
+    """-> {kernel symbol: number of findings} for the kernels of one ISA text whose name contains `want`."""
+    cur, body, res = None, [], {}
     for i, line in enumerate(open(path), 1):
         m = re.match(r"^(_Z\w+):\s*(;.*)?$", line)
         if m:
@@ -91,12 +103,18 @@ def main():
             continue
         if cur and line.startswith(".Lfunc_end"):
             if want in cur:
-                total += audit(cur, body)
+                res[cur] = audit(cur, body, quiet)
             cur = None
             continue
         if cur:
             body.append((i, line))
-    sys.exit(1 if total else 0)
+    return res
+
+
+def main():
+    path = sys.argv[1]
+    want = sys.argv[2] if len(sys.argv) > 2 else ""
+    sys.exit(1 if sum(audit_file(path, want).values()) else 0)
 
 
 if __name__ == "__main__":
