@@ -5,10 +5,11 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof
 B=${1:-1}
 TAG=${2:-enc_b$B}
+ENC=${3:-resnet}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pe_t
-rocprofv3 --kernel-trace --stats -d /tmp/pe_t/trace -- python3 $ROOT/tools/prof_encoder.py $B 10 > $OUT/${TAG}_run.txt 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/pe_t/trace -- python3 $ROOT/tools/prof_encoder.py $B 10 $ENC > $OUT/${TAG}_run.txt 2>&1
 python3 $ROOT/tools/rocpd_summary.py /tmp/pe_t > $OUT/${TAG}_summary.txt 2>&1
 python3 - > $OUT/${TAG}_by_grid.txt 2>&1 <<PY
 import glob, sqlite3
