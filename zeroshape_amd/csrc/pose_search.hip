@@ -402,6 +402,7 @@ __device__ unsigned long long g_pose_blocks[2];   // [0] evaluated, [1] all
 // chunk in flight that wait covers exactly the chunk needed next.  The wait statement "returns" the chunk's registers, so
 // every consumer is ordered behind it.  (No LDS operation is outstanding inside the walk; all loads are drained on return.)
 typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct Chunk8 {
     f32x8 x, y, z;
     __device__ __forceinline__ void request(const float *c) {
@@ -420,20 +421,26 @@ static_assert(PS_SUB * sizeof(float) == 0x100, "Chunk8::request addresses the y 
 template <bool D0, bool D1>
 __device__ __forceinline__ void scan_chunk(const Chunk8 &a, const float (&qx)[PS_Q], const float (&qy)[PS_Q],
                                            const float (&qz)[PS_Q], float (&bestd)[PS_Q]) {
+    // Two candidates per instruction (round 4): the packed fp32 forms v_pk_add / v_pk_mul / v_pk_fma take an SGPR PAIR - two
+    // consecutive candidates of the chunk - as one operand and the lane's query coordinate broadcast by op_sel, so a pair of
+    // distances costs 3 + 1 + 2 packed instructions instead of 12.  Lane by lane they are the same IEEE operations in the same
+    // order (c + (-q) == c - q exactly; v_pk_fma_f32 is a fused multiply-add): every d, hence every minimum, keeps its bits.
+    // 6.4 -> 3.8 VALU instructions per pair; the culled scan was at 91 % of the VALU issue rate (profiles/r03_eval_sq_*).
 #pragma unroll
     for (int h = 0; h < 8; h += 4)
 #pragma unroll
         for (int q = 0; q < PS_Q; q++) {
             if ((q == 0 && !D0) || (q == 1 && !D1)) continue;
-            float d[4];
+            const f32x2 qx2 = {qx[q], qx[q]}, qy2 = {qy[q], qy[q]}, qz2 = {qz[q], qz[q]};
+            f32x2 d[2];
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const float dx = a.x[h + e] - qx[q];
-                const float dy = a.y[h + e] - qy[q];
-                const float dz = a.z[h + e] - qz[q];
-                d[e] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+            for (int e = 0; e < 2; e++) {
+                const f32x2 cx = {a.x[h + 2 * e], a.x[h + 2 * e + 1]}, cy = {a.y[h + 2 * e], a.y[h + 2 * e + 1]},
+                            cz = {a.z[h + 2 * e], a.z[h + 2 * e + 1]};
+                const f32x2 dx = cx - qx2, dy = cy - qy2, dz = cz - qz2;
+                d[e] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
             }
-            bestd[q] = fminf(bestd[q], fminf(fminf(d[0], d[1]), fminf(d[2], d[3])));
+            bestd[q] = fminf(bestd[q], fminf(fminf(d[0].x, d[0].y), fminf(d[1].x, d[1].y)));
         }
 }
 template <bool D0, bool D1>
@@ -442,6 +449,14 @@ __device__ __forceinline__ void scan_subtile(const float *__restrict__ c, const 
     Chunk8 a, b;
     a.request(c);
     a.arrived();
+#ifdef ZS_POSE_EXP_NOLOAD       // timing experiment (wrong results): the arithmetic of a sub-tile on its first chunk only
+#pragma unroll
+    for (int k = 0; k < PS_SUB; k += 8) {
+        scan_chunk<D0, D1>(a, qx, qy, qz, bestd);
+        asm volatile("" : "+s"(a.x), "+s"(a.y), "+s"(a.z));
+    }
+    return;
+#endif
 #pragma unroll
     for (int k = 0; k < PS_SUB; k += 16) {
         b.request_before(c + k + 8, a);
