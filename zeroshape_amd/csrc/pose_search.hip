@@ -163,6 +163,22 @@ __global__ __launch_bounds__(PS_THREADS) void pose_apply_kernel(const float *__r
 }
 
 // ---- nearest neighbours both ways + per-workgroup metric partials ------------------------- //
+// Staged drop with a device-side MERGE (round 4).  The query blocks of a batch are scanned in stages with a pose_kill_kernel
+// between them; when nothing can be dropped (an unalignable ground truth) the stages are pure cost - small launches that leave
+// CUs idle (45.6 ms staged vs 37 ms unstaged over the whole sphere).  The host cannot look (every batch is enqueued up front),
+// so the first kill kernel decides: if at least 3/4 of the batch survived the first stage it sets dead[PS_THREADS] = 1, the
+// SECOND stage's launch - whose grid always spans all remaining blocks - then scans them all, and the later stages' launches
+// return at once.  `stage` = (mode << 24) | end of the stage's own block range; mode 0: plain, 1: second stage, 2: later stage.
+// Which launch forms a partial sum does not change the sum: records are bit-identical either way.
+constexpr int PS_MERGE_SLOT = PS_THREADS;       // index of the merge flag behind the per-rotation dead flags
+constexpr int PS_DEAD_INTS = PS_THREADS + 64;
+__device__ __forceinline__ bool stage_skips(int stage, int bx, const int *__restrict__ dead) {
+    const int mode = stage >> 24, end = stage & 0xffffff;
+    if (mode == 0 || !dead) return false;
+    const bool merged = dead[PS_MERGE_SLOT] != 0;
+    return mode == 1 ? (bx >= end && !merged) : merged;
+}
+
 // grid (ceil(max(n, m) / (256 Q)), rotations in the batch, 2)
 // The launch covers query blocks x_begin .. x_begin + gridDim.x - 1 of blocks_x; `dead` (nullable): rotations that the
 // probe (block 0, see zs_pose_search_batch) has already shown to lose - they are skipped.
@@ -170,11 +186,12 @@ __global__ __launch_bounds__(PS_THREADS) void pose_nn_kernel(
     const float *__restrict__ pred, int n, const float *__restrict__ gt, int m,
     const float *__restrict__ stats, const float *__restrict__ thresholds, float *__restrict__ partial,
     const float *__restrict__ lower_bound, const float *__restrict__ best, int x_begin, int blocks_x,
-    const int *__restrict__ dead) {
+    const int *__restrict__ dead, int stage) {
     if (batch_pruned(lower_bound, best)) return;
     __shared__ __attribute__((aligned(16))) float tile[3 * PS_STRIDE];
     __shared__ float red[PS_PART][PS_THREADS / 64];
     const int dir = blockIdx.z, rot = blockIdx.y, bx = x_begin + blockIdx.x;
+    if (stage_skips(stage, bx, dead)) return;
     if (dead && dead[rot]) return;
     const int nq = dir == 0 ? n : m;      // queries
     const int nc = dir == 0 ? m : n;      // candidates
@@ -474,10 +491,11 @@ template <bool CULL>
 __global__ __launch_bounds__(PS_THREADS) void pose_nn_soa_kernel(
     const float *__restrict__ pred_packs, size_t pack_stride, int n, const float *__restrict__ gt_pack, int m,
     const float *__restrict__ thresholds, float *__restrict__ partial, const float *__restrict__ lower_bound,
-    const float *__restrict__ best, int x_begin, int blocks_x, const int *__restrict__ dead) {
+    const float *__restrict__ best, int x_begin, int blocks_x, const int *__restrict__ dead, int stage) {
     if (batch_pruned(lower_bound, best)) return;
     __shared__ float red[PS_PART][PS_THREADS / 64];
     const int dir = blockIdx.z, rot = blockIdx.y, bx = x_begin + blockIdx.x;
+    if (stage_skips(stage, bx, dead)) return;
     if (dead && dead[rot]) return;
     const int nq = dir == 0 ? n : m;      // queries
     const int nc = dir == 0 ? m : n;      // candidates
@@ -621,19 +639,33 @@ __global__ __launch_bounds__(PS_THREADS) void pose_nn_soa_kernel(
 // A rotation whose first `done` query blocks alone already give (s0 / n + s1 / m) / 2 > best cannot win: acc >= s0 / n and
 // comp >= s1 / m (fixed-order sums of non-negative terms only grow; division, addition and halving are monotone under
 // rounding), so cd = (acc + comp) / 2 is at least that - strictly above the running best, so ties are not affected.  First batch of a search: best = +inf, nobody dies.
-__global__ __launch_bounds__(PS_THREADS) void pose_kill_kernel(const float *__restrict__ partial, int count, int n, int m,
-                                                               int blocks_x, int done, const float *__restrict__ best,
-                                                               int *__restrict__ dead,
-                                                               const float *__restrict__ lower_bound) {
-    if (batch_pruned(lower_bound, best)) return;
-    const int rot = threadIdx.x;
-    if (rot >= count) return;
+__device__ __forceinline__ bool kill_test(const float *__restrict__ partial, int count, int n, int m, int blocks_x, int done,
+                                          const float *__restrict__ best, int rot) {
     const int nb[2] = {(n + PS_THREADS * PS_Q - 1) / (PS_THREADS * PS_Q), (m + PS_THREADS * PS_Q - 1) / (PS_THREADS * PS_Q)};
     float s[2] = {0.f, 0.f};
     for (int dir = 0; dir < 2; dir++)
         for (int b = 0; b < min(done, nb[dir]); b++) s[dir] += partial[(((size_t)rot * 2 + dir) * blocks_x + b) * PS_PART];
     const float bst = prune_bound(best);
-    if ((s[0] / (float)n + s[1] / (float)m) / 2.f > bst) dead[rot] = 1;
+    return (s[0] / (float)n + s[1] / (float)m) / 2.f > bst;
+}
+// decide_merge: this is the kill behind the FIRST stage - at most a quarter of the batch dropped -> merge the remaining stages
+__global__ __launch_bounds__(PS_THREADS) void pose_kill_kernel(const float *__restrict__ partial, int count, int n, int m,
+                                                               int blocks_x, int done, const float *__restrict__ best,
+                                                               int *__restrict__ dead,
+                                                               const float *__restrict__ lower_bound, int decide_merge) {
+    if (batch_pruned(lower_bound, best)) return;
+    __shared__ int killed;
+    if (threadIdx.x == 0) killed = 0;
+    __syncthreads();
+    const int rot = threadIdx.x;
+    bool dies = false;
+    if (rot < count) dies = kill_test(partial, count, n, m, blocks_x, done, best, rot);
+    if (dies) {
+        dead[rot] = 1;
+        atomicAdd(&killed, 1);
+    }
+    __syncthreads();
+    if (decide_merge && threadIdx.x == 0) dead[PS_MERGE_SLOT] = 4 * killed <= count ? 1 : 0;
 }
 
 // ---- the same search through uniform grids (csrc/zs_point_grid.h): ~10^2 instead of 10^4 distance evaluations per
@@ -849,7 +881,7 @@ extern "C" int zs_pose_max_batch(void) { return PS_THREADS; }
 
 extern "C" size_t zs_pose_scratch_bytes(int n, int m, int count) {
     if (n <= 0 || m <= 0 || count <= 0) return 0;
-    return ((size_t)count * PS_STAT + (size_t)count * 2 * blocks_x_of(n, m) * PS_PART + (size_t)PS_THREADS) * sizeof(float);
+    return ((size_t)count * PS_STAT + (size_t)count * 2 * blocks_x_of(n, m) * PS_PART + (size_t)PS_DEAD_INTS) * sizeof(float);
 }
 
 extern "C" size_t zs_pose_best_bytes(void) { return PS_BEST * sizeof(float); }
@@ -909,36 +941,50 @@ int search_batch(const float *pred, const float *pred_nn, int n, const float *gt
     // not have won, and the survivors' sums are formed as before.  On an alignable ground truth most of the sphere dies
     // after 5-15 % of its queries.
     int *dead = reinterpret_cast<int *>(partial + (size_t)count * 2 * bx * PS_PART);
-    if (hipMemsetAsync(dead, 0, (size_t)PS_THREADS * sizeof(int), st) != hipSuccess) {
+    if (hipMemsetAsync(dead, 0, (size_t)PS_DEAD_INTS * sizeof(int), st) != hipSuccess) {
         zs::set_err("zs_pose_search_batch: hipMemsetAsync failed");
         return 0;
     }
-    float *packs = reinterpret_cast<float *>(dead + PS_THREADS);
+    float *packs = reinterpret_cast<float *>(dead + PS_DEAD_INTS);
     const size_t pstride = pack_floats(n);
     if (mode != 0)
         hipLaunchKernelGGL(pose_pack_kernel, dim3(pack_subs(n) / PS_NSUB, count), dim3(PS_TILE), 0, st, pred_nn, n,
                            static_cast<const float *>(stats), packs, pstride, lower_bound, static_cast<const float *>(best));
-    const int stage_end[4] = {1, 3, 7, bx};
-    int lo = 0;
+    // ZS_POSE_STAGES="a,b,c" moves the stage boundaries (measurement; "0,0,0" = one stage: no staged drop); ZS_POSE_MERGE=0
+    // keeps every stage to its own blocks.  Defaults from tools/pose_stages.py (6,912 rotations, 10k x 10k points, batch 256):
+    // stages 1,3,7: unalignable 41.3 / alignable 2.86 ms; 2,6,6: 39.5 / 2.62; one stage: 35.4 / 3.58.
+    static const char *stage_env = getenv("ZS_POSE_STAGES");
+    static const bool merge_on = getenv("ZS_POSE_MERGE") == nullptr || atoi(getenv("ZS_POSE_MERGE")) != 0;
+    int stage_end[4] = {2, 6, 6, bx};
+    if (stage_env) {
+        int a = 1, b = 3, c = 7;
+        if (sscanf(stage_env, "%d,%d,%d", &a, &b, &c) == 3) { stage_end[0] = a; stage_end[1] = b; stage_end[2] = c; }
+    }
+    int lo = 0, launched = 0;
     for (int sidx = 0; sidx < 4 && lo < bx; sidx++) {
         const int hi = stage_end[sidx] < bx ? stage_end[sidx] : bx;
         if (hi <= lo) continue;
-        const dim3 grid(hi - lo, count, 2);
+        // the second launch spans every remaining block (it scans them all when the first kill merged the stages)
+        const int smode = !merge_on || launched == 0 ? 0 : launched == 1 ? 1 : 2;
+        const int span = smode == 1 ? bx - lo : hi - lo;
+        const int stage = (smode << 24) | hi;
+        const dim3 grid(span, count, 2);
         if (mode == 2)
             hipLaunchKernelGGL(pose_nn_soa_kernel<true>, grid, dim3(PS_THREADS), 0, st, static_cast<const float *>(packs), pstride,
                                n, gt_pack, m, thresholds6, partial, lower_bound, static_cast<const float *>(best), lo, bx,
-                               static_cast<const int *>(dead));
+                               static_cast<const int *>(dead), stage);
         else if (mode == 1)
             hipLaunchKernelGGL(pose_nn_soa_kernel<false>, grid, dim3(PS_THREADS), 0, st, static_cast<const float *>(packs), pstride,
                                n, gt_pack, m, thresholds6, partial, lower_bound, static_cast<const float *>(best), lo, bx,
-                               static_cast<const int *>(dead));
+                               static_cast<const int *>(dead), stage);
         else
             hipLaunchKernelGGL(pose_nn_kernel, grid, dim3(PS_THREADS), 0, st, pred_nn, n, gt_nn, m, stats, thresholds6, partial,
-                               lower_bound, best, lo, bx, static_cast<const int *>(dead));
+                               lower_bound, best, lo, bx, static_cast<const int *>(dead), stage);
         if (hi < bx)
             hipLaunchKernelGGL(pose_kill_kernel, dim3(1), dim3(PS_THREADS), 0, st, partial, count, n, m, bx, hi, best, dead,
-                               lower_bound);
+                               lower_bound, merge_on && launched == 0 ? 1 : 0);
         lo = hi;
+        launched++;
     }
     hipLaunchKernelGGL(pose_finish_kernel, dim3(1), dim3(PS_THREADS), 0, st, partial, count, n, m, bx, order,
                        index_offset, best, lower_bound, static_cast<const int *>(dead));

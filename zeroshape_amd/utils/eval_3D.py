@@ -281,7 +281,7 @@ def _rotation_sphere(device):
 
 @torch.no_grad()
 def brute_force_search(pc_pred, pc_gt, f_thresholds=[0.005, 0.01, 0.02, 0.05, 0.1, 0.2], device="cuda",
-                       rotations=None, rot_slice=None, return_index=False, batch_size=192, prune=True, nn=None,
+                       rotations=None, rot_slice=None, return_index=False, batch_size=256, prune=True, nn=None,
                        first_batch=None, rot_shard=None, group=None):
     """utils/eval_3D.py:140-170: best rigid alignment over the 6912-rotation sphere by
     Chamfer-L1, with the reference's first-strict-minimum rule (:161-168).
@@ -329,7 +329,7 @@ def brute_force_search(pc_pred, pc_gt, f_thresholds=[0.005, 0.01, 0.02, 0.05, 0.
     start, stop = (0, len(rotations)) if rot_slice is None else rot_slice
     if stop <= start:
         raise ValueError("empty rotation range")
-    batch_size = min(int(batch_size), lib.zs_pose_max_batch())
+    batch_size = min(int(batch_size), lib.zs_pose_max_batch())      # (256: the kernels address a batch by thread)
     first_batch = min(batch_size, 32) if first_batch is None else max(1, min(int(first_batch), batch_size))
     K = stop - start
     n, m = pred.shape[0], pc_gt.shape[1]
