@@ -290,12 +290,12 @@ def _out_size(n, k, stride, padding):
 
 _CONV_W_PRESPLIT = 128
 _PRESPLIT_TABLE = {}    # device -> (signature, device arrays of zs_conv2d_presplit_weight_multi, n, total pairs, splits)
-# ZS_TRAIN_PRESPLIT_ALL=1 (opt-in, measured SLOWER): ONE launch right behind the re-pack splits every registered operand
-# (zs_conv2d_presplit_weight_multi), so the small-tile and register-staged kernels skip the per-use split of their B fragments
-# as well and the 40 per-layer split launches go.  The kernel-time sum of the small-tile kernels does drop (7.9 -> 7.35 ms per
-# step in the trace), but they are latency-bound: in wall time the step goes 29.75 -> 30.1 ms, the 1.5 GB the split of 192 M
-# parameters moves costs more than it buys.  Default: only the >= 192-tile layers, per layer.
-PRESPLIT_ALL = os.environ.get("ZS_TRAIN_PRESPLIT_ALL", "0") != "0"
+# ONE launch right behind the re-pack splits every registered operand (zs_conv2d_presplit_weight_multi), so every split-fp16
+# kernel reads ready halves and the 40 per-layer split launches go.  Round 3 measured this SLOWER (29.75 -> 30.1 ms: the
+# small-tile kernels are latency-bound and the split of 192 M parameters moves 1.5 GB); since round 4 the few-row pointwise
+# layers with a split operand take the streaming GEMM kernel (csrc/nn_gemm_stream.hip; batch 4 = 788 token rows) and it pays:
+# optim.amp step 29.71 -> 28.87 ms on the same box.  ZS_TRAIN_PRESPLIT_ALL=0: only the >= 192-tile layers, per layer.
+PRESPLIT_ALL = os.environ.get("ZS_TRAIN_PRESPLIT_ALL", "1") != "0"
 
 
 def _amp_splits_operands():
