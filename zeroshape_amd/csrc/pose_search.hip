@@ -173,7 +173,7 @@ __global__ __launch_bounds__(PS_THREADS) void pose_apply_kernel(const float *__r
 constexpr int PS_MERGE_SLOT = PS_THREADS;       // index of the merge flag behind the per-rotation dead flags
 constexpr int PS_DEAD_INTS = PS_THREADS + 64;
 __device__ __forceinline__ bool stage_skips(int stage, int bx, const int *__restrict__ dead) {
-    const int mode = stage >> 24, end = stage & 0xffffff;
+    const int mode = (stage >> 24) & 3, end = stage & 0xffffff;
     if (mode == 0 || !dead) return false;
     const bool merged = dead[PS_MERGE_SLOT] != 0;
     return mode == 1 ? (bx >= end && !merged) : merged;
@@ -327,21 +327,28 @@ __device__ __forceinline__ float dpp_f(float v) {
 __device__ __forceinline__ float lane_f(float v, int l) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
-// wave-wide min / max at VALU speed: quad swaps, half-row and row mirrors, then the four row results (wave-uniform)
+// wave-wide min / max at VALU speed: quad swaps, half-row and row mirrors, then the four row results (wave-uniform).
+// The DPP modifier sits on the v_min / v_max itself (inline asm: through fminf(v, dpp(v)) hipcc emits v_mov_dpp + two
+// canonicalising v_max + v_min per step); "s_nop 1" covers the VALU-write -> DPP-read hazard of the chained steps.  Inputs here
+// are box gaps and running minima - never NaN - so v_min / v_max return exactly what fminf / fmaxf do.
+#define ZS_DPP_STEP(OP, CTRL) asm volatile("s_nop 1\n\t" OP " %0, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v)); v = r
 __device__ __forceinline__ float wave_minf(float v) {
-    v = fminf(v, dpp_f<0xB1>(v));
-    v = fminf(v, dpp_f<0x4E>(v));
-    v = fminf(v, dpp_f<0x141>(v));
-    v = fminf(v, dpp_f<0x140>(v));
+    float r;
+    ZS_DPP_STEP("v_min_f32_dpp", "quad_perm:[1,0,3,2]");
+    ZS_DPP_STEP("v_min_f32_dpp", "quad_perm:[2,3,0,1]");
+    ZS_DPP_STEP("v_min_f32_dpp", "row_half_mirror");
+    ZS_DPP_STEP("v_min_f32_dpp", "row_mirror");
     return fminf(fminf(lane_f(v, 0), lane_f(v, 16)), fminf(lane_f(v, 32), lane_f(v, 48)));
 }
 __device__ __forceinline__ float wave_maxf(float v) {
-    v = fmaxf(v, dpp_f<0xB1>(v));
-    v = fmaxf(v, dpp_f<0x4E>(v));
-    v = fmaxf(v, dpp_f<0x141>(v));
-    v = fmaxf(v, dpp_f<0x140>(v));
+    float r;
+    ZS_DPP_STEP("v_max_f32_dpp", "quad_perm:[1,0,3,2]");
+    ZS_DPP_STEP("v_max_f32_dpp", "quad_perm:[2,3,0,1]");
+    ZS_DPP_STEP("v_max_f32_dpp", "row_half_mirror");
+    ZS_DPP_STEP("v_max_f32_dpp", "row_mirror");
     return fmaxf(fmaxf(lane_f(v, 0), lane_f(v, 16)), fmaxf(lane_f(v, 32), lane_f(v, 48)));
 }
+#undef ZS_DPP_STEP
 // squared distance between two axis-aligned boxes (0 when they overlap; +inf when one is empty: lo = +inf, hi = -inf)
 __device__ __forceinline__ float box_gap2(const float *alo, const float *ahi, const float *blo, const float *bhi) {
     float s = 0.f;
@@ -357,6 +364,21 @@ __device__ __forceinline__ float point_gap2(float x, float y, float z, const flo
     const float gy = fmaxf(0.f, fmaxf(lo[1] - y, y - hi[1]));
     const float gz = fmaxf(0.f, fmaxf(lo[2] - z, z - hi[2]));
     return fmaf(gz, gz, fmaf(gy, gy, gx * gx));
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// point_gap2 of the lane's two queries at once: v_pk_add / v_pk_mul / v_pk_fma on (query 0, query 1) pairs, the box bounds
+// broadcast; per lane the operations and their order are point_gap2's, so the two results carry the same bits
+__device__ __forceinline__ f32x2 point_gap2_pair(const float (&qx)[PS_Q], const float (&qy)[PS_Q], const float (&qz)[PS_Q],
+                                                 const float *lo, const float *hi) {
+    const f32x2 x = {qx[0], qx[1]}, y = {qy[0], qy[1]}, z = {qz[0], qz[1]};
+    const f32x2 ax = f32x2{lo[0], lo[0]} - x, bx = x - f32x2{hi[0], hi[0]};
+    const f32x2 ay = f32x2{lo[1], lo[1]} - y, by = y - f32x2{hi[1], hi[1]};
+    const f32x2 az = f32x2{lo[2], lo[2]} - z, bz = z - f32x2{hi[2], hi[2]};
+    const f32x2 gx = {fmaxf(0.f, fmaxf(ax.x, bx.x)), fmaxf(0.f, fmaxf(ax.y, bx.y))};
+    const f32x2 gy = {fmaxf(0.f, fmaxf(ay.x, by.x)), fmaxf(0.f, fmaxf(ay.y, by.y))};
+    const f32x2 gz = {fmaxf(0.f, fmaxf(az.x, bz.x)), fmaxf(0.f, fmaxf(az.y, bz.y))};
+    return __builtin_elementwise_fma(gz, gz, __builtin_elementwise_fma(gy, gy, gx * gx));
 }
 
 // grid (tiles of the cloud, clouds): cloud b = normalize_pc(R_b src) (stats) or src itself (stats == nullptr) -> pack b
@@ -419,7 +441,6 @@ __device__ unsigned long long g_pose_blocks[2];   // [0] evaluated, [1] all
 // chunk in flight that wait covers exactly the chunk needed next.  The wait statement "returns" the chunk's registers, so
 // every consumer is ordered behind it.  (No LDS operation is outstanding inside the walk; all loads are drained on return.)
 typedef float f32x8 __attribute__((ext_vector_type(8)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct Chunk8 {
     f32x8 x, y, z;
     __device__ __forceinline__ void request(const float *c) {
@@ -579,13 +600,20 @@ __global__ __launch_bounds__(PS_THREADS) void pose_nn_soa_kernel(
                 gm = fminf(g0, g1);
             }
             while (__ballot(cand) != 0ull) {
-                const float near_sub = wave_minf(cand ? gm : INFINITY);
-                const int sl = __builtin_ctzll(__ballot(cand && gm == near_sub));
+                int sl;
+                if ((stage >> 30) & 1) {           // measurement (ZS_POSE_LANE_ORDER=1): candidates in index order
+                    sl = __builtin_ctzll(__ballot(cand));
+                } else {
+                    const float near_sub = wave_minf(cand ? gm : INFINITY);
+                    sl = __builtin_ctzll(__ballot(cand && gm == near_sub));
+                }
                 cand = cand && lane != sl;
                 const float lo[3] = {lane_f(slo[0], sl), lane_f(slo[1], sl), lane_f(slo[2], sl)};
                 const float hi[3] = {lane_f(shi[0], sl), lane_f(shi[1], sl), lane_f(shi[2], sl)};
-                const bool d0 = __ballot(point_gap2(qx[0], qy[0], qz[0], lo, hi) * PS_SKIP <= bestd[0]) != 0ull;
-                const bool d1 = __ballot(point_gap2(qx[1], qy[1], qz[1], lo, hi) * PS_SKIP <= bestd[1]) != 0ull;
+                // both runs' point-to-box distances in packed form (the same operations per lane as point_gap2)
+                const f32x2 pg = point_gap2_pair(qx, qy, qz, lo, hi) * f32x2{PS_SKIP, PS_SKIP};
+                const bool d0 = __ballot(pg.x <= bestd[0]) != 0ull;
+                const bool d1 = __ballot(pg.y <= bestd[1]) != 0ull;
                 const float *c = C + ((size_t)t * PS_NSUB + sl) * PS_SUB_FLOATS;        // uniform: scalar loads
                 if (d0 && d1)
                     scan_subtile<true, true>(c, qx, qy, qz, bestd);
@@ -967,7 +995,8 @@ int search_batch(const float *pred, const float *pred_nn, int n, const float *gt
         // the second launch spans every remaining block (it scans them all when the first kill merged the stages)
         const int smode = !merge_on || launched == 0 ? 0 : launched == 1 ? 1 : 2;
         const int span = smode == 1 ? bx - lo : hi - lo;
-        const int stage = (smode << 24) | hi;
+        static const int lane_order = getenv("ZS_POSE_LANE_ORDER") && atoi(getenv("ZS_POSE_LANE_ORDER")) ? 1 : 0;
+        const int stage = (lane_order << 30) | (smode << 24) | hi;
         const dim3 grid(span, count, 2);
         if (mode == 2)
             hipLaunchKernelGGL(pose_nn_soa_kernel<true>, grid, dim3(PS_THREADS), 0, st, static_cast<const float *>(packs), pstride,
