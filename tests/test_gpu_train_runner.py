@@ -135,6 +135,43 @@ def test_grad_reducer_rehearsal_on_one_gpu(tmp_path, encoder_sd, seeded_sd):
         dist.destroy_process_group()
 
 
+def test_captured_step_with_a_grad_reducer_on_one_gpu(tmp_path, encoder_sd, seeded_sd):
+    """the captured step is no longer switched off by a GradReducer.  RCCL group of one rank,
+    GradReducer(always=True): the graph holds forward + backward, reduce_in_place() packs / all-reduces / copies the buckets back
+    into the graph's static gradients behind every replay - same weights as the captured step without a reducer."""
+    import torch.distributed as dist
+    from zeroshape_amd import parallel
+    from zeroshape_amd.utils import util
+    from zeroshape_amd.utils.options import EasyDict as edict
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        results = []
+        for use_reducer in (False, True):
+            opt = train_opt(tmp_path, "--optim.fix_dpt", "--optim.hip_graph")
+            r = make_runner(opt, encoder_sd, seeded_sd, n_train=4)
+            if use_reducer:
+                r.reducer = parallel.GradReducer(r.graph.parameters(), bucket_mb=16.0, always=True)
+            assert r._step_capture_enabled(opt)
+            r.graph.train()
+            batch = next(iter(torch.utils.data.DataLoader(r.train_data, batch_size=4, shuffle=False)))
+            for it in range(5):                          # two eager warm-up steps, the capture, two replays
+                torch.manual_seed(11 + it)
+                var = util.move_to_device(edict({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}),
+                                          opt.device)
+                r.train_iteration(opt, var)
+            assert getattr(r, "_captured", None) is not None
+            if use_reducer:
+                assert len(r.reducer.buckets) >= 5 and not r.reducer.armed
+                r.reducer.close()
+            results.append({k: v.detach().clone() for k, v in r.graph.state_dict().items()})
+        for k in results[0]:
+            assert torch.equal(results[0][k], results[1][k]), k
+    finally:
+        dist.destroy_process_group()
+
+
 def test_train_loop_checkpoints_and_resume_skip(tmp_path, encoder_sd, seeded_sd):
     """Runner.train like the reference's (model/shape_engine.py:164-246, 283-284): an evaluation before
     the first step of a fresh run, latest.ckpt every freq.ckpt_latest iterations, checkpoint/ep<N>.ckpt at

@@ -124,6 +124,46 @@ def _worker_uneven(rank, world, initfile):
         dist.destroy_process_group()
 
 
+def _worker_in_place(rank, world, initfile):
+    """reduce_in_place(): the captured step's form - gradients stay in the tensors they were written to (a hipGraph replay's
+    static gradients), the hooks are quiet, every bucket is packed, all-reduced and copied back."""
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        net = Net()
+        red = parallel.GradReducer(net.parameters(), bucket_mb=0.3, pack_fn=torch_pack, module=net)
+        red.armed = False
+        ref = Net()
+        ref.load_state_dict(net.state_dict())
+        data = [torch.randn(world, 6, 40, generator=torch.Generator().manual_seed(200 + it)) for it in range(3)]
+        net(data[0][rank]).pow(2).mean().backward()                     # creates the gradient tensors ("the capture")
+        homes = {n: p.grad.data_ptr() for n, p in net.named_parameters() if p.grad is not None}
+        for it in range(3):
+            for p in net.parameters():                                  # a replay overwrites them in place
+                if p.grad is not None:
+                    p.grad.zero_()
+            net(data[it][rank]).pow(2).mean().backward()
+            red.reduce_in_place()
+            ref.zero_grad(set_to_none=True)
+            for r in range(world):
+                (ref(data[it][r]).pow(2).mean() / world).backward()
+            for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+                if n.startswith("unused"):
+                    assert p.grad is None
+                else:
+                    assert p.grad.data_ptr() == homes[n], n             # still the same tensor
+                    assert torch.allclose(p.grad, q.grad, atol=1e-6, rtol=1e-5), (it, n)
+        assert len(red.buckets) >= 3 and not red.works
+        red.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_reducer_in_place_form_of_the_captured_step():
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_in_place, args=(2, os.path.join(d, "init")), nprocs=2, join=True)
+
+
 def test_grad_reducer_uneven_usage_across_ranks():
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker_uneven, args=(2, os.path.join(d, "init")), nprocs=2, join=True)

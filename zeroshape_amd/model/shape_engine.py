@@ -221,8 +221,10 @@ class Runner:
     # static inputs, the gradients land in the capture's static .grad tensors, and gradient clipping + the one-launch
     # AdamW run eagerly behind it (their scalars - step count, learning rate - change every step).  Everything the
     # sequence reads besides the inputs is addressed in place (parameters, buffers, packed operands, workspaces);
-    # DropPath draws come from torch's graph-safe device generator.  Not captured: gradient accumulation windows
-    # and the multi-process reducer (the eager path below handles both).
+    # DropPath draws come from torch's graph-safe device generator.  Not captured: gradient accumulation windows (the eager
+    # path handles them).  With a multi-process GradReducer the graph still holds forward + backward; the buckets are packed,
+    # all-reduced and copied back into the graph's static gradients behind the replay (parallel.GradReducer.reduce_in_place:
+    # no overlap with the backward pass, which is inside the graph - the price of the captured step on more than one GPU).
     def _optimizer_step(self, opt):
         """:270-277: clip, step; under optim.amp through the loss scaler (unscale, skip on overflow, update the scale)."""
         scaler = getattr(self, "scaler", None)
@@ -236,7 +238,7 @@ class Runner:
     def _step_capture_enabled(self, opt):
         flag = os.environ.get("ZS_TRAIN_HIP_GRAPH")
         on = flag not in ("0", "") if flag is not None else bool(opt.optim.get("hip_graph", False))
-        return on and opt.optim.accum == 1 and self.reducer is None
+        return on and opt.optim.accum == 1
 
     def _train_iteration_captured(self, opt, var):
         """One step through the captured launch sequence; the first two steps of a signature run eagerly (they
@@ -278,6 +280,8 @@ class Runner:
             A.bump_generation()                    # the capture must contain the operand re-pack
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
+            if self.reducer is not None:
+                self.reducer.armed = False         # no collective inside the capture: reduce_in_place() runs behind the replay
             with torch.cuda.graph(graph, stream=cs):
                 out_var, loss = self.graph.forward(opt, static_var, training=True, get_loss=True)
                 loss = self.summarize_loss(opt, out_var, loss)
@@ -288,6 +292,8 @@ class Runner:
         for k, t in st["static"].items():
             t.copy_(tensors[k], non_blocking=True)
         st["graph"].replay()
+        if self.reducer is not None:
+            self.reducer.reduce_in_place()
         self._optimizer_step(opt)                  # no zero_grad: the replay overwrites the static gradients
         if self._rank() == 0 and getattr(opt, "output_path", None) and not getattr(opt, "debug", False) \
                 and self.it > 0 and self.it % opt.freq.ckpt_latest == 0:

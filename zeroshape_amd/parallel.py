@@ -340,6 +340,35 @@ class GradReducer(object):
                 p.grad = self.flat[bi][off:off + p.numel()].view_as(p)
             self.pending[bi] = len(plist)
 
+    def reduce_in_place(self):
+        """The captured training step (model/shape_engine.py): a hipGraph replay writes the gradients into FIXED tensors, so they
+        cannot be re-pointed at the buckets as finish() does.  Pack every bucket (grad / world -> flat), all-reduce the buckets in
+        order, and copy the averages back into the gradient tensors where they live.  No overlap with the backward pass (it is
+        inside the graph); the hooks stay quiet (`armed` False while the step is captured / replayed)."""
+        if self.world == 1 and not self.always:
+            return
+        if self.buckets is None:
+            mask = torch.tensor([0 if p.grad is None else 1 for p in self.params], dtype=torch.int32,
+                                device=self.params[0].device)
+            dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)    # one layout on every rank
+            mask = mask.cpu().tolist()
+            self._build({id(p) for p, u in zip(self.params, mask) if u})
+        self.next_launch = 0
+        self._launch_ready(flush=True)
+        for w in self.works:
+            w.wait()
+        self.works = []
+        self.next_launch = 0
+        for bi, plist in enumerate(self.buckets):
+            back = []
+            for q in plist:
+                _, off = self.slot[id(q)]
+                if q.grad is not None:
+                    back.append((q.grad.data_ptr(), self.flat[bi].data_ptr() + 4 * off, q.numel()))
+            if back:
+                self.pack_fn(back, 1.0, self.flat[bi].device)
+            self.pending[bi] = len(plist)
+
     def close(self):
         for h in self._hooks:
             h.remove()
