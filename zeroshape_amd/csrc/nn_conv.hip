@@ -1584,7 +1584,7 @@ static int conv2d_impl(const float *in, const float *packed_w, const float *scal
         // few tiles (14 x 14 maps at batch 28: 112; everything at batch 1): split the slabs across ~384 workgroups, partial
         // tiles through the workspace, summed in range order by conv_splitk_reduce_kernel (which applies the epilogue)
         static const long long split_target = getenv("ZS_CONV_PATCH_SPLIT_TARGET") ? atoll(getenv("ZS_CONV_PATCH_SPLIT_TARGET")) : 384;
-        static const long long split_min = getenv("ZS_CONV_PATCH_SPLIT_MIN") ? atoll(getenv("ZS_CONV_PATCH_SPLIT_MIN")) : 64;
+        static const long long split_min = getenv("ZS_CONV_PATCH_SPLIT_MIN") ? atoll(getenv("ZS_CONV_PATCH_SPLIT_MIN")) : 32;   // (64 until round 4: the 56 x 56 fusion layers at batch 1 - 50 workgroups - took the LDS-DMA kernel + split-K; batch 1 3.00 -> 2.95 ms)
         long long sp = 1;
         if (wgs < patch_min && workspace && wgs >= split_min) {
             sp = (split_target + wgs - 1) / wgs;

@@ -383,7 +383,7 @@ bool launch(const Args &a, hipStream_t st) {
     // The kernel wins where its tiles fill the chip once (ViT qkv / fc1 at batch 1: 8.8 vs 13.6 us, 11 vs 19.6 us); with few
     // tiles the small-tile kernel's narrower tiles (two workgroups per CU) are faster (proj 7.8 vs 8.6 us, 1 x 1 layers of
     // 256 channels on 14 x 14 maps 4.9 vs 7.0 us) - tools/ubench/small_gemm.hip.  ZS_STREAM_MIN_TILES moves the line.
-    static const long long min_tiles = getenv("ZS_STREAM_MIN_TILES") ? atoll(getenv("ZS_STREAM_MIN_TILES")) : 192;
+    static const long long min_tiles = getenv("ZS_STREAM_MIN_TILES") ? atoll(getenv("ZS_STREAM_MIN_TILES")) : 160;      // 96 / 128 / 160 / 192 / 256: 2.934 / 2.921 / 2.917 / 2.947 / 3.03 ms per batch-1 forward
     // ... or where splitting a long contraction puts the whole chip on a layer that has few tiles (ViT fc2: 84 tiles x 3)
     // OFF by default (ZS_STREAM_SPLIT=1 enables it).  It is correct now (the round-4 faults were ring registers reused ahead of the
     // final vmcnt wait - see the pin block after the K loop and tools/ring_audit.py; 900 back-to-back split launches and the
