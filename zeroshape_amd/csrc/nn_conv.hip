@@ -1667,9 +1667,21 @@ static int conv2d_impl(const float *in, const float *packed_w, const float *scal
         // 197-token matrices at batch 1: 28-84 workgroups): ~512 workgroups, >= 16 t-steps (K = 128) per
         // split, partial tiles inside the caller's workspace (zs_conv2d_splitk_workspace_bytes()).
         static const int split_target = getenv("ZS_CONV_SPLIT_TARGET") ? atoi(getenv("ZS_CONV_SPLIT_TARGET")) : 512;
-        if (workspace && (flags & ZS_CONV_SPLIT_SMALL) && wgs < 256) {
+        // ... and, whatever the caller's flag, layers with a LONG contraction on few workgroups (3 x 3 768 -> 768 on 7 x 7 maps at
+        // batch 1: 48 workgroups stream 21 MB of weights in 33.7 us): K >= ZS_CONV_SPLIT_LONG_K on <= ZS_CONV_SPLIT_LONG_WGS workgroups
+        // split towards ZS_CONV_SPLIT_LONG_TARGET workgroups.  Round 3 had tried the split everywhere at target 512 and found it a
+        // loss at batch 1; restricted to long contractions and with FEW ranges it pays (tools/enc_b1.py, batch-1 forward):
+        //   off 2.923 ms | K >= 6912: 2.838 | 4096: 2.844 | 2304: 2.792 (target 512) | 2304 at target 384 / 256 / 192: 2.785 / 2.787 /
+        //   2.726 | K >= 2048 at target 192 / 160 / 128 / 96: 2.712 / 2.717 / 2.752 / 2.788 | K >= 1024 at 160: 2.723
+        static const long long long_k = getenv("ZS_CONV_SPLIT_LONG_K") ? atoll(getenv("ZS_CONV_SPLIT_LONG_K")) : 2048;
+        static const long long long_wgs = getenv("ZS_CONV_SPLIT_LONG_WGS") ? atoll(getenv("ZS_CONV_SPLIT_LONG_WGS")) : 64;
+        static const int long_target = getenv("ZS_CONV_SPLIT_LONG_TARGET") ? atoi(getenv("ZS_CONV_SPLIT_LONG_TARGET")) : 192;
+        const bool flagged = (flags & ZS_CONV_SPLIT_SMALL) != 0;
+        const bool long_split = workspace && !fuse && a.K >= long_k && wgs <= long_wgs;
+        if (workspace && (flagged || long_split) && wgs < 256) {
             const int T = (a.K + BK - 1) / BK * 2;
-            long long sp = (split_target + wgs - 1) / wgs;
+            const int target = flagged ? split_target : long_target;
+            long long sp = (target + wgs - 1) / wgs;
             if (sp > T / 16) sp = T / 16;
             if (sp > 16) sp = 16;
             const long long cap = (long long)(WS_SPLITK_BYTES / 4) / (M * (long long)Cout);
