@@ -1407,6 +1407,95 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs a) {
     }
 }
 
+// The same for a layer that also writes statistics of what it stores (zs_conv_fuse.out_mode 1 / 2): one workgroup per
+// (32-row tile, 32 NJ columns) of the output - the tile shape, thread <-> quad map and reduction trees of
+// conv_gemm_small_kernel's vector epilogue, so the statistics land in the layout (and the order of summation within a tile)
+// the unsplit launch would have produced; the value of each element is the sum of the ranges' partials in range order.
+template <int NJ>
+__global__ __launch_bounds__(256) void conv_splitk_reduce_stats_kernel(ConvArgs a) {
+    constexpr int SN = 32 * NJ, QPR = SN / 4, PASSES = SM * QPR / 256;
+    __shared__ float wsum[4 * 2 * QPR * 2 + 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * SM, n0 = blockIdx.y * SN;
+    const size_t total = (size_t)a.M * a.Cout;
+    const float *ws = a.ws + WS_COUNTER_FLOATS;
+    const int om = a.fz.out_mode, gw = om == 1 ? a.Cout / a.fz.out_groups : 4;
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ps++) {
+        const int e = tid + 256 * ps;
+        const int row = e / QPR, col = 4 * (e % QPR), m = m0 + row, n = n0 + col;
+        const bool valid = m < a.M && n < a.Cout;
+        const size_t o = (size_t)(valid ? m : 0) * a.Cout + (valid ? n : 0);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+            v = *reinterpret_cast<const f32x4 *>(ws + o);
+            for (int sp = 1; sp < a.splits; sp++) v += *reinterpret_cast<const f32x4 *>(ws + (size_t)sp * total + o);
+#pragma unroll
+            for (int c = 0; c < 4; c++) v[c] = v[c] * (a.scale ? a.scale[n + c] : 1.0f) + (a.shift ? a.shift[n + c] : 0.0f);
+            if (a.res1) v += *reinterpret_cast<const f32x4 *>(a.res1 + o);
+            if (a.res2) v += *reinterpret_cast<const f32x4 *>(a.res2 + o);
+#pragma unroll
+            for (int c = 0; c < 4; c++) v[c] = activate(v[c], a.act);
+            *reinterpret_cast<f32x4 *>(a.out + o) = v;
+        }
+        if (om == 1) {
+            if (gw >= 4) {
+                s0 += (v[0] + v[1]) + (v[2] + v[3]);
+                q0 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            } else {
+                s0 += v[0] + v[1]; q0 += v[0] * v[0] + v[1] * v[1];
+                s1 += v[2] + v[3]; q1 += v[2] * v[2] + v[3] * v[3];
+            }
+        } else if (om == 2) {
+            float rs = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+            for (int sh = 1; sh < QPR; sh <<= 1) rs += __shfl_xor(rs, sh, 64);
+            const float mean = rs * (1.0f / SN);
+            float d2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; c++) d2 += (v[c] - mean) * (v[c] - mean);
+#pragma unroll
+            for (int sh = 1; sh < QPR; sh <<= 1) d2 += __shfl_xor(d2, sh, 64);
+            if (valid && (e % QPR) == 0) {
+                float *dst = a.fz.out_stats + ((size_t)m * gridDim.y + blockIdx.y) * 2;
+                dst[0] = rs;
+                dst[1] = d2;
+            }
+        }
+    }
+    if (om == 1) {
+        const int qpg = gw >= 4 ? gw / 4 : 1;
+#pragma unroll
+        for (int sh = QPR; sh < 64; sh <<= 1) {
+            s0 += __shfl_xor(s0, sh, 64); q0 += __shfl_xor(q0, sh, 64);
+            s1 += __shfl_xor(s1, sh, 64); q1 += __shfl_xor(q1, sh, 64);
+        }
+        for (int sh = 1; sh < qpg; sh <<= 1) { s0 += __shfl_xor(s0, sh, 64); q0 += __shfl_xor(q0, sh, 64); }
+        const int gpt = gw >= 4 ? QPR / qpg : 2 * QPR;
+        if (lane < QPR && (lane % qpg) == 0) {
+            if (gw >= 4) {
+                wsum[(wave * gpt + lane / qpg) * 2] = s0;
+                wsum[(wave * gpt + lane / qpg) * 2 + 1] = q0;
+            } else {
+                wsum[(wave * gpt + 2 * lane) * 2] = s0;     wsum[(wave * gpt + 2 * lane) * 2 + 1] = q0;
+                wsum[(wave * gpt + 2 * lane + 1) * 2] = s1; wsum[(wave * gpt + 2 * lane + 1) * 2 + 1] = q1;
+            }
+        }
+        __syncthreads();
+        if (tid < gpt) {
+            const int g = n0 / gw + tid;
+            if (g < a.fz.out_groups) {
+                float ts = 0.f, tq = 0.f;
+                for (int w = 0; w < 4; w++) { ts += wsum[(w * gpt + tid) * 2]; tq += wsum[(w * gpt + tid) * 2 + 1]; }
+                float *dst = a.fz.out_stats + ((size_t)blockIdx.x * a.fz.out_groups + g) * 2;
+                dst[0] = ts;
+                dst[1] = tq;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" size_t zs_conv2d_splitk_workspace_bytes(void) {
@@ -1677,7 +1766,8 @@ static int conv2d_impl(const float *in, const float *packed_w, const float *scal
         static const long long long_wgs = getenv("ZS_CONV_SPLIT_LONG_WGS") ? atoll(getenv("ZS_CONV_SPLIT_LONG_WGS")) : 64;
         static const int long_target = getenv("ZS_CONV_SPLIT_LONG_TARGET") ? atoi(getenv("ZS_CONV_SPLIT_LONG_TARGET")) : 192;
         const bool flagged = (flags & ZS_CONV_SPLIT_SMALL) != 0;
-        const bool long_split = workspace && !fuse && a.K >= long_k && wgs <= long_wgs;
+        // (fused layers too - their statistics are then written by conv_splitk_reduce_stats_kernel; the vector epilogue needs Cout % 4)
+        const bool long_split = workspace && (!fuse || (Cout & 3) == 0) && a.K >= long_k && wgs <= long_wgs;
         if (workspace && (flagged || long_split) && wgs < 256) {
             const int T = (a.K + BK - 1) / BK * 2;
             const int target = flagged ? split_target : long_target;
@@ -1690,7 +1780,7 @@ static int conv2d_impl(const float *in, const float *packed_w, const float *scal
         }
         if (fuse && fuse->in_mode) {
             // fused input normalisation: pointwise (in_mode 1, 2, 3) or tap-major plain (in_mode 1) geometry, split-fp16
-            if (!(pw || (tm && plain && fuse->in_mode == 1)) || a.splits != 1) {
+            if (!(pw || (tm && plain && fuse->in_mode == 1))) {
                 zs::set_err("zs_conv2d_nhwc_fused: in_mode %d needs a pointwise layer (or, for in_mode 1, Cin %% 8 == 0)", fuse->in_mode);
                 return 0;
             }
@@ -1699,7 +1789,7 @@ static int conv2d_impl(const float *in, const float *packed_w, const float *scal
         if (pw) hipLaunchKernelGGL((conv_gemm_small_kernel<NJ_, true, 0, false, true, XF_>), grid, dim3(256), 0, st, a);          \
         else hipLaunchKernelGGL((conv_gemm_small_kernel<NJ_, false, 2, true, true, (XF_ == 1 ? 1 : 0)>), grid, dim3(256), 0, st, a); \
     } while (0)
-            const dim3 grid((unsigned)((M + SM - 1) / SM), (unsigned)((Cout + (narrow ? 31 : 63)) / (narrow ? 32 : 64)), 1);
+            const dim3 grid((unsigned)((M + SM - 1) / SM), (unsigned)((Cout + (narrow ? 31 : 63)) / (narrow ? 32 : 64)), (unsigned)a.splits);
             if (narrow) {
                 if (fuse->in_mode == 1) ZS_LAUNCH_XF(1, 1); else ZS_LAUNCH_XF(1, 2);
             } else {
@@ -1714,9 +1804,15 @@ static int conv2d_impl(const float *in, const float *packed_w, const float *scal
             ZS_LAUNCH(conv_gemm_small_kernel, 2,);
         }
         if (a.splits > 1) {
-            const long long total = M * (long long)Cout;
-            const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
-            hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
+            if (fuse && fuse->out_mode) {           // epilogue + statistics of the summed ranges, in the unsplit launch's layout
+                const dim3 rgrid((unsigned)((M + SM - 1) / SM), (unsigned)((Cout + (narrow ? 31 : 63)) / (narrow ? 32 : 64)));
+                if (narrow) hipLaunchKernelGGL(conv_splitk_reduce_stats_kernel<1>, rgrid, dim3(256), 0, st, a);
+                else hipLaunchKernelGGL(conv_splitk_reduce_stats_kernel<2>, rgrid, dim3(256), 0, st, a);
+            } else {
+                const long long total = M * (long long)Cout;
+                const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+                hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
+            }
         }
     } else {
         const bool tm = !pw && !no_tm && (Cin % BK) == 0;

@@ -377,6 +377,8 @@ bool launch(const Args &a, hipStream_t st) {
         int k = 0, n = 0;
         if (sscanf(only, "%d,%d", &k, &n) == 2 && (k != a.K || n != a.N)) return false;
     }
+    static const int max_k = getenv("ZS_STREAM_MAX_K") ? atoi(getenv("ZS_STREAM_MAX_K")) : (1 << 30);   // measurement: longer K -> small-tile kernel
+    if (a.K > max_k) return false;
     const Plan p = plan(a);
     if (a.out_stats && 32 * p.nj != a.stats_cols) return false;
     const long long T = (long long)p.mtiles * p.ntiles;
