@@ -1749,7 +1749,25 @@ static int conv2d_impl(const float *in, const float *packed_w, const float *scal
             g.tickets = static_cast<int *>(workspace);
             g.parts_bytes = WS_PARTS_BYTES;
             g.max_tickets = (int)WS_COUNTER_FLOATS;
-            if (zs::stream_gemm::launch(g, st)) return zs::check_launch("zs_conv2d_nhwc") ? 1 : 0;
+            int ranges = 1;
+            g.two_launch_max = workspace && (Cout & 3) == 0 ? 4 : 1;
+            g.ranges = &ranges;
+            if (zs::stream_gemm::launch(g, st)) {
+                if (ranges > 1) {           // the kernel wrote raw partial sums of `ranges` K ranges: sum + epilogue (+ statistics) here
+                    a.splits = ranges;
+                    if (g.out_stats) {
+                        const int cols = g.stats_cols;
+                        const dim3 rgrid((unsigned)((M + SM - 1) / SM), (unsigned)((Cout + cols - 1) / cols));
+                        if (cols == 32) hipLaunchKernelGGL(conv_splitk_reduce_stats_kernel<1>, rgrid, dim3(256), 0, st, a);
+                        else hipLaunchKernelGGL(conv_splitk_reduce_stats_kernel<2>, rgrid, dim3(256), 0, st, a);
+                    } else {
+                        const long long total = M * (long long)Cout;
+                        const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+                        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
+                    }
+                }
+                return zs::check_launch("zs_conv2d_nhwc") ? 1 : 0;
+            }
         }
         const long long wgs = ((M + SM - 1) / SM) * ((Cout + (narrow ? 31 : 63)) / (narrow ? 32 : 64));
         // Split K across workgroups while the launch would leave most of the 256 CUs idle (14x14 maps,

@@ -24,6 +24,11 @@ struct Args {
     int *tickets;
     size_t parts_bytes;
     int max_tickets;
+    // two-launch K split: with `two_launch_max` > 1 the launcher may split a long contraction into up to that many ranges whose
+    // raw partial sums go to parts[z][M][N]; it returns the number of ranges in *ranges (1: complete output written) and the
+    // CALLER runs the reduction + epilogue (nn_conv.hip: conv_splitk_reduce[_stats]_kernel)
+    int two_launch_max;
+    int *ranges;
 };
 
 // true when the kernel takes the problem (and has launched it); false: the caller uses another kernel

@@ -31,7 +31,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-struct Geo { int mtiles, ntiles, splits; };
+struct Geo { int mtiles, ntiles, splits, raw; };      // raw: K ranges write raw partial sums [z][M][N], no ticket
 
 __device__ __forceinline__ float activate(float v, int act) {
     if (act == ZS_ACT_RELU) return fmaxf(v, 0.f);
@@ -225,6 +225,18 @@ __global__ __launch_bounds__(64 * NW) void stream_gemm_kernel(Args a, Geo g) {
 #pragma unroll
         for (int w = 1; w < NW; w++) v[ps] += *reinterpret_cast<const f32x4 *>(&part[w][p][4 * c]);
     }
+    if (g.splits > 1 && g.raw) {
+        // two-launch split: this range's raw partial sums, laid out like the output; the caller's reduce launch sums the ranges
+        // in range order and runs the epilogue (and the statistics)
+        float *dstz = a.parts + (size_t)z * a.M * a.N;
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ps++) {
+            const int e = tid + THREADS * ps, p = e / QPR, c = e % QPR;
+            const int m = m0 + p, n = n0 + 4 * c;
+            if (m < a.M && n < a.N) *reinterpret_cast<f32x4 *>(dstz + (size_t)m * a.N + n) = v[ps];
+        }
+        return;
+    }
     if (g.splits > 1) {
         // K split across blockIdx.y: publish this range's partial tile, take a ticket; the last arriver sums all ranges in range
         // order - the same sum whoever it is
@@ -370,7 +382,7 @@ Plan plan(const Args &a) {
 
 bool launch(const Args &a, hipStream_t st) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K & 15) || (a.N & 3) || (a.lda & 3)) return false;
-    if (a.out_stats && (a.stats_cols != 32 && a.stats_cols != 64 || a.N % a.stats_cols)) return false;
+    if (a.out_stats && ((a.stats_cols != 32 && a.stats_cols != 64) || a.N % a.stats_cols)) return false;
     if (a.in_stats && (a.in_tiles <= 0 || a.in_tiles > 32 || a.lda != a.K)) return false;
     if ((size_t)a.M * a.lda * 4 >= ((size_t)1 << 32)) return false;        // 32-bit lane offsets
     if (const char *only = getenv("ZS_STREAM_ONLY")) {                // debugging: the kernel for one (K, N) only
@@ -398,8 +410,25 @@ bool launch(const Args &a, hipStream_t st) {
         int k = 0, n = 0;
         if (p.splits > 1 && sscanf(only, "%d,%d", &k, &n) == 2 && (k != a.K || n != a.N)) return false;
     }
-    Geo g = {p.mtiles, p.ntiles, p.splits};
-    const dim3 grid((unsigned)(8 * ((T + 7) / 8)), (unsigned)p.splits);
+    Geo g = {p.mtiles, p.ntiles, p.splits, 0};
+    if (a.ranges) *a.ranges = 1;
+    // two-launch K split (the caller reduces).  OFF by default (ZS_STREAM_2L_K = smallest K that splits): for the ViT fc2 at batch 1
+    // (168 tiles of 32 x 32, K 3,072, every workgroup streams 786 KB) two / three ranges + the reduce launch measured 2.71 / 2.68 ms
+    // per forward against 2.67 without - the reduce launch eats what the shorter ranges save.
+    static const int two_k = getenv("ZS_STREAM_2L_K") ? atoi(getenv("ZS_STREAM_2L_K")) : (1 << 30);
+    static const int two_target = getenv("ZS_STREAM_2L_TARGET") ? atoi(getenv("ZS_STREAM_2L_TARGET")) : 384;
+    if (a.two_launch_max > 1 && a.ranges && a.parts && p.splits == 1 && a.K >= two_k) {
+        long long z = two_target / T;
+        if (z > a.two_launch_max) z = a.two_launch_max;
+        if (z > (a.K / 16) / 8) z = (a.K / 16) / 8;                               // at least eight K = 16 steps per range
+        while (z > 1 && (size_t)z * a.M * a.N * 4 > a.parts_bytes) z--;
+        if (z > 1) {
+            g.splits = (int)z;
+            g.raw = 1;
+            *a.ranges = (int)z;
+        }
+    }
+    const dim3 grid((unsigned)(8 * ((T + 7) / 8)), (unsigned)g.splits);
 #define ZS_SG(MI_, NJ_)                                                                                              \
     do {                                                                                                             \
         if (a.in_stats) hipLaunchKernelGGL((stream_gemm_kernel<4, MI_, NJ_, 3, true>), grid, dim3(256), 0, st, a, g); \
