@@ -245,6 +245,24 @@ def main():
     points_per_step = batch * G ** 3
     value = points_per_step * args.steps / dt
 
+    # what prepare()'s per-image output check (on by default since round 4; Implicit._launch_image_check) costs the step:
+    # the same timed loop without it (round 3's behaviour)
+    image_check = None
+    if world == 1 and precision_run == "f16x3" and getattr(net, "image_check", False) and not args.no_extras:
+        net.image_check = False
+        for _ in range(max(1, args.warmup)):
+            step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt0 = time.perf_counter() - t1
+        net.image_check = True
+        image_check = {"on": True, "ms_per_step_without": round(dt0 / args.steps * 1e3, 3),
+                       "value_without": round(points_per_step * args.steps / dt0, 1),
+                       "what": "per-image f16x3-vs-fp32 probe of every prepare() on side streams beside the grid launch"}
+
     # ---- roofline of the dominant kernel: HIP events around decoder launches only -------
     b, e, _ = parallel.point_bounds(G ** 3, world, rank)
     stream = torch.cuda.current_stream(dev)       # the stream the C ABI launches on
@@ -378,6 +396,8 @@ def main():
         }
         if exact_f32 is not None:
             line["exact_f32"] = exact_f32
+        if image_check is not None:
+            line["image_check"] = image_check
         line.update(extras)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -21,6 +21,7 @@ Not on the HIP path (raises, never silently approximated):
   * ``semantic=True`` / ``posenc_3D>0`` / ``pos_perlayer=True`` variants (unused by
     options/shape.yaml).
 """
+import contextlib
 import os
 from functools import partial
 
@@ -84,7 +85,8 @@ class DecoderState(object):
         self.programs, self.batch, self.precision, self.exact = programs, batch, precision, exact
         # split states from a calibrating prepare(): int32 [batch] on the device, 1 = this image's probe points differed by
         # more than CALIBRATION_TOL between the two arithmetics -> every tile of the image is re-evaluated in fp32
-        self.image_flags = None
+        self.image_flags = None       # int32 [B] from prepare()'s per-image check (1: evaluate this image in fp32)
+        self.check_event = None       # recorded behind that check on its side stream; consumers wait for it on THEIR stream
 
     @property
     def stride_bytes(self):
@@ -131,7 +133,9 @@ class Implicit(nn.Module):
         # from the same arithmetic whether or not the attention map is requested; the map itself
         # and the training path always use fp32.
         self.precision = os.environ.get("ZS_DECODER_PRECISION", "f16x3")
-        self._workspace = {}      # device -> scratch tensor for the query kernels
+        self._workspace = {}      # (device, stream) -> scratch tensor for the query kernels
+        self._check_streams = {}  # device -> side stream of the per-image check
+        self._probe_cache = {}    # device -> the probe points
         self.last_tile_flags = None   # int32 per 128-point tile of the last split-fp16 query (1 = re-evaluated in fp32)
         self.envelope_guard = True    # False: raw split-fp16 results everywhere (measurements of the arithmetic itself)
         # Output-error calibration of the default arithmetic (prepare()): once per weight version the raw split
@@ -140,13 +144,15 @@ class Implicit(nn.Module):
         # otherwise every later prepare() of these weights returns an fp32 state.  The envelope fences above look
         # at operands; this one looks at the result.  ZS_DECODER_CALIBRATE=0 / .calibrate = False turns it off.
         self.calibrate = os.environ.get("ZS_DECODER_CALIBRATE", "1") != "0"
-        # per-image output check of prepare().  It costs the latency of one fp32 wave tile + one split wave tile
-        # per prepare() - 1.2 + 0.45 ms at any batch up to 8 images, however few probe points - which is 1.7 of the 9.7 ms of a
-        # batch-1 vox-64 inference; ZS_DECODER_IMAGE_CHECK=0 (or impl.image_check = False) leaves the per-weights verdict +
-        # the kernel's own envelope flags (S_GUARD) as the only guards, as in round 3.
+        # per-image output check of prepare().  Its two probe launches cost the latency of one fp32 wave tile + one
+        # split wave tile (1.2 + 0.45 ms at any batch up to 8 images, however few probe points); they run on a side stream beside
+        # the first grid launch (_launch_image_check), which still delays that launch's last workgroups: ~0.8 ms per prepare()
+        # instead of 2.6 ms in front of it.  ZS_DECODER_IMAGE_CHECK=0 (or impl.image_check = False) leaves the per-weights
+        # verdict + the kernel's own envelope flags (S_GUARD) as the only guards, as in round 3.
         self.image_check = os.environ.get("ZS_DECODER_IMAGE_CHECK", "1") != "0"
         self.calibration_range = (-1.5, 1.5)      # probe cube (options/shape.yaml:52 eval.range)
-        self.last_calibration = None  # dict(max_abs_diff, mean_abs_diff, max_abs_logit, points, tol, selected)
+        self._last_calibration = None  # dict(max_abs_diff, mean_abs_diff, max_abs_logit, points, tol, selected)
+        self._last_check_event = None  # the newest per-image check (side stream): readers of last_calibration wait for it
         self._calibration = None      # (weights key, last_calibration)
 
     # ---- init (implicit.py:232-249) -------------------------------------------------
@@ -191,15 +197,28 @@ class Implicit(nn.Module):
             self._packed = (key, prog, lat, P.split_envelope(sd)[0])
         return self._packed[1], self._packed[2]
 
+    @property
+    def last_calibration(self):
+        """The newest calibration record.  Its per-image maxima are written by the side-stream check of prepare(): the
+        CURRENT stream is made to wait for that check first (no host wait), so a later .cpu() / .tolist() reads finished data."""
+        ev = self._last_check_event
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+        return self._last_calibration
+
+    @last_calibration.setter
+    def last_calibration(self, value):
+        self._last_calibration = value
+
     def split_allowed(self, device):
         """Host half of the envelope guard: weights finite and within program.W_MAX."""
         self.packed(device)
         return self._packed[3]
 
     def workspace(self, device, extra_bytes=0):
-        """Scratch for the query kernels (zs_sdf_workspace_bytes() [+ the attention dump], one
-        per device; launches on one stream serialise, so sharing it is safe)."""
-        key = str(device)
+        """Scratch for the query kernels (zs_sdf_workspace_bytes() [+ the attention dump], one per (device, stream):
+        launches on one stream serialise, so sharing it there is safe)."""
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream)      # (the per-image check runs on a side stream)
         need = (_lib.load().zs_sdf_workspace_bytes() + extra_bytes + 3) // 4
         if key not in self._workspace or self._workspace[key].numel() < need:
             self._workspace[key] = torch.empty(need, dtype=torch.float32, device=device)
@@ -211,11 +230,15 @@ class Implicit(nn.Module):
     def _probe_points(self, device):
         """Deterministic probe cloud in the evaluation cube: a scrambled lattice (golden-ratio steps per axis), so
         every call and every box uses the same 4096 points."""
+        cached = self._probe_cache.get(str(device))
+        if cached is not None:
+            return cached
         i = torch.arange(self.CALIBRATION_POINTS, dtype=torch.float64)
         lo, hi = self.calibration_range
         frac = torch.stack([(i * a + b) % 1.0 for a, b in ((0.7548776662466927, 0.5), (0.5698402909980532, 0.25),
                                                             (0.4301597090019468, 0.75))], -1)
-        return (lo + (hi - lo) * frac).to(torch.float32)[None].to(device)
+        pts = self._probe_cache[str(device)] = (lo + (hi - lo) * frac).to(torch.float32)[None].to(device)
+        return pts
 
     @torch.no_grad()
     def _calibrate(self, split, exact):
@@ -291,42 +314,92 @@ class Implicit(nn.Module):
             if self._calibrate(split, programs):
                 state = DecoderState(split, B, "f16x3", exact=programs)
                 if self.image_check:
-                    state.image_flags, maxima = self._image_check(split, programs)
-                    self.last_calibration = dict(self.last_calibration, per_image_max_abs_diff=maxima)
+                    self._launch_image_check(state, split, programs)
                 return state
         return DecoderState(programs, B)
 
+    def _launch_image_check(self, state, split, exact):
+        """The per-image check on a SIDE stream, so that it runs beside the first grid launch instead of in front of it: the
+        fp32 probe launch alone is the latency of one fp32 wave tile (1.2 ms however few points).  The state carries the
+        flags and an event; the query paths wait for the event (on their stream, no host wait) between the split launch and
+        the fp32 launch that re-evaluates flagged tiles, and OR the image flags into the tile flags there.  Inside a stream
+        capture the check runs inline (a fork that the capture might not join is not worth the risk)."""
+        dev = split.device
+        main = torch.cuda.current_stream(dev)
+        if torch.cuda.is_current_stream_capturing() or os.environ.get("ZS_DECODER_CHECK_INLINE", "0") != "0":
+            state.image_flags, maxima = self._image_check(split, exact)
+            self._last_check_event = None
+        else:
+            pair = self._check_streams.get(str(dev))
+            if pair is None:
+                # HIGH priority: when the prologue ends, the probe launches and the caller's grid launch become ready together;
+                # a resident persistent grid launch would keep the probes waiting until its workgroups retire
+                pair = self._check_streams[str(dev)] = (torch.cuda.Stream(device=dev, priority=-1),
+                                                        torch.cuda.Stream(device=dev, priority=-1))
+            side, side2 = pair
+            side.wait_stream(main)                          # the programs are ready
+            side2.wait_stream(main)
+            state.image_flags, maxima = self._image_check(split, exact, streams=(side, side2))
+            state.check_event = torch.cuda.Event()
+            state.check_event.record(side)
+            for t in (split, exact):
+                t.record_stream(side)                       # read over there: the allocator must not recycle them early
+                t.record_stream(side2)
+            for t in (state.image_flags, maxima):
+                t.record_stream(main)                       # written over there, read here
+            self._last_check_event = state.check_event
+        self._last_calibration = dict(self._last_calibration, per_image_max_abs_diff=maxima)
+
     @torch.no_grad()
-    def _image_check(self, split, exact):
+    def _image_check(self, split, exact, streams=None):
         """The f16x3 error also depends on the image's K / V records, and the per-weights verdict above was measured on the
-        first image seen.  So every prepare() runs the probe points of EVERY image through both kernels (~0.2 ms per image)
-        and flags - on the device, no host read - the images whose max |logit difference| exceeds CALIBRATION_TOL (or is not
-        finite): their tiles start flagged (see _tile_flags), so the fp32 launch behind every split launch re-evaluates
-        them entirely.  -> (int32 flags [B], float32 maxima [B]), both device tensors."""
+        first image seen.  So every prepare() runs the probe points of EVERY image through both kernels and flags - on the
+        device, no host read - the images whose max |logit difference| exceeds CALIBRATION_TOL (or is not finite): the fp32
+        launch behind every split launch re-evaluates them entirely (_join_image_check).  `streams` = (a, b): the fp32 probes
+        on a, the split probes on b (concurrently), the comparison on a; None: everything on the current stream.
+        -> (int32 flags [B], float32 maxima [B]), both device tensors."""
         B = split.shape[0]
-        pts = self._probe_points(split.device).expand(B, -1, -1).contiguous()
+        a, b = streams if streams is not None else (None, None)
+        ctx = (lambda st: torch.cuda.stream(st)) if streams is not None else (lambda st: contextlib.nullcontext())
+        with ctx(a):
+            pts = self._probe_points(split.device).expand(B, -1, -1).contiguous()
+        if b is not None:
+            b.wait_stream(a)                            # pts (before a's probe launch: b must not wait for THAT)
+        with ctx(a):
+            want = self.query_points(DecoderState(exact, B), pts)
         guard, flags = self.envelope_guard, self.last_tile_flags
         self.envelope_guard = False                 # the raw arithmetic is what is being measured
         try:
-            got = self.query_points(DecoderState(split, B, "f16x3", exact=exact), pts)
+            with ctx(b):
+                got = self.query_points(DecoderState(split, B, "f16x3", exact=exact), pts)
         finally:
             self.envelope_guard, self.last_tile_flags = guard, flags
-        want = self.query_points(DecoderState(exact, B), pts)
-        maxima = (got - want).abs().amax(1)
-        bad = ~(maxima <= self.CALIBRATION_TOL)          # NaN / inf compare false: flagged
-        return bad.to(torch.int32), maxima
+        if b is not None:
+            a.wait_stream(b)
+            got.record_stream(a)
+            pts.record_stream(b)
+        with ctx(a):
+            maxima = (got - want).abs().amax(1)
+            bad = ~(maxima <= self.CALIBRATION_TOL)          # NaN / inf compare false: flagged
+            return bad.to(torch.int32), maxima
 
     def _tile_flags(self, batch, m, device, state=None):
-        """Tile flags of one split launch: zero (the kernel sets the tiles that leave its envelope), or - for the images the
-        per-image check of prepare() flagged - one from the start: the fp32 launch that follows then re-evaluates the whole
-        image.  No host read anywhere."""
-        image_flags = getattr(state, "image_flags", None)
-        if not self.envelope_guard and image_flags is None:
+        """Tile flags of one split launch: zero - the kernel sets the tiles that leave its envelope, _join_image_check() adds
+        the images the per-image check of prepare() flagged.  None: neither guard is on.  No host read anywhere."""
+        if not self.envelope_guard and getattr(state, "image_flags", None) is None:
             return None
-        tiles = (m + 127) // 128
-        if image_flags is None:
-            return torch.zeros(batch * tiles, dtype=torch.int32, device=device)
-        return image_flags[:, None].expand(batch, tiles).contiguous().view(-1)
+        return torch.zeros(batch * ((m + 127) // 128), dtype=torch.int32, device=device)
+
+    @staticmethod
+    def _join_image_check(state, flags):
+        """Between a split launch and the fp32 launch that re-evaluates flagged tiles: wait (this stream, not the host) for the
+        state's per-image check and flag every tile of the images it flagged - the fp32 launch then evaluates them whole."""
+        image_flags = getattr(state, "image_flags", None)
+        if image_flags is None or flags is None:
+            return
+        if state.check_event is not None:
+            torch.cuda.current_stream(flags.device).wait_event(state.check_event)
+        flags.view(state.batch, -1).bitwise_or_(image_flags[:, None])
 
     @torch.no_grad()
     def query_points(self, state, points_3D, need_attn=False):
@@ -351,6 +424,7 @@ class Implicit(nn.Module):
                                                    _lib.ptr(pts), M, _lib.ptr(out), _lib.ptr(flags), ws, st)
                 _lib.check(rc, "zs_sdf_query_points_split")
                 # flagged tiles (outside the split arithmetic's envelope) again, exactly
+                self._join_image_check(state, flags)
                 if flags is not None:
                     rc = lib.zs_sdf_query_points(_lib.ptr(state.exact), state.exact.stride(0) * 4, state.batch,
                                                  _lib.ptr(pts), M, _lib.ptr(out), None, _lib.ptr(flags), ws, st)
@@ -392,6 +466,7 @@ class Implicit(nn.Module):
                                                  _lib.ptr(axis), G, slice_begin, slice_end,
                                                  1 if apply_sigmoid else 0, _lib.ptr(out), _lib.ptr(flags), ws, st)
                 _lib.check(rc, "zs_sdf_query_grid_split")
+                self._join_image_check(state, flags)
                 if flags is not None:
                     rc = lib.zs_sdf_query_grid(_lib.ptr(state.exact), state.exact.stride(0) * 4, state.batch,
                                                _lib.ptr(axis), G, slice_begin, slice_end,
@@ -429,6 +504,7 @@ class Implicit(nn.Module):
                                                        _lib.ptr(axis), G, point_begin, point_end, sig, _lib.ptr(out),
                                                        _lib.ptr(flags), ws, st)
                 _lib.check(rc, "zs_sdf_query_grid_range_split")
+                self._join_image_check(state, flags)
                 if flags is not None:
                     rc = lib.zs_sdf_query_grid_range(_lib.ptr(state.exact), state.exact.stride(0) * 4, state.batch,
                                                      _lib.ptr(axis), G, point_begin, point_end, sig, _lib.ptr(out),
