@@ -1066,7 +1066,20 @@ __global__ __launch_bounds__(WAVES * 64, 1) void sdf_decode_split_kernel(
 
     const int tiles_per_img = (m + PTS_PER_BLOCK - 1) / PTS_PER_BLOCK;
     const int total = tiles_per_img * batch;
-    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+    // DYNAMIC tile order (round 4).  Every workgroup takes tile blockIdx.x first, then fetches the next index from a counter in
+    // the workspace tail (one agent-scope atomic per 128-point tile of ~0.44 ms, issued when the tile is done: nothing of this
+    // kernel's own is in flight then, so the hand-counted vmcnt waits of decode_tile are not disturbed).  A static
+    // tile += gridDim.x deal makes the launch as slow as its unluckiest workgroup: one whose CU was still busy when the launch
+    // started (the per-image probe launches of Implicit.prepare run beside it), or the 98 of 256 that get a ninth tile at
+    // vox 64.  Thread 0 fetches, the index reaches the other waves through a per-workgroup slot in global memory (the kernel
+    // owns all 160 KiB of LDS) behind one barrier.  D = total - gridDim.x indices are real; each workgroup's terminal fetch
+    // is >= D, and the one that draws D + gridDim.x - 1 - the last fetch of the launch - puts the counter back to zero for
+    // the next launch.  Which workgroup evaluates a tile does not change its result.
+    int *tile_counter = reinterpret_cast<int *>(workspace + (size_t)MAX_WGS * WAVES * ZSLAB_F4) + 256;   // 1 KiB into the tail
+    int *tile_slot = tile_counter + 16 + blockIdx.x;
+    const int dyn_tiles = total > (int)gridDim.x ? total - (int)gridDim.x : 0;
+    for (int tile = blockIdx.x;;) {
+      if (tile < total) {
         const int img = tile / tiles_per_img;
         const int t = tile - img * tiles_per_img;
         const char *prog = programs + (size_t)img * program_stride_bytes;
@@ -1112,6 +1125,17 @@ __global__ __launch_bounds__(WAVES * 64, 1) void sdf_decode_split_kernel(
             if (__builtin_amdgcn_ballot_w64(over || bad != 0) != 0 && lane == 0) tile_flags[tile] = 1;
         }
         if (lane < 32 && p < m) out[(size_t)img * m + p] = logit;
+      }
+        if (threadIdx.x == 0) {
+            const int d = __hip_atomic_fetch_add(tile_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == dyn_tiles + (int)gridDim.x - 1)
+                __hip_atomic_store(tile_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(tile_slot, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();                      // (also drains thread 0's store: s_waitcnt vmcnt(0) in front of the barrier)
+        const int d = __builtin_amdgcn_readfirstlane(__hip_atomic_load(tile_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (d >= dyn_tiles) break;
+        tile = (int)gridDim.x + d;
     }
 }
 

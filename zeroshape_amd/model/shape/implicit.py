@@ -221,7 +221,8 @@ class Implicit(nn.Module):
         key = (str(device), torch.cuda.current_stream(device).cuda_stream)      # (the per-image check runs on a side stream)
         need = (_lib.load().zs_sdf_workspace_bytes() + extra_bytes + 3) // 4
         if key not in self._workspace or self._workspace[key].numel() < need:
-            self._workspace[key] = torch.empty(need, dtype=torch.float32, device=device)
+            # zeroed ONCE: the tail holds the split kernel's tile counter, which every launch leaves at zero again
+            self._workspace[key] = torch.zeros(need, dtype=torch.float32, device=device)
         return self._workspace[key]
 
     CALIBRATION_POINTS = 4096
