@@ -112,7 +112,10 @@ size_t zs_sdf_program_bytes(void);
 /* Bytes of the per-image scratch the prologue needs. */
 size_t zs_sdf_prologue_scratch_bytes(void);
 /* Bytes of the workspace the query kernels need (independent of batch and point count:
- * one 96 KiB slab per resident wave, 96 MiB in all; contents are scratch). */
+ * one 96 KiB slab per resident wave, 96 MiB in all; contents are scratch).  ZERO it once after
+ * allocating it: its last 4 KiB hold the split-fp16 kernels' tile counter (dynamic tile order,
+ * DESIGN 3b.2), which every launch finds at zero and leaves at zero.  One workspace per stream
+ * that launches concurrently. */
 size_t zs_sdf_workspace_bytes(void);
 /* Extra workspace bytes zs_sdf_query_points needs BEHIND the fixed part when `attn` is
  * requested (raw probability tiles: ~14.5 KiB per point). */

@@ -397,3 +397,25 @@ def test_per_image_check_sends_an_outlier_image_to_the_exact_kernels():
     g = m.query_grid(lat, axis, apply_sigmoid=False, state=st)
     ge = m.query_grid(lat, axis, apply_sigmoid=False, state=m.prepare(lat, "f32"))
     assert torch.equal(g[1], ge[1])
+
+
+def test_dynamic_tile_order_leaves_its_counter_at_zero_and_changes_no_value(net):
+    """Round 4: the split kernels draw tiles from a counter in the workspace tail.  Launches of very different sizes back to
+    back (fewer tiles than workgroups, one tile, many tiles, a grid) give the values a fresh workspace gives, and the counter is
+    back at zero after each."""
+    latent = torch.from_numpy(syn.seeded_latent(seed=5, batch=1)).cuda()
+    dev = latent.device
+    st = net.prepare(latent, "f16x3", calibrate=False)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    outs = []
+    for m in (5, 128, 129, 128 * 300 + 17, 1000):
+        pts = (torch.rand(1, m, 3, generator=g) * 3 - 1.5).to(dev)
+        outs.append((pts, net.query_points(st, pts)))
+        torch.cuda.synchronize()
+        from zeroshape_amd import _lib
+        words = _lib.load().zs_sdf_workspace_bytes() // 4         # (the tensor may be longer: attention dumps live behind)
+        counter = net.workspace(dev).view(torch.int32)[words - 1024 + 256]       # 1 KiB into the 4 KiB tail
+        assert int(counter) == 0, (m, int(counter))
+    net._workspace.clear()                                       # a fresh (zeroed) workspace
+    for pts, want in outs:
+        assert torch.equal(net.query_points(st, pts), want)
