@@ -248,6 +248,21 @@ def _graph(dev, encoder="resnet"):
     return opt, g.to(dev).eval()
 
 
+def _profiled_kernels_per_forward(path, forwards=11):
+    """Kernel launches per forward from a tools/prof_encoder.sh per-(kernel, grid) table: every row except the model build's
+    (weight uploads = __amd_rocclr_copyBuffer, one presplit per layer, torch's fills)."""
+    import re
+    try:
+        n = 0
+        for line in open(path):
+            m = re.match(r"(.*?)\s+grid\s+\d+\s+\d+\s+\d+\s+calls\s+(\d+)", line)
+            if m and not any(t in m.group(1) for t in ("copyBuffer", "presplit_weight", "FillFunctor", "fillBuffer")):
+                n += int(m.group(2))
+        return round(n / forwards, 1) if n else None
+    except OSError:
+        return None
+
+
 def encoder_leg(dev, cpu=True):
     """Encoder half of Graph.forward (graph_shape.py:117-150: DPT-hybrid depth + intrinsics head + seen-surface
     geometry + ResNet-50 coordinate encoder), replayed as one hipGraph, batch 1 and options/shape.yaml's 28;
@@ -271,6 +286,11 @@ def encoder_leg(dev, cpu=True):
         out["b%d" % B] = {"ms": round(ms, 3), "ms_min": round(mn, 3), "tflops": round(gflop * B / ms, 1),
                           "frac_of_peak": round(gflop * B / ms / 2500.0, 4), "abi_calls_per_forward": calls}
     g.enable_hip_graph(False)
+    for B in (1, 28):                          # kernels per forward from the committed kernel trace of the same forward (eager)
+        k = _profiled_kernels_per_forward(os.path.join(ROOT, "profiles", "r04_encoder_b%d_by_grid.txt" % B))
+        if k is not None and "b%d" % B in out:
+            out["b%d" % B]["kernels_per_forward"] = k
+            out["b%d" % B]["kernels_per_forward_source"] = "profiles/r04_encoder_b%d_by_grid.txt (rocprofv3 kernel trace, 11 forwards)" % B
     if cpu:
         from oracle import encoder_ref
         sd = {k: v.detach().cpu() for k, v in g.state_dict().items()}
