@@ -418,11 +418,13 @@ def inference_leg(dev):
             v = v[0] if isinstance(v, tuple) else v
             pts = E.get_dense_3D_grid(o, v, N)
             return E.compute_level_grid(o, g.impl_network, v.latent_depth, None, pts, None)[0]
-        ms, mn = _events(run, 8)
+        for _ in range(3):                     # the side-stream check's scratch and the allocator's pools settle in a few calls
+            run()
+        ms, mn = _events(run, 10)
         out["vox%d" % N] = {"ms": round(ms, 3), "ms_min": round(mn, 3), "points": (N + 1) ** 3}
         if N == 64:         # the same without prepare()'s per-image output check (round 3's behaviour): what that guarantee costs
             g.impl_network.image_check = False
-            ms, mn = _events(run, 8)
+            ms, mn = _events(run, 10)
             g.impl_network.image_check = True
             out["vox64_without_image_check"] = {"ms": round(ms, 3), "ms_min": round(mn, 3)}
     g.enable_hip_graph(False)
@@ -602,6 +604,10 @@ if __name__ == "__main__":
         print(json.dumps({"encoder": encoder_leg(dev)}), flush=True)
     if "surface" in want:
         print(json.dumps({"iso_surface": surface_leg(dev)}), flush=True)
+    if "inference" in want:
+        print(json.dumps({"inference": inference_leg(dev)}), flush=True)
+    if "encoder_att" in want:
+        print(json.dumps({"encoder_att": encoder_att_leg(dev)}), flush=True)
     if "train" in want:
         print(json.dumps({"train_step": train_leg(dev)}), flush=True)
     if "trained" in want:

@@ -136,6 +136,7 @@ class Implicit(nn.Module):
         self._workspace = {}      # (device, stream) -> scratch tensor for the query kernels
         self._check_streams = {}  # device -> side stream of the per-image check
         self._probe_cache = {}    # device -> the probe points
+        self._check_keepalive = []  # (event, split programs, exact programs) of checks that may still be running
         self.last_tile_flags = None   # int32 per 128-point tile of the last split-fp16 query (1 = re-evaluated in fp32)
         self.envelope_guard = True    # False: raw split-fp16 results everywhere (measurements of the arithmetic itself)
         # Output-error calibration of the default arithmetic (prepare()): once per weight version the raw split
@@ -343,9 +344,12 @@ class Implicit(nn.Module):
             state.image_flags, maxima = self._image_check(split, exact, streams=(side, side2))
             state.check_event = torch.cuda.Event()
             state.check_event.record(side)
-            for t in (split, exact):
-                t.record_stream(side)                       # read over there: the allocator must not recycle them early
-                t.record_stream(side2)
+            # the side streams read `split` / `exact` (10 MB per image each): they must outlive that work even if the caller drops
+            # the state at once.  Not record_stream() - it parks the blocks behind events and makes the allocator grow its pool
+            # with fresh 10 MB hipMallocs for several calls - but a reference held here until the check's event has completed
+            while self._check_keepalive and self._check_keepalive[0][0].query():
+                self._check_keepalive.pop(0)
+            self._check_keepalive.append((state.check_event, split, exact))
             for t in (state.image_flags, maxima):
                 t.record_stream(main)                       # written over there, read here
             self._last_check_event = state.check_event
