@@ -341,15 +341,28 @@ class Implicit(nn.Module):
             side, side2 = pair
             side.wait_stream(main)                          # the programs are ready
             side2.wait_stream(main)
+            # ... and the caller's stream waits for a marker at the HEAD of each side stream: when the prologue ends all three
+            # queues become ready at once, and whichever launch is dispatched first takes the CUs.  Behind the markers the probe
+            # launches are the next packets of their queues, while the caller's queue first has to resolve its barrier: the
+            # probes start first (vox 128 without the markers: the grid launch won the race and the fp32 probe ran AFTER its 28 ms)
+            for st_ in (side, side2):
+                head = torch.cuda.Event()
+                head.record(st_)
+                main.wait_event(head)
             state.image_flags, maxima = self._image_check(split, exact, streams=(side, side2))
             state.check_event = torch.cuda.Event()
             state.check_event.record(side)
             # the side streams read `split` / `exact` (10 MB per image each): they must outlive that work even if the caller drops
             # the state at once.  Not record_stream() - it parks the blocks behind events and makes the allocator grow its pool
             # with fresh 10 MB hipMallocs for several calls - but a reference held here until the check's event has completed
-            while self._check_keepalive and self._check_keepalive[0][0].query():
-                self._check_keepalive.pop(0)
-            self._check_keepalive.append((state.check_event, split, exact))
+            if os.environ.get("ZS_DECODER_CHECK_RECORD_STREAM", "0") != "0":      # A/B: the allocator-side alternative
+                for t in (split, exact):
+                    t.record_stream(side)
+                    t.record_stream(side2)
+            else:
+                while self._check_keepalive and self._check_keepalive[0][0].query():
+                    self._check_keepalive.pop(0)
+                self._check_keepalive.append((state.check_event, split, exact))
             for t in (state.image_flags, maxima):
                 t.record_stream(main)                       # written over there, read here
             self._last_check_event = state.check_event
