@@ -433,6 +433,9 @@ int zs_depth_metrics(const float *prediction, const float *target, const float *
                                * weights at run time */
 #define ZS_CONV_IN_DILATE2 8  /* read the input as if zero-stuffed x2 ([B][2H-1][2W-1][Cin] virtual): the
                                  data gradient of a stride-2 convolution as a stride-1 convolution */
+#define ZS_CONV_FORCE_TILE256 1024 /* tests / tuning: the 256 x 256 ping-pong kernel (csrc/nn_conv_pp256.h) for every layer it can
+                                    * run - pointwise, ZS_CONV_F16X3 | ZS_CONV_W_PRESPLIT, Cin % 32 == 0, Cout % 4 == 0 - whatever
+                                    * its size (by default: K >= 768 and at least half a round of tiles, or K >= 2048) */
 #define ZS_CONV_IN_UPSAMPLE2 512 /* zs_conv3x3_tail_nhwc only: `in` is [B][H/2][W/2][Cin] and the layer runs on its x2 bilinear
                                     up-sampling (align_corners, zs_upsample2x_nhwc's formula), which is never written */
 size_t zs_conv2d_packed_floats(int Cin, int Cout, int kh, int kw);

@@ -556,3 +556,46 @@ def test_conv3x3_tail_on_the_upsampled_input(B, Cin, H, W, Cmid):
     finally:
         ops.set_conv_precision(prev)
         ops.FUSE_UPSAMPLE = prev_up
+
+
+@pytest.mark.parametrize("M,Cin,Cout,res,act", [
+    (5516, 768, 3072, False, "gelu"),         # ViT fc1 at batch 28: 264 tiles = 256 whole + 8 tail tiles in K ranges
+    (5516, 768, 2304, False, "none"),         # qkv: 198 whole tiles, no tail
+    (5516, 3072, 768, True, "none"),          # fc2: 66 tiles, every one of them in K ranges
+    (5488, 768, 768, True, "none"),           # proj (196-token form): ragged last row tile
+    (16384, 256, 1028, True, "relu"),         # Cout % 256 = 4 (CoutPad 1152: the last column tile is half empty), 5 x 64 tiles
+    (12544, 32, 512, False, "relu"),          # one stage of K = 32
+])
+def test_conv2d_pointwise_256_tiles(M, Cin, Cout, res, act):
+    """The 256 x 256 ping-pong kernel of the large pointwise layers (csrc/nn_conv_pp256.h): parity with torch, whole tiles
+    bit-identical to the 128 x 128 LDS-DMA kernel (same MFMAs in the same k order), tail tiles (K ranges summed by a second
+    launch) within summation order of it, bit-reproducible."""
+    from zeroshape_amd.nn import ops, pack
+    g = torch.Generator().manual_seed(M + Cin + Cout)
+    x = torch.randn(1, M, 1, Cin, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / np.sqrt(Cin)
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(1, M, 1, Cout, generator=g) if res else None
+    want = F.linear(x, w[:, :, 0, 0], b)
+    if res:
+        want = want + r
+    want = {"gelu": F.gelu, "relu": F.relu, "none": lambda t: t}[act](want)
+    a = {"gelu": ops.ACT_GELU, "relu": ops.ACT_RELU, "none": ops.ACT_NONE}[act]
+    pc = pack.pack_conv(w, b).to("cuda")
+    prev = ops.CONV_PRECISION
+    try:
+        ops.set_conv_precision("f16x3")
+        xg, rg = x.cuda(), (r.cuda() if res else None)
+        got = ops.conv2d(xg, pc, res1=rg, act=a, tiling="tile256")
+        close(got, want)
+        assert torch.equal(got, ops.conv2d(xg, pc, res1=rg, act=a, tiling="tile256"))
+        tiles = -(-M // 256) * -(-Cout // 256)
+        if Cin >= 768 and (tiles >= 128 or Cin >= 2048):            # large layers take this kernel by themselves
+            assert torch.equal(got, ops.conv2d(xg, pc, res1=rg, act=a))
+        old = ops.conv2d(xg, pc, res1=rg, act=a, tiling="large")
+        close(got, old.cpu(), tol=5e-6)
+        tiles = -(-M // 256) * -(-Cout // 256)
+        if tiles > 128 and tiles % 256 == 0 or 128 < tiles < 256:      # no tail: every tile whole
+            assert torch.equal(got, old)
+    finally:
+        ops.set_conv_precision(prev)

@@ -15,7 +15,7 @@ from zeroshape_amd.nn import autograd as A          # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    for n, d in (("B", 4), ("H", 14), ("Cin", 256), ("Cout", 256), ("k", 3), ("stride", 1), ("iters", 50)):
+    for n, d in (("B", 4), ("H", 14), ("Cin", 256), ("Cout", 256), ("k", 3), ("stride", 1), ("iters", 50), ("W", 0)):
         ap.add_argument("--" + n, type=int, default=d)
     ap.add_argument("--mode", default="all")
     ap.add_argument("--engine", default="autograd", help="autograd (training path, nn/autograd.py) | ops (inference path, nn/ops.py)")
@@ -23,7 +23,7 @@ def main():
     a = ap.parse_args()
     if a.engine == "ops":
         from zeroshape_amd.nn import ops, pack
-        x = torch.randn(a.B, a.H, a.H, a.Cin, device="cuda")
+        x = torch.randn(a.B, a.H, a.W or a.H, a.Cin, device="cuda")
         w = torch.randn(a.Cout, a.Cin, a.k, a.k) / (a.Cin * a.k * a.k) ** 0.5
         pc = pack.pack_conv(w, None, stride=a.stride, padding=a.k // 2).to("cuda")
         y = ops.conv2d(x, pc, tiling=a.tiling)

@@ -42,11 +42,23 @@ def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def _includes(path, seen):
+    """The quoted includes of a source file that live under csrc/ or include/, transitively."""
+    import re
+    with open(path, "rb") as fh:
+        text = fh.read().decode("utf-8", "replace")
+    for name in re.findall(r'^\s*#\s*include\s+"([^"]+)"', text, flags=re.M):
+        f = os.path.normpath(os.path.join(os.path.dirname(path), name))
+        if os.path.exists(f) and f not in seen:
+            seen.append(f)
+            _includes(f, seen)
+    return seen
+
+
 def _stamp(src, flags):
     h = hashlib.sha1()
     h.update(" ".join(flags).encode())
-    for f in [src] + [os.path.join(CSRC, x) for x in sorted(os.listdir(CSRC)) if x.endswith(".h")] + \
-            [os.path.join(INCLUDE, "zeroshape_hip.h")]:
+    for f in [src] + sorted(_includes(src, [])):
         with open(f, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()

@@ -984,6 +984,7 @@ __global__ __launch_bounds__(512) void conv_gemm_dma256_kernel(ConvArgs a) {
 }
 
 #include "nn_conv_patch.h"
+#include "nn_conv_pp256.h"
 
 // ---- small-problem variant: many small tiles, K split across the four waves ----
 // The 128x128 tiling needs >= ~256 tiles to fill 256 CUs; a 14x14 feature map or a 197-token
@@ -1697,6 +1698,43 @@ static int conv2d_impl(const float *in, const float *packed_w, const float *scal
                 const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
                 hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
             }
+            return zs::check_launch("zs_conv2d_nhwc") ? 1 : 0;
+        }
+    }
+    // ---- large pointwise layers: 256 x 256 ping-pong tiles (nn_conv_pp256.h) ----
+    {
+        static const int pp_on = getenv("ZS_CONV_PP256") ? atoi(getenv("ZS_CONV_PP256")) : 1;
+        // (tools/bench_pp256.py, old -> new us: fc1 110 -> 97, qkv 91 -> 73, fc2 142 -> 95, 16,384 x 3,072 x 768 312 -> 236; it loses
+        // where a tile's K loop is short against its 256 KiB epilogue and one workgroup per CU cannot overlap the two: proj
+        // (66 tiles x K 768) 38 -> 44, K <= 512 everywhere)
+        static const long long pp_min_tiles = getenv("ZS_CONV_PP256_MIN_TILES") ? atoll(getenv("ZS_CONV_PP256_MIN_TILES")) : 48;
+        static const long long pp_min_k = getenv("ZS_CONV_PP256_MIN_K") ? atoll(getenv("ZS_CONV_PP256_MIN_K")) : 768;
+        static const long long pp_long_k = getenv("ZS_CONV_PP256_LONG_K") ? atoll(getenv("ZS_CONV_PP256_LONG_K")) : 2048;
+        static const int pp_max_split = getenv("ZS_CONV_PP256_MAX_SPLIT") ? atoi(getenv("ZS_CONV_PP256_MAX_SPLIT")) : 8;
+        static const int pp_min_steps = getenv("ZS_CONV_PP256_MIN_STEPS") ? atoi(getenv("ZS_CONV_PP256_MIN_STEPS")) : 4;
+        static const int cus = [] { int dev = 0, n = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+        const long long T = ((M + pp256::TM - 1) / pp256::TM) * ((a.CoutPad + pp256::TN - 1) / pp256::TN);
+        const bool pp_forced = (flags & ZS_CONV_FORCE_TILE256) != 0;
+        const bool pp_pays = pp_on && T >= pp_min_tiles && a.K >= pp_min_k && (T >= cus / 2 || a.K >= pp_long_k);
+        if ((pp_forced || pp_pays) && pw && f16 && a.w_split && !fuse && (Cin % pp256::SK) == 0 && (Cout & 3) == 0 &&
+            !(flags & (ZS_CONV_FORCE_SMALL | ZS_CONV_FORCE_LARGE))) {
+            const long long steps = a.K / pp256::SK;
+            // the tail: tiles beyond the last whole round of the CUs (or all of them, when they fill less than half of one)
+            long long tail = T <= cus / 2 ? T : (T % cus < cus / 2 ? T % cus : 0), sp = 1;
+            if (T < cus && T > cus / 2) tail = 0;
+            if (tail && workspace) {
+                sp = cus / tail;
+                if (sp > pp_max_split) sp = pp_max_split;
+                if (sp > steps / pp_min_steps) sp = steps / pp_min_steps;
+                const long long cap = (long long)(WS_PARTS_BYTES / 4) / ((long long)pp256::TM * pp256::TN);
+                if (tail * sp > cap) sp = cap / tail;
+            }
+            if (sp < 2) { tail = 0; sp = 1; }
+            a.sk_per = (int)tail;
+            a.splits = (int)sp;
+            const dim3 grid((unsigned)(T - tail + tail * sp));
+            hipLaunchKernelGGL(pp256::conv_gemm_pp256_kernel, grid, dim3(512), 0, st, a);
+            if (tail) hipLaunchKernelGGL(pp256::pp256_tail_kernel, dim3(pp256::MI * pp256::NJ * 4, (unsigned)tail), dim3(512), 0, st, a);
             return zs::check_launch("zs_conv2d_nhwc") ? 1 : 0;
         }
     }

@@ -20,7 +20,7 @@ def _stream(t):
     return _lib.current_stream_ptr(t.device)
 
 
-_TILING = {None: 0, "large": 2, "small": 4}
+_TILING = {None: 0, "large": 2, "small": 4, "tile256": 1024}
 
 # Arithmetic of the inference convolutions / linear layers (zs_conv2d_nhwc): "f32" = exact fp32 MFMA,
 # "f16x3" = split-fp16 on the 16-bit matrix pipe (ZS_CONV_F16X3; operands as two fp16 halves, ~2^-21
