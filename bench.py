@@ -216,13 +216,27 @@ def main():
     # the once-per-weight-version calibration of the default arithmetic (Implicit.prepare: 4096 probe points through
     # both kernels, one host read) happens here, outside the timed region, like the packing; its verdict decides
     # which kernel the timed steps run and is reported on the line
-    precision_run = net.prepare(latent).precision
+    st0 = net.prepare(latent)
+    # the timed steps return occupancies (apply_sigmoid=True): the arithmetic they run is the state's verdict in THAT space
+    precision_run = "f16x3" if st0.precision == "f16x3" and st0.occ_ok else "f32"
     calibration = net.last_calibration
+    stream = torch.cuda.current_stream(dev)       # the stream the C ABI launches on
 
-    def step():
+    def step(events=None):
         st = net.prepare(latent)                   # per-image prologue (all images, every rank)
-        return parallel.sharded_level_grid_points(
-            lambda b, e: net.query_grid_range(latent, axis, b, e, apply_sigmoid=True, state=st), G)
+
+        def query(b, e):
+            # the decoder launch of this step between two HIP events on its own stream (roofline.launch_ms_*: measured INSIDE the
+            # timed steps, so launch time <= step time by construction)
+            if events is None:
+                return net.query_grid_range(latent, axis, b, e, apply_sigmoid=True, state=st)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            out = net.query_grid_range(latent, axis, b, e, apply_sigmoid=True, state=st)
+            e1.record(stream)
+            events.append((e0, e1))
+            return out
+        return parallel.sharded_level_grid_points(query, G)
 
     def barrier():
         if world > 1:
@@ -232,11 +246,13 @@ def main():
     for _ in range(args.warmup):
         occ = step()
     barrier()
+    step_events = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        occ = step()
+        occ = step(step_events)
     barrier()
     dt = time.perf_counter() - t0
+    kern_ms = sorted(a_.elapsed_time(b_) for a_, b_ in step_events)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -265,7 +281,6 @@ def main():
 
     # ---- roofline of the dominant kernel: HIP events around decoder launches only -------
     b, e, _ = parallel.point_bounds(G ** 3, world, rank)
-    stream = torch.cuda.current_stream(dev)       # the stream the C ABI launches on
     pts_launch = batch * (e - b)
 
     def time_launches(precision, reps):
@@ -295,13 +310,15 @@ def main():
                 "points_per_launch": pts_launch, "launch_ms_mean": round(mean, 4),
                 "launch_ms_min": round(kern_ms[0], 4), "algorithmic_flop_per_point": FLOP_PER_POINT}
 
-    kern_ms, st = time_launches(precision_run, max(3, min(args.steps, 10)))
-    roofline = roofline_of(precision_run, kern_ms)
+    roofline = roofline_of(precision_run, kern_ms)          # the launches of the timed steps themselves
+    roofline["launch_ms_source"] = "HIP events around the decoder launch inside each of the %d timed steps" % args.steps
+    st = net.prepare(latent)
     if world == 1 and not args.no_extras:
         roofline["power"] = power_under_load(
             lambda: net.query_grid_range(latent, axis, b, e, apply_sigmoid=True, state=st))
 
     exact_f32 = None
+    logit_sweep = None
     if precision_run == "f16x3" and world == 1:
         ms32, st32 = time_launches("f32", 3)
         r32 = roofline_of("f32", ms32)
@@ -315,6 +332,12 @@ def main():
                      "occupancy_flips": int(flips.sum()), "points": int(lg.numel()),
                      "max_abs_logit_at_flip": float(lg32[flips].abs().max()) if int(flips.sum()) else 0.0}
         del lg, lg32
+        if not args.no_extras:
+            from tools import bench_legs as legs
+            try:
+                logit_sweep = legs.logit_sweep_leg(dev, sd)
+            except Exception as ex:                     # a leg must never take the headline line down
+                logit_sweep = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -398,6 +421,8 @@ def main():
             line["exact_f32"] = exact_f32
         if image_check is not None:
             line["image_check"] = image_check
+        if logit_sweep is not None:
+            line["logit_scale_sweep"] = logit_sweep
         line.update(extras)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 32
+#define ZS_ABI_VERSION 33
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -112,10 +112,11 @@ size_t zs_sdf_program_bytes(void);
 /* Bytes of the per-image scratch the prologue needs. */
 size_t zs_sdf_prologue_scratch_bytes(void);
 /* Bytes of the workspace the query kernels need (independent of batch and point count:
- * one 96 KiB slab per resident wave, 96 MiB in all; contents are scratch).  ZERO it once after
- * allocating it: its last 4 KiB hold the split-fp16 kernels' tile counter (dynamic tile order,
- * DESIGN 3b.2), which every launch finds at zero and leaves at zero.  One workspace per stream
- * that launches concurrently. */
+ * one 96 KiB slab per resident wave, 96 MiB in all; contents are scratch, the caller need not
+ * initialise it: since ABI 33 the library zeroes the split-fp16 kernels' tile counter in its last
+ * 4 KiB (dynamic tile order) on the stream in front of every launch - a 4-byte memset
+ * node under stream capture).  One workspace per stream that launches concurrently.
+ * ZS_SPLIT_STATIC_TILES=1 in the environment (read per launch) selects the static tile deal. */
 size_t zs_sdf_workspace_bytes(void);
 /* Extra workspace bytes zs_sdf_query_points needs BEHIND the fixed part when `attn` is
  * requested (raw probability tiles: ~14.5 KiB per point). */

@@ -194,7 +194,7 @@ SIGNATURES = {
     "zs_readout_concat_bwd": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
 }
 
-ABI_VERSION = 32
+ABI_VERSION = 33
 _lib = None
 
 

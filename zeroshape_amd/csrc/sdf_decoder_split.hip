@@ -40,6 +40,7 @@
 //    program permutes those K-blocks accordingly - and over the output tiles of impl_mlp).
 //  * The attention map (implicit.py:277) is only produced by the fp32 kernel.
 #include "zs_common.h"
+#include <stdlib.h>
 #include "sdf_layout.h"
 #include "sdf_math.h"
 #include "zs_split16.h"
@@ -1053,7 +1054,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void sdf_decode_split_kernel(
     int G, long long first_point,      //  GRID: linear index of the first grid point
     int m,                             // points per image handled by this launch
     float *__restrict__ out, int apply_sigmoid, f32x4 *__restrict__ workspace,
-    int *__restrict__ tile_flags) {  // [tiles] zeroed by the caller, or null
+    int *__restrict__ tile_flags,    // [tiles] zeroed by the caller, or null
+    int static_order) {              // 1: tile += gridDim.x, no counter (ZS_SPLIT_STATIC_TILES=1: the A/B arm of tools/ab_tile_order.py)
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     float *prm = lds;
     const int lane = threadIdx.x & 63;
@@ -1075,6 +1077,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void sdf_decode_split_kernel(
     // owns all 160 KiB of LDS) behind one barrier.  D = total - gridDim.x indices are real; each workgroup's terminal fetch
     // is >= D, and the one that draws D + gridDim.x - 1 - the last fetch of the launch - puts the counter back to zero for
     // the next launch.  Which workgroup evaluates a tile does not change its result.
+    // The counter is the LIBRARY's: launch_counter_reset() zeroes it on the stream in front of every launch (a
+    // caller's un-zeroed workspace, or a faulted launch that left it non-zero, must not decide which tiles get evaluated),
+    // and a fetched index is used only when it is a real one (unsigned compare).
     int *tile_counter = reinterpret_cast<int *>(workspace + (size_t)MAX_WGS * WAVES * ZSLAB_F4) + 256;   // 1 KiB into the tail
     int *tile_slot = tile_counter + 16 + blockIdx.x;
     const int dyn_tiles = total > (int)gridDim.x ? total - (int)gridDim.x : 0;
@@ -1126,6 +1131,11 @@ __global__ __launch_bounds__(WAVES * 64, 1) void sdf_decode_split_kernel(
         }
         if (lane < 32 && p < m) out[(size_t)img * m + p] = logit;
       }
+        if (static_order) {                   // wave-uniform
+            tile += (int)gridDim.x;
+            if (tile >= total) break;
+            continue;
+        }
         if (threadIdx.x == 0) {
             const int d = __hip_atomic_fetch_add(tile_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (d == dyn_tiles + (int)gridDim.x - 1)
@@ -1134,7 +1144,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void sdf_decode_split_kernel(
         }
         __syncthreads();                      // (also drains thread 0's store: s_waitcnt vmcnt(0) in front of the barrier)
         const int d = __builtin_amdgcn_readfirstlane(__hip_atomic_load(tile_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        if (d >= dyn_tiles) break;
+        if ((unsigned)d >= (unsigned)dyn_tiles) break;
         tile = (int)gridDim.x + d;
     }
 }
@@ -1290,6 +1300,16 @@ extern "C" int zs_sdf_split_programs(const void *programs, size_t program_stride
     return zs::check_launch("zs_sdf_split_programs") ? 1 : 0;
 }
 
+// in front of every split launch: the dynamic tile order's counter (1 KiB into the workspace tail) starts at zero whatever
+// the caller's workspace held (a memset node when the stream is being captured); -> static_order of the launch
+static int launch_counter_reset(void *workspace, hipStream_t st) {
+    const char *e = getenv("ZS_SPLIT_STATIC_TILES");                  // read per launch: tools/ab_tile_order.py alternates the arms in one process
+    if (e && atoi(e) != 0) return 1;
+    int *tile_counter = reinterpret_cast<int *>(static_cast<f32x4 *>(workspace) + (size_t)MAX_WGS * WAVES * ZSLAB_F4) + 256;
+    (void)hipMemsetAsync(tile_counter, 0, sizeof(int), st);
+    return 0;
+}
+
 extern "C" int zs_sdf_query_points_split(const void *split_programs, size_t program_stride_bytes,
                                          int batch, const float *points, int m, float *logits,
                                          int *tile_flags, void *workspace, void *stream) {
@@ -1307,10 +1327,11 @@ extern "C" int zs_sdf_query_points_split(const void *split_programs, size_t prog
         zs::set_err("zs_sdf_query_points_split: too many tiles");
         return 0;
     }
+    const int static_order = launch_counter_reset(workspace, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL((sdf_decode_split_kernel<false>), dim3(decode_grid_size(batch, m)),
                        dim3(WAVES * 64), 0, static_cast<hipStream_t>(stream),
                        static_cast<const char *>(split_programs), program_stride_bytes, batch, points,
-                       nullptr, 0, 0LL, m, logits, 0, static_cast<f32x4 *>(workspace), tile_flags);
+                       nullptr, 0, 0LL, m, logits, 0, static_cast<f32x4 *>(workspace), tile_flags, static_order);
     return zs::check_launch("zs_sdf_query_points_split") ? 1 : 0;
 }
 
@@ -1336,10 +1357,11 @@ extern "C" int zs_sdf_query_grid_range_split(const void *split_programs, size_t 
     }
     if (!check_programs("zs_sdf_query_grid_range_split", split_programs, program_stride_bytes)) return 0;
     const int m = (int)mm;
+    const int static_order = launch_counter_reset(workspace, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL((sdf_decode_split_kernel<true>), dim3(decode_grid_size(batch, m)),
                        dim3(WAVES * 64), 0, static_cast<hipStream_t>(stream),
                        static_cast<const char *>(split_programs), program_stride_bytes, batch, nullptr,
-                       axis, G, point_begin, m, out, apply_sigmoid, static_cast<f32x4 *>(workspace), tile_flags);
+                       axis, G, point_begin, m, out, apply_sigmoid, static_cast<f32x4 *>(workspace), tile_flags, static_order);
     return zs::check_launch("zs_sdf_query_grid_range_split") ? 1 : 0;
 }
 
@@ -1364,10 +1386,11 @@ extern "C" int zs_sdf_query_grid_split(const void *split_programs, size_t progra
     }
     if (!check_programs("zs_sdf_query_grid_split", split_programs, program_stride_bytes)) return 0;
     const int m = (int)mm;
+    const int static_order = launch_counter_reset(workspace, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL((sdf_decode_split_kernel<true>), dim3(decode_grid_size(batch, m)),
                        dim3(WAVES * 64), 0, static_cast<hipStream_t>(stream),
                        static_cast<const char *>(split_programs), program_stride_bytes, batch, nullptr,
                        axis, G, (long long)slice_begin * G * G, m, out, apply_sigmoid,
-                       static_cast<f32x4 *>(workspace), tile_flags);
+                       static_cast<f32x4 *>(workspace), tile_flags, static_order);
     return zs::check_launch("zs_sdf_query_grid_split") ? 1 : 0;
 }

@@ -85,8 +85,13 @@ class DecoderState(object):
         self.programs, self.batch, self.precision, self.exact = programs, batch, precision, exact
         # split states from a calibrating prepare(): int32 [batch] on the device, 1 = this image's probe points differed by
         # more than CALIBRATION_TOL between the two arithmetics -> every tile of the image is re-evaluated in fp32
-        self.image_flags = None       # int32 [B] from prepare()'s per-image check (1: evaluate this image in fp32)
+        self.image_flags = None       # int32 [B] from prepare()'s per-image check (1: evaluate this image in fp32), raw-logit rule
+        self.image_flags_occ = None   # the same under the occupancy rule (calls that return sigmoid(logit))
         self.check_event = None       # recorded behind that check on its side stream; consumers wait for it on THEIR stream
+        # per-weights verdicts of a calibrating prepare() on a split state (Implicit._calibrate): may calls that return raw
+        # logits / calls that return occupancies use the split arithmetic?  (an uncalibrated split state: both True)
+        self.logit_ok = True
+        self.occ_ok = True
 
     @property
     def stride_bytes(self):
@@ -141,8 +146,8 @@ class Implicit(nn.Module):
         self.envelope_guard = True    # False: raw split-fp16 results everywhere (measurements of the arithmetic itself)
         # Output-error calibration of the default arithmetic (prepare()): once per weight version the raw split
         # kernel and the exact kernel evaluate the same CALIBRATION_POINTS probe points of the first image seen;
-        # "f16x3" is kept only while max |logit difference| <= CALIBRATION_TOL (a quarter of the 1e-4 contract),
-        # otherwise every later prepare() of these weights returns an fp32 state.  The envelope fences above look
+        # "f16x3" is kept per output space (CALIBRATION_TOL on raw logits, CALIBRATION_TOL_OCC + no index flip on
+        # occupancies: see the constants); when both fail every later prepare() of these weights returns an fp32 state.  The envelope fences above look
         # at operands; this one looks at the result.  ZS_DECODER_CALIBRATE=0 / .calibrate = False turns it off.
         self.calibrate = os.environ.get("ZS_DECODER_CALIBRATE", "1") != "0"
         # per-image output check of prepare().  Its two probe launches cost the latency of one fp32 wave tile + one
@@ -227,7 +232,15 @@ class Implicit(nn.Module):
         return self._workspace[key]
 
     CALIBRATION_POINTS = 4096
+    # The verdict is taken in the space the call RETURNS.  Raw logits (query_points, apply_sigmoid=False):
+    # max |logit difference| <= CALIBRATION_TOL, a quarter of the 1e-4 contract.  Occupancies (compute_level_grid's sigmoid,
+    # utils/eval_3D.py:44-45 - what the 1e-4 contract and the occ > 0.5 index set are defined on): max |occupancy difference|
+    # <= CALIBRATION_TOL_OCC and no occ > 0.5 flip outside |logit| < FLIP_BAND.  A confident checkpoint (|logit| 30-100) has raw
+    # differences that grow with the logit scale while its occupancies agree to 1e-7: under the raw rule alone its grids would
+    # silently run the 2.7x slower fp32 kernel.
     CALIBRATION_TOL = 2.5e-5
+    CALIBRATION_TOL_OCC = 2.5e-5
+    FLIP_BAND = 1e-5
 
     def _probe_points(self, device):
         """Deterministic probe cloud in the evaluation cube: a scrambled lattice (golden-ratio steps per axis), so
@@ -242,14 +255,21 @@ class Implicit(nn.Module):
         pts = self._probe_cache[str(device)] = (lo + (hi - lo) * frac).to(torch.float32)[None].to(device)
         return pts
 
+    def _verdict_stats(self, got, want):
+        """[max |dlogit|, mean |dlogit|, max |logit|, max |docc|, flips outside the band] per leading row of got / want [B, M]."""
+        diff = (got - want).abs()
+        flips = (((got > 0) != (want > 0)) & (want.abs() >= self.FLIP_BAND)).sum(-1).to(torch.float32)
+        return torch.stack([diff.amax(-1), diff.mean(-1), want.abs().amax(-1),
+                            (torch.sigmoid(got) - torch.sigmoid(want)).abs().amax(-1), flips], -1)
+
     @torch.no_grad()
     def _calibrate(self, split, exact):
-        """max |raw f16x3 logit - fp32 logit| over the probe points of image 0 -> last_calibration (one host read).
+        """Raw f16x3 vs fp32 logits over the probe points of image 0 -> last_calibration (one host read) -> (logit_ok, occ_ok).
         Cached per weight version: an optimizer step or load_state_dict() triggers the next measurement."""
         key = self._weights_key()
         if self._calibration is not None and self._calibration[0] == key:
             self.last_calibration = self._calibration[1]
-            return self.last_calibration["selected"] == "f16x3"
+            return self.last_calibration["selected"] == "f16x3", self.last_calibration["selected_occ"] == "f16x3"
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("Implicit.prepare: the f16x3 calibration of new weights needs one host read; run one "
                                "eager prepare() before capturing, or request precision='f32'")
@@ -257,32 +277,37 @@ class Implicit(nn.Module):
         guard, flags = self.envelope_guard, self.last_tile_flags
         self.envelope_guard = False                 # the raw arithmetic is what is being measured
         try:
-            got = self.query_points(DecoderState(split[:1], 1, "f16x3", exact=exact[:1]), pts)
+            raw = DecoderState(split[:1], 1, "f16x3", exact=exact[:1])
+            got = self.query_points(raw, pts)
         finally:
             self.envelope_guard, self.last_tile_flags = guard, flags
         want = self.query_points(DecoderState(exact[:1], 1), pts)
-        diff = (got - want).abs()
-        stats = torch.stack([diff.max(), diff.mean(), want.abs().max(),
-                             (torch.sigmoid(got) - torch.sigmoid(want)).abs().max()]).cpu()
+        stats = self._verdict_stats(got, want)[0].cpu()
         if not bool(torch.isfinite(stats[2])):
             # the exact kernel itself is not finite on this image (NaN latent): no verdict on the weights - this
             # call gets the fp32 state (NaN like the reference), the next image calibrates
             self.last_calibration = None
-            return False
-        ok = bool(torch.isfinite(stats).all()) and float(stats[0]) <= self.CALIBRATION_TOL
+            return False, False
+        finite = bool(torch.isfinite(stats).all())
+        ok = finite and float(stats[0]) <= self.CALIBRATION_TOL
+        ok_occ = finite and float(stats[3]) <= self.CALIBRATION_TOL_OCC and float(stats[4]) == 0.0
         self.last_calibration = dict(max_abs_diff=float(stats[0]), mean_abs_diff=float(stats[1]),
                                      max_abs_logit=float(stats[2]), max_abs_occ_diff=float(stats[3]),
-                                     points=self.CALIBRATION_POINTS, tol=self.CALIBRATION_TOL,
-                                     selected="f16x3" if ok else "f32")
+                                     flips_outside_band=int(stats[4]) if finite else -1,
+                                     points=self.CALIBRATION_POINTS, tol=self.CALIBRATION_TOL, tol_occ=self.CALIBRATION_TOL_OCC,
+                                     flip_band=self.FLIP_BAND,
+                                     selected="f16x3" if ok else "f32", selected_occ="f16x3" if ok_occ else "f32")
         self._calibration = (key, self.last_calibration)
-        return ok
+        return ok, ok_occ
 
     @torch.no_grad()
     def prepare(self, latent_depth, precision=None, calibrate=None):
         """Per-image prologue: latent_depth [B,197,C] (any float dtype, GPU) -> DecoderState.
         ``precision``: None = self.precision.  "f16x3" is a request: outside the host envelope (W_MAX), or when
-        the calibration of these weights measured more than CALIBRATION_TOL between the two arithmetics, the
-        state returned is an fp32 one (``state.precision`` says which).  ``calibrate``: None = self.calibrate;
+        the calibration of these weights fails BOTH rules (raw logits beyond CALIBRATION_TOL and occupancies beyond
+        CALIBRATION_TOL_OCC / an index flip), the state returned is an fp32 one (``state.precision`` says which).  A split
+        state that passes only one rule serves the calls of that kind and hands the others to the exact kernels
+        (``state.logit_ok`` / ``state.occ_ok``).  ``calibrate``: None = self.calibrate;
         False returns the split state unchecked (measurements of the arithmetic itself)."""
         precision = self.precision if precision is None else precision
         calibrate = self.calibrate if calibrate is None else calibrate
@@ -313,8 +338,10 @@ class Implicit(nn.Module):
             _lib.check(rc, "zs_sdf_split_programs")
             if not calibrate:
                 return DecoderState(split, B, "f16x3", exact=programs)
-            if self._calibrate(split, programs):
+            ok, ok_occ = self._calibrate(split, programs)
+            if ok or ok_occ:
                 state = DecoderState(split, B, "f16x3", exact=programs)
+                state.logit_ok, state.occ_ok = ok, ok_occ
                 if self.image_check:
                     self._launch_image_check(state, split, programs)
                 return state
@@ -329,7 +356,7 @@ class Implicit(nn.Module):
         dev = split.device
         main = torch.cuda.current_stream(dev)
         if torch.cuda.is_current_stream_capturing() or os.environ.get("ZS_DECODER_CHECK_INLINE", "0") != "0":
-            state.image_flags, maxima = self._image_check(split, exact)
+            state.image_flags, state.image_flags_occ, maxima, maxima_occ = self._image_check(split, exact)
             self._last_check_event = None
         else:
             pair = self._check_streams.get(str(dev))
@@ -349,7 +376,7 @@ class Implicit(nn.Module):
                 head = torch.cuda.Event()
                 head.record(st_)
                 main.wait_event(head)
-            state.image_flags, maxima = self._image_check(split, exact, streams=(side, side2))
+            state.image_flags, state.image_flags_occ, maxima, maxima_occ = self._image_check(split, exact, streams=(side, side2))
             state.check_event = torch.cuda.Event()
             state.check_event.record(side)
             # the side streams read `split` / `exact` (10 MB per image each): they must outlive that work even if the caller drops
@@ -363,19 +390,20 @@ class Implicit(nn.Module):
                 while self._check_keepalive and self._check_keepalive[0][0].query():
                     self._check_keepalive.pop(0)
                 self._check_keepalive.append((state.check_event, split, exact))
-            for t in (state.image_flags, maxima):
+            for t in (state.image_flags, state.image_flags_occ, maxima, maxima_occ):
                 t.record_stream(main)                       # written over there, read here
             self._last_check_event = state.check_event
-        self._last_calibration = dict(self._last_calibration, per_image_max_abs_diff=maxima)
+        self._last_calibration = dict(self._last_calibration, per_image_max_abs_diff=maxima, per_image_max_abs_occ_diff=maxima_occ)
 
     @torch.no_grad()
     def _image_check(self, split, exact, streams=None):
         """The f16x3 error also depends on the image's K / V records, and the per-weights verdict above was measured on the
         first image seen.  So every prepare() runs the probe points of EVERY image through both kernels and flags - on the
-        device, no host read - the images whose max |logit difference| exceeds CALIBRATION_TOL (or is not finite): the fp32
+        device, no host read - the images that fail the raw-logit rule / the occupancy rule (or are not finite): the fp32
         launch behind every split launch re-evaluates them entirely (_join_image_check).  `streams` = (a, b): the fp32 probes
         on a, the split probes on b (concurrently), the comparison on a; None: everything on the current stream.
-        -> (int32 flags [B], float32 maxima [B]), both device tensors."""
+        -> (int32 flags [B] under the raw-logit rule, int32 flags [B] under the occupancy rule, float32 max |dlogit| [B],
+        float32 max |docc| [B]), all device tensors."""
         B = split.shape[0]
         a, b = streams if streams is not None else (None, None)
         ctx = (lambda st: torch.cuda.stream(st)) if streams is not None else (lambda st: contextlib.nullcontext())
@@ -397,9 +425,11 @@ class Implicit(nn.Module):
             got.record_stream(a)
             pts.record_stream(b)
         with ctx(a):
-            maxima = (got - want).abs().amax(1)
-            bad = ~(maxima <= self.CALIBRATION_TOL)          # NaN / inf compare false: flagged
-            return bad.to(torch.int32), maxima
+            st = self._verdict_stats(got, want)              # [B, 5]
+            finite = torch.isfinite(st).all(-1)
+            bad = ~(finite & (st[:, 0] <= self.CALIBRATION_TOL))          # NaN / inf compare false: flagged
+            bad_occ = ~(finite & (st[:, 3] <= self.CALIBRATION_TOL_OCC) & (st[:, 4] == 0))
+            return bad.to(torch.int32), bad_occ.to(torch.int32), st[:, 0].contiguous(), st[:, 3].contiguous()
 
     def _tile_flags(self, batch, m, device, state=None):
         """Tile flags of one split launch: zero - the kernel sets the tiles that leave its envelope, _join_image_check() adds
@@ -409,10 +439,19 @@ class Implicit(nn.Module):
         return torch.zeros(batch * ((m + 127) // 128), dtype=torch.int32, device=device)
 
     @staticmethod
-    def _join_image_check(state, flags):
+    def _for_space(state, occupancy):
+        """The state a call returning raw logits (occupancy=False) / sigmoid occupancies (True) runs on: a split state whose
+        per-weights verdict rejected that space hands the call to the exact kernels."""
+        if state.precision == "f16x3" and not (state.occ_ok if occupancy else state.logit_ok):
+            return DecoderState(state.exact, state.batch)
+        return state
+
+    @staticmethod
+    def _join_image_check(state, flags, occupancy=False):
         """Between a split launch and the fp32 launch that re-evaluates flagged tiles: wait (this stream, not the host) for the
-        state's per-image check and flag every tile of the images it flagged - the fp32 launch then evaluates them whole."""
-        image_flags = getattr(state, "image_flags", None)
+        state's per-image check and flag every tile of the images it flagged - under the rule of the space the call returns
+        (occupancy: sigmoid outputs) - the fp32 launch then evaluates them whole."""
+        image_flags = getattr(state, "image_flags_occ" if occupancy else "image_flags", None)
         if image_flags is None or flags is None:
             return
         if state.check_event is not None:
@@ -424,6 +463,7 @@ class Implicit(nn.Module):
         """state from prepare(); points_3D [B,M,3] -> logits [B,M] fp32 (and, with need_attn,
         the attention map [B,M,197] of implicit.py:277)."""
         lib = _lib.load()
+        state = self._for_space(state, False)
         pts = points_3D.detach().to(torch.float32).contiguous()
         if pts.dim() != 3 or pts.shape[2] != 3 or pts.shape[0] != state.batch:
             raise ValueError("points_3D must be [%d,M,3], got %s" % (state.batch, tuple(pts.shape)))
@@ -469,6 +509,7 @@ class Implicit(nn.Module):
         lib = _lib.load()
         if state is None:
             state = self.prepare(latent_depth)
+        state = self._for_space(state, bool(apply_sigmoid))
         axis = axis.detach().to(torch.float32).contiguous()
         if axis.device != state.programs.device:
             raise ValueError("axis and latent_depth live on different devices")
@@ -484,7 +525,7 @@ class Implicit(nn.Module):
                                                  _lib.ptr(axis), G, slice_begin, slice_end,
                                                  1 if apply_sigmoid else 0, _lib.ptr(out), _lib.ptr(flags), ws, st)
                 _lib.check(rc, "zs_sdf_query_grid_split")
-                self._join_image_check(state, flags)
+                self._join_image_check(state, flags, occupancy=bool(apply_sigmoid))
                 if flags is not None:
                     rc = lib.zs_sdf_query_grid(_lib.ptr(state.exact), state.exact.stride(0) * 4, state.batch,
                                                _lib.ptr(axis), G, slice_begin, slice_end,
@@ -508,6 +549,7 @@ class Implicit(nn.Module):
         lib = _lib.load()
         if state is None:
             state = self.prepare(latent_depth)
+        state = self._for_space(state, bool(apply_sigmoid))
         axis = axis.detach().to(torch.float32).contiguous()
         if axis.device != state.programs.device:
             raise ValueError("axis and latent_depth live on different devices")
@@ -522,7 +564,7 @@ class Implicit(nn.Module):
                                                        _lib.ptr(axis), G, point_begin, point_end, sig, _lib.ptr(out),
                                                        _lib.ptr(flags), ws, st)
                 _lib.check(rc, "zs_sdf_query_grid_range_split")
-                self._join_image_check(state, flags)
+                self._join_image_check(state, flags, occupancy=bool(apply_sigmoid))
                 if flags is not None:
                     rc = lib.zs_sdf_query_grid_range(_lib.ptr(state.exact), state.exact.stride(0) * 4, state.batch,
                                                      _lib.ptr(axis), G, point_begin, point_end, sig, _lib.ptr(out),

@@ -85,6 +85,21 @@ def seeded_state_dict(seed=0, pos_embed=None, **cfg):
     return sd
 
 
+def confident_state_dict(sd, gain, layers=3):
+    """A decoder state dict whose logits are ~gain x those of ``sd``: weight and bias of the last ``layers`` linear layers of
+    impl_mlp each x gain^(1/layers) (softplus(beta=100) is positively homogeneous to ~1e-2, so the factors multiply; spread
+    over several layers so that no single weight leaves the split arithmetic's host envelope, program.W_MAX).  A stand-in for
+    the logit scale of a converged checkpoint (|logit| 30-100) - no trained weights exist in this container."""
+    out = dict(sd)
+    last = max(int(k.split(".")[2]) for k in sd if k.startswith("impl_mlp.layers."))
+    f = float(gain) ** (1.0 / layers)
+    for l in range(last - layers + 1, last + 1):
+        for part in ("weight", "bias"):
+            k = "impl_mlp.layers.%d.%s" % (l, part)
+            out[k] = sd[k] * f
+    return out
+
+
 def seeded_latent(seed=0, batch=1, n_tokens=NUM_PATCHES + 1, dim=LATENT_DIM):
     """latent_depth stand-in: N(0,1) [B, 197, 256]."""
     rs = np.random.RandomState(seed + 7919)
