@@ -155,3 +155,22 @@ def test_hip_graph_replay_equals_eager(graph):
                 outs[seed] = [t.clone() for t in got]
     assert len(graph._captured) == 1
     graph.enable_hip_graph(False)
+
+
+@pytest.mark.parametrize("B,size", [(2, 160), (2, 96), (2, 128), (3, 64)])
+def test_batches_of_small_images_through_the_fused_trunk_gate(graph, encoder_sd, B, size, monkeypatch):
+    """with B > 1 the fused GroupNorm path needs every map of the ResNetV2 trunk to hold a multiple of 32 pixels
+    (statistics tiles must not straddle samples); the gate looked at the first two maps only and 2 x 160 x 160 died in
+    stage 1 (20 x 20 pixels).  Batches of small images now run - fused where every map allows it (128: 64^2, 32^2, 16^2,
+    8^2), unfused otherwise - and agree with the unfused engine and the oracle."""
+    from zeroshape_amd.nn import blocks
+    rgb = torch.from_numpy(syn.seeded_rgb_scene(seed=4, batch=B, size=size)[0])
+    depth, feat = graph.dpt_depth(rgb.cuda(), get_feat=True)
+    monkeypatch.setattr(blocks, "FUSED_GN_MAX_ROWS", 0)                     # the unfused engine
+    depth_u, feat_u = graph.dpt_depth(rgb.cuda(), get_feat=True)
+    close(feat, feat_u, tol=2e-5, msg="fused vs unfused trunk")
+    np.testing.assert_allclose(depth.cpu().numpy(), depth_u.cpu().numpy(), atol=2e-5, rtol=0)
+    odepth, ofeat = E.dpt_depth(E._sub(encoder_sd, "dpt_depth."), rgb)
+    np.testing.assert_allclose(depth.cpu().numpy(), odepth.numpy(), atol=1e-4, rtol=0)
+    close(feat, ofeat, msg="layer_4 @%d x %d" % (B, size))
+    assert blocks._fused_maps_ok(B, size, size, 3) == (size == 128)

@@ -599,3 +599,45 @@ def test_conv2d_pointwise_256_tiles(M, Cin, Cout, res, act):
             assert torch.equal(got, old)
     finally:
         ops.set_conv_precision(prev)
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 14, 14), (1, 9, 7), (2, 8, 8), (3, 16, 8)])
+def test_fused_group_norm_launches_directly(B, H, W):
+    """zs_conv2d_nhwc_fused (statistics from a convolution's epilogue, normalisation on the consumer's operand load),
+    zs_group_norm_apply_stats and zs_gn_relu_max_pool_nhwc had no unit tests of their own.  Each against the unfused ops
+    (ops.group_norm on the materialised tensors) and torch, at batch 1 (any map) and batch > 1 (maps of a multiple of 32)."""
+    from zeroshape_amd.nn import ops, pack
+    g = torch.Generator().manual_seed(B * 100 + H)
+    C0, C1, C2 = 64, 128, 256
+    x = torch.randn(B, C0, H, W, generator=g)
+    w1 = torch.randn(C1, C0, 1, 1, generator=g) / 8
+    w2 = torch.randn(C2, C1, 3, 3, generator=g) / 34
+    ga1, be1 = torch.randn(C1, generator=g) * 0.3 + 1, torch.randn(C1, generator=g) * 0.2
+    ga2, be2 = torch.randn(C2, generator=g) * 0.3 + 1, torch.randn(C2, generator=g) * 0.2
+    res = torch.randn(B, C2, H, W, generator=g)
+    prev = ops.CONV_PRECISION
+    try:
+        ops.set_conv_precision("f16x3")
+        xg = nhwc(x).cuda()
+        assert ops.fused_ok(xg)
+        p1, p2 = pack.pack_conv(w1, None).to("cuda"), pack.pack_conv(w2, None, padding=1).to("cuda")
+        # producer statistics -> consumer normalises on load -> one-pass GN + residual + ReLU of the block output
+        z1, st1 = ops.conv2d(xg, p1, stats_out="group")
+        z2, st2 = ops.conv2d(z1, p2, gn_in=(st1, ga1.cuda(), be1.cuda(), 1e-5), stats_out="group")
+        y = ops.group_norm_apply(z2, st2, ga2.cuda(), be2.cuda(), 1e-5, relu=True, residual=nhwc(res).cuda())
+        # the unfused engine on the same packed layers
+        u1 = ops.conv2d(xg, p1)
+        close(z1, u1.cpu(), tol=1e-6)
+        u2 = ops.conv2d(ops.group_norm(u1, ga1.cuda(), be1.cuda(), relu=True), p2)
+        close(z2, u2.cpu(), tol=2e-5)
+        close(y, ops.group_norm(u2, ga2.cuda(), be2.cuda(), relu=True, residual=nhwc(res).cuda()).cpu(), tol=2e-5)
+        # torch
+        t1 = F.conv2d(x, w1)
+        t2 = F.conv2d(F.relu(F.group_norm(t1, 32, ga1, be1, 1e-5)), w2, padding=1)
+        close(y, nhwc(F.relu(F.group_norm(t2, 32, ga2, be2, 1e-5) + res)))
+        # GN + ReLU riding on the max pool
+        pooled = ops.gn_relu_max_pool(z1, st1, ga1.cuda(), be1.cuda(), 3, 2, 1, 1e-5)
+        close(pooled, nhwc(F.max_pool2d(F.relu(F.group_norm(t1, 32, ga1, be1, 1e-5)), 3, 2, 1)))
+        close(pooled, ops.max_pool(ops.group_norm(u1, ga1.cuda(), be1.cuda(), relu=True), 3, 2, 1).cpu(), tol=2e-5)
+    finally:
+        ops.set_conv_precision(prev)

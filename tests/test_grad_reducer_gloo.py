@@ -159,6 +159,35 @@ def _worker_in_place(rank, world, initfile):
         dist.destroy_process_group()
 
 
+def _worker_in_place_uneven(rank, world, initfile):
+    """reduce_in_place() when a parameter has a gradient on ONE rank only: it is in the common layout, the rank
+    without a local gradient receives the average too - the ranks stay in step."""
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        net = Net()
+        red = parallel.GradReducer(net.parameters(), bucket_mb=0.3, pack_fn=torch_pack, module=net)
+        red.armed = False
+        x = torch.randn(6, 40, generator=torch.Generator().manual_seed(70 + rank))
+        net(x, use_sometimes=rank == 0).pow(2).mean().backward()
+        assert (net.sometimes.grad is None) == (rank == 1)
+        red.reduce_in_place()
+        assert net.sometimes.grad is not None and net.unused.weight.grad is None
+        for p in (net.sometimes, net.c.weight):
+            g = [torch.zeros_like(p.grad) for _ in range(world)]
+            dist.all_gather(g, p.grad.contiguous())
+            assert all(torch.equal(g[0], t) for t in g)
+        assert float(net.sometimes.grad.abs().sum()) > 0
+        red.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_reducer_in_place_with_a_parameter_used_on_one_rank_only():
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_in_place_uneven, args=(2, os.path.join(d, "init")), nprocs=2, join=True)
+
+
 def test_grad_reducer_in_place_form_of_the_captured_step():
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker_in_place, args=(2, os.path.join(d, "init")), nprocs=2, join=True)

@@ -11,7 +11,12 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 def _audit(src, tmp_path, want):
+    import shutil
+
+    import pytest
     import ring_audit as R
+    if not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")) and shutil.which("hipcc") is None:
+        pytest.skip("no hipcc on this host: the ISA audit needs the compiler")
     res = R.audit_file(R.compile_to_asm(src, str(tmp_path / (src + ".s"))), want, quiet=True)
     assert res, "no kernel matching %r in %s" % (want, src)
     bad = {k: v for k, v in res.items() if v}

@@ -44,6 +44,8 @@ for label, br in (("one stream", False), ("branches", True)):
     if br and not on:
         continue
     branch.ENABLED = br
+    if br and branch.KINDS == 0:
+        branch.KINDS = 15         # every branch kind (ZS_BRANCH_KINDS defaults to 0: without this both legs time the same graph)
     g.enable_hip_graph(True)
     ms, mn = _events(fwd, args.reps)
     v = fwd()

@@ -85,9 +85,12 @@ def compile_to_asm(src, out, extra=()):
     """hipcc -S of one translation unit of zeroshape_amd/csrc for gfx950 (no GPU needed)."""
     import os
     import subprocess
+    import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from zeroshape_amd import build as B          # the flags the shipped object is built with: the audited ISA is the shipped one
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(root, "include"), "--cuda-device-only", "-S",
+    cmd = [hipcc] + B.COMMON + B.EXTRA.get(src, []) + ["--cuda-device-only", "-S",
            os.path.join(root, "zeroshape_amd", "csrc", src), "-o", out] + list(extra)
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return out

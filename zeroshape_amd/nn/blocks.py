@@ -105,11 +105,26 @@ def pack_resnetv2(sd, p, device, layers=(3, 4, 9)):
     return pk
 
 
+def _fused_maps_ok(B, H, W, stages):
+    """The fused launches write their GroupNorm statistics per 32-row tile of the [B * H * W, C] matrix, and a tile must not
+    straddle two samples (zs_conv2d_nhwc_fused rejects it): with B > 1 EVERY map of the trunk - the stem's output, the pooled
+    map and each stride-2 stage's ('same' padding: ceil halves) - needs a multiple of 32 pixels.  (only the first
+    two were checked; 2 x 160 x 160 passed the gate and died in stage 1 with 20 x 20 = 400 pixels.)"""
+    if B == 1:
+        return True
+    h, w = H, W
+    for _ in range(2 + stages - 1):          # stem conv (stride 2), max pool (stride 2), stages 1.. (stride 2 each)
+        h, w = -(-h // 2), -(-w // 2)
+        if (h * w) % 32:
+            return False
+    return True
+
+
 def run_resnetv2(x, pk, in_scale=1.0, in_shift=0.0, on_stage=None):
     """x [B,H,W,4] (RGB + zero channel) -> list of stage outputs.  on_stage(index, output) is called as soon as a stage's
     output is queued (the caller forks work that needs only that tap)."""
     B, H, W = x.shape[0], x.shape[1], x.shape[2]
-    if ops.fused_ok(x) and B * (H // 4) * (W // 4) <= FUSED_GN_MAX_ROWS and (B == 1 or ((H // 2) * (W // 2)) % 32 == 0):
+    if ops.fused_ok(x) and B * (H // 4) * (W // 4) <= FUSED_GN_MAX_ROWS and _fused_maps_ok(B, H, W, len(pk["stages"])):
         # the stem's GroupNorm + ReLU ride on the max pool (statistics from the convolution's epilogue), then the fused stages
         x, st = ops.conv2d(x, pk["stem"], in_scale=in_scale, in_shift=in_shift, stats_out="group")
         x = ops.gn_relu_max_pool(x, st, pk["stem_gn"][0], pk["stem_gn"][1], 3, 2, "same", GN_EPS)

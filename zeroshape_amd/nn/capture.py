@@ -8,6 +8,9 @@ stable) and replayed with one call."""
 import torch
 
 
+_CAPTURE_STREAMS = {}          # device -> the stream every capture of that device runs on
+
+
 class CapturedCall:
     """fn(*tensors) -> tensor | tuple of tensors, captured for the shapes of `example_inputs`."""
 
@@ -18,7 +21,13 @@ class CapturedCall:
         branch.warm(dev)
         # warm-up and capture run on the SAME stream: the per-stream scratch buffers of nn/ops.py (and the side streams of
         # nn/branch.py) are created by the warm-up and found again by the capture
-        side = torch.cuda.Stream(device=dev)
+        # ONE capture stream per device, shared by every CapturedCall: the scratch buffers are keyed by (device, stream) and kept
+        # for the life of the process (the split-K workspace alone is ~129 MiB, the decoder workspace 96 MiB); a fresh pool stream
+        # per capture - the graphs are re-captured whenever the weights change - pinned a new set each time.
+        # Replays of different CapturedCalls are ordered by the caller's stream, so they never use the scratch concurrently.
+        side = _CAPTURE_STREAMS.get(str(dev))
+        if side is None:
+            side = _CAPTURE_STREAMS[str(dev)] = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):                       # packs weights, primes caches
             for _ in range(warmup):

@@ -286,7 +286,7 @@ class GradReducer(object):
         for p in order:
             self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
-    def _launch(self, bi):
+    def _launch(self, bi, in_place=False):
         plist, flat = self.buckets[bi], self.flat[bi]
         entries = []
         missing = False
@@ -295,19 +295,24 @@ class GradReducer(object):
             if p.grad is None:
                 missing = True
                 continue
-            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            if in_place:
+                # the captured step's gradients are FIXED tensors: rebinding one to a contiguous copy would detach it from the graph
+                assert p.grad.is_contiguous(), "reduce_in_place: a gradient of the captured step is not contiguous"
+                g = p.grad
+            else:
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                p.grad = g
             entries.append((flat.data_ptr() + 4 * off, g.data_ptr(), p.numel()))
-            p.grad = g
         if missing:
             flat.zero_()
         self.pack_fn(entries, 1.0 / self.world, flat.device)
         self.works.append(dist.all_reduce(flat, group=self.group, async_op=True))
         self.pending[bi] = -1
 
-    def _launch_ready(self, flush=False):
+    def _launch_ready(self, flush=False, in_place=False):
         """Issue buckets next_launch, next_launch + 1, ... while they are complete (all, with flush)."""
         while self.next_launch < len(self.buckets) and (flush or self.pending[self.next_launch] == 0):
-            self._launch(self.next_launch)
+            self._launch(self.next_launch, in_place)
             self.next_launch += 1
 
     def _on_grad(self, p):
@@ -354,7 +359,7 @@ class GradReducer(object):
             mask = mask.cpu().tolist()
             self._build({id(p) for p, u in zip(self.params, mask) if u})
         self.next_launch = 0
-        self._launch_ready(flush=True)
+        self._launch_ready(flush=True, in_place=True)
         for w in self.works:
             w.wait()
         self.works = []
@@ -365,6 +370,10 @@ class GradReducer(object):
                 _, off = self.slot[id(q)]
                 if q.grad is not None:
                     back.append((q.grad.data_ptr(), self.flat[bi].data_ptr() + 4 * off, q.numel()))
+                else:
+                    # in the layout (used on SOME rank) but without a local gradient: take the average like finish() does - a
+                    # private copy, the bucket is reused - or the ranks' parameters drift apart under uneven usage
+                    q.grad = self.flat[bi][off:off + q.numel()].view_as(q).clone()
             if back:
                 self.pack_fn(back, 1.0, self.flat[bi].device)
             self.pending[bi] = len(plist)
