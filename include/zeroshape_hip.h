@@ -128,6 +128,12 @@ size_t zs_sdf_attn_scratch_bytes(int batch, int m);
  * parameter block (zeroshape_amd/program.py: pack_latent_params). */
 int zs_sdf_prologue(void *programs, size_t program_stride_bytes, const float *lat_params,
                     const float *latent_depth, int batch, void *scratch, void *stream);
+/* The same with options (ABI 33).  ZS_SDF_POS_PERLAYER: Implicit(pos_perlayer=True) - the reference class's own default,
+ * model/shape/implicit.py:269-272 - adds pos_embed to the latent rows in front of EVERY attention block, not only the first:
+ * the K/V records of block 1 come from LN1'(x2 + pos_embed).  zs_sdf_prologue == flags 0 (options/shape.yaml:44). */
+#define ZS_SDF_POS_PERLAYER 1
+int zs_sdf_prologue_ex(void *programs, size_t program_stride_bytes, const float *lat_params,
+                       const float *latent_depth, int batch, void *scratch, int flags, void *stream);
 
 /* logits[batch][m] = Implicit(latent, None, points[batch][m][3]) (pre-sigmoid).
  * attn (optional, may be NULL): [batch][m][197] = mean over heads and blocks of the

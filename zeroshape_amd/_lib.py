@@ -42,6 +42,8 @@ SIGNATURES = {
     "zs_sdf_attn_scratch_bytes": (_c_size_t, [_c_int, _c_int]),
     "zs_sdf_prologue": (_c_int, [_c_void_p, _c_size_t, _c_void_p, _c_void_p, _c_int,
                                  _c_void_p, _c_void_p]),
+    "zs_sdf_prologue_ex": (_c_int, [_c_void_p, _c_size_t, _c_void_p, _c_void_p, _c_int,
+                                    _c_void_p, _c_int, _c_void_p]),
     "zs_sdf_query_points": (_c_int, [_c_void_p, _c_size_t, _c_int, _c_void_p, _c_int,
                                      _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "zs_sdf_query_grid": (_c_int, [_c_void_p, _c_size_t, _c_int, _c_void_p, _c_int, _c_int,

@@ -190,6 +190,15 @@ extern "C" size_t zs_sdf_prologue_scratch_bytes(void) { return (size_t)SCRATCH_F
 
 extern "C" int zs_sdf_prologue(void *programs, size_t program_stride_bytes, const float *lat_params,
                                const float *latent_depth, int batch, void *scratch, void *stream) {
+    return zs_sdf_prologue_ex(programs, program_stride_bytes, lat_params, latent_depth, batch, scratch, 0, stream);
+}
+
+extern "C" int zs_sdf_prologue_ex(void *programs, size_t program_stride_bytes, const float *lat_params,
+                                  const float *latent_depth, int batch, void *scratch, int flags, void *stream) {
+    if (flags & ~ZS_SDF_POS_PERLAYER) {
+        zs::set_err("zs_sdf_prologue_ex: unknown flags 0x%x", flags);
+        return 0;
+    }
     if (batch < 0) {
         zs::set_err("zs_sdf_prologue: negative batch %d", batch);
         return 0;
@@ -229,9 +238,15 @@ extern "C" int zs_sdf_prologue(void *programs, size_t program_stride_bytes, cons
     launch_linear<true, true, false, false>(s, batch, sc + S_X1, C, ss, C, P + LQ_W1, P + LQ_B1, HID,
                                             P + LQ_LN2G0, P + LQ_LN2B0, nullptr, 0, 0, nullptr,
                                             sc + S_HID, HID, ss);
-    launch_linear<false, false, true, false>(s, batch, sc + S_HID, HID, ss, HID, P + LQ_W2, P + LQ_B2,
-                                             C, nullptr, nullptr, sc + S_X1, C, ss, nullptr,
-                                             sc + S_X2, C, ss);
+    // (pos_perlayer, implicit.py:269-272: + pos_embed again in front of block 1 - only its K/V rows read x2)
+    if (flags & ZS_SDF_POS_PERLAYER)
+        launch_linear<false, false, true, true>(s, batch, sc + S_HID, HID, ss, HID, P + LQ_W2, P + LQ_B2,
+                                                C, nullptr, nullptr, sc + S_X1, C, ss, P + LQ_POS,
+                                                sc + S_X2, C, ss);
+    else
+        launch_linear<false, false, true, false>(s, batch, sc + S_HID, HID, ss, HID, P + LQ_W2, P + LQ_B2,
+                                                 C, nullptr, nullptr, sc + S_X1, C, ss, nullptr,
+                                                 sc + S_X2, C, ss);
     // kv1 = (k,v rows of block 1's qkv)(LN1'(x2))                      (implicit.py:30-38,100)
     launch_linear<true, false, false, false>(s, batch, sc + S_X2, C, ss, C, P + LQ_WKV1, P + LQ_BKV1,
                                              2 * C, P + LQ_LN1G1, P + LQ_LN1B1, nullptr, 0, 0, nullptr,

@@ -18,7 +18,7 @@ backward op, torch.autograd only as the tape - including timm's per-sample DropP
 (implicit.py:83-109, drop_path=0.1).
 
 Not on the HIP path (raises, never silently approximated):
-  * ``semantic=True`` / ``posenc_3D>0`` / ``pos_perlayer=True`` variants (unused by
+  * ``semantic=True`` / ``posenc_3D>0`` variants (unused by
     options/shape.yaml).
 """
 import contextlib
@@ -179,9 +179,12 @@ class Implicit(nn.Module):
     # ---- HIP path ---------------------------------------------------------------------
     def _check_supported(self):
         c = self.cfg
+        # pos_perlayer (the reference class's own default; options/shape.yaml:44 sets False) is a prologue option since round 5:
+        # both values run.  posenc_3D > 0 widens the per-point MLP's first and skip layers (implicit.py:147-150) - a kernel
+        # change, not built; the other entries are the kernels' compile-time geometry.
         want = dict(num_patches=P.L - 1, n_channels=P.C, latent_dim=P.C, n_blocks_attn=P.BLOCKS,
                     n_layers_mlp=P.MLP_LAYERS - 1, num_heads=P.HEADS, posenc_3D=0, mlp_ratio=4.0,
-                    skip_in=P.SKIP_IN, pos_perlayer=False, semantic=False)
+                    skip_in=P.SKIP_IN, semantic=False)
         bad = {k: (c[k], v) for k, v in want.items() if c[k] != v}
         if bad:
             raise NotImplementedError(
@@ -189,7 +192,7 @@ class Implicit(nn.Module):
                 "(got, need): %s" % bad)
 
     def _weights_key(self):
-        return (A.GENERATION[0],) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (A.GENERATION[0], bool(self.pos_perlayer)) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def packed(self, device):
         """(template program [PROGRAM_FLOATS], lat_params) on ``device``; repacked when any
@@ -326,10 +329,10 @@ class Implicit(nn.Module):
         scratch = torch.empty(B * (lib.zs_sdf_prologue_scratch_bytes() // 4), dtype=torch.float32,
                               device=lat.device)
         with _lib.on(lat.device):
-            rc = lib.zs_sdf_prologue(_lib.ptr(programs), programs.stride(0) * 4, _lib.ptr(lat_params),
-                                     _lib.ptr(lat), B, _lib.ptr(scratch),
-                                     _lib.current_stream_ptr(lat.device))
-        _lib.check(rc, "zs_sdf_prologue")
+            rc = lib.zs_sdf_prologue_ex(_lib.ptr(programs), programs.stride(0) * 4, _lib.ptr(lat_params),
+                                        _lib.ptr(lat), B, _lib.ptr(scratch), 1 if self.pos_perlayer else 0,     # ZS_SDF_POS_PERLAYER
+                                        _lib.current_stream_ptr(lat.device))
+        _lib.check(rc, "zs_sdf_prologue_ex")
         if precision == "f16x3" and self.split_allowed(lat.device):
             split = torch.empty_like(programs)
             with _lib.on(lat.device):
@@ -632,9 +635,12 @@ class Implicit(nn.Module):
                 return A.linear(branch_in, w, b, res1=x)
             return A.add_scaled_rows(x, A.linear(branch_in, w, b), scale)
 
+        ones = torch.ones(B, dtype=torch.float32, device=pts.device) if self.pos_perlayer and nb > 1 else None
         for i, blk in enumerate(self.blocks_attn):
             last = i == nb - 1
             s_attn, s_mlp = scales[2 * i], scales[2 * i + 1]
+            if self.pos_perlayer and i > 0:
+                xl = A.add_scaled_rows(xl, pos, ones)                                                # :269-272, every block
             qkv_l = A.linear(A.layer_norm(xl, blk.norm1.weight, blk.norm1.bias), blk.attn.qkv.weight,
                              blk.attn.qkv.bias)
             qkv_p = A.linear(A.layer_norm(xp, blk.norm1.weight, blk.norm1.bias), blk.attn.qkv.weight,

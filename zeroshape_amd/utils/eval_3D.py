@@ -119,13 +119,26 @@ def compute_level_grid(opt, impl_network, latent_depth, latent_semantic, points_
     return occ, images_vis
 
 
+def _jet_lut():
+    """The 256-entry 'jet' colour table (RGB, uint8) from its closed form - r, g, b = clamp(1.5 - |4x - 3|, |4x - 2|, |4x - 1|)
+    at x = i / 255 - the map cv2.COLORMAP_JET tabulates (utils/util_vis.py:285; cv2 is not a dependency of this package,
+    and its table may differ from the closed form by one grey level)."""
+    x = np.arange(256, dtype=np.float64) / 255.0
+    chan = lambda c: np.clip(1.5 - np.abs(4.0 * x - c), 0.0, 1.0)      # noqa: E731
+    return np.uint8(np.round(255.0 * np.stack([chan(3.0), chan(2.0), chan(1.0)], -1)))
+
+
+def show_att_on_image(img, mask):
+    """utils/util_vis.py:267-293: the attention map [H, W] in [0, 1] as a jet heat map added onto the image [H, W, 3] in
+    [0, 1], rescaled to a maximum of 1.  numpy only (round 5: the product path no longer reaches for the reference's module)."""
+    assert np.max(img) <= 1 and np.max(mask) <= 1
+    heatmap = np.float32(_jet_lut()[np.uint8(255 * mask)]) / 255
+    merged = heatmap + np.float32(img)
+    return merged / np.max(merged)
+
+
 def _attention_frames(opt, attn, images, batch_size, N):
-    """utils/eval_3D.py:47-80: host-side heat-map frames for the demo GIF.  Needs the
-    reference's utils.util_vis.show_att_on_image (cv2) -> not part of the hot path."""
-    try:
-        from utils.util_vis import show_att_on_image  # the reference's own helper, if on path
-    except Exception as e:  # pragma: no cover
-        raise RuntimeError("vis_attn=True needs the reference's utils.util_vis (cv2) on sys.path") from e
+    """utils/eval_3D.py:47-80: host-side heat-map frames for the demo GIF (not part of the hot path)."""
     N_global = 1
     feat_res = opt.H // opt.arch.win_size
     attn = torch.stack(attn, dim=1).view(batch_size, N, N, N, N_global + feat_res ** 2)
