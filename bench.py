@@ -160,6 +160,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the Chamfer / pose-search / evaluation / encoder / training legs (tools/bench_legs.py)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--skip-legs", default="",
+                    help="comma-separated extra legs to leave out (names of the line's objects, plus 'chamfer_l1_vox128' for the "
+                         "CPU-oracle pipeline at vox 128 inside chamfer_l1); the test suite skips the legs its own tests cover")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
@@ -332,7 +335,7 @@ def main():
                      "occupancy_flips": int(flips.sum()), "points": int(lg.numel()),
                      "max_abs_logit_at_flip": float(lg32[flips].abs().max()) if int(flips.sum()) else 0.0}
         del lg, lg32
-        if not args.no_extras:
+        if not args.no_extras and "logit_scale_sweep" not in args.skip_legs.split(","):
             from tools import bench_legs as legs
             try:
                 logit_sweep = legs.logit_sweep_leg(dev, sd)
@@ -388,12 +391,16 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras and N == VOX_RES:
         from tools import bench_legs as legs
         cpu = not args.no_cpu_baseline
+        skip = set(args.skip_legs.split(","))
         for name, fn in (("chamfer", lambda: legs.chamfer_leg(dev, cpu)), ("pose_search", lambda: legs.pose_search_leg(dev)),
-                         ("chamfer_l1", lambda: legs.eval_leg(dev, net, sd)), ("encoder", lambda: legs.encoder_leg(dev, cpu)),
+                         ("chamfer_l1", lambda: legs.eval_leg(dev, net, sd, vox128="chamfer_l1_vox128" not in skip)),
+                         ("encoder", lambda: legs.encoder_leg(dev, cpu)),
                          ("encoder_att", lambda: legs.encoder_att_leg(dev)), ("vox256", lambda: legs.vox256_leg(dev, net)),
                          ("inference", lambda: legs.inference_leg(dev)), ("iso_surface", lambda: legs.surface_leg(dev)),
                          ("train_step", lambda: legs.in_subprocess("train", "train_step")),
                          ("trained_weights", lambda: legs.in_subprocess("trained", "trained_weights"))):
+            if name in skip:
+                continue
             try:
                 extras[name] = fn()
             except Exception as e:                      # a leg must never take the headline line down

@@ -15,6 +15,13 @@ os.environ.setdefault("ZS_SYNTHETIC_STANDIN", "1")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle (torch fp32) stops scaling at ~32 intra-op threads; a GPU box's default is every one of its 256 cores, which
+    # ran the vox-128 oracle grid at 11 k points/s instead of 49 k (187 s of the suite's 1,009 s in round 5)
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")

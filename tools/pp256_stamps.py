@@ -15,7 +15,7 @@ ops.set_conv_precision("f16x3")
 x = torch.randn(1, M, 1, K, device="cuda")
 pc = pack.pack_conv(torch.randn(N, K, 1, 1) / K ** 0.5, torch.randn(N)).to("cuda")
 for _ in range(3):
-    ops.conv2d(x, pc)
+    ops.conv2d(x, pc, tiling="tile256")
 torch.cuda.synchronize()
 ws = ops.splitk_workspace(x.device)
 off = (1 << 18) + (64 << 20) // 4

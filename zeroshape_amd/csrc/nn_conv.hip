@@ -79,6 +79,25 @@ __device__ __forceinline__ float activate(float v, int act) {
     return v;
 }
 
+// Four values at once with the activation code known at compile time (ACT) or decided ONCE per quad: the per-element form
+// above costs three wave-uniform compare-and-branch pairs per VALUE inside the unrolled epilogues - 500 taken branches per
+// wave and tile, through ~60 KiB of instructions, were most of the 30,000-cycle epilogue of the 256 x 256 kernel (round 5)
+template <int ACT>
+__device__ __forceinline__ void activate4_t(f32x4 &v) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        if (ACT == ZS_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+        if (ACT == ZS_ACT_GELU) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+        if (ACT == ZS_ACT_RELU_CLAMP1) v[e] = fminf(fmaxf(v[e], 0.f), 1.f);
+    }
+}
+__device__ __forceinline__ void activate4(f32x4 &v, int act) {
+    if (act == ZS_ACT_NONE) return;
+    if (act == ZS_ACT_RELU) activate4_t<ZS_ACT_RELU>(v);
+    else if (act == ZS_ACT_GELU) activate4_t<ZS_ACT_GELU>(v);
+    else activate4_t<ZS_ACT_RELU_CLAMP1>(v);
+}
+
 // position of a lane's current k (4 consecutive channels of one tap) in (ky, kx, channel) form,
 // advanced incrementally: no integer division in the K loop
 struct TapIter {
@@ -399,8 +418,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
                 if (a.shift) v += *reinterpret_cast<const f32x4 *>(a.shift + n);
                 if (a.res1) v += *reinterpret_cast<const f32x4 *>(a.res1 + row + n);
                 if (a.res2) v += *reinterpret_cast<const f32x4 *>(a.res2 + row + n);
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = activate(v[e], a.act);
+                activate4(v, a.act);
                 *reinterpret_cast<f32x4 *>(a.out + row + n) = v;
             } else {
 #pragma unroll
@@ -692,8 +710,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DMA_NS == 2
                 v = v * *reinterpret_cast<const f32x4 *>(&ep_lds[0][n - n0]) + *reinterpret_cast<const f32x4 *>(&ep_lds[1][n - n0]);
                 if (a.res1) v += *reinterpret_cast<const f32x4 *>(a.res1 + row + n);
                 if (a.res2) v += *reinterpret_cast<const f32x4 *>(a.res2 + row + n);
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = activate(v[e], a.act);
+                activate4(v, a.act);
                 *reinterpret_cast<f32x4 *>(a.out + row + n) = v;
             } else {
 #pragma unroll
@@ -1265,8 +1282,7 @@ __global__ __launch_bounds__(256) void conv_gemm_small_kernel(ConvArgs a) {
                 for (int c = 0; c < 4; c++) v[c] = v[c] * (a.scale ? a.scale[n + c] : 1.0f) + (a.shift ? a.shift[n + c] : 0.0f);
                 if (a.res1) v += *reinterpret_cast<const f32x4 *>(a.res1 + o);
                 if (a.res2) v += *reinterpret_cast<const f32x4 *>(a.res2 + o);
-#pragma unroll
-                for (int c = 0; c < 4; c++) v[c] = activate(v[c], a.act);
+                activate4(v, a.act);
                 *reinterpret_cast<f32x4 *>(a.out + o) = v;
             } else {
                 v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1436,8 +1452,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_stats_kernel(ConvArgs 
             for (int c = 0; c < 4; c++) v[c] = v[c] * (a.scale ? a.scale[n + c] : 1.0f) + (a.shift ? a.shift[n + c] : 0.0f);
             if (a.res1) v += *reinterpret_cast<const f32x4 *>(a.res1 + o);
             if (a.res2) v += *reinterpret_cast<const f32x4 *>(a.res2 + o);
-#pragma unroll
-            for (int c = 0; c < 4; c++) v[c] = activate(v[c], a.act);
+            activate4(v, a.act);
             *reinterpret_cast<f32x4 *>(a.out + o) = v;
         }
         if (om == 1) {

@@ -318,8 +318,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 2,
                     if (a.shift) v += *reinterpret_cast<const f32x4 *>(a.shift + n);
                     if (a.res1) v += *reinterpret_cast<const f32x4 *>(a.res1 + pix + n);
                     if (a.res2) v += *reinterpret_cast<const f32x4 *>(a.res2 + pix + n);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = activate(v[e], a.act);
+                    activate4(v, a.act);
                     *reinterpret_cast<f32x4 *>(a.out + pix + n) = v;
                 } else {
 #pragma unroll
@@ -544,8 +543,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
                     v = v * *reinterpret_cast<const f32x4 *>(&ep_lds[0][n - n0]) + *reinterpret_cast<const f32x4 *>(&ep_lds[1][n - n0]);
                     if (a.res1) v += *reinterpret_cast<const f32x4 *>(a.res1 + pix + n);
                     if (a.res2) v += *reinterpret_cast<const f32x4 *>(a.res2 + pix + n);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = activate(v[e], a.act);
+                    activate4(v, a.act);
                     *reinterpret_cast<f32x4 *>(a.out + pix + n) = v;
                 } else {
 #pragma unroll

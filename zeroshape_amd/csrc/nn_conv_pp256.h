@@ -300,37 +300,64 @@ __global__ __launch_bounds__(512) void conv_gemm_pp256_kernel(ConvArgs a) {
     // load behind a store waits for the store's acknowledgement (and hipcc cannot hoist it: `out` may alias).  The first
     // form - scale / shift / residual loaded per 16-byte piece between the stores - spent 32-38 k cycles per tile here, with
     // the stores redirected to a 4 MiB window as well (tools/pp256_stamps.py): 32 dependent store -> load round trips.
+    // ... and the activation is a compile-time constant of the store loop (one switch per tile, activate4_t): decided per
+    // value it cost 500 taken branches per wave through an instruction stream far larger than the instruction cache
     if (range < 0) {
+        // the pointers as opaque scalar registers: hipcc otherwise re-loads a.out / a.res2 from the kernel arguments in front of
+        // EVERY store (s_load + s_waitcnt lgkmcnt(0), twice per store)
+        // (generic pointers: flat_ stores.  Casting them to the global address space made hipcc spill 214 registers in these
+        // loops - 46.8 k cycles per tile instead of 21.5 k)
+        float *out = a.out;
+        const float *res1 = a.res1, *res2 = a.res2;
+        asm volatile("" : "+s"(out), "+s"(res1), "+s"(res2));
+        const int Cout = a.Cout;
+        // FAST: the wave's 64 x 128 block lies inside the matrix and there is no second residual - no per-lane predicates
+        auto store_tile = [&](auto act_tag, auto fast_tag) {
+            constexpr int ACT = decltype(act_tag)::value;
+            constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
-        for (int i = 0; i < MI; i++) {
-            const int m = m0 + wm + 32 * i + l32;
-            const bool mok = m < a.M;
-            const size_t row = (size_t)(mok ? m : 0) * a.Cout;
-            f32x4 r[NJ][4];                                       // res1 (res2, if any, is read between the stores: no pointwise layer of the encoders has one)
-            if (a.res1) {
+            for (int i = 0; i < MI; i++) {
+                const int m = m0 + wm + 32 * i + l32;
+                const bool mok = FAST || m < a.M;
+                const size_t row = (size_t)(mok ? m : 0) * Cout;
 #pragma unroll
-                for (int j = 0; j < NJ; j++)
+                for (int jp = 0; jp < NJ; jp += 2) {              // half a row block at a time: 8 residual quads in flight, then 8 stores
+                    f32x4 r[2][4];                                // res1 (res2, if any, is read between the stores: no pointwise layer of the encoders has one)
+                    if (res1) {
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const int n = n0 + wn + 32 * j + 8 * q + 4 * half;
-                        r[j][q] = *reinterpret_cast<const f32x4 *>(a.res1 + row + (n < a.Cout ? n : 0));
+                        for (int j = 0; j < 2; j++)
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                const int n = n0 + wn + 32 * (jp + j) + 8 * q + 4 * half;
+                                r[j][q] = *reinterpret_cast<const f32x4 *>(res1 + row + (FAST || n < Cout ? n : 0));
+                            }
                     }
-            }
 #pragma unroll
-            for (int j = 0; j < NJ; j++)
+                    for (int j = 0; j < 2; j++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int c = wn + 32 * j + 8 * q + 4 * half, n = n0 + c;
-                    if (!mok || n >= a.Cout) continue;            // Cout % 4 == 0 (checked by the launcher)
-                    const f32x16 &d = acc[i][j];
-                    f32x4 v = {d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
-                    v = v * *reinterpret_cast<const f32x4 *>(&ep_lds[0][c]) + *reinterpret_cast<const f32x4 *>(&ep_lds[1][c]);
-                    if (a.res1) v += r[j][q];
-                    if (a.res2) v += *reinterpret_cast<const f32x4 *>(a.res2 + row + n);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = activate(v[e], a.act);
-                    *reinterpret_cast<f32x4 *>(a.out + row + n) = v;
+                        for (int q = 0; q < 4; q++) {
+                            const int c = wn + 32 * (jp + j) + 8 * q + 4 * half, n = n0 + c;
+                            if (!FAST && (!mok || n >= Cout)) continue;        // Cout % 4 == 0 (checked by the launcher)
+                            const f32x16 &d = acc[i][jp + j];
+                            f32x4 v = {d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
+                            v = v * *reinterpret_cast<const f32x4 *>(&ep_lds[0][c]) + *reinterpret_cast<const f32x4 *>(&ep_lds[1][c]);
+                            if (res1) v += r[j][q];
+                            if (!FAST && res2) v += *reinterpret_cast<const f32x4 *>(res2 + row + n);
+                            activate4_t<ACT>(v);
+                            *reinterpret_cast<f32x4 *>(out + row + n) = v;
+                        }
                 }
+            }
+        };
+        const bool fast = m0 + wm + 64 <= a.M && n0 + wn + 128 <= Cout && !res2;      // wave-uniform
+        auto run = [&](auto act_tag) {
+            if (fast) store_tile(act_tag, std::true_type{}); else store_tile(act_tag, std::false_type{});
+        };
+        switch (a.act) {
+            case ZS_ACT_RELU: run(std::integral_constant<int, ZS_ACT_RELU>{}); break;
+            case ZS_ACT_GELU: run(std::integral_constant<int, ZS_ACT_GELU>{}); break;
+            case ZS_ACT_RELU_CLAMP1: run(std::integral_constant<int, ZS_ACT_RELU_CLAMP1>{}); break;
+            default: run(std::integral_constant<int, ZS_ACT_NONE>{}); break;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PP_PHASE(2)
@@ -366,8 +393,7 @@ __global__ __launch_bounds__(512) void pp256_tail_kernel(ConvArgs a) {
     if (a.shift) v += *reinterpret_cast<const f32x4 *>(a.shift + n);
     if (a.res1) v += *reinterpret_cast<const f32x4 *>(a.res1 + o);
     if (a.res2) v += *reinterpret_cast<const f32x4 *>(a.res2 + o);
-#pragma unroll
-    for (int e = 0; e < 4; e++) v[e] = activate(v[e], a.act);
+    activate4(v, a.act);
     *reinterpret_cast<f32x4 *>(a.out + o) = v;
 }
 

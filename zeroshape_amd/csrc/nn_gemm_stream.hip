@@ -40,6 +40,12 @@ __device__ __forceinline__ float activate(float v, int act) {
     return v;
 }
 
+__device__ __forceinline__ void activate4(f32x4 &v, int act) {          // one decision per quad, not three per value (nn_conv.hip)
+    if (act == ZS_ACT_NONE) return;
+#pragma unroll
+    for (int e = 0; e < 4; e++) v[e] = activate(v[e], act);
+}
+
 template <int NW, int MI, int NJ, int DEPTH, bool LN>
 __global__ __launch_bounds__(64 * NW) void stream_gemm_kernel(Args a, Geo g) {
     constexpr int SM = 32 * MI, SN = 32 * NJ, PAD = SN + 4;
@@ -308,8 +314,7 @@ __global__ __launch_bounds__(64 * NW) void stream_gemm_kernel(Args a, Geo g) {
             if (a.shift) r += *reinterpret_cast<const f32x4 *>(a.shift + n);
             if (a.res1) r += *reinterpret_cast<const f32x4 *>(a.res1 + o);
             if (a.res2) r += *reinterpret_cast<const f32x4 *>(a.res2 + o);
-#pragma unroll
-            for (int k = 0; k < 4; k++) r[k] = activate(r[k], a.act);
+            activate4(r, a.act);
             *reinterpret_cast<f32x4 *>(a.out + o) = r;
         }
         if constexpr ((QPR & (QPR - 1)) == 0) {
