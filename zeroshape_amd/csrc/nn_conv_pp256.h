@@ -55,7 +55,12 @@ __global__ __launch_bounds__(512) void conv_gemm_pp256_kernel(ConvArgs a) {
         const int xcd = (int)blockIdx.x & 7, q8 = full >> 3, r8 = full & 7;
         tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ((int)blockIdx.x >> 3);
     } else {
-        const int u = (int)blockIdx.x - full;
+        int u = (int)blockIdx.x - full;
+        if (full == 0) {      // every tile is cut (fc2: 66 tiles x 3 ranges): XCD-contiguous runs here too - neighbouring tiles of ONE K
+                              // range share operand panels (r05 counters: TCC hit rate 38 % with the round-robin deal)
+            const int nu = (int)gridDim.x, xcd = u & 7, q8 = nu >> 3, r8 = nu & 7;
+            u = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (u >> 3);
+        }
         tile = full + u % a.sk_per;
         range = u / a.sk_per;
         t_lo = (int)(((long long)range * steps_all) / a.splits);
