@@ -24,7 +24,10 @@ SHAPES = [(128, 32, 224, 224, 3, 1, False, False), (256, 256, 56, 56, 3, 1, True
           # batch-1 shapes of the streaming kernel (nn_conv_stream.h): 7 x 7 maps, the one-pixel fc head, stride 2, readout
           (768, 768, 14, 14, 3, 2, False, False), (512, 512, 7, 7, 3, 1, False, False), (2048, 512, 7, 7, 1, 1, False, False),
           (512, 2048, 7, 7, 1, 1, False, True), (2048, 2048, 1, 1, 1, 1, False, False), (1536, 768, 1, 196, 1, 1, False, False),
-          (1024, 768, 14, 14, 1, 1, False, False), (768, 256, 14, 14, 3, 1, False, False), (1024, 1024, 14, 14, 1, 1, False, True)]
+          (1024, 768, 14, 14, 1, 1, False, False), (768, 256, 14, 14, 3, 1, False, False), (1024, 1024, 14, 14, 1, 1, False, True),
+          # the 256 x 256 ping-pong kernel (nn_conv_pp256.h) beyond the ViT shapes above: three rounds of tiles + a K-range tail,
+          # a long contraction, a ragged last row tile
+          (768, 3072, 1, 586, 1, 1, False, True), (3072, 1024, 1, 293, 1, 1, False, False), (2048, 772, 1, 200, 1, 1, False, True)]
 
 
 def main():
