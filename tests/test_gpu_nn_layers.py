@@ -641,3 +641,33 @@ def test_fused_group_norm_launches_directly(B, H, W):
         close(pooled, ops.max_pool(ops.group_norm(u1, ga1.cuda(), be1.cuda(), relu=True), 3, 2, 1).cpu(), tol=2e-5)
     finally:
         ops.set_conv_precision(prev)
+
+
+@pytest.mark.parametrize("B,L,heads,d", [(28, 197, 12, 64), (28, 197, 8, 32), (600, 65, 8, 32), (40, 33, 4, 64), (20, 224, 8, 64), (17, 96, 8, 32)])
+def test_attention_with_keys_and_values_staged_in_lds(B, L, heads, d):
+    """Many (sample, head) pairs (the ViT blocks at batch 28, the window stage's windows): attention_lds_kernel stages K and V once per
+    pair in LDS, pre-split and in fragment order (csrc/nn_ops.hip).  Parity with torch, and - the same MFMAs on the same operand
+    bits in the same order - bit-identical to the one-wave-per-query-tile kernel, which sub-batches of fewer than 128 pairs take."""
+    from zeroshape_amd.nn import ops
+    g = torch.Generator().manual_seed(B + L)
+    C = heads * d
+    qkv = torch.randn(B, L, 3 * C, generator=g)
+    q, k, v = qkv.reshape(B, L, 3, heads, d).permute(2, 0, 3, 1, 4)
+    want = (((q * d ** -0.5) @ k.transpose(-2, -1)).softmax(-1) @ v).transpose(1, 2).reshape(B, L, C)
+    prev = ops.CONV_PRECISION
+    try:
+        ops.set_conv_precision("f16x3")
+        assert B * heads >= 128
+        x = qkv.cuda()
+        got = ops.attention(x, heads)
+        close(got, want)
+        assert torch.equal(got, ops.attention(x, heads))
+        step = max(1, 127 // heads)                     # sub-batches below the 128-pair threshold: the register-only kernels
+        assert step * heads < 128
+        parts = torch.cat([ops.attention(x[i:i + step].contiguous(), heads) for i in range(0, min(B, 4 * step) // step * step, step)], 0)
+        if L > 64 and step * heads * ((L + 31) // 32) < 512:
+            close(got[:parts.shape[0]], parts.cpu(), tol=2e-6)      # (few pairs and several key tiles: the key-split kernel, another association)
+        else:
+            assert torch.equal(got[:parts.shape[0]], parts)
+    finally:
+        ops.set_conv_precision(prev)

@@ -18,6 +18,9 @@ SHAPES = [  # (name, M, K, N)
     ("big3r", 16384, 768, 3072), ("full1r", 8192, 768, 2048), ("r1024", 5488, 1024, 1024), ("r256", 5488, 1024, 256),
     ("c56a", 87808, 64, 256), ("c56b", 87808, 256, 64), ("c28", 21952, 128, 512), ("c28b", 21952, 512, 128),
     ("c14", 5488, 256, 1024),
+    # window stage of the transformer coordinate encoder at batch 28 (5,488 windows x 65 tokens) and the 56 x 56 bottleneck layers
+    ("w_qkv", 356720, 256, 768), ("w_proj", 356720, 256, 256), ("w_fc1", 356720, 256, 1024), ("w_fc2", 356720, 1024, 256),
+    ("c56c", 87808, 256, 256), ("c56d", 87808, 512, 128), ("c28c", 21952, 1024, 256), ("c28d", 21952, 256, 1024),
 ]
 
 

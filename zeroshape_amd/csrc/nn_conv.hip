@@ -1730,7 +1730,12 @@ static int conv2d_impl(const float *in, const float *packed_w, const float *scal
         static const int cus = [] { int dev = 0, n = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
         const long long T = ((M + pp256::TM - 1) / pp256::TM) * ((a.CoutPad + pp256::TN - 1) / pp256::TN);
         const bool pp_forced = (flags & ZS_CONV_FORCE_TILE256) != 0;
-        const bool pp_pays = pp_on && T >= pp_min_tiles && a.K >= pp_min_k && (T >= cus / 2 || a.K >= pp_long_k);
+        // ... and from K = 256 where the tiles make four rounds or more (the window stage of the transformer coordinate encoder at
+        // batch 28: 356,720 rows - qkv 770 -> 562 us, fc1 1,096 -> 695, fc2 807 -> 560, proj 272 -> 245; at 343 tiles the same K
+        // loses: 56 -> 68): over many rounds the XCDs drift apart and one tile's epilogue runs beside another's loop
+        static const long long pp_many_k = getenv("ZS_CONV_PP256_MANY_K") ? atoll(getenv("ZS_CONV_PP256_MANY_K")) : 256;
+        const bool pp_pays = pp_on && T >= pp_min_tiles &&
+                             ((a.K >= pp_min_k && (T >= cus / 2 || a.K >= pp_long_k)) || (a.K >= pp_many_k && T >= 4LL * cus));
         if ((pp_forced || pp_pays) && pw && f16 && a.w_split && !fuse && (Cin % pp256::SK) == 0 && (Cout & 3) == 0 &&
             !(flags & (ZS_CONV_FORCE_SMALL | ZS_CONV_FORCE_LARGE))) {
             const long long steps = a.K / pp256::SK;

@@ -465,6 +465,131 @@ __global__ __launch_bounds__(64) void attention_split_kernel(const float *__rest
     }
 }
 
+// ---- many sequences (batch 28; the window stage's 43,904 windows x heads): K and V staged ONCE per (sample, head) ----
+// attention_split_kernel gives every 32-query tile a workgroup of one wave that loads - and splits - the sequence's whole K
+// and V straight from global memory: at L = 197 seven waves fetch and split the same 100 KB (2,352 waves x 100 KB = 235 MB
+// per ViT block at batch 28, 52 us).  Here one workgroup owns a (sample, head): its waves first stage K and V into LDS,
+// ALREADY SPLIT into the fp16 halves and in the order the MFMA fragments want them (one conflict-free ds_read_b128 each),
+// then take the query tiles qt = wave, wave + NW, ...  Per (query tile, key tile) the same MFMAs on the same operand bits in
+// the same order as attention_split_kernel: bit-identical results.
+//   K: row = key, 4 DS slots of 16 B: slot ((t * 2 + half) * 2 + plane) ^ swizzle(key) holds the hi (plane 0) / lo halves of the
+//      eight d values {4 (4 t + half) .. + 3, 4 (4 t + 2 + half) .. + 3} - what lane (key, half) contracts in d-step t;
+//   V: [key group g of 16][half][plane][d][16 B]: the eight keys 16 g + 4 half + {0..3, 8..11} of column d - what lane
+//      (d, half) contracts in step g & 1 of key tile g / 2.
+template <int D, int LP>
+__global__ __launch_bounds__(64 * (LP / 32 < 8 ? LP / 32 : 8)) void attention_lds_kernel(const float *__restrict__ qkv, float *__restrict__ out,
+                                                                                      int L, int heads, float scale) {
+    using zs::s16::mfma3;
+    using zs::s16::split8;
+    constexpr int DS = D / 16, DT = D / 32, NW = LP / 32 < 8 ? LP / 32 : 8, SLOTS = 4 * DS;
+    __shared__ u32x4 kl[LP * SLOTS];                      // LP x D x 4 bytes
+    __shared__ u32x4 vl[(LP / 16) * 2 * 2 * D];           // the same size
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, half = lane >> 5;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads, C = heads * D;
+    const float *base = qkv + (size_t)b * L * 3 * C + h * D;
+    const int QT = (L + 31) / 32;
+    auto swz = [](int key) { return D == 64 ? (key & 15) : ((key >> 1) & 7); };
+    // ---- stage K: item = (key, t, half)
+    for (int it = tid; it < QT * 32 * DS * 2; it += 64 * NW) {
+        const int hf = it & 1, t = (it >> 1) % DS, key = it / (2 * DS), kr = min(key, L - 1);
+        const f32x4 q0 = *reinterpret_cast<const f32x4 *>(base + (size_t)kr * 3 * C + C + 4 * (4 * t + hf));
+        const f32x4 q1 = *reinterpret_cast<const f32x4 *>(base + (size_t)kr * 3 * C + C + 4 * (4 * t + 2 + hf));
+        u32x4 hi, lo;
+        split8(q0, q1, hi, lo);
+        const int s0 = (t * 2 + hf) * 2;
+        kl[key * SLOTS + (s0 ^ swz(key))] = hi;
+        kl[key * SLOTS + ((s0 + 1) ^ swz(key))] = lo;
+    }
+    // ---- stage V: item = (g, half, d), d fastest (coalesced rows)
+    for (int it = tid; it < QT * 2 * 2 * D; it += 64 * NW) {
+        const int d = it % D, hf = (it / D) & 1, g = it / (2 * D);
+        float vf[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int key = min(16 * g + 4 * hf + (e & 3) + 8 * (e >> 2), L - 1);
+            vf[e] = base[(size_t)key * 3 * C + 2 * C + d];
+        }
+        u32x4 hi, lo;
+        split8(f32x4{vf[0], vf[1], vf[2], vf[3]}, f32x4{vf[4], vf[5], vf[6], vf[7]}, hi, lo);
+        vl[((g * 2 + hf) * 2 + 0) * D + d] = hi;
+        vl[((g * 2 + hf) * 2 + 1) * D + d] = lo;
+    }
+    __syncthreads();
+    for (int qt = wave; qt < QT; qt += NW) {
+        const int q0 = qt * 32, qrow = min(q0 + l32, L - 1);
+        u32x4 qh[DS], ql[DS];
+#pragma unroll
+        for (int t = 0; t < DS; t++) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(base + (size_t)qrow * 3 * C + 4 * (4 * t + half)) * scale;
+            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(base + (size_t)qrow * 3 * C + 4 * (4 * t + 2 + half)) * scale;
+            split8(a0, a1, qh[t], ql[t]);
+        }
+        f32x16 o[DT];
+#pragma unroll
+        for (int i = 0; i < DT; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[i][r] = 0.f;
+        float mx = -INFINITY, den = 0.f;
+        for (int kt = 0; kt < QT; kt++) {
+            const int k0 = kt * 32, key = k0 + l32;
+            f32x16 sT;
+#pragma unroll
+            for (int r = 0; r < 16; r++) sT[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < DS; t++) {
+                const int s0 = (t * 2 + half) * 2;
+                const u32x4 kh = kl[key * SLOTS + (s0 ^ swz(key))], klo = kl[key * SLOTS + ((s0 + 1) ^ swz(key))];
+                mfma3(sT, kh, klo, qh[t], ql[t]);
+            }
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int kk = k0 + 8 * (r >> 2) + 4 * half + (r & 3);
+                sT[r] = kk < L ? sT[r] : -INFINITY;
+                tmax = fmaxf(tmax, sT[r]);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float nm = fmaxf(mx, tmax), corr = __expf(mx - nm);
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                sT[r] = __expf(sT[r] - nm);
+                psum += sT[r];
+            }
+            psum += __shfl_xor(psum, 32, 64);
+            den = den * corr + psum;
+            mx = nm;
+            u32x4 ph[2], pl[2];
+#pragma unroll
+            for (int sidx = 0; sidx < 2; sidx++)
+                split8(f32x4{sT[8 * sidx], sT[8 * sidx + 1], sT[8 * sidx + 2], sT[8 * sidx + 3]},
+                       f32x4{sT[8 * sidx + 4], sT[8 * sidx + 5], sT[8 * sidx + 6], sT[8 * sidx + 7]}, ph[sidx], pl[sidx]);
+#pragma unroll
+            for (int i = 0; i < DT; i++) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) o[i][r] *= corr;
+#pragma unroll
+                for (int sidx = 0; sidx < 2; sidx++) {
+                    const int g = kt * 2 + sidx, d = 32 * i + l32;
+                    const u32x4 vh = vl[((g * 2 + half) * 2 + 0) * D + d], vlo = vl[((g * 2 + half) * 2 + 1) * D + d];
+                    mfma3(o[i], vh, vlo, ph[sidx], pl[sidx]);
+                }
+            }
+        }
+        if (q0 + l32 < L) {
+            const float inv = 1.0f / den;
+            float *dst = out + ((size_t)b * L + q0 + l32) * C + h * D;
+#pragma unroll
+            for (int i = 0; i < DT; i++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const f32x4 v = {o[i][4 * g] * inv, o[i][4 * g + 1] * inv, o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv};
+                    *reinterpret_cast<f32x4 *>(dst + 32 * i + 8 * g + 4 * half) = v;
+                }
+        }
+    }
+}
+
 // ---- few sequences (batch 1): the key tiles of one (sample, head, 32-query tile) spread over the waves of a workgroup ----
 // attention_split_kernel walks its key tiles one after the other, each a dependent pair of load round trips (K, then V):
 // 7 tiles at L = 197 = 21 us for 84 waves on 256 CUs.  Here every wave takes the key tiles kt = wave, wave + KW, ... (one
@@ -988,6 +1113,18 @@ extern "C" int zs_attention_split(const float *qkv, float *out, int batch, int L
             hipLaunchKernelGGL(attention_split_kw_kernel<64>, grid, dim3(64 * ATT_KW), 0, S(stream), qkv, out, L, heads, scale);
         else
             hipLaunchKernelGGL(attention_split_kw_kernel<32>, grid, dim3(64 * ATT_KW), 0, S(stream), qkv, out, L, heads, scale);
+        return zs::check_launch("zs_attention_split") ? 1 : 0;
+    }
+    // many (sample, head) pairs of several query tiles: K / V staged once per pair in LDS (attention_lds_kernel); the staged
+    // image holds the keys padded to whole tiles: L <= 96 (window stage: 65) or <= 224 (ViT: 197)
+    static const bool no_lds = getenv("ZS_ATT_NO_LDS") != nullptr;           // A/B switch
+    static const long long lds_min_pairs = getenv("ZS_ATT_LDS_MIN_PAIRS") ? atoll(getenv("ZS_ATT_LDS_MIN_PAIRS")) : 128;
+    if (!no_lds && (long long)batch * heads >= lds_min_pairs && L > 32 && L <= 224) {
+        const dim3 g1(batch * heads);
+#define ZS_ATT_LDS(D_, LP_) hipLaunchKernelGGL((attention_lds_kernel<D_, LP_>), g1, dim3(64 * (LP_ / 32 < 8 ? LP_ / 32 : 8)), 0, S(stream), qkv, out, L, heads, scale)
+        if (head_dim == 64) { if (L <= 96) ZS_ATT_LDS(64, 96); else ZS_ATT_LDS(64, 224); }
+        else { if (L <= 96) ZS_ATT_LDS(32, 96); else ZS_ATT_LDS(32, 224); }
+#undef ZS_ATT_LDS
         return zs::check_launch("zs_attention_split") ? 1 : 0;
     }
     if (head_dim == 64)
