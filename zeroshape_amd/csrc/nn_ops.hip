@@ -489,28 +489,45 @@ __global__ __launch_bounds__(64 * (LP / 32 < 8 ? LP / 32 : 8)) void attention_ld
     const float *base = qkv + (size_t)b * L * 3 * C + h * D;
     const int QT = (L + 31) / 32;
     auto swz = [](int key) { return D == 64 ? (key & 15) : ((key >> 1) & 7); };
-    // ---- stage K: item = (key, t, half)
-    for (int it = tid; it < QT * 32 * DS * 2; it += 64 * NW) {
+    // ---- stage K: item = (key, t, half).  Compile-time trip counts (the padded image, keys beyond L clamp to L - 1): every
+    // global load of the staging phase is in flight before the first split - one latency, not one per item (35.1 -> 33.0 us per ViT block at batch 28)
+    constexpr int KIT = LP * DS * 2 / (64 * NW), VIT = (LP / 16) * 2 * D / (64 * NW);
+    static_assert(KIT * 64 * NW == LP * DS * 2 && VIT * 64 * NW == (LP / 16) * 2 * D, "staging items divide evenly");
+    f32x4 kq[KIT][2];
+    float vf[VIT][8];
+#pragma unroll
+    for (int u = 0; u < KIT; u++) {
+        const int it = tid + u * 64 * NW;
         const int hf = it & 1, t = (it >> 1) % DS, key = it / (2 * DS), kr = min(key, L - 1);
-        const f32x4 q0 = *reinterpret_cast<const f32x4 *>(base + (size_t)kr * 3 * C + C + 4 * (4 * t + hf));
-        const f32x4 q1 = *reinterpret_cast<const f32x4 *>(base + (size_t)kr * 3 * C + C + 4 * (4 * t + 2 + hf));
+        kq[u][0] = *reinterpret_cast<const f32x4 *>(base + (size_t)kr * 3 * C + C + 4 * (4 * t + hf));
+        kq[u][1] = *reinterpret_cast<const f32x4 *>(base + (size_t)kr * 3 * C + C + 4 * (4 * t + 2 + hf));
+    }
+#pragma unroll
+    for (int u = 0; u < VIT; u++) {
+        const int it = tid + u * 64 * NW;
+        const int d = it % D, hf = (it / D) & 1, g = it / (2 * D);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int key = min(16 * g + 4 * hf + (e & 3) + 8 * (e >> 2), L - 1);
+            vf[u][e] = base[(size_t)key * 3 * C + 2 * C + d];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < KIT; u++) {
+        const int it = tid + u * 64 * NW;
+        const int hf = it & 1, t = (it >> 1) % DS, key = it / (2 * DS);
         u32x4 hi, lo;
-        split8(q0, q1, hi, lo);
+        split8(kq[u][0], kq[u][1], hi, lo);
         const int s0 = (t * 2 + hf) * 2;
         kl[key * SLOTS + (s0 ^ swz(key))] = hi;
         kl[key * SLOTS + ((s0 + 1) ^ swz(key))] = lo;
     }
-    // ---- stage V: item = (g, half, d), d fastest (coalesced rows)
-    for (int it = tid; it < QT * 2 * 2 * D; it += 64 * NW) {
-        const int d = it % D, hf = (it / D) & 1, g = it / (2 * D);
-        float vf[8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const int key = min(16 * g + 4 * hf + (e & 3) + 8 * (e >> 2), L - 1);
-            vf[e] = base[(size_t)key * 3 * C + 2 * C + d];
-        }
+    for (int u = 0; u < VIT; u++) {
+        const int it = tid + u * 64 * NW;
+        const int d = it % D, hf = (it / D) & 1, g = it / (2 * D);
         u32x4 hi, lo;
-        split8(f32x4{vf[0], vf[1], vf[2], vf[3]}, f32x4{vf[4], vf[5], vf[6], vf[7]}, hi, lo);
+        split8(f32x4{vf[u][0], vf[u][1], vf[u][2], vf[u][3]}, f32x4{vf[u][4], vf[u][5], vf[u][6], vf[u][7]}, hi, lo);
         vl[((g * 2 + hf) * 2 + 0) * D + d] = hi;
         vl[((g * 2 + hf) * 2 + 1) * D + d] = lo;
     }
