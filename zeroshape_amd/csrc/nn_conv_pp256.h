@@ -254,7 +254,9 @@ __global__ __launch_bounds__(512) void conv_gemm_pp256_kernel(ConvArgs a) {
             PP_STAMP(1)
             mfmas_dma(buf ^ 1, t + 2 < steps);                    // stage t + 1
             PP_STAMP(2)
+#ifndef ZS_EXP_PP_ONE_BARRIER
             bar();                                                // A(t)
+#endif
             PP_STAMP(3)
             frags(buf, 1);
             PP_STAMP(4)
@@ -281,7 +283,9 @@ __global__ __launch_bounds__(512) void conv_gemm_pp256_kernel(ConvArgs a) {
             PP_STAMP(0)
             frags(buf, 0);
             PP_STAMP(1)
+#ifndef ZS_EXP_PP_ONE_BARRIER
             bar();                                                // A(t)
+#endif
             PP_STAMP(2)
             mfmas();
             PP_STAMP(3)
