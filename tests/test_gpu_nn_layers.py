@@ -671,3 +671,20 @@ def test_attention_with_keys_and_values_staged_in_lds(B, L, heads, d):
             assert torch.equal(got[:parts.shape[0]], parts)
     finally:
         ops.set_conv_precision(prev)
+
+
+@pytest.mark.parametrize("B,H,W,C,win", [(2, 16, 24, 256, 8), (3, 8, 8, 64, 4), (1, 16, 16, 20, 8), (2, 16, 16, 768, 8)])
+def test_window_tokens_quad_and_scalar_forms(B, H, W, C, win):
+    """zs_window_tokens (CoordEmb's window gather, model/depth/... via nn/blocks.py): [cls | win^2 pixels of a window] + pos, masked
+    pixels replaced by the invalid token - bit-equal to the torch construction, through the four-channels-per-lane kernel (C / 4
+    divides 256) and the scalar one (C = 20: 5 quads do not; 768: 192 quads do not)."""
+    from zeroshape_amd.nn import ops
+    g = torch.Generator().manual_seed(C + win)
+    emb = torch.randn(B, H, W, C, generator=g)
+    mask = torch.rand(B, H, W, generator=g) > 0.3
+    inv, cls, pos = torch.randn(C, generator=g), torch.randn(C, generator=g), torch.randn(win * win + 1, C, generator=g)
+    got = ops.window_tokens(emb.cuda(), mask.cuda(), inv.cuda(), cls.cuda(), pos.cuda(), win)
+    x = torch.where(mask[..., None], emb, inv.expand_as(emb))
+    x = x.reshape(B, H // win, win, W // win, win, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, win * win, C)
+    want = torch.cat([cls.expand(x.shape[0], 1, C), x], 1) + pos
+    assert got.shape == want.shape and torch.equal(got.cpu(), want)
