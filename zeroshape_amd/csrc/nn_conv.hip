@@ -513,7 +513,7 @@ __device__ f32x4 zs_zero_page[4];
 
 
 __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst) {   // 64 lanes x 16 B -> LDS[dst + 16 lane]
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
 }
 
 template <int N>

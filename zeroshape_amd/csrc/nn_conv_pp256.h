@@ -201,7 +201,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp256_kernel(ConvArgs a) {
             : PP_ACCS
             : PP_FRAGS, [a0] "v"(apo[0]), [a1] "v"(apo[1]), [a2] "v"(apo[2]), [a3] "v"(apo[3]),
               [b0] "v"(bpo[0]), [b1] "v"(bpo[1]), [b2] "v"(bpo[2]), [b3] "v"(bpo[3]), [da] "s"(da)
-            : "memory", "scc");
+            : "memory", "scc", "m0");
         const int ia = more ? a_inc : 0, ib = more ? b_inc : 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
