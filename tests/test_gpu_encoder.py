@@ -174,3 +174,32 @@ def test_batches_of_small_images_through_the_fused_trunk_gate(graph, encoder_sd,
     np.testing.assert_allclose(depth.cpu().numpy(), odepth.numpy(), atol=1e-4, rtol=0)
     close(feat, ofeat, msg="layer_4 @%d x %d" % (B, size))
     assert blocks._fused_maps_ok(B, size, size, 3) == (size == 128)
+
+
+def test_batch_28_takes_the_large_tile_kernels_and_agrees_with_small_batches_and_the_oracle(graph, encoder_sd):
+    """options/shape.yaml's batch of 28: the ViT qkv / fc1 / fc2 layers run the 256 x 256 ping-pong GEMM kernel (csrc/nn_conv_pp256.h,
+    incl. its K-range tails: 264 = 256 + 8 tiles on fc1, 66 x 3 ranges on fc2) and attention with K / V staged in LDS - kernels the
+    batch-2 tests above never select.  The same images in batches of 2 (128 x 128 / streaming kernels, register-only attention)
+    give the same depth, tap-4 feature and latent to summation order, and the first two images agree with the CPU oracle."""
+    B = 28
+    rgb, mask = [torch.from_numpy(a) for a in syn.seeded_rgb_scene(seed=3, batch=B)]
+    depth, feat = graph.dpt_depth(rgb.cuda(), get_feat=True)
+    assert depth.shape == (B, 1, 224, 224) and feat.shape == (B, 768, 7, 7)
+    d2, f2 = [], []
+    for i in range(0, 8, 2):
+        a, b = graph.dpt_depth(rgb[i:i + 2].cuda(), get_feat=True)
+        d2.append(a)
+        f2.append(b)
+    close(feat[:8], torch.cat(f2).cpu(), tol=2e-5, msg="tap-4 feature, batch 28 vs batches of 2")
+    np.testing.assert_allclose(depth[:8].cpu().numpy(), torch.cat(d2).cpu().numpy(), atol=2e-5, rtol=0)
+    odepth, ofeat = E.dpt_depth(E._sub(encoder_sd, "dpt_depth."), rgb[:2])
+    np.testing.assert_allclose(depth[:2].cpu().numpy(), odepth.numpy(), atol=1e-4, rtol=0)
+    close(feat[:2], ofeat, msg="layer_4 at batch 28 vs oracle")
+    # the whole graph: latent codes
+    opt = make_opt()
+    opt.arch.depth.dsp = 1
+    var = edict(dict(idx=torch.arange(B), rgb_input_map=rgb.cuda(), mask_input_map=mask.cuda(), pose_gt=torch.zeros(B, 3, 4).cuda()))
+    var = graph.forward(opt, var, training=False, get_loss=False)
+    v2 = edict(dict(idx=torch.arange(2), rgb_input_map=rgb[:2].cuda(), mask_input_map=mask[:2].cuda(), pose_gt=torch.zeros(2, 3, 4).cuda()))
+    v2 = graph.forward(opt, v2, training=False, get_loss=False)
+    close(var.latent_depth[:2], v2.latent_depth.cpu(), tol=5e-5, msg="latent, batch 28 vs batch 2")
