@@ -1638,7 +1638,12 @@ static int conv2d_impl(const float *in, const float *packed_w, const float *scal
     // fewer than ~3/4 of a wave of 128x128 tiles over the 256 CUs: use the small-tile split-K variant
     const long long big_tiles = ((M + BM - 1) / BM) * (a.CoutPad / BN);
     static const long long big_min = getenv("ZS_CONV_BIG_MIN") ? atoll(getenv("ZS_CONV_BIG_MIN")) : 192;   // (128 is ~1 % faster at batch 28 - 15.3 vs 15.5 ms - but moves the training kernels too: the 300-iteration from-scratch run of tests/test_gpu_trained_weights.py then takes the trajectory on which the untrained depth head dies; kept at 192)
-    const bool small = (flags & ZS_CONV_FORCE_SMALL) || (!(flags & ZS_CONV_FORCE_LARGE) && big_tiles < big_min);
+    // With a workspace - the inference engine (nn/ops.py); the training path calls zs_conv2d_nhwc without one and keeps 192 - the
+    // large-tile kernels start at 96 tiles (round 5, tools/enc_b28.py on one box: 192 / 128 / 96 / 80 / 64 / 40 tiles = 14.24 / 14.08 /
+    // 14.11 / 14.06 / 14.61 / 14.87 ms per batch-28 forward; batch 1 has no layer in that range)
+    static const long long big_min_ws = getenv("ZS_CONV_BIG_MIN_WS") ? atoll(getenv("ZS_CONV_BIG_MIN_WS")) : 96;
+    const long long big_min_eff = workspace && !getenv("ZS_CONV_BIG_MIN") ? big_min_ws : big_min;
+    const bool small = (flags & ZS_CONV_FORCE_SMALL) || (!(flags & ZS_CONV_FORCE_LARGE) && big_tiles < big_min_eff);
     const bool pw = kh == 1 && kw == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && a.dil == 1 && !a.in_relu &&
                     in_scale == 1.0f && in_shift == 0.0f && Hin == Hout && Win == Wout;
     hipStream_t st = static_cast<hipStream_t>(stream);
