@@ -747,6 +747,27 @@ __global__ __launch_bounds__(256) void max_pool_kernel(const float *__restrict__
     y[i] = m;
 }
 
+// the same, four channels per lane and 32-bit index arithmetic (C % 4 == 0, fewer than 2^31 output quads): fmaxf per component in
+// the same tap order - the same values
+__global__ __launch_bounds__(256) void max_pool_quad_kernel(const f32x4 *__restrict__ x, f32x4 *__restrict__ y, unsigned total,
+                                                            int Hin, int Win, int C4, int Hout, int Wout, int k, int stride,
+                                                            int pad_t, int pad_l) {
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const unsigned c = i % C4, p = i / C4, ox = p % Wout, q = p / Wout, oy = q % Hout, b = q / Hout;
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int ky = 0; ky < k; ky++)
+        for (int kx = 0; kx < k; kx++) {
+            const int iy = (int)oy * stride - pad_t + ky, ix = (int)ox * stride - pad_l + kx;
+            if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
+                const f32x4 v = x[(((size_t)b * Hin + iy) * Win + ix) * C4 + c];
+#pragma unroll
+                for (int e = 0; e < 4; e++) m[e] = fmaxf(m[e], v[e]);
+            }
+        }
+    y[i] = m;
+}
+
 // 64 channels x 4 pixel slices per workgroup (a lane per channel walking all pixels alone was 13 us for a 7 x 7 map: a chain of
 // dependent adds on 8 workgroups); the four slice sums are added in slice order
 __global__ __launch_bounds__(256) void global_mean_kernel(const float *__restrict__ x, float *__restrict__ y, int HW,
@@ -1193,6 +1214,12 @@ extern "C" int zs_max_pool_nhwc(const float *x, float *y, int batch, int Hin, in
                "zs_max_pool_nhwc: bad size");
     if (batch == 0) return 1;
     ZS_REQUIRE(x && y, "zs_max_pool_nhwc: null pointer");
+    const size_t quads = (size_t)batch * Hout * Wout * (C / 4);
+    if ((C & 3) == 0 && quads < (1u << 31)) {
+        hipLaunchKernelGGL(max_pool_quad_kernel, dim3(blocks_for(quads)), dim3(256), 0, S(stream), reinterpret_cast<const f32x4 *>(x),
+                           reinterpret_cast<f32x4 *>(y), (unsigned)quads, Hin, Win, C / 4, Hout, Wout, k, stride, pad_t, pad_l);
+        return zs::check_launch("zs_max_pool_nhwc") ? 1 : 0;
+    }
     hipLaunchKernelGGL(max_pool_kernel, dim3(blocks_for((size_t)batch * Hout * Wout * C)), dim3(256), 0, S(stream), x,
                        y, batch, Hin, Win, C, Hout, Wout, k, stride, pad_t, pad_l);
     return zs::check_launch("zs_max_pool_nhwc") ? 1 : 0;
