@@ -1,5 +1,6 @@
-// 256 x 256 ping-pong tiles for the large pointwise layers (ViT qkv / proj / fc1 / fc2 and the wide 1x1 layers at batch 28).
-// Included by nn_conv.hip inside its anonymous namespace (ConvArgs, dma16, zs_zero_page, activate, the vector types).
+// 256 x 256 ping-pong tiles for the large pointwise layers (ViT qkv / fc1 / fc2 at batch 28, the window stage's layers of the
+// transformer coordinate encoder).  Included by nn_conv.hip inside its anonymous namespace (ConvArgs, dma16, activate4_t, the
+// vector types).  Design notes, the stamp history of the schedule and what was tried and dropped: DESIGN.md section 10.7.
 //
 // Why another GEMM kernel (round 5; profiles/r04_conv_gemm_pmc.txt): the 128 x 128 LDS-DMA kernel moves 16 KiB into LDS per
 // 384 MFMA cycles - 43 B/clk/CU at full matrix rate - through a path that delivered 14 (MFMA pipe 34 % busy), and it
@@ -8,9 +9,10 @@
 //   * a stage is K = 32: an activation row piece is one whole 128-byte line (a DMA instruction = 8 rows x 128 B), the
 //     weights' k-quad rows are 4 KiB runs; two 64 KiB stages, the next one in flight under the current one's 96 MFMAs
 //     per wave (3,072 matrix-pipe cycles per SIMD: longer than a loaded LDS-DMA's issue-to-landed time);
-//   * the two waves of a SIMD run half a K = 16 group apart ("ping-pong"): while waves 0-3 issue their 24 MFMAs of a group,
-//     waves 4-7 read / split the fragments of theirs, and vice versa - four barriers per stage, none drains the DMA
-//     queue (all waits on it are counted and sit a whole stage behind the issue);
+//   * the two waves of a SIMD run a segment apart ("ping-pong"): while one issues the 24 MFMAs of a K = 16 group - with its
+//     DMAs of the next stage between them, in ONE asm statement - the other reads / splits the fragments of its group; two
+//     workgroup barriers per stage, static priority for the group that opens an interval with MFMAs, and no wait on the DMA
+//     queue closer than 1.5 intervals to the issue;
 //   * workgroups are dealt to the XCDs in contiguous runs of tiles (neighbouring tiles share operand panels in ONE L2).
 // Arithmetic per output element: the same three MFMAs per K = 16 group in the same k order as conv_gemm_dma_kernel -
 // whole tiles are bit-identical to that kernel's results.
