@@ -1412,6 +1412,25 @@ __global__ __launch_bounds__(256) void presplit_weight_multi_kernel(const f32x4 
 // out = epilogue(sum over the splits, in split order: deterministic)
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs a) {
     const size_t total = (size_t)a.M * a.Cout;
+    if ((a.Cout & 3) == 0 && total < ((size_t)1 << 32)) {
+        // four channels per lane, 32-bit indices (round 5: the scalar loop below pays a 64-bit modulo per value; 30 launches of it
+        // per batch-28 forward, 34 per batch-1 forward).  Per element the same sums in the same order: the same values
+        const unsigned quads = (unsigned)(total >> 2), cq = (unsigned)a.Cout >> 2;
+        const f32x4 *ws4 = reinterpret_cast<const f32x4 *>(a.ws + WS_COUNTER_FLOATS);
+        for (unsigned o = blockIdx.x * 256 + threadIdx.x; o < quads; o += gridDim.x * 256) {
+            const unsigned n = (o % cq) << 2;
+            f32x4 v = ws4[o];
+            for (int sp = 1; sp < a.splits; sp++) v += ws4[(size_t)sp * quads + o];
+            const f32x4 sc = a.scale ? *reinterpret_cast<const f32x4 *>(a.scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+            const f32x4 sh = a.shift ? *reinterpret_cast<const f32x4 *>(a.shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            v = v * sc + sh;                                  // (one contraction per component, as the scalar form)
+            if (a.res1) v += reinterpret_cast<const f32x4 *>(a.res1)[o];
+            if (a.res2) v += reinterpret_cast<const f32x4 *>(a.res2)[o];
+            activate4(v, a.act);
+            reinterpret_cast<f32x4 *>(a.out)[o] = v;
+        }
+        return;
+    }
     for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
         const int n = (int)(o % a.Cout);
         const float *ws = a.ws + WS_COUNTER_FLOATS;
