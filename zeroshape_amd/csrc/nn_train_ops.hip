@@ -137,20 +137,24 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__res
 
 // ---- LayerNorm backward: wave per row for dx, per-workgroup partial dgamma / dbeta ----
 constexpr int LN_ROWS = 16;      // rows per workgroup (4 per wave): many small workgroups, the rows are latency bound
+constexpr int LN_ROWS_FEW = 4;   // ... one per wave while that still leaves <= 1,024 workgroups (batch 4: 788 token rows on
+                                 // 197 instead of 50 workgroups, 13.9 -> x us per launch)
+static int ln_rows_per_wg(int rows) { return rows <= 1024 * LN_ROWS_FEW ? LN_ROWS_FEW : LN_ROWS; }
 constexpr int LN_MAXQ = 16;      // C <= 64 * LN_MAXQ
 __global__ __launch_bounds__(256) void layer_norm_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                              const float *__restrict__ gamma, float *__restrict__ dx,
-                                                             float *__restrict__ partial, int rows, int C, float eps) {
+                                                             float *__restrict__ partial, int rows, int C, float eps,
+                                                             int per_wg) {
     extern __shared__ float lds[];                      // [4][2][C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float dg[LN_MAXQ], db[LN_MAXQ];
 #pragma unroll
     for (int q = 0; q < LN_MAXQ; q++) dg[q] = db[q] = 0.f;
-    const int r0 = blockIdx.x * LN_ROWS;
+    const int r0 = blockIdx.x * per_wg;
     float gam[LN_MAXQ];
 #pragma unroll
     for (int q = 0; q < LN_MAXQ; q++) gam[q] = lane + 64 * q < C ? gamma[lane + 64 * q] : 0.f;
-    for (int rr = wave; rr < LN_ROWS; rr += 4) {
+    for (int rr = wave; rr < per_wg; rr += 4) {
         const int row = r0 + rr;
         if (row >= rows) break;
         // the row lives in registers (C <= 64 * LN_MAXQ): x and dy are read once
@@ -222,7 +226,7 @@ template <int D>
 __global__ __launch_bounds__(256) void attention_bwd_rows_kernel(const float *__restrict__ qkv,
                                                                  const float *__restrict__ dout,
                                                                  float *__restrict__ Pbuf, float *__restrict__ dSbuf,
-                                                                 int L, int heads, float scale) {
+                                                                 int L, int LS, int heads, float scale) {
     extern __shared__ float lds[];
     constexpr int KS = D + 1;
     float *Ks = lds, *Vs = lds + (size_t)L * KS;
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(256) void attention_bwd_rows_kernel(const float *__
 #pragma unroll
         for (int t = 0; t < ATT_MAXJ; t++) { s[t] /= den; delta += s[t] * dp[t]; }
         delta = wave_sum(delta);
-        float *Prow = Pbuf + ((size_t)bh * L + i) * L, *dSrow = dSbuf + ((size_t)bh * L + i) * L;
+        float *Prow = Pbuf + ((size_t)bh * L + i) * LS, *dSrow = dSbuf + ((size_t)bh * L + i) * LS;
 #pragma unroll
         for (int t = 0; t < ATT_MAXJ; t++) {
             const int j = lane + 64 * t;
@@ -281,14 +285,15 @@ __global__ __launch_bounds__(256) void attention_bwd_rows_kernel(const float *__
 // pass 1 on the MFMA pipe (L <= 256): one wave per (b, h, 32-query tile), transposed like the forward kernel
 // (csrc/nn_ops.hip): S^T[key][query] = K Q^T and dP^T[key][query] = V dO^T for all key tiles stay in the accumulators
 // (2 x 8 tiles x 16 registers), the softmax statistics and delta = sum_j P dP are sums over a lane's registers + its
-// partner half; P and dS = P (dP - delta) leave as float4 row segments.  Replaces attention_bwd_rows_kernel, whose dot
+// partner half; P and dS = P (dP - delta) leave as float4 row segments (rows of LS = L rounded up to 4 floats, so that
+// the segments are aligned; the padding receives zeros).  Replaces attention_bwd_rows_kernel, whose dot
 // products run on the vector ALU with one LDS read per multiply-add (103 us per ViT block at batch 4).
 constexpr int ATT_MFMA_TILES = 8;
 template <int D>
 __global__ __launch_bounds__(64) void attention_bwd_probs_kernel(const float *__restrict__ qkv,
                                                                  const float *__restrict__ dout,
                                                                  float *__restrict__ Pbuf, float *__restrict__ dSbuf,
-                                                                 int L, int heads, float scale) {
+                                                                 int L, int LS, int heads, float scale) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     constexpr int DQ = D / 8;
     const int lane = threadIdx.x, l32 = lane & 31, half = lane >> 5;
@@ -304,25 +309,36 @@ __global__ __launch_bounds__(64) void attention_bwd_probs_kernel(const float *__
     }
     f32x16 sT[ATT_MFMA_TILES], dT[ATT_MFMA_TILES];
     float mx = -INFINITY;
+    // the K / V rows of key tile kt + 1 are requested in front of the 64 MFMAs of tile kt (a lone wave per workgroup)
+    f32x4 kf[DQ], vf[DQ], kn[DQ] = {}, vn[DQ] = {};
+    auto fetch = [&](int kt, f32x4 (&k_)[DQ], f32x4 (&v_)[DQ]) {
+        const float *row = base + (size_t)min(kt * 32 + l32, L - 1) * 3 * C + 4 * half;
+#pragma unroll
+        for (int t = 0; t < DQ; t++) {
+            k_[t] = *reinterpret_cast<const f32x4 *>(row + C + 8 * t);
+            v_[t] = *reinterpret_cast<const f32x4 *>(row + 2 * C + 8 * t);
+        }
+    };
+    fetch(0, kf, vf);
 #pragma unroll
     for (int kt = 0; kt < ATT_MFMA_TILES; kt++) {
 #pragma unroll
         for (int r = 0; r < 16; r++) { sT[kt][r] = -INFINITY; dT[kt][r] = 0.f; }
         if (kt < LT) {
-            const int krow = min(kt * 32 + l32, L - 1);
+            if (kt + 1 < LT) fetch(kt + 1, kn, vn);
             f32x16 a, c;
 #pragma unroll
             for (int r = 0; r < 16; r++) { a[r] = 0.f; c[r] = 0.f; }
 #pragma unroll
             for (int t = 0; t < DQ; t++) {
-                const f32x4 kf = *reinterpret_cast<const f32x4 *>(base + (size_t)krow * 3 * C + C + 4 * (2 * t + half));
-                const f32x4 vf = *reinterpret_cast<const f32x4 *>(base + (size_t)krow * 3 * C + 2 * C + 4 * (2 * t + half));
 #pragma unroll
                 for (int s4 = 0; s4 < 4; s4++) {
-                    a = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s4], qf[t][s4], a, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[s4], gf[t][s4], c, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t][s4], qf[t][s4], a, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[t][s4], gf[t][s4], c, 0, 0, 0);
                 }
             }
+#pragma unroll
+            for (int t = 0; t < DQ; t++) { kf[t] = kn[t]; vf[t] = vn[t]; }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int key = kt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
@@ -353,20 +369,20 @@ __global__ __launch_bounds__(64) void attention_bwd_probs_kernel(const float *__
         }
     delta += __shfl_xor(delta, 32, 64);
     if (q0 + l32 >= L) return;
-    float *Prow = Pbuf + ((size_t)bh * L + q0 + l32) * L, *dSrow = dSbuf + ((size_t)bh * L + q0 + l32) * L;
+    float *Prow = Pbuf + ((size_t)bh * L + q0 + l32) * LS, *dSrow = dSbuf + ((size_t)bh * L + q0 + l32) * LS;
 #pragma unroll
     for (int kt = 0; kt < ATT_MFMA_TILES; kt++)
         if (kt < LT)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int key0 = kt * 32 + 8 * g + 4 * half;
-#pragma unroll
-                for (int e = 0; e < 4; e++)
-                    if (key0 + e < L) {
-                        const float pv = sT[kt][4 * g + e];
-                        Prow[key0 + e] = pv;
-                        dSrow[key0 + e] = pv * (dT[kt][4 * g + e] - delta);
-                    }
+                if (key0 < LS) {          // keys L .. LS - 1: P = exp(-inf) = 0 and dS = 0 * (finite) = 0
+                    const f32x4 pv = {sT[kt][4 * g], sT[kt][4 * g + 1], sT[kt][4 * g + 2], sT[kt][4 * g + 3]};
+                    const f32x4 dv = {dT[kt][4 * g] - delta, dT[kt][4 * g + 1] - delta, dT[kt][4 * g + 2] - delta,
+                                      dT[kt][4 * g + 3] - delta};
+                    *reinterpret_cast<f32x4 *>(Prow + key0) = pv;
+                    *reinterpret_cast<f32x4 *>(dSrow + key0) = pv * dv;
+                }
             }
 }
 
@@ -374,7 +390,7 @@ template <int D>
 __global__ __launch_bounds__(64) void attention_bwd_mfma_kernel(const float *__restrict__ qkv,
                                                                 const float *__restrict__ dout, float *__restrict__ dqkv,
                                                                 const float *__restrict__ Pbuf,
-                                                                const float *__restrict__ dSbuf, int L, int heads,
+                                                                const float *__restrict__ dSbuf, int L, int LS, int heads,
                                                                 float scale) {
     constexpr int DT = D / 32;
     const int lane = threadIdx.x, l32 = lane & 31, half = lane >> 5;
@@ -382,32 +398,39 @@ __global__ __launch_bounds__(64) void attention_bwd_mfma_kernel(const float *__r
     const int LT = (L + 31) / 32;
     const int t = blockIdx.y, which = t / (LT * DT), r0 = ((t / DT) % LT) * 32, d0 = (t % DT) * 32;
     const float *base = qkv + (size_t)b * L * 3 * C + h * D;
-    const float *M = (which == 2 ? Pbuf : dSbuf) + (size_t)bh * L * L;
+    const float *M = (which == 2 ? Pbuf : dSbuf) + (size_t)bh * L * LS;
     // A[m][k]: which 0 (dQ): dS[r0+m][k];  which 1, 2 (dK, dV): dS / P [k][r0+m]   (k = contraction index)
     // B[k][n]: which 0: K[k][d0+n];  which 1: Q[k][d0+n];  which 2: dO[k][d0+n]
     const int m = r0 + l32;
     const bool m_ok = m < L;
-    const size_t a_row = which == 0 ? (size_t)min(m, L - 1) * L : (size_t)min(m, L - 1), a_step = which == 0 ? 1 : L;
+    const size_t a_row = which == 0 ? (size_t)min(m, L - 1) * LS : (size_t)min(m, L - 1), a_step = which == 0 ? 1 : LS;
     const float *Bp = which == 0 ? base + C + d0 + l32 : (which == 1 ? base + d0 + l32 : dout + (size_t)b * L * C + h * D + d0 + l32);
     const size_t b_step = which == 2 ? C : 3 * C;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    // the 16 operand values of the NEXT eight K = 2 steps are requested in front of the MFMAs of the current ones (a lone
+    // wave per workgroup: nothing else hides the loads; 34 -> 2x us per ViT block at batch 4)
     constexpr int U = 8;
-    for (int k0 = 0; k0 < L; k0 += 2 * U) {
-        float av[U], bv[U];
+    float av[U], bv[U], an[U] = {}, bn[U] = {};
+    auto fetch = [&](int k0, float (&a_)[U], float (&b_)[U]) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int k = k0 + 2 * u + half;
-            const bool ok = k < L;
-            const int kc = ok ? k : L - 1;
-            av[u] = M[a_row + (size_t)kc * a_step];
-            bv[u] = Bp[(size_t)kc * b_step];
-            av[u] = (ok && m_ok) ? av[u] : 0.f;
-            bv[u] = ok ? bv[u] : 0.f;
+            const int kc = min(k0 + 2 * u + half, L - 1);
+            a_[u] = M[a_row + (size_t)kc * a_step];
+            b_[u] = Bp[(size_t)kc * b_step];
+        }
+    };
+    fetch(0, av, bv);
+    for (int k0 = 0; k0 < L; k0 += 2 * U) {
+        if (k0 + 2 * U < L) fetch(k0 + 2 * U, an, bn);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bool ok = k0 + 2 * u + half < L;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32((ok && m_ok) ? av[u] : 0.f, ok ? bv[u] : 0.f, acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int u = 0; u < U; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+        for (int u = 0; u < U; u++) { av[u] = an[u]; bv[u] = bn[u]; }
     }
     const float mul = which == 2 ? 1.0f : scale;
     const int col = which == 0 ? 0 : (which == 1 ? C : 2 * C);
@@ -539,7 +562,8 @@ extern "C" int zs_column_sum(const float *x, float *out, int rows, int C, float 
 }
 
 extern "C" size_t zs_layer_norm_bwd_workspace_bytes(int rows, int C) {
-    return (size_t)((rows + LN_ROWS - 1) / LN_ROWS) * 2 * C * sizeof(float);
+    const int per = ln_rows_per_wg(rows);
+    return (size_t)((rows + per - 1) / per) * 2 * C * sizeof(float);
 }
 
 extern "C" int zs_layer_norm_bwd(const float *dy, const float *x, const float *gamma, float *dx, float *dgamma,
@@ -547,10 +571,10 @@ extern "C" int zs_layer_norm_bwd(const float *dy, const float *x, const float *g
     ZS_REQUIRE(rows > 0 && C > 0 && C <= 64 * LN_MAXQ, "zs_layer_norm_bwd: bad size (rows=%d C=%d, C <= %d)", rows, C,
                64 * LN_MAXQ);
     ZS_REQUIRE(dy && x && gamma && dx && dgamma && dbeta && workspace, "zs_layer_norm_bwd: null pointer");
-    const int wgs = (rows + LN_ROWS - 1) / LN_ROWS;
+    const int per = ln_rows_per_wg(rows), wgs = (rows + per - 1) / per;
     float *partial = static_cast<float *>(workspace);
     hipLaunchKernelGGL(layer_norm_bwd_kernel, dim3(wgs), dim3(256), 8 * C * sizeof(float), S(stream), dy, x, gamma, dx,
-                       partial, rows, C, eps);
+                       partial, rows, C, eps, per);
     // partial is [wg][2][C]: rows of stride 2C, dgamma in the first half, dbeta in the second
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, S(stream), partial, dgamma, dbeta,
                        wgs, C, 2 * C, 2 * C, 1.0f);
@@ -558,7 +582,7 @@ extern "C" int zs_layer_norm_bwd(const float *dy, const float *x, const float *g
 }
 
 extern "C" size_t zs_attention_bwd_workspace_bytes(int batch, int L, int heads) {
-    return (size_t)2 * batch * heads * L * L * sizeof(float);
+    return (size_t)2 * batch * heads * L * ((L + 3) & ~3) * sizeof(float);       // P and dS, rows padded to 16 bytes
 }
 
 extern "C" int zs_attention_bwd(const float *qkv, const float *dout, float *dqkv, void *workspace, int batch, int L,
@@ -570,7 +594,9 @@ extern "C" int zs_attention_bwd(const float *qkv, const float *dout, float *dqkv
     ZS_REQUIRE(qkv && dout && dqkv && workspace, "zs_attention_bwd: null pointer");
     const float scale = 1.0f / sqrtf((float)head_dim);
     const int BH = batch * heads;
-    float *P = static_cast<float *>(workspace), *dS = P + (size_t)BH * L * L;
+    const int LS = (L + 3) & ~3;
+    ZS_REQUIRE((reinterpret_cast<size_t>(workspace) & 15) == 0, "zs_attention_bwd: workspace must be 16-byte aligned");
+    float *P = static_cast<float *>(workspace), *dS = P + (size_t)BH * L * LS;
     const dim3 grid1(BH, (L + ATT_ROWS - 1) / ATT_ROWS), grid2(BH, 3 * ((L + 31) / 32) * (head_dim / 32));
     const size_t lds = (size_t)2 * L * (head_dim + 1) * sizeof(float);
     ZS_REQUIRE(lds <= 160 * 1024, "zs_attention_bwd: L = %d needs %zu bytes of LDS", L, lds);
@@ -586,24 +612,24 @@ extern "C" int zs_attention_bwd(const float *qkv, const float *dout, float *dqkv
     if (L <= 32 * ATT_MFMA_TILES && !rows_valu) {
         const dim3 gridp(BH, (L + 31) / 32);
         if (head_dim == 64)
-            hipLaunchKernelGGL(attention_bwd_probs_kernel<64>, gridp, dim3(64), 0, S(stream), qkv, dout, P, dS, L, heads, scale);
+            hipLaunchKernelGGL(attention_bwd_probs_kernel<64>, gridp, dim3(64), 0, S(stream), qkv, dout, P, dS, L, LS, heads, scale);
         else
-            hipLaunchKernelGGL(attention_bwd_probs_kernel<32>, gridp, dim3(64), 0, S(stream), qkv, dout, P, dS, L, heads, scale);
+            hipLaunchKernelGGL(attention_bwd_probs_kernel<32>, gridp, dim3(64), 0, S(stream), qkv, dout, P, dS, L, LS, heads, scale);
         if (head_dim == 64)
-            hipLaunchKernelGGL(attention_bwd_mfma_kernel<64>, grid2, dim3(64), 0, S(stream), qkv, dout, dqkv, P, dS, L, heads,
+            hipLaunchKernelGGL(attention_bwd_mfma_kernel<64>, grid2, dim3(64), 0, S(stream), qkv, dout, dqkv, P, dS, L, LS, heads,
                                scale);
         else
-            hipLaunchKernelGGL(attention_bwd_mfma_kernel<32>, grid2, dim3(64), 0, S(stream), qkv, dout, dqkv, P, dS, L, heads,
+            hipLaunchKernelGGL(attention_bwd_mfma_kernel<32>, grid2, dim3(64), 0, S(stream), qkv, dout, dqkv, P, dS, L, LS, heads,
                                scale);
         return zs::check_launch("zs_attention_bwd") ? 1 : 0;
     }
     if (head_dim == 64) {
-        hipLaunchKernelGGL(attention_bwd_rows_kernel<64>, grid1, dim3(256), lds, S(stream), qkv, dout, P, dS, L, heads, scale);
-        hipLaunchKernelGGL(attention_bwd_mfma_kernel<64>, grid2, dim3(64), 0, S(stream), qkv, dout, dqkv, P, dS, L, heads,
+        hipLaunchKernelGGL(attention_bwd_rows_kernel<64>, grid1, dim3(256), lds, S(stream), qkv, dout, P, dS, L, LS, heads, scale);
+        hipLaunchKernelGGL(attention_bwd_mfma_kernel<64>, grid2, dim3(64), 0, S(stream), qkv, dout, dqkv, P, dS, L, LS, heads,
                            scale);
     } else {
-        hipLaunchKernelGGL(attention_bwd_rows_kernel<32>, grid1, dim3(256), lds, S(stream), qkv, dout, P, dS, L, heads, scale);
-        hipLaunchKernelGGL(attention_bwd_mfma_kernel<32>, grid2, dim3(64), 0, S(stream), qkv, dout, dqkv, P, dS, L, heads,
+        hipLaunchKernelGGL(attention_bwd_rows_kernel<32>, grid1, dim3(256), lds, S(stream), qkv, dout, P, dS, L, LS, heads, scale);
+        hipLaunchKernelGGL(attention_bwd_mfma_kernel<32>, grid2, dim3(64), 0, S(stream), qkv, dout, dqkv, P, dS, L, LS, heads,
                            scale);
     }
     return zs::check_launch("zs_attention_bwd") ? 1 : 0;

@@ -307,19 +307,20 @@ __global__ __launch_bounds__(256) void point_attention_bwd_kernel(const float *_
 // ---- the backward on the MFMA pipe --------------------------------------------------------------------------- //
 // pass 1, one wave per (b, h, 32 points), transposed like the forward kernel: S^T = K_l Q^T and dP^T = V_l dO^T of
 // all latent tiles stay in the accumulators; with the point's own logit and dO . v_self they give the probabilities,
-// delta = sum P dP and dS = P (dP - delta).  Written: dS^T [BH][Ll][M] (the accumulator layout IS the transposed one -
-// consecutive lanes are consecutive points), dS and P as rows [BH][M][Ll], and the self parts of the point gradients
-// (dq += scale ds_self k_self, dk_self = scale ds_self q, dv_self = p_self dO).  Pass 2 reads each product's A
-// operand from the copy in which the 32 rows of its tile are adjacent (dq: points -> dS^T; dK_l / dV_l: latents ->
-// the row copies), so a wave's loads are whole lines.
-// pass 2, one wave per 32 x 32 output tile: dq = scale dS K_l (added to the self part), dK_l = scale dS^T Q and
-// dV_l = P^T dO over chunks of PA2_CHUNK points -> partial tiles, summed in chunk order by point_attention_reduce_kernel.
+// delta = sum P dP and dS = P (dP - delta).  dS^T in the accumulators IS the B operand of dq^T = K_l^T dS^T (the forward
+// kernel's O^T = V^T P^T again: step r pairs key(r, half) on both operands), so dq = scale (dS K_l + ds_self k_self) is
+// finished here - no dS^T copy in memory (103 MB per call at 4 x 4,096 points, written dword-wise and read back), no
+// read-modify-write of dq in pass 2.  Written: dS and P as rows [BH][M][LS] and the point gradients (dq, dk_self = scale
+// ds_self q, dv_self = p_self dO).
+// pass 2, one wave per 32 x 32 output tile: dK_l = scale dS^T Q and dV_l = P^T dO over chunks of PA2_CHUNK points ->
+// partial tiles, summed in chunk order by point_attention_reduce_kernel.
 constexpr int PA2_TILES = 8;          // Ll <= 256
 constexpr int PA2_CHUNK = 512;        // points per dK_l / dV_l partial
 __global__ __launch_bounds__(64) void point_attention_bwd_probs_kernel(
     const float *__restrict__ qkv_p, const float *__restrict__ qkv_l, const float *__restrict__ dout,
-    float *__restrict__ dqkv_p, float *__restrict__ dSbuf, float *__restrict__ dSTbuf, float *__restrict__ Pbuf, int M,
-    int Ll, int heads, float scale) {
+    float *__restrict__ dqkv_p, float *__restrict__ dSbuf, float *__restrict__ Pbuf, int M, int Ll, int LS, int heads,
+    float scale) {
+    static_assert(D == 32, "dq^T is one 32-row MFMA tile");
     constexpr int DQ = D / 8;
     const int lane = threadIdx.x, l32 = lane & 31, half = lane >> 5;
     const int bh = blockIdx.x, b = bh / heads, h = bh % heads, C = heads * D, p0 = blockIdx.y * 32;
@@ -344,25 +345,36 @@ __global__ __launch_bounds__(64) void point_attention_bwd_probs_kernel(
     dp_self += __shfl_xor(dp_self, 32, 64);
     f32x16v sT[PA2_TILES], dT[PA2_TILES];
     float mx = s_self;
+    // a lone wave per SIMD: the K_l / V_l rows of latent tile kt + 1 are requested in front of the MFMAs of tile kt
+    f32x4v kf[DQ], vf[DQ], kn[DQ] = {}, vn[DQ] = {};
+    auto fetch = [&](int kt, f32x4v (&k_)[DQ], f32x4v (&v_)[DQ]) {
+        const float *row = lbase + (size_t)min(kt * 32 + l32, Ll - 1) * 3 * C + 4 * half;
+#pragma unroll
+        for (int t = 0; t < DQ; t++) {
+            k_[t] = *reinterpret_cast<const f32x4v *>(row + C + 8 * t);
+            v_[t] = *reinterpret_cast<const f32x4v *>(row + 2 * C + 8 * t);
+        }
+    };
+    fetch(0, kf, vf);
 #pragma unroll
     for (int kt = 0; kt < PA2_TILES; kt++) {
 #pragma unroll
         for (int r = 0; r < 16; r++) { sT[kt][r] = -INFINITY; dT[kt][r] = 0.f; }
         if (kt < LT) {
-            const int krow = min(kt * 32 + l32, Ll - 1);
+            if (kt + 1 < LT) fetch(kt + 1, kn, vn);
             f32x16v a, c;
 #pragma unroll
             for (int r = 0; r < 16; r++) { a[r] = 0.f; c[r] = 0.f; }
 #pragma unroll
             for (int t = 0; t < DQ; t++) {
-                const f32x4v kf = *reinterpret_cast<const f32x4v *>(lbase + (size_t)krow * 3 * C + C + 4 * (2 * t + half));
-                const f32x4v vf = *reinterpret_cast<const f32x4v *>(lbase + (size_t)krow * 3 * C + 2 * C + 4 * (2 * t + half));
 #pragma unroll
                 for (int s4 = 0; s4 < 4; s4++) {
-                    a = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s4], qf[t][s4], a, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[s4], gf[t][s4], c, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t][s4], qf[t][s4], a, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[t][s4], gf[t][s4], c, 0, 0, 0);
                 }
             }
+#pragma unroll
+            for (int t = 0; t < DQ; t++) { kf[t] = kn[t]; vf[t] = vn[t]; }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int key = kt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
@@ -398,92 +410,99 @@ __global__ __launch_bounds__(64) void point_attention_bwd_probs_kernel(
     delta += p_self * dp_self;
     const float ds_self = p_self * (dp_self - delta);
     const bool live = p0 + l32 < M;
+    // dS^T = P (dP - delta) replaces dP^T in its registers; dq^T[d][point] += K_l[key][d] dS^T[key][point]
+    f32x16v dq;
+#pragma unroll
+    for (int r = 0; r < 16; r++) dq[r] = 0.f;
+    float kv[16], kvn[16] = {};
+    auto fetch_k = [&](int kt, float (&k_)[16]) {
+#pragma unroll
+        for (int r = 0; r < 16; r++)           // padded keys re-read the last row: their dS is 0
+            k_[r] = lbase[(size_t)min(kt * 32 + 8 * (r >> 2) + 4 * half + (r & 3), Ll - 1) * 3 * C + C + l32];
+    };
+    fetch_k(0, kv);
+#pragma unroll
+    for (int kt = 0; kt < PA2_TILES; kt++)
+        if (kt < LT) {
+            if (kt + 1 < LT) fetch_k(kt + 1, kvn);
+#pragma unroll
+            for (int r = 0; r < 16; r++) dT[kt][r] = sT[kt][r] * (dT[kt][r] - delta);
+#pragma unroll
+            for (int r = 0; r < 16; r++) dq = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[r], dT[kt][r], dq, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; r++) kv[r] = kvn[r];
+        }
     if (live) {
         float *o = dqkv_p + ((size_t)b * M + p0 + l32) * 3 * C + h * D;
 #pragma unroll
         for (int t = 0; t < DQ; t++) {
-            *reinterpret_cast<f32x4v *>(o + 4 * (2 * t + half)) = ksf[t] * (scale * ds_self);
+            const f32x4v dqt = {dq[4 * t], dq[4 * t + 1], dq[4 * t + 2], dq[4 * t + 3]};    // d = 8 t + 4 half + e
+            *reinterpret_cast<f32x4v *>(o + 4 * (2 * t + half)) = (ksf[t] * ds_self + dqt) * scale;
             *reinterpret_cast<f32x4v *>(o + C + 4 * (2 * t + half)) = qr[t] * (scale * ds_self);
             *reinterpret_cast<f32x4v *>(o + 2 * C + 4 * (2 * t + half)) = gf[t] * p_self;
         }
     }
-    float *dSrow = dSbuf + ((size_t)bh * M + min(p0 + l32, M - 1)) * Ll;
-    float *Prow = Pbuf + ((size_t)bh * M + min(p0 + l32, M - 1)) * Ll;
+    // rows of LS = Ll rounded up to 4 floats: a lane's four consecutive keys leave as ONE aligned 16-byte store (the padding
+    // receives P = exp(-inf) = 0 and dS = 0).  Per-key dword stores to 64 different rows per instruction ran this kernel at
+    // 1.3 TB/s (240 us per call at 4 x 4,096 points; tools/ubench/store_rate.hip: dword stores are 4x slower)
+    float *dSrow = dSbuf + ((size_t)bh * M + min(p0 + l32, M - 1)) * LS;
+    float *Prow = Pbuf + ((size_t)bh * M + min(p0 + l32, M - 1)) * LS;
 #pragma unroll
     for (int kt = 0; kt < PA2_TILES; kt++)
         if (kt < LT)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int key = kt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-                if (key < Ll && live) {
-                    const float pv = sT[kt][r], ds = pv * (dT[kt][r] - delta);
-                    dSrow[key] = ds;
-                    Prow[key] = pv;
-                    dSTbuf[((size_t)bh * Ll + key) * M + p0 + l32] = ds;
+            for (int g = 0; g < 4; g++) {
+                const int key0 = kt * 32 + 8 * g + 4 * half;
+                const f32x4v pv = {sT[kt][4 * g], sT[kt][4 * g + 1], sT[kt][4 * g + 2], sT[kt][4 * g + 3]};
+                const f32x4v ds = {dT[kt][4 * g], dT[kt][4 * g + 1], dT[kt][4 * g + 2], dT[kt][4 * g + 3]};
+                if (live && key0 < LS) {
+                    *reinterpret_cast<f32x4v *>(dSrow + key0) = ds;
+                    *reinterpret_cast<f32x4v *>(Prow + key0) = pv;
                 }
             }
 }
 
-// which 0: dq tile (32 points);  which 1 / 2: a dK_l / dV_l partial (32 latents x one chunk of points)
+// which 1 / 2: a dK_l / dV_l partial (32 latents x one chunk of points)
 __global__ __launch_bounds__(64) void point_attention_bwd_gemm_kernel(
-    const float *__restrict__ qkv_p, const float *__restrict__ qkv_l, const float *__restrict__ dout,
-    float *__restrict__ dqkv_p, float *__restrict__ partial, const float *__restrict__ dSbuf,
-    const float *__restrict__ dSTbuf, const float *__restrict__ Pbuf, int M, int Ll, int heads, float scale, int MT,
-    int LT, int MS) {
+    const float *__restrict__ qkv_p, const float *__restrict__ dout, float *__restrict__ partial,
+    const float *__restrict__ dSbuf, const float *__restrict__ Pbuf, int M, int Ll, int LS, int heads, float scale, int LT,
+    int MS) {
     const int lane = threadIdx.x, l32 = lane & 31, half = lane >> 5;
     const int bh = blockIdx.x, b = bh / heads, h = bh % heads, C = heads * D;
-    int t = blockIdx.y, which, r0, ms = 0;
-    if (t < MT) { which = 0; r0 = t * 32; }
-    else { t -= MT; which = 1 + t / (LT * MS); t %= LT * MS; r0 = (t / MS) * 32; ms = t % MS; }
+    int t = blockIdx.y;
+    const int which = 1 + t / (LT * MS);
+    t %= LT * MS;
+    const int r0 = (t / MS) * 32, ms = t % MS;
     f32x16v acc;
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
     const int m = r0 + l32;                                    // this lane's A row
     constexpr int U = 8;
-    if (which == 0) {
-        const bool m_ok = m < M;
-        const float *A = dSTbuf + (size_t)bh * Ll * M + min(m, M - 1);           // A[m = point][k = latent] = dS^T[k][m]
-        const float *Bp = qkv_l + (size_t)b * Ll * 3 * C + C + h * D + l32;
-        for (int k0 = 0; k0 < Ll; k0 += 2 * U) {
-            float av[U], bv[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int k = k0 + 2 * u + half;
-                const bool ok = k < Ll;
-                const int kc = ok ? k : Ll - 1;
-                av[u] = (ok && m_ok) ? A[(size_t)kc * M] : 0.f;
-                bv[u] = ok ? Bp[(size_t)kc * 3 * C] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = r0 + 8 * (r >> 2) + 4 * half + (r & 3);
-            if (row < M) {
-                float *o = dqkv_p + ((size_t)b * M + row) * 3 * C + h * D + l32;
-                *o = *o + scale * acc[r];                      // the self part is already there (pass 1)
-            }
-        }
-        return;
-    }
+    // the operands of the next eight K = 2 steps are requested in front of the MFMAs of the current ones
     const bool m_ok = m < Ll;
-    const float *A = (which == 1 ? dSbuf : Pbuf) + (size_t)bh * M * Ll + min(m, Ll - 1);   // A[m = latent][k = point]
+    const float *A = (which == 1 ? dSbuf : Pbuf) + (size_t)bh * M * LS + min(m, Ll - 1);   // A[m = latent][k = point]
     const float *Bp = which == 1 ? qkv_p + (size_t)b * M * 3 * C + h * D + l32 : dout + (size_t)b * M * C + h * D + l32;
     const size_t b_step = which == 1 ? 3 * C : C;
     const int k_end = min(M, (ms + 1) * PA2_CHUNK);
-    for (int k0 = ms * PA2_CHUNK; k0 < k_end; k0 += 2 * U) {
-        float av[U], bv[U];
+    float av[U], bv[U], an[U] = {}, bn[U] = {};
+    auto fetch = [&](int k0, float (&a_)[U], float (&b_)[U]) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int k = k0 + 2 * u + half;
-            const bool ok = k < k_end;
-            const int kc = ok ? k : k_end - 1;
-            av[u] = (ok && m_ok) ? A[(size_t)kc * Ll] : 0.f;
-            bv[u] = ok ? Bp[(size_t)kc * b_step] : 0.f;
+            const int kc = min(k0 + 2 * u + half, k_end - 1);
+            a_[u] = A[(size_t)kc * LS];
+            b_[u] = Bp[(size_t)kc * b_step];
+        }
+    };
+    fetch(ms * PA2_CHUNK, av, bv);
+    for (int k0 = ms * PA2_CHUNK; k0 < k_end; k0 += 2 * U) {
+        if (k0 + 2 * U < k_end) fetch(k0 + 2 * U, an, bn);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bool ok = k0 + 2 * u + half < k_end;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32((ok && m_ok) ? av[u] : 0.f, ok ? bv[u] : 0.f, acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int u = 0; u < U; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+        for (int u = 0; u < U; u++) { av[u] = an[u]; bv[u] = bn[u]; }
     }
     float *dst = partial + (((size_t)ms * gridDim.x + bh) * 2 + (which - 1)) * Ll * D;
     const float mul = which == 1 ? scale : 1.0f;
@@ -654,8 +673,8 @@ static size_t pa_partial_floats(int batch, int M, int Ll, int heads) {
     return (size_t)(tiles > chunks ? tiles : chunks) * batch * heads * 2 * Ll * D;
 }
 extern "C" size_t zs_point_attention_bwd_workspace_bytes(int batch, int M, int Ll, int heads) {
-    // [partial tiles of dK_l / dV_l][dS rows][dS^T][P^T]
-    return (pa_partial_floats(batch, M, Ll, heads) + (size_t)3 * batch * heads * M * Ll) * sizeof(float);
+    // [partial tiles of dK_l / dV_l][dS rows][P rows]; the rows are padded to 16 bytes
+    return (pa_partial_floats(batch, M, Ll, heads) + (size_t)batch * heads * M * 2 * ((Ll + 3) & ~3)) * sizeof(float);
 }
 
 extern "C" int zs_point_attention_bwd(const float *qkv_points, const float *qkv_latent, const float *dout,
@@ -670,14 +689,15 @@ extern "C" int zs_point_attention_bwd(const float *qkv_points, const float *qkv_
     float *partial = static_cast<float *>(workspace);
     static const bool bwd_valu = getenv("ZS_POINT_ATTN_VALU") != nullptr;    // A/B switch: the vector-ALU kernel
     const int MT = (M + 31) / 32, LT = (Ll + 31) / 32, MS = (M + PA2_CHUNK - 1) / PA2_CHUNK;
-    if (!bwd_valu && LT <= PA2_TILES && MT + 2 * LT * MS <= 65535) {
+    if (!bwd_valu && LT <= PA2_TILES && MT <= 65535 && 2 * LT * MS <= 65535) {
         const float scale = 1.0f / sqrtf((float)head_dim);
-        float *dS = partial + pa_partial_floats(batch, M, Ll, heads), *dST = dS + (size_t)BH * M * Ll,
-              *PTb = dST + (size_t)BH * M * Ll;
+        const int LS = (Ll + 3) & ~3;
+        ZS_REQUIRE((reinterpret_cast<size_t>(workspace) & 15) == 0, "zs_point_attention_bwd: workspace must be 16-byte aligned");
+        float *dS = partial + pa_partial_floats(batch, M, Ll, heads), *PTb = dS + (size_t)BH * M * LS;
         hipLaunchKernelGGL(point_attention_bwd_probs_kernel, dim3(BH, MT), dim3(64), 0, S(stream), qkv_points, qkv_latent,
-                           dout, dqkv_points, dS, dST, PTb, M, Ll, heads, scale);
-        hipLaunchKernelGGL(point_attention_bwd_gemm_kernel, dim3(BH, MT + 2 * LT * MS), dim3(64), 0, S(stream), qkv_points,
-                           qkv_latent, dout, dqkv_points, partial, dS, dST, PTb, M, Ll, heads, scale, MT, LT, MS);
+                           dout, dqkv_points, dS, PTb, M, Ll, LS, heads, scale);
+        hipLaunchKernelGGL(point_attention_bwd_gemm_kernel, dim3(BH, 2 * LT * MS), dim3(64), 0, S(stream), qkv_points, dout,
+                           partial, dS, PTb, M, Ll, LS, heads, scale, LT, MS);
         if (!zs::check_launch("zs_point_attention_bwd")) return 0;
         hipLaunchKernelGGL(point_attention_reduce_kernel, dim3(blocks_for((size_t)BH * 3 * Ll * D)), dim3(256), 0, S(stream),
                            partial, dqkv_latent, MS, BH, Ll, heads, accumulate_latent ? 1 : 0);

@@ -609,6 +609,9 @@ def layer_norm(x, gamma, beta, eps=1e-6):
     return _LayerNorm.apply(x, gamma, beta, eps)
 
 
+ATT_FWD_SPLIT = os.environ.get("ZS_TRAIN_ATT_SPLIT", "1") != "0"      # A/B switch
+
+
 class _Attention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, heads):
@@ -617,9 +620,13 @@ class _Attention(torch.autograd.Function):
         B, L, C3 = qkv.shape
         C = C3 // 3
         out = torch.empty(B, L, C, dtype=torch.float32, device=qkv.device)
+        # optim.amp: the split-fp16 forms, like the forward GEMMs around it (batch 4 = 48 (sample, head) pairs: the key-split
+        # kernel, 25 -> 9 us per ViT block); the backward pass recomputes the probabilities in fp32 either way
+        split = FWD_CONV_PRECISION == "f16x3" and ATT_FWD_SPLIT
         with _lib.on(qkv.device):
-            _lib.check(lib.zs_attention(_lib.ptr(qkv), _lib.ptr(out), B, L, heads, C // heads, _stream(qkv)),
-                       "zs_attention")
+            _lib.check((lib.zs_attention_split if split else lib.zs_attention)(
+                _lib.ptr(qkv), _lib.ptr(out), B, L, heads, C // heads, _stream(qkv)),
+                "zs_attention_split" if split else "zs_attention")
         ctx.heads = heads
         ctx.save_for_backward(qkv)
         return out
