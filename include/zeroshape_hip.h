@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 33
+#define ZS_ABI_VERSION 34
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -631,6 +631,15 @@ int zs_pack_chunk_elems(void);
 int zs_pack_entry_chunks(int Cout, int Cin, int taps, int dgrad, int K16, int NPad);
 int zs_pack_conv_weight_multi(const zs_pack_entry *table, const int *chunk_entry, const unsigned long long *chunk_start,
                               int n_chunks, void *stream);
+/* The same launch also writing the fp16 halves of the operands (the layout of zs_conv2d_presplit_weight) from the tiles it
+ * holds: split_dst[e] = the split buffer of entry e (K16 * NPad floats) or NULL; non-NULL only for entries for which
+ * zs_pack_entry_inline_split(Cout, Cin, taps, dgrad) returns 1 (kernels up to 3x3 whose K-side channel count, rounded up
+ * to 4, is a multiple of 16).  split_only != 0: the fp32 operand (entry.dst) of those entries is NOT rewritten - for
+ * callers whose every consumer reads the halves (optim.amp: one pass over the weights instead of re-pack + split). */
+int zs_pack_entry_inline_split(int Cout, int Cin, int taps, int dgrad);
+int zs_pack_conv_weight_multi_split(const zs_pack_entry *table, const int *chunk_entry,
+                                    const unsigned long long *chunk_start, int n_chunks, float *const *split_dst,
+                                    int split_only, void *stream);
 size_t zs_conv2d_wgrad_workspace_bytes(int batch, int Hout, int Wout, int Cin, int Cout, int kh, int kw);
 int zs_conv2d_wgrad(const float *in, const float *dy, float *dw, float *db, void *workspace, int batch, int Hin, int Win,
                     int CinP, int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad_t, int pad_l,

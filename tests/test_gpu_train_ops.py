@@ -401,6 +401,73 @@ def test_repack_of_all_operands_in_one_launch_equals_the_single_packs():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fwd,bwd", [("f16x3", "f16x3"), ("f16x3", "f32")])
+def test_repack_writes_the_fp16_halves_itself(fwd, bwd, monkeypatch):
+    """optim.amp: zs_pack_conv_weight_multi_split writes the halves of every operand whose tiles hold whole K = 16 groups in
+    the launch that re-packs them - bit for bit what zs_conv2d_presplit_weight makes of the single pack - and, when forward
+    AND data gradients read the halves, leaves the fp32 operand of those entries alone; the others (3-channel stem, ragged
+    channel counts, 7x7) are split by the launch behind it as before."""
+    from zeroshape_amd import _lib
+    from zeroshape_amd.nn import autograd as A
+    A.clear_pack_cache()
+    A.set_forward_precision(fwd)
+    A.set_backward_precision(bwd)
+    try:
+        assert A._inline_split_mode() == (2 if bwd == "f16x3" else 1)
+        g = torch.Generator().manual_seed(6)
+        shapes = [(3072, 768, 1, 1), (768, 3072, 1, 1), (256, 256, 3, 3), (64, 3, 7, 7), (10, 6, 3, 3), (130, 70, 1, 1),
+                  (32, 128, 3, 3), (48, 32, 1, 1), (96, 64, 2, 2)]
+        weights = [torch.nn.Parameter(torch.randn(s, generator=g).cuda()) for s in shapes]
+        keys = [(w, 0, w.shape[1], d) for w in weights for d in (False, True)]
+        keys += [(weights[2], 64, 128, False), (weights[2], 64, 128, True)]
+        first = [A._pack(w, c0, c, d).clone() for w, c0, c, d in keys]
+        with torch.no_grad():
+            for w in weights:
+                w.copy_(torch.randn(w.shape, generator=g).cuda())
+        A.bump_generation()
+        A._pack(*keys[0])                       # re-packs (and splits) every stale operand
+        lib = _lib.load()
+        inline = 0
+        for (w, c0, c, d), old in zip(keys, first):
+            packed = A._pack(w, c0, c, d)
+            rec = A._rec_of(packed)
+            kh, kw = w.shape[2], w.shape[3]
+            want, want_split = torch.empty_like(packed), torch.empty_like(packed)
+            cout, cin = (c, w.shape[0]) if d else (w.shape[0], c)      # the operand's N and K-side channel counts
+            with torch.cuda.device(w.device):
+                st = _lib.current_stream_ptr(w.device)
+                _lib.check(lib.zs_pack_conv_weight(_lib.ptr(w.detach()), _lib.ptr(want), w.shape[0], c, c0, w.shape[1], kh, kw,
+                                                   1 if d else 0, st), "zs_pack_conv_weight")
+                _lib.check(lib.zs_conv2d_presplit_weight(_lib.ptr(want), _lib.ptr(want_split), (cin + 3) // 4 * 4, cout, kh, kw,
+                                                         st), "zs_conv2d_presplit_weight")
+            assert A._split_of(packed) is not None, (tuple(w.shape), c0, c, d)
+            assert torch.equal(A._split_of(packed).view(torch.int32), want_split.view(torch.int32)), (tuple(w.shape), c0, c, d)
+            eligible = bool(lib.zs_pack_entry_inline_split(w.shape[0], c, kh * kw, 1 if d else 0))
+            assert rec.inline_split == eligible
+            inline += eligible
+            if eligible and bwd == "f16x3":
+                assert torch.equal(packed, old), "split_only rewrote the fp32 operand"
+            else:
+                assert torch.equal(packed, want), (tuple(w.shape), c0, c, d)
+        assert inline >= 10
+        # back to fp32: the generation moves, every fp32 operand is current again before anything reads it
+        A.set_forward_precision("f32")
+        A.set_backward_precision("f32")
+        for (w, c0, c, d) in keys[:6]:
+            packed = A._pack(w, c0, c, d)
+            want = torch.empty_like(packed)
+            with torch.cuda.device(w.device):
+                _lib.check(lib.zs_pack_conv_weight(_lib.ptr(w.detach()), _lib.ptr(want), w.shape[0], c, c0, w.shape[1],
+                                                   w.shape[2], w.shape[3], 1 if d else 0, _lib.current_stream_ptr(w.device)),
+                           "zs_pack_conv_weight")
+            assert torch.equal(packed, want)
+    finally:
+        A.set_forward_precision("f32")
+        A.set_backward_precision("f32")
+        A.clear_pack_cache()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("presplit_all", [False, True])
 def test_split_operand_follows_in_place_weight_updates(presplit_all, monkeypatch):
     """the fp16 halves of a packed operand (optim.amp forward) were cached by packed.data_ptr() + generation, so a

@@ -144,6 +144,8 @@ SIGNATURES = {
     "zs_pack_chunk_elems": (_c_int, []),
     "zs_pack_entry_chunks": (_c_int, [_c_int] * 6),
     "zs_pack_conv_weight_multi": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p]),
+    "zs_pack_entry_inline_split": (_c_int, [_c_int] * 4),
+    "zs_pack_conv_weight_multi_split": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p]),
     "zs_conv2d_wgrad_workspace_bytes": (_c_size_t, [_c_int] * 7),
     "zs_conv2d_wgrad": (_c_int, [_c_void_p] * 5 + [_c_int] * 13 + [_c_float, _c_float] + [_c_int] * 4 + [_c_void_p]),
     "zs_conv2d_dgrad_small_cin": (_c_int, [_c_void_p] * 3 + [_c_int] * 15 + [_c_float, _c_void_p]),
@@ -196,7 +198,7 @@ SIGNATURES = {
     "zs_readout_concat_bwd": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
 }
 
-ABI_VERSION = 33
+ABI_VERSION = 34
 _lib = None
 
 

@@ -74,11 +74,23 @@ constexpr int PACK_LDS_FLOATS = 64 * 145;  // >= 64 x (16*9 | 1), 16 x 64*9, 64 
 // (k-group, n) cells that are contiguous over n (1 KB runs).  Reading the source cell by cell instead made every
 // 64-byte line travel to four (pointwise) or nine (3x3) workgroups on different XCDs.
 // The K padding rows of the operand (k >= taps * Kc) are written once by zs_pack_conv_weight and never change.
+// split_dst (optional, one pointer per entry, NULL entries allowed): the operand's fp16 halves in the layout of
+// zs_conv2d_presplit_weight, written from the same LDS tile - for entries pack_inline_split() accepts (tile path, K side a
+// multiple of 16 channels: a tile then holds whole K = 16 groups, k-quads 4 s + q and 4 s + q + 2 meet in one thread).  With
+// split_only the fp32 operand of such an entry is not written at all (optim.amp: every consumer reads the halves) - the
+// re-pack + split of 191 M parameters moved 6.1 GB per optimiser step in two launches, this way 3.1 GB in one.
+static bool pack_inline_split(int Cout, int Cin, int taps, int dgrad) {
+    const int Kc = ((dgrad ? Cout : Cin) + 3) / 4 * 4;
+    return taps <= PACK_TILE_TAPS && Kc % 16 == 0;
+}
 __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackEntry *__restrict__ tab,
                                                                 const int *__restrict__ chunk_entry,
-                                                                const unsigned long long *__restrict__ chunk_start) {
+                                                                const unsigned long long *__restrict__ chunk_start,
+                                                                float *const *__restrict__ split_dst, int split_only) {
     extern __shared__ __attribute__((aligned(16))) float plds[];
-    const PackEntry t = tab[chunk_entry[blockIdx.x]];
+    const int entry = chunk_entry[blockIdx.x];
+    const PackEntry t = tab[entry];
+    float *const sp = split_dst ? split_dst[entry] : nullptr;      // (host: non-NULL only for pack_inline_split entries)
     const int CinP = (t.Cin + 3) & ~3, CoutP = (t.Cout + 3) & ~3;
     const unsigned ord = (unsigned)chunk_start[blockIdx.x];
     if (t.taps > PACK_TILE_TAPS) {
@@ -129,6 +141,26 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackEntry 
             }
         }
         __syncthreads();
+        if (sp) {           // pairs of k-quads (cq, cq + 2), cq % 4 < 2: one K = 16 step's lane half
+            for (int idx = threadIdx.x; idx < cells / 2; idx += 256) {
+                const int nl = idx & (PACK_ROWS - 1), q = idx >> 6, pq = q % (quads / 2), tap = q / (quads / 2);
+                const int cq = (pq >> 1) * 4 + (pq & 1), c = c0 + 4 * cq;
+                if (c >= CinP) continue;
+                const float *cell = plds + nl * stride + 4 * cq * taps + tap;
+                const f32x4 v0 = {cell[0], cell[taps], cell[2 * taps], cell[3 * taps]};
+                const f32x4 v1 = {cell[8 * taps], cell[9 * taps], cell[10 * taps], cell[11 * taps]};
+                const size_t o = ((size_t)(tap * (CinP / 4) + c / 4) * t.NPad + n0 + nl) * 4, o2 = o + (size_t)2 * t.NPad * 4;
+                zs::s16::u32x4 hi, lo;
+                zs::s16::split8(v0, v1, hi, lo);
+                *reinterpret_cast<f32x4 *>(sp + o) = __builtin_bit_cast(f32x4, hi);
+                *reinterpret_cast<f32x4 *>(sp + o2) = __builtin_bit_cast(f32x4, lo);
+                if (!split_only) {
+                    *reinterpret_cast<f32x4 *>(t.dst + o) = v0;
+                    *reinterpret_cast<f32x4 *>(t.dst + o2) = v1;
+                }
+            }
+            return;
+        }
         for (int idx = threadIdx.x; idx < cells; idx += 256) {
             const int nl = idx & (PACK_ROWS - 1), q = idx >> 6, cq = q % quads, tap = q / quads, c = c0 + 4 * cq;
             if (c >= CinP) continue;
@@ -154,6 +186,26 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackEntry 
             }
         }
         __syncthreads();
+        if (sp) {
+            for (int idx = threadIdx.x; idx < cells / 2; idx += 256) {
+                const int nl = idx & (PACK_ROWS - 1), q = idx >> 6, pq = q % (quads / 2), tap = q / (quads / 2);
+                const int cq = (pq >> 1) * 4 + (pq & 1), co = c0 + 4 * cq;
+                if (co >= CoutP) continue;
+                const float *cell = plds + 4 * cq * span + nl * taps + (taps - 1 - tap);
+                const f32x4 v0 = {cell[0], cell[span], cell[2 * span], cell[3 * span]};
+                const f32x4 v1 = {cell[8 * span], cell[9 * span], cell[10 * span], cell[11 * span]};
+                const size_t o = ((size_t)(tap * (CoutP / 4) + co / 4) * t.NPad + n0 + nl) * 4, o2 = o + (size_t)2 * t.NPad * 4;
+                zs::s16::u32x4 hi, lo;
+                zs::s16::split8(v0, v1, hi, lo);
+                *reinterpret_cast<f32x4 *>(sp + o) = __builtin_bit_cast(f32x4, hi);
+                *reinterpret_cast<f32x4 *>(sp + o2) = __builtin_bit_cast(f32x4, lo);
+                if (!split_only) {
+                    *reinterpret_cast<f32x4 *>(t.dst + o) = v0;
+                    *reinterpret_cast<f32x4 *>(t.dst + o2) = v1;
+                }
+            }
+            return;
+        }
         for (int idx = threadIdx.x; idx < cells; idx += 256) {
             const int nl = idx & (PACK_ROWS - 1), q = idx >> 6, cq = q % quads, tap = q / quads, co = c0 + 4 * cq;
             if (co >= CoutP) continue;
@@ -727,14 +779,25 @@ extern "C" int zs_pack_entry_chunks(int Cout, int Cin, int taps, int dgrad, int 
     return pack_entry_chunks(Cout, Cin, taps, dgrad, K16, NPad);
 }
 
-extern "C" int zs_pack_conv_weight_multi(const zs_pack_entry *table, const int *chunk_entry,
-                                         const unsigned long long *chunk_start, int n_chunks, void *stream) {
+extern "C" int zs_pack_entry_inline_split(int Cout, int Cin, int taps, int dgrad) {
+    return pack_inline_split(Cout, Cin, taps, dgrad) ? 1 : 0;
+}
+
+extern "C" int zs_pack_conv_weight_multi_split(const zs_pack_entry *table, const int *chunk_entry,
+                                               const unsigned long long *chunk_start, int n_chunks, float *const *split_dst,
+                                               int split_only, void *stream) {
     ZS_REQUIRE(n_chunks >= 0, "zs_pack_conv_weight_multi: bad arguments");
     if (n_chunks == 0) return 1;
     ZS_REQUIRE(table && chunk_entry && chunk_start, "zs_pack_conv_weight_multi: null pointer");
     hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(n_chunks), dim3(256), PACK_LDS_FLOATS * sizeof(float), S(stream),
-                       reinterpret_cast<const PackEntry *>(table), chunk_entry, chunk_start);
+                       reinterpret_cast<const PackEntry *>(table), chunk_entry, chunk_start, split_dst,
+                       split_dst && split_only ? 1 : 0);
     return zs::check_launch("zs_pack_conv_weight_multi") ? 1 : 0;
+}
+
+extern "C" int zs_pack_conv_weight_multi(const zs_pack_entry *table, const int *chunk_entry,
+                                         const unsigned long long *chunk_start, int n_chunks, void *stream) {
+    return zs_pack_conv_weight_multi_split(table, chunk_entry, chunk_start, n_chunks, nullptr, 0, stream);
 }
 
 // tile edge and number of pixel-range splits of one weight gradient

@@ -18,6 +18,9 @@ from .. import _lib
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_CLAMP1, ACT_SOFTPLUS = 0, 1, 2, 3, 4
 _CONV_IN_RELU, _CONV_IN_DILATE2 = 1, 8
 _CONV_F16X3 = 16
+# Bumped whenever parameters are updated through raw pointers (the fused optimiser): tensor
+# ._version does not see those writes, so every pack cache also keys on this counter.
+GENERATION = [0]
 # Arithmetic of the FORWARD convolutions / linear layers of the training path: "f32" (default) or
 # "f16x3" = split-fp16 (opt-in: 15.4 -> 14.4 ms forward per step at batch 4, but the 1e-6 forward
 # differences are amplified by the batch-statistics BatchNorms to ~2e-3 relative in some gradients,
@@ -31,6 +34,8 @@ def set_forward_precision(p):
     global FWD_CONV_PRECISION
     if p not in ("f32", "f16x3"):
         raise ValueError("forward precision must be 'f32' or 'f16x3', got %r" % (p,))
+    if p != FWD_CONV_PRECISION:
+        GENERATION[0] += 1      # operands re-packed under the other setting may hold only the form that one reads
     FWD_CONV_PRECISION = p
 
 # Data gradients (dx = dy * W^T through the same convolution engine).  "f16x3" needs the incoming gradients inside
@@ -53,12 +58,9 @@ def set_backward_precision(p):
     global BWD_DATA_PRECISION
     if p not in ("f32", "f16x3"):
         raise ValueError("data-gradient precision must be 'f32' or 'f16x3', got %r" % (p,))
+    if p != BWD_DATA_PRECISION:
+        GENERATION[0] += 1
     BWD_DATA_PRECISION = p
-
-
-# Bumped whenever parameters are updated through raw pointers (the fused optimiser): tensor
-# ._version does not see those writes, so every pack cache also keys on this counter.
-GENERATION = [0]
 
 
 def bump_generation():
@@ -127,7 +129,8 @@ class _PackRec(object):
     # split / split_stamp: the operand's fp16 halves (optim.amp) and the stamp of the pack they were made from - a re-pack
     # (in-place weight update, load_state_dict, optimiser step) moves `stamp` and so invalidates the split with it; the
     # buffer dies with the record (a cache keyed by packed.data_ptr() + generation served stale weights)
-    __slots__ = ("ref", "key", "packed", "stamp", "dims", "split", "split_stamp", "__weakref__")
+    # inline_split: the multi re-pack writes this operand's halves itself (zs_pack_conv_weight_multi_split)
+    __slots__ = ("ref", "key", "packed", "stamp", "dims", "split", "split_stamp", "inline_split", "__weakref__")
 
 
 _PACKS = {}     # (id(weight), cin0, cin, dgrad, std_eps) -> _PackRec
@@ -157,6 +160,39 @@ def _pack_dims(w, cin, dgrad):
     return cout, cintot, kh, kw, taps, (taps * kc + 15) // 16 * 16, (n + 127) // 128 * 128
 
 
+INLINE_SPLIT = os.environ.get("ZS_TRAIN_INLINE_SPLIT", "1") != "0"      # A/B switch
+
+
+def _inline_split_mode():
+    """0: re-pack only.  1: the re-pack also writes the fp16 halves.  2: ... and leaves the fp32 operands of those entries
+    alone (forward AND data gradients read the halves: nothing reads the fp32 form until the precision changes, which
+    bumps the generation and so re-packs everything)."""
+    if not (INLINE_SPLIT and _amp_splits_operands()):
+        return 0
+    return 2 if FWD_CONV_PRECISION == "f16x3" and BWD_DATA_PRECISION == "f16x3" else 1
+
+
+def _launch_multi_pack(lib, device, recs):
+    _, tab_d, ce_d, cs_d, n, split_d, _splits = _PACK_TABLE[device]
+    with _lib.on(device):
+        if split_d is None:
+            _lib.check(lib.zs_pack_conv_weight_multi(_lib.ptr(tab_d), _lib.ptr(ce_d), _lib.ptr(cs_d), n,
+                                                     _lib.current_stream_ptr(device)), "zs_pack_conv_weight_multi")
+        else:
+            _lib.check(lib.zs_pack_conv_weight_multi_split(_lib.ptr(tab_d), _lib.ptr(ce_d), _lib.ptr(cs_d), n,
+                                                           _lib.ptr(split_d), 1 if _PACK_TABLE[device][0][-1] == 2 else 0,
+                                                           _lib.current_stream_ptr(device)),
+                       "zs_pack_conv_weight_multi_split")
+
+
+def _mark_inline_splits(device, recs):
+    """After the launch and the new stamps: the halves written by the re-pack are those of the current operand."""
+    if _PACK_TABLE[device][5] is not None:
+        for rec in recs:
+            if rec.inline_split and rec.split is not None:
+                rec.split_stamp = rec.stamp
+
+
 def _refresh_all_packs(device):
     """Re-pack every registered operand on `device` whose weight changed, in ONE launch."""
     import numpy as np
@@ -171,14 +207,13 @@ def _refresh_all_packs(device):
             for rec, w in live:
                 if rec.key[4] is not None:
                     standardize(w, rec.key[4])
-            _, tab_d, ce_d, cs_d, n = _PACK_TABLE[device]
-            with _lib.on(device):
-                _lib.check(lib.zs_pack_conv_weight_multi(_lib.ptr(tab_d), _lib.ptr(ce_d), _lib.ptr(cs_d), n,
-                                                         _lib.current_stream_ptr(device)), "zs_pack_conv_weight_multi")
-            for rec, w in live:
-                rec.stamp = _stamp(w)
-            fast["generation"] = GENERATION[0]
-            return
+            if _PACK_TABLE[device][0][-1] == _inline_split_mode():
+                _launch_multi_pack(lib, device, [rec for rec, _ in live])
+                for rec, w in live:
+                    rec.stamp = _stamp(w)
+                _mark_inline_splits(device, [rec for rec, _ in live])
+                fast["generation"] = GENERATION[0]
+                return
     recs = []
     for key, rec in list(_PACKS.items()):
         w = rec.ref()
@@ -196,7 +231,8 @@ def _refresh_all_packs(device):
         cout, cintot, kh, kw, taps, K16, NPad = rec.dims
         entries.append((src.data_ptr(), rec.packed.data_ptr(), cout, cin, cin0, cintot * taps, taps, 1 if dgrad else 0,
                         K16, NPad))
-    sig = tuple(entries)
+    mode = _inline_split_mode()
+    sig = tuple(entries) + (mode,)
     cached = _PACK_TABLE.get(device)
     if cached is None or cached[0] != sig:
         if torch.cuda.is_current_stream_capturing():
@@ -217,15 +253,31 @@ def _refresh_all_packs(device):
             ce.append(np.full(len(starts), i, np.int32))
             cs.append(starts)
         ce, cs = np.concatenate(ce), np.concatenate(cs)
+        # optim.amp: the halves of every operand whose tiles hold whole K = 16 groups leave the same launch (split_d: one
+        # pointer per entry, 0 = the operand is split by _presplit_all's launch behind this one)
+        split_d, splits = None, []
+        if mode:
+            ptrs = []
+            for (rec, _), e in zip(recs, entries):
+                rec.inline_split = bool(lib.zs_pack_entry_inline_split(e[2], e[3], e[6], e[7]))
+                if rec.inline_split:
+                    if rec.split is None or rec.split.numel() != rec.packed.numel() or rec.split.device != device:
+                        rec.split = torch.empty_like(rec.packed)
+                    ptrs.append(rec.split.data_ptr())
+                    splits.append(rec.split)
+                else:
+                    ptrs.append(0)
+            split_d = torch.tensor(ptrs, dtype=torch.int64).to(device)
+        else:
+            for rec, _ in recs:
+                rec.inline_split = False
         cached = (sig, torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(device), torch.from_numpy(ce).to(device),
-                  torch.from_numpy(cs.view(np.int64)).to(device), len(ce))
+                  torch.from_numpy(cs.view(np.int64)).to(device), len(ce), split_d, splits)
         _PACK_TABLE[device] = cached
-    _, tab_d, ce_d, cs_d, n = cached
-    with _lib.on(device):
-        _lib.check(lib.zs_pack_conv_weight_multi(_lib.ptr(tab_d), _lib.ptr(ce_d), _lib.ptr(cs_d), n,
-                                                 _lib.current_stream_ptr(device)), "zs_pack_conv_weight_multi")
+    _launch_multi_pack(lib, device, [rec for rec, _ in recs])
     for rec, w in recs:
         rec.stamp = _stamp(w)
+    _mark_inline_splits(device, [rec for rec, _ in recs])
     if complete:
         _PACK_FAST[device] = dict(epoch=_PACK_EPOCH[0], generation=GENERATION[0], recs=[rec for rec, _ in recs],
                                   ptrs=[w.data_ptr() for _, w in recs])
@@ -270,7 +322,7 @@ def _pack(weight, cin0, cin, dgrad, std_eps=None):
     rec.ref = weakref.ref(weight, lambda _r, k=key: _drop_pack(k))
     rec.key, rec.dims = key, dims
     rec.packed = torch.empty(K16 * NPad, dtype=torch.float32, device=w.device)
-    rec.split, rec.split_stamp = None, None
+    rec.split, rec.split_stamp, rec.inline_split = None, None, False
     rec.packed._zs_rec = weakref.ref(rec)              # _conv_launch finds the record (and its split) from the operand
     with _lib.on(w.device):
         _lib.check(lib.zs_pack_conv_weight(_lib.ptr(w), _lib.ptr(rec.packed), cout, cin, cin0, cintot, kh, kw,
@@ -305,7 +357,8 @@ def _amp_splits_operands():
 def _presplit_all(device):
     """Split every registered packed operand on `device` (call right after they were re-packed)."""
     lib = _lib.load()
-    recs = [rec for rec in _PACKS.values() if rec.ref() is not None and rec.packed.device == device]
+    recs = [rec for rec in _PACKS.values() if rec.ref() is not None and rec.packed.device == device and
+            not (rec.inline_split and rec.split is not None and rec.split_stamp == rec.stamp)]   # (split by the re-pack itself)
     if not recs:
         return
     sig = tuple((rec.packed.data_ptr(), rec.packed.numel()) for rec in recs)
