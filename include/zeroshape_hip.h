@@ -664,6 +664,10 @@ int zs_column_sum(const float *x, float *out, int rows, int C, float scale, void
 size_t zs_layer_norm_bwd_workspace_bytes(int rows, int C);
 int zs_layer_norm_bwd(const float *dy, const float *x, const float *gamma, float *dx, float *dgamma, float *dbeta,
                       int rows, int C, float eps, void *workspace, void *stream);
+/* The same with dx = (LayerNorm's input gradient) + add [rows][C] (may be NULL): the gradient arriving at x from its other
+ * consumer (a residual connection), summed in the same pass instead of by a separate elementwise launch. */
+int zs_layer_norm_bwd_add(const float *dy, const float *x, const float *gamma, const float *add, float *dx, float *dgamma,
+                          float *dbeta, int rows, int C, float eps, void *workspace, void *stream);
 size_t zs_attention_bwd_workspace_bytes(int batch, int L, int heads);
 int zs_attention_bwd(const float *qkv, const float *dout, float *dqkv, void *workspace, int batch, int L, int heads,
                      int head_dim, void *stream);

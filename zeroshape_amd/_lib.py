@@ -158,6 +158,7 @@ SIGNATURES = {
     "zs_column_sum": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_float, _c_void_p, _c_void_p]),
     "zs_layer_norm_bwd_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
     "zs_layer_norm_bwd": (_c_int, [_c_void_p] * 6 + [_c_int, _c_int, _c_float, _c_void_p, _c_void_p]),
+    "zs_layer_norm_bwd_add": (_c_int, [_c_void_p] * 7 + [_c_int, _c_int, _c_float, _c_void_p, _c_void_p]),
     "zs_attention_bwd_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "zs_attention_bwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 4 + [_c_void_p]),
     "zs_point_attention": (_c_int, [_c_void_p] * 3 + [_c_int] * 5 + [_c_void_p]),

@@ -144,7 +144,7 @@ constexpr int LN_MAXQ = 16;      // C <= 64 * LN_MAXQ
 __global__ __launch_bounds__(256) void layer_norm_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                              const float *__restrict__ gamma, float *__restrict__ dx,
                                                              float *__restrict__ partial, int rows, int C, float eps,
-                                                             int per_wg) {
+                                                             int per_wg, const float *__restrict__ add) {
     extern __shared__ float lds[];                      // [4][2][C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float dg[LN_MAXQ], db[LN_MAXQ];
@@ -192,7 +192,10 @@ __global__ __launch_bounds__(256) void layer_norm_bwd_kernel(const float *__rest
 #pragma unroll
         for (int q = 0; q < LN_MAXQ; q++) {
             const int c = lane + 64 * q;
-            if (c < C) dx[(size_t)row * C + c] = rstd * (gv[q] * gam[q] - mg - xv[q] * mgx);
+            if (c < C) {
+                const float v = rstd * (gv[q] * gam[q] - mg - xv[q] * mgx);
+                dx[(size_t)row * C + c] = add ? v + add[(size_t)row * C + c] : v;      // (+ the gradient of x's other consumer)
+            }
         }
     }
 #pragma unroll
@@ -568,13 +571,18 @@ extern "C" size_t zs_layer_norm_bwd_workspace_bytes(int rows, int C) {
 
 extern "C" int zs_layer_norm_bwd(const float *dy, const float *x, const float *gamma, float *dx, float *dgamma,
                                  float *dbeta, int rows, int C, float eps, void *workspace, void *stream) {
+    return zs_layer_norm_bwd_add(dy, x, gamma, nullptr, dx, dgamma, dbeta, rows, C, eps, workspace, stream);
+}
+
+extern "C" int zs_layer_norm_bwd_add(const float *dy, const float *x, const float *gamma, const float *add, float *dx,
+                                     float *dgamma, float *dbeta, int rows, int C, float eps, void *workspace, void *stream) {
     ZS_REQUIRE(rows > 0 && C > 0 && C <= 64 * LN_MAXQ, "zs_layer_norm_bwd: bad size (rows=%d C=%d, C <= %d)", rows, C,
                64 * LN_MAXQ);
     ZS_REQUIRE(dy && x && gamma && dx && dgamma && dbeta && workspace, "zs_layer_norm_bwd: null pointer");
     const int per = ln_rows_per_wg(rows), wgs = (rows + per - 1) / per;
     float *partial = static_cast<float *>(workspace);
     hipLaunchKernelGGL(layer_norm_bwd_kernel, dim3(wgs), dim3(256), 8 * C * sizeof(float), S(stream), dy, x, gamma, dx,
-                       partial, rows, C, eps, per);
+                       partial, rows, C, eps, per, add);
     // partial is [wg][2][C]: rows of stride 2C, dgamma in the first half, dbeta in the second
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, S(stream), partial, dgamma, dbeta,
                        wgs, C, 2 * C, 2 * C, 1.0f);

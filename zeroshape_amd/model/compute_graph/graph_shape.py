@@ -198,41 +198,42 @@ class Graph(nn.Module):
                     return var, self.compute_loss(opt, var, training)
             return var
         # ---- autograd branch (:117-192 under graph.train()) ----
-        H, W = opt.H, opt.W
-        rgb = var.rgb_input_map.detach().float().contiguous()
-        mask = var.mask_input_map.detach().float().contiguous()
-        if self.dpt_depth.training:
-            var.depth_pred, layer_4 = self.dpt_depth.forward_train(rgb)
-        else:                                             # a frozen, eval-mode depth model
-            with torch.no_grad():
-                var.depth_pred, feat = self.dpt_depth(rgb, get_feat=True)
-                layer_4 = ops.to_nhwc(feat)
-        if self.intr_head.training:
-            x = train_blocks.bottleneck_conv(train_blocks.bottleneck_conv(layer_4, self.intr_head[0]), self.intr_head[1])
-            intr_params = A.linear(A.global_mean(x), self.intr_proj.weight, self.intr_proj.bias)      # :125-127
-        else:
-            with torch.no_grad():
-                intr_params = self._intr.run(ops.to_nchw(layer_4))
-        var.intr_pred = A.intr_param2mtx(intr_params, H, W)                                            # :129
-        var.validity_mask = (mask > 0.5).float().view(batch_size, -1)
-        if opt.arch.depth.encoder == 'resnet':
-            assert opt.arch.depth.dsp == 1
-            var.seen_points, seen_3D_dsp, mask_dsp = A.seen_surface(var.depth_pred, var.intr_pred, mask)   # :131-144
-            var.latent_depth = self.coord_encoder(seen_3D_dsp, mask_dsp)                               # :147-150
-        else:                                              # transformer coordinate encoder
-            assert opt.arch.depth.dsp == 2, "the transformer coordinate encoder trains with arch.depth.dsp = 2 (options/shape.yaml:28)"
-            var.seen_points, seen_3D_dsp, mask_dsp = A.seen_surface_dsp2(var.depth_pred, var.intr_pred, mask)
-            var.latent_depth = self.coord_encoder(seen_3D_dsp.permute(0, 2, 3, 1).contiguous(),
-                                                  mask_dsp.squeeze(1) > 0.5)
-        var.pose = var.pose_gt if 'pose_gt' in var else None
-        if with_samples:
-            with torch.no_grad():
-                self._gt_branch(opt, var)
-            var.pred_sample_occ, _ = self.impl_network(var.latent_depth, None, var.gt_points_cam,     # :185
-                                                       need_attn=False)
-        if get_loss:
-            return var, self.compute_loss(opt, var, training)
-        return var
+        with A.deferred_bn_counters():          # the BatchNorm step counters: one launch for all 66 layers
+            H, W = opt.H, opt.W
+            rgb = var.rgb_input_map.detach().float().contiguous()
+            mask = var.mask_input_map.detach().float().contiguous()
+            if self.dpt_depth.training:
+                var.depth_pred, layer_4 = self.dpt_depth.forward_train(rgb)
+            else:                                             # a frozen, eval-mode depth model
+                with torch.no_grad():
+                    var.depth_pred, feat = self.dpt_depth(rgb, get_feat=True)
+                    layer_4 = ops.to_nhwc(feat)
+            if self.intr_head.training:
+                x = train_blocks.bottleneck_conv(train_blocks.bottleneck_conv(layer_4, self.intr_head[0]), self.intr_head[1])
+                intr_params = A.linear(A.global_mean(x), self.intr_proj.weight, self.intr_proj.bias)      # :125-127
+            else:
+                with torch.no_grad():
+                    intr_params = self._intr.run(ops.to_nchw(layer_4))
+            var.intr_pred = A.intr_param2mtx(intr_params, H, W)                                            # :129
+            var.validity_mask = (mask > 0.5).float().view(batch_size, -1)
+            if opt.arch.depth.encoder == 'resnet':
+                assert opt.arch.depth.dsp == 1
+                var.seen_points, seen_3D_dsp, mask_dsp = A.seen_surface(var.depth_pred, var.intr_pred, mask)   # :131-144
+                var.latent_depth = self.coord_encoder(seen_3D_dsp, mask_dsp)                               # :147-150
+            else:                                              # transformer coordinate encoder
+                assert opt.arch.depth.dsp == 2, "the transformer coordinate encoder trains with arch.depth.dsp = 2 (options/shape.yaml:28)"
+                var.seen_points, seen_3D_dsp, mask_dsp = A.seen_surface_dsp2(var.depth_pred, var.intr_pred, mask)
+                var.latent_depth = self.coord_encoder(seen_3D_dsp.permute(0, 2, 3, 1).contiguous(),
+                                                      mask_dsp.squeeze(1) > 0.5)
+            var.pose = var.pose_gt if 'pose_gt' in var else None
+            if with_samples:
+                with torch.no_grad():
+                    self._gt_branch(opt, var)
+                var.pred_sample_occ, _ = self.impl_network(var.latent_depth, None, var.gt_points_cam,     # :185
+                                                           need_attn=False)
+            if get_loss:
+                return var, self.compute_loss(opt, var, training)
+            return var
 
     def _gt_branch(self, opt, var):
         """:152-181 (no gradient): normalisation factors of the GT seen surface, GT query points

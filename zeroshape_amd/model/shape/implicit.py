@@ -641,20 +641,25 @@ class Implicit(nn.Module):
             s_attn, s_mlp = scales[2 * i], scales[2 * i + 1]
             if self.pos_perlayer and i > 0:
                 xl = A.add_scaled_rows(xl, pos, ones)                                                # :269-272, every block
-            qkv_l = A.linear(A.layer_norm(xl, blk.norm1.weight, blk.norm1.bias), blk.attn.qkv.weight,
-                             blk.attn.qkv.bias)
-            qkv_p = A.linear(A.layer_norm(xp, blk.norm1.weight, blk.norm1.bias), blk.attn.qkv.weight,
-                             blk.attn.qkv.bias)
+            # (fork=True: a normalisation hands its input through to the residual connection behind it and adds that
+            # connection's gradient in its own backward kernel - nn/autograd.py "Forks")
+            if last:
+                hl, xl_res = A.layer_norm(xl, blk.norm1.weight, blk.norm1.bias), None
+            else:
+                hl, xl_res = A.layer_norm(xl, blk.norm1.weight, blk.norm1.bias, fork=True)
+            qkv_l = A.linear(hl, blk.attn.qkv.weight, blk.attn.qkv.bias)
+            hp, xp = A.layer_norm(xp, blk.norm1.weight, blk.norm1.bias, fork=True)
+            qkv_p = A.linear(hp, blk.attn.qkv.weight, blk.attn.qkv.bias)
             op = A.point_attention(qkv_p, qkv_l, H)                                                  # :44-66
             xp = residual(xp, op, blk.attn.proj.weight, blk.attn.proj.bias, s_attn)
-            hp = A.gelu(A.linear(A.layer_norm(xp, blk.norm2.weight, blk.norm2.bias), blk.mlp.fc1.weight,
-                                 blk.mlp.fc1.bias))
+            hp, xp = A.layer_norm(xp, blk.norm2.weight, blk.norm2.bias, fork=True)
+            hp = A.gelu(A.linear(hp, blk.mlp.fc1.weight, blk.mlp.fc1.bias))
             xp = residual(xp, hp, blk.mlp.fc2.weight, blk.mlp.fc2.bias, s_mlp)
             if not last:                                                                             # :67-76
                 ol = A.attention(qkv_l, H)
-                xl = residual(xl, ol, blk.attn.proj.weight, blk.attn.proj.bias, s_attn)
-                hl = A.gelu(A.linear(A.layer_norm(xl, blk.norm2.weight, blk.norm2.bias), blk.mlp.fc1.weight,
-                                     blk.mlp.fc1.bias))
+                xl = residual(xl_res, ol, blk.attn.proj.weight, blk.attn.proj.bias, s_attn)
+                hl, xl = A.layer_norm(xl, blk.norm2.weight, blk.norm2.bias, fork=True)
+                hl = A.gelu(A.linear(hl, blk.mlp.fc1.weight, blk.mlp.fc1.bias))
                 xl = residual(xl, hl, blk.mlp.fc2.weight, blk.mlp.fc2.bias, s_mlp)
         feat = A.layer_norm(xp, self.norm.weight, self.norm.bias)                                    # :279
         # MLPBlocks (:168-184): inputs = cat([xyz, feat]); skip layers see cat([x, inputs]) / sqrt(2).

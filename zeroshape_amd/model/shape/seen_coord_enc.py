@@ -85,7 +85,8 @@ class CoordEncRes(HipModule):
         self._need_gpu(coord_obj, "coord_obj")
         assert len(coord_obj.shape) == len(mask_obj.shape) == 4
         if self.training and torch.is_grad_enabled():
-            return self._forward_train(coord_obj, mask_obj)
+            with A.deferred_bn_counters():
+                return self._forward_train(coord_obj, mask_obj)
         with torch.no_grad():
             return self._forward_eval(coord_obj, mask_obj)
 
@@ -186,7 +187,8 @@ class CoordEncAtt(HipModule):
         timm's per-sample DropPath on the 12 global blocks (seen_coord_enc.py:93-97, drop_path 0.1)."""
         self._need_gpu(coord_obj, "coord_obj")
         if self.training and torch.is_grad_enabled():
-            return self._forward_train(coord_obj, mask_obj)
+            with A.deferred_bn_counters():
+                return self._forward_train(coord_obj, mask_obj)
         with torch.no_grad():
             return self._forward_eval(coord_obj, mask_obj)
 

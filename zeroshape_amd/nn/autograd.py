@@ -513,12 +513,14 @@ class _Conv(torch.autograd.Function):
         ctx.cfg = dict(cfg, pt=pt, pl=pl, kh=kh, kw=kw, cin0=cin0, cin=cin)
         ctx.has = (bias is not None, res1 is not None, res2 is not None)
         ctx.save_for_backward(x, weight, out if act != ACT_NONE else None)
-        return out
+        return (out, x.view_as(x)) if cfg.get("fork") else out
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dpass=None):
         lib = _lib.load()
         x, weight, out = ctx.saved_tensors
+        if dpass is not None:
+            dpass = _f32c(dpass, "conv pass-through grad")
         cfg = ctx.cfg
         kh, kw, stride, pt, pl = cfg["kh"], cfg["kw"], cfg["stride"], cfg["pt"], cfg["pl"]
         cin0, cin, act = cfg["cin0"], cfg["cin"], cfg["act"]
@@ -568,20 +570,27 @@ class _Conv(torch.autograd.Function):
             else:
                 dx = torch.empty(B, H, W, cin, dtype=torch.float32, device=x.device)
                 flags = (_CONV_IN_DILATE2 if stride == 2 else 0) | (_CONV_F16X3 if BWD_DATA_PRECISION == "f16x3" else 0)
-                _conv_launch(gp, _pack(weight, cin0, cin, True, std_eps), None, None, None, dx, kh, kw, 1, kh - 1 - pt,
-                             kw - 1 - pl, flags, in_scale, 0.0, ACT_NONE)
+                fused = dpass is not None and cin == Cx and not in_relu     # the pass-through's gradient: the GEMM's residual
+                _conv_launch(gp, _pack(weight, cin0, cin, True, std_eps), None, dpass if fused else None, None, dx, kh, kw, 1,
+                             kh - 1 - pt, kw - 1 - pl, flags, in_scale, 0.0, ACT_NONE)
+                if fused:
+                    dpass = None
                 if cin != Cx:                       # the input carried zero padding channels
                     dx = _pad_channels(dx, Cx)
             if in_relu:
                 dx = _act_backward(dx, x, ACT_RELU)
+        if dpass is not None:
+            dx = dpass if dx is None else dx + dpass
         return dx, dw, db, (g if ctx.has[1] else None), (g if ctx.has[2] else None), None
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, act=ACT_NONE, in_relu=False, in_scale=1.0, in_shift=0.0,
-           res1=None, res2=None, std_eps=None, cin0=0, cin=None):
+           res1=None, res2=None, std_eps=None, cin0=0, cin=None, fork=False):
+    """fork=True: returns (conv(x), x) - see "Forks" below; x's other consumer takes the returned x."""
     cfg = dict(stride=stride, padding=padding, act=act, in_relu=in_relu, in_scale=in_scale, in_shift=in_shift,
-               std_eps=std_eps, cin0=cin0, cin=cin)
-    return _Conv.apply(x, weight, bias, res1, res2, cfg)
+               std_eps=std_eps, cin0=cin0, cin=cin, fork=bool(fork) and FUSE_FORKS)
+    y = _Conv.apply(x, weight, bias, res1, res2, cfg)
+    return (y, x) if fork and not FUSE_FORKS else y
 
 
 def linear(x, weight, bias=None, act=ACT_NONE, res1=None, in_scale=1.0, cin0=0, cin=None):
@@ -626,9 +635,17 @@ def relu(x):
     return _Act.apply(x, ACT_RELU, 0.0)
 
 
+# Forks.  A tensor with two consumers (x -> [norm / conv -> branch] and x -> residual add) receives two gradients, which
+# the autograd engine sums with an elementwise launch of its own (~95 per training step of the shape graph, 4 us each).
+# With fork=True the first consumer also hands x through (`y, x = op(x, fork=True)`, the second consumer takes THAT x):
+# the pass-through's gradient arrives in the op's backward, which adds it inside the kernel that writes dx anyway
+# (zs_layer_norm_bwd_add; the data-gradient GEMM's residual operand), and x's producer sees ONE gradient.
+FUSE_FORKS = os.environ.get("ZS_TRAIN_FUSE_FORKS", "1") != "0"      # A/B switch: off = the pass-through is x itself
+
+
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, fork):
         lib = _lib.load()
         x = _f32c(x, "layer_norm input")
         C = x.shape[-1]
@@ -638,13 +655,14 @@ class _LayerNorm(torch.autograd.Function):
                                          x.numel() // C, C, float(eps), _stream(x)), "zs_layer_norm")
         ctx.eps = eps
         ctx.save_for_backward(x, gamma)
-        return y
+        return (y, x.view_as(x)) if fork else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dpass=None):
         lib = _lib.load()
         x, gamma = ctx.saved_tensors
         dy = _f32c(dy, "layer_norm grad")
+        add = None if dpass is None else _f32c(dpass, "layer_norm pass-through grad")
         C = x.shape[-1]
         rows = x.numel() // C
         dx = torch.empty_like(x)
@@ -652,14 +670,19 @@ class _LayerNorm(torch.autograd.Function):
         db = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = scratch(x.device, "ln_bwd", lib.zs_layer_norm_bwd_workspace_bytes(rows, C))
         with _lib.on(x.device):
-            _lib.check(lib.zs_layer_norm_bwd(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(gamma.detach()), _lib.ptr(dx),
-                                             _lib.ptr(dg), _lib.ptr(db), rows, C, float(ctx.eps), _lib.ptr(ws),
-                                             _stream(x)), "zs_layer_norm_bwd")
-        return dx, dg, db, None
+            _lib.check(lib.zs_layer_norm_bwd_add(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(gamma.detach()), _lib.ptr(add),
+                                                 _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), rows, C, float(ctx.eps),
+                                                 _lib.ptr(ws), _stream(x)), "zs_layer_norm_bwd_add")
+        return dx, dg, db, None, None
 
 
-def layer_norm(x, gamma, beta, eps=1e-6):
-    return _LayerNorm.apply(x, gamma, beta, eps)
+def layer_norm(x, gamma, beta, eps=1e-6, fork=False):
+    """fork=True: returns (LayerNorm(x), x) - see "Forks" above."""
+    if not fork:
+        return _LayerNorm.apply(x, gamma, beta, eps, False)
+    if not FUSE_FORKS:
+        return _LayerNorm.apply(x, gamma, beta, eps, False), x
+    return _LayerNorm.apply(x, gamma, beta, eps, True)
 
 
 ATT_FWD_SPLIT = os.environ.get("ZS_TRAIN_ATT_SPLIT", "1") != "0"      # A/B switch
@@ -853,12 +876,37 @@ class _BatchNormTrain(torch.autograd.Function):
         return dx, dg, db, dres, None, None, None, None, None
 
 
+_BN_COUNTERS = [None]      # inside deferred_bn_counters(): the num_batches_tracked buffers to bump on exit
+
+
+class deferred_bn_counters(object):
+    """Within the block batch_norm_train() only notes the layers' `num_batches_tracked` buffers; on exit they are all
+    incremented by ONE multi-tensor launch (a training forward of the shape graph has 66 BatchNorm layers: 66 one-element
+    kernels, 0.27 ms of a 27 ms step).  Re-entrant: an inner block leaves the flush to the outermost one."""
+
+    def __enter__(self):
+        self.outer = _BN_COUNTERS[0] is not None
+        if not self.outer:
+            _BN_COUNTERS[0] = []
+        return self
+
+    def __exit__(self, *exc):
+        if not self.outer:
+            pending, _BN_COUNTERS[0] = _BN_COUNTERS[0], None
+            if pending and exc[0] is None:
+                torch._foreach_add_(pending, 1)
+        return False
+
+
 def batch_norm_train(x, bn, relu=False, residual=None):
     """bn: an nn.BatchNorm2d in training mode (its running statistics are updated in place)."""
     momentum = 0.1 if bn.momentum is None else bn.momentum
     y = _BatchNormTrain.apply(x, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, bn.eps, momentum, relu)
     if bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+        if _BN_COUNTERS[0] is not None:
+            _BN_COUNTERS[0].append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked += 1
     return y
 
 

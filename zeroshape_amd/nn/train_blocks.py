@@ -17,7 +17,8 @@ def _bn(x, bn, relu=False, residual=None):
 def bottleneck_conv(x, m):
     """utils/layers.py:76-100 Bottleneck_Conv."""
     k = m.linear1.kernel_size[0]
-    h = _bn(A.conv2d(x, m.linear1.weight, padding=k // 2), m.bn1, relu=True)
+    h, x = A.conv2d(x, m.linear1.weight, padding=k // 2, fork=True)         # (see resnet50)
+    h = _bn(h, m.bn1, relu=True)
     return _bn(A.conv2d(h, m.linear2.weight, padding=k // 2), m.bn2, relu=True, residual=x)
 
 
@@ -29,10 +30,12 @@ def resnet50(x, enc):
     for layer in (enc.layer1, enc.layer2, enc.layer3, enc.layer4):
         for blk in layer:
             stride = blk.conv2.stride[0]
-            identity = x
+            # x has two consumers: conv1 hands it through to the other one (A.conv2d fork=True: its data-gradient GEMM adds
+            # the second gradient in its epilogue, the autograd engine does not launch an add)
+            y, identity = A.conv2d(x, blk.conv1.weight, fork=True)
             if hasattr(blk, "downsample"):
-                identity = _bn(A.conv2d(x, blk.downsample[0].weight, stride=stride), blk.downsample[1])
-            y = _bn(A.conv2d(x, blk.conv1.weight), blk.bn1, relu=True)
+                identity = _bn(A.conv2d(identity, blk.downsample[0].weight, stride=stride), blk.downsample[1])
+            y = _bn(y, blk.bn1, relu=True)
             y = _bn(A.conv2d(y, blk.conv2.weight, stride=stride, padding=1), blk.bn2, relu=True)
             x = _bn(A.conv2d(y, blk.conv3.weight), blk.bn3, relu=True, residual=identity)
         feats.append(x)
@@ -43,13 +46,15 @@ def vit_block(x, blk, heads, scales=None):
     """timm Block: x + drop_path(proj(attn(LN x))); x + drop_path(fc2(gelu(fc1(LN x)))).  scales = (s_attn, s_mlp):
     per-sample DropPath factors [B] (bernoulli(keep) / keep, timm layers/drop.py) or None for drop_path 0 / eval."""
     s_attn, s_mlp = scales if scales is not None else (None, None)
-    h = A.layer_norm(x, blk.norm1.weight, blk.norm1.bias, 1e-6)
+    # (fork=True: the normalisation hands x through to the residual connection and its backward kernel adds that
+    # connection's gradient - A.layer_norm)
+    h, x = A.layer_norm(x, blk.norm1.weight, blk.norm1.bias, 1e-6, fork=True)
     a = A.attention(A.linear(h, blk.attn.qkv.weight, blk.attn.qkv.bias), heads)
     if s_attn is None:
         x = A.linear(a, blk.attn.proj.weight, blk.attn.proj.bias, res1=x)
     else:
         x = A.add_scaled_rows(x, A.linear(a, blk.attn.proj.weight, blk.attn.proj.bias), s_attn)
-    h = A.layer_norm(x, blk.norm2.weight, blk.norm2.bias, 1e-6)
+    h, x = A.layer_norm(x, blk.norm2.weight, blk.norm2.bias, 1e-6, fork=True)
     h = A.gelu(A.linear(h, blk.mlp.fc1.weight, blk.mlp.fc1.bias))
     if s_mlp is None:
         return A.linear(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias, res1=x)
@@ -72,11 +77,11 @@ def resnetv2(x, bb, in_scale=1.0, in_shift=0.0):
     for stage in bb.stages:
         for blk in stage.blocks:
             stride = blk.conv2.stride[0]
-            shortcut = x
+            y, shortcut = A.conv2d(x, blk.conv1.weight, padding="same", std_eps=STD_EPS, fork=True)     # (see resnet50)
             if hasattr(blk, "downsample"):
-                shortcut = _gn(A.conv2d(x, blk.downsample.conv.weight, stride=stride, padding="same", std_eps=STD_EPS),
+                shortcut = _gn(A.conv2d(shortcut, blk.downsample.conv.weight, stride=stride, padding="same", std_eps=STD_EPS),
                                blk.downsample.norm, False)
-            y = _gn(A.conv2d(x, blk.conv1.weight, padding="same", std_eps=STD_EPS), blk.norm1, True)
+            y = _gn(y, blk.norm1, True)
             y = _gn(A.conv2d(y, blk.conv2.weight, stride=stride, padding="same", std_eps=STD_EPS), blk.norm2, True)
             x = _gn(A.conv2d(y, blk.conv3.weight, padding="same", std_eps=STD_EPS), blk.norm3, True, residual=shortcut)
         feats.append(x)
