@@ -549,17 +549,26 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(WgradArgs a) {
     const int wm = (wave & 1) * (T / 2), wn = (wave >> 1) * (T / 2);
     const int steps = (p_end - p_begin + WP - 1) / WP;
     if (steps > 0) {
-        Frag f[PASSES];
+        // the global loads run TWO steps ahead of the MFMAs (f: step s + 1, loaded during step s - 1 and stored to LDS during
+        // step s; g: step s + 2, requested now): a step is 3-12 MFMAs and a barrier, a load takes longer than that - with one
+        // step of distance every step waited for its loads (ViT fc layers at batch 4: 45 us for 50 steps)
+        Frag f[PASSES], g[PASSES];
 #pragma unroll
         for (int q = 0; q < PASSES; q++) f[q] = load(p_begin + PASSES * prow + q, q);
         store(0, f);
+        if (steps > 1) {
+#pragma unroll
+            for (int q = 0; q < PASSES; q++) f[q] = load(p_begin + WP + PASSES * prow + q, q);
+        }
+#pragma unroll
+        for (int q = 0; q < PASSES; q++) g[q] = f[q];
         __syncthreads();
         for (int s = 0; s < steps; s++) {
             const int cur = s & 1;
             const bool more = s + 1 < steps;
-            if (more) {
+            if (s + 2 < steps) {
 #pragma unroll
-                for (int q = 0; q < PASSES; q++) f[q] = load(p_begin + (s + 1) * WP + PASSES * prow + q, q);
+                for (int q = 0; q < PASSES; q++) g[q] = load(p_begin + (s + 2) * WP + PASSES * prow + q, q);
             }
             u32x4 ah[NI], al[NI], bh[NI], bl[NI];
 #pragma unroll
@@ -578,6 +587,8 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(WgradArgs a) {
                 for (int j = 0; j < NI; j++) zs::s16::mfma3(acc[i][j], ah[i], al[i], bh[j], bl[j]);
             if (more) store(cur ^ 1, f);
             __syncthreads();
+#pragma unroll
+            for (int q = 0; q < PASSES; q++) f[q] = g[q];
         }
     }
     if (a.bias_partial && blockIdx.y == 0) {          // bias gradient: column sums of this tile's dY rows (fp32)
@@ -809,7 +820,8 @@ static void wgrad_plan(long long M, int CoutP, int K, int *tile, int *splits_out
     // the pixel range (every split costs a partial tile to write and to reduce); measured per shape
     const bool small_tiles = (M < 4096 && tiles128 < 192) || tiles128 <= 12;
     const long long tiles = small_tiles ? tiles64 : tiles128;
-    long long splits = ((small_tiles ? 512 : target) + tiles - 1) / tiles;     // aim at 2-3 workgroups per CU
+    static const long long target_small = getenv("ZS_WGRAD_TARGET_SMALL") ? atoll(getenv("ZS_WGRAD_TARGET_SMALL")) : 1024;
+    long long splits = ((small_tiles ? target_small : target) + tiles - 1) / tiles;     // aim at 2-3 workgroups per CU
     const long long max_by_pixels = (M + 127) / 128;                           // at least 128 pixels per split
     if (splits > max_by_pixels) splits = max_by_pixels;
     if (splits < 1) splits = 1;
