@@ -618,6 +618,103 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(WgradArgs a) {
     }
 }
 
+// Pointwise layers on 64 x 64 tiles (every ViT layer at batch 4).  In wgrad_split_kernel<64, PW> a thread stages ONE pixel of
+// both operands and writes its fp16 halves with sixteen 16-bit LDS stores per step; the loader, not the three MFMAs per wave
+// and step, bounded the kernel (a build whose loader only copied pre-split words ran the ViT fc layers in 23.8 instead of
+// 33.1 us; its pre-pass launches cost more than that - DESIGN 11.6).  Here the workgroup's halves take one operand each:
+// threads 0..127 the dY tile, 128..255 the input tile, a thread the channel quad of TWO adjacent pixels - the pixel-pair
+// words of four channels are one ds_write_b128 per half, as in the 128 x 128 form.  Branch-free (the role only selects
+// pointers), same words, same MFMA order: the weight AND the bias gradient are bit-identical.
+__global__ __launch_bounds__(256) void wgrad_split_pw64_kernel(WgradArgs a) {
+    using zs::s16::u32x4;
+    constexpr int T = 64, QUADS = T / 4, RS = T + 8;
+    __shared__ __attribute__((aligned(16))) unsigned lds[2][2][2][(WP / 2) * RS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, half = lane >> 5;
+    const int c0 = blockIdx.x * T, k0 = blockIdx.y * T;
+    const int p_begin = blockIdx.z * a.pix_per_split, p_end = min(a.M, p_begin + a.pix_per_split);
+    const int role = tid >> 7, prow = (tid & 127) / QUADS, quad = tid & (QUADS - 1);      // role 0: dY, 1: the input
+    const int width = role ? a.Cin : a.CoutP, col = (role ? k0 : c0) + 4 * quad;
+    const bool col_ok = col < (role ? a.K : a.CoutP);
+    const float *base = (role ? a.in : a.dy) + (col_ok ? col : 0);
+    unsigned *const my_hi = &lds[0][role][0][prow * RS + 4 * quad];
+    constexpr int BUF = 4 * (WP / 2) * RS, HALF = (WP / 2) * RS;
+    f32x4 bsum0 = {0.f, 0.f, 0.f, 0.f}, bsum1 = bsum0;       // per pixel row of the step, like the one-pixel loaders: same sums
+    struct Pair { f32x4 v0, v1; };
+    auto load = [&](int s) -> Pair {
+        const int p = p_begin + s * WP + 2 * prow;
+        Pair f;
+        f.v0 = (col_ok && p < p_end) ? *reinterpret_cast<const f32x4 *>(base + (size_t)p * width) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f.v1 = (col_ok && p + 1 < p_end) ? *reinterpret_cast<const f32x4 *>(base + (size_t)(p + 1) * width)
+                                         : f32x4{0.f, 0.f, 0.f, 0.f};
+        return f;
+    };
+    auto store = [&](int buf, const Pair &f) {
+        u32x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            unsigned hh, ll;
+            zs::s16::split2(f.v0[e], f.v1[e], hh, ll);
+            h[e] = hh; l[e] = ll;
+        }
+        *reinterpret_cast<u32x4 *>(my_hi + buf * BUF) = h;
+        *reinterpret_cast<u32x4 *>(my_hi + buf * BUF + HALF) = l;
+        bsum0 += f.v0;                          // (meaningful for role 0 only)
+        bsum1 += f.v1;
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    const int wm = (wave & 1) * (T / 2), wn = (wave >> 1) * (T / 2);
+    const int steps = (p_end - p_begin + WP - 1) / WP;
+    if (steps > 0) {
+        Pair f = load(0), g;
+        store(0, f);
+        if (steps > 1) f = load(1);
+        g = f;
+        __syncthreads();
+        for (int s = 0; s < steps; s++) {
+            const int cur = s & 1;
+            if (s + 2 < steps) g = load(s + 2);
+            u32x4 ah, al, bh, bl;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int oa = (4 * half + t) * RS + wm + l32, ob = (4 * half + t) * RS + wn + l32;
+                ah[t] = lds[cur][0][0][oa];
+                al[t] = lds[cur][0][1][oa];
+                bh[t] = lds[cur][1][0][ob];
+                bl[t] = lds[cur][1][1][ob];
+            }
+            zs::s16::mfma3(acc, ah, al, bh, bl);
+            if (s + 1 < steps) store(cur ^ 1, f);
+            __syncthreads();
+            f = g;
+        }
+    }
+    if (a.bias_partial && blockIdx.y == 0) {          // bias gradient: column sums of this tile's dY rows (fp32)
+        __shared__ __attribute__((aligned(16))) float bred[WP][T];
+        __syncthreads();
+        if (role == 0) {
+            *reinterpret_cast<f32x4 *>(&bred[2 * prow][4 * quad]) = bsum0;
+            *reinterpret_cast<f32x4 *>(&bred[2 * prow + 1][4 * quad]) = bsum1;
+        }
+        __syncthreads();
+        if (role == 0 && prow == 0 && col_ok) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < WP; r++) t += *reinterpret_cast<const f32x4 *>(&bred[r][4 * quad]);
+            *reinterpret_cast<f32x4 *>(a.bias_partial + (size_t)blockIdx.z * a.CoutP + col) = t;
+        }
+    }
+    float *dst = a.partial + (size_t)blockIdx.z * a.CoutP * a.K;
+    const int k = k0 + wn + l32;
+    if (k < a.K)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int co = c0 + wm + 8 * (r >> 2) + 4 * half + (r & 3);
+            if (co < a.CoutP) dst[(size_t)co * a.K + k] = acc[r];
+        }
+}
+
 // partial [splits][CoutP][K] (k = tap*CinP + c) -> dw[cout*ld + (cin0+c)*taps + tap], cout < Cout, c < Cin; the bias
 // gradient (column sums of dY per split) rides as Cout extra outputs.  An output is summed by ZL adjacent lanes
 // (splits strided over them, combined by a fixed butterfly): small weights with hundreds of splits must not be a
@@ -875,8 +972,10 @@ extern "C" int zs_conv2d_wgrad(const float *in, const float *dy, float *dw, floa
         else if (mode == 2) hipLaunchKernelGGL((KERNEL<TT, 2>), grid, dim3(256), 0, S(stream), a);             \
         else hipLaunchKernelGGL((KERNEL<TT, 0>), grid, dim3(256), 0, S(stream), a);                            \
     } while (0)
+    static const bool no_pw64 = getenv("ZS_WGRAD_NO_PW64") != nullptr;        // A/B switch
     if (flags & ZS_CONV_F16X3) {                 // split-fp16 arithmetic (optim.amp)
-        if (tile == 64) ZS_WGRAD(wgrad_split_kernel, 64);
+        if (tile == 64 && mode == 1 && !no_pw64) hipLaunchKernelGGL(wgrad_split_pw64_kernel, grid, dim3(256), 0, S(stream), a);
+        else if (tile == 64) ZS_WGRAD(wgrad_split_kernel, 64);
         else ZS_WGRAD(wgrad_split_kernel, 128);
     } else {
         if (tile == 64) ZS_WGRAD(wgrad_kernel, 64);
