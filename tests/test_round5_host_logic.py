@@ -83,3 +83,47 @@ def test_pp256_tile_and_tail_plan_of_the_vit_layers():
     assert _pp256_plan(16384, 3072, 768) == (768, 0, 1)         # three whole rounds
     full, tail, sp = _pp256_plan(8204, 2048, 768)               # 33 x 8 = 264 again
     assert (full, tail) == (256, 8) and full + tail * sp <= 256 + 8 * 8
+
+
+def test_deferred_bn_counters_flush_once_and_not_after_an_exception():
+    """nn/autograd.deferred_bn_counters: batch_norm_train() only notes the `num_batches_tracked` buffers inside the block, the
+    OUTERMOST block bumps them all with one multi-tensor add; an exception leaves them alone."""
+    from zeroshape_amd.nn import autograd as A
+    counters = [torch.zeros((), dtype=torch.int64) for _ in range(5)]
+    assert A._BN_COUNTERS[0] is None
+    with A.deferred_bn_counters():
+        A._BN_COUNTERS[0].extend(counters[:2])              # what batch_norm_train() does inside a block
+        with A.deferred_bn_counters():                      # e.g. the coordinate encoder inside Graph.forward
+            A._BN_COUNTERS[0].extend(counters[2:])
+        assert all(int(c) == 0 for c in counters)           # the inner block did not flush
+    assert all(int(c) == 1 for c in counters) and A._BN_COUNTERS[0] is None
+    try:
+        with A.deferred_bn_counters():
+            A._BN_COUNTERS[0].append(counters[0])
+            raise RuntimeError("forward failed")
+    except RuntimeError:
+        pass
+    assert int(counters[0]) == 1 and A._BN_COUNTERS[0] is None
+
+
+def test_inline_split_mode_follows_the_precisions_and_a_change_re_packs_everything():
+    """The re-pack writes the operands' fp16 halves itself only under optim.amp's settings, skips the fp32 operands only when
+    forward AND data gradients read the halves, and any precision change moves the generation (stale fp32 operands must not
+    be served after switching back)."""
+    from zeroshape_amd.nn import autograd as A
+    try:
+        A.set_forward_precision("f32")
+        A.set_backward_precision("f32")
+        assert A._inline_split_mode() == 0
+        g0 = A.GENERATION[0]
+        A.set_forward_precision("f16x3")
+        assert A.GENERATION[0] == g0 + 1 and A._inline_split_mode() == 1
+        A.set_forward_precision("f16x3")                    # no change: no re-pack
+        assert A.GENERATION[0] == g0 + 1
+        A.set_backward_precision("f16x3")
+        assert A.GENERATION[0] == g0 + 2 and A._inline_split_mode() == 2
+        A.set_forward_precision("f32")
+        assert A._inline_split_mode() == 1                  # the data gradients still read halves, the forward reads fp32
+    finally:
+        A.set_forward_precision("f32")
+        A.set_backward_precision("f32")
