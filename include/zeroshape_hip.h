@@ -653,6 +653,17 @@ int zs_conv2d_dgrad_small_cin(const float *dy, const float *w, float *dx, int ba
                               int Wout, int Cout, int kh, int kw, int stride, int pad_t, int pad_l, int Cin, int cin0,
                               int CinTot, float scale, void *stream);
 int zs_standardize_weight(const float *w, float *out, int Cout, int n, float eps, void *stream);
+/* zs_standardize_weight over a device table of weights in one launch: entry e = rows x n weights (rows = Cout, n = the
+ * fan-in) from w to out with its eps; row_prefix[e] = the number of rows of the entries before e (n_entries ints,
+ * row_prefix[0] = 0), total_rows = their sum.  Same arithmetic as the single call. */
+typedef struct zs_std_entry {
+    const float *w;
+    float *out;
+    int rows, n;
+    float eps;
+    int pad;
+} zs_std_entry;
+int zs_standardize_weight_multi(const zs_std_entry *table, const int *row_prefix, int n_entries, int total_rows, void *stream);
 int zs_standardize_weight_bwd(const float *w, const float *grad_out, float *dw, int Cout, int n, float eps,
                               void *stream);
 int zs_act_forward(const float *x, float *y, size_t n, int act, float beta, void *stream);

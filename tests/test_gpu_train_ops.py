@@ -401,6 +401,39 @@ def test_repack_of_all_operands_in_one_launch_equals_the_single_packs():
 
 
 @pytest.mark.gpu
+def test_standardize_all_equals_the_single_launches():
+    """zs_standardize_weight_multi (one launch for every stale StdConv weight after an optimiser step) writes exactly what
+    zs_standardize_weight writes per weight; fresh weights are skipped, a repeated weight is standardised once."""
+    from zeroshape_amd.nn import autograd as A
+    A.clear_pack_cache()
+    g = torch.Generator().manual_seed(9)
+    shapes = [(64, 3, 7, 7), (256, 64, 1, 1), (64, 64, 3, 3), (1024, 512, 1, 1), (10, 6, 3, 3), (1, 32, 1, 1)]
+    ws = [torch.nn.Parameter(torch.randn(s, generator=g).cuda()) for s in shapes]
+    want = [A.standardize(w, 1e-8).clone() for w in ws]                    # single launches
+    with torch.no_grad():
+        for w in ws:
+            w.mul_(1.5).add_(0.25)
+    A.bump_generation()
+    want2 = []
+    for w in ws:
+        m = w.detach().reshape(w.shape[0], -1)
+        want2.append(((m - m.mean(1, keepdim=True)) / torch.sqrt(m.var(1, unbiased=False, keepdim=True) + 1e-8)).reshape(w.shape))
+    A.standardize_all([(w, 1e-8) for w in ws] + [(ws[1], 1e-8)])           # one launch (ws[1] listed twice)
+    for w, old, ref in zip(ws, want, want2):
+        got = A._STD[id(w)][2]
+        assert A._STD[id(w)][3] == A._stamp(w)
+        assert not torch.equal(got, old) or w.shape[0] == 1
+        single = torch.empty_like(got)
+        from zeroshape_amd import _lib
+        with torch.cuda.device(w.device):
+            _lib.check(_lib.load().zs_standardize_weight(_lib.ptr(w.detach()), _lib.ptr(single), w.shape[0], w[0].numel(), 1e-8,
+                                                         _lib.current_stream_ptr(w.device)), "zs_standardize_weight")
+        assert torch.equal(got, single), tuple(w.shape)
+        close(got, ref.cpu(), rtol=1e-5, what="standardised weight")
+    A.clear_pack_cache()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fwd,bwd", [("f16x3", "f16x3"), ("f16x3", "f32")])
 def test_repack_writes_the_fp16_halves_itself(fwd, bwd, monkeypatch):
     """optim.amp: zs_pack_conv_weight_multi_split writes the halves of every operand whose tiles hold whole K = 16 groups in

@@ -150,6 +150,7 @@ SIGNATURES = {
     "zs_conv2d_wgrad": (_c_int, [_c_void_p] * 5 + [_c_int] * 13 + [_c_float, _c_float] + [_c_int] * 4 + [_c_void_p]),
     "zs_conv2d_dgrad_small_cin": (_c_int, [_c_void_p] * 3 + [_c_int] * 15 + [_c_float, _c_void_p]),
     "zs_standardize_weight": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_float, _c_void_p]),
+    "zs_standardize_weight_multi": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p]),
     "zs_standardize_weight_bwd": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_float, _c_void_p]),
     "zs_act_forward": (_c_int, [_c_void_p, _c_void_p, _c_size_t, _c_int, _c_float, _c_void_p]),
     "zs_act_backward": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_int, _c_float, _c_void_p]),

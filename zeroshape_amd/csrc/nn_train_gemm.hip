@@ -787,6 +787,35 @@ __global__ __launch_bounds__(256) void std_weight_kernel(const float *__restrict
     for (int e = threadIdx.x; e < n; e += 256) out[(size_t)blockIdx.x * n + e] = (r[e] - mean) * rstd;
 }
 
+// the same for a device table of weights in ONE launch (the training step re-standardises the 52 StdConv weights of the
+// DPT-hybrid backbone after every optimiser step): block b works on global row b, row_prefix[e] <= b < row_prefix[e + 1]
+struct StdEntry {               // mirrors include/zeroshape_hip.h zs_std_entry
+    const float *w;
+    float *out;
+    int rows, n;
+    float eps;
+    int pad;
+};
+__global__ __launch_bounds__(256) void std_weight_multi_kernel(const StdEntry *__restrict__ tab,
+                                                               const int *__restrict__ row_prefix, int n_entries) {
+    __shared__ float lds[4];
+    int lo = 0, hi = n_entries - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (row_prefix[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const StdEntry t = tab[lo];
+    const int row = (int)blockIdx.x - row_prefix[lo], n = t.n;
+    const float *r = t.w + (size_t)row * n;
+    float s = 0.f;
+    for (int e = threadIdx.x; e < n; e += 256) s += r[e];
+    const float mean = block_sum256(s, lds) / n;
+    float q = 0.f;
+    for (int e = threadIdx.x; e < n; e += 256) { const float d = r[e] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(block_sum256(q, lds) / n + t.eps);
+    for (int e = threadIdx.x; e < n; e += 256) t.out[(size_t)row * n + e] = (r[e] - mean) * rstd;
+}
+
 // dw = rstd * (g - mean(g) - what * mean(g * what))
 __global__ __launch_bounds__(256) void std_weight_bwd_kernel(const float *__restrict__ w, const float *__restrict__ g,
                                                              float *__restrict__ dw, int n, float eps) {
@@ -1009,6 +1038,17 @@ extern "C" int zs_standardize_weight(const float *w, float *out, int Cout, int n
     ZS_REQUIRE(Cout > 0 && n > 0 && w && out, "zs_standardize_weight: bad arguments");
     hipLaunchKernelGGL(std_weight_kernel, dim3(Cout), dim3(256), 0, S(stream), w, out, n, eps);
     return zs::check_launch("zs_standardize_weight") ? 1 : 0;
+}
+
+extern "C" int zs_standardize_weight_multi(const zs_std_entry *table, const int *row_prefix, int n_entries, int total_rows,
+                                           void *stream) {
+    static_assert(sizeof(StdEntry) == sizeof(zs_std_entry), "zs_std_entry layout");
+    ZS_REQUIRE(n_entries >= 0 && total_rows >= 0, "zs_standardize_weight_multi: bad arguments");
+    if (n_entries == 0 || total_rows == 0) return 1;
+    ZS_REQUIRE(table && row_prefix, "zs_standardize_weight_multi: null pointer");
+    hipLaunchKernelGGL(std_weight_multi_kernel, dim3(total_rows), dim3(256), 0, S(stream),
+                       reinterpret_cast<const StdEntry *>(table), row_prefix, n_entries);
+    return zs::check_launch("zs_standardize_weight_multi") ? 1 : 0;
 }
 
 extern "C" int zs_standardize_weight_bwd(const float *w, const float *grad_out, float *dw, int Cout, int n, float eps,

@@ -84,6 +84,19 @@ _SCRATCH = {}
 SCRATCH_GENERATION = [0]     # bumped when a workspace is (re)allocated: a captured step holds the old address
 
 
+_WS_BYTES = {}      # (query, args) -> bytes: the *_workspace_bytes queries are pure functions of their arguments
+
+
+def _ws_bytes(query, *args):
+    """A workspace-size query of the C ABI, asked once per argument tuple (a training step made 459 such calls - a quarter of
+    its C-ABI calls - for sizes that never change)."""
+    key = (query,) + args
+    n = _WS_BYTES.get(key)
+    if n is None:
+        n = _WS_BYTES[key] = int(getattr(_lib.load(), query)(*args))
+    return n
+
+
 def scratch(device, name, nbytes):
     key = (str(device), name)
     n = (int(nbytes) + 3) // 4
@@ -124,6 +137,56 @@ def standardize(weight, eps):
     return rec[2]
 
 
+_STD_TABLE = {}     # device -> (signature, entry table, row prefix, entries, rows): the launch table of standardize_all
+
+
+def standardize_all(pairs):
+    """standardize() for a list of (weight, eps) in ONE launch (zs_standardize_weight_multi): the stale ones of the list go
+    through a cached device table - after an optimiser step that is every StdConv weight of the model (52 launches before)."""
+    import numpy as np
+    import weakref
+    todo, seen = [], set()
+    for weight, eps in pairs:
+        rec = _STD.get(id(weight))
+        if rec is None or rec[0]() is not weight or rec[1] != float(eps):
+            rec = [weakref.ref(weight, lambda _r, k=id(weight): _STD.pop(k, None)), float(eps),
+                   torch.empty_like(weight.detach()), None]
+            _STD[id(weight)] = rec
+        if rec[3] != _stamp(weight) and id(weight) not in seen:
+            seen.add(id(weight))
+            todo.append((weight, rec))
+    if not todo:
+        return
+    if len(todo) == 1:
+        standardize(todo[0][0], todo[0][1][1])
+        return
+    lib = _lib.load()
+    device = todo[0][0].device
+    sig = tuple((w.data_ptr(), rec[2].data_ptr(), w.shape[0], w[0].numel(), rec[1]) for w, rec in todo)
+    cached = _STD_TABLE.get(device)
+    if cached is None or cached[0] != sig:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the set of standardised weights changed inside a stream capture; call "
+                               "zeroshape_amd.nn.autograd.refresh_packs(device) before capturing")
+        dt = np.dtype([("w", "<u8"), ("out", "<u8"), ("rows", "<i4"), ("n", "<i4"), ("eps", "<f4"), ("pad", "<i4")])
+        assert dt.itemsize == 32
+        tab = np.zeros(len(sig), dt)
+        prefix, total = [], 0
+        for i, e in enumerate(sig):
+            tab[i] = e + (0,)
+            prefix.append(total)
+            total += e[2]
+        cached = (sig, torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(device),
+                  torch.tensor(prefix, dtype=torch.int32).to(device), len(sig), total)
+        _STD_TABLE[device] = cached
+    _, tab_d, pre_d, n, total = cached
+    with _lib.on(device):
+        _lib.check(lib.zs_standardize_weight_multi(_lib.ptr(tab_d), _lib.ptr(pre_d), n, total, _lib.current_stream_ptr(device)),
+                   "zs_standardize_weight_multi")
+    for w, rec in todo:
+        rec[3] = _stamp(w)
+
+
 # ---- packed GEMM operands: persistent buffers, re-packed for ALL layers in one launch ----
 class _PackRec(object):
     # split / split_stamp: the operand's fp16 halves (optim.amp) and the stamp of the pack they were made from - a re-pack
@@ -147,6 +210,7 @@ def _drop_pack(key):
 def clear_pack_cache():
     _PACKS.clear()
     _STD.clear()
+    _STD_TABLE.clear()
     _PACK_TABLE.clear()
     _PACK_FAST.clear()
     _PACK_EPOCH[0] += 1
@@ -204,9 +268,7 @@ def _refresh_all_packs(device):
     if fast is not None and fast["epoch"] == _PACK_EPOCH[0] and fast["generation"] != GENERATION[0]:
         live = [(rec, rec.ref()) for rec in fast["recs"]]
         if all(w is not None and w.data_ptr() == ptr for (rec, w), ptr in zip(live, fast["ptrs"])):
-            for rec, w in live:
-                if rec.key[4] is not None:
-                    standardize(w, rec.key[4])
+            standardize_all([(w, rec.key[4]) for rec, w in live if rec.key[4] is not None])
             if _PACK_TABLE[device][0][-1] == _inline_split_mode():
                 _launch_multi_pack(lib, device, [rec for rec, _ in live])
                 for rec, w in live:
@@ -225,6 +287,7 @@ def _refresh_all_packs(device):
         return
     complete = len(recs) == sum(1 for rec in _PACKS.values() if rec.ref() is not None and rec.ref().device == device)
     entries = []
+    standardize_all([(w, rec.key[4]) for rec, w in recs if rec.key[4] is not None and w.device == device])
     for rec, w in recs:
         _, cin0, cin, dgrad, std_eps = rec.key
         src = standardize(w, std_eps) if std_eps is not None else w.detach()
@@ -445,7 +508,7 @@ def column_sum(x2d, scale=1.0):
     lib = _lib.load()
     rows, C = x2d.shape
     out = torch.empty(C, dtype=torch.float32, device=x2d.device)
-    ws = scratch(x2d.device, "colsum", lib.zs_column_sum_workspace_bytes(rows, C))
+    ws = scratch(x2d.device, "colsum", _ws_bytes("zs_column_sum_workspace_bytes", rows, C))
     with _lib.on(x2d.device):
         _lib.check(lib.zs_column_sum(_lib.ptr(x2d), _lib.ptr(out), rows, C, float(scale), _lib.ptr(ws), _stream(x2d)),
                    "zs_column_sum")
@@ -542,7 +605,7 @@ class _Conv(torch.autograd.Function):
             dw = torch.zeros_like(weight) if sub else torch.empty_like(weight)
             if want_b:          # the bias gradient rides on the weight-gradient kernel (it stages dY anyway)
                 db = torch.empty(cout, dtype=torch.float32, device=x.device)
-            ws = scratch(x.device, "wgrad", lib.zs_conv2d_wgrad_workspace_bytes(B, Ho, Wo, Cx, cout, kh, kw))
+            ws = scratch(x.device, "wgrad", _ws_bytes("zs_conv2d_wgrad_workspace_bytes", B, Ho, Wo, Cx, cout, kh, kw))
             flags = (_CONV_IN_RELU if in_relu else 0) | (_CONV_F16X3 if wgrad_precision() == "f16x3" else 0)
             with _lib.on(x.device):
                 _lib.check(lib.zs_conv2d_wgrad(_lib.ptr(x), _lib.ptr(gp), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws), B, H, W, Cx, Ho,
@@ -668,7 +731,7 @@ class _LayerNorm(torch.autograd.Function):
         dx = torch.empty_like(x)
         dg = torch.empty(C, dtype=torch.float32, device=x.device)
         db = torch.empty(C, dtype=torch.float32, device=x.device)
-        ws = scratch(x.device, "ln_bwd", lib.zs_layer_norm_bwd_workspace_bytes(rows, C))
+        ws = scratch(x.device, "ln_bwd", _ws_bytes("zs_layer_norm_bwd_workspace_bytes", rows, C))
         with _lib.on(x.device):
             _lib.check(lib.zs_layer_norm_bwd_add(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(gamma.detach()), _lib.ptr(add),
                                                  _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), rows, C, float(ctx.eps),
@@ -715,7 +778,7 @@ class _Attention(torch.autograd.Function):
         B, L, C3 = qkv.shape
         heads = ctx.heads
         dqkv = torch.empty_like(qkv)
-        ws = scratch(qkv.device, "attn_bwd", lib.zs_attention_bwd_workspace_bytes(B, L, heads))
+        ws = scratch(qkv.device, "attn_bwd", _ws_bytes("zs_attention_bwd_workspace_bytes", B, L, heads))
         with _lib.on(qkv.device):
             _lib.check(lib.zs_attention_bwd(_lib.ptr(qkv), _lib.ptr(dout), _lib.ptr(dqkv), _lib.ptr(ws), B, L, heads,
                                             C3 // 3 // heads, _stream(qkv)), "zs_attention_bwd")
@@ -751,7 +814,7 @@ class _PointAttention(torch.autograd.Function):
         B, M, C3 = qkv_p.shape
         Ll, C, heads = qkv_l.shape[1], C3 // 3, ctx.heads
         dp, dl = torch.empty_like(qkv_p), torch.empty_like(qkv_l)
-        ws = scratch(qkv_p.device, "pa_bwd", lib.zs_point_attention_bwd_workspace_bytes(B, M, Ll, heads))
+        ws = scratch(qkv_p.device, "pa_bwd", _ws_bytes("zs_point_attention_bwd_workspace_bytes", B, M, Ll, heads))
         with _lib.on(qkv_p.device):
             _lib.check(lib.zs_point_attention_bwd(_lib.ptr(qkv_p), _lib.ptr(qkv_l), _lib.ptr(dout), _lib.ptr(dp),
                                                   _lib.ptr(dl), 0, _lib.ptr(ws), B, M, Ll, heads, C // heads,
@@ -802,7 +865,7 @@ class _BCELogits(torch.autograd.Function):
         logits, sdf = _f32c(logits, "logits"), _f32c(sdf, "sdf")
         n = logits.numel()
         loss = torch.empty((), dtype=torch.float32, device=logits.device)
-        ws = scratch(logits.device, "bce", lib.zs_bce_logits_workspace_bytes(n))
+        ws = scratch(logits.device, "bce", _ws_bytes("zs_bce_logits_workspace_bytes", n))
         with _lib.on(logits.device):
             _lib.check(lib.zs_bce_logits(_lib.ptr(logits), _lib.ptr(sdf), n, float(thres), float(weight),
                                          _lib.ptr(loss), _lib.ptr(ws), _stream(logits)), "zs_bce_logits")
@@ -843,7 +906,7 @@ class _BatchNormTrain(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
         rstd = torch.empty(C, dtype=torch.float32, device=x.device)
-        ws = scratch(x.device, "bn", lib.zs_batch_norm_workspace_bytes(rows, C))
+        ws = scratch(x.device, "bn", _ws_bytes("zs_batch_norm_workspace_bytes", rows, C))
         res = None if residual is None else _f32c(residual, "batch_norm residual")
         with _lib.on(x.device):
             _lib.check(lib.zs_batch_norm_train(_lib.ptr(x), _lib.ptr(gamma.detach()), _lib.ptr(beta.detach()),
@@ -866,7 +929,7 @@ class _BatchNormTrain(torch.autograd.Function):
         dres = torch.empty_like(x) if (ctx.has_res and ctx.relu) else None
         dg = torch.empty(C, dtype=torch.float32, device=x.device)
         db = torch.empty(C, dtype=torch.float32, device=x.device)
-        ws = scratch(x.device, "bn", lib.zs_batch_norm_workspace_bytes(rows, C))
+        ws = scratch(x.device, "bn", _ws_bytes("zs_batch_norm_workspace_bytes", rows, C))
         with _lib.on(x.device):
             _lib.check(lib.zs_batch_norm_bwd(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(y), _lib.ptr(gamma.detach()),
                                              _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dg),
@@ -937,7 +1000,7 @@ class _GroupNorm(torch.autograd.Function):
         dres = torch.empty_like(x) if (has_res and relu) else None
         dg = torch.empty(C, dtype=torch.float32, device=x.device)
         db = torch.empty(C, dtype=torch.float32, device=x.device)
-        ws = scratch(x.device, "gn_bwd", lib.zs_group_norm_bwd_workspace_bytes(B, C))
+        ws = scratch(x.device, "gn_bwd", _ws_bytes("zs_group_norm_bwd_workspace_bytes", B, C))
         with _lib.on(x.device):
             _lib.check(lib.zs_group_norm_bwd(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(y), _lib.ptr(gamma.detach()),
                                              _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dg), _lib.ptr(db), B, H * W, C,
@@ -1361,7 +1424,7 @@ class _MidasLoss(torch.autograd.Function):
         m = _f32c(mask.float(), "depth mask")
         B, _, H, W = p.shape
         loss = torch.empty((), dtype=torch.float32, device=p.device)
-        ws = torch.empty((lib.zs_midas_loss_workspace_bytes(B) + 3) // 4, dtype=torch.float32, device=p.device)
+        ws = torch.empty((_ws_bytes("zs_midas_loss_workspace_bytes", B) + 3) // 4, dtype=torch.float32, device=p.device)
         with _lib.on(p.device):
             _lib.check(lib.zs_midas_loss(_lib.ptr(p), _lib.ptr(t), _lib.ptr(m), B, H, W, float(alpha), int(scales),
                                          1 if inverse_depth else 0, _lib.ptr(loss), _lib.ptr(ws), _stream(p)),
