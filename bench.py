@@ -28,9 +28,12 @@ Extra objects on the JSON line:
                  section 8d) x points per launch / mean launch duration from HIP events on the launch
                  stream.  For f16x3 every algorithmic product costs three fp16 MFMAs; the executed
                  matrix rate is reported beside it (`executed`).
-  exact_f32    - (f16x3 runs, N = 1) the same grid through the exact-fp32 kernel, outside the
-                 timed region: its rate, its roofline fraction, and the largest |logit| difference
-                 and the occupancy flips between the two arithmetics on the full grid.
+  exact_f32    - (f16x3 runs, N = 1) the SAME timed contract (warmup + steps of prologue + launch + sigmoid between
+                 barriers, launch event-timed inside each step) through the exact-fp32 kernel - the reference's own
+                 arithmetic: ms_per_step, value, its roofline object - and the largest |logit| difference and the
+                 occupancy flips between the two arithmetics on the full grid.
+  virtual_ranks_8 - (N = 1) what ONE rank of `--gpus 8` does per step (batch 8, its point range of every image), timed for
+                 every rank in turn on this GPU; `bound` = the compute-side weak-scaling bound (tools/bench_legs.py).
   cpu_baseline - the oracle (torch-CPU fp32 restatement of the reference, "port") timed on
                  this host's cores on a bounded sample of x-slices of the same grid.
   calibration  - Implicit.prepare's once-per-weight-version verdict on the requested arithmetic: max |f16x3 - f32| logit
@@ -225,8 +228,10 @@ def main():
     calibration = net.last_calibration
     stream = torch.cuda.current_stream(dev)       # the stream the C ABI launches on
 
-    def step(events=None):
-        st = net.prepare(latent)                   # per-image prologue (all images, every rank)
+    def step(events=None, precision=None):
+        # per-image prologue (all images, every rank; None: the configured arithmetic); N > 1: the per-image output check of
+        # image i on rank i % N, verdicts all-gathered (parallel.prepare_sharded)
+        st = net.prepare(latent, precision) if world == 1 else parallel.prepare_sharded(net, latent, precision=precision)
 
         def query(b, e):
             # the decoder launch of this step between two HIP events on its own stream (roofline.launch_ms_*: measured INSIDE the
@@ -286,18 +291,6 @@ def main():
     b, e, _ = parallel.point_bounds(G ** 3, world, rank)
     pts_launch = batch * (e - b)
 
-    def time_launches(precision, reps):
-        st = net.prepare(latent, precision)
-        net.query_grid_range(latent, axis, b, e, apply_sigmoid=True, state=st)
-        torch.cuda.synchronize()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
-        ev[0].record(stream)
-        for i in range(reps):
-            net.query_grid_range(latent, axis, b, e, apply_sigmoid=True, state=st)
-            ev[i + 1].record(stream)
-        torch.cuda.synchronize()
-        return sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps)), st
-
     def roofline_of(precision, kern_ms):
         mean = sum(kern_ms) / len(kern_ms)
         peak = PEAK_F16_MFMA_TFLOPS if precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
@@ -323,12 +316,28 @@ def main():
     exact_f32 = None
     logit_sweep = None
     if precision_run == "f16x3" and world == 1:
-        ms32, st32 = time_launches("f32", 3)
+        # the SAME timed contract in the reference's own arithmetic (options/shape.yaml:96 amp false; implicit.py:251-288 is
+        # fp32): `warmup` untimed + `steps` timed steps of prologue + exact-fp32 launch + sigmoid between the same barriers, the
+        # launch event-timed inside each step - the like-for-like-precision number, driver-checkable (ms_per_step x steps)
+        for _ in range(args.warmup):
+            step(precision="f32")
+        barrier()
+        ev32 = []
+        t32 = time.perf_counter()
+        for _ in range(args.steps):
+            step(ev32, precision="f32")
+        barrier()
+        dt32 = time.perf_counter() - t32
+        ms32 = sorted(a_.elapsed_time(b_) for a_, b_ in ev32)
         r32 = roofline_of("f32", ms32)
+        r32["launch_ms_source"] = "HIP events around the decoder launch inside each of the %d timed fp32 steps" % args.steps
+        st32 = net.prepare(latent, "f32")
         lg = net.query_grid(latent, axis, apply_sigmoid=False, state=st)
         lg32 = net.query_grid(latent, axis, apply_sigmoid=False, state=st32)
         flips = (lg > 0) != (lg32 > 0)
-        exact_f32 = {"value": round(pts_launch / (r32["launch_ms_mean"] * 1e-3), 1), "unit": "points/s",
+        exact_f32 = {"value": round(points_per_step * args.steps / dt32, 1), "unit": "points/s",
+                     "ms_per_step": round(dt32 / args.steps * 1e3, 3), "steps": args.steps, "warmup": args.warmup,
+                     "dtype": "f32", "roofline": r32,
                      "launch_ms_mean": r32["launch_ms_mean"], "roofline_frac": r32["frac"],
                      "roofline_peak": r32["peak"],
                      "max_abs_logit_diff": float((lg - lg32).abs().max()),
@@ -396,6 +405,7 @@ def main():
                          ("chamfer_l1", lambda: legs.eval_leg(dev, net, sd, vox128="chamfer_l1_vox128" not in skip)),
                          ("encoder", lambda: legs.encoder_leg(dev, cpu)),
                          ("encoder_att", lambda: legs.encoder_att_leg(dev)), ("vox256", lambda: legs.vox256_leg(dev, net)),
+                         ("virtual_ranks_8", lambda: legs.virtual_ranks_leg(dev, net)),
                          ("inference", lambda: legs.inference_leg(dev)), ("iso_surface", lambda: legs.surface_leg(dev)),
                          ("train_step", lambda: legs.in_subprocess("train", "train_step")),
                          ("trained_weights", lambda: legs.in_subprocess("trained", "trained_weights"))):

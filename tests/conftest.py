@@ -31,6 +31,13 @@ def decoder_golden():
 
 
 @pytest.fixture(scope="session")
+def grid_golden():
+    """Full 65^3 / 129^3 grids of the reference's own compute_level_grid (tests/golden/make_grid_golden.py)."""
+    import numpy as np
+    return dict(np.load(os.path.join(GOLDEN, "grid_golden.npz")))
+
+
+@pytest.fixture(scope="session")
 def geometry_golden():
     import numpy as np
     return dict(np.load(os.path.join(GOLDEN, "geometry_golden.npz")))

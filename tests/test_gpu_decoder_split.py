@@ -465,6 +465,28 @@ def test_per_image_check_sends_an_outlier_image_to_the_exact_kernels():
     g = m.query_grid(lat, axis, apply_sigmoid=False, state=st)
     ge = m.query_grid(lat, axis, apply_sigmoid=False, state=m.prepare(lat, "f32"))
     assert torch.equal(g[1], ge[1])
+    # the multi-GPU step's prepare (parallel.prepare_sharded): image i is checked by rank i % W only.  Rank 1 of 2 finds the
+    # outlier itself; rank 0 checks image 0 only and learns image 1's verdict from the exchange (here: a stand-in gather that
+    # delivers what rank 1 measured); both then return what the unsharded state returned, bit for bit
+    from zeroshape_amd import parallel
+    st1 = parallel.prepare_sharded(m, lat, rank=1, world_size=2, gather=parallel.solo_gather(1, 2))
+    assert st1.image_flags.cpu().tolist() == [0, 1]
+    mx = m.last_calibration["per_image_max_abs_diff"].cpu()
+    assert float(mx[0]) == -1.0 and float(mx[1]) > m.CALIBRATION_TOL          # image 0 was not measured on this rank
+    assert torch.equal(m.query_points(st1, pts), out)
+    st0_alone = parallel.prepare_sharded(m, lat, rank=0, world_size=2, gather=parallel.solo_gather(0, 2))
+    assert st0_alone.image_flags.cpu().tolist() == [0, 0]
+    seen = []
+
+    def gather_with_rank1(own):
+        seen.append(own.cpu().clone())
+        full = own.new_zeros((2,) + tuple(own.shape))
+        full[0], full[1] = own, st1.image_flags.new_tensor([[1, 1]])
+        return full
+    st0 = parallel.prepare_sharded(m, lat, rank=0, world_size=2, gather=gather_with_rank1)
+    assert seen[0].tolist() == [[0, 0]] and st0.image_flags.cpu().tolist() == [0, 1]
+    assert torch.equal(m.query_points(st0, pts), out)
+    assert torch.equal(m.query_grid(lat, axis, apply_sigmoid=False, state=st0), g)
 
 
 def test_dynamic_tile_order_leaves_its_counter_at_zero_and_changes_no_value(net):

@@ -88,6 +88,11 @@ def test_sharded_grid_rehearsal_on_one_gpu():
     rec = rh.main(["--world", "4", "--vox-res", "64", "--points", "512"])
     assert rec["gathered_equals_single_launch"] and rec["max_abs_occupancy_error_vs_oracle"] < 1e-4
     assert sum(rec["points_per_rank"]) == 65 ** 3 and max(rec["points_per_rank"]) - min(rec["points_per_rank"]) < 128 * 4
+    # the multi-GPU step's batch (more images than ranks, uneven): the per-image checks are sharded (image i on rank i % 2), the
+    # verdicts really exchanged between the processes, the gathered grids equal one process's unsharded launch bit for bit
+    rec = rh.main(["--world", "2", "--vox-res", "32", "--points", "256", "--batch", "3"])
+    assert rec["gathered_equals_single_launch"] and rec["max_abs_occupancy_error_vs_oracle"] < 1e-4
+    assert rec["image_flags_identical_on_every_rank"] is True
 
 
 def test_depth_engine_evaluates(tmp_path, encoder_sd):
@@ -166,6 +171,12 @@ def test_bench_line_contract():
     assert r["launch_ms_mean"] <= d["ms_per_step"] * 1.02           # the kernel is inside the step
     assert r["traffic"] is None or (r["traffic"] > pts * 4 and "stale" not in r["traffic_source"])
     assert d["exact_f32"]["occupancy_flips"] <= 2 and d["exact_f32"]["max_abs_logit_diff"] < 1e-4
+    # the exact-fp32 arithmetic under the same timed contract: its launch is inside its step, its value is its step time
+    x = d["exact_f32"]
+    assert x["steps"] == 3 and x["roofline"]["peak"] == 157.3 and x["roofline"]["launch_ms_mean"] <= x["ms_per_step"] * 1.02
+    assert abs(x["value"] - pts / (x["ms_per_step"] * 1e-3)) < 1e-3 * x["value"] and x["ms_per_step"] > d["ms_per_step"]
+    v = d["virtual_ranks_8"]
+    assert v["world"] == 8 and len(v["step_ms_per_rank"]) == 8 and sum(v["points_per_rank"]) == 8 * pts and 0.5 < v["bound"] < 1.1
     for leg in ("chamfer", "pose_search", "chamfer_l1", "encoder", "inference", "iso_surface", "train_step"):
         assert leg in d, leg
     assert d["iso_surface"]["vox128"]["triangles"] > 1000 and 0 < d["iso_surface"]["vox128"]["ms"] < 5

@@ -168,16 +168,32 @@ def _worker_in_place_uneven(rank, world, initfile):
         net = Net()
         red = parallel.GradReducer(net.parameters(), bucket_mb=0.3, pack_fn=torch_pack, module=net)
         red.armed = False
-        x = torch.randn(6, 40, generator=torch.Generator().manual_seed(70 + rank))
-        net(x, use_sometimes=rank == 0).pow(2).mean().backward()
+        ref = Net()
+        ref.load_state_dict(net.state_dict())
+        xs = [[torch.randn(6, 40, generator=torch.Generator().manual_seed(70 + 10 * it + r)) for r in range(world)] for it in range(3)]
+        net(xs[0][rank], use_sometimes=rank == 0).pow(2).mean().backward()       # "the capture": rank 1's graph has no `sometimes`
         assert (net.sometimes.grad is None) == (rank == 1)
-        red.reduce_in_place()
-        assert net.sometimes.grad is not None and net.unused.weight.grad is None
-        for p in (net.sometimes, net.c.weight):
-            g = [torch.zeros_like(p.grad) for _ in range(world)]
-            dist.all_gather(g, p.grad.contiguous())
-            assert all(torch.equal(g[0], t) for t in g)
-        assert float(net.sometimes.grad.abs().sum()) > 0
+        local = [p for p in net.parameters() if p.grad is not None]
+        for it in range(3):
+            # CONSECUTIVE steps: a replay overwrites the gradients of ITS graph only - the average the previous
+            # reduce_in_place() lent to a parameter without a local gradient must not be packed as this rank's contribution
+            if it:
+                for p in local:
+                    p.grad.zero_()
+                net(xs[it][rank], use_sometimes=rank == 0).pow(2).mean().backward()
+            red.reduce_in_place()
+            assert net.sometimes.grad is not None and net.unused.weight.grad is None
+            ref.zero_grad(set_to_none=True)
+            for r in range(world):
+                (ref(xs[it][r], use_sometimes=r == 0).pow(2).mean() / world).backward()
+            for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+                if p.grad is not None:
+                    assert torch.allclose(p.grad, q.grad, atol=1e-6, rtol=1e-5), (it, n)     # the TRUE mean, every step
+            for p in (net.sometimes, net.c.weight):
+                g = [torch.zeros_like(p.grad) for _ in range(world)]
+                dist.all_gather(g, p.grad.contiguous())
+                assert all(torch.equal(g[0], t) for t in g)
+            assert float(net.sometimes.grad.abs().sum()) > 0
         red.close()
     finally:
         dist.destroy_process_group()

@@ -56,6 +56,20 @@ def _worker(rank, world, initfile, G, B):
         cover[b:e] = 1
         dist.all_reduce(cover)
         assert torch.all(cover == 1)
+        # sharded per-image check of Implicit.prepare (parallel.prepare_sharded): image i's verdict pair comes from rank i % W
+        for batch in (1, world, world + 1, 2 * world + 1):
+            k = (batch + world - 1) // world
+            mine = list(range(rank, batch, world))
+            own = torch.zeros(k, 2, dtype=torch.int32)
+            for slot, i in enumerate(mine):
+                own[slot, 0], own[slot, 1] = 10 * i + 1, 10 * i + 2          # (what only image i's owner knows)
+            got_flags = parallel.exchange_image_flags(own, batch)
+            want_flags = torch.tensor([[10 * i + 1, 10 * i + 2] for i in range(batch)], dtype=torch.int32)
+            assert got_flags.dtype == torch.int32 and torch.equal(got_flags, want_flags), (rank, batch, got_flags)
+            # the single-process stand-in of the collective places this rank's slots where the collective would
+            solo = parallel.exchange_image_flags(own, batch, gather=parallel.solo_gather(rank, world))
+            for i in range(batch):
+                assert torch.equal(solo[i], want_flags[i] if i % world == rank else torch.zeros(2, dtype=torch.int32))
         # the sharded pose search refuses ranks that hold different clouds
         from zeroshape_amd.utils.eval_3D import _check_identical_inputs
         pred, gt, order = torch.randn(50, 3), torch.randn(1, 40, 3), torch.arange(24, dtype=torch.int32)

@@ -444,6 +444,71 @@ def vox256_leg(dev, net):
                                 "sum_over_whole": round(sum(per) / ms, 3)}}
 
 
+def virtual_ranks_leg(dev, net, world=8, N=128, steps=6, distributed_prepare=None):
+    """EXACTLY what one rank of `bench.py --gpus <world>` does in a step, timed on ONE GPU for every rank r in turn
+    (the 8-GPU step had never been timed, not even virtually): a batch of `world` images, the step's
+    prepare() (per-image prologues + the per-image f16x3-vs-fp32 probe checks) and ONE decoder launch over rank r's
+    `parallel.point_bounds` range of EVERY image (`world` different 10 MB programs in flight, tiles image-major).  The N = 1
+    step (one image, the whole grid) is timed the same way in the same process: `bound` = ms(N = 1) / max_r ms(rank r) is the
+    compute-side weak-scaling bound - what `--gpus 8` could reach at best if the all_gather were free.
+    distributed_prepare: None / True = bench.py's step for N > 1 (`parallel.prepare_sharded`: every rank runs every prologue,
+    the per-image check of image i runs on rank i % world only; the 8-byte all_gather of the verdicts is stood in for by
+    `parallel.solo_gather`); False = every rank also checks every image (round 5's step)."""
+    from zeroshape_amd import parallel, synthetic as syn
+    G = N + 1
+    axis = torch.linspace(-1.5, 1.5, G, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    if distributed_prepare is None:
+        distributed_prepare = True
+
+    def timed(latent, b, e, rank=None):
+        """-> (ms per step: perf_counter between synchronisations, mean launch ms: HIP events around the decoder launch)"""
+        W = latent.shape[0]
+
+        def step(ev=None):
+            if rank is not None and distributed_prepare:
+                st = parallel.prepare_sharded(net, latent, rank=rank, world_size=W, gather=parallel.solo_gather(rank, W))
+            else:
+                st = net.prepare(latent)
+            if ev is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+            out = net.query_grid_range(latent, axis, b, e, apply_sigmoid=True, state=st)
+            if ev is not None:
+                e1.record(stream)
+                ev.append((e0, e1))
+            return out
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        ev = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(ev)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        return ms, sum(a.elapsed_time(b_) for a, b_ in ev) / len(ev)
+
+    one_ms, one_launch = timed(torch.from_numpy(syn.seeded_latent(0, 1)).to(dev), 0, G ** 3)
+    latent = torch.from_numpy(syn.seeded_latent(0, world)).to(dev)
+    rows = []
+    for r in range(world):
+        b, e, _ = parallel.point_bounds(G ** 3, world, r)
+        ms, launch = timed(latent, b, e, rank=r)
+        rows.append((ms, launch, world * (e - b)))
+    worst = max(ms for ms, _, _ in rows)
+    return {"world": world, "vox_res": N, "steps": steps, "distributed_prepare": bool(distributed_prepare),
+            "n1_step_ms": round(one_ms, 3), "n1_launch_ms": round(one_launch, 3),
+            "step_ms_per_rank": [round(ms, 3) for ms, _, _ in rows],
+            "launch_ms_per_rank": [round(l, 3) for _, l, _ in rows],
+            "prepare_and_check_ms_per_rank": [round(ms - l, 3) for ms, l, _ in rows],
+            "points_per_rank": [p for _, _, p in rows],
+            "bound": round(one_ms / worst, 4),
+            "what": "one GPU plays every rank of `bench.py --gpus %d` in turn: batch %d, the step's prepare (incl. per-image checks) + one "
+                    "launch over the rank's point range of every image; bound = n1_step_ms / max(step_ms_per_rank); the RCCL "
+                    "all_gather of the results (8.6 MB per image) is NOT in it" % (world, world)}
+
+
 def inference_leg(dev):
     """BASELINE config 2 ("shape_engine inference, synthetic 224x224 RGB + mask, vox_res=64", one image): image ->
     latent (Graph.forward as one hipGraph) -> 65^3 occupancy grid (prologue + fused decoder), and the evaluation

@@ -43,10 +43,13 @@ def worker(rank, world, initfile, a, out_path):
         net.load_state_dict(sd, strict=True)
         net = net.to(dev).eval()
         net.precision = a.precision
-        latent_c = torch.from_numpy(syn.seeded_latent(2, 1))
+        latent_c = torch.from_numpy(syn.seeded_latent(2, a.batch))
         latent = latent_c.to(dev)
         axis = torch.linspace(-1.5, 1.5, G, device=dev)
-        st = net.prepare(latent)
+        # the multi-GPU step's prepare: every prologue on every rank, image i's output check on rank i % world, the verdicts
+        # all-gathered (here: gloo on CUDA tensors)
+        st = parallel.prepare_sharded(net, latent)
+        torch.cuda.synchronize()
         b, e, per = parallel.point_bounds(P, world, rank)
         net.query_grid_range(latent, axis, b, min(e, b + 4096), state=st)      # warm-up (workspace, code object)
         torch.cuda.synchronize()
@@ -67,19 +70,26 @@ def worker(rank, world, initfile, a, out_path):
             dist.barrier()
         dist.all_reduce(ms)
         full = parallel.sharded_level_grid_points(lambda bb, ee: local.cpu(), G)     # the product's partition + gather
-        assert full.shape == (1, G, G, G)
+        assert full.shape == (a.batch, G, G, G)
+        flags_everywhere = None
+        if st.image_flags is not None:
+            fl = torch.stack([st.image_flags, st.image_flags_occ], -1).cpu()
+            every = [torch.zeros_like(fl) for _ in range(world)]
+            dist.all_gather(every, fl)
+            flags_everywhere = bool(all(torch.equal(every[0], t) for t in every)) and tuple(fl.shape) == (a.batch, 2)
         if rank == 0:
-            single = net.query_grid_range(latent, axis, 0, P, apply_sigmoid=True, state=st).cpu().view(1, G, G, G)
+            single = net.query_grid_range(latent, axis, 0, P, apply_sigmoid=True, state=net.prepare(latent)).cpu().view(a.batch, G, G, G)
             rs = np.random.RandomState(3)
             idx = rs.randint(0, G, size=(a.points, 3))
             ax = axis.cpu()
             pts = torch.stack([ax[idx[:, 0]], ax[idx[:, 1]], ax[idx[:, 2]]], -1)[None]
-            want, _ = decoder_ref.implicit_forward(sd, latent_c, pts)
-            got = full[0, idx[:, 0], idx[:, 1], idx[:, 2]]
-            err = float((got - torch.sigmoid(want[0])).abs().max())
+            want, _ = decoder_ref.implicit_forward(sd, latent_c, pts.expand(a.batch, -1, -1))
+            got = full[:, idx[:, 0], idx[:, 1], idx[:, 2]]
+            err = float((got - torch.sigmoid(want)).abs().max())
             times = ms.tolist()
             mean = sum(times) / len(times)
-            rec = {"world": world, "vox_res": a.vox_res, "points": P, "precision": a.precision,
+            rec = {"world": world, "vox_res": a.vox_res, "points": P, "precision": a.precision, "batch": a.batch,
+                   "image_flags_identical_on_every_rank": flags_everywhere,
                    "points_per_rank": [min(P, (r + 1) * per) - min(P, r * per) for r in range(world)],
                    "launch_ms_per_rank": [round(t, 3) for t in times], "launches_per_rank": a.repeats,
                    "imbalance_max_over_mean": round(max(times) / mean - 1.0, 5),
@@ -100,6 +110,7 @@ def main(argv=None):
     ap.add_argument("--vox-res", type=int, default=256)
     ap.add_argument("--points", type=int, default=4096)
     ap.add_argument("--precision", default="f16x3")
+    ap.add_argument("--batch", type=int, default=1, help="images per step (bench.py --gpus N: N)")
     ap.add_argument("--repeats", type=int, default=4, help="launches per rank; the fastest is reported")
     a = ap.parse_args(argv)
     with tempfile.TemporaryDirectory() as d:

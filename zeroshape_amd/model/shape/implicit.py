@@ -304,8 +304,14 @@ class Implicit(nn.Module):
         return ok, ok_occ
 
     @torch.no_grad()
-    def prepare(self, latent_depth, precision=None, calibrate=None):
+    def prepare(self, latent_depth, precision=None, calibrate=None, shard=None):
         """Per-image prologue: latent_depth [B,197,C] (any float dtype, GPU) -> DecoderState.
+        ``shard``: None, or (rank, world, exchange) when the grid of every image is sharded over `world` ranks that all hold the
+        whole batch (parallel.prepare_sharded): every rank runs every prologue (0.5 ms at any batch up to 8, bit-identical
+        programs everywhere, no collective), but the per-image f16x3-vs-fp32 CHECK of image i - 4,096 probe points through both
+        kernels, 6 % of a rank's step when all 8 images are checked by all 8 ranks - runs on rank i % world only; ``exchange``
+        (own int32 [k, 2] -> [B, 2]; parallel.exchange_image_flags: one 8k-byte all_gather) completes the flags on the check's
+        side stream.
         ``precision``: None = self.precision.  "f16x3" is a request: outside the host envelope (W_MAX), or when
         the calibration of these weights fails BOTH rules (raw logits beyond CALIBRATION_TOL and occupancies beyond
         CALIBRATION_TOL_OCC / an index flip), the state returned is an fp32 one (``state.precision`` says which).  A split
@@ -346,11 +352,33 @@ class Implicit(nn.Module):
                 state = DecoderState(split, B, "f16x3", exact=programs)
                 state.logit_ok, state.occ_ok = ok, ok_occ
                 if self.image_check:
-                    self._launch_image_check(state, split, programs)
+                    self._launch_image_check(state, split, programs, shard)
                 return state
         return DecoderState(programs, B)
 
-    def _launch_image_check(self, state, split, exact):
+    def _sharded_image_check(self, split, exact, shard, streams=None):
+        """_image_check() of this rank's images (rank, rank + world, ...) + the exchange that completes the flags: the same
+        four tensors, over the whole batch (the maxima of the other ranks' images are not exchanged: -1)."""
+        rank, world, exchange = shard
+        B = split.shape[0]
+        k = (B + world - 1) // world
+        a = streams[0] if streams is not None else None
+        ctx = (lambda st: torch.cuda.stream(st)) if streams is not None else (lambda st: contextlib.nullcontext())
+        mine = len(range(rank, B, world))
+        if mine:
+            # (a strided view of the programs: the C ABI takes the program stride)
+            f, f_occ, mx, mx_occ = self._image_check(split[rank::world], exact[rank::world], streams=streams)
+        with ctx(a):
+            own = torch.zeros(k, 2, dtype=torch.int32, device=split.device)
+            maxima = torch.full((B,), -1.0, dtype=torch.float32, device=split.device)
+            maxima_occ = maxima.clone()
+            if mine:
+                own[:mine, 0], own[:mine, 1] = f, f_occ
+                maxima[rank::world], maxima_occ[rank::world] = mx, mx_occ
+            flags = exchange(own, B)                    # [B, 2] on every rank
+            return flags[:, 0].contiguous(), flags[:, 1].contiguous(), maxima, maxima_occ
+
+    def _launch_image_check(self, state, split, exact, shard=None):
         """The per-image check on a SIDE stream, so that it runs beside the first grid launch instead of in front of it: the
         fp32 probe launch alone is the latency of one fp32 wave tile (1.2 ms however few points).  The state carries the
         flags and an event; the query paths wait for the event (on their stream, no host wait) between the split launch and
@@ -359,7 +387,8 @@ class Implicit(nn.Module):
         dev = split.device
         main = torch.cuda.current_stream(dev)
         if torch.cuda.is_current_stream_capturing() or os.environ.get("ZS_DECODER_CHECK_INLINE", "0") != "0":
-            state.image_flags, state.image_flags_occ, maxima, maxima_occ = self._image_check(split, exact)
+            state.image_flags, state.image_flags_occ, maxima, maxima_occ = \
+                self._image_check(split, exact) if shard is None else self._sharded_image_check(split, exact, shard)
             self._last_check_event = None
         else:
             pair = self._check_streams.get(str(dev))
@@ -379,7 +408,9 @@ class Implicit(nn.Module):
                 head = torch.cuda.Event()
                 head.record(st_)
                 main.wait_event(head)
-            state.image_flags, state.image_flags_occ, maxima, maxima_occ = self._image_check(split, exact, streams=(side, side2))
+            state.image_flags, state.image_flags_occ, maxima, maxima_occ = \
+                self._image_check(split, exact, streams=(side, side2)) if shard is None else \
+                self._sharded_image_check(split, exact, shard, streams=(side, side2))
             state.check_event = torch.cuda.Event()
             state.check_event.record(side)
             # the side streams read `split` / `exact` (10 MB per image each): they must outlive that work even if the caller drops

@@ -108,6 +108,47 @@ def sharded_level_grid_points(query_range, G, group=None):
     return gather_points(local, P, group).view(local.shape[0], G, G, G)
 
 
+def exchange_image_flags(own, batch, group=None, gather=None):
+    """The per-image verdicts of Implicit.prepare()'s f16x3-vs-fp32 check when the CHECK is sharded (image i on rank i % W):
+    own = int32 [k, 2] (k = ceil(batch / W): this rank's images rank, rank + W, ... in order, zero padded; columns = raw-logit
+    rule, occupancy rule) -> [batch, 2] on every rank with ONE all_gather_into_tensor of 8 k bytes.
+    ``gather``: own -> [W, k, 2] stand-in for the collective (single-process rehearsals: tools/bench_legs.virtual_ranks_leg)."""
+    if gather is not None:
+        out = gather(own)
+    else:
+        rank, W = world(group)
+        if W == 1:
+            return own[:batch]
+        out = own.new_empty((W,) + tuple(own.shape))
+        dist.all_gather_into_tensor(out.view(-1), own.contiguous().view(-1), group=group)
+    W, k = out.shape[0], out.shape[1]
+    return out.permute(1, 0, 2).reshape(k * W, 2)[:batch].contiguous()      # image i = slot i // W of rank i % W
+
+
+def solo_gather(rank, world_size):
+    """gather stand-in of exchange_image_flags for ONE process playing rank `rank` of `world_size`: the other ranks' verdicts are
+    "passed" (zeros) - what the step costs is what is being rehearsed, the flags of the other images are not."""
+    def gather(own):
+        out = own.new_zeros((world_size,) + tuple(own.shape))
+        out[rank] = own
+        return out
+    return gather
+
+
+def prepare_sharded(net, latent, group=None, rank=None, world_size=None, gather=None, precision=None):
+    """Implicit.prepare() for a batch whose grids are sharded over the ranks (sharded_level_grid_points): every rank needs every
+    image's program, and gets them by running every prologue itself - measured 0.55 ms for 1 image and for 8 (latency-bound;
+    the programs are bit-identical everywhere: same kernel, same inputs), cheaper than any collective - but the per-image
+    output check of image i runs on rank i % W only and the 8-byte verdicts are all-gathered.  (Round 5: every rank checked
+    every image - 8 x 4,096 probe points through both kernels beside a launch of 2.1 M points: +1.75 ms on a 28 ms step.)"""
+    if rank is None or world_size is None:
+        rank, world_size = world(group)
+    if world_size == 1 and gather is None:
+        return net.prepare(latent, precision)
+    return net.prepare(latent, precision,
+                       shard=(rank, world_size, lambda own, batch: exchange_image_flags(own, batch, group, gather)))
+
+
 def rotation_range(n_rot, world_size, rank, batch=24):
     """contiguous rotation range of ``rank``, aligned to the reference's batches of 24
     so every rank evaluates whole batches (utils/eval_3D.py:149-152)."""
@@ -243,6 +284,7 @@ class GradReducer(object):
         self._hooks = []
         self.armed = True              # False during gradient-accumulation micro-steps: hooks stay quiet
         self.next_launch = 0           # collectives go out in bucket order
+        self._lent = []                # reduce_in_place: parameters whose .grad is an average this reducer put there
         if self.world > 1 or self.always:
             with torch.no_grad():
                 for p in params:
@@ -358,6 +400,12 @@ class GradReducer(object):
             dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)    # one layout on every rank
             mask = mask.cpu().tolist()
             self._build({id(p) for p, u in zip(self.params, mask) if u})
+        # averages handed out last time to parameters WITHOUT a local gradient are not this rank's contribution: the replay does
+        # not write them (they are not in this rank's graph), so left in .grad they would be packed again as "local" gradients -
+        # a stale term in every rank's average from the second step on
+        for q in self._lent:
+            q.grad = None
+        self._lent = []
         self.next_launch = 0
         self._launch_ready(flush=True, in_place=True)
         for w in self.works:
@@ -374,6 +422,7 @@ class GradReducer(object):
                     # in the layout (used on SOME rank) but without a local gradient: take the average like finish() does - a
                     # private copy, the bucket is reused - or the ranks' parameters drift apart under uneven usage
                     q.grad = self.flat[bi][off:off + q.numel()].view_as(q).clone()
+                    self._lent.append(q)
             if back:
                 self.pack_fn(back, 1.0, self.flat[bi].device)
             self.pending[bi] = len(plist)
