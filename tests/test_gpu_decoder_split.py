@@ -469,13 +469,17 @@ def test_per_image_check_sends_an_outlier_image_to_the_exact_kernels():
     # outlier itself; rank 0 checks image 0 only and learns image 1's verdict from the exchange (here: a stand-in gather that
     # delivers what rank 1 measured); both then return what the unsharded state returned, bit for bit
     from zeroshape_amd import parallel
+
+    def flags_of(state):          # (written on the check's side stream: this stream waits for its event, as the query paths do)
+        torch.cuda.current_stream().wait_event(state.check_event)
+        return state.image_flags.cpu().tolist()
     st1 = parallel.prepare_sharded(m, lat, rank=1, world_size=2, gather=parallel.solo_gather(1, 2))
-    assert st1.image_flags.cpu().tolist() == [0, 1]
+    assert flags_of(st1) == [0, 1]
     mx = m.last_calibration["per_image_max_abs_diff"].cpu()
     assert float(mx[0]) == -1.0 and float(mx[1]) > m.CALIBRATION_TOL          # image 0 was not measured on this rank
     assert torch.equal(m.query_points(st1, pts), out)
     st0_alone = parallel.prepare_sharded(m, lat, rank=0, world_size=2, gather=parallel.solo_gather(0, 2))
-    assert st0_alone.image_flags.cpu().tolist() == [0, 0]
+    assert flags_of(st0_alone) == [0, 0]
     seen = []
 
     def gather_with_rank1(own):
@@ -484,7 +488,7 @@ def test_per_image_check_sends_an_outlier_image_to_the_exact_kernels():
         full[0], full[1] = own, st1.image_flags.new_tensor([[1, 1]])
         return full
     st0 = parallel.prepare_sharded(m, lat, rank=0, world_size=2, gather=gather_with_rank1)
-    assert seen[0].tolist() == [[0, 0]] and st0.image_flags.cpu().tolist() == [0, 1]
+    assert flags_of(st0) == [0, 1] and seen[0].tolist() == [[0, 0]]
     assert torch.equal(m.query_points(st0, pts), out)
     assert torch.equal(m.query_grid(lat, axis, apply_sigmoid=False, state=st0), g)
 
