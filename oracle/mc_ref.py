@@ -7,20 +7,207 @@ Reference step being replaced: utils/eval_3D.py:233-263 - ``mcubes.marching_cube
 Both packages are un-vendored dependencies that are NOT installable here -> **parity
 unpinned**: this file restates the published algorithm (classic marching cubes on the
 Bourke corner/edge numbering with a case bit set when value < iso; linear interpolation on
-edges; area-weighted triangle choice + uniform barycentric sample with reflection) on the
-build-owned case tables of zeroshape_amd/mc_tables.py, with the device code's exact
+edges; area-weighted triangle choice + uniform barycentric sample with reflection) with the device code's exact
 operation order so triangles can be compared bit for bit.  What it cannot pin: PyMCubes'
 choice inside ambiguous cubes and trimesh's random stream (the reference's sampled cloud is
 not reproducible run to run either).
+
+The 256 case tables are the ORACLE'S OWN (round 6; until round 5 this file imported the product's
+zeroshape_amd/mc_tables.py, so a wrong table entry was invisible to every comparison):
+  * ``build_case_tables()`` derives them GEOMETRICALLY - faces are found from corner coordinates, their corners ordered
+    by angle, the contour segments of a face come from the marching-squares rule on its four corner states (two
+    diagonal inside corners are each cut off by their own segment), a segment's direction from a cross product
+    (inside on the left, seen from outside the cube), the loops from linking segments over shared cube edges; each loop
+    is fan-triangulated from its lowest edge id - none of the product generator's face cycles or run walking;
+  * ``verify_case_tables(table, count)`` checks ANY table exhaustively without generating one: every triangle corner
+    is a sign-change edge, no directed half-edge twice, every unmatched half-edge is exactly one of the face's directed
+    contour segments and every such segment is there (the mesh of a cube is a manifold whose boundary is the face
+    contours, consistently oriented), and for all 256 x 3 x 16 (cube, axis, neighbour) pairs the two cubes put the
+    same segments, reversed, on their shared face: crack-free for every sign pattern, not on a sphere.
+tests/test_oracle_mc.py holds the product's tables to both, and shows that changing any single entry of any row fails.
 """
 import numpy as np
 
-from zeroshape_amd import mc_tables as T
-
+# the published numbering (Bourke / PyMCubes): corner i of a cube, the two corners of edge e
+CORNERS = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0],
+                    [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]], np.int32)
 _EA = np.array([0, 1, 3, 0, 4, 5, 7, 4, 0, 1, 2, 3])   # low-coordinate endpoint of each edge
 _EB = np.array([1, 2, 2, 3, 5, 6, 6, 7, 4, 5, 6, 7])
 _AXIS = np.array([0, 1, 0, 1, 0, 1, 0, 1, 2, 2, 2, 2])
 M64 = (1 << 64) - 1
+MAX_TRIS = 5
+
+
+# ----------------------------------------------------------------------------- #
+# case tables: the oracle's own derivation and its table-independent verifier
+# ----------------------------------------------------------------------------- #
+def _edge_of(a, b):
+    for e in range(12):
+        if {int(_EA[e]), int(_EB[e])} == {int(a), int(b)}:
+            return e
+    raise KeyError((a, b))
+
+
+def _faces():
+    """[(axis, side, outward normal, corners in cyclic order)] from the corner coordinates alone."""
+    out = []
+    for axis in range(3):
+        for side in (0, 1):
+            n = np.zeros(3)
+            n[axis] = 1.0 if side else -1.0
+            cs = [c for c in range(8) if CORNERS[c][axis] == side]
+            ctr = CORNERS[cs].mean(0)
+            u = (CORNERS[cs[0]] - ctr).astype(np.float64)
+            v = np.cross(n, u)                                    # counter-clockwise about the outward normal
+            cs.sort(key=lambda c: np.arctan2(np.dot(CORNERS[c] - ctr, v), np.dot(CORNERS[c] - ctr, u)))
+            out.append((axis, side, n, cs))
+    return out
+
+
+_FACES = _faces()
+
+
+def _mid(e):
+    return 0.5 * (CORNERS[_EA[e]] + CORNERS[_EB[e]])
+
+
+def face_segments(case, face):
+    """Directed contour segments [(edge_from, edge_to)] of one face: marching squares on its four corner states, diagonal
+    inside corners cut off one by one; inside (value < iso, bit set) on the LEFT of from -> to, seen from outside."""
+    axis, side, n, cs = face
+    ins = [(case >> c) & 1 for c in cs]
+    cross = [i for i in range(4) if ins[i] != ins[(i + 1) % 4]]           # boundary edge i joins cs[i], cs[i+1]
+    if not cross:
+        return []
+    pairs = []
+    if len(cross) == 2:
+        q = next(cs[i] for i in range(4) if ins[i])
+        pairs.append((cross[0], cross[1], q))
+    else:                                                               # alternating states: each inside corner alone
+        for i in range(4):
+            if ins[i]:
+                pairs.append(((i - 1) % 4, i, cs[i]))                   # the two boundary edges that meet at cs[i]
+    segs = []
+    for i, j, q in pairs:
+        a, b = _edge_of(cs[i], cs[(i + 1) % 4]), _edge_of(cs[j], cs[(j + 1) % 4])
+        pa, pb = _mid(a), _mid(b)
+        if np.dot(np.cross(pb - pa, CORNERS[q] - pa), n) < 0:           # q must be on the left
+            a, b = b, a
+        segs.append((a, b))
+    return segs
+
+
+def case_segments(case):
+    return [s for f in _FACES for s in face_segments(case, f)]
+
+
+def build_case_tables():
+    """-> (tri_table int8 [256, 15], tri_count int32 [256]) - see the module docstring."""
+    table = -np.ones((256, 3 * MAX_TRIS), np.int8)
+    count = np.zeros(256, np.int32)
+    for case in range(256):
+        nxt = {}
+        for a, b in case_segments(case):
+            assert a not in nxt, "two contour segments leave edge %d in case %d" % (a, case)
+            nxt[a] = b
+        assert sorted(nxt) == sorted(nxt.values())
+        tris, seen = [], set()
+        for start in sorted(nxt):
+            if start in seen:
+                continue
+            loop, e = [], start
+            while e not in seen:
+                seen.add(e)
+                loop.append(e)
+                e = nxt[e]
+            assert e == start and len(loop) >= 3
+            tris += [(loop[0], loop[k], loop[k + 1]) for k in range(1, len(loop) - 1)]
+        assert len(tris) <= MAX_TRIS
+        count[case] = len(tris)
+        table[case, :3 * len(tris)] = np.array(tris, np.int8).reshape(-1)
+    return table, count
+
+
+TRI_TABLE, TRI_COUNT = build_case_tables()
+
+
+def _boundary_half_edges(row, n_tris):
+    """(errors, unmatched directed half-edges) of the triangles of one table row."""
+    errs, half = [], {}
+    for t in range(n_tris):
+        tri = [int(x) for x in row[3 * t:3 * t + 3]]
+        if len(set(tri)) != 3:
+            errs.append("triangle %d is degenerate %s" % (t, tri))
+        for k in range(3):
+            h = (tri[k], tri[(k + 1) % 3])
+            if h in half:
+                errs.append("directed half-edge %s twice" % (h,))
+            half[h] = t
+    return errs, {h for h in half if (h[1], h[0]) not in half}
+
+
+def verify_case(case, row, n_tris):
+    """Errors of ONE row (empty list = the row is a consistently oriented manifold mesh whose boundary is exactly the
+    contour of the six faces)."""
+    row = np.asarray(row).astype(np.int64)
+    errs = []
+    if not (0 <= n_tris <= MAX_TRIS):
+        return ["triangle count %d" % n_tris]
+    if np.any(row[3 * n_tris:] != -1):
+        errs.append("entries beyond the count are not -1")
+    used = row[:3 * n_tris]
+    crossing = {e for e in range(12) if ((case >> int(_EA[e])) & 1) != ((case >> int(_EB[e])) & 1)}
+    if np.any(used < 0) or np.any(used > 11):
+        return errs + ["edge id out of range"]
+    if set(used.tolist()) != crossing:
+        errs.append("vertices %s are not the sign-change edges %s" % (sorted(set(used.tolist())), sorted(crossing)))
+    e2, boundary = _boundary_half_edges(row, n_tris)
+    errs += e2
+    want = set(case_segments(case))
+    if boundary != want:
+        errs.append("mesh boundary %s is not the face contour %s" % (sorted(boundary), sorted(want)))
+    return errs
+
+
+def _shift_edge(e, axis):
+    """The edge of the -axis face of the NEXT cube that coincides with edge e of this cube's +axis face."""
+    a, b = CORNERS[_EA[e]].copy(), CORNERS[_EB[e]].copy()
+    assert a[axis] == 1 and b[axis] == 1
+    a[axis] = b[axis] = 0
+    ca = next(c for c in range(8) if np.array_equal(CORNERS[c], a))
+    cb = next(c for c in range(8) if np.array_equal(CORNERS[c], b))
+    return _edge_of(ca, cb)
+
+
+def verify_case_tables(table, count):
+    """Exhaustive check of a whole table (module docstring).  -> list of error strings, empty when the table is sound."""
+    table, count = np.asarray(table), np.asarray(count)
+    errs = []
+    if table.shape != (256, 3 * MAX_TRIS) or count.shape != (256,):
+        return ["table shapes %s %s" % (table.shape, count.shape)]
+    bnd = []
+    for case in range(256):
+        errs += ["case %d: %s" % (case, m) for m in verify_case(case, table[case], int(count[case]))]
+        bnd.append(_boundary_half_edges(table[case].astype(np.int64), int(count[case]))[1])
+    # neighbours: cube `c` and the next cube along `axis` share c's +axis face; whatever the other four corners of either cube
+    for axis in range(3):
+        plus = [c for c in range(8) if CORNERS[c][axis] == 1]
+        on_plus = {e for e in range(12) if CORNERS[_EA[e]][axis] == 1 and CORNERS[_EB[e]][axis] == 1}
+        on_minus = {e for e in range(12) if CORNERS[_EA[e]][axis] == 0 and CORNERS[_EB[e]][axis] == 0}
+        twin = {c: next(k for k in range(8) if np.array_equal(CORNERS[k] + np.eye(3, dtype=np.int32)[axis], CORNERS[c]))
+                for c in plus}                                   # corner of the next cube that IS corner c of this one
+        shift = {e: _shift_edge(e, axis) for e in on_plus}
+        for c in range(256):
+            mine = {(shift[b], shift[a]) for a, b in bnd[c] if a in on_plus and b in on_plus}      # reversed: seen from the other side
+            fixed = sum(((c >> k) & 1) << twin[k] for k in plus)
+            free = [k for k in range(8) if CORNERS[k][axis] == 1]
+            for other in range(16):
+                c2 = fixed | sum(((other >> i) & 1) << free[i] for i in range(4))
+                theirs = {(a, b) for a, b in bnd[c2] if a in on_minus and b in on_minus}
+                if mine != theirs:
+                    errs.append("cases %d | %d disagree on their shared face along axis %d: %s vs %s"
+                                % (c, c2, axis, sorted(mine), sorted(theirs)))
+    return errs
 
 
 def _fma32(a, b, c):
@@ -37,18 +224,18 @@ def marching_cubes(vol, iso, scale, offset):
     C = G - 1
     iso = np.float32(iso)
     scale, offset = np.float32(scale), np.float32(offset)
-    corners = np.asarray(T.CORNERS)
+    corners = np.asarray(CORNERS)
     f = np.stack([vol[c[0]:c[0] + C, c[1]:c[1] + C, c[2]:c[2] + C] for c in corners], -1)       # [C,C,C,8]
     case = np.zeros((C, C, C), np.int64)
     for b in range(8):
         case |= (f[..., b] < iso).astype(np.int64) << b
-    count = np.asarray(T.TRI_COUNT)[case]
+    count = np.asarray(TRI_COUNT)[case]
     ii, jj, kk = np.nonzero(count)                       # C order: x slowest, z fastest
     if len(ii) == 0:
         return np.zeros((0, 3, 3), np.float32)
     fc = f[ii, jj, kk]                                   # [n,8]
     cs = case[ii, jj, kk]
-    e = np.asarray(T.TRI_TABLE)[cs][:, :15].astype(np.int64)          # [n,15] edge ids (-1 beyond the count)
+    e = np.asarray(TRI_TABLE)[cs][:, :15].astype(np.int64)          # [n,15] edge ids (-1 beyond the count)
     live = np.arange(15)[None, :] < 3 * count[ii, jj, kk][:, None]
     e = np.where(live, e, 0)
     a, b, ax = _EA[e], _EB[e], _AXIS[e]
@@ -75,15 +262,15 @@ def marching_cubes_loop(vol, iso, scale, offset):
     for i in range(C):
         for j in range(C):
             for k in range(C):
-                f = np.array([vol[i + c[0], j + c[1], k + c[2]] for c in T.CORNERS], np.float32)
+                f = np.array([vol[i + c[0], j + c[1], k + c[2]] for c in CORNERS], np.float32)
                 case = int(sum(1 << b for b in range(8) if f[b] < iso))
-                for t in range(T.TRI_COUNT[case]):
+                for t in range(TRI_COUNT[case]):
                     tri = np.zeros((3, 3), np.float32)
                     for v in range(3):
-                        e = int(T.TRI_TABLE[case, 3 * t + v])
+                        e = int(TRI_TABLE[case, 3 * t + v])
                         a, b, ax = _EA[e], _EB[e], _AXIS[e]
                         tt = np.float32(iso - f[a]) / np.float32(f[b] - f[a])
-                        p = np.array([i, j, k], np.float32) + T.CORNERS[a].astype(np.float32)
+                        p = np.array([i, j, k], np.float32) + CORNERS[a].astype(np.float32)
                         p[ax] = np.float32(p[ax] + tt)
                         tri[v] = _fma32(p, scale, offset)
                     tris.append(tri)
