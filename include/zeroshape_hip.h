@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 34
+#define ZS_ABI_VERSION 35
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -668,6 +668,10 @@ int zs_standardize_weight_bwd(const float *w, const float *grad_out, float *dw, 
                               void *stream);
 int zs_act_forward(const float *x, float *y, size_t n, int act, float beta, void *stream);
 int zs_act_backward(const float *dy, const float *ref, float *dx, size_t n, int act, float beta, void *stream);
+/* NeRF positional encoding of 3D points - the reference's get_embedder(L, 3) (utils/layers.py:8-53; used by MLPBlocks when
+ * posenc_3D = L > 0, model/shape/implicit.py:139-166): out[i][0:3+6L] = [x | sin(x 2^0) | cos(x 2^0) | ... | sin(x 2^(L-1)) |
+ * cos(x 2^(L-1))], each group 3 wide (x, y, z), zero padded to `stride` floats per point (stride >= 3 + 6 L). */
+int zs_posenc3d(const float *points, size_t n, int L, float *out, int stride, void *stream);
 int zs_add_scaled_rows(const float *x, const float *branch, const float *scale, float *y, int batch,
                        size_t per_sample, void *stream);
 size_t zs_column_sum_workspace_bytes(int rows, int C);

@@ -38,6 +38,13 @@ def grid_golden():
 
 
 @pytest.fixture(scope="session")
+def posenc_golden():
+    """The reference's Implicit(posenc_3D=4) on the seeded weights (tests/golden/make_posenc_golden.py)."""
+    import numpy as np
+    return dict(np.load(os.path.join(GOLDEN, "posenc_golden.npz")))
+
+
+@pytest.fixture(scope="session")
 def geometry_golden():
     import numpy as np
     return dict(np.load(os.path.join(GOLDEN, "geometry_golden.npz")))

@@ -1,0 +1,82 @@
+"""posenc_3D > 0 on the HIP path (VERDICT r05 missing 3 / next 9): `Implicit(posenc_3D=4)` - the per-point MLP's first and
+skip layers take 3 + 6 posenc_3D point features (model/shape/implicit.py:139-166, get_embedder utils/layers.py:8-53) - against
+the golden of the reference itself (tests/golden/make_posenc_golden.py) and the oracle.  The fused inference kernels are
+specialised for posenc_3D = 0; this variant runs layer by layer on the training path's HIP kernels (zs_posenc3d + the GEMM /
+attention / normalisation kernels), in inference and under autograd; the attention map still comes from the fused fp32 kernel."""
+import numpy as np
+import pytest
+import torch
+
+from zeroshape_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+L = 4
+
+
+@pytest.fixture(scope="module")
+def net(decoder_golden):
+    from zeroshape_amd.model.shape.implicit import Implicit
+    sd = syn.seeded_state_dict(seed=0, pos_embed=decoder_golden["pos_embed_f32"], posenc_3D=L)
+    m = Implicit(syn.NUM_PATCHES, latent_dim=syn.LATENT_DIM, semantic=False, n_channels=syn.N_CHANNELS,
+                 n_blocks_attn=syn.ATT_BLOCKS, n_layers_mlp=syn.MLP_LAYERS, num_heads=syn.NUM_HEADS,
+                 posenc_3D=L, mlp_ratio=syn.MLP_RATIO, skip_in=list(syn.SKIP_IN), pos_perlayer=False)
+    assert list(m.state_dict().keys()) == list(syn.impl_network_shapes(posenc_3D=L).keys())
+    for k, shp in syn.impl_network_shapes(posenc_3D=L).items():
+        assert tuple(m.state_dict()[k].shape) == tuple(shp), k
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return m.cuda().eval()
+
+
+def _points():
+    rs = np.random.RandomState(321)
+    return torch.from_numpy(rs.uniform(-1.5, 1.5, size=(2, 1024, 3)).astype(np.float32)).cuda()
+
+
+def test_encoding_kernel_vs_reference_rows(posenc_golden):
+    from zeroshape_amd.nn import autograd as A
+    enc = A.posenc3d(_points()[0, :64], L)
+    assert enc.shape == (64, 28)
+    np.testing.assert_allclose(enc[:, :27].cpu().numpy(), posenc_golden["embed_rows"], atol=1e-6, rtol=0)
+    assert float(enc[:, 27].abs().max()) == 0.0
+    e0 = A.posenc3d(_points()[0, :5], 0)
+    assert e0.shape == (5, 4) and torch.equal(e0[:, :3], _points()[0, :5])
+
+
+def test_inference_vs_reference_golden(net, posenc_golden):
+    assert not net.fused
+    latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=2)).cuda()
+    with torch.no_grad():
+        lg, at = net(latent, None, _points())
+    np.testing.assert_allclose(lg.cpu().numpy(), posenc_golden["logit"], atol=2e-5, rtol=0)        # contract: 1e-4
+    np.testing.assert_allclose(at[:, ::128].cpu().numpy(), posenc_golden["attn_rows"], atol=2e-7, rtol=0)
+    lg2, none = net(latent, None, _points(), need_attn=False)
+    assert none is None and torch.equal(lg2, lg)
+    with pytest.raises(NotImplementedError):
+        net.prepare(latent)
+
+
+def test_level_grid_takes_the_slice_loop(net, posenc_golden):
+    from zeroshape_amd.utils import eval_3D as E
+    from zeroshape_amd.utils.options import EasyDict as edict
+    latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=2))[:1].cuda()
+    opt = edict(dict(device="cuda", H=224, W=224, eval=dict(vox_res=8, range=[-1.5, 1.5]), arch=dict(win_size=16)))
+    grid = E.get_dense_3D_grid(opt, edict(dict(idx=[0])))
+    occ, vis = E.compute_level_grid(opt, net, latent, None, grid, None)
+    assert vis is None and occ.shape == (1, 9, 9, 9)
+    np.testing.assert_allclose(occ[0].cpu().numpy(), posenc_golden["occ8"], atol=1e-5, rtol=0)
+    assert np.array_equal(occ[0].cpu().numpy() > 0.5, posenc_golden["occ8"] > 0.5)
+
+
+def test_gradients_vs_reference_golden(net, posenc_golden):
+    latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=2)).cuda().requires_grad_(True)
+    for p in net.parameters():
+        p.grad = None
+    lg, _ = net(latent, None, _points(), need_attn=False)
+    (lg * torch.from_numpy(posenc_golden["loss_weights"]).cuda()).sum().backward()
+    params = dict(net.named_parameters())
+    for k in [k[5:] for k in posenc_golden if k.startswith("grad.") and k != "grad.latent"]:
+        w = torch.from_numpy(posenc_golden["grad." + k]).double()
+        g = params[k].grad.cpu().double()
+        assert float((g - w).norm()) <= 1e-4 * float(w.norm()), (k, float((g - w).norm()) / float(w.norm()))
+    w = torch.from_numpy(posenc_golden["grad.latent"]).double()
+    assert float((latent.grad.cpu().double() - w).norm()) <= 1e-4 * float(w.norm())

@@ -46,3 +46,38 @@ def test_oracle_vs_full_grid_golden_of_the_reference(seeded_sd, grid_golden, N):
     pts = torch.stack([gx, gy, gz], -1).view(1, -1, 3)
     got = R.implicit_forward(seeded_sd, latent, pts)[0][0].numpy()
     np.testing.assert_allclose(got, grid_golden["logit%d_s%d" % (N, s)].reshape(-1), atol=2e-5, rtol=0)
+
+
+def _posenc_sd(posenc_golden, decoder_golden):
+    from zeroshape_amd import synthetic as syn
+    L = int(posenc_golden["posenc_3D"][0])
+    sd = syn.seeded_state_dict(seed=0, pos_embed=decoder_golden["pos_embed_f32"], posenc_3D=L)
+    return L, {k: torch.from_numpy(v) for k, v in sd.items()}
+
+
+def test_oracle_posenc_3d_vs_reference_golden(posenc_golden, decoder_golden):
+    """oracle/decoder_ref.py with posenc_3D = 4 (implicit.py:139-166) against the reference's own outputs: the embedding,
+    the logits and attention rows of a training-shape call, the 9^3 level grid, and gradients through the differentiable form."""
+    from oracle import decoder_ref as R
+    from zeroshape_amd import synthetic as syn
+    L, sd = _posenc_sd(posenc_golden, decoder_golden)
+    assert sd["impl_mlp.layers.0.weight"].shape == (256, 3 + 6 * L + 256) and sd["impl_mlp.layers.2.weight"].shape == (256, 512 + 3 + 6 * L)
+    rs = np.random.RandomState(321)
+    pts = torch.from_numpy(rs.uniform(-1.5, 1.5, size=(2, 1024, 3)).astype(np.float32))
+    np.testing.assert_allclose(R.posenc_3d(pts[0, :64], L).numpy(), posenc_golden["embed_rows"], atol=1e-6, rtol=0)
+    latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=2))
+    lg, at = R.implicit_forward(sd, latent, pts)
+    np.testing.assert_allclose(lg.numpy(), posenc_golden["logit"], atol=5e-6, rtol=0)
+    np.testing.assert_allclose(at[:, ::128].numpy(), posenc_golden["attn_rows"], atol=2e-7, rtol=0)
+    occ = R.level_grid(sd, latent[:1], R.dense_grid(-1.5, 1.5, 8))
+    np.testing.assert_allclose(occ[0].numpy(), posenc_golden["occ8"], atol=2e-6, rtol=0)
+    # gradients: torch autograd through the oracle's differentiable restatement
+    leaf = {k: v.clone().requires_grad_(k != "pos_embed") for k, v in sd.items()}
+    lat = latent.clone().requires_grad_(True)
+    out = R.implicit_forward_train(leaf, lat, pts)
+    (out * torch.from_numpy(posenc_golden["loss_weights"])).sum().backward()
+    for k in [k[5:] for k in posenc_golden if k.startswith("grad.") and k != "grad.latent"]:
+        w = torch.from_numpy(posenc_golden["grad." + k]).double()
+        assert float((leaf[k].grad.double() - w).norm()) <= 2e-5 * float(w.norm()), k
+    w = torch.from_numpy(posenc_golden["grad.latent"]).double()
+    assert float((lat.grad.double() - w).norm()) <= 2e-5 * float(w.norm())

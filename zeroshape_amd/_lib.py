@@ -154,6 +154,7 @@ SIGNATURES = {
     "zs_standardize_weight_bwd": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_float, _c_void_p]),
     "zs_act_forward": (_c_int, [_c_void_p, _c_void_p, _c_size_t, _c_int, _c_float, _c_void_p]),
     "zs_act_backward": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_int, _c_float, _c_void_p]),
+    "zs_posenc3d": (_c_int, [_c_void_p, _c_size_t, _c_int, _c_void_p, _c_int, _c_void_p]),
     "zs_add_scaled_rows": (_c_int, [_c_void_p] * 4 + [_c_int, _c_size_t, _c_void_p]),
     "zs_column_sum_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
     "zs_column_sum": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_float, _c_void_p, _c_void_p]),
@@ -200,7 +201,7 @@ SIGNATURES = {
     "zs_readout_concat_bwd": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
 }
 
-ABI_VERSION = 34
+ABI_VERSION = 35
 _lib = None
 
 

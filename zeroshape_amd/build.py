@@ -47,11 +47,16 @@ def _includes(path, seen):
     import re
     with open(path, "rb") as fh:
         text = fh.read().decode("utf-8", "replace")
-    for name in re.findall(r'^\s*#\s*include\s+"([^"]+)"', text, flags=re.M):
-        f = os.path.normpath(os.path.join(os.path.dirname(path), name))
-        if os.path.exists(f) and f not in seen:
-            seen.append(f)
-            _includes(f, seen)
+    for name in re.findall(r'^\s*#\s*include\s+["<]([^">]+)[">]', text, flags=re.M):
+        # relative to the including file first, then through `-I include` (angle-bracket includes too: a header found there is
+        # ours; system headers do not exist under either and are skipped)
+        for base in (os.path.dirname(path), INCLUDE):
+            f = os.path.normpath(os.path.join(base, name))
+            if os.path.exists(f):
+                if f not in seen:
+                    seen.append(f)
+                    _includes(f, seen)
+                break
     return seen
 
 

@@ -530,6 +530,34 @@ extern "C" int zs_act_backward(const float *dy, const float *ref, float *dx, siz
     return zs::check_launch("zs_act_backward") ? 1 : 0;
 }
 
+// NeRF positional encoding of 3D points (utils/layers.py:8-53 of the reference, get_embedder(L, 3): include_input,
+// log-sampled frequencies 2^0 .. 2^(L-1), [sin, cos] per frequency): out[i] = [x | sin(x 1) | cos(x 1) | sin(x 2) | cos(x 2)
+// | ...] (3 + 6 L values, x*freq rounded to fp32 first like torch), zero padded to `stride` floats.
+__global__ __launch_bounds__(256) void posenc3d_kernel(const float *__restrict__ pts, size_t n, int L, float *__restrict__ out,
+                                                       int stride) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+    float *o = out + i * stride;
+    for (int d = 0; d < 3; d++) o[d] = x[d];
+    float freq = 1.0f;
+    for (int k = 0; k < L; k++, freq *= 2.0f)
+        for (int d = 0; d < 3; d++) {
+            const float a = x[d] * freq;
+            o[3 + 6 * k + d] = sinf(a);
+            o[3 + 6 * k + 3 + d] = cosf(a);
+        }
+    for (int c = 3 + 6 * L; c < stride; c++) o[c] = 0.f;
+}
+
+extern "C" int zs_posenc3d(const float *points, size_t n, int L, float *out, int stride, void *stream) {
+    ZS_REQUIRE(L >= 0 && L <= 16 && stride >= 3 + 6 * L, "zs_posenc3d: bad sizes (L=%d stride=%d)", L, stride);
+    if (n == 0) return 1;
+    ZS_REQUIRE(points && out, "zs_posenc3d: null pointer");
+    hipLaunchKernelGGL(posenc3d_kernel, dim3(blocks_for(n)), dim3(256), 0, S(stream), points, n, L, out, stride);
+    return zs::check_launch("zs_posenc3d") ? 1 : 0;
+}
+
 extern "C" int zs_add_scaled_rows(const float *x, const float *branch, const float *scale, float *y, int batch,
                                   size_t per_sample, void *stream) {
     ZS_REQUIRE(batch >= 0 && per_sample > 0, "zs_add_scaled_rows: bad size");

@@ -17,9 +17,11 @@ network layer by layer through zeroshape_amd/nn/autograd.py - HIP kernels for ev
 backward op, torch.autograd only as the tape - including timm's per-sample DropPath
 (implicit.py:83-109, drop_path=0.1).
 
+``posenc_3D > 0`` (implicit.py:139-166; options/shape.yaml has 0) runs layer by layer on the training path's HIP kernels
+in inference too (`fused` is False: forward() and compute_level_grid's slice loop; prepare / query_* raise).
+
 Not on the HIP path (raises, never silently approximated):
-  * ``semantic=True`` / ``posenc_3D>0`` variants (unused by
-    options/shape.yaml).
+  * ``semantic=True`` (unused by options/shape.yaml).
 """
 import contextlib
 import os
@@ -67,9 +69,10 @@ class _Proj3D(nn.Module):
 
 
 class _MLPBlocks(nn.Module):
-    def __init__(self, num_hidden_layers, n_channels, latent_dim, skip_in):
+    def __init__(self, num_hidden_layers, n_channels, latent_dim, skip_in, posenc_res=0):
         super().__init__()
-        dims = [3 + latent_dim] + [n_channels] * num_hidden_layers + [1]
+        # implicit.py:139-150: get_embedder(posenc_res, 3) widens the point part of `inputs` from 3 to 3 + 6 posenc_res
+        dims = [3 + 6 * int(posenc_res) + latent_dim] + [n_channels] * num_hidden_layers + [1]
         self.layers = nn.ModuleList([
             nn.Linear(dims[l] + (dims[0] if l in skip_in else 0), dims[l + 1])
             for l in range(len(dims) - 1)])
@@ -121,7 +124,8 @@ class Implicit(nn.Module):
         self.blocks_attn = nn.ModuleList([_Block(n_channels, mlp_ratio, norm_layer)
                                           for _ in range(n_blocks_attn)])
         self.norm = norm_layer(n_channels)
-        self.impl_mlp = _MLPBlocks(n_layers_mlp, n_channels, n_channels, self.skip_in) \
+        self.posenc_3D = int(posenc_3D)
+        self.impl_mlp = _MLPBlocks(n_layers_mlp, n_channels, n_channels, self.skip_in, self.posenc_3D) \
             if n_layers_mlp > 0 else None
         if self.impl_mlp is None:
             self.pred_head = nn.Linear(n_channels, 1, bias=True)
@@ -177,7 +181,14 @@ class Implicit(nn.Module):
             nn.init.constant_(m.weight, 1.0)
 
     # ---- HIP path ---------------------------------------------------------------------
-    def _check_supported(self):
+    @property
+    def fused(self):
+        """True when the fused inference kernels (prepare / query_*) serve this configuration.  posenc_3D > 0
+        (implicit.py:139-166: the per-point MLP's first and skip layers take 3 + 6 posenc_3D point features) runs layer by
+        layer on the same HIP kernels as the training path instead - forward(), and the slice loop of compute_level_grid."""
+        return self.posenc_3D == 0
+
+    def _check_supported(self, fused=True):
         c = self.cfg
         # pos_perlayer (the reference class's own default; options/shape.yaml:44 sets False) is a prologue option since round 5:
         # both values run.  posenc_3D > 0 widens the per-point MLP's first and skip layers (implicit.py:147-150) - a kernel
@@ -185,6 +196,8 @@ class Implicit(nn.Module):
         want = dict(num_patches=P.L - 1, n_channels=P.C, latent_dim=P.C, n_blocks_attn=P.BLOCKS,
                     n_layers_mlp=P.MLP_LAYERS - 1, num_heads=P.HEADS, posenc_3D=0, mlp_ratio=4.0,
                     skip_in=P.SKIP_IN, semantic=False)
+        if not fused:
+            del want["posenc_3D"]                   # the layer-by-layer path takes any posenc_3D
         bad = {k: (c[k], v) for k, v in want.items() if c[k] != v}
         if bad:
             raise NotImplementedError(
@@ -199,8 +212,17 @@ class Implicit(nn.Module):
         parameter changed (in-place update or re-assignment)."""
         key = (str(device),) + self._weights_key()
         if self._packed is None or self._packed[0] != key:
-            self._check_supported()
+            self._check_supported(fused=self.posenc_3D == 0)
             sd = {k: v.detach().float().cpu().numpy() for k, v in self.state_dict().items()}
+            if self.posenc_3D > 0:
+                # only the ATTENTION MAP of such a network comes from the fused kernel (forward(need_attn=True)): the map is
+                # complete before the per-point MLP starts, so the MLP is packed without its 6 posenc_3D encoding columns -
+                # the logits of this program are meaningless and never returned
+                e = 6 * self.posenc_3D
+                for l in (0,) + tuple(self.skip_in):
+                    w = sd["impl_mlp.layers.%d.weight" % l]
+                    at = 3 if l == 0 else P.C + 3
+                    sd["impl_mlp.layers.%d.weight" % l] = np.concatenate([w[:, :at], w[:, at + e:]], 1)
             prog = torch.from_numpy(P.pack_program(sd)).to(device)
             lat = torch.from_numpy(P.pack_latent_params(sd)).to(device)
             self._packed = (key, prog, lat, P.split_envelope(sd)[0])
@@ -320,6 +342,9 @@ class Implicit(nn.Module):
         False returns the split state unchecked (measurements of the arithmetic itself)."""
         precision = self.precision if precision is None else precision
         calibrate = self.calibrate if calibrate is None else calibrate
+        if not self.fused and not getattr(self, "_attn_only", False):
+            raise NotImplementedError("posenc_3D = %d: the fused decoder kernels are specialised for posenc_3D = 0; this "
+                                      "network runs layer by layer - call it (forward) instead of prepare / query_*" % self.posenc_3D)
         if precision not in ("f32", "f16x3"):
             raise ValueError("decoder precision must be 'f32' or 'f16x3', got %r" % (precision,))
         if not latent_depth.is_cuda:
@@ -617,12 +642,16 @@ class Implicit(nn.Module):
         probes) pass need_attn=False and get (logits, None) from the faster kernel variant."""
         if self.semantic or latent_semantic is not None:
             raise NotImplementedError("semantic latent codes are not used by options/shape.yaml")
-        if torch.is_grad_enabled() and (self.training or points_3D.requires_grad or latent_depth.requires_grad):
+        if not self.fused or (torch.is_grad_enabled() and (self.training or points_3D.requires_grad or latent_depth.requires_grad)):
             logits = self._forward_autograd(latent_depth, points_3D)
             if not need_attn:
                 return logits, None
             with torch.no_grad():      # the attention map carries no gradient in the reference's losses
-                return logits, self.query_points(self.prepare(latent_depth, "f32"), points_3D, need_attn=True)[1]
+                self._attn_only = True
+                try:
+                    return logits, self.query_points(self.prepare(latent_depth, "f32"), points_3D, need_attn=True)[1]
+                finally:
+                    self._attn_only = False
         state = self.prepare(latent_depth)
         if need_attn and state.precision == "f32":
             return self.query_points(state, points_3D, need_attn=True)
@@ -646,7 +675,7 @@ class Implicit(nn.Module):
         """implicit.py:251-288 with the latent rows and the point rows kept as two row blocks
         (every op but the attention is row-wise, and the attention treats the blocks differently
         anyway, implicit.py:38-71), so no concatenated [B,197+M,C] tensor is ever built."""
-        self._check_supported()
+        self._check_supported(fused=False)
         if not (latent_depth.is_cuda and points_3D.is_cuda):
             raise ValueError("latent_depth / points_3D must be GPU tensors; zeroshape_amd has no CPU path")
         lat = latent_depth.to(torch.float32)
@@ -699,13 +728,16 @@ class Implicit(nn.Module):
         layers = self.impl_mlp.layers
         r2 = 0.7071067811865476
         x = None
+        # the point part of `inputs`: xyz, or its NeRF encoding [xyz | sin, cos at 2^0 .. 2^(L-1)] (implicit.py:158-160)
+        E = 3 + 6 * self.posenc_3D
+        enc = pts4 if self.posenc_3D == 0 else A.posenc3d(pts, self.posenc_3D)
         for l, lin in enumerate(layers):
             if l == 0:
-                y = A.linear(pts4, lin.weight, None, cin0=0, cin=3)
-                y = A.linear(feat, lin.weight, lin.bias, res1=y, cin0=3, cin=C)
+                y = A.linear(enc, lin.weight, None, cin0=0, cin=E)
+                y = A.linear(feat, lin.weight, lin.bias, res1=y, cin0=E, cin=C)
             elif l in self.skip_in:
-                y = A.linear(pts4, lin.weight, None, in_scale=r2, cin0=C, cin=3)
-                y = A.linear(feat, lin.weight, None, in_scale=r2, res1=y, cin0=C + 3, cin=C)
+                y = A.linear(enc, lin.weight, None, in_scale=r2, cin0=C, cin=E)
+                y = A.linear(feat, lin.weight, None, in_scale=r2, res1=y, cin0=C + E, cin=C)
                 y = A.linear(x, lin.weight, lin.bias, in_scale=r2, res1=y, cin0=0, cin=C)
             else:
                 y = A.linear(x, lin.weight, lin.bias)

@@ -534,6 +534,18 @@ def _pad_channels(x, cpad):
     return y
 
 
+def posenc3d(points, L):
+    """points [..., 3] (no gradient: the decoder's query points are data) -> NeRF encoding [..., pad4(3 + 6 L)], the
+    reference's get_embedder(L, 3) (utils/layers.py:8-53), channels beyond 3 + 6 L zero (the channel count the GEMM stages)."""
+    lib = _lib.load()
+    pts = _f32c(points.detach(), "posenc3d input")
+    cpad = (3 + 6 * L + 3) // 4 * 4
+    out = torch.empty(*pts.shape[:-1], cpad, dtype=torch.float32, device=pts.device)
+    with _lib.on(pts.device):
+        _lib.check(lib.zs_posenc3d(_lib.ptr(pts), pts.numel() // 3, int(L), _lib.ptr(out), cpad, _stream(pts)), "zs_posenc3d")
+    return out
+
+
 class _PadChannels(torch.autograd.Function):
     """[..., C] -> [..., cpad] with zero padding channels (the channel count the convolution engine stages)."""
 

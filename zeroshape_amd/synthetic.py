@@ -22,8 +22,9 @@ NUM_PATCHES = 196  # (224 // 16) ** 2, graph_shape.py:58-64
 
 def impl_network_shapes(n_channels=N_CHANNELS, latent_dim=LATENT_DIM, att_blocks=ATT_BLOCKS,
                         mlp_ratio=MLP_RATIO, mlp_layers=MLP_LAYERS, skip_in=SKIP_IN,
-                        num_patches=NUM_PATCHES):
-    """Ordered {key: shape} of the reference decoder's state_dict."""
+                        num_patches=NUM_PATCHES, posenc_3D=0):
+    """Ordered {key: shape} of the reference decoder's state_dict (posenc_3D: implicit.py:139-150 widens the point part of
+    the per-point MLP's inputs to 3 + 6 posenc_3D)."""
     C = n_channels
     s = {}
     s["pos_embed"] = (1, num_patches + 1, C)
@@ -47,7 +48,7 @@ def impl_network_shapes(n_channels=N_CHANNELS, latent_dim=LATENT_DIM, att_blocks
         s[p + "mlp.fc2.bias"] = (C,)
     s["norm.weight"] = (C,)
     s["norm.bias"] = (C,)
-    dims = [3 + C] + [C] * mlp_layers + [1]
+    dims = [3 + 6 * int(posenc_3D) + C] + [C] * mlp_layers + [1]
     for l in range(len(dims) - 1):
         in_dim = dims[l] + (dims[0] if l in skip_in else 0)
         s["impl_mlp.layers.%d.weight" % l] = (dims[l + 1], in_dim)

@@ -86,13 +86,13 @@ def compute_level_grid(opt, impl_network, latent_depth, latent_semantic, points_
     info = getattr(points_3D, "_zs_grid", None)
     if info is not None and (info.version != points_3D._version or info.G != N):
         info = None            # modified in place since get_dense_3D_grid made it: read the points
-    if info is not None and hasattr(impl_network, "query_grid") and not vis_attn \
+    if info is not None and hasattr(impl_network, "query_grid") and getattr(impl_network, "fused", True) and not vis_attn \
             and latent_semantic is None:
         if image_sharding(opt) is not None:
             # every rank holds the same images (and ran the same prologue); rank r evaluates its tile-aligned
             # point range of every image and ONE all_gather_into_tensor rebuilds the grids everywhere
             from .. import parallel
-            state = impl_network.prepare(latent_depth)
+            state = parallel.prepare_sharded(impl_network, latent_depth)      # image i's output check on rank i % world
             occ = parallel.sharded_level_grid_points(
                 lambda b, e: impl_network.query_grid_range(latent_depth, info.axis, b, e, apply_sigmoid=True,
                                                            state=state), N)
