@@ -172,6 +172,60 @@ def test_captured_step_with_a_grad_reducer_on_one_gpu(tmp_path, encoder_sd, seed
         dist.destroy_process_group()
 
 
+def test_segmented_captured_step_overlaps_buckets_and_changes_nothing(tmp_path, encoder_sd, seeded_sd):
+    """with a reducer that really exchanges buckets the step is captured as one hipGraph per backward
+    segment (nn/autograd.py "Segmented backward": decoder + losses | coordinate encoder | DPT decoder + heads | ViT blocks
+    6-11 | stem + blocks 0-5) and the buckets go out between the replays.  RCCL group of one rank, the WHOLE network
+    trainable: five graphs, buckets issued after the first, second, ... replay - not all behind the last - and the
+    weights after two eager + three replayed steps equal those of the single-graph captured step
+    (optim.hip_graph_segments=false) bit for bit."""
+    import torch.distributed as dist
+    from zeroshape_amd import parallel
+    from zeroshape_amd.utils import util
+    from zeroshape_amd.utils.options import EasyDict as edict
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29536")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        results = []
+        for segments in (False, True):
+            opt = train_opt(tmp_path, "--optim.hip_graph", "--optim.hip_graph_segments=%s" % ("true" if segments else "false"))
+            r = make_runner(opt, encoder_sd, seeded_sd, n_train=4)
+            r.reducer = parallel.GradReducer(r.graph.parameters(), bucket_mb=16.0, always=True)
+            assert r._step_capture_enabled(opt) and r._segmented_capture(opt) == segments
+            r.graph.train()
+            issued = []
+            launch_done = r.reducer.launch_done
+            r.reducer.launch_done = lambda params: issued.append(launch_done(params)) or issued[-1]
+            batch = next(iter(torch.utils.data.DataLoader(r.train_data, batch_size=4, shuffle=False)))
+            for it in range(5):                          # two eager warm-up steps, the capture, two more replays
+                torch.manual_seed(11 + it)
+                var = util.move_to_device(edict({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}),
+                                          opt.device)
+                loss = r.train_iteration(opt, var)
+            assert np.isfinite(float(loss.all))
+            cap = r._captured
+            if segments:
+                assert len(cap["graphs"]) == 5 and len(cap["seg_params"]) == 5
+                trainable = [p for p in r.graph.parameters() if p.requires_grad and p.grad is not None]
+                assert sum(len(g) for g in cap["seg_params"]) == len(trainable)
+                names = {id(p): n for n, p in r.graph.named_parameters()}
+                first = {names[id(p)].split(".")[0] for p in cap["seg_params"][0]}
+                assert first == {"impl_network"}, first                      # the decoder's gradients are final first ...
+                assert all(names[id(p)].startswith("dpt_depth.pretrained.model.") for p in cap["seg_params"][4])      # ... the stem's last
+                per_step = issued[-5:]
+                assert per_step == sorted(per_step) and per_step[-1] == len(r.reducer.buckets)
+                assert per_step[1] >= 1 and per_step[3] > per_step[1], per_step        # buckets leave while backward is still replaying
+            else:
+                assert len(cap["graphs"]) == 1 and cap["seg_params"] is None and not issued
+            r.reducer.close()
+            results.append({k: v.detach().clone() for k, v in r.graph.state_dict().items()})
+        for k in results[0]:
+            assert torch.equal(results[0][k], results[1][k]), k
+    finally:
+        dist.destroy_process_group()
+
+
 def test_train_loop_checkpoints_and_resume_skip(tmp_path, encoder_sd, seeded_sd):
     """Runner.train like the reference's (model/shape_engine.py:164-246, 283-284): an evaluation before
     the first step of a fresh run, latest.ckpt every freq.ckpt_latest iterations, checkpoint/ep<N>.ckpt at

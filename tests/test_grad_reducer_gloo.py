@@ -199,6 +199,64 @@ def _worker_in_place_uneven(rank, world, initfile):
         dist.destroy_process_group()
 
 
+def _worker_in_place_segments(rank, world, initfile):
+    """begin_in_place / launch_done / end_in_place: the segmented captured step's form.  The backward pass arrives in three
+    segments (c + sometimes | b | a); a bucket goes out as soon as all its gradients are final - before the later segments
+    exist - in bucket order, and the result is the plain average."""
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        net = Net()
+        red = parallel.GradReducer(net.parameters(), bucket_mb=0.3, pack_fn=torch_pack, module=net)
+        red.armed = False
+        ref = Net()
+        ref.load_state_dict(net.state_dict())
+        segs = [[net.c.weight, net.c.bias, net.sometimes], [net.b.weight, net.b.bias], [net.a.weight, net.a.bias]]
+        for it in range(2):
+            x = [torch.randn(6, 40, generator=torch.Generator().manual_seed(300 + 10 * it + r)) for r in range(world)]
+            for p in net.parameters():
+                if p.grad is not None:
+                    p.grad.zero_()
+            net(x[rank]).pow(2).mean().backward()
+            truth = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+            # segments 2 and 3 "have not replayed yet": their gradient tensors hold garbage until launch_done() names them
+            for p in segs[1] + segs[2]:
+                p.grad.fill_(float("nan"))
+            assert red.begin_in_place()
+
+            def expected(done):       # leading buckets made of final gradients only (a bucket that straddles a cut waits)
+                ids, n = {id(p) for seg in done for p in seg}, 0
+                while n < len(red.buckets) and all(id(p) in ids for p in red.buckets[n]):
+                    n += 1
+                return n
+            n1 = red.launch_done(segs[0])
+            assert n1 == expected(segs[:1]) and n1 < len(red.buckets)
+            for p in segs[1]:
+                p.grad.copy_(truth[[n for n, q in net.named_parameters() if q is p][0]])
+            n2 = red.launch_done(segs[1])
+            assert n2 == expected(segs[:2]) and 1 <= n2 < len(red.buckets)      # out before the last segment exists
+            assert len(red.works) == n2
+            for p in segs[2]:
+                p.grad.copy_(truth[[n for n, q in net.named_parameters() if q is p][0]])
+            n3 = red.launch_done(segs[2])
+            assert n3 == len(red.buckets)
+            red.end_in_place()
+            ref.zero_grad(set_to_none=True)
+            for r in range(world):
+                (ref(x[r]).pow(2).mean() / world).backward()
+            for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+                if not n.startswith("unused"):
+                    assert torch.allclose(p.grad, q.grad, atol=1e-6, rtol=1e-5), (it, n)
+        red.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_reducer_in_place_by_backward_segments():
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_in_place_segments, args=(2, os.path.join(d, "init")), nprocs=2, join=True)
+
+
 def test_grad_reducer_in_place_with_a_parameter_used_on_one_rank_only():
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker_in_place_uneven, args=(2, os.path.join(d, "init")), nprocs=2, join=True)

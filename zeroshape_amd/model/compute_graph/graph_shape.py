@@ -219,12 +219,19 @@ class Graph(nn.Module):
             if opt.arch.depth.encoder == 'resnet':
                 assert opt.arch.depth.dsp == 1
                 var.seen_points, seen_3D_dsp, mask_dsp = A.seen_surface(var.depth_pred, var.intr_pred, mask)   # :131-144
+                # (segmented backward, nn/autograd.py: depth + intrinsics model | coordinate encoder | decoder + losses)
+                var.depth_pred, var.seen_points, seen_3D_dsp = A.cut(var.depth_pred, var.seen_points, seen_3D_dsp)
+                A.segment_break()
                 var.latent_depth = self.coord_encoder(seen_3D_dsp, mask_dsp)                               # :147-150
             else:                                              # transformer coordinate encoder
                 assert opt.arch.depth.dsp == 2, "the transformer coordinate encoder trains with arch.depth.dsp = 2 (options/shape.yaml:28)"
                 var.seen_points, seen_3D_dsp, mask_dsp = A.seen_surface_dsp2(var.depth_pred, var.intr_pred, mask)
+                var.depth_pred, var.seen_points, seen_3D_dsp = A.cut(var.depth_pred, var.seen_points, seen_3D_dsp)
+                A.segment_break()
                 var.latent_depth = self.coord_encoder(seen_3D_dsp.permute(0, 2, 3, 1).contiguous(),
                                                       mask_dsp.squeeze(1) > 0.5)
+            var.latent_depth = A.cut(var.latent_depth)
+            A.segment_break()
             var.pose = var.pose_gt if 'pose_gt' in var else None
             if with_samples:
                 with torch.no_grad():

@@ -231,6 +231,7 @@ class DPTDepthModel(HipModule):
         x = A.to_nhwc(image.float(), cpad=4)
         s0, s1, s2 = train_blocks.resnetv2(x, vit.patch_embed.backbone, in_scale=2.0, in_shift=-1.0)
         record(stage0=s0, stage1=s1, stage2=s2)
+        s0c, s1c = A.cut(s0, s1)                     # (segmented backward, nn/autograd.py: read by the decoder, two cuts on)
         feat = A.conv2d(s2, vit.patch_embed.proj.weight, vit.patch_embed.proj.bias).view(B, gh * gw, 768)
         # vit.py:103-120: the native position grid re-sampled to (gh, gw) on every forward
         pos = vit.pos_embed[0]
@@ -242,17 +243,22 @@ class DPTDepthModel(HipModule):
             tok = train_blocks.vit_block(tok, blk, 12)
             if i in (0, 8, 11):
                 hooked[i] = tok
+            if i == 5:                               # cut: stem + blocks 0-5 | blocks 6-11
+                tok = A.cut(tok)
+                A.segment_break()
         record(block0=hooked[0], block8=hooked[8], block11=hooked[11])
+        t8, t11 = A.cut(hooked[8], hooked[11])       # cut: ViT | reassemble + fusion decoder + head
+        A.segment_break()
 
         def reassemble(t, post):
             lin = post[0].project[0]
             r = A.gelu(A.linear(A.readout_concat(t), lin.weight, lin.bias))
             return A.conv2d(r.view(B, gh, gw, 768), post[3].weight, post[3].bias)
-        layer_3 = reassemble(hooked[8], pre.act_postprocess3)
+        layer_3 = reassemble(t8, pre.act_postprocess3)
         p4 = pre.act_postprocess4
-        layer_4 = A.conv2d(reassemble(hooked[11], p4), p4[4].weight, p4[4].bias, stride=2, padding=1)
+        layer_4 = A.conv2d(reassemble(t11, p4), p4[4].weight, p4[4].bias, stride=2, padding=1)
         rn = [A.conv2d(l, getattr(sc, "layer%d_rn" % i).weight, None, padding=1)
-              for i, l in enumerate((s0, s1, layer_3, layer_4), 1)]
+              for i, l in enumerate((s0c, s1c, layer_3, layer_4), 1)]
         record(layer3_rn=rn[2], layer4_rn=rn[3])
         path4 = train_blocks.fusion(rn[3], sc.refinenet4)
         path3 = train_blocks.fusion(path4, sc.refinenet3, rn[2])

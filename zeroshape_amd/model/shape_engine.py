@@ -222,9 +222,12 @@ class Runner:
     # AdamW run eagerly behind it (their scalars - step count, learning rate - change every step).  Everything the
     # sequence reads besides the inputs is addressed in place (parameters, buffers, packed operands, workspaces);
     # DropPath draws come from torch's graph-safe device generator.  Not captured: gradient accumulation windows (the eager
-    # path handles them).  With a multi-process GradReducer the graph still holds forward + backward; the buckets are packed,
-    # all-reduced and copied back into the graph's static gradients behind the replay (parallel.GradReducer.reduce_in_place:
-    # no overlap with the backward pass, which is inside the graph - the price of the captured step on more than one GPU).
+    # path handles them).  With a multi-process GradReducer the step is captured as one hipGraph per backward SEGMENT (decoder +
+    # losses | coordinate encoder | DPT decoder + heads | ViT blocks 6-11 | stem + blocks 0-5: nn/autograd.py "Segmented
+    # backward"); between two replays the buckets whose gradients are final are packed and all-reduced on RCCL's stream
+    # while the next segment's backward replays, and the averages are copied back into the graphs' static gradients at the
+    # end (parallel.GradReducer.begin_in_place / launch_done / end_in_place).  optim.hip_graph_segments=false: one graph, every
+    # bucket behind it (round 5's form: no overlap).
     def _optimizer_step(self, opt):
         """:270-277: clip, step; under optim.amp through the loss scaler (unscale, skip on overflow, update the scale)."""
         scaler = getattr(self, "scaler", None)
@@ -239,6 +242,14 @@ class Runner:
         flag = os.environ.get("ZS_TRAIN_HIP_GRAPH")
         on = flag not in ("0", "") if flag is not None else bool(opt.optim.get("hip_graph", False))
         return on and opt.optim.accum == 1
+
+    def _segmented_capture(self, opt):
+        """Capture the step as one hipGraph per backward segment?  Only worth it when buckets are really exchanged (a reducer
+        that is not a no-op); optim.hip_graph_segments / ZS_TRAIN_GRAPH_SEGMENTS = 0 keeps the single graph (A/B switch)."""
+        flag = os.environ.get("ZS_TRAIN_GRAPH_SEGMENTS")
+        on = flag not in ("0", "") if flag is not None else bool(opt.optim.get("hip_graph_segments", True))
+        r = self.reducer
+        return on and r is not None and (r.world > 1 or r.always)
 
     def _train_iteration_captured(self, opt, var):
         """One step through the captured launch sequence; the first two steps of a signature run eagerly (they
@@ -280,20 +291,56 @@ class Runner:
             A.bump_generation()                    # the capture must contain the operand re-pack
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
+            graphs, seg_params = [graph], None
+            scaler = getattr(self, "scaler", None)
             if self.reducer is not None:
-                self.reducer.armed = False         # no collective inside the capture: reduce_in_place() runs behind the replay
-            with torch.cuda.graph(graph, stream=cs):
-                out_var, loss = self.graph.forward(opt, static_var, training=True, get_loss=True)
-                loss = self.summarize_loss(opt, out_var, loss)
-                scaler = getattr(self, "scaler", None)
-                (loss.all if scaler is None else scaler.scale_loss(loss.all)).backward()
+                self.reducer.armed = False         # no collective inside a capture: the buckets go out BETWEEN the replays
+            if self._segmented_capture(opt):
+                # forward + the last segment's backward in the first graph, every earlier segment's backward in a graph of its
+                # own (one memory pool: the replays run in capture order) - nn/autograd.py "Segmented backward"
+                params = [p for p in self.graph.parameters() if p.requires_grad]
+                A.begin_segments()
+                try:
+                    with torch.cuda.graph(graph, stream=cs):
+                        out_var, loss = self.graph.forward(opt, static_var, training=True, get_loss=True)
+                        loss = self.summarize_loss(opt, out_var, loss)
+                        last = A.SEGMENTS["index"]
+                        A.backward_segment(last, params, loss=loss.all if scaler is None else scaler.scale_loss(loss.all))
+                    have = {id(p) for p in params if p.grad is not None}
+                    seg_params = [[p for p in params if id(p) in have]]
+                    for s in range(last - 1, -1, -1):
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, pool=graph.pool(), stream=cs):
+                            ran = A.backward_segment(s, [p for p in params if id(p) not in have])
+                        if not ran:
+                            continue                # (a frozen or absent part of the network: nothing was captured)
+                        new = [p for p in params if p.grad is not None and id(p) not in have]
+                        have.update(id(p) for p in new)
+                        graphs.append(g)
+                        seg_params.append(new)
+                finally:
+                    A.end_segments()
+            else:
+                with torch.cuda.graph(graph, stream=cs):
+                    out_var, loss = self.graph.forward(opt, static_var, training=True, get_loss=True)
+                    loss = self.summarize_loss(opt, out_var, loss)
+                    (loss.all if scaler is None else scaler.scale_loss(loss.all)).backward()
             loss = edict({k: (v.detach() if torch.is_tensor(v) else v) for k, v in loss.items()})
-            st = self._captured = dict(sig=sig, scratch=A.SCRATCH_GENERATION[0], graph=graph, static=static, loss=loss)
+            st = self._captured = dict(sig=sig, scratch=A.SCRATCH_GENERATION[0], graph=graph, graphs=graphs,
+                                       seg_params=seg_params, static=static, loss=loss)
         for k, t in st["static"].items():
             t.copy_(tensors[k], non_blocking=True)
-        st["graph"].replay()
-        if self.reducer is not None:
-            self.reducer.reduce_in_place()
+        if st["seg_params"] is not None and self.reducer is not None and self.reducer.begin_in_place():
+            # bucket k's all-reduce (RCCL's own stream) runs while the replay of the next segment's backward does
+            for g, done in zip(st["graphs"], st["seg_params"]):
+                g.replay()
+                self.reducer.launch_done(done)
+            self.reducer.end_in_place()
+        else:
+            for g in st["graphs"]:
+                g.replay()
+            if self.reducer is not None:
+                self.reducer.reduce_in_place()
         self._optimizer_step(opt)                  # no zero_grad: the replay overwrites the static gradients
         if self._rank() == 0 and getattr(opt, "output_path", None) and not getattr(opt, "debug", False) \
                 and self.it > 0 and self.it % opt.freq.ckpt_latest == 0:

@@ -534,6 +534,65 @@ def _pad_channels(x, cpad):
     return y
 
 
+# Segmented backward (the captured training step on more than one GPU, model/shape_engine.py).  One hipGraph of forward +
+# backward leaves the bucket all-reduce nothing to overlap with: every gradient appears "at once" when the replay ends.  So
+# the forward marks a few places where the network can be CUT (A.cut / A.segment_break, no-ops unless a segmenting capture
+# is active): a cut tensor is handed to the consumers of LATER segments as a detached leaf, so torch.autograd can run the
+# backward pass one segment at a time - backward_segment(s) starts from the cut tensors segment s produced, with the
+# gradients their leaves collected, and stops at the leaves of earlier segments - each segment captured into its own
+# hipGraph.  Between two replays the engine packs and all-reduces the buckets whose gradients are final while the next
+# segment's backward runs (parallel.GradReducer.launch_done).  The arithmetic is the unsegmented step's: a cut adds no
+# operation, and a tensor with consumers on both sides of a cut receives the same two-term gradient sum.
+SEGMENTS = None               # {"index": current segment, "cuts": [(producer segment, tensor, detached leaf)]} while segmenting
+
+
+def begin_segments():
+    global SEGMENTS
+    SEGMENTS = {"index": 0, "cuts": []}
+
+
+def end_segments():
+    global SEGMENTS
+    SEGMENTS = None
+
+
+def segment_break():
+    """The forward moves on to the next segment (everything computed from here on may only read earlier segments' tensors
+    through cut())."""
+    if SEGMENTS is not None:
+        SEGMENTS["index"] += 1
+
+
+def cut(*tensors):
+    """The tensors as LATER segments must read them: detached leaves that collect their gradient (the same storage - no copy);
+    the originals stay usable inside the segment that produced them.  Identity when no segmenting capture is active, and for
+    tensors that carry no gradient."""
+    out = []
+    for x in tensors:
+        if SEGMENTS is not None and torch.is_tensor(x) and x.requires_grad:
+            leaf = x.detach().requires_grad_()
+            SEGMENTS["cuts"].append((SEGMENTS["index"], x, leaf))
+            x = leaf
+        out.append(x)
+    return out[0] if len(out) == 1 else tuple(out)
+
+
+def backward_segment(s, params, loss=None):
+    """Backward pass of segment s: from `loss` (the last segment) and from the cut tensors segment s produced - seeded with
+    what their leaves collected in the later segments - to the parameters (those of other segments are unreachable and
+    skipped) and the leaves cut by earlier segments.  -> False when the segment has nothing to differentiate."""
+    roots, grads = ([loss], [None]) if loss is not None else ([], [])
+    for seg, x, leaf in SEGMENTS["cuts"]:
+        if seg == s and leaf.grad is not None:
+            roots.append(x)
+            grads.append(leaf.grad)
+    inputs = list(params) + [leaf for seg, _, leaf in SEGMENTS["cuts"] if seg < s]
+    if not roots or not inputs:
+        return False
+    torch.autograd.backward(roots, grads, inputs=inputs)
+    return True
+
+
 def posenc3d(points, L):
     """points [..., 3] (no gradient: the decoder's query points are data) -> NeRF encoding [..., pad4(3 + 6 L)], the
     reference's get_embedder(L, 3) (utils/layers.py:8-53), channels beyond 3 + 6 L zero (the channel count the GEMM stages)."""

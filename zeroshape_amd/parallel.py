@@ -285,6 +285,7 @@ class GradReducer(object):
         self.armed = True              # False during gradient-accumulation micro-steps: hooks stay quiet
         self.next_launch = 0           # collectives go out in bucket order
         self._lent = []                # reduce_in_place: parameters whose .grad is an average this reducer put there
+        self._final = set()            # begin_in_place .. end_in_place: ids of the parameters whose gradients are final
         if self.world > 1 or self.always:
             with torch.no_grad():
                 for p in params:
@@ -370,12 +371,7 @@ class GradReducer(object):
         """Call after backward(): all gradients averaged over the ranks when it returns."""
         if self.world == 1 and not self.always:
             return
-        if self.buckets is None:
-            mask = torch.tensor([0 if p.grad is None else 1 for p in self.params], dtype=torch.int32,
-                                device=self.params[0].device)
-            dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)    # one layout on every rank
-            mask = mask.cpu().tolist()
-            self._build({id(p) for p, u in zip(self.params, mask) if u})
+        self._ensure_layout()
         self._launch_ready(flush=True)          # incl. buckets a gradient did not reach this time (zeros)
         for w in self.works:
             w.wait()
@@ -387,19 +383,24 @@ class GradReducer(object):
                 p.grad = self.flat[bi][off:off + p.numel()].view_as(p)
             self.pending[bi] = len(plist)
 
-    def reduce_in_place(self):
-        """The captured training step (model/shape_engine.py): a hipGraph replay writes the gradients into FIXED tensors, so they
-        cannot be re-pointed at the buckets as finish() does.  Pack every bucket (grad / world -> flat), all-reduce the buckets in
-        order, and copy the averages back into the gradient tensors where they live.  No overlap with the backward pass (it is
-        inside the graph); the hooks stay quiet (`armed` False while the step is captured / replayed)."""
-        if self.world == 1 and not self.always:
-            return
+    def _ensure_layout(self):
         if self.buckets is None:
             mask = torch.tensor([0 if p.grad is None else 1 for p in self.params], dtype=torch.int32,
                                 device=self.params[0].device)
             dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)    # one layout on every rank
             mask = mask.cpu().tolist()
             self._build({id(p) for p, u in zip(self.params, mask) if u})
+
+    def begin_in_place(self):
+        """The captured training step (model/shape_engine.py): hipGraph replays write the gradients into FIXED tensors, so they
+        cannot be re-pointed at the buckets as finish() does; the hooks stay quiet (`armed` False while the step is captured /
+        replayed).  begin_in_place() -> launch_done(params) after every replayed segment -> end_in_place(): a bucket is packed
+        (grad / world -> flat) and its all-reduce issued as soon as all its gradients are final, i.e. while the NEXT segment's
+        backward replays; end_in_place() flushes the rest, waits, and copies the averages back into the gradient tensors where
+        they live.  -> False when there is nothing to reduce (one rank, not `always`)."""
+        if self.world == 1 and not self.always:
+            return False
+        self._ensure_layout()
         # averages handed out last time to parameters WITHOUT a local gradient are not this rank's contribution: the replay does
         # not write them (they are not in this rank's graph), so left in .grad they would be packed again as "local" gradients -
         # a stale term in every rank's average from the second step on (ADVICE r05)
@@ -407,6 +408,21 @@ class GradReducer(object):
             q.grad = None
         self._lent = []
         self.next_launch = 0
+        self._final = set()
+        return True
+
+    def launch_done(self, params):
+        """`params`: parameters whose gradients the segment that just replayed made final.  Issues, in bucket order, every
+        bucket all of whose gradients are final (a parameter without a local gradient - used on other ranks only - counts as
+        final: it contributes zeros).  Every rank issues the same buckets in the same order; WHEN it does may differ."""
+        self._final.update(id(p) for p in params)
+        while self.next_launch < len(self.buckets) and \
+                all(id(p) in self._final or p.grad is None for p in self.buckets[self.next_launch]):
+            self._launch(self.next_launch, in_place=True)
+            self.next_launch += 1
+        return self.next_launch
+
+    def end_in_place(self):
         self._launch_ready(flush=True, in_place=True)
         for w in self.works:
             w.wait()
@@ -426,6 +442,12 @@ class GradReducer(object):
             if back:
                 self.pack_fn(back, 1.0, self.flat[bi].device)
             self.pending[bi] = len(plist)
+
+    def reduce_in_place(self):
+        """The unsegmented captured step: every bucket behind the one replay (no overlap with the backward pass, which is inside
+        the graph)."""
+        if self.begin_in_place():
+            self.end_in_place()
 
     def close(self):
         for h in self._hooks:
