@@ -175,8 +175,8 @@ def test_captured_step_with_a_grad_reducer_on_one_gpu(tmp_path, encoder_sd, seed
 def test_segmented_captured_step_overlaps_buckets_and_changes_nothing(tmp_path, encoder_sd, seeded_sd):
     """with a reducer that really exchanges buckets the step is captured as one hipGraph per backward
     segment (nn/autograd.py "Segmented backward": decoder + losses | coordinate encoder | DPT decoder + heads | ViT blocks
-    6-11 | stem + blocks 0-5) and the buckets go out between the replays.  RCCL group of one rank, the WHOLE network
-    trainable: five graphs, buckets issued after the first, second, ... replay - not all behind the last - and the
+    6-11 | blocks 3-5 | stem + blocks 0-2) and the buckets go out between the replays.  RCCL group of one rank, the WHOLE
+    network trainable: six graphs, buckets issued after the first, second, ... replay - not all behind the last - and the
     weights after two eager + three replayed steps equal those of the single-graph captured step
     (optim.hip_graph_segments=false) bit for bit."""
     import torch.distributed as dist
@@ -206,14 +206,14 @@ def test_segmented_captured_step_overlaps_buckets_and_changes_nothing(tmp_path, 
             assert np.isfinite(float(loss.all))
             cap = r._captured
             if segments:
-                assert len(cap["graphs"]) == 5 and len(cap["seg_params"]) == 5
+                assert len(cap["graphs"]) == 6 and len(cap["seg_params"]) == 6
                 trainable = [p for p in r.graph.parameters() if p.requires_grad and p.grad is not None]
                 assert sum(len(g) for g in cap["seg_params"]) == len(trainable)
                 names = {id(p): n for n, p in r.graph.named_parameters()}
                 first = {names[id(p)].split(".")[0] for p in cap["seg_params"][0]}
                 assert first == {"impl_network"}, first                      # the decoder's gradients are final first ...
-                assert all(names[id(p)].startswith("dpt_depth.pretrained.model.") for p in cap["seg_params"][4])      # ... the stem's last
-                per_step = issued[-5:]
+                assert all(names[id(p)].startswith("dpt_depth.pretrained.model.") for p in cap["seg_params"][5])      # ... the stem's last
+                per_step = issued[-6:]
                 assert per_step == sorted(per_step) and per_step[-1] == len(r.reducer.buckets)
                 assert per_step[1] >= 1 and per_step[3] > per_step[1], per_step        # buckets leave while backward is still replaying
             else:

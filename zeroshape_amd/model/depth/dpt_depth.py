@@ -243,7 +243,7 @@ class DPTDepthModel(HipModule):
             tok = train_blocks.vit_block(tok, blk, 12)
             if i in (0, 8, 11):
                 hooked[i] = tok
-            if i == 5:                               # cut: stem + blocks 0-5 | blocks 6-11
+            if i in (2, 5):                          # cuts: stem + blocks 0-2 | blocks 3-5 | blocks 6-11
                 tok = A.cut(tok)
                 A.segment_break()
         record(block0=hooked[0], block8=hooked[8], block11=hooked[11])

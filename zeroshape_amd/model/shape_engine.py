@@ -223,7 +223,7 @@ class Runner:
     # sequence reads besides the inputs is addressed in place (parameters, buffers, packed operands, workspaces);
     # DropPath draws come from torch's graph-safe device generator.  Not captured: gradient accumulation windows (the eager
     # path handles them).  With a multi-process GradReducer the step is captured as one hipGraph per backward SEGMENT (decoder +
-    # losses | coordinate encoder | DPT decoder + heads | ViT blocks 6-11 | stem + blocks 0-5: nn/autograd.py "Segmented
+    # losses | coordinate encoder | DPT decoder + heads | ViT blocks 6-11 | blocks 3-5 | stem + blocks 0-2: nn/autograd.py "Segmented
     # backward"); between two replays the buckets whose gradients are final are packed and all-reduced on RCCL's stream
     # while the next segment's backward replays, and the averages are copied back into the graphs' static gradients at the
     # end (parallel.GradReducer.begin_in_place / launch_done / end_in_place).  optim.hip_graph_segments=false: one graph, every
@@ -309,11 +309,12 @@ class Runner:
                     have = {id(p) for p in params if p.grad is not None}
                     seg_params = [[p for p in params if id(p) in have]]
                     for s in range(last - 1, -1, -1):
+                        if not A.segment_has_work(s):
+                            continue                # (a frozen or absent part of the network: nothing to capture)
                         g = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(g, pool=graph.pool(), stream=cs):
                             ran = A.backward_segment(s, [p for p in params if id(p) not in have])
-                        if not ran:
-                            continue                # (a frozen or absent part of the network: nothing was captured)
+                        assert ran
                         new = [p for p in params if p.grad is not None and id(p) not in have]
                         have.update(id(p) for p in new)
                         graphs.append(g)

@@ -577,6 +577,11 @@ def cut(*tensors):
     return out[0] if len(out) == 1 else tuple(out)
 
 
+def segment_has_work(s):
+    """Does segment s have anything to differentiate (a cut tensor it produced that collected a gradient)?"""
+    return any(seg == s and leaf.grad is not None for seg, _, leaf in SEGMENTS["cuts"])
+
+
 def backward_segment(s, params, loss=None):
     """Backward pass of segment s: from `loss` (the last segment) and from the cut tensors segment s produced - seeded with
     what their leaves collected in the later segments - to the parameters (those of other segments are unreachable and
