@@ -22,7 +22,7 @@ def test_jet_heat_map_and_overlay():
     lut = _jet_lut()
     assert lut.shape == (256, 3) and lut.dtype == np.uint8
     assert tuple(lut[0]) == (0, 0, 128) and tuple(lut[255]) == (128, 0, 0) and lut[128, 1] == 255
-    assert np.all(np.diff(lut[:96, 2].astype(int)) >= 0) and np.all(np.diff(lut[160:, 0].astype(int)) <= 0) is not None
+    assert np.all(np.diff(lut[:96, 2].astype(int)) >= 0) and np.all(np.diff(lut[160:, 0].astype(int)) <= 0)
     img = np.random.RandomState(0).rand(8, 8, 3).astype(np.float32)
     mask = np.linspace(0, 1, 64, dtype=np.float32).reshape(8, 8)
     out = show_att_on_image(img, mask)
@@ -85,9 +85,10 @@ def test_pp256_tile_and_tail_plan_of_the_vit_layers():
     assert (full, tail) == (256, 8) and full + tail * sp <= 256 + 8 * 8
 
 
-def test_deferred_bn_counters_flush_once_and_not_after_an_exception():
+def test_deferred_bn_counters_flush_once_also_when_an_exception_leaves_the_block():
     """nn/autograd.deferred_bn_counters: batch_norm_train() only notes the `num_batches_tracked` buffers inside the block, the
-    OUTERMOST block bumps them all with one multi-tensor add; an exception leaves them alone."""
+    OUTERMOST block bumps them all with one multi-tensor add - also when an exception leaves the block: the running
+    statistics of the layers that ran were updated in place, the counters must say so."""
     from zeroshape_amd.nn import autograd as A
     counters = [torch.zeros((), dtype=torch.int64) for _ in range(5)]
     assert A._BN_COUNTERS[0] is None
@@ -103,7 +104,7 @@ def test_deferred_bn_counters_flush_once_and_not_after_an_exception():
             raise RuntimeError("forward failed")
     except RuntimeError:
         pass
-    assert int(counters[0]) == 1 and A._BN_COUNTERS[0] is None
+    assert int(counters[0]) == 2 and int(counters[1]) == 1 and A._BN_COUNTERS[0] is None
 
 
 def test_inline_split_mode_follows_the_precisions_and_a_change_re_packs_everything():
@@ -127,3 +128,21 @@ def test_inline_split_mode_follows_the_precisions_and_a_change_re_packs_everythi
     finally:
         A.set_forward_precision("f32")
         A.set_backward_precision("f32")
+
+
+def test_operand_form_switches_are_part_of_the_stamp():
+    """flipping PRESPLIT_ALL / INLINE_SPLIT at run time (tools, A/B tests) must make every packed operand stale -
+    in inline-split mode 2 the fp32 form has not been rewritten since the mode was entered."""
+    from zeroshape_amd.nn import autograd as A
+    w = torch.zeros(4, 4)
+    keep = (A.PRESPLIT_ALL, A.INLINE_SPLIT)
+    try:
+        s0 = A._stamp(w)
+        A.PRESPLIT_ALL = not keep[0]
+        s1 = A._stamp(w)
+        A.INLINE_SPLIT = not keep[1]
+        s2 = A._stamp(w)
+        assert len({s0, s1, s2}) == 3
+    finally:
+        A.PRESPLIT_ALL, A.INLINE_SPLIT = keep
+    assert A._stamp(w) == s0

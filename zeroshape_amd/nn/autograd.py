@@ -113,7 +113,15 @@ def _ceil4(n):
 
 
 def _stamp(w):
-    return (w.data_ptr(), w._version, GENERATION[0])
+    # ... and the switches that decide WHICH forms of a packed operand are kept current (in mode 2 the re-pack
+    # writes only the fp16 halves; a tool or test that flips PRESPLIT_ALL / INLINE_SPLIT at run time must find every record
+    # stale, not a fresh-looking stamp over an fp32 operand nobody has rewritten since)
+    return (w.data_ptr(), w._version, GENERATION[0], _operand_forms())
+
+
+def _operand_forms():
+    g = globals()
+    return (bool(g.get("PRESPLIT_ALL", True)), bool(g.get("INLINE_SPLIT", True)), FWD_CONV_PRECISION == "f16x3", BWD_DATA_PRECISION == "f16x3")
 
 
 _STD = {}       # id(weight) -> [weakref, eps, buffer, stamp]: standardised weights in persistent buffers
@@ -1032,7 +1040,9 @@ class deferred_bn_counters(object):
     def __exit__(self, *exc):
         if not self.outer:
             pending, _BN_COUNTERS[0] = _BN_COUNTERS[0], None
-            if pending and exc[0] is None:
+            # flushed whether or not an exception leaves the block: the counters describe running-statistics updates that
+            # already happened in place (a BatchNorm with momentum=None averages over exactly this count - ADVICE r05)
+            if pending:
                 torch._foreach_add_(pending, 1)
         return False
 
