@@ -124,9 +124,18 @@ def _worker_uneven(rank, world, initfile):
         dist.destroy_process_group()
 
 
+def _replay(net, statics, loss):
+    """What a hipGraph replay does: the gradients of THIS rank's graph land in the fixed tensors the capture allocated
+    (`statics`), whatever `.grad` points at by now."""
+    names = [n for n, p in net.named_parameters() if n in statics]
+    params = dict(net.named_parameters())
+    for n, g in zip(names, torch.autograd.grad(loss, [params[n] for n in names], allow_unused=True)):
+        statics[n].copy_(g if g is not None else torch.zeros_like(statics[n]))
+
+
 def _worker_in_place(rank, world, initfile):
-    """reduce_in_place(): the captured step's form - gradients stay in the tensors they were written to (a hipGraph replay's
-    static gradients), the hooks are quiet, every bucket is packed, all-reduced and copied back."""
+    """reduce_in_place(): the captured step's form - the replays keep writing the tensors the capture allocated, the hooks are
+    quiet, every bucket is packed from those tensors and all-reduced, `.grad` points at the bucket slices (no copy back)."""
     dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
     try:
         torch.manual_seed(0)
@@ -137,12 +146,10 @@ def _worker_in_place(rank, world, initfile):
         ref.load_state_dict(net.state_dict())
         data = [torch.randn(world, 6, 40, generator=torch.Generator().manual_seed(200 + it)) for it in range(3)]
         net(data[0][rank]).pow(2).mean().backward()                     # creates the gradient tensors ("the capture")
-        homes = {n: p.grad.data_ptr() for n, p in net.named_parameters() if p.grad is not None}
+        statics = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
         for it in range(3):
-            for p in net.parameters():                                  # a replay overwrites them in place
-                if p.grad is not None:
-                    p.grad.zero_()
-            net(data[it][rank]).pow(2).mean().backward()
+            if it:
+                _replay(net, statics, net(data[it][rank]).pow(2).mean())
             red.reduce_in_place()
             ref.zero_grad(set_to_none=True)
             for r in range(world):
@@ -151,9 +158,23 @@ def _worker_in_place(rank, world, initfile):
                 if n.startswith("unused"):
                     assert p.grad is None
                 else:
-                    assert p.grad.data_ptr() == homes[n], n             # still the same tensor
+                    assert red._grad_src[id(p)] is statics[n], n             # the replays' tensors are still the pack's source ...
+                    assert p.grad.data_ptr() == red._slice(p).data_ptr() != statics[n].data_ptr(), n   # ... .grad is the bucket slice
                     assert torch.allclose(p.grad, q.grad, atol=1e-6, rtol=1e-5), (it, n)
         assert len(red.buckets) >= 3 and not red.works
+        # a re-capture (the engine drops the gradients first) allocates new tensors: the reducer follows them
+        for p in net.parameters():
+            p.grad = None
+        net(data[1][rank]).pow(2).mean().backward()
+        fresh = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
+        red.reduce_in_place()
+        for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+            if not n.startswith("unused"):
+                assert red._grad_src[id(p)] is fresh[n] and fresh[n] is not statics[n]
+        ref.zero_grad(set_to_none=True)
+        for r in range(world):
+            (ref(data[1][r]).pow(2).mean() / world).backward()
+        assert torch.allclose(net.b.weight.grad, ref.b.weight.grad, atol=1e-6, rtol=1e-5)
         red.close()
     finally:
         dist.destroy_process_group()
@@ -173,14 +194,12 @@ def _worker_in_place_uneven(rank, world, initfile):
         xs = [[torch.randn(6, 40, generator=torch.Generator().manual_seed(70 + 10 * it + r)) for r in range(world)] for it in range(3)]
         net(xs[0][rank], use_sometimes=rank == 0).pow(2).mean().backward()       # "the capture": rank 1's graph has no `sometimes`
         assert (net.sometimes.grad is None) == (rank == 1)
-        local = [p for p in net.parameters() if p.grad is not None]
+        statics = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
         for it in range(3):
             # CONSECUTIVE steps: a replay overwrites the gradients of ITS graph only - the average the previous
-            # reduce_in_place() lent to a parameter without a local gradient must not be packed as this rank's contribution
+            # reduce_in_place() gave a parameter without a local gradient must not be packed as this rank's contribution
             if it:
-                for p in local:
-                    p.grad.zero_()
-                net(xs[it][rank], use_sometimes=rank == 0).pow(2).mean().backward()
+                _replay(net, statics, net(xs[it][rank], use_sometimes=rank == 0).pow(2).mean())
             red.reduce_in_place()
             assert net.sometimes.grad is not None and net.unused.weight.grad is None
             ref.zero_grad(set_to_none=True)
@@ -212,16 +231,19 @@ def _worker_in_place_segments(rank, world, initfile):
         ref = Net()
         ref.load_state_dict(net.state_dict())
         segs = [[net.c.weight, net.c.bias, net.sometimes], [net.b.weight, net.b.bias], [net.a.weight, net.a.bias]]
+        statics = None
         for it in range(2):
             x = [torch.randn(6, 40, generator=torch.Generator().manual_seed(300 + 10 * it + r)) for r in range(world)]
-            for p in net.parameters():
-                if p.grad is not None:
-                    p.grad.zero_()
-            net(x[rank]).pow(2).mean().backward()
-            truth = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+            if statics is None:
+                net(x[rank]).pow(2).mean().backward()                   # "the capture"
+                statics = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
+            else:
+                _replay(net, statics, net(x[rank]).pow(2).mean())
+            truth = {n: g.clone() for n, g in statics.items()}
+            name_of = {id(q): n for n, q in net.named_parameters()}
             # segments 2 and 3 "have not replayed yet": their gradient tensors hold garbage until launch_done() names them
             for p in segs[1] + segs[2]:
-                p.grad.fill_(float("nan"))
+                statics[name_of[id(p)]].fill_(float("nan"))
             assert red.begin_in_place()
 
             def expected(done):       # leading buckets made of final gradients only (a bucket that straddles a cut waits)
@@ -232,12 +254,12 @@ def _worker_in_place_segments(rank, world, initfile):
             n1 = red.launch_done(segs[0])
             assert n1 == expected(segs[:1]) and n1 < len(red.buckets)
             for p in segs[1]:
-                p.grad.copy_(truth[[n for n, q in net.named_parameters() if q is p][0]])
+                statics[name_of[id(p)]].copy_(truth[name_of[id(p)]])
             n2 = red.launch_done(segs[1])
             assert n2 == expected(segs[:2]) and 1 <= n2 < len(red.buckets)      # out before the last segment exists
             assert len(red.works) == n2
             for p in segs[2]:
-                p.grad.copy_(truth[[n for n, q in net.named_parameters() if q is p][0]])
+                statics[name_of[id(p)]].copy_(truth[name_of[id(p)]])
             n3 = red.launch_done(segs[2])
             assert n3 == len(red.buckets)
             red.end_in_place()

@@ -284,7 +284,7 @@ class GradReducer(object):
         self._hooks = []
         self.armed = True              # False during gradient-accumulation micro-steps: hooks stay quiet
         self.next_launch = 0           # collectives go out in bucket order
-        self._lent = []                # reduce_in_place: parameters whose .grad is an average this reducer put there
+        self._grad_src = {}                 # begin_in_place: id(parameter) -> the tensor the captured replays write its gradient into
         self._final = set()            # begin_in_place .. end_in_place: ids of the parameters whose gradients are final
         if self.world > 1 or self.always:
             with torch.no_grad():
@@ -335,13 +335,19 @@ class GradReducer(object):
         missing = False
         for p in plist:
             _, off = self.slot[id(p)]
+            if in_place:
+                # the captured step's gradients are FIXED tensors (self._grad_src: where the replays write them; .grad itself points
+                # at the bucket slice between the steps): rebinding one to a contiguous copy would detach it from the graph
+                g = self._grad_src.get(id(p))
+                if g is None:
+                    missing = True
+                    continue
+                assert g.is_contiguous(), "reduce_in_place: a gradient of the captured step is not contiguous"
+                entries.append((flat.data_ptr() + 4 * off, g.data_ptr(), p.numel()))
+                continue
             if p.grad is None:
                 missing = True
                 continue
-            if in_place:
-                # the captured step's gradients are FIXED tensors: rebinding one to a contiguous copy would detach it from the graph
-                assert p.grad.is_contiguous(), "reduce_in_place: a gradient of the captured step is not contiguous"
-                g = p.grad
             else:
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 p.grad = g
@@ -391,22 +397,32 @@ class GradReducer(object):
             mask = mask.cpu().tolist()
             self._build({id(p) for p, u in zip(self.params, mask) if u})
 
+    def _slice(self, p):
+        bi, off = self.slot[id(p)]
+        return self.flat[bi][off:off + p.numel()].view_as(p)
+
     def begin_in_place(self):
-        """The captured training step (model/shape_engine.py): hipGraph replays write the gradients into FIXED tensors, so they
-        cannot be re-pointed at the buckets as finish() does; the hooks stay quiet (`armed` False while the step is captured /
-        replayed).  begin_in_place() -> launch_done(params) after every replayed segment -> end_in_place(): a bucket is packed
-        (grad / world -> flat) and its all-reduce issued as soon as all its gradients are final, i.e. while the NEXT segment's
-        backward replays; end_in_place() flushes the rest, waits, and copies the averages back into the gradient tensors where
-        they live.  -> False when there is nothing to reduce (one rank, not `always`)."""
+        """The captured training step (model/shape_engine.py): hipGraph replays write the gradients into FIXED tensors, which
+        finish() would lose by re-pointing `.grad`; the hooks stay quiet (`armed` False while the step is captured / replayed).
+        begin_in_place() -> launch_done(params) after every replayed segment -> end_in_place(): the reducer remembers the tensors
+        the replays write (`_grad_src`: whatever it finds in `.grad` that is not one of its own bucket slices), packs a bucket
+        (src / world -> flat) and issues its all-reduce as soon as all its gradients are final, i.e. while the NEXT segment's
+        backward replays; end_in_place() flushes the rest, waits, and points every `.grad` at its slice of the reduced bucket -
+        the optimiser reads the averages there, no copy back (round 6; the copy-back was 0.77 GB read + written per step).
+        -> False when there is nothing to reduce (one rank, not `always`)."""
         if self.world == 1 and not self.always:
             return False
         self._ensure_layout()
-        # averages handed out last time to parameters WITHOUT a local gradient are not this rank's contribution: the replay does
-        # not write them (they are not in this rank's graph), so left in .grad they would be packed again as "local" gradients -
-        # a stale term in every rank's average from the second step on (ADVICE r05)
-        for q in self._lent:
-            q.grad = None
-        self._lent = []
+        for p in self.params:
+            if id(p) not in self.slot:
+                continue
+            g = p.grad
+            if g is None:
+                self._grad_src.pop(id(p), None)             # (a re-capture dropped it: no local gradient any more)
+            elif g.data_ptr() != self._slice(p).data_ptr():
+                self._grad_src[id(p)] = g                   # a gradient tensor of a (new) capture
+            # else: .grad is our slice - the source is unchanged, or the parameter has no local gradient (used on other
+            # ranks only: its slice carries the ranks' average, which must never be packed as this rank's contribution)
         self.next_launch = 0
         self._final = set()
         return True
@@ -417,7 +433,7 @@ class GradReducer(object):
         final: it contributes zeros).  Every rank issues the same buckets in the same order; WHEN it does may differ."""
         self._final.update(id(p) for p in params)
         while self.next_launch < len(self.buckets) and \
-                all(id(p) in self._final or p.grad is None for p in self.buckets[self.next_launch]):
+                all(id(p) in self._final or id(p) not in self._grad_src for p in self.buckets[self.next_launch]):
             self._launch(self.next_launch, in_place=True)
             self.next_launch += 1
         return self.next_launch
@@ -429,18 +445,11 @@ class GradReducer(object):
         self.works = []
         self.next_launch = 0
         for bi, plist in enumerate(self.buckets):
-            back = []
             for q in plist:
-                _, off = self.slot[id(q)]
-                if q.grad is not None:
-                    back.append((q.grad.data_ptr(), self.flat[bi].data_ptr() + 4 * off, q.numel()))
-                else:
-                    # in the layout (used on SOME rank) but without a local gradient: take the average like finish() does - a
-                    # private copy, the bucket is reused - or the ranks' parameters drift apart under uneven usage
-                    q.grad = self.flat[bi][off:off + q.numel()].view_as(q).clone()
-                    self._lent.append(q)
-            if back:
-                self.pack_fn(back, 1.0, self.flat[bi].device)
+                # also parameters in the layout (used on SOME rank) without a local gradient: they take the average like
+                # finish() gives it to them, or the ranks' parameters drift apart under uneven usage
+                if q.grad is None or q.grad.data_ptr() != self._slice(q).data_ptr():
+                    q.grad = self._slice(q)
             self.pending[bi] = len(plist)
 
     def reduce_in_place(self):
