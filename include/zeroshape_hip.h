@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 35
+#define ZS_ABI_VERSION 36
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -688,6 +688,12 @@ int zs_attention_bwd(const float *qkv, const float *dout, float *dqkv, void *wor
                      int head_dim, void *stream);
 int zs_point_attention(const float *qkv_points, const float *qkv_latent, float *out, int batch, int M, int Ll,
                        int heads, int head_dim, void *stream);
+/* The attention map a decoder call returns (implicit.py:60-66,277): attn[b][i][j] (=|+=, `accumulate`) weight * mean over the
+ * heads of the softmax probability of point i for latent token j (softmax over the Ll latent keys AND the point itself; the
+ * point's own column is dropped afterwards).  One call per attention block with weight = 1 / n_blocks gives the reference's
+ * average over blocks.  Same size limits as zs_point_attention. */
+int zs_point_attention_probs(const float *qkv_points, const float *qkv_latent, float *attn, int batch, int M, int Ll,
+                             int heads, int head_dim, float weight, int accumulate, void *stream);
 size_t zs_point_attention_bwd_workspace_bytes(int batch, int M, int Ll, int heads);
 int zs_point_attention_bwd(const float *qkv_points, const float *qkv_latent, const float *dout, float *dqkv_points,
                            float *dqkv_latent, int accumulate_latent, void *workspace, int batch, int M, int Ll,

@@ -45,6 +45,13 @@ def posenc_golden():
 
 
 @pytest.fixture(scope="session")
+def variants_golden():
+    """The reference's Implicit in other constructor configurations (tests/golden/make_variants_golden.py)."""
+    import numpy as np
+    return dict(np.load(os.path.join(GOLDEN, "variants_golden.npz")))
+
+
+@pytest.fixture(scope="session")
 def geometry_golden():
     import numpy as np
     return dict(np.load(os.path.join(GOLDEN, "geometry_golden.npz")))

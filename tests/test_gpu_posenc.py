@@ -2,7 +2,7 @@
 skip layers take 3 + 6 posenc_3D point features (model/shape/implicit.py:139-166, get_embedder utils/layers.py:8-53) - against
 the golden of the reference itself (tests/golden/make_posenc_golden.py) and the oracle.  The fused inference kernels are
 specialised for posenc_3D = 0; this variant runs layer by layer on the training path's HIP kernels (zs_posenc3d + the GEMM /
-attention / normalisation kernels), in inference and under autograd; the attention map still comes from the fused fp32 kernel."""
+attention / normalisation kernels), in inference and under autograd; the attention map comes from zs_point_attention_probs."""
 import numpy as np
 import pytest
 import torch

@@ -81,3 +81,47 @@ def test_oracle_posenc_3d_vs_reference_golden(posenc_golden, decoder_golden):
         assert float((leaf[k].grad.double() - w).norm()) <= 2e-5 * float(w.norm()), k
     w = torch.from_numpy(posenc_golden["grad.latent"]).double()
     assert float((lat.grad.double() - w).norm()) <= 2e-5 * float(w.norm())
+
+
+def _variant(name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_variants_golden", os.path.join(os.path.dirname(__file__), "golden",
+                                                                                       "make_variants_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)                   # (only its tables and the seeded inputs: nothing of the reference is imported)
+    return mod.VARIANTS[name], mod.inputs(name)
+
+
+@pytest.mark.parametrize("name", ["defaults", "head", "skips"])
+def test_oracle_other_constructor_configurations_vs_reference_golden(variants_golden, name):
+    """oracle/decoder_ref.py on the reference class's own defaults, on a prediction head + semantic codes + three blocks, and on
+    other skips + posenc_3D 2 - logits, attention rows and row sums, gradients - against the reference's outputs."""
+    from oracle import decoder_ref as R
+    from zeroshape_amd import synthetic as syn
+    from zeroshape_amd.utils.pos_embed import get_2d_sincos_pos_embed
+    v, (lat, sem, pts, w) = _variant(name)
+    g = int(round(v["syn"]["num_patches"] ** 0.5))
+    pe = get_2d_sincos_pos_embed(v["syn"]["n_channels"], g, cls_token=True).astype(np.float32)
+    np.testing.assert_allclose([pe.astype(np.float64).sum(), np.abs(pe.astype(np.float64)).sum()], variants_golden[name + ".pos_embed_sum"],
+                               rtol=1e-12)
+    sd = {k: torch.from_numpy(a) for k, a in syn.seeded_state_dict(seed=3, pos_embed=pe, **v["syn"]).items()}
+    per_layer = v["ctor"].get("pos_perlayer", True)
+    sem_t = torch.from_numpy(sem) if sem is not None else None
+    lg, at = R.implicit_forward(sd, torch.from_numpy(lat), torch.from_numpy(pts), num_heads=v["heads"], pos_perlayer=per_layer,
+                                latent_semantic=sem_t)
+    np.testing.assert_allclose(lg.numpy(), variants_golden[name + ".logit"], atol=5e-6, rtol=0)
+    np.testing.assert_allclose(at[:, ::64].numpy(), variants_golden[name + ".attn_rows"], atol=2e-7, rtol=0)
+    np.testing.assert_allclose(at.sum(-1).numpy(), variants_golden[name + ".attn_rowsum"], atol=2e-6, rtol=0)
+    leaf = {k: t.clone().requires_grad_(k != "pos_embed") for k, t in sd.items()}
+    lat_t = torch.from_numpy(lat).requires_grad_(True)
+    full = torch.cat([lat_t, sem_t], -1) if sem_t is not None else lat_t
+    out = R.implicit_forward_train(leaf, full, torch.from_numpy(pts), num_heads=v["heads"], pos_perlayer=per_layer)
+    (out * torch.from_numpy(w)).sum().backward()
+    for k in [k for k in variants_golden if k.startswith(name + ".grad.") and not k.endswith(".latent")]:
+        pk = k[len(name) + 6:]
+        stride = 16 if "qkv" in pk else (4 if pk.startswith("impl_mlp") else 1)
+        want = torch.from_numpy(variants_golden[k]).double()
+        got = leaf[pk].grad[::stride].double() if stride > 1 else leaf[pk].grad.double()
+        assert float((got - want).norm()) <= 2e-5 * float(want.norm()), k
+    want = torch.from_numpy(variants_golden[name + ".grad.latent"]).double()
+    assert float((lat_t.grad[:, ::8].double() - want).norm()) <= 2e-5 * float(want.norm())

@@ -164,6 +164,8 @@ SIGNATURES = {
     "zs_attention_bwd_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "zs_attention_bwd": (_c_int, [_c_void_p] * 4 + [_c_int] * 4 + [_c_void_p]),
     "zs_point_attention": (_c_int, [_c_void_p] * 3 + [_c_int] * 5 + [_c_void_p]),
+    "zs_point_attention_probs": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int,
+                                          _c_void_p]),
     "zs_point_attention_bwd_workspace_bytes": (_c_size_t, [_c_int] * 4),
     "zs_point_attention_bwd": (_c_int, [_c_void_p] * 5 + [_c_int, _c_void_p] + [_c_int] * 5 + [_c_void_p]),
     "zs_bce_logits_workspace_bytes": (_c_size_t, [_c_size_t]),
@@ -201,7 +203,7 @@ SIGNATURES = {
     "zs_readout_concat_bwd": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
 }
 
-ABI_VERSION = 35
+ABI_VERSION = 36
 _lib = None
 
 

@@ -116,6 +116,57 @@ __global__ __launch_bounds__(256) void point_attention_kernel(const float *__res
     }
 }
 
+// The attention MAP of the decoder call (implicit.py:60-66,277: per block the softmax probabilities of a point over the latent
+// tokens - the point's own column dropped after the softmax - averaged over the heads; the blocks' maps averaged by the
+// caller through `weight` / `accumulate`).  For decoder geometries the fused kernels (csrc/sdf_decoder.hip) are not specialised
+// for; a visualisation path: one wave per point, the heads in a loop, K_h restaged per head.
+constexpr int PP = 32;           // points per workgroup: 8 per wave, their probability sums stay in registers over the heads
+__global__ __launch_bounds__(256) void point_attention_probs_kernel(const float *__restrict__ qkv_p,
+                                                                    const float *__restrict__ qkv_l, float *__restrict__ attn,
+                                                                    int M, int Ll, int heads, float scale, float weight,
+                                                                    int accumulate) {
+    extern __shared__ float lds[];
+    float *Ks = lds, *Vs = Ks + Ll * KS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x, C = heads * D;
+    float acc[PP / 4][PA_MAXJ];
+#pragma unroll
+    for (int s = 0; s < PP / 4; s++)
+#pragma unroll
+        for (int t = 0; t < PA_MAXJ; t++) acc[s][t] = 0.f;
+    for (int h = 0; h < heads; h++) {
+        __syncthreads();
+        stage_kv(qkv_l, Ks, Vs, b, h, Ll, C);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < PP / 4; s++) {
+            const int i = blockIdx.y * PP + wave + 4 * s;
+            if (i >= M) continue;                      // (wave-uniform)
+            const float *src = qkv_p + ((size_t)b * M + i) * 3 * C + h * D;
+            float q[D], ks[D];
+#pragma unroll
+            for (int d = 0; d < D; d++) { q[d] = src[d]; ks[d] = src[C + d]; }
+            const Row r = softmax_row(q, ks, Ks, Ll, lane, scale);
+#pragma unroll
+            for (int t = 0; t < PA_MAXJ; t++) acc[s][t] += r.p[t];
+        }
+    }
+    const float w = weight / (float)heads;
+#pragma unroll
+    for (int s = 0; s < PP / 4; s++) {
+        const int i = blockIdx.y * PP + wave + 4 * s;
+        if (i >= M) continue;
+#pragma unroll
+        for (int t = 0; t < PA_MAXJ; t++) {
+            const int j = lane + 64 * t;
+            if (j < Ll) {
+                float *o = attn + ((size_t)b * M + i) * Ll + j;
+                *o = (accumulate ? *o : 0.f) + w * acc[s][t];
+            }
+        }
+    }
+}
+
 // The same on the MFMA pipe: one wave per (b, h, 32 points), transposed like the encoder's attention kernel
 // (csrc/nn_ops.hip): S^T[latent][point] = K_l Q^T per 32-latent tile, online softmax over a lane's registers + its
 // partner half, O^T[d][point] += V_l^T P^T with the probabilities staying in the lane that computed them; the point's
@@ -666,6 +717,19 @@ extern "C" int zs_point_attention(const float *qkv_points, const float *qkv_late
     hipLaunchKernelGGL(point_attention_kernel, grid, dim3(256), pa_lds_bytes(Ll, false), S(stream), qkv_points,
                        qkv_latent, out, M, Ll, heads, 1.0f / sqrtf((float)head_dim));
     return zs::check_launch("zs_point_attention") ? 1 : 0;
+}
+
+extern "C" int zs_point_attention_probs(const float *qkv_points, const float *qkv_latent, float *attn, int batch, int M,
+                                        int Ll, int heads, int head_dim, float weight, int accumulate, void *stream) {
+    ZS_REQUIRE(batch >= 0 && batch <= 65535 && M > 0 && Ll > 0 && Ll <= 64 * PA_MAXJ && heads > 0 && head_dim == D,
+               "zs_point_attention_probs: bad size (B=%d M=%d Ll=%d heads=%d head_dim=%d; Ll <= %d, head_dim %d)", batch, M, Ll,
+               heads, head_dim, 64 * PA_MAXJ, D);
+    if (batch == 0) return 1;
+    ZS_REQUIRE(qkv_points && qkv_latent && attn, "zs_point_attention_probs: null pointer");
+    ZS_REQUIRE((M + PP - 1) / PP <= 65535, "zs_point_attention_probs: too many points per call (M=%d)", M);
+    hipLaunchKernelGGL(point_attention_probs_kernel, dim3(batch, (M + PP - 1) / PP), dim3(256), pa_lds_bytes(Ll, false), S(stream),
+                       qkv_points, qkv_latent, attn, M, Ll, heads, 1.0f / sqrtf((float)head_dim), weight, accumulate ? 1 : 0);
+    return zs::check_launch("zs_point_attention_probs") ? 1 : 0;
 }
 
 static size_t pa_partial_floats(int batch, int M, int Ll, int heads) {

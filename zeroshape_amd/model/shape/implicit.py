@@ -17,11 +17,11 @@ network layer by layer through zeroshape_amd/nn/autograd.py - HIP kernels for ev
 backward op, torch.autograd only as the tape - including timm's per-sample DropPath
 (implicit.py:83-109, drop_path=0.1).
 
-``posenc_3D > 0`` (implicit.py:139-166; options/shape.yaml has 0) runs layer by layer on the training path's HIP kernels
-in inference too (`fused` is False: forward() and compute_level_grid's slice loop; prepare / query_* raise).
-
-Not on the HIP path (raises, never silently approximated):
-  * ``semantic=True`` (unused by options/shape.yaml).
+Every OTHER constructor configuration of the reference class with a head dimension of 32 - its own defaults (512 channels,
+16 heads, 6 MLP layers, latent_dim 768), a prediction head instead of the MLP (n_layers_mlp=0), other skips / ratios / block
+counts, ``posenc_3D > 0`` (implicit.py:139-166), ``semantic=True`` - runs layer by layer on the training path's HIP kernels in
+inference too (`fused` is False: forward(), with the attention map from zs_point_attention_probs, and compute_level_grid's
+slice loop; prepare / query_* raise).  Head dimensions other than 32 and more than 256 latent rows raise.
 """
 import contextlib
 import os
@@ -183,26 +183,33 @@ class Implicit(nn.Module):
     # ---- HIP path ---------------------------------------------------------------------
     @property
     def fused(self):
-        """True when the fused inference kernels (prepare / query_*) serve this configuration.  posenc_3D > 0
-        (implicit.py:139-166: the per-point MLP's first and skip layers take 3 + 6 posenc_3D point features) runs layer by
-        layer on the same HIP kernels as the training path instead - forward(), and the slice loop of compute_level_grid."""
-        return self.posenc_3D == 0
-
-    def _check_supported(self, fused=True):
+        """True when the fused inference kernels (prepare / query_*) serve this configuration: the geometry of
+        options/shape.yaml:19-44 the kernels are specialised for (256 channels, 8 heads, 2 blocks, 8 MLP layers, skips 2/4/6, 196
+        patches, posenc_3D 0, no semantic codes).  Every other constructor configuration of the reference class (its own
+        defaults - 512 channels, 16 heads, 6 MLP layers, latent_dim 768 - a prediction head instead of the MLP, other skips /
+        ratios / block counts, posenc_3D > 0, semantic codes) runs layer by layer on the same HIP kernels as the training
+        path instead - forward(), and the slice loop of compute_level_grid."""
         c = self.cfg
-        # pos_perlayer (the reference class's own default; options/shape.yaml:44 sets False) is a prologue option since round 5:
-        # both values run.  posenc_3D > 0 widens the per-point MLP's first and skip layers (implicit.py:147-150) - a kernel
-        # change, not built; the other entries are the kernels' compile-time geometry.
         want = dict(num_patches=P.L - 1, n_channels=P.C, latent_dim=P.C, n_blocks_attn=P.BLOCKS,
                     n_layers_mlp=P.MLP_LAYERS - 1, num_heads=P.HEADS, posenc_3D=0, mlp_ratio=4.0,
                     skip_in=P.SKIP_IN, semantic=False)
-        if not fused:
-            del want["posenc_3D"]                   # the layer-by-layer path takes any posenc_3D
-        bad = {k: (c[k], v) for k, v in want.items() if c[k] != v}
-        if bad:
-            raise NotImplementedError(
-                "the HIP decoder is specialised for options/shape.yaml:19-44; unsupported "
-                "(got, need): %s" % bad)
+        return all(c[k] == v for k, v in want.items())
+
+    def _check_supported(self, fused=True):
+        c = self.cfg
+        if fused:
+            if not self.fused:
+                raise NotImplementedError(
+                    "the fused HIP decoder kernels are specialised for options/shape.yaml:19-44; this configuration (%s) runs "
+                    "layer by layer - call the module (forward) instead of prepare / query_*" % c)
+            return
+        # the layer-by-layer path: what its kernels need (zs_point_attention / zs_attention: head dimension 32, <= 256 latent rows)
+        if c["n_channels"] % c["num_heads"] or c["n_channels"] // c["num_heads"] != 32:
+            raise NotImplementedError("the HIP attention kernels need a head dimension of 32 (n_channels %d / num_heads %d)"
+                                      % (c["n_channels"], c["num_heads"]))
+        if c["num_patches"] + 1 > 256 or c["n_blocks_attn"] < 1:
+            raise NotImplementedError("the HIP point-attention kernels take at most 256 latent rows (num_patches + 1 = %d) and "
+                                      "at least one attention block" % (c["num_patches"] + 1))
 
     def _weights_key(self):
         return (A.GENERATION[0], bool(self.pos_perlayer)) + tuple((p.data_ptr(), p._version) for p in self.parameters())
@@ -212,17 +219,8 @@ class Implicit(nn.Module):
         parameter changed (in-place update or re-assignment)."""
         key = (str(device),) + self._weights_key()
         if self._packed is None or self._packed[0] != key:
-            self._check_supported(fused=self.posenc_3D == 0)
+            self._check_supported()
             sd = {k: v.detach().float().cpu().numpy() for k, v in self.state_dict().items()}
-            if self.posenc_3D > 0:
-                # only the ATTENTION MAP of such a network comes from the fused kernel (forward(need_attn=True)): the map is
-                # complete before the per-point MLP starts, so the MLP is packed without its 6 posenc_3D encoding columns -
-                # the logits of this program are meaningless and never returned
-                e = 6 * self.posenc_3D
-                for l in (0,) + tuple(self.skip_in):
-                    w = sd["impl_mlp.layers.%d.weight" % l]
-                    at = 3 if l == 0 else P.C + 3
-                    sd["impl_mlp.layers.%d.weight" % l] = np.concatenate([w[:, :at], w[:, at + e:]], 1)
             prog = torch.from_numpy(P.pack_program(sd)).to(device)
             lat = torch.from_numpy(P.pack_latent_params(sd)).to(device)
             self._packed = (key, prog, lat, P.split_envelope(sd)[0])
@@ -342,9 +340,7 @@ class Implicit(nn.Module):
         False returns the split state unchecked (measurements of the arithmetic itself)."""
         precision = self.precision if precision is None else precision
         calibrate = self.calibrate if calibrate is None else calibrate
-        if not self.fused and not getattr(self, "_attn_only", False):
-            raise NotImplementedError("posenc_3D = %d: the fused decoder kernels are specialised for posenc_3D = 0; this "
-                                      "network runs layer by layer - call it (forward) instead of prepare / query_*" % self.posenc_3D)
+        self._check_supported()                 # (raises for configurations that run layer by layer)
         if precision not in ("f32", "f16x3"):
             raise ValueError("decoder precision must be 'f32' or 'f16x3', got %r" % (precision,))
         if not latent_depth.is_cuda:
@@ -640,18 +636,20 @@ class Implicit(nn.Module):
         """implicit.py:251-288.  Returns (logits [B,M], attn [B,M,197]) like the reference;
         callers that drop the attention map (our compute_level_grid without vis, training-shape
         probes) pass need_attn=False and get (logits, None) from the faster kernel variant."""
-        if self.semantic or latent_semantic is not None:
-            raise NotImplementedError("semantic latent codes are not used by options/shape.yaml")
-        if not self.fused or (torch.is_grad_enabled() and (self.training or points_3D.requires_grad or latent_depth.requires_grad)):
-            logits = self._forward_autograd(latent_depth, points_3D)
+        if self.semantic:                                                                            # :253
+            if latent_semantic is None:
+                raise ValueError("this Implicit was built with semantic=True: latent_semantic is required")
+            latent_depth = torch.cat([latent_depth.to(torch.float32), latent_semantic.to(torch.float32)], dim=-1)
+        elif latent_semantic is not None:
+            raise ValueError("latent_semantic given to an Implicit built with semantic=False")
+        if not self.fused:
+            return self._forward_autograd(latent_depth, points_3D, want_attn=need_attn)
+        if torch.is_grad_enabled() and (self.training or points_3D.requires_grad or latent_depth.requires_grad):
+            logits = self._forward_autograd(latent_depth, points_3D)[0]
             if not need_attn:
                 return logits, None
             with torch.no_grad():      # the attention map carries no gradient in the reference's losses
-                self._attn_only = True
-                try:
-                    return logits, self.query_points(self.prepare(latent_depth, "f32"), points_3D, need_attn=True)[1]
-                finally:
-                    self._attn_only = False
+                return logits, self.query_points(self.prepare(latent_depth, "f32"), points_3D, need_attn=True)[1]
         state = self.prepare(latent_depth)
         if need_attn and state.precision == "f32":
             return self.query_points(state, points_3D, need_attn=True)
@@ -671,10 +669,11 @@ class Implicit(nn.Module):
         keep = 1.0 - self.drop_path
         return torch.empty(B, dtype=torch.float32, device=device).bernoulli_(keep).div_(keep)
 
-    def _forward_autograd(self, latent_depth, points_3D):
+    def _forward_autograd(self, latent_depth, points_3D, want_attn=False):
         """implicit.py:251-288 with the latent rows and the point rows kept as two row blocks
         (every op but the attention is row-wise, and the attention treats the blocks differently
-        anyway, implicit.py:38-71), so no concatenated [B,197+M,C] tensor is ever built."""
+        anyway, implicit.py:38-71), so no concatenated [B,197+M,C] tensor is ever built.  Any constructor configuration
+        with a head dimension of 32 (_check_supported).  -> (logits [B,M], attention map [B,M,1+num_patches] | None)."""
         self._check_supported(fused=False)
         if not (latent_depth.is_cuda and points_3D.is_cuda):
             raise ValueError("latent_depth / points_3D must be GPU tensors; zeroshape_amd has no CPU path")
@@ -682,10 +681,17 @@ class Implicit(nn.Module):
         pts = points_3D.detach().to(torch.float32).contiguous()
         B, M = pts.shape[0], pts.shape[1]
         H = self.num_heads
+        Ll = self.num_patches + 1
+        if tuple(lat.shape[1:]) != (Ll, self.latent_proj.in_features):
+            raise ValueError("latent codes must be [B,%d,%d], got %s" % (Ll, self.latent_proj.in_features, tuple(lat.shape)))
+        attn = torch.empty(B, M, Ll, dtype=torch.float32, device=pts.device) if want_attn else None
         pts4 = A._pad_channels(pts, 4)
         xp = A.linear(pts4, self.point_proj.proj.weight, self.point_proj.proj.bias, cin=3)            # :253
         pos = self.pos_embed.detach().expand(B, -1, -1).contiguous()
-        xl = A.linear(lat, self.latent_proj.weight, self.latent_proj.bias, res1=pos)                # :255,271-272
+        cl = lat.shape[-1]
+        if cl % 4:
+            lat = A.pad_channels(lat.contiguous(), (cl + 3) // 4 * 4)
+        xl = A.linear(lat, self.latent_proj.weight, self.latent_proj.bias, res1=pos, cin=cl)         # :255,271-272
         nb = len(self.blocks_attn)
         scales = list(self.drop_scales) if self.drop_scales is not None else \
             [self._drop_scale(B, pts.device) for _ in range(2 * nb)]
@@ -710,6 +716,8 @@ class Implicit(nn.Module):
             qkv_l = A.linear(hl, blk.attn.qkv.weight, blk.attn.qkv.bias)
             hp, xp = A.layer_norm(xp, blk.norm1.weight, blk.norm1.bias, fork=True)
             qkv_p = A.linear(hp, blk.attn.qkv.weight, blk.attn.qkv.bias)
+            if want_attn:                                                                            # :60-66,277
+                A.point_attention_probs(qkv_p, qkv_l, H, attn, weight=1.0 / nb, accumulate=i > 0)
             op = A.point_attention(qkv_p, qkv_l, H)                                                  # :44-66
             xp = residual(xp, op, blk.attn.proj.weight, blk.attn.proj.bias, s_attn)
             hp, xp = A.layer_norm(xp, blk.norm2.weight, blk.norm2.bias, fork=True)
@@ -722,6 +730,8 @@ class Implicit(nn.Module):
                 hl = A.gelu(A.linear(hl, blk.mlp.fc1.weight, blk.mlp.fc1.bias))
                 xl = residual(xl, hl, blk.mlp.fc2.weight, blk.mlp.fc2.bias, s_mlp)
         feat = A.layer_norm(xp, self.norm.weight, self.norm.bias)                                    # :279
+        if self.impl_mlp is None:                                                                    # :284-286: prediction head
+            return A.linear(feat, self.pred_head.weight, self.pred_head.bias).squeeze(-1), attn
         # MLPBlocks (:168-184): inputs = cat([xyz, feat]); skip layers see cat([x, inputs]) / sqrt(2).
         # The concatenations become sums of column-range products of the same weight matrix.
         C = feat.shape[-1]
@@ -742,4 +752,4 @@ class Implicit(nn.Module):
             else:
                 y = A.linear(x, lin.weight, lin.bias)
             x = A.softplus(y, 100.0) if l < len(layers) - 1 else y
-        return x.squeeze(-1)
+        return x.squeeze(-1), attn

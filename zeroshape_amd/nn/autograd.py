@@ -910,6 +910,19 @@ def point_attention(qkv_p, qkv_l, heads):
     return _PointAttention.apply(qkv_p, qkv_l, heads)
 
 
+def point_attention_probs(qkv_p, qkv_l, heads, attn, weight=1.0, accumulate=False):
+    """attn [B,M,Ll] (=|+=) weight * mean over the heads of the points' softmax probabilities over the latent tokens (the
+    attention map the reference returns, implicit.py:60-66,277).  No gradient (visualisation only)."""
+    lib = _lib.load()
+    qp, ql = _f32c(qkv_p.detach(), "qkv points"), _f32c(qkv_l.detach(), "qkv latent")
+    B, M, Ll = qp.shape[0], qp.shape[1], ql.shape[1]
+    assert attn.shape == (B, M, Ll) and attn.is_contiguous() and attn.dtype == torch.float32
+    with _lib.on(qp.device):
+        _lib.check(lib.zs_point_attention_probs(_lib.ptr(qp), _lib.ptr(ql), _lib.ptr(attn), B, M, Ll, heads, qp.shape[-1] // (3 * heads),
+                                                float(weight), 1 if accumulate else 0, _stream(qp)), "zs_point_attention_probs")
+    return attn
+
+
 def _scaled_rows(x, branch, scale):
     lib = _lib.load()
     B = branch.shape[0]

@@ -48,6 +48,10 @@ def impl_network_shapes(n_channels=N_CHANNELS, latent_dim=LATENT_DIM, att_blocks
         s[p + "mlp.fc2.bias"] = (C,)
     s["norm.weight"] = (C,)
     s["norm.bias"] = (C,)
+    if mlp_layers == 0:                                   # implicit.py:226-229: a prediction head instead of the MLP
+        s["pred_head.weight"] = (1, C)
+        s["pred_head.bias"] = (1,)
+        return s
     dims = [3 + 6 * int(posenc_3D) + C] + [C] * mlp_layers + [1]
     for l in range(len(dims) - 1):
         in_dim = dims[l] + (dims[0] if l in skip_in else 0)
