@@ -12,7 +12,9 @@ resident in HBM: for a batch of n_gpus images (one per rank's worth of work, "we
 scaling) the per-image prologue + the fused decoder over every rank's share of each
 image's (128+1)^3 grid (equal point ranges in memory order, rounded to kernel tiles), then -
 for N > 1 - one RCCL all_gather that rebuilds the full occupancy grids on every rank
-(zeroshape_amd/parallel.py).  N = 1: one image, one full
+(zeroshape_amd/parallel.py).  For N > 1 every rank runs every image's prologue (0.5 ms at any batch up to 8, no
+collective), the per-image f16x3-vs-fp32 output check of image i runs on rank i mod N only and the 8-byte verdicts are
+all-gathered (parallel.prepare_sharded).  N = 1: one image, one full
 129^3 grid, no collective.  value = grid points evaluated by all ranks / max-over-ranks
 time.  Weights: seeded random (no checkpoint ships with the reference); latent_depth:
 seeded N(0,1).
