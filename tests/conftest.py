@@ -38,6 +38,13 @@ def grid_golden():
 
 
 @pytest.fixture(scope="session")
+def grid256_golden():
+    """The full 257^3 grid (BASELINE config 5) of the reference's own compute_level_grid (make_grid_golden.py 256)."""
+    import numpy as np
+    return dict(np.load(os.path.join(GOLDEN, "grid256_golden.npz")))
+
+
+@pytest.fixture(scope="session")
 def posenc_golden():
     """The reference's Implicit(posenc_3D=4) on the seeded weights (tests/golden/make_posenc_golden.py)."""
     import numpy as np

@@ -2,6 +2,7 @@
 """Full-grid goldens of the REAL reference at the BASELINE grid sizes (build container only).
 
 Run:  python tests/golden/make_grid_golden.py          (needs /root/reference; ~2 minutes on 8 threads)
+      python tests/golden/make_grid_golden.py 256      (BASELINE config 5's 257^3 grid -> grid256_golden.npz; ~17 minutes)
 
 The reference's own `get_dense_3D_grid` + `compute_level_grid` (utils/eval_3D.py:11-45) are run over the WHOLE
 (N+1)^3 grid at vox_res N = 64 and N = 128 (BASELINE.json configs 2 / 3) with the reference's `Implicit`
@@ -35,7 +36,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 
 NEAR = 1e-3
-STRIDE = {64: 4, 128: 8}
+STRIDE = {64: 4, 128: 8, 256: 16}
 
 
 def main():
@@ -73,8 +74,12 @@ def main():
             self.logits.append(lg[0].clone())
             return lg, at
 
+    # `python tests/golden/make_grid_golden.py 256`: BASELINE config 5's grid (257^3 = 17 M points, ~17 minutes, 13 GB of attention
+    # maps the reference keeps alive) into its own file, grid256_golden.npz
+    sizes = tuple(int(a) for a in sys.argv[1:]) or (64, 128)
+    target = "grid_golden.npz" if sizes == (64, 128) else "grid%s_golden.npz" % "_".join(str(n) for n in sizes)
     out = {}
-    for N in (64, 128):
+    for N in sizes:
         G = N + 1
         rec = Recorder()
         t0 = time.time()
@@ -99,8 +104,8 @@ def main():
               % (N, flat.size, time.time() - t0, int((occ > 0.5).sum()), NEAR, near.size, np.abs(flat).min(),
                  np.abs(flat).max()), flush=True)
     out["near_band"] = np.array([NEAR], np.float64)
-    np.savez_compressed(os.path.join(HERE, "grid_golden.npz"), **out)
-    print("grid_golden.npz: %d arrays, %d bytes" % (len(out), os.path.getsize(os.path.join(HERE, "grid_golden.npz"))))
+    np.savez_compressed(os.path.join(HERE, target), **out)
+    print("%s: %d arrays, %d bytes" % (target, len(out), os.path.getsize(os.path.join(HERE, target))))
 
 
 if __name__ == "__main__":

@@ -23,14 +23,16 @@ def test_product_pos_embed_and_rotation_sphere_vs_the_reference(decoder_golden, 
     np.testing.assert_array_equal(R[[0, 1, 12, 287, 288, 1234, 6911]].numpy(), geometry_golden["rot_rows"])
 
 
-@pytest.mark.parametrize("N", [64, 128])
-def test_oracle_vs_full_grid_golden_of_the_reference(seeded_sd, grid_golden, N):
+@pytest.mark.parametrize("N", [64, 128, 256])
+def test_oracle_vs_full_grid_golden_of_the_reference(seeded_sd, grid_golden, grid256_golden, N):
     """oracle/decoder_ref.py against the reference's own full-grid run at the BASELINE sizes: every near-surface point
     (|logit| < 1e-3: the candidates for an index flip) and the strided sample, logits within 2e-5, no sign disagreement
     outside |logit| < 1e-5."""
     from oracle import decoder_ref as R
     from zeroshape_amd import synthetic as syn
     G = N + 1
+    if N == 256:
+        grid_golden = grid256_golden
     latent = torch.from_numpy(syn.seeded_latent(seed=0, batch=2))[:1]
     axis = torch.linspace(-1.5, 1.5, G)
     idx, want = grid_golden["near%d_idx" % N].astype(np.int64), grid_golden["near%d_logit" % N]
@@ -40,7 +42,7 @@ def test_oracle_vs_full_grid_golden_of_the_reference(seeded_sd, grid_golden, N):
     np.testing.assert_allclose(got, want, atol=2e-5, rtol=0)
     flips = (got > 0) != (want > 0)
     assert np.all(np.abs(want[flips]) < 1e-5)
-    s = {64: 4, 128: 8}[N]
+    s = {64: 4, 128: 8, 256: 16}[N]
     a = axis[::s]
     gx, gy, gz = torch.meshgrid(a, a, a, indexing="ij")
     pts = torch.stack([gx, gy, gz], -1).view(1, -1, 3)
