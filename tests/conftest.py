@@ -45,6 +45,13 @@ def grid256_golden():
 
 
 @pytest.fixture(scope="session")
+def eval_golden():
+    """The reference's own eval_metrics_default / eval_metrics_BF / brute_force_search on seeded clouds (make_eval_golden.py)."""
+    import numpy as np
+    return dict(np.load(os.path.join(GOLDEN, "eval_golden.npz")))
+
+
+@pytest.fixture(scope="session")
 def posenc_golden():
     """The reference's Implicit(posenc_3D=4) on the seeded weights (tests/golden/make_posenc_golden.py)."""
     import numpy as np

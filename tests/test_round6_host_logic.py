@@ -127,3 +127,34 @@ def test_oracle_other_constructor_configurations_vs_reference_golden(variants_go
         assert float((got - want).norm()) <= 2e-5 * float(want.norm()), k
     want = torch.from_numpy(variants_golden[name + ".grad.latent"]).double()
     assert float((lat_t.grad[:, ::8].double() - want).norm()) <= 2e-5 * float(want.norm())
+
+
+def test_oracle_evaluation_glue_vs_reference_golden(eval_golden):
+    """oracle/geometry_ref.py (normalize_pc, chamfer_distance on the C kernel restatement, icp, compute_fscore,
+    brute_force_search) composed the way utils/eval_3D.py:104-213 composes them, against what the reference's own
+    eval_metrics_default / eval_metrics_BF / brute_force_search returned for the same clouds."""
+    from oracle import geometry_ref as G
+    g = eval_golden
+    thresholds = (0.005, 0.01, 0.02, 0.05, 0.1, 0.2)
+    pred, gt, pose = torch.from_numpy(g["pred"]), torch.from_numpy(g["gt"]), torch.from_numpy(g["pose"])
+
+    def view_frame(flip):
+        p = (pose[..., :3] @ gt.permute(0, 2, 1)).permute(0, 2, 1).contiguous()          # :120-121
+        if flip:
+            p[:, :, :2] *= -1                                                            # :122-123 (pix3d)
+        return p
+    for tag, flip, icp in (("default_synthetic", False, False), ("default_pix3d_icp", True, True)):
+        a, b = G.normalize_pc(pred), G.normalize_pc(view_frame(flip))
+        if icp:
+            a = G.icp(a, b)
+        d1, d2, _, _ = G.chamfer_distance(a, b)
+        np.testing.assert_allclose(d1.mean(1).numpy(), g[tag + ".cd_acc"], atol=1e-6, rtol=0)
+        np.testing.assert_allclose(d2.mean(1).numpy(), g[tag + ".cd_comp"], atol=1e-6, rtol=0)
+        np.testing.assert_allclose(G.compute_fscore(d1, d2, thresholds).numpy(), g[tag + ".f_score"], atol=1e-6, rtol=0)
+        np.testing.assert_allclose(a.numpy(), g[tag + ".dpc_pred"], atol=2e-6, rtol=0)
+        np.testing.assert_allclose(b.numpy(), g[tag + ".dpc_gt"], atol=1e-6, rtol=0)
+    out = G.brute_force_search(pred[0], gt[0], thresholds)
+    acc, comp, fs, best_pred = out[0], out[1], out[2], out[3]
+    assert abs(float(acc) - float(g["search.acc"])) < 1e-6 and abs(float(comp) - float(g["search.comp"])) < 1e-6
+    np.testing.assert_allclose(np.asarray(fs, np.float32).reshape(-1), g["search.f_score"].reshape(-1), atol=1e-6, rtol=0)
+    np.testing.assert_allclose(np.asarray(best_pred, np.float32).reshape(-1, 3), g["search.best_pred"], atol=2e-6, rtol=0)

@@ -475,11 +475,18 @@ def _surface_clouds(opt, level_vox, seed=0):
 
 
 def _gt_to_view_frame(opt, var):
-    # utils/eval_3D.py:120-123 / :186-190
-    R_gt = var.pose_gt[..., :3]
-    var.dpc.points = (R_gt @ var.dpc.points.permute(0, 2, 1)).permute(0, 2, 1).contiguous()
+    """utils/eval_3D.py:120-123 / :186-190: the ground truth rotated into the view frame (R_gt p, no translation; x and y
+    negated for pix3d).  One launch of zs_transform_points (round 6: the reference's `R @ p^T` was a rocBLAS batched GEMM on
+    this path) - the pix3d sign flip rides on the rotation's first two rows, which negates exactly."""
+    from . import camera
+    pose = var.pose_gt.detach().to(torch.float32)
+    B = pose.shape[0]
+    T = torch.zeros(B, 3, 4, dtype=torch.float32, device=pose.device)
+    T[:, :, :3] = pose[..., :3]
     if opt.data.dataset_test == 'pix3d':
-        var.dpc.points[:, :, :2] *= -1
+        T[:, :2] = -T[:, :2]
+    zero, one = torch.zeros(B, 3, device=pose.device), torch.ones(B, device=pose.device)
+    var.dpc.points = camera.transform_points(var.dpc.points, T, zero, one)
 
 
 @torch.no_grad()
