@@ -172,7 +172,8 @@ def test_captured_step_with_a_grad_reducer_on_one_gpu(tmp_path, encoder_sd, seed
         dist.destroy_process_group()
 
 
-def test_segmented_captured_step_overlaps_buckets_and_changes_nothing(tmp_path, encoder_sd, seeded_sd):
+@pytest.mark.parametrize("amp", [False, True])
+def test_segmented_captured_step_overlaps_buckets_and_changes_nothing(tmp_path, encoder_sd, seeded_sd, amp):
     """with a reducer that really exchanges buckets the step is captured as one hipGraph per backward
     segment (nn/autograd.py "Segmented backward": decoder + losses | coordinate encoder | DPT decoder + heads | ViT blocks
     6-11 | blocks 3-5 | stem + blocks 0-2) and the buckets go out between the replays.  RCCL group of one rank, the WHOLE
@@ -184,12 +185,13 @@ def test_segmented_captured_step_overlaps_buckets_and_changes_nothing(tmp_path, 
     from zeroshape_amd.utils import util
     from zeroshape_amd.utils.options import EasyDict as edict
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29536")
+    os.environ["MASTER_PORT"] = "29537" if amp else "29536"
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:
         results = []
         for segments in (False, True):
-            opt = train_opt(tmp_path, "--optim.hip_graph", "--optim.hip_graph_segments=%s" % ("true" if segments else "false"))
+            opt = train_opt(tmp_path, "--optim.hip_graph", "--optim.hip_graph_segments=%s" % ("true" if segments else "false"),
+                            *(["--optim.amp"] if amp else []))      # amp: split-fp16 GEMMs + the loss scaler (unscale / skip read .grad)
             r = make_runner(opt, encoder_sd, seeded_sd, n_train=4)
             r.reducer = parallel.GradReducer(r.graph.parameters(), bucket_mb=16.0, always=True)
             assert r._step_capture_enabled(opt) and r._segmented_capture(opt) == segments
