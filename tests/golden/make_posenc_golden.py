@@ -73,8 +73,8 @@ def main():
     params = dict(net.named_parameters())
     for k in ["impl_mlp.layers.0.weight", "impl_mlp.layers.2.weight", "impl_mlp.layers.6.weight", "impl_mlp.layers.8.weight",
               "blocks_attn.0.attn.qkv.weight", "point_proj.proj.weight", "latent_proj.bias"]:
-        out["grad." + k] = params[k].grad.numpy().copy()
-    out["grad.latent"] = lat.grad.numpy().copy()
+        out["grad." + k] = params[k].grad.numpy()[::(16 if "qkv" in k else 4 if k.startswith("impl_mlp") and k.endswith("weight") and params[k].shape[0] > 1 else 1)].copy()
+    out["grad.latent"] = lat.grad.numpy()[:, ::8].copy()      # (rows: every 16th of the qkv weight, 4th of the MLP layers, 8th latent token)
     np.savez_compressed(os.path.join(HERE, "posenc_golden.npz"), **out)
     print("posenc_golden.npz: %d arrays, logit range [%.3f, %.3f], %d bytes"
           % (len(out), lg.min().item(), lg.max().item(), os.path.getsize(os.path.join(HERE, "posenc_golden.npz"))))

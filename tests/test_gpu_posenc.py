@@ -76,7 +76,8 @@ def test_gradients_vs_reference_golden(net, posenc_golden):
     params = dict(net.named_parameters())
     for k in [k[5:] for k in posenc_golden if k.startswith("grad.") and k != "grad.latent"]:
         w = torch.from_numpy(posenc_golden["grad." + k]).double()
-        g = params[k].grad.cpu().double()
+        stride = 16 if "qkv" in k else (4 if k.startswith("impl_mlp") and params[k].shape[0] > 1 else 1)
+        g = params[k].grad.cpu()[::stride].double()
         assert float((g - w).norm()) <= 1e-4 * float(w.norm()), (k, float((g - w).norm()) / float(w.norm()))
     w = torch.from_numpy(posenc_golden["grad.latent"]).double()
-    assert float((latent.grad.cpu().double() - w).norm()) <= 1e-4 * float(w.norm())
+    assert float((latent.grad.cpu()[:, ::8].double() - w).norm()) <= 1e-4 * float(w.norm())

@@ -80,9 +80,10 @@ def test_oracle_posenc_3d_vs_reference_golden(posenc_golden, decoder_golden):
     (out * torch.from_numpy(posenc_golden["loss_weights"])).sum().backward()
     for k in [k[5:] for k in posenc_golden if k.startswith("grad.") and k != "grad.latent"]:
         w = torch.from_numpy(posenc_golden["grad." + k]).double()
-        assert float((leaf[k].grad.double() - w).norm()) <= 2e-5 * float(w.norm()), k
+        stride = 16 if "qkv" in k else (4 if k.startswith("impl_mlp") and leaf[k].shape[0] > 1 else 1)
+        assert float((leaf[k].grad[::stride].double() - w).norm()) <= 2e-5 * float(w.norm()), k
     w = torch.from_numpy(posenc_golden["grad.latent"]).double()
-    assert float((lat.grad.double() - w).norm()) <= 2e-5 * float(w.norm())
+    assert float((lat.grad[:, ::8].double() - w).norm()) <= 2e-5 * float(w.norm())
 
 
 def _variant(name):
