@@ -45,6 +45,14 @@ def grid256_golden():
 
 
 @pytest.fixture(scope="session")
+def grid_gain60_golden():
+    """The full 129^3 grid of the reference for the seeded network at a converged checkpoint's logit scale (last three MLP
+    layers x 60^(1/3): |logit| up to 36) on another image (make_grid_golden.py 128 gain=60 latent=1)."""
+    import numpy as np
+    return dict(np.load(os.path.join(GOLDEN, "grid128_gain60_golden.npz")))
+
+
+@pytest.fixture(scope="session")
 def eval_golden():
     """The reference's own eval_metrics_default / eval_metrics_BF / brute_force_search on seeded clouds (make_eval_golden.py)."""
     import numpy as np

@@ -76,8 +76,17 @@ def main():
 
     # `python tests/golden/make_grid_golden.py 256`: BASELINE config 5's grid (257^3 = 17 M points, ~17 minutes, 13 GB of attention
     # maps the reference keeps alive) into its own file, grid256_golden.npz
-    sizes = tuple(int(a) for a in sys.argv[1:]) or (64, 128)
-    target = "grid_golden.npz" if sizes == (64, 128) else "grid%s_golden.npz" % "_".join(str(n) for n in sizes)
+    # `python tests/golden/make_grid_golden.py 128 gain=60 latent=1`: the same network with its last three MLP layers scaled to a
+    # converged checkpoint's logit scale (synthetic.confident_state_dict: |logit| up to ~30) on ANOTHER image -> grid128_gain60_golden.npz
+    sizes = tuple(int(a) for a in sys.argv[1:] if a.isdigit()) or (64, 128)
+    kw = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
+    gain, latent_seed = float(kw.get("gain", 1)), int(kw.get("latent", 0))
+    target = "grid_golden.npz" if sizes == (64, 128) and not kw else \
+        "grid%s%s_golden.npz" % ("_".join(str(n) for n in sizes), "_gain%g" % gain if gain != 1 else "")
+    if gain != 1:
+        sd_np = syn.confident_state_dict(sd_np, gain)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    latent = torch.from_numpy(syn.seeded_latent(seed=latent_seed, batch=2))[:1]
     out = {}
     for N in sizes:
         G = N + 1
@@ -104,6 +113,7 @@ def main():
               % (N, flat.size, time.time() - t0, int((occ > 0.5).sum()), NEAR, near.size, np.abs(flat).min(),
                  np.abs(flat).max()), flush=True)
     out["near_band"] = np.array([NEAR], np.float64)
+    out["gain_and_latent_seed"] = np.array([gain, latent_seed], np.float64)
     np.savez_compressed(os.path.join(HERE, target), **out)
     print("%s: %d arrays, %d bytes" % (target, len(out), os.path.getsize(os.path.join(HERE, target))))
 
