@@ -81,3 +81,56 @@ def test_the_yaml_geometry_stays_on_the_fused_kernels_and_odd_head_sizes_raise(d
         odd(torch.zeros(1, 197, 64).cuda(), None, torch.zeros(1, 8, 3).cuda())
     with pytest.raises(ValueError):
         m.cuda()(torch.zeros(1, 197, 256).cuda(), torch.zeros(1, 197, 8).cuda(), torch.zeros(1, 8, 3).cuda())
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_random_constructor_configurations_vs_oracle(seed):
+    """Random constructor configurations (head dimension 32) against the CPU oracle: channel / head counts, 1-3 blocks,
+    0-8 MLP layers with random skips, posenc_3D 0-3, mlp_ratio, patch counts, latent widths that are NOT multiples of 4 (the
+    padded-operand path), semantic codes, pos_perlayer - logits, attention map and the gradient of the latent codes."""
+    from oracle import decoder_ref as R
+    from zeroshape_amd.model.shape.implicit import Implicit
+    from zeroshape_amd.utils.pos_embed import get_2d_sincos_pos_embed
+    rs = np.random.RandomState(100 + seed)
+    heads = int(rs.choice([2, 4, 8, 16]))
+    C = 32 * heads
+    blocks = int(rs.randint(1, 4))
+    mlp_layers = int(rs.choice([0, 1, 3, 5, 8]))
+    skips = tuple(sorted(int(x) for x in rs.choice(np.arange(1, max(mlp_layers, 2)), size=min(2, max(mlp_layers - 1, 0)), replace=False))) \
+        if mlp_layers > 1 else ()
+    posenc = int(rs.randint(0, 4)) if mlp_layers else 0
+    g = int(rs.choice([5, 7, 14]))
+    sem = int(rs.choice([0, 0, 10]))
+    latent_dim = int(rs.choice([64, 130, 257])) + sem
+    ratio = float(rs.choice([1.0, 2.0, 4.0]))
+    per_layer = bool(rs.randint(0, 2))
+    cfg = dict(n_channels=C, latent_dim=latent_dim, att_blocks=blocks, mlp_ratio=ratio, mlp_layers=mlp_layers, skip_in=skips,
+               num_patches=g * g, posenc_3D=posenc)
+    pe = get_2d_sincos_pos_embed(C, g, cls_token=True).astype(np.float32)
+    sd = {k: torch.from_numpy(a) for k, a in syn.seeded_state_dict(seed=20 + seed, pos_embed=pe, **cfg).items()}
+    net = Implicit(g * g, latent_dim=latent_dim, semantic=sem > 0, n_channels=C, n_blocks_attn=blocks, n_layers_mlp=mlp_layers,
+                   num_heads=heads, posenc_3D=posenc, mlp_ratio=ratio, skip_in=list(skips), pos_perlayer=per_layer)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    assert not net.fused
+    M = int(rs.choice([1, 33, 200]))
+    lat = torch.from_numpy(rs.randn(2, g * g + 1, latent_dim - sem).astype(np.float32))
+    semt = torch.from_numpy(rs.randn(2, g * g + 1, sem).astype(np.float32)) if sem else None
+    pts = torch.from_numpy(rs.uniform(-1.5, 1.5, size=(2, M, 3)).astype(np.float32))
+    want, want_at = R.implicit_forward(sd, lat, pts, num_heads=heads, pos_perlayer=per_layer, latent_semantic=semt)
+    with torch.no_grad():
+        got, at = net(lat.cuda(), semt.cuda() if sem else None, pts.cuda())
+    scale = max(1.0, float(want.abs().max()))
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=3e-5 * scale, rtol=0, err_msg=str(cfg))
+    np.testing.assert_allclose(at.cpu().numpy(), want_at.numpy(), atol=5e-7, rtol=0)
+    # gradient of the latent codes through the whole network (autograd over HIP kernels vs torch CPU autograd of the oracle)
+    w = torch.from_numpy(rs.randn(2, M).astype(np.float32))
+    lat_r = lat.clone().cuda().requires_grad_(True)
+    out, _ = net(lat_r, semt.cuda() if sem else None, pts.cuda(), need_attn=False)
+    (out * w.cuda()).sum().backward()
+    leaf = {k: t.clone() for k, t in sd.items()}
+    lat_c = lat.clone().requires_grad_(True)
+    full = torch.cat([lat_c, semt], -1) if sem else lat_c
+    (R.implicit_forward_train(leaf, full, pts, num_heads=heads, pos_perlayer=per_layer) * w).sum().backward()
+    wg = lat_c.grad.double()
+    assert float((lat_r.grad.cpu().double() - wg).norm()) <= 2e-4 * float(wg.norm()) + 1e-9, cfg
