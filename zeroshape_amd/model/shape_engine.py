@@ -15,6 +15,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from ..nn import autograd as A
 from ..utils import eval_3D, util
 from ..utils.options import EasyDict as edict
 from .compute_graph.graph_shape import Graph
@@ -200,7 +201,9 @@ class Runner:
             loss_scaled = scaler.scale_loss(loss_scaled)
         if self.reducer is not None:          # only the last micro-step of an accumulation window is reduced
             self.reducer.armed = (self.it + 1) % opt.optim.accum == 0
-        loss_scaled.backward()
+        # (weight gradients on a side stream only where nothing reads a gradient before the join: no bucket hooks, no accumulation)
+        with A.side_wgrads(self._side_wgrads(opt) and self.reducer is None and opt.optim.accum == 1):
+            loss_scaled.backward()
         if (self.it + 1) % opt.optim.accum == 0:
             if self.reducer is not None:
                 self.reducer.finish()
@@ -242,6 +245,12 @@ class Runner:
         flag = os.environ.get("ZS_TRAIN_HIP_GRAPH")
         on = flag not in ("0", "") if flag is not None else bool(opt.optim.get("hip_graph", False))
         return on and opt.optim.accum == 1
+
+    def _side_wgrads(self, opt):
+        """Weight-gradient GEMMs on a side stream beside the data-gradient chain (nn/autograd.py SIDE_WGRAD)?
+        optim.side_wgrads / ZS_TRAIN_SIDE_WGRADS (A/B switch)."""
+        flag = os.environ.get("ZS_TRAIN_SIDE_WGRADS")
+        return flag not in ("0", "") if flag is not None else bool(opt.optim.get("side_wgrads", False))
 
     def _segmented_capture(self, opt):
         """Capture the step as one hipGraph per backward segment?  Only worth it when buckets are really exchanged (a reducer
@@ -305,14 +314,15 @@ class Runner:
                         out_var, loss = self.graph.forward(opt, static_var, training=True, get_loss=True)
                         loss = self.summarize_loss(opt, out_var, loss)
                         last = A.SEGMENTS["index"]
-                        A.backward_segment(last, params, loss=loss.all if scaler is None else scaler.scale_loss(loss.all))
+                        with A.side_wgrads(self._side_wgrads(opt)):
+                            A.backward_segment(last, params, loss=loss.all if scaler is None else scaler.scale_loss(loss.all))
                     have = {id(p) for p in params if p.grad is not None}
                     seg_params = [[p for p in params if id(p) in have]]
                     for s in range(last - 1, -1, -1):
                         if not A.segment_has_work(s):
                             continue                # (a frozen or absent part of the network: nothing to capture)
                         g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g, pool=graph.pool(), stream=cs):
+                        with torch.cuda.graph(g, pool=graph.pool(), stream=cs), A.side_wgrads(self._side_wgrads(opt)):
                             ran = A.backward_segment(s, [p for p in params if id(p) not in have])
                         assert ran
                         new = [p for p in params if p.grad is not None and id(p) not in have]
@@ -325,7 +335,8 @@ class Runner:
                 with torch.cuda.graph(graph, stream=cs):
                     out_var, loss = self.graph.forward(opt, static_var, training=True, get_loss=True)
                     loss = self.summarize_loss(opt, out_var, loss)
-                    (loss.all if scaler is None else scaler.scale_loss(loss.all)).backward()
+                    with A.side_wgrads(self._side_wgrads(opt)):
+                        (loss.all if scaler is None else scaler.scale_loss(loss.all)).backward()
             loss = edict({k: (v.detach() if torch.is_tensor(v) else v) for k, v in loss.items()})
             st = self._captured = dict(sig=sig, scratch=A.SCRATCH_GENERATION[0], graph=graph, graphs=graphs,
                                        seg_params=seg_params, static=static, loss=loss)

@@ -9,6 +9,7 @@ change (zs_pack_conv_weight), so optimiser steps need no host work.
 Reference behaviour reproduced: what torch.autograd gives train.py for Graph.forward(training=True)
 (model/compute_graph/graph_shape.py:115-204) and Loss.shape_loss (utils/loss.py:18-28).
 """
+import contextlib
 import os
 
 import torch
@@ -585,6 +586,45 @@ def cut(*tensors):
     return out[0] if len(out) == 1 else tuple(out)
 
 
+# Weight gradients on a side stream (see _Conv.backward).  Off unless the caller of backward() switches it on AND joins
+# afterwards: a gradient tensor handed to autograd is written later, on another stream.
+SIDE_WGRAD = [False]
+_SIDE_STREAMS = {}
+_SIDE_KEEP = []
+
+
+def _side_wgrad_stream(device):
+    st = _SIDE_STREAMS.get(str(device))
+    if st is None:
+        st = _SIDE_STREAMS[str(device)] = torch.cuda.Stream(device=device)
+    return st
+
+
+def join_side_wgrads():
+    """The current stream of every device with weight gradients in flight waits for them; their operands may be freed."""
+    for dev, st in _SIDE_STREAMS.items():
+        torch.cuda.current_stream(torch.device(dev)).wait_stream(st)
+    _SIDE_KEEP.clear()
+
+
+class side_wgrads(object):
+    """with side_wgrads(on): loss.backward()  - weight gradients overlap the data-gradient chain, joined on exit."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = SIDE_WGRAD[0]
+        SIDE_WGRAD[0] = self.on
+        return self
+
+    def __exit__(self, *exc):
+        SIDE_WGRAD[0] = self.prev
+        if self.on:
+            join_side_wgrads()
+        return False
+
+
 def segment_has_work(s):
     """Does segment s have anything to differentiate (a cut tensor it produced that collected a gradient)?"""
     return any(seg == s and leaf.grad is not None for seg, _, leaf in SEGMENTS["cuts"])
@@ -689,19 +729,29 @@ class _Conv(torch.autograd.Function):
             dw = torch.zeros_like(weight) if sub else torch.empty_like(weight)
             if want_b:          # the bias gradient rides on the weight-gradient kernel (it stages dY anyway)
                 db = torch.empty(cout, dtype=torch.float32, device=x.device)
-            ws = scratch(x.device, "wgrad", _ws_bytes("zs_conv2d_wgrad_workspace_bytes", B, Ho, Wo, Cx, cout, kh, kw))
+            dws = torch.empty_like(weight) if std_eps is not None else None
             flags = (_CONV_IN_RELU if in_relu else 0) | (_CONV_F16X3 if wgrad_precision() == "f16x3" else 0)
-            with _lib.on(x.device):
-                _lib.check(lib.zs_conv2d_wgrad(_lib.ptr(x), _lib.ptr(gp), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws), B, H, W, Cx, Ho,
-                                               Wo, cout, kh, kw, stride, pt, pl, flags, float(in_scale),
-                                               float(in_shift), cin, cin0, weight.shape[1], 0, _stream(x)),
-                           "zs_conv2d_wgrad")
-            if std_eps is not None:
-                dws = torch.empty_like(weight)
+            # SIDE_WGRAD (the engine's backward passes): nothing in the backward pass waits for a weight gradient, so it goes to a
+            # side stream behind everything enqueued so far and the data-gradient chain continues at once - the weight-gradient
+            # launches fill the tails of the chain's launches (join_side_wgrads() before anyone reads a gradient)
+            side = _side_wgrad_stream(x.device) if SIDE_WGRAD[0] else None
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream(x.device))
+                _SIDE_KEEP.append((x, gp, weight, dw, db, dws))       # alive until the join: the side stream reads / writes them
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                ws = scratch(x.device, "wgrad_side" if side is not None else "wgrad",
+                             _ws_bytes("zs_conv2d_wgrad_workspace_bytes", B, Ho, Wo, Cx, cout, kh, kw))
                 with _lib.on(x.device):
-                    _lib.check(lib.zs_standardize_weight_bwd(_lib.ptr(weight.detach()), _lib.ptr(dw), _lib.ptr(dws),
-                                                             weight.shape[0], weight[0].numel(), float(std_eps),
-                                                             _stream(x)), "zs_standardize_weight_bwd")
+                    _lib.check(lib.zs_conv2d_wgrad(_lib.ptr(x), _lib.ptr(gp), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws), B, H, W, Cx, Ho,
+                                                   Wo, cout, kh, kw, stride, pt, pl, flags, float(in_scale),
+                                                   float(in_shift), cin, cin0, weight.shape[1], 0, _stream(x)),
+                               "zs_conv2d_wgrad")
+                if std_eps is not None:
+                    with _lib.on(x.device):
+                        _lib.check(lib.zs_standardize_weight_bwd(_lib.ptr(weight.detach()), _lib.ptr(dw), _lib.ptr(dws),
+                                                                 weight.shape[0], weight[0].numel(), float(std_eps),
+                                                                 _stream(x)), "zs_standardize_weight_bwd")
+            if std_eps is not None:
                 dw = dws
         dx = None
         if need_x:
