@@ -34,8 +34,8 @@ Extra objects on the JSON line:
                  barriers, launch event-timed inside each step) through the exact-fp32 kernel - the reference's own
                  arithmetic: ms_per_step, value, its roofline object - and the largest |logit| difference and the
                  occupancy flips between the two arithmetics on the full grid.
-  virtual_ranks_8 - (N = 1) what ONE rank of `--gpus 8` does per step (batch 8, its point range of every image), timed for
-                 every rank in turn on this GPU; `bound` = the compute-side weak-scaling bound (tools/bench_legs.py).
+  virtual_ranks_8 / _4 / _2 - (N = 1) what ONE rank of `--gpus 8 / 4 / 2` does per step (batch N, its point range of every image),
+                 timed for every rank in turn on this GPU; `bound` = the compute-side weak-scaling bound (tools/bench_legs.py).
   cpu_baseline - the oracle (torch-CPU fp32 restatement of the reference, "port") timed on
                  this host's cores on a bounded sample of x-slices of the same grid.
   calibration  - Implicit.prepare's once-per-weight-version verdict on the requested arithmetic: max |f16x3 - f32| logit
@@ -408,6 +408,8 @@ def main():
                          ("encoder", lambda: legs.encoder_leg(dev, cpu)),
                          ("encoder_att", lambda: legs.encoder_att_leg(dev)), ("vox256", lambda: legs.vox256_leg(dev, net)),
                          ("virtual_ranks_8", lambda: legs.virtual_ranks_leg(dev, net)),
+                         ("virtual_ranks_4", lambda: legs.virtual_ranks_leg(dev, net, world=4)),
+                         ("virtual_ranks_2", lambda: legs.virtual_ranks_leg(dev, net, world=2)),
                          ("inference", lambda: legs.inference_leg(dev)), ("iso_surface", lambda: legs.surface_leg(dev)),
                          ("train_step", lambda: legs.in_subprocess("train", "train_step")),
                          ("trained_weights", lambda: legs.in_subprocess("trained", "trained_weights"))):
