@@ -493,6 +493,28 @@ def test_per_image_check_sends_an_outlier_image_to_the_exact_kernels():
     assert torch.equal(m.query_grid(lat, axis, apply_sigmoid=False, state=st0), g)
 
 
+def test_sharded_prepare_on_a_rank_without_an_image_of_its_own(net):
+    """More ranks than images (evaluate.py --eval.shard_image with batch 1 on 8 GPUs): rank r > 0 checks nothing itself, still
+    joins the exchange, and serves its point range with the verdict it received - the same numbers as the unsharded state."""
+    from zeroshape_amd import parallel
+    latent = torch.from_numpy(syn.seeded_latent(seed=4, batch=1)).cuda()
+    axis = torch.linspace(-1.5, 1.5, 33).cuda()
+    want = net.query_grid_range(latent, axis, 4096, 9000, state=net.prepare(latent))
+    calls = []
+
+    def gather(own):
+        calls.append(own.cpu().clone())
+        full = own.new_zeros((8,) + tuple(own.shape))
+        full[3] = own                                  # this rank's (empty) contribution; rank 0's verdict: passed
+        return full
+    st = parallel.prepare_sharded(net, latent, rank=3, world_size=8, gather=gather)
+    torch.cuda.current_stream().wait_event(st.check_event)
+    assert len(calls) == 1 and calls[0].shape == (1, 2) and int(calls[0].abs().sum()) == 0
+    assert st.image_flags.cpu().tolist() == [0] and st.precision == "f16x3"
+    assert float(net.last_calibration["per_image_max_abs_diff"].cpu()[0]) == -1.0       # not measured on this rank
+    assert torch.equal(net.query_grid_range(latent, axis, 4096, 9000, state=st), want)
+
+
 def test_dynamic_tile_order_leaves_its_counter_at_zero_and_changes_no_value(net):
     """Round 4: the split kernels draw tiles from a counter in the workspace tail.  Launches of very different sizes back to
     back (fewer tiles than workgroups, one tile, many tiles, a grid) give the values a fresh workspace gives, and the counter is
