@@ -182,5 +182,7 @@ def test_bench_line_contract():
         assert leg in d, leg
     assert d["iso_surface"]["vox128"]["triangles"] > 1000 and 0 < d["iso_surface"]["vox128"]["ms"] < 5
     assert 0 < d["train_step"]["ms_amp"] < d["train_step"]["ms"] <= d["train_step"]["ms_eager"] * 1.05
+    wr = d["train_step"]["with_reducer_1rank"]          # the data-parallel step's rank-local work: six segment graphs, buckets between
+    assert wr["graphs"] == 6 and wr["buckets_issued_after_each_replay"][-1] == wr["buckets"] and 0.8 < wr["compute_side_bound"] < 1.05
     assert d["inference"]["vox64"]["points"] == 65 ** 3 and 0 < d["inference"]["vox64"]["ms"] < d["inference"]["vox128"]["ms"]
     assert d["pose_search"]["pruned_equals_exhaustive"] is True and d["chamfer_l1"]["chamfer_l1_vs_oracle_pipeline_vox16"] < 1e-4

@@ -604,6 +604,28 @@ def train_leg(dev, steps=8, warmup=3):
     finally:
         A.set_forward_precision("f32")
         A.set_backward_precision("f32")
+    # what ONE rank of the data-parallel step does besides (BASELINE config 4 at 4 images per GPU): the captured step with a
+    # GradReducer that really packs and issues its buckets - an RCCL group of one rank, GradReducer(always=True) - as one graph
+    # per backward segment.  ms / ms_with_reducer = the compute-side weak-scaling bound of the captured step.
+    with_reducer = None
+    try:
+        import torch.distributed as dist
+        from tools import train_segments
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29543")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        try:
+            rec = train_segments.run(True, steps)
+        finally:
+            dist.destroy_process_group()
+        with_reducer = {"ms": rec["ms_per_step"], "graphs": rec["graphs"], "buckets": rec["buckets"],
+                        "buckets_issued_after_each_replay": rec["buckets_issued_after_each_replay"],
+                        "gradient_mb_per_segment": rec["gradient_mb_per_segment"],
+                        "compute_side_bound": round(ms / rec["ms_per_step"], 4),
+                        "what": "captured step, one hipGraph per backward segment, 1-rank RCCL reducer: packs + collective calls "
+                                "without a wire; the ring all-reduce itself is unmeasured"}
+    except Exception as ex:                               # never take the leg down
+        with_reducer = {"error": "%s: %s" % (type(ex).__name__, ex)}
     tflop = 3 * 4 * (GFLOP_DPT + GFLOP_RES + GFLOP_INTR + 4096 * 5.0e-3) / 1e3      # forward + 2x backward
     return {"per_gpu_batch": 4, "sdf_points": 4096, "ms": round(ms, 2), "mode": "fp32, optim.hip_graph (captured step)",
             "ms_eager": round(ms_eager, 2), "ms_amp": round(ms_amp, 2), "images_per_s": round(4 / ms * 1e3, 1),
@@ -611,6 +633,7 @@ def train_leg(dev, steps=8, warmup=3):
             # one eager step's calls into libzeroshape_hip.so (a call is one to a few launches; a kernel trace counts
             # ~2,000 launches per step, profiles/r02_train_b4_final_*) and what a data-parallel step all-reduces
             "abi_calls_per_step": counts.get("abi_calls"), "allreduce_bytes_per_step": counts.get("grad_bytes"),
+            "with_reducer_1rank": with_reducer,
             "allreduce": "fp32 gradients in 64 MB buckets under the backward pass (parallel.GradReducer); never run on > 1 GPU"}
 
 
