@@ -5,7 +5,7 @@ buckets issued between the replays (the default) - what the split itself costs w
 Under `tools/prof_train_timeline.sh` the kernel trace of the segmented form shows where the bucket launches
 (`copy_multi_kernel` = pack, RCCL kernels when the group has more than one rank) fall inside the backward window.
 
-    python3 tools/train_segments.py [segments|single|both] [steps]"""
+    python3 tools/train_segments.py [segments|single|eager|both] [steps]"""
 import json
 import os
 import sys
@@ -22,12 +22,14 @@ from zeroshape_amd.utils import options, util          # noqa: E402
 from zeroshape_amd.utils.options import EasyDict as edict   # noqa: E402
 
 
-def run(segments, steps):
+def run(segments, steps, eager=False):
+    """eager=True: the DEFAULT data-parallel step (options/shape.yaml: hip_graph false) - eager launches, the buckets packed and
+    all-reduced by the gradient hooks under the backward pass (GradReducer.finish)."""
     from zeroshape_amd.model.shape_engine import Runner
     cmd = options.parse_arguments(["--yaml=%s/options/shape.yaml" % ROOT, "--output_root=/tmp/zs_bench_train", "--batch_size=4",
                                    "--pretrain.depth=", "--arch.depth.pretrained=", "--training.n_sdf_points=4096",
-                                   "--optim.lr=1.e-7", "--optim.lr_ft=1.e-7", "--optim.hip_graph",
-                                   "--optim.hip_graph_segments=%s" % ("true" if segments else "false")] +
+                                   "--optim.lr=1.e-7", "--optim.lr_ft=1.e-7"] +
+                                  ([] if eager else ["--optim.hip_graph", "--optim.hip_graph_segments=%s" % ("true" if segments else "false")]) +
                                   (["--optim.amp"] if os.environ.get("ZS_TRAIN_AMP") else []))
     opt = options.set(cmd)
     opt.world_size = 1
@@ -53,9 +55,9 @@ def run(segments, steps):
         step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
-    cap = r._captured
-    out = {"segments": bool(segments), "ms_per_step": round(ms, 3), "graphs": len(cap["graphs"]), "buckets": len(r.reducer.buckets),
-           "bucket_mb": [round(f.numel() * 4 / 2 ** 20, 1) for f in r.reducer.flat]}
+    cap = getattr(r, "_captured", None) or {"graphs": [], "seg_params": None}
+    out = {"segments": bool(segments), "eager": bool(eager), "ms_per_step": round(ms, 3), "graphs": len(cap["graphs"]),
+           "buckets": len(r.reducer.buckets), "bucket_mb": [round(f.numel() * 4 / 2 ** 20, 1) for f in r.reducer.flat]}
     if cap["seg_params"] is not None:
         out["parameters_per_segment"] = [len(g) for g in cap["seg_params"]]
         out["gradient_mb_per_segment"] = [round(sum(p.numel() for p in g) * 4 / 2 ** 20, 1) for g in cap["seg_params"]]
@@ -71,7 +73,8 @@ if __name__ == "__main__":
     os.environ.setdefault("MASTER_PORT", "29541")
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:
-        res = [run(m == "segments", steps) for m in (("single", "segments") if mode == "both" else (mode,))]
+        res = [run(m == "segments", steps, eager=m == "eager")
+               for m in (("single", "segments", "eager") if mode == "both" else (mode,))]
     finally:
         dist.destroy_process_group()
     print(json.dumps(res), flush=True)
