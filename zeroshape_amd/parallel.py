@@ -230,13 +230,23 @@ def gather_sample_rows(ids, tensors, group=None):
 # =============================================================================================
 # Data-parallel training: bucketed gradient averaging overlapped with the backward pass
 # =============================================================================================
+_PACK_TABLES = {}        # (device, entries) -> device tables of hip_pack: the captured step packs the same tensors every step
+
+
 def hip_pack(entries, scale, device):
     """Default bucket packer: ONE zs_copy_multi launch copies `scale * grad` of every tensor of a
-    bucket into its slot of the flat buffer.  entries: [(dst_ptr, src_ptr, numel)]."""
+    bucket into its slot of the flat buffer.  entries: [(dst_ptr, src_ptr, numel)].  The device tables of an entry list are
+    kept (the captured step's sources never move: 12 host-built tables + uploads per step otherwise); bounded, oldest first."""
     from . import _lib
     from .optim import build_table
     lib = _lib.load()
-    tab, ct, cs, n = build_table([(d, s, 0, 0, k, 0.0, 0.0) for d, s, k in entries], device)
+    key = (str(device), tuple(entries))
+    hit = _PACK_TABLES.get(key)
+    if hit is None:
+        if len(_PACK_TABLES) >= 256:
+            _PACK_TABLES.pop(next(iter(_PACK_TABLES)))
+        hit = _PACK_TABLES[key] = build_table([(d, s, 0, 0, k, 0.0, 0.0) for d, s, k in entries], device)
+    tab, ct, cs, n = hit
     with torch.cuda.device(device):
         _lib.check(lib.zs_copy_multi(_lib.ptr(tab), _lib.ptr(ct), _lib.ptr(cs), n, float(scale),
                                      _lib.current_stream_ptr(device)), "zs_copy_multi")
@@ -401,6 +411,11 @@ class GradReducer(object):
         bi, off = self.slot[id(p)]
         return self.flat[bi][off:off + p.numel()].view_as(p)
 
+    def _slice_ptr(self, p):
+        """Address of p's bucket slice (an int: the per-step loops over ~600 parameters must not build tensor views)."""
+        bi, off = self.slot[id(p)]
+        return self.flat[bi].data_ptr() + 4 * off
+
     def begin_in_place(self):
         """The captured training step (model/shape_engine.py): hipGraph replays write the gradients into FIXED tensors, which
         finish() would lose by re-pointing `.grad`; the hooks stay quiet (`armed` False while the step is captured / replayed).
@@ -419,7 +434,7 @@ class GradReducer(object):
             g = p.grad
             if g is None:
                 self._grad_src.pop(id(p), None)             # (a re-capture dropped it: no local gradient any more)
-            elif g.data_ptr() != self._slice(p).data_ptr():
+            elif g.data_ptr() != self._slice_ptr(p):
                 self._grad_src[id(p)] = g                   # a gradient tensor of a (new) capture
             # else: .grad is our slice - the source is unchanged, or the parameter has no local gradient (used on other
             # ranks only: its slice carries the ranks' average, which must never be packed as this rank's contribution)
@@ -448,7 +463,7 @@ class GradReducer(object):
             for q in plist:
                 # also parameters in the layout (used on SOME rank) without a local gradient: they take the average like
                 # finish() gives it to them, or the ranks' parameters drift apart under uneven usage
-                if q.grad is None or q.grad.data_ptr() != self._slice(q).data_ptr():
+                if q.grad is None or q.grad.data_ptr() != self._slice_ptr(q):
                     q.grad = self._slice(q)
             self.pending[bi] = len(plist)
 
