@@ -294,6 +294,7 @@ class GradReducer(object):
         self._hooks = []
         self.armed = True              # False during gradient-accumulation micro-steps: hooks stay quiet
         self.next_launch = 0           # collectives go out in bucket order
+        self._views = {}
         self._grad_src = {}                 # begin_in_place: id(parameter) -> the tensor the captured replays write its gradient into
         self._final = set()            # begin_in_place .. end_in_place: ids of the parameters whose gradients are final
         if self.world > 1 or self.always:
@@ -326,7 +327,7 @@ class GradReducer(object):
             size += nbytes
         if cur:
             self.buckets.append(cur)
-        self.flat, self.slot, self.pending = [], {}, []
+        self.flat, self.slot, self.pending, self._views = [], {}, [], {}
         for bi, plist in enumerate(self.buckets):
             total = sum(p.numel() for p in plist)
             flat = torch.zeros(total, dtype=torch.float32, device=plist[0].device)
@@ -395,8 +396,7 @@ class GradReducer(object):
         self.next_launch = 0
         for bi, plist in enumerate(self.buckets):
             for p in plist:
-                _, off = self.slot[id(p)]
-                p.grad = self.flat[bi][off:off + p.numel()].view_as(p)
+                p.grad = self._slice(p)
             self.pending[bi] = len(plist)
 
     def _ensure_layout(self):
@@ -408,8 +408,13 @@ class GradReducer(object):
             self._build({id(p) for p, u in zip(self.params, mask) if u})
 
     def _slice(self, p):
-        bi, off = self.slot[id(p)]
-        return self.flat[bi][off:off + p.numel()].view_as(p)
+        """p's slice of its reduced bucket, shaped like p (ONE tensor object per parameter, made on first use: finish() hands
+        ~600 of them out after every backward pass, between the last all-reduce and the optimiser)."""
+        v = self._views.get(id(p))
+        if v is None:
+            bi, off = self.slot[id(p)]
+            v = self._views[id(p)] = self.flat[bi][off:off + p.numel()].view_as(p)
+        return v
 
     def _slice_ptr(self, p):
         """Address of p's bucket slice (an int: the per-step loops over ~600 parameters must not build tensor views)."""
