@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 36
+#define ZS_ABI_VERSION 37
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -134,6 +134,14 @@ int zs_sdf_prologue(void *programs, size_t program_stride_bytes, const float *la
 #define ZS_SDF_POS_PERLAYER 1
 int zs_sdf_prologue_ex(void *programs, size_t program_stride_bytes, const float *lat_params,
                        const float *latent_depth, int batch, void *scratch, int flags, void *stream);
+
+/* The comparison behind the choice of arithmetic (zeroshape_amd/model/shape/implicit.py: Implicit.prepare): got / want
+ * [batch][m] logits of the same probe points from the split-fp16 and the exact-fp32 kernel -> stats[batch][5] = max |got - want|,
+ * mean |got - want|, max |want|, max |sigmoid(got) - sigmoid(want)|, number of sign disagreements at |want| >= flip_band (any
+ * non-finite input: the first four NaN); flags (optional) [batch][2] int32 = 1 when the image FAILS the raw-logit rule
+ * (max |d| <= tol) / the occupancy rule (max |d occ| <= tol_occ and no such disagreement).  One launch, fixed reduction order. */
+int zs_sdf_verdict_stats(const float *got, const float *want, int batch, int m, float flip_band, float tol, float tol_occ,
+                         float *stats, int *flags, void *stream);
 
 /* logits[batch][m] = Implicit(latent, None, points[batch][m][3]) (pre-sigmoid).
  * attn (optional, may be NULL): [batch][m][197] = mean over heads and blocks of the

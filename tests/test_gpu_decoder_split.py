@@ -493,6 +493,35 @@ def test_per_image_check_sends_an_outlier_image_to_the_exact_kernels():
     assert torch.equal(m.query_grid(lat, axis, apply_sigmoid=False, state=st0), g)
 
 
+def test_verdict_statistics_of_both_output_spaces(net):
+    """Implicit._verdict_stats (one launch of zs_sdf_verdict_stats per check): a confident network's raw error fails the raw
+    rule while its occupancies agree; a flip counts only outside the band; a non-finite value fails both rules; the numbers
+    equal the tensor-op formulation they replaced."""
+    want = torch.tensor([[40.0, -35.0, 2e-6, -3e-4, 0.2]]).cuda()
+    got = want + torch.tensor([[6e-5, -5e-5, -4e-6, 1e-6, 1e-6]]).cuda()      # index 2 flips inside the band
+    st, fl = net._verdict_stats(got, want)
+    assert abs(float(st[0, 0]) - 6e-5) < 4e-6 and float(st[0, 0]) > net.CALIBRATION_TOL          # raw rule fails (fp32 ulp at 40: 3.8e-6)
+    assert float(st[0, 3]) <= net.CALIBRATION_TOL_OCC and float(st[0, 4]) == 0.0                 # occupancy rule passes
+    assert fl.cpu().tolist() == [[1, 0]]
+    got2 = want.clone()
+    got2[0, 3] = 1e-6                                   # a flip at |logit| 3e-4: outside the band
+    st2, fl2 = net._verdict_stats(got2, want)
+    assert float(st2[0, 4]) == 1.0 and fl2.cpu().tolist() == [[1, 1]]           # (3.01e-4 of raw difference, and the flip)
+    rs = np.random.RandomState(3)
+    w = torch.from_numpy(rs.randn(3, 4096).astype(np.float32)).cuda()
+    g = w + torch.from_numpy((1e-5 * rs.randn(3, 4096)).astype(np.float32)).cuda()
+    g[1, 100] = float("nan")
+    st3, fl3 = net._verdict_stats(g, w)
+    d = (g - w).abs()
+    ref = torch.stack([d.amax(-1), d.mean(-1), w.abs().amax(-1), (torch.sigmoid(g) - torch.sigmoid(w)).abs().amax(-1),
+                       (((g > 0) != (w > 0)) & (w.abs() >= net.FLIP_BAND)).sum(-1).float()], -1)
+    for b in (0, 2):
+        np.testing.assert_allclose(st3[b].cpu().numpy(), ref[b].cpu().numpy(), rtol=1e-5, atol=1e-9)
+    assert bool(torch.isnan(st3[1, :4]).all()) and fl3[1].cpu().tolist() == [1, 1]
+    assert fl3[0].cpu().tolist() == [1 if float(ref[0, 0]) > net.CALIBRATION_TOL else 0,
+                                     1 if float(ref[0, 3]) > net.CALIBRATION_TOL_OCC or float(ref[0, 4]) else 0]
+
+
 def test_sharded_prepare_on_a_rank_without_an_image_of_its_own(net):
     """More ranks than images (evaluate.py --eval.shard_image with batch 1 on 8 GPUs): rank r > 0 checks nothing itself, still
     joins the exchange, and serves its point range with the verdict it received - the same numbers as the unsharded state."""

@@ -44,21 +44,6 @@ def test_confident_state_dict_scales_the_logits():
     assert 20.0 < ratio < 200.0              # ~gain (softplus(beta=100) is homogeneous to ~1e-2, upstream biases are not scaled)
 
 
-def test_verdict_statistics_of_both_output_spaces():
-    """Implicit._verdict_stats on CPU tensors: a confident network's raw error fails the raw rule while its occupancies agree;
-    a flip counts only outside the band."""
-    from zeroshape_amd.model.shape.implicit import Implicit
-    net = Implicit.__new__(Implicit)                     # the method reads class constants only
-    want = torch.tensor([[40.0, -35.0, 2e-6, -3e-4, 0.2]])
-    got = want + torch.tensor([[6e-5, -5e-5, -4e-6, 1e-6, 1e-6]])      # index 2 flips inside the band
-    st = Implicit._verdict_stats(net, got, want)[0]
-    assert abs(float(st[0]) - 6e-5) < 4e-6 and float(st[0]) > Implicit.CALIBRATION_TOL          # raw rule fails (fp32 ulp at 40: 3.8e-6)
-    assert float(st[3]) <= Implicit.CALIBRATION_TOL_OCC and float(st[4]) == 0.0                 # occupancy rule passes
-    got2 = want.clone()
-    got2[0, 3] = 1e-6                                   # a flip at |logit| 3e-4: outside the band
-    assert float(Implicit._verdict_stats(net, got2, want)[0, 4]) == 1.0
-
-
 def _pp256_plan(M, cout_pad, K, cus=256, max_split=8, min_steps=4, parts_cap=512):
     """csrc/nn_conv.hip, the 256 x 256 kernel's launcher: (whole tiles, tail tiles, K ranges per tail tile)."""
     T = -(-M // 256) * -(-cout_pad // 256)

@@ -44,6 +44,8 @@ SIGNATURES = {
                                  _c_void_p, _c_void_p]),
     "zs_sdf_prologue_ex": (_c_int, [_c_void_p, _c_size_t, _c_void_p, _c_void_p, _c_int,
                                     _c_void_p, _c_int, _c_void_p]),
+    "zs_sdf_verdict_stats": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_float, _c_float, _c_float, _c_void_p, _c_void_p,
+                                      _c_void_p]),
     "zs_sdf_query_points": (_c_int, [_c_void_p, _c_size_t, _c_int, _c_void_p, _c_int,
                                      _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "zs_sdf_query_grid": (_c_int, [_c_void_p, _c_size_t, _c_int, _c_void_p, _c_int, _c_int,
@@ -203,7 +205,7 @@ SIGNATURES = {
     "zs_readout_concat_bwd": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
 }
 
-ABI_VERSION = 36
+ABI_VERSION = 37
 _lib = None
 
 

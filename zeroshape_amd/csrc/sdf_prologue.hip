@@ -78,11 +78,16 @@ __global__ __launch_bounds__(LIN_THREADS) void lat_linear_kernel(
     float acc[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; r++) acc[r] = 0.f;
-#pragma unroll 4
-    for (int k = 0; k < K; k++) {
-        const float w = Wt[(size_t)k * N + n];
+    // 16 weight loads in flight per thread (round 6: with 4 the K loop was a chain of exposed L2 latencies - 32 us per launch
+    // for 13 MFLOP); the products are still added in k order: bit-identical results
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        float w[16];
 #pragma unroll
-        for (int r = 0; r < ROWS; r++) acc[r] = fmaf(xs[r][k], w, acc[r]);
+        for (int j = 0; j < 16; j++) w[j] = Wt[(size_t)(k0 + j) * N + n];
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) acc[r] = fmaf(xs[r][k0 + j], w[j], acc[r]);
     }
     const float b = bias[n];
 #pragma unroll
@@ -185,6 +190,75 @@ void launch_linear(hipStream_t s, int batch, const float *X, int ldx, size_t x_s
 }
 
 }  // namespace
+
+// The verdict of Implicit.prepare()'s f16x3-vs-fp32 probe check in ONE launch (one workgroup per image): until round 6 it
+// was ~15 ATen launches (abs, compare, amax, mean, two sigmoids, ...) on the check's side stream - small kernels that share
+// their CUs with the grid launch's priority-raised MFMA waves and took up to 9 ms EACH there (rocprofv3: reduce_kernel 9.4 ms),
+// which a short grid launch (vox 64: 4.3 ms) then had to wait for.
+__global__ __launch_bounds__(256) void verdict_stats_kernel(const float *__restrict__ got, const float *__restrict__ want, int m,
+                                                            float band, float tol, float tol_occ, float *__restrict__ stats,
+                                                            int *__restrict__ flags) {
+    __shared__ float red[4][256];
+    __shared__ int redi[2][256];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float *g = got + (size_t)b * m, *w = want + (size_t)b * m;
+    float mx = 0.f, sum = 0.f, mw = 0.f, mo = 0.f;
+    int flips = 0, bad = 0;
+    for (int i = t; i < m; i += 256) {
+        const float x = g[i], y = w[i];
+        if (!isfinite(x) || !isfinite(y)) bad = 1;
+        const float d = fabsf(x - y);
+        mx = fmaxf(mx, d);
+        sum += d;
+        mw = fmaxf(mw, fabsf(y));
+        mo = fmaxf(mo, fabsf(1.0f / (1.0f + expf(-x)) - 1.0f / (1.0f + expf(-y))));
+        flips += ((x > 0.f) != (y > 0.f)) && fabsf(y) >= band;
+    }
+    red[0][t] = mx; red[1][t] = sum; red[2][t] = mw; red[3][t] = mo;
+    redi[0][t] = flips; redi[1][t] = bad;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {           // fixed order: bit-reproducible
+        if (t < o) {
+            red[0][t] = fmaxf(red[0][t], red[0][t + o]);
+            red[1][t] += red[1][t + o];
+            red[2][t] = fmaxf(red[2][t], red[2][t + o]);
+            red[3][t] = fmaxf(red[3][t], red[3][t + o]);
+            redi[0][t] += redi[0][t + o];
+            redi[1][t] |= redi[1][t + o];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const bool finite = redi[1][0] == 0;
+        const float nan = __builtin_bit_cast(float, 0x7fc00000u);
+        float *o = stats + (size_t)b * 5;
+        o[0] = finite ? red[0][0] : nan;
+        o[1] = finite ? red[1][0] / (float)m : nan;
+        o[2] = finite ? red[2][0] : nan;
+        o[3] = finite ? red[3][0] : nan;
+        o[4] = (float)redi[0][0];
+        if (flags) {
+            flags[2 * b] = (finite && red[0][0] <= tol) ? 0 : 1;                              // raw-logit rule
+            flags[2 * b + 1] = (finite && red[3][0] <= tol_occ && redi[0][0] == 0) ? 0 : 1;   // occupancy rule
+        }
+    }
+}
+
+extern "C" int zs_sdf_verdict_stats(const float *got, const float *want, int batch, int m, float flip_band, float tol,
+                                    float tol_occ, float *stats, int *flags, void *stream) {
+    if (batch < 0 || batch > 65535 || m <= 0) {
+        zs::set_err("zs_sdf_verdict_stats: bad size (batch=%d m=%d)", batch, m);
+        return 0;
+    }
+    if (batch == 0) return 1;
+    if (!got || !want || !stats) {
+        zs::set_err("zs_sdf_verdict_stats: null pointer");
+        return 0;
+    }
+    hipLaunchKernelGGL(verdict_stats_kernel, dim3(batch), dim3(256), 0, static_cast<hipStream_t>(stream), got, want, m, flip_band,
+                       tol, tol_occ, stats, flags);
+    return zs::check_launch("zs_sdf_verdict_stats") ? 1 : 0;
+}
 
 extern "C" size_t zs_sdf_prologue_scratch_bytes(void) { return (size_t)SCRATCH_FLOATS * sizeof(float); }
 

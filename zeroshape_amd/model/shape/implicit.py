@@ -282,11 +282,20 @@ class Implicit(nn.Module):
         return pts
 
     def _verdict_stats(self, got, want):
-        """[max |dlogit|, mean |dlogit|, max |logit|, max |docc|, flips outside the band] per leading row of got / want [B, M]."""
-        diff = (got - want).abs()
-        flips = (((got > 0) != (want > 0)) & (want.abs() >= self.FLIP_BAND)).sum(-1).to(torch.float32)
-        return torch.stack([diff.amax(-1), diff.mean(-1), want.abs().amax(-1),
-                            (torch.sigmoid(got) - torch.sigmoid(want)).abs().amax(-1), flips], -1)
+        """([max |dlogit|, mean |dlogit|, max |logit|, max |docc|, flips outside the band] per leading row of got / want [B, M],
+        int32 [B, 2]: 1 where the row FAILS the raw-logit rule / the occupancy rule) - one launch of zs_sdf_verdict_stats on
+        the current stream.  (Round 6: these were ~15 ATen launches; on the check's side stream, beside the grid launch's
+        priority-raised waves, each of them took milliseconds.)"""
+        lib = _lib.load()
+        got, want = got.contiguous(), want.contiguous()
+        B, M = got.shape
+        stats = torch.empty(B, 5, dtype=torch.float32, device=got.device)
+        flags = torch.empty(B, 2, dtype=torch.int32, device=got.device)
+        with _lib.on(got.device):
+            _lib.check(lib.zs_sdf_verdict_stats(_lib.ptr(got), _lib.ptr(want), B, M, float(self.FLIP_BAND), float(self.CALIBRATION_TOL),
+                                                float(self.CALIBRATION_TOL_OCC), _lib.ptr(stats), _lib.ptr(flags),
+                                                _lib.current_stream_ptr(got.device)), "zs_sdf_verdict_stats")
+        return stats, flags
 
     @torch.no_grad()
     def _calibrate(self, split, exact):
@@ -308,7 +317,7 @@ class Implicit(nn.Module):
         finally:
             self.envelope_guard, self.last_tile_flags = guard, flags
         want = self.query_points(DecoderState(exact[:1], 1), pts)
-        stats = self._verdict_stats(got, want)[0].cpu()
+        stats = self._verdict_stats(got, want)[0][0].cpu()
         if not bool(torch.isfinite(stats[2])):
             # the exact kernel itself is not finite on this image (NaN latent): no verdict on the weights - this
             # call gets the fp32 state (NaN like the reference), the next image calibrates
@@ -483,11 +492,8 @@ class Implicit(nn.Module):
             got.record_stream(a)
             pts.record_stream(b)
         with ctx(a):
-            st = self._verdict_stats(got, want)              # [B, 5]
-            finite = torch.isfinite(st).all(-1)
-            bad = ~(finite & (st[:, 0] <= self.CALIBRATION_TOL))          # NaN / inf compare false: flagged
-            bad_occ = ~(finite & (st[:, 3] <= self.CALIBRATION_TOL_OCC) & (st[:, 4] == 0))
-            return bad.to(torch.int32), bad_occ.to(torch.int32), st[:, 0].contiguous(), st[:, 3].contiguous()
+            st, flags = self._verdict_stats(got, want)       # [B, 5], [B, 2] (NaN / inf anywhere: both flags set)
+            return flags[:, 0], flags[:, 1], st[:, 0], st[:, 3]
 
     def _tile_flags(self, batch, m, device, state=None):
         """Tile flags of one split launch: zero - the kernel sets the tiles that leave its envelope, _join_image_check() adds
