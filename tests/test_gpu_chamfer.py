@@ -350,6 +350,35 @@ def test_morton_sort_is_a_stable_permutation_with_tile_boxes():
         assert torch.equal(perm, perm2)
 
 
+def test_lower_bound_field_by_sweeps_equals_the_all_cells_form(monkeypatch):
+    """csrc/bf_prune.hip: the 32^3 distance field of the pose search's lower bounds by three separable sweeps (round 6)
+    against the form that visits every occupied cell (ZS_BF_FIELD_BRUTE=1): the same integer cell distances, so the fields
+    and the 6,912 bounds are bit-identical - on a surface cloud, a volume cloud, one point, and a flat cloud - and a bound never
+    exceeds the exact Chamfer-L1 of its rotation."""
+    from zeroshape_amd.utils import eval_3D as E
+    R = E._rotation_sphere(torch.device("cuda"))
+    clouds = [(syn.ellipsoid_cloud(0, 3000), syn.ellipsoid_cloud(1, 2500)), (syn.seeded_cloud(4, 1, 2000)[0], syn.seeded_cloud(5, 1, 1500)[0]),
+              (np.zeros((1, 3), np.float32) + 0.25, syn.ellipsoid_cloud(2, 300)),
+              (syn.seeded_cloud(6, 1, 500)[0] * np.array([1, 1, 0], np.float32), syn.seeded_cloud(7, 1, 400)[0])]
+    for a, b in clouds:
+        pred = torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+        gt = E.normalize_pc(torch.from_numpy(np.ascontiguousarray(b, np.float32)).cuda()[None])[0]
+        monkeypatch.setenv("ZS_BF_FIELD_BRUTE", "1")
+        want = E._bf_lower_bounds(pred, gt, R).cpu()
+        monkeypatch.setenv("ZS_BF_FIELD_BRUTE", "0")
+        got = E._bf_lower_bounds(pred, gt, R).cpu()
+        assert torch.equal(got, want)
+        assert bool(torch.isfinite(got).all()) and float(got.min()) >= 0.0
+    # rigorous: the bound of a rotation <= its exact Chamfer-L1 (checked on a few rotations of the first pair)
+    from oracle import geometry_ref as G
+    pred_c, gt_c = torch.from_numpy(clouds[0][0]), torch.from_numpy(clouds[0][1])
+    lb = E._bf_lower_bounds(pred_c.cuda(), E.normalize_pc(gt_c.cuda()[None])[0], R).cpu()
+    for k in (0, 100, 1234, 6911):
+        rot = G.normalize_pc((R[k].cpu() @ pred_c.T).T[None])
+        d1, d2, _, _ = G.chamfer_distance(rot, G.normalize_pc(gt_c[None]))
+        assert float(lb[k]) <= 0.5 * (float(d1.mean()) + float(d2.mean())) * (1 + 1e-4) + 1e-6
+
+
 def test_str_sort_is_a_permutation_into_compact_leaves():
     """zs_str_sort (sort-tile-recursive: x slabs, y strips, z inside; three stable sorts): a permutation, reproducible,
     non-finite points at the end, and leaves of 64 consecutive points with far smaller boxes than the input order - and
