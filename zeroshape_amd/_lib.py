@@ -223,6 +223,10 @@ def load():
         raise ZeroShapeHipError(
             "HIP library not built: %s is missing (run `python -m zeroshape_amd.build`). "
             "zeroshape_amd has no CPU/PyTorch fallback for this path." % LIB_PATH)
+    # torch FIRST: it ships its own libamdhip64 in torch/lib.  Loaded before torch, this library binds the system's copy and the
+    # process ends up with two HIP runtimes - every launch on a torch stream then fails with "no ROCm-capable device is
+    # detected" (`python __graft_entry__.py smoke`: build() loaded the library before smoke() imported torch)
+    import torch  # noqa: F401
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # e.g. libamdhip64 not found
