@@ -599,6 +599,7 @@ __global__ __launch_bounds__(PS_THREADS) void pose_nn_soa_kernel(
                 cand = g0 * PS_SKIP <= w0 || g1 * PS_SKIP <= w1;
                 gm = fminf(g0, g1);
             }
+#ifdef ZS_POSE_ITER_MIN   // rounds 3-5 (A/B): one wave-wide minimum per candidate
             while (__ballot(cand) != 0ull) {
                 int sl;
                 if ((stage >> 30) & 1) {           // measurement (ZS_POSE_LANE_ORDER=1): candidates in index order
@@ -608,6 +609,21 @@ __global__ __launch_bounds__(PS_THREADS) void pose_nn_soa_kernel(
                     sl = __builtin_ctzll(__ballot(cand && gm == near_sub));
                 }
                 cand = cand && lane != sl;
+#else
+            // The order is fixed when the tile is entered, so it is computed once: a candidate's rank among the tile's candidates
+            // by (gap, lane) - the lane index rides in the four low mantissa bits of the non-negative gap, whose bit pattern orders
+            // like an unsigned integer - from sixteen uniform compares, instead of one wave-wide minimum (~19 VALU instructions)
+            // per candidate.  The order only decides how soon the running minima shrink, never a result.
+            unsigned key = 0xffffffffu;
+            if (cand) key = ((stage >> 30) & 1) ? (unsigned)lane     // measurement (ZS_POSE_LANE_ORDER=1): index order
+                                                : ((__builtin_bit_cast(unsigned, gm) & ~15u) | (unsigned)lane);
+            int rank = 0;
+#pragma unroll
+            for (int j = 0; j < PS_NSUB; j++) rank += (unsigned)__builtin_amdgcn_readlane((int)key, j) < key ? 1 : 0;
+            const int ncand = __popcll(__ballot(cand));
+            for (int r = 0; r < ncand; r++) {
+                const int sl = __builtin_ctzll(__ballot(cand && rank == r));
+#endif
                 const float lo[3] = {lane_f(slo[0], sl), lane_f(slo[1], sl), lane_f(slo[2], sl)};
                 const float hi[3] = {lane_f(shi[0], sl), lane_f(shi[1], sl), lane_f(shi[2], sl)};
                 // both runs' point-to-box distances in packed form (the same operations per lane as point_gap2)
