@@ -31,6 +31,37 @@ def test_forward_bit_exact(b, n, m):
         np.testing.assert_array_equal(g, w, err_msg=name)
 
 
+@pytest.mark.parametrize("lds", [False, True])
+def test_brute_force_scans_bit_exact_on_chunk_edges(lds, monkeypatch):
+    """zs_chamfer_forward's two scans - nn_both_sgpr_kernel (default since round 6: eight candidates per chunk through the
+    scalar cache, two chunks in ping-pong, the last m % 8 one at a time) and the LDS-staged nn_both_kernel (ZS_CHAMFER_LDS=1) -
+    against the oracle on every chunk-count parity and tail length, with duplicates that straddle chunk boundaries (the lowest
+    index must win) and an infinite point."""
+    from zeroshape_amd import chamfer_3D
+    if lds:
+        monkeypatch.setenv("ZS_CHAMFER_LDS", "1")
+    else:
+        monkeypatch.delenv("ZS_CHAMFER_LDS", raising=False)
+    rs = np.random.RandomState(11)
+    for n, m in [(1, 1), (5, 7), (64, 8), (65, 9), (300, 15), (257, 16), (513, 17), (100, 23), (100, 24), (100, 25),
+                 (700, 1000), (1025, 1029), (3, 2047)]:
+        b = 3
+        a = rs.uniform(-0.5, 0.5, (b, n, 3)).astype(np.float32)
+        c = rs.uniform(-0.5, 0.5, (b, m, 3)).astype(np.float32)
+        if m >= 9:
+            c[:, 8] = c[:, 7]                   # equal candidates on both sides of a chunk boundary
+            c[1, m - 1] = c[1, 0]               # ... and in the tail / the last chunk
+        if m >= 17:
+            c[0, 16] = np.inf
+        A, Cc = torch.from_numpy(a).cuda(), torch.from_numpy(c).cuda()
+        d1, d2 = torch.zeros(b, n, device="cuda"), torch.zeros(b, m, device="cuda")
+        i1, i2 = torch.zeros(b, n, dtype=torch.int32, device="cuda"), torch.zeros(b, m, dtype=torch.int32, device="cuda")
+        assert chamfer_3D.forward(A, Cc, d1, d2, i1, i2, method="brute") == 1
+        want = C.chamfer_forward(a, c)
+        for g, w, name in zip((d1, d2, i1, i2), want, ("dist1", "dist2", "idx1", "idx2")):
+            np.testing.assert_array_equal(g.cpu().numpy(), w, err_msg="%s n=%d m=%d lds=%s" % (name, n, m, lds))
+
+
 @pytest.mark.parametrize("kind", ["uniform", "surface", "clusters", "flat", "outliers", "line", "scaled"])
 def test_grid_accelerated_path_equals_brute_force(kind, monkeypatch):
     """zs_chamfer_forward_ws prunes candidates with a conservative bound: results must stay

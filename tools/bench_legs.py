@@ -52,18 +52,21 @@ def chamfer_leg(dev, cpu=True):
     pairs = 2.0 * B * n * m
     from zeroshape_amd import chamfer_3D as plugin
     auto_is_grid = max(n, m) >= plugin.GRID_MIN_POINTS and not os.environ.get("ZS_CHAMFER_BRUTE")
+    # zs_chamfer_forward's scan since round 6: candidates as scalar operands of packed fp32 instructions (ZS_CHAMFER_LDS=1: the
+    # LDS-staged kernel of rounds 1-5)
+    brute_kernel = "nn_both_kernel<2>" if os.environ.get("ZS_CHAMFER_LDS") else "nn_both_sgpr_kernel<2>"
     out = {"shape": [B, n, m], "ms": round(ms_brute, 4), "ms_min": round(min_brute, 4),
            "tpairs_per_s": round(pairs / (ms_brute * 1e-3) / 1e12, 3),
            "roofline": {"bound": "valu_f32", "achieved": round(pairs * FLOP_PER_PAIR / (ms_brute * 1e-3) / 1e12, 2),
                         "peak": PEAK_F32_VALU_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(pairs * FLOP_PER_PAIR / (ms_brute * 1e-3) / 1e12 / PEAK_F32_VALU_TFLOPS, 4),
-                        "kernel": "nn_both_kernel<2>", "flop_per_pair": FLOP_PER_PAIR},
+                        "kernel": brute_kernel, "flop_per_pair": FLOP_PER_PAIR},
            "grid_accelerated_ms": round(ms_grid, 4),
            # the kernel chamfer_distance(..., method="auto") - the default of every caller - launches at this size:
            # the exact grid walk evaluates ~10^2 of the 10^4 candidates per query, so its rate is quoted against the
            # ALGORITHMIC pairs of the call (what the reference's kernel evaluates) and may exceed the VALU roofline
            # of the all-pairs form; the walk itself is latency / divergence bound, not on any roofline
-           "auto": {"kernel": "nn_grid_kernel (csrc/chamfer_grid.hip)" if auto_is_grid else "nn_both_kernel<2>",
+           "auto": {"kernel": "nn_grid_kernel (csrc/chamfer_grid.hip)" if auto_is_grid else brute_kernel,
                     "ms": round(ms_auto, 4),
                     "all_pairs_equivalent_tpairs_per_s": round(pairs / (ms_auto * 1e-3) / 1e12, 3),
                     # all-pairs-EQUIVALENT rate: the grid kernel skips most pairs, so this is how fast an all-pairs scan would have to
