@@ -4,6 +4,7 @@
 # Text summaries land in gpurun_out/prof/<tag>_*.txt (tools/rocpd_summary.py); copy the ones to keep into profiles/.
 set -u
 TAG=${1:-r02}
+PASSES=${2:-all}          # all | decoder | eval
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof
 mkdir -p $OUT
@@ -22,13 +23,17 @@ run() {  # name, command..., then counters
     python3 $ROOT/tools/rocpd_summary.py /tmp/prof_$name > $OUT/${TAG}_$name.txt 2>&1
     rm -rf /tmp/prof_$name
 }
+if [ "$PASSES" != eval ]; then
 run decoder_trace "$BENCH"
 run decoder_sq "$BENCH" SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
 run decoder_lds "$BENCH" SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_IDX_ACTIVE
 run decoder_fetch "$BENCH" FETCH_SIZE
 run decoder_write "$BENCH" WRITE_SIZE
+fi
+if [ "$PASSES" != decoder ]; then
 run eval_trace "$EVAL"
 run eval_sq "$EVAL" SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE
 run eval_fetch "$EVAL" FETCH_SIZE
 run eval_write "$EVAL" WRITE_SIZE
+fi
 ls -la $OUT
