@@ -186,3 +186,24 @@ def test_bench_line_contract():
     assert wr["graphs"] == 6 and wr["buckets_issued_after_each_replay"][-1] == wr["buckets"] and 0.8 < wr["compute_side_bound"] < 1.05
     assert d["inference"]["vox64"]["points"] == 65 ** 3 and 0 < d["inference"]["vox64"]["ms"] < d["inference"]["vox128"]["ms"]
     assert d["pose_search"]["pruned_equals_exhaustive"] is True and d["chamfer_l1"]["chamfer_l1_vs_oracle_pipeline_vox16"] < 1e-4
+
+
+def test_bench_two_ranks_rehearsed_on_one_gpu():
+    """`bench.py --gpus 2` end to end with both ranks on this GPU and gloo in place of RCCL (ZS_DEVICE_OVERRIDE /
+    ZS_DIST_BACKEND: the rehearsal switches of bench.py): the self-launch, the sharded prepare with its verdict exchange, the
+    point-range launches, the all-gather, the max-over-ranks timing and rank 0's single line."""
+    import json
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="0", ZS_DEVICE_OVERRIDE="0", ZS_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--vox-res", "64", "--no-extras", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    pts = 2 * 65 ** 3
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch_images"] == 2
+    assert d["config"]["points_per_step"] == pts and abs(d["value"] - pts / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    assert d["roofline"]["points_per_launch"] >= 65 ** 3 and d["roofline"]["launch_ms_mean"] <= d["ms_per_step"] * 1.02
+    assert len(d["calibration"]["per_image_max_abs_diff"]) == 2 and d["dtype"] == "f16x3"
