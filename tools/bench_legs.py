@@ -337,10 +337,10 @@ def encoder_leg(dev, cpu=True):
                           "frac_of_peak": round(gflop * B / ms / 2500.0, 4), "abi_calls_per_forward": calls}
     g.enable_hip_graph(False)
     for B in (1, 28):                          # kernels per forward from the committed kernel trace of the same forward (eager)
-        k = _profiled_kernels_per_forward(os.path.join(ROOT, "profiles", "r05_encoder_b%d_by_grid.txt" % B))
+        k = _profiled_kernels_per_forward(os.path.join(ROOT, "profiles", "r06_encoder_b%d_by_grid.txt" % B))
         if k is not None and "b%d" % B in out:
             out["b%d" % B]["kernels_per_forward"] = k
-            out["b%d" % B]["kernels_per_forward_source"] = "profiles/r05_encoder_b%d_by_grid.txt (rocprofv3 kernel trace, 11 forwards)" % B
+            out["b%d" % B]["kernels_per_forward_source"] = "profiles/r06_encoder_b%d_by_grid.txt (rocprofv3 kernel trace, 11 forwards)" % B
     if cpu:
         from oracle import encoder_ref
         sd = {k: v.detach().cpu() for k, v in g.state_dict().items()}
