@@ -23,6 +23,13 @@ def run(script, *args, items=4, standin=None):
     env = dict(os.environ, HIP_VISIBLE_DEVICES="0", ZS_SYNTHETIC_ITEMS=str(items), ZS_SYNTHETIC_STANDIN="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, script)] + list(args), cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:           # keep the whole output of a failed launcher where a later reader finds it (scratch directory)
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "launcher_failure_%s.log" % script.replace(".py", "")), "w") as f:
+                f.write("argv: %s\nrc: %d\n--- stdout\n%s\n--- stderr\n%s\n" % (list(args), r.returncode, r.stdout, r.stderr))
+        except OSError:
+            pass
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     if script in ("train.py", "evaluate.py") if standin is None else standin:     # the launchers that load data by name
         assert "SYNTHETIC STAND-IN" in r.stderr
