@@ -62,7 +62,8 @@ def _includes(path, seen):
 
 def _stamp(src, flags):
     h = hashlib.sha1()
-    h.update(" ".join(flags).encode())
+    # (paths relative to the package: the stamp must not change when the tree is copied - a gpurun box sees it elsewhere)
+    h.update(" ".join(os.path.relpath(f, HERE) if os.path.isabs(f) else f for f in flags).encode())
     for f in [src] + sorted(_includes(src, [])):
         with open(f, "rb") as fh:
             h.update(fh.read())
