@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define ZS_ABI_VERSION 37
+#define ZS_ABI_VERSION 38
 
 /* ABI version of the loaded library (== ZS_ABI_VERSION it was built with). */
 int zs_abi_version(void);
@@ -451,6 +451,12 @@ int zs_depth_metrics(const float *prediction, const float *target, const float *
 #define ZS_CONV_FORCE_TILE256 1024 /* tests / tuning: the 256 x 256 ping-pong kernel (csrc/nn_conv_pp256.h) for every layer it can
                                     * run - pointwise, ZS_CONV_F16X3 | ZS_CONV_W_PRESPLIT, Cin % 32 == 0, Cout % 4 == 0 - whatever
                                     * its size (by default: K >= 768 and at least half a round of tiles, or K >= 2048) */
+#define ZS_CONV_OUT_K16 2048  /* pointwise split-fp16 layers of few rows only (the streaming GEMM kernel, csrc/nn_gemm_stream.hip): `out`
+                              * is written K16-MAJOR, [Cout / 16][M][16] floats instead of [M][Cout] (Cout % 16 == 0, no residuals, no
+                              * statistics) ... */
+#define ZS_CONV_IN_K16 4096   /* ... and `in` is read that way ([Cin / 16][M][16]): the 32 rows of a K = 16 step are 2 KiB of consecutive
+                              * bytes for the consumer (the ViT MLP's hidden tensor at batch 1: fc2 20 -> 14 us).  A layer the kernel
+                              * does not take is refused (returns 0): ask zs_conv2d_k16_ok first. */
 #define ZS_CONV_IN_UPSAMPLE2 512 /* zs_conv3x3_tail_nhwc only: `in` is [B][H/2][W/2][Cin] and the layer runs on its x2 bilinear
                                     up-sampling (align_corners, zs_upsample2x_nhwc's formula), which is never written */
 size_t zs_conv2d_packed_floats(int Cin, int Cout, int kh, int kw);
@@ -511,6 +517,9 @@ int zs_conv2d_nhwc_fused(const float *in, const float *packed_w, const float *sc
 /* columns per tile (32 or 64) the fused small-tile launch uses for a problem of M rows and Cout columns: the consumer of
  * out_mode 2 statistics needs ceil(Cout / this) as its in_tiles */
 int zs_conv2d_fused_cols(int M, int Cout);
+/* 1 when a pointwise layer of M rows, Cin -> Cout, with `flags` (ZS_CONV_IN_K16 and / or ZS_CONV_OUT_K16) would be accepted:
+ * ln_in_tiles > 0 = fuse.in_mode 2 with that many statistics tiles, row_stats_out = fuse.out_mode 2, has_res = a residual. */
+int zs_conv2d_k16_ok(int M, int Cin, int Cout, int flags, int ln_in_tiles, int row_stats_out, int has_res);
 /* y = [relu]( GroupNorm_32(x) * gamma + beta + r ) in ONE pass over x, from the (sum, sum of squares) tiles a fused launch wrote
  * (out_mode 1; `tiles` per sample).  r = residual [B][HW][C] (may be NULL), or GroupNorm_32(residual) * res_gamma + res_beta when
  * res_stats is given (the projection shortcut of a bottleneck's first block). */

@@ -122,6 +122,7 @@ SIGNATURES = {
     "zs_conv2d_nhwc_fused": (_c_int, [_c_void_p] * 7 + [_c_int] * 13 + [ctypes.c_float, ctypes.c_float, _c_int,
                                                                         _c_void_p, _c_void_p, _c_void_p]),
     "zs_conv2d_fused_cols": (_c_int, [_c_int, _c_int]),
+    "zs_conv2d_k16_ok": (_c_int, [_c_int] * 7),
     "zs_gn_relu_max_pool_nhwc": (_c_int, [_c_void_p, _c_void_p, _c_int] + [_c_void_p] * 4 + [_c_int] * 10 + [ctypes.c_float, _c_void_p]),
     "zs_group_norm_apply_stats": (_c_int, [_c_void_p, _c_void_p, _c_int] + [_c_void_p] * 4 + [_c_int] + [_c_void_p] * 3 +
                                   [_c_int, _c_int, _c_int, ctypes.c_float, _c_int, _c_void_p]),
@@ -205,7 +206,7 @@ SIGNATURES = {
     "zs_readout_concat_bwd": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p]),
 }
 
-ABI_VERSION = 37
+ABI_VERSION = 38
 _lib = None
 
 

@@ -1620,6 +1620,50 @@ extern "C" int zs_conv2d_nhwc_fused(const float *in, const float *packed_w, cons
                        pad_t, pad_l, (flags | ZS_CONV_FORCE_SMALL) & ~ZS_CONV_SPLIT_SMALL, in_scale, in_shift, act, &f2, workspace, stream);
 }
 
+// the streaming kernel's description of a pointwise layer with K16-major operands (shape, fusion and workspace fields; the
+// caller adds the tensors)
+static void k16_stream_args(zs::stream_gemm::Args &g, const ConvArgs &a, int Cin, int Cout, int flags, const zs_conv_fuse *fuse,
+                            void *workspace) {
+    memset(&g, 0, sizeof g);
+    g.M = a.M; g.K = a.K; g.N = Cout; g.CoutPad = a.CoutPad; g.lda = Cin; g.act = a.act; g.in_relu = 0;
+    g.in_stats = fuse && fuse->in_mode == 2 ? fuse->in_stats : nullptr;
+    g.in_tiles = fuse ? fuse->in_tiles : 0;
+    g.in_eps = fuse ? fuse->in_eps : 0.f;
+    g.out_stats = fuse && fuse->out_mode == 2 ? fuse->out_stats : nullptr;
+    g.stats_cols = zs_conv2d_fused_cols(a.M, Cout);
+    g.parts = workspace ? static_cast<float *>(workspace) + WS_COUNTER_FLOATS : nullptr;
+    g.tickets = static_cast<int *>(workspace);
+    g.parts_bytes = WS_PARTS_BYTES;
+    g.max_tickets = (int)WS_COUNTER_FLOATS;
+    g.two_launch_max = 1;
+    g.a_k16 = (flags & ZS_CONV_IN_K16) ? 1 : 0;
+    g.out_k16 = (flags & ZS_CONV_OUT_K16) ? 1 : 0;
+}
+
+// Would zs_conv2d_nhwc[_fused] accept this pointwise layer with the given K16 flags?  (ln_in: fuse.in_mode 2 with `in_tiles` tiles;
+// row_stats_out: fuse.out_mode 2; has_res: a residual is added.)  The caller asks before choosing the layout of a tensor.
+extern "C" int zs_conv2d_k16_ok(int M, int Cin, int Cout, int flags, int ln_in_tiles, int row_stats_out, int has_res) {
+    if (M <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 15) || (Cout & 3) || !stream_enabled() || M > stream_max_rows()) return 0;
+    if (!(flags & (ZS_CONV_IN_K16 | ZS_CONV_OUT_K16))) return 0;
+    ConvArgs a;
+    memset(&a, 0, sizeof a);
+    a.M = M; a.K = Cin; a.CoutPad = (Cout + BN - 1) / BN * BN; a.act = 0;
+    zs_conv_fuse f;
+    memset(&f, 0, sizeof f);
+    static float dummy[2];
+    if (ln_in_tiles > 0) { f.in_mode = 2; f.in_tiles = ln_in_tiles; f.in_stats = dummy; }
+    if (row_stats_out) {
+        if (Cout % zs_conv2d_fused_cols(M, Cout)) return 0;
+        f.out_mode = 2; f.out_stats = dummy;
+    }
+    zs::stream_gemm::Args g;
+    k16_stream_args(g, a, Cin, Cout, flags, &f, dummy);          // (a workspace is always there in the inference engine)
+    g.res1 = has_res ? dummy : nullptr;
+    int ranges = 1;
+    g.ranges = &ranges;
+    return zs::stream_gemm::launch(g, nullptr, true) ? 1 : 0;
+}
+
 static int conv2d_impl(const float *in, const float *packed_w, const float *scale, const float *shift,
                        const float *res1, const float *res2, float *out, int batch, int Hin, int Win,
                        int Cin, int Hout, int Wout, int Cout, int kh, int kw, int stride, int pad_t,
@@ -1688,6 +1732,23 @@ static int conv2d_impl(const float *in, const float *packed_w, const float *scal
         else if (tm) hipLaunchKernelGGL((conv_gemm_kernel<false, 2, false, F, SKF>), grid, dim3(256), 0, st, a);            \
         else hipLaunchKernelGGL((conv_gemm_kernel<false, 0, false, F, SKF>), grid, dim3(256), 0, st, a);                    \
     } while (0)
+    // ---- K16-major activations (ZS_CONV_IN_K16 / ZS_CONV_OUT_K16): only the streaming GEMM kernel reads / writes that layout ----
+    if (flags & (ZS_CONV_IN_K16 | ZS_CONV_OUT_K16)) {
+        const bool ok = kh == 1 && kw == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && a.dil == 1 && Hin == Hout && Win == Wout &&
+                        f16 && a.w_split && in_scale == 1.0f && in_shift == 0.0f && !a.in_relu && stream_enabled() &&
+                        (!fuse || ((fuse->in_mode == 0 || fuse->in_mode == 2) && (fuse->out_mode == 0 || fuse->out_mode == 2)));
+        zs::stream_gemm::Args g;
+        k16_stream_args(g, a, Cin, Cout, flags, fuse, workspace);
+        g.a = in; g.w = packed_w; g.scale = scale; g.shift = shift; g.res1 = res1; g.res2 = res2; g.out = out;
+        int ranges = 1;
+        g.ranges = &ranges;
+        if (!ok || !zs::stream_gemm::launch(g, st)) {
+            zs::set_err("zs_conv2d_nhwc: the K16-major layout flags need a pointwise split-fp16 layer the streaming kernel takes "
+                        "(zs_conv2d_k16_ok; M=%lld Cin=%d Cout=%d)", M, Cin, Cout);
+            return 0;
+        }
+        return zs::check_launch("zs_conv2d_nhwc") ? 1 : 0;
+    }
     // 3 x 3 stride-1 pad-1 layers in split-fp16 with pre-split weights: the input-patch kernels (nn_conv_patch.h)
     static const bool no_patch = getenv("ZS_CONV_NO_PATCH") != nullptr;          // A/B switch for measurements
     const bool patch_geom = f16 && a.w_split && !no_patch && kh == 3 && kw == 3 && stride == 1 && a.dil == 1 && pad_t == 1 &&
@@ -1834,6 +1895,7 @@ static int conv2d_impl(const float *in, const float *packed_w, const float *scal
             int ranges = 1;
             g.two_launch_max = workspace && (Cout & 3) == 0 ? 4 : 1;
             g.ranges = &ranges;
+            g.a_k16 = g.out_k16 = 0;
             if (zs::stream_gemm::launch(g, st)) {
                 if (ranges > 1) {           // the kernel wrote raw partial sums of `ranges` K ranges: sum + epilogue (+ statistics) here
                     a.splits = ranges;

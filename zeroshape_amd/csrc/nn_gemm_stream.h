@@ -29,10 +29,16 @@ struct Args {
     // CALLER runs the reduction + epilogue (nn_conv.hip: conv_splitk_reduce[_stats]_kernel)
     int two_launch_max;
     int *ranges;
+    // K16-major activations (round 6; the ViT MLP's hidden tensor at batch 1): [K / 16][M][16] instead of [M][K] - the 32 rows of a
+    // tile's K = 16 step are 2 KiB of consecutive bytes instead of 32 pieces a row pitch apart.  a_k16: `a` is laid out that way
+    // (lda is ignored; no in_stats); out_k16: `out` is written that way ([N / 16][M][16]; N % 16 == 0, no residuals, no out_stats).
+    // Neither combines with a K split.
+    int a_k16, out_k16;
 };
 
 // true when the kernel takes the problem (and has launched it); false: the caller uses another kernel
-bool launch(const Args &a, hipStream_t stream);
+// dry_run: decide only (does the kernel take this problem as described?), launch nothing
+bool launch(const Args &a, hipStream_t stream, bool dry_run = false);
 
 }  // namespace stream_gemm
 }  // namespace zs

@@ -82,8 +82,10 @@ __global__ __launch_bounds__(64 * NW) void stream_gemm_kernel(Args a, Geo g) {
     for (int i = 0; i < MI; i++) {
         const int m = m0 + 32 * i + l32;
         rok[i] = m < a.M;
-        aoff[i] = (unsigned)(((size_t)(rok[i] ? m : 0) * a.lda + 4 * half) * 4);
+        aoff[i] = a.a_k16 ? (unsigned)((rok[i] ? m : 0) * 64 + 16 * half)
+                          : (unsigned)(((size_t)(rok[i] ? m : 0) * a.lda + 4 * half) * 4);
     }
+    const size_t astep = a.a_k16 ? (size_t)a.M * 64 : 64;         // bytes from one K = 16 step of A to the next (uniform)
     unsigned boff = (unsigned)(((size_t)half * a.CoutPad + n0 + l32) * 16);
     const char *abase = reinterpret_cast<const char *>(a.a);
     const char *bbase = reinterpret_cast<const char *>(a.w);
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(64 * NW) void stream_gemm_kernel(Args a, Geo g) {
         const int sc = min(s, S - 1);               // clamped: always a valid address
         const int sa = sc;
         const char *pb0 = bbase + (size_t)sc * 2 * bstep2, *pb1 = pb0 + bstep2;
-        const char *pa = abase + (size_t)sa * 64;
+        const char *pa = abase + (size_t)sa * astep;
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
             ZS_GLDS(rb[slot][j][0], boff, pb0, 512 * j);
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(64 * NW) void stream_gemm_kernel(Args a, Geo g) {
         if (!valid && !a.out_stats) continue;
         f32x4 r = v[ps];
         if (valid) {
-            const size_t o = (size_t)m * a.N + n;
+            const size_t o = a.out_k16 ? ((size_t)(n >> 4) * a.M + m) * 16 + (n & 15) : (size_t)m * a.N + n;
             if (a.scale) r *= *reinterpret_cast<const f32x4 *>(a.scale + n);
             if (a.shift) r += *reinterpret_cast<const f32x4 *>(a.shift + n);
             if (a.res1) r += *reinterpret_cast<const f32x4 *>(a.res1 + o);
@@ -352,7 +354,7 @@ Plan plan(const Args &a) {
     const int steps = (a.K + 15) / 16;
     Plan best = {1, 2, 1, 0, 0};
     double best_cost = 1e30;
-    const bool can_split = a.parts && a.tickets;
+    const bool can_split = a.parts && a.tickets && !a.a_k16 && !a.out_k16;
     // candidates: 32 / 64 rows x 32 / 64 / 96 columns (96: the weight rows of the last tile must exist, nt * 96 <= CoutPad)
     for (int mi = 1; mi <= 2; mi++) {
         if (mi == 2 && a.M <= 32) continue;
@@ -385,8 +387,10 @@ Plan plan(const Args &a) {
 
 }  // namespace
 
-bool launch(const Args &a, hipStream_t st) {
+bool launch(const Args &a, hipStream_t st, bool dry_run) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || (a.K & 15) || (a.N & 3) || (a.lda & 3)) return false;
+    if (a.a_k16 && a.in_stats) return false;
+    if (a.out_k16 && ((a.N & 15) || a.res1 || a.res2 || a.out_stats)) return false;
     if (a.out_stats && ((a.stats_cols != 32 && a.stats_cols != 64) || a.N % a.stats_cols)) return false;
     if (a.in_stats && (a.in_tiles <= 0 || a.in_tiles > 32 || a.lda != a.K)) return false;
     if ((size_t)a.M * a.lda * 4 >= ((size_t)1 << 32)) return false;        // 32-bit lane offsets
@@ -422,7 +426,7 @@ bool launch(const Args &a, hipStream_t st) {
     // per forward against 2.67 without - the reduce launch eats what the shorter ranges save.
     static const int two_k = getenv("ZS_STREAM_2L_K") ? atoi(getenv("ZS_STREAM_2L_K")) : (1 << 30);
     static const int two_target = getenv("ZS_STREAM_2L_TARGET") ? atoi(getenv("ZS_STREAM_2L_TARGET")) : 384;
-    if (a.two_launch_max > 1 && a.ranges && a.parts && p.splits == 1 && a.K >= two_k) {
+    if (a.two_launch_max > 1 && a.ranges && a.parts && p.splits == 1 && a.K >= two_k && !a.a_k16 && !a.out_k16) {
         long long z = two_target / T;
         if (z > a.two_launch_max) z = a.two_launch_max;
         if (z > (a.K / 16) / 8) z = (a.K / 16) / 8;                               // at least eight K = 16 steps per range
@@ -433,6 +437,7 @@ bool launch(const Args &a, hipStream_t st) {
             *a.ranges = (int)z;
         }
     }
+    if (dry_run) return true;
     const dim3 grid((unsigned)(8 * ((T + 7) / 8)), (unsigned)g.splits);
 #define ZS_SG(MI_, NJ_)                                                                                              \
     do {                                                                                                             \

@@ -70,10 +70,15 @@ def run_vit_block(x, pk, heads, stats=None, want_stats=False):
         qkv = ops.linear(x, pk["qkv_ln"], ln_in=(stats, 1e-6))
     a = ops.attention(qkv, heads)
     x, st = ops.linear(a, pk["proj"], res1=x, stats_out="row")
-    h = ops.linear(x, pk["fc1_ln"], act=ops.ACT_GELU, ln_in=(st, 1e-6))
+    # the hidden tensor in K16-major layout ([hidden / 16][rows][16]) where the streaming kernel serves both layers: fc2's operand
+    # loads become whole lines (it is never read by anything else)
+    dim, hidden = pk["fc1_ln"].cin, pk["fc1_ln"].cout
+    k16 = (ops.k16_ok(rows, dim, hidden, out_k16=True, ln_tiles=st.tiles) and
+           ops.k16_ok(rows, hidden, dim, in_k16=True, row_stats=want_stats, has_res=True))
+    h = ops.linear(x, pk["fc1_ln"], act=ops.ACT_GELU, ln_in=(st, 1e-6), out_k16=k16)
     if want_stats:
-        return ops.linear(h, pk["fc2"], res1=x, stats_out="row")
-    return ops.linear(h, pk["fc2"], res1=x)
+        return ops.linear(h, pk["fc2"], res1=x, stats_out="row", in_k16=k16)
+    return ops.linear(h, pk["fc2"], res1=x, in_k16=k16)
 
 
 # ---- timm ResNetV2 stem + stages (StdConv2dSame eps 1e-8, GroupNorm 32) ----

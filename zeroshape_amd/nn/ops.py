@@ -44,6 +44,9 @@ _CONV_SPLIT_SMALL, _CONV_STREAM_K, _CONV_W_PRESPLIT, _CONV_STREAM_K_ALWAYS = 32,
 # f16x3: the weights' fp16 halves are computed once per layer (zs_conv2d_presplit_weight) instead of in every
 # workgroup of every launch.  ZS_CONV_PRESPLIT=0: split at run time (A/B measurements).
 PRESPLIT = os.environ.get("ZS_CONV_PRESPLIT", "1") != "0"
+# the ViT MLP's hidden tensor between fc1 and fc2 in K16-major layout where the streaming kernel serves both (batch 1);
+# ZS_K16_HIDDEN=0: row-major everywhere (A/B measurements)
+K16_HIDDEN = os.environ.get("ZS_K16_HIDDEN", "1") != "0"
 
 
 def set_conv_precision(p):
@@ -97,8 +100,21 @@ def fused_ok(x, pc=None):
 FUSE_NORM = os.environ.get("ZS_CONV_FUSE_NORM", "1") != "0"
 
 
+_CONV_OUT_K16, _CONV_IN_K16 = 2048, 4096       # include/zeroshape_hip.h
+
+
+def k16_ok(rows, cin, cout, in_k16=False, out_k16=False, ln_tiles=0, row_stats=False, has_res=False):
+    """Would the library take this pointwise layer with K16-major operands (zs_conv2d_k16_ok)?  Asked before a tensor's layout is
+    chosen: only the streaming GEMM kernel of the batch-1 engine reads / writes [C / 16][rows][16]."""
+    if not (CONV_PRECISION == "f16x3" and PRESPLIT and K16_HIDDEN):
+        return False
+    flags = (_CONV_IN_K16 if in_k16 else 0) | (_CONV_OUT_K16 if out_k16 else 0)
+    return bool(_lib.load().zs_conv2d_k16_ok(int(rows), int(cin), int(cout), flags, int(ln_tiles), 1 if row_stats else 0,
+                                             1 if has_res else 0))
+
+
 def conv2d(x, pc, res1=None, res2=None, act=ACT_NONE, in_relu=False, in_scale=1.0, in_shift=0.0, tiling=None,
-           gn_in=None, ln_in=None, stats_out=None, out_groups=32):
+           gn_in=None, ln_in=None, stats_out=None, out_groups=32, in_k16=False, out_k16=False):
     """x [B,H,W,Cin] -> [B,Ho,Wo,Cout] with the fused epilogue of zs_conv2d_nhwc.  `tiling`
     ("large" / "small") overrides the size-based choice of kernel variant (tests, tuning).
 
@@ -118,6 +134,9 @@ def conv2d(x, pc, res1=None, res2=None, act=ACT_NONE, in_relu=False, in_scale=1.
             _chk(r, "conv2d residual")
             assert r.shape == out.shape
     flags = (1 if in_relu else 0) | _TILING[tiling] | conv_flags()
+    # K16-major operands (pointwise layers of few rows; the caller has asked k16_ok): x / the result keep their logical shape,
+    # the bytes are [C / 16][rows][16]
+    flags |= (_CONV_IN_K16 if in_k16 else 0) | (_CONV_OUT_K16 if out_k16 else 0)
     w = pc.w
     if PRESPLIT and CONV_PRECISION == "f16x3":
         if pc.w16 is None:
@@ -219,15 +238,16 @@ def conv2d_tail(x, pc, pc_tail, act=ACT_NONE, tail_act=ACT_NONE, in_relu=False, 
     return out
 
 
-def linear(x, pc, res1=None, act=ACT_NONE, ln_in=None, stats_out=None):
+def linear(x, pc, res1=None, act=ACT_NONE, ln_in=None, stats_out=None, in_k16=False, out_k16=False):
     """x [..., Cin] -> [..., Cout] through the same GEMM (1x1 geometry).  ln_in / stats_out: see conv2d (rows = tokens);
-    with stats_out the result is (y, Stats)."""
+    with stats_out the result is (y, Stats).  in_k16 / out_k16: the operand's bytes are K16-major (conv2d)."""
     lead = x.shape[:-1]
     n = 1
     for d in lead:
         n *= d
     y = conv2d(x.reshape(1, 1, n, x.shape[-1]), pc,
-               res1=None if res1 is None else res1.reshape(1, 1, n, pc.cout), act=act, ln_in=ln_in, stats_out=stats_out)
+               res1=None if res1 is None else res1.reshape(1, 1, n, pc.cout), act=act, ln_in=ln_in, stats_out=stats_out,
+               in_k16=in_k16, out_k16=out_k16)
     if stats_out is not None:
         return y[0].view(*lead, pc.cout), y[1]
     return y.view(*lead, pc.cout)
